@@ -1,0 +1,177 @@
+/* rp_math.h — the arithmetic contract of the MI355X robopoker hot paths.
+ *
+ * Every f32 result the library produces (regret/strategy tables, Sinkhorn
+ * potentials, EMD distances, bucket assignments) is defined by the functions
+ * in this header evaluated in a documented order.  The same text is compiled
+ * by hipcc for gfx950 (device), by g++ for the host side of the C-ABI library
+ * and by gcc for the CPU oracle, always with floating-point contraction OFF,
+ * so "identical seeds -> identical bits" holds between CPU and GPU.
+ *
+ * Why it exists (reference boundaries that are NOT reproducible):
+ *   - f32::exp / f32::ln / f32::powf are platform libm in the reference
+ *     (crates/lloyd/src/sinkhorn.rs:115,120-127,136; phi.rs:36;
+ *      crates/mccfr/src/regret/discounted.rs:33,37)           -> rp_expf/rp_logf/rp_pow15/rp_pow05
+ *   - DefaultHasher(SipHash-1-3) + SmallRng::seed_from_u64 + WeightedIndex /
+ *     random_range / random::<f32>() from rand 0.9.2
+ *     (crates/mccfr/src/strategy/flow.rs:285-295, sample/external.rs:57-63,
+ *      sample/mod.rs:76-81, sample/pluribus.rs:91, crates/lloyd/src/layer.rs:155-165)
+ *                                                               -> rp_node_hash / rp_u01 / rp_pick_*
+ * Only IEEE-754 correctly rounded primitives are used: + - * / sqrt, fma,
+ * int<->float conversion and integer bit operations.
+ */
+#ifndef RP_MATH_H
+#define RP_MATH_H
+
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define RP_HD __host__ __device__ __forceinline__
+#else
+#define RP_HD static inline
+#endif
+
+/* pokerkit::EPSILON = f32::MIN_POSITIVE (crates/pokerkit/src/lib.rs:204) */
+#define RP_EPSILON 1.17549435e-38f
+#define RP_F32_MAX 3.40282347e+38f
+
+RP_HD float rp_u2f(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+RP_HD uint32_t rp_f2u(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+/* f32::max / f32::min semantics for non-NaN inputs (NaN never occurs on the hot path:
+ * the reference debug_asserts it, flow.rs:81-82). */
+RP_HD float rp_maxf(float a, float b) { return a > b ? a : b; }
+RP_HD float rp_minf(float a, float b) { return a < b ? a : b; }
+RP_HD float rp_absf(float a) { return rp_u2f(rp_f2u(a) & 0x7fffffffu); }
+
+/* e^x, ~1 ulp.  Cephes-style: k = rint(x*log2e), r = x - k*ln2 (two-step),
+ * e^r = 1 + r + r^2 * P(r), result scaled by 2^k in two exact steps.
+ * x < -87.34 flushes to +0 (the Sinkhorn softmin clamps every term at
+ * MIN_POSITIVE afterwards, sinkhorn.rs:124-126); x > 88.72 -> +inf. */
+RP_HD float rp_expf(float x) {
+    if (!(x == x)) return x;
+    if (x > 88.72283f) return rp_u2f(0x7f800000u);
+    if (x < -87.33654f) return 0.0f;
+    const float MAGIC = 12582912.0f; /* 1.5 * 2^23: round-to-nearest-even via add/sub */
+    float kf = (x * 1.44269504088896341f + MAGIC) - MAGIC;
+    float r = fmaf(kf, -0.693359375f, x);
+    r = fmaf(kf, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = fmaf(p, r2, r) + 1.0f;
+    int k = (int)kf;
+    int k1 = k >> 1;
+    int k2 = k - k1;
+    float s1 = rp_u2f((uint32_t)(k1 + 127) << 23);
+    float s2 = rp_u2f((uint32_t)(k2 + 127) << 23);
+    return (y * s1) * s2;
+}
+
+/* ln x, ~1 ulp.  Cephes-style: x = m * 2^e with m in [sqrt(1/2), sqrt(2)),
+ * polynomial in (m - 1); no division.  x == 0 -> -inf, x < 0 -> NaN.
+ * Subnormal inputs are pre-scaled by 2^23. */
+RP_HD float rp_logf(float x) {
+    if (!(x == x)) return x;
+    if (x < 0.0f) return rp_u2f(0x7fc00000u);
+    if (x == 0.0f) return rp_u2f(0xff800000u);
+    if (x == rp_u2f(0x7f800000u)) return x;
+    uint32_t u = rp_f2u(x);
+    int e = 0;
+    if (u < 0x00800000u) {
+        x = x * 8388608.0f;
+        u = rp_f2u(x);
+        e = -23;
+    }
+    e += (int)(u >> 23) - 126;
+    float m = rp_u2f((u & 0x007fffffu) | 0x3f000000u); /* [0.5, 1) */
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = (m + m) - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, m, -1.1514610310e-1f);
+    p = fmaf(p, m, 1.1676998740e-1f);
+    p = fmaf(p, m, -1.2420140846e-1f);
+    p = fmaf(p, m, 1.4249322787e-1f);
+    p = fmaf(p, m, -1.6668057665e-1f);
+    p = fmaf(p, m, 2.0000714765e-1f);
+    p = fmaf(p, m, -2.4999993993e-1f);
+    p = fmaf(p, m, 3.3333331174e-1f);
+    float y = (m * z) * p;
+    float fe = (float)e;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(z, -0.5f, y);
+    float res = m + y;
+    res = fmaf(fe, 0.693359375f, res);
+    return res;
+}
+
+/* powf(x, 1.5) and powf(x, 0.5) for DiscountedRegret's ALPHA/BETA constants
+ * (crates/mccfr/src/regret/discounted.rs:12-13,33,37), via correctly rounded sqrt. */
+RP_HD float rp_pow15(float x) { return x * sqrtf(x); }
+RP_HD float rp_pow05(float x) { return sqrtf(x); }
+
+/* ---------------------------------------------------------------- RNG ----
+ * The reference builds a fresh SmallRng per sampled node from
+ * SipHash(epoch, info, tree-id) (flow.rs:285-295).  Same structure here with
+ * a documented 64-bit mixer: one 64-bit hash per (seed, epoch, tree, key).
+ * key = infoset id at player nodes, 0x80000000|state id at chance nodes. */
+RP_HD uint64_t rp_mix64(uint64_t z) { /* SplitMix64 finalizer */
+    z ^= z >> 30;
+    z *= 0xbf58476d1ce4e5b9ull;
+    z ^= z >> 27;
+    z *= 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return z;
+}
+RP_HD uint64_t rp_node_hash(uint64_t seed, uint64_t epoch, uint64_t tree, uint64_t key) {
+    uint64_t h = rp_mix64(seed + 0x9e3779b97f4a7c15ull);
+    h = rp_mix64(h ^ (epoch * 0xd1342543de82ef95ull + 0x632be59bd9b4e019ull));
+    h = rp_mix64(h ^ (tree * 0xaf251af3b0f025b5ull + 0x2545f4914f6cdd1dull));
+    h = rp_mix64(h ^ (key * 0x9fb21c651e98df25ull + 0x27d4eb2f165667c5ull));
+    return h;
+}
+/* uniform f32 in [0,1): top 24 bits (rand's random::<f32>() shape) */
+RP_HD float rp_u01(uint64_t h) { return (float)(uint32_t)(h >> 40) * 5.9604644775390625e-8f; }
+/* uniform index in 0..n (rand's random_range shape, multiply-shift without rejection) */
+RP_HD uint32_t rp_pick_uniform(uint64_t h, uint32_t n) {
+    return (uint32_t)(((h >> 32) * (uint64_t)n) >> 32);
+}
+/* xoshiro-free stream for the k-means++ seeding loop: counter-based */
+RP_HD uint64_t rp_stream(uint64_t seed, uint64_t counter) {
+    return rp_mix64(rp_mix64(seed + 0x9e3779b97f4a7c15ull) ^ (counter * 0xd1342543de82ef95ull + 1ull));
+}
+/* k-means++ weighted draw (crates/lloyd/src/layer.rs:160-178 uses WeightedIndex<f32>,
+ * whose f32 cumulative sums are order dependent).  Here each potential is quantised
+ * to a 2^-36 fixed-point integer so prefix sums are exact and order independent
+ * (a parallel scan on the GPU and a serial loop on the CPU agree bit for bit);
+ * the draw is r = floor(h * total / 2^64), winner = first i with prefix_incl(i) > r. */
+RP_HD uint64_t rp_kpp_quant(float p) {
+    if (!(p > 0.0f)) return 0ull;
+    return (uint64_t)(p * 68719476736.0f);
+}
+RP_HD uint64_t rp_mulhi64(uint64_t a, uint64_t b) {
+    uint64_t a0 = a & 0xffffffffull, a1 = a >> 32;
+    uint64_t b0 = b & 0xffffffffull, b1 = b >> 32;
+    uint64_t p00 = a0 * b0, p01 = a0 * b1, p10 = a1 * b0, p11 = a1 * b1;
+    uint64_t mid = (p00 >> 32) + (p01 & 0xffffffffull) + (p10 & 0xffffffffull);
+    return p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32);
+}
+
+#endif /* RP_MATH_H */

@@ -1,0 +1,297 @@
+/* rp_mi355x.h — C ABI of librp_mi355x.so: robopoker's two numeric hot paths on MI355X (gfx950).
+ *
+ * The reference (krukah/robopoker, Rust) has NO FFI seam for these paths: they sit behind
+ * Rust traits with default methods.  This header IS the seam: every entry
+ * point names the reference trait item it replaces so a thin Rust shim can implement
+ * `mccfr::Solver` / `elkan::Elkan` / `monge::Coupling` by delegation (INTEGRATION.md shows
+ * the binding).  Conventions kept from the reference: values are plain-old-data, the batch
+ * (tree sampling + regret vectors) is pure w.r.t. the profile and the table mutation happens
+ * afterwards in tree-id order; no Result on the hot path — here every call returns an
+ * `rp_status` (0 = ok) and never unwinds across the boundary.
+ *
+ * All handles are opaque.  All buffers are caller-owned flat arrays.  `device` is a HIP
+ * device ordinal; there is NO CPU fallback in this library: a call that needs the GPU on a
+ * machine without one returns RP_ERR_NO_DEVICE.
+ *
+ * Arithmetic (exp/ln/pow, RNG, summation orders) is specified in rp_math.h and DESIGN.md.
+ */
+#ifndef RP_MI355X_H
+#define RP_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RP_API __attribute__((visibility("default")))
+
+typedef enum rp_status {
+    RP_OK = 0,
+    RP_ERR_INVALID = 1,     /* bad argument / inconsistent table                */
+    RP_ERR_NO_DEVICE = 2,   /* no HIP device (the product path has no CPU mode) */
+    RP_ERR_HIP = 3,         /* a HIP runtime call failed (see rp_last_error)    */
+    RP_ERR_UNSUPPORTED = 4, /* combination not implemented on the device path   */
+    RP_ERR_CAPACITY = 5     /* game exceeds the compiled per-tree limits        */
+} rp_status;
+
+/* human-readable text of the last failure on the calling thread */
+RP_API const char* rp_last_error(void);
+/* number of visible HIP devices (0 when there is none); never fails */
+RP_API int rp_device_count(void);
+/* library build info: "rp_mi355x <version> gfx950 hip <ver>" */
+RP_API const char* rp_version(void);
+
+/* ======================================================================= mccfr ==
+ * crates/mccfr: Solver (solver/solver.rs:38-351), RefProf/MutProf/CfrSampling
+ * (strategy/{profile.rs:12-29,storage.rs:9-18,training.rs:10-30}), schedules
+ * (regret/mod.rs:18-29, policy/mod.rs:18-25), samplers (sample/mod.rs:53-65).
+ */
+
+/* RegretSchedule impls: regret/{summed,linear,discounted,floored,asymmetric}.rs */
+typedef enum rp_regret_kind {
+    RP_REGRET_SUMMED = 0,
+    RP_REGRET_LINEAR = 1,
+    RP_REGRET_DISCOUNTED = 2,
+    RP_REGRET_FLOORED = 3,
+    RP_REGRET_ASYMMETRIC = 4
+} rp_regret_kind;
+
+/* WeightSchedule impls: policy/{constant,linear,quadratic,exponential}.rs */
+typedef enum rp_weight_kind {
+    RP_WEIGHT_CONSTANT = 0,
+    RP_WEIGHT_LINEAR = 1,
+    RP_WEIGHT_QUADRATIC = 2,
+    RP_WEIGHT_EXPONENTIAL = 3
+} rp_weight_kind;
+
+/* SamplingScheme impls: sample/{external,pruning,pluribus}.rs */
+typedef enum rp_sampling_kind {
+    RP_SAMPLING_EXTERNAL = 0,
+    RP_SAMPLING_PRUNABLE = 1,
+    RP_SAMPLING_PLURIBUS = 2
+} rp_sampling_kind;
+
+/* hyperparams/{sampling.rs:39-50, pruning.rs:36-53, training.rs:49-60}; rp_hyper_default() fills the
+ * reference defaults {tau 1.0, beta 2.0, eps 0.05, threshold -3e5, explore 0.05, warmup 16384, regret_min -4e6}. */
+typedef struct rp_hyper {
+    float temperature;
+    float smoothing;
+    float curiosity;
+    float prune_threshold;
+    float prune_explore;
+    uint64_t prune_warmup;
+    float regret_min;
+    uint32_t _pad;
+} rp_hyper;
+RP_API void rp_hyper_default(rp_hyper* out);
+
+/* Encounter: solver/encounter.rs:22-27 (16-byte AoS at the boundary; SoA by field in HBM) */
+typedef struct rp_encounter {
+    float weight;
+    float regret;
+    float payoff;
+    uint32_t visits;
+} rp_encounter;
+
+/* Flat description of an extensive-form game: the boundary's answer to "games are Rust generics"
+ * (CfrGame/CfrTurn/CfrEdge/CfrInfo/CfrEncoder; kuhn/src/game.rs:115-167, leduc/src/game.rs:177-245).
+ * A state is a node of the full game tree; children of a player state are listed in `choices()` order
+ * (kuhn/src/info.rs:36-42, leduc/src/info.rs:29-35), children of a chance state in deal order. */
+#define RP_TURN_CHANCE 254u
+#define RP_TURN_TERMINAL 255u
+#define RP_NO_INFO 0xffffffffu
+typedef struct rp_state {
+    uint8_t turn;       /* acting player 0..n_players-1, RP_TURN_CHANCE or RP_TURN_TERMINAL */
+    uint8_t n_children; /* branching factor (0 for terminals)                                */
+    uint16_t reserved;
+    uint32_t info;      /* infoset id at player states, RP_NO_INFO otherwise                  */
+    uint32_t offset;    /* player/chance: first child in children[]; terminal: row in payoffs */
+} rp_state;
+
+typedef struct rp_game_table {
+    uint32_t n_states;
+    uint32_t n_infos;
+    uint32_t n_players;
+    uint32_t max_actions;  /* A: row stride of the regret/strategy tables          */
+    uint32_t n_children;   /* length of children[]                                  */
+    uint32_t n_terminals;  /* rows of payoffs[]                                     */
+    uint32_t train_root;   /* CfrGame::root(): chance over deals -> first decision  */
+    uint32_t exploit_root; /* CfrGame::exploitability_root()                        */
+    uint32_t max_depth;    /* longest root->leaf path (states)                      */
+    uint32_t max_tree_nodes; /* bound on nodes of one externally-sampled tree       */
+    const rp_state* states;
+    const uint32_t* children;
+    const float* payoffs;          /* [n_terminals][n_players]                       */
+    const uint8_t* info_actions;   /* [n_infos] number of choices()                  */
+    const uint8_t* info_player;    /* [n_infos] acting player                        */
+    const float* default_regret;   /* [n_infos][max_actions] or NULL (= 0): CfrEdge::default_regret */
+} rp_game_table;
+
+/* Built-in game models (crates/kuhn, crates/leduc, crates/roshambo), owned by the library. */
+typedef enum rp_game_kind { RP_GAME_KUHN = 0, RP_GAME_LEDUC = 1, RP_GAME_RPS = 2 } rp_game_kind;
+typedef struct rp_game rp_game;
+RP_API int rp_game_create(rp_game_kind kind, rp_game** out);
+RP_API int rp_game_view(const rp_game* g, rp_game_table* out); /* pointers valid until destroy */
+RP_API int rp_game_destroy(rp_game* g);
+/* Named infoset lookup for the built-in games, e.g. "K|XB" (Kuhn: rank|history, kuhn/src/info.rs:58-66)
+ * or "Q|K|XRC|R" (Leduc: rank|board|round1|round2). Returns RP_ERR_INVALID when unknown. */
+RP_API int rp_game_info_id(const rp_game* g, const char* name, uint32_t* out);
+RP_API int rp_game_info_name(const rp_game* g, uint32_t info, char* buf, size_t cap);
+/* structural validation of a caller-built table (tree shape, offsets, perfect recall of ids) */
+RP_API int rp_game_table_check(const rp_game_table* t);
+
+typedef struct rp_mccfr rp_mccfr;
+
+typedef enum rp_update_mode {
+    RP_UPDATE_ORDERED = 0, /* per-key sequential application in tree-id order: solver.rs:96-105 exactly */
+    RP_UPDATE_COMPOSED = 1 /* per-key composed (a,b,floor) maps; used for the multi-GPU exchange         */
+} rp_update_mode;
+
+/* mccfr!(Prefix, Encoder, T, E, G, I, batch) + <R, W, S> (strategy/macros.rs:7-151): one solver instance.
+ * `batch_size` = Solver::batch_size() (trees per step). */
+RP_API int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind w, rp_sampling_kind s,
+                           uint32_t batch_size, const rp_hyper* hp, uint64_t seed, int device, rp_mccfr** out);
+RP_API int rp_mccfr_destroy(rp_mccfr* h);
+/* Solver::step (solver.rs:96-105): batch() then update_{regret,weight,payoff,visits} then epoch += 1 */
+RP_API int rp_mccfr_step(rp_mccfr* h);
+/* Solver::solve (solver.rs:111-122): trees / batch_size steps */
+RP_API int rp_mccfr_solve(rp_mccfr* h, uint64_t trees);
+/* Solver::spend (solver.rs:130-137) */
+RP_API int rp_mccfr_spend(rp_mccfr* h, double seconds, uint64_t* iterations, double* elapsed);
+/* enqueue `steps` steps on the stream without host synchronisation (FastSession::step loop shape) */
+RP_API int rp_mccfr_step_async(rp_mccfr* h, uint32_t steps);
+RP_API int rp_mccfr_sync(rp_mccfr* h);
+/* RefProf::t (profile.rs:14) */
+RP_API int rp_mccfr_epoch(rp_mccfr* h, uint64_t* epoch);
+/* Metrics nodes / infos counters (metrics/mod.rs:21-80; infos = the "infoset-updates" unit, solver.rs:273) */
+RP_API int rp_mccfr_counters(rp_mccfr* h, uint64_t* nodes, uint64_t* infos);
+/* RefProf::cum_{weight,regret,payoff,visits} / MutProf::mut_* (profile.rs:16-23, storage.rs:9-18) */
+RP_API int rp_mccfr_get(rp_mccfr* h, uint32_t info, uint32_t edge, rp_encounter* out);
+RP_API int rp_mccfr_set(rp_mccfr* h, uint32_t info, uint32_t edge, const rp_encounter* in);
+/* CfrData::encounters_ref / hydrate (book.rs:14-24, nlhe/src/profile.rs:97-163): rows[n_infos*max_actions] */
+RP_API int rp_mccfr_export(rp_mccfr* h, rp_encounter* rows, uint64_t cap);
+RP_API int rp_mccfr_import(rp_mccfr* h, const rp_encounter* rows, uint64_t n, uint64_t epoch);
+typedef enum rp_dist_kind {
+    RP_DIST_ITERATED = 0, /* RefProf::iterated_distribution (profile.rs:47-51) */
+    RP_DIST_AVERAGED = 1, /* RefProf::averaged_distribution (profile.rs:40-44) */
+    RP_DIST_SAMPLING = 2  /* CfrFlow::sampling_distribution (flow.rs:33-42)    */
+} rp_dist_kind;
+RP_API int rp_mccfr_policy(rp_mccfr* h, uint32_t info, rp_dist_kind kind, float* out, uint32_t* n);
+/* Solver::exploitability (solver.rs:327-337) -> CfrNash::exploitability (nash.rs:31-38); host-side validation */
+RP_API int rp_mccfr_exploitability(rp_mccfr* h, float* out);
+/* RefProf::sum_regret (book.rs:124-131), summed in (info, edge) order */
+RP_API int rp_mccfr_sum_regret(rp_mccfr* h, float* out);
+/* batch size may be changed between steps (no reference equivalent: batch_size is a const fn there) */
+RP_API int rp_mccfr_set_batch(rp_mccfr* h, uint32_t batch_size);
+RP_API int rp_mccfr_set_update_mode(rp_mccfr* h, rp_update_mode mode);
+/* run on a caller-provided hipStream_t (NULL = the library's own stream) */
+RP_API int rp_mccfr_set_stream(rp_mccfr* h, void* hip_stream);
+
+/* ---- multi-GPU: trees sharded by rank, per-key composed maps exchanged -------------
+ * rank r samples tree ids [r*B, (r+1)*B) of a world*B-tree batch.  step_local() runs the traversal and
+ * reduces this rank's Decisions to one composed map per table cell; the caller all-gathers the
+ * `summary_bytes` blobs (RCCL) and every rank folds them in rank order with step_apply(). */
+RP_API int rp_mccfr_set_shard(rp_mccfr* h, uint32_t rank, uint32_t world);
+RP_API int rp_mccfr_summary_bytes(rp_mccfr* h, size_t* bytes);
+RP_API int rp_mccfr_step_local(rp_mccfr* h, void* summary_dev);
+RP_API int rp_mccfr_step_apply(rp_mccfr* h, const void* gathered_dev, uint32_t world);
+
+/* ---- profiling hooks used by bench.py (HIP events on the launch stream) ------------------------- */
+RP_API int rp_mccfr_profile(rp_mccfr* h, int enable);
+/* name in {"traverse","update"}; total milliseconds and launch count since profiling was enabled */
+RP_API int rp_mccfr_kernel_time(rp_mccfr* h, const char* name, double* total_ms, uint64_t* launches);
+
+/* ===================================================================== lloyd ==
+ * crates/elkan: Elkan<K,N> (elkan.rs:27-207), Bounds (bounds.rs:19-120), Prior::tally (prior.rs:35-47)
+ * crates/lloyd: Layer (layer.rs:23-273), Kmeans (kmeans.rs:29-111), Sinkhorn (sinkhorn.rs:62-230),
+ *               Metric::emd (metric.rs:109-115), Equity::variation (equity.rs:41-53)
+ * crates/monge: Coupling::{minimize, flow, cost} (coupling.rs:23-51)
+ */
+typedef enum rp_metric_kind {
+    RP_METRIC_SINKHORN = 0, /* Histogram over Flop/Turn buckets -> Sinkhorn::divergence */
+    RP_METRIC_VARIATION = 1 /* Histogram over river equity bins -> Equity::variation    */
+} rp_metric_kind;
+
+/* SinkhornHyperParams::DEFAULT {0.025, 128, 5e-4} (lloyd/src/hyperparams/sinkhorn.rs:17-23) */
+typedef struct rp_sinkhorn_hp {
+    float temperature;
+    uint32_t iterations;
+    float tolerance;
+} rp_sinkhorn_hp;
+RP_API void rp_sinkhorn_hp_default(rp_sinkhorn_hp* out);
+
+/* Pair::merge (lloyd/src/pair.rs:58-65): triangular index of an unordered bin pair, i != j */
+static inline uint32_t rp_tri_index(uint32_t i, uint32_t j) {
+    uint32_t lo = i < j ? i : j, hi = i < j ? j : i;
+    return hi == 0 ? 0 : hi * (hi - 1) / 2 + lo;
+}
+
+typedef struct rp_kmeans rp_kmeans;
+
+/* Layer::build (layer.rs:250-272): K clusters over N points, each a dense histogram of `bins` u8 counts
+ * (Bins<N>, bins.rs:30-37; reference stores usize counts, point mass <= 47 so u8 is lossless).
+ * `tri_metric` is Metric's triangular table bins*(bins-1)/2 (metric.rs:26-55) for RP_METRIC_SINKHORN,
+ * NULL for RP_METRIC_VARIATION.  `counts` is a host pointer; use the _device variant when the
+ * histograms already live in HBM. */
+RP_API int rp_kmeans_create(uint32_t K, uint64_t N, uint32_t bins, const uint8_t* counts, rp_metric_kind kind,
+                            const float* tri_metric, const rp_sinkhorn_hp* hp, uint64_t seed, int device,
+                            rp_kmeans** out);
+RP_API int rp_kmeans_create_device(uint32_t K, uint64_t N, uint32_t bins, const void* counts_dev,
+                                   rp_metric_kind kind, const float* tri_metric, const rp_sinkhorn_hp* hp,
+                                   uint64_t seed, int device, rp_kmeans** out);
+RP_API int rp_kmeans_destroy(rp_kmeans* h);
+/* Elkan::init_centroids = k-means++ (layer.rs:140-181); chosen[] receives the K point indices (may be NULL) */
+RP_API int rp_kmeans_init_centroids(rp_kmeans* h, uint64_t* chosen);
+/* install centroids = copies of the given points (TestLayer-style explicit seeding, tests.rs:100-102) */
+RP_API int rp_kmeans_set_centroids(rp_kmeans* h, const uint64_t* point_index);
+/* Elkan::init_bounds (elkan.rs:39-47) */
+RP_API int rp_kmeans_init_bounds(rp_kmeans* h);
+/* Kmeans::next (kmeans.rs:82-110): step_elkan (elkan.rs:153-168), install centroids, Prior::tally.
+ * drift[K], sizes[K], reassigned may be NULL. */
+RP_API int rp_kmeans_step(rp_kmeans* h, float* drift, uint64_t* sizes, double* reassigned);
+/* Elkan::step_naive (elkan.rs:171-188) + install */
+RP_API int rp_kmeans_step_naive(rp_kmeans* h);
+/* Layer::lookup (layer.rs:62-82): fresh neighbor(i) for every point; bucket[N], distance[N] (may be NULL) */
+RP_API int rp_kmeans_assign(rp_kmeans* h, uint8_t* bucket, float* distance);
+/* current Elkan bounds: j[N] (u8), upper[N]; lower[N*K] may be NULL */
+RP_API int rp_kmeans_bounds(rp_kmeans* h, uint8_t* j, float* upper, float* lower);
+/* centroids as integer sums: counts[K*bins] (u32), weight[K] (u64) (histogram.rs:286-294, bins.rs:75-82) */
+RP_API int rp_kmeans_centroids(rp_kmeans* h, uint32_t* counts, uint64_t* weight);
+/* Layer::metric (layer.rs:85-101) + Metric::from(BTreeMap) normalisation (metric.rs:127-141): tri[K*(K-1)/2] */
+RP_API int rp_kmeans_metric(rp_kmeans* h, float* tri);
+/* Elkan::rms (elkan.rs:191-200), summed in point order */
+RP_API int rp_kmeans_rms(rp_kmeans* h, float* out);
+/* number of distance evaluations so far (Sinkhorn/variation calls incl. self terms), for reporting */
+RP_API int rp_kmeans_stats(rp_kmeans* h, uint64_t* distances, uint64_t* sinkhorn_iterations);
+RP_API int rp_kmeans_set_stream(rp_kmeans* h, void* hip_stream);
+RP_API int rp_kmeans_profile(rp_kmeans* h, int enable);
+/* name in {"pairwise","step","recompute","bounds","neighbor","selfcost","kpp"} */
+RP_API int rp_kmeans_kernel_time(rp_kmeans* h, const char* name, double* total_ms, uint64_t* launches);
+
+/* ---- multi-GPU: points sharded by rank, integer centroid sums all-reduced ----------
+ * step_local(): pairwise + bound refresh on this rank's points, then partial centroid sums into
+ * partial_dev (K*bins u32 counts, K u64 weights, K u64 sizes: partial_bytes()).  After an
+ * all-reduce(sum) over ranks, step_finish() installs the centroids, computes drift and updates bounds. */
+RP_API int rp_kmeans_partial_bytes(rp_kmeans* h, size_t* bytes);
+RP_API int rp_kmeans_step_local(rp_kmeans* h, void* partial_dev);
+RP_API int rp_kmeans_step_finish(rp_kmeans* h, const void* reduced_dev, float* drift, uint64_t* sizes,
+                                 double* reassigned);
+
+/* Sinkhorn::divergence (sinkhorn.rs:166-171) / Metric::emd for P independent pairs:
+ * mu[P*bins], nu[P*bins] u32 counts (host), out[P].  One wavefront per pair. */
+RP_API int rp_sinkhorn_divergence(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_t* nu,
+                                  const float* tri_metric, const rp_sinkhorn_hp* hp, int device, float* out);
+/* Coupling::minimize().cost() (sinkhorn.rs:194-218): raw entropic OT cost, and iterations used */
+RP_API int rp_sinkhorn_cost(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_t* nu,
+                            const float* tri_metric, const rp_sinkhorn_hp* hp, int device, float* out,
+                            uint32_t* iterations);
+/* Equity::variation (equity.rs:41-53) for P pairs of `bins`-bin histograms (bins = 101 on the turn layer) */
+RP_API int rp_equity_variation(uint32_t bins, uint64_t pairs, const uint32_t* x, const uint32_t* y, int device,
+                               float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RP_MI355X_H */

@@ -1,0 +1,439 @@
+/* rp_oracle_lloyd.c — CPU restatement of robopoker's `lloyd`/`elkan` hot path.      TEST INFRASTRUCTURE.
+ *
+ * ORACLE for the MI355X hand-abstraction path (Elkan k-means over Sinkhorn EMD / equity variation).
+ * Plain C, single threaded, deterministic.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product never does.
+ *
+ * What it follows (paths under /root/reference/crates, cited per function):
+ *   lloyd/src/sinkhorn.rs   Sinkhorn::{sinkhorn, lhs, rhs, softmin, delta, coupling, cost, divergence, self_cost}
+ *   lloyd/src/{phi.rs, potential.rs, bins.rs, metric.rs, pair.rs, equity.rs, layer.rs, kmeans.rs}
+ *   elkan/src/{elkan.rs, bounds.rs, drift.rs, prior.rs}
+ *
+ * PARITY STATUS.  The reference cannot be built here (Rust).  Its k-means is deterministic but every
+ * distance goes through platform libm exp/ln (sinkhorn.rs:115-128), so it holds no golden vectors —
+ * only property tests.  The oracle is pinned against all of them (tests/test_oracle_lloyd.py):
+ * self-divergence < 1e-4 and symmetry < 1e-3 on the closed-form fixture (sinkhorn.rs:240-293),
+ * OT(mu,mu) <= 0.01 / positivity / triangle (emd.rs:105-131), variation symmetric/zero/positive
+ * (emd.rs:72-97), Elkan == naive (tests.rs:148-161), Pair bijection (pair.rs:171-189).
+ * exp/ln are include/rp_math.h's rp_expf/rp_logf (<= 1 ulp from libm); the k-means++ draw is the
+ * documented fixed-point scheme of rp_math.h ("parity unpinned" at the rand/SipHash boundary).
+ *
+ * f32 operation order follows the reference: supports ascend by bin index (phi.rs:51-57), every softmin
+ * term is clamped at MIN_POSITIVE before the left-fold sum (sinkhorn.rs:119-128), the cost is summed
+ * x-major (sinkhorn.rs:206-217).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/rp_math.h"
+#include "../include/rp_mi355x.h"
+
+#define ORA_API __attribute__((visibility("default")))
+#define ORA_MAXBINS 256
+
+typedef struct ora_hist {
+    uint32_t counts[ORA_MAXBINS];
+    uint64_t weight;
+} ora_hist;
+
+/* Bins::density (bins.rs:58-60): integer count over integer weight, both cast to f32 */
+static float h_density(const ora_hist* h, uint32_t i) { return (float)h->counts[i] / (float)h->weight; }
+
+/* Metric::raw_distance (metric.rs:41-55) over Pair::merge (pair.rs:58-65) */
+static float raw_distance(const float* tri, uint32_t x, uint32_t y) {
+    if (x == y) return 0.0f;
+    return tri[rp_tri_index(x, y)];
+}
+
+/* SinkhornHyperParams::DEFAULT (lloyd/src/hyperparams/sinkhorn.rs:17-23), oracle-local copy */
+static void ora_hp_default(rp_sinkhorn_hp* out) {
+    out->temperature = 0.025f;
+    out->iterations = 128;
+    out->tolerance = 0.0005f;
+}
+
+static uint64_t g_sinkhorn_iters = 0;
+static uint64_t g_distances = 0;
+
+/* Sinkhorn::from(..).minimize().cost() (sinkhorn.rs:77-92,194-230) */
+static float sinkhorn_cost(uint32_t bins, const ora_hist* mu, const ora_hist* nu, const float* tri,
+                           const rp_sinkhorn_hp* hp, uint32_t* iters_out) {
+    uint32_t sx[ORA_MAXBINS], sy[ORA_MAXBINS];
+    uint32_t m = 0, n = 0;
+    for (uint32_t i = 0; i < bins; ++i) { /* Bins::support ascending (bins.rs:84-88) */
+        if (mu->counts[i] > 0) sx[m++] = i;
+        if (nu->counts[i] > 0) sy[n++] = i;
+    }
+    if (iters_out) *iters_out = 0;
+    if (m == 0 || n == 0) return 0.0f; /* empty support: the cost sum is empty */
+    float lhs[ORA_MAXBINS], rhs[ORA_MAXBINS], nxt[ORA_MAXBINS];
+    /* Potential::uniform (phi.rs:34-39): ln(1 / n()) on the support */
+    float lu = rp_logf(1.0f / (float)m), ru = rp_logf(1.0f / (float)n);
+    for (uint32_t i = 0; i < m; ++i) lhs[i] = lu;
+    for (uint32_t j = 0; j < n; ++j) rhs[j] = ru;
+    float T = hp->temperature;
+    uint32_t t;
+    for (t = 0; t < hp->iterations; ++t) {
+        /* lhs (sinkhorn.rs:94-102) via softmin (sinkhorn.rs:119-128) */
+        float lhs_err = 0.0f;
+        for (uint32_t i = 0; i < m; ++i) {
+            float s = 0.0f;
+            for (uint32_t j = 0; j < n; ++j) {
+                float e = rp_expf(rhs[j] - raw_distance(tri, sx[i], sy[j]) / T);
+                s += rp_maxf(e, RP_EPSILON);
+            }
+            nxt[i] = rp_logf(h_density(mu, sx[i])) - rp_logf(s);
+        }
+        for (uint32_t i = 0; i < m; ++i) lhs_err += rp_absf(rp_expf(nxt[i]) - rp_expf(lhs[i])); /* delta :134-139 */
+        for (uint32_t i = 0; i < m; ++i) lhs[i] = nxt[i];
+        /* rhs sees the fresh lhs (Gauss-Seidel, sinkhorn.rs:80-87) */
+        float rhs_err = 0.0f;
+        for (uint32_t j = 0; j < n; ++j) {
+            float s = 0.0f;
+            for (uint32_t i = 0; i < m; ++i) {
+                float e = rp_expf(lhs[i] - raw_distance(tri, sy[j], sx[i]) / T);
+                s += rp_maxf(e, RP_EPSILON);
+            }
+            nxt[j] = rp_logf(h_density(nu, sy[j])) - rp_logf(s);
+        }
+        for (uint32_t j = 0; j < n; ++j) rhs_err += rp_absf(rp_expf(nxt[j]) - rp_expf(rhs[j]));
+        for (uint32_t j = 0; j < n; ++j) rhs[j] = nxt[j];
+        g_sinkhorn_iters += 1;
+        if (lhs_err + rhs_err < hp->tolerance) { t += 1; break; }
+    }
+    if (iters_out) *iters_out = t;
+    /* cost (sinkhorn.rs:206-217): x-major sum of coupling * distance */
+    float cost = 0.0f;
+    for (uint32_t i = 0; i < m; ++i)
+        for (uint32_t j = 0; j < n; ++j) {
+            float c = raw_distance(tri, sx[i], sy[j]);
+            cost += rp_expf(lhs[i] + rhs[j] - c / T) * c;
+        }
+    return cost;
+}
+
+/* Sinkhorn::divergence (sinkhorn.rs:166-171) with the self terms passed in (self_cost :175-191 memoises
+ * them by histogram content; a pure function of the histogram, so precomputing is equivalent) */
+static float divergence_with(uint32_t bins, const ora_hist* mu, float xx, const ora_hist* nu, float yy,
+                             const float* tri, const rp_sinkhorn_hp* hp) {
+    float xy = sinkhorn_cost(bins, mu, nu, tri, hp, NULL);
+    g_distances += 1;
+    return rp_maxf(xy - 0.5f * xx - 0.5f * yy, 0.0f);
+}
+
+/* Equity::variation (equity.rs:41-53): running CDFs over the `bins` equity buckets */
+static float variation(uint32_t bins, const ora_hist* x, const ora_hist* y) {
+    float cdf_x = 0.0f, cdf_y = 0.0f, sum = 0.0f;
+    for (uint32_t i = 0; i < bins; ++i) {
+        cdf_x += h_density(x, i);
+        cdf_y += h_density(y, i);
+        sum += rp_absf(cdf_x - cdf_y);
+    }
+    g_distances += 1;
+    return sum / (float)bins;
+}
+
+static void hist_from_u32(ora_hist* h, uint32_t bins, const uint32_t* c) {
+    memset(h, 0, sizeof(*h));
+    for (uint32_t i = 0; i < bins; ++i) {
+        h->counts[i] = c[i];
+        h->weight += c[i];
+    }
+}
+
+ORA_API float ora_sinkhorn_cost(uint32_t bins, const uint32_t* mu, const uint32_t* nu, const float* tri,
+                                const rp_sinkhorn_hp* hp, uint32_t* iters) {
+    ora_hist a, b;
+    hist_from_u32(&a, bins, mu);
+    hist_from_u32(&b, bins, nu);
+    return sinkhorn_cost(bins, &a, &b, tri, hp, iters);
+}
+ORA_API float ora_sinkhorn_divergence(uint32_t bins, const uint32_t* mu, const uint32_t* nu, const float* tri,
+                                      const rp_sinkhorn_hp* hp) {
+    ora_hist a, b;
+    hist_from_u32(&a, bins, mu);
+    hist_from_u32(&b, bins, nu);
+    float xx = sinkhorn_cost(bins, &a, &a, tri, hp, NULL);
+    float yy = sinkhorn_cost(bins, &b, &b, tri, hp, NULL);
+    return divergence_with(bins, &a, xx, &b, yy, tri, hp);
+}
+ORA_API float ora_equity_variation(uint32_t bins, const uint32_t* x, const uint32_t* y) {
+    ora_hist a, b;
+    hist_from_u32(&a, bins, x);
+    hist_from_u32(&b, bins, y);
+    return variation(bins, &a, &b);
+}
+
+/* ------------------------------------------------------------------ Elkan k-means (Layer<K,N>) */
+typedef struct ora_bound { /* Bounds<K> (bounds.rs:19-25) */
+    uint32_t j;
+    float* lower;
+    float error;
+    int stale;
+} ora_bound;
+
+typedef struct ora_kmeans {
+    uint32_t K, bins;
+    uint64_t N;
+    int kind;
+    float* tri;
+    rp_sinkhorn_hp hp;
+    uint64_t seed;
+    ora_hist* points;
+    float* self_p; /* OT(p,p) per point */
+    ora_hist* cent;
+    float* self_c;
+    ora_bound* bounds;
+    float* lower_store;
+    uint8_t* prior; /* Prior<N> (prior.rs:20) */
+    int has_prior;
+} ora_kmeans;
+
+static float point_self(const ora_kmeans* h, const ora_hist* p) {
+    if (h->kind != RP_METRIC_SINKHORN) return 0.0f;
+    return sinkhorn_cost(h->bins, p, p, h->tri, &h->hp, NULL);
+}
+/* Layer::distance -> Metric::emd (layer.rs:136-138, metric.rs:109-115) */
+static float dist(const ora_kmeans* h, const ora_hist* a, float sa, const ora_hist* b, float sb) {
+    if (h->kind == RP_METRIC_SINKHORN) return divergence_with(h->bins, a, sa, b, sb, h->tri, &h->hp);
+    return variation(h->bins, a, b);
+}
+static void refresh_self_c(ora_kmeans* h) {
+    for (uint32_t j = 0; j < h->K; ++j) h->self_c[j] = point_self(h, &h->cent[j]);
+}
+
+ORA_API ora_kmeans* ora_kmeans_create(uint32_t K, uint64_t N, uint32_t bins, const uint8_t* counts, int kind,
+                                      const float* tri, const rp_sinkhorn_hp* hp, uint64_t seed) {
+    if (bins > ORA_MAXBINS || K == 0 || K > 256 || N == 0) return NULL;
+    ora_kmeans* h = (ora_kmeans*)calloc(1, sizeof(*h));
+    h->K = K; h->N = N; h->bins = bins; h->kind = kind; h->seed = seed;
+    if (hp) h->hp = *hp; else ora_hp_default(&h->hp);
+    if (kind == RP_METRIC_SINKHORN) {
+        size_t nt = (size_t)bins * (bins - 1) / 2;
+        h->tri = (float*)malloc(4 * (nt ? nt : 1));
+        memcpy(h->tri, tri, 4 * nt);
+    }
+    h->points = (ora_hist*)calloc(N, sizeof(ora_hist));
+    for (uint64_t i = 0; i < N; ++i)
+        for (uint32_t b = 0; b < bins; ++b) {
+            h->points[i].counts[b] = counts[i * bins + b];
+            h->points[i].weight += counts[i * bins + b];
+        }
+    h->self_p = (float*)malloc(4 * N);
+    for (uint64_t i = 0; i < N; ++i) h->self_p[i] = point_self(h, &h->points[i]);
+    h->cent = (ora_hist*)calloc(K, sizeof(ora_hist));
+    h->self_c = (float*)calloc(K, 4);
+    h->bounds = (ora_bound*)calloc(N, sizeof(ora_bound));
+    h->lower_store = (float*)calloc((size_t)N * K, 4);
+    for (uint64_t i = 0; i < N; ++i) h->bounds[i].lower = h->lower_store + i * K;
+    h->prior = (uint8_t*)calloc(N, 1);
+    return h;
+}
+ORA_API void ora_kmeans_destroy(ora_kmeans* h) {
+    if (!h) return;
+    free(h->tri); free(h->points); free(h->self_p); free(h->cent); free(h->self_c);
+    free(h->bounds); free(h->lower_store); free(h->prior); free(h);
+}
+
+ORA_API void ora_kmeans_set_centroids(ora_kmeans* h, const uint64_t* idx) {
+    for (uint32_t j = 0; j < h->K; ++j) h->cent[j] = h->points[idx[j]];
+    refresh_self_c(h);
+}
+
+/* Layer::init_centroids, k-means++ (layer.rs:140-181).  Draw = rp_math.h fixed-point scheme. */
+ORA_API void ora_kmeans_init_centroids(ora_kmeans* h, uint64_t* chosen) {
+    float* pot = (float*)malloc(4 * h->N);
+    for (uint64_t i = 0; i < h->N; ++i) pot[i] = 1.0f;
+    for (uint32_t k = 0; k < h->K; ++k) {
+        uint64_t total = 0;
+        for (uint64_t i = 0; i < h->N; ++i) total += rp_kpp_quant(pot[i]);
+        uint64_t pick = 0;
+        if (total > 0) {
+            uint64_t r = rp_mulhi64(rp_stream(h->seed, k), total);
+            uint64_t acc = 0;
+            for (uint64_t i = 0; i < h->N; ++i) {
+                acc += rp_kpp_quant(pot[i]);
+                if (acc > r) { pick = i; break; }
+            }
+        } else {
+            pick = rp_mulhi64(rp_stream(h->seed, k), h->N);
+        }
+        if (chosen) chosen[k] = pick;
+        h->cent[k] = h->points[pick];
+        h->self_c[k] = h->self_p[pick];
+        pot[pick] = 0.0f;
+        for (uint64_t i = 0; i < h->N; ++i) { /* distance(&x, h) with the new centroid first (layer.rs:172) */
+            float d = dist(h, &h->cent[k], h->self_c[k], &h->points[i], h->self_p[i]);
+            pot[i] = rp_minf(d * d, pot[i]);
+        }
+    }
+    free(pot);
+}
+
+/* Elkan::neighbor (elkan.rs:68-77): distance(centroid, point), first minimum wins */
+static void neighbor(const ora_kmeans* h, uint64_t i, uint32_t* jo, float* dout) {
+    uint32_t bj = 0;
+    float bd = 0.0f;
+    for (uint32_t j = 0; j < h->K; ++j) {
+        float d = dist(h, &h->cent[j], h->self_c[j], &h->points[i], h->self_p[i]);
+        if (j == 0 || d < bd) { bj = j; bd = d; }
+    }
+    *jo = bj;
+    *dout = bd;
+}
+
+/* Elkan::init_bounds (elkan.rs:39-47) + Bounds::from (bounds.rs:111-120) */
+ORA_API void ora_kmeans_init_bounds(ora_kmeans* h) {
+    for (uint64_t i = 0; i < h->N; ++i) {
+        ora_bound* b = &h->bounds[i];
+        neighbor(h, i, &b->j, &b->error);
+        for (uint32_t k = 0; k < h->K; ++k) b->lower[k] = 0.0f;
+        b->stale = 0;
+    }
+    for (uint64_t i = 0; i < h->N; ++i) h->prior[i] = (uint8_t)h->bounds[i].j; /* Prior::from_bounds (prior.rs:23-32) */
+    h->has_prior = 1;
+}
+
+static void absorb(ora_hist* acc, const ora_hist* p, uint32_t bins) { /* Bins::merge (bins.rs:75-82) */
+    acc->weight += p->weight;
+    for (uint32_t b = 0; b < bins; ++b) acc->counts[b] += p->counts[b];
+}
+
+/* Kmeans::next (kmeans.rs:82-110) = Elkan::step_elkan (elkan.rs:153-168) + install + Prior::tally */
+ORA_API void ora_kmeans_step(ora_kmeans* h, float* drift_out, uint64_t* sizes_out, double* reassigned) {
+    uint32_t K = h->K;
+    float* pw = (float*)malloc(4 * (size_t)K * K);
+    float* mid = (float*)malloc(4 * K);
+    /* pairwises (elkan.rs:80-93): both orders, not symmetrised */
+    for (uint32_t i = 0; i < K; ++i)
+        for (uint32_t j = 0; j < K; ++j)
+            pw[i * K + j] = (i == j) ? 0.0f : dist(h, &h->cent[i], h->self_c[i], &h->cent[j], h->self_c[j]);
+    /* midpoints (elkan.rs:96-105) */
+    for (uint32_t i = 0; i < K; ++i) {
+        float r = RP_F32_MAX;
+        for (uint32_t j = 0; j < K; ++j)
+            if (j != i) r = rp_minf(r, pw[i * K + j] * 0.5f);
+        mid[i] = r;
+    }
+    for (uint64_t i = 0; i < h->N; ++i) {
+        ora_bound* b = &h->bounds[i];
+        if (!(b->error > mid[b->j])) continue; /* filter u > s[j] (elkan.rs:159) */
+        const ora_hist* x = &h->points[i];
+        if (b->stale) { /* refresh (elkan.rs:113-117, bounds.rs:79-83): distance(point, centroid) */
+            float d = dist(h, x, h->self_p[i], &h->cent[b->j], h->self_c[b->j]);
+            b->lower[b->j] = d;
+            b->error = d;
+            b->stale = 0;
+        }
+        for (uint32_t j = 0; j < K; ++j) { /* rebound (elkan.rs:119-123), has_shifted (bounds.rs:57-61) */
+            if (b->j != j && b->error > b->lower[j] && b->error > 0.5f * pw[b->j * K + j]) {
+                float d = dist(h, x, h->self_p[i], &h->cent[j], h->self_c[j]);
+                b->lower[j] = d; /* witness (bounds.rs:85-91) */
+                if (d < b->error) {
+                    b->j = j;
+                    b->error = d;
+                }
+            }
+        }
+    }
+    /* recompute (elkan.rs:128-142): integer sums of members */
+    ora_hist* nc = (ora_hist*)calloc(K, sizeof(ora_hist));
+    for (uint64_t i = 0; i < h->N; ++i) absorb(&nc[h->bounds[i].j], &h->points[i], h->bins);
+    /* drift (elkan.rs:108-110): distance(new, old) */
+    float* drift = (float*)malloc(4 * K);
+    float* self_n = (float*)malloc(4 * K);
+    for (uint32_t j = 0; j < K; ++j) self_n[j] = point_self(h, &nc[j]);
+    for (uint32_t j = 0; j < K; ++j) drift[j] = dist(h, &nc[j], self_n[j], &h->cent[j], h->self_c[j]);
+    /* Bounds::update (bounds.rs:69-77) */
+    for (uint64_t i = 0; i < h->N; ++i) {
+        ora_bound* b = &h->bounds[i];
+        for (uint32_t j = 0; j < K; ++j) b->lower[j] = rp_maxf(b->lower[j] - drift[j], 0.0f);
+        b->error += drift[b->j];
+        b->stale = 1;
+    }
+    memcpy(h->cent, nc, sizeof(ora_hist) * K);
+    memcpy(h->self_c, self_n, 4 * K);
+    /* Prior::tally (prior.rs:35-47) */
+    uint64_t moved = 0;
+    if (sizes_out) memset(sizes_out, 0, 8 * K);
+    for (uint64_t i = 0; i < h->N; ++i) {
+        uint32_t j = h->bounds[i].j;
+        if (sizes_out) sizes_out[j] += 1;
+        if ((uint8_t)j != h->prior[i]) {
+            moved += 1;
+            h->prior[i] = (uint8_t)j;
+        }
+    }
+    if (reassigned) *reassigned = (double)moved / (double)h->N;
+    if (drift_out) memcpy(drift_out, drift, 4 * K);
+    free(pw); free(mid); free(nc); free(drift); free(self_n);
+}
+
+/* Elkan::step_naive (elkan.rs:171-188) + install */
+ORA_API void ora_kmeans_step_naive(ora_kmeans* h) {
+    ora_hist* nc = (ora_hist*)calloc(h->K, sizeof(ora_hist));
+    for (uint64_t i = 0; i < h->N; ++i) {
+        uint32_t j;
+        float d;
+        neighbor(h, i, &j, &d);
+        absorb(&nc[j], &h->points[i], h->bins);
+    }
+    memcpy(h->cent, nc, sizeof(ora_hist) * h->K);
+    refresh_self_c(h);
+    free(nc);
+}
+
+/* Layer::lookup (layer.rs:62-82) */
+ORA_API void ora_kmeans_assign(const ora_kmeans* h, uint8_t* bucket, float* distance) {
+    for (uint64_t i = 0; i < h->N; ++i) {
+        uint32_t j;
+        float d;
+        neighbor(h, i, &j, &d);
+        if (bucket) bucket[i] = (uint8_t)j;
+        if (distance) distance[i] = d;
+    }
+}
+ORA_API void ora_kmeans_bounds(const ora_kmeans* h, uint8_t* j, float* upper, float* lower) {
+    for (uint64_t i = 0; i < h->N; ++i) {
+        if (j) j[i] = (uint8_t)h->bounds[i].j;
+        if (upper) upper[i] = h->bounds[i].error;
+        if (lower) memcpy(lower + i * h->K, h->bounds[i].lower, 4 * h->K);
+    }
+}
+ORA_API void ora_kmeans_centroids(const ora_kmeans* h, uint32_t* counts, uint64_t* weight) {
+    for (uint32_t j = 0; j < h->K; ++j) {
+        if (counts) memcpy(counts + (size_t)j * h->bins, h->cent[j].counts, 4 * h->bins);
+        if (weight) weight[j] = h->cent[j].weight;
+    }
+}
+/* Layer::metric (layer.rs:85-101) then Metric::from(BTreeMap) (metric.rs:127-141) */
+ORA_API void ora_kmeans_metric(const ora_kmeans* h, float* tri_out) {
+    uint32_t K = h->K;
+    float mx = RP_EPSILON;
+    for (uint32_t i = 0; i < K; ++i)
+        for (uint32_t j = 0; j < i; ++j) {
+            float d = dist(h, &h->cent[i], h->self_c[i], &h->cent[j], h->self_c[j]) +
+                      dist(h, &h->cent[j], h->self_c[j], &h->cent[i], h->self_c[i]);
+            d = d / 2.0f;
+            tri_out[rp_tri_index(i, j)] = d;
+            mx = rp_maxf(mx, d);
+        }
+    for (uint32_t t = 0; t < K * (K - 1) / 2; ++t) tri_out[t] = tri_out[t] / mx;
+}
+/* Elkan::rms_with (elkan.rs:191-200): per-point d^2 accumulated in f64 in point order */
+ORA_API float ora_kmeans_rms(const ora_kmeans* h) {
+    double acc = 0.0;
+    for (uint64_t i = 0; i < h->N; ++i) {
+        uint32_t j = h->bounds[i].j;
+        float d = dist(h, &h->points[i], h->self_p[i], &h->cent[j], h->self_c[j]);
+        acc += (double)(d * d);
+    }
+    return (float)sqrt(acc / (double)h->N);
+}
+ORA_API void ora_lloyd_stats(uint64_t* distances, uint64_t* iters, int reset) {
+    if (distances) *distances = g_distances;
+    if (iters) *iters = g_sinkhorn_iters;
+    if (reset) { g_distances = 0; g_sinkhorn_iters = 0; }
+}
+

@@ -1,0 +1,716 @@
+/* rp_oracle_mccfr.c — CPU restatement of robopoker's `mccfr` hot path.            TEST INFRASTRUCTURE.
+ *
+ * This file is the ORACLE for the MI355X MCCFR path: a plain-C, single-threaded, deterministic
+ * restatement of the reference algorithm.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product (librp_mi355x.so) never does.
+ *
+ * What it follows (paths under /root/reference/crates, cited per function):
+ *   mccfr/src/solver/solver.rs   Solver::{step, batch, update_*, exploitability}
+ *   mccfr/src/solver/builder.rs  TreeBuilder (explicit DFS stack, node numbering)
+ *   mccfr/src/strategy/flow.rs   CfrFlow::{regret_denom, weight_denom, sampling_weight, dfs,
+ *                                ancestor_reach, recursed_value, rng}
+ *   mccfr/src/strategy/profile.rs, book.rs, nash.rs; mccfr/src/{sample,regret,policy}/ (all files)
+ *
+ * PARITY STATUS.  The reference cannot be compiled or run here (no Rust toolchain) and its MCCFR is
+ * not bit-reproducible against itself (thread RNG root deals, RandomState HashMaps).
+ * The oracle is therefore pinned against every known-answer test the reference holds for this path —
+ * Kuhn analytic Nash (kuhn/src/solver.rs:176-203), the 44 Kuhn / 3 Leduc exploitability thresholds,
+ * RPS equilibrium, sampling-distribution normalisation — see tests/test_oracle_mccfr.py.  RNG, hashing
+ * and libm boundaries are "parity unpinned" by construction; they are replaced by the documented
+ * definitions of include/rp_math.h (same structure: one hash per (epoch, info, tree)).
+ *
+ * f32 operation order follows the reference expression by expression (sums fold left from 0 in
+ * `choices()` order; petgraph's newest-edge-first adjacency over children pushed in reverse pop order
+ * yields `choices()` order — mccfr/src/state/node.rs:103-107, solver/builder.rs:141-161).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/rp_math.h"
+#include "../include/rp_mi355x.h"
+
+#define ORA_MAXA 16
+
+typedef struct ora_node {
+    uint32_t state;
+    int32_t parent;
+    int32_t edge;             /* child slot taken at the parent */
+    int32_t kids[ORA_MAXA];   /* node index per child slot, -1 if not expanded */
+} ora_node;
+
+typedef struct ora_tree {
+    ora_node* nodes;
+    uint32_t n, cap;
+    uint64_t id;
+} ora_tree;
+
+typedef struct ora_decision {
+    uint32_t info;
+    uint32_t n_actions;
+    uint32_t expanded;        /* bitmask of edges present in the regret vector */
+    float regret[ORA_MAXA];
+    float policy[ORA_MAXA];
+    float payoff;
+    uint64_t tree;
+} ora_decision;
+
+typedef struct ora_mccfr {
+    rp_game_table g;
+    rp_state* states;
+    uint32_t* children;
+    float* payoffs;
+    uint8_t* info_actions;
+    uint8_t* info_player;
+    float* default_regret;
+    int R, W, S;
+    rp_hyper hp;
+    uint64_t seed;
+    uint32_t batch;
+    uint64_t epoch;
+    uint64_t nodes, infos;
+    float* regret;
+    float* weight;
+    float* payoff;
+    uint32_t* visits;
+    /* scratch */
+    ora_tree tree;
+    ora_decision* dec;
+    uint64_t ndec, capdec;
+} ora_mccfr;
+
+/* ------------------------------------------------------------------ profile reads */
+/* RefProf::{regret, weight} (profile.rs:31-37): floored at EPSILON */
+static float p_regret(const ora_mccfr* h, uint32_t info, uint32_t a) {
+    return rp_maxf(h->regret[info * h->g.max_actions + a], RP_EPSILON);
+}
+static float p_weight(const ora_mccfr* h, uint32_t info, uint32_t a) {
+    return rp_maxf(h->weight[info * h->g.max_actions + a], RP_EPSILON);
+}
+/* CfrFlow::regret_denom (flow.rs:20-22) */
+static float regret_denom(const ora_mccfr* h, uint32_t info) {
+    float s = 0.0f;
+    for (uint32_t a = 0; a < h->info_actions[info]; ++a) s += p_regret(h, info, a);
+    return s;
+}
+/* CfrFlow::weight_denom (flow.rs:24-26) */
+static float weight_denom(const ora_mccfr* h, uint32_t info) {
+    float s = 0.0f;
+    for (uint32_t a = 0; a < h->info_actions[info]; ++a) s += p_weight(h, info, a);
+    return s + h->hp.smoothing;
+}
+/* CfrFlow::sampling_weight (flow.rs:30-32) */
+static float sampling_weight(const ora_mccfr* h, uint32_t info, uint32_t a, float denom) {
+    return rp_maxf((p_weight(h, info, a) / h->hp.temperature + h->hp.smoothing) / denom, h->hp.curiosity);
+}
+static float sampling_z(const ora_mccfr* h, uint32_t info, float denom) {
+    float z = 0.0f;
+    for (uint32_t a = 0; a < h->info_actions[info]; ++a) z += sampling_weight(h, info, a, denom);
+    return z;
+}
+/* CfrFlow::instant_policy (flow.rs:46-48) */
+static float instant_policy(const ora_mccfr* h, uint32_t info, uint32_t a) {
+    return p_regret(h, info, a) / regret_denom(h, info);
+}
+/* CfrFlow::sampling (flow.rs:52-59) */
+static float sampling_prob(const ora_mccfr* h, uint32_t info, uint32_t a) {
+    float denom = weight_denom(h, info);
+    float z = sampling_z(h, info, denom);
+    return sampling_weight(h, info, a, denom) / z;
+}
+/* RefProf::averaged_distribution(..).density(edge) (profile.rs:40-44, nash.rs:14-16) */
+static float averaged_policy(const ora_mccfr* h, uint32_t info, uint32_t a) {
+    float sum = 0.0f;
+    for (uint32_t k = 0; k < h->info_actions[info]; ++k) sum += p_weight(h, info, k);
+    return p_weight(h, info, a) / sum;
+}
+
+/* ------------------------------------------------------------------ tree */
+static uint32_t tree_push(ora_tree* t, uint32_t state, int32_t parent, int32_t edge) {
+    if (t->n == t->cap) {
+        t->cap = t->cap ? t->cap * 2 : 64;
+        t->nodes = (ora_node*)realloc(t->nodes, (size_t)t->cap * sizeof(ora_node));
+    }
+    ora_node* nd = &t->nodes[t->n];
+    nd->state = state;
+    nd->parent = parent;
+    nd->edge = edge;
+    for (int k = 0; k < ORA_MAXA; ++k) nd->kids[k] = -1;
+    if (parent >= 0) t->nodes[parent].kids[edge] = (int32_t)t->n;
+    return t->n++;
+}
+static int node_width(const ora_node* nd) {
+    int w = 0;
+    for (int k = 0; k < ORA_MAXA; ++k) w += nd->kids[k] >= 0;
+    return w;
+}
+
+/* CfrFlow::rng (flow.rs:285-295): one hash per (epoch, info, tree id); chance nodes key on the state */
+static uint64_t node_hash(const ora_mccfr* h, uint64_t tree_id, const rp_state* st, uint32_t state) {
+    uint64_t key = st->turn == RP_TURN_CHANCE ? (0x80000000ull | state) : (uint64_t)st->info;
+    return rp_node_hash(h->seed, h->epoch, tree_id, key);
+}
+
+/* SamplingScheme::sample: returns a bitmask over child slots to expand.
+ * vanilla != 0 -> VanillaSampling (sample/vanilla.rs), used only by exploitability. */
+static uint32_t sample_mask(const ora_mccfr* h, uint64_t tree_id, uint32_t state, uint32_t walker, int vanilla) {
+    const rp_state* st = &h->states[state];
+    uint32_t n = st->n_children;
+    uint32_t all = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+    if (n == 0) return 0;
+    if (vanilla) return all;
+    if (st->turn == RP_TURN_CHANCE) {
+        /* randomly (sample/mod.rs:68-82) */
+        return 1u << rp_pick_uniform(node_hash(h, tree_id, st, state), n);
+    }
+    if (st->turn != walker) {
+        /* weighted (sample/external.rs:41-64): WeightedIndex over sampling_distribution.max(EPSILON) */
+        uint32_t info = st->info;
+        float denom = weight_denom(h, info);
+        float raw[ORA_MAXA];
+        float z = 0.0f;
+        for (uint32_t a = 0; a < n; ++a) {
+            raw[a] = sampling_weight(h, info, a, denom);
+            z += raw[a];
+        }
+        float cum[ORA_MAXA];
+        float total = 0.0f;
+        for (uint32_t a = 0; a < n; ++a) {
+            total += rp_maxf(raw[a] / z, RP_EPSILON);
+            cum[a] = total;
+        }
+        float x = rp_u01(node_hash(h, tree_id, st, state)) * total;
+        uint32_t idx = 0;
+        while (idx + 1 < n && cum[idx] <= x) ++idx;
+        return 1u << idx;
+    }
+    /* walker node */
+    if (h->S == RP_SAMPLING_EXTERNAL) return all;
+    uint32_t info = st->info;
+    if (h->S == RP_SAMPLING_PLURIBUS) {
+        /* sample/pluribus.rs:72-101 */
+        if (h->epoch < h->hp.prune_warmup) return all;
+        if (rp_u01(node_hash(h, tree_id, st, state)) < h->hp.prune_explore) return all;
+    }
+    uint32_t mask = 0;
+    for (uint32_t a = 0; a < n; ++a) {
+        int keep = h->regret[info * h->g.max_actions + a] > h->hp.prune_threshold;
+        if (h->S == RP_SAMPLING_PLURIBUS) {
+            const rp_state* c = &h->states[h->children[st->offset + a]];
+            keep = keep || c->turn == RP_TURN_TERMINAL;
+        }
+        if (keep) mask |= 1u << a;
+    }
+    return mask ? mask : all; /* sample/pruning.rs:64, pluribus.rs:99 */
+}
+
+/* TreeBuilder::{new, next, build} (builder.rs:74-87,141-161): explicit stack, pop-last order */
+typedef struct ora_leaf {
+    uint32_t state;
+    int32_t parent;
+    int32_t edge;
+} ora_leaf;
+
+static void build_tree(ora_mccfr* h, uint64_t tree_id, uint32_t root, uint32_t walker, int vanilla) {
+    ora_tree* t = &h->tree;
+    t->n = 0;
+    t->id = tree_id;
+    size_t cap = 256, top = 0;
+    ora_leaf* todo = (ora_leaf*)malloc(cap * sizeof(ora_leaf));
+    uint32_t r = tree_push(t, root, -1, -1);
+    uint32_t cur = r;
+    uint32_t cur_state = root;
+    for (;;) {
+        const rp_state* st = &h->states[cur_state];
+        uint32_t mask = sample_mask(h, tree_id, cur_state, walker, vanilla);
+        for (uint32_t k = 0; k < st->n_children; ++k) {
+            if (!(mask >> k & 1u)) continue;
+            if (top == cap) {
+                cap *= 2;
+                todo = (ora_leaf*)realloc(todo, cap * sizeof(ora_leaf));
+            }
+            todo[top].state = h->children[st->offset + k];
+            todo[top].parent = (int32_t)cur;
+            todo[top].edge = (int32_t)k;
+            ++top;
+        }
+        if (top == 0) break;
+        ora_leaf lf = todo[--top];
+        cur = tree_push(t, lf.state, lf.parent, lf.edge);
+        cur_state = lf.state;
+    }
+    free(todo);
+}
+
+/* ------------------------------------------------------------------ counterfactual values */
+/* CfrNash::terminal_value (nash.rs:66-79), terminal case only (trees are never depth limited here) */
+static float terminal_value(const ora_mccfr* h, uint32_t state, uint32_t hero) {
+    return h->payoffs[h->states[state].offset * h->g.n_players + hero];
+}
+
+/* CfrFlow::recursed_value (flow.rs:182-216) */
+static float recursed_value(const ora_mccfr* h, uint32_t walker, uint32_t hero, int32_t node, float rel, float smp) {
+    const ora_node* nd = &h->tree.nodes[node];
+    const rp_state* st = &h->states[nd->state];
+    if (node_width(nd) == 0) return rel / smp * terminal_value(h, nd->state, hero);
+    int chance = st->turn == RP_TURN_CHANCE;
+    int is_walker = st->turn == walker;
+    float rd = 0.0f, denom = 0.0f, z = 0.0f;
+    if (!chance) rd = regret_denom(h, st->info);
+    if (!chance && !is_walker) {
+        denom = weight_denom(h, st->info);
+        z = sampling_z(h, st->info, denom);
+    }
+    float sum = 0.0f;
+    for (uint32_t k = 0; k < st->n_children; ++k) {
+        if (nd->kids[k] < 0) continue;
+        float r2 = rel * (chance ? 1.0f : p_regret(h, st->info, k) / rd);
+        float s2 = smp * ((!chance && !is_walker) ? sampling_weight(h, st->info, k, denom) / z : 1.0f);
+        sum += recursed_value(h, walker, hero, nd->kids[k], r2, s2);
+    }
+    return sum;
+}
+
+/* CfrFlow::ancestor_reach (flow.rs:166-174): upward over non-walker decision ancestors */
+static float ancestor_reach(const ora_mccfr* h, uint32_t walker, int32_t node) {
+    float cf = 1.0f, sm = 1.0f;
+    const ora_node* nd = &h->tree.nodes[node];
+    while (nd->parent >= 0) {
+        const ora_node* par = &h->tree.nodes[nd->parent];
+        const rp_state* ps = &h->states[par->state];
+        if (ps->turn != RP_TURN_CHANCE && ps->turn != walker) {
+            cf = cf * instant_policy(h, ps->info, (uint32_t)nd->edge);
+            sm = sm * sampling_prob(h, ps->info, (uint32_t)nd->edge);
+        }
+        nd = par;
+    }
+    return cf / sm;
+}
+
+static ora_decision* push_decision(ora_mccfr* h) {
+    if (h->ndec == h->capdec) {
+        h->capdec = h->capdec ? h->capdec * 2 : 1024;
+        h->dec = (ora_decision*)realloc(h->dec, (size_t)h->capdec * sizeof(ora_decision));
+    }
+    ora_decision* d = &h->dec[h->ndec++];
+    memset(d, 0, sizeof(*d));
+    return d;
+}
+
+/* Solver::record_infosets + update_vector (solver.rs:263-275,296-305) with CfrFlow::dfs (flow.rs:64-87):
+ * Tree::partition groups non-leaf nodes by info in ascending node index (tree.rs:88-98); groups whose head
+ * is a walker node become Decisions. */
+static void tree_decisions(ora_mccfr* h, uint32_t walker) {
+    const ora_tree* t = &h->tree;
+    for (uint32_t i = 0; i < t->n; ++i) {
+        const ora_node* nd = &t->nodes[i];
+        const rp_state* st = &h->states[nd->state];
+        if (st->turn != walker || node_width(nd) == 0) continue;
+        uint32_t info = st->info;
+        int head = 1;
+        for (uint32_t j = 0; j < i; ++j) {
+            const ora_node* o = &t->nodes[j];
+            const rp_state* os = &h->states[o->state];
+            if (os->turn < RP_TURN_CHANCE && os->info == info && node_width(o) > 0) head = 0;
+        }
+        if (!head) continue;
+        ora_decision* d = push_decision(h);
+        d->info = info;
+        d->n_actions = h->info_actions[info];
+        d->tree = t->id;
+        float rd = regret_denom(h, info);
+        /* policy_vector = iterated_distribution (flow.rs:118-120, profile.rs:47-51) */
+        for (uint32_t a = 0; a < d->n_actions; ++a) d->policy[a] = p_regret(h, info, a) / rd;
+        float payoff = 0.0f;
+        for (uint32_t j = i; j < t->n; ++j) { /* span, ascending node index */
+            const ora_node* root = &t->nodes[j];
+            const rp_state* rs = &h->states[root->state];
+            if (rs->turn >= RP_TURN_CHANCE || rs->info != info || node_width(root) == 0) continue;
+            float reach = ancestor_reach(h, walker, (int32_t)j);
+            float v[ORA_MAXA];
+            float ev = 0.0f;
+            for (uint32_t a = 0; a < rs->n_children; ++a) {
+                if (root->kids[a] < 0) continue;
+                v[a] = reach * recursed_value(h, walker, rs->turn, root->kids[a], 1.0f, 1.0f);
+            }
+            for (uint32_t a = 0; a < rs->n_children; ++a) {
+                if (root->kids[a] < 0) continue;
+                ev += p_regret(h, info, a) / rd * v[a];
+            }
+            payoff += ev;
+            for (uint32_t a = 0; a < rs->n_children; ++a) {
+                if (root->kids[a] < 0) continue;
+                d->expanded |= 1u << a;
+                d->regret[a] += v[a] - ev;
+            }
+        }
+        d->payoff = payoff;
+        h->infos += 1; /* inc_infos(1) per walker infoset (solver.rs:273) */
+    }
+}
+
+/* ------------------------------------------------------------------ schedules */
+/* RegretSchedule::accumulate (regret/{summed,linear,discounted,floored,asymmetric}.rs) */
+static float regret_accumulate(int kind, float acc, float imm, uint64_t epoch) {
+    float t = (float)epoch;
+    switch (kind) {
+        case RP_REGRET_SUMMED:
+        case RP_REGRET_FLOORED:
+            return acc + imm;
+        case RP_REGRET_LINEAR: {
+            float discount = t / (t + 1.0f);
+            return acc * discount + imm;
+        }
+        case RP_REGRET_DISCOUNTED: {
+            float p = 1.0f;
+            float x;
+            if (acc > 0.0f) x = rp_pow15(t / p);
+            else if (acc < 0.0f) x = rp_pow05(t / p);
+            else x = t / p;
+            float discount = x / (x + 1.0f);
+            return acc * discount + imm;
+        }
+        case RP_REGRET_ASYMMETRIC: {
+            if (acc > 0.0f) return acc + imm;
+            float discount = t / (t + 1.0f);
+            return acc * discount + imm;
+        }
+    }
+    return acc + imm;
+}
+static float regret_floor(const ora_mccfr* h) {
+    if (h->R == RP_REGRET_FLOORED) return 0.0f;
+    if (h->R == RP_REGRET_SUMMED) return rp_u2f(0xff800000u);
+    return h->hp.regret_min;
+}
+/* RegretSchedule::gain (regret/mod.rs:22-24) */
+static float regret_gain(const ora_mccfr* h, float acc, float imm) {
+    return rp_maxf(regret_accumulate(h->R, acc, imm, h->epoch), regret_floor(h));
+}
+/* WeightSchedule::learn (policy/mod.rs:22-24) over policy/{constant,linear,quadratic,exponential}.rs */
+static float weight_learn(const ora_mccfr* h, float acc, float imm) {
+    float t = (float)h->epoch;
+    float v;
+    switch (h->W) {
+        case RP_WEIGHT_LINEAR: v = acc + imm * t; break;
+        case RP_WEIGHT_QUADRATIC: v = acc + imm * t * t; break;
+        case RP_WEIGHT_EXPONENTIAL: v = acc * 0.9999f + imm; break;
+        default: v = acc + imm; break;
+    }
+    return rp_maxf(v, RP_EPSILON);
+}
+
+/* Solver::update_{regret,weight,payoff,visits} (solver.rs:143-192) for one Decisions */
+static void apply_decision(ora_mccfr* h, const ora_decision* d) {
+    uint32_t A = h->g.max_actions;
+    for (uint32_t a = 0; a < d->n_actions; ++a) {
+        if (!(d->expanded >> a & 1u)) continue;
+        float* r = &h->regret[d->info * A + a];
+        *r = regret_gain(h, *r, d->regret[a]);
+    }
+    for (uint32_t a = 0; a < d->n_actions; ++a) {
+        float* w = &h->weight[d->info * A + a];
+        *w = weight_learn(h, *w, d->policy[a]);
+    }
+    for (uint32_t a = 0; a < d->n_actions; ++a) {
+        uint32_t n = h->visits[d->info * A + a];
+        float* ev = &h->payoff[d->info * A + a];
+        *ev += (d->payoff - *ev) / (float)(n + 1u);
+    }
+    for (uint32_t a = 0; a < d->n_actions; ++a) h->visits[d->info * A + a] += 1u;
+}
+
+/* ------------------------------------------------------------------ public API */
+#define ORA_API __attribute__((visibility("default")))
+
+ORA_API ora_mccfr* ora_mccfr_create(const rp_game_table* g, int R, int W, int S, uint32_t batch,
+                                    const rp_hyper* hp, uint64_t seed) {
+    if (!g || g->max_actions > ORA_MAXA) return NULL;
+    ora_mccfr* h = (ora_mccfr*)calloc(1, sizeof(ora_mccfr));
+    h->g = *g;
+    h->states = (rp_state*)malloc(sizeof(rp_state) * g->n_states);
+    memcpy(h->states, g->states, sizeof(rp_state) * g->n_states);
+    h->children = (uint32_t*)malloc(4u * g->n_children);
+    memcpy(h->children, g->children, 4u * g->n_children);
+    h->payoffs = (float*)malloc(4u * g->n_terminals * g->n_players);
+    memcpy(h->payoffs, g->payoffs, 4u * g->n_terminals * g->n_players);
+    h->info_actions = (uint8_t*)malloc(g->n_infos);
+    memcpy(h->info_actions, g->info_actions, g->n_infos);
+    h->info_player = (uint8_t*)malloc(g->n_infos);
+    memcpy(h->info_player, g->info_player, g->n_infos);
+    size_t cells = (size_t)g->n_infos * g->max_actions;
+    h->default_regret = (float*)calloc(cells, 4);
+    if (g->default_regret) memcpy(h->default_regret, g->default_regret, cells * 4);
+    h->R = R;
+    h->W = W;
+    h->S = S;
+    h->hp = *hp;
+    h->seed = seed;
+    h->batch = batch ? batch : 1;
+    h->regret = (float*)malloc(cells * 4);
+    memcpy(h->regret, h->default_regret, cells * 4); /* cum_regret of a missing entry = default_regret (book.rs:101-106) */
+    h->weight = (float*)calloc(cells, 4);
+    h->payoff = (float*)calloc(cells, 4);
+    h->visits = (uint32_t*)calloc(cells, 4);
+    return h;
+}
+
+ORA_API void ora_mccfr_destroy(ora_mccfr* h) {
+    if (!h) return;
+    free(h->states); free(h->children); free(h->payoffs); free(h->info_actions); free(h->info_player);
+    free(h->default_regret); free(h->regret); free(h->weight); free(h->payoff); free(h->visits);
+    free(h->tree.nodes); free(h->dec);
+    free(h);
+}
+
+/* Solver::batch for tree ids [first, first+count) (solver.rs:225-250); Decisions land in h->dec */
+static void batch_range(ora_mccfr* h, uint64_t first, uint64_t count) {
+    uint32_t walker = (uint32_t)(h->epoch % h->g.n_players); /* CfrSampling::walker (book.rs:142-144) */
+    for (uint64_t i = 0; i < count; ++i) {
+        build_tree(h, first + i, h->g.train_root, walker, 0);
+        h->nodes += h->tree.n;
+        tree_decisions(h, walker);
+    }
+}
+
+/* Solver::step (solver.rs:96-105) */
+ORA_API void ora_mccfr_step(ora_mccfr* h) {
+    h->ndec = 0;
+    batch_range(h, 0, h->batch);
+    for (uint64_t i = 0; i < h->ndec; ++i) apply_decision(h, &h->dec[i]);
+    h->epoch += 1;
+}
+
+ORA_API void ora_mccfr_solve(ora_mccfr* h, uint64_t trees) {
+    for (uint64_t i = 0; i < trees / h->batch; ++i) ora_mccfr_step(h);
+}
+
+/* the batch without the update: Decisions of the current epoch, tree-id major (for kernel debugging) */
+ORA_API uint64_t ora_mccfr_batch(ora_mccfr* h, ora_decision** out) {
+    h->ndec = 0;
+    uint64_t nodes = h->nodes, infos = h->infos;
+    batch_range(h, 0, h->batch);
+    h->nodes = nodes;
+    h->infos = infos;
+    *out = h->dec;
+    return h->ndec;
+}
+
+/* ---- the multi-GPU exchange semantics (include/rp_mi355x.h, rp_mccfr_step_local/apply) --------------
+ * `world` ranks each sample tree ids [r*B, (r+1)*B); every table cell receives one composed map per rank,
+ * F(x) = max(a*x + b, m), built sequentially over that rank's touches in tree order; ranks are folded in
+ * rank order.  Exact in real arithmetic for schedules with a sign-independent discount (Summed, Linear,
+ * Floored x all weight schedules); Discounted/Asymmetric are rejected (-1). */
+typedef struct ora_cell {
+    float ra, rb, rm; /* regret map   */
+    float wa, wb, wm; /* weight map   */
+    uint32_t rn, wn;  /* touch counts */
+} ora_cell;
+
+static int composed_discount(const ora_mccfr* h, float* dr, float* dw) {
+    float t = (float)h->epoch;
+    switch (h->R) {
+        case RP_REGRET_SUMMED:
+        case RP_REGRET_FLOORED: *dr = 1.0f; break;
+        case RP_REGRET_LINEAR: *dr = t / (t + 1.0f); break;
+        default: return -1;
+    }
+    *dw = h->W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f;
+    return 0;
+}
+static float composed_wdelta(const ora_mccfr* h, float sigma) {
+    float t = (float)h->epoch;
+    switch (h->W) {
+        case RP_WEIGHT_LINEAR: return sigma * t;
+        case RP_WEIGHT_QUADRATIC: return sigma * t * t;
+        default: return sigma;
+    }
+}
+
+ORA_API int ora_mccfr_step_world(ora_mccfr* h, uint32_t world) {
+    float dr, dw;
+    if (composed_discount(h, &dr, &dw)) return -1;
+    uint32_t A = h->g.max_actions;
+    size_t cells = (size_t)h->g.n_infos * A;
+    float floor_r = regret_floor(h);
+    /* every rank traverses against the SAME start-of-epoch table (Solver::batch is pure w.r.t. the
+     * profile, solver.rs:225); only afterwards are the per-rank maps folded in rank order */
+    ora_cell* all_cell = (ora_cell*)malloc((size_t)world * cells * sizeof(ora_cell));
+    uint32_t* all_pcount = (uint32_t*)calloc((size_t)world * h->g.n_infos, 4);
+    float* all_psum = (float*)calloc((size_t)world * h->g.n_infos, 4);
+    for (uint32_t r = 0; r < world; ++r) {
+        ora_cell* cell = all_cell + (size_t)r * cells;
+        uint32_t* pcount = all_pcount + (size_t)r * h->g.n_infos;
+        float* psum = all_psum + (size_t)r * h->g.n_infos;
+        for (size_t c = 0; c < cells; ++c) {
+            cell[c].ra = 1.0f; cell[c].rb = 0.0f; cell[c].rm = rp_u2f(0xff800000u); cell[c].rn = 0;
+            cell[c].wa = 1.0f; cell[c].wb = 0.0f; cell[c].wm = rp_u2f(0xff800000u); cell[c].wn = 0;
+        }
+        h->ndec = 0;
+        batch_range(h, (uint64_t)r * h->batch, h->batch);
+        for (uint64_t i = 0; i < h->ndec; ++i) {
+            const ora_decision* d = &h->dec[i];
+            for (uint32_t a = 0; a < d->n_actions; ++a) {
+                ora_cell* c = &cell[d->info * A + a];
+                if (d->expanded >> a & 1u) {
+                    if (c->rn == 0) { c->ra = dr; c->rb = d->regret[a]; c->rm = floor_r; }
+                    else { c->ra = c->ra * dr; c->rb = c->rb * dr + d->regret[a];
+                           c->rm = rp_maxf(c->rm * dr + d->regret[a], floor_r); }
+                    c->rn += 1;
+                }
+                float dl = composed_wdelta(h, d->policy[a]);
+                if (c->wn == 0) { c->wa = dw; c->wb = dl; c->wm = RP_EPSILON; }
+                else { c->wa = c->wa * dw; c->wb = c->wb * dw + dl; c->wm = rp_maxf(c->wm * dw + dl, RP_EPSILON); }
+                c->wn += 1;
+            }
+            pcount[d->info] += 1;
+            psum[d->info] += d->payoff;
+        }
+    }
+    for (uint32_t r = 0; r < world; ++r) { /* fold rank r into the table */
+        const ora_cell* cell = all_cell + (size_t)r * cells;
+        const uint32_t* pcount = all_pcount + (size_t)r * h->g.n_infos;
+        const float* psum = all_psum + (size_t)r * h->g.n_infos;
+        for (uint32_t info = 0; info < h->g.n_infos; ++info) {
+            for (uint32_t a = 0; a < h->info_actions[info]; ++a) {
+                size_t k = (size_t)info * A + a;
+                if (cell[k].rn) h->regret[k] = rp_maxf(cell[k].ra * h->regret[k] + cell[k].rb, cell[k].rm);
+                if (cell[k].wn) h->weight[k] = rp_maxf(cell[k].wa * h->weight[k] + cell[k].wb, cell[k].wm);
+                if (pcount[info]) {
+                    uint32_t n2 = h->visits[k] + pcount[info];
+                    h->payoff[k] = h->payoff[k] + (psum[info] - (float)pcount[info] * h->payoff[k]) / (float)n2;
+                    h->visits[k] = n2;
+                }
+            }
+        }
+    }
+    free(all_cell); free(all_pcount); free(all_psum);
+    h->epoch += 1;
+    return 0;
+}
+
+ORA_API uint64_t ora_mccfr_epoch(const ora_mccfr* h) { return h->epoch; }
+ORA_API void ora_mccfr_counters(const ora_mccfr* h, uint64_t* nodes, uint64_t* infos) {
+    if (nodes) *nodes = h->nodes;
+    if (infos) *infos = h->infos;
+}
+ORA_API void ora_mccfr_set_batch(ora_mccfr* h, uint32_t batch) { h->batch = batch ? batch : 1; }
+
+ORA_API void ora_mccfr_export(const ora_mccfr* h, rp_encounter* rows) {
+    size_t cells = (size_t)h->g.n_infos * h->g.max_actions;
+    for (size_t c = 0; c < cells; ++c) {
+        rows[c].weight = h->weight[c];
+        rows[c].regret = h->regret[c];
+        rows[c].payoff = h->payoff[c];
+        rows[c].visits = h->visits[c];
+    }
+}
+ORA_API void ora_mccfr_import(ora_mccfr* h, const rp_encounter* rows, uint64_t epoch) {
+    size_t cells = (size_t)h->g.n_infos * h->g.max_actions;
+    for (size_t c = 0; c < cells; ++c) {
+        h->weight[c] = rows[c].weight;
+        h->regret[c] = rows[c].regret;
+        h->payoff[c] = rows[c].payoff;
+        h->visits[c] = rows[c].visits;
+    }
+    h->epoch = epoch;
+}
+
+/* RefProf::{iterated,averaged}_distribution, CfrFlow::sampling_distribution */
+ORA_API void ora_mccfr_policy(const ora_mccfr* h, uint32_t info, int kind, float* out) {
+    uint32_t n = h->info_actions[info];
+    if (kind == RP_DIST_ITERATED) {
+        float denom = 0.0f;
+        for (uint32_t a = 0; a < n; ++a) denom += p_regret(h, info, a);
+        for (uint32_t a = 0; a < n; ++a) out[a] = p_regret(h, info, a) / denom;
+    } else if (kind == RP_DIST_AVERAGED) {
+        float sum = 0.0f;
+        for (uint32_t a = 0; a < n; ++a) sum += p_weight(h, info, a);
+        for (uint32_t a = 0; a < n; ++a) out[a] = p_weight(h, info, a) / sum;
+    } else {
+        float denom = weight_denom(h, info);
+        float z = sampling_z(h, info, denom);
+        for (uint32_t a = 0; a < n; ++a) out[a] = sampling_weight(h, info, a, denom) / z;
+    }
+}
+
+/* RefProf::sum_regret (book.rs:124-131); HashMap order in the reference, (info, edge) order here */
+ORA_API float ora_mccfr_sum_regret(const ora_mccfr* h) {
+    float s = 0.0f;
+    for (uint32_t info = 0; info < h->g.n_infos; ++info)
+        for (uint32_t a = 0; a < h->info_actions[info]; ++a)
+            s += rp_maxf(h->regret[info * h->g.max_actions + a], 0.0f);
+    uint64_t e = h->epoch > 1 ? h->epoch : 1;
+    return s / (float)e;
+}
+
+/* ------------------------------------------------------------------ exploitability (nash.rs) */
+/* CfrNash::subgamed_payoff (nash.rs:103-139); br == NULL -> average strategy everywhere */
+static float subgamed_payoff(const ora_mccfr* h, int32_t node, uint32_t hero, const int32_t* br) {
+    const ora_node* nd = &h->tree.nodes[node];
+    const rp_state* st = &h->states[nd->state];
+    int n = node_width(nd);
+    if (n == 0) return terminal_value(h, nd->state, hero);
+    if (st->turn == RP_TURN_CHANCE) {
+        float s = 0.0f;
+        for (uint32_t k = 0; k < st->n_children; ++k)
+            if (nd->kids[k] >= 0) s += subgamed_payoff(h, nd->kids[k], hero, br);
+        return s / (float)n;
+    }
+    if (st->turn == hero && br) return subgamed_payoff(h, nd->kids[br[st->info]], hero, br);
+    float s = 0.0f;
+    for (uint32_t k = 0; k < st->n_children; ++k)
+        if (nd->kids[k] >= 0) s += averaged_policy(h, st->info, k) * subgamed_payoff(h, nd->kids[k], hero, br);
+    return s;
+}
+/* CfrNash::external_reach (nash.rs:146-151) */
+static float external_reach(const ora_mccfr* h, int32_t node, uint32_t hero) {
+    float p = 1.0f;
+    const ora_node* nd = &h->tree.nodes[node];
+    while (nd->parent >= 0) {
+        const ora_node* par = &h->tree.nodes[nd->parent];
+        const rp_state* ps = &h->states[par->state];
+        if (ps->turn != RP_TURN_CHANCE && ps->turn != hero) p = p * averaged_policy(h, ps->info, (uint32_t)nd->edge);
+        nd = par;
+    }
+    return p;
+}
+/* Solver::exploitability (solver.rs:327-337) -> CfrNash::exploitability (nash.rs:31-38) with
+ * optimal_response_payoff / optimal_cfactual_{payoff,choice} (nash.rs:155-194) */
+ORA_API float ora_mccfr_exploitability(ora_mccfr* h) {
+    build_tree(h, 0, h->g.exploit_root, 0xffffffffu, 1);
+    const ora_tree* t = &h->tree;
+    int32_t* br = (int32_t*)malloc(sizeof(int32_t) * h->g.n_infos);
+    float* cfv = (float*)malloc(sizeof(float) * (size_t)h->g.n_infos * ORA_MAXA);
+    float total = 0.0f;
+    for (uint32_t hero = 0; hero < h->g.n_players; ++hero) {
+        memset(cfv, 0, sizeof(float) * (size_t)h->g.n_infos * ORA_MAXA);
+        /* optimal_cfactual_payoff: sum over the span in ascending node index (nash.rs:170-181) */
+        for (uint32_t i = 0; i < t->n; ++i) {
+            const ora_node* nd = &t->nodes[i];
+            const rp_state* st = &h->states[nd->state];
+            if (st->turn != hero || node_width(nd) == 0) continue;
+            for (uint32_t a = 0; a < st->n_children; ++a) {
+                if (nd->kids[a] < 0) continue;
+                int32_t c = nd->kids[a];
+                cfv[st->info * ORA_MAXA + a] += external_reach(h, c, hero) * subgamed_payoff(h, c, hero, NULL);
+            }
+        }
+        /* optimal_cfactual_choice: max_by keeps the last maximum (nash.rs:184-193) */
+        for (uint32_t info = 0; info < h->g.n_infos; ++info) {
+            br[info] = 0;
+            if (h->info_player[info] != hero) continue;
+            float best = cfv[info * ORA_MAXA];
+            for (uint32_t a = 1; a < h->info_actions[info]; ++a) {
+                if (cfv[info * ORA_MAXA + a] >= best) {
+                    best = cfv[info * ORA_MAXA + a];
+                    br[info] = (int32_t)a;
+                }
+            }
+        }
+        total += subgamed_payoff(h, 0, hero, br);
+    }
+    free(br);
+    free(cfv);
+    return total / (float)h->g.n_players;
+}

@@ -1,0 +1,204 @@
+"""ctypes binding of librp_mi355x.so (include/rp_mi355x.h).
+
+This is the Python face of the C-ABI: plain pointers and sizes, no torch types.  The library is
+built in-tree by ``__graft_entry__.build()`` (``make -C robopoker_amd/csrc``); importing this module
+when the shared object is missing raises — there is no CPU fallback for the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librp_mi355x.so")
+
+RP_OK = 0
+RP_ERR_INVALID = 1
+RP_ERR_NO_DEVICE = 2
+RP_ERR_HIP = 3
+RP_ERR_UNSUPPORTED = 4
+RP_ERR_CAPACITY = 5
+
+RP_TURN_CHANCE = 254
+RP_TURN_TERMINAL = 255
+RP_NO_INFO = 0xFFFFFFFF
+
+# enums (rp_regret_kind, rp_weight_kind, rp_sampling_kind, rp_game_kind, rp_dist_kind, rp_metric_kind)
+REGRET = {"summed": 0, "linear": 1, "discounted": 2, "floored": 3, "asymmetric": 4}
+WEIGHT = {"constant": 0, "linear": 1, "quadratic": 2, "exponential": 3}
+SAMPLING = {"external": 0, "prunable": 1, "pluribus": 2}
+GAME = {"kuhn": 0, "leduc": 1, "rps": 2}
+DIST = {"iterated": 0, "averaged": 1, "sampling": 2}
+METRIC = {"sinkhorn": 0, "variation": 1}
+UPDATE = {"ordered": 0, "composed": 1}
+
+
+class Hyper(C.Structure):
+    _fields_ = [
+        ("temperature", C.c_float),
+        ("smoothing", C.c_float),
+        ("curiosity", C.c_float),
+        ("prune_threshold", C.c_float),
+        ("prune_explore", C.c_float),
+        ("prune_warmup", C.c_uint64),
+        ("regret_min", C.c_float),
+        ("_pad", C.c_uint32),
+    ]
+
+
+class Encounter(C.Structure):
+    _fields_ = [("weight", C.c_float), ("regret", C.c_float), ("payoff", C.c_float), ("visits", C.c_uint32)]
+
+
+class State(C.Structure):
+    _fields_ = [
+        ("turn", C.c_uint8),
+        ("n_children", C.c_uint8),
+        ("reserved", C.c_uint16),
+        ("info", C.c_uint32),
+        ("offset", C.c_uint32),
+    ]
+
+
+class GameTable(C.Structure):
+    _fields_ = [
+        ("n_states", C.c_uint32),
+        ("n_infos", C.c_uint32),
+        ("n_players", C.c_uint32),
+        ("max_actions", C.c_uint32),
+        ("n_children", C.c_uint32),
+        ("n_terminals", C.c_uint32),
+        ("train_root", C.c_uint32),
+        ("exploit_root", C.c_uint32),
+        ("max_depth", C.c_uint32),
+        ("max_tree_nodes", C.c_uint32),
+        ("states", C.POINTER(State)),
+        ("children", C.POINTER(C.c_uint32)),
+        ("payoffs", C.POINTER(C.c_float)),
+        ("info_actions", C.POINTER(C.c_uint8)),
+        ("info_player", C.POINTER(C.c_uint8)),
+        ("default_regret", C.POINTER(C.c_float)),
+    ]
+
+
+class SinkhornHP(C.Structure):
+    _fields_ = [("temperature", C.c_float), ("iterations", C.c_uint32), ("tolerance", C.c_float)]
+
+
+class RpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rp_mi355x error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/rp_mi355x.h declares (tests/test_abi.py checks the list against the header)
+_SIGNATURES = {
+    "rp_last_error": (C.c_char_p, []),
+    "rp_device_count": (C.c_int, []),
+    "rp_version": (C.c_char_p, []),
+    "rp_hyper_default": (None, [C.POINTER(Hyper)]),
+    "rp_game_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "rp_game_view": (C.c_int, [C.c_void_p, C.POINTER(GameTable)]),
+    "rp_game_destroy": (C.c_int, [C.c_void_p]),
+    "rp_game_info_id": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32)]),
+    "rp_game_info_name": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]),
+    "rp_game_table_check": (C.c_int, [C.POINTER(GameTable)]),
+    "rp_mccfr_create": (
+        C.c_int,
+        [C.POINTER(GameTable), C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(Hyper), C.c_uint64, C.c_int,
+         C.POINTER(C.c_void_p)],
+    ),
+    "rp_mccfr_destroy": (C.c_int, [C.c_void_p]),
+    "rp_mccfr_step": (C.c_int, [C.c_void_p]),
+    "rp_mccfr_solve": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "rp_mccfr_spend": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "rp_mccfr_step_async": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rp_mccfr_sync": (C.c_int, [C.c_void_p]),
+    "rp_mccfr_epoch": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rp_mccfr_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rp_mccfr_get": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Encounter)]),
+    "rp_mccfr_set": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Encounter)]),
+    "rp_mccfr_export": (C.c_int, [C.c_void_p, C.POINTER(Encounter), C.c_uint64]),
+    "rp_mccfr_import": (C.c_int, [C.c_void_p, C.POINTER(Encounter), C.c_uint64, C.c_uint64]),
+    "rp_mccfr_policy": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
+    "rp_mccfr_exploitability": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "rp_mccfr_sum_regret": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "rp_mccfr_set_batch": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rp_mccfr_set_update_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "rp_mccfr_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rp_mccfr_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "rp_mccfr_summary_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "rp_mccfr_step_local": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rp_mccfr_step_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "rp_mccfr_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "rp_mccfr_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "rp_sinkhorn_hp_default": (None, [C.POINTER(SinkhornHP)]),
+    "rp_kmeans_create": (
+        C.c_int,
+        [C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(SinkhornHP), C.c_uint64,
+         C.c_int, C.POINTER(C.c_void_p)],
+    ),
+    "rp_kmeans_create_device": (
+        C.c_int,
+        [C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(SinkhornHP), C.c_uint64,
+         C.c_int, C.POINTER(C.c_void_p)],
+    ),
+    "rp_kmeans_destroy": (C.c_int, [C.c_void_p]),
+    "rp_kmeans_init_centroids": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rp_kmeans_set_centroids": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rp_kmeans_init_bounds": (C.c_int, [C.c_void_p]),
+    "rp_kmeans_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "rp_kmeans_step_naive": (C.c_int, [C.c_void_p]),
+    "rp_kmeans_assign": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rp_kmeans_bounds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rp_kmeans_centroids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rp_kmeans_metric": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rp_kmeans_rms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "rp_kmeans_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rp_kmeans_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rp_kmeans_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "rp_kmeans_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "rp_kmeans_partial_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "rp_kmeans_step_local": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rp_kmeans_step_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "rp_sinkhorn_divergence": (
+        C.c_int,
+        [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SinkhornHP), C.c_int, C.c_void_p],
+    ),
+    "rp_sinkhorn_cost": (
+        C.c_int,
+        [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SinkhornHP), C.c_int, C.c_void_p,
+         C.c_void_p],
+    ),
+    "rp_equity_variation": (C.c_int, [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load librp_mi355x.so (once).  Raises if it has not been built: no silent fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C robopoker_amd/csrc).  The MI355X path has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != RP_OK:
+        raise RpError(code, load().rp_last_error().decode("utf-8", "replace"))
+
+
+def declared_symbols() -> list[str]:
+    return sorted(_SIGNATURES)

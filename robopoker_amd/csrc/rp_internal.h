@@ -1,0 +1,23 @@
+// rp_internal.h — shared host-side helpers of librp_mi355x.so (not part of the ABI).
+#ifndef RP_INTERNAL_H
+#define RP_INTERNAL_H
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/rp_mi355x.h"
+
+#define RP_MAX_ACTIONS 16u   // widest infoset row the device kernels are compiled for (NLHE needs 9..14)
+#define RP_MAX_PLAYERS 8u
+#define RP_STR2(x) #x
+#define RP_STR(x) RP_STR2(x)
+
+namespace rp {
+
+// records the message for rp_last_error() and returns the code
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+}  // namespace rp
+
+#endif

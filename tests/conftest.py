@@ -1,0 +1,40 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long CPU convergence runs")
+
+
+def _build_once():
+    """Build the product library and the oracle if their shared objects are missing (CPU-only build)."""
+    lib = os.path.join(ROOT, "robopoker_amd", "librp_mi355x.so")
+    ora = os.path.join(ROOT, "oracle", "_build", "librp_oracle.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "robopoker_amd", "csrc")])
+    if not os.path.exists(ora):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+
+
+_build_once()
+
+
+def has_gpu() -> bool:
+    from robopoker_amd import _lib
+
+    return _lib.load().rp_device_count() > 0
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    if not has_gpu():
+        pytest.fail("this test is marked gpu but no HIP device is visible (no CPU fallback exists)")
+    return 0

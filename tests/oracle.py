@@ -1,0 +1,278 @@
+"""ctypes wrapper of the CPU oracle (oracle/_build/librp_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from robopoker_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_PATH = os.path.join(ROOT, "oracle", "_build", "librp_oracle.so")
+MAXA = 16
+
+
+class Decision(C.Structure):
+    _fields_ = [
+        ("info", C.c_uint32),
+        ("n_actions", C.c_uint32),
+        ("expanded", C.c_uint32),
+        ("regret", C.c_float * MAXA),
+        ("policy", C.c_float * MAXA),
+        ("payoff", C.c_float),
+        ("tree", C.c_uint64),
+    ]
+
+
+_ora = None
+
+
+def load() -> C.CDLL:
+    global _ora
+    if _ora is not None:
+        return _ora
+    if not os.path.exists(ORACLE_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    o = C.CDLL(ORACLE_PATH)
+    vp = C.c_void_p
+    o.ora_mccfr_create.restype = vp
+    o.ora_mccfr_create.argtypes = [C.POINTER(_lib.GameTable), C.c_int, C.c_int, C.c_int, C.c_uint32,
+                                   C.POINTER(_lib.Hyper), C.c_uint64]
+    o.ora_mccfr_destroy.argtypes = [vp]
+    o.ora_mccfr_step.argtypes = [vp]
+    o.ora_mccfr_solve.argtypes = [vp, C.c_uint64]
+    o.ora_mccfr_batch.restype = C.c_uint64
+    o.ora_mccfr_batch.argtypes = [vp, C.POINTER(C.POINTER(Decision))]
+    o.ora_mccfr_step_world.restype = C.c_int
+    o.ora_mccfr_step_world.argtypes = [vp, C.c_uint32]
+    o.ora_mccfr_epoch.restype = C.c_uint64
+    o.ora_mccfr_epoch.argtypes = [vp]
+    o.ora_mccfr_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    o.ora_mccfr_set_batch.argtypes = [vp, C.c_uint32]
+    o.ora_mccfr_export.argtypes = [vp, C.POINTER(_lib.Encounter)]
+    o.ora_mccfr_import.argtypes = [vp, C.POINTER(_lib.Encounter), C.c_uint64]
+    o.ora_mccfr_policy.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(C.c_float)]
+    o.ora_mccfr_sum_regret.restype = C.c_float
+    o.ora_mccfr_sum_regret.argtypes = [vp]
+    o.ora_mccfr_exploitability.restype = C.c_float
+    o.ora_mccfr_exploitability.argtypes = [vp]
+    # lloyd
+    o.ora_sinkhorn_cost.restype = C.c_float
+    o.ora_sinkhorn_cost.argtypes = [C.c_uint32, vp, vp, vp, C.POINTER(_lib.SinkhornHP), C.POINTER(C.c_uint32)]
+    o.ora_sinkhorn_divergence.restype = C.c_float
+    o.ora_sinkhorn_divergence.argtypes = [C.c_uint32, vp, vp, vp, C.POINTER(_lib.SinkhornHP)]
+    o.ora_equity_variation.restype = C.c_float
+    o.ora_equity_variation.argtypes = [C.c_uint32, vp, vp]
+    o.ora_kmeans_create.restype = vp
+    o.ora_kmeans_create.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, vp, C.c_int, vp,
+                                    C.POINTER(_lib.SinkhornHP), C.c_uint64]
+    o.ora_kmeans_destroy.argtypes = [vp]
+    o.ora_kmeans_set_centroids.argtypes = [vp, vp]
+    o.ora_kmeans_init_centroids.argtypes = [vp, vp]
+    o.ora_kmeans_init_bounds.argtypes = [vp]
+    o.ora_kmeans_step.argtypes = [vp, vp, vp, C.POINTER(C.c_double)]
+    o.ora_kmeans_step_naive.argtypes = [vp]
+    o.ora_kmeans_assign.argtypes = [vp, vp, vp]
+    o.ora_kmeans_bounds.argtypes = [vp, vp, vp, vp]
+    o.ora_kmeans_centroids.argtypes = [vp, vp, vp]
+    o.ora_kmeans_metric.argtypes = [vp, vp]
+    o.ora_kmeans_rms.restype = C.c_float
+    o.ora_kmeans_rms.argtypes = [vp]
+    o.ora_lloyd_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
+    _ora = o
+    return o
+
+
+def default_hyper() -> _lib.Hyper:
+    hp = _lib.Hyper()
+    _lib.load().rp_hyper_default(C.byref(hp))
+    return hp
+
+
+def default_sinkhorn() -> _lib.SinkhornHP:
+    hp = _lib.SinkhornHP()
+    _lib.load().rp_sinkhorn_hp_default(C.byref(hp))
+    return hp
+
+
+class OracleSolver:
+    """CPU oracle with the same surface as robopoker_amd.mccfr.Solver."""
+
+    def __init__(self, game, regret="floored", weight="linear", sampling="external", batch=1, seed=0, hyper=None):
+        self.game = game
+        self.hp = hyper if hyper is not None else default_hyper()
+        self._o = load()
+        self._h = self._o.ora_mccfr_create(C.byref(game.table), _lib.REGRET[regret], _lib.WEIGHT[weight],
+                                           _lib.SAMPLING[sampling], batch, C.byref(self.hp), seed)
+        assert self._h, "oracle create failed"
+        self.cells = game.table.n_infos * game.table.max_actions
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._o.ora_mccfr_destroy(self._h)
+            self._h = None
+
+    def step(self):
+        self._o.ora_mccfr_step(self._h)
+
+    def solve(self, trees: int):
+        self._o.ora_mccfr_solve(self._h, trees)
+        return self
+
+    def step_world(self, world: int):
+        rc = self._o.ora_mccfr_step_world(self._h, world)
+        if rc != 0:
+            raise RuntimeError("composed update unsupported for this schedule")
+
+    def batch(self):
+        p = C.POINTER(Decision)()
+        n = self._o.ora_mccfr_batch(self._h, C.byref(p))
+        out = []
+        for i in range(n):
+            d = p[i]
+            out.append(dict(info=d.info, n=d.n_actions, expanded=d.expanded, regret=list(d.regret)[: d.n_actions],
+                            policy=list(d.policy)[: d.n_actions], payoff=d.payoff, tree=d.tree))
+        return out
+
+    @property
+    def epoch(self) -> int:
+        return self._o.ora_mccfr_epoch(self._h)
+
+    def counters(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._o.ora_mccfr_counters(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def set_batch(self, b: int):
+        self._o.ora_mccfr_set_batch(self._h, b)
+
+    def export(self) -> np.ndarray:
+        rows = (_lib.Encounter * self.cells)()
+        self._o.ora_mccfr_export(self._h, rows)
+        return np.frombuffer(rows, dtype=ENC_DTYPE).copy()
+
+    def load_rows(self, rows: np.ndarray, epoch: int):
+        buf = np.ascontiguousarray(rows, dtype=ENC_DTYPE)
+        self._o.ora_mccfr_import(self._h, buf.ctypes.data_as(C.POINTER(_lib.Encounter)), epoch)
+
+    def policy(self, info: int, kind="averaged") -> np.ndarray:
+        out = (C.c_float * MAXA)()
+        self._o.ora_mccfr_policy(self._h, info, _lib.DIST[kind], out)
+        return np.array(out[: self.game.n_actions(info)], dtype=np.float32)
+
+    def sum_regret(self) -> float:
+        return self._o.ora_mccfr_sum_regret(self._h)
+
+    def exploitability(self) -> float:
+        return self._o.ora_mccfr_exploitability(self._h)
+
+
+ENC_DTYPE = np.dtype([("weight", "<f4"), ("regret", "<f4"), ("payoff", "<f4"), ("visits", "<u4")])
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def sinkhorn_cost(mu, nu, tri, hp=None, bins=None):
+    hp = hp or default_sinkhorn()
+    mu = np.ascontiguousarray(mu, dtype=np.uint32)
+    nu = np.ascontiguousarray(nu, dtype=np.uint32)
+    tri = np.ascontiguousarray(tri, dtype=np.float32)
+    it = C.c_uint32()
+    c = load().ora_sinkhorn_cost(bins or mu.size, _p(mu), _p(nu), _p(tri), C.byref(hp), C.byref(it))
+    return c, it.value
+
+
+def sinkhorn_divergence(mu, nu, tri, hp=None, bins=None):
+    hp = hp or default_sinkhorn()
+    mu = np.ascontiguousarray(mu, dtype=np.uint32)
+    nu = np.ascontiguousarray(nu, dtype=np.uint32)
+    tri = np.ascontiguousarray(tri, dtype=np.float32)
+    return load().ora_sinkhorn_divergence(bins or mu.size, _p(mu), _p(nu), _p(tri), C.byref(hp))
+
+
+def equity_variation(x, y):
+    x = np.ascontiguousarray(x, dtype=np.uint32)
+    y = np.ascontiguousarray(y, dtype=np.uint32)
+    return load().ora_equity_variation(x.size, _p(x), _p(y))
+
+
+class OracleKmeans:
+    """CPU oracle with the same surface as robopoker_amd.lloyd.Layer."""
+
+    def __init__(self, K, counts, kind="sinkhorn", tri=None, hp=None, seed=0):
+        counts = np.ascontiguousarray(counts, dtype=np.uint8)
+        self.N, self.bins = counts.shape
+        self.K = K
+        self.hp = hp or default_sinkhorn()
+        self._o = load()
+        tri_arr = np.ascontiguousarray(tri, dtype=np.float32) if tri is not None else None
+        self._h = self._o.ora_kmeans_create(K, self.N, self.bins, _p(counts), _lib.METRIC[kind],
+                                            _p(tri_arr) if tri_arr is not None else None, C.byref(self.hp), seed)
+        assert self._h, "oracle kmeans create failed"
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._o.ora_kmeans_destroy(self._h)
+            self._h = None
+
+    def init_centroids(self):
+        chosen = np.zeros(self.K, dtype=np.uint64)
+        self._o.ora_kmeans_init_centroids(self._h, _p(chosen))
+        return chosen
+
+    def set_centroids(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        self._o.ora_kmeans_set_centroids(self._h, _p(idx))
+
+    def init_bounds(self):
+        self._o.ora_kmeans_init_bounds(self._h)
+
+    def step(self):
+        drift = np.zeros(self.K, dtype=np.float32)
+        sizes = np.zeros(self.K, dtype=np.uint64)
+        re = C.c_double()
+        self._o.ora_kmeans_step(self._h, _p(drift), _p(sizes), C.byref(re))
+        return drift, sizes, re.value
+
+    def step_naive(self):
+        self._o.ora_kmeans_step_naive(self._h)
+
+    def assign(self):
+        b = np.zeros(self.N, dtype=np.uint8)
+        d = np.zeros(self.N, dtype=np.float32)
+        self._o.ora_kmeans_assign(self._h, _p(b), _p(d))
+        return b, d
+
+    def bounds(self):
+        j = np.zeros(self.N, dtype=np.uint8)
+        u = np.zeros(self.N, dtype=np.float32)
+        lo = np.zeros((self.N, self.K), dtype=np.float32)
+        self._o.ora_kmeans_bounds(self._h, _p(j), _p(u), _p(lo))
+        return j, u, lo
+
+    def centroids(self):
+        c = np.zeros((self.K, self.bins), dtype=np.uint32)
+        w = np.zeros(self.K, dtype=np.uint64)
+        self._o.ora_kmeans_centroids(self._h, _p(c), _p(w))
+        return c, w
+
+    def metric(self):
+        t = np.zeros(self.K * (self.K - 1) // 2, dtype=np.float32)
+        self._o.ora_kmeans_metric(self._h, _p(t))
+        return t
+
+    def rms(self) -> float:
+        return self._o.ora_kmeans_rms(self._h)
+
+
+def lloyd_stats(reset=False):
+    a, b = C.c_uint64(), C.c_uint64()
+    load().ora_lloyd_stats(C.byref(a), C.byref(b), 1 if reset else 0)
+    return a.value, b.value
