@@ -42,6 +42,11 @@ RP_API const char* rp_last_error(void);
 RP_API int rp_device_count(void);
 /* library build info: "rp_mi355x <version> gfx950 hip <ver>" */
 RP_API const char* rp_version(void);
+/* Arithmetic-contract self test: evaluates rp_math.h's primitives ON THE DEVICE for n input pairs so a
+ * caller can compare them bit for bit with a host evaluation of the same header.
+ * out[0*n..] = rp_expf(x), [1*n..] = rp_logf(|x|), [2*n..] = x / y, [3*n..] = sqrtf(|x|),
+ * [4*n..] = fmaf(x, y, x), [5*n..] = (float)(uint32)|x| as u32->f32 conversion of y's bits. */
+RP_API int rp_math_selftest(int device, uint64_t n, const float* x, const float* y, float* out);
 
 /* ======================================================================= mccfr ==
  * crates/mccfr: Solver (solver/solver.rs:38-351), RefProf/MutProf/CfrSampling

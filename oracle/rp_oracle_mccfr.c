@@ -714,3 +714,16 @@ ORA_API float ora_mccfr_exploitability(ora_mccfr* h) {
     free(cfv);
     return total / (float)h->g.n_players;
 }
+
+/* host evaluation of the arithmetic contract, same layout as rp_math_selftest (include/rp_mi355x.h) */
+ORA_API void ora_math_selftest(uint64_t n, const float* x, const float* y, float* out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        float a = x[i], b = y[i];
+        out[0 * n + i] = rp_expf(a);
+        out[1 * n + i] = rp_logf(rp_absf(a));
+        out[2 * n + i] = a / b;
+        out[3 * n + i] = sqrtf(rp_absf(a));
+        out[4 * n + i] = fmaf(a, b, a);
+        out[5 * n + i] = (float)rp_f2u(b);
+    }
+}

@@ -1,0 +1,1326 @@
+// mccfr.hip — external-sampling MCCFR on MI355X (gfx950): kernels + the rp_mccfr_* C ABI.
+//
+// Reference path (crates/mccfr): Solver::step (solver/solver.rs:96-105) = batch() (:225-250) then the
+// sequential update_{regret,weight,payoff,visits} (:143-192).  MI355X mapping:
+//
+//   k_traverse   one LANE per sampled tree (trees of the table-driven games have <= a few dozen nodes):
+//                TreeBuilder's explicit DFS stack (builder.rs:141-161) and the node list live in a
+//                lane-interleaved HBM scratch (64 lanes = 64 consecutive dwords), the regret/strategy
+//                tables are read through L1/L2.  Each walker infoset is evaluated exactly as CfrFlow::dfs /
+//                recursed_value / ancestor_reach do (flow.rs:64-87,166-216) — same f32 operation order —
+//                by a top-down reach sweep and a bottom-up value sweep over the contiguous subtree.
+//   k_update     one WORKGROUP per infoset: Decisions of the batch are compacted in tree-id order
+//                (slot map -> block scan -> LDS staging) and applied by 3*A "chain" lanes, one per table
+//                cell, sequentially: this is the reference's order-dependent semantics
+//                (R <- max(R*d + delta, floor) per touch), bit for bit.
+//   k_summarize / k_fold   the multi-GPU exchange: per-cell composed maps.
+//
+// Everything f32 is spelled with the primitives of include/rp_math.h and compiled -ffp-contract=off.
+#include "mccfr_kernels.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace rp {
+
+#define HIP_TRY(expr)                                                                                 \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return rp::fail(RP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// device: profile reads (RefProf::{regret,weight} profile.rs:31-37; CfrFlow flow.rs:20-59)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float d_regret(const DevTables& t, uint32_t A, uint32_t info, uint32_t a) {
+    return rp_maxf(t.regret[info * A + a], RP_EPSILON);
+}
+__device__ __forceinline__ float d_weight(const DevTables& t, uint32_t A, uint32_t info, uint32_t a) {
+    return rp_maxf(t.weight[info * A + a], RP_EPSILON);
+}
+__device__ __forceinline__ float d_regret_denom(const DevTables& t, uint32_t A, uint32_t info, uint32_t n) {
+    float s = 0.0f;
+    for (uint32_t a = 0; a < n; ++a) s += d_regret(t, A, info, a);
+    return s;
+}
+__device__ __forceinline__ float d_weight_denom(const DevTables& t, uint32_t A, uint32_t info, uint32_t n,
+                                                float smoothing) {
+    float s = 0.0f;
+    for (uint32_t a = 0; a < n; ++a) s += d_weight(t, A, info, a);
+    return s + smoothing;
+}
+__device__ __forceinline__ float d_sampling_weight(const DevTables& t, uint32_t A, uint32_t info, uint32_t a,
+                                                   float denom, const StepParams& p) {
+    return rp_maxf((d_weight(t, A, info, a) / p.temperature + p.smoothing) / denom, p.curiosity);
+}
+__device__ __forceinline__ float d_sampling_z(const DevTables& t, uint32_t A, uint32_t info, uint32_t n,
+                                              float denom, const StepParams& p) {
+    float z = 0.0f;
+    for (uint32_t a = 0; a < n; ++a) z += d_sampling_weight(t, A, info, a, denom, p);
+    return z;
+}
+
+// SamplingScheme::sample as a bitmask over child slots (sample/{mod,external,pruning,pluribus}.rs)
+__device__ uint32_t d_sample_mask(const DevGame& g, const DevTables& t, const StepParams& p, uint64_t tree_id,
+                                  uint32_t state, uint32_t turn, uint32_t n, uint32_t info, uint32_t off) {
+    const uint32_t all = (1u << n) - 1u;
+    if (n == 0) return 0;
+    if (turn == RP_TURN_CHANCE) {
+        uint64_t h = rp_node_hash(p.seed, p.epoch, tree_id, 0x80000000ull | state);
+        return 1u << rp_pick_uniform(h, n);
+    }
+    if (turn != p.walker) {
+        // weighted (external.rs:41-64): WeightedIndex over sampling_distribution().max(EPSILON)
+        const float denom = d_weight_denom(t, g.A, info, n, p.smoothing);
+        const float z = d_sampling_z(t, g.A, info, n, denom, p);
+        float total = 0.0f;
+        for (uint32_t a = 0; a < n; ++a)
+            total += rp_maxf(d_sampling_weight(t, g.A, info, a, denom, p) / z, RP_EPSILON);
+        const float x = rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info)) * total;
+        float cum = 0.0f;
+        uint32_t idx = 0;
+        bool open = true;
+        for (uint32_t a = 0; a + 1 < n; ++a) {
+            cum += rp_maxf(d_sampling_weight(t, g.A, info, a, denom, p) / z, RP_EPSILON);
+            open = open && (cum <= x);
+            if (open) idx = a + 1;
+        }
+        return 1u << idx;
+    }
+    if (p.S == RP_SAMPLING_EXTERNAL) return all;
+    if (p.S == RP_SAMPLING_PLURIBUS) {
+        if (p.epoch < p.prune_warmup) return all;
+        if (rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info)) < p.prune_explore) return all;
+    }
+    uint32_t mask = 0;
+    for (uint32_t a = 0; a < n; ++a) {
+        bool keep = t.regret[info * g.A + a] > p.prune_threshold;
+        if (p.S == RP_SAMPLING_PLURIBUS) {
+            const uint4 c = g.states[g.children[off + a]];
+            keep = keep || ((c.x & 0xffu) == RP_TURN_TERMINAL);
+        }
+        if (keep) mask |= 1u << a;
+    }
+    return mask ? mask : all;
+}
+
+#define META_PARENT(m) ((m)&0xffu)
+#define META_EDGE(m) (((m) >> 8) & 0xffu)
+#define META_PTYPE(m) (((m) >> 16) & 3u)
+#define META_LEAF(m) (((m) >> 18) & 1u)
+#define META_WALKER(m) (((m) >> 19) & 1u)
+#define META_NACT(m) (((m) >> 24) & 0xffu)
+#define NO_PARENT 0xffu
+
+// ------------------------------------------------------------------------------------------------
+// k_traverse: Solver::batch for one shard of trees
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_traverse(DevGame g, DevTables t, DevScratch sc, DevDecisions dc,
+                                                  StepParams p) {
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= p.batch) return;
+    const uint64_t tree_id = p.tree_base + lane;
+    const size_t S = sc.stride;
+    uint32_t err = 0;
+
+    // ---- TreeBuilder::build (builder.rs:74-87,141-161): pop-last DFS -----------------------------
+    uint32_t nn = 0, sp = 0;
+    uint32_t cur_state = g.root;
+    uint32_t cur_meta_in = NO_PARENT | (PT_NONE << 16);
+    float cur_frel = 1.0f, cur_fsmp = 1.0f;
+    for (;;) {
+        const uint4 st = g.states[cur_state];
+        const uint32_t turn = st.x & 0xffu, nch = (st.x >> 8) & 0xffu, info = st.y, off = st.z;
+        const uint32_t me = nn;
+        if (nn >= sc.maxn) {
+            err |= ERR_NODE_CAPACITY;
+            break;
+        }
+        const bool is_walker = turn == p.walker;
+        uint32_t meta = cur_meta_in | ((nch == 0 ? 1u : 0u) << 18) | ((is_walker ? 1u : 0u) << 19) | (nch << 24);
+        sc.n_meta[me * S + lane] = meta;
+        sc.n_info[me * S + lane] = info;
+        sc.n_frel[me * S + lane] = cur_frel;
+        sc.n_fsmp[me * S + lane] = cur_fsmp;
+        if (nch == 0) sc.n_pay[me * S + lane] = g.payoffs[off * g.n_players + p.walker];
+        nn += 1;
+        if (nch > 0) {
+            const uint32_t mask = d_sample_mask(g, t, p, tree_id, cur_state, turn, nch, info, off);
+            const bool chance = turn == RP_TURN_CHANCE;
+            const uint32_t ptype = chance ? PT_CHANCE : (is_walker ? PT_WALKER : PT_OPP);
+            float rd = 0.0f, denom = 0.0f, z = 0.0f;
+            if (!chance) rd = d_regret_denom(t, g.A, info, nch);
+            if (ptype == PT_OPP) {
+                denom = d_weight_denom(t, g.A, info, nch, p.smoothing);
+                z = d_sampling_z(t, g.A, info, nch, denom, p);
+            }
+            for (uint32_t k = 0; k < nch; ++k) {
+                if (!((mask >> k) & 1u)) continue;
+                if (sp >= sc.maxs) {
+                    err |= ERR_STACK_CAPACITY;
+                    break;
+                }
+                // reach factors of the edge parent->child (flow.rs:195-212)
+                const float frel = chance ? 1.0f : d_regret(t, g.A, info, k) / rd;
+                const float fsmp = ptype == PT_OPP ? d_sampling_weight(t, g.A, info, k, denom, p) / z : 1.0f;
+                sc.s_state[sp * S + lane] = g.children[off + k];
+                sc.s_meta[sp * S + lane] = me | (k << 8) | (ptype << 16);
+                sc.s_frel[sp * S + lane] = frel;
+                sc.s_fsmp[sp * S + lane] = fsmp;
+                sp += 1;
+            }
+        }
+        if (sp == 0 || err) break;
+        sp -= 1;
+        cur_state = sc.s_state[sp * S + lane];
+        cur_meta_in = sc.s_meta[sp * S + lane];
+        cur_frel = sc.s_frel[sp * S + lane];
+        cur_fsmp = sc.s_fsmp[sp * S + lane];
+    }
+
+    // ---- Tree::partition + CfrFlow::dfs per walker infoset (tree.rs:88-98, flow.rs:64-87) --------
+    uint32_t ndec = 0;
+    if (!err) {
+        for (uint32_t i = 0; i < nn; ++i) {
+            const uint32_t mi = sc.n_meta[i * S + lane];
+            if (!META_WALKER(mi) || META_LEAF(mi)) continue;
+            const uint32_t info = sc.n_info[i * S + lane];
+            bool head = true;
+            for (uint32_t j = 0; j < i; ++j) {
+                const uint32_t mj = sc.n_meta[j * S + lane];
+                if (META_WALKER(mj) && !META_LEAF(mj) && sc.n_info[j * S + lane] == info) head = false;
+            }
+            if (!head) continue;
+            if (ndec >= dc.maxdec) {
+                err |= ERR_DEC_CAPACITY;
+                break;
+            }
+            const uint32_t nact = META_NACT(mi);
+            const uint32_t slot = ndec++;
+            const size_t D = dc.stride;
+            const float rd = d_regret_denom(t, g.A, info, nact);
+            for (uint32_t a = 0; a < nact; ++a) {  // policy_vector = iterated_distribution (profile.rs:47-51)
+                dc.policy[(slot * g.A + a) * D + lane] = d_regret(t, g.A, info, a) / rd;
+                dc.regret[(slot * g.A + a) * D + lane] = 0.0f;
+            }
+            float payoff = 0.0f;
+            uint32_t expanded = 0;
+            for (uint32_t j = i; j < nn; ++j) {  // span in ascending node index
+                const uint32_t mj = sc.n_meta[j * S + lane];
+                if (!META_WALKER(mj) || META_LEAF(mj) || sc.n_info[j * S + lane] != info) continue;
+                // top-down: reach products below root j, starting at 1 on j's children (flow.rs:72)
+                uint32_t end = j;
+                for (uint32_t n = j + 1; n < nn; ++n) {
+                    const uint32_t mn = sc.n_meta[n * S + lane];
+                    const uint32_t par = META_PARENT(mn);
+                    if (par < j) break;
+                    float rel = 1.0f, smp = 1.0f;
+                    if (par != j) {
+                        rel = sc.n_rel[par * S + lane] * sc.n_frel[n * S + lane];
+                        smp = sc.n_smp[par * S + lane] * sc.n_fsmp[n * S + lane];
+                    }
+                    sc.n_rel[n * S + lane] = rel;
+                    sc.n_smp[n * S + lane] = smp;
+                    sc.n_acc[n * S + lane] = 0.0f;
+                    end = n;
+                }
+                // bottom-up: children were created in reverse choices() order, so descending node index
+                // adds them to the parent's sum in choices() order, as node.edges() does (node.rs:103-107)
+                uint32_t kids = 0;
+                for (uint32_t n = end; n > j; --n) {
+                    const uint32_t mn = sc.n_meta[n * S + lane];
+                    const float v = META_LEAF(mn)
+                                        ? sc.n_rel[n * S + lane] / sc.n_smp[n * S + lane] * sc.n_pay[n * S + lane]
+                                        : sc.n_acc[n * S + lane];
+                    const uint32_t par = META_PARENT(mn);
+                    if (par == j) {
+                        sc.t_v[META_EDGE(mn) * S + lane] = v;
+                        kids |= 1u << META_EDGE(mn);
+                    } else {
+                        sc.n_acc[par * S + lane] = sc.n_acc[par * S + lane] + v;
+                    }
+                }
+                // ancestor_reach (flow.rs:166-174): upward over opponent decision ancestors
+                float cf = 1.0f, sm = 1.0f;
+                for (uint32_t n = j;;) {
+                    const uint32_t mn = sc.n_meta[n * S + lane];
+                    const uint32_t par = META_PARENT(mn);
+                    if (par == NO_PARENT) break;
+                    if (META_PTYPE(mn) == PT_OPP) {
+                        cf = cf * sc.n_frel[n * S + lane];
+                        sm = sm * sc.n_fsmp[n * S + lane];
+                    }
+                    n = par;
+                }
+                const float reach = cf / sm;
+                float ev = 0.0f;
+                for (uint32_t a = 0; a < nact; ++a) {
+                    if (!((kids >> a) & 1u)) continue;
+                    const float v = reach * sc.t_v[a * S + lane];
+                    sc.t_v[a * S + lane] = v;
+                }
+                for (uint32_t a = 0; a < nact; ++a) {
+                    if (!((kids >> a) & 1u)) continue;
+                    ev += d_regret(t, g.A, info, a) / rd * sc.t_v[a * S + lane];
+                }
+                payoff += ev;
+                for (uint32_t a = 0; a < nact; ++a) {
+                    if (!((kids >> a) & 1u)) continue;
+                    const size_t k = (slot * g.A + a) * D + lane;
+                    dc.regret[k] = dc.regret[k] + (sc.t_v[a * S + lane] - ev);
+                }
+                expanded |= kids;
+            }
+            dc.info[slot * D + lane] = info;
+            dc.mask[slot * D + lane] = expanded;
+            dc.payoff[slot * D + lane] = payoff;
+            dc.slotmap[(size_t)info * D + lane] = (uint8_t)(slot + 1);
+        }
+    }
+    // Metrics: nodes / infos (metrics/mod.rs:21-80; solver.rs:273)
+    atomicAdd(&p.counters[0], (unsigned long long)nn);
+    atomicAdd(&p.counters[1], (unsigned long long)ndec);
+    if (err) atomicOr(&p.counters[2], (unsigned long long)err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// schedules (regret/*.rs, policy/*.rs)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float d_regret_gain(int kind, float acc, float imm, float t, float floor_r) {
+    float v;
+    switch (kind) {
+        case RP_REGRET_LINEAR: {
+            const float discount = t / (t + 1.0f);
+            v = acc * discount + imm;
+        } break;
+        case RP_REGRET_DISCOUNTED: {
+            float x;
+            if (acc > 0.0f) x = rp_pow15(t / 1.0f);
+            else if (acc < 0.0f) x = rp_pow05(t / 1.0f);
+            else x = t / 1.0f;
+            const float discount = x / (x + 1.0f);
+            v = acc * discount + imm;
+        } break;
+        case RP_REGRET_ASYMMETRIC: {
+            if (acc > 0.0f) v = acc + imm;
+            else {
+                const float discount = t / (t + 1.0f);
+                v = acc * discount + imm;
+            }
+        } break;
+        default: v = acc + imm; break;  // Summed, Floored
+    }
+    return rp_maxf(v, floor_r);
+}
+__device__ __forceinline__ float d_weight_learn(int kind, float acc, float imm, float t) {
+    float v;
+    switch (kind) {
+        case RP_WEIGHT_LINEAR: v = acc + imm * t; break;
+        case RP_WEIGHT_QUADRATIC: v = acc + imm * t * t; break;
+        case RP_WEIGHT_EXPONENTIAL: v = acc * 0.9999f + imm; break;
+        default: v = acc + imm; break;
+    }
+    return rp_maxf(v, RP_EPSILON);
+}
+__host__ __device__ inline float regret_floor_of(int R, float regret_min) {
+    if (R == RP_REGRET_FLOORED) return 0.0f;
+    if (R == RP_REGRET_SUMMED) return rp_u2f(0xff800000u);
+    return regret_min;
+}
+
+// ------------------------------------------------------------------------------------------------
+// compaction of one infoset's Decisions in tree-id order into LDS (shared by k_update / k_summarize)
+// ------------------------------------------------------------------------------------------------
+#define UPD_THREADS 256
+#define UPD_TREES_PER_THREAD 4
+#define UPD_CHUNK (UPD_THREADS * UPD_TREES_PER_THREAD)
+
+struct Stage {
+    float* regret;   // [A][UPD_CHUNK]
+    float* policy;   // [A][UPD_CHUNK]
+    float* payoff;   // [UPD_CHUNK]
+    uint32_t* mask;  // [UPD_CHUNK]
+};
+
+// returns the number of staged Decisions of `info` among trees [base, base + UPD_CHUNK)
+__device__ uint32_t stage_chunk(const DevDecisions& dc, uint32_t A, uint32_t nact, uint32_t info, uint32_t base,
+                                uint32_t batch, const Stage& s, uint32_t* wave_tot) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t t0 = base + tid * UPD_TREES_PER_THREAD;
+    uint32_t slots = 0;
+    if (t0 + UPD_TREES_PER_THREAD <= batch) {
+        slots = *reinterpret_cast<const uint32_t*>(&dc.slotmap[(size_t)info * dc.stride + t0]);
+    } else {
+        for (uint32_t k = 0; k < UPD_TREES_PER_THREAD; ++k)
+            if (t0 + k < batch) slots |= (uint32_t)dc.slotmap[(size_t)info * dc.stride + t0 + k] << (8 * k);
+    }
+    uint32_t cnt = 0;
+    for (uint32_t k = 0; k < UPD_TREES_PER_THREAD; ++k) cnt += ((slots >> (8 * k)) & 0xffu) != 0;
+    // block-wide exclusive scan of cnt in thread order (= tree order)
+    uint32_t incl = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if ((int)(tid & 63) >= d) incl += o;
+    }
+    const uint32_t wave = tid >> 6;
+    if ((tid & 63) == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+    for (uint32_t w = 0; w < UPD_THREADS / 64; ++w) {
+        const uint32_t c = wave_tot[w];
+        if (w < wave) wbase += c;
+        total += c;
+    }
+    uint32_t rank = wbase + incl - cnt;
+    for (uint32_t k = 0; k < UPD_TREES_PER_THREAD; ++k) {
+        const uint32_t sl = (slots >> (8 * k)) & 0xffu;
+        if (!sl) continue;
+        const uint32_t tree = t0 + k, slot = sl - 1;
+        for (uint32_t a = 0; a < nact; ++a) {
+            s.regret[a * UPD_CHUNK + rank] = dc.regret[(slot * A + a) * dc.stride + tree];
+            s.policy[a * UPD_CHUNK + rank] = dc.policy[(slot * A + a) * dc.stride + tree];
+        }
+        s.payoff[rank] = dc.payoff[slot * dc.stride + tree];
+        s.mask[rank] = dc.mask[slot * dc.stride + tree];
+        rank += 1;
+    }
+    __syncthreads();
+    return total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_update: Solver::update_{regret,weight,payoff,visits} in tree-id order (solver.rs:96-105,143-192)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(UPD_THREADS) void k_update(DevGame g, DevTables t, DevDecisions dc, StepParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t info = blockIdx.x;
+    if (g.info_player[info] != p.walker) return;  // only walker infosets receive Decisions
+    const uint32_t A = g.A, nact = g.info_actions[info];
+    Stage s;
+    s.regret = reinterpret_cast<float*>(smem);
+    s.policy = s.regret + (size_t)A * UPD_CHUNK;
+    s.payoff = s.policy + (size_t)A * UPD_CHUNK;
+    s.mask = reinterpret_cast<uint32_t*>(s.payoff + UPD_CHUNK);
+    uint32_t* wave_tot = s.mask + UPD_CHUNK;
+
+    const uint32_t tid = threadIdx.x;
+    // chain lanes: [0,A) regret, [A,2A) weight, [2A,3A) payoff+visits; one table cell each
+    const uint32_t kind = tid / A, a = tid % A;
+    const bool chain = tid < 3 * A && a < nact;
+    const size_t cell = (size_t)info * A + a;
+    float acc = 0.0f;
+    uint32_t visits = 0;
+    if (chain) {
+        if (kind == 0) acc = t.regret[cell];
+        else if (kind == 1) acc = t.weight[cell];
+        else {
+            acc = t.payoff[cell];
+            visits = t.visits[cell];
+        }
+    }
+    const float tf = (float)p.epoch;
+    const float floor_r = regret_floor_of(p.R, p.regret_min);
+    for (uint32_t base = 0; base < p.batch; base += UPD_CHUNK) {
+        const uint32_t n = stage_chunk(dc, A, nact, info, base, p.batch, s, wave_tot);
+        if (chain) {
+            if (kind == 0) {
+                for (uint32_t i = 0; i < n; ++i)
+                    if ((s.mask[i] >> a) & 1u) acc = d_regret_gain(p.R, acc, s.regret[a * UPD_CHUNK + i], tf, floor_r);
+            } else if (kind == 1) {
+                for (uint32_t i = 0; i < n; ++i) acc = d_weight_learn(p.W, acc, s.policy[a * UPD_CHUNK + i], tf);
+            } else {
+                for (uint32_t i = 0; i < n; ++i) {  // Welford mean with the pre-increment count (solver.rs:174-192)
+                    acc += (s.payoff[i] - acc) / (float)(visits + 1u);
+                    visits += 1u;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (chain) {
+        if (kind == 0) t.regret[cell] = acc;
+        else if (kind == 1) t.weight[cell] = acc;
+        else {
+            t.payoff[cell] = acc;
+            t.visits[cell] = visits;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_summarize / k_fold: the multi-GPU exchange (oracle: ora_mccfr_step_world)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(UPD_THREADS) void k_summarize(DevGame g, DevDecisions dc, StepParams p, Cell* cells,
+                                                           InfoSum* sums) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t info = blockIdx.x;
+    const uint32_t A = g.A, nact = g.info_actions[info];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t kind = tid / A, a = tid % A;
+    const bool chain = tid < 3 * A && a < nact;
+    const float NEG_INF = rp_u2f(0xff800000u);
+    if (g.info_player[info] != p.walker) {  // identity maps
+        if (tid < A) {
+            Cell c{1.0f, 0.0f, NEG_INF, 1.0f, 0.0f, NEG_INF, 0u, 0u};
+            cells[(size_t)info * A + tid] = c;
+        }
+        if (tid == 0) sums[info] = InfoSum{0u, 0.0f};
+        return;
+    }
+    Stage s;
+    s.regret = reinterpret_cast<float*>(smem);
+    s.policy = s.regret + (size_t)A * UPD_CHUNK;
+    s.payoff = s.policy + (size_t)A * UPD_CHUNK;
+    s.mask = reinterpret_cast<uint32_t*>(s.payoff + UPD_CHUNK);
+    uint32_t* wave_tot = s.mask + UPD_CHUNK;
+
+    const float tf = (float)p.epoch;
+    const float floor_r = regret_floor_of(p.R, p.regret_min);
+    const float dr = p.R == RP_REGRET_LINEAR ? tf / (tf + 1.0f) : 1.0f;
+    const float dw = p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f;
+    float ma = 1.0f, mb = 0.0f, mm = NEG_INF;
+    uint32_t cnt = 0;
+    float psum = 0.0f;
+    for (uint32_t base = 0; base < p.batch; base += UPD_CHUNK) {
+        const uint32_t n = stage_chunk(dc, A, nact, info, base, p.batch, s, wave_tot);
+        if (chain) {
+            if (kind == 0) {
+                for (uint32_t i = 0; i < n; ++i) {
+                    if (!((s.mask[i] >> a) & 1u)) continue;
+                    const float dl = s.regret[a * UPD_CHUNK + i];
+                    if (cnt == 0) { ma = dr; mb = dl; mm = floor_r; }
+                    else { ma = ma * dr; mb = mb * dr + dl; mm = rp_maxf(mm * dr + dl, floor_r); }
+                    cnt += 1;
+                }
+            } else if (kind == 1) {
+                for (uint32_t i = 0; i < n; ++i) {
+                    const float sg = s.policy[a * UPD_CHUNK + i];
+                    float dl = sg;
+                    if (p.W == RP_WEIGHT_LINEAR) dl = sg * tf;
+                    else if (p.W == RP_WEIGHT_QUADRATIC) dl = sg * tf * tf;
+                    if (cnt == 0) { ma = dw; mb = dl; mm = RP_EPSILON; }
+                    else { ma = ma * dw; mb = mb * dw + dl; mm = rp_maxf(mm * dw + dl, RP_EPSILON); }
+                    cnt += 1;
+                }
+            } else if (a == 0) {
+                for (uint32_t i = 0; i < n; ++i) {
+                    psum += s.payoff[i];
+                    cnt += 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (chain) {
+        Cell* c = &cells[(size_t)info * A + a];
+        if (kind == 0) { c->ra = ma; c->rb = mb; c->rm = mm; c->rn = cnt; }
+        else if (kind == 1) { c->wa = ma; c->wb = mb; c->wm = mm; c->wn = cnt; }
+        else if (a == 0) sums[info] = InfoSum{cnt, psum};
+    }
+    if (tid < A && tid >= nact) {
+        Cell c{1.0f, 0.0f, NEG_INF, 1.0f, 0.0f, NEG_INF, 0u, 0u};
+        cells[(size_t)info * A + tid] = c;
+    }
+}
+
+// one thread per table cell; `blob` holds `world` summaries back to back: [cells][sums]
+__global__ void k_fold(DevGame g, DevTables t, const unsigned char* blob, size_t blob_stride, uint32_t world) {
+    const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ncell = g.n_infos * g.A;
+    if (cell >= ncell) return;
+    const uint32_t info = cell / g.A, a = cell % g.A;
+    if (a >= g.info_actions[info]) return;
+    float r = t.regret[cell], w = t.weight[cell], ev = t.payoff[cell];
+    uint32_t visits = t.visits[cell];
+    for (uint32_t rk = 0; rk < world; ++rk) {
+        const unsigned char* b = blob + (size_t)rk * blob_stride;
+        const Cell c = reinterpret_cast<const Cell*>(b)[cell];
+        const InfoSum s = reinterpret_cast<const InfoSum*>(b + (size_t)ncell * sizeof(Cell))[info];
+        if (c.rn) r = rp_maxf(c.ra * r + c.rb, c.rm);
+        if (c.wn) w = rp_maxf(c.wa * w + c.wb, c.wm);
+        if (s.count) {
+            const uint32_t n2 = visits + s.count;
+            ev = ev + (s.psum - (float)s.count * ev) / (float)n2;
+            visits = n2;
+        }
+    }
+    t.regret[cell] = r;
+    t.weight[cell] = w;
+    t.payoff[cell] = ev;
+    t.visits[cell] = visits;
+}
+
+}  // namespace rp
+
+// =================================================================================================
+// host side
+// =================================================================================================
+using namespace rp;
+
+struct KernelClock {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0.0;
+    uint64_t launches = 0;
+};
+
+struct rp_mccfr {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // host copy of the game (exploitability, validation)
+    std::vector<rp_state> states;
+    std::vector<uint32_t> children;
+    std::vector<float> payoffs;
+    std::vector<uint8_t> info_actions, info_player;
+    std::vector<float> default_regret;
+    rp_game_table tbl{};
+    // device
+    DevGame g{};
+    DevTables t{};
+    DevScratch sc{};
+    DevDecisions dc{};
+    void* d_states = nullptr;
+    void* d_children = nullptr;
+    void* d_payoffs = nullptr;
+    void* d_info_actions = nullptr;
+    void* d_info_player = nullptr;
+    void* d_scratch = nullptr;
+    void* d_dec = nullptr;
+    void* d_summary = nullptr;
+    unsigned long long* d_counters = nullptr;
+    int R = 0, W = 0, S = 0;
+    rp_hyper hp{};
+    uint64_t seed = 0;
+    uint32_t batch = 1, capacity = 0;
+    uint64_t epoch = 0;
+    uint32_t rank = 0, world = 1;
+    uint32_t maxdec = 1;
+    rp_update_mode mode = RP_UPDATE_ORDERED;
+    bool profiling = false;
+    KernelClock clk_traverse, clk_update;
+};
+
+namespace {
+
+int set_device(const rp_mccfr* h) {
+    HIP_TRY(hipSetDevice(h->device));
+    return RP_OK;
+}
+
+size_t update_lds_bytes(uint32_t A) {
+    return ((size_t)2 * A * UPD_CHUNK + UPD_CHUNK) * sizeof(float) + UPD_CHUNK * sizeof(uint32_t) + 64;
+}
+
+size_t summary_bytes_of(const rp_mccfr* h) {
+    return (size_t)h->tbl.n_infos * h->tbl.max_actions * sizeof(Cell) + (size_t)h->tbl.n_infos * sizeof(InfoSum);
+}
+
+// largest number of walker nodes / stack entries an externally sampled tree can have
+void sampled_tree_bounds(const rp_mccfr* h, uint32_t* maxdec, uint32_t* maxstack) {
+    const rp_game_table& t = h->tbl;
+    uint32_t best_dec = 1, best_stack = 1;
+    for (uint32_t w = 0; w < t.n_players; ++w) {
+        std::function<uint32_t(uint32_t)> wn = [&](uint32_t s) -> uint32_t {
+            const rp_state& st = h->states[s];
+            uint32_t acc = 0;
+            for (uint32_t k = 0; k < st.n_children; ++k) {
+                uint32_t c = wn(h->children[st.offset + k]);
+                acc = st.turn == w ? acc + c : std::max(acc, c);
+            }
+            return acc + (st.turn == w && st.n_children ? 1u : 0u);
+        };
+        // pending leaves: at a walker node all children are pushed, one is popped and explored first
+        std::function<uint32_t(uint32_t)> stk = [&](uint32_t s) -> uint32_t {
+            const rp_state& st = h->states[s];
+            if (!st.n_children) return 0;
+            uint32_t deepest = 0;
+            for (uint32_t k = 0; k < st.n_children; ++k) deepest = std::max(deepest, stk(h->children[st.offset + k]));
+            uint32_t pushed = st.turn == w ? st.n_children : 1u;
+            return pushed - 1 + std::max(deepest, 1u);
+        };
+        best_dec = std::max(best_dec, wn(t.train_root));
+        best_stack = std::max(best_stack, stk(t.train_root));
+    }
+    *maxdec = best_dec;
+    *maxstack = best_stack + 1;
+}
+
+int alloc_batch_buffers(rp_mccfr* h, uint32_t batch) {
+    if (batch <= h->capacity) return RP_OK;
+    if (h->d_scratch) HIP_TRY(hipFree(h->d_scratch));
+    if (h->d_dec) HIP_TRY(hipFree(h->d_dec));
+    h->d_scratch = h->d_dec = nullptr;
+    const size_t stride = ((size_t)batch + 255) & ~(size_t)255;
+    const uint32_t A = h->tbl.max_actions;
+    DevScratch& sc = h->sc;
+    sc.stride = stride;
+    const size_t node_words = (size_t)sc.maxn * stride, stack_words = (size_t)sc.maxs * stride;
+    const size_t total_words = 8 * node_words + 4 * stack_words + (size_t)A * stride;
+    HIP_TRY(hipMalloc(&h->d_scratch, total_words * 4));
+    uint32_t* base = reinterpret_cast<uint32_t*>(h->d_scratch);
+    sc.n_meta = base; base += node_words;
+    sc.n_info = base; base += node_words;
+    sc.n_frel = reinterpret_cast<float*>(base); base += node_words;
+    sc.n_fsmp = reinterpret_cast<float*>(base); base += node_words;
+    sc.n_pay = reinterpret_cast<float*>(base); base += node_words;
+    sc.n_rel = reinterpret_cast<float*>(base); base += node_words;
+    sc.n_smp = reinterpret_cast<float*>(base); base += node_words;
+    sc.n_acc = reinterpret_cast<float*>(base); base += node_words;
+    sc.s_state = base; base += stack_words;
+    sc.s_meta = base; base += stack_words;
+    sc.s_frel = reinterpret_cast<float*>(base); base += stack_words;
+    sc.s_fsmp = reinterpret_cast<float*>(base); base += stack_words;
+    sc.t_v = reinterpret_cast<float*>(base);
+
+    DevDecisions& dc = h->dc;
+    dc.stride = stride;
+    dc.maxdec = h->maxdec;
+    const size_t slot_words = (size_t)dc.maxdec * stride;
+    const size_t dec_bytes = (3 * slot_words + 2 * slot_words * A) * 4 + (size_t)h->tbl.n_infos * stride;
+    HIP_TRY(hipMalloc(&h->d_dec, dec_bytes));
+    uint32_t* d = reinterpret_cast<uint32_t*>(h->d_dec);
+    dc.info = d; d += slot_words;
+    dc.mask = d; d += slot_words;
+    dc.payoff = reinterpret_cast<float*>(d); d += slot_words;
+    dc.regret = reinterpret_cast<float*>(d); d += slot_words * A;
+    dc.policy = reinterpret_cast<float*>(d); d += slot_words * A;
+    dc.slotmap = reinterpret_cast<uint8_t*>(d);
+    h->capacity = batch;
+    return RP_OK;
+}
+
+StepParams make_params(const rp_mccfr* h) {
+    StepParams p{};
+    p.seed = h->seed;
+    p.epoch = h->epoch;
+    p.tree_base = (uint64_t)h->rank * h->batch;
+    p.batch = h->batch;
+    p.walker = (uint32_t)(h->epoch % h->tbl.n_players);  // CfrSampling::walker (book.rs:142-144)
+    p.R = h->R; p.W = h->W; p.S = h->S;
+    p.temperature = h->hp.temperature; p.smoothing = h->hp.smoothing; p.curiosity = h->hp.curiosity;
+    p.prune_threshold = h->hp.prune_threshold; p.prune_explore = h->hp.prune_explore;
+    p.prune_warmup = h->hp.prune_warmup;
+    p.regret_min = h->hp.regret_min;
+    p.counters = h->d_counters;
+    return p;
+}
+
+void clock_begin(rp_mccfr* h, KernelClock& c) {
+    if (!h->profiling) return;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, h->stream);
+    c.pending.emplace_back(a, b);
+}
+void clock_end(rp_mccfr* h, KernelClock& c) {
+    if (!h->profiling) return;
+    (void)hipEventRecord(c.pending.back().second, h->stream);
+    c.launches += 1;
+}
+void clock_drain(KernelClock& c) {
+    for (auto& pr : c.pending) {
+        float ms = 0.0f;
+        (void)hipEventSynchronize(pr.second);
+        (void)hipEventElapsedTime(&ms, pr.first, pr.second);
+        c.total_ms += ms;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    c.pending.clear();
+}
+
+int launch_traverse(rp_mccfr* h, const StepParams& p) {
+    HIP_TRY(hipMemsetAsync(h->dc.slotmap, 0, (size_t)h->tbl.n_infos * h->dc.stride, h->stream));
+    const uint32_t threads = 256, blocks = (h->batch + threads - 1) / threads;
+    clock_begin(h, h->clk_traverse);
+    hipLaunchKernelGGL(k_traverse, dim3(blocks), dim3(threads), 0, h->stream, h->g, h->t, h->sc, h->dc, p);
+    clock_end(h, h->clk_traverse);
+    HIP_TRY(hipGetLastError());
+    return RP_OK;
+}
+
+int enqueue_step(rp_mccfr* h) {
+    const StepParams p = make_params(h);
+    int rc = launch_traverse(h, p);
+    if (rc) return rc;
+    const size_t lds = update_lds_bytes(h->tbl.max_actions);
+    if (h->mode == RP_UPDATE_ORDERED) {
+        clock_begin(h, h->clk_update);
+        hipLaunchKernelGGL(k_update, dim3(h->tbl.n_infos), dim3(UPD_THREADS), lds, h->stream, h->g, h->t, h->dc, p);
+        clock_end(h, h->clk_update);
+        HIP_TRY(hipGetLastError());
+    } else {
+        unsigned char* blob = reinterpret_cast<unsigned char*>(h->d_summary);
+        Cell* cells = reinterpret_cast<Cell*>(blob);
+        InfoSum* sums = reinterpret_cast<InfoSum*>(blob + (size_t)h->tbl.n_infos * h->tbl.max_actions * sizeof(Cell));
+        clock_begin(h, h->clk_update);
+        hipLaunchKernelGGL(k_summarize, dim3(h->tbl.n_infos), dim3(UPD_THREADS), lds, h->stream, h->g, h->dc, p, cells,
+                           sums);
+        const uint32_t ncell = h->tbl.n_infos * h->tbl.max_actions;
+        hipLaunchKernelGGL(k_fold, dim3((ncell + 255) / 256), dim3(256), 0, h->stream, h->g, h->t, blob,
+                           summary_bytes_of(h), 1u);
+        clock_end(h, h->clk_update);
+        HIP_TRY(hipGetLastError());
+    }
+    h->epoch += 1;  // CfrSampling::increment via Solver::advance (solver.rs:103-104)
+    return RP_OK;
+}
+
+int check_device_errors(rp_mccfr* h) {
+    unsigned long long c[3];
+    HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (c[2]) return rp::fail(RP_ERR_CAPACITY, "mccfr kernel capacity exceeded (flags %llu): nodes/stack/decisions", c[2]);
+    return RP_OK;
+}
+
+int composed_supported(const rp_mccfr* h) {
+    if (h->R == RP_REGRET_DISCOUNTED || h->R == RP_REGRET_ASYMMETRIC)
+        return rp::fail(RP_ERR_UNSUPPORTED,
+                        "composed update needs a sign-independent discount (Summed/Linear/Floored regret)");
+    return RP_OK;
+}
+
+int fetch_tables(rp_mccfr* h, std::vector<float>& regret, std::vector<float>& weight, std::vector<float>& payoff,
+                 std::vector<uint32_t>& visits) {
+    const size_t cells = (size_t)h->tbl.n_infos * h->tbl.max_actions;
+    regret.resize(cells); weight.resize(cells); payoff.resize(cells); visits.resize(cells);
+    HIP_TRY(hipMemcpyAsync(regret.data(), h->t.regret, cells * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(weight.data(), h->t.weight, cells * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(payoff.data(), h->t.payoff, cells * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(visits.data(), h->t.visits, cells * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind w, rp_sampling_kind s,
+                    uint32_t batch_size, const rp_hyper* hp, uint64_t seed, int device, rp_mccfr** out) {
+    if (!game || !out) return rp::fail(RP_ERR_INVALID, "rp_mccfr_create: NULL argument");
+    int rc = rp_game_table_check(game);
+    if (rc) return rc;
+    if ((int)r < 0 || (int)r > 4 || (int)w < 0 || (int)w > 3 || (int)s < 0 || (int)s > 2)
+        return rp::fail(RP_ERR_INVALID, "rp_mccfr_create: unknown schedule / sampling kind");
+    if (batch_size == 0) return rp::fail(RP_ERR_INVALID, "rp_mccfr_create: batch_size must be > 0");
+    if (rp_device_count() <= 0)
+        return rp::fail(RP_ERR_NO_DEVICE, "rp_mccfr_create: no HIP device visible; the MI355X path has no CPU fallback");
+    if (game->max_tree_nodes == 0 || game->max_tree_nodes >= 255)
+        return rp::fail(RP_ERR_CAPACITY, "rp_mccfr_create: sampled trees of up to %u nodes exceed the per-lane limit (254)",
+                        game->max_tree_nodes);
+    rp_mccfr* h = new rp_mccfr();
+    h->device = device;
+    h->tbl = *game;
+    h->states.assign(game->states, game->states + game->n_states);
+    h->children.assign(game->children, game->children + game->n_children);
+    h->payoffs.assign(game->payoffs, game->payoffs + (size_t)game->n_terminals * game->n_players);
+    h->info_actions.assign(game->info_actions, game->info_actions + game->n_infos);
+    h->info_player.assign(game->info_player, game->info_player + game->n_infos);
+    const size_t cells = (size_t)game->n_infos * game->max_actions;
+    h->default_regret.assign(cells, 0.0f);
+    if (game->default_regret) h->default_regret.assign(game->default_regret, game->default_regret + cells);
+    h->tbl.states = h->states.data();
+    h->tbl.children = h->children.data();
+    h->tbl.payoffs = h->payoffs.data();
+    h->tbl.info_actions = h->info_actions.data();
+    h->tbl.info_player = h->info_player.data();
+    h->tbl.default_regret = h->default_regret.data();
+    h->R = r; h->W = w; h->S = s;
+    if (hp) h->hp = *hp; else rp_hyper_default(&h->hp);
+    h->seed = seed;
+    h->batch = batch_size;
+
+#define CREATE_TRY(expr)                                                                             \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            int _rc = rp::fail(RP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));           \
+            rp_mccfr_destroy(h);                                                                     \
+            return _rc;                                                                              \
+        }                                                                                            \
+    } while (0)
+
+    CREATE_TRY(hipSetDevice(device));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+    // game table -> HBM (states repacked to 16 B)
+    std::vector<uint4> packed(game->n_states);
+    for (uint32_t i = 0; i < game->n_states; ++i) {
+        const rp_state& st = game->states[i];
+        packed[i] = make_uint4((uint32_t)st.turn | ((uint32_t)st.n_children << 8), st.info, st.offset, 0u);
+    }
+    CREATE_TRY(hipMalloc(&h->d_states, packed.size() * sizeof(uint4)));
+    CREATE_TRY(hipMemcpy(h->d_states, packed.data(), packed.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc(&h->d_children, h->children.size() * 4));
+    CREATE_TRY(hipMemcpy(h->d_children, h->children.data(), h->children.size() * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc(&h->d_payoffs, h->payoffs.size() * 4));
+    CREATE_TRY(hipMemcpy(h->d_payoffs, h->payoffs.data(), h->payoffs.size() * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc(&h->d_info_actions, game->n_infos));
+    CREATE_TRY(hipMemcpy(h->d_info_actions, h->info_actions.data(), game->n_infos, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc(&h->d_info_player, game->n_infos));
+    CREATE_TRY(hipMemcpy(h->d_info_player, h->info_player.data(), game->n_infos, hipMemcpyHostToDevice));
+    h->g.states = reinterpret_cast<const uint4*>(h->d_states);
+    h->g.children = reinterpret_cast<const uint32_t*>(h->d_children);
+    h->g.payoffs = reinterpret_cast<const float*>(h->d_payoffs);
+    h->g.info_actions = reinterpret_cast<const uint8_t*>(h->d_info_actions);
+    h->g.info_player = reinterpret_cast<const uint8_t*>(h->d_info_player);
+    h->g.n_players = game->n_players;
+    h->g.n_infos = game->n_infos;
+    h->g.A = game->max_actions;
+    h->g.root = game->train_root;
+    // tables: a missing Encounter reads (weight 0, regret default_regret, payoff 0, visits 0) (book.rs:93-122)
+    CREATE_TRY(hipMalloc(&h->t.regret, cells * 4));
+    CREATE_TRY(hipMalloc(&h->t.weight, cells * 4));
+    CREATE_TRY(hipMalloc(&h->t.payoff, cells * 4));
+    CREATE_TRY(hipMalloc(&h->t.visits, cells * 4));
+    CREATE_TRY(hipMemcpy(h->t.regret, h->default_regret.data(), cells * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemset(h->t.weight, 0, cells * 4));
+    CREATE_TRY(hipMemset(h->t.payoff, 0, cells * 4));
+    CREATE_TRY(hipMemset(h->t.visits, 0, cells * 4));
+    CREATE_TRY(hipMalloc(&h->d_counters, 3 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemset(h->d_counters, 0, 3 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(&h->d_summary, summary_bytes_of(h)));
+    uint32_t maxstack = 1;
+    sampled_tree_bounds(h, &h->maxdec, &maxstack);
+    h->sc.maxn = game->max_tree_nodes;
+    h->sc.maxs = maxstack;
+    if (h->maxdec > 254) {
+        rp_mccfr_destroy(h);
+        return rp::fail(RP_ERR_CAPACITY, "rp_mccfr_create: more than 254 walker infosets per tree");
+    }
+    // the update kernel stages UPD_CHUNK Decisions in LDS
+    const size_t lds = update_lds_bytes(game->max_actions);
+    if (lds > 160 * 1024) {
+        rp_mccfr_destroy(h);
+        return rp::fail(RP_ERR_CAPACITY, "rp_mccfr_create: update staging needs %zu B of LDS", lds);
+    }
+    if (lds > 64 * 1024) {
+        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_summarize),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    rc = alloc_batch_buffers(h, batch_size);
+    if (rc) {
+        rp_mccfr_destroy(h);
+        return rc;
+    }
+#undef CREATE_TRY
+    *out = h;
+    return RP_OK;
+}
+
+int rp_mccfr_destroy(rp_mccfr* h) {
+    if (!h) return RP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    clock_drain(h->clk_traverse);
+    clock_drain(h->clk_update);
+    void* ptrs[] = {h->d_states, h->d_children, h->d_payoffs, h->d_info_actions, h->d_info_player, h->d_scratch,
+                    h->d_dec, h->d_summary, h->d_counters, h->t.regret, h->t.weight, h->t.payoff, h->t.visits};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return RP_OK;
+}
+
+int rp_mccfr_step_async(rp_mccfr* h, uint32_t steps) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_mccfr_step_async: NULL handle");
+    int rc = set_device(h);
+    if (rc) return rc;
+    if (h->mode == RP_UPDATE_COMPOSED && (rc = composed_supported(h))) return rc;
+    for (uint32_t i = 0; i < steps; ++i)
+        if ((rc = enqueue_step(h))) return rc;
+    return RP_OK;
+}
+
+int rp_mccfr_sync(rp_mccfr* h) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_mccfr_sync: NULL handle");
+    int rc = set_device(h);
+    if (rc) return rc;
+    rc = check_device_errors(h);
+    clock_drain(h->clk_traverse);
+    clock_drain(h->clk_update);
+    return rc;
+}
+
+int rp_mccfr_step(rp_mccfr* h) {
+    int rc = rp_mccfr_step_async(h, 1);
+    if (rc) return rc;
+    return rp_mccfr_sync(h);
+}
+
+int rp_mccfr_solve(rp_mccfr* h, uint64_t trees) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_mccfr_solve: NULL handle");
+    uint64_t steps = trees / h->batch;
+    while (steps) {  // bounded queue depth; the loop shape of Solver::solve (solver.rs:111-122)
+        const uint32_t n = (uint32_t)std::min<uint64_t>(steps, 256);
+        int rc = rp_mccfr_step_async(h, n);
+        if (rc) return rc;
+        if ((rc = rp_mccfr_sync(h))) return rc;
+        steps -= n;
+    }
+    return RP_OK;
+}
+
+int rp_mccfr_spend(rp_mccfr* h, double seconds, uint64_t* iterations, double* elapsed) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_mccfr_spend: NULL handle");
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t it = 0;
+    double el = 0.0;
+    for (;;) {
+        el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (el >= seconds) break;
+        int rc = rp_mccfr_step(h);
+        if (rc) return rc;
+        it += 1;
+    }
+    if (iterations) *iterations = it;
+    if (elapsed) *elapsed = el;
+    return RP_OK;
+}
+
+int rp_mccfr_epoch(rp_mccfr* h, uint64_t* epoch) {
+    if (!h || !epoch) return rp::fail(RP_ERR_INVALID, "rp_mccfr_epoch: NULL argument");
+    *epoch = h->epoch;
+    return RP_OK;
+}
+
+int rp_mccfr_counters(rp_mccfr* h, uint64_t* nodes, uint64_t* infos) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_mccfr_counters: NULL handle");
+    int rc = set_device(h);
+    if (rc) return rc;
+    unsigned long long c[3];
+    HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (nodes) *nodes = c[0];
+    if (infos) *infos = c[1];
+    return RP_OK;
+}
+
+int rp_mccfr_get(rp_mccfr* h, uint32_t info, uint32_t edge, rp_encounter* out) {
+    if (!h || !out) return rp::fail(RP_ERR_INVALID, "rp_mccfr_get: NULL argument");
+    if (info >= h->tbl.n_infos || edge >= h->info_actions[info]) return rp::fail(RP_ERR_INVALID, "rp_mccfr_get: out of range");
+    int rc = set_device(h);
+    if (rc) return rc;
+    const size_t c = (size_t)info * h->tbl.max_actions + edge;
+    HIP_TRY(hipMemcpyAsync(&out->regret, h->t.regret + c, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&out->weight, h->t.weight + c, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&out->payoff, h->t.payoff + c, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&out->visits, h->t.visits + c, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RP_OK;
+}
+
+int rp_mccfr_set(rp_mccfr* h, uint32_t info, uint32_t edge, const rp_encounter* in) {
+    if (!h || !in) return rp::fail(RP_ERR_INVALID, "rp_mccfr_set: NULL argument");
+    if (info >= h->tbl.n_infos || edge >= h->info_actions[info]) return rp::fail(RP_ERR_INVALID, "rp_mccfr_set: out of range");
+    int rc = set_device(h);
+    if (rc) return rc;
+    const size_t c = (size_t)info * h->tbl.max_actions + edge;
+    HIP_TRY(hipMemcpyAsync(h->t.regret + c, &in->regret, 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->t.weight + c, &in->weight, 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->t.payoff + c, &in->payoff, 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->t.visits + c, &in->visits, 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RP_OK;
+}
+
+int rp_mccfr_export(rp_mccfr* h, rp_encounter* rows, uint64_t cap) {
+    if (!h || !rows) return rp::fail(RP_ERR_INVALID, "rp_mccfr_export: NULL argument");
+    const size_t cells = (size_t)h->tbl.n_infos * h->tbl.max_actions;
+    if (cap < cells) return rp::fail(RP_ERR_INVALID, "rp_mccfr_export: need %zu rows", cells);
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::vector<float> r, w, p;
+    std::vector<uint32_t> v;
+    if ((rc = fetch_tables(h, r, w, p, v))) return rc;
+    for (size_t c = 0; c < cells; ++c) rows[c] = rp_encounter{w[c], r[c], p[c], v[c]};
+    return RP_OK;
+}
+
+int rp_mccfr_import(rp_mccfr* h, const rp_encounter* rows, uint64_t n, uint64_t epoch) {
+    if (!h || !rows) return rp::fail(RP_ERR_INVALID, "rp_mccfr_import: NULL argument");
+    const size_t cells = (size_t)h->tbl.n_infos * h->tbl.max_actions;
+    if (n != cells) return rp::fail(RP_ERR_INVALID, "rp_mccfr_import: expected %zu rows", cells);
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::vector<float> r(cells), w(cells), p(cells);
+    std::vector<uint32_t> v(cells);
+    for (size_t c = 0; c < cells; ++c) {
+        w[c] = rows[c].weight; r[c] = rows[c].regret; p[c] = rows[c].payoff; v[c] = rows[c].visits;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->t.regret, r.data(), cells * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->t.weight, w.data(), cells * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->t.payoff, p.data(), cells * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->t.visits, v.data(), cells * 4, hipMemcpyHostToDevice));
+    h->epoch = epoch;
+    return RP_OK;
+}
+
+int rp_mccfr_policy(rp_mccfr* h, uint32_t info, rp_dist_kind kind, float* out, uint32_t* n) {
+    if (!h || !out) return rp::fail(RP_ERR_INVALID, "rp_mccfr_policy: NULL argument");
+    if (info >= h->tbl.n_infos) return rp::fail(RP_ERR_INVALID, "rp_mccfr_policy: info out of range");
+    int rc = set_device(h);
+    if (rc) return rc;
+    const uint32_t A = h->tbl.max_actions, na = h->info_actions[info];
+    float reg[RP_MAX_ACTIONS], wgt[RP_MAX_ACTIONS];
+    HIP_TRY(hipMemcpyAsync(reg, h->t.regret + (size_t)info * A, na * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(wgt, h->t.weight + (size_t)info * A, na * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (kind == RP_DIST_ITERATED) {  // profile.rs:47-51
+        float denom = 0.0f;
+        for (uint32_t a = 0; a < na; ++a) denom += rp_maxf(reg[a], RP_EPSILON);
+        for (uint32_t a = 0; a < na; ++a) out[a] = rp_maxf(reg[a], RP_EPSILON) / denom;
+    } else if (kind == RP_DIST_AVERAGED) {  // profile.rs:40-44
+        float sum = 0.0f;
+        for (uint32_t a = 0; a < na; ++a) sum += rp_maxf(wgt[a], RP_EPSILON);
+        for (uint32_t a = 0; a < na; ++a) out[a] = rp_maxf(wgt[a], RP_EPSILON) / sum;
+    } else if (kind == RP_DIST_SAMPLING) {  // flow.rs:33-42
+        float denom = 0.0f;
+        for (uint32_t a = 0; a < na; ++a) denom += rp_maxf(wgt[a], RP_EPSILON);
+        denom = denom + h->hp.smoothing;
+        float raw[RP_MAX_ACTIONS], z = 0.0f;
+        for (uint32_t a = 0; a < na; ++a) {
+            raw[a] = rp_maxf((rp_maxf(wgt[a], RP_EPSILON) / h->hp.temperature + h->hp.smoothing) / denom, h->hp.curiosity);
+            z += raw[a];
+        }
+        for (uint32_t a = 0; a < na; ++a) out[a] = raw[a] / z;
+    } else {
+        return rp::fail(RP_ERR_INVALID, "rp_mccfr_policy: unknown distribution kind");
+    }
+    if (n) *n = na;
+    return RP_OK;
+}
+
+int rp_mccfr_sum_regret(rp_mccfr* h, float* out) {
+    if (!h || !out) return rp::fail(RP_ERR_INVALID, "rp_mccfr_sum_regret: NULL argument");
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::vector<float> r, w, p;
+    std::vector<uint32_t> v;
+    if ((rc = fetch_tables(h, r, w, p, v))) return rc;
+    float s = 0.0f;
+    for (uint32_t info = 0; info < h->tbl.n_infos; ++info)
+        for (uint32_t a = 0; a < h->info_actions[info]; ++a) s += rp_maxf(r[(size_t)info * h->tbl.max_actions + a], 0.0f);
+    *out = s / (float)(h->epoch > 1 ? h->epoch : 1);
+    return RP_OK;
+}
+
+int rp_mccfr_set_batch(rp_mccfr* h, uint32_t batch_size) {
+    if (!h || batch_size == 0) return rp::fail(RP_ERR_INVALID, "rp_mccfr_set_batch: bad argument");
+    int rc = set_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if ((rc = alloc_batch_buffers(h, batch_size))) return rc;
+    h->batch = batch_size;
+    return RP_OK;
+}
+
+int rp_mccfr_set_update_mode(rp_mccfr* h, rp_update_mode mode) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_mccfr_set_update_mode: NULL handle");
+    if (mode != RP_UPDATE_ORDERED && mode != RP_UPDATE_COMPOSED) return rp::fail(RP_ERR_INVALID, "unknown update mode");
+    h->mode = mode;
+    return RP_OK;
+}
+
+int rp_mccfr_set_stream(rp_mccfr* h, void* hip_stream) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_mccfr_set_stream: NULL handle");
+    int rc = set_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->own_stream) {
+        HIP_TRY(hipStreamDestroy(h->stream));
+        h->own_stream = false;
+    }
+    if (hip_stream) {
+        h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    return RP_OK;
+}
+
+int rp_mccfr_set_shard(rp_mccfr* h, uint32_t rank, uint32_t world) {
+    if (!h || world == 0 || rank >= world) return rp::fail(RP_ERR_INVALID, "rp_mccfr_set_shard: bad rank/world");
+    h->rank = rank;
+    h->world = world;
+    return RP_OK;
+}
+
+int rp_mccfr_summary_bytes(rp_mccfr* h, size_t* bytes) {
+    if (!h || !bytes) return rp::fail(RP_ERR_INVALID, "rp_mccfr_summary_bytes: NULL argument");
+    *bytes = summary_bytes_of(h);
+    return RP_OK;
+}
+
+int rp_mccfr_step_local(rp_mccfr* h, void* summary_dev) {
+    if (!h || !summary_dev) return rp::fail(RP_ERR_INVALID, "rp_mccfr_step_local: NULL argument");
+    int rc = set_device(h);
+    if (rc) return rc;
+    if ((rc = composed_supported(h))) return rc;
+    const StepParams p = make_params(h);
+    if ((rc = launch_traverse(h, p))) return rc;
+    unsigned char* blob = reinterpret_cast<unsigned char*>(summary_dev);
+    Cell* cells = reinterpret_cast<Cell*>(blob);
+    InfoSum* sums = reinterpret_cast<InfoSum*>(blob + (size_t)h->tbl.n_infos * h->tbl.max_actions * sizeof(Cell));
+    clock_begin(h, h->clk_update);
+    hipLaunchKernelGGL(k_summarize, dim3(h->tbl.n_infos), dim3(UPD_THREADS), update_lds_bytes(h->tbl.max_actions),
+                       h->stream, h->g, h->dc, p, cells, sums);
+    clock_end(h, h->clk_update);
+    HIP_TRY(hipGetLastError());
+    return RP_OK;
+}
+
+int rp_mccfr_step_apply(rp_mccfr* h, const void* gathered_dev, uint32_t world) {
+    if (!h || !gathered_dev || world == 0) return rp::fail(RP_ERR_INVALID, "rp_mccfr_step_apply: bad argument");
+    int rc = set_device(h);
+    if (rc) return rc;
+    const uint32_t ncell = h->tbl.n_infos * h->tbl.max_actions;
+    hipLaunchKernelGGL(k_fold, dim3((ncell + 255) / 256), dim3(256), 0, h->stream, h->g, h->t,
+                       reinterpret_cast<const unsigned char*>(gathered_dev), summary_bytes_of(h), world);
+    HIP_TRY(hipGetLastError());
+    h->epoch += 1;
+    return RP_OK;
+}
+
+int rp_mccfr_profile(rp_mccfr* h, int enable) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_mccfr_profile: NULL handle");
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    clock_drain(h->clk_traverse);
+    clock_drain(h->clk_update);
+    h->profiling = enable != 0;
+    h->clk_traverse.total_ms = h->clk_update.total_ms = 0.0;
+    h->clk_traverse.launches = h->clk_update.launches = 0;
+    return RP_OK;
+}
+
+int rp_mccfr_kernel_time(rp_mccfr* h, const char* name, double* total_ms, uint64_t* launches) {
+    if (!h || !name) return rp::fail(RP_ERR_INVALID, "rp_mccfr_kernel_time: NULL argument");
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    clock_drain(h->clk_traverse);
+    clock_drain(h->clk_update);
+    const KernelClock* c = nullptr;
+    if (std::string(name) == "traverse") c = &h->clk_traverse;
+    else if (std::string(name) == "update") c = &h->clk_update;
+    else return rp::fail(RP_ERR_INVALID, "rp_mccfr_kernel_time: unknown kernel '%s'", name);
+    if (total_ms) *total_ms = c->total_ms;
+    if (launches) *launches = c->launches;
+    return RP_OK;
+}
+
+// ---- Solver::exploitability (solver.rs:327-337) on the host: validation, not the hot path -------------
+// Full-tree best response exactly as CfrNash does it (nash.rs:31-38,103-194): per-infoset argmax of
+// sum_{n in span} external_reach * average-strategy value, then evaluation with those choices.
+namespace {
+struct XNode {
+    uint32_t state;
+    int32_t parent, edge;
+    int32_t kids[RP_MAX_ACTIONS];
+};
+struct XCtx {
+    const rp_mccfr* h;
+    const float* weight;
+    std::vector<XNode> nodes;
+    float wt(uint32_t info, uint32_t a) const { return rp_maxf(weight[(size_t)info * h->tbl.max_actions + a], RP_EPSILON); }
+    float averaged(uint32_t info, uint32_t a) const {
+        float sum = 0.0f;
+        for (uint32_t k = 0; k < h->info_actions[info]; ++k) sum += wt(info, k);
+        return wt(info, a) / sum;
+    }
+    float value(int32_t n, uint32_t hero, const int32_t* br) const {
+        const XNode& nd = nodes[n];
+        const rp_state& st = h->states[nd.state];
+        if (st.n_children == 0) return h->payoffs[(size_t)st.offset * h->tbl.n_players + hero];
+        if (st.turn == RP_TURN_CHANCE) {
+            float s = 0.0f;
+            for (uint32_t k = 0; k < st.n_children; ++k) s += value(nd.kids[k], hero, br);
+            return s / (float)st.n_children;
+        }
+        if (st.turn == hero && br) return value(nd.kids[br[st.info]], hero, br);
+        float s = 0.0f;
+        for (uint32_t k = 0; k < st.n_children; ++k) s += averaged(st.info, k) * value(nd.kids[k], hero, br);
+        return s;
+    }
+    float reach(int32_t n, uint32_t hero) const {
+        float p = 1.0f;
+        const XNode* nd = &nodes[n];
+        while (nd->parent >= 0) {
+            const XNode& par = nodes[nd->parent];
+            const rp_state& ps = h->states[par.state];
+            if (ps.turn != RP_TURN_CHANCE && ps.turn != hero) p = p * averaged(ps.info, (uint32_t)nd->edge);
+            nd = &par;
+        }
+        return p;
+    }
+};
+}  // namespace
+
+int rp_mccfr_exploitability(rp_mccfr* h, float* out) {
+    if (!h || !out) return rp::fail(RP_ERR_INVALID, "rp_mccfr_exploitability: NULL argument");
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::vector<float> r, w, p;
+    std::vector<uint32_t> v;
+    if ((rc = fetch_tables(h, r, w, p, v))) return rc;
+    XCtx x{h, w.data(), {}};
+    // VanillaSampling tree in TreeBuilder's pop-last order (builder.rs:141-161) so spans ascend like the reference's
+    struct Leaf { uint32_t state; int32_t parent, edge; };
+    std::vector<Leaf> todo;
+    auto push = [&](uint32_t state, int32_t parent, int32_t edge) {
+        XNode nd{state, parent, edge, {}};
+        for (auto& k : nd.kids) k = -1;
+        x.nodes.push_back(nd);
+        const int32_t me = (int32_t)x.nodes.size() - 1;
+        if (parent >= 0) x.nodes[parent].kids[edge] = me;
+        const rp_state& st = h->states[state];
+        for (uint32_t k = 0; k < st.n_children; ++k) todo.push_back(Leaf{h->children[st.offset + k], me, (int32_t)k});
+    };
+    push(h->tbl.exploit_root, -1, -1);
+    while (!todo.empty()) {
+        Leaf lf = todo.back();
+        todo.pop_back();
+        push(lf.state, lf.parent, lf.edge);
+    }
+    std::vector<int32_t> br(h->tbl.n_infos, 0);
+    std::vector<float> cfv((size_t)h->tbl.n_infos * RP_MAX_ACTIONS);
+    float total = 0.0f;
+    for (uint32_t hero = 0; hero < h->tbl.n_players; ++hero) {
+        std::fill(cfv.begin(), cfv.end(), 0.0f);
+        for (size_t i = 0; i < x.nodes.size(); ++i) {
+            const XNode& nd = x.nodes[i];
+            const rp_state& st = h->states[nd.state];
+            if (st.turn != hero || st.n_children == 0) continue;
+            for (uint32_t a = 0; a < st.n_children; ++a) {
+                const int32_t c = nd.kids[a];
+                cfv[(size_t)st.info * RP_MAX_ACTIONS + a] += x.reach(c, hero) * x.value(c, hero, nullptr);
+            }
+        }
+        for (uint32_t info = 0; info < h->tbl.n_infos; ++info) {
+            br[info] = 0;
+            if (h->info_player[info] != hero) continue;
+            float best = cfv[(size_t)info * RP_MAX_ACTIONS];
+            for (uint32_t a = 1; a < h->info_actions[info]; ++a)
+                if (cfv[(size_t)info * RP_MAX_ACTIONS + a] >= best) {  // max_by keeps the last maximum (nash.rs:184-193)
+                    best = cfv[(size_t)info * RP_MAX_ACTIONS + a];
+                    br[info] = (int32_t)a;
+                }
+        }
+        total += x.value(0, hero, br.data());
+    }
+    *out = total / (float)h->tbl.n_players;
+    return RP_OK;
+}
+
+}  // extern "C"

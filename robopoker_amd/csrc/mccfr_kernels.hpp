@@ -1,0 +1,96 @@
+// mccfr_kernels.hpp — device-side data layout shared by mccfr.hip's kernels and host code.
+#ifndef RP_MCCFR_KERNELS_HPP
+#define RP_MCCFR_KERNELS_HPP
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/rp_math.h"
+#include "rp_internal.h"
+
+namespace rp {
+
+// rp_state repacked to one 16-byte load: x = turn | n_children << 8, y = info, z = offset
+struct DevGame {
+    const uint4* states;
+    const uint32_t* children;
+    const float* payoffs;         // [n_terminals][n_players]
+    const uint8_t* info_actions;  // [n_infos]
+    const uint8_t* info_player;   // [n_infos]
+    uint32_t n_players;
+    uint32_t n_infos;
+    uint32_t A;                   // table row stride (max_actions)
+    uint32_t root;                // train_root
+};
+
+// regret/strategy tables, SoA by field, row-major [info][A] (Encounter, solver/encounter.rs:22-27)
+struct DevTables {
+    float* regret;
+    float* weight;
+    float* payoff;
+    uint32_t* visits;
+};
+
+// per-tree scratch, lane-interleaved: element (slot, tree) lives at base[slot * stride + tree] so the
+// 64 lanes of a wave (64 consecutive trees) touch 64 consecutive dwords
+struct DevScratch {
+    uint32_t* n_meta;  // parent | edge << 8 | ptype << 16 | leaf << 18 | walker << 19 | nact << 24
+    uint32_t* n_info;
+    float* n_frel;
+    float* n_fsmp;
+    float* n_pay;
+    float* n_rel;
+    float* n_smp;
+    float* n_acc;
+    uint32_t* s_state;  // leaf stack (TreeBuilder::todo, builder.rs:54)
+    uint32_t* s_meta;   // parent | edge << 8 | ptype << 16
+    float* s_frel;
+    float* s_fsmp;
+    float* t_v;         // [A] action values of the span root being evaluated
+    size_t stride;
+    uint32_t maxn;      // node capacity per tree
+    uint32_t maxs;      // stack capacity per tree
+};
+
+// Decisions of one batch (solver/decisions.rs:23-32), slot-major and lane-interleaved like the scratch
+struct DevDecisions {
+    uint32_t* info;     // [maxdec][stride]   0xffffffff = empty slot
+    uint32_t* mask;     // [maxdec][stride]   edges present in the regret vector
+    float* payoff;      // [maxdec][stride]
+    float* regret;      // [maxdec][A][stride]
+    float* policy;      // [maxdec][A][stride]
+    uint8_t* slotmap;   // [n_infos][stride]  slot + 1 of the tree's Decisions for that infoset, 0 = none
+    size_t stride;
+    uint32_t maxdec;
+};
+
+struct StepParams {
+    uint64_t seed;
+    uint64_t epoch;
+    uint64_t tree_base;  // first tree id of this shard (rank * batch)
+    uint32_t batch;
+    uint32_t walker;
+    int R, W, S;
+    float temperature, smoothing, curiosity;
+    float prune_threshold, prune_explore;
+    uint64_t prune_warmup;
+    float regret_min;
+    unsigned long long* counters;  // [0] nodes, [1] infos, [2] error flags
+};
+
+// per-cell composed map of the multi-GPU exchange (rp_mccfr_step_local / step_apply)
+struct Cell {
+    float ra, rb, rm;
+    float wa, wb, wm;
+    uint32_t rn, wn;
+};
+struct InfoSum {
+    uint32_t count;
+    float psum;
+};
+
+enum : uint32_t { PT_CHANCE = 0, PT_WALKER = 1, PT_OPP = 2, PT_NONE = 3 };
+enum : uint32_t { ERR_NODE_CAPACITY = 1u, ERR_STACK_CAPACITY = 2u, ERR_DEC_CAPACITY = 4u };
+
+}  // namespace rp
+
+#endif

@@ -1,31 +1,6 @@
 // TEMPORARY stubs (replaced as the device paths land)
 #include "rp_internal.h"
 extern "C" {
-int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind w, rp_sampling_kind s, uint32_t batch_size, const rp_hyper* hp, uint64_t seed, int device, rp_mccfr** out) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_create: not implemented yet"); }
-int rp_mccfr_destroy(rp_mccfr* h) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_destroy: not implemented yet"); }
-int rp_mccfr_step(rp_mccfr* h) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_step: not implemented yet"); }
-int rp_mccfr_solve(rp_mccfr* h, uint64_t trees) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_solve: not implemented yet"); }
-int rp_mccfr_spend(rp_mccfr* h, double seconds, uint64_t* iterations, double* elapsed) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_spend: not implemented yet"); }
-int rp_mccfr_step_async(rp_mccfr* h, uint32_t steps) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_step_async: not implemented yet"); }
-int rp_mccfr_sync(rp_mccfr* h) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_sync: not implemented yet"); }
-int rp_mccfr_epoch(rp_mccfr* h, uint64_t* epoch) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_epoch: not implemented yet"); }
-int rp_mccfr_counters(rp_mccfr* h, uint64_t* nodes, uint64_t* infos) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_counters: not implemented yet"); }
-int rp_mccfr_get(rp_mccfr* h, uint32_t info, uint32_t edge, rp_encounter* out) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_get: not implemented yet"); }
-int rp_mccfr_set(rp_mccfr* h, uint32_t info, uint32_t edge, const rp_encounter* in) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_set: not implemented yet"); }
-int rp_mccfr_export(rp_mccfr* h, rp_encounter* rows, uint64_t cap) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_export: not implemented yet"); }
-int rp_mccfr_import(rp_mccfr* h, const rp_encounter* rows, uint64_t n, uint64_t epoch) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_import: not implemented yet"); }
-int rp_mccfr_policy(rp_mccfr* h, uint32_t info, rp_dist_kind kind, float* out, uint32_t* n) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_policy: not implemented yet"); }
-int rp_mccfr_exploitability(rp_mccfr* h, float* out) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_exploitability: not implemented yet"); }
-int rp_mccfr_sum_regret(rp_mccfr* h, float* out) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_sum_regret: not implemented yet"); }
-int rp_mccfr_set_batch(rp_mccfr* h, uint32_t batch_size) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_set_batch: not implemented yet"); }
-int rp_mccfr_set_update_mode(rp_mccfr* h, rp_update_mode mode) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_set_update_mode: not implemented yet"); }
-int rp_mccfr_set_stream(rp_mccfr* h, void* hip_stream) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_set_stream: not implemented yet"); }
-int rp_mccfr_set_shard(rp_mccfr* h, uint32_t rank, uint32_t world) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_set_shard: not implemented yet"); }
-int rp_mccfr_summary_bytes(rp_mccfr* h, size_t* bytes) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_summary_bytes: not implemented yet"); }
-int rp_mccfr_step_local(rp_mccfr* h, void* summary_dev) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_step_local: not implemented yet"); }
-int rp_mccfr_step_apply(rp_mccfr* h, const void* gathered_dev, uint32_t world) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_step_apply: not implemented yet"); }
-int rp_mccfr_profile(rp_mccfr* h, int enable) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_profile: not implemented yet"); }
-int rp_mccfr_kernel_time(rp_mccfr* h, const char* name, double* total_ms, uint64_t* launches) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_mccfr_kernel_time: not implemented yet"); }
 int rp_kmeans_create(uint32_t K, uint64_t N, uint32_t bins, const uint8_t* counts, rp_metric_kind kind, const float* tri_metric, const rp_sinkhorn_hp* hp, uint64_t seed, int device, rp_kmeans** out) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_kmeans_create: not implemented yet"); }
 int rp_kmeans_create_device(uint32_t K, uint64_t N, uint32_t bins, const void* counts_dev, rp_metric_kind kind, const float* tri_metric, const rp_sinkhorn_hp* hp, uint64_t seed, int device, rp_kmeans** out) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_kmeans_create_device: not implemented yet"); }
 int rp_kmeans_destroy(rp_kmeans* h) { return rp::fail(RP_ERR_UNSUPPORTED, "rp_kmeans_destroy: not implemented yet"); }

@@ -1,0 +1,153 @@
+"""GPU parity: the HIP MCCFR path (through the C-ABI) against the CPU oracle — bit-exact.
+
+The ordered update applies every touch of a table cell sequentially in tree-id order, so the regret /
+weight / payoff / visit tables must be IDENTICAL to the oracle's, not merely close.  Parity at
+BASELINE's full batch is covered through size-independent properties (visit conservation, determinism,
+convergence thresholds of the reference's own tests).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from robopoker_amd import Game, _lib
+from robopoker_amd.mccfr import Solver
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_tables_equal(a: np.ndarray, b: np.ndarray):
+    for f in ("visits", "regret", "weight", "payoff"):
+        assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), f"{f} differs bitwise"
+
+
+def test_arithmetic_contract_on_device(gpu):
+    # rp_math.h primitives, IEEE division / sqrt / fma and u32->f32 conversion: device == host, bit for bit
+    rng = np.random.default_rng(0)
+    n = 1 << 18
+    x = np.concatenate([rng.uniform(-90, 90, n // 2), rng.standard_normal(n // 4) * 1e-3,
+                        np.exp(rng.uniform(-80, 80, n // 4))]).astype(np.float32)
+    y = np.concatenate([rng.uniform(-5, 5, n // 2), np.exp(rng.uniform(-60, 60, n // 2))]).astype(np.float32)
+    y[y == 0] = 1.0
+    dev = np.zeros(6 * n, dtype=np.float32)
+    _lib.check(_lib.load().rp_math_selftest(0, n, x.ctypes.data, y.ctypes.data, dev.ctypes.data))
+    host = np.zeros(6 * n, dtype=np.float32)
+    o = oracle.load()
+    o.ora_math_selftest.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    o.ora_math_selftest(n, x.ctypes.data, y.ctypes.data, host.ctypes.data)
+    names = ["expf", "logf", "div", "sqrt", "fma", "u32->f32"]
+    for k, nm in enumerate(names):
+        d, h = dev[k * n:(k + 1) * n].view(np.uint32), host[k * n:(k + 1) * n].view(np.uint32)
+        assert np.array_equal(d, h), f"{nm}: {np.count_nonzero(d != h)} of {n} differ"
+
+
+@pytest.mark.parametrize("game", ["kuhn", "leduc", "rps"])
+@pytest.mark.parametrize("regret,weight,sampling", [
+    ("floored", "linear", "external"), ("linear", "linear", "pluribus"), ("summed", "constant", "external"),
+    ("discounted", "quadratic", "prunable"), ("asymmetric", "exponential", "external")])
+def test_tables_bit_exact_vs_oracle(gpu, game, regret, weight, sampling):
+    g = Game(game)
+    hp = oracle.default_hyper()
+    hp.prune_warmup = 3          # let Pluribus pruning engage inside the test
+    hp.prune_threshold = -2.0
+    B, steps = 333, 12           # ragged batch: not a multiple of the wave / chunk sizes
+    dev = Solver(g, regret, weight, sampling, batch=B, seed=42, hyper=hp)
+    ora = oracle.OracleSolver(g, regret, weight, sampling, batch=B, seed=42, hyper=hp)
+    for s in range(steps):
+        dev.step()
+        ora.step()
+        assert_tables_equal(dev.export(), ora.export())
+    assert dev.epoch == ora.epoch == steps
+    assert dev.counters() == ora.counters()
+    assert dev.exploitability() == ora.exploitability()
+    assert dev.sum_regret() == ora.sum_regret()
+    for info in range(g.n_infos):
+        for kind in ("iterated", "averaged", "sampling"):
+            assert np.array_equal(dev.policy(info, kind), ora.policy(info, kind))
+
+
+@pytest.mark.parametrize("batch", [1, 63, 64, 65, 1024, 1025, 5000])
+def test_batch_size_edges(gpu, batch):
+    g = Game("leduc")
+    dev = Solver(g, "linear", "linear", "external", batch=batch, seed=7)
+    ora = oracle.OracleSolver(g, "linear", "linear", "external", batch=batch, seed=7)
+    for _ in range(3):
+        dev.step()
+        ora.step()
+    assert_tables_equal(dev.export(), ora.export())
+
+
+def test_import_export_roundtrip_and_resume(gpu):
+    g = Game("kuhn")
+    a = Solver(g, "floored", "linear", "external", batch=128, seed=3)
+    a.solve(128 * 20)
+    rows, epoch = a.export(), a.epoch
+    b = Solver(g, "floored", "linear", "external", batch=128, seed=3)
+    b.load_rows(rows, epoch)          # Flagship::hydrate shape (nlhe/src/profile.rs:97-140)
+    assert_tables_equal(b.export(), rows)
+    a.solve(128 * 5)
+    b.solve(128 * 5)
+    assert_tables_equal(a.export(), b.export())
+    e = a.get(g.info_id("K|B"), 1)
+    assert e.visits == rows["visits"][g.info_id("K|B") * 2 + 1] + (a.export()["visits"] - rows["visits"])[g.info_id("K|B") * 2 + 1]
+
+
+def test_composed_mode_matches_oracle_world_semantics(gpu):
+    # single-GPU composed update == the oracle's model of the multi-GPU exchange with world = 1, bit for bit
+    g = Game("leduc")
+    dev = Solver(g, "linear", "linear", "external", batch=777, seed=11)
+    dev.set_update_mode("composed")
+    ora = oracle.OracleSolver(g, "linear", "linear", "external", batch=777, seed=11)
+    for _ in range(6):
+        dev.step()
+        ora.step_world(1)
+        assert_tables_equal(dev.export(), ora.export())
+
+
+def test_composed_mode_rejects_sign_dependent_discount(gpu):
+    g = Game("kuhn")
+    dev = Solver(g, "discounted", "linear", "external", batch=64, seed=1)
+    dev.set_update_mode("composed")
+    with pytest.raises(_lib.RpError) as ei:
+        dev.step()
+    assert ei.value.code == _lib.RP_ERR_UNSUPPORTED
+
+
+def test_full_batch_properties(gpu):
+    # BASELINE config 2 at the bench batch: visit conservation and determinism are size independent
+    g = Game("leduc")
+    B = 1 << 16
+    a = Solver(g, "floored", "linear", "external", batch=B, seed=5)
+    b = Solver(g, "floored", "linear", "external", batch=B, seed=5)
+    for _ in range(4):
+        a.step()
+        b.step()
+    ra, rb = a.export(), b.export()
+    assert_tables_equal(ra, rb)
+    nodes, infos = a.counters()
+    # every Decisions increments the visits of each of its infoset's 2 edges once (solver.rs:187-192)
+    assert int(ra["visits"].sum()) == 2 * infos
+    roots = [g.info_id(n) for n in ("J|", "Q|", "K|")]
+    # walker alternates (book.rs:142-144): P0's root infosets are visited by every tree of epochs 0 and 2
+    assert sum(int(ra["visits"][i * 2]) for i in roots) == 2 * B
+    assert np.isfinite(ra["regret"]).all() and np.isfinite(ra["weight"]).all()
+
+
+def test_leduc_converges_like_the_reference(gpu):
+    # crates/leduc/src/solver.rs:105-123 threshold with a GPU-sized batch (epoch-stale regrets, as NLHE's 128)
+    g = Game("leduc")
+    dev = Solver(g, "floored", "linear", "external", batch=4096, seed=18)
+    dev.solve(4096 * 1024)
+    assert dev.exploitability() < 0.080
+
+
+def test_kuhn_nash_on_device(gpu):
+    g = Game("kuhn")
+    dev = Solver(g, "floored", "linear", "external", batch=1024, seed=7)
+    dev.solve(1024 * 2048)
+    pol = lambda name, a: float(dev.policy(g.info_id(name), "averaged")[a])  # noqa: E731
+    assert dev.exploitability() < 0.020
+    assert pol("J|B", 0) > 0.95 and pol("K|B", 1) > 0.95 and pol("K|X", 1) > 0.95
+    assert abs(pol("J|", 1) - 9 / 31) < 0.05 and abs(pol("K|", 1) - 27 / 31) < 0.05
+    assert abs(pol("Q|XB", 1) - 23 / 31) < 0.05 and abs(pol("J|X", 1) - 9 / 31) < 0.05
