@@ -1,0 +1,1392 @@
+// lloyd.hip — Elkan k-means over Sinkhorn EMD / equity variation on MI355X (gfx950): kernels + rp_kmeans_* ABI.
+//
+// Reference path: crates/elkan (Elkan<K,N>::{init_bounds, neighbor, pairwises, step_elkan, step_naive}),
+// crates/lloyd (Layer, Kmeans, Sinkhorn, Metric::emd, Equity::variation).  MI355X mapping:
+//
+//   one WAVEFRONT per (point) work item.  A Sinkhorn solve (sinkhorn.rs:77-92) is wave-cooperative:
+//   lane i owns support row i and walks the other support sequentially, so every softmin sum is the
+//   reference's left fold in ascending bin order — bit-exact with the CPU oracle — and needs no cross-lane
+//   reduction.  Potentials, supports and log-densities live in 6 KB of LDS per wave; the ground cost C and
+//   C/T (bins x bins f32, 2 x 256 KB) are L2-resident and read row-wise (coalesced or in-row gathers).
+//   Elkan's candidate loop (elkan.rs:153-168) keeps its sequential semantics per point: the wave evaluates
+//   has_shifted() for all K centroids at once (ballot), solves the first hit, re-tests with the updated (j,u).
+//   Centroids are exact integer sums (bins.rs:75-82): order-free, so recompute() is a parallel reduction.
+//
+// Everything f32 is spelled with the primitives of include/rp_math.h and compiled -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/rp_math.h"
+#include "rp_internal.h"
+
+namespace rp {
+
+#define HIP_TRY(expr)                                                                                 \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return rp::fail(RP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define MAXB 256  // bins and K are both <= 256 (Abstraction index is 8 bits, kicker/src/abstraction.rs:22-23)
+
+struct Metric {
+    const float* Cm;  // [bins][bins] raw_distance (0 on the diagonal)          metric.rs:41-55
+    const float* Rt;  // [bins][bins] raw_distance / temperature                sinkhorn.rs:129-131
+    uint32_t bins;
+    uint32_t iters;
+    float tol;
+    unsigned long long* stats;  // [0] distances, [1] sinkhorn iterations
+};
+
+// one prepared centroid set: integer sums + the derived support / log-density tables
+struct CentroidSet {
+    uint32_t* counts;  // [K][bins]
+    uint32_t* weight;  // [K]
+    uint32_t* n;       // [K]  support size
+    uint16_t* sup;     // [K][MAXB] support bins ascending
+    float* lnd;        // [K][MAXB] ln(density) on the support
+    float* dens;       // [bins][K] density, transposed (variation path)
+    float* self;       // [K] OT(c,c)
+};
+
+struct Points {
+    const uint8_t* counts;  // [N][stride]
+    const uint32_t* weight; // [N]
+    const float* self;      // [N] OT(p,p)
+    uint32_t stride;
+    uint64_t N;
+};
+
+struct WaveLds {
+    uint16_t supA[MAXB];
+    uint16_t supB[MAXB];
+    float lnA[MAXB];
+    float lnB[MAXB];
+    float f[MAXB];
+    float g[MAXB];
+    float tmp[MAXB];
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Bins::support + Bins::density (bins.rs:58-60,84-88) of a dense histogram into LDS; returns the support size
+template <typename CT>
+__device__ uint32_t wave_load_hist(const CT* counts, uint32_t weight, uint32_t bins, uint16_t* sup, float* lnd) {
+    const uint32_t lane = lane_id();
+    const float fw = (float)weight;
+    uint32_t base = 0;
+    for (uint32_t q = 0; q * 64 < bins; ++q) {
+        const uint32_t b = q * 64 + lane;
+        const uint32_t c = b < bins ? (uint32_t)counts[b] : 0u;
+        const bool has = c > 0;
+        const unsigned long long mask = __ballot(has);
+        if (has) {
+            const uint32_t r = base + __popcll(mask & ((1ull << lane) - 1ull));
+            sup[r] = (uint16_t)b;
+            lnd[r] = rp_logf((float)c / fw);
+        }
+        base += __popcll(mask);
+    }
+    __syncthreads();
+    return base;
+}
+
+__device__ uint32_t wave_load_centroid(const CentroidSet& cs, uint32_t k, uint16_t* sup, float* lnd) {
+    const uint32_t n = cs.n[k];
+    for (uint32_t i = lane_id(); i < n; i += 64) {
+        sup[i] = cs.sup[(size_t)k * MAXB + i];
+        lnd[i] = cs.lnd[(size_t)k * MAXB + i];
+    }
+    __syncthreads();
+    return n;
+}
+
+// Sinkhorn::from(mu, nu, metric).minimize().cost() (sinkhorn.rs:77-92,194-230).  A = mu, B = nu, supports and
+// log-densities already in LDS.  All 64 lanes return the same value.
+__device__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint32_t n, const Metric& M) {
+    const uint32_t lane = lane_id();
+    if (m == 0 || n == 0) return 0.0f;  // empty support: the cost sum is empty
+    const uint32_t bins = M.bins;
+    const float lu = rp_logf(1.0f / (float)m), ru = rp_logf(1.0f / (float)n);  // Potential::uniform (phi.rs:34-39)
+    for (uint32_t i = lane; i < m; i += 64) w.f[i] = lu;
+    for (uint32_t j = lane; j < n; j += 64) w.g[j] = ru;
+    __syncthreads();
+    uint32_t t = 0;
+    for (; t < M.iters; ++t) {
+        // lhs(): f(x) <- ln mu(x) - ln sum_y max(exp(g(y) - C(x,y)/T), MIN_POSITIVE)   (sinkhorn.rs:94-102,119-128)
+        for (uint32_t i0 = 0; i0 < m; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool act = i < m;
+            const uint32_t x = act ? w.supA[i] : w.supA[0];
+            float s = 0.0f;
+            for (uint32_t j = 0; j < n; ++j) {
+                const uint32_t y = w.supB[j];
+                const float e = rp_expf(w.g[j] - M.Rt[y * bins + x]);
+                s += rp_maxf(e, RP_EPSILON);
+            }
+            if (act) {
+                const float nf = w.lnA[i] - rp_logf(s);
+                w.tmp[i] = rp_absf(rp_expf(nf) - rp_expf(w.f[i]));  // delta term (sinkhorn.rs:134-139)
+                w.f[i] = nf;
+            }
+        }
+        __syncthreads();
+        float lhs_err = 0.0f;
+        for (uint32_t i = 0; i < m; ++i) lhs_err += w.tmp[i];
+        __syncthreads();
+        // rhs(): sees the fresh lhs (Gauss-Seidel, sinkhorn.rs:80-87)
+        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            const bool act = j < n;
+            const uint32_t y = act ? w.supB[j] : w.supB[0];
+            float s = 0.0f;
+            for (uint32_t i = 0; i < m; ++i) {
+                const uint32_t x = w.supA[i];
+                const float e = rp_expf(w.f[i] - M.Rt[x * bins + y]);
+                s += rp_maxf(e, RP_EPSILON);
+            }
+            if (act) {
+                const float ng = w.lnB[j] - rp_logf(s);
+                w.tmp[j] = rp_absf(rp_expf(ng) - rp_expf(w.g[j]));
+                w.g[j] = ng;
+            }
+        }
+        __syncthreads();
+        float rhs_err = 0.0f;
+        for (uint32_t j = 0; j < n; ++j) rhs_err += w.tmp[j];
+        __syncthreads();
+        if (lhs_err + rhs_err < M.tol) {
+            t += 1;
+            break;
+        }
+    }
+    if (lane == 0) atomicAdd(&M.stats[1], (unsigned long long)t);
+    // cost(): x-major left fold of coupling * distance (sinkhorn.rs:206-217)
+    float cost = 0.0f;
+    for (uint32_t i = 0; i < m; ++i) {
+        const uint32_t x = w.supA[i];
+        const float fi = w.f[i];
+        for (uint32_t j = lane; j < n; j += 64) {
+            const uint32_t y = w.supB[j];
+            const float c = M.Cm[x * bins + y];
+            w.tmp[j] = rp_expf(fi + w.g[j] - M.Rt[x * bins + y]) * c;
+        }
+        __syncthreads();
+        for (uint32_t j = 0; j < n; ++j) cost += w.tmp[j];
+        __syncthreads();
+    }
+    return cost;
+}
+
+// Sinkhorn::divergence (sinkhorn.rs:166-171) with memoised self terms
+__device__ __forceinline__ float wave_divergence(WaveLds& w, uint32_t m, uint32_t n, float selfA, float selfB,
+                                                 const Metric& M) {
+    const float xy = wave_sinkhorn_cost(w, m, n, M);
+    if (lane_id() == 0) atomicAdd(&M.stats[0], 1ull);
+    return rp_maxf(xy - 0.5f * selfA - 0.5f * selfB, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// histogram preparation
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_point_weights(const uint8_t* counts, uint32_t stride, uint32_t bins, uint64_t N,
+                                                      uint32_t* weight) {
+    const uint64_t i = blockIdx.x;
+    if (i >= N) return;
+    uint32_t s = 0;
+    for (uint32_t b = lane_id(); b < bins; b += 64) s += counts[i * stride + b];
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane_id() == 0) weight[i] = s;
+}
+
+__global__ __launch_bounds__(64) void k_point_self(Points P, Metric M, float* self_out) {
+    __shared__ WaveLds w;
+    const uint64_t i = blockIdx.x;
+    const uint32_t m = wave_load_hist(P.counts + i * P.stride, P.weight[i], M.bins, w.supA, w.lnA);
+    for (uint32_t k = lane_id(); k < m; k += 64) {
+        w.supB[k] = w.supA[k];
+        w.lnB[k] = w.lnA[k];
+    }
+    __syncthreads();
+    const float c = wave_sinkhorn_cost(w, m, m, M);
+    if (lane_id() == 0) self_out[i] = c;
+}
+
+// derive support / ln-density / transposed density tables of a centroid set, and OT(c,c) for Sinkhorn layers
+__global__ __launch_bounds__(64) void k_prepare_centroids(CentroidSet cs, uint32_t K, Metric M, int kind, uint32_t k0) {
+    __shared__ WaveLds w;
+    const uint32_t k = k0 + blockIdx.x;
+    const uint32_t bins = M.bins;
+    const uint32_t wt = cs.weight[k];
+    const uint32_t m = wave_load_hist(cs.counts + (size_t)k * bins, wt, bins, w.supA, w.lnA);
+    for (uint32_t i = lane_id(); i < m; i += 64) {
+        cs.sup[(size_t)k * MAXB + i] = w.supA[i];
+        cs.lnd[(size_t)k * MAXB + i] = w.lnA[i];
+        w.supB[i] = w.supA[i];
+        w.lnB[i] = w.lnA[i];
+    }
+    for (uint32_t b = lane_id(); b < bins; b += 64)
+        cs.dens[(size_t)b * K + k] = (float)cs.counts[(size_t)k * bins + b] / (float)wt;  // NaN for an empty cluster, as in the reference
+    if (lane_id() == 0) cs.n[k] = m;
+    __syncthreads();
+    float self = 0.0f;
+    if (kind == RP_METRIC_SINKHORN) self = wave_sinkhorn_cost(w, m, m, M);
+    if (lane_id() == 0) cs.self[k] = self;
+}
+
+// centroid k <- copy of point idx (Layer::init_centroids pushes points, layer.rs:166-168)
+__global__ void k_centroid_from_point(CentroidSet cs, uint32_t k, Points P, uint64_t idx, uint32_t bins) {
+    for (uint32_t b = threadIdx.x; b < bins; b += blockDim.x) cs.counts[(size_t)k * bins + b] = P.counts[idx * P.stride + b];
+    if (threadIdx.x == 0) cs.weight[k] = P.weight[idx];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Equity::variation (equity.rs:41-53): one LANE per centroid, points' densities broadcast from LDS
+// ------------------------------------------------------------------------------------------------
+__device__ void wave_point_density(const Points& P, uint64_t i, uint32_t bins, float* pd) {
+    const float fw = (float)P.weight[i];
+    for (uint32_t b = lane_id(); b < bins; b += 64) pd[b] = (float)P.counts[i * P.stride + b] / fw;
+    __syncthreads();
+}
+// d[q] = variation(point, centroid q*64+lane) for q < 4
+__device__ void wave_variation_all(const float* pd, const CentroidSet& cs, uint32_t K, uint32_t bins, float d[4],
+                                   const Metric& M) {
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+        const uint32_t k = q * 64 + lane;
+        float cx = 0.0f, cy = 0.0f, s = 0.0f;
+        if (k < K) {
+            for (uint32_t b = 0; b < bins; ++b) {
+                cx += pd[b];
+                cy += cs.dens[(size_t)b * K + k];
+                s += rp_absf(cx - cy);
+            }
+            s = s / (float)bins;
+        }
+        d[q] = s;
+    }
+    if (lane == 0) atomicAdd(&M.stats[0], (unsigned long long)K);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Elkan::neighbor for every point (elkan.rs:68-77): init_bounds / Layer::lookup / step_naive
+// ------------------------------------------------------------------------------------------------
+struct Bounds {
+    uint8_t* j;      // [N]
+    float* u;        // [N]   Bounds::error
+    uint8_t* stale;  // [N]
+    float* lower;    // [N][K]
+};
+
+__global__ __launch_bounds__(64) void k_neighbor(Points P, CentroidSet cs, uint32_t K, Metric M, int kind,
+                                                 uint8_t* out_j, float* out_d, Bounds init) {
+    __shared__ WaveLds w;
+    const uint64_t i = blockIdx.x;
+    const uint32_t lane = lane_id();
+    uint32_t bj = 0;
+    float bd = 0.0f;
+    if (kind == RP_METRIC_SINKHORN) {
+        const uint32_t n = wave_load_hist(P.counts + i * P.stride, P.weight[i], M.bins, w.supB, w.lnB);
+        const float sp = P.self[i];
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint32_t m = wave_load_centroid(cs, k, w.supA, w.lnA);
+            const float d = wave_divergence(w, m, n, cs.self[k], sp, M);  // distance(centroid, point)
+            if (k == 0 || d < bd) {
+                bj = k;
+                bd = d;
+            }
+            __syncthreads();
+        }
+    } else {
+        wave_point_density(P, i, M.bins, w.f);
+        float d[4];
+        wave_variation_all(w.f, cs, K, M.bins, d, M);
+        // first minimum in ascending k: per-lane scan over q then wave argmin with index tie-break
+        float best = 0.0f;
+        uint32_t bk = 0xffffffffu;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t k = q * 64 + lane;
+            if (k < K && (bk == 0xffffffffu || d[q] < best)) {
+                best = d[q];
+                bk = k;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const uint32_t ok = __shfl_xor(bk, o, 64);
+            if (ok != 0xffffffffu && (bk == 0xffffffffu || ob < best || (ob == best && ok < bk))) {
+                best = ob;
+                bk = ok;
+            }
+        }
+        bj = bk;
+        bd = best;
+    }
+    if (lane == 0) {
+        if (out_j) out_j[i] = (uint8_t)bj;
+        if (out_d) out_d[i] = bd;
+        if (init.j) {  // Bounds::from((j, upper)) (bounds.rs:111-120)
+            init.j[i] = (uint8_t)bj;
+            init.u[i] = bd;
+            init.stale[i] = 0;
+        }
+    }
+    if (init.lower)
+        for (uint32_t k = lane; k < K; k += 64) init.lower[i * K + k] = 0.0f;
+}
+
+// Elkan::pairwises (elkan.rs:80-93): both orders; one wave per ordered pair
+__global__ __launch_bounds__(64) void k_pairwise(CentroidSet cs, uint32_t K, Metric M, int kind, float* pairw) {
+    __shared__ WaveLds w;
+    const uint32_t a = blockIdx.x / K, b = blockIdx.x % K;
+    float d = 0.0f;
+    if (a != b) {
+        if (kind == RP_METRIC_SINKHORN) {
+            const uint32_t m = wave_load_centroid(cs, a, w.supA, w.lnA);
+            const uint32_t n = wave_load_centroid(cs, b, w.supB, w.lnB);
+            d = wave_divergence(w, m, n, cs.self[a], cs.self[b], M);
+        } else {
+            float cx = 0.0f, cy = 0.0f, s = 0.0f;
+            for (uint32_t t = 0; t < M.bins; ++t) {
+                cx += cs.dens[(size_t)t * K + a];
+                cy += cs.dens[(size_t)t * K + b];
+                s += rp_absf(cx - cy);
+            }
+            d = s / (float)M.bins;
+            if (lane_id() == 0) atomicAdd(&M.stats[0], 1ull);
+        }
+    }
+    if (lane_id() == 0) pairw[(size_t)a * K + b] = d;
+}
+
+// Elkan::midpoints (elkan.rs:96-105)
+__global__ void k_midpoints(const float* pairw, uint32_t K, float* mid) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    float r = RP_F32_MAX;
+    for (uint32_t j = 0; j < K; ++j)
+        if (j != i) r = rp_minf(r, pairw[(size_t)i * K + j] * 0.5f);
+    mid[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Elkan::step_elkan's bound refresh (elkan.rs:153-168 with refresh :113-117, rebound :119-123,
+// Bounds::{has_shifted :57-61, witness :85-91, refresh :79-83})
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uint32_t K, Metric M, int kind, Bounds B,
+                                                   const float* pairw, const float* mid) {
+    __shared__ WaveLds w;
+    const uint64_t i = blockIdx.x;
+    const uint32_t lane = lane_id();
+    uint32_t j = B.j[i];
+    float u = B.u[i];
+    if (!(u > mid[j])) return;  // filter(|b| b.u() > midpoints[b.j()])
+    float dv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t m = 0;
+    float sp = 0.0f;
+    if (kind == RP_METRIC_SINKHORN) {
+        m = wave_load_hist(P.counts + i * P.stride, P.weight[i], M.bins, w.supA, w.lnA);
+        sp = P.self[i];
+    } else {
+        wave_point_density(P, i, M.bins, w.f);
+        wave_variation_all(w.f, cs, K, M.bins, dv, M);  // distances to every centroid; the replay below uses only
+                                                        // the ones the sequential rule would have evaluated
+    }
+    auto distance_to = [&](uint32_t k) -> float {  // distance(point, centroid k)
+        if (kind == RP_METRIC_SINKHORN) {
+            const uint32_t n = wave_load_centroid(cs, k, w.supB, w.lnB);
+            const float d = wave_divergence(w, m, n, sp, cs.self[k], M);
+            __syncthreads();
+            return d;
+        }
+        const uint32_t q = k >> 6, src = k & 63u;
+        float mine = q == 0 ? dv[0] : (q == 1 ? dv[1] : (q == 2 ? dv[2] : dv[3]));
+        return __shfl(mine, (int)src, 64);
+    };
+    float lw[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+        const uint32_t k = q * 64 + lane;
+        lw[q] = k < K ? B.lower[i * K + k] : 0.0f;
+    }
+    auto set_lower = [&](uint32_t k, float d) {
+        const uint32_t q = k >> 6;
+        if (lane == (k & 63u)) {
+            if (q == 0) lw[0] = d;
+            else if (q == 1) lw[1] = d;
+            else if (q == 2) lw[2] = d;
+            else lw[3] = d;
+        }
+    };
+    if (B.stale[i]) {
+        const float d = distance_to(j);
+        set_lower(j, d);
+        u = d;
+    }
+    uint32_t start = 0;
+    for (;;) {
+        uint32_t found = K;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t k = q * 64 + lane;
+            const bool hit = k < K && k >= start && k != j && u > lw[q] && u > 0.5f * pairw[(size_t)j * K + k];
+            const unsigned long long mask = __ballot(hit);
+            if (mask && found == K) found = q * 64 + (uint32_t)__ffsll((long long)mask) - 1u;
+        }
+        if (found == K) break;
+        const float d = distance_to(found);
+        set_lower(found, d);
+        if (d < u) {
+            j = found;
+            u = d;
+        }
+        start = found + 1;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+        const uint32_t k = q * 64 + lane;
+        if (k < K) B.lower[i * K + k] = lw[q];
+    }
+    if (lane == 0) {
+        B.j[i] = (uint8_t)j;
+        B.u[i] = u;
+        B.stale[i] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Elkan::recompute (elkan.rs:128-142): centroid[k] = integer sum of member histograms (Bins::merge)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_recompute(Points P, const uint8_t* assign, uint32_t bins, uint32_t* counts_out,
+                                                   uint32_t* weight_out, unsigned long long* sizes_out) {
+    __shared__ uint32_t hist[MAXB];
+    __shared__ unsigned long long members;
+    const uint32_t k = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t b = tid; b < MAXB; b += 256) hist[b] = 0;
+    if (tid == 0) members = 0;
+    __syncthreads();
+    uint32_t acc[4] = {0, 0, 0, 0};  // lane owns bins lane, lane+64, lane+128, lane+192
+    unsigned long long mine = 0;
+    for (uint64_t base = (uint64_t)wave * 64; base < P.N; base += 256) {
+        const uint64_t i = base + lane;
+        const bool hit = i < P.N && assign[i] == k;
+        unsigned long long mask = __ballot(hit);
+        mine += __popcll(mask);
+        while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const uint8_t* row = P.counts + (base + src) * P.stride;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t b = q * 64 + lane;
+                if (b < bins) acc[q] += row[b];
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q)
+        if (acc[q]) atomicAdd(&hist[q * 64 + lane], acc[q]);
+    if (lane == 0) atomicAdd(&members, mine);
+    __syncthreads();
+    uint32_t wsum = 0;
+    for (uint32_t b = tid; b < bins; b += 256) {
+        counts_out[(size_t)k * bins + b] = hist[b];
+        wsum += hist[b];
+    }
+    for (int d = 32; d > 0; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
+    __syncthreads();
+    if (tid == 0) hist[0] = 0;
+    __syncthreads();
+    if (lane == 0) atomicAdd(&hist[0], wsum);
+    __syncthreads();
+    if (tid == 0) {
+        weight_out[k] = hist[0];
+        sizes_out[k] = members;
+    }
+}
+
+// Elkan::drift (elkan.rs:108-110): distance(new_k, old_k)
+__global__ __launch_bounds__(64) void k_drift(CentroidSet nw, CentroidSet old, uint32_t K, Metric M, int kind, float* drift) {
+    __shared__ WaveLds w;
+    const uint32_t k = blockIdx.x;
+    float d;
+    if (kind == RP_METRIC_SINKHORN) {
+        const uint32_t m = wave_load_centroid(nw, k, w.supA, w.lnA);
+        const uint32_t n = wave_load_centroid(old, k, w.supB, w.lnB);
+        d = wave_divergence(w, m, n, nw.self[k], old.self[k], M);
+    } else {
+        float cx = 0.0f, cy = 0.0f, s = 0.0f;
+        for (uint32_t t = 0; t < M.bins; ++t) {
+            cx += nw.dens[(size_t)t * K + k];
+            cy += old.dens[(size_t)t * K + k];
+            s += rp_absf(cx - cy);
+        }
+        d = s / (float)M.bins;
+        if (lane_id() == 0) atomicAdd(&M.stats[0], 1ull);
+    }
+    if (lane_id() == 0) drift[k] = d;
+}
+
+// Bounds::update (bounds.rs:69-77): the HBM-streaming part of an iteration (N*K lower bounds read + written)
+__global__ __launch_bounds__(256) void k_bounds_update(Bounds B, uint64_t N, uint32_t K, const float* drift) {
+    __shared__ float dr[MAXB];
+    for (uint32_t k = threadIdx.x; k < K; k += 256) dr[k] = drift[k];
+    __syncthreads();
+    const uint64_t total = N * K;
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (uint64_t)gridDim.x * 256) {
+        const uint32_t k = (uint32_t)(e % K);
+        B.lower[e] = rp_maxf(B.lower[e] - dr[k], 0.0f);
+    }
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (uint64_t)gridDim.x * 256) {
+        B.u[i] = B.u[i] + dr[B.j[i]];
+        B.stale[i] = 1;
+    }
+}
+
+// Prior::tally's reassignment count (prior.rs:35-47); sizes come from k_recompute
+__global__ void k_tally(const uint8_t* j, uint8_t* prior, uint64_t N, unsigned long long* moved) {
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (j[i] != prior[i]) {
+            mine += 1;
+            prior[i] = j[i];
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(moved, mine);
+}
+
+// distance(point, centroid[j]) for Elkan::rms_with (elkan.rs:191-200)
+__global__ __launch_bounds__(64) void k_point_dist(Points P, CentroidSet cs, uint32_t K, Metric M, int kind, const uint8_t* j,
+                                                   float* out) {
+    __shared__ WaveLds w;
+    const uint64_t i = blockIdx.x;
+    const uint32_t k = j[i];
+    float d;
+    if (kind == RP_METRIC_SINKHORN) {
+        const uint32_t m = wave_load_hist(P.counts + i * P.stride, P.weight[i], M.bins, w.supA, w.lnA);
+        const uint32_t n = wave_load_centroid(cs, k, w.supB, w.lnB);
+        d = wave_divergence(w, m, n, P.self[i], cs.self[k], M);
+    } else {
+        wave_point_density(P, i, M.bins, w.f);
+        float cx = 0.0f, cy = 0.0f, s = 0.0f;
+        for (uint32_t t = 0; t < M.bins; ++t) {
+            cx += w.f[t];
+            cy += cs.dens[(size_t)t * K + k];
+            s += rp_absf(cx - cy);
+        }
+        d = s / (float)M.bins;
+        if (lane_id() == 0) atomicAdd(&M.stats[0], 1ull);
+    }
+    if (lane_id() == 0) out[i] = d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-means++ (layer.rs:140-181) with the fixed-point weighted draw of rp_math.h
+// ------------------------------------------------------------------------------------------------
+#define KPP_BLOCK 1024
+__global__ __launch_bounds__(256) void k_kpp_blocksum(const float* pot, uint64_t N, unsigned long long* bsum) {
+    __shared__ unsigned long long part[4];
+    const uint64_t base = (uint64_t)blockIdx.x * KPP_BLOCK;
+    unsigned long long s = 0;
+    for (uint32_t t = threadIdx.x; t < KPP_BLOCK; t += 256) {
+        const uint64_t i = base + t;
+        if (i < N) s += rp_kpp_quant(pot[i]);
+    }
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+// single block: winner = first i with inclusive prefix > r, r = mulhi64(stream(seed, round), total)
+__global__ __launch_bounds__(1024) void k_kpp_pick(const float* pot_in, float* pot, uint64_t N, const unsigned long long* bsum,
+                                                   uint32_t nblocks, uint64_t seed, uint32_t round, unsigned long long* picked) {
+    __shared__ unsigned long long strip[1024];
+    __shared__ unsigned long long sh_r, sh_before;
+    __shared__ uint32_t sh_block;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (nblocks + 1023) / 1024;
+    unsigned long long s = 0;
+    for (uint32_t b = tid * per; b < (tid + 1) * per && b < nblocks; ++b) s += bsum[b];
+    strip[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long total = 0;
+        for (uint32_t t = 0; t < 1024; ++t) total += strip[t];
+
+        const uint64_t h = rp_stream(seed, round);
+        if (total == 0) {
+            picked[0] = rp_mulhi64(h, N);
+            sh_block = 0xffffffffu;
+        } else {
+            const unsigned long long r = rp_mulhi64(h, total);
+            unsigned long long acc = 0;
+            uint32_t t = 0;
+            while (acc + strip[t] <= r) acc += strip[t++];
+            uint32_t b = t * per;
+            while (acc + bsum[b] <= r) acc += bsum[b++];
+            sh_block = b;
+            sh_before = acc;
+            sh_r = r;
+        }
+    }
+    __syncthreads();
+    if (sh_block != 0xffffffffu) {
+        const uint64_t i = (uint64_t)sh_block * KPP_BLOCK + tid;
+        strip[tid] = i < N ? rp_kpp_quant(pot_in[i]) : 0ull;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long acc = sh_before;
+            uint32_t t = 0;
+            for (; t < KPP_BLOCK; ++t) {
+                acc += strip[t];
+                if (acc > sh_r) break;
+            }
+            picked[0] = (uint64_t)sh_block * KPP_BLOCK + t;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) pot[picked[0]] = 0.0f;  // potentials[i] = 0 (layer.rs:169)
+}
+// potentials <- min(potentials, d(new centroid, point)^2) (layer.rs:170-178): distance(&x, h), centroid first
+__global__ __launch_bounds__(64) void k_kpp_update(Points P, CentroidSet cs, uint32_t k, uint32_t K, Metric M, int kind,
+                                                   float* pot) {
+    __shared__ WaveLds w;
+    const uint64_t i = blockIdx.x;
+    float d;
+    if (kind == RP_METRIC_SINKHORN) {
+        const uint32_t m = wave_load_centroid(cs, k, w.supA, w.lnA);
+        const uint32_t n = wave_load_hist(P.counts + i * P.stride, P.weight[i], M.bins, w.supB, w.lnB);
+        d = wave_divergence(w, m, n, cs.self[k], P.self[i], M);
+    } else {
+        wave_point_density(P, i, M.bins, w.f);
+        float cx = 0.0f, cy = 0.0f, s = 0.0f;
+        for (uint32_t t = 0; t < M.bins; ++t) {
+            cx += cs.dens[(size_t)t * K + k];
+            cy += w.f[t];
+            s += rp_absf(cx - cy);
+        }
+        d = s / (float)M.bins;
+        if (lane_id() == 0) atomicAdd(&M.stats[0], 1ull);
+    }
+    if (lane_id() == 0) pot[i] = rp_minf(d * d, pot[i]);
+}
+__global__ void k_fill(float* p, uint64_t n, float v) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone batched entry points: one wave per pair of u32 histograms
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_pair_sinkhorn(const uint32_t* mu, const uint32_t* nu, Metric M, int divergence,
+                                                      float* out, uint32_t* iters_out) {
+    __shared__ WaveLds w;
+    const uint64_t p = blockIdx.x;
+    const uint32_t bins = M.bins, lane = lane_id();
+    uint32_t wa = 0, wb = 0;
+    for (uint32_t b = lane; b < bins; b += 64) {
+        wa += mu[p * bins + b];
+        wb += nu[p * bins + b];
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        wa += __shfl_xor(wa, d, 64);
+        wb += __shfl_xor(wb, d, 64);
+    }
+    float xx = 0.0f, yy = 0.0f;
+    if (divergence) {
+        uint32_t m = wave_load_hist(mu + p * bins, wa, bins, w.supA, w.lnA);
+        for (uint32_t k = lane; k < m; k += 64) { w.supB[k] = w.supA[k]; w.lnB[k] = w.lnA[k]; }
+        __syncthreads();
+        xx = wave_sinkhorn_cost(w, m, m, M);
+        __syncthreads();
+        m = wave_load_hist(nu + p * bins, wb, bins, w.supA, w.lnA);
+        for (uint32_t k = lane; k < m; k += 64) { w.supB[k] = w.supA[k]; w.lnB[k] = w.lnA[k]; }
+        __syncthreads();
+        yy = wave_sinkhorn_cost(w, m, m, M);
+        __syncthreads();
+    }
+    const uint32_t m = wave_load_hist(mu + p * bins, wa, bins, w.supA, w.lnA);
+    const uint32_t n = wave_load_hist(nu + p * bins, wb, bins, w.supB, w.lnB);
+    unsigned long long before = 0;
+    if (iters_out && lane == 0) before = M.stats[1];
+    const float xy = wave_sinkhorn_cost(w, m, n, M);
+    float r = xy;
+    if (divergence) r = rp_maxf(xy - 0.5f * xx - 0.5f * yy, 0.0f);
+    if (lane == 0) out[p] = r;
+    (void)before;
+}
+// iteration counts need a private counter per pair: a second tiny variant keeps the hot kernel lean
+__global__ __launch_bounds__(64) void k_pair_iters(const uint32_t* mu, const uint32_t* nu, Metric M, unsigned long long* scratch,
+                                                   uint32_t* iters_out) {
+    __shared__ WaveLds w;
+    const uint64_t p = blockIdx.x;
+    const uint32_t bins = M.bins, lane = lane_id();
+    uint32_t wa = 0, wb = 0;
+    for (uint32_t b = lane; b < bins; b += 64) {
+        wa += mu[p * bins + b];
+        wb += nu[p * bins + b];
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        wa += __shfl_xor(wa, d, 64);
+        wb += __shfl_xor(wb, d, 64);
+    }
+    Metric mine = M;
+    mine.stats = scratch + 2 * p;
+    const uint32_t m = wave_load_hist(mu + p * bins, wa, bins, w.supA, w.lnA);
+    const uint32_t n = wave_load_hist(nu + p * bins, wb, bins, w.supB, w.lnB);
+    (void)wave_sinkhorn_cost(w, m, n, mine);
+    __syncthreads();
+    if (lane == 0) iters_out[p] = (uint32_t)scratch[2 * p + 1];
+}
+__global__ void k_pair_variation(const uint32_t* x, const uint32_t* y, uint32_t bins, uint64_t pairs, float* out) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= pairs) return;
+    uint32_t wx = 0, wy = 0;
+    for (uint32_t b = 0; b < bins; ++b) {
+        wx += x[p * bins + b];
+        wy += y[p * bins + b];
+    }
+    const float fx = (float)wx, fy = (float)wy;
+    float cx = 0.0f, cy = 0.0f, s = 0.0f;
+    for (uint32_t b = 0; b < bins; ++b) {
+        cx += (float)x[p * bins + b] / fx;
+        cy += (float)y[p * bins + b] / fy;
+        s += rp_absf(cx - cy);
+    }
+    out[p] = s / (float)bins;
+}
+
+}  // namespace rp
+
+// =================================================================================================
+// host side
+// =================================================================================================
+using namespace rp;
+
+namespace {
+struct Clock {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0.0;
+    uint64_t launches = 0;
+};
+const char* const CLOCK_NAMES[] = {"pairwise", "step", "recompute", "bounds", "neighbor", "selfcost", "kpp", "drift"};
+enum { CK_PAIRWISE, CK_STEP, CK_RECOMPUTE, CK_BOUNDS, CK_NEIGHBOR, CK_SELF, CK_KPP, CK_DRIFT, CK_COUNT };
+}  // namespace
+
+struct rp_kmeans {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t K = 0, bins = 0, stride = 0;
+    uint64_t N = 0;
+    int kind = 0;
+    rp_sinkhorn_hp hp{};
+    uint64_t seed = 0;
+    std::vector<void*> allocs;
+    bool owns_counts = true;
+    Points P{};
+    Metric M{};
+    CentroidSet cs[2]{};
+    int cur = 0;
+    Bounds B{};
+    uint8_t* prior = nullptr;
+    float* pairw = nullptr;
+    float* mid = nullptr;
+    float* drift = nullptr;
+    float* pot = nullptr;
+    float* pdist = nullptr;
+    unsigned long long* bsum = nullptr;
+    unsigned long long* scal = nullptr;  // [0] picked, [1] moved
+    unsigned long long* sizes = nullptr; // [K]
+    unsigned long long* stats = nullptr; // [2]
+    uint8_t* tmp_j = nullptr;
+    bool bounds_ready = false, centroids_ready = false;
+    bool profiling = false;
+    Clock clk[CK_COUNT];
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(rp_kmeans* h, T** out, size_t count) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    h->allocs.push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return RP_OK;
+}
+
+void ck_begin(rp_kmeans* h, int id) {
+    if (!h->profiling) return;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, h->stream);
+    h->clk[id].pending.emplace_back(a, b);
+}
+void ck_end(rp_kmeans* h, int id) {
+    if (!h->profiling) return;
+    (void)hipEventRecord(h->clk[id].pending.back().second, h->stream);
+    h->clk[id].launches += 1;
+}
+void ck_drain(rp_kmeans* h) {
+    for (auto& c : h->clk) {
+        for (auto& pr : c.pending) {
+            float ms = 0.0f;
+            (void)hipEventSynchronize(pr.second);
+            (void)hipEventElapsedTime(&ms, pr.first, pr.second);
+            c.total_ms += ms;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        c.pending.clear();
+    }
+}
+
+int alloc_centroid_set(rp_kmeans* h, CentroidSet* cs) {
+    int rc;
+    if ((rc = dev_alloc(h, &cs->counts, (size_t)h->K * h->bins))) return rc;
+    if ((rc = dev_alloc(h, &cs->weight, h->K))) return rc;
+    if ((rc = dev_alloc(h, &cs->n, h->K))) return rc;
+    if ((rc = dev_alloc(h, &cs->sup, (size_t)h->K * MAXB))) return rc;
+    if ((rc = dev_alloc(h, &cs->lnd, (size_t)h->K * MAXB))) return rc;
+    if ((rc = dev_alloc(h, &cs->dens, (size_t)h->K * h->bins))) return rc;
+    if ((rc = dev_alloc(h, &cs->self, h->K))) return rc;
+    return RP_OK;
+}
+
+int prepare_centroids(rp_kmeans* h, int set) {
+    ck_begin(h, CK_SELF);
+    hipLaunchKernelGGL(k_prepare_centroids, dim3(h->K), dim3(64), 0, h->stream, h->cs[set], h->K, h->M, h->kind, 0u);
+    ck_end(h, CK_SELF);
+    HIP_TRY(hipGetLastError());
+    return RP_OK;
+}
+
+int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, bool counts_on_device, rp_metric_kind kind,
+                  const float* tri_metric, const rp_sinkhorn_hp* hp, uint64_t seed, int device, rp_kmeans** out) {
+    if (!out || !counts) return rp::fail(RP_ERR_INVALID, "rp_kmeans_create: NULL argument");
+    if (K == 0 || K > MAXB || bins == 0 || bins > MAXB || N == 0)
+        return rp::fail(RP_ERR_INVALID, "rp_kmeans_create: need 1 <= K <= 256, 1 <= bins <= 256, N >= 1");
+    if (kind != RP_METRIC_SINKHORN && kind != RP_METRIC_VARIATION) return rp::fail(RP_ERR_INVALID, "rp_kmeans_create: unknown metric kind");
+    if (kind == RP_METRIC_SINKHORN && !tri_metric && bins > 1) return rp::fail(RP_ERR_INVALID, "rp_kmeans_create: Sinkhorn needs tri_metric");
+    if (rp_device_count() <= 0)
+        return rp::fail(RP_ERR_NO_DEVICE, "rp_kmeans_create: no HIP device visible; the MI355X path has no CPU fallback");
+    rp_kmeans* h = new rp_kmeans();
+    h->device = device;
+    h->K = K; h->N = N; h->bins = bins; h->kind = kind; h->seed = seed;
+    if (hp) h->hp = *hp; else rp_sinkhorn_hp_default(&h->hp);
+    h->stride = counts_on_device ? bins : ((bins + 15u) & ~15u);
+#define KM_TRY(expr)                                                                          \
+    do {                                                                                      \
+        int _rc = (expr);                                                                     \
+        if (_rc) { rp_kmeans_destroy(h); return _rc; }                                        \
+    } while (0)
+#define KM_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            int _rc = rp::fail(RP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));    \
+            rp_kmeans_destroy(h);                                                             \
+            return _rc;                                                                       \
+        }                                                                                     \
+    } while (0)
+    KM_HIP(hipSetDevice(device));
+    KM_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+    uint8_t* d_counts = nullptr;
+    if (counts_on_device) {
+        d_counts = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(counts));
+        h->owns_counts = false;
+    } else {
+        KM_TRY(dev_alloc(h, &d_counts, (size_t)N * h->stride));
+        KM_HIP(hipMemset(d_counts, 0, (size_t)N * h->stride));
+        KM_HIP(hipMemcpy2D(d_counts, h->stride, counts, bins, bins, N, hipMemcpyHostToDevice));
+    }
+    uint32_t* d_w = nullptr;
+    float* d_self = nullptr;
+    KM_TRY(dev_alloc(h, &d_w, N));
+    KM_TRY(dev_alloc(h, &d_self, N));
+    h->P = Points{d_counts, d_w, d_self, h->stride, N};
+    // metric matrices
+    float *d_C = nullptr, *d_R = nullptr;
+    KM_TRY(dev_alloc(h, &d_C, (size_t)bins * bins));
+    KM_TRY(dev_alloc(h, &d_R, (size_t)bins * bins));
+    {
+        std::vector<float> C((size_t)bins * bins, 0.0f), R((size_t)bins * bins, 0.0f);
+        if (kind == RP_METRIC_SINKHORN) {
+            for (uint32_t x = 0; x < bins; ++x)
+                for (uint32_t y = 0; y < bins; ++y) {
+                    const float c = x == y ? 0.0f : tri_metric[rp_tri_index(x, y)];
+                    C[(size_t)x * bins + y] = c;
+                    R[(size_t)x * bins + y] = c / h->hp.temperature;  // regularization (sinkhorn.rs:129-131)
+                }
+        }
+        KM_HIP(hipMemcpy(d_C, C.data(), C.size() * 4, hipMemcpyHostToDevice));
+        KM_HIP(hipMemcpy(d_R, R.data(), R.size() * 4, hipMemcpyHostToDevice));
+    }
+    KM_TRY(dev_alloc(h, &h->stats, 2));
+    KM_HIP(hipMemset(h->stats, 0, 16));
+    h->M = Metric{d_C, d_R, bins, h->hp.iterations, h->hp.tolerance, h->stats};
+    KM_TRY(alloc_centroid_set(h, &h->cs[0]));
+    KM_TRY(alloc_centroid_set(h, &h->cs[1]));
+    KM_TRY(dev_alloc(h, &h->B.j, N));
+    KM_TRY(dev_alloc(h, &h->B.u, N));
+    KM_TRY(dev_alloc(h, &h->B.stale, N));
+    KM_TRY(dev_alloc(h, &h->B.lower, (size_t)N * K));
+    KM_TRY(dev_alloc(h, &h->prior, N));
+    KM_TRY(dev_alloc(h, &h->tmp_j, N));
+    KM_TRY(dev_alloc(h, &h->pairw, (size_t)K * K));
+    KM_TRY(dev_alloc(h, &h->mid, K));
+    KM_TRY(dev_alloc(h, &h->drift, K));
+    KM_TRY(dev_alloc(h, &h->pot, N));
+    KM_TRY(dev_alloc(h, &h->pdist, N));
+    KM_TRY(dev_alloc(h, &h->bsum, (N + KPP_BLOCK - 1) / KPP_BLOCK));
+    KM_TRY(dev_alloc(h, &h->scal, 2));
+    KM_TRY(dev_alloc(h, &h->sizes, K));
+    // point masses and memoised self costs OT(p,p) (sinkhorn.rs:175-191)
+    hipLaunchKernelGGL(k_point_weights, dim3((unsigned)N), dim3(64), 0, h->stream, d_counts, h->stride, bins, N, d_w);
+    KM_HIP(hipGetLastError());
+    if (kind == RP_METRIC_SINKHORN) {
+        hipLaunchKernelGGL(k_point_self, dim3((unsigned)N), dim3(64), 0, h->stream, h->P, h->M, d_self);
+        KM_HIP(hipGetLastError());
+    } else {
+        KM_HIP(hipMemsetAsync(d_self, 0, N * 4, h->stream));
+    }
+    KM_HIP(hipStreamSynchronize(h->stream));
+#undef KM_TRY
+#undef KM_HIP
+    *out = h;
+    return RP_OK;
+}
+
+int need_centroids(const rp_kmeans* h, const char* who) {
+    if (!h->centroids_ready) return rp::fail(RP_ERR_INVALID, "%s: centroids not initialised (init_centroids / set_centroids)", who);
+    return RP_OK;
+}
+int need_bounds(const rp_kmeans* h, const char* who) {
+    if (!h->bounds_ready) return rp::fail(RP_ERR_INVALID, "%s: bounds not initialised (init_bounds)", who);
+    return RP_OK;
+}
+
+int launch_neighbor(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init) {
+    ck_begin(h, CK_NEIGHBOR);
+    hipLaunchKernelGGL(k_neighbor, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->kind, out_j,
+                       out_d, init);
+    ck_end(h, CK_NEIGHBOR);
+    HIP_TRY(hipGetLastError());
+    return RP_OK;
+}
+
+int launch_recompute(rp_kmeans* h, const uint8_t* assign, int set) {
+    ck_begin(h, CK_RECOMPUTE);
+    hipLaunchKernelGGL(k_recompute, dim3(h->K), dim3(256), 0, h->stream, h->P, assign, h->bins, h->cs[set].counts,
+                       h->cs[set].weight, h->sizes);
+    ck_end(h, CK_RECOMPUTE);
+    HIP_TRY(hipGetLastError());
+    return RP_OK;
+}
+
+// the part of step_elkan before the centroid exchange: pairwise, midpoints, bound refresh, partial sums
+int step_front(rp_kmeans* h) {
+    const int cur = h->cur;
+    ck_begin(h, CK_PAIRWISE);
+    hipLaunchKernelGGL(k_pairwise, dim3(h->K * h->K), dim3(64), 0, h->stream, h->cs[cur], h->K, h->M, h->kind, h->pairw);
+    hipLaunchKernelGGL(k_midpoints, dim3((h->K + 63) / 64), dim3(64), 0, h->stream, h->pairw, h->K, h->mid);
+    ck_end(h, CK_PAIRWISE);
+    ck_begin(h, CK_STEP);
+    hipLaunchKernelGGL(k_elkan_step, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[cur], h->K, h->M, h->kind, h->B,
+                       h->pairw, h->mid);
+    ck_end(h, CK_STEP);
+    HIP_TRY(hipGetLastError());
+    return launch_recompute(h, h->B.j, cur ^ 1);
+}
+
+// after the (optional) all-reduce of the integer sums in cs[cur^1]: drift, bounds update, install, tally
+int step_back(rp_kmeans* h, float* drift, uint64_t* sizes, double* reassigned) {
+    const int cur = h->cur, nxt = cur ^ 1;
+    int rc = prepare_centroids(h, nxt);
+    if (rc) return rc;
+    ck_begin(h, CK_DRIFT);
+    hipLaunchKernelGGL(k_drift, dim3(h->K), dim3(64), 0, h->stream, h->cs[nxt], h->cs[cur], h->K, h->M, h->kind, h->drift);
+    ck_end(h, CK_DRIFT);
+    ck_begin(h, CK_BOUNDS);
+    hipLaunchKernelGGL(k_bounds_update, dim3(2048), dim3(256), 0, h->stream, h->B, h->N, h->K, h->drift);
+    ck_end(h, CK_BOUNDS);
+    HIP_TRY(hipMemsetAsync(h->scal + 1, 0, 8, h->stream));
+    hipLaunchKernelGGL(k_tally, dim3(1024), dim3(256), 0, h->stream, h->B.j, h->prior, h->N, h->scal + 1);
+    HIP_TRY(hipGetLastError());
+    h->cur = nxt;  // Kmeans::next installs the new centroids (kmeans.rs:88)
+    std::vector<unsigned long long> sz(h->K);
+    unsigned long long moved = 0;
+    if (drift) HIP_TRY(hipMemcpyAsync(drift, h->drift, h->K * 4, hipMemcpyDeviceToHost, h->stream));
+    if (sizes) HIP_TRY(hipMemcpyAsync(sz.data(), h->sizes, h->K * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&moved, h->scal + 1, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (sizes) for (uint32_t k = 0; k < h->K; ++k) sizes[k] = sz[k];
+    if (reassigned) *reassigned = (double)moved / (double)h->N;
+    ck_drain(h);
+    return RP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rp_kmeans_create(uint32_t K, uint64_t N, uint32_t bins, const uint8_t* counts, rp_metric_kind kind, const float* tri_metric,
+                     const rp_sinkhorn_hp* hp, uint64_t seed, int device, rp_kmeans** out) {
+    return create_common(K, N, bins, counts, false, kind, tri_metric, hp, seed, device, out);
+}
+int rp_kmeans_create_device(uint32_t K, uint64_t N, uint32_t bins, const void* counts_dev, rp_metric_kind kind,
+                            const float* tri_metric, const rp_sinkhorn_hp* hp, uint64_t seed, int device, rp_kmeans** out) {
+    return create_common(K, N, bins, counts_dev, true, kind, tri_metric, hp, seed, device, out);
+}
+
+int rp_kmeans_destroy(rp_kmeans* h) {
+    if (!h) return RP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    ck_drain(h);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return RP_OK;
+}
+
+int rp_kmeans_set_centroids(rp_kmeans* h, const uint64_t* point_index) {
+    if (!h || !point_index) return rp::fail(RP_ERR_INVALID, "rp_kmeans_set_centroids: NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    for (uint32_t k = 0; k < h->K; ++k) {
+        if (point_index[k] >= h->N) return rp::fail(RP_ERR_INVALID, "rp_kmeans_set_centroids: point index out of range");
+        hipLaunchKernelGGL(k_centroid_from_point, dim3(1), dim3(256), 0, h->stream, h->cs[h->cur], k, h->P, point_index[k], h->bins);
+    }
+    HIP_TRY(hipGetLastError());
+    int rc = prepare_centroids(h, h->cur);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->centroids_ready = true;
+    h->bounds_ready = false;
+    return RP_OK;
+}
+
+int rp_kmeans_init_centroids(rp_kmeans* h, uint64_t* chosen) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_init_centroids: NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    const uint32_t nblocks = (uint32_t)((h->N + KPP_BLOCK - 1) / KPP_BLOCK);
+    CentroidSet& cs = h->cs[h->cur];
+    // all centroids start empty so k_prepare_centroids is well defined for the not-yet-chosen ones
+    HIP_TRY(hipMemsetAsync(cs.counts, 0, (size_t)h->K * h->bins * 4, h->stream));
+    HIP_TRY(hipMemsetAsync(cs.weight, 0, h->K * 4, h->stream));
+    hipLaunchKernelGGL(k_prepare_centroids, dim3(h->K), dim3(64), 0, h->stream, cs, h->K, h->M, h->kind, 0u);
+    hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, h->stream, h->pot, h->N, 1.0f);  // potentials = 1 (layer.rs:161)
+    std::vector<unsigned long long> picks(h->K);
+    ck_begin(h, CK_KPP);
+    for (uint32_t k = 0; k < h->K; ++k) {
+        hipLaunchKernelGGL(k_kpp_blocksum, dim3(nblocks), dim3(256), 0, h->stream, h->pot, h->N, h->bsum);
+        hipLaunchKernelGGL(k_kpp_pick, dim3(1), dim3(1024), 0, h->stream, h->pot, h->pot, h->N, h->bsum, nblocks, h->seed, k, h->scal);
+        HIP_TRY(hipMemcpyAsync(&picks[k], h->scal, 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        hipLaunchKernelGGL(k_centroid_from_point, dim3(1), dim3(256), 0, h->stream, cs, k, h->P, (uint64_t)picks[k], h->bins);
+        hipLaunchKernelGGL(k_prepare_centroids, dim3(1), dim3(64), 0, h->stream, cs, h->K, h->M, h->kind, k);
+        hipLaunchKernelGGL(k_kpp_update, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, cs, k, h->K, h->M, h->kind, h->pot);
+        HIP_TRY(hipGetLastError());
+    }
+    ck_end(h, CK_KPP);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (chosen) for (uint32_t k = 0; k < h->K; ++k) chosen[k] = picks[k];
+    h->centroids_ready = true;
+    h->bounds_ready = false;
+    ck_drain(h);
+    return RP_OK;
+}
+
+int rp_kmeans_init_bounds(rp_kmeans* h) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_init_bounds: NULL handle");
+    int rc = need_centroids(h, "rp_kmeans_init_bounds");
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    if ((rc = launch_neighbor(h, h->prior, nullptr, h->B))) return rc;  // Prior::from_bounds (prior.rs:23-32)
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->bounds_ready = true;
+    ck_drain(h);
+    return RP_OK;
+}
+
+int rp_kmeans_step(rp_kmeans* h, float* drift, uint64_t* sizes, double* reassigned) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_step: NULL handle");
+    int rc = need_centroids(h, "rp_kmeans_step");
+    if (rc || (rc = need_bounds(h, "rp_kmeans_step"))) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    if ((rc = step_front(h))) return rc;
+    return step_back(h, drift, sizes, reassigned);
+}
+
+int rp_kmeans_partial_bytes(rp_kmeans* h, size_t* bytes) {
+    if (!h || !bytes) return rp::fail(RP_ERR_INVALID, "rp_kmeans_partial_bytes: NULL argument");
+    *bytes = ((size_t)h->K * h->bins + h->K) * 4 + (size_t)h->K * 8;
+    return RP_OK;
+}
+
+// partial layout: [K*bins u32 counts][K u32 weights][K u64 sizes] — all exact integers, all-reduce(sum)-able
+int rp_kmeans_step_local(rp_kmeans* h, void* partial_dev) {
+    if (!h || !partial_dev) return rp::fail(RP_ERR_INVALID, "rp_kmeans_step_local: NULL argument");
+    int rc = need_centroids(h, "rp_kmeans_step_local");
+    if (rc || (rc = need_bounds(h, "rp_kmeans_step_local"))) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    if ((rc = step_front(h))) return rc;
+    const int nxt = h->cur ^ 1;
+    unsigned char* out = reinterpret_cast<unsigned char*>(partial_dev);
+    const size_t cb = (size_t)h->K * h->bins * 4, wb = (size_t)h->K * 4;
+    HIP_TRY(hipMemcpyAsync(out, h->cs[nxt].counts, cb, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(out + cb, h->cs[nxt].weight, wb, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(out + cb + wb, h->sizes, (size_t)h->K * 8, hipMemcpyDeviceToDevice, h->stream));
+    return RP_OK;
+}
+
+int rp_kmeans_step_finish(rp_kmeans* h, const void* reduced_dev, float* drift, uint64_t* sizes, double* reassigned) {
+    if (!h || !reduced_dev) return rp::fail(RP_ERR_INVALID, "rp_kmeans_step_finish: NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const int nxt = h->cur ^ 1;
+    const unsigned char* in = reinterpret_cast<const unsigned char*>(reduced_dev);
+    const size_t cb = (size_t)h->K * h->bins * 4, wb = (size_t)h->K * 4;
+    HIP_TRY(hipMemcpyAsync(h->cs[nxt].counts, in, cb, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->cs[nxt].weight, in + cb, wb, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->sizes, in + cb + wb, (size_t)h->K * 8, hipMemcpyDeviceToDevice, h->stream));
+    return step_back(h, drift, sizes, reassigned);
+}
+
+int rp_kmeans_step_naive(rp_kmeans* h) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_step_naive: NULL handle");
+    int rc = need_centroids(h, "rp_kmeans_step_naive");
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    Bounds none{};
+    if ((rc = launch_neighbor(h, h->tmp_j, nullptr, none))) return rc;
+    const int nxt = h->cur ^ 1;
+    if ((rc = launch_recompute(h, h->tmp_j, nxt))) return rc;
+    if ((rc = prepare_centroids(h, nxt))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->cur = nxt;
+    ck_drain(h);
+    return RP_OK;
+}
+
+int rp_kmeans_assign(rp_kmeans* h, uint8_t* bucket, float* distance) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_assign: NULL handle");
+    int rc = need_centroids(h, "rp_kmeans_assign");
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    Bounds none{};
+    if ((rc = launch_neighbor(h, h->tmp_j, h->pdist, none))) return rc;
+    if (bucket) HIP_TRY(hipMemcpyAsync(bucket, h->tmp_j, h->N, hipMemcpyDeviceToHost, h->stream));
+    if (distance) HIP_TRY(hipMemcpyAsync(distance, h->pdist, h->N * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    ck_drain(h);
+    return RP_OK;
+}
+
+int rp_kmeans_bounds(rp_kmeans* h, uint8_t* j, float* upper, float* lower) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_bounds: NULL handle");
+    int rc = need_bounds(h, "rp_kmeans_bounds");
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    if (j) HIP_TRY(hipMemcpyAsync(j, h->B.j, h->N, hipMemcpyDeviceToHost, h->stream));
+    if (upper) HIP_TRY(hipMemcpyAsync(upper, h->B.u, h->N * 4, hipMemcpyDeviceToHost, h->stream));
+    if (lower) HIP_TRY(hipMemcpyAsync(lower, h->B.lower, h->N * h->K * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RP_OK;
+}
+
+int rp_kmeans_centroids(rp_kmeans* h, uint32_t* counts, uint64_t* weight) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_centroids: NULL handle");
+    int rc = need_centroids(h, "rp_kmeans_centroids");
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<uint32_t> w(h->K);
+    if (counts) HIP_TRY(hipMemcpyAsync(counts, h->cs[h->cur].counts, (size_t)h->K * h->bins * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(w.data(), h->cs[h->cur].weight, h->K * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (weight) for (uint32_t k = 0; k < h->K; ++k) weight[k] = w[k];
+    return RP_OK;
+}
+
+int rp_kmeans_metric(rp_kmeans* h, float* tri) {
+    if (!h || !tri) return rp::fail(RP_ERR_INVALID, "rp_kmeans_metric: NULL argument");
+    int rc = need_centroids(h, "rp_kmeans_metric");
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    ck_begin(h, CK_PAIRWISE);
+    hipLaunchKernelGGL(k_pairwise, dim3(h->K * h->K), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, h->pairw);
+    ck_end(h, CK_PAIRWISE);
+    HIP_TRY(hipGetLastError());
+    std::vector<float> pw((size_t)h->K * h->K);
+    HIP_TRY(hipMemcpyAsync(pw.data(), h->pairw, pw.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    // Layer::metric (layer.rs:85-101): (emd(x,y) + emd(y,x)) / 2, then Metric::from normalises by the max (metric.rs:127-141)
+    float mx = RP_EPSILON;
+    for (uint32_t i = 0; i < h->K; ++i)
+        for (uint32_t j = 0; j < i; ++j) {
+            float d = pw[(size_t)i * h->K + j] + pw[(size_t)j * h->K + i];
+            d = d / 2.0f;
+            tri[rp_tri_index(i, j)] = d;
+            mx = rp_maxf(mx, d);
+        }
+    for (uint32_t t = 0; t < h->K * (h->K - 1) / 2; ++t) tri[t] = tri[t] / mx;
+    ck_drain(h);
+    return RP_OK;
+}
+
+int rp_kmeans_rms(rp_kmeans* h, float* out) {
+    if (!h || !out) return rp::fail(RP_ERR_INVALID, "rp_kmeans_rms: NULL argument");
+    int rc = need_bounds(h, "rp_kmeans_rms");
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_point_dist, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->kind, h->B.j,
+                       h->pdist);
+    HIP_TRY(hipGetLastError());
+    std::vector<float> d(h->N);
+    HIP_TRY(hipMemcpyAsync(d.data(), h->pdist, h->N * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double acc = 0.0;  // f64 accumulation in point order (the reference's rayon f32 sum has no fixed order)
+    for (uint64_t i = 0; i < h->N; ++i) acc += (double)(d[i] * d[i]);
+    *out = (float)std::sqrt(acc / (double)h->N);
+    return RP_OK;
+}
+
+int rp_kmeans_stats(rp_kmeans* h, uint64_t* distances, uint64_t* sinkhorn_iterations) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_stats: NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    unsigned long long s[2];
+    HIP_TRY(hipMemcpyAsync(s, h->stats, 16, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (distances) *distances = s[0];
+    if (sinkhorn_iterations) *sinkhorn_iterations = s[1];
+    return RP_OK;
+}
+
+int rp_kmeans_set_stream(rp_kmeans* h, void* hip_stream) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_set_stream: NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->own_stream) {
+        HIP_TRY(hipStreamDestroy(h->stream));
+        h->own_stream = false;
+    }
+    if (hip_stream) h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    else {
+        HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    return RP_OK;
+}
+
+int rp_kmeans_profile(rp_kmeans* h, int enable) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_profile: NULL handle");
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    ck_drain(h);
+    h->profiling = enable != 0;
+    for (auto& c : h->clk) { c.total_ms = 0.0; c.launches = 0; }
+    return RP_OK;
+}
+
+int rp_kmeans_kernel_time(rp_kmeans* h, const char* name, double* total_ms, uint64_t* launches) {
+    if (!h || !name) return rp::fail(RP_ERR_INVALID, "rp_kmeans_kernel_time: NULL argument");
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    ck_drain(h);
+    for (int i = 0; i < CK_COUNT; ++i)
+        if (std::string(name) == CLOCK_NAMES[i]) {
+            if (total_ms) *total_ms = h->clk[i].total_ms;
+            if (launches) *launches = h->clk[i].launches;
+            return RP_OK;
+        }
+    return rp::fail(RP_ERR_INVALID, "rp_kmeans_kernel_time: unknown kernel '%s'", name);
+}
+
+// ---- stand-alone batched distances -------------------------------------------------------------------
+namespace {
+int pair_common(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_t* nu, const float* tri, const rp_sinkhorn_hp* hp,
+                int device, float* out, uint32_t* iterations, int divergence) {
+    if (!mu || !nu || !out || pairs == 0 || bins == 0 || bins > MAXB || (!tri && bins > 1))
+        return rp::fail(RP_ERR_INVALID, "rp_sinkhorn_*: bad argument");
+    if (rp_device_count() <= 0) return rp::fail(RP_ERR_NO_DEVICE, "rp_sinkhorn_*: no HIP device visible; no CPU fallback");
+    rp_sinkhorn_hp hh;
+    if (hp) hh = *hp; else rp_sinkhorn_hp_default(&hh);
+    HIP_TRY(hipSetDevice(device));
+    std::vector<float> C((size_t)bins * bins, 0.0f), R((size_t)bins * bins, 0.0f);
+    for (uint32_t x = 0; x < bins; ++x)
+        for (uint32_t y = 0; y < bins; ++y) {
+            const float c = x == y ? 0.0f : tri[rp_tri_index(x, y)];
+            C[(size_t)x * bins + y] = c;
+            R[(size_t)x * bins + y] = c / hh.temperature;
+        }
+    float *dC = nullptr, *dR = nullptr, *dout = nullptr;
+    uint32_t *dmu = nullptr, *dnu = nullptr, *dit = nullptr;
+    unsigned long long *dstats = nullptr, *dscr = nullptr;
+    const size_t hb = (size_t)pairs * bins * 4;
+    HIP_TRY(hipMalloc(&dC, C.size() * 4));
+    HIP_TRY(hipMalloc(&dR, R.size() * 4));
+    HIP_TRY(hipMalloc(&dout, pairs * 4));
+    HIP_TRY(hipMalloc(&dmu, hb));
+    HIP_TRY(hipMalloc(&dnu, hb));
+    HIP_TRY(hipMalloc(&dstats, 16));
+    HIP_TRY(hipMemset(dstats, 0, 16));
+    HIP_TRY(hipMemcpy(dC, C.data(), C.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dR, R.data(), R.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dmu, mu, hb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dnu, nu, hb, hipMemcpyHostToDevice));
+    Metric M{dC, dR, bins, hh.iterations, hh.tolerance, dstats};
+    hipLaunchKernelGGL(k_pair_sinkhorn, dim3((unsigned)pairs), dim3(64), 0, 0, dmu, dnu, M, divergence, dout, (uint32_t*)nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, pairs * 4, hipMemcpyDeviceToHost));
+    if (iterations) {
+        HIP_TRY(hipMalloc(&dit, pairs * 4));
+        HIP_TRY(hipMalloc(&dscr, pairs * 16));
+        HIP_TRY(hipMemset(dscr, 0, pairs * 16));
+        hipLaunchKernelGGL(k_pair_iters, dim3((unsigned)pairs), dim3(64), 0, 0, dmu, dnu, M, dscr, dit);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(iterations, dit, pairs * 4, hipMemcpyDeviceToHost));
+        (void)hipFree(dit);
+        (void)hipFree(dscr);
+    }
+    (void)hipFree(dC); (void)hipFree(dR); (void)hipFree(dout); (void)hipFree(dmu); (void)hipFree(dnu); (void)hipFree(dstats);
+    return RP_OK;
+}
+}  // namespace
+
+int rp_sinkhorn_divergence(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_t* nu, const float* tri_metric,
+                           const rp_sinkhorn_hp* hp, int device, float* out) {
+    return pair_common(bins, pairs, mu, nu, tri_metric, hp, device, out, nullptr, 1);
+}
+int rp_sinkhorn_cost(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_t* nu, const float* tri_metric,
+                     const rp_sinkhorn_hp* hp, int device, float* out, uint32_t* iterations) {
+    return pair_common(bins, pairs, mu, nu, tri_metric, hp, device, out, iterations, 0);
+}
+int rp_equity_variation(uint32_t bins, uint64_t pairs, const uint32_t* x, const uint32_t* y, int device, float* out) {
+    if (!x || !y || !out || pairs == 0 || bins == 0) return rp::fail(RP_ERR_INVALID, "rp_equity_variation: bad argument");
+    if (rp_device_count() <= 0) return rp::fail(RP_ERR_NO_DEVICE, "rp_equity_variation: no HIP device visible; no CPU fallback");
+    HIP_TRY(hipSetDevice(device));
+    uint32_t *dx = nullptr, *dy = nullptr;
+    float* dout = nullptr;
+    const size_t hb = (size_t)pairs * bins * 4;
+    HIP_TRY(hipMalloc(&dx, hb));
+    HIP_TRY(hipMalloc(&dy, hb));
+    HIP_TRY(hipMalloc(&dout, pairs * 4));
+    HIP_TRY(hipMemcpy(dx, x, hb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dy, y, hb, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_pair_variation, dim3((unsigned)((pairs + 63) / 64)), dim3(64), 0, 0, dx, dy, bins, pairs, dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, pairs * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    return RP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,244 @@
+"""Host mirror of the reference's ``elkan::Elkan`` / ``lloyd::Layer`` / ``lloyd::Sinkhorn`` surface over the C-ABI.
+
+``Layer`` follows crates/lloyd/src/layer.rs + kmeans.rs (``init_centroids`` = k-means++, ``init_bounds``,
+``step`` = one ``Kmeans::next``, ``lookup`` = ``Layer::lookup``, ``metric`` = ``Layer::metric``), the free functions
+follow ``Sinkhorn::divergence`` / ``Coupling::cost`` / ``Equity::variation``.  All compute runs in librp_mi355x.so's
+HIP kernels; there is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib
+
+
+def default_sinkhorn() -> _lib.SinkhornHP:
+    hp = _lib.SinkhornHP()
+    _lib.load().rp_sinkhorn_hp_default(C.byref(hp))
+    return hp
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Layer:
+    """``Layer<K, N>`` (layer.rs:23-33): N histogram points, K centroids, Elkan bounds — resident in HBM."""
+
+    def __init__(self, K: int, counts, kind="sinkhorn", tri=None, hp=None, seed=0, device=0, counts_dev_ptr=None,
+                 shape=None):
+        self._lib = _lib.load()
+        self.hp = hp or default_sinkhorn()
+        self.K = K
+        self._tri = np.ascontiguousarray(tri, dtype=np.float32) if tri is not None else None
+        self._h = C.c_void_p()
+        if counts_dev_ptr is not None:
+            self.N, self.bins = shape
+            _lib.check(self._lib.rp_kmeans_create_device(K, self.N, self.bins, C.c_void_p(counts_dev_ptr),
+                                                         _lib.METRIC[kind], _p(self._tri), C.byref(self.hp), seed,
+                                                         device, C.byref(self._h)))
+        else:
+            counts = np.ascontiguousarray(counts, dtype=np.uint8)
+            self.N, self.bins = counts.shape
+            _lib.check(self._lib.rp_kmeans_create(K, self.N, self.bins, _p(counts), _lib.METRIC[kind], _p(self._tri),
+                                                  C.byref(self.hp), seed, device, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rp_kmeans_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- Elkan / Layer --------------------------------------------------------------------------
+    def init_centroids(self) -> np.ndarray:
+        chosen = np.zeros(self.K, dtype=np.uint64)
+        _lib.check(self._lib.rp_kmeans_init_centroids(self._h, _p(chosen)))
+        return chosen
+
+    def set_centroids(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        _lib.check(self._lib.rp_kmeans_set_centroids(self._h, _p(idx)))
+
+    def init_bounds(self):
+        _lib.check(self._lib.rp_kmeans_init_bounds(self._h))
+
+    def step(self):
+        drift = np.zeros(self.K, dtype=np.float32)
+        sizes = np.zeros(self.K, dtype=np.uint64)
+        re = C.c_double()
+        _lib.check(self._lib.rp_kmeans_step(self._h, _p(drift), _p(sizes), C.byref(re)))
+        return drift, sizes, re.value
+
+    def step_naive(self):
+        _lib.check(self._lib.rp_kmeans_step_naive(self._h))
+
+    def lookup(self):
+        b = np.zeros(self.N, dtype=np.uint8)
+        d = np.zeros(self.N, dtype=np.float32)
+        _lib.check(self._lib.rp_kmeans_assign(self._h, _p(b), _p(d)))
+        return b, d
+
+    assign = lookup
+
+    def bounds(self):
+        j = np.zeros(self.N, dtype=np.uint8)
+        u = np.zeros(self.N, dtype=np.float32)
+        lo = np.zeros((self.N, self.K), dtype=np.float32)
+        _lib.check(self._lib.rp_kmeans_bounds(self._h, _p(j), _p(u), _p(lo)))
+        return j, u, lo
+
+    def centroids(self):
+        c = np.zeros((self.K, self.bins), dtype=np.uint32)
+        w = np.zeros(self.K, dtype=np.uint64)
+        _lib.check(self._lib.rp_kmeans_centroids(self._h, _p(c), _p(w)))
+        return c, w
+
+    def metric(self) -> np.ndarray:
+        t = np.zeros(self.K * (self.K - 1) // 2, dtype=np.float32)
+        _lib.check(self._lib.rp_kmeans_metric(self._h, _p(t)))
+        return t
+
+    def rms(self) -> float:
+        out = C.c_float()
+        _lib.check(self._lib.rp_kmeans_rms(self._h, C.byref(out)))
+        return out.value
+
+    def stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _lib.check(self._lib.rp_kmeans_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # ---- multi-GPU exchange --------------------------------------------------------
+    def partial_bytes(self) -> int:
+        n = C.c_size_t()
+        _lib.check(self._lib.rp_kmeans_partial_bytes(self._h, C.byref(n)))
+        return n.value
+
+    def step_local(self, partial_dev_ptr: int):
+        _lib.check(self._lib.rp_kmeans_step_local(self._h, C.c_void_p(partial_dev_ptr)))
+
+    def step_finish(self, reduced_dev_ptr: int):
+        drift = np.zeros(self.K, dtype=np.float32)
+        sizes = np.zeros(self.K, dtype=np.uint64)
+        re = C.c_double()
+        _lib.check(self._lib.rp_kmeans_step_finish(self._h, C.c_void_p(reduced_dev_ptr), _p(drift), _p(sizes),
+                                                   C.byref(re)))
+        return drift, sizes, re.value
+
+    def set_stream(self, hip_stream_ptr):
+        _lib.check(self._lib.rp_kmeans_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    # ---- profiling hooks ------------------------------------------------------------------------
+    def profile(self, enable=True):
+        _lib.check(self._lib.rp_kmeans_profile(self._h, 1 if enable else 0))
+
+    def kernel_time(self, name: str):
+        ms, n = C.c_double(), C.c_uint64()
+        _lib.check(self._lib.rp_kmeans_kernel_time(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def sinkhorn_divergence(mu, nu, tri, hp=None, device=0) -> np.ndarray:
+    """``Sinkhorn::divergence`` (sinkhorn.rs:166-171) for P pairs: mu, nu are (P, bins) u32 counts."""
+    mu = np.ascontiguousarray(np.atleast_2d(mu), dtype=np.uint32)
+    nu = np.ascontiguousarray(np.atleast_2d(nu), dtype=np.uint32)
+    tri = np.ascontiguousarray(tri, dtype=np.float32)
+    hp = hp or default_sinkhorn()
+    out = np.zeros(mu.shape[0], dtype=np.float32)
+    _lib.check(_lib.load().rp_sinkhorn_divergence(mu.shape[1], mu.shape[0], _p(mu), _p(nu), _p(tri), C.byref(hp),
+                                                  device, _p(out)))
+    return out
+
+
+def sinkhorn_cost(mu, nu, tri, hp=None, device=0):
+    """``Coupling::minimize().cost()`` (sinkhorn.rs:194-218) for P pairs, and the iterations each solve used."""
+    mu = np.ascontiguousarray(np.atleast_2d(mu), dtype=np.uint32)
+    nu = np.ascontiguousarray(np.atleast_2d(nu), dtype=np.uint32)
+    tri = np.ascontiguousarray(tri, dtype=np.float32)
+    hp = hp or default_sinkhorn()
+    out = np.zeros(mu.shape[0], dtype=np.float32)
+    it = np.zeros(mu.shape[0], dtype=np.uint32)
+    _lib.check(_lib.load().rp_sinkhorn_cost(mu.shape[1], mu.shape[0], _p(mu), _p(nu), _p(tri), C.byref(hp), device,
+                                            _p(out), _p(it)))
+    return out, it
+
+
+def equity_variation(x, y, device=0) -> np.ndarray:
+    """``Equity::variation`` (equity.rs:41-53) for P pairs of equal-width histograms."""
+    x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.uint32)
+    y = np.ascontiguousarray(np.atleast_2d(y), dtype=np.uint32)
+    out = np.zeros(x.shape[0], dtype=np.float32)
+    _lib.check(_lib.load().rp_equity_variation(x.shape[1], x.shape[0], _p(x), _p(y), device, _p(out)))
+    return out
+
+
+def smoke(oracle) -> None:
+    """Tiny k-means on device 0 checked bit for bit against the CPU oracle (called by __graft_entry__.smoke)."""
+    from lloyd_fixtures import flop_like_points, smooth_metric
+
+    bins, K, N = 32, 4, 96
+    pts = flop_like_points(N, bins=bins, mass=20, seed=5)
+    tri = smooth_metric(bins, 5)
+    dev = Layer(K, pts, "sinkhorn", tri, seed=9)
+    ora = oracle.OracleKmeans(K, pts, "sinkhorn", tri, seed=9)
+    assert np.array_equal(dev.init_centroids(), ora.init_centroids()), "k-means++ picks differ"
+    dev.init_bounds()
+    ora.init_bounds()
+    for _ in range(2):
+        d1, s1, m1 = dev.step()
+        d2, s2, m2 = ora.step()
+        assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32)) and np.array_equal(s1, s2) and m1 == m2
+    b1, _ = dev.lookup()
+    b2, _ = ora.assign()
+    assert np.array_equal(b1, b2), "bucket assignments differ"
+    print(f"smoke lloyd ok: K={K} N={N} bins={bins} distances={dev.stats()[0]}")
+    dev.close()
+
+
+def bench_slice(n_points: int = 4096, K: int = 256, bins: int = 256, iters: int = 2, seed: int = 0xF10F):
+    """points/sec of Elkan iterations on a bounded slice of the flop-street configuration (BASELINE configs[2]):
+    K = 256 centroids, 256-bin histograms of mass 47, Sinkhorn T=0.025 / <=128 iterations / tol 5e-4."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from lloyd_fixtures import flop_like_points, smooth_metric
+
+    pts = flop_like_points(n_points, bins=bins, mass=47, seed=seed)
+    tri = smooth_metric(bins, 1)
+    layer = Layer(K, pts, "sinkhorn", tri, seed=seed)
+    rng = np.random.default_rng(seed)
+    layer.set_centroids(rng.choice(n_points, size=K, replace=False).astype(np.uint64))
+    t0 = time.perf_counter()
+    layer.init_bounds()
+    t_bounds = time.perf_counter() - t0
+    d0, i0 = layer.stats()
+    layer.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        layer.step()
+    dt = time.perf_counter() - t0
+    d1, i1 = layer.stats()
+    step_ms, step_n = layer.kernel_time("step")
+    pw_ms, pw_n = layer.kernel_time("pairwise")
+    bd_ms, bd_n = layer.kernel_time("bounds")
+    layer.profile(False)
+    out = {
+        "metric": "kmeans_points_per_sec",
+        "value": n_points * iters / dt,
+        "unit": "points/s",
+        "workload": f"flop-layer slice: N={n_points} of 1286792, K={K}, bins={bins}, mass 47, Sinkhorn EMD, "
+                    f"{iters} Elkan iterations after init_bounds",
+        "init_bounds_points_per_sec": n_points / t_bounds,
+        "init_bounds_distances_per_sec": n_points * K / t_bounds,
+        "distances": d1 - d0,
+        "sinkhorn_iterations": i1 - i0,
+        "kernels_ms": {"step": step_ms / max(step_n, 1), "pairwise": pw_ms / max(pw_n, 1),
+                       "bounds": bd_ms / max(bd_n, 1)},
+    }
+    layer.close()
+    return out

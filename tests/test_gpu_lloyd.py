@@ -1,0 +1,196 @@
+"""GPU parity: the HIP lloyd path (through the C-ABI) against the CPU oracle — bit-exact.
+
+Every f32 the kernels produce follows the oracle's (= the reference's) operation order, so Sinkhorn costs,
+divergences, Elkan bounds, drifts and bucket assignments must be IDENTICAL, not merely close.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from lloyd_fixtures import flop_hist, flop_like_points, flop_metric, random_metric, smooth_metric, turn_like_points
+from robopoker_amd import lloyd
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_sinkhorn_fixture_bit_exact_and_properties(gpu):
+    # the reference's closed-form fixture (sinkhorn.rs:240-293)
+    tri = flop_metric()
+    mu = flop_hist([(0, 3), (5, 1), (12, 4)])
+    nu = flop_hist([(2, 2), (8, 5), (20, 1), (24, 3)])
+    h = flop_hist([(0, 3), (5, 1), (12, 4), (24, 2)])
+    d = lloyd.sinkhorn_divergence(np.stack([mu, nu, h]), np.stack([nu, mu, h]), tri)
+    exp = [oracle.sinkhorn_divergence(mu, nu, tri), oracle.sinkhorn_divergence(nu, mu, tri),
+           oracle.sinkhorn_divergence(h, h, tri)]
+    assert np.array_equal(bits(d), bits(exp))
+    assert abs(d[2]) < 1e-4 and abs(d[0] - d[1]) < 1e-3 and d[0] > 0
+    c, it = lloyd.sinkhorn_cost(np.stack([mu, h]), np.stack([nu, h]), tri)
+    for k, (a, b) in enumerate([(mu, nu), (h, h)]):
+        ec, eit = oracle.sinkhorn_cost(a, b, tri)
+        assert bits(c[k]) == bits(ec) and it[k] == eit
+
+
+@pytest.mark.parametrize("bins,nnz_a,nnz_b", [(32, 5, 9), (101, 30, 60), (256, 47, 256), (256, 256, 47), (64, 1, 64)])
+def test_sinkhorn_random_pairs_bit_exact(gpu, bins, nnz_a, nnz_b):
+    rng = np.random.default_rng(bins * 1000 + nnz_a)
+    tri = random_metric(bins, rng)
+    P = 6
+    mu = np.zeros((P, bins), dtype=np.uint32)
+    nu = np.zeros((P, bins), dtype=np.uint32)
+    for p in range(P):
+        mu[p, rng.choice(bins, nnz_a, replace=False)] = rng.integers(1, 9, nnz_a)
+        nu[p, rng.choice(bins, nnz_b, replace=False)] = rng.integers(1, 2000, nnz_b)
+    hp = oracle.default_sinkhorn()
+    hp.iterations = 24  # keeps the CPU oracle quick; the cap itself is part of the checked behaviour
+    d = lloyd.sinkhorn_divergence(mu, nu, tri, hp)
+    c, it = lloyd.sinkhorn_cost(mu, nu, tri, hp)
+    for p in range(P):
+        assert bits(d[p]) == bits(oracle.sinkhorn_divergence(mu[p], nu[p], tri, hp))
+        ec, eit = oracle.sinkhorn_cost(mu[p], nu[p], tri, hp)
+        assert bits(c[p]) == bits(ec) and it[p] == eit
+
+
+def test_empty_histogram_costs_zero(gpu):
+    tri = flop_metric()
+    d = lloyd.sinkhorn_divergence(flop_hist([]), flop_hist([(2, 2), (8, 5)]), tri)
+    assert d[0] == 0.0
+
+
+def test_equity_variation_bit_exact(gpu):
+    pts = turn_like_points(64, bins=101, mass=46, seed=3).astype(np.uint32)
+    x, y = pts[:32], pts[32:]
+    d = lloyd.equity_variation(x, y)
+    exp = [oracle.equity_variation(x[i], y[i]) for i in range(32)]
+    assert np.array_equal(bits(d), bits(exp))
+    assert np.array_equal(bits(lloyd.equity_variation(y, x)), bits(d))  # exactly symmetric (emd.rs:72-80)
+    assert np.all(lloyd.equity_variation(x, x) == 0.0)
+
+
+def _pair(kind, K, N, bins, mass, seed, iters=None):
+    if kind == "sinkhorn":
+        pts = flop_like_points(N, bins=bins, mass=mass, seed=seed)
+        tri = smooth_metric(bins, seed)
+    else:
+        pts = turn_like_points(N, bins=bins, mass=mass, seed=seed)
+        tri = None
+    hp = oracle.default_sinkhorn()
+    if iters:
+        hp.iterations = iters
+    return (lloyd.Layer(K, pts, kind, tri, hp=hp, seed=seed), oracle.OracleKmeans(K, pts, kind, tri, hp=hp, seed=seed))
+
+
+def _check_state(dev, ora):
+    j1, u1, l1 = dev.bounds()
+    j2, u2, l2 = ora.bounds()
+    assert np.array_equal(j1, j2), "assignments differ"
+    assert np.array_equal(bits(u1), bits(u2)), "upper bounds differ"
+    assert np.array_equal(bits(l1), bits(l2)), "lower bounds differ"
+    c1, w1 = dev.centroids()
+    c2, w2 = ora.centroids()
+    assert np.array_equal(c1, c2) and np.array_equal(w1, w2), "centroids differ"
+
+
+@pytest.mark.parametrize("kind,K,N,bins,mass", [("sinkhorn", 5, 150, 32, 20), ("sinkhorn", 70, 200, 48, 24),
+                                                ("variation", 8, 2048, 101, 46), ("variation", 130, 700, 101, 46)])
+def test_elkan_iterations_bit_exact(gpu, kind, K, N, bins, mass):
+    dev, ora = _pair(kind, K, N, bins, mass, seed=K + N, iters=16)
+    assert np.array_equal(dev.init_centroids(), ora.init_centroids()), "k-means++ picks differ"
+    dev.init_bounds()
+    ora.init_bounds()
+    _check_state(dev, ora)
+    for _ in range(4):
+        d1, s1, m1 = dev.step()
+        d2, s2, m2 = ora.step()
+        assert np.array_equal(bits(d1), bits(d2)), "drift differs"
+        assert np.array_equal(s1, s2) and m1 == m2
+        _check_state(dev, ora)
+    b1, dd1 = dev.lookup()
+    b2, dd2 = ora.assign()
+    assert np.array_equal(b1, b2) and np.array_equal(bits(dd1), bits(dd2))
+    assert np.array_equal(bits(dev.metric()), bits(ora.metric()))
+    assert bits(dev.rms()) == bits(ora.rms())
+
+
+def test_elkan_equals_naive_on_device(gpu):
+    # crates/lloyd/src/tests.rs:148-161 (variation layer, K=8, N=2048, 8 iterations) on the GPU
+    pts = turn_like_points(2048, bins=101, mass=46, seed=1)
+    start = np.random.default_rng(1).choice(2048, size=8, replace=False).astype(np.uint64)
+    e = lloyd.Layer(8, pts, "variation", seed=1)
+    n = lloyd.Layer(8, pts, "variation", seed=1)
+    e.set_centroids(start)
+    n.set_centroids(start)
+    e.init_bounds()
+    for _ in range(8):
+        e.step()
+        n.step_naive()
+        ce, we = e.centroids()
+        cn, wn = n.centroids()
+        assert np.array_equal(ce, cn) and np.array_equal(we, wn)
+
+
+def test_step_naive_and_set_centroids_bit_exact(gpu):
+    dev, ora = _pair("sinkhorn", 6, 120, 32, 16, seed=4, iters=12)
+    start = np.arange(0, 120, 20, dtype=np.uint64)
+    dev.set_centroids(start)
+    ora.set_centroids(start)
+    for _ in range(2):
+        dev.step_naive()
+        ora.step_naive()
+        c1, w1 = dev.centroids()
+        c2, w2 = ora.centroids()
+        assert np.array_equal(c1, c2) and np.array_equal(w1, w2)
+
+
+def test_empty_cluster_attracts_like_the_reference(gpu):
+    # duplicate seeds leave one cluster empty after the first step; an empty centroid
+    # has divergence 0 to everything.  The device must reproduce the oracle here too.
+    dev, ora = _pair("sinkhorn", 3, 60, 32, 16, seed=8, iters=12)
+    start = np.array([5, 5, 17], dtype=np.uint64)
+    for km in (dev, ora):
+        km.set_centroids(start)
+        km.init_bounds()
+    for _ in range(3):
+        d1, s1, _ = dev.step()
+        d2, s2, _ = ora.step()
+        assert np.array_equal(bits(d1), bits(d2)) and np.array_equal(s1, s2)
+    b1, _ = dev.lookup()
+    b2, _ = ora.assign()
+    assert np.array_equal(b1, b2)
+
+
+def test_preflop_shape_k_equals_n_metric_only(gpu):
+    # Pref layer: K = N, zero iterations, only Layer::metric runs Sinkhorn
+    pts = flop_like_points(24, bins=40, mass=30, seed=2)
+    tri = smooth_metric(40, 2)
+    hp = oracle.default_sinkhorn()
+    hp.iterations = 16
+    dev = lloyd.Layer(24, pts, "sinkhorn", tri, hp=hp)
+    ora = oracle.OracleKmeans(24, pts, "sinkhorn", tri, hp=hp)
+    idx = np.arange(24, dtype=np.uint64)
+    dev.set_centroids(idx)
+    ora.set_centroids(idx)
+    assert np.array_equal(bits(dev.metric()), bits(ora.metric()))
+
+
+def test_flop_config_slice_properties(gpu):
+    # BASELINE config 3 shape (K=256, 256 bins, mass 47) on a slice: size-independent properties
+    N, K = 1024, 256
+    pts = flop_like_points(N, bins=256, mass=47, seed=0xF10F)
+    tri = smooth_metric(256, 1)
+    dev = lloyd.Layer(K, pts, "sinkhorn", tri, seed=1)
+    dev.set_centroids(np.arange(0, N, N // K, dtype=np.uint64)[:K])
+    dev.init_bounds()
+    j0, u0, _ = dev.bounds()
+    assert np.all(u0 >= 0) and np.all(u0[np.arange(0, N, N // K)[:K]] == 0.0)  # a seed point is at distance 0 of itself
+    drift, sizes, moved = dev.step()
+    c, w = dev.centroids()
+    assert sizes.sum() == N and w.sum() == N * 47 and c.sum() == N * 47  # centroids are exact integer sums
+    assert np.array_equal(c.sum(axis=1), w)
+    j1, _, lo = dev.bounds()
+    for k in range(K):  # recompute() == sum of members, checked on the host
+        assert np.array_equal(c[k], pts[j1 == k].astype(np.uint32).sum(axis=0))
+    assert np.all(lo >= 0) and np.all(drift >= 0) and 0.0 <= moved <= 1.0
