@@ -144,6 +144,7 @@ def main():
     infos = infos1 - infos0
     trav_ms, trav_n = solver.kernel_time("traverse")
     upd_ms, upd_n = solver.kernel_time("update")
+    cmp_ms, cmp_n = solver.kernel_time("compact")
     solver.profile(False)
 
     if world > 1:
@@ -188,7 +189,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                 "bytes_per_update": bytes_per_update, "updates_per_launch": per_launch_updates,
                 "avg_launch_ms": dom_ms,
-                "kernels_ms": {"traverse": trav_avg_ms, "update": upd_avg_ms},
+                "kernels_ms": {"traverse": trav_avg_ms, "compact": cmp_ms / max(cmp_n, 1), "update": upd_avg_ms},
                 "note": "Leduc's tables are 3.8 KB (L2/LDS resident): HBM is not the binding limit of this "
                         "configuration (SURVEY §8d); the update is bound by the serial per-cell chains",
             },

@@ -46,10 +46,23 @@ RP_HD uint32_t rp_f2u(float f) {
     memcpy(&u, &f, 4);
     return u;
 }
-/* f32::max / f32::min semantics for non-NaN inputs (NaN never occurs on the hot path:
- * the reference debug_asserts it, flow.rs:81-82). */
-RP_HD float rp_maxf(float a, float b) { return a > b ? a : b; }
-RP_HD float rp_minf(float a, float b) { return a < b ? a : b; }
+/* f32::max / f32::min for non-NaN inputs (NaN never occurs on the hot path: the reference
+ * debug_asserts it, flow.rs:81-82), specified as IEEE 754-2019 maximum / minimum: +0 is greater
+ * than -0.  On gfx950 this is exactly one v_max_f32 / v_min_f32 (CDNA ISA: max(+0,-0) = +0,
+ * min(+0,-0) = -0); the host spells the same function with compares. */
+#if defined(__HIP_DEVICE_COMPILE__)
+RP_HD float rp_maxf(float a, float b) { return __builtin_fmaxf(a, b); }
+RP_HD float rp_minf(float a, float b) { return __builtin_fminf(a, b); }
+#else
+RP_HD float rp_maxf(float a, float b) {
+    if (a == b) return (rp_f2u(a) & 0x80000000u) ? b : a; /* equal: prefer the one without a sign bit */
+    return a > b ? a : b;
+}
+RP_HD float rp_minf(float a, float b) {
+    if (a == b) return (rp_f2u(a) & 0x80000000u) ? a : b; /* equal: prefer the one with a sign bit */
+    return a < b ? a : b;
+}
+#endif
 RP_HD float rp_absf(float a) { return rp_u2f(rp_f2u(a) & 0x7fffffffu); }
 
 /* e^x, ~1 ulp.  Cephes-style: k = rint(x*log2e), r = x - k*ln2 (two-step),
@@ -121,6 +134,24 @@ RP_HD float rp_logf(float x) {
     res = fmaf(fe, 0.693359375f, res);
     return res;
 }
+
+/* a / b for a correctly rounded reciprocal r = 1.0f / b, without a division on the dependent path
+ * (Markstein's sequence: two fma corrections; the first makes the quotient faithful, the second
+ * correctly rounded).  Bit-identical to IEEE a / b whenever no intermediate under/overflows:
+ * callers guarantee 1 <= b <= 2^32 and (a == 0 or |a| >= 2^-60), see rp_div_by_recip_ok.
+ * Used only to shorten the serial Welford chain of the MCCFR update; the oracle divides plainly. */
+RP_HD float rp_div_by_recip(float a, float b, float r) {
+    float q0 = a * r;
+    float e0 = fmaf(-b, q0, a);
+    float q1 = fmaf(e0, r, q0);
+    float e1 = fmaf(-b, q1, a);
+    return fmaf(e1, r, q1);
+}
+/* the same quotient through one f64 multiply: rd = 1.0 / (double)b.  a * rd carries a relative error
+ * <= 2^-52 while an f32 quotient of f32 operands stays >= 2^-49 (relative) away from every rounding
+ * midpoint, so rounding the product to f32 gives RN(a / b).  Same operand guarantees as above. */
+RP_HD float rp_div_by_recip64(float a, double rd) { return (float)((double)a * rd); }
+RP_HD int rp_div_by_recip_ok(float a) { return a == 0.0f || rp_absf(a) >= 8.6736174e-19f; /* 2^-60 */ }
 
 /* powf(x, 1.5) and powf(x, 0.5) for DiscountedRegret's ALPHA/BETA constants
  * (crates/mccfr/src/regret/discounted.rs:12-13,33,37), via correctly rounded sqrt. */

@@ -205,7 +205,7 @@ RP_API int rp_mccfr_step_apply(rp_mccfr* h, const void* gathered_dev, uint32_t w
 
 /* ---- profiling hooks used by bench.py (HIP events on the launch stream) ------------------------- */
 RP_API int rp_mccfr_profile(rp_mccfr* h, int enable);
-/* name in {"traverse","update"}; total milliseconds and launch count since profiling was enabled */
+/* name in {"traverse","compact","update"}; total milliseconds and launch count since profiling was enabled */
 RP_API int rp_mccfr_kernel_time(rp_mccfr* h, const char* name, double* total_ms, uint64_t* launches);
 
 /* ===================================================================== lloyd ==

@@ -727,3 +727,37 @@ ORA_API void ora_math_selftest(uint64_t n, const float* x, const float* y, float
         out[5 * n + i] = (float)rp_f2u(b);
     }
 }
+
+/* brute-force check of rp_div_by_recip against IEEE division (tests/test_oracle_mccfr.py):
+ * random and adversarial (quotient next to a rounding midpoint) numerators over integer divisors */
+ORA_API uint64_t ora_div_by_recip_mismatches(uint64_t n, uint64_t seed) {
+    uint64_t st = seed | 1ull, bad = 0;
+    for (uint64_t it = 0; it < n; ++it) {
+        st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+        uint64_t r1 = st;
+        st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+        uint64_t r2 = st;
+        uint32_t k;
+        switch (r1 & 7) {
+            case 0: case 1: case 2: k = 1u + (uint32_t)((r1 >> 8) % 16777216u); break;
+            case 3: k = 16777215u - (uint32_t)((r1 >> 8) % 64u); break;
+            case 4: k = (1u << (1 + ((r1 >> 8) % 24))) - 1u; break;
+            case 5: k = 1u + (uint32_t)((r1 >> 8) % 4096u); break;
+            default: k = (uint32_t)(r1 >> 20) | 1u; break;
+        }
+        float b = (float)k, a;
+        if (r2 & 1) { /* adversarial: a ~= b * (odd 25-bit integer) * 2^-j */
+            uint32_t m = (1u << 24) | (uint32_t)((r2 >> 8) & 0xffffffu) | 1u;
+            a = (float)((double)b * ldexp((double)m, -(int)((r2 >> 40) % 60)));
+            if ((r2 >> 60) & 1) a = rp_u2f(rp_f2u(a) + (((r2 >> 61) & 1) ? 1u : 0xffffffffu));
+        } else {
+            int e = (int)((r2 >> 40) % 60) - 50;
+            a = rp_u2f(((uint32_t)(e + 127) << 23) | (uint32_t)((r2 >> 8) & 0x7fffffu));
+        }
+        if ((r2 >> 62) & 1) a = -a;
+        if (!rp_div_by_recip_ok(a)) continue;
+        if (rp_f2u(rp_div_by_recip(a, b, 1.0f / b)) != rp_f2u(a / b)) bad += 1;
+        if (rp_f2u(rp_div_by_recip64(a, 1.0 / (double)b)) != rp_f2u(a / b)) bad += 1;
+    }
+    return bad;
+}

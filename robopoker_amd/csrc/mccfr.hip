@@ -9,10 +9,11 @@
 //                tables are read through L1/L2.  Each walker infoset is evaluated exactly as CfrFlow::dfs /
 //                recursed_value / ancestor_reach do (flow.rs:64-87,166-216) — same f32 operation order —
 //                by a top-down reach sweep and a bottom-up value sweep over the contiguous subtree.
-//   k_update     one WORKGROUP per infoset: Decisions of the batch are compacted in tree-id order
-//                (slot map -> block scan -> LDS staging) and applied by 3*A "chain" lanes, one per table
-//                cell, sequentially: this is the reference's order-dependent semantics
-//                (R <- max(R*d + delta, floor) per touch), bit for bit.
+//   k_count / k_scan / k_compact   stable counting sort of the batch's Decisions into one tree-id-ordered
+//                segment per infoset (slot map -> chunk counts -> offsets -> scatter), all CUs busy.
+//   k_chain      one workgroup per infoset streams its segment through LDS tiles; one lane per table cell
+//                applies the touches sequentially: the reference's order-dependent semantics
+//                (R <- max(R*d + delta, floor) per touch, Welford payoff mean), bit for bit.
 //   k_summarize / k_fold   the multi-GPU exchange: per-cell composed maps.
 //
 // Everything f32 is spelled with the primitives of include/rp_math.h and compiled -ffp-contract=off.
@@ -106,6 +107,8 @@ __device__ uint32_t d_sample_mask(const DevGame& g, const DevTables& t, const St
     }
     return mask ? mask : all;
 }
+
+__device__ __forceinline__ uint32_t lane_of() { return threadIdx.x & 63u; }
 
 #define META_PARENT(m) ((m)&0xffu)
 #define META_EDGE(m) (((m) >> 8) & 0xffu)
@@ -332,197 +335,407 @@ __host__ __device__ inline float regret_floor_of(int R, float regret_min) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// compaction of one infoset's Decisions in tree-id order into LDS (shared by k_update / k_summarize)
+// Update pipeline (Solver::update_{regret,weight,payoff,visits}, solver.rs:96-105,143-192):
+//   k_count    per (infoset, 1024-tree chunk): how many trees of the chunk produced Decisions for it
+//   k_scan     per infoset: exclusive scan of the chunk counts -> offsets, segment length
+//   k_compact  scatter the Decisions into ONE tree-id-ordered segment per infoset (stable counting sort)
+//   k_chain    per infoset: stream the segment through LDS tiles and apply the touches sequentially,
+//              one lane per table cell (the reference's order-dependent semantics, bit for bit)
 // ------------------------------------------------------------------------------------------------
-#define UPD_THREADS 256
-#define UPD_TREES_PER_THREAD 4
-#define UPD_CHUNK (UPD_THREADS * UPD_TREES_PER_THREAD)
+#define CH_TREES 1024u   // trees per compaction chunk
+#define CH_THREADS 256u
 
-struct Stage {
-    float* regret;   // [A][UPD_CHUNK]
-    float* policy;   // [A][UPD_CHUNK]
-    float* payoff;   // [UPD_CHUNK]
-    uint32_t* mask;  // [UPD_CHUNK]
+struct DevSorted {
+    float* rw;         // [cap][2A]  per Decisions: regret delta a=0..A-1, then weight delta a=0..A-1
+    uint32_t* mask;    // [cap]      edges present in the regret vector
+    float* payoff;     // [cap]
+    uint32_t* counts;  // [n_infos][n_chunks]
+    uint32_t* offs;    // [n_infos][n_chunks]
+    uint32_t* total;   // [n_infos]  segment length
+    uint32_t n_chunks;
 };
 
-// returns the number of staged Decisions of `info` among trees [base, base + UPD_CHUNK)
-__device__ uint32_t stage_chunk(const DevDecisions& dc, uint32_t A, uint32_t nact, uint32_t info, uint32_t base,
-                                uint32_t batch, const Stage& s, uint32_t* wave_tot) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t t0 = base + tid * UPD_TREES_PER_THREAD;
+__device__ __forceinline__ uint32_t chunk_slots(const DevDecisions& dc, uint32_t info, uint32_t t0, uint32_t batch) {
     uint32_t slots = 0;
-    if (t0 + UPD_TREES_PER_THREAD <= batch) {
+    if (t0 + 4 <= batch) {
         slots = *reinterpret_cast<const uint32_t*>(&dc.slotmap[(size_t)info * dc.stride + t0]);
     } else {
-        for (uint32_t k = 0; k < UPD_TREES_PER_THREAD; ++k)
+        for (uint32_t k = 0; k < 4; ++k)
             if (t0 + k < batch) slots |= (uint32_t)dc.slotmap[(size_t)info * dc.stride + t0 + k] << (8 * k);
     }
-    uint32_t cnt = 0;
-    for (uint32_t k = 0; k < UPD_TREES_PER_THREAD; ++k) cnt += ((slots >> (8 * k)) & 0xffu) != 0;
-    // block-wide exclusive scan of cnt in thread order (= tree order)
-    uint32_t incl = cnt;
+    return slots;
+}
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t v) {
+    return ((v & 0xffu) != 0) + ((v & 0xff00u) != 0) + ((v & 0xff0000u) != 0) + ((v & 0xff000000u) != 0);
+}
+// block-wide exclusive scan over CH_THREADS threads in thread order; returns (exclusive prefix, total)
+__device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* wave_tot, uint32_t* total) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t incl = v;
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t o = __shfl_up(incl, d, 64);
         if ((int)(tid & 63) >= d) incl += o;
     }
-    const uint32_t wave = tid >> 6;
-    if ((tid & 63) == 63) wave_tot[wave] = incl;
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
     __syncthreads();
-    uint32_t wbase = 0, total = 0;
-    for (uint32_t w = 0; w < UPD_THREADS / 64; ++w) {
+    uint32_t wbase = 0, tot = 0;
+    for (uint32_t w = 0; w < CH_THREADS / 64; ++w) {
         const uint32_t c = wave_tot[w];
-        if (w < wave) wbase += c;
-        total += c;
+        if (w < (tid >> 6)) wbase += c;
+        tot += c;
     }
-    uint32_t rank = wbase + incl - cnt;
-    for (uint32_t k = 0; k < UPD_TREES_PER_THREAD; ++k) {
+    __syncthreads();
+    *total = tot;
+    return wbase + incl - v;
+}
+
+__global__ __launch_bounds__(CH_THREADS) void k_count(DevGame g, DevDecisions dc, DevSorted so, StepParams p) {
+    __shared__ uint32_t wave_tot[CH_THREADS / 64];
+    const uint32_t info = blockIdx.y, chunk = blockIdx.x;
+    if (g.info_player[info] != p.walker) return;
+    const uint32_t t0 = chunk * CH_TREES + threadIdx.x * 4;
+    uint32_t cnt = nonzero_bytes(chunk_slots(dc, info, t0, p.batch));
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) so.counts[(size_t)info * so.n_chunks + chunk] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+__global__ __launch_bounds__(CH_THREADS) void k_scan(DevGame g, DevSorted so, StepParams p) {
+    __shared__ uint32_t wave_tot[CH_THREADS / 64];
+    const uint32_t info = blockIdx.x;
+    if (g.info_player[info] != p.walker) {
+        if (threadIdx.x == 0) so.total[info] = 0;
+        return;
+    }
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < so.n_chunks; base += CH_THREADS) {
+        const uint32_t c = base + threadIdx.x;
+        const uint32_t v = c < so.n_chunks ? so.counts[(size_t)info * so.n_chunks + c] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_exscan(v, wave_tot, &tot);
+        if (c < so.n_chunks) so.offs[(size_t)info * so.n_chunks + c] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) so.total[info] = carry;
+}
+
+__global__ __launch_bounds__(CH_THREADS) void k_compact(DevGame g, DevDecisions dc, DevSorted so, StepParams p) {
+    __shared__ uint32_t wave_tot[CH_THREADS / 64];
+    __shared__ uint32_t sh_base;
+    const uint32_t info = blockIdx.y, chunk = blockIdx.x;
+    if (g.info_player[info] != p.walker) return;
+    // segment base = sum of the lengths of all lower infosets
+    uint32_t part = 0;
+    for (uint32_t i = threadIdx.x; i < info; i += CH_THREADS) part += so.total[i];
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) sh_base = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3] + so.offs[(size_t)info * so.n_chunks + chunk];
+    __syncthreads();
+    const uint32_t A = g.A, nact = g.info_actions[info];
+    const uint32_t t0 = chunk * CH_TREES + threadIdx.x * 4;
+    const uint32_t slots = chunk_slots(dc, info, t0, p.batch);
+    uint32_t tot;
+    uint32_t rank = block_exscan(nonzero_bytes(slots), wave_tot, &tot);
+    const float tf = (float)p.epoch;
+    for (uint32_t k = 0; k < 4; ++k) {
         const uint32_t sl = (slots >> (8 * k)) & 0xffu;
         if (!sl) continue;
         const uint32_t tree = t0 + k, slot = sl - 1;
-        for (uint32_t a = 0; a < nact; ++a) {
-            s.regret[a * UPD_CHUNK + rank] = dc.regret[(slot * A + a) * dc.stride + tree];
-            s.policy[a * UPD_CHUNK + rank] = dc.policy[(slot * A + a) * dc.stride + tree];
+        const size_t pos = (size_t)sh_base + rank;
+        for (uint32_t a = 0; a < A; ++a) {
+            float rd = 0.0f, wd = 0.0f;
+            if (a < nact) {
+                rd = dc.regret[(slot * A + a) * dc.stride + tree];
+                const float sg = dc.policy[(slot * A + a) * dc.stride + tree];
+                // WeightSchedule::accumulate's immediate term (policy/{linear,quadratic}.rs): sigma * t, sigma * t * t
+                wd = p.W == RP_WEIGHT_LINEAR ? sg * tf : (p.W == RP_WEIGHT_QUADRATIC ? sg * tf * tf : sg);
+            }
+            so.rw[pos * 2 * A + a] = rd;
+            so.rw[pos * 2 * A + A + a] = wd;
         }
-        s.payoff[rank] = dc.payoff[slot * dc.stride + tree];
-        s.mask[rank] = dc.mask[slot * dc.stride + tree];
+        so.mask[pos] = dc.mask[slot * dc.stride + tree];
+        so.payoff[pos] = dc.payoff[slot * dc.stride + tree];
         rank += 1;
     }
-    __syncthreads();
-    return total;
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_update: Solver::update_{regret,weight,payoff,visits} in tree-id order (solver.rs:96-105,143-192)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(UPD_THREADS) void k_update(DevGame g, DevTables t, DevDecisions dc, StepParams p) {
+// per-epoch discount constants of a RegretSchedule (regret/{linear,discounted,asymmetric}.rs)
+struct Discount {
+    float pos, neg, zero;
+};
+__device__ __forceinline__ Discount regret_discount(int R, float t) {
+    Discount d{1.0f, 1.0f, 1.0f};
+    const float lin = t / (t + 1.0f);
+    if (R == RP_REGRET_LINEAR) d = Discount{lin, lin, lin};
+    else if (R == RP_REGRET_ASYMMETRIC) d = Discount{1.0f, lin, lin};
+    else if (R == RP_REGRET_DISCOUNTED) {
+        const float xp = rp_pow15(t / 1.0f), xn = rp_pow05(t / 1.0f), xz = t / 1.0f;
+        d = Discount{xp / (xp + 1.0f), xn / (xn + 1.0f), xz / (xz + 1.0f)};
+    }
+    return d;
+}
+__device__ __forceinline__ uint32_t seg_base(const DevSorted& so, uint32_t info) {
+    uint32_t part = 0;
+    for (uint32_t i = lane_of(); i < info; i += 64) part += so.total[i];
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+    return part;
+}
+
+#define TILE_FLOATS 1024u  // regret/weight deltas per LDS tile (16 per lane)
+#define TILE_REGS (TILE_FLOATS / 64u)
+#define TILE_PAD 4u        // row padding of the stream-major tile (keeps 16-B alignment, staggers banks)
+#define PTILE 1024u        // payoffs per LDS tile
+
+// LDS carve of k_chain (bytes): regret/weight tiles, mask tiles, payoff / reciprocal / divisor tiles
+#define CHAIN_TILE_WORDS (TILE_FLOATS + 2u * RP_MAX_ACTIONS * TILE_PAD)
+#define CHAIN_LDS_WORDS (2u * CHAIN_TILE_WORDS + 2u * (TILE_FLOATS / 2u) + 6u * PTILE)
+
+// wave 0: regret + weight cells, universal op acc <- max(acc * d + delta, floor) (x * 1.0f is exact, so Summed /
+// Floored / Constant / Linear-weight schedules are the same instruction stream with d = 1).  wave 1: payoff + visits.
+// Tiles are double buffered: the global loads of tile t+1 are issued into registers BEFORE the chain over tile t
+// and committed to LDS after it, so HBM/L2 latency hides under the serial chain.  In LDS a tile is stream-major
+// ([cell][entry]) so each chain lane reads its own stream 4 entries at a time (ds_read_b128), 16 entries ahead.
+template <bool SIGNED, bool PRUNED>
+__global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted so, StepParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t info = blockIdx.x;
-    if (g.info_player[info] != p.walker) return;  // only walker infosets receive Decisions
-    const uint32_t A = g.A, nact = g.info_actions[info];
-    Stage s;
-    s.regret = reinterpret_cast<float*>(smem);
-    s.policy = s.regret + (size_t)A * UPD_CHUNK;
-    s.payoff = s.policy + (size_t)A * UPD_CHUNK;
-    s.mask = reinterpret_cast<uint32_t*>(s.payoff + UPD_CHUNK);
-    uint32_t* wave_tot = s.mask + UPD_CHUNK;
-
-    const uint32_t tid = threadIdx.x;
-    // chain lanes: [0,A) regret, [A,2A) weight, [2A,3A) payoff+visits; one table cell each
-    const uint32_t kind = tid / A, a = tid % A;
-    const bool chain = tid < 3 * A && a < nact;
-    const size_t cell = (size_t)info * A + a;
-    float acc = 0.0f;
-    uint32_t visits = 0;
-    if (chain) {
-        if (kind == 0) acc = t.regret[cell];
-        else if (kind == 1) acc = t.weight[cell];
-        else {
-            acc = t.payoff[cell];
+    if (g.info_player[info] != p.walker) return;
+    const uint32_t len = so.total[info];
+    if (len == 0) return;
+    const uint32_t A = g.A, nact = g.info_actions[info], W2 = 2 * A;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const size_t base = seg_base(so, info);
+    const float tf = (float)p.epoch;
+    float* tile = reinterpret_cast<float*>(smem);                                  // [2][CHAIN_TILE_WORDS]
+    uint32_t* mtile = reinterpret_cast<uint32_t*>(tile + 2 * CHAIN_TILE_WORDS);    // [2][TILE_FLOATS / 2]
+    float* ptile = reinterpret_cast<float*>(mtile + TILE_FLOATS);                  // [2][3][PTILE]: payoff f32, 1/b f64
+    if (wave == 0) {
+        const uint32_t T = (TILE_FLOATS / W2) & ~3u;  // Decisions per tile, multiple of 4
+        const uint32_t TP = T + TILE_PAD;             // row stride of the stream-major tile
+        const bool isreg = lane < A;
+        const uint32_t a = lane % A;
+        const bool chain = lane < W2 && a < nact;
+        const size_t cell = (size_t)info * A + a;
+        float acc = 0.0f, fl = RP_EPSILON;
+        Discount d{1.0f, 1.0f, 1.0f};
+        if (chain) {
+            if (isreg) {
+                acc = t.regret[cell];
+                fl = regret_floor_of(p.R, p.regret_min);
+                d = regret_discount(p.R, tf);
+            } else {
+                acc = t.weight[cell];
+                const float dw = p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f;
+                d = Discount{dw, dw, dw};
+            }
+        }
+        const uint32_t ntiles = (len + T - 1) / T;
+        float rg[TILE_REGS];
+        uint32_t mk[TILE_REGS / 2];
+        auto issue = [&](uint32_t tl) {
+            const size_t e0 = (base + (size_t)tl * T) * W2;
+            const uint32_t ne = min(T, len - tl * T), nfl = ne * W2;
+#pragma unroll
+            for (uint32_t r = 0; r < TILE_REGS; ++r) {
+                const uint32_t k = lane + 64 * r;
+                rg[r] = k < nfl ? so.rw[e0 + k] : 0.0f;
+            }
+            if (PRUNED) {
+#pragma unroll
+                for (uint32_t r = 0; r < TILE_REGS / 2; ++r) {
+                    const uint32_t k = lane + 64 * r;
+                    mk[r] = k < ne ? so.mask[base + (size_t)tl * T + k] : 0u;
+                }
+            }
+        };
+        auto commit = [&](uint32_t buf) {  // entry-major registers -> stream-major LDS
+#pragma unroll
+            for (uint32_t r = 0; r < TILE_REGS; ++r) {
+                const uint32_t k = lane + 64 * r;
+                if (k < T * W2) tile[buf * CHAIN_TILE_WORDS + (k % W2) * TP + k / W2] = rg[r];
+            }
+            if (PRUNED) {
+#pragma unroll
+                for (uint32_t r = 0; r < TILE_REGS / 2; ++r) mtile[buf * (TILE_FLOATS / 2) + lane + 64 * r] = mk[r];
+            }
+        };
+        auto step = [&](float delta, uint32_t m) {
+            float dd = d.zero;
+            if (SIGNED) dd = acc > 0.0f ? d.pos : (acc < 0.0f ? d.neg : d.zero);
+            const float nv = rp_maxf(acc * dd + delta, fl);
+            if (PRUNED) acc = (isreg && !((m >> a) & 1u)) ? acc : nv;
+            else acc = nv;
+        };
+        issue(0);
+        commit(0);
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t tl = 0; tl < ntiles; ++tl) {
+            const uint32_t buf = tl & 1u;
+            const bool more = tl + 1 < ntiles;
+            if (more) issue(tl + 1);
+            const uint32_t n = min(T, len - tl * T);
+            const float* row = tile + buf * CHAIN_TILE_WORDS + (chain ? lane : 0u) * TP;
+            const uint32_t* mrow = mtile + buf * (TILE_FLOATS / 2);
+            if (chain) {
+                const uint32_t n16 = n & ~15u;
+                uint32_t i = 0;
+                if (n16) {
+                    float4 c0 = *reinterpret_cast<const float4*>(row + 0), c1 = *reinterpret_cast<const float4*>(row + 4);
+                    float4 c2 = *reinterpret_cast<const float4*>(row + 8), c3 = *reinterpret_cast<const float4*>(row + 12);
+                    for (; i < n16; i += 16) {
+                        float4 x0 = c0, x1 = c1, x2 = c2, x3 = c3;
+                        if (i + 16 < n16) {  // the next 16 entries travel from LDS while these 16 are chained
+                            c0 = *reinterpret_cast<const float4*>(row + i + 16);
+                            c1 = *reinterpret_cast<const float4*>(row + i + 20);
+                            c2 = *reinterpret_cast<const float4*>(row + i + 24);
+                            c3 = *reinterpret_cast<const float4*>(row + i + 28);
+                        }
+                        uint32_t m[16];
+#pragma unroll
+                        for (uint32_t q = 0; q < 16; ++q) m[q] = PRUNED ? mrow[i + q] : 0xffffffffu;
+                        step(x0.x, m[0]); step(x0.y, m[1]); step(x0.z, m[2]); step(x0.w, m[3]);
+                        step(x1.x, m[4]); step(x1.y, m[5]); step(x1.z, m[6]); step(x1.w, m[7]);
+                        step(x2.x, m[8]); step(x2.y, m[9]); step(x2.z, m[10]); step(x2.w, m[11]);
+                        step(x3.x, m[12]); step(x3.y, m[13]); step(x3.z, m[14]); step(x3.w, m[15]);
+                    }
+                }
+                for (; i < n; ++i) step(row[i], PRUNED ? mrow[i] : 0xffffffffu);
+            }
+            if (more) commit(buf ^ 1u);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (chain) {
+            if (isreg) t.regret[cell] = acc;
+            else t.weight[cell] = acc;
+        }
+    } else {
+        // Welford mean with the pre-increment visit count (solver.rs:174-192): ev += (payoff - ev) / (n + 1).
+        // The divisor sequence is known in advance, so the whole wave precomputes b = (float)(n+1) and the
+        // correctly rounded 1/b per entry, and the serial chain divides with rp_div_by_recip (== IEEE a/b).
+        const bool chain = lane < nact;
+        const size_t cell = (size_t)info * A + lane;
+        float ev = 0.0f;
+        uint32_t visits = 0;
+        if (chain) {
+            ev = t.payoff[cell];
             visits = t.visits[cell];
         }
-    }
-    const float tf = (float)p.epoch;
-    const float floor_r = regret_floor_of(p.R, p.regret_min);
-    for (uint32_t base = 0; base < p.batch; base += UPD_CHUNK) {
-        const uint32_t n = stage_chunk(dc, A, nact, info, base, p.batch, s, wave_tot);
-        if (chain) {
-            if (kind == 0) {
-                for (uint32_t i = 0; i < n; ++i)
-                    if ((s.mask[i] >> a) & 1u) acc = d_regret_gain(p.R, acc, s.regret[a * UPD_CHUNK + i], tf, floor_r);
-            } else if (kind == 1) {
-                for (uint32_t i = 0; i < n; ++i) acc = d_weight_learn(p.W, acc, s.policy[a * UPD_CHUNK + i], tf);
-            } else {
-                for (uint32_t i = 0; i < n; ++i) {  // Welford mean with the pre-increment count (solver.rs:174-192)
-                    acc += (s.payoff[i] - acc) / (float)(visits + 1u);
-                    visits += 1u;
+        const uint32_t v0 = __shfl(visits, 0, 64);
+        const bool uniform = __all(!chain || visits == v0);  // every edge of an infoset is always visited together
+        const float ev_start = ev;
+        bool bad = false;
+        if (uniform) {
+            const uint32_t ntiles = (len + PTILE - 1) / PTILE;
+            float rg[PTILE / 64];
+            auto issue = [&](uint32_t tl) {
+                const uint32_t n = min(PTILE, len - tl * PTILE);
+#pragma unroll
+                for (uint32_t r = 0; r < PTILE / 64; ++r) {
+                    const uint32_t k = lane + 64 * r;
+                    rg[r] = k < n ? so.payoff[base + (size_t)tl * PTILE + k] : 0.0f;
                 }
+            };
+            auto commit = [&](uint32_t tl, uint32_t buf) {
+                float* pt = ptile + buf * 3 * PTILE;
+                double* rt = reinterpret_cast<double*>(pt + PTILE);
+#pragma unroll
+                for (uint32_t r = 0; r < PTILE / 64; ++r) {
+                    const uint32_t k = lane + 64 * r;
+                    const float b = (float)(v0 + tl * PTILE + k + 1u);  // (n + 1) as f32 (solver.rs:179)
+                    pt[k] = rg[r];
+                    rt[k] = 1.0 / (double)b;
+                }
+            };
+            issue(0);
+            commit(0, 0);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t tl = 0; tl < ntiles; ++tl) {
+                const uint32_t buf = tl & 1u;
+                const bool more = tl + 1 < ntiles;
+                if (more) issue(tl + 1);
+                const uint32_t n = min(PTILE, len - tl * PTILE);
+                const float* pt = ptile + buf * 3 * PTILE;
+                const double* rt = reinterpret_cast<const double*>(pt + PTILE);
+#ifndef RP_EXPERIMENT_SKIP_PAYOFF
+                if (chain) {
+                    const uint32_t n4 = n & ~3u;
+                    uint32_t i = 0;
+                    for (; i < n4; i += 4) {
+                        const float4 pv = *reinterpret_cast<const float4*>(pt + i);
+                        const double2 ra = *reinterpret_cast<const double2*>(rt + i);
+                        const double2 rb = *reinterpret_cast<const double2*>(rt + i + 2);
+                        float s;
+                        s = pv.x - ev; bad |= !rp_div_by_recip_ok(s); ev += rp_div_by_recip64(s, ra.x);
+                        s = pv.y - ev; bad |= !rp_div_by_recip_ok(s); ev += rp_div_by_recip64(s, ra.y);
+                        s = pv.z - ev; bad |= !rp_div_by_recip_ok(s); ev += rp_div_by_recip64(s, rb.x);
+                        s = pv.w - ev; bad |= !rp_div_by_recip_ok(s); ev += rp_div_by_recip64(s, rb.y);
+                    }
+                    for (; i < n; ++i) {
+                        const float s = pt[i] - ev;
+                        bad |= !rp_div_by_recip_ok(s);
+                        ev += rp_div_by_recip64(s, rt[i]);
+                    }
+                }
+#endif
+                if (more) commit(tl + 1, buf ^ 1u);
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        __syncthreads();
-    }
-    if (chain) {
-        if (kind == 0) t.regret[cell] = acc;
-        else if (kind == 1) t.weight[cell] = acc;
-        else {
-            t.payoff[cell] = acc;
-            t.visits[cell] = visits;
+        if (chain) {
+            if (!uniform || bad) {  // plain IEEE divisions (never taken in practice; keeps the result exact regardless)
+                ev = ev_start;
+                uint32_t v = visits;
+                for (uint32_t i = 0; i < len; ++i) {
+                    ev += (so.payoff[base + i] - ev) / (float)(v + 1u);
+                    v += 1u;
+                }
+            }
+            t.payoff[cell] = ev;
+            t.visits[cell] = visits + len;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_summarize / k_fold: the multi-GPU exchange (oracle: ora_mccfr_step_world)
+// k_summarize / k_fold: the multi-GPU exchange (oracle: ora_mccfr_step_world).  One wave per infoset
+// composes its tree-ordered segment into F(x) = max(a x + b, m) per table cell.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(UPD_THREADS) void k_summarize(DevGame g, DevDecisions dc, StepParams p, Cell* cells,
-                                                           InfoSum* sums) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__global__ __launch_bounds__(64) void k_summarize(DevGame g, DevSorted so, StepParams p, Cell* cells, InfoSum* sums) {
     const uint32_t info = blockIdx.x;
-    const uint32_t A = g.A, nact = g.info_actions[info];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t kind = tid / A, a = tid % A;
-    const bool chain = tid < 3 * A && a < nact;
+    const uint32_t A = g.A, nact = g.info_actions[info], W2 = 2 * A;
+    const uint32_t lane = threadIdx.x;
     const float NEG_INF = rp_u2f(0xff800000u);
-    if (g.info_player[info] != p.walker) {  // identity maps
-        if (tid < A) {
-            Cell c{1.0f, 0.0f, NEG_INF, 1.0f, 0.0f, NEG_INF, 0u, 0u};
-            cells[(size_t)info * A + tid] = c;
-        }
-        if (tid == 0) sums[info] = InfoSum{0u, 0.0f};
-        return;
-    }
-    Stage s;
-    s.regret = reinterpret_cast<float*>(smem);
-    s.policy = s.regret + (size_t)A * UPD_CHUNK;
-    s.payoff = s.policy + (size_t)A * UPD_CHUNK;
-    s.mask = reinterpret_cast<uint32_t*>(s.payoff + UPD_CHUNK);
-    uint32_t* wave_tot = s.mask + UPD_CHUNK;
-
+    const bool walker = g.info_player[info] == p.walker;
+    const uint32_t len = walker ? so.total[info] : 0u;
+    const size_t base = walker ? seg_base(so, info) : 0;
+    const bool isreg = lane < A;
+    const uint32_t a = lane % A;
+    const bool chain = lane < W2 && a < nact;
     const float tf = (float)p.epoch;
-    const float floor_r = regret_floor_of(p.R, p.regret_min);
-    const float dr = p.R == RP_REGRET_LINEAR ? tf / (tf + 1.0f) : 1.0f;
-    const float dw = p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f;
+    const float floor_v = isreg ? regret_floor_of(p.R, p.regret_min) : RP_EPSILON;
+    const float dd = isreg ? (p.R == RP_REGRET_LINEAR ? tf / (tf + 1.0f) : 1.0f) : (p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f);
     float ma = 1.0f, mb = 0.0f, mm = NEG_INF;
     uint32_t cnt = 0;
-    float psum = 0.0f;
-    for (uint32_t base = 0; base < p.batch; base += UPD_CHUNK) {
-        const uint32_t n = stage_chunk(dc, A, nact, info, base, p.batch, s, wave_tot);
-        if (chain) {
-            if (kind == 0) {
-                for (uint32_t i = 0; i < n; ++i) {
-                    if (!((s.mask[i] >> a) & 1u)) continue;
-                    const float dl = s.regret[a * UPD_CHUNK + i];
-                    if (cnt == 0) { ma = dr; mb = dl; mm = floor_r; }
-                    else { ma = ma * dr; mb = mb * dr + dl; mm = rp_maxf(mm * dr + dl, floor_r); }
-                    cnt += 1;
-                }
-            } else if (kind == 1) {
-                for (uint32_t i = 0; i < n; ++i) {
-                    const float sg = s.policy[a * UPD_CHUNK + i];
-                    float dl = sg;
-                    if (p.W == RP_WEIGHT_LINEAR) dl = sg * tf;
-                    else if (p.W == RP_WEIGHT_QUADRATIC) dl = sg * tf * tf;
-                    if (cnt == 0) { ma = dw; mb = dl; mm = RP_EPSILON; }
-                    else { ma = ma * dw; mb = mb * dw + dl; mm = rp_maxf(mm * dw + dl, RP_EPSILON); }
-                    cnt += 1;
-                }
-            } else if (a == 0) {
-                for (uint32_t i = 0; i < n; ++i) {
-                    psum += s.payoff[i];
-                    cnt += 1;
-                }
-            }
-        }
-        __syncthreads();
-    }
     if (chain) {
-        Cell* c = &cells[(size_t)info * A + a];
-        if (kind == 0) { c->ra = ma; c->rb = mb; c->rm = mm; c->rn = cnt; }
-        else if (kind == 1) { c->wa = ma; c->wb = mb; c->wm = mm; c->wn = cnt; }
-        else if (a == 0) sums[info] = InfoSum{cnt, psum};
+        for (uint32_t i = 0; i < len; ++i) {
+            if (isreg && !((so.mask[base + i] >> a) & 1u)) continue;
+            const float dl = so.rw[(base + i) * W2 + lane];
+            if (cnt == 0) { ma = dd; mb = dl; mm = floor_v; }
+            else { ma = ma * dd; mb = mb * dd + dl; mm = rp_maxf(mm * dd + dl, floor_v); }
+            cnt += 1;
+        }
     }
-    if (tid < A && tid >= nact) {
-        Cell c{1.0f, 0.0f, NEG_INF, 1.0f, 0.0f, NEG_INF, 0u, 0u};
-        cells[(size_t)info * A + tid] = c;
+    if (lane < W2) {
+        Cell* c = &cells[(size_t)info * A + a];
+        if (isreg) { c->ra = ma; c->rb = mb; c->rm = mm; c->rn = cnt; }
+        else { c->wa = ma; c->wb = mb; c->wm = mm; c->wn = cnt; }
+    }
+    if (lane == W2) {  // one extra lane sums the payoffs in tree order
+        float psum = 0.0f;
+        for (uint32_t i = 0; i < len; ++i) psum += so.payoff[base + i];
+        sums[info] = InfoSum{len, psum};
     }
 }
 
@@ -590,6 +803,8 @@ struct rp_mccfr {
     void* d_scratch = nullptr;
     void* d_dec = nullptr;
     void* d_summary = nullptr;
+    void* d_sorted = nullptr;
+    DevSorted so{};
     unsigned long long* d_counters = nullptr;
     int R = 0, W = 0, S = 0;
     rp_hyper hp{};
@@ -600,7 +815,7 @@ struct rp_mccfr {
     uint32_t maxdec = 1;
     rp_update_mode mode = RP_UPDATE_ORDERED;
     bool profiling = false;
-    KernelClock clk_traverse, clk_update;
+    KernelClock clk_traverse, clk_compact, clk_update;
 };
 
 namespace {
@@ -610,9 +825,7 @@ int set_device(const rp_mccfr* h) {
     return RP_OK;
 }
 
-size_t update_lds_bytes(uint32_t A) {
-    return ((size_t)2 * A * UPD_CHUNK + UPD_CHUNK) * sizeof(float) + UPD_CHUNK * sizeof(uint32_t) + 64;
-}
+size_t chain_lds_bytes(uint32_t A) { (void)A; return (size_t)CHAIN_LDS_WORDS * 4; }
 
 size_t summary_bytes_of(const rp_mccfr* h) {
     return (size_t)h->tbl.n_infos * h->tbl.max_actions * sizeof(Cell) + (size_t)h->tbl.n_infos * sizeof(InfoSum);
@@ -688,6 +901,22 @@ int alloc_batch_buffers(rp_mccfr* h, uint32_t batch) {
     dc.regret = reinterpret_cast<float*>(d); d += slot_words * A;
     dc.policy = reinterpret_cast<float*>(d); d += slot_words * A;
     dc.slotmap = reinterpret_cast<uint8_t*>(d);
+    // tree-ordered segments: at most maxdec Decisions per tree
+    if (h->d_sorted) HIP_TRY(hipFree(h->d_sorted));
+    h->d_sorted = nullptr;
+    DevSorted& so = h->so;
+    so.n_chunks = (uint32_t)((stride + CH_TREES - 1) / CH_TREES);
+    const size_t cap = slot_words;
+    const size_t nic = (size_t)h->tbl.n_infos * so.n_chunks;
+    const size_t sorted_words = cap * 2 * A + 2 * cap + 2 * nic + h->tbl.n_infos;
+    HIP_TRY(hipMalloc(&h->d_sorted, sorted_words * 4));
+    uint32_t* sw = reinterpret_cast<uint32_t*>(h->d_sorted);
+    so.rw = reinterpret_cast<float*>(sw); sw += cap * 2 * A;
+    so.mask = sw; sw += cap;
+    so.payoff = reinterpret_cast<float*>(sw); sw += cap;
+    so.counts = sw; sw += nic;
+    so.offs = sw; sw += nic;
+    so.total = sw;
     h->capacity = batch;
     return RP_OK;
 }
@@ -743,27 +972,56 @@ int launch_traverse(rp_mccfr* h, const StepParams& p) {
     return RP_OK;
 }
 
+// stable counting sort of the batch's Decisions into per-infoset, tree-ordered segments
+int launch_sort(rp_mccfr* h, const StepParams& p) {
+    const uint32_t nchunks = (h->batch + CH_TREES - 1) / CH_TREES;
+    h->so.n_chunks = nchunks;
+    clock_begin(h, h->clk_compact);
+    hipLaunchKernelGGL(k_count, dim3(nchunks, h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
+    hipLaunchKernelGGL(k_scan, dim3(h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->so, p);
+    hipLaunchKernelGGL(k_compact, dim3(nchunks, h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
+    clock_end(h, h->clk_compact);
+    HIP_TRY(hipGetLastError());
+    return RP_OK;
+}
+
+int launch_chain(rp_mccfr* h, const StepParams& p) {
+    const size_t lds = chain_lds_bytes(h->tbl.max_actions);
+    const bool sgn = h->R == RP_REGRET_DISCOUNTED || h->R == RP_REGRET_ASYMMETRIC;
+    const bool prn = h->S != RP_SAMPLING_EXTERNAL;
+    const dim3 grid(h->tbl.n_infos), block(128);
+    clock_begin(h, h->clk_update);
+    if (sgn && prn) hipLaunchKernelGGL((k_chain<true, true>), grid, block, lds, h->stream, h->g, h->t, h->so, p);
+    else if (sgn) hipLaunchKernelGGL((k_chain<true, false>), grid, block, lds, h->stream, h->g, h->t, h->so, p);
+    else if (prn) hipLaunchKernelGGL((k_chain<false, true>), grid, block, lds, h->stream, h->g, h->t, h->so, p);
+    else hipLaunchKernelGGL((k_chain<false, false>), grid, block, lds, h->stream, h->g, h->t, h->so, p);
+    clock_end(h, h->clk_update);
+    HIP_TRY(hipGetLastError());
+    return RP_OK;
+}
+
+int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev) {
+    unsigned char* blob = reinterpret_cast<unsigned char*>(blob_dev);
+    Cell* cells = reinterpret_cast<Cell*>(blob);
+    InfoSum* sums = reinterpret_cast<InfoSum*>(blob + (size_t)h->tbl.n_infos * h->tbl.max_actions * sizeof(Cell));
+    clock_begin(h, h->clk_update);
+    hipLaunchKernelGGL(k_summarize, dim3(h->tbl.n_infos), dim3(64), 0, h->stream, h->g, h->so, p, cells, sums);
+    clock_end(h, h->clk_update);
+    HIP_TRY(hipGetLastError());
+    return RP_OK;
+}
+
 int enqueue_step(rp_mccfr* h) {
     const StepParams p = make_params(h);
     int rc = launch_traverse(h, p);
-    if (rc) return rc;
-    const size_t lds = update_lds_bytes(h->tbl.max_actions);
+    if (rc || (rc = launch_sort(h, p))) return rc;
     if (h->mode == RP_UPDATE_ORDERED) {
-        clock_begin(h, h->clk_update);
-        hipLaunchKernelGGL(k_update, dim3(h->tbl.n_infos), dim3(UPD_THREADS), lds, h->stream, h->g, h->t, h->dc, p);
-        clock_end(h, h->clk_update);
-        HIP_TRY(hipGetLastError());
+        if ((rc = launch_chain(h, p))) return rc;
     } else {
-        unsigned char* blob = reinterpret_cast<unsigned char*>(h->d_summary);
-        Cell* cells = reinterpret_cast<Cell*>(blob);
-        InfoSum* sums = reinterpret_cast<InfoSum*>(blob + (size_t)h->tbl.n_infos * h->tbl.max_actions * sizeof(Cell));
-        clock_begin(h, h->clk_update);
-        hipLaunchKernelGGL(k_summarize, dim3(h->tbl.n_infos), dim3(UPD_THREADS), lds, h->stream, h->g, h->dc, p, cells,
-                           sums);
+        if ((rc = launch_summarize(h, p, h->d_summary))) return rc;
         const uint32_t ncell = h->tbl.n_infos * h->tbl.max_actions;
-        hipLaunchKernelGGL(k_fold, dim3((ncell + 255) / 256), dim3(256), 0, h->stream, h->g, h->t, blob,
-                           summary_bytes_of(h), 1u);
-        clock_end(h, h->clk_update);
+        hipLaunchKernelGGL(k_fold, dim3((ncell + 255) / 256), dim3(256), 0, h->stream, h->g, h->t,
+                           reinterpret_cast<const unsigned char*>(h->d_summary), summary_bytes_of(h), 1u);
         HIP_TRY(hipGetLastError());
     }
     h->epoch += 1;  // CfrSampling::increment via Solver::advance (solver.rs:103-104)
@@ -894,17 +1152,9 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
         rp_mccfr_destroy(h);
         return rp::fail(RP_ERR_CAPACITY, "rp_mccfr_create: more than 254 walker infosets per tree");
     }
-    // the update kernel stages UPD_CHUNK Decisions in LDS
-    const size_t lds = update_lds_bytes(game->max_actions);
-    if (lds > 160 * 1024) {
+    if (chain_lds_bytes(game->max_actions) > 64 * 1024) {
         rp_mccfr_destroy(h);
-        return rp::fail(RP_ERR_CAPACITY, "rp_mccfr_create: update staging needs %zu B of LDS", lds);
-    }
-    if (lds > 64 * 1024) {
-        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_update), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds));
-        CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_summarize),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        return rp::fail(RP_ERR_CAPACITY, "rp_mccfr_create: chain tiles need %zu B of LDS", chain_lds_bytes(game->max_actions));
     }
     rc = alloc_batch_buffers(h, batch_size);
     if (rc) {
@@ -921,9 +1171,10 @@ int rp_mccfr_destroy(rp_mccfr* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     clock_drain(h->clk_traverse);
+    clock_drain(h->clk_compact);
     clock_drain(h->clk_update);
     void* ptrs[] = {h->d_states, h->d_children, h->d_payoffs, h->d_info_actions, h->d_info_player, h->d_scratch,
-                    h->d_dec, h->d_summary, h->d_counters, h->t.regret, h->t.weight, h->t.payoff, h->t.visits};
+                    h->d_dec, h->d_sorted, h->d_summary, h->d_counters, h->t.regret, h->t.weight, h->t.payoff, h->t.visits};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -947,6 +1198,7 @@ int rp_mccfr_sync(rp_mccfr* h) {
     if (rc) return rc;
     rc = check_device_errors(h);
     clock_drain(h->clk_traverse);
+    clock_drain(h->clk_compact);
     clock_drain(h->clk_update);
     return rc;
 }
@@ -1169,16 +1421,8 @@ int rp_mccfr_step_local(rp_mccfr* h, void* summary_dev) {
     if (rc) return rc;
     if ((rc = composed_supported(h))) return rc;
     const StepParams p = make_params(h);
-    if ((rc = launch_traverse(h, p))) return rc;
-    unsigned char* blob = reinterpret_cast<unsigned char*>(summary_dev);
-    Cell* cells = reinterpret_cast<Cell*>(blob);
-    InfoSum* sums = reinterpret_cast<InfoSum*>(blob + (size_t)h->tbl.n_infos * h->tbl.max_actions * sizeof(Cell));
-    clock_begin(h, h->clk_update);
-    hipLaunchKernelGGL(k_summarize, dim3(h->tbl.n_infos), dim3(UPD_THREADS), update_lds_bytes(h->tbl.max_actions),
-                       h->stream, h->g, h->dc, p, cells, sums);
-    clock_end(h, h->clk_update);
-    HIP_TRY(hipGetLastError());
-    return RP_OK;
+    if ((rc = launch_traverse(h, p)) || (rc = launch_sort(h, p))) return rc;
+    return launch_summarize(h, p, summary_dev);
 }
 
 int rp_mccfr_step_apply(rp_mccfr* h, const void* gathered_dev, uint32_t world) {
@@ -1198,10 +1442,11 @@ int rp_mccfr_profile(rp_mccfr* h, int enable) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     clock_drain(h->clk_traverse);
+    clock_drain(h->clk_compact);
     clock_drain(h->clk_update);
     h->profiling = enable != 0;
-    h->clk_traverse.total_ms = h->clk_update.total_ms = 0.0;
-    h->clk_traverse.launches = h->clk_update.launches = 0;
+    h->clk_traverse.total_ms = h->clk_compact.total_ms = h->clk_update.total_ms = 0.0;
+    h->clk_traverse.launches = h->clk_compact.launches = h->clk_update.launches = 0;
     return RP_OK;
 }
 
@@ -1210,9 +1455,11 @@ int rp_mccfr_kernel_time(rp_mccfr* h, const char* name, double* total_ms, uint64
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     clock_drain(h->clk_traverse);
+    clock_drain(h->clk_compact);
     clock_drain(h->clk_update);
     const KernelClock* c = nullptr;
     if (std::string(name) == "traverse") c = &h->clk_traverse;
+    else if (std::string(name) == "compact") c = &h->clk_compact;
     else if (std::string(name) == "update") c = &h->clk_update;
     else return rp::fail(RP_ERR_INVALID, "rp_mccfr_kernel_time: unknown kernel '%s'", name);
     if (total_ms) *total_ms = c->total_ms;

@@ -183,3 +183,12 @@ def test_composed_world_update_matches_ordered_within_tolerance(leduc):
         np.testing.assert_allclose(ra["regret"], rb["regret"], rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(ra["weight"], rb["weight"], rtol=2e-5, atol=1e-6)
         np.testing.assert_allclose(ra["payoff"], rb["payoff"], rtol=2e-4, atol=2e-5)
+
+
+def test_division_by_reciprocal_is_exact():
+    # rp_math.h's rp_div_by_recip (used on the GPU to keep the Welford chain short) == IEEE division
+    import ctypes as C
+    o = oracle.load()
+    o.ora_div_by_recip_mismatches.restype = C.c_uint64
+    o.ora_div_by_recip_mismatches.argtypes = [C.c_uint64, C.c_uint64]
+    assert o.ora_div_by_recip_mismatches(40_000_000, 12345) == 0
