@@ -108,16 +108,13 @@ def main():
     solver = Solver(g, args.regret, args.weight, args.sampling, batch=args.batch, seed=args.seed, device=local_rank)
 
     if world > 1:
-        solver.set_shard(rank, world)
-        solver.set_stream(torch.cuda.current_stream().cuda_stream)
-        nbytes = solver.summary_bytes()
-        mine = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        gathered = torch.empty(nbytes * world, dtype=torch.uint8, device="cuda")
+        from robopoker_amd.parallel import ShardedSolver
+
+        # tree ids [rank*B, (rank+1)*B); one RCCL all-gather of the per-cell composed maps per step
+        sharded = ShardedSolver(solver, device="cuda", stream_ptr=torch.cuda.current_stream().cuda_stream)
 
         def step():
-            solver.step_local(mine.data_ptr())
-            dist.all_gather_into_tensor(gathered, mine)
-            solver.step_apply(gathered.data_ptr(), world)
+            sharded.step()
 
         def fence():
             torch.cuda.synchronize()

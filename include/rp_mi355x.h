@@ -251,6 +251,21 @@ RP_API int rp_kmeans_destroy(rp_kmeans* h);
 RP_API int rp_kmeans_init_centroids(rp_kmeans* h, uint64_t* chosen);
 /* install centroids = copies of the given points (TestLayer-style explicit seeding, tests.rs:100-102) */
 RP_API int rp_kmeans_set_centroids(rp_kmeans* h, const uint64_t* point_index);
+/* install / read one centroid as an integer histogram (counts[bins] u32): resume, and the multi-GPU
+ * k-means++ where the chosen point lives on another rank */
+RP_API int rp_kmeans_set_centroid(rp_kmeans* h, uint32_t k, const uint32_t* counts);
+RP_API int rp_kmeans_get_point(rp_kmeans* h, uint64_t index, uint32_t* counts);
+/* k-means++ (layer.rs:140-181) one primitive at a time, so a point-sharded job can interleave collectives:
+ *   kpp_begin   potentials <- 1, centroids cleared
+ *   kpp_total   this shard's sum of quantised potentials (exact u64, rp_math.h rp_kpp_quant)
+ *   kpp_pick    first local i whose inclusive quantised prefix exceeds r; its potential <- 0
+ *   kpp_update  potentials <- min(potentials, distance(centroid k, point)^2)
+ * rp_kmeans_init_centroids is exactly: for k in 0..K { total; r = mulhi64(rp_stream(seed,k), total); pick;
+ * set_centroid(k, point); update(k) }. */
+RP_API int rp_kmeans_kpp_begin(rp_kmeans* h);
+RP_API int rp_kmeans_kpp_total(rp_kmeans* h, uint64_t* total);
+RP_API int rp_kmeans_kpp_pick(rp_kmeans* h, uint64_t r, uint64_t* index);
+RP_API int rp_kmeans_kpp_update(rp_kmeans* h, uint32_t k);
 /* Elkan::init_bounds (elkan.rs:39-47) */
 RP_API int rp_kmeans_init_bounds(rp_kmeans* h);
 /* Kmeans::next (kmeans.rs:82-110): step_elkan (elkan.rs:153-168), install centroids, Prior::tally.

@@ -187,6 +187,9 @@ typedef struct ora_kmeans {
     ora_bound* bounds;
     float* lower_store;
     uint8_t* prior; /* Prior<N> (prior.rs:20) */
+    float* pot;     /* k-means++ potentials */
+    float* pw;      /* pairwise scratch of a split step */
+    ora_hist* nc;   /* partial centroid sums of a split step */
     int has_prior;
 } ora_kmeans;
 
@@ -233,7 +236,7 @@ ORA_API ora_kmeans* ora_kmeans_create(uint32_t K, uint64_t N, uint32_t bins, con
 ORA_API void ora_kmeans_destroy(ora_kmeans* h) {
     if (!h) return;
     free(h->tri); free(h->points); free(h->self_p); free(h->cent); free(h->self_c);
-    free(h->bounds); free(h->lower_store); free(h->prior); free(h);
+    free(h->bounds); free(h->lower_store); free(h->prior); free(h->pot); free(h->pw); free(h->nc); free(h);
 }
 
 ORA_API void ora_kmeans_set_centroids(ora_kmeans* h, const uint64_t* idx) {
@@ -241,34 +244,55 @@ ORA_API void ora_kmeans_set_centroids(ora_kmeans* h, const uint64_t* idx) {
     refresh_self_c(h);
 }
 
-/* Layer::init_centroids, k-means++ (layer.rs:140-181).  Draw = rp_math.h fixed-point scheme. */
-ORA_API void ora_kmeans_init_centroids(ora_kmeans* h, uint64_t* chosen) {
-    float* pot = (float*)malloc(4 * h->N);
-    for (uint64_t i = 0; i < h->N; ++i) pot[i] = 1.0f;
-    for (uint32_t k = 0; k < h->K; ++k) {
-        uint64_t total = 0;
-        for (uint64_t i = 0; i < h->N; ++i) total += rp_kpp_quant(pot[i]);
-        uint64_t pick = 0;
-        if (total > 0) {
-            uint64_t r = rp_mulhi64(rp_stream(h->seed, k), total);
-            uint64_t acc = 0;
-            for (uint64_t i = 0; i < h->N; ++i) {
-                acc += rp_kpp_quant(pot[i]);
-                if (acc > r) { pick = i; break; }
-            }
-        } else {
-            pick = rp_mulhi64(rp_stream(h->seed, k), h->N);
-        }
-        if (chosen) chosen[k] = pick;
-        h->cent[k] = h->points[pick];
-        h->self_c[k] = h->self_p[pick];
-        pot[pick] = 0.0f;
-        for (uint64_t i = 0; i < h->N; ++i) { /* distance(&x, h) with the new centroid first (layer.rs:172) */
-            float d = dist(h, &h->cent[k], h->self_c[k], &h->points[i], h->self_p[i]);
-            pot[i] = rp_minf(d * d, pot[i]);
-        }
+/* k-means++ primitives (include/rp_mi355x.h rp_kmeans_kpp_*), Layer::init_centroids (layer.rs:140-181) is
+ * their composition.  Draw = rp_math.h fixed-point scheme. */
+ORA_API void ora_kmeans_kpp_begin(ora_kmeans* h) {
+    free(h->pot);
+    h->pot = (float*)malloc(4 * h->N);
+    for (uint64_t i = 0; i < h->N; ++i) h->pot[i] = 1.0f;
+    memset(h->cent, 0, sizeof(ora_hist) * h->K);
+    memset(h->self_c, 0, 4 * h->K);
+}
+ORA_API uint64_t ora_kmeans_kpp_total(const ora_kmeans* h) {
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < h->N; ++i) total += rp_kpp_quant(h->pot[i]);
+    return total;
+}
+ORA_API uint64_t ora_kmeans_kpp_pick(ora_kmeans* h, uint64_t r) {
+    uint64_t acc = 0, pick = h->N - 1;
+    for (uint64_t i = 0; i < h->N; ++i) {
+        acc += rp_kpp_quant(h->pot[i]);
+        if (acc > r) { pick = i; break; }
     }
-    free(pot);
+    h->pot[pick] = 0.0f;
+    return pick;
+}
+ORA_API void ora_kmeans_get_point(const ora_kmeans* h, uint64_t idx, uint32_t* counts) {
+    memcpy(counts, h->points[idx].counts, 4 * h->bins);
+}
+ORA_API void ora_kmeans_set_centroid(ora_kmeans* h, uint32_t k, const uint32_t* counts) {
+    hist_from_u32(&h->cent[k], h->bins, counts);
+    h->self_c[k] = point_self(h, &h->cent[k]);
+}
+ORA_API void ora_kmeans_kpp_update(ora_kmeans* h, uint32_t k) {
+    for (uint64_t i = 0; i < h->N; ++i) { /* distance(&x, h) with the new centroid first (layer.rs:172) */
+        float d = dist(h, &h->cent[k], h->self_c[k], &h->points[i], h->self_p[i]);
+        h->pot[i] = rp_minf(d * d, h->pot[i]);
+    }
+}
+ORA_API void ora_kmeans_init_centroids(ora_kmeans* h, uint64_t* chosen) {
+    uint32_t* hist = (uint32_t*)malloc(4 * ORA_MAXBINS);
+    ora_kmeans_kpp_begin(h);
+    for (uint32_t k = 0; k < h->K; ++k) {
+        uint64_t total = ora_kmeans_kpp_total(h);
+        uint64_t hsh = rp_stream(h->seed, k);
+        uint64_t pick = total ? ora_kmeans_kpp_pick(h, rp_mulhi64(hsh, total)) : rp_mulhi64(hsh, h->N);
+        if (chosen) chosen[k] = pick;
+        ora_kmeans_get_point(h, pick, hist);
+        ora_kmeans_set_centroid(h, k, hist);
+        ora_kmeans_kpp_update(h, k);
+    }
+    free(hist);
 }
 
 /* Elkan::neighbor (elkan.rs:68-77): distance(centroid, point), first minimum wins */
@@ -300,8 +324,15 @@ static void absorb(ora_hist* acc, const ora_hist* p, uint32_t bins) { /* Bins::m
     for (uint32_t b = 0; b < bins; ++b) acc->counts[b] += p->counts[b];
 }
 
-/* Kmeans::next (kmeans.rs:82-110) = Elkan::step_elkan (elkan.rs:153-168) + install + Prior::tally */
-ORA_API void ora_kmeans_step(ora_kmeans* h, float* drift_out, uint64_t* sizes_out, double* reassigned) {
+/* Kmeans::next (kmeans.rs:82-110) = Elkan::step_elkan (elkan.rs:153-168) + install + Prior::tally, split at
+ * the centroid sums so a point-sharded job can all-reduce them (rp_kmeans_step_local / rp_kmeans_step_finish).
+ * partial layout: [K*bins u32 counts][K u32 weights][pad to 8][K u64 sizes] */
+ORA_API size_t ora_kmeans_partial_bytes(const ora_kmeans* h) {
+    size_t a = ((size_t)h->K * h->bins + h->K) * 4;
+    a = (a + 7) & ~(size_t)7;
+    return a + (size_t)h->K * 8;
+}
+ORA_API void ora_kmeans_step_local(ora_kmeans* h, void* partial) {
     uint32_t K = h->K;
     float* pw = (float*)malloc(4 * (size_t)K * K);
     float* mid = (float*)malloc(4 * K);
@@ -337,9 +368,38 @@ ORA_API void ora_kmeans_step(ora_kmeans* h, float* drift_out, uint64_t* sizes_ou
             }
         }
     }
-    /* recompute (elkan.rs:128-142): integer sums of members */
+    /* recompute (elkan.rs:128-142): integer sums of members (this shard's share) */
     ora_hist* nc = (ora_hist*)calloc(K, sizeof(ora_hist));
-    for (uint64_t i = 0; i < h->N; ++i) absorb(&nc[h->bounds[i].j], &h->points[i], h->bins);
+    uint64_t* sizes = (uint64_t*)calloc(K, 8);
+    for (uint64_t i = 0; i < h->N; ++i) {
+        absorb(&nc[h->bounds[i].j], &h->points[i], h->bins);
+        sizes[h->bounds[i].j] += 1;
+    }
+    unsigned char* out = (unsigned char*)partial;
+    uint32_t* pc = (uint32_t*)out;
+    uint32_t* pwt = pc + (size_t)K * h->bins;
+    size_t off = (((size_t)K * h->bins + K) * 4 + 7) & ~(size_t)7;
+    uint64_t* ps = (uint64_t*)(out + off);
+    for (uint32_t k = 0; k < K; ++k) {
+        memcpy(pc + (size_t)k * h->bins, nc[k].counts, 4 * h->bins);
+        pwt[k] = (uint32_t)nc[k].weight;
+        ps[k] = sizes[k];
+    }
+    free(pw); free(mid); free(nc); free(sizes);
+}
+ORA_API void ora_kmeans_step_finish(ora_kmeans* h, const void* reduced, float* drift_out, uint64_t* sizes_out,
+                                    double* reassigned) {
+    uint32_t K = h->K;
+    const unsigned char* in = (const unsigned char*)reduced;
+    const uint32_t* pc = (const uint32_t*)in;
+    const uint32_t* pwt = pc + (size_t)K * h->bins;
+    size_t off = (((size_t)K * h->bins + K) * 4 + 7) & ~(size_t)7;
+    const uint64_t* ps = (const uint64_t*)(in + off);
+    ora_hist* nc = (ora_hist*)calloc(K, sizeof(ora_hist));
+    for (uint32_t k = 0; k < K; ++k) {
+        memcpy(nc[k].counts, pc + (size_t)k * h->bins, 4 * h->bins);
+        nc[k].weight = pwt[k];
+    }
     /* drift (elkan.rs:108-110): distance(new, old) */
     float* drift = (float*)malloc(4 * K);
     float* self_n = (float*)malloc(4 * K);
@@ -354,20 +414,25 @@ ORA_API void ora_kmeans_step(ora_kmeans* h, float* drift_out, uint64_t* sizes_ou
     }
     memcpy(h->cent, nc, sizeof(ora_hist) * K);
     memcpy(h->self_c, self_n, 4 * K);
-    /* Prior::tally (prior.rs:35-47) */
+    /* Prior::tally (prior.rs:35-47): reassignments of this shard; sizes are the reduced (global) ones */
     uint64_t moved = 0;
-    if (sizes_out) memset(sizes_out, 0, 8 * K);
     for (uint64_t i = 0; i < h->N; ++i) {
         uint32_t j = h->bounds[i].j;
-        if (sizes_out) sizes_out[j] += 1;
         if ((uint8_t)j != h->prior[i]) {
             moved += 1;
             h->prior[i] = (uint8_t)j;
         }
     }
+    if (sizes_out) memcpy(sizes_out, ps, 8 * K);
     if (reassigned) *reassigned = (double)moved / (double)h->N;
     if (drift_out) memcpy(drift_out, drift, 4 * K);
-    free(pw); free(mid); free(nc); free(drift); free(self_n);
+    free(nc); free(drift); free(self_n);
+}
+ORA_API void ora_kmeans_step(ora_kmeans* h, float* drift_out, uint64_t* sizes_out, double* reassigned) {
+    void* partial = malloc(ora_kmeans_partial_bytes(h));
+    ora_kmeans_step_local(h, partial);
+    ora_kmeans_step_finish(h, partial, drift_out, sizes_out, reassigned);
+    free(partial);
 }
 
 /* Elkan::step_naive (elkan.rs:171-188) + install */

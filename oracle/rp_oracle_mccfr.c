@@ -527,65 +527,92 @@ static float composed_wdelta(const ora_mccfr* h, float sigma) {
     }
 }
 
-ORA_API int ora_mccfr_step_world(ora_mccfr* h, uint32_t world) {
+typedef struct ora_isum {
+    uint32_t count;
+    float psum;
+} ora_isum;
+
+/* bytes of one rank's summary blob: [n_infos*A ora_cell][n_infos ora_isum] — the same layout as the device's
+ * rp_mccfr_summary_bytes, so host logic written against one works against the other */
+ORA_API size_t ora_mccfr_summary_bytes(const ora_mccfr* h) {
+    return (size_t)h->g.n_infos * h->g.max_actions * sizeof(ora_cell) + (size_t)h->g.n_infos * sizeof(ora_isum);
+}
+
+/* rp_mccfr_step_local: this rank's trees [rank*B, (rank+1)*B) against the current table -> composed maps */
+ORA_API int ora_mccfr_step_local(ora_mccfr* h, uint32_t rank, void* blob) {
     float dr, dw;
     if (composed_discount(h, &dr, &dw)) return -1;
     uint32_t A = h->g.max_actions;
     size_t cells = (size_t)h->g.n_infos * A;
     float floor_r = regret_floor(h);
-    /* every rank traverses against the SAME start-of-epoch table (Solver::batch is pure w.r.t. the
-     * profile, solver.rs:225); only afterwards are the per-rank maps folded in rank order */
-    ora_cell* all_cell = (ora_cell*)malloc((size_t)world * cells * sizeof(ora_cell));
-    uint32_t* all_pcount = (uint32_t*)calloc((size_t)world * h->g.n_infos, 4);
-    float* all_psum = (float*)calloc((size_t)world * h->g.n_infos, 4);
-    for (uint32_t r = 0; r < world; ++r) {
-        ora_cell* cell = all_cell + (size_t)r * cells;
-        uint32_t* pcount = all_pcount + (size_t)r * h->g.n_infos;
-        float* psum = all_psum + (size_t)r * h->g.n_infos;
-        for (size_t c = 0; c < cells; ++c) {
-            cell[c].ra = 1.0f; cell[c].rb = 0.0f; cell[c].rm = rp_u2f(0xff800000u); cell[c].rn = 0;
-            cell[c].wa = 1.0f; cell[c].wb = 0.0f; cell[c].wm = rp_u2f(0xff800000u); cell[c].wn = 0;
-        }
-        h->ndec = 0;
-        batch_range(h, (uint64_t)r * h->batch, h->batch);
-        for (uint64_t i = 0; i < h->ndec; ++i) {
-            const ora_decision* d = &h->dec[i];
-            for (uint32_t a = 0; a < d->n_actions; ++a) {
-                ora_cell* c = &cell[d->info * A + a];
-                if (d->expanded >> a & 1u) {
-                    if (c->rn == 0) { c->ra = dr; c->rb = d->regret[a]; c->rm = floor_r; }
-                    else { c->ra = c->ra * dr; c->rb = c->rb * dr + d->regret[a];
-                           c->rm = rp_maxf(c->rm * dr + d->regret[a], floor_r); }
-                    c->rn += 1;
-                }
-                float dl = composed_wdelta(h, d->policy[a]);
-                if (c->wn == 0) { c->wa = dw; c->wb = dl; c->wm = RP_EPSILON; }
-                else { c->wa = c->wa * dw; c->wb = c->wb * dw + dl; c->wm = rp_maxf(c->wm * dw + dl, RP_EPSILON); }
-                c->wn += 1;
-            }
-            pcount[d->info] += 1;
-            psum[d->info] += d->payoff;
-        }
+    ora_cell* cell = (ora_cell*)blob;
+    ora_isum* sums = (ora_isum*)((unsigned char*)blob + cells * sizeof(ora_cell));
+    for (size_t c = 0; c < cells; ++c) {
+        cell[c].ra = 1.0f; cell[c].rb = 0.0f; cell[c].rm = rp_u2f(0xff800000u); cell[c].rn = 0;
+        cell[c].wa = 1.0f; cell[c].wb = 0.0f; cell[c].wm = rp_u2f(0xff800000u); cell[c].wn = 0;
     }
-    for (uint32_t r = 0; r < world; ++r) { /* fold rank r into the table */
-        const ora_cell* cell = all_cell + (size_t)r * cells;
-        const uint32_t* pcount = all_pcount + (size_t)r * h->g.n_infos;
-        const float* psum = all_psum + (size_t)r * h->g.n_infos;
+    memset(sums, 0, (size_t)h->g.n_infos * sizeof(ora_isum));
+    h->ndec = 0;
+    batch_range(h, (uint64_t)rank * h->batch, h->batch);
+    for (uint64_t i = 0; i < h->ndec; ++i) {
+        const ora_decision* d = &h->dec[i];
+        for (uint32_t a = 0; a < d->n_actions; ++a) {
+            ora_cell* c = &cell[d->info * A + a];
+            if (d->expanded >> a & 1u) {
+                if (c->rn == 0) { c->ra = dr; c->rb = d->regret[a]; c->rm = floor_r; }
+                else { c->ra = c->ra * dr; c->rb = c->rb * dr + d->regret[a];
+                       c->rm = rp_maxf(c->rm * dr + d->regret[a], floor_r); }
+                c->rn += 1;
+            }
+            float dl = composed_wdelta(h, d->policy[a]);
+            if (c->wn == 0) { c->wa = dw; c->wb = dl; c->wm = RP_EPSILON; }
+            else { c->wa = c->wa * dw; c->wb = c->wb * dw + dl; c->wm = rp_maxf(c->wm * dw + dl, RP_EPSILON); }
+            c->wn += 1;
+        }
+        sums[d->info].count += 1;
+        sums[d->info].psum += d->payoff;
+    }
+    return 0;
+}
+
+/* rp_mccfr_step_apply: fold `world` blobs (back to back) in rank order, then epoch += 1 */
+ORA_API void ora_mccfr_step_apply(ora_mccfr* h, const void* gathered, uint32_t world) {
+    uint32_t A = h->g.max_actions;
+    size_t cells = (size_t)h->g.n_infos * A;
+    size_t stride = ora_mccfr_summary_bytes(h);
+    for (uint32_t r = 0; r < world; ++r) {
+        const unsigned char* b = (const unsigned char*)gathered + (size_t)r * stride;
+        const ora_cell* cell = (const ora_cell*)b;
+        const ora_isum* sums = (const ora_isum*)(b + cells * sizeof(ora_cell));
         for (uint32_t info = 0; info < h->g.n_infos; ++info) {
             for (uint32_t a = 0; a < h->info_actions[info]; ++a) {
                 size_t k = (size_t)info * A + a;
                 if (cell[k].rn) h->regret[k] = rp_maxf(cell[k].ra * h->regret[k] + cell[k].rb, cell[k].rm);
                 if (cell[k].wn) h->weight[k] = rp_maxf(cell[k].wa * h->weight[k] + cell[k].wb, cell[k].wm);
-                if (pcount[info]) {
-                    uint32_t n2 = h->visits[k] + pcount[info];
-                    h->payoff[k] = h->payoff[k] + (psum[info] - (float)pcount[info] * h->payoff[k]) / (float)n2;
+                if (sums[info].count) {
+                    uint32_t n2 = h->visits[k] + sums[info].count;
+                    h->payoff[k] = h->payoff[k] + (sums[info].psum - (float)sums[info].count * h->payoff[k]) / (float)n2;
                     h->visits[k] = n2;
                 }
             }
         }
     }
-    free(all_cell); free(all_pcount); free(all_psum);
     h->epoch += 1;
+}
+
+/* single-process model of a `world`-rank step: every rank traverses against the SAME start-of-epoch table
+ * (Solver::batch is pure w.r.t. the profile, solver.rs:225), then the maps are folded in rank order */
+ORA_API int ora_mccfr_step_world(ora_mccfr* h, uint32_t world) {
+    size_t stride = ora_mccfr_summary_bytes(h);
+    unsigned char* all = (unsigned char*)malloc(stride * world);
+    for (uint32_t r = 0; r < world; ++r) {
+        if (ora_mccfr_step_local(h, r, all + (size_t)r * stride)) {
+            free(all);
+            return -1;
+        }
+    }
+    ora_mccfr_step_apply(h, all, world);
+    free(all);
     return 0;
 }
 

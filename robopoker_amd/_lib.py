@@ -147,6 +147,12 @@ _SIGNATURES = {
     "rp_kmeans_destroy": (C.c_int, [C.c_void_p]),
     "rp_kmeans_init_centroids": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_kmeans_set_centroids": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rp_kmeans_set_centroid": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rp_kmeans_get_point": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "rp_kmeans_kpp_begin": (C.c_int, [C.c_void_p]),
+    "rp_kmeans_kpp_total": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rp_kmeans_kpp_pick": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "rp_kmeans_kpp_update": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rp_kmeans_init_bounds": (C.c_int, [C.c_void_p]),
     "rp_kmeans_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "rp_kmeans_step_naive": (C.c_int, [C.c_void_p]),

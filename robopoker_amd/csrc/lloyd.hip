@@ -244,6 +244,20 @@ __global__ void k_centroid_from_point(CentroidSet cs, uint32_t k, Points P, uint
     if (threadIdx.x == 0) cs.weight[k] = P.weight[idx];
 }
 
+__global__ void k_centroid_from_hist(CentroidSet cs, uint32_t k, const uint32_t* hist, uint32_t bins) {
+    __shared__ uint32_t wsum;
+    if (threadIdx.x == 0) wsum = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t b = threadIdx.x; b < bins; b += blockDim.x) {
+        cs.counts[(size_t)k * bins + b] = hist[b];
+        mine += hist[b];
+    }
+    atomicAdd(&wsum, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) cs.weight[k] = wsum;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Equity::variation (equity.rs:41-53): one LANE per centroid, points' densities broadcast from LDS
 // ------------------------------------------------------------------------------------------------
@@ -605,11 +619,25 @@ __global__ __launch_bounds__(256) void k_kpp_blocksum(const float* pot, uint64_t
     __syncthreads();
     if (threadIdx.x == 0) bsum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
-// single block: winner = first i with inclusive prefix > r, r = mulhi64(stream(seed, round), total)
-__global__ __launch_bounds__(1024) void k_kpp_pick(const float* pot_in, float* pot, uint64_t N, const unsigned long long* bsum,
-                                                   uint32_t nblocks, uint64_t seed, uint32_t round, unsigned long long* picked) {
+// block sums -> one u64 (single block)
+__global__ __launch_bounds__(1024) void k_kpp_total(const unsigned long long* bsum, uint32_t nblocks, unsigned long long* total) {
+    __shared__ unsigned long long part[16];
+    unsigned long long s = 0;
+    for (uint32_t b = threadIdx.x; b < nblocks; b += 1024) s += bsum[b];
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        total[0] = t;
+    }
+}
+// single block: winner = first i whose inclusive quantised prefix exceeds r (r < this shard's total)
+__global__ __launch_bounds__(1024) void k_kpp_pick(float* pot, uint64_t N, const unsigned long long* bsum, uint32_t nblocks,
+                                                   unsigned long long r, unsigned long long* picked) {
     __shared__ unsigned long long strip[1024];
-    __shared__ unsigned long long sh_r, sh_before;
+    __shared__ unsigned long long sh_before;
     __shared__ uint32_t sh_block;
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (nblocks + 1023) / 1024;
@@ -618,42 +646,29 @@ __global__ __launch_bounds__(1024) void k_kpp_pick(const float* pot_in, float* p
     strip[tid] = s;
     __syncthreads();
     if (tid == 0) {
-        unsigned long long total = 0;
-        for (uint32_t t = 0; t < 1024; ++t) total += strip[t];
-
-        const uint64_t h = rp_stream(seed, round);
-        if (total == 0) {
-            picked[0] = rp_mulhi64(h, N);
-            sh_block = 0xffffffffu;
-        } else {
-            const unsigned long long r = rp_mulhi64(h, total);
-            unsigned long long acc = 0;
-            uint32_t t = 0;
-            while (acc + strip[t] <= r) acc += strip[t++];
-            uint32_t b = t * per;
-            while (acc + bsum[b] <= r) acc += bsum[b++];
-            sh_block = b;
-            sh_before = acc;
-            sh_r = r;
-        }
+        unsigned long long acc = 0;
+        uint32_t t = 0;
+        while (t < 1023 && acc + strip[t] <= r) acc += strip[t++];
+        uint32_t b = t * per;
+        while (b + 1 < nblocks && acc + bsum[b] <= r) acc += bsum[b++];
+        sh_block = b;
+        sh_before = acc;
     }
     __syncthreads();
-    if (sh_block != 0xffffffffu) {
-        const uint64_t i = (uint64_t)sh_block * KPP_BLOCK + tid;
-        strip[tid] = i < N ? rp_kpp_quant(pot_in[i]) : 0ull;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long acc = sh_before;
-            uint32_t t = 0;
-            for (; t < KPP_BLOCK; ++t) {
-                acc += strip[t];
-                if (acc > sh_r) break;
-            }
-            picked[0] = (uint64_t)sh_block * KPP_BLOCK + t;
-        }
-    }
+    const uint64_t i = (uint64_t)sh_block * KPP_BLOCK + tid;
+    strip[tid] = i < N ? rp_kpp_quant(pot[i]) : 0ull;
     __syncthreads();
-    if (tid == 0) pot[picked[0]] = 0.0f;  // potentials[i] = 0 (layer.rs:169)
+    if (tid == 0) {
+        unsigned long long acc = sh_before;
+        uint32_t t = 0;
+        for (; t + 1 < KPP_BLOCK; ++t) {
+            acc += strip[t];
+            if (acc > r) break;
+        }
+        const uint64_t win = (uint64_t)sh_block * KPP_BLOCK + t;
+        picked[0] = win;
+        pot[win] = 0.0f;  // potentials[i] = 0 (layer.rs:169)
+    }
 }
 // potentials <- min(potentials, d(new centroid, point)^2) (layer.rs:170-178): distance(&x, h), centroid first
 __global__ __launch_bounds__(64) void k_kpp_update(Points P, CentroidSet cs, uint32_t k, uint32_t K, Metric M, int kind,
@@ -807,6 +822,7 @@ struct rp_kmeans {
     unsigned long long* sizes = nullptr; // [K]
     unsigned long long* stats = nullptr; // [2]
     uint8_t* tmp_j = nullptr;
+    uint32_t* hist_stage = nullptr;
     bool bounds_ready = false, centroids_ready = false;
     bool profiling = false;
     Clock clk[CK_COUNT];
@@ -951,6 +967,7 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
     KM_TRY(dev_alloc(h, &h->bsum, (N + KPP_BLOCK - 1) / KPP_BLOCK));
     KM_TRY(dev_alloc(h, &h->scal, 2));
     KM_TRY(dev_alloc(h, &h->sizes, K));
+    KM_TRY(dev_alloc(h, &h->hist_stage, MAXB));
     // point masses and memoised self costs OT(p,p) (sinkhorn.rs:175-191)
     hipLaunchKernelGGL(k_point_weights, dim3((unsigned)N), dim3(64), 0, h->stream, d_counts, h->stride, bins, N, d_w);
     KM_HIP(hipGetLastError());
@@ -966,6 +983,8 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
     *out = h;
     return RP_OK;
 }
+
+size_t partial_sizes_offset(const rp_kmeans* h) { return ((((size_t)h->K * h->bins + h->K) * 4) + 7) & ~(size_t)7; }
 
 int need_centroids(const rp_kmeans* h, const char* who) {
     if (!h->centroids_ready) return rp::fail(RP_ERR_INVALID, "%s: centroids not initialised (init_centroids / set_centroids)", who);
@@ -1076,31 +1095,110 @@ int rp_kmeans_set_centroids(rp_kmeans* h, const uint64_t* point_index) {
     return RP_OK;
 }
 
-int rp_kmeans_init_centroids(rp_kmeans* h, uint64_t* chosen) {
-    if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_init_centroids: NULL handle");
+int rp_kmeans_kpp_begin(rp_kmeans* h) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_kpp_begin: NULL handle");
     HIP_TRY(hipSetDevice(h->device));
-    const uint32_t nblocks = (uint32_t)((h->N + KPP_BLOCK - 1) / KPP_BLOCK);
     CentroidSet& cs = h->cs[h->cur];
-    // all centroids start empty so k_prepare_centroids is well defined for the not-yet-chosen ones
+    // all centroids start empty so every derived table is well defined for the not-yet-chosen ones
     HIP_TRY(hipMemsetAsync(cs.counts, 0, (size_t)h->K * h->bins * 4, h->stream));
     HIP_TRY(hipMemsetAsync(cs.weight, 0, h->K * 4, h->stream));
     hipLaunchKernelGGL(k_prepare_centroids, dim3(h->K), dim3(64), 0, h->stream, cs, h->K, h->M, h->kind, 0u);
     hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, h->stream, h->pot, h->N, 1.0f);  // potentials = 1 (layer.rs:161)
-    std::vector<unsigned long long> picks(h->K);
+    HIP_TRY(hipGetLastError());
+    h->centroids_ready = false;
+    h->bounds_ready = false;
+    return RP_OK;
+}
+
+int rp_kmeans_kpp_total(rp_kmeans* h, uint64_t* total) {
+    if (!h || !total) return rp::fail(RP_ERR_INVALID, "rp_kmeans_kpp_total: NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const uint32_t nblocks = (uint32_t)((h->N + KPP_BLOCK - 1) / KPP_BLOCK);
     ck_begin(h, CK_KPP);
-    for (uint32_t k = 0; k < h->K; ++k) {
-        hipLaunchKernelGGL(k_kpp_blocksum, dim3(nblocks), dim3(256), 0, h->stream, h->pot, h->N, h->bsum);
-        hipLaunchKernelGGL(k_kpp_pick, dim3(1), dim3(1024), 0, h->stream, h->pot, h->pot, h->N, h->bsum, nblocks, h->seed, k, h->scal);
-        HIP_TRY(hipMemcpyAsync(&picks[k], h->scal, 8, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        hipLaunchKernelGGL(k_centroid_from_point, dim3(1), dim3(256), 0, h->stream, cs, k, h->P, (uint64_t)picks[k], h->bins);
-        hipLaunchKernelGGL(k_prepare_centroids, dim3(1), dim3(64), 0, h->stream, cs, h->K, h->M, h->kind, k);
-        hipLaunchKernelGGL(k_kpp_update, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, cs, k, h->K, h->M, h->kind, h->pot);
-        HIP_TRY(hipGetLastError());
-    }
+    hipLaunchKernelGGL(k_kpp_blocksum, dim3(nblocks), dim3(256), 0, h->stream, h->pot, h->N, h->bsum);
+    hipLaunchKernelGGL(k_kpp_total, dim3(1), dim3(1024), 0, h->stream, h->bsum, nblocks, h->scal);
     ck_end(h, CK_KPP);
+    HIP_TRY(hipGetLastError());
+    unsigned long long t = 0;
+    HIP_TRY(hipMemcpyAsync(&t, h->scal, 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (chosen) for (uint32_t k = 0; k < h->K; ++k) chosen[k] = picks[k];
+    *total = t;
+    return RP_OK;
+}
+
+// requires a preceding rp_kmeans_kpp_total (block sums) with unchanged potentials, and r < that total
+int rp_kmeans_kpp_pick(rp_kmeans* h, uint64_t r, uint64_t* index) {
+    if (!h || !index) return rp::fail(RP_ERR_INVALID, "rp_kmeans_kpp_pick: NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const uint32_t nblocks = (uint32_t)((h->N + KPP_BLOCK - 1) / KPP_BLOCK);
+    hipLaunchKernelGGL(k_kpp_pick, dim3(1), dim3(1024), 0, h->stream, h->pot, h->N, h->bsum, nblocks, (unsigned long long)r, h->scal);
+    HIP_TRY(hipGetLastError());
+    unsigned long long p = 0;
+    HIP_TRY(hipMemcpyAsync(&p, h->scal, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *index = p;
+    return RP_OK;
+}
+
+int rp_kmeans_kpp_update(rp_kmeans* h, uint32_t k) {
+    if (!h || k >= h->K) return rp::fail(RP_ERR_INVALID, "rp_kmeans_kpp_update: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    ck_begin(h, CK_KPP);
+    hipLaunchKernelGGL(k_kpp_update, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->K, h->M, h->kind, h->pot);
+    ck_end(h, CK_KPP);
+    HIP_TRY(hipGetLastError());
+    if (k + 1 == h->K) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->centroids_ready = true;
+        ck_drain(h);
+    }
+    return RP_OK;
+}
+
+int rp_kmeans_get_point(rp_kmeans* h, uint64_t index, uint32_t* counts) {
+    if (!h || !counts || index >= h->N) return rp::fail(RP_ERR_INVALID, "rp_kmeans_get_point: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<uint8_t> row(h->bins);
+    HIP_TRY(hipMemcpyAsync(row.data(), h->P.counts + index * h->P.stride, h->bins, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (uint32_t b = 0; b < h->bins; ++b) counts[b] = row[b];
+    return RP_OK;
+}
+
+int rp_kmeans_set_centroid(rp_kmeans* h, uint32_t k, const uint32_t* counts) {
+    if (!h || !counts || k >= h->K) return rp::fail(RP_ERR_INVALID, "rp_kmeans_set_centroid: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->hist_stage, counts, (size_t)h->bins * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_centroid_from_hist, dim3(1), dim3(256), 0, h->stream, h->cs[h->cur], k, h->hist_stage, h->bins);
+    hipLaunchKernelGGL(k_prepare_centroids, dim3(1), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, k);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));  // `counts` may be a temporary on the caller's side
+    h->bounds_ready = false;
+    return RP_OK;
+}
+
+// Layer::init_centroids (layer.rs:140-181) composed from the primitives above
+int rp_kmeans_init_centroids(rp_kmeans* h, uint64_t* chosen) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_init_centroids: NULL handle");
+    int rc = rp_kmeans_kpp_begin(h);
+    if (rc) return rc;
+    std::vector<uint32_t> hist(h->bins);
+    for (uint32_t k = 0; k < h->K; ++k) {
+        uint64_t total = 0, pick = 0;
+        if ((rc = rp_kmeans_kpp_total(h, &total))) return rc;
+        const uint64_t hsh = rp_stream(h->seed, k);
+        if (total == 0) {
+            pick = rp_mulhi64(hsh, h->N);
+        } else if ((rc = rp_kmeans_kpp_pick(h, rp_mulhi64(hsh, total), &pick))) {
+            return rc;
+        }
+        if (chosen) chosen[k] = pick;
+        hipLaunchKernelGGL(k_centroid_from_point, dim3(1), dim3(256), 0, h->stream, h->cs[h->cur], k, h->P, pick, h->bins);
+        hipLaunchKernelGGL(k_prepare_centroids, dim3(1), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, k);
+        HIP_TRY(hipGetLastError());
+        if ((rc = rp_kmeans_kpp_update(h, k))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
     h->centroids_ready = true;
     h->bounds_ready = false;
     ck_drain(h);
@@ -1130,11 +1228,11 @@ int rp_kmeans_step(rp_kmeans* h, float* drift, uint64_t* sizes, double* reassign
 
 int rp_kmeans_partial_bytes(rp_kmeans* h, size_t* bytes) {
     if (!h || !bytes) return rp::fail(RP_ERR_INVALID, "rp_kmeans_partial_bytes: NULL argument");
-    *bytes = ((size_t)h->K * h->bins + h->K) * 4 + (size_t)h->K * 8;
+    *bytes = partial_sizes_offset(h) + (size_t)h->K * 8;
     return RP_OK;
 }
 
-// partial layout: [K*bins u32 counts][K u32 weights][K u64 sizes] — all exact integers, all-reduce(sum)-able
+// partial layout: [K*bins u32 counts][K u32 weights][pad to 8][K u64 sizes] — exact integers, all-reduce(sum)-able
 int rp_kmeans_step_local(rp_kmeans* h, void* partial_dev) {
     if (!h || !partial_dev) return rp::fail(RP_ERR_INVALID, "rp_kmeans_step_local: NULL argument");
     int rc = need_centroids(h, "rp_kmeans_step_local");
@@ -1146,7 +1244,8 @@ int rp_kmeans_step_local(rp_kmeans* h, void* partial_dev) {
     const size_t cb = (size_t)h->K * h->bins * 4, wb = (size_t)h->K * 4;
     HIP_TRY(hipMemcpyAsync(out, h->cs[nxt].counts, cb, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(out + cb, h->cs[nxt].weight, wb, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(out + cb + wb, h->sizes, (size_t)h->K * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(out + cb + wb, 0, partial_sizes_offset(h) - (cb + wb), h->stream));
+    HIP_TRY(hipMemcpyAsync(out + partial_sizes_offset(h), h->sizes, (size_t)h->K * 8, hipMemcpyDeviceToDevice, h->stream));
     return RP_OK;
 }
 
@@ -1158,7 +1257,7 @@ int rp_kmeans_step_finish(rp_kmeans* h, const void* reduced_dev, float* drift, u
     const size_t cb = (size_t)h->K * h->bins * 4, wb = (size_t)h->K * 4;
     HIP_TRY(hipMemcpyAsync(h->cs[nxt].counts, in, cb, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->cs[nxt].weight, in + cb, wb, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->sizes, in + cb + wb, (size_t)h->K * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->sizes, in + partial_sizes_offset(h), (size_t)h->K * 8, hipMemcpyDeviceToDevice, h->stream));
     return step_back(h, drift, sizes, reassigned);
 }
 

@@ -63,6 +63,32 @@ class Layer:
         idx = np.ascontiguousarray(idx, dtype=np.uint64)
         _lib.check(self._lib.rp_kmeans_set_centroids(self._h, _p(idx)))
 
+    def set_centroid(self, k: int, counts):
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        _lib.check(self._lib.rp_kmeans_set_centroid(self._h, k, _p(counts)))
+
+    def get_point(self, index: int) -> np.ndarray:
+        out = np.zeros(self.bins, dtype=np.uint32)
+        _lib.check(self._lib.rp_kmeans_get_point(self._h, index, _p(out)))
+        return out
+
+    # k-means++ primitives (a point-sharded job interleaves collectives between them)
+    def kpp_begin(self):
+        _lib.check(self._lib.rp_kmeans_kpp_begin(self._h))
+
+    def kpp_total(self) -> int:
+        t = C.c_uint64()
+        _lib.check(self._lib.rp_kmeans_kpp_total(self._h, C.byref(t)))
+        return t.value
+
+    def kpp_pick(self, r: int) -> int:
+        i = C.c_uint64()
+        _lib.check(self._lib.rp_kmeans_kpp_pick(self._h, r, C.byref(i)))
+        return i.value
+
+    def kpp_update(self, k: int):
+        _lib.check(self._lib.rp_kmeans_kpp_update(self._h, k))
+
     def init_bounds(self):
         _lib.check(self._lib.rp_kmeans_init_bounds(self._h))
 

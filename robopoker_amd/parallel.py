@@ -1,0 +1,153 @@
+"""One-process-per-GPU sharding of the two hot paths over ``torch.distributed`` (RCCL on MI355X, gloo on CPU).
+
+The reference is single-process (rayon) — SURVEY.md §8e defines the MI355X-native exchange:
+
+* MCCFR: trees sharded by rank; each rank reduces its Decisions to one composed map per table cell; ONE
+  all-gather per step; every rank folds the maps in rank order (replicas stay bit-identical).
+* k-means: points (and their Elkan bounds) sharded by rank; ONE all-reduce(sum) of the integer centroid
+  sums per iteration; k-means++ draws with an exact integer prefix over ranks (same picks as one GPU).
+
+``engine`` is anything with the C-ABI's sharded surface (``summary_bytes/step_local/step_apply`` resp.
+``partial_bytes/step_local/step_finish/kpp_*``): the HIP ``Solver``/``Layer`` on a GPU box, the CPU oracle in
+the gloo tests.  Buffers are torch tensors on ``device``; only raw pointers cross into the engine.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+MASK64 = (1 << 64) - 1
+
+
+def rp_mix64(z: int) -> int:
+    z &= MASK64
+    z ^= z >> 30
+    z = (z * 0xBF58476D1CE4E5B9) & MASK64
+    z ^= z >> 27
+    z = (z * 0x94D049BB133111EB) & MASK64
+    z ^= z >> 31
+    return z
+
+
+def rp_stream(seed: int, counter: int) -> int:
+    """include/rp_math.h rp_stream (k-means++ round hash)."""
+    return rp_mix64(rp_mix64((seed + 0x9E3779B97F4A7C15) & MASK64) ^ ((counter * 0xD1342543DE82EF95 + 1) & MASK64))
+
+
+def rp_mulhi64(a: int, b: int) -> int:
+    return ((a & MASK64) * (b & MASK64)) >> 64
+
+
+def _all_gather_bytes(out: torch.Tensor, mine: torch.Tensor, group=None):
+    try:
+        dist.all_gather_into_tensor(out, mine, group=group)
+    except (RuntimeError, NotImplementedError):  # backends without the flat variant
+        world = dist.get_world_size(group)
+        parts = list(out.view(world, -1).unbind(0))
+        dist.all_gather(parts, mine, group=group)
+
+
+class ShardedSolver:
+    """Tree-sharded MCCFR: rank r samples tree ids [r*B, (r+1)*B) of a world*B-tree epoch."""
+
+    def __init__(self, engine, device="cpu", group=None, stream_ptr=None):
+        self.engine = engine
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        engine.set_shard(self.rank, self.world)
+        if stream_ptr is not None:
+            engine.set_stream(stream_ptr)
+        n = engine.summary_bytes()
+        self.mine = torch.empty(n, dtype=torch.uint8, device=device)
+        self.all = torch.empty(n * self.world, dtype=torch.uint8, device=device)
+
+    def step(self):
+        self.engine.step_local(self.mine.data_ptr())
+        _all_gather_bytes(self.all, self.mine, self.group)
+        self.engine.step_apply(self.all.data_ptr(), self.world)
+
+    def solve(self, trees_per_rank: int, batch: int):
+        for _ in range(trees_per_rank // batch):
+            self.step()
+        return self
+
+
+class ShardedLayer:
+    """Point-sharded Elkan k-means: this rank owns the contiguous point range [lo, hi) of the global set."""
+
+    def __init__(self, engine, K: int, bins: int, seed: int, device="cpu", group=None, stream_ptr=None):
+        self.engine = engine
+        self.K, self.bins, self.seed = K, bins, seed
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = device
+        if stream_ptr is not None:
+            engine.set_stream(stream_ptr)
+        self.nbytes = engine.partial_bytes()
+        self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        # partial layout: [K*bins u32][K u32][pad to 8][K u64]
+        self.words32 = K * bins + K
+        self.off64 = ((self.words32 * 4) + 7) & ~7
+
+    def init_centroids(self):
+        """Layer::init_centroids (k-means++, layer.rs:140-181) with a global exact-integer draw."""
+        e = self.engine
+        e.kpp_begin()
+        chosen = []
+        for k in range(self.K):
+            local = e.kpp_total()
+            totals = torch.zeros(self.world, dtype=torch.int64)
+            mine = torch.tensor([local], dtype=torch.int64)
+            if self.device != "cpu":
+                totals, mine = totals.to(self.device), mine.to(self.device)
+            dist.all_gather_into_tensor(totals, mine, group=self.group) if hasattr(dist, "all_gather_into_tensor") \
+                else dist.all_gather(list(totals.unbind(0)), mine, group=self.group)
+            totals = [int(t) for t in totals.cpu().tolist()]
+            total = sum(totals)
+            h = rp_stream(self.seed, k)
+            counts_all = self._point_counts()
+            if total == 0:
+                g = rp_mulhi64(h, sum(counts_all))  # uniform over the global point index
+                owner, before = 0, 0
+                while g >= before + counts_all[owner]:
+                    before += counts_all[owner]
+                    owner += 1
+                idx = g - before
+            else:
+                r = rp_mulhi64(h, total)
+                owner, before = 0, 0
+                while r >= before + totals[owner]:  # first rank whose inclusive prefix exceeds r
+                    before += totals[owner]
+                    owner += 1
+                idx = e.kpp_pick(r - before) if owner == self.rank else -1
+            hist = torch.zeros(self.bins, dtype=torch.int64)
+            if owner == self.rank:
+                hist = torch.from_numpy(e.get_point(idx).astype(np.int64))
+            if self.device != "cpu":
+                hist = hist.to(self.device)
+            dist.broadcast(hist, src=owner, group=self.group)
+            e.set_centroid(k, hist.cpu().numpy().astype(np.uint32))
+            e.kpp_update(k)
+            chosen.append((owner, idx if owner == self.rank else None))
+        return chosen
+
+    def _point_counts(self):
+        n = torch.tensor([self.engine.N], dtype=torch.int64)
+        out = torch.zeros(self.world, dtype=torch.int64)
+        if self.device != "cpu":
+            n, out = n.to(self.device), out.to(self.device)
+        dist.all_gather_into_tensor(out, n, group=self.group)
+        return [int(v) for v in out.cpu().tolist()]
+
+    def init_bounds(self):
+        self.engine.init_bounds()
+
+    def step(self):
+        """Kmeans::next with the centroid sums all-reduced across ranks (exact integers, order free)."""
+        self.engine.step_local(self.buf.data_ptr())
+        dist.all_reduce(self.buf[: self.words32 * 4].view(torch.int32), op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(self.buf[self.off64:].view(torch.int64), op=dist.ReduceOp.SUM, group=self.group)
+        return self.engine.step_finish(self.buf.data_ptr())

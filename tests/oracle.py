@@ -50,6 +50,11 @@ def load() -> C.CDLL:
     o.ora_mccfr_batch.argtypes = [vp, C.POINTER(C.POINTER(Decision))]
     o.ora_mccfr_step_world.restype = C.c_int
     o.ora_mccfr_step_world.argtypes = [vp, C.c_uint32]
+    o.ora_mccfr_summary_bytes.restype = C.c_size_t
+    o.ora_mccfr_summary_bytes.argtypes = [vp]
+    o.ora_mccfr_step_local.restype = C.c_int
+    o.ora_mccfr_step_local.argtypes = [vp, C.c_uint32, vp]
+    o.ora_mccfr_step_apply.argtypes = [vp, vp, C.c_uint32]
     o.ora_mccfr_epoch.restype = C.c_uint64
     o.ora_mccfr_epoch.argtypes = [vp]
     o.ora_mccfr_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -83,6 +88,18 @@ def load() -> C.CDLL:
     o.ora_kmeans_metric.argtypes = [vp, vp]
     o.ora_kmeans_rms.restype = C.c_float
     o.ora_kmeans_rms.argtypes = [vp]
+    o.ora_kmeans_kpp_begin.argtypes = [vp]
+    o.ora_kmeans_kpp_total.restype = C.c_uint64
+    o.ora_kmeans_kpp_total.argtypes = [vp]
+    o.ora_kmeans_kpp_pick.restype = C.c_uint64
+    o.ora_kmeans_kpp_pick.argtypes = [vp, C.c_uint64]
+    o.ora_kmeans_kpp_update.argtypes = [vp, C.c_uint32]
+    o.ora_kmeans_get_point.argtypes = [vp, C.c_uint64, vp]
+    o.ora_kmeans_set_centroid.argtypes = [vp, C.c_uint32, vp]
+    o.ora_kmeans_partial_bytes.restype = C.c_size_t
+    o.ora_kmeans_partial_bytes.argtypes = [vp]
+    o.ora_kmeans_step_local.argtypes = [vp, vp]
+    o.ora_kmeans_step_finish.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_double)]
     o.ora_lloyd_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
     _ora = o
     return o
@@ -123,6 +140,23 @@ class OracleSolver:
     def solve(self, trees: int):
         self._o.ora_mccfr_solve(self._h, trees)
         return self
+
+    # ---- the sharded surface of the C-ABI (rp_mccfr_set_shard / step_local / step_apply), host pointers ----
+    def set_shard(self, rank: int, world: int):
+        self._rank, self._world = rank, world
+
+    def set_stream(self, ptr):
+        pass
+
+    def summary_bytes(self) -> int:
+        return self._o.ora_mccfr_summary_bytes(self._h)
+
+    def step_local(self, ptr: int):
+        if self._o.ora_mccfr_step_local(self._h, getattr(self, "_rank", 0), C.c_void_p(ptr)) != 0:
+            raise RuntimeError("composed update unsupported for this schedule")
+
+    def step_apply(self, ptr: int, world: int):
+        self._o.ora_mccfr_step_apply(self._h, C.c_void_p(ptr), world)
 
     def step_world(self, world: int):
         rc = self._o.ora_mccfr_step_world(self._h, world)
@@ -233,6 +267,44 @@ class OracleKmeans:
 
     def init_bounds(self):
         self._o.ora_kmeans_init_bounds(self._h)
+
+    # ---- the sharded surface of the C-ABI (rp_kmeans_kpp_* / step_local / step_finish), host pointers ----
+    def set_stream(self, ptr):
+        pass
+
+    def kpp_begin(self):
+        self._o.ora_kmeans_kpp_begin(self._h)
+
+    def kpp_total(self) -> int:
+        return self._o.ora_kmeans_kpp_total(self._h)
+
+    def kpp_pick(self, r: int) -> int:
+        return self._o.ora_kmeans_kpp_pick(self._h, r)
+
+    def kpp_update(self, k: int):
+        self._o.ora_kmeans_kpp_update(self._h, k)
+
+    def get_point(self, idx: int) -> np.ndarray:
+        out = np.zeros(self.bins, dtype=np.uint32)
+        self._o.ora_kmeans_get_point(self._h, idx, _p(out))
+        return out
+
+    def set_centroid(self, k: int, counts):
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        self._o.ora_kmeans_set_centroid(self._h, k, _p(counts))
+
+    def partial_bytes(self) -> int:
+        return self._o.ora_kmeans_partial_bytes(self._h)
+
+    def step_local(self, ptr: int):
+        self._o.ora_kmeans_step_local(self._h, C.c_void_p(ptr))
+
+    def step_finish(self, ptr: int):
+        drift = np.zeros(self.K, dtype=np.float32)
+        sizes = np.zeros(self.K, dtype=np.uint64)
+        re = C.c_double()
+        self._o.ora_kmeans_step_finish(self._h, C.c_void_p(ptr), _p(drift), _p(sizes), C.byref(re))
+        return drift, sizes, re.value
 
     def step(self):
         drift = np.zeros(self.K, dtype=np.float32)

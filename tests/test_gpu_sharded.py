@@ -1,0 +1,100 @@
+"""GPU: the sharded C-ABI surface (step_local / step_apply, kpp_* / step_local / step_finish) on ONE device,
+two handles playing rank 0 and rank 1, buffers exchanged by hand — against the oracle's world model, bit-exact."""
+import numpy as np
+import pytest
+
+import oracle
+from lloyd_fixtures import flop_like_points, smooth_metric, turn_like_points
+from robopoker_amd import Game, lloyd
+from robopoker_amd.mccfr import Solver
+from robopoker_amd.parallel import rp_mulhi64, rp_stream
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mccfr_two_shards_on_one_gpu_match_world_model(gpu):
+    import torch
+
+    g = Game("leduc")
+    B, world = 500, 2
+    devs = [Solver(g, "floored", "linear", "external", batch=B, seed=33) for _ in range(world)]
+    for r, d in enumerate(devs):
+        d.set_shard(r, world)
+    n = devs[0].summary_bytes()
+    gathered = torch.zeros(n * world, dtype=torch.uint8, device="cuda")
+    ora = oracle.OracleSolver(g, "floored", "linear", "external", batch=B, seed=33)
+    for _ in range(5):
+        for r, d in enumerate(devs):
+            d.step_local(gathered.data_ptr() + r * n)
+            d.sync()
+        for d in devs:
+            d.step_apply(gathered.data_ptr(), world)
+            d.sync()
+        ora.step_world(world)
+        exp = ora.export()
+        for d in devs:
+            got = d.export()
+            for f in ("visits", "regret", "weight", "payoff"):
+                assert np.array_equal(got[f].view(np.uint32), exp[f].view(np.uint32)), f
+    assert devs[0].epoch == 5
+
+
+@pytest.mark.parametrize("kind", ["sinkhorn", "variation"])
+def test_kmeans_two_shards_on_one_gpu_match_single(gpu, kind):
+    import torch
+
+    K, N, seed = 7, 300, 4
+    if kind == "sinkhorn":
+        bins, pts, tri = 32, flop_like_points(N, bins=32, mass=20, seed=seed), smooth_metric(32, seed)
+    else:
+        bins, pts, tri = 101, turn_like_points(N, bins=101, mass=46, seed=seed), None
+    hp = oracle.default_sinkhorn()
+    hp.iterations = 12
+    cuts = [0, 131, N]
+    shards = [lloyd.Layer(K, pts[cuts[r]:cuts[r + 1]], kind, tri, hp=hp, seed=seed) for r in range(2)]
+    single = oracle.OracleKmeans(K, pts, kind, tri, hp=hp, seed=seed)
+    # k-means++ across shards with the exact integer prefix over ranks
+    for s in shards:
+        s.kpp_begin()
+    picks = []
+    for k in range(K):
+        totals = [s.kpp_total() for s in shards]
+        r = rp_mulhi64(rp_stream(seed, k), sum(totals))
+        owner, before = 0, 0
+        while r >= before + totals[owner]:
+            before += totals[owner]
+            owner += 1
+        idx = shards[owner].kpp_pick(r - before)
+        hist = shards[owner].get_point(idx)
+        picks.append(cuts[owner] + idx)
+        for s in shards:
+            s.set_centroid(k, hist)
+            s.kpp_update(k)
+    assert np.array_equal(np.array(picks, dtype=np.uint64), single.init_centroids())
+    for s in shards:
+        s.init_bounds()
+    single.init_bounds()
+    nb = shards[0].partial_bytes()
+    bufs = [torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    words32 = K * bins + K
+    off64 = (words32 * 4 + 7) & ~7
+    for _ in range(3):
+        for s, b in zip(shards, bufs):
+            s.step_local(b.data_ptr())
+        torch.cuda.synchronize()
+        red = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        red[: words32 * 4].view(torch.int32).copy_(bufs[0][: words32 * 4].view(torch.int32) + bufs[1][: words32 * 4].view(torch.int32))
+        red[off64:].view(torch.int64).copy_(bufs[0][off64:].view(torch.int64) + bufs[1][off64:].view(torch.int64))
+        torch.cuda.synchronize()
+        outs = [s.step_finish(red.data_ptr()) for s in shards]
+        d, sizes, _ = single.step()
+        for od, osz, _ in outs:
+            assert np.array_equal(od.view(np.uint32), d.view(np.uint32)) and np.array_equal(osz, sizes)
+    sc, sw = single.centroids()
+    sj, su, _ = single.bounds()
+    for r, s in enumerate(shards):
+        c, w = s.centroids()
+        assert np.array_equal(c, sc) and np.array_equal(w, sw)
+        j, u, _ = s.bounds()
+        assert np.array_equal(j, sj[cuts[r]:cuts[r + 1]])
+        assert np.array_equal(u.view(np.uint32), su[cuts[r]:cuts[r + 1]].view(np.uint32))
