@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1 << 16, help="trees per step per GPU (Solver::batch_size)")
+    ap.add_argument("--batch", type=int, default=1 << 18, help="trees per step per GPU (Solver::batch_size)")
     ap.add_argument("--game", default="leduc", choices=["leduc", "kuhn", "rps"])
     ap.add_argument("--regret", default="floored")
     ap.add_argument("--weight", default="linear")
@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-oracle baseline sample length (0 = skip)")
     ap.add_argument("--no-kmeans", action="store_true", help="skip the secondary k-means measurement")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="exercise the RCCL all-gather path even with one rank (plumbing check)")
     return ap.parse_args()
 
 
@@ -96,22 +98,25 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    sharded_mode = world > 1 or args.force_sharded
+    if sharded_mode:
         import torch
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     g = Game(args.game)
     A = g.max_actions
     solver = Solver(g, args.regret, args.weight, args.sampling, batch=args.batch, seed=args.seed, device=local_rank)
 
-    if world > 1:
+    if sharded_mode:
         from robopoker_amd.parallel import ShardedSolver
 
         # tree ids [rank*B, (rank+1)*B); one RCCL all-gather of the per-cell composed maps per step
-        sharded = ShardedSolver(solver, device="cuda", stream_ptr=torch.cuda.current_stream().cuda_stream)
+        sharded = ShardedSolver(solver, device="cuda")
 
         def step():
             sharded.step()
@@ -144,7 +149,7 @@ def main():
     cmp_ms, cmp_n = solver.kernel_time("compact")
     solver.profile(False)
 
-    if world > 1:
+    if sharded_mode:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -178,7 +183,7 @@ def main():
                 "workload": f"{args.game}-holdem external-sampling MCCFR, tables resident in HBM (BASELINE configs[1])",
                 "regret": args.regret, "weight": args.weight, "sampling": args.sampling,
                 "batch_per_gpu": args.batch, "global_batch": args.batch * world, "infosets": g.n_infos,
-                "actions": A, "update": "ordered" if world == 1 else "composed+allgather",
+                "actions": A, "update": "composed+allgather" if sharded_mode else "ordered",
                 "parallelism": f"tree-sharded x{world}",
             },
             "roofline": {
@@ -202,7 +207,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     solver.close()
-    if world > 1:
+    if sharded_mode:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -147,6 +147,22 @@ RP_HD float rp_div_by_recip(float a, float b, float r) {
     float e1 = fmaf(-b, q1, a);
     return fmaf(e1, r, q1);
 }
+/* One correction only, plus an EXACT proof of the result that stays off the dependent path: with the exact
+ * residual r1 = a - b*q1, q1 is the correctly rounded quotient iff |a/b - q1| < half the f32 spacing next to
+ * q1, i.e. 2|r1| < |b| * spacing (the smaller spacing is used when |q1| is a power of two; ties count as
+ * "not proven").  *proven = 0 happens essentially never; the caller then divides plainly. */
+RP_HD float rp_div_by_recip1(float a, float b, float r, int* proven) {
+    float q0 = a * r;
+    float e0 = fmaf(-b, q0, a);
+    float q1 = fmaf(e0, r, q0);
+    float r1 = fmaf(-b, q1, a);
+    uint32_t uq = rp_f2u(q1) & 0x7fffffffu;
+    uint32_t ex = (uq >> 23) - 23u - ((uq & 0x007fffffu) == 0u ? 1u : 0u);
+    float spacing = rp_u2f(ex << 23);
+    *proven = (a == 0.0f) || ((uq >> 23) >= 30u && 2.0f * rp_absf(r1) < rp_absf(b) * spacing);
+    return q1;
+}
+
 /* the same quotient through one f64 multiply: rd = 1.0 / (double)b.  a * rd carries a relative error
  * <= 2^-52 while an f32 quotient of f32 operands stays >= 2^-49 (relative) away from every rounding
  * midpoint, so rounding the product to f32 gives RN(a / b).  Same operand guarantees as above. */

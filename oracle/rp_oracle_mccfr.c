@@ -757,8 +757,11 @@ ORA_API void ora_math_selftest(uint64_t n, const float* x, const float* y, float
 
 /* brute-force check of rp_div_by_recip against IEEE division (tests/test_oracle_mccfr.py):
  * random and adversarial (quotient next to a rounding midpoint) numerators over integer divisors */
+static uint64_t g_div_unproven = 0;
+ORA_API uint64_t ora_div_unproven(void) { return g_div_unproven; }
 ORA_API uint64_t ora_div_by_recip_mismatches(uint64_t n, uint64_t seed) {
     uint64_t st = seed | 1ull, bad = 0;
+    g_div_unproven = 0;
     for (uint64_t it = 0; it < n; ++it) {
         st ^= st << 13; st ^= st >> 7; st ^= st << 17;
         uint64_t r1 = st;
@@ -785,6 +788,10 @@ ORA_API uint64_t ora_div_by_recip_mismatches(uint64_t n, uint64_t seed) {
         if (!rp_div_by_recip_ok(a)) continue;
         if (rp_f2u(rp_div_by_recip(a, b, 1.0f / b)) != rp_f2u(a / b)) bad += 1;
         if (rp_f2u(rp_div_by_recip64(a, 1.0 / (double)b)) != rp_f2u(a / b)) bad += 1;
+        int proven = 0;
+        float q1 = rp_div_by_recip1(a, b, 1.0f / b, &proven);
+        if (proven && rp_f2u(q1) != rp_f2u(a / b)) bad += 1; /* a proven quotient must be THE quotient */
+        if (!proven) g_div_unproven += 1;
     }
     return bad;
 }

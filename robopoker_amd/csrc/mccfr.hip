@@ -490,19 +490,29 @@ __device__ __forceinline__ uint32_t seg_base(const DevSorted& so, uint32_t info)
 
 // LDS carve of k_chain (bytes): regret/weight tiles, mask tiles, payoff / reciprocal / divisor tiles
 #define CHAIN_TILE_WORDS (TILE_FLOATS + 2u * RP_MAX_ACTIONS * TILE_PAD)
-#define CHAIN_LDS_WORDS (2u * CHAIN_TILE_WORDS + 2u * (TILE_FLOATS / 2u) + 6u * PTILE)
+#define CHAIN_LDS_WORDS (2u * CHAIN_TILE_WORDS + 2u * (TILE_FLOATS / 2u) + 7u * PTILE)
 
 // wave 0: regret + weight cells, universal op acc <- max(acc * d + delta, floor) (x * 1.0f is exact, so Summed /
 // Floored / Constant / Linear-weight schedules are the same instruction stream with d = 1).  wave 1: payoff + visits.
 // Tiles are double buffered: the global loads of tile t+1 are issued into registers BEFORE the chain over tile t
 // and committed to LDS after it, so HBM/L2 latency hides under the serial chain.  In LDS a tile is stream-major
 // ([cell][entry]) so each chain lane reads its own stream 4 entries at a time (ds_read_b128), 16 entries ahead.
-template <bool SIGNED, bool PRUNED>
-__global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted so, StepParams p) {
+//
+// COMPOSE = true turns the same streaming machinery into the multi-GPU summary (oracle: ora_mccfr_step_local):
+// instead of applying the touches to the table, every cell lane composes them into F(x) = max(a x + b, m) and
+// wave 1 sums the payoffs in tree order; nothing is written to the tables.
+template <bool SIGNED, bool PRUNED, bool COMPOSE>
+__global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted so, StepParams p, Cell* cells, InfoSum* sums) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t info = blockIdx.x;
-    if (g.info_player[info] != p.walker) return;
-    const uint32_t len = so.total[info];
+    const float NEG_INF = rp_u2f(0xff800000u);
+    const bool is_walker = g.info_player[info] == p.walker;
+    const uint32_t len = is_walker ? so.total[info] : 0u;
+    if (COMPOSE && len == 0) {  // identity maps for untouched infosets
+        if (threadIdx.x < g.A) cells[(size_t)info * g.A + threadIdx.x] = Cell{1.0f, 0.0f, NEG_INF, 1.0f, 0.0f, NEG_INF, 0u, 0u};
+        if (threadIdx.x == 0) sums[info] = InfoSum{0u, 0.0f};
+        return;
+    }
     if (len == 0) return;
     const uint32_t A = g.A, nact = g.info_actions[info], W2 = 2 * A;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
     const float tf = (float)p.epoch;
     float* tile = reinterpret_cast<float*>(smem);                                  // [2][CHAIN_TILE_WORDS]
     uint32_t* mtile = reinterpret_cast<uint32_t*>(tile + 2 * CHAIN_TILE_WORDS);    // [2][TILE_FLOATS / 2]
-    float* ptile = reinterpret_cast<float*>(mtile + TILE_FLOATS);                  // [2][3][PTILE]: payoff f32, 1/b f64
+    float* ptile = reinterpret_cast<float*>(mtile + TILE_FLOATS);                  // [2][3][PTILE]: payoff, 1/b, b
     if (wave == 0) {
         const uint32_t T = (TILE_FLOATS / W2) & ~3u;  // Decisions per tile, multiple of 4
         const uint32_t TP = T + TILE_PAD;             // row stride of the stream-major tile
@@ -531,6 +541,9 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
                 d = Discount{dw, dw, dw};
             }
         }
+        float ma = 1.0f, mb = 0.0f, mm = NEG_INF;  // COMPOSE: the composed map of this cell
+        uint32_t cnt = 0;
+        if (COMPOSE) acc = 0.0f;
         const uint32_t ntiles = (len + T - 1) / T;
         float rg[TILE_REGS];
         uint32_t mk[TILE_REGS / 2];
@@ -562,6 +575,18 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
             }
         };
         auto step = [&](float delta, uint32_t m) {
+            if (COMPOSE) {
+                // first touch: (d, delta, floor); then a <- a*d, b <- b*d + delta, m <- max(m*d + delta, floor)
+                const bool skip = PRUNED && isreg && !((m >> a) & 1u);
+                const float na = ma * d.zero;
+                const float nb = cnt ? mb * d.zero + delta : delta;
+                const float nm = cnt ? rp_maxf(mm * d.zero + delta, fl) : fl;
+                ma = skip ? ma : na;
+                mb = skip ? mb : nb;
+                mm = skip ? mm : nm;
+                cnt += skip ? 0u : 1u;
+                return;
+            }
             float dd = d.zero;
             if (SIGNED) dd = acc > 0.0f ? d.pos : (acc < 0.0f ? d.neg : d.zero);
             const float nv = rp_maxf(acc * dd + delta, fl);
@@ -606,14 +631,59 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
             if (more) commit(buf ^ 1u);
             __builtin_amdgcn_wave_barrier();
         }
-        if (chain) {
+        if (COMPOSE) {
+            if (lane < W2) {
+                Cell* c = &cells[(size_t)info * A + a];
+                if (!chain) { ma = 1.0f; mb = 0.0f; mm = NEG_INF; cnt = 0; }
+                if (isreg) { c->ra = ma; c->rb = mb; c->rm = mm; c->rn = cnt; }
+                else { c->wa = ma; c->wb = mb; c->wm = mm; c->wn = cnt; }
+            }
+        } else if (chain) {
             if (isreg) t.regret[cell] = acc;
             else t.weight[cell] = acc;
         }
+    } else if (COMPOSE) {
+        // payoffs summed in tree order (the exchange carries (count, sum) per infoset), streamed through LDS tiles
+        float psum = 0.0f;
+        const uint32_t ntiles = (len + PTILE - 1) / PTILE;
+        float rg[PTILE / 64];
+        auto issue = [&](uint32_t tl) {
+            const uint32_t n = min(PTILE, len - tl * PTILE);
+#pragma unroll
+            for (uint32_t r = 0; r < PTILE / 64; ++r) {
+                const uint32_t k = lane + 64 * r;
+                rg[r] = k < n ? so.payoff[base + (size_t)tl * PTILE + k] : 0.0f;
+            }
+        };
+        auto commit = [&](uint32_t buf) {
+#pragma unroll
+            for (uint32_t r = 0; r < PTILE / 64; ++r) ptile[buf * 3 * PTILE + lane + 64 * r] = rg[r];
+        };
+        issue(0);
+        commit(0);
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t tl = 0; tl < ntiles; ++tl) {
+            const uint32_t buf = tl & 1u;
+            const bool more = tl + 1 < ntiles;
+            if (more) issue(tl + 1);
+            const uint32_t n = min(PTILE, len - tl * PTILE);
+            const float* pt = ptile + buf * 3 * PTILE;
+            const uint32_t n4 = n & ~3u;
+            uint32_t i = 0;
+            for (; i < n4; i += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(pt + i);
+                psum += v.x; psum += v.y; psum += v.z; psum += v.w;
+            }
+            for (; i < n; ++i) psum += pt[i];
+            if (more) commit(buf ^ 1u);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) sums[info] = InfoSum{len, psum};
     } else {
         // Welford mean with the pre-increment visit count (solver.rs:174-192): ev += (payoff - ev) / (n + 1).
         // The divisor sequence is known in advance, so the whole wave precomputes b = (float)(n+1) and the
-        // correctly rounded 1/b per entry, and the serial chain divides with rp_div_by_recip (== IEEE a/b).
+        // correctly rounded 1/b per entry; the serial chain then needs mul + 2 fma per division
+        // (rp_div_by_recip1) and each quotient carries an exact off-path proof that it equals IEEE a / b.
         const bool chain = lane < nact;
         const size_t cell = (size_t)info * A + lane;
         float ev = 0.0f;
@@ -623,9 +693,13 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
             visits = t.visits[cell];
         }
         const uint32_t v0 = __shfl(visits, 0, 64);
-        const bool uniform = __all(!chain || visits == v0);  // every edge of an infoset is always visited together
+        const float ev0 = __shfl(ev, 0, 64);
+        // every edge of an infoset is always visited together, so all its (payoff, visits) cells hold the same
+        // value and ONE chain serves them; anything else (a hand-made import) takes the plain path below
+        const bool uniform = __all(!chain || (visits == v0 && rp_f2u(ev) == rp_f2u(ev0)));
+        float* hist = ptile + 6 * PTILE;  // [PTILE] ev after each touch of the current tile
+        if (uniform) ev = ev0;
         const float ev_start = ev;
-        bool bad = false;
         if (uniform) {
             const uint32_t ntiles = (len + PTILE - 1) / PTILE;
             float rg[PTILE / 64];
@@ -639,13 +713,13 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
             };
             auto commit = [&](uint32_t tl, uint32_t buf) {
                 float* pt = ptile + buf * 3 * PTILE;
-                double* rt = reinterpret_cast<double*>(pt + PTILE);
 #pragma unroll
                 for (uint32_t r = 0; r < PTILE / 64; ++r) {
                     const uint32_t k = lane + 64 * r;
                     const float b = (float)(v0 + tl * PTILE + k + 1u);  // (n + 1) as f32 (solver.rs:179)
                     pt[k] = rg[r];
-                    rt[k] = 1.0 / (double)b;
+                    pt[PTILE + k] = 1.0f / b;
+                    pt[2 * PTILE + k] = b;
                 }
             };
             issue(0);
@@ -657,34 +731,55 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
                 if (more) issue(tl + 1);
                 const uint32_t n = min(PTILE, len - tl * PTILE);
                 const float* pt = ptile + buf * 3 * PTILE;
-                const double* rt = reinterpret_cast<const double*>(pt + PTILE);
 #ifndef RP_EXPERIMENT_SKIP_PAYOFF
-                if (chain) {
+                // (1) the serial chain: 5 VALU ops per touch (sub, mul, fma, fma, add); lane 0 logs ev after each touch
+                const float ev_tile = ev;
+                {
+                    auto fast = [&](float pv, float rv, float bv) {
+                        const float s = pv - ev;
+                        const float q0 = s * rv;
+                        const float e0 = fmaf(-bv, q0, s);
+                        ev += fmaf(e0, rv, q0);
+                        return ev;
+                    };
                     const uint32_t n4 = n & ~3u;
                     uint32_t i = 0;
                     for (; i < n4; i += 4) {
                         const float4 pv = *reinterpret_cast<const float4*>(pt + i);
-                        const double2 ra = *reinterpret_cast<const double2*>(rt + i);
-                        const double2 rb = *reinterpret_cast<const double2*>(rt + i + 2);
-                        float s;
-                        s = pv.x - ev; bad |= !rp_div_by_recip_ok(s); ev += rp_div_by_recip64(s, ra.x);
-                        s = pv.y - ev; bad |= !rp_div_by_recip_ok(s); ev += rp_div_by_recip64(s, ra.y);
-                        s = pv.z - ev; bad |= !rp_div_by_recip_ok(s); ev += rp_div_by_recip64(s, rb.x);
-                        s = pv.w - ev; bad |= !rp_div_by_recip_ok(s); ev += rp_div_by_recip64(s, rb.y);
+                        const float4 rv = *reinterpret_cast<const float4*>(pt + PTILE + i);
+                        const float4 bv = *reinterpret_cast<const float4*>(pt + 2 * PTILE + i);
+                        float4 h;
+                        h.x = fast(pv.x, rv.x, bv.x); h.y = fast(pv.y, rv.y, bv.y);
+                        h.z = fast(pv.z, rv.z, bv.z); h.w = fast(pv.w, rv.w, bv.w);
+                        if (lane == 0) *reinterpret_cast<float4*>(hist + i) = h;
                     }
                     for (; i < n; ++i) {
-                        const float s = pt[i] - ev;
-                        bad |= !rp_div_by_recip_ok(s);
-                        ev += rp_div_by_recip64(s, rt[i]);
+                        const float e = fast(pt[i], pt[PTILE + i], pt[2 * PTILE + i]);
+                        if (lane == 0) hist[i] = e;
                     }
                 }
+                __builtin_amdgcn_wave_barrier();
+                // (2) the proof, lane-parallel and off the chain: every touch's quotient is re-derived from the logged
+                //     ev and checked with the exact-residual criterion of rp_div_by_recip1 (== IEEE s / b when proven)
+                bool bad = false;
+                for (uint32_t k = lane; k < n; k += 64) {
+                    const float prev = k ? hist[k - 1] : ev_tile;
+                    int proven;
+                    const float q = rp_div_by_recip1(pt[k] - prev, pt[2 * PTILE + k], pt[PTILE + k], &proven);
+                    bad |= !proven || (prev + q != hist[k]);
+                }
+                if (__any(bad)) {  // essentially never: redo this tile with IEEE divisions
+                    ev = ev_tile;
+                    for (uint32_t k = 0; k < n; ++k) ev += (pt[k] - ev) / pt[2 * PTILE + k];
+                }
+                __builtin_amdgcn_wave_barrier();
 #endif
                 if (more) commit(tl + 1, buf ^ 1u);
                 __builtin_amdgcn_wave_barrier();
             }
         }
         if (chain) {
-            if (!uniform || bad) {  // plain IEEE divisions (never taken in practice; keeps the result exact regardless)
+            if (!uniform) {  // edges of one infoset with different visit counts (only after a hand-made import)
                 ev = ev_start;
                 uint32_t v = visits;
                 for (uint32_t i = 0; i < len; ++i) {
@@ -699,46 +794,8 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_summarize / k_fold: the multi-GPU exchange (oracle: ora_mccfr_step_world).  One wave per infoset
-// composes its tree-ordered segment into F(x) = max(a x + b, m) per table cell.
+// k_fold: the receiving side of the multi-GPU exchange (oracle: ora_mccfr_step_apply)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_summarize(DevGame g, DevSorted so, StepParams p, Cell* cells, InfoSum* sums) {
-    const uint32_t info = blockIdx.x;
-    const uint32_t A = g.A, nact = g.info_actions[info], W2 = 2 * A;
-    const uint32_t lane = threadIdx.x;
-    const float NEG_INF = rp_u2f(0xff800000u);
-    const bool walker = g.info_player[info] == p.walker;
-    const uint32_t len = walker ? so.total[info] : 0u;
-    const size_t base = walker ? seg_base(so, info) : 0;
-    const bool isreg = lane < A;
-    const uint32_t a = lane % A;
-    const bool chain = lane < W2 && a < nact;
-    const float tf = (float)p.epoch;
-    const float floor_v = isreg ? regret_floor_of(p.R, p.regret_min) : RP_EPSILON;
-    const float dd = isreg ? (p.R == RP_REGRET_LINEAR ? tf / (tf + 1.0f) : 1.0f) : (p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f);
-    float ma = 1.0f, mb = 0.0f, mm = NEG_INF;
-    uint32_t cnt = 0;
-    if (chain) {
-        for (uint32_t i = 0; i < len; ++i) {
-            if (isreg && !((so.mask[base + i] >> a) & 1u)) continue;
-            const float dl = so.rw[(base + i) * W2 + lane];
-            if (cnt == 0) { ma = dd; mb = dl; mm = floor_v; }
-            else { ma = ma * dd; mb = mb * dd + dl; mm = rp_maxf(mm * dd + dl, floor_v); }
-            cnt += 1;
-        }
-    }
-    if (lane < W2) {
-        Cell* c = &cells[(size_t)info * A + a];
-        if (isreg) { c->ra = ma; c->rb = mb; c->rm = mm; c->rn = cnt; }
-        else { c->wa = ma; c->wb = mb; c->wm = mm; c->wn = cnt; }
-    }
-    if (lane == W2) {  // one extra lane sums the payoffs in tree order
-        float psum = 0.0f;
-        for (uint32_t i = 0; i < len; ++i) psum += so.payoff[base + i];
-        sums[info] = InfoSum{len, psum};
-    }
-}
-
 // one thread per table cell; `blob` holds `world` summaries back to back: [cells][sums]
 __global__ void k_fold(DevGame g, DevTables t, const unsigned char* blob, size_t blob_stride, uint32_t world) {
     const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
@@ -991,10 +1048,12 @@ int launch_chain(rp_mccfr* h, const StepParams& p) {
     const bool prn = h->S != RP_SAMPLING_EXTERNAL;
     const dim3 grid(h->tbl.n_infos), block(128);
     clock_begin(h, h->clk_update);
-    if (sgn && prn) hipLaunchKernelGGL((k_chain<true, true>), grid, block, lds, h->stream, h->g, h->t, h->so, p);
-    else if (sgn) hipLaunchKernelGGL((k_chain<true, false>), grid, block, lds, h->stream, h->g, h->t, h->so, p);
-    else if (prn) hipLaunchKernelGGL((k_chain<false, true>), grid, block, lds, h->stream, h->g, h->t, h->so, p);
-    else hipLaunchKernelGGL((k_chain<false, false>), grid, block, lds, h->stream, h->g, h->t, h->so, p);
+    Cell* nc = nullptr;
+    InfoSum* ns = nullptr;
+    if (sgn && prn) hipLaunchKernelGGL((k_chain<true, true, false>), grid, block, lds, h->stream, h->g, h->t, h->so, p, nc, ns);
+    else if (sgn) hipLaunchKernelGGL((k_chain<true, false, false>), grid, block, lds, h->stream, h->g, h->t, h->so, p, nc, ns);
+    else if (prn) hipLaunchKernelGGL((k_chain<false, true, false>), grid, block, lds, h->stream, h->g, h->t, h->so, p, nc, ns);
+    else hipLaunchKernelGGL((k_chain<false, false, false>), grid, block, lds, h->stream, h->g, h->t, h->so, p, nc, ns);
     clock_end(h, h->clk_update);
     HIP_TRY(hipGetLastError());
     return RP_OK;
@@ -1004,8 +1063,13 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev) {
     unsigned char* blob = reinterpret_cast<unsigned char*>(blob_dev);
     Cell* cells = reinterpret_cast<Cell*>(blob);
     InfoSum* sums = reinterpret_cast<InfoSum*>(blob + (size_t)h->tbl.n_infos * h->tbl.max_actions * sizeof(Cell));
+    const size_t lds = chain_lds_bytes(h->tbl.max_actions);
+    const dim3 grid(h->tbl.n_infos), block(128);
     clock_begin(h, h->clk_update);
-    hipLaunchKernelGGL(k_summarize, dim3(h->tbl.n_infos), dim3(64), 0, h->stream, h->g, h->so, p, cells, sums);
+    if (h->S != RP_SAMPLING_EXTERNAL)
+        hipLaunchKernelGGL((k_chain<false, true, true>), grid, block, lds, h->stream, h->g, h->t, h->so, p, cells, sums);
+    else
+        hipLaunchKernelGGL((k_chain<false, false, true>), grid, block, lds, h->stream, h->g, h->t, h->so, p, cells, sums);
     clock_end(h, h->clk_update);
     HIP_TRY(hipGetLastError());
     return RP_OK;

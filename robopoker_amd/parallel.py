@@ -48,25 +48,48 @@ def _all_gather_bytes(out: torch.Tensor, mine: torch.Tensor, group=None):
         dist.all_gather(parts, mine, group=group)
 
 
+class _StreamScope:
+    """On a GPU the engine's kernels and the collectives must share ONE stream so they are ordered without host
+    synchronisation: a dedicated (non-null) torch stream is handed to the engine and made current around every
+    step.  On CPU (gloo tests) this is a no-op."""
+
+    def __init__(self, engine, device):
+        self.stream = None
+        if str(device) != "cpu":
+            self.stream = torch.cuda.Stream()
+            engine.set_stream(self.stream.cuda_stream)
+
+    def __enter__(self):
+        if self.stream is not None:
+            self._ctx = torch.cuda.stream(self.stream)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.stream is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+
 class ShardedSolver:
     """Tree-sharded MCCFR: rank r samples tree ids [r*B, (r+1)*B) of a world*B-tree epoch."""
 
-    def __init__(self, engine, device="cpu", group=None, stream_ptr=None):
+    def __init__(self, engine, device="cpu", group=None):
         self.engine = engine
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         engine.set_shard(self.rank, self.world)
-        if stream_ptr is not None:
-            engine.set_stream(stream_ptr)
+        self.scope = _StreamScope(engine, device)
         n = engine.summary_bytes()
         self.mine = torch.empty(n, dtype=torch.uint8, device=device)
         self.all = torch.empty(n * self.world, dtype=torch.uint8, device=device)
 
     def step(self):
-        self.engine.step_local(self.mine.data_ptr())
-        _all_gather_bytes(self.all, self.mine, self.group)
-        self.engine.step_apply(self.all.data_ptr(), self.world)
+        with self.scope:
+            self.engine.step_local(self.mine.data_ptr())
+            _all_gather_bytes(self.all, self.mine, self.group)
+            self.engine.step_apply(self.all.data_ptr(), self.world)
 
     def solve(self, trees_per_rank: int, batch: int):
         for _ in range(trees_per_rank // batch):
@@ -77,15 +100,14 @@ class ShardedSolver:
 class ShardedLayer:
     """Point-sharded Elkan k-means: this rank owns the contiguous point range [lo, hi) of the global set."""
 
-    def __init__(self, engine, K: int, bins: int, seed: int, device="cpu", group=None, stream_ptr=None):
+    def __init__(self, engine, K: int, bins: int, seed: int, device="cpu", group=None):
         self.engine = engine
         self.K, self.bins, self.seed = K, bins, seed
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = device
-        if stream_ptr is not None:
-            engine.set_stream(stream_ptr)
+        self.scope = _StreamScope(engine, device)
         self.nbytes = engine.partial_bytes()
         self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
         # partial layout: [K*bins u32][K u32][pad to 8][K u64]
@@ -147,7 +169,8 @@ class ShardedLayer:
 
     def step(self):
         """Kmeans::next with the centroid sums all-reduced across ranks (exact integers, order free)."""
-        self.engine.step_local(self.buf.data_ptr())
-        dist.all_reduce(self.buf[: self.words32 * 4].view(torch.int32), op=dist.ReduceOp.SUM, group=self.group)
-        dist.all_reduce(self.buf[self.off64:].view(torch.int64), op=dist.ReduceOp.SUM, group=self.group)
-        return self.engine.step_finish(self.buf.data_ptr())
+        with self.scope:
+            self.engine.step_local(self.buf.data_ptr())
+            dist.all_reduce(self.buf[: self.words32 * 4].view(torch.int32), op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self.buf[self.off64:].view(torch.int64), op=dist.ReduceOp.SUM, group=self.group)
+            return self.engine.step_finish(self.buf.data_ptr())

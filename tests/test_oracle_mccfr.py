@@ -192,3 +192,6 @@ def test_division_by_reciprocal_is_exact():
     o.ora_div_by_recip_mismatches.restype = C.c_uint64
     o.ora_div_by_recip_mismatches.argtypes = [C.c_uint64, C.c_uint64]
     assert o.ora_div_by_recip_mismatches(40_000_000, 12345) == 0
+    o.ora_div_unproven.restype = C.c_uint64
+    # the single-correction quotient carries an exact proof; "not proven" (-> plain division) must stay rare
+    assert o.ora_div_unproven() < 40_000_000 * 1e-3
