@@ -70,12 +70,13 @@ RP_HD float rp_absf(float a) { return rp_u2f(rp_f2u(a) & 0x7fffffffu); }
  * x < -87.34 flushes to +0 (the Sinkhorn softmin clamps every term at
  * MIN_POSITIVE afterwards, sinkhorn.rs:124-126); x > 88.72 -> +inf. */
 RP_HD float rp_expf(float x) {
-    if (!(x == x)) return x;
-    if (x > 88.72283f) return rp_u2f(0x7f800000u);
-    if (x < -87.33654f) return 0.0f;
+    /* branch free: evaluate on the clamped argument, patch the special cases with selects at the end */
+    float xc = x > 88.72283f ? 88.72283f : x;
+    xc = xc < -87.33654f ? -87.33654f : xc;
+    xc = (x == x) ? xc : 0.0f;
     const float MAGIC = 12582912.0f; /* 1.5 * 2^23: round-to-nearest-even via add/sub */
-    float kf = (x * 1.44269504088896341f + MAGIC) - MAGIC;
-    float r = fmaf(kf, -0.693359375f, x);
+    float kf = (xc * 1.44269504088896341f + MAGIC) - MAGIC;
+    float r = fmaf(kf, -0.693359375f, xc);
     r = fmaf(kf, 2.12194440e-4f, r);
     float p = 1.9875691500e-4f;
     p = fmaf(p, r, 1.3981999507e-3f);
@@ -90,7 +91,10 @@ RP_HD float rp_expf(float x) {
     int k2 = k - k1;
     float s1 = rp_u2f((uint32_t)(k1 + 127) << 23);
     float s2 = rp_u2f((uint32_t)(k2 + 127) << 23);
-    return (y * s1) * s2;
+    float res = (y * s1) * s2;
+    res = x > 88.72283f ? rp_u2f(0x7f800000u) : res;
+    res = x < -87.33654f ? 0.0f : res;
+    return (x == x) ? res : x;
 }
 
 /* ln x, ~1 ulp.  Cephes-style: x = m * 2^e with m in [sqrt(1/2), sqrt(2)),

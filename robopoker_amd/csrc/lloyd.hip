@@ -123,7 +123,17 @@ __device__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint32_t n, const Me
             const bool act = i < m;
             const uint32_t x = act ? w.supA[i] : w.supA[0];
             float s = 0.0f;
-            for (uint32_t j = 0; j < n; ++j) {
+            uint32_t j = 0;
+            for (; j + 8 <= n; j += 8) {  // 8 independent loads + exps in flight; the sum stays a left fold
+                float e[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) e[q] = w.g[j + q] - M.Rt[(uint32_t)w.supB[j + q] * bins + x];
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) e[q] = rp_maxf(rp_expf(e[q]), RP_EPSILON);
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) s += e[q];
+            }
+            for (; j < n; ++j) {
                 const uint32_t y = w.supB[j];
                 const float e = rp_expf(w.g[j] - M.Rt[y * bins + x]);
                 s += rp_maxf(e, RP_EPSILON);
@@ -144,7 +154,17 @@ __device__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint32_t n, const Me
             const bool act = j < n;
             const uint32_t y = act ? w.supB[j] : w.supB[0];
             float s = 0.0f;
-            for (uint32_t i = 0; i < m; ++i) {
+            uint32_t i = 0;
+            for (; i + 8 <= m; i += 8) {
+                float e[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) e[q] = w.f[i + q] - M.Rt[(uint32_t)w.supA[i + q] * bins + y];
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) e[q] = rp_maxf(rp_expf(e[q]), RP_EPSILON);
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) s += e[q];
+            }
+            for (; i < m; ++i) {
                 const uint32_t x = w.supA[i];
                 const float e = rp_expf(w.f[i] - M.Rt[x * bins + y]);
                 s += rp_maxf(e, RP_EPSILON);

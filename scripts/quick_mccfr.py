@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0,'.')
+import os; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,'tests'))
 from robopoker_amd import Game
 from robopoker_amd.mccfr import Solver
 g=Game("leduc")
