@@ -285,6 +285,8 @@ RP_API int rp_kmeans_metric(rp_kmeans* h, float* tri);
 RP_API int rp_kmeans_rms(rp_kmeans* h, float* out);
 /* number of distance evaluations so far (Sinkhorn/variation calls incl. self terms), for reporting */
 RP_API int rp_kmeans_stats(rp_kmeans* h, uint64_t* distances, uint64_t* sinkhorn_iterations);
+/* exp evaluations spent in Sinkhorn softmin / cost loops so far: sum over solves of (2*iterations + 1) * m * n */
+RP_API int rp_kmeans_exp_evals(rp_kmeans* h, uint64_t* evals);
 RP_API int rp_kmeans_set_stream(rp_kmeans* h, void* hip_stream);
 RP_API int rp_kmeans_profile(rp_kmeans* h, int enable);
 /* name in {"pairwise","step","recompute","bounds","neighbor","selfcost","kpp"} */

@@ -162,6 +162,7 @@ _SIGNATURES = {
     "rp_kmeans_metric": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_kmeans_rms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rp_kmeans_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rp_kmeans_exp_evals": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rp_kmeans_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_kmeans_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "rp_kmeans_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

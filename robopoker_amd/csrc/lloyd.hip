@@ -39,7 +39,7 @@ struct Metric {
     uint32_t bins;
     uint32_t iters;
     float tol;
-    unsigned long long* stats;  // [0] distances, [1] sinkhorn iterations
+    unsigned long long* stats;  // [0] distances, [1] sinkhorn iterations, [2] exp evaluations of the softmin/cost loops
 };
 
 // one prepared centroid set: integer sums + the derived support / log-density tables
@@ -184,7 +184,10 @@ __device__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint32_t n, const Me
             break;
         }
     }
-    if (lane == 0) atomicAdd(&M.stats[1], (unsigned long long)t);
+    if (lane == 0) {
+        atomicAdd(&M.stats[1], (unsigned long long)t);
+        atomicAdd(&M.stats[2], (unsigned long long)(2 * t + 1) * m * n);
+    }
     // cost(): x-major left fold of coupling * distance (sinkhorn.rs:206-217)
     float cost = 0.0f;
     for (uint32_t i = 0; i < m; ++i) {
@@ -773,12 +776,12 @@ __global__ __launch_bounds__(64) void k_pair_iters(const uint32_t* mu, const uin
         wb += __shfl_xor(wb, d, 64);
     }
     Metric mine = M;
-    mine.stats = scratch + 2 * p;
+    mine.stats = scratch + 4 * p;
     const uint32_t m = wave_load_hist(mu + p * bins, wa, bins, w.supA, w.lnA);
     const uint32_t n = wave_load_hist(nu + p * bins, wb, bins, w.supB, w.lnB);
     (void)wave_sinkhorn_cost(w, m, n, mine);
     __syncthreads();
-    if (lane == 0) iters_out[p] = (uint32_t)scratch[2 * p + 1];
+    if (lane == 0) iters_out[p] = (uint32_t)scratch[4 * p + 1];
 }
 __global__ void k_pair_variation(const uint32_t* x, const uint32_t* y, uint32_t bins, uint64_t pairs, float* out) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -943,8 +946,14 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         h->owns_counts = false;
     } else {
         KM_TRY(dev_alloc(h, &d_counts, (size_t)N * h->stride));
-        KM_HIP(hipMemset(d_counts, 0, (size_t)N * h->stride));
-        KM_HIP(hipMemcpy2D(d_counts, h->stride, counts, bins, bins, N, hipMemcpyHostToDevice));
+        if (h->stride == bins) {
+            KM_HIP(hipMemcpy(d_counts, counts, (size_t)N * bins, hipMemcpyHostToDevice));
+        } else {  // pad rows to 16 B on the host: one large copy instead of N pitched ones
+            std::vector<uint8_t> padded((size_t)N * h->stride, 0);
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(counts);
+            for (uint64_t i = 0; i < N; ++i) memcpy(&padded[i * h->stride], src + i * bins, bins);
+            KM_HIP(hipMemcpy(d_counts, padded.data(), padded.size(), hipMemcpyHostToDevice));
+        }
     }
     uint32_t* d_w = nullptr;
     float* d_self = nullptr;
@@ -968,8 +977,8 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         KM_HIP(hipMemcpy(d_C, C.data(), C.size() * 4, hipMemcpyHostToDevice));
         KM_HIP(hipMemcpy(d_R, R.data(), R.size() * 4, hipMemcpyHostToDevice));
     }
-    KM_TRY(dev_alloc(h, &h->stats, 2));
-    KM_HIP(hipMemset(h->stats, 0, 16));
+    KM_TRY(dev_alloc(h, &h->stats, 4));
+    KM_HIP(hipMemset(h->stats, 0, 32));
     h->M = Metric{d_C, d_R, bins, h->hp.iterations, h->hp.tolerance, h->stats};
     KM_TRY(alloc_centroid_set(h, &h->cs[0]));
     KM_TRY(alloc_centroid_set(h, &h->cs[1]));
@@ -1390,6 +1399,16 @@ int rp_kmeans_stats(rp_kmeans* h, uint64_t* distances, uint64_t* sinkhorn_iterat
     return RP_OK;
 }
 
+int rp_kmeans_exp_evals(rp_kmeans* h, uint64_t* evals) {
+    if (!h || !evals) return rp::fail(RP_ERR_INVALID, "rp_kmeans_exp_evals: NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, h->stats + 2, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *evals = v;
+    return RP_OK;
+}
+
 int rp_kmeans_set_stream(rp_kmeans* h, void* hip_stream) {
     if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_set_stream: NULL handle");
     HIP_TRY(hipSetDevice(h->device));
@@ -1456,8 +1475,8 @@ int pair_common(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_
     HIP_TRY(hipMalloc(&dout, pairs * 4));
     HIP_TRY(hipMalloc(&dmu, hb));
     HIP_TRY(hipMalloc(&dnu, hb));
-    HIP_TRY(hipMalloc(&dstats, 16));
-    HIP_TRY(hipMemset(dstats, 0, 16));
+    HIP_TRY(hipMalloc(&dstats, 32));
+    HIP_TRY(hipMemset(dstats, 0, 32));
     HIP_TRY(hipMemcpy(dC, C.data(), C.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dR, R.data(), R.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dmu, mu, hb, hipMemcpyHostToDevice));
@@ -1468,8 +1487,8 @@ int pair_common(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_
     HIP_TRY(hipMemcpy(out, dout, pairs * 4, hipMemcpyDeviceToHost));
     if (iterations) {
         HIP_TRY(hipMalloc(&dit, pairs * 4));
-        HIP_TRY(hipMalloc(&dscr, pairs * 16));
-        HIP_TRY(hipMemset(dscr, 0, pairs * 16));
+        HIP_TRY(hipMalloc(&dscr, pairs * 32));
+        HIP_TRY(hipMemset(dscr, 0, pairs * 32));
         hipLaunchKernelGGL(k_pair_iters, dim3((unsigned)pairs), dim3(64), 0, 0, dmu, dnu, M, dscr, dit);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(iterations, dit, pairs * 4, hipMemcpyDeviceToHost));

@@ -138,6 +138,11 @@ class Layer:
         _lib.check(self._lib.rp_kmeans_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def exp_evals(self) -> int:
+        v = C.c_uint64()
+        _lib.check(self._lib.rp_kmeans_exp_evals(self._h, C.byref(v)))
+        return v.value
+
     # ---- multi-GPU exchange --------------------------------------------------------
     def partial_bytes(self) -> int:
         n = C.c_size_t()
@@ -225,9 +230,12 @@ def smoke(oracle) -> None:
     dev.close()
 
 
-def bench_slice(n_points: int = 4096, K: int = 256, bins: int = 256, iters: int = 2, seed: int = 0xF10F):
+def bench_slice(n_points: int = 16384, K: int = 256, bins: int = 256, iters: int = 2, seed: int = 0xF10F):
     """points/sec of Elkan iterations on a bounded slice of the flop-street configuration (BASELINE configs[2]):
-    K = 256 centroids, 256-bin histograms of mass 47, Sinkhorn T=0.025 / <=128 iterations / tol 5e-4."""
+    K = 256 centroids, 256-bin histograms of mass 47, Sinkhorn T=0.025 / <=128 iterations / tol 5e-4.
+
+    Reports the Sinkhorn phase against the VALU roofline (it is exp-bound, not HBM-bound: SURVEY §8d) and the
+    bound-update phase against the HBM roofline (2 * 4 * K bytes of lower bounds per point, read + written)."""
     import os
     import sys
 
@@ -243,16 +251,25 @@ def bench_slice(n_points: int = 4096, K: int = 256, bins: int = 256, iters: int 
     layer.init_bounds()
     t_bounds = time.perf_counter() - t0
     d0, i0 = layer.stats()
+    e0 = layer.exp_evals()
     layer.profile(True)
     t0 = time.perf_counter()
     for _ in range(iters):
         layer.step()
     dt = time.perf_counter() - t0
     d1, i1 = layer.stats()
+    e1 = layer.exp_evals()
     step_ms, step_n = layer.kernel_time("step")
     pw_ms, pw_n = layer.kernel_time("pairwise")
     bd_ms, bd_n = layer.kernel_time("bounds")
+    dr_ms, dr_n = layer.kernel_time("drift")
+    sc_ms, sc_n = layer.kernel_time("selfcost")
     layer.profile(False)
+    sinkhorn_s = (step_ms + pw_ms + dr_ms + sc_ms) * 1e-3
+    # one rp_expf + clamp + accumulate is ~30 VALU instructions; 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz = 78.6e12 lane-ops/s
+    valu_peak_exps = 78.6e12 / 30.0
+    exps = e1 - e0
+    bd_avg_s = bd_ms / max(bd_n, 1) * 1e-3
     out = {
         "metric": "kmeans_points_per_sec",
         "value": n_points * iters / dt,
@@ -263,8 +280,16 @@ def bench_slice(n_points: int = 4096, K: int = 256, bins: int = 256, iters: int 
         "init_bounds_distances_per_sec": n_points * K / t_bounds,
         "distances": d1 - d0,
         "sinkhorn_iterations": i1 - i0,
+        "exp_evals": exps,
+        "roofline_sinkhorn": {"bound": "valu-exp", "achieved": exps / sinkhorn_s if sinkhorn_s > 0 else 0.0,
+                              "peak": valu_peak_exps, "unit": "exp/s",
+                              "frac": (exps / sinkhorn_s) / valu_peak_exps if sinkhorn_s > 0 else 0.0,
+                              "note": "software rp_expf (bit-reproducible on the CPU), ~30 VALU ops per softmin term"},
+        "roofline_bounds": {"bound": "hbm", "achieved": (n_points * K * 8) / bd_avg_s / 1e9 if bd_avg_s > 0 else 0.0,
+                            "peak": 8000.0, "unit": "GB/s",
+                            "frac": (n_points * K * 8) / bd_avg_s / 1e9 / 8000.0 if bd_avg_s > 0 else 0.0},
         "kernels_ms": {"step": step_ms / max(step_n, 1), "pairwise": pw_ms / max(pw_n, 1),
-                       "bounds": bd_ms / max(bd_n, 1)},
+                       "bounds": bd_ms / max(bd_n, 1), "drift": dr_ms / max(dr_n, 1)},
     }
     layer.close()
     return out

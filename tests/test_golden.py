@@ -1,0 +1,139 @@
+"""Committed golden vectors (tests/golden/*.json, made by scripts/make_golden.py from the CPU oracle).
+
+CPU tests: the oracle still reproduces them (freezes rp_math.h, the RNG definitions and the f32 operation order
+across rounds).  GPU tests: the HIP path reproduces the same committed bits without the oracle in the loop.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from lloyd_fixtures import flop_hist, flop_like_points, flop_metric, smooth_metric, turn_like_points
+from robopoker_amd import Game
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32).tolist()
+
+
+def _hyper(case):
+    hp = oracle.default_hyper()
+    hp.prune_warmup = case["prune_warmup"]
+    hp.prune_threshold = case["prune_threshold"]
+    return hp
+
+
+def _check_tables(rows, case):
+    assert bits(rows["regret"]) == case["regret_bits"]
+    assert bits(rows["weight"]) == case["weight_bits"]
+    assert bits(rows["payoff"]) == case["payoff_bits"]
+    assert rows["visits"].tolist() == case["visits"]
+
+
+def _points(case):
+    if case["kind"] == "sinkhorn":
+        return (flop_like_points(case["N"], bins=case["bins"], mass=case["mass"], seed=case["seed"]),
+                smooth_metric(case["bins"], case["seed"]))
+    return turn_like_points(case["N"], bins=case["bins"], mass=case["mass"], seed=case["seed"]), None
+
+
+def _run_kmeans(km, case):
+    assert km.init_centroids().tolist() == case["chosen"]
+    km.init_bounds()
+    for k in range(3):
+        d, sizes, _ = km.step()
+        assert bits(d) == case["drift_bits"][k]
+    assert sizes.tolist() == case["sizes"]
+    b, dist = km.assign() if hasattr(km, "assign") else km.lookup()
+    assert b.tolist() == case["buckets"] and bits(dist) == case["distance_bits"]
+    c, w = km.centroids()
+    assert w.tolist() == case["centroid_weight"] and int(c.astype(np.uint64).sum()) == case["centroid_checksum"]
+    assert bits(km.metric()) == case["metric_bits"]
+    assert bits([km.rms()])[0] == case["rms_bits"]
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+@pytest.mark.parametrize("case", load("mccfr_tables.json"), ids=lambda c: f"{c['game']}-{c['regret']}-{c['sampling']}")
+def test_oracle_reproduces_mccfr_golden(case):
+    s = oracle.OracleSolver(Game(case["game"]), case["regret"], case["weight"], case["sampling"], batch=case["batch"],
+                            seed=case["seed"], hyper=_hyper(case))
+    for _ in range(case["steps"]):
+        s.step()
+    _check_tables(s.export(), case)
+    assert list(s.counters()) == case["counters"]
+    assert bits([s.exploitability()])[0] == case["exploitability_bits"]
+
+
+def test_oracle_reproduces_sinkhorn_golden():
+    g = load("sinkhorn.json")
+    tri = flop_metric()
+    for c in g["sinkhorn"]:
+        mu, nu = flop_hist([tuple(e) for e in c["mu"]]), flop_hist([tuple(e) for e in c["nu"]])
+        cost, it = oracle.sinkhorn_cost(mu, nu, tri)
+        assert bits([cost])[0] == c["cost_bits"] and it == c["iterations"]
+        assert bits([oracle.sinkhorn_divergence(mu, nu, tri)])[0] == c["divergence_bits"]
+    pts = turn_like_points(8, bins=101, mass=46, seed=11).astype(np.uint32)
+    for v in g["variation"]:
+        assert bits([oracle.equity_variation(pts[v["i"]], pts[v["j"]])])[0] == v["bits"]
+
+
+@pytest.mark.parametrize("case", load("kmeans.json"), ids=lambda c: c["kind"])
+def test_oracle_reproduces_kmeans_golden(case):
+    pts, tri = _points(case)
+    hp = oracle.default_sinkhorn()
+    hp.iterations = case["sinkhorn_iterations"]
+    _run_kmeans(oracle.OracleKmeans(case["K"], pts, case["kind"], tri, hp=hp, seed=case["seed"]), case)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", load("mccfr_tables.json"), ids=lambda c: f"{c['game']}-{c['regret']}-{c['sampling']}")
+def test_device_reproduces_mccfr_golden(gpu, case):
+    from robopoker_amd.mccfr import Solver
+
+    s = Solver(Game(case["game"]), case["regret"], case["weight"], case["sampling"], batch=case["batch"],
+               seed=case["seed"], hyper=_hyper(case))
+    for _ in range(case["steps"]):
+        s.step()
+    _check_tables(s.export(), case)
+    assert list(s.counters()) == case["counters"]
+    assert bits([s.exploitability()])[0] == case["exploitability_bits"]
+
+
+@pytest.mark.gpu
+def test_device_reproduces_sinkhorn_golden(gpu):
+    from robopoker_amd import lloyd
+
+    g = load("sinkhorn.json")
+    tri = flop_metric()
+    mu = np.stack([flop_hist([tuple(e) for e in c["mu"]]) for c in g["sinkhorn"]])
+    nu = np.stack([flop_hist([tuple(e) for e in c["nu"]]) for c in g["sinkhorn"]])
+    cost, it = lloyd.sinkhorn_cost(mu, nu, tri)
+    div = lloyd.sinkhorn_divergence(mu, nu, tri)
+    assert bits(cost) == [c["cost_bits"] for c in g["sinkhorn"]]
+    assert it.tolist() == [c["iterations"] for c in g["sinkhorn"]]
+    assert bits(div) == [c["divergence_bits"] for c in g["sinkhorn"]]
+    pts = turn_like_points(8, bins=101, mass=46, seed=11).astype(np.uint32)
+    x = np.stack([pts[v["i"]] for v in g["variation"]])
+    y = np.stack([pts[v["j"]] for v in g["variation"]])
+    assert bits(lloyd.equity_variation(x, y)) == [v["bits"] for v in g["variation"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", load("kmeans.json"), ids=lambda c: c["kind"])
+def test_device_reproduces_kmeans_golden(gpu, case):
+    from robopoker_amd import lloyd
+
+    pts, tri = _points(case)
+    hp = oracle.default_sinkhorn()
+    hp.iterations = case["sinkhorn_iterations"]
+    _run_kmeans(lloyd.Layer(case["K"], pts, case["kind"], tri, hp=hp, seed=case["seed"]), case)
