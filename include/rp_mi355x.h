@@ -154,6 +154,13 @@ typedef enum rp_update_mode {
     RP_UPDATE_COMPOSED = 1 /* per-key composed (a,b,floor) maps; used for the multi-GPU exchange         */
 } rp_update_mode;
 
+/* Composed update: the tree-ordered touches of an infoset are cut into blocks of rp_compose_block(A)
+ * consecutive Decisions; each block is composed sequentially from the identity into a map
+ * F(x) = max(a x + b, m) per table cell, the block maps are then composed in block order, and the result is
+ * applied to the table (rank by rank in the multi-GPU exchange).  Exact in real arithmetic; in f32 it is a
+ * fixed re-association of the reference's sequential update (tests state the tolerance). */
+static inline uint32_t rp_compose_block(uint32_t max_actions) { return (1024u / (2u * max_actions)) & ~3u; }
+
 /* mccfr!(Prefix, Encoder, T, E, G, I, batch) + <R, W, S> (strategy/macros.rs:7-151): one solver instance.
  * `batch_size` = Solver::batch_size() (trees per step). */
 RP_API int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind w, rp_sampling_kind s,

@@ -23,6 +23,7 @@
  * `choices()` order; petgraph's newest-edge-first adjacency over children pushed in reverse pop order
  * yields `choices()` order — mccfr/src/state/node.rs:103-107, solver/builder.rs:141-161).
  */
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -538,40 +539,90 @@ ORA_API size_t ora_mccfr_summary_bytes(const ora_mccfr* h) {
     return (size_t)h->g.n_infos * h->g.max_actions * sizeof(ora_cell) + (size_t)h->g.n_infos * sizeof(ora_isum);
 }
 
-/* rp_mccfr_step_local: this rank's trees [rank*B, (rank+1)*B) against the current table -> composed maps */
+/* composition of two per-cell maps, `first` applied before `second`:
+ * an untouched map is the identity and is skipped exactly; -inf floors stay -inf (no 0 * inf) */
+typedef struct ora_map {
+    float a, b, m;
+    uint32_t n;
+} ora_map;
+static ora_map map_compose(ora_map first, ora_map second) {
+    if (second.n == 0) return first;
+    if (first.n == 0) return second;
+    ora_map r;
+    r.a = second.a * first.a;
+    r.b = second.a * first.b + second.b;
+    float t = rp_f2u(first.m) == 0xff800000u ? first.m : second.a * first.m + second.b;
+    r.m = rp_maxf(t, second.m);
+    r.n = first.n + second.n;
+    return r;
+}
+static void map_touch(ora_map* mp, float d, float delta, float floor_v) {
+    if (mp->n == 0) { mp->a = d; mp->b = delta; mp->m = floor_v; }
+    else { mp->a = mp->a * d; mp->b = mp->b * d + delta; mp->m = rp_maxf(mp->m * d + delta, floor_v); }
+    mp->n += 1;
+}
+static const ora_map MAP_ID = {1.0f, 0.0f, -INFINITY, 0};
+
+/* rp_mccfr_step_local: this rank's trees [rank*B, (rank+1)*B) against the current table -> composed maps.
+ * Blocks of rp_compose_block(A) consecutive Decisions of one infoset (include/rp_mi355x.h). */
 ORA_API int ora_mccfr_step_local(ora_mccfr* h, uint32_t rank, void* blob) {
     float dr, dw;
     if (composed_discount(h, &dr, &dw)) return -1;
-    uint32_t A = h->g.max_actions;
-    size_t cells = (size_t)h->g.n_infos * A;
+    uint32_t A = h->g.max_actions, NI = h->g.n_infos;
+    uint32_t T = rp_compose_block(A);
+    size_t cells = (size_t)NI * A;
     float floor_r = regret_floor(h);
     ora_cell* cell = (ora_cell*)blob;
     ora_isum* sums = (ora_isum*)((unsigned char*)blob + cells * sizeof(ora_cell));
-    for (size_t c = 0; c < cells; ++c) {
-        cell[c].ra = 1.0f; cell[c].rb = 0.0f; cell[c].rm = rp_u2f(0xff800000u); cell[c].rn = 0;
-        cell[c].wa = 1.0f; cell[c].wb = 0.0f; cell[c].wm = rp_u2f(0xff800000u); cell[c].wn = 0;
-    }
-    memset(sums, 0, (size_t)h->g.n_infos * sizeof(ora_isum));
+    ora_map* blk_r = (ora_map*)malloc(cells * sizeof(ora_map));
+    ora_map* blk_w = (ora_map*)malloc(cells * sizeof(ora_map));
+    ora_map* tot_r = (ora_map*)malloc(cells * sizeof(ora_map));
+    ora_map* tot_w = (ora_map*)malloc(cells * sizeof(ora_map));
+    uint32_t* pos = (uint32_t*)calloc(NI, 4);       /* position of the next Decisions inside its infoset's segment */
+    float* blk_p = (float*)calloc(NI, 4);           /* payoff sum of the open block */
+    uint32_t* blk_pn = (uint32_t*)calloc(NI, 4);
+    float* tot_p = (float*)calloc(NI, 4);
+    uint32_t* tot_pn = (uint32_t*)calloc(NI, 4);
+    for (size_t c = 0; c < cells; ++c) blk_r[c] = blk_w[c] = tot_r[c] = tot_w[c] = MAP_ID;
     h->ndec = 0;
     batch_range(h, (uint64_t)rank * h->batch, h->batch);
-    for (uint64_t i = 0; i < h->ndec; ++i) {
+    for (uint64_t i = 0; i <= h->ndec; ++i) {
+        /* flush finished blocks: before a Decisions that opens a new block of its infoset, and at the end */
+        for (uint32_t info = 0; info < NI; ++info) {
+            int last = i == h->ndec;
+            int opens = !last && h->dec[i].info == info && pos[info] > 0 && pos[info] % T == 0;
+            if (!(last || opens) || blk_pn[info] == 0) continue;
+            for (uint32_t a = 0; a < A; ++a) {
+                size_t k = (size_t)info * A + a;
+                tot_r[k] = map_compose(tot_r[k], blk_r[k]);
+                tot_w[k] = map_compose(tot_w[k], blk_w[k]);
+                blk_r[k] = blk_w[k] = MAP_ID;
+            }
+            tot_p[info] += blk_p[info]; /* left folds from 0.0f, like the device */
+            tot_pn[info] += blk_pn[info];
+            blk_p[info] = 0.0f;
+            blk_pn[info] = 0;
+        }
+        if (i == h->ndec) break;
         const ora_decision* d = &h->dec[i];
         for (uint32_t a = 0; a < d->n_actions; ++a) {
-            ora_cell* c = &cell[d->info * A + a];
-            if (d->expanded >> a & 1u) {
-                if (c->rn == 0) { c->ra = dr; c->rb = d->regret[a]; c->rm = floor_r; }
-                else { c->ra = c->ra * dr; c->rb = c->rb * dr + d->regret[a];
-                       c->rm = rp_maxf(c->rm * dr + d->regret[a], floor_r); }
-                c->rn += 1;
-            }
-            float dl = composed_wdelta(h, d->policy[a]);
-            if (c->wn == 0) { c->wa = dw; c->wb = dl; c->wm = RP_EPSILON; }
-            else { c->wa = c->wa * dw; c->wb = c->wb * dw + dl; c->wm = rp_maxf(c->wm * dw + dl, RP_EPSILON); }
-            c->wn += 1;
+            size_t k = (size_t)d->info * A + a;
+            if (d->expanded >> a & 1u) map_touch(&blk_r[k], dr, d->regret[a], floor_r);
+            map_touch(&blk_w[k], dw, composed_wdelta(h, d->policy[a]), RP_EPSILON);
         }
-        sums[d->info].count += 1;
-        sums[d->info].psum += d->payoff;
+        blk_p[d->info] += d->payoff;
+        blk_pn[d->info] += 1;
+        pos[d->info] += 1;
     }
+    for (size_t c = 0; c < cells; ++c) {
+        cell[c].ra = tot_r[c].a; cell[c].rb = tot_r[c].b; cell[c].rm = tot_r[c].m; cell[c].rn = tot_r[c].n;
+        cell[c].wa = tot_w[c].a; cell[c].wb = tot_w[c].b; cell[c].wm = tot_w[c].m; cell[c].wn = tot_w[c].n;
+    }
+    for (uint32_t info = 0; info < NI; ++info) {
+        sums[info].count = tot_pn[info];
+        sums[info].psum = tot_p[info];
+    }
+    free(blk_r); free(blk_w); free(tot_r); free(tot_w); free(pos); free(blk_p); free(blk_pn); free(tot_p); free(tot_pn);
     return 0;
 }
 

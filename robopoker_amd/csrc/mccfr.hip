@@ -497,22 +497,12 @@ __device__ __forceinline__ uint32_t seg_base(const DevSorted& so, uint32_t info)
 // Tiles are double buffered: the global loads of tile t+1 are issued into registers BEFORE the chain over tile t
 // and committed to LDS after it, so HBM/L2 latency hides under the serial chain.  In LDS a tile is stream-major
 // ([cell][entry]) so each chain lane reads its own stream 4 entries at a time (ds_read_b128), 16 entries ahead.
-//
-// COMPOSE = true turns the same streaming machinery into the multi-GPU summary (oracle: ora_mccfr_step_local):
-// instead of applying the touches to the table, every cell lane composes them into F(x) = max(a x + b, m) and
-// wave 1 sums the payoffs in tree order; nothing is written to the tables.
-template <bool SIGNED, bool PRUNED, bool COMPOSE>
-__global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted so, StepParams p, Cell* cells, InfoSum* sums) {
+template <bool SIGNED, bool PRUNED>
+__global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted so, StepParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t info = blockIdx.x;
-    const float NEG_INF = rp_u2f(0xff800000u);
-    const bool is_walker = g.info_player[info] == p.walker;
-    const uint32_t len = is_walker ? so.total[info] : 0u;
-    if (COMPOSE && len == 0) {  // identity maps for untouched infosets
-        if (threadIdx.x < g.A) cells[(size_t)info * g.A + threadIdx.x] = Cell{1.0f, 0.0f, NEG_INF, 1.0f, 0.0f, NEG_INF, 0u, 0u};
-        if (threadIdx.x == 0) sums[info] = InfoSum{0u, 0.0f};
-        return;
-    }
+    if (g.info_player[info] != p.walker) return;
+    const uint32_t len = so.total[info];
     if (len == 0) return;
     const uint32_t A = g.A, nact = g.info_actions[info], W2 = 2 * A;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -541,9 +531,6 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
                 d = Discount{dw, dw, dw};
             }
         }
-        float ma = 1.0f, mb = 0.0f, mm = NEG_INF;  // COMPOSE: the composed map of this cell
-        uint32_t cnt = 0;
-        if (COMPOSE) acc = 0.0f;
         const uint32_t ntiles = (len + T - 1) / T;
         float rg[TILE_REGS];
         uint32_t mk[TILE_REGS / 2];
@@ -575,18 +562,6 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
             }
         };
         auto step = [&](float delta, uint32_t m) {
-            if (COMPOSE) {
-                // first touch: (d, delta, floor); then a <- a*d, b <- b*d + delta, m <- max(m*d + delta, floor)
-                const bool skip = PRUNED && isreg && !((m >> a) & 1u);
-                const float na = ma * d.zero;
-                const float nb = cnt ? mb * d.zero + delta : delta;
-                const float nm = cnt ? rp_maxf(mm * d.zero + delta, fl) : fl;
-                ma = skip ? ma : na;
-                mb = skip ? mb : nb;
-                mm = skip ? mm : nm;
-                cnt += skip ? 0u : 1u;
-                return;
-            }
             float dd = d.zero;
             if (SIGNED) dd = acc > 0.0f ? d.pos : (acc < 0.0f ? d.neg : d.zero);
             const float nv = rp_maxf(acc * dd + delta, fl);
@@ -631,54 +606,10 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
             if (more) commit(buf ^ 1u);
             __builtin_amdgcn_wave_barrier();
         }
-        if (COMPOSE) {
-            if (lane < W2) {
-                Cell* c = &cells[(size_t)info * A + a];
-                if (!chain) { ma = 1.0f; mb = 0.0f; mm = NEG_INF; cnt = 0; }
-                if (isreg) { c->ra = ma; c->rb = mb; c->rm = mm; c->rn = cnt; }
-                else { c->wa = ma; c->wb = mb; c->wm = mm; c->wn = cnt; }
-            }
-        } else if (chain) {
+        if (chain) {
             if (isreg) t.regret[cell] = acc;
             else t.weight[cell] = acc;
         }
-    } else if (COMPOSE) {
-        // payoffs summed in tree order (the exchange carries (count, sum) per infoset), streamed through LDS tiles
-        float psum = 0.0f;
-        const uint32_t ntiles = (len + PTILE - 1) / PTILE;
-        float rg[PTILE / 64];
-        auto issue = [&](uint32_t tl) {
-            const uint32_t n = min(PTILE, len - tl * PTILE);
-#pragma unroll
-            for (uint32_t r = 0; r < PTILE / 64; ++r) {
-                const uint32_t k = lane + 64 * r;
-                rg[r] = k < n ? so.payoff[base + (size_t)tl * PTILE + k] : 0.0f;
-            }
-        };
-        auto commit = [&](uint32_t buf) {
-#pragma unroll
-            for (uint32_t r = 0; r < PTILE / 64; ++r) ptile[buf * 3 * PTILE + lane + 64 * r] = rg[r];
-        };
-        issue(0);
-        commit(0);
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t tl = 0; tl < ntiles; ++tl) {
-            const uint32_t buf = tl & 1u;
-            const bool more = tl + 1 < ntiles;
-            if (more) issue(tl + 1);
-            const uint32_t n = min(PTILE, len - tl * PTILE);
-            const float* pt = ptile + buf * 3 * PTILE;
-            const uint32_t n4 = n & ~3u;
-            uint32_t i = 0;
-            for (; i < n4; i += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(pt + i);
-                psum += v.x; psum += v.y; psum += v.z; psum += v.w;
-            }
-            for (; i < n; ++i) psum += pt[i];
-            if (more) commit(buf ^ 1u);
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (lane == 0) sums[info] = InfoSum{len, psum};
     } else {
         // Welford mean with the pre-increment visit count (solver.rs:174-192): ev += (payoff - ev) / (n + 1).
         // The divisor sequence is known in advance, so the whole wave precomputes b = (float)(n+1) and the
@@ -794,6 +725,116 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
 }
 
 // ------------------------------------------------------------------------------------------------
+// Composed update (include/rp_mi355x.h rp_compose_block; oracle: ora_mccfr_step_local): the serial chain of the
+// ordered mode is replaced by a two-level composition of per-cell maps F(x) = max(a x + b, m).
+//   k_block_maps  one workgroup per (infoset, block of T consecutive Decisions): sequential composition inside the
+//                 block, all blocks of all infosets in parallel
+//   k_combine     one wave per infoset: the block maps composed in block order -> Cell / InfoSum blob
+// ------------------------------------------------------------------------------------------------
+struct Map {
+    float a, b, m;
+    uint32_t n;
+};
+// include/rp_mi355x.h rp_compose_block, callable from device code
+__host__ __device__ inline uint32_t compose_block(uint32_t max_actions) { return (1024u / (2u * max_actions)) & ~3u; }
+__device__ __forceinline__ Map map_compose(const Map& first, const Map& second) {  // `first` is applied first
+    if (second.n == 0) return first;
+    if (first.n == 0) return second;
+    Map r;
+    r.a = second.a * first.a;
+    r.b = second.a * first.b + second.b;
+    const float t = rp_f2u(first.m) == 0xff800000u ? first.m : second.a * first.m + second.b;
+    r.m = rp_maxf(t, second.m);
+    r.n = first.n + second.n;
+    return r;
+}
+
+template <bool PRUNED>
+__global__ __launch_bounds__(128) void k_block_maps(DevGame g, DevSorted so, StepParams p, Map* bmaps, float* bpsum,
+                                                    uint32_t nblk_max) {
+    __shared__ __attribute__((aligned(16))) float tile[TILE_FLOATS + 2 * RP_MAX_ACTIONS * TILE_PAD];
+    __shared__ uint32_t mtile[TILE_FLOATS / 2];
+    __shared__ __attribute__((aligned(16))) float ptile[TILE_FLOATS / 2];
+    const uint32_t info = blockIdx.y, blk = blockIdx.x;
+    if (g.info_player[info] != p.walker) return;
+    const uint32_t len = so.total[info];
+    const uint32_t A = g.A, nact = g.info_actions[info], W2 = 2 * A;
+    const uint32_t T = compose_block(A);
+    if (blk * T >= len) return;
+    const uint32_t n = min(T, len - blk * T);
+    const uint32_t TP = T + TILE_PAD;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const size_t base = seg_base(so, info) + (size_t)blk * T;
+    const float NEG_INF = rp_u2f(0xff800000u);
+    if (wave == 0) {
+        const size_t e0 = base * W2;
+        const uint32_t nfl = n * W2;
+        for (uint32_t k = lane; k < nfl; k += 64) tile[(k % W2) * TP + k / W2] = so.rw[e0 + k];
+        if (PRUNED)
+            for (uint32_t k = lane; k < n; k += 64) mtile[k] = so.mask[base + k];
+        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        const bool isreg = lane < A;
+        const uint32_t a = lane % A;
+        const bool chain = lane < W2 && a < nact;
+        const float tf = (float)p.epoch;
+        const float fl = isreg ? regret_floor_of(p.R, p.regret_min) : RP_EPSILON;
+        const float d = isreg ? (p.R == RP_REGRET_LINEAR ? tf / (tf + 1.0f) : 1.0f)
+                              : (p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f);
+        float ma = 1.0f, mb = 0.0f, mm = NEG_INF;
+        uint32_t cnt = 0;
+        if (chain) {
+            const float* row = tile + lane * TP;
+            for (uint32_t i = 0; i < n; ++i) {
+                const float delta = row[i];
+                const bool skip = PRUNED && isreg && !((mtile[i] >> a) & 1u);
+                // first touch of the block: (d, delta, floor); then a <- a d, b <- b d + delta, m <- max(m d + delta, floor)
+                const float na = cnt ? ma * d : d;
+                const float nb = cnt ? mb * d + delta : delta;
+                const float nm = cnt ? rp_maxf(mm * d + delta, fl) : fl;
+                ma = skip ? ma : na;
+                mb = skip ? mb : nb;
+                mm = skip ? mm : nm;
+                cnt += skip ? 0u : 1u;
+            }
+        }
+        if (lane < W2) bmaps[((size_t)info * nblk_max + blk) * W2 + lane] = Map{ma, mb, mm, chain ? cnt : 0u};
+    } else {
+        for (uint32_t k = lane; k < n; k += 64) ptile[k] = so.payoff[base + k];
+        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        if (lane == 0) {
+            float s = 0.0f;
+            for (uint32_t i = 0; i < n; ++i) s += ptile[i];
+            bpsum[(size_t)info * nblk_max + blk] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_combine(DevGame g, DevSorted so, StepParams p, const Map* bmaps, const float* bpsum,
+                                                uint32_t nblk_max, Cell* cells, InfoSum* sums) {
+    const uint32_t info = blockIdx.x, lane = threadIdx.x;
+    const uint32_t A = g.A, W2 = 2 * A;
+    const float NEG_INF = rp_u2f(0xff800000u);
+    const bool walker = g.info_player[info] == p.walker;
+    const uint32_t len = walker ? so.total[info] : 0u;
+    const uint32_t T = compose_block(A);
+    const uint32_t nb = (len + T - 1) / T;
+    Map tot{1.0f, 0.0f, NEG_INF, 0u};
+    if (lane < W2) {
+        const Map* src = bmaps + (size_t)info * nblk_max * W2 + lane;
+        for (uint32_t b = 0; b < nb; ++b) tot = map_compose(tot, src[(size_t)b * W2]);
+        Cell* c = &cells[(size_t)info * A + lane % A];
+        if (lane < A) { c->ra = tot.a; c->rb = tot.b; c->rm = tot.m; c->rn = tot.n; }
+        else { c->wa = tot.a; c->wb = tot.b; c->wm = tot.m; c->wn = tot.n; }
+    } else if (lane == W2) {
+        float ps = 0.0f;
+        for (uint32_t b = 0; b < nb; ++b) ps += bpsum[(size_t)info * nblk_max + b];
+        sums[info] = InfoSum{len, ps};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_fold: the receiving side of the multi-GPU exchange (oracle: ora_mccfr_step_apply)
 // ------------------------------------------------------------------------------------------------
 // one thread per table cell; `blob` holds `world` summaries back to back: [cells][sums]
@@ -861,6 +902,7 @@ struct rp_mccfr {
     void* d_dec = nullptr;
     void* d_summary = nullptr;
     void* d_sorted = nullptr;
+    void* d_bmaps = nullptr;
     DevSorted so{};
     unsigned long long* d_counters = nullptr;
     int R = 0, W = 0, S = 0;
@@ -974,6 +1016,11 @@ int alloc_batch_buffers(rp_mccfr* h, uint32_t batch) {
     so.counts = sw; sw += nic;
     so.offs = sw; sw += nic;
     so.total = sw;
+    // per-(infoset, block) maps of the composed update
+    if (h->d_bmaps) HIP_TRY(hipFree(h->d_bmaps));
+    h->d_bmaps = nullptr;
+    const size_t nblk_max = (stride + rp_compose_block(A) - 1) / rp_compose_block(A);
+    HIP_TRY(hipMalloc(&h->d_bmaps, (size_t)h->tbl.n_infos * nblk_max * (2 * A * sizeof(Map) + sizeof(float))));
     h->capacity = batch;
     return RP_OK;
 }
@@ -1048,12 +1095,10 @@ int launch_chain(rp_mccfr* h, const StepParams& p) {
     const bool prn = h->S != RP_SAMPLING_EXTERNAL;
     const dim3 grid(h->tbl.n_infos), block(128);
     clock_begin(h, h->clk_update);
-    Cell* nc = nullptr;
-    InfoSum* ns = nullptr;
-    if (sgn && prn) hipLaunchKernelGGL((k_chain<true, true, false>), grid, block, lds, h->stream, h->g, h->t, h->so, p, nc, ns);
-    else if (sgn) hipLaunchKernelGGL((k_chain<true, false, false>), grid, block, lds, h->stream, h->g, h->t, h->so, p, nc, ns);
-    else if (prn) hipLaunchKernelGGL((k_chain<false, true, false>), grid, block, lds, h->stream, h->g, h->t, h->so, p, nc, ns);
-    else hipLaunchKernelGGL((k_chain<false, false, false>), grid, block, lds, h->stream, h->g, h->t, h->so, p, nc, ns);
+    if (sgn && prn) hipLaunchKernelGGL((k_chain<true, true>), grid, block, lds, h->stream, h->g, h->t, h->so, p);
+    else if (sgn) hipLaunchKernelGGL((k_chain<true, false>), grid, block, lds, h->stream, h->g, h->t, h->so, p);
+    else if (prn) hipLaunchKernelGGL((k_chain<false, true>), grid, block, lds, h->stream, h->g, h->t, h->so, p);
+    else hipLaunchKernelGGL((k_chain<false, false>), grid, block, lds, h->stream, h->g, h->t, h->so, p);
     clock_end(h, h->clk_update);
     HIP_TRY(hipGetLastError());
     return RP_OK;
@@ -1063,13 +1108,16 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev) {
     unsigned char* blob = reinterpret_cast<unsigned char*>(blob_dev);
     Cell* cells = reinterpret_cast<Cell*>(blob);
     InfoSum* sums = reinterpret_cast<InfoSum*>(blob + (size_t)h->tbl.n_infos * h->tbl.max_actions * sizeof(Cell));
-    const size_t lds = chain_lds_bytes(h->tbl.max_actions);
-    const dim3 grid(h->tbl.n_infos), block(128);
+    const uint32_t A = h->tbl.max_actions, T = rp_compose_block(A);
+    const uint32_t nblk_max = (uint32_t)((h->dc.stride + T - 1) / T), nblk = (h->batch + T - 1) / T;
+    Map* bmaps = reinterpret_cast<Map*>(h->d_bmaps);
+    float* bpsum = reinterpret_cast<float*>(bmaps + (size_t)h->tbl.n_infos * nblk_max * 2 * A);
     clock_begin(h, h->clk_update);
     if (h->S != RP_SAMPLING_EXTERNAL)
-        hipLaunchKernelGGL((k_chain<false, true, true>), grid, block, lds, h->stream, h->g, h->t, h->so, p, cells, sums);
+        hipLaunchKernelGGL((k_block_maps<true>), dim3(nblk, h->tbl.n_infos), dim3(128), 0, h->stream, h->g, h->so, p, bmaps, bpsum, nblk_max);
     else
-        hipLaunchKernelGGL((k_chain<false, false, true>), grid, block, lds, h->stream, h->g, h->t, h->so, p, cells, sums);
+        hipLaunchKernelGGL((k_block_maps<false>), dim3(nblk, h->tbl.n_infos), dim3(128), 0, h->stream, h->g, h->so, p, bmaps, bpsum, nblk_max);
+    hipLaunchKernelGGL(k_combine, dim3(h->tbl.n_infos), dim3(64), 0, h->stream, h->g, h->so, p, bmaps, bpsum, nblk_max, cells, sums);
     clock_end(h, h->clk_update);
     HIP_TRY(hipGetLastError());
     return RP_OK;
@@ -1238,7 +1286,7 @@ int rp_mccfr_destroy(rp_mccfr* h) {
     clock_drain(h->clk_compact);
     clock_drain(h->clk_update);
     void* ptrs[] = {h->d_states, h->d_children, h->d_payoffs, h->d_info_actions, h->d_info_player, h->d_scratch,
-                    h->d_dec, h->d_sorted, h->d_summary, h->d_counters, h->t.regret, h->t.weight, h->t.payoff, h->t.visits};
+                    h->d_dec, h->d_sorted, h->d_bmaps, h->d_summary, h->d_counters, h->t.regret, h->t.weight, h->t.payoff, h->t.visits};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);

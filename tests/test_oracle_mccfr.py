@@ -169,7 +169,7 @@ def test_first_epoch_semantics(kuhn):
 def test_composed_world_update_matches_ordered_within_tolerance(leduc):
     # the multi-GPU exchange semantics (ora_mccfr_step_world) against plain ordered steps on the same
     # world*B trees: identical sampling, fp32-reassociation-level difference in the tables
-    B, world = 64, 4
+    B, world = 1500, 4  # hot infosets span several rp_compose_block(A) = 256-touch blocks per rank
     a = oracle.OracleSolver(leduc, "linear", "linear", "external", batch=B * world, seed=11)
     b = oracle.OracleSolver(leduc, "linear", "linear", "external", batch=B, seed=11)
     for _ in range(6):
@@ -180,8 +180,8 @@ def test_composed_world_update_matches_ordered_within_tolerance(leduc):
         b.step_world(world)
         ra, rb = a.export(), b.export()
         assert np.array_equal(ra["visits"], rb["visits"])
-        np.testing.assert_allclose(ra["regret"], rb["regret"], rtol=2e-5, atol=2e-5)
-        np.testing.assert_allclose(ra["weight"], rb["weight"], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(ra["regret"], rb["regret"], rtol=1e-4, atol=2e-4)
+        np.testing.assert_allclose(ra["weight"], rb["weight"], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(ra["payoff"], rb["payoff"], rtol=2e-4, atol=2e-5)
 
 
