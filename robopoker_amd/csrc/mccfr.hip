@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <functional>
 #include <string>
 #include <vector>
@@ -284,6 +285,209 @@ __global__ __launch_bounds__(256) void k_traverse(DevGame g, DevTables t, DevScr
         }
     }
     // Metrics: nodes / infos (metrics/mod.rs:21-80; solver.rs:273)
+    atomicAdd(&p.counters[0], (unsigned long long)nn);
+    atomicAdd(&p.counters[1], (unsigned long long)ndec);
+    if (err) atomicOr(&p.counters[2], (unsigned long long)err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_traverse_lds: the same traversal with the per-tree scratch in LDS instead of HBM.
+//
+// The HBM variant moves ~1.1 GB per 262 144-tree launch (profiles/r01_mccfr_hbm_traffic.json) against ~72 MB of
+// algorithmic bytes: the multi-pass evaluation re-reads the node list.  Here a node is 4 dwords
+// (meta | frel | fsmp | value) in a lane-interleaved LDS array (bank = lane: conflict free), the leaf stack 4
+// dwords per entry; reach products of a leaf are rebuilt by walking its (<= 10 node) path instead of being stored.
+// One wave per workgroup; 4*maxn + 4*maxs + A dwords per lane (Leduc: 472 B/lane, 30 KB/wave, 5 waves/CU).
+// Used when the game fits: <= 62 nodes per sampled tree, depth <= 10, <= 8191 infosets, <= 16 actions.
+// ------------------------------------------------------------------------------------------------
+#define LM_PARENT(m) ((m)&63u)
+#define LM_EDGE(m) (((m) >> 6) & 15u)
+#define LM_PTYPE(m) (((m) >> 10) & 3u)
+#define LM_LEAF(m) (((m) >> 12) & 1u)
+#define LM_WALKER(m) (((m) >> 13) & 1u)
+#define LM_NACT(m) (((m) >> 14) & 31u)
+#define LM_INFO(m) ((m) >> 19)
+#define LM_NO_PARENT 63u
+
+__global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevTables t, DevDecisions dc, StepParams p, uint32_t maxn,
+                                                     uint32_t maxs) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t ln = threadIdx.x;
+    const uint32_t lane = blockIdx.x * 64 + ln;
+    uint32_t* nm = lds;                                              // [maxn][64] meta
+    float* nfr = reinterpret_cast<float*>(nm + (size_t)maxn * 64);   // [maxn][64] relative-reach factor of the incoming edge
+    float* nfs = nfr + (size_t)maxn * 64;                            // [maxn][64] sampling-reach factor of the incoming edge
+    float* nv = nfs + (size_t)maxn * 64;                             // [maxn][64] leaf: payoff; internal: child-value sum
+    uint32_t* ss = reinterpret_cast<uint32_t*>(nv + (size_t)maxn * 64);  // [maxs][64] stack: state
+    uint32_t* sm = ss + (size_t)maxs * 64;                           // [maxs][64] stack: parent | edge << 6 | ptype << 10
+    float* sfr = reinterpret_cast<float*>(sm + (size_t)maxs * 64);
+    float* sfs = sfr + (size_t)maxs * 64;
+    float* tv = sfs + (size_t)maxs * 64;                             // [A][64]
+    if (lane >= p.batch) return;
+    const uint64_t tree_id = p.tree_base + lane;
+    uint32_t err = 0;
+#define L(arr, slot) arr[(slot)*64 + ln]
+
+    // ---- TreeBuilder::build (builder.rs:74-87,141-161): pop-last DFS -----------------------------
+    uint32_t nn = 0, sp = 0;
+    uint32_t cur_state = g.root;
+    uint32_t cur_in = LM_NO_PARENT | (PT_NONE << 10);
+    float cur_frel = 1.0f, cur_fsmp = 1.0f;
+    for (;;) {
+        const uint4 st = g.states[cur_state];
+        const uint32_t turn = st.x & 0xffu, nch = (st.x >> 8) & 0xffu, info = st.y, off = st.z;
+        const uint32_t me = nn;
+        if (nn >= maxn) {
+            err |= ERR_NODE_CAPACITY;
+            break;
+        }
+        const bool is_walker = turn == p.walker;
+        L(nm, me) = cur_in | ((nch == 0 ? 1u : 0u) << 12) | ((is_walker ? 1u : 0u) << 13) | (nch << 14) |
+                    ((turn < RP_TURN_CHANCE ? info : 0u) << 19);
+        L(nfr, me) = cur_frel;
+        L(nfs, me) = cur_fsmp;
+        if (nch == 0) L(nv, me) = g.payoffs[off * g.n_players + p.walker];
+        nn += 1;
+        if (nch > 0) {
+            const uint32_t mask = d_sample_mask(g, t, p, tree_id, cur_state, turn, nch, info, off);
+            const bool chance = turn == RP_TURN_CHANCE;
+            const uint32_t ptype = chance ? PT_CHANCE : (is_walker ? PT_WALKER : PT_OPP);
+            float rd = 0.0f, denom = 0.0f, z = 0.0f;
+            if (!chance) rd = d_regret_denom(t, g.A, info, nch);
+            if (ptype == PT_OPP) {
+                denom = d_weight_denom(t, g.A, info, nch, p.smoothing);
+                z = d_sampling_z(t, g.A, info, nch, denom, p);
+            }
+            for (uint32_t k = 0; k < nch; ++k) {
+                if (!((mask >> k) & 1u)) continue;
+                if (sp >= maxs) {
+                    err |= ERR_STACK_CAPACITY;
+                    break;
+                }
+                L(ss, sp) = g.children[off + k];
+                L(sm, sp) = me | (k << 6) | (ptype << 10);
+                L(sfr, sp) = chance ? 1.0f : d_regret(t, g.A, info, k) / rd;
+                L(sfs, sp) = ptype == PT_OPP ? d_sampling_weight(t, g.A, info, k, denom, p) / z : 1.0f;
+                sp += 1;
+            }
+        }
+        if (sp == 0 || err) break;
+        sp -= 1;
+        cur_state = L(ss, sp);
+        cur_in = L(sm, sp);
+        cur_frel = L(sfr, sp);
+        cur_fsmp = L(sfs, sp);
+    }
+
+    // ---- Tree::partition + CfrFlow::dfs per walker infoset (tree.rs:88-98, flow.rs:64-87) --------
+    uint32_t ndec = 0;
+    if (!err) {
+        for (uint32_t i = 0; i < nn; ++i) {
+            const uint32_t mi = L(nm, i);
+            if (!LM_WALKER(mi) || LM_LEAF(mi)) continue;
+            const uint32_t info = LM_INFO(mi);
+            bool head = true;
+            for (uint32_t j = 0; j < i; ++j) {
+                const uint32_t mj = L(nm, j);
+                if (LM_WALKER(mj) && !LM_LEAF(mj) && LM_INFO(mj) == info) head = false;
+            }
+            if (!head) continue;
+            if (ndec >= dc.maxdec) {
+                err |= ERR_DEC_CAPACITY;
+                break;
+            }
+            const uint32_t nact = LM_NACT(mi);
+            const uint32_t slot = ndec++;
+            const size_t D = dc.stride;
+            const float rd = d_regret_denom(t, g.A, info, nact);
+            float payoff = 0.0f;
+            uint32_t expanded = 0;
+            for (uint32_t j = i; j < nn; ++j) {  // span in ascending node index
+                const uint32_t mj = L(nm, j);
+                if (!LM_WALKER(mj) || LM_LEAF(mj) || LM_INFO(mj) != info) continue;
+                // extent of the (contiguous) subtree of j; internal nodes start their child-value sum at 0
+                uint32_t end = j;
+                for (uint32_t n = j + 1; n < nn; ++n) {
+                    const uint32_t mn = L(nm, n);
+                    if (LM_PARENT(mn) < j) break;
+                    if (!LM_LEAF(mn)) L(nv, n) = 0.0f;
+                    end = n;
+                }
+                // bottom-up: descending node index adds children in choices() order (node.rs:103-107)
+                uint32_t kids = 0;
+                for (uint32_t n = end; n > j; --n) {
+                    const uint32_t mn = L(nm, n);
+                    float v;
+                    if (LM_LEAF(mn)) {
+                        // reach products along the path j -> n (flow.rs:195-212), top-down, starting at 1 on j's child
+                        unsigned long long path = 0;
+                        uint32_t depth = 0;
+                        for (uint32_t q = n; LM_PARENT(L(nm, q)) != j; q = LM_PARENT(L(nm, q))) {
+                            path = (path << 6) | q;
+                            depth += 1;
+                        }
+                        float rel = 1.0f, smp = 1.0f;
+                        for (uint32_t d = 0; d < depth; ++d) {
+                            const uint32_t q = (uint32_t)(path & 63ull);
+                            path >>= 6;
+                            rel = rel * L(nfr, q);
+                            smp = smp * L(nfs, q);
+                        }
+                        v = rel / smp * L(nv, n);
+                    } else {
+                        v = L(nv, n);
+                    }
+                    const uint32_t par = LM_PARENT(mn);
+                    if (par == j) {
+                        L(tv, LM_EDGE(mn)) = v;
+                        kids |= 1u << LM_EDGE(mn);
+                    } else {
+                        L(nv, par) = L(nv, par) + v;
+                    }
+                }
+                // ancestor_reach (flow.rs:166-174)
+                float cf = 1.0f, sm_ = 1.0f;
+                for (uint32_t n = j;;) {
+                    const uint32_t mn = L(nm, n);
+                    const uint32_t par = LM_PARENT(mn);
+                    if (par == LM_NO_PARENT) break;
+                    if (LM_PTYPE(mn) == PT_OPP) {
+                        cf = cf * L(nfr, n);
+                        sm_ = sm_ * L(nfs, n);
+                    }
+                    n = par;
+                }
+                const float reach = cf / sm_;
+                float ev = 0.0f;
+                for (uint32_t a = 0; a < nact; ++a) {
+                    if (!((kids >> a) & 1u)) continue;
+                    L(tv, a) = reach * L(tv, a);
+                }
+                for (uint32_t a = 0; a < nact; ++a) {
+                    if (!((kids >> a) & 1u)) continue;
+                    ev += d_regret(t, g.A, info, a) / rd * L(tv, a);
+                }
+                payoff += ev;
+                for (uint32_t a = 0; a < nact; ++a) {
+                    if (!((kids >> a) & 1u)) continue;
+                    const size_t k = (slot * g.A + a) * D + lane;
+                    // first root of the span writes, later roots accumulate (0 + x = x exactly)
+                    const float prev = (expanded >> a) & 1u ? dc.regret[k] : 0.0f;
+                    dc.regret[k] = prev + (L(tv, a) - ev);
+                }
+                expanded |= kids;
+            }
+            for (uint32_t a = 0; a < nact; ++a) {  // policy_vector = iterated_distribution (profile.rs:47-51)
+                dc.policy[(slot * g.A + a) * D + lane] = d_regret(t, g.A, info, a) / rd;
+                if (!((expanded >> a) & 1u)) dc.regret[(slot * g.A + a) * D + lane] = 0.0f;
+            }
+            dc.info[slot * D + lane] = info;
+            dc.mask[slot * D + lane] = expanded;
+            dc.payoff[slot * D + lane] = payoff;
+            dc.slotmap[(size_t)info * D + lane] = (uint8_t)(slot + 1);
+        }
+    }
+#undef L
     atomicAdd(&p.counters[0], (unsigned long long)nn);
     atomicAdd(&p.counters[1], (unsigned long long)ndec);
     if (err) atomicOr(&p.counters[2], (unsigned long long)err);
@@ -913,6 +1117,7 @@ struct rp_mccfr {
     uint32_t rank = 0, world = 1;
     uint32_t maxdec = 1;
     rp_update_mode mode = RP_UPDATE_ORDERED;
+    bool use_lds_traverse = false;
     bool profiling = false;
     KernelClock clk_traverse, clk_compact, clk_update;
 };
@@ -1066,11 +1271,24 @@ void clock_drain(KernelClock& c) {
     c.pending.clear();
 }
 
+size_t traverse_lds_bytes(const rp_mccfr* h) {
+    return ((size_t)4 * h->sc.maxn + 4 * h->sc.maxs + h->tbl.max_actions) * 64 * 4;
+}
+bool traverse_fits_lds(const rp_mccfr* h) {
+    return h->sc.maxn <= 62 && h->tbl.max_depth <= 10 && h->tbl.n_infos <= 8191 && h->tbl.max_actions <= 16 &&
+           traverse_lds_bytes(h) <= 64 * 1024;
+}
+
 int launch_traverse(rp_mccfr* h, const StepParams& p) {
     HIP_TRY(hipMemsetAsync(h->dc.slotmap, 0, (size_t)h->tbl.n_infos * h->dc.stride, h->stream));
-    const uint32_t threads = 256, blocks = (h->batch + threads - 1) / threads;
     clock_begin(h, h->clk_traverse);
-    hipLaunchKernelGGL(k_traverse, dim3(blocks), dim3(threads), 0, h->stream, h->g, h->t, h->sc, h->dc, p);
+    if (h->use_lds_traverse) {
+        hipLaunchKernelGGL(k_traverse_lds, dim3((h->batch + 63) / 64), dim3(64), traverse_lds_bytes(h), h->stream, h->g, h->t,
+                           h->dc, p, h->sc.maxn, h->sc.maxs);
+    } else {
+        const uint32_t threads = 256, blocks = (h->batch + threads - 1) / threads;
+        hipLaunchKernelGGL(k_traverse, dim3(blocks), dim3(threads), 0, h->stream, h->g, h->t, h->sc, h->dc, p);
+    }
     clock_end(h, h->clk_traverse);
     HIP_TRY(hipGetLastError());
     return RP_OK;
@@ -1268,6 +1486,7 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
         rp_mccfr_destroy(h);
         return rp::fail(RP_ERR_CAPACITY, "rp_mccfr_create: chain tiles need %zu B of LDS", chain_lds_bytes(game->max_actions));
     }
+    h->use_lds_traverse = traverse_fits_lds(h) && getenv("RP_MCCFR_HBM_SCRATCH") == nullptr;
     rc = alloc_batch_buffers(h, batch_size);
     if (rc) {
         rp_mccfr_destroy(h);

@@ -67,6 +67,27 @@ def test_tables_bit_exact_vs_oracle(gpu, game, regret, weight, sampling):
             assert np.array_equal(dev.policy(info, kind), ora.policy(info, kind))
 
 
+def test_hbm_scratch_traversal_variant_is_identical(gpu, monkeypatch):
+    # the generic traversal kernel (per-tree scratch in HBM, any game size) and the LDS-resident one used for
+    # small games must produce the same Decisions
+    g = Game("leduc")
+    hp = oracle.default_hyper()
+    hp.prune_warmup = 2
+    hp.prune_threshold = -2.0
+    a = Solver(g, "linear", "linear", "pluribus", batch=999, seed=77, hyper=hp)
+    monkeypatch.setenv("RP_MCCFR_HBM_SCRATCH", "1")
+    b = Solver(g, "linear", "linear", "pluribus", batch=999, seed=77, hyper=hp)
+    monkeypatch.delenv("RP_MCCFR_HBM_SCRATCH")
+    ora = oracle.OracleSolver(g, "linear", "linear", "pluribus", batch=999, seed=77, hyper=hp)
+    for _ in range(8):
+        a.step()
+        b.step()
+        ora.step()
+        assert_tables_equal(a.export(), ora.export())
+        assert_tables_equal(b.export(), ora.export())
+    assert a.counters() == b.counters() == ora.counters()
+
+
 @pytest.mark.parametrize("batch", [1, 63, 64, 65, 1024, 1025, 5000])
 def test_batch_size_edges(gpu, batch):
     g = Game("leduc")
