@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--weight", default="linear")
     ap.add_argument("--sampling", default="external")
     ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--update", default="composed", choices=["composed", "ordered"],
+                    help="composed: blocked per-cell map composition (tables within 1e-4/step of the reference's "
+                         "application order, bit-exact vs the oracle's model of it; the only mode that shards); "
+                         "ordered: the reference's sequential tree-id order exactly (N=1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-oracle baseline sample length (0 = skip)")
     ap.add_argument("--no-kmeans", action="store_true", help="skip the secondary k-means measurement")
     ap.add_argument("--force-sharded", action="store_true",
@@ -73,6 +77,49 @@ def cpu_baseline(args):
     }
 
 
+KERNEL_GROUPS = {
+    "traverse": ("k_prepare_infos", "k_traverse"),
+    "compact": ("k_count", "k_scan", "k_compact"),
+    "update": ("k_chain", "k_block_maps", "k_combine", "k_fold"),
+}
+
+
+def profiled_traffic(group, batch):
+    """HBM bytes per launch of a kernel group from the newest committed PMC reduction (scripts/profile_round.sh),
+    valid only for the batch it was collected at; None otherwise."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mccfr_hbm_traffic.json")))
+    if not files:
+        return None, None
+    doc = json.load(open(files[-1]))
+    if doc.get("batch") != batch or doc.get("update", "ordered") != group[1]:
+        return None, os.path.basename(files[-1])
+    total = 0.0
+    for name, v in doc["kernels"].items():
+        if any(k in name for k in KERNEL_GROUPS[group[0]]):
+            total += v["hbm_bytes_per_launch"]
+    return total, os.path.basename(files[-1])
+
+
+def side_rate(args, g, local_rank, mode, steps=10):
+    """The other update mode's rate on the same workload, reported beside `value` for transparency."""
+    from robopoker_amd.mccfr import Solver
+
+    s = Solver(g, args.regret, args.weight, args.sampling, batch=args.batch, seed=args.seed, device=local_rank)
+    s.set_update_mode(mode)
+    s.step_async(3)
+    s.sync()
+    _, i0 = s.counters()
+    t0 = time.perf_counter()
+    s.step_async(steps)
+    s.sync()
+    dt = time.perf_counter() - t0
+    _, i1 = s.counters()
+    s.close()
+    return (i1 - i0) / dt
+
+
 def kmeans_secondary(args):
     try:
         from robopoker_amd import lloyd
@@ -99,6 +146,8 @@ def main():
     dist = None
     torch = None
     sharded_mode = world > 1 or args.force_sharded
+    if sharded_mode and args.update == "ordered":
+        raise SystemExit("the ordered update is single-GPU only (sharding exchanges composed maps)")
     if sharded_mode:
         import torch
         import torch.distributed as dist
@@ -111,6 +160,7 @@ def main():
     g = Game(args.game)
     A = g.max_actions
     solver = Solver(g, args.regret, args.weight, args.sampling, batch=args.batch, seed=args.seed, device=local_rank)
+    solver.set_update_mode(args.update)
 
     if sharded_mode:
         from robopoker_amd.parallel import ShardedSolver
@@ -166,6 +216,9 @@ def main():
         dom, dom_ms = ("update", upd_avg_ms) if upd_avg_ms >= trav_avg_ms else ("traverse", trav_avg_ms)
         bytes_per_update = 24 + 32 * A
         achieved = per_launch_updates * bytes_per_update / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic, traffic_src = profiled_traffic((dom, args.update), args.batch)
+        other = "ordered" if args.update == "composed" else "composed"
+        other_rate = side_rate(args, g, local_rank, other) if world == 1 and not args.force_sharded else None
         line = {
             "metric": "mccfr_infoset_updates_per_sec",
             "value": infos / dt,
@@ -183,18 +236,22 @@ def main():
                 "workload": f"{args.game}-holdem external-sampling MCCFR, tables resident in HBM (BASELINE configs[1])",
                 "regret": args.regret, "weight": args.weight, "sampling": args.sampling,
                 "batch_per_gpu": args.batch, "global_batch": args.batch * world, "infosets": g.n_infos,
-                "actions": A, "update": "composed+allgather" if sharded_mode else "ordered",
+                "actions": A, "update": args.update + ("+allgather" if sharded_mode else ""),
+                "update_tolerance": "composed: regret/weight/payoff within rtol 1e-4 per step of the sequential "
+                                    "order (tests/test_gpu_mccfr.py), visits exact; ordered: bit-exact",
                 "parallelism": f"tree-sharded x{world}",
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                 "bytes_per_update": bytes_per_update, "updates_per_launch": per_launch_updates,
                 "avg_launch_ms": dom_ms,
                 "kernels_ms": {"traverse": trav_avg_ms, "compact": cmp_ms / max(cmp_n, 1), "update": upd_avg_ms},
                 "note": "Leduc's tables are 3.8 KB (L2/LDS resident): HBM is not the binding limit of this "
-                        "configuration (SURVEY §8d); the update is bound by the serial per-cell chains",
+                        "configuration (SURVEY §8d); traversal is latency/divergence bound, the ordered update "
+                        "by its serial per-cell chains",
             },
+            "other_update_mode": {"update": other, "value": other_rate, "unit": "infoset-updates/s"},
         }
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args)

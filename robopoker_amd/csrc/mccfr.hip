@@ -291,6 +291,72 @@ __global__ __launch_bounds__(256) void k_traverse(DevGame g, DevTables t, DevScr
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_prepare_infos: everything a node needs from its infoset, computed ONCE per epoch per infoset instead of at
+// every visited node: regret-matching policy sigma(a) = regret(a)/sum (profile.rs:47-51), the normalised sampling
+// distribution q(a) (flow.rs:33-42), the cumulative weights WeightedIndex draws from (external.rs:52-62) and the
+// regret-based pruning mask (pruning.rs:57-63).  Same expressions, same order => same bits as the per-node code.
+// ------------------------------------------------------------------------------------------------
+struct DevInfoTab {
+    float* sigma;    // [n_infos][A]
+    float* q;        // [n_infos][A]
+    float* cum;      // [n_infos][A] inclusive cumulative of max(q, EPSILON)
+    float* total;    // [n_infos]
+    uint32_t* keep;  // [n_infos] edges with cum_regret > prune_threshold
+};
+
+__global__ void k_prepare_infos(DevGame g, DevTables t, StepParams p, DevInfoTab it) {
+    const uint32_t info = blockIdx.x * blockDim.x + threadIdx.x;
+    if (info >= g.n_infos) return;
+    const uint32_t A = g.A, n = g.info_actions[info];
+    const float rd = d_regret_denom(t, A, info, n);
+    const float denom = d_weight_denom(t, A, info, n, p.smoothing);
+    const float z = d_sampling_z(t, A, info, n, denom, p);
+    float total = 0.0f;
+    uint32_t keep = 0;
+    for (uint32_t a = 0; a < n; ++a) {
+        it.sigma[info * A + a] = d_regret(t, A, info, a) / rd;
+        const float qa = d_sampling_weight(t, A, info, a, denom, p) / z;
+        it.q[info * A + a] = qa;
+        total += rp_maxf(qa, RP_EPSILON);
+        it.cum[info * A + a] = total;
+        if (t.regret[info * A + a] > p.prune_threshold) keep |= 1u << a;
+    }
+    it.total[info] = total;
+    it.keep[info] = keep;
+}
+
+// SamplingScheme::sample with the per-infoset tables
+__device__ __forceinline__ uint32_t d_sample_mask_tab(const DevGame& g, const DevInfoTab& it, const StepParams& p,
+                                                      uint64_t tree_id, uint32_t state, uint32_t turn, uint32_t n,
+                                                      uint32_t info, uint32_t off) {
+    const uint32_t all = (1u << n) - 1u;
+    if (turn == RP_TURN_CHANCE) return 1u << rp_pick_uniform(rp_node_hash(p.seed, p.epoch, tree_id, 0x80000000ull | state), n);
+    if (turn != p.walker) {
+        const float x = rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info)) * it.total[info];
+        uint32_t idx = 0;
+        bool open = true;
+        for (uint32_t a = 0; a + 1 < n; ++a) {
+            open = open && (it.cum[info * g.A + a] <= x);
+            if (open) idx = a + 1;
+        }
+        return 1u << idx;
+    }
+    if (p.S == RP_SAMPLING_EXTERNAL) return all;
+    if (p.S == RP_SAMPLING_PLURIBUS) {
+        if (p.epoch < p.prune_warmup) return all;
+        if (rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info)) < p.prune_explore) return all;
+    }
+    uint32_t mask = it.keep[info] & all;
+    if (p.S == RP_SAMPLING_PLURIBUS) {
+        for (uint32_t a = 0; a < n; ++a) {
+            const uint4 c = g.states[g.children[off + a]];
+            if ((c.x & 0xffu) == RP_TURN_TERMINAL) mask |= 1u << a;
+        }
+    }
+    return mask ? mask : all;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_traverse_lds: the same traversal with the per-tree scratch in LDS instead of HBM.
 //
 // The HBM variant moves ~1.1 GB per 262 144-tree launch (profiles/r01_mccfr_hbm_traffic.json) against ~72 MB of
@@ -309,7 +375,7 @@ __global__ __launch_bounds__(256) void k_traverse(DevGame g, DevTables t, DevScr
 #define LM_INFO(m) ((m) >> 19)
 #define LM_NO_PARENT 63u
 
-__global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevTables t, DevDecisions dc, StepParams p, uint32_t maxn,
+__global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, DevDecisions dc, StepParams p, uint32_t maxn,
                                                      uint32_t maxs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t ln = threadIdx.x;
@@ -349,15 +415,9 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevTables t, Dev
         if (nch == 0) L(nv, me) = g.payoffs[off * g.n_players + p.walker];
         nn += 1;
         if (nch > 0) {
-            const uint32_t mask = d_sample_mask(g, t, p, tree_id, cur_state, turn, nch, info, off);
+            const uint32_t mask = d_sample_mask_tab(g, it, p, tree_id, cur_state, turn, nch, info, off);
             const bool chance = turn == RP_TURN_CHANCE;
             const uint32_t ptype = chance ? PT_CHANCE : (is_walker ? PT_WALKER : PT_OPP);
-            float rd = 0.0f, denom = 0.0f, z = 0.0f;
-            if (!chance) rd = d_regret_denom(t, g.A, info, nch);
-            if (ptype == PT_OPP) {
-                denom = d_weight_denom(t, g.A, info, nch, p.smoothing);
-                z = d_sampling_z(t, g.A, info, nch, denom, p);
-            }
             for (uint32_t k = 0; k < nch; ++k) {
                 if (!((mask >> k) & 1u)) continue;
                 if (sp >= maxs) {
@@ -366,8 +426,8 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevTables t, Dev
                 }
                 L(ss, sp) = g.children[off + k];
                 L(sm, sp) = me | (k << 6) | (ptype << 10);
-                L(sfr, sp) = chance ? 1.0f : d_regret(t, g.A, info, k) / rd;
-                L(sfs, sp) = ptype == PT_OPP ? d_sampling_weight(t, g.A, info, k, denom, p) / z : 1.0f;
+                L(sfr, sp) = chance ? 1.0f : it.sigma[info * g.A + k];
+                L(sfs, sp) = ptype == PT_OPP ? it.q[info * g.A + k] : 1.0f;
                 sp += 1;
             }
         }
@@ -399,7 +459,6 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevTables t, Dev
             const uint32_t nact = LM_NACT(mi);
             const uint32_t slot = ndec++;
             const size_t D = dc.stride;
-            const float rd = d_regret_denom(t, g.A, info, nact);
             float payoff = 0.0f;
             uint32_t expanded = 0;
             for (uint32_t j = i; j < nn; ++j) {  // span in ascending node index
@@ -465,7 +524,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevTables t, Dev
                 }
                 for (uint32_t a = 0; a < nact; ++a) {
                     if (!((kids >> a) & 1u)) continue;
-                    ev += d_regret(t, g.A, info, a) / rd * L(tv, a);
+                    ev += it.sigma[info * g.A + a] * L(tv, a);
                 }
                 payoff += ev;
                 for (uint32_t a = 0; a < nact; ++a) {
@@ -478,7 +537,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevTables t, Dev
                 expanded |= kids;
             }
             for (uint32_t a = 0; a < nact; ++a) {  // policy_vector = iterated_distribution (profile.rs:47-51)
-                dc.policy[(slot * g.A + a) * D + lane] = d_regret(t, g.A, info, a) / rd;
+                dc.policy[(slot * g.A + a) * D + lane] = it.sigma[info * g.A + a];
                 if (!((expanded >> a) & 1u)) dc.regret[(slot * g.A + a) * D + lane] = 0.0f;
             }
             dc.info[slot * D + lane] = info;
@@ -1107,6 +1166,8 @@ struct rp_mccfr {
     void* d_summary = nullptr;
     void* d_sorted = nullptr;
     void* d_bmaps = nullptr;
+    void* d_itab = nullptr;
+    DevInfoTab itab{};
     DevSorted so{};
     unsigned long long* d_counters = nullptr;
     int R = 0, W = 0, S = 0;
@@ -1283,7 +1344,8 @@ int launch_traverse(rp_mccfr* h, const StepParams& p) {
     HIP_TRY(hipMemsetAsync(h->dc.slotmap, 0, (size_t)h->tbl.n_infos * h->dc.stride, h->stream));
     clock_begin(h, h->clk_traverse);
     if (h->use_lds_traverse) {
-        hipLaunchKernelGGL(k_traverse_lds, dim3((h->batch + 63) / 64), dim3(64), traverse_lds_bytes(h), h->stream, h->g, h->t,
+        hipLaunchKernelGGL(k_prepare_infos, dim3((h->tbl.n_infos + 63) / 64), dim3(64), 0, h->stream, h->g, h->t, p, h->itab);
+        hipLaunchKernelGGL(k_traverse_lds, dim3((h->batch + 63) / 64), dim3(64), traverse_lds_bytes(h), h->stream, h->g, h->itab,
                            h->dc, p, h->sc.maxn, h->sc.maxs);
     } else {
         const uint32_t threads = 256, blocks = (h->batch + threads - 1) / threads;
@@ -1474,6 +1536,15 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
     CREATE_TRY(hipMalloc(&h->d_counters, 3 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(h->d_counters, 0, 3 * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(&h->d_summary, summary_bytes_of(h)));
+    CREATE_TRY(hipMalloc(&h->d_itab, (3 * cells + 2 * (size_t)game->n_infos) * 4));
+    {
+        float* f = reinterpret_cast<float*>(h->d_itab);
+        h->itab.sigma = f;
+        h->itab.q = f + cells;
+        h->itab.cum = f + 2 * cells;
+        h->itab.total = f + 3 * cells;
+        h->itab.keep = reinterpret_cast<uint32_t*>(f + 3 * cells + game->n_infos);
+    }
     uint32_t maxstack = 1;
     sampled_tree_bounds(h, &h->maxdec, &maxstack);
     h->sc.maxn = game->max_tree_nodes;
@@ -1505,7 +1576,7 @@ int rp_mccfr_destroy(rp_mccfr* h) {
     clock_drain(h->clk_compact);
     clock_drain(h->clk_update);
     void* ptrs[] = {h->d_states, h->d_children, h->d_payoffs, h->d_info_actions, h->d_info_player, h->d_scratch,
-                    h->d_dec, h->d_sorted, h->d_bmaps, h->d_summary, h->d_counters, h->t.regret, h->t.weight, h->t.payoff, h->t.visits};
+                    h->d_dec, h->d_sorted, h->d_bmaps, h->d_itab, h->d_summary, h->d_counters, h->t.regret, h->t.weight, h->t.payoff, h->t.visits};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
