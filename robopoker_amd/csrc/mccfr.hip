@@ -384,21 +384,26 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
     float* nfr = reinterpret_cast<float*>(nm + (size_t)maxn * 64);   // [maxn][64] relative-reach factor of the incoming edge
     float* nfs = nfr + (size_t)maxn * 64;                            // [maxn][64] sampling-reach factor of the incoming edge
     float* nv = nfs + (size_t)maxn * 64;                             // [maxn][64] leaf: payoff; internal: child-value sum
-    uint32_t* ss = reinterpret_cast<uint32_t*>(nv + (size_t)maxn * 64);  // [maxs][64] stack: state
+    float* tv = nv + (size_t)maxn * 64;                              // [A][64]
+    // build phase: the DFS stack; evaluation phase: per-root reach prefixes of internal nodes (same storage)
+    uint32_t* ss = reinterpret_cast<uint32_t*>(tv + (size_t)g.A * 64);  // [maxs][64] stack: state
     uint32_t* sm = ss + (size_t)maxs * 64;                           // [maxs][64] stack: parent | edge << 6 | ptype << 10
     float* sfr = reinterpret_cast<float*>(sm + (size_t)maxs * 64);
     float* sfs = sfr + (size_t)maxs * 64;
-    float* tv = sfs + (size_t)maxs * 64;                             // [A][64]
+    float* xr = reinterpret_cast<float*>(ss);                        // [maxn][64] relative reach root's child -> node
+    float* xs = xr + (size_t)maxn * 64;                              // [maxn][64] sampling reach root's child -> node
     if (lane >= p.batch) return;
     const uint64_t tree_id = p.tree_base + lane;
     uint32_t err = 0;
 #define L(arr, slot) arr[(slot)*64 + ln]
 
     // ---- TreeBuilder::build (builder.rs:74-87,141-161): pop-last DFS -----------------------------
+    // the last child pushed is the next node popped, so it is carried in registers instead of through the stack
     uint32_t nn = 0, sp = 0;
     uint32_t cur_state = g.root;
     uint32_t cur_in = LM_NO_PARENT | (PT_NONE << 10);
     float cur_frel = 1.0f, cur_fsmp = 1.0f;
+    unsigned long long wmask = 0;  // walker decision nodes
     for (;;) {
         const uint4 st = g.states[cur_state];
         const uint32_t turn = st.x & 0xffu, nch = (st.x >> 8) & 0xffu, info = st.y, off = st.z;
@@ -412,26 +417,36 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     ((turn < RP_TURN_CHANCE ? info : 0u) << 19);
         L(nfr, me) = cur_frel;
         L(nfs, me) = cur_fsmp;
-        if (nch == 0) L(nv, me) = g.payoffs[off * g.n_players + p.walker];
         nn += 1;
         if (nch > 0) {
-            const uint32_t mask = d_sample_mask_tab(g, it, p, tree_id, cur_state, turn, nch, info, off);
+            if (is_walker) wmask |= 1ull << me;
+            uint32_t mask = d_sample_mask_tab(g, it, p, tree_id, cur_state, turn, nch, info, off);
             const bool chance = turn == RP_TURN_CHANCE;
             const uint32_t ptype = chance ? PT_CHANCE : (is_walker ? PT_WALKER : PT_OPP);
-            for (uint32_t k = 0; k < nch; ++k) {
-                if (!((mask >> k) & 1u)) continue;
+            const uint32_t last = 31u - (uint32_t)__builtin_clz(mask);
+            mask &= ~(1u << last);
+            while (mask) {
+                const uint32_t k = (uint32_t)__builtin_ctz(mask);
+                mask &= mask - 1u;
                 if (sp >= maxs) {
                     err |= ERR_STACK_CAPACITY;
                     break;
                 }
                 L(ss, sp) = g.children[off + k];
                 L(sm, sp) = me | (k << 6) | (ptype << 10);
-                L(sfr, sp) = chance ? 1.0f : it.sigma[info * g.A + k];
-                L(sfs, sp) = ptype == PT_OPP ? it.q[info * g.A + k] : 1.0f;
+                L(sfr, sp) = it.sigma[info * g.A + k];  // only walker nodes push more than one child
+                L(sfs, sp) = 1.0f;
                 sp += 1;
             }
+            if (err) break;
+            cur_state = g.children[off + last];
+            cur_in = me | (last << 6) | (ptype << 10);
+            cur_frel = chance ? 1.0f : it.sigma[info * g.A + last];
+            cur_fsmp = ptype == PT_OPP ? it.q[info * g.A + last] : 1.0f;
+            continue;
         }
-        if (sp == 0 || err) break;
+        L(nv, me) = g.payoffs[off * g.n_players + p.walker];
+        if (sp == 0) break;
         sp -= 1;
         cur_state = L(ss, sp);
         cur_in = L(sm, sp);
@@ -442,16 +457,11 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
     // ---- Tree::partition + CfrFlow::dfs per walker infoset (tree.rs:88-98, flow.rs:64-87) --------
     uint32_t ndec = 0;
     if (!err) {
-        for (uint32_t i = 0; i < nn; ++i) {
+        unsigned long long todo = wmask;
+        while (todo) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(todo);  // head of the next infoset span
             const uint32_t mi = L(nm, i);
-            if (!LM_WALKER(mi) || LM_LEAF(mi)) continue;
             const uint32_t info = LM_INFO(mi);
-            bool head = true;
-            for (uint32_t j = 0; j < i; ++j) {
-                const uint32_t mj = L(nm, j);
-                if (LM_WALKER(mj) && !LM_LEAF(mj) && LM_INFO(mj) == info) head = false;
-            }
-            if (!head) continue;
             if (ndec >= dc.maxdec) {
                 err |= ERR_DEC_CAPACITY;
                 break;
@@ -461,42 +471,44 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
             const size_t D = dc.stride;
             float payoff = 0.0f;
             uint32_t expanded = 0;
-            for (uint32_t j = i; j < nn; ++j) {  // span in ascending node index
-                const uint32_t mj = L(nm, j);
-                if (!LM_WALKER(mj) || LM_LEAF(mj) || LM_INFO(mj) != info) continue;
-                // extent of the (contiguous) subtree of j; internal nodes start their child-value sum at 0
+            unsigned long long span = todo;
+            while (span) {  // roots of the span in ascending node index
+                const uint32_t j = (uint32_t)__builtin_ctzll(span);
+                span &= span - 1ull;
+                if (j != i && LM_INFO(L(nm, j)) != info) continue;
+                todo &= ~(1ull << j);
+                // top-down over the (contiguous) subtree of j: reach products from j's child (flow.rs:195-212),
+                // which start at 1 there; internal nodes also start their child-value sum at 0
                 uint32_t end = j;
                 for (uint32_t n = j + 1; n < nn; ++n) {
                     const uint32_t mn = L(nm, n);
-                    if (LM_PARENT(mn) < j) break;
-                    if (!LM_LEAF(mn)) L(nv, n) = 0.0f;
+                    const uint32_t par = LM_PARENT(mn);
+                    if (par < j) break;
                     end = n;
+                    if (LM_LEAF(mn)) continue;
+                    float rel = 1.0f, smp = 1.0f;
+                    if (par != j) {
+                        rel = L(xr, par) * L(nfr, n);
+                        smp = L(xs, par) * L(nfs, n);
+                    }
+                    L(xr, n) = rel;
+                    L(xs, n) = smp;
+                    L(nv, n) = 0.0f;
                 }
                 // bottom-up: descending node index adds children in choices() order (node.rs:103-107)
                 uint32_t kids = 0;
                 for (uint32_t n = end; n > j; --n) {
                     const uint32_t mn = L(nm, n);
-                    float v;
-                    if (LM_LEAF(mn)) {
-                        // reach products along the path j -> n (flow.rs:195-212), top-down, starting at 1 on j's child
-                        unsigned long long path = 0;
-                        uint32_t depth = 0;
-                        for (uint32_t q = n; LM_PARENT(L(nm, q)) != j; q = LM_PARENT(L(nm, q))) {
-                            path = (path << 6) | q;
-                            depth += 1;
-                        }
-                        float rel = 1.0f, smp = 1.0f;
-                        for (uint32_t d = 0; d < depth; ++d) {
-                            const uint32_t q = (uint32_t)(path & 63ull);
-                            path >>= 6;
-                            rel = rel * L(nfr, q);
-                            smp = smp * L(nfs, q);
-                        }
-                        v = rel / smp * L(nv, n);
-                    } else {
-                        v = L(nv, n);
-                    }
                     const uint32_t par = LM_PARENT(mn);
+                    float v = L(nv, n);
+                    if (LM_LEAF(mn)) {
+                        float rel = 1.0f, smp = 1.0f;
+                        if (par != j) {
+                            rel = L(xr, par) * L(nfr, n);
+                            smp = L(xs, par) * L(nfs, n);
+                        }
+                        v = rel / smp * v;
+                    }
                     if (par == j) {
                         L(tv, LM_EDGE(mn)) = v;
                         kids |= 1u << LM_EDGE(mn);
@@ -520,11 +532,9 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                 float ev = 0.0f;
                 for (uint32_t a = 0; a < nact; ++a) {
                     if (!((kids >> a) & 1u)) continue;
-                    L(tv, a) = reach * L(tv, a);
-                }
-                for (uint32_t a = 0; a < nact; ++a) {
-                    if (!((kids >> a) & 1u)) continue;
-                    ev += it.sigma[info * g.A + a] * L(tv, a);
+                    const float u = reach * L(tv, a);
+                    L(tv, a) = u;
+                    ev += it.sigma[info * g.A + a] * u;
                 }
                 payoff += ev;
                 for (uint32_t a = 0; a < nact; ++a) {
@@ -1333,7 +1343,8 @@ void clock_drain(KernelClock& c) {
 }
 
 size_t traverse_lds_bytes(const rp_mccfr* h) {
-    return ((size_t)4 * h->sc.maxn + 4 * h->sc.maxs + h->tbl.max_actions) * 64 * 4;
+    const size_t shared = std::max<size_t>(2 * (size_t)h->sc.maxn, 4 * (size_t)h->sc.maxs);  // stack, then reach prefixes
+    return ((size_t)4 * h->sc.maxn + shared + h->tbl.max_actions) * 64 * 4;
 }
 bool traverse_fits_lds(const rp_mccfr* h) {
     return h->sc.maxn <= 62 && h->tbl.max_depth <= 10 && h->tbl.n_infos <= 8191 && h->tbl.max_actions <= 16 &&
