@@ -1086,6 +1086,11 @@ __global__ __launch_bounds__(128) void k_block_maps(DevGame g, DevSorted so, Ste
 
 __global__ __launch_bounds__(64) void k_combine(DevGame g, DevSorted so, StepParams p, const Map* bmaps, const float* bpsum,
                                                 uint32_t nblk_max, Cell* cells, InfoSum* sums) {
+    // The fold over blocks is sequential per cell (its order is part of the model), but the loads are not: the whole
+    // wave streams the infoset's contiguous [block][cell] maps through a double-buffered LDS tile, 64 maps a pass,
+    // and the 2A chain lanes compose out of LDS.
+    __shared__ __attribute__((aligned(16))) Map mbuf[2][64];
+    __shared__ float pbuf[2][64];
     const uint32_t info = blockIdx.x, lane = threadIdx.x;
     const uint32_t A = g.A, W2 = 2 * A;
     const float NEG_INF = rp_u2f(0xff800000u);
@@ -1093,16 +1098,49 @@ __global__ __launch_bounds__(64) void k_combine(DevGame g, DevSorted so, StepPar
     const uint32_t len = walker ? so.total[info] : 0u;
     const uint32_t T = compose_block(A);
     const uint32_t nb = (len + T - 1) / T;
-    Map tot{1.0f, 0.0f, NEG_INF, 0u};
+    const Map ident{1.0f, 0.0f, NEG_INF, 0u};
+    Map tot = ident;
+    {
+        const Map* src = bmaps + (size_t)info * nblk_max * W2;
+        const uint32_t P = 64u / W2, step = P * W2, total = nb * W2;
+        Map nxt = (lane < step && lane < total) ? src[lane] : ident;
+        uint32_t cur = 0;
+        for (uint32_t base = 0; base < total; base += step) {
+            mbuf[cur][lane] = nxt;
+            const uint32_t k = base + step + lane;
+            nxt = (lane < step && k < total) ? src[k] : ident;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the tile is visible to the chain lanes
+            if (lane < W2) {
+#pragma unroll 4
+                for (uint32_t u = 0; u < P; ++u) tot = map_compose(tot, mbuf[cur][u * W2 + lane]);
+            }
+            cur ^= 1u;
+        }
+    }
+    float ps = 0.0f;
+    {
+        const float* src = bpsum + (size_t)info * nblk_max;
+        float nxt = lane < nb ? src[lane] : 0.0f;
+        uint32_t cur = 0;
+        for (uint32_t base = 0; base < nb; base += 64) {
+            pbuf[cur][lane] = nxt;
+            const uint32_t k = base + 64 + lane;
+            nxt = k < nb ? src[k] : 0.0f;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (lane == W2) {
+                const uint32_t n = min(64u, nb - base);
+                for (uint32_t u = 0; u < n; ++u) ps += pbuf[cur][u];
+            }
+            cur ^= 1u;
+        }
+    }
     if (lane < W2) {
-        const Map* src = bmaps + (size_t)info * nblk_max * W2 + lane;
-        for (uint32_t b = 0; b < nb; ++b) tot = map_compose(tot, src[(size_t)b * W2]);
         Cell* c = &cells[(size_t)info * A + lane % A];
         if (lane < A) { c->ra = tot.a; c->rb = tot.b; c->rm = tot.m; c->rn = tot.n; }
         else { c->wa = tot.a; c->wb = tot.b; c->wm = tot.m; c->wn = tot.n; }
     } else if (lane == W2) {
-        float ps = 0.0f;
-        for (uint32_t b = 0; b < nb; ++b) ps += bpsum[(size_t)info * nblk_max + b];
         sums[info] = InfoSum{len, ps};
     }
 }
