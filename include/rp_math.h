@@ -69,7 +69,7 @@ RP_HD float rp_absf(float a) { return rp_u2f(rp_f2u(a) & 0x7fffffffu); }
  * e^r = 1 + r + r^2 * P(r), result scaled by 2^k in two exact steps.
  * x < -87.34 flushes to +0 (the Sinkhorn softmin clamps every term at
  * MIN_POSITIVE afterwards, sinkhorn.rs:124-126); x > 88.72 -> +inf. */
-RP_HD float rp_expf(float x) {
+RP_HD float rp_expf_spec(float x) {
     /* branch free: evaluate on the clamped argument, patch the special cases with selects at the end */
     float xc = x > 88.72283f ? 88.72283f : x;
     xc = xc < -87.33654f ? -87.33654f : xc;
@@ -95,6 +95,73 @@ RP_HD float rp_expf(float x) {
     res = x > 88.72283f ? rp_u2f(0x7f800000u) : res;
     res = x < -87.33654f ? 0.0f : res;
     return (x == x) ? res : x;
+}
+
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define RP_D __device__ __forceinline__
+/* gfx950 spellings of rp_expf_spec.  Same value for EVERY input bit pattern (rp_math_selftest sweeps all 2^32 on
+ * the device), fewer VALU instructions: v_max/v_min clamp, v_rndne instead of the magic add/sub (same round-to-nearest-
+ * even for |t| < 2^22), one v_ldexp instead of the two exact scalings (both round once), packed v_pk_fma/mul/add
+ * for two arguments at a time.  The Sinkhorn softmin evaluates max(exp(x), MIN_POSITIVE) (sinkhorn.rs:124-126):
+ * there the underflow / NaN patches are subsumed by the final max (a subnormal, 0 or NaN all give MIN_POSITIVE),
+ * and the overflow patch by clamping above the overflow threshold so that ldexp saturates to +inf by itself. */
+typedef float rp_f2 __attribute__((ext_vector_type(2)));
+
+RP_D float rp_exp_core(float xc) { /* xc already clamped, not NaN */
+    const float kf = __builtin_rintf(xc * 1.44269504088896341f);
+    float r = __builtin_fmaf(kf, -0.693359375f, xc);
+    r = __builtin_fmaf(kf, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    const float y = __builtin_fmaf(p, r2, r) + 1.0f;
+    return __builtin_ldexpf(y, (int)kf);
+}
+RP_D float rp_expf_dev(float x) {
+    float res = rp_exp_core(__builtin_amdgcn_fmed3f(x, -87.33654f, 88.72283f));
+    res = x > 88.72283f ? rp_u2f(0x7f800000u) : res;
+    res = x < -87.33654f ? 0.0f : res;
+    return (x == x) ? res : x;
+}
+/* == rp_maxf(rp_expf_spec(x), RP_EPSILON) */
+RP_D float rp_exp_floor(float x) {
+    return __builtin_fmaxf(rp_exp_core(__builtin_fminf(__builtin_fmaxf(x, -104.0f), 89.5f)), RP_EPSILON);
+}
+/* two arguments at a time on the packed-f32 pipe */
+RP_D rp_f2 rp_exp_floor2(rp_f2 x) {
+    rp_f2 xc;
+    xc.x = __builtin_fminf(__builtin_fmaxf(x.x, -104.0f), 89.5f); /* max first: a NaN becomes -104 -> MIN_POSITIVE */
+    xc.y = __builtin_fminf(__builtin_fmaxf(x.y, -104.0f), 89.5f);
+    const rp_f2 t = xc * 1.44269504088896341f;
+    rp_f2 kf;
+    kf.x = __builtin_rintf(t.x);
+    kf.y = __builtin_rintf(t.y);
+    rp_f2 r = __builtin_elementwise_fma(kf, (rp_f2)(-0.693359375f), xc);
+    r = __builtin_elementwise_fma(kf, (rp_f2)(2.12194440e-4f), r);
+    rp_f2 p = __builtin_elementwise_fma((rp_f2)(1.9875691500e-4f), r, (rp_f2)(1.3981999507e-3f));
+    p = __builtin_elementwise_fma(p, r, (rp_f2)(8.3334519073e-3f));
+    p = __builtin_elementwise_fma(p, r, (rp_f2)(4.1665795894e-2f));
+    p = __builtin_elementwise_fma(p, r, (rp_f2)(1.6666665459e-1f));
+    p = __builtin_elementwise_fma(p, r, (rp_f2)(5.0000001201e-1f));
+    const rp_f2 r2 = r * r;
+    const rp_f2 y = __builtin_elementwise_fma(p, r2, r) + 1.0f;
+    rp_f2 res;
+    res.x = __builtin_fmaxf(__builtin_ldexpf(y.x, (int)kf.x), RP_EPSILON);
+    res.y = __builtin_fmaxf(__builtin_ldexpf(y.y, (int)kf.y), RP_EPSILON);
+    return res;
+}
+#endif
+RP_HD float rp_expf(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return rp_expf_dev(x);
+#else
+    return rp_expf_spec(x);
+#endif
 }
 
 /* ln x, ~1 ulp.  Cephes-style: x = m * 2^e with m in [sqrt(1/2), sqrt(2)),

@@ -47,6 +47,10 @@ RP_API const char* rp_version(void);
  * out[0*n..] = rp_expf(x), [1*n..] = rp_logf(|x|), [2*n..] = x / y, [3*n..] = sqrtf(|x|),
  * [4*n..] = fmaf(x, y, x), [5*n..] = (float)(uint32)|x| as u32->f32 conversion of y's bits. */
 RP_API int rp_math_selftest(int device, uint64_t n, const float* x, const float* y, float* out);
+/* Sweeps ALL 2^32 f32 bit patterns on the device and counts where the gfx950 spellings of exp differ from the
+ * contract's spec sequence (rp_expf_spec): mismatches[0] rp_expf, [1] rp_exp_floor vs max(spec, MIN_POSITIVE),
+ * [2] rp_exp_floor2 (packed), [3] smallest mismatching bit pattern (~0 if none).  All counts must be 0. */
+RP_API int rp_math_exp_sweep(int device, uint64_t* mismatches);
 
 /* ======================================================================= mccfr ==
  * crates/mccfr: Solver (solver/solver.rs:38-351), RefProf/MutProf/CfrSampling

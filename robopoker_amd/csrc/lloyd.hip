@@ -61,7 +61,7 @@ struct Points {
     uint64_t N;
 };
 
-struct WaveLds {
+struct __attribute__((aligned(16))) WaveLds {
     uint16_t supA[MAXB];
     uint16_t supB[MAXB];
     float lnA[MAXB];
@@ -107,10 +107,62 @@ __device__ uint32_t wave_load_centroid(const CentroidSet& cs, uint32_t k, uint16
 
 // Sinkhorn::from(mu, nu, metric).minimize().cost() (sinkhorn.rs:77-92,194-230).  A = mu, B = nu, supports and
 // log-densities already in LDS.  All 64 lanes return the same value.
-__device__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint32_t n, const Metric& M) {
+// sum_j max(exp(pot[j] - Rt[sup[j]][x]), MIN_POSITIVE), j ascending: the reference's left fold (sinkhorn.rs:119-128).
+// `sup`/`pot` are the OTHER side's support and potential (LDS, wave uniform), `xi` = this lane's bin.
+// The row base of Rt is uniform, so it is formed on the scalar unit (readfirstlane of two packed u16 bins -> SALU
+// shifts/adds) and the load is `global_load saddr + voffset`: no per-term VALU address arithmetic.  Exponentials go
+// through the packed-f32 pipe two at a time (rp_exp_floor2); the adds stay sequential.
+// C/T through a buffer descriptor: `buffer_load_dword v, voffset, rsrc, soffset` takes the (uniform) row offset
+// from an SGPR and the lane's column offset from a loop-invariant VGPR, so a term needs no VALU address arithmetic.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rt_resource(const Metric& M) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(M.Rt), 0, (int)(M.bins * M.bins * 4u), 0x00020000);
+}
+__device__ __forceinline__ float rt_load(__amdgpu_buffer_rsrc_t rt, uint32_t col_bytes, uint32_t row_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, (int)col_bytes, (int)row_bytes, 0));
+}
+__device__ __forceinline__ float softmin_sum(const uint16_t* sup, const float* pot, uint32_t cnt,
+                                              __amdgpu_buffer_rsrc_t rt, uint32_t bins, uint32_t xi) {
+    const uint32_t rowb = bins * 4u, xoff = xi * 4u;
+    float s = 0.0f;
+    uint32_t j = 0;
+    for (; j + 8 <= cnt; j += 8) {
+        const uint4 sp = *reinterpret_cast<const uint4*>(sup + j);  // 8 bins (LDS arrays are 16-B aligned, j % 8 == 0)
+        const float4 p0 = *reinterpret_cast<const float4*>(pot + j);
+        const float4 p1 = *reinterpret_cast<const float4*>(pot + j + 4);
+        const uint32_t w0 = __builtin_amdgcn_readfirstlane(sp.x), w1 = __builtin_amdgcn_readfirstlane(sp.y);
+        const uint32_t w2 = __builtin_amdgcn_readfirstlane(sp.z), w3 = __builtin_amdgcn_readfirstlane(sp.w);
+        float r[8];
+        r[0] = rt_load(rt, xoff, (w0 & 0xffffu) * rowb);
+        r[1] = rt_load(rt, xoff, (w0 >> 16) * rowb);
+        r[2] = rt_load(rt, xoff, (w1 & 0xffffu) * rowb);
+        r[3] = rt_load(rt, xoff, (w1 >> 16) * rowb);
+        r[4] = rt_load(rt, xoff, (w2 & 0xffffu) * rowb);
+        r[5] = rt_load(rt, xoff, (w2 >> 16) * rowb);
+        r[6] = rt_load(rt, xoff, (w3 & 0xffffu) * rowb);
+        r[7] = rt_load(rt, xoff, (w3 >> 16) * rowb);
+        rp_f2 e0, e1, e2, e3;
+        e0.x = p0.x - r[0]; e0.y = p0.y - r[1];
+        e1.x = p0.z - r[2]; e1.y = p0.w - r[3];
+        e2.x = p1.x - r[4]; e2.y = p1.y - r[5];
+        e3.x = p1.z - r[6]; e3.y = p1.w - r[7];
+        e0 = rp_exp_floor2(e0);
+        e1 = rp_exp_floor2(e1);
+        e2 = rp_exp_floor2(e2);
+        e3 = rp_exp_floor2(e3);
+        s += e0.x; s += e0.y; s += e1.x; s += e1.y; s += e2.x; s += e2.y; s += e3.x; s += e3.y;
+    }
+    for (; j < cnt; ++j) {
+        const uint32_t y = __builtin_amdgcn_readfirstlane((uint32_t)sup[j]);
+        s += rp_exp_floor(pot[j] - rt_load(rt, xoff, y * rowb));
+    }
+    return s;
+}
+
+__device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint32_t n, const Metric& M) {
     const uint32_t lane = lane_id();
     if (m == 0 || n == 0) return 0.0f;  // empty support: the cost sum is empty
     const uint32_t bins = M.bins;
+    const __amdgpu_buffer_rsrc_t rt = rt_resource(M);
     const float lu = rp_logf(1.0f / (float)m), ru = rp_logf(1.0f / (float)n);  // Potential::uniform (phi.rs:34-39)
     for (uint32_t i = lane; i < m; i += 64) w.f[i] = lu;
     for (uint32_t j = lane; j < n; j += 64) w.g[j] = ru;
@@ -122,22 +174,7 @@ __device__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint32_t n, const Me
             const uint32_t i = i0 + lane;
             const bool act = i < m;
             const uint32_t x = act ? w.supA[i] : w.supA[0];
-            float s = 0.0f;
-            uint32_t j = 0;
-            for (; j + 8 <= n; j += 8) {  // 8 independent loads + exps in flight; the sum stays a left fold
-                float e[8];
-#pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) e[q] = w.g[j + q] - M.Rt[(uint32_t)w.supB[j + q] * bins + x];
-#pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) e[q] = rp_maxf(rp_expf(e[q]), RP_EPSILON);
-#pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) s += e[q];
-            }
-            for (; j < n; ++j) {
-                const uint32_t y = w.supB[j];
-                const float e = rp_expf(w.g[j] - M.Rt[y * bins + x]);
-                s += rp_maxf(e, RP_EPSILON);
-            }
+            const float s = softmin_sum(w.supB, w.g, n, rt, bins, x);
             if (act) {
                 const float nf = w.lnA[i] - rp_logf(s);
                 w.tmp[i] = rp_absf(rp_expf(nf) - rp_expf(w.f[i]));  // delta term (sinkhorn.rs:134-139)
@@ -153,22 +190,7 @@ __device__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint32_t n, const Me
             const uint32_t j = j0 + lane;
             const bool act = j < n;
             const uint32_t y = act ? w.supB[j] : w.supB[0];
-            float s = 0.0f;
-            uint32_t i = 0;
-            for (; i + 8 <= m; i += 8) {
-                float e[8];
-#pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) e[q] = w.f[i + q] - M.Rt[(uint32_t)w.supA[i + q] * bins + y];
-#pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) e[q] = rp_maxf(rp_expf(e[q]), RP_EPSILON);
-#pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) s += e[q];
-            }
-            for (; i < m; ++i) {
-                const uint32_t x = w.supA[i];
-                const float e = rp_expf(w.f[i] - M.Rt[x * bins + y]);
-                s += rp_maxf(e, RP_EPSILON);
-            }
+            const float s = softmin_sum(w.supA, w.f, m, rt, bins, y);
             if (act) {
                 const float ng = w.lnB[j] - rp_logf(s);
                 w.tmp[j] = rp_absf(rp_expf(ng) - rp_expf(w.g[j]));

@@ -16,6 +16,35 @@ __global__ void k_math_selftest(uint64_t n, const float* x, const float* y, floa
     out[4 * n + i] = fmaf(a, b, a);
     out[5 * n + i] = (float)rp_f2u(b);
 }
+
+// every f32 bit pattern: the gfx950 spellings of exp against the contract's spec sequence, bit for bit
+__global__ void k_exp_sweep(unsigned long long* bad) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;  // 2^24 threads x 256 patterns
+    unsigned long long b0 = 0, b1 = 0, b2 = 0;
+    uint32_t first = 0xffffffffu;
+    for (uint32_t k = 0; k < 256; k += 2) {
+        const uint32_t u0 = (k << 24) | tid, u1 = ((k + 1) << 24) | tid;
+        const float x0 = rp_u2f(u0), x1 = rp_u2f(u1);
+        const float s0 = rp_expf_spec(x0), s1 = rp_expf_spec(x1);
+        const bool e0 = rp_f2u(rp_expf(x0)) != rp_f2u(s0), e1 = rp_f2u(rp_expf(x1)) != rp_f2u(s1);
+        b0 += e0 + e1;
+        const float f0 = rp_maxf(s0, RP_EPSILON), f1 = rp_maxf(s1, RP_EPSILON);
+        const bool g0 = rp_f2u(rp_exp_floor(x0)) != rp_f2u(f0), g1 = rp_f2u(rp_exp_floor(x1)) != rp_f2u(f1);
+        b1 += g0 + g1;
+        rp_f2 v;
+        v.x = x0;
+        v.y = x1;
+        const rp_f2 r = rp_exp_floor2(v);
+        const bool h0 = rp_f2u(r.x) != rp_f2u(f0), h1 = rp_f2u(r.y) != rp_f2u(f1);
+        b2 += h0 + h1;
+        if (e0 || g0 || h0) first = min(first, u0);
+        if (e1 || g1 || h1) first = min(first, u1);
+    }
+    if (b0) atomicAdd(&bad[0], b0);
+    if (b1) atomicAdd(&bad[1], b1);
+    if (b2) atomicAdd(&bad[2], b2);
+    if (first != 0xffffffffu) atomicMin(&bad[3], (unsigned long long)first);
+}
 }  // namespace rp
 
 extern "C" int rp_math_selftest(int device, uint64_t n, const float* x, const float* y, float* out) {
@@ -39,5 +68,22 @@ extern "C" int rp_math_selftest(int device, uint64_t n, const float* x, const fl
     (void)hipFree(dx);
     (void)hipFree(dy);
     (void)hipFree(dout);
+    return RP_OK;
+}
+
+extern "C" int rp_math_exp_sweep(int device, uint64_t* mismatches) {
+    if (!mismatches) return rp::fail(RP_ERR_INVALID, "rp_math_exp_sweep: bad argument");
+    if (rp_device_count() <= 0) return rp::fail(RP_ERR_NO_DEVICE, "rp_math_exp_sweep: no HIP device");
+    ST_TRY(hipSetDevice(device));
+    unsigned long long* d = nullptr;
+    const unsigned long long init[4] = {0, 0, 0, ~0ull};
+    ST_TRY(hipMalloc(&d, sizeof(init)));
+    ST_TRY(hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rp::k_exp_sweep, dim3(1u << 16), dim3(256), 0, 0, d);
+    ST_TRY(hipGetLastError());
+    unsigned long long out[4];
+    ST_TRY(hipMemcpy(out, d, sizeof(out), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    for (int i = 0; i < 4; ++i) mismatches[i] = out[i];
     return RP_OK;
 }

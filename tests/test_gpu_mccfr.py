@@ -42,6 +42,14 @@ def test_arithmetic_contract_on_device(gpu):
         assert np.array_equal(d, h), f"{nm}: {np.count_nonzero(d != h)} of {n} differ"
 
 
+def test_device_exp_spellings_equal_the_spec_for_every_f32(gpu):
+    # rp_expf / rp_exp_floor / rp_exp_floor2 (v_med3, v_rndne, v_ldexp, packed fma) vs the contract's spec sequence,
+    # all 2^32 bit patterns evaluated on the device
+    bad = (C.c_uint64 * 4)()
+    _lib.check(_lib.load().rp_math_exp_sweep(0, bad))
+    assert list(bad)[:3] == [0, 0, 0], f"mismatches {list(bad)[:3]}, first at bits {bad[3]:#010x}"
+
+
 @pytest.mark.parametrize("game", ["kuhn", "leduc", "rps"])
 @pytest.mark.parametrize("regret,weight,sampling", [
     ("floored", "linear", "external"), ("linear", "linear", "pluribus"), ("summed", "constant", "external"),
