@@ -266,8 +266,10 @@ def bench_slice(n_points: int = 16384, K: int = 256, bins: int = 256, iters: int
     sc_ms, sc_n = layer.kernel_time("selfcost")
     layer.profile(False)
     sinkhorn_s = (step_ms + pw_ms + dr_ms + sc_ms) * 1e-3
-    # one rp_expf + clamp + accumulate is ~30 VALU instructions; 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz = 78.6e12 lane-ops/s
-    valu_peak_exps = 78.6e12 / 30.0
+    # VALU issue roofline: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction x 64 lanes = 3.93e13
+    # lane-instructions/s; one softmin term costs 13.25 VALU instructions in the shipped ISA (106 per 8 terms: sub,
+    # clamp, packed exp polynomial, ldexp, floor, sequential add), i.e. 2.97e12 terms/s with every lane busy.
+    valu_peak_exps = 256 * 4 * 2.4e9 / 4.0 * 64 / 13.25
     exps = e1 - e0
     bd_avg_s = bd_ms / max(bd_n, 1) * 1e-3
     out = {
@@ -284,7 +286,8 @@ def bench_slice(n_points: int = 16384, K: int = 256, bins: int = 256, iters: int
         "roofline_sinkhorn": {"bound": "valu-exp", "achieved": exps / sinkhorn_s if sinkhorn_s > 0 else 0.0,
                               "peak": valu_peak_exps, "unit": "exp/s",
                               "frac": (exps / sinkhorn_s) / valu_peak_exps if sinkhorn_s > 0 else 0.0,
-                              "note": "software rp_expf (bit-reproducible on the CPU), ~30 VALU ops per softmin term"},
+                              "note": "bit-reproducible software exp on the packed-f32 pipe, 13.25 VALU instr per softmin term; "
+                                      "lanes are rows of one support (<= 47 of 64 busy on the point side)"},
         "roofline_bounds": {"bound": "hbm", "achieved": (n_points * K * 8) / bd_avg_s / 1e9 if bd_avg_s > 0 else 0.0,
                             "peak": 8000.0, "unit": "GB/s",
                             "frac": (n_points * K * 8) / bd_avg_s / 1e9 / 8000.0 if bd_avg_s > 0 else 0.0},
