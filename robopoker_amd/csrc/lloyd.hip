@@ -120,36 +120,53 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rt_resource(const Metric& M) {
 __device__ __forceinline__ float rt_load(__amdgpu_buffer_rsrc_t rt, uint32_t col_bytes, uint32_t row_bytes) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, (int)col_bytes, (int)row_bytes, 0));
 }
+struct SoftminGroup {  // 8 consecutive terms: potentials + the C/T entries of this lane's column
+    float4 p0, p1;
+    float r[8];
+};
+__device__ __forceinline__ void softmin_fetch(SoftminGroup& gq, const uint16_t* sup, const float* pot, uint32_t j,
+                                              __amdgpu_buffer_rsrc_t rt, uint32_t rowb, uint32_t xoff) {
+    const uint4 sp = *reinterpret_cast<const uint4*>(sup + j);  // 8 bins (LDS arrays are 16-B aligned, j % 8 == 0)
+    gq.p0 = *reinterpret_cast<const float4*>(pot + j);
+    gq.p1 = *reinterpret_cast<const float4*>(pot + j + 4);
+    const uint32_t w0 = __builtin_amdgcn_readfirstlane(sp.x), w1 = __builtin_amdgcn_readfirstlane(sp.y);
+    const uint32_t w2 = __builtin_amdgcn_readfirstlane(sp.z), w3 = __builtin_amdgcn_readfirstlane(sp.w);
+    gq.r[0] = rt_load(rt, xoff, (w0 & 0xffffu) * rowb);
+    gq.r[1] = rt_load(rt, xoff, (w0 >> 16) * rowb);
+    gq.r[2] = rt_load(rt, xoff, (w1 & 0xffffu) * rowb);
+    gq.r[3] = rt_load(rt, xoff, (w1 >> 16) * rowb);
+    gq.r[4] = rt_load(rt, xoff, (w2 & 0xffffu) * rowb);
+    gq.r[5] = rt_load(rt, xoff, (w2 >> 16) * rowb);
+    gq.r[6] = rt_load(rt, xoff, (w3 & 0xffffu) * rowb);
+    gq.r[7] = rt_load(rt, xoff, (w3 >> 16) * rowb);
+}
+__device__ __forceinline__ float softmin_fold(float s, const SoftminGroup& gq) {
+    rp_f2 e0, e1, e2, e3;
+    e0.x = gq.p0.x - gq.r[0]; e0.y = gq.p0.y - gq.r[1];
+    e1.x = gq.p0.z - gq.r[2]; e1.y = gq.p0.w - gq.r[3];
+    e2.x = gq.p1.x - gq.r[4]; e2.y = gq.p1.y - gq.r[5];
+    e3.x = gq.p1.z - gq.r[6]; e3.y = gq.p1.w - gq.r[7];
+    e0 = rp_exp_floor2(e0);
+    e1 = rp_exp_floor2(e1);
+    e2 = rp_exp_floor2(e2);
+    e3 = rp_exp_floor2(e3);
+    s += e0.x; s += e0.y; s += e1.x; s += e1.y; s += e2.x; s += e2.y; s += e3.x; s += e3.y;
+    return s;
+}
 __device__ __forceinline__ float softmin_sum(const uint16_t* sup, const float* pot, uint32_t cnt,
                                               __amdgpu_buffer_rsrc_t rt, uint32_t bins, uint32_t xi) {
     const uint32_t rowb = bins * 4u, xoff = xi * 4u;
     float s = 0.0f;
     uint32_t j = 0;
-    for (; j + 8 <= cnt; j += 8) {
-        const uint4 sp = *reinterpret_cast<const uint4*>(sup + j);  // 8 bins (LDS arrays are 16-B aligned, j % 8 == 0)
-        const float4 p0 = *reinterpret_cast<const float4*>(pot + j);
-        const float4 p1 = *reinterpret_cast<const float4*>(pot + j + 4);
-        const uint32_t w0 = __builtin_amdgcn_readfirstlane(sp.x), w1 = __builtin_amdgcn_readfirstlane(sp.y);
-        const uint32_t w2 = __builtin_amdgcn_readfirstlane(sp.z), w3 = __builtin_amdgcn_readfirstlane(sp.w);
-        float r[8];
-        r[0] = rt_load(rt, xoff, (w0 & 0xffffu) * rowb);
-        r[1] = rt_load(rt, xoff, (w0 >> 16) * rowb);
-        r[2] = rt_load(rt, xoff, (w1 & 0xffffu) * rowb);
-        r[3] = rt_load(rt, xoff, (w1 >> 16) * rowb);
-        r[4] = rt_load(rt, xoff, (w2 & 0xffffu) * rowb);
-        r[5] = rt_load(rt, xoff, (w2 >> 16) * rowb);
-        r[6] = rt_load(rt, xoff, (w3 & 0xffffu) * rowb);
-        r[7] = rt_load(rt, xoff, (w3 >> 16) * rowb);
-        rp_f2 e0, e1, e2, e3;
-        e0.x = p0.x - r[0]; e0.y = p0.y - r[1];
-        e1.x = p0.z - r[2]; e1.y = p0.w - r[3];
-        e2.x = p1.x - r[4]; e2.y = p1.y - r[5];
-        e3.x = p1.z - r[6]; e3.y = p1.w - r[7];
-        e0 = rp_exp_floor2(e0);
-        e1 = rp_exp_floor2(e1);
-        e2 = rp_exp_floor2(e2);
-        e3 = rp_exp_floor2(e3);
-        s += e0.x; s += e0.y; s += e1.x; s += e1.y; s += e2.x; s += e2.y; s += e3.x; s += e3.y;
+    if (cnt >= 8) {  // software pipeline: the loads of group j+8 are in flight while group j is exponentiated
+        SoftminGroup cur, nxt;
+        softmin_fetch(cur, sup, pot, 0, rt, rowb, xoff);
+        for (j = 8; j + 8 <= cnt; j += 8) {
+            softmin_fetch(nxt, sup, pot, j, rt, rowb, xoff);
+            s = softmin_fold(s, cur);
+            cur = nxt;
+        }
+        s = softmin_fold(s, cur);
     }
     for (; j < cnt; ++j) {
         const uint32_t y = __builtin_amdgcn_readfirstlane((uint32_t)sup[j]);
@@ -520,34 +537,272 @@ __global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uin
 }
 
 // ------------------------------------------------------------------------------------------------
+// Equity::variation against ALL K centroids with the centroid CDFs in REGISTERS (turn layer: bins = 101).
+//
+// Workgroup = 4 waves x VB points.  Wave q owns centroids q*64 + lane: its CDF column (BINS running sums of the
+// transposed density table, the reference's left fold) is loaded once per workgroup into BINS VGPRs.  The points'
+// CDFs are built once in LDS (division in parallel, the sequential prefix by one lane per point) and broadcast to the
+// waves as float4.  A (point, 64 centroids) step is then 2 VALU instructions per bin: t = cx_b - CY_b, s += |t|
+// — the same operations, in the same order, as equity.rs:41-53.
+// ------------------------------------------------------------------------------------------------
+#define VB 32  // points per workgroup
+
+template <int BINS>
+struct VarLds {
+    static constexpr int ROW = (BINS + 3) & ~3;
+    float cx[VB][ROW];       // point CDFs
+    uint32_t active[VB];     // compacted list of points that need distances
+    uint32_t n_active;
+};
+
+// phase A: CDFs of the workgroup's points into LDS
+template <int BINS>
+__device__ __forceinline__ void var_point_cdfs(VarLds<BINS>& L, const Points& P, uint64_t i0, uint32_t np) {
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t e = tid; e < np * BINS; e += 256) {
+        const uint32_t pl = e / BINS, b = e % BINS;
+        const uint64_t i = i0 + pl;
+        L.cx[pl][b] = (float)P.counts[i * P.stride + b] / (float)P.weight[i];
+    }
+    __syncthreads();
+    if (tid < np) {
+        float acc = 0.0f;
+        for (int b = 0; b < BINS; ++b) {
+            acc += L.cx[tid][b];
+            L.cx[tid][b] = acc;
+        }
+    }
+    __syncthreads();
+}
+// the CDF column of centroid k into registers
+template <int BINS>
+__device__ __forceinline__ void var_centroid_cdf(float (&CY)[BINS], const CentroidSet& cs, uint32_t K, uint32_t k) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int b = 0; b < BINS; ++b) {
+        acc += k < K ? cs.dens[(size_t)b * K + k] : 0.0f;
+        CY[b] = acc;
+    }
+}
+template <int BINS>
+__device__ __forceinline__ float var_distance(const float* cxrow, const float (&CY)[BINS]) {
+    float s = 0.0f;
+#pragma unroll
+    for (int b = 0; b < BINS; b += 4) {
+        const float4 c = *reinterpret_cast<const float4*>(cxrow + b);
+        s += rp_absf(c.x - CY[b]);
+        if (b + 1 < BINS) s += rp_absf(c.y - CY[b + 1]);
+        if (b + 2 < BINS) s += rp_absf(c.z - CY[b + 2]);
+        if (b + 3 < BINS) s += rp_absf(c.w - CY[b + 3]);
+    }
+    return s / (float)BINS;
+}
+
+// Elkan::neighbor for every point (init_bounds / lookup / step_naive), variation metric
+template <int BINS>
+__global__ __launch_bounds__(256) void k_neighbor_var(Points P, CentroidSet cs, uint32_t K, Metric M, uint8_t* out_j,
+                                                      float* out_d, Bounds init) {
+    __shared__ __attribute__((aligned(16))) VarLds<BINS> L;
+    __shared__ float wbest[VB][4];
+    __shared__ uint32_t wbk[VB][4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, q = tid >> 6;
+    const uint64_t i0 = (uint64_t)blockIdx.x * VB;
+    const uint32_t np = (uint32_t)min((uint64_t)VB, P.N - i0);
+    var_point_cdfs<BINS>(L, P, i0, np);
+    const uint32_t k = q * 64 + lane;
+    float CY[BINS];
+    var_centroid_cdf<BINS>(CY, cs, K, k);
+    for (uint32_t pl = 0; pl < np; ++pl) {
+        float best = var_distance<BINS>(L.cx[pl], CY);
+        uint32_t bk = k < K ? k : 0xffffffffu;
+        // first minimum in ascending k within the wave
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const uint32_t ok = __shfl_xor(bk, o, 64);
+            if (ok != 0xffffffffu && (bk == 0xffffffffu || ob < best || (ob == best && ok < bk))) {
+                best = ob;
+                bk = ok;
+            }
+        }
+        if (lane == 0) {
+            wbest[pl][q] = best;
+            wbk[pl][q] = bk;
+        }
+    }
+    __syncthreads();
+    if (tid < np) {
+        float best = wbest[tid][0];
+        uint32_t bk = wbk[tid][0];
+        for (uint32_t w = 1; w < 4; ++w)
+            if (wbk[tid][w] != 0xffffffffu && wbest[tid][w] < best) {  // strict: ties keep the lower index
+                best = wbest[tid][w];
+                bk = wbk[tid][w];
+            }
+        const uint64_t i = i0 + tid;
+        if (out_j) out_j[i] = (uint8_t)bk;
+        if (out_d) out_d[i] = best;
+        if (init.j) {
+            init.j[i] = (uint8_t)bk;
+            init.u[i] = best;
+            init.stale[i] = 0;
+        }
+        atomicAdd(&M.stats[0], (unsigned long long)K);
+    }
+    if (init.lower)
+        for (uint64_t e = tid; e < (uint64_t)np * K; e += 256) init.lower[i0 * K + e] = 0.0f;
+}
+
+// Elkan::step_elkan's per-point part (elkan.rs:144-168), variation metric: distances of the unfiltered points of
+// the workgroup to every centroid (phase B), then the sequential candidate rule replayed per point (phase C)
+template <int BINS>
+__global__ __launch_bounds__(256) void k_elkan_step_var(Points P, CentroidSet cs, uint32_t K, Metric M, Bounds B,
+                                                        const float* pairw, const float* mid) {
+    __shared__ __attribute__((aligned(16))) VarLds<BINS> L;
+    __shared__ float dist[VB][MAXB];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, q = tid >> 6;
+    const uint64_t i0 = (uint64_t)blockIdx.x * VB;
+    const uint32_t np = (uint32_t)min((uint64_t)VB, P.N - i0);
+    if (tid < 64) {  // filter(|b| b.u() > midpoints[b.j()]), compacted in point order
+        bool need = false;
+        if (tid < np) need = B.u[i0 + tid] > mid[B.j[i0 + tid]];
+        const unsigned long long mask = __ballot(need);
+        if (need) L.active[__popcll(mask & ((1ull << tid) - 1ull))] = tid;
+        if (tid == 0) L.n_active = (uint32_t)__popcll(mask);
+    }
+    __syncthreads();
+    const uint32_t na = L.n_active;
+    if (na == 0) return;
+    var_point_cdfs<BINS>(L, P, i0, np);
+    {
+        const uint32_t k = q * 64 + lane;
+        float CY[BINS];
+        var_centroid_cdf<BINS>(CY, cs, K, k);
+        for (uint32_t a = 0; a < na; ++a) {
+            const uint32_t pl = L.active[a];
+            const float d = var_distance<BINS>(L.cx[pl], CY);
+            if (k < K) dist[a][k] = d;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) atomicAdd(&M.stats[0], (unsigned long long)K * na);
+    for (uint32_t a = q; a < na; a += 4) {  // one wave per point, as k_elkan_step
+        const uint64_t i = i0 + L.active[a];
+        uint32_t j = B.j[i];
+        float u = B.u[i];
+        float lw[4];
+#pragma unroll
+        for (uint32_t qq = 0; qq < 4; ++qq) {
+            const uint32_t k = qq * 64 + lane;
+            lw[qq] = k < K ? B.lower[i * K + k] : 0.0f;
+        }
+        auto set_lower = [&](uint32_t k, float d) {
+            const uint32_t qq = k >> 6;
+            if (lane == (k & 63u)) {
+                if (qq == 0) lw[0] = d;
+                else if (qq == 1) lw[1] = d;
+                else if (qq == 2) lw[2] = d;
+                else lw[3] = d;
+            }
+        };
+        if (B.stale[i]) {
+            const float d = dist[a][j];
+            set_lower(j, d);
+            u = d;
+        }
+        uint32_t start = 0;
+        for (;;) {
+            uint32_t found = K;
+#pragma unroll
+            for (uint32_t qq = 0; qq < 4; ++qq) {
+                const uint32_t k = qq * 64 + lane;
+                const bool hit = k < K && k >= start && k != j && u > lw[qq] && u > 0.5f * pairw[(size_t)j * K + k];
+                const unsigned long long mask = __ballot(hit);
+                if (mask && found == K) found = qq * 64 + (uint32_t)__ffsll((long long)mask) - 1u;
+            }
+            if (found == K) break;
+            const float d = dist[a][found];
+            set_lower(found, d);
+            if (d < u) {
+                j = found;
+                u = d;
+            }
+            start = found + 1;
+        }
+#pragma unroll
+        for (uint32_t qq = 0; qq < 4; ++qq) {
+            const uint32_t k = qq * 64 + lane;
+            if (k < K) B.lower[i * K + k] = lw[qq];
+        }
+        if (lane == 0) {
+            B.j[i] = (uint8_t)j;
+            B.u[i] = u;
+            B.stale[i] = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Elkan::recompute (elkan.rs:128-142): centroid[k] = integer sum of member histograms (Bins::merge)
 // ------------------------------------------------------------------------------------------------
+#define RC_CHUNK 16384  // points per round (256 threads x 64 assignment bytes)
 __global__ __launch_bounds__(256) void k_recompute(Points P, const uint8_t* assign, uint32_t bins, uint32_t* counts_out,
                                                    uint32_t* weight_out, unsigned long long* sizes_out) {
     __shared__ uint32_t hist[MAXB];
     __shared__ unsigned long long members;
+    __shared__ uint16_t queue[RC_CHUNK];
+    __shared__ uint32_t qn;
     const uint32_t k = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t b = tid; b < MAXB; b += 256) hist[b] = 0;
     if (tid == 0) members = 0;
     __syncthreads();
+    // Rounds of RC_CHUNK points: (1) every thread scans 64 assignment bytes and queues the members of centroid k
+    // in LDS, (2) the waves drain the queue four member rows at a time (loads of independent rows in flight
+    // together).  Integer sums: the order of members is free.
     uint32_t acc[4] = {0, 0, 0, 0};  // lane owns bins lane, lane+64, lane+128, lane+192
     unsigned long long mine = 0;
-    for (uint64_t base = (uint64_t)wave * 64; base < P.N; base += 256) {
-        const uint64_t i = base + lane;
-        const bool hit = i < P.N && assign[i] == k;
-        unsigned long long mask = __ballot(hit);
-        mine += __popcll(mask);
-        while (mask) {
-            const int src = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const uint8_t* row = P.counts + (base + src) * P.stride;
+    for (uint64_t cbase = 0; cbase < P.N; cbase += RC_CHUNK) {
+        if (tid == 0) qn = 0;
+        __syncthreads();
+        const uint64_t t0 = cbase + (uint64_t)tid * 64;
+        if (t0 < P.N) {
+            const uint32_t cnt = (uint32_t)min((uint64_t)64, P.N - t0);
+            if (cnt == 64 && ((uintptr_t)(assign + t0) & 15u) == 0) {
+                const uint4* v = reinterpret_cast<const uint4*>(assign + t0);
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) {
-                const uint32_t b = q * 64 + lane;
-                if (b < bins) acc[q] += row[b];
+                for (uint32_t g = 0; g < 4; ++g) {
+                    const uint4 w4 = v[g];
+                    const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (uint32_t e = 0; e < 16; ++e)
+                        if (((ws[e >> 2] >> ((e & 3u) * 8)) & 0xffu) == k) queue[atomicAdd(&qn, 1u)] = (uint16_t)(tid * 64 + g * 16 + e);
+                }
+            } else {
+                for (uint32_t e = 0; e < cnt; ++e)
+                    if (assign[t0 + e] == k) queue[atomicAdd(&qn, 1u)] = (uint16_t)(tid * 64 + e);
             }
         }
+        __syncthreads();
+        const uint32_t n = qn;
+        if (wave == 0 && lane == 0) mine += n;
+        for (uint32_t m0 = wave * 4; m0 < n; m0 += 16) {
+            uint32_t v[4][4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const bool on = m0 + u < n;
+                const uint8_t* row = P.counts + (cbase + (on ? queue[m0 + u] : 0u)) * P.stride;
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) {
+                    const uint32_t bb = q * 64 + lane;
+                    v[u][q] = (on && bb < bins) ? (uint32_t)row[bb] : 0u;
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) acc[q] += v[u][q];
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (uint32_t q = 0; q < 4; ++q)
@@ -1048,8 +1303,12 @@ int need_bounds(const rp_kmeans* h, const char* who) {
 
 int launch_neighbor(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init) {
     ck_begin(h, CK_NEIGHBOR);
-    hipLaunchKernelGGL(k_neighbor, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->kind, out_j,
-                       out_d, init);
+    if (h->kind == RP_METRIC_VARIATION && h->bins == 101)  // turn layer: register-resident centroid CDFs
+        hipLaunchKernelGGL(k_neighbor_var<101>, dim3((unsigned)((h->N + VB - 1) / VB)), dim3(256), 0, h->stream, h->P,
+                           h->cs[h->cur], h->K, h->M, out_j, out_d, init);
+    else
+        hipLaunchKernelGGL(k_neighbor, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->kind, out_j,
+                           out_d, init);
     ck_end(h, CK_NEIGHBOR);
     HIP_TRY(hipGetLastError());
     return RP_OK;
@@ -1072,8 +1331,12 @@ int step_front(rp_kmeans* h) {
     hipLaunchKernelGGL(k_midpoints, dim3((h->K + 63) / 64), dim3(64), 0, h->stream, h->pairw, h->K, h->mid);
     ck_end(h, CK_PAIRWISE);
     ck_begin(h, CK_STEP);
-    hipLaunchKernelGGL(k_elkan_step, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[cur], h->K, h->M, h->kind, h->B,
-                       h->pairw, h->mid);
+    if (h->kind == RP_METRIC_VARIATION && h->bins == 101)
+        hipLaunchKernelGGL(k_elkan_step_var<101>, dim3((unsigned)((h->N + VB - 1) / VB)), dim3(256), 0, h->stream, h->P, h->cs[cur],
+                           h->K, h->M, h->B, h->pairw, h->mid);
+    else
+        hipLaunchKernelGGL(k_elkan_step, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[cur], h->K, h->M, h->kind, h->B,
+                           h->pairw, h->mid);
     ck_end(h, CK_STEP);
     HIP_TRY(hipGetLastError());
     return launch_recompute(h, h->B.j, cur ^ 1);

@@ -95,7 +95,8 @@ def _check_state(dev, ora):
 
 
 @pytest.mark.parametrize("kind,K,N,bins,mass", [("sinkhorn", 5, 150, 32, 20), ("sinkhorn", 70, 200, 48, 24),
-                                                ("variation", 8, 2048, 101, 46), ("variation", 130, 700, 101, 46)])
+                                                ("variation", 8, 2048, 101, 46), ("variation", 130, 700, 101, 46),
+                                                ("variation", 20, 500, 64, 30)])
 def test_elkan_iterations_bit_exact(gpu, kind, K, N, bins, mass):
     dev, ora = _pair(kind, K, N, bins, mass, seed=K + N, iters=16)
     assert np.array_equal(dev.init_centroids(), ora.init_centroids()), "k-means++ picks differ"
