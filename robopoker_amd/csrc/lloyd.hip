@@ -417,6 +417,26 @@ __global__ __launch_bounds__(64) void k_neighbor(Points P, CentroidSet cs, uint3
         for (uint32_t k = lane; k < K; k += 64) init.lower[i * K + k] = 0.0f;
 }
 
+// Elkan::pairwises for the variation metric: one LANE per ordered pair (a, b), b fastest so the transposed density
+// table is read coalesced; same left folds as equity.rs:41-53
+__global__ __launch_bounds__(256) void k_pairwise_var(CentroidSet cs, uint32_t K, Metric M, float* pairw) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= K * K) return;
+    const uint32_t a = e / K, b = e % K;
+    float d = 0.0f;
+    if (a != b) {
+        float cx = 0.0f, cy = 0.0f, s = 0.0f;
+        for (uint32_t t = 0; t < M.bins; ++t) {
+            cx += cs.dens[(size_t)t * K + a];
+            cy += cs.dens[(size_t)t * K + b];
+            s += rp_absf(cx - cy);
+        }
+        d = s / (float)M.bins;
+    }
+    pairw[e] = d;
+    if (e == 0) atomicAdd(&M.stats[0], (unsigned long long)K * (K - 1));
+}
+
 // Elkan::pairwises (elkan.rs:80-93): both orders; one wave per ordered pair
 __global__ __launch_bounds__(64) void k_pairwise(CentroidSet cs, uint32_t K, Metric M, int kind, float* pairw) {
     __shared__ WaveLds w;
@@ -684,6 +704,8 @@ __global__ __launch_bounds__(256) void k_elkan_step_var(Points P, CentroidSet cs
         }
     }
     __syncthreads();
+    // (skipping a wave's 64 centroids when none of them can become a candidate was measured: candidates are spread
+    // over all four waves, the test costs more than it saves)
     if (tid == 0) atomicAdd(&M.stats[0], (unsigned long long)K * na);
     for (uint32_t a = q; a < na; a += 4) {  // one wave per point, as k_elkan_step
         const uint64_t i = i0 + L.active[a];
@@ -900,6 +922,36 @@ __global__ __launch_bounds__(64) void k_point_dist(Points P, CentroidSet cs, uin
         if (lane_id() == 0) atomicAdd(&M.stats[0], 1ull);
     }
     if (lane_id() == 0) out[i] = d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// variation(point i, ONE centroid) with a LANE per point (k-means++ rounds, rms): the centroid's density column is
+// wave uniform, the point's row is read by its own lane.  Same folds as equity.rs:41-53.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lane_variation(const Points& P, uint64_t i, const CentroidSet& cs, uint32_t K, uint32_t k,
+                                                uint32_t bins) {
+    const uint8_t* row = P.counts + i * P.stride;
+    const float fw = (float)P.weight[i];
+    float cx = 0.0f, cy = 0.0f, s = 0.0f;
+    for (uint32_t t = 0; t < bins; ++t) {
+        cx += (float)row[t] / fw;
+        cy += cs.dens[(size_t)t * K + k];
+        s += rp_absf(cx - cy);
+    }
+    return s / (float)bins;
+}
+__global__ __launch_bounds__(256) void k_kpp_update_var(Points P, CentroidSet cs, uint32_t k, uint32_t K, Metric M, float* pot) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) atomicAdd(&M.stats[0], (unsigned long long)P.N);
+    if (i >= P.N) return;
+    const float d = lane_variation(P, i, cs, K, k, M.bins);
+    pot[i] = rp_minf(d * d, pot[i]);
+}
+__global__ __launch_bounds__(256) void k_point_dist_var(Points P, CentroidSet cs, uint32_t K, Metric M, const uint8_t* j, float* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) atomicAdd(&M.stats[0], (unsigned long long)P.N);
+    if (i >= P.N) return;
+    out[i] = lane_variation(P, i, cs, K, j[i], M.bins);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1327,7 +1379,10 @@ int launch_recompute(rp_kmeans* h, const uint8_t* assign, int set) {
 int step_front(rp_kmeans* h) {
     const int cur = h->cur;
     ck_begin(h, CK_PAIRWISE);
-    hipLaunchKernelGGL(k_pairwise, dim3(h->K * h->K), dim3(64), 0, h->stream, h->cs[cur], h->K, h->M, h->kind, h->pairw);
+    if (h->kind == RP_METRIC_VARIATION)
+        hipLaunchKernelGGL(k_pairwise_var, dim3((h->K * h->K + 255) / 256), dim3(256), 0, h->stream, h->cs[cur], h->K, h->M, h->pairw);
+    else
+        hipLaunchKernelGGL(k_pairwise, dim3(h->K * h->K), dim3(64), 0, h->stream, h->cs[cur], h->K, h->M, h->kind, h->pairw);
     hipLaunchKernelGGL(k_midpoints, dim3((h->K + 63) / 64), dim3(64), 0, h->stream, h->pairw, h->K, h->mid);
     ck_end(h, CK_PAIRWISE);
     ck_begin(h, CK_STEP);
@@ -1458,7 +1513,11 @@ int rp_kmeans_kpp_update(rp_kmeans* h, uint32_t k) {
     if (!h || k >= h->K) return rp::fail(RP_ERR_INVALID, "rp_kmeans_kpp_update: bad argument");
     HIP_TRY(hipSetDevice(h->device));
     ck_begin(h, CK_KPP);
-    hipLaunchKernelGGL(k_kpp_update, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->K, h->M, h->kind, h->pot);
+    if (h->kind == RP_METRIC_VARIATION)
+        hipLaunchKernelGGL(k_kpp_update_var, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->P, h->cs[h->cur], k, h->K,
+                           h->M, h->pot);
+    else
+        hipLaunchKernelGGL(k_kpp_update, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->K, h->M, h->kind, h->pot);
     ck_end(h, CK_KPP);
     HIP_TRY(hipGetLastError());
     if (k + 1 == h->K) {
@@ -1661,8 +1720,12 @@ int rp_kmeans_rms(rp_kmeans* h, float* out) {
     int rc = need_bounds(h, "rp_kmeans_rms");
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_point_dist, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->kind, h->B.j,
-                       h->pdist);
+    if (h->kind == RP_METRIC_VARIATION)
+        hipLaunchKernelGGL(k_point_dist_var, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->P, h->cs[h->cur], h->K,
+                           h->M, h->B.j, h->pdist);
+    else
+        hipLaunchKernelGGL(k_point_dist, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->kind, h->B.j,
+                           h->pdist);
     HIP_TRY(hipGetLastError());
     std::vector<float> d(h->N);
     HIP_TRY(hipMemcpyAsync(d.data(), h->pdist, h->N * 4, hipMemcpyDeviceToHost, h->stream));
