@@ -45,6 +45,9 @@ def parse():
                          "ordered: the reference's sequential tree-id order exactly (N=1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-oracle baseline sample length (0 = skip)")
     ap.add_argument("--no-kmeans", action="store_true", help="skip the secondary k-means measurement")
+    ap.add_argument("--kmeans", default="slice", choices=["slice", "flop", "turn"],
+                    help="k-means measurement in the `kmeans` object: a bounded flop-layer slice (default, ~10 s), or a "
+                         "FULL-size configuration (flop: BASELINE configs[2], ~4 min; turn: one GPU's share of configs[4])")
     ap.add_argument("--force-sharded", action="store_true",
                     help="exercise the RCCL all-gather path even with one rank (plumbing check)")
     return ap.parse_args()
@@ -125,9 +128,12 @@ def kmeans_secondary(args):
         from robopoker_amd import lloyd
     except ImportError:
         return None
-    if not hasattr(lloyd, "bench_slice"):
-        return None
-    return lloyd.bench_slice()
+    import oracle
+
+    out = lloyd.bench_slice() if args.kmeans == "slice" else lloyd.bench_full(args.kmeans)
+    if args.cpu_seconds > 0:
+        out["cpu_baseline"] = lloyd.cpu_baseline_slice(oracle, seconds=min(args.cpu_seconds, 8.0))
+    return out
 
 
 def main():

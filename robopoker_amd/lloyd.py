@@ -296,3 +296,94 @@ def bench_slice(n_points: int = 16384, K: int = 256, bins: int = 256, iters: int
     }
     layer.close()
     return out
+
+
+def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None, seed: int = 1, log=None):
+    """A full-size k-means configuration of BASELINE.json on one GPU:
+
+    flop (configs[2]): N = 1 286 792 histograms, K = 256, bins = 256, mass 47, Sinkhorn EMD, k-means++,
+                       init_bounds, `iters` Elkan iterations, final lookup;
+    turn (configs[4], one GPU's 1/8 share): N = 1 745 006, K = 256, bins = 101, mass 46, Equity::variation.
+    Returns per-phase wall times and rates (a dict)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from lloyd_fixtures import flop_like_points, smooth_metric, turn_like_points
+
+    K = 256
+    if which == "flop":
+        N = n_points or 1286792
+        bins, kind, tri, bytes_per_point = 256, "sinkhorn", smooth_metric(256, 1), 2320
+        pts = flop_like_points(N, bins=bins, mass=47, seed=0xF10F)
+    elif which == "turn":
+        N = n_points or 1745006
+        bins, kind, tri, bytes_per_point = 101, "variation", None, 2165
+        pts = turn_like_points(N, bins=bins, mass=46, seed=5)
+    else:
+        raise ValueError(which)
+    out = {"workload": which, "N": N, "K": K, "bins": bins, "metric": kind, "iterations": iters}
+    t0 = time.perf_counter()
+    layer = Layer(K, pts, kind, tri, seed=seed)
+    out["create_s"] = time.perf_counter() - t0  # upload + point masses + memoised OT(p,p)
+    t0 = time.perf_counter()
+    layer.init_centroids()
+    out["kmeanspp_s"] = time.perf_counter() - t0
+    d0, _ = layer.stats()
+    t0 = time.perf_counter()
+    layer.init_bounds()
+    out["init_bounds_s"] = time.perf_counter() - t0
+    d1, _ = layer.stats()
+    out["init_bounds_distances_per_s"] = (d1 - d0) / out["init_bounds_s"]
+    per_iter = []
+    t_all = time.perf_counter()
+    for it in range(iters):
+        da, _ = layer.stats()
+        t0 = time.perf_counter()
+        _, _, moved = layer.step()
+        dt = time.perf_counter() - t0
+        db, _ = layer.stats()
+        per_iter.append({"s": round(dt, 4), "distances": db - da, "moved": round(float(moved), 5)})
+        if log:
+            log(f"iter {it}: {dt:.3f}s distances={db - da} moved={moved:.4f}")
+    total = time.perf_counter() - t_all
+    out["elkan_total_s"] = total
+    out["points_per_s"] = N * iters / total if iters else 0.0
+    out["algorithmic_GBps"] = N * iters * bytes_per_point / total / 1e9 if iters else 0.0
+    out["hbm_frac"] = out["algorithmic_GBps"] / 8000.0
+    out["per_iteration"] = per_iter
+    t0 = time.perf_counter()
+    layer.lookup()
+    out["lookup_s"] = time.perf_counter() - t0
+    out["rms"] = layer.rms()
+    d2, i2 = layer.stats()
+    out["distances_total"] = d2
+    out["sinkhorn_iterations_total"] = i2
+    layer.close()
+    return out
+
+
+def cpu_baseline_slice(oracle, seconds: float = 8.0, K: int = 256, bins: int = 256, seed: int = 0xF10F):
+    """The CPU oracle (oracle/rp_oracle_lloyd.c, 1 thread) on a bounded sample of the flop-layer workload:
+    init_bounds-style full distances point -> centroid, as many points as fit in `seconds`."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from lloyd_fixtures import flop_like_points, smooth_metric
+
+    pts = flop_like_points(K + 64, bins=bins, mass=47, seed=seed)
+    tri = smooth_metric(bins, 1)
+    cents, probe = pts[:K].astype(np.uint32), pts[K:].astype(np.uint32)
+    done = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        i, k = divmod(done, K)
+        if i >= probe.shape[0]:
+            break
+        oracle.sinkhorn_cost(cents[k], probe[i], tri, bins=bins)  # OT(centroid, point); self terms are memoised (sinkhorn.rs:166-171)
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "distances/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/rp_oracle_lloyd.c Sinkhorn solve (self terms memoised as in the reference), {done} point-centroid distances of the flop-layer "
+                      f"init_bounds (K={K}, bins={bins}, mass 47) in {dt:.1f} s on 1 host thread"}
