@@ -219,6 +219,56 @@ RP_API int rp_mccfr_profile(rp_mccfr* h, int enable);
 /* name in {"traverse","compact","update"}; total milliseconds and launch count since profiling was enabled */
 RP_API int rp_mccfr_kernel_time(rp_mccfr* h, const char* name, double* total_ms, uint64_t* launches);
 
+/* ============================================================= sparse profile ==
+ * The update half of Solver::step (solver/solver.rs:96-105,143-192: update_regret, update_weight, update_payoff,
+ * update_visits in batch order, then epoch += 1) for tables addressed by ROW INDEX: the NLHE-scale shape
+ * (~2^27 infosets x <= 9 actions, crates/forge/README.md:175), where a per-infoset launch grid is impossible and the
+ * Decisions come from a producer other than the built-in traversal (synthetic batches;
+ * §8f f1: the on-device NLHE engine).  Rows are 16*max_actions contiguous bytes in HBM
+ * {regret[A], weight[A], payoff[A], visits[A]} so that one touch reads and writes ONE contiguous row.
+ *
+ *   ORDERED   stable radix sort by row, then every row's touches applied sequentially in batch order:
+ *             the reference loop, bit for bit.
+ *   COMPOSED  per-row maps F(x) = max(a x + b, m) composed over blocks of RP_SPARSE_BLOCK consecutive touches,
+ *             folded in block order (hot rows parallelise); the multi-GPU exchange uses the same entries:
+ *             summarize -> all-gather -> fold in rank order.
+ */
+#define RP_SPARSE_BLOCK 256u
+typedef struct rp_profile rp_profile;
+typedef struct rp_decisions { /* one batch of Decisions in DEVICE memory, in application (tree-id) order */
+    uint32_t n;
+    const uint32_t* row;        /* [n] table row of the infoset                                   */
+    const uint8_t* n_actions;   /* [n] |choices()| of the infoset (the same for every touch of a row) */
+    const uint16_t* expanded;   /* [n] edges present in the regret vector (solver.rs:143-152)       */
+    const float* regret;        /* [n][max_actions] regret_vector                                  */
+    const float* policy;        /* [n][max_actions] policy_vector                                  */
+    const float* payoff;        /* [n] infoset value                                               */
+} rp_decisions;
+/* default_regret: [max_actions] CfrEdge::default_regret per action slot (NULL = 0), book.rs:101-106 */
+RP_API int rp_profile_create(int device, uint64_t n_rows, uint32_t max_actions, rp_regret_kind regret,
+                             rp_weight_kind weight, const rp_hyper* hp, const float* default_regret,
+                             uint32_t max_batch, rp_profile** out);
+RP_API int rp_profile_destroy(rp_profile* h);
+/* one Solver::step worth of updates: applies the batch (asynchronously on the profile's stream), epoch += 1 */
+RP_API int rp_profile_apply(rp_profile* h, const rp_decisions* batch, rp_update_mode mode);
+RP_API int rp_profile_sync(rp_profile* h);
+RP_API int rp_profile_epoch(const rp_profile* h, uint64_t* epoch);
+RP_API int rp_profile_set_epoch(rp_profile* h, uint64_t epoch);
+/* out[i*max_actions + a] = Encounter of (rows[i], action a); rows is a HOST array */
+RP_API int rp_profile_get_rows(rp_profile* h, uint64_t n, const uint32_t* rows, rp_encounter* out);
+RP_API int rp_profile_set_stream(rp_profile* h, void* hip_stream);
+/* multi-GPU: bytes of one summary entry (16 + 2*max_actions*16), and the two halves of a sharded step.
+ * summarize: this rank's batch -> entries sorted by row in `entries_dev` (capacity >= batch->n entries);
+ *            *n_entries is written on the host after a stream sync.
+ * fold:      `n_entries` entries (all ranks' lists back to back, rank-major) -> stable sort by row -> per-row fold in
+ *            rank order -> table; epoch += 1.  Every replica that folds the same list stays bit-identical. */
+RP_API int rp_profile_entry_bytes(const rp_profile* h, size_t* bytes);
+RP_API int rp_profile_summarize(rp_profile* h, const rp_decisions* batch, void* entries_dev, uint32_t* n_entries);
+RP_API int rp_profile_fold(rp_profile* h, const void* entries_dev, uint32_t n_entries);
+/* name in {"sort","apply"}: HIP-event milliseconds since rp_profile_profile(h, 1) */
+RP_API int rp_profile_profile(rp_profile* h, int enable);
+RP_API int rp_profile_kernel_time(rp_profile* h, const char* name, double* total_ms, uint64_t* launches);
+
 /* ===================================================================== lloyd ==
  * crates/elkan: Elkan<K,N> (elkan.rs:27-207), Bounds (bounds.rs:19-120), Prior::tally (prior.rs:35-47)
  * crates/lloyd: Layer (layer.rs:23-273), Kmeans (kmeans.rs:29-111), Sinkhorn (sinkhorn.rs:62-230),

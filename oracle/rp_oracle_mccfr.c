@@ -846,3 +846,161 @@ ORA_API uint64_t ora_div_by_recip_mismatches(uint64_t n, uint64_t seed) {
     }
     return bad;
 }
+
+/* ======================================================================================================
+ * Sparse profile (include/rp_mi355x.h rp_profile_*): the update half of Solver::step (solver.rs:96-105,143-192)
+ * on a table addressed by row index — the NLHE-scale shape, where the producer of the
+ * Decisions is not the built-in traversal.  `apply` is the reference's loop verbatim (batch order, same epoch for
+ * the whole batch, epoch += 1 afterwards); `summarize` / `fold` restate the composed exchange semantics with
+ * blocks of RP_SPARSE_BLOCK consecutive touches of a row.
+ * ====================================================================================================== */
+ORA_API ora_mccfr* ora_profile_create(uint64_t n_rows, uint32_t max_actions, int R, int W, const rp_hyper* hp,
+                                      const float* default_regret) {
+    ora_mccfr* h = (ora_mccfr*)calloc(1, sizeof(ora_mccfr));
+    h->g.n_infos = (uint32_t)n_rows;
+    h->g.max_actions = max_actions;
+    h->R = R;
+    h->W = W;
+    h->hp = *hp; /* the caller passes the schedule constants (tests/oracle.py default_hyper) */
+    size_t cells = (size_t)n_rows * max_actions;
+    h->regret = (float*)calloc(cells, 4);
+    h->weight = (float*)calloc(cells, 4);
+    h->payoff = (float*)calloc(cells, 4);
+    h->visits = (uint32_t*)calloc(cells, 4);
+    if (default_regret)
+        for (size_t r = 0; r < n_rows; ++r)
+            for (uint32_t a = 0; a < max_actions; ++a) h->regret[r * max_actions + a] = default_regret[a];
+    return h;
+}
+ORA_API void ora_profile_destroy(ora_mccfr* h) {
+    if (!h) return;
+    free(h->regret); free(h->weight); free(h->payoff); free(h->visits);
+    free(h);
+}
+static ora_decision sparse_decision(const ora_mccfr* h, uint64_t i, const uint32_t* row, const uint8_t* nact,
+                                    const uint16_t* expanded, const float* regret, const float* policy,
+                                    const float* payoff) {
+    ora_decision d;
+    uint32_t A = h->g.max_actions;
+    memset(&d, 0, sizeof(d));
+    d.info = row[i];
+    d.n_actions = nact[i];
+    d.expanded = expanded[i];
+    for (uint32_t a = 0; a < d.n_actions; ++a) {
+        d.regret[a] = regret[i * A + a];
+        d.policy[a] = policy[i * A + a];
+    }
+    d.payoff = payoff[i];
+    return d;
+}
+ORA_API void ora_profile_apply(ora_mccfr* h, uint64_t n, const uint32_t* row, const uint8_t* nact,
+                               const uint16_t* expanded, const float* regret, const float* policy, const float* payoff) {
+    for (uint64_t i = 0; i < n; ++i) {
+        ora_decision d = sparse_decision(h, i, row, nact, expanded, regret, policy, payoff);
+        apply_decision(h, &d);
+    }
+    h->infos += n;
+    h->epoch += 1;
+}
+ORA_API void ora_profile_get(const ora_mccfr* h, uint32_t row, rp_encounter* out) {
+    uint32_t A = h->g.max_actions;
+    for (uint32_t a = 0; a < A; ++a) {
+        size_t k = (size_t)row * A + a;
+        out[a].weight = h->weight[k];
+        out[a].regret = h->regret[k];
+        out[a].payoff = h->payoff[k];
+        out[a].visits = h->visits[k];
+    }
+}
+ORA_API void ora_profile_set_epoch(ora_mccfr* h, uint64_t e) { h->epoch = e; }
+
+/* summary entry: [row u32][count u32][psum f32][n_actions u32][regret maps A x {a,b,m,n}][weight maps A x {a,b,m,n}] */
+ORA_API size_t ora_profile_entry_bytes(const ora_mccfr* h) { return 16 + (size_t)2 * h->g.max_actions * sizeof(ora_map); }
+
+typedef struct ora_touch_ref {
+    uint32_t row;
+    uint64_t idx;
+} ora_touch_ref;
+static int touch_cmp(const void* x, const void* y) { /* stable: row, then batch position */
+    const ora_touch_ref* a = (const ora_touch_ref*)x;
+    const ora_touch_ref* b = (const ora_touch_ref*)y;
+    if (a->row != b->row) return a->row < b->row ? -1 : 1;
+    return a->idx < b->idx ? -1 : (a->idx > b->idx ? 1 : 0);
+}
+/* one rank's batch -> entries sorted by row; returns the entry count, or -1 for a sign-dependent schedule */
+ORA_API int64_t ora_profile_summarize(ora_mccfr* h, uint64_t n, const uint32_t* row, const uint8_t* nact,
+                                      const uint16_t* expanded, const float* regret, const float* policy,
+                                      const float* payoff, void* blob) {
+    float dr, dw;
+    if (composed_discount(h, &dr, &dw)) return -1;
+    uint32_t A = h->g.max_actions;
+    float floor_r = regret_floor(h);
+    size_t eb = ora_profile_entry_bytes(h);
+    ora_touch_ref* ord = (ora_touch_ref*)malloc((n ? n : 1) * sizeof(ora_touch_ref));
+    for (uint64_t i = 0; i < n; ++i) { ord[i].row = row[i]; ord[i].idx = i; }
+    qsort(ord, n, sizeof(ora_touch_ref), touch_cmp);
+    int64_t ne = 0;
+    ora_map blk_r[ORA_MAXA], blk_w[ORA_MAXA], tot_r[ORA_MAXA], tot_w[ORA_MAXA];
+    for (uint64_t s = 0; s < n;) {
+        uint64_t e = s;
+        while (e < n && ord[e].row == ord[s].row) ++e;
+        for (uint32_t a = 0; a < A; ++a) tot_r[a] = tot_w[a] = MAP_ID;
+        float tot_p = 0.0f;
+        uint32_t na = 0;
+        for (uint64_t b0 = s; b0 < e; b0 += RP_SPARSE_BLOCK) {
+            uint64_t b1 = b0 + RP_SPARSE_BLOCK < e ? b0 + RP_SPARSE_BLOCK : e;
+            for (uint32_t a = 0; a < A; ++a) blk_r[a] = blk_w[a] = MAP_ID;
+            float blk_p = 0.0f;
+            for (uint64_t t = b0; t < b1; ++t) {
+                ora_decision d = sparse_decision(h, ord[t].idx, row, nact, expanded, regret, policy, payoff);
+                na = d.n_actions;
+                for (uint32_t a = 0; a < d.n_actions; ++a) {
+                    if (d.expanded >> a & 1u) map_touch(&blk_r[a], dr, d.regret[a], floor_r);
+                    map_touch(&blk_w[a], dw, composed_wdelta(h, d.policy[a]), RP_EPSILON);
+                }
+                blk_p += d.payoff;
+            }
+            for (uint32_t a = 0; a < A; ++a) {
+                tot_r[a] = map_compose(tot_r[a], blk_r[a]);
+                tot_w[a] = map_compose(tot_w[a], blk_w[a]);
+            }
+            tot_p += blk_p;
+        }
+        unsigned char* ent = (unsigned char*)blob + (size_t)ne * eb;
+        uint32_t hdr[4] = {ord[s].row, (uint32_t)(e - s), rp_f2u(tot_p), na};
+        memcpy(ent, hdr, 16);
+        memcpy(ent + 16, tot_r, A * sizeof(ora_map));
+        memcpy(ent + 16 + A * sizeof(ora_map), tot_w, A * sizeof(ora_map));
+        ne += 1;
+        s = e;
+    }
+    free(ord);
+    h->infos += n;
+    return ne;
+}
+/* fold entries (any number of ranks' lists back to back, rank-major) into the table in the given order — rows are
+ * independent, so this equals the device's stable sort by row followed by a per-row fold in rank order — epoch += 1 */
+ORA_API void ora_profile_fold(ora_mccfr* h, const void* blob, uint64_t n_entries) {
+    uint32_t A = h->g.max_actions;
+    size_t eb = ora_profile_entry_bytes(h);
+    for (uint64_t i = 0; i < n_entries; ++i) {
+        const unsigned char* ent = (const unsigned char*)blob + i * eb;
+        uint32_t hdr[4];
+        memcpy(hdr, ent, 16);
+        const ora_map* mr = (const ora_map*)(ent + 16);
+        const ora_map* mw = mr + A;
+        uint32_t r = hdr[0], count = hdr[1], na = hdr[3];
+        float psum = rp_u2f(hdr[2]);
+        for (uint32_t a = 0; a < na; ++a) {
+            size_t k = (size_t)r * A + a;
+            if (mr[a].n) h->regret[k] = rp_maxf(mr[a].a * h->regret[k] + mr[a].b, mr[a].m);
+            if (mw[a].n) h->weight[k] = rp_maxf(mw[a].a * h->weight[k] + mw[a].b, mw[a].m);
+            if (count) {
+                uint32_t n2 = h->visits[k] + count;
+                h->payoff[k] = h->payoff[k] + (psum - (float)count * h->payoff[k]) / (float)n2;
+                h->visits[k] = n2;
+            }
+        }
+    }
+    h->epoch += 1;
+}

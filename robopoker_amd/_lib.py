@@ -81,6 +81,19 @@ class GameTable(C.Structure):
     ]
 
 
+class Decisions(C.Structure):
+    """rp_decisions: one batch of Decisions in DEVICE memory (raw pointers)."""
+    _fields_ = [
+        ("n", C.c_uint32),
+        ("row", C.c_void_p),
+        ("n_actions", C.c_void_p),
+        ("expanded", C.c_void_p),
+        ("regret", C.c_void_p),
+        ("policy", C.c_void_p),
+        ("payoff", C.c_void_p),
+    ]
+
+
 class SinkhornHP(C.Structure):
     _fields_ = [("temperature", C.c_float), ("iterations", C.c_uint32), ("tolerance", C.c_float)]
 
@@ -134,6 +147,20 @@ _SIGNATURES = {
     "rp_mccfr_step_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "rp_mccfr_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "rp_mccfr_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "rp_profile_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.POINTER(Hyper), C.c_void_p, C.c_uint32,
+                                    C.POINTER(C.c_void_p)]),
+    "rp_profile_destroy": (C.c_int, [C.c_void_p]),
+    "rp_profile_apply": (C.c_int, [C.c_void_p, C.POINTER(Decisions), C.c_int]),
+    "rp_profile_sync": (C.c_int, [C.c_void_p]),
+    "rp_profile_epoch": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rp_profile_set_epoch": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "rp_profile_get_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "rp_profile_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rp_profile_entry_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "rp_profile_summarize": (C.c_int, [C.c_void_p, C.POINTER(Decisions), C.c_void_p, C.POINTER(C.c_uint32)]),
+    "rp_profile_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "rp_profile_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "rp_profile_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "rp_sinkhorn_hp_default": (None, [C.POINTER(SinkhornHP)]),
     "rp_kmeans_create": (
         C.c_int,

@@ -565,47 +565,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
 // ------------------------------------------------------------------------------------------------
 // schedules (regret/*.rs, policy/*.rs)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float d_regret_gain(int kind, float acc, float imm, float t, float floor_r) {
-    float v;
-    switch (kind) {
-        case RP_REGRET_LINEAR: {
-            const float discount = t / (t + 1.0f);
-            v = acc * discount + imm;
-        } break;
-        case RP_REGRET_DISCOUNTED: {
-            float x;
-            if (acc > 0.0f) x = rp_pow15(t / 1.0f);
-            else if (acc < 0.0f) x = rp_pow05(t / 1.0f);
-            else x = t / 1.0f;
-            const float discount = x / (x + 1.0f);
-            v = acc * discount + imm;
-        } break;
-        case RP_REGRET_ASYMMETRIC: {
-            if (acc > 0.0f) v = acc + imm;
-            else {
-                const float discount = t / (t + 1.0f);
-                v = acc * discount + imm;
-            }
-        } break;
-        default: v = acc + imm; break;  // Summed, Floored
-    }
-    return rp_maxf(v, floor_r);
-}
-__device__ __forceinline__ float d_weight_learn(int kind, float acc, float imm, float t) {
-    float v;
-    switch (kind) {
-        case RP_WEIGHT_LINEAR: v = acc + imm * t; break;
-        case RP_WEIGHT_QUADRATIC: v = acc + imm * t * t; break;
-        case RP_WEIGHT_EXPONENTIAL: v = acc * 0.9999f + imm; break;
-        default: v = acc + imm; break;
-    }
-    return rp_maxf(v, RP_EPSILON);
-}
-__host__ __device__ inline float regret_floor_of(int R, float regret_min) {
-    if (R == RP_REGRET_FLOORED) return 0.0f;
-    if (R == RP_REGRET_SUMMED) return rp_u2f(0xff800000u);
-    return regret_min;
-}
+// d_regret_gain / d_weight_learn / regret_floor_of live in mccfr_kernels.hpp (shared with sparse.hip)
 
 // ------------------------------------------------------------------------------------------------
 // Update pipeline (Solver::update_{regret,weight,payoff,visits}, solver.rs:96-105,143-192):
@@ -1004,24 +964,7 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
 //                 block, all blocks of all infosets in parallel
 //   k_combine     one wave per infoset: the block maps composed in block order -> Cell / InfoSum blob
 // ------------------------------------------------------------------------------------------------
-struct Map {
-    float a, b, m;
-    uint32_t n;
-};
-// include/rp_mi355x.h rp_compose_block, callable from device code
-__host__ __device__ inline uint32_t compose_block(uint32_t max_actions) { return (1024u / (2u * max_actions)) & ~3u; }
-__device__ __forceinline__ Map map_compose(const Map& first, const Map& second) {  // `first` is applied first
-    if (second.n == 0) return first;
-    if (first.n == 0) return second;
-    Map r;
-    r.a = second.a * first.a;
-    r.b = second.a * first.b + second.b;
-    const float t = rp_f2u(first.m) == 0xff800000u ? first.m : second.a * first.m + second.b;
-    r.m = rp_maxf(t, second.m);
-    r.n = first.n + second.n;
-    return r;
-}
-
+// Map / map_compose live in mccfr_kernels.hpp
 template <bool PRUNED>
 __global__ __launch_bounds__(128) void k_block_maps(DevGame g, DevSorted so, StepParams p, Map* bmaps, float* bpsum,
                                                     uint32_t nblk_max) {

@@ -1,0 +1,591 @@
+// sparse.hip — rp_profile_*: the update half of Solver::step on a row-addressed table in HBM (include/rp_mi355x.h,
+// "sparse profile").  Reference: crates/mccfr/src/solver/solver.rs:96-105 (step), :143-192 (update_regret /
+// update_weight / update_payoff / update_visits), regret/*.rs, policy/*.rs; oracle: ora_profile_* in
+// oracle/rp_oracle_mccfr.c.
+//
+// MI355X mapping.  A table row is 16*A contiguous bytes {regret[A], weight[A], payoff[A], visits[A]}: the touches of
+// a row read and write one contiguous span, so the HBM traffic of a batch is (rows touched) x 32*A bytes plus the
+// Decisions themselves, independent of the table size.  A batch is brought into per-row, batch-ordered segments by a
+// stable radix sort of (row, position) pairs (rocPRIM through hipCUB: a plain library sort) and a run-length
+// encode; then a group of 16 lanes owns one row — lane a owns action a's four cells, so a row is loaded and stored
+// with coalesced dwords — and walks the row's touches in order.  Four rows per wavefront.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <string>
+#include <vector>
+
+#include "mccfr_kernels.hpp"
+
+namespace rp {
+
+#define HIP_TRY(expr)                                                                                 \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return rp::fail(RP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define GROUP 16u  // lanes per row (max_actions <= 16)
+
+struct SparseParams {
+    float* tab;           // [n_rows][4A]
+    uint32_t A;
+    int R, W;
+    float tf;             // (float)epoch
+    float floor_r;
+    float dr, dw;         // composed discounts
+};
+struct DevBatch {
+    const uint32_t* row;
+    const uint8_t* nact;
+    const uint16_t* expanded;
+    const float* regret;
+    const float* policy;
+    const float* payoff;
+};
+struct Segments {
+    const uint32_t* rows;     // [n_segs] distinct rows ascending
+    const uint32_t* counts;   // [n_segs]
+    const uint32_t* offsets;  // [n_segs] exclusive scan of counts
+    const uint32_t* n_segs;   // device scalar
+    const uint32_t* perm;     // [n] batch positions sorted by (row, position)
+};
+
+__global__ void k_iota(uint32_t* p, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+// ORDERED: Solver::update_* per touch, in batch order (solver.rs:143-192)
+__global__ __launch_bounds__(256) void k_apply_ordered(SparseParams p, DevBatch b, Segments sg) {
+    const uint32_t n_segs = *sg.n_segs;
+    const uint32_t a = threadIdx.x % GROUP;
+    const uint32_t A = p.A;
+    for (uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / GROUP; g < n_segs; g += gridDim.x * blockDim.x / GROUP) {
+        const uint32_t off = sg.offsets[g], cnt = sg.counts[g];
+        float* row = p.tab + (size_t)sg.rows[g] * 4u * A;
+        const uint32_t nact = b.nact[sg.perm[off]];
+        const bool mine = a < nact;
+        float r = 0.0f, w = 0.0f, ev = 0.0f;
+        uint32_t v = 0;
+        if (mine) {
+            r = row[a];
+            w = row[A + a];
+            ev = row[2 * A + a];
+            v = reinterpret_cast<const uint32_t*>(row)[3 * A + a];
+        }
+        for (uint32_t t = 0; t < cnt; ++t) {
+            const uint32_t idx = sg.perm[off + t];
+            if (!mine) continue;
+            if ((b.expanded[idx] >> a) & 1u) r = d_regret_gain(p.R, r, b.regret[(size_t)idx * A + a], p.tf, p.floor_r);
+            w = d_weight_learn(p.W, w, b.policy[(size_t)idx * A + a], p.tf);
+            ev += (b.payoff[idx] - ev) / (float)(v + 1u);
+            v += 1u;
+        }
+        if (mine) {
+            row[a] = r;
+            row[A + a] = w;
+            row[2 * A + a] = ev;
+            reinterpret_cast<uint32_t*>(row)[3 * A + a] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ float composed_wdelta(int W, float sigma, float tf) {
+    if (W == RP_WEIGHT_LINEAR) return sigma * tf;
+    if (W == RP_WEIGHT_QUADRATIC) return sigma * tf * tf;
+    return sigma;
+}
+
+// COMPOSED, first half: a row's touches -> one entry (oracle: ora_profile_summarize).  Blocks of RP_SPARSE_BLOCK
+// consecutive touches are composed sequentially, block maps folded in block order.
+// entry = [row][count][psum][n_actions][A regret maps][A weight maps]
+__global__ __launch_bounds__(256) void k_summarize(SparseParams p, DevBatch b, Segments sg, unsigned char* entries,
+                                                   uint32_t entry_bytes) {
+    const uint32_t n_segs = *sg.n_segs;
+    const uint32_t a = threadIdx.x % GROUP;
+    const uint32_t A = p.A;
+    const float NEG_INF = rp_u2f(0xff800000u);
+    const Map ident{1.0f, 0.0f, NEG_INF, 0u};
+    for (uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / GROUP; g < n_segs; g += gridDim.x * blockDim.x / GROUP) {
+        const uint32_t off = sg.offsets[g], cnt = sg.counts[g];
+        const uint32_t nact = b.nact[sg.perm[off]];
+        const bool mine = a < nact;
+        Map tr = ident, tw = ident, br = ident, bw = ident;
+        float tp = 0.0f, bp = 0.0f;
+        for (uint32_t t = 0; t < cnt; ++t) {
+            const uint32_t idx = sg.perm[off + t];
+            if (mine) {
+                if ((b.expanded[idx] >> a) & 1u) map_touch(br, p.dr, b.regret[(size_t)idx * A + a], p.floor_r);
+                map_touch(bw, p.dw, composed_wdelta(p.W, b.policy[(size_t)idx * A + a], p.tf), RP_EPSILON);
+            }
+            bp += b.payoff[idx];
+            if ((t + 1u) % RP_SPARSE_BLOCK == 0u || t + 1u == cnt) {
+                tr = map_compose(tr, br);
+                tw = map_compose(tw, bw);
+                tp += bp;
+                br = ident;
+                bw = ident;
+                bp = 0.0f;
+            }
+        }
+        unsigned char* ent = entries + (size_t)g * entry_bytes;
+        if (a == 0) {
+            uint32_t* hdr = reinterpret_cast<uint32_t*>(ent);
+            hdr[0] = sg.rows[g];
+            hdr[1] = cnt;
+            hdr[2] = rp_f2u(tp);
+            hdr[3] = nact;
+        }
+        if (a < A) {
+            Map* mr = reinterpret_cast<Map*>(ent + 16);
+            mr[a] = mine ? tr : ident;
+            mr[A + a] = mine ? tw : ident;
+        }
+    }
+}
+
+// COMPOSED, second half: entries of one row, in the given (rank) order, folded into the table row
+// (oracle: ora_profile_fold).  `order` == nullptr: entry g is its own segment (single rank: rows are distinct,
+// *n_segs_dev entries).
+__global__ __launch_bounds__(256) void k_fold(SparseParams p, const unsigned char* entries, uint32_t entry_bytes,
+                                              const uint32_t* order, const uint32_t* offsets, const uint32_t* counts,
+                                              const uint32_t* n_segs_dev) {
+    const uint32_t n_segs = *n_segs_dev;
+    const uint32_t a = threadIdx.x % GROUP;
+    const uint32_t A = p.A;
+    for (uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / GROUP; g < n_segs; g += gridDim.x * blockDim.x / GROUP) {
+        const uint32_t off = order ? offsets[g] : g, cnt = order ? counts[g] : 1u;
+        const unsigned char* first = entries + (size_t)(order ? order[off] : g) * entry_bytes;
+        const uint32_t rowid = reinterpret_cast<const uint32_t*>(first)[0];
+        const uint32_t nact = reinterpret_cast<const uint32_t*>(first)[3];
+        if (a >= nact) continue;
+        float* row = p.tab + (size_t)rowid * 4u * A;
+        float r = row[a], w = row[A + a], ev = row[2 * A + a];
+        uint32_t v = reinterpret_cast<const uint32_t*>(row)[3 * A + a];
+        for (uint32_t t = 0; t < cnt; ++t) {
+            const unsigned char* ent = entries + (size_t)(order ? order[off + t] : g) * entry_bytes;
+            const uint32_t* hdr = reinterpret_cast<const uint32_t*>(ent);
+            const Map mr = reinterpret_cast<const Map*>(ent + 16)[a];
+            const Map mw = reinterpret_cast<const Map*>(ent + 16)[A + a];
+            if (mr.n) r = rp_maxf(mr.a * r + mr.b, mr.m);
+            if (mw.n) w = rp_maxf(mw.a * w + mw.b, mw.m);
+            const uint32_t c = hdr[1];
+            if (c) {
+                const uint32_t n2 = v + c;
+                ev = ev + (rp_u2f(hdr[2]) - (float)c * ev) / (float)n2;
+                v = n2;
+            }
+        }
+        row[a] = r;
+        row[A + a] = w;
+        row[2 * A + a] = ev;
+        reinterpret_cast<uint32_t*>(row)[3 * A + a] = v;
+    }
+}
+
+__global__ void k_entry_rows(const unsigned char* entries, uint32_t entry_bytes, uint32_t n, uint32_t* rows) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rows[i] = *reinterpret_cast<const uint32_t*>(entries + (size_t)i * entry_bytes);
+}
+
+__global__ void k_init_rows(float* tab, uint64_t n_rows, uint32_t A, const float* default_regret) {
+    const uint64_t cells = n_rows * 4u * A;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < cells; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)(e % (4u * A));
+        tab[e] = c < A ? default_regret[c] : 0.0f;  // regret <- default, weight/payoff/visits <- 0 (book.rs:93-122)
+    }
+}
+
+__global__ void k_gather_rows(const float* tab, uint32_t A, const uint32_t* rows, uint64_t n, rp_encounter* out) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * A) return;
+    const uint64_t i = e / A;
+    const uint32_t a = (uint32_t)(e % A);
+    const float* row = tab + (size_t)rows[i] * 4u * A;
+    out[e].regret = row[a];
+    out[e].weight = row[A + a];
+    out[e].payoff = row[2 * A + a];
+    out[e].visits = reinterpret_cast<const uint32_t*>(row)[3 * A + a];
+}
+
+struct SpClock {
+    double total_ms = 0.0;
+    uint64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace rp
+
+using namespace rp;
+
+struct rp_profile {
+    int device = 0;
+    uint64_t n_rows = 0;
+    uint32_t A = 0;
+    int R = 0, W = 0;
+    rp_hyper hp{};
+    uint64_t epoch = 0;
+    uint32_t max_batch = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    float* tab = nullptr;
+    // sort / segment workspace (capacity `cap` items)
+    uint32_t cap = 0;
+    uint32_t *iota = nullptr, *keys_out = nullptr, *perm = nullptr, *seg_rows = nullptr, *seg_counts = nullptr,
+             *seg_offsets = nullptr, *n_segs = nullptr, *ent_rows = nullptr;
+    void* cub_tmp = nullptr;
+    size_t cub_bytes = 0;
+    unsigned char* entries = nullptr;  // local composed apply
+    bool profiling = false;
+    SpClock clk_sort, clk_apply;
+};
+
+namespace rp {
+
+static size_t entry_bytes_of(const rp_profile* h) { return 16 + (size_t)2 * h->A * sizeof(Map); }
+
+static void sp_begin(rp_profile* h, SpClock& c) {
+    if (!h->profiling) return;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, h->stream);
+    c.pending.emplace_back(a, b);
+}
+static void sp_end(rp_profile* h, SpClock& c) {
+    if (!h->profiling || c.pending.empty()) return;
+    (void)hipEventRecord(c.pending.back().second, h->stream);
+    c.launches += 1;
+}
+static void sp_drain(SpClock& c) {
+    for (auto& pr : c.pending) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess)
+            c.total_ms += ms;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    c.pending.clear();
+}
+
+static void free_workspace(rp_profile* h) {
+    for (void* p : {(void*)h->iota, (void*)h->keys_out, (void*)h->perm, (void*)h->seg_rows, (void*)h->seg_counts,
+                    (void*)h->seg_offsets, (void*)h->ent_rows, h->cub_tmp, (void*)h->entries})
+        if (p) (void)hipFree(p);
+    h->iota = h->keys_out = h->perm = h->seg_rows = h->seg_counts = h->seg_offsets = h->ent_rows = nullptr;
+    h->cub_tmp = nullptr;
+    h->entries = nullptr;
+    h->cap = 0;
+}
+
+// workspace for sorting / segmenting up to n items
+static int ensure_capacity(rp_profile* h, uint32_t n) {
+    if (n <= h->cap) return RP_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    free_workspace(h);
+    const uint32_t cap = n;
+    HIP_TRY(hipMalloc(&h->iota, (size_t)cap * 4));
+    HIP_TRY(hipMalloc(&h->keys_out, (size_t)cap * 4));
+    HIP_TRY(hipMalloc(&h->perm, (size_t)cap * 4));
+    HIP_TRY(hipMalloc(&h->seg_rows, (size_t)cap * 4));
+    HIP_TRY(hipMalloc(&h->seg_counts, (size_t)cap * 4));
+    HIP_TRY(hipMalloc(&h->seg_offsets, (size_t)cap * 4));
+    HIP_TRY(hipMalloc(&h->ent_rows, (size_t)cap * 4));
+    HIP_TRY(hipMalloc(&h->entries, (size_t)cap * entry_bytes_of(h)));
+    size_t s1 = 0, s2 = 0, s3 = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, s1, h->iota, h->keys_out, h->iota, h->perm, (int)cap, 0, 32, h->stream));
+    HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, s2, h->keys_out, h->seg_rows, h->seg_counts, h->n_segs, (int)cap, h->stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, s3, h->seg_counts, h->seg_offsets, (int)cap, h->stream));
+    h->cub_bytes = std::max(s1, std::max(s2, s3));
+    HIP_TRY(hipMalloc(&h->cub_tmp, h->cub_bytes));
+    hipLaunchKernelGGL(k_iota, dim3((cap + 255) / 256), dim3(256), 0, h->stream, h->iota, cap);
+    HIP_TRY(hipGetLastError());
+    h->cap = cap;
+    return RP_OK;
+}
+
+static uint32_t key_bits(uint64_t n_rows) {
+    uint32_t bits = 1;
+    while (bits < 32 && (1ull << bits) < n_rows) ++bits;
+    return bits;
+}
+
+// rows[n] (device) -> perm (stable by row), distinct rows, counts, offsets, n_segs
+static int sort_and_segment(rp_profile* h, const uint32_t* rows, uint32_t n) {
+    int rc = ensure_capacity(h, n);
+    if (rc) return rc;
+    size_t tmp = h->cub_bytes;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, tmp, rows, h->keys_out, h->iota, h->perm, (int)n, 0,
+                                               (int)key_bits(h->n_rows), h->stream));
+    tmp = h->cub_bytes;
+    HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(h->cub_tmp, tmp, h->keys_out, h->seg_rows, h->seg_counts, h->n_segs, (int)n,
+                                                  h->stream));
+    tmp = h->cub_bytes;
+    // scanning all n slots is harmless (slots past n_segs are never read) and avoids a host round trip
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp, tmp, h->seg_counts, h->seg_offsets, (int)n, h->stream));
+    return RP_OK;
+}
+
+static int composed_params(const rp_profile* h, SparseParams& p) {
+    const float t = (float)h->epoch;
+    switch (h->R) {
+        case RP_REGRET_SUMMED:
+        case RP_REGRET_FLOORED: p.dr = 1.0f; break;
+        case RP_REGRET_LINEAR: p.dr = t / (t + 1.0f); break;
+        default:
+            return rp::fail(RP_ERR_UNSUPPORTED,
+                            "composed update needs a sign-independent discount (Summed/Linear/Floored regret)");
+    }
+    p.dw = h->W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f;
+    return RP_OK;
+}
+static SparseParams make_params(const rp_profile* h) {
+    SparseParams p{};
+    p.tab = h->tab;
+    p.A = h->A;
+    p.R = h->R;
+    p.W = h->W;
+    p.tf = (float)h->epoch;
+    p.floor_r = regret_floor_of(h->R, h->hp.regret_min);
+    p.dr = p.dw = 1.0f;
+    return p;
+}
+static int check_batch(const rp_profile* h, const rp_decisions* b, const char* who) {
+    if (!h || !b) return rp::fail(RP_ERR_INVALID, "%s: null argument", who);
+    if (b->n == 0) return RP_OK;
+    if (!b->row || !b->n_actions || !b->expanded || !b->regret || !b->policy || !b->payoff)
+        return rp::fail(RP_ERR_INVALID, "%s: null batch array", who);
+    return RP_OK;
+}
+static uint32_t group_blocks(uint32_t n) { return std::max(1u, std::min((n * GROUP + 255u) / 256u, 65535u)); }
+
+}  // namespace rp
+
+extern "C" {
+
+int rp_profile_create(int device, uint64_t n_rows, uint32_t max_actions, rp_regret_kind regret, rp_weight_kind weight,
+                      const rp_hyper* hp, const float* default_regret, uint32_t max_batch, rp_profile** out) {
+    if (!out) return rp::fail(RP_ERR_INVALID, "rp_profile_create: out is null");
+    *out = nullptr;
+    if (n_rows == 0 || n_rows > 0xffffffffull) return rp::fail(RP_ERR_INVALID, "rp_profile_create: n_rows must be in 1..2^32-1");
+    if (max_actions == 0 || max_actions > GROUP) return rp::fail(RP_ERR_INVALID, "rp_profile_create: max_actions must be in 1..16");
+    if ((int)regret < 0 || (int)regret > RP_REGRET_ASYMMETRIC || (int)weight < 0 || (int)weight > RP_WEIGHT_EXPONENTIAL)
+        return rp::fail(RP_ERR_INVALID, "rp_profile_create: unknown schedule");
+    if (rp_device_count() <= 0) return rp::fail(RP_ERR_NO_DEVICE, "rp_profile_create: no HIP device (there is no CPU fallback)");
+    rp_profile* h = new rp_profile();
+    h->device = device;
+    h->n_rows = n_rows;
+    h->A = max_actions;
+    h->R = regret;
+    h->W = weight;
+    if (hp) h->hp = *hp; else rp_hyper_default(&h->hp);
+    h->max_batch = max_batch;
+#define PF_TRY(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            int _rc = rp::fail(RP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));        \
+            rp_profile_destroy(h);                                                                \
+            return _rc;                                                                           \
+        }                                                                                         \
+    } while (0)
+    PF_TRY(hipSetDevice(device));
+    PF_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    PF_TRY(hipMalloc(&h->tab, (size_t)n_rows * 4u * max_actions * 4u));
+    PF_TRY(hipMalloc(&h->n_segs, 4));
+    float* d_def = nullptr;
+    std::vector<float> def(max_actions, 0.0f);
+    if (default_regret) def.assign(default_regret, default_regret + max_actions);
+    PF_TRY(hipMalloc(&d_def, max_actions * 4u));
+    PF_TRY(hipMemcpyAsync(d_def, def.data(), max_actions * 4u, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_init_rows, dim3(4096), dim3(256), 0, h->stream, h->tab, n_rows, max_actions, d_def);
+    PF_TRY(hipGetLastError());
+    PF_TRY(hipStreamSynchronize(h->stream));
+    (void)hipFree(d_def);
+    if (max_batch) {
+        int rc = ensure_capacity(h, max_batch);
+        if (rc) {
+            rp_profile_destroy(h);
+            return rc;
+        }
+    }
+    *out = h;
+    return RP_OK;
+}
+
+int rp_profile_destroy(rp_profile* h) {
+    if (!h) return RP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    sp_drain(h->clk_sort);
+    sp_drain(h->clk_apply);
+    free_workspace(h);
+    if (h->tab) (void)hipFree(h->tab);
+    if (h->n_segs) (void)hipFree(h->n_segs);
+    if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return RP_OK;
+}
+
+int rp_profile_apply(rp_profile* h, const rp_decisions* batch, rp_update_mode mode) {
+    int rc = check_batch(h, batch, "rp_profile_apply");
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    SparseParams p = make_params(h);
+    if (mode == RP_UPDATE_COMPOSED && (rc = composed_params(h, p))) return rc;
+    if (batch->n) {
+        const DevBatch b{batch->row, batch->n_actions, batch->expanded, batch->regret, batch->policy, batch->payoff};
+        sp_begin(h, h->clk_sort);
+        if ((rc = sort_and_segment(h, batch->row, batch->n))) return rc;
+        sp_end(h, h->clk_sort);
+        const Segments sg{h->seg_rows, h->seg_counts, h->seg_offsets, h->n_segs, h->perm};
+        sp_begin(h, h->clk_apply);
+        if (mode == RP_UPDATE_ORDERED) {
+            hipLaunchKernelGGL(k_apply_ordered, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, b, sg);
+        } else {
+            const uint32_t eb = (uint32_t)entry_bytes_of(h);
+            hipLaunchKernelGGL(k_summarize, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, b, sg, h->entries, eb);
+            // a single rank's entries have distinct rows: entry g is its own segment, the count comes from n_segs
+            hipLaunchKernelGGL(k_fold, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, h->entries, eb,
+                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, h->n_segs);
+        }
+        sp_end(h, h->clk_apply);
+        HIP_TRY(hipGetLastError());
+    }
+    h->epoch += 1;  // CfrSampling::increment via Solver::advance (solver.rs:103-104)
+    return RP_OK;
+}
+
+int rp_profile_sync(rp_profile* h) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_profile_sync: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RP_OK;
+}
+int rp_profile_epoch(const rp_profile* h, uint64_t* epoch) {
+    if (!h || !epoch) return rp::fail(RP_ERR_INVALID, "rp_profile_epoch: null argument");
+    *epoch = h->epoch;
+    return RP_OK;
+}
+int rp_profile_set_epoch(rp_profile* h, uint64_t epoch) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_profile_set_epoch: null handle");
+    h->epoch = epoch;
+    return RP_OK;
+}
+
+int rp_profile_get_rows(rp_profile* h, uint64_t n, const uint32_t* rows, rp_encounter* out) {
+    if (!h || (n && (!rows || !out))) return rp::fail(RP_ERR_INVALID, "rp_profile_get_rows: null argument");
+    if (n == 0) return RP_OK;
+    for (uint64_t i = 0; i < n; ++i)
+        if (rows[i] >= h->n_rows) return rp::fail(RP_ERR_INVALID, "rp_profile_get_rows: row %u out of range", rows[i]);
+    HIP_TRY(hipSetDevice(h->device));
+    uint32_t* d_rows = nullptr;
+    rp_encounter* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_rows, n * 4));
+    HIP_TRY(hipMalloc(&d_out, n * h->A * sizeof(rp_encounter)));
+    HIP_TRY(hipMemcpyAsync(d_rows, rows, n * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n * h->A + 255) / 256)), dim3(256), 0, h->stream, h->tab, h->A, d_rows, n, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_out, n * h->A * sizeof(rp_encounter), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    (void)hipFree(d_rows);
+    (void)hipFree(d_out);
+    return RP_OK;
+}
+
+int rp_profile_set_stream(rp_profile* h, void* hip_stream) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_profile_set_stream: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    if (hip_stream) {
+        h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+        h->own_stream = false;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    return RP_OK;
+}
+
+int rp_profile_entry_bytes(const rp_profile* h, size_t* bytes) {
+    if (!h || !bytes) return rp::fail(RP_ERR_INVALID, "rp_profile_entry_bytes: null argument");
+    *bytes = entry_bytes_of(h);
+    return RP_OK;
+}
+
+int rp_profile_summarize(rp_profile* h, const rp_decisions* batch, void* entries_dev, uint32_t* n_entries) {
+    int rc = check_batch(h, batch, "rp_profile_summarize");
+    if (rc) return rc;
+    if (!entries_dev || !n_entries) return rp::fail(RP_ERR_INVALID, "rp_profile_summarize: null output");
+    HIP_TRY(hipSetDevice(h->device));
+    SparseParams p = make_params(h);
+    if ((rc = composed_params(h, p))) return rc;
+    *n_entries = 0;
+    if (batch->n == 0) return RP_OK;
+    const DevBatch b{batch->row, batch->n_actions, batch->expanded, batch->regret, batch->policy, batch->payoff};
+    sp_begin(h, h->clk_sort);
+    if ((rc = sort_and_segment(h, batch->row, batch->n))) return rc;
+    sp_end(h, h->clk_sort);
+    const Segments sg{h->seg_rows, h->seg_counts, h->seg_offsets, h->n_segs, h->perm};
+    sp_begin(h, h->clk_apply);
+    hipLaunchKernelGGL(k_summarize, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, b, sg,
+                       reinterpret_cast<unsigned char*>(entries_dev), (uint32_t)entry_bytes_of(h));
+    sp_end(h, h->clk_apply);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(n_entries, h->n_segs, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RP_OK;
+}
+
+int rp_profile_fold(rp_profile* h, const void* entries_dev, uint32_t n_entries) {
+    if (!h || (n_entries && !entries_dev)) return rp::fail(RP_ERR_INVALID, "rp_profile_fold: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    SparseParams p = make_params(h);
+    int rc = composed_params(h, p);
+    if (rc) return rc;
+    if (n_entries) {
+        const unsigned char* ent = reinterpret_cast<const unsigned char*>(entries_dev);
+        const uint32_t eb = (uint32_t)entry_bytes_of(h);
+        if ((rc = ensure_capacity(h, n_entries))) return rc;
+        sp_begin(h, h->clk_sort);
+        hipLaunchKernelGGL(k_entry_rows, dim3((n_entries + 255) / 256), dim3(256), 0, h->stream, ent, eb, n_entries, h->ent_rows);
+        if ((rc = sort_and_segment(h, h->ent_rows, n_entries))) return rc;
+        sp_end(h, h->clk_sort);
+        sp_begin(h, h->clk_apply);
+        hipLaunchKernelGGL(k_fold, dim3(group_blocks(n_entries)), dim3(256), 0, h->stream, p, ent, eb, h->perm, h->seg_offsets,
+                           h->seg_counts, h->n_segs);
+        sp_end(h, h->clk_apply);
+        HIP_TRY(hipGetLastError());
+    }
+    h->epoch += 1;
+    return RP_OK;
+}
+
+int rp_profile_profile(rp_profile* h, int enable) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_profile_profile: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    sp_drain(h->clk_sort);
+    sp_drain(h->clk_apply);
+    if (enable && !h->profiling) {
+        h->clk_sort = SpClock{};
+        h->clk_apply = SpClock{};
+    }
+    h->profiling = enable != 0;
+    return RP_OK;
+}
+int rp_profile_kernel_time(rp_profile* h, const char* name, double* total_ms, uint64_t* launches) {
+    if (!h || !name || !total_ms || !launches) return rp::fail(RP_ERR_INVALID, "rp_profile_kernel_time: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    SpClock* c = std::string(name) == "sort" ? &h->clk_sort : (std::string(name) == "apply" ? &h->clk_apply : nullptr);
+    if (!c) return rp::fail(RP_ERR_INVALID, "rp_profile_kernel_time: unknown kernel '%s'", name);
+    sp_drain(*c);
+    *total_ms = c->total_ms;
+    *launches = c->launches;
+    return RP_OK;
+}
+
+}  // extern "C"

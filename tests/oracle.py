@@ -209,6 +209,76 @@ class OracleSolver:
 ENC_DTYPE = np.dtype([("weight", "<f4"), ("regret", "<f4"), ("payoff", "<f4"), ("visits", "<u4")])
 
 
+class OracleProfile:
+    """ora_profile_*: the sparse-profile oracle (oracle/rp_oracle_mccfr.c)."""
+
+    def __init__(self, n_rows, max_actions, regret="linear", weight="linear", hyper=None, default_regret=None):
+        o = load()
+        vp = C.c_void_p
+        o.ora_profile_create.restype = vp
+        o.ora_profile_create.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.POINTER(_lib.Hyper), vp]
+        o.ora_profile_destroy.argtypes = [vp]
+        o.ora_profile_apply.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp, vp]
+        o.ora_profile_get.argtypes = [vp, C.c_uint32, vp]
+        o.ora_profile_set_epoch.argtypes = [vp, C.c_uint64]
+        o.ora_profile_entry_bytes.restype = C.c_size_t
+        o.ora_profile_entry_bytes.argtypes = [vp]
+        o.ora_profile_summarize.restype = C.c_int64
+        o.ora_profile_summarize.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]
+        o.ora_profile_fold.argtypes = [vp, vp, C.c_uint64]
+        self.o, self.A, self.n_rows = o, max_actions, n_rows
+        hp = hyper or default_hyper()
+        dr = None if default_regret is None else np.ascontiguousarray(default_regret, dtype=np.float32)
+        self.h = o.ora_profile_create(n_rows, max_actions, _lib.REGRET[regret], _lib.WEIGHT[weight], C.byref(hp),
+                                      dr.ctypes.data if dr is not None else None)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.o.ora_profile_destroy(self.h)
+            self.h = None
+
+    @staticmethod
+    def _arrays(batch):
+        row, nact, expanded, regret, policy, payoff = batch
+        return (np.ascontiguousarray(row, dtype=np.uint32), np.ascontiguousarray(nact, dtype=np.uint8),
+                np.ascontiguousarray(expanded, dtype=np.uint16), np.ascontiguousarray(regret, dtype=np.float32),
+                np.ascontiguousarray(policy, dtype=np.float32), np.ascontiguousarray(payoff, dtype=np.float32))
+
+    def apply(self, batch):
+        a = self._arrays(batch)
+        self.o.ora_profile_apply(self.h, len(a[0]), *[x.ctypes.data for x in a])
+
+    def summarize(self, batch) -> np.ndarray:
+        a = self._arrays(batch)
+        eb = self.o.ora_profile_entry_bytes(self.h)
+        blob = np.zeros(max(len(a[0]), 1) * eb, dtype=np.uint8)
+        n = self.o.ora_profile_summarize(self.h, len(a[0]), *[x.ctypes.data for x in a], blob.ctypes.data)
+        if n < 0:
+            raise ValueError("composed update unsupported for this schedule")
+        return blob[: n * eb].copy()
+
+    def fold(self, blob: np.ndarray):
+        eb = self.o.ora_profile_entry_bytes(self.h)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self.o.ora_profile_fold(self.h, blob.ctypes.data, blob.size // eb)
+
+    def entry_bytes(self) -> int:
+        return self.o.ora_profile_entry_bytes(self.h)
+
+    def set_epoch(self, e: int):
+        self.o.ora_profile_set_epoch(self.h, e)
+
+    def epoch(self) -> int:
+        return self.o.ora_mccfr_epoch(self.h)
+
+    def rows(self, rows) -> np.ndarray:
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        out = np.zeros((rows.size, self.A), dtype=[("weight", "<f4"), ("regret", "<f4"), ("payoff", "<f4"), ("visits", "<u4")])
+        for i, r in enumerate(rows):
+            self.o.ora_profile_get(self.h, int(r), out[i].ctypes.data)
+        return out
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 

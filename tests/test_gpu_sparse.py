@@ -1,0 +1,107 @@
+"""Sparse profile (rp_profile_*) on the GPU vs the CPU oracle (ora_profile_*): bit-exact tables and summary entries."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from robopoker_amd import _lib
+from robopoker_amd.sparse import DeviceBatch, SparseProfile, synthetic_batch
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("weight", "regret", "payoff", "visits")
+
+
+def same(a, b):
+    for f in FIELDS:
+        assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), f"{f}: {np.count_nonzero(a[f].view(np.uint32) != b[f].view(np.uint32))} cells differ"
+
+
+@pytest.mark.parametrize("regret,weight", [("linear", "linear"), ("floored", "linear"), ("summed", "constant"),
+                                           ("discounted", "quadratic"), ("asymmetric", "exponential")])
+def test_ordered_apply_bit_exact(gpu, regret, weight):
+    n_rows, A = 500, 9  # few rows: the popular ones collect thousands of touches per batch
+    dr = np.array([100, 10, 0, 50, 0, 0, 0, 0, 0], dtype=np.float32)  # NLHE-style bias (kicker/src/edge.rs:61-72)
+    g = SparseProfile(n_rows, A, regret, weight, default_regret=dr)
+    o = oracle.OracleProfile(n_rows, A, regret, weight, default_regret=dr)
+    for e in range(5):
+        batch = synthetic_batch(20000, n_rows, A, seed=100 + e)
+        g.apply(DeviceBatch(*batch), "ordered")
+        o.apply(batch)
+    g.sync()
+    assert g.epoch() == o.epoch() == 5
+    same(g.rows(np.arange(n_rows)), o.rows(np.arange(n_rows)))
+
+
+@pytest.mark.parametrize("regret,weight,A", [("linear", "linear", 9), ("floored", "quadratic", 16), ("summed", "exponential", 2)])
+def test_composed_apply_and_entries_bit_exact(gpu, regret, weight, A):
+    n_rows = 300
+    g = SparseProfile(n_rows, A, regret, weight)
+    o = oracle.OracleProfile(n_rows, A, regret, weight)
+    assert g.entry_bytes() == o.entry_bytes() == 16 + 32 * A
+    for e in range(4):
+        batch = synthetic_batch(15000, n_rows, A, seed=7 + e)
+        db = DeviceBatch(*batch)
+        # entries first (same epoch), then the local composed apply
+        buf = torch.zeros(db.n * g.entry_bytes(), dtype=torch.uint8, device="cuda")
+        n = g.summarize(db, buf.data_ptr())
+        exp = o.summarize(batch)
+        assert n * g.entry_bytes() == exp.size
+        assert np.array_equal(buf[: exp.size].cpu().numpy(), exp), "summary entries differ"
+        g.apply(db, "composed")
+        o.fold(exp)
+    g.sync()
+    assert g.epoch() == o.epoch() == 4
+    same(g.rows(np.arange(n_rows)), o.rows(np.arange(n_rows)))
+
+
+def test_fold_of_several_ranks_in_rank_order_bit_exact(gpu):
+    n_rows, A, world = 400, 7, 3
+    g = SparseProfile(n_rows, A, "linear", "linear")
+    o = oracle.OracleProfile(n_rows, A, "linear", "linear")
+    for e in range(3):
+        blobs = []
+        for r in range(world):
+            batch = synthetic_batch(6000, n_rows, A, seed=1000 * e + r)
+            blobs.append(o.summarize(batch))
+            db = DeviceBatch(*batch)
+            buf = torch.zeros(db.n * g.entry_bytes(), dtype=torch.uint8, device="cuda")
+            n = g.summarize(db, buf.data_ptr())
+            assert np.array_equal(buf[: n * g.entry_bytes()].cpu().numpy(), blobs[-1])
+        allb = np.concatenate(blobs)
+        dev = torch.from_numpy(allb).cuda()
+        g.fold(dev.data_ptr(), allb.size // g.entry_bytes())
+        o.fold(allb)
+    g.sync()
+    assert g.epoch() == o.epoch() == 3
+    same(g.rows(np.arange(n_rows)), o.rows(np.arange(n_rows)))
+
+
+def test_edges_empty_batch_single_row_and_large_table(gpu):
+    g = SparseProfile(1 << 22, 4, "floored", "linear")  # 4M rows x 64 B
+    o = oracle.OracleProfile(1 << 22, 4, "floored", "linear")
+    empty = tuple(x[:0] for x in synthetic_batch(8, 1 << 22, 4))
+    g.apply(DeviceBatch(*empty), "ordered")
+    o.apply(empty)
+    one = synthetic_batch(3000, 1 << 22, 4, seed=5)
+    one = (np.full_like(one[0], 4194303),) + (np.full_like(one[1], 3),) + one[2:]
+    one = (one[0], one[1], (one[2] & 7).astype(np.uint16) | 1, one[3], one[4], one[5])
+    g.apply(DeviceBatch(*one), "ordered")
+    o.apply(one)
+    wide = synthetic_batch(50000, 1 << 22, 4, seed=6)
+    g.apply(DeviceBatch(*wide), "composed")
+    o.fold(o.summarize(wide))
+    g.sync()
+    rows = np.unique(np.concatenate([wide[0], [4194303, 0, 17]]))
+    same(g.rows(rows), o.rows(rows))
+    assert g.epoch() == o.epoch() == 3
+
+
+def test_composed_rejects_sign_dependent_discount_and_bad_arguments(gpu):
+    g = SparseProfile(64, 4, "discounted", "linear")
+    with pytest.raises(_lib.RpError) as e:
+        g.apply(DeviceBatch(*synthetic_batch(10, 64, 4)), "composed")
+    assert e.value.code == _lib.RP_ERR_UNSUPPORTED
+    with pytest.raises(_lib.RpError):
+        SparseProfile(64, 17)
+    with pytest.raises(_lib.RpError):
+        g.rows([64])
