@@ -21,6 +21,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -34,6 +36,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1 << 18, help="trees per step per GPU (Solver::batch_size)")
+    ap.add_argument("--workload", default="leduc", choices=["leduc", "nlhe-synth"],
+                    help="leduc: BASELINE configs[1] (default, the quoted metric); nlhe-synth: configs[3]'s synthetic "
+                         "NLHE-scale infoset batches through the sparse profile (SURVEY.md §8d config 4)")
+    ap.add_argument("--rows", type=int, default=1 << 27, help="nlhe-synth: table rows (infoset slots)")
+    ap.add_argument("--decisions", type=int, default=128 * 1500, help="nlhe-synth: Decisions per step per GPU")
     ap.add_argument("--game", default="leduc", choices=["leduc", "kuhn", "rps"])
     ap.add_argument("--regret", default="floored")
     ap.add_argument("--weight", default="linear")
@@ -136,6 +143,101 @@ def kmeans_secondary(args):
     return out
 
 
+def nlhe_synth(args, rank, world, local_rank):
+    """2^27-row table (A <= 9), 128 x 1500 Zipf(1.1)-popular Decisions per step per GPU,
+    LinearRegret / LinearWeight, exchanged every step.  One step = one Solver::step worth of updates."""
+    import torch
+    import torch.distributed as dist
+
+    from robopoker_amd.sparse import DeviceBatch, SparseProfile, synthetic_batch
+
+    torch.cuda.set_device(local_rank)
+    sharded = world > 1 or args.force_sharded
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    A = 9
+    prof = SparseProfile(args.rows, A, "linear", "linear", max_batch=args.decisions * (world if sharded else 1), device=local_rank)
+    host = [synthetic_batch(args.decisions, args.rows, A, seed=args.seed + 17 * rank + k) for k in range(4)]
+    batches = [DeviceBatch(*b, device=local_rank) for b in host]
+    algo_bytes = sum(int((24 + 32 * b[1].astype(np.int64)).sum()) for b in host) / len(host)
+    if sharded:
+        from robopoker_amd.parallel import ShardedProfile
+
+        sh = ShardedProfile(prof, max_batch=args.decisions, device="cuda")
+        step = lambda k: sh.step(batches[k % 4])  # noqa: E731
+    else:
+        step = lambda k: prof.apply(batches[k % 4], args.update)  # noqa: E731
+
+    def fence():
+        torch.cuda.synchronize()
+        prof.sync()
+        if sharded:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    prof.profile(True)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    fence()
+    dt = time.perf_counter() - t0
+    sort_ms, sort_n = prof.kernel_time("sort")
+    app_ms, app_n = prof.kernel_time("apply")
+    prof.profile(False)
+    if sharded:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        app_avg = app_ms / max(app_n, 1)
+        achieved = algo_bytes / (app_avg * 1e-3) / 1e9 if app_avg > 0 else 0.0
+        line = {
+            "metric": "mccfr_infoset_updates_per_sec", "value": args.decisions * world * args.steps / dt,
+            "unit": "infoset-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "NLHE-scale synthetic infoset batches through the sparse profile (SURVEY §8d config 4; "
+                                   "BASELINE configs[3] without the game engine)",
+                       "rows": args.rows, "max_actions": A, "decisions_per_gpu": args.decisions, "row_popularity": "zipf(1.1)",
+                       "regret": "linear", "weight": "linear",
+                       "update": ("composed+allgather" if sharded else args.update), "parallelism": f"batch-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "apply", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
+                         "avg_launch_ms": app_avg, "kernels_ms": {"sort": sort_ms / max(sort_n, 1), "apply": app_avg},
+                         "note": "24 + 32*|choices| bytes per update (SURVEY §8d); the hottest row of a Zipf(1.1) batch "
+                                 "receives ~12 % of the touches and is one sequential chain in the ordered mode"},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            import oracle
+
+            rows_cpu = min(args.rows, 1 << 22)  # the CPU port allocates the table densely
+            o = oracle.OracleProfile(rows_cpu, A, "linear", "linear")
+            b = tuple([host[0][0] % rows_cpu] + list(host[0][1:]))
+            nact = (2 + (b[0].astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) >> np.uint64(40)) % np.uint64(A - 1)).astype(np.uint8)
+            b = (b[0], nact, ((1 << nact.astype(np.uint32)) - 1).astype(np.uint16)) + b[3:]
+            t0 = time.perf_counter()
+            done = 0
+            while time.perf_counter() - t0 < args.cpu_seconds:
+                o.apply(b)
+                done += len(b[0])
+            dtc = time.perf_counter() - t0
+            line["cpu_baseline"] = {"value": done / dtc, "unit": "infoset-updates/s", "cores": 1, "kind": "port",
+                                    "sample": f"oracle ora_profile_apply, the same batch on a {rows_cpu}-row table, {done} updates "
+                                              f"in {dtc:.1f} s on 1 host thread"}
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    prof.close()
+    if sharded:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -145,6 +247,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
+    if args.workload == "nlhe-synth":
+        return nlhe_synth(args, rank, world, local_rank)
 
     from robopoker_amd import Game
     from robopoker_amd.mccfr import Solver

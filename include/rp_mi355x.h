@@ -233,7 +233,7 @@ RP_API int rp_mccfr_kernel_time(rp_mccfr* h, const char* name, double* total_ms,
  *             folded in block order (hot rows parallelise); the multi-GPU exchange uses the same entries:
  *             summarize -> all-gather -> fold in rank order.
  */
-#define RP_SPARSE_BLOCK 256u
+#define RP_SPARSE_BLOCK 64u
 typedef struct rp_profile rp_profile;
 typedef struct rp_decisions { /* one batch of Decisions in DEVICE memory, in application (tree-id) order */
     uint32_t n;

@@ -26,6 +26,7 @@ namespace rp {
     } while (0)
 
 #define GROUP 16u  // lanes per row (max_actions <= 16)
+#define PF 8       // touches fetched ahead of the sequential chain
 
 struct SparseParams {
     float* tab;           // [n_rows][4A]
@@ -74,13 +75,28 @@ __global__ __launch_bounds__(256) void k_apply_ordered(SparseParams p, DevBatch 
             ev = row[2 * A + a];
             v = reinterpret_cast<const uint32_t*>(row)[3 * A + a];
         }
-        for (uint32_t t = 0; t < cnt; ++t) {
-            const uint32_t idx = sg.perm[off + t];
+        // the gathers of a touch do not depend on the chain: fetch PF touches ahead of it, apply them in order
+        for (uint32_t t0 = 0; t0 < cnt; t0 += PF) {
+            const uint32_t m = min((uint32_t)PF, cnt - t0);
+            float dv[PF], sv[PF], pv[PF];
+            uint32_t ev_mask = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < PF; ++u) {
+                const uint32_t idx = sg.perm[off + t0 + (u < m ? u : 0u)];
+                dv[u] = mine ? b.regret[(size_t)idx * A + a] : 0.0f;
+                sv[u] = mine ? b.policy[(size_t)idx * A + a] : 0.0f;
+                pv[u] = b.payoff[idx];
+                ev_mask |= ((b.expanded[idx] >> a) & 1u) << u;
+            }
             if (!mine) continue;
-            if ((b.expanded[idx] >> a) & 1u) r = d_regret_gain(p.R, r, b.regret[(size_t)idx * A + a], p.tf, p.floor_r);
-            w = d_weight_learn(p.W, w, b.policy[(size_t)idx * A + a], p.tf);
-            ev += (b.payoff[idx] - ev) / (float)(v + 1u);
-            v += 1u;
+#pragma unroll
+            for (uint32_t u = 0; u < PF; ++u) {
+                if (u >= m) break;
+                if ((ev_mask >> u) & 1u) r = d_regret_gain(p.R, r, dv[u], p.tf, p.floor_r);
+                w = d_weight_learn(p.W, w, sv[u], p.tf);
+                ev += (pv[u] - ev) / (float)(v + 1u);
+                v += 1u;
+            }
         }
         if (mine) {
             row[a] = r;
@@ -98,49 +114,128 @@ __device__ __forceinline__ float composed_wdelta(int W, float sigma, float tf) {
 }
 
 // COMPOSED, first half: a row's touches -> one entry (oracle: ora_profile_summarize).  Blocks of RP_SPARSE_BLOCK
-// consecutive touches are composed sequentially, block maps folded in block order.
-// entry = [row][count][psum][n_actions][A regret maps][A weight maps]
-__global__ __launch_bounds__(256) void k_summarize(SparseParams p, DevBatch b, Segments sg, unsigned char* entries,
-                                                   uint32_t entry_bytes) {
+// consecutive touches are composed sequentially — every (row, block) pair by its own 16-lane group, so a hot row's
+// thousands of touches spread over the chip — and the block records of a row are folded in block order.
+// entry = [row][count][psum][n_actions][A regret maps][A weight maps]; a block record has the same layout.
+__global__ void k_block_counts(const uint32_t* counts, const uint32_t* n_segs, uint32_t n, uint32_t* nblk) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) nblk[g] = g < *n_segs ? (counts[g] + RP_SPARSE_BLOCK - 1u) / RP_SPARSE_BLOCK : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_block_maps_sparse(SparseParams p, DevBatch b, Segments sg, const uint32_t* nblk,
+                                                           const uint32_t* boff, unsigned char* entries,
+                                                           unsigned char* blocks, uint32_t entry_bytes, uint32_t max_blocks) {
+    const uint32_t n_segs = *sg.n_segs;
+    if (n_segs == 0) return;
+    const uint32_t total = boff[n_segs - 1] + nblk[n_segs - 1];
+    const uint32_t a = threadIdx.x % GROUP;
+    const uint32_t A = p.A;
+    const float NEG_INF = rp_u2f(0xff800000u);
+    const Map ident{1.0f, 0.0f, NEG_INF, 0u};
+    for (uint32_t bi = (blockIdx.x * blockDim.x + threadIdx.x) / GROUP; bi < total && bi < max_blocks;
+         bi += gridDim.x * blockDim.x / GROUP) {
+        // segment of block bi: last g with boff[g] <= bi
+        uint32_t lo = 0, hi = n_segs - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1u) >> 1;
+            if (boff[mid] <= bi) lo = mid; else hi = mid - 1u;
+        }
+        const uint32_t g = lo, blk = bi - boff[g];
+        const uint32_t cnt = sg.counts[g];
+        const uint32_t t_lo = blk * RP_SPARSE_BLOCK, t_hi = min(cnt, t_lo + RP_SPARSE_BLOCK);
+        const uint32_t off = sg.offsets[g];
+        const uint32_t nact = b.nact[sg.perm[off]];
+        const bool mine = a < nact;
+        Map br = ident, bw = ident;
+        float bp = 0.0f;
+        for (uint32_t t0 = t_lo; t0 < t_hi; t0 += PF) {
+            const uint32_t m = min((uint32_t)PF, t_hi - t0);
+            float dv[PF], sv[PF], pv[PF];
+            uint32_t ev_mask = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < PF; ++u) {
+                const uint32_t idx = sg.perm[off + t0 + (u < m ? u : 0u)];
+                dv[u] = mine ? b.regret[(size_t)idx * A + a] : 0.0f;
+                sv[u] = mine ? b.policy[(size_t)idx * A + a] : 0.0f;
+                pv[u] = b.payoff[idx];
+                ev_mask |= ((b.expanded[idx] >> a) & 1u) << u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < PF; ++u) {
+                if (u >= m) break;
+                if (mine) {
+                    if ((ev_mask >> u) & 1u) map_touch(br, p.dr, dv[u], p.floor_r);
+                    map_touch(bw, p.dw, composed_wdelta(p.W, sv[u], p.tf), RP_EPSILON);
+                }
+                bp += pv[u];
+            }
+        }
+        // a row with a single block is final: tot = compose(identity, block) = block, psum = 0 + bp
+        const bool single = nblk[g] == 1u;
+        unsigned char* ent = single ? entries + (size_t)g * entry_bytes : blocks + (size_t)bi * entry_bytes;
+        if (a == 0) {
+            uint32_t* hdr = reinterpret_cast<uint32_t*>(ent);
+            hdr[0] = sg.rows[g];
+            hdr[1] = single ? cnt : t_hi - t_lo;
+            hdr[2] = rp_f2u(single ? 0.0f + bp : bp);
+            hdr[3] = nact;
+        }
+        if (a < A) {
+            Map* mr = reinterpret_cast<Map*>(ent + 16);
+            mr[a] = mine ? br : ident;
+            mr[A + a] = mine ? bw : ident;
+        }
+    }
+}
+
+// rows with several blocks: fold the block records in block order into the entry
+__global__ __launch_bounds__(256) void k_seg_fold(SparseParams p, Segments sg, const uint32_t* nblk, const uint32_t* boff,
+                                                  unsigned char* entries, const unsigned char* blocks, uint32_t entry_bytes) {
     const uint32_t n_segs = *sg.n_segs;
     const uint32_t a = threadIdx.x % GROUP;
     const uint32_t A = p.A;
     const float NEG_INF = rp_u2f(0xff800000u);
     const Map ident{1.0f, 0.0f, NEG_INF, 0u};
     for (uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / GROUP; g < n_segs; g += gridDim.x * blockDim.x / GROUP) {
-        const uint32_t off = sg.offsets[g], cnt = sg.counts[g];
-        const uint32_t nact = b.nact[sg.perm[off]];
-        const bool mine = a < nact;
-        Map tr = ident, tw = ident, br = ident, bw = ident;
-        float tp = 0.0f, bp = 0.0f;
-        for (uint32_t t = 0; t < cnt; ++t) {
-            const uint32_t idx = sg.perm[off + t];
-            if (mine) {
-                if ((b.expanded[idx] >> a) & 1u) map_touch(br, p.dr, b.regret[(size_t)idx * A + a], p.floor_r);
-                map_touch(bw, p.dw, composed_wdelta(p.W, b.policy[(size_t)idx * A + a], p.tf), RP_EPSILON);
+        const uint32_t nb = nblk[g];
+        if (nb <= 1u) continue;
+        Map tr = ident, tw = ident;
+        float tp = 0.0f;
+        uint32_t nact = 0;
+        const unsigned char* rec0 = blocks + (size_t)boff[g] * entry_bytes;
+        for (uint32_t k0 = 0; k0 < nb; k0 += PF) {  // records are fetched PF at a time, folded in order
+            const uint32_t m = min((uint32_t)PF, nb - k0);
+            Map mr[PF], mw[PF];
+            float ps[PF];
+#pragma unroll
+            for (uint32_t u = 0; u < PF; ++u) {
+                const unsigned char* rec = rec0 + (size_t)(k0 + (u < m ? u : 0u)) * entry_bytes;
+                const uint32_t* hdr = reinterpret_cast<const uint32_t*>(rec);
+                nact = hdr[3];
+                ps[u] = rp_u2f(hdr[2]);
+                mr[u] = a < A ? reinterpret_cast<const Map*>(rec + 16)[a] : ident;
+                mw[u] = a < A ? reinterpret_cast<const Map*>(rec + 16)[A + a] : ident;
             }
-            bp += b.payoff[idx];
-            if ((t + 1u) % RP_SPARSE_BLOCK == 0u || t + 1u == cnt) {
-                tr = map_compose(tr, br);
-                tw = map_compose(tw, bw);
-                tp += bp;
-                br = ident;
-                bw = ident;
-                bp = 0.0f;
+#pragma unroll
+            for (uint32_t u = 0; u < PF; ++u) {
+                if (u >= m) break;
+                tr = map_compose(tr, mr[u]);
+                tw = map_compose(tw, mw[u]);
+                tp += ps[u];
             }
         }
         unsigned char* ent = entries + (size_t)g * entry_bytes;
         if (a == 0) {
             uint32_t* hdr = reinterpret_cast<uint32_t*>(ent);
             hdr[0] = sg.rows[g];
-            hdr[1] = cnt;
+            hdr[1] = sg.counts[g];
             hdr[2] = rp_f2u(tp);
             hdr[3] = nact;
         }
         if (a < A) {
             Map* mr = reinterpret_cast<Map*>(ent + 16);
-            mr[a] = mine ? tr : ident;
-            mr[A + a] = mine ? tw : ident;
+            mr[a] = tr;
+            mr[A + a] = tw;
         }
     }
 }
@@ -233,7 +328,8 @@ struct rp_profile {
     // sort / segment workspace (capacity `cap` items)
     uint32_t cap = 0;
     uint32_t *iota = nullptr, *keys_out = nullptr, *perm = nullptr, *seg_rows = nullptr, *seg_counts = nullptr,
-             *seg_offsets = nullptr, *n_segs = nullptr, *ent_rows = nullptr;
+             *seg_offsets = nullptr, *n_segs = nullptr, *ent_rows = nullptr, *nblk = nullptr, *boff = nullptr;
+    unsigned char* blocks = nullptr;   // block records of multi-block rows
     void* cub_tmp = nullptr;
     size_t cub_bytes = 0;
     unsigned char* entries = nullptr;  // local composed apply
@@ -244,6 +340,8 @@ struct rp_profile {
 namespace rp {
 
 static size_t entry_bytes_of(const rp_profile* h) { return 16 + (size_t)2 * h->A * sizeof(Map); }
+// sum over rows of ceil(count / RP_SPARSE_BLOCK) <= rows + n / RP_SPARSE_BLOCK <= n + n / RP_SPARSE_BLOCK
+static uint32_t max_blocks_of(uint32_t n) { return n + n / RP_SPARSE_BLOCK + 1u; }
 
 static void sp_begin(rp_profile* h, SpClock& c) {
     if (!h->profiling) return;
@@ -271,9 +369,11 @@ static void sp_drain(SpClock& c) {
 
 static void free_workspace(rp_profile* h) {
     for (void* p : {(void*)h->iota, (void*)h->keys_out, (void*)h->perm, (void*)h->seg_rows, (void*)h->seg_counts,
-                    (void*)h->seg_offsets, (void*)h->ent_rows, h->cub_tmp, (void*)h->entries})
+                    (void*)h->seg_offsets, (void*)h->ent_rows, (void*)h->nblk, (void*)h->boff, (void*)h->blocks, h->cub_tmp,
+                    (void*)h->entries})
         if (p) (void)hipFree(p);
-    h->iota = h->keys_out = h->perm = h->seg_rows = h->seg_counts = h->seg_offsets = h->ent_rows = nullptr;
+    h->iota = h->keys_out = h->perm = h->seg_rows = h->seg_counts = h->seg_offsets = h->ent_rows = h->nblk = h->boff = nullptr;
+    h->blocks = nullptr;
     h->cub_tmp = nullptr;
     h->entries = nullptr;
     h->cap = 0;
@@ -293,6 +393,9 @@ static int ensure_capacity(rp_profile* h, uint32_t n) {
     HIP_TRY(hipMalloc(&h->seg_offsets, (size_t)cap * 4));
     HIP_TRY(hipMalloc(&h->ent_rows, (size_t)cap * 4));
     HIP_TRY(hipMalloc(&h->entries, (size_t)cap * entry_bytes_of(h)));
+    HIP_TRY(hipMalloc(&h->nblk, (size_t)cap * 4));
+    HIP_TRY(hipMalloc(&h->boff, (size_t)cap * 4));
+    HIP_TRY(hipMalloc(&h->blocks, (size_t)max_blocks_of(cap) * entry_bytes_of(h)));
     size_t s1 = 0, s2 = 0, s3 = 0;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, s1, h->iota, h->keys_out, h->iota, h->perm, (int)cap, 0, 32, h->stream));
     HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, s2, h->keys_out, h->seg_rows, h->seg_counts, h->n_segs, (int)cap, h->stream));
@@ -359,6 +462,21 @@ static int check_batch(const rp_profile* h, const rp_decisions* b, const char* w
     return RP_OK;
 }
 static uint32_t group_blocks(uint32_t n) { return std::max(1u, std::min((n * GROUP + 255u) / 256u, 65535u)); }
+
+// segments (already built for this batch) -> entries[g] for g < n_segs
+static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch& b, const Segments& sg, uint32_t n,
+                            unsigned char* entries) {
+    const uint32_t eb = (uint32_t)entry_bytes_of(h);
+    hipLaunchKernelGGL(k_block_counts, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->seg_counts, h->n_segs, n, h->nblk);
+    size_t tmp = h->cub_bytes;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp, tmp, h->nblk, h->boff, (int)n, h->stream));
+    const uint32_t mb = max_blocks_of(n);
+    hipLaunchKernelGGL(k_block_maps_sparse, dim3(group_blocks(mb)), dim3(256), 0, h->stream, p, b, sg, h->nblk, h->boff, entries,
+                       h->blocks, eb, mb);
+    hipLaunchKernelGGL(k_seg_fold, dim3(group_blocks(n)), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb);
+    HIP_TRY(hipGetLastError());
+    return RP_OK;
+}
 
 }  // namespace rp
 
@@ -445,7 +563,7 @@ int rp_profile_apply(rp_profile* h, const rp_decisions* batch, rp_update_mode mo
             hipLaunchKernelGGL(k_apply_ordered, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, b, sg);
         } else {
             const uint32_t eb = (uint32_t)entry_bytes_of(h);
-            hipLaunchKernelGGL(k_summarize, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, b, sg, h->entries, eb);
+            if ((rc = launch_summarize(h, p, b, sg, batch->n, h->entries))) return rc;
             // a single rank's entries have distinct rows: entry g is its own segment, the count comes from n_segs
             hipLaunchKernelGGL(k_fold, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, h->entries, eb,
                                (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, h->n_segs);
@@ -530,8 +648,7 @@ int rp_profile_summarize(rp_profile* h, const rp_decisions* batch, void* entries
     sp_end(h, h->clk_sort);
     const Segments sg{h->seg_rows, h->seg_counts, h->seg_offsets, h->n_segs, h->perm};
     sp_begin(h, h->clk_apply);
-    hipLaunchKernelGGL(k_summarize, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, b, sg,
-                       reinterpret_cast<unsigned char*>(entries_dev), (uint32_t)entry_bytes_of(h));
+    if ((rc = launch_summarize(h, p, b, sg, batch->n, reinterpret_cast<unsigned char*>(entries_dev)))) return rc;
     sp_end(h, h->clk_apply);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(n_entries, h->n_segs, 4, hipMemcpyDeviceToHost, h->stream));

@@ -174,3 +174,46 @@ class ShardedLayer:
             dist.all_reduce(self.buf[: self.words32 * 4].view(torch.int32), op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(self.buf[self.off64:].view(torch.int64), op=dist.ReduceOp.SUM, group=self.group)
             return self.engine.step_finish(self.buf.data_ptr())
+
+
+class ShardedProfile:
+    """Batch-sharded sparse profile (rp_profile_*): every rank holds a replica of the table and summarises ITS
+    Decisions into per-row composed entries; the entry lists are all-gathered (padded to the longest list) and every
+    rank folds the same rank-major list, so replicas stay bit-identical.  SURVEY.md §8e: the sparse variant of the
+    periodic regret/strategy exchange — traffic is proportional to the rows touched, not to the table size.
+
+    ``engine`` has ``entry_bytes / summarize / fold`` (robopoker_amd.sparse.SparseProfile on a GPU; the oracle in the
+    gloo tests); ``make_buffer(nbytes)`` returns a uint8 torch tensor on the engine's device."""
+
+    def __init__(self, engine, max_batch: int, device="cpu", group=None):
+        self.engine = engine
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = device
+        self.eb = engine.entry_bytes()
+        self.scope = _StreamScope(engine, device)
+        self.mine = torch.zeros(max_batch * self.eb, dtype=torch.uint8, device=device)
+        self.all = torch.zeros(self.world * max_batch * self.eb, dtype=torch.uint8, device=device)
+        self.packed = torch.zeros(self.world * max_batch * self.eb, dtype=torch.uint8, device=device)
+
+    def step(self, batch):
+        with self.scope:
+            n = self.engine.summarize(batch, self.mine.data_ptr())
+            counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+            mine_n = torch.tensor([n], dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(counts, mine_n, group=self.group)
+            counts = [int(c) for c in counts.cpu().tolist()]
+            width = max(counts) * self.eb  # every rank sends the same number of bytes
+            if width == 0:
+                self.engine.fold(self.packed.data_ptr(), 0)
+                return 0
+            _all_gather_bytes(self.all[: self.world * width], self.mine[:width], self.group)
+            # compact the padded lists into one rank-major list
+            off = 0
+            for r, c in enumerate(counts):
+                self.packed[off: off + c * self.eb] = self.all[r * width: r * width + c * self.eb]
+                off += c * self.eb
+            total = sum(counts)
+            self.engine.fold(self.packed.data_ptr(), total)
+            return total

@@ -279,6 +279,22 @@ class OracleProfile:
         return out
 
 
+class OracleProfileEngine(OracleProfile):
+    """OracleProfile behind the pointer-based sharded surface of the C-ABI (summarize / fold on raw host pointers)."""
+
+    def set_stream(self, ptr):
+        pass
+
+    def summarize(self, batch, ptr: int) -> int:
+        blob = OracleProfile.summarize(self, batch)
+        C.memmove(ptr, blob.ctypes.data, blob.size)
+        return blob.size // self.entry_bytes()
+
+    def fold(self, ptr: int, n: int):
+        blob = np.ctypeslib.as_array((C.c_uint8 * max(n * self.entry_bytes(), 1)).from_address(ptr))[: n * self.entry_bytes()]
+        OracleProfile.fold(self, blob.copy())
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 

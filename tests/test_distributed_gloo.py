@@ -17,7 +17,8 @@ import torch.multiprocessing as mp
 import oracle
 from lloyd_fixtures import smooth_metric, turn_like_points
 from robopoker_amd import Game
-from robopoker_amd.parallel import ShardedLayer, ShardedSolver, rp_mulhi64, rp_stream
+from robopoker_amd.parallel import ShardedLayer, ShardedProfile, ShardedSolver, rp_mulhi64, rp_stream
+from robopoker_amd.sparse import synthetic_batch
 
 WORLD = 2
 
@@ -108,6 +109,33 @@ def _kmeans_worker(rank, port, out, kind):
     dist.destroy_process_group()
 
 
+def _profile_worker(rank, port, out):
+    _init(rank, port)
+    n_rows, A, steps = 300, 9, 4
+    eng = oracle.OracleProfileEngine(n_rows, A, "linear", "linear")
+    sh = ShardedProfile(eng, max_batch=4000, device="cpu")
+    for e in range(steps):
+        n = 4000 if rank == 0 else 2500 + 100 * e  # ragged shards: the gather is padded to the longest list
+        sh.step(synthetic_batch(n, n_rows, A, seed=10 * e + rank))
+    rows = eng.rows(np.arange(n_rows))
+    t = torch.from_numpy(rows["regret"].view(np.int32).copy())
+    ref = t.clone()
+    dist.broadcast(ref, src=0)
+    same = bool(torch.equal(t, ref))
+    if rank == 0:
+        single = oracle.OracleProfile(n_rows, A, "linear", "linear")
+        for e in range(steps):
+            blobs = [single.summarize(synthetic_batch(4000 if r == 0 else 2500 + 100 * e, n_rows, A, seed=10 * e + r))
+                     for r in range(WORLD)]
+            single.fold(np.concatenate(blobs))
+        exp = single.rows(np.arange(n_rows))
+        ok = all(np.array_equal(rows[f].view(np.uint32), exp[f].view(np.uint32)) for f in ("regret", "weight", "payoff", "visits"))
+        out.put(("profile", same and ok and eng.epoch() == steps))
+    else:
+        out.put(("profile-replica", same))
+    dist.destroy_process_group()
+
+
 def _run(fn, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -142,3 +170,8 @@ def test_sharded_mccfr_two_ranks_equals_world_model():
 def test_sharded_kmeans_two_ranks_equals_single_process(kind):
     res = _run(_kmeans_worker, kind)
     assert res[f"kmeans-{kind}"] is True
+
+
+def test_sharded_sparse_profile_two_ranks_equals_world_model():
+    res = _run(_profile_worker)
+    assert res == {"profile": True, "profile-replica": True}
