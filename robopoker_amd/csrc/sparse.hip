@@ -57,8 +57,44 @@ __global__ void k_iota(uint32_t* p, uint32_t n) {
     if (i < n) p[i] = i;
 }
 
+// the batch in sorted (row, position) order: the chains below then stream their inputs instead of chasing `perm`
+struct SortedBatch {
+    float* regret;       // [n][A]
+    float* policy;       // [n][A]
+    float* payoff;       // [n]
+    uint16_t* expanded;  // [n]
+};
+__global__ void k_permute(DevBatch b, const uint32_t* perm, uint32_t n, uint32_t A, SortedBatch o) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)n * A) return;
+    const uint32_t t = (uint32_t)(e / A), a = (uint32_t)(e % A);
+    const uint32_t idx = perm[t];
+    o.regret[e] = b.regret[(size_t)idx * A + a];
+    o.policy[e] = b.policy[(size_t)idx * A + a];
+    if (a == 0) {
+        o.payoff[t] = b.payoff[idx];
+        o.expanded[t] = b.expanded[idx];
+    }
+}
+
 // ORDERED: Solver::update_* per touch, in batch order (solver.rs:143-192)
-__global__ __launch_bounds__(256) void k_apply_ordered(SparseParams p, DevBatch b, Segments sg) {
+struct TouchChunk {
+    float dv[PF], sv[PF], pv[PF];
+    uint32_t ev_mask;
+};
+__device__ __forceinline__ void fetch_chunk(TouchChunk& c, const SortedBatch& sb, uint32_t base, uint32_t m, uint32_t A,
+                                            uint32_t a, bool mine) {
+    c.ev_mask = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < PF; ++u) {
+        const uint32_t t = base + (u < m ? u : 0u);
+        c.dv[u] = mine ? sb.regret[(size_t)t * A + a] : 0.0f;
+        c.sv[u] = mine ? sb.policy[(size_t)t * A + a] : 0.0f;
+        c.pv[u] = sb.payoff[t];
+        c.ev_mask |= (((uint32_t)sb.expanded[t] >> a) & 1u) << u;
+    }
+}
+__global__ __launch_bounds__(256) void k_apply_ordered(SparseParams p, DevBatch b, Segments sg, SortedBatch sb) {
     const uint32_t n_segs = *sg.n_segs;
     const uint32_t a = threadIdx.x % GROUP;
     const uint32_t A = p.A;
@@ -75,28 +111,23 @@ __global__ __launch_bounds__(256) void k_apply_ordered(SparseParams p, DevBatch 
             ev = row[2 * A + a];
             v = reinterpret_cast<const uint32_t*>(row)[3 * A + a];
         }
-        // the gathers of a touch do not depend on the chain: fetch PF touches ahead of it, apply them in order
+        // the inputs of a touch do not depend on the chain: chunk k+1 is in flight while chunk k is applied
+        TouchChunk cur, nxt;
+        fetch_chunk(cur, sb, off, min((uint32_t)PF, cnt), A, a, mine);
         for (uint32_t t0 = 0; t0 < cnt; t0 += PF) {
             const uint32_t m = min((uint32_t)PF, cnt - t0);
-            float dv[PF], sv[PF], pv[PF];
-            uint32_t ev_mask = 0;
+            if (t0 + PF < cnt) fetch_chunk(nxt, sb, off + t0 + PF, min((uint32_t)PF, cnt - t0 - PF), A, a, mine);
+            if (mine) {
 #pragma unroll
-            for (uint32_t u = 0; u < PF; ++u) {
-                const uint32_t idx = sg.perm[off + t0 + (u < m ? u : 0u)];
-                dv[u] = mine ? b.regret[(size_t)idx * A + a] : 0.0f;
-                sv[u] = mine ? b.policy[(size_t)idx * A + a] : 0.0f;
-                pv[u] = b.payoff[idx];
-                ev_mask |= ((b.expanded[idx] >> a) & 1u) << u;
+                for (uint32_t u = 0; u < PF; ++u) {
+                    if (u >= m) break;
+                    if ((cur.ev_mask >> u) & 1u) r = d_regret_gain(p.R, r, cur.dv[u], p.tf, p.floor_r);
+                    w = d_weight_learn(p.W, w, cur.sv[u], p.tf);
+                    ev += (cur.pv[u] - ev) / (float)(v + 1u);
+                    v += 1u;
+                }
             }
-            if (!mine) continue;
-#pragma unroll
-            for (uint32_t u = 0; u < PF; ++u) {
-                if (u >= m) break;
-                if ((ev_mask >> u) & 1u) r = d_regret_gain(p.R, r, dv[u], p.tf, p.floor_r);
-                w = d_weight_learn(p.W, w, sv[u], p.tf);
-                ev += (pv[u] - ev) / (float)(v + 1u);
-                v += 1u;
-            }
+            cur = nxt;
         }
         if (mine) {
             row[a] = r;
@@ -330,6 +361,8 @@ struct rp_profile {
     uint32_t *iota = nullptr, *keys_out = nullptr, *perm = nullptr, *seg_rows = nullptr, *seg_counts = nullptr,
              *seg_offsets = nullptr, *n_segs = nullptr, *ent_rows = nullptr, *nblk = nullptr, *boff = nullptr;
     unsigned char* blocks = nullptr;   // block records of multi-block rows
+    float *srt_regret = nullptr, *srt_policy = nullptr, *srt_payoff = nullptr;  // the batch in sorted order (ordered mode)
+    uint16_t* srt_expanded = nullptr;
     void* cub_tmp = nullptr;
     size_t cub_bytes = 0;
     unsigned char* entries = nullptr;  // local composed apply
@@ -370,10 +403,13 @@ static void sp_drain(SpClock& c) {
 static void free_workspace(rp_profile* h) {
     for (void* p : {(void*)h->iota, (void*)h->keys_out, (void*)h->perm, (void*)h->seg_rows, (void*)h->seg_counts,
                     (void*)h->seg_offsets, (void*)h->ent_rows, (void*)h->nblk, (void*)h->boff, (void*)h->blocks, h->cub_tmp,
-                    (void*)h->entries})
+                    (void*)h->entries, (void*)h->srt_regret, (void*)h->srt_policy, (void*)h->srt_payoff,
+                    (void*)h->srt_expanded})
         if (p) (void)hipFree(p);
     h->iota = h->keys_out = h->perm = h->seg_rows = h->seg_counts = h->seg_offsets = h->ent_rows = h->nblk = h->boff = nullptr;
     h->blocks = nullptr;
+    h->srt_regret = h->srt_policy = h->srt_payoff = nullptr;
+    h->srt_expanded = nullptr;
     h->cub_tmp = nullptr;
     h->entries = nullptr;
     h->cap = 0;
@@ -393,6 +429,10 @@ static int ensure_capacity(rp_profile* h, uint32_t n) {
     HIP_TRY(hipMalloc(&h->seg_offsets, (size_t)cap * 4));
     HIP_TRY(hipMalloc(&h->ent_rows, (size_t)cap * 4));
     HIP_TRY(hipMalloc(&h->entries, (size_t)cap * entry_bytes_of(h)));
+    HIP_TRY(hipMalloc(&h->srt_regret, (size_t)cap * h->A * 4));
+    HIP_TRY(hipMalloc(&h->srt_policy, (size_t)cap * h->A * 4));
+    HIP_TRY(hipMalloc(&h->srt_payoff, (size_t)cap * 4));
+    HIP_TRY(hipMalloc(&h->srt_expanded, (size_t)cap * 2));
     HIP_TRY(hipMalloc(&h->nblk, (size_t)cap * 4));
     HIP_TRY(hipMalloc(&h->boff, (size_t)cap * 4));
     HIP_TRY(hipMalloc(&h->blocks, (size_t)max_blocks_of(cap) * entry_bytes_of(h)));
@@ -560,7 +600,10 @@ int rp_profile_apply(rp_profile* h, const rp_decisions* batch, rp_update_mode mo
         const Segments sg{h->seg_rows, h->seg_counts, h->seg_offsets, h->n_segs, h->perm};
         sp_begin(h, h->clk_apply);
         if (mode == RP_UPDATE_ORDERED) {
-            hipLaunchKernelGGL(k_apply_ordered, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, b, sg);
+            const SortedBatch sb{h->srt_regret, h->srt_policy, h->srt_payoff, h->srt_expanded};
+            hipLaunchKernelGGL(k_permute, dim3((unsigned)(((uint64_t)batch->n * h->A + 255) / 256)), dim3(256), 0, h->stream, b,
+                               h->perm, batch->n, h->A, sb);
+            hipLaunchKernelGGL(k_apply_ordered, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, b, sg, sb);
         } else {
             const uint32_t eb = (uint32_t)entry_bytes_of(h);
             if ((rc = launch_summarize(h, p, b, sg, batch->n, h->entries))) return rc;
