@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1 << 18, help="trees per step per GPU (Solver::batch_size)")
+    ap.add_argument("--batch", type=int, default=1 << 20, help="trees per step per GPU (Solver::batch_size)")
     ap.add_argument("--workload", default="leduc", choices=["leduc", "nlhe-synth"],
                     help="leduc: BASELINE configs[1] (default, the quoted metric); nlhe-synth: configs[3]'s synthetic "
                          "NLHE-scale infoset batches through the sparse profile (SURVEY.md §8d config 4)")

@@ -15,5 +15,11 @@ grep -o '{"metric.*' $OUT/kt.log > $OUT/${TAG}_bench_line_under_rocprof.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o pmc -- $BENCH > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o pmc -- $BENCH > $OUT/write.log 2>&1
 python $REPO/scripts/pmc_traffic.py $OUT/fetch/pmc_counter_collection.csv $OUT/write/pmc_counter_collection.csv \
-    $OUT/${TAG}_mccfr_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of: $BENCH; FETCH_SIZE doubled (gfx950), KiB -> bytes" 262144 composed
+    $OUT/${TAG}_mccfr_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of: $BENCH; FETCH_SIZE doubled (gfx950), KiB -> bytes" 1048576 composed
+# the other two kernel families: k-means (flop-layer slice) and the sparse profile
+rocprofv3 --kernel-trace --stats -d $OUT/kl -o kl -- python $REPO/scripts/quick_lloyd.py 8192 > $OUT/kl.log 2>&1
+python $REPO/scripts/rocpd_summary.py $(ls $OUT/kl/*.db | head -1) $OUT/${TAG}_lloyd_kernel_stats.txt "python scripts/quick_lloyd.py 8192 (flop-layer slice: N=8192, K=256, bins=256, init_bounds + 2 Elkan iterations)" > /dev/null
+SP="python $REPO/bench.py --workload nlhe-synth --cpu-seconds 0 --steps 20 --warmup 3"
+rocprofv3 --kernel-trace --stats -d $OUT/ks -o ks -- $SP > $OUT/ks.log 2>&1
+python $REPO/scripts/rocpd_summary.py $(ls $OUT/ks/*.db | head -1) $OUT/${TAG}_sparse_kernel_stats.txt "$SP" > /dev/null
 cat $OUT/${TAG}_bench_kernel_stats.txt

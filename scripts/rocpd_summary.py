@@ -13,6 +13,7 @@ def main():
         f.write(f"# {title}\n# rocprofv3 --kernel-trace --stats (durations in microseconds)\n")
         f.write(f"{'calls':>8} {'total_us':>14} {'avg_us':>12} {'pct':>7}  kernel\n")
         for name, calls, total, avg, pct in rows:
+            name = name if len(name) <= 200 else name[:197] + "..."  # rocPRIM template names run to kilobytes
             f.write(f"{calls:>8} {total:>14.3f} {avg:>12.3f} {pct:>7.2f}  {name}\n")
     print(open(out).read())
 
