@@ -73,3 +73,27 @@ def test_infoset_names_follow_reference_display():
     l = Game("leduc")
     names = {l.info_name(i) for i in range(l.n_infos)}
     assert "J|" in names and "K|XR" in names and "Q|K|XRCXR" in names and "J|J|XX" in names
+
+
+def _build_c_host(tmp_path):
+    import subprocess
+
+    exe = str(tmp_path / "abi_smoke")
+    lib_dir = os.path.join(ROOT, "robopoker_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-O1", os.path.join(ROOT, "tests", "c", "abi_smoke.c"),
+                           "-o", exe, "-L" + lib_dir, "-l:librp_mi355x.so", "-Wl,-rpath," + lib_dir])
+    return exe
+
+
+def test_header_is_valid_c11_and_a_plain_c_host_links(tmp_path):
+    # the drop-in boundary is C, not C++: the header must compile with gcc -std=c11 -Werror and a C program must link
+    import subprocess
+
+    exe = _build_c_host(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    if _lib.load().rp_device_count() > 0:
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        # no device: the library must refuse (RP_ERR_NO_DEVICE -> exit code 2), never compute on the CPU
+        assert r.returncode == 2, r.stdout + r.stderr
+        assert "no HIP device" in r.stderr or "NO_DEVICE" in r.stderr or "device" in r.stderr
