@@ -164,6 +164,10 @@ typedef enum rp_update_mode {
  * applied to the table (rank by rank in the multi-GPU exchange).  Exact in real arithmetic; in f32 it is a
  * fixed re-association of the reference's sequential update (tests state the tolerance). */
 static inline uint32_t rp_compose_block(uint32_t max_actions) { return (1024u / (2u * max_actions)) & ~3u; }
+/* The block maps of a cell are folded sequentially inside groups of RP_FOLD_GROUP consecutive blocks, the group maps
+ * sequentially into the cell's map: a fixed two-level shape, so that the groups of a hot infoset (or hot row of the
+ * sparse profile) fold in parallel on the device and the oracle can restate the association exactly. */
+#define RP_FOLD_GROUP 64u
 
 /* mccfr!(Prefix, Encoder, T, E, G, I, batch) + <R, W, S> (strategy/macros.rs:7-151): one solver instance.
  * `batch_size` = Solver::batch_size() (trees per step). */

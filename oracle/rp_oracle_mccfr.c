@@ -578,30 +578,53 @@ ORA_API int ora_mccfr_step_local(ora_mccfr* h, uint32_t rank, void* blob) {
     ora_map* blk_w = (ora_map*)malloc(cells * sizeof(ora_map));
     ora_map* tot_r = (ora_map*)malloc(cells * sizeof(ora_map));
     ora_map* tot_w = (ora_map*)malloc(cells * sizeof(ora_map));
+    ora_map* sup_r = (ora_map*)malloc(cells * sizeof(ora_map));   /* open group of RP_FOLD_GROUP blocks */
+    ora_map* sup_w = (ora_map*)malloc(cells * sizeof(ora_map));
     uint32_t* pos = (uint32_t*)calloc(NI, 4);       /* position of the next Decisions inside its infoset's segment */
     float* blk_p = (float*)calloc(NI, 4);           /* payoff sum of the open block */
     uint32_t* blk_pn = (uint32_t*)calloc(NI, 4);
+    float* sup_p = (float*)calloc(NI, 4);           /* payoff sum of the open group */
+    uint32_t* sup_pn = (uint32_t*)calloc(NI, 4);
+    uint32_t* sup_nb = (uint32_t*)calloc(NI, 4);    /* blocks folded into the open group */
     float* tot_p = (float*)calloc(NI, 4);
     uint32_t* tot_pn = (uint32_t*)calloc(NI, 4);
-    for (size_t c = 0; c < cells; ++c) blk_r[c] = blk_w[c] = tot_r[c] = tot_w[c] = MAP_ID;
+    for (size_t c = 0; c < cells; ++c) blk_r[c] = blk_w[c] = sup_r[c] = sup_w[c] = tot_r[c] = tot_w[c] = MAP_ID;
     h->ndec = 0;
     batch_range(h, (uint64_t)rank * h->batch, h->batch);
     for (uint64_t i = 0; i <= h->ndec; ++i) {
-        /* flush finished blocks: before a Decisions that opens a new block of its infoset, and at the end */
+        /* close finished blocks: before a Decisions that opens a new block of its infoset, and at the end.  Block
+         * maps are folded sequentially into a group of RP_FOLD_GROUP blocks, groups sequentially into the total
+         * (the device folds the groups of an infoset in parallel). */
         for (uint32_t info = 0; info < NI; ++info) {
             int last = i == h->ndec;
             int opens = !last && h->dec[i].info == info && pos[info] > 0 && pos[info] % T == 0;
-            if (!(last || opens) || blk_pn[info] == 0) continue;
-            for (uint32_t a = 0; a < A; ++a) {
-                size_t k = (size_t)info * A + a;
-                tot_r[k] = map_compose(tot_r[k], blk_r[k]);
-                tot_w[k] = map_compose(tot_w[k], blk_w[k]);
-                blk_r[k] = blk_w[k] = MAP_ID;
+            if (!(last || opens)) continue;
+            if (blk_pn[info] != 0) {
+                for (uint32_t a = 0; a < A; ++a) {
+                    size_t k = (size_t)info * A + a;
+                    sup_r[k] = map_compose(sup_r[k], blk_r[k]);
+                    sup_w[k] = map_compose(sup_w[k], blk_w[k]);
+                    blk_r[k] = blk_w[k] = MAP_ID;
+                }
+                sup_p[info] += blk_p[info]; /* left folds from 0.0f, like the device */
+                sup_pn[info] += blk_pn[info];
+                sup_nb[info] += 1;
+                blk_p[info] = 0.0f;
+                blk_pn[info] = 0;
             }
-            tot_p[info] += blk_p[info]; /* left folds from 0.0f, like the device */
-            tot_pn[info] += blk_pn[info];
-            blk_p[info] = 0.0f;
-            blk_pn[info] = 0;
+            if (sup_nb[info] == RP_FOLD_GROUP || (last && sup_nb[info] > 0)) {
+                for (uint32_t a = 0; a < A; ++a) {
+                    size_t k = (size_t)info * A + a;
+                    tot_r[k] = map_compose(tot_r[k], sup_r[k]);
+                    tot_w[k] = map_compose(tot_w[k], sup_w[k]);
+                    sup_r[k] = sup_w[k] = MAP_ID;
+                }
+                tot_p[info] += sup_p[info];
+                tot_pn[info] += sup_pn[info];
+                sup_p[info] = 0.0f;
+                sup_pn[info] = 0;
+                sup_nb[info] = 0;
+            }
         }
         if (i == h->ndec) break;
         const ora_decision* d = &h->dec[i];
@@ -622,7 +645,8 @@ ORA_API int ora_mccfr_step_local(ora_mccfr* h, uint32_t rank, void* blob) {
         sums[info].count = tot_pn[info];
         sums[info].psum = tot_p[info];
     }
-    free(blk_r); free(blk_w); free(tot_r); free(tot_w); free(pos); free(blk_p); free(blk_pn); free(tot_p); free(tot_pn);
+    free(blk_r); free(blk_w); free(sup_r); free(sup_w); free(tot_r); free(tot_w); free(pos); free(blk_p); free(blk_pn);
+    free(sup_p); free(sup_pn); free(sup_nb); free(tot_p); free(tot_pn);
     return 0;
 }
 
@@ -940,13 +964,13 @@ ORA_API int64_t ora_profile_summarize(ora_mccfr* h, uint64_t n, const uint32_t* 
     for (uint64_t i = 0; i < n; ++i) { ord[i].row = row[i]; ord[i].idx = i; }
     qsort(ord, n, sizeof(ora_touch_ref), touch_cmp);
     int64_t ne = 0;
-    ora_map blk_r[ORA_MAXA], blk_w[ORA_MAXA], tot_r[ORA_MAXA], tot_w[ORA_MAXA];
+    ora_map blk_r[ORA_MAXA], blk_w[ORA_MAXA], sup_r[ORA_MAXA], sup_w[ORA_MAXA], tot_r[ORA_MAXA], tot_w[ORA_MAXA];
     for (uint64_t s = 0; s < n;) {
         uint64_t e = s;
         while (e < n && ord[e].row == ord[s].row) ++e;
-        for (uint32_t a = 0; a < A; ++a) tot_r[a] = tot_w[a] = MAP_ID;
-        float tot_p = 0.0f;
-        uint32_t na = 0;
+        for (uint32_t a = 0; a < A; ++a) tot_r[a] = tot_w[a] = sup_r[a] = sup_w[a] = MAP_ID;
+        float tot_p = 0.0f, sup_p = 0.0f;
+        uint32_t na = 0, sup_nb = 0;
         for (uint64_t b0 = s; b0 < e; b0 += RP_SPARSE_BLOCK) {
             uint64_t b1 = b0 + RP_SPARSE_BLOCK < e ? b0 + RP_SPARSE_BLOCK : e;
             for (uint32_t a = 0; a < A; ++a) blk_r[a] = blk_w[a] = MAP_ID;
@@ -960,11 +984,23 @@ ORA_API int64_t ora_profile_summarize(ora_mccfr* h, uint64_t n, const uint32_t* 
                 }
                 blk_p += d.payoff;
             }
+            /* blocks fold sequentially into a group of RP_FOLD_GROUP blocks, groups into the total */
             for (uint32_t a = 0; a < A; ++a) {
-                tot_r[a] = map_compose(tot_r[a], blk_r[a]);
-                tot_w[a] = map_compose(tot_w[a], blk_w[a]);
+                sup_r[a] = map_compose(sup_r[a], blk_r[a]);
+                sup_w[a] = map_compose(sup_w[a], blk_w[a]);
             }
-            tot_p += blk_p;
+            sup_p += blk_p;
+            sup_nb += 1;
+            if (sup_nb == RP_FOLD_GROUP || b1 == e) {
+                for (uint32_t a = 0; a < A; ++a) {
+                    tot_r[a] = map_compose(tot_r[a], sup_r[a]);
+                    tot_w[a] = map_compose(tot_w[a], sup_w[a]);
+                    sup_r[a] = sup_w[a] = MAP_ID;
+                }
+                tot_p += sup_p;
+                sup_p = 0.0f;
+                sup_nb = 0;
+            }
         }
         unsigned char* ent = (unsigned char*)blob + (size_t)ne * eb;
         uint32_t hdr[4] = {ord[s].row, (uint32_t)(e - s), rp_f2u(tot_p), na};

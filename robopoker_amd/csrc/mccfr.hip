@@ -1027,63 +1027,67 @@ __global__ __launch_bounds__(128) void k_block_maps(DevGame g, DevSorted so, Ste
     }
 }
 
-__global__ __launch_bounds__(64) void k_combine(DevGame g, DevSorted so, StepParams p, const Map* bmaps, const float* bpsum,
-                                                uint32_t nblk_max, Cell* cells, InfoSum* sums) {
-    // The fold over blocks is sequential per cell (its order is part of the model), but the loads are not: the whole
-    // wave streams the infoset's contiguous [block][cell] maps through a double-buffered LDS tile, 64 maps a pass,
-    // and the 2A chain lanes compose out of LDS.
-    __shared__ __attribute__((aligned(16))) Map mbuf[2][64];
-    __shared__ float pbuf[2][64];
-    const uint32_t info = blockIdx.x, lane = threadIdx.x;
+// One workgroup per infoset.  Two-level fold (include/rp_mi355x.h RP_FOLD_GROUP): thread (slot s, cell c) composes
+// the RP_FOLD_GROUP consecutive block maps of group g = g0 + s sequentially — 256 / 2A groups in parallel, loads
+// CB_PF ahead of the chain — then the 2A cell threads fold the group maps in group order.
+#define CB_PF 8
+__global__ __launch_bounds__(256) void k_combine(DevGame g, DevSorted so, StepParams p, const Map* bmaps, const float* bpsum,
+                                                 uint32_t nblk_max, Cell* cells, InfoSum* sums) {
+    __shared__ __attribute__((aligned(16))) Map sup[256];
+    __shared__ float supp[256];
+    const uint32_t info = blockIdx.x, tid = threadIdx.x;
     const uint32_t A = g.A, W2 = 2 * A;
     const float NEG_INF = rp_u2f(0xff800000u);
     const bool walker = g.info_player[info] == p.walker;
     const uint32_t len = walker ? so.total[info] : 0u;
     const uint32_t T = compose_block(A);
     const uint32_t nb = (len + T - 1) / T;
+    const uint32_t ngrp = (nb + RP_FOLD_GROUP - 1) / RP_FOLD_GROUP;
+    const uint32_t NS = 256u / W2, c = tid % W2, s = tid / W2;
     const Map ident{1.0f, 0.0f, NEG_INF, 0u};
+    const Map* src = bmaps + (size_t)info * nblk_max * W2;
+    const float* psrc = bpsum + (size_t)info * nblk_max;
     Map tot = ident;
-    {
-        const Map* src = bmaps + (size_t)info * nblk_max * W2;
-        const uint32_t P = 64u / W2, step = P * W2, total = nb * W2;
-        Map nxt = (lane < step && lane < total) ? src[lane] : ident;
-        uint32_t cur = 0;
-        for (uint32_t base = 0; base < total; base += step) {
-            mbuf[cur][lane] = nxt;
-            const uint32_t k = base + step + lane;
-            nxt = (lane < step && k < total) ? src[k] : ident;
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the tile is visible to the chain lanes
-            if (lane < W2) {
-#pragma unroll 4
-                for (uint32_t u = 0; u < P; ++u) tot = map_compose(tot, mbuf[cur][u * W2 + lane]);
-            }
-            cur ^= 1u;
-        }
-    }
     float ps = 0.0f;
-    {
-        const float* src = bpsum + (size_t)info * nblk_max;
-        float nxt = lane < nb ? src[lane] : 0.0f;
-        uint32_t cur = 0;
-        for (uint32_t base = 0; base < nb; base += 64) {
-            pbuf[cur][lane] = nxt;
-            const uint32_t k = base + 64 + lane;
-            nxt = k < nb ? src[k] : 0.0f;
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            if (lane == W2) {
-                const uint32_t n = min(64u, nb - base);
-                for (uint32_t u = 0; u < n; ++u) ps += pbuf[cur][u];
+    for (uint32_t g0 = 0; g0 < ngrp; g0 += NS) {
+        const uint32_t grp = g0 + s;
+        if (s < NS && grp < ngrp) {
+            const uint32_t b_lo = grp * RP_FOLD_GROUP, b_hi = min(nb, b_lo + RP_FOLD_GROUP);
+            Map m = ident;
+            float gp = 0.0f;
+            for (uint32_t b0 = b_lo; b0 < b_hi; b0 += CB_PF) {
+                const uint32_t cnt = min((uint32_t)CB_PF, b_hi - b0);
+                Map mm[CB_PF];
+                float pp[CB_PF];
+#pragma unroll
+                for (uint32_t q = 0; q < CB_PF; ++q) {
+                    mm[q] = q < cnt ? src[(size_t)(b0 + q) * W2 + c] : ident;
+                    pp[q] = (c == 0 && q < cnt) ? psrc[b0 + q] : 0.0f;
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < CB_PF; ++q) {
+                    if (q >= cnt) break;
+                    m = map_compose(m, mm[q]);
+                    gp += pp[q];
+                }
             }
-            cur ^= 1u;
+            sup[s * W2 + c] = m;
+            if (c == 0) supp[s] = gp;
         }
+        __syncthreads();
+        const uint32_t have = min(NS, ngrp - g0);
+        if (tid < W2) {
+            for (uint32_t k = 0; k < have; ++k) tot = map_compose(tot, sup[k * W2 + tid]);
+        } else if (tid == W2) {
+            for (uint32_t k = 0; k < have; ++k) ps += supp[k];
+        }
+        __syncthreads();
     }
-    if (lane < W2) {
-        Cell* c = &cells[(size_t)info * A + lane % A];
-        if (lane < A) { c->ra = tot.a; c->rb = tot.b; c->rm = tot.m; c->rn = tot.n; }
-        else { c->wa = tot.a; c->wb = tot.b; c->wm = tot.m; c->wn = tot.n; }
-    } else if (lane == W2) {
+    if (tid < W2) {
+        Cell* cl = &cells[(size_t)info * A + tid % A];
+        if (tid < A) { cl->ra = tot.a; cl->rb = tot.b; cl->rm = tot.m; cl->rn = tot.n; }
+        else { cl->wa = tot.a; cl->wb = tot.b; cl->wm = tot.m; cl->wn = tot.n; }
+    } else if (tid == W2) {
         sums[info] = InfoSum{len, ps};
     }
 }
@@ -1389,7 +1393,7 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev) {
         hipLaunchKernelGGL((k_block_maps<true>), dim3(nblk, h->tbl.n_infos), dim3(128), 0, h->stream, h->g, h->so, p, bmaps, bpsum, nblk_max);
     else
         hipLaunchKernelGGL((k_block_maps<false>), dim3(nblk, h->tbl.n_infos), dim3(128), 0, h->stream, h->g, h->so, p, bmaps, bpsum, nblk_max);
-    hipLaunchKernelGGL(k_combine, dim3(h->tbl.n_infos), dim3(64), 0, h->stream, h->g, h->so, p, bmaps, bpsum, nblk_max, cells, sums);
+    hipLaunchKernelGGL(k_combine, dim3(h->tbl.n_infos), dim3(256), 0, h->stream, h->g, h->so, p, bmaps, bpsum, nblk_max, cells, sums);
     clock_end(h, h->clk_update);
     HIP_TRY(hipGetLastError());
     return RP_OK;

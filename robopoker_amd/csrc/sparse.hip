@@ -27,6 +27,7 @@ namespace rp {
 
 #define GROUP 16u  // lanes per row (max_actions <= 16)
 #define PF 8       // touches fetched ahead of the sequential chain
+#define HOT_CAP 4096  // rows per batch folded by k_hot_fold; further hot rows fold (serially) in k_seg_fold
 
 struct SparseParams {
     float* tab;           // [n_rows][4A]
@@ -201,14 +202,14 @@ __global__ __launch_bounds__(256) void k_block_maps_sparse(SparseParams p, DevBa
                 bp += pv[u];
             }
         }
-        // a row with a single block is final: tot = compose(identity, block) = block, psum = 0 + bp
+        // a row with a single block is final: group = total = compose(identity, block) = block
         const bool single = nblk[g] == 1u;
         unsigned char* ent = single ? entries + (size_t)g * entry_bytes : blocks + (size_t)bi * entry_bytes;
         if (a == 0) {
             uint32_t* hdr = reinterpret_cast<uint32_t*>(ent);
             hdr[0] = sg.rows[g];
             hdr[1] = single ? cnt : t_hi - t_lo;
-            hdr[2] = rp_f2u(single ? 0.0f + bp : bp);
+            hdr[2] = rp_f2u(single ? 0.0f + (0.0f + bp) : bp);  // group sum = 0 + block sum, total = 0 + group sum
             hdr[3] = nact;
         }
         if (a < A) {
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(256) void k_block_maps_sparse(SparseParams p, DevBa
 
 // rows with several blocks: fold the block records in block order into the entry
 __global__ __launch_bounds__(256) void k_seg_fold(SparseParams p, Segments sg, const uint32_t* nblk, const uint32_t* boff,
-                                                  unsigned char* entries, const unsigned char* blocks, uint32_t entry_bytes) {
+                                                  unsigned char* entries, const unsigned char* blocks, uint32_t entry_bytes,
+                                                  uint32_t* hot, uint32_t* n_hot, uint32_t hot_cap) {
     const uint32_t n_segs = *sg.n_segs;
     const uint32_t a = threadIdx.x % GROUP;
     const uint32_t A = p.A;
@@ -230,30 +232,48 @@ __global__ __launch_bounds__(256) void k_seg_fold(SparseParams p, Segments sg, c
     for (uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / GROUP; g < n_segs; g += gridDim.x * blockDim.x / GROUP) {
         const uint32_t nb = nblk[g];
         if (nb <= 1u) continue;
+        if (nb > RP_FOLD_GROUP) {  // a hot row: its groups fold in parallel in k_hot_fold
+            uint32_t slot = hot_cap;
+            if (a == 0) slot = atomicAdd(n_hot, 1u);
+            slot = __shfl(slot, (int)(threadIdx.x & 48u), 64);
+            if (slot < hot_cap) {
+                if (a == 0) hot[slot] = g;
+                continue;
+            }
+        }
+        // two-level fold (RP_FOLD_GROUP): block records sequentially into a group, groups sequentially into the total
         Map tr = ident, tw = ident;
         float tp = 0.0f;
         uint32_t nact = 0;
         const unsigned char* rec0 = blocks + (size_t)boff[g] * entry_bytes;
-        for (uint32_t k0 = 0; k0 < nb; k0 += PF) {  // records are fetched PF at a time, folded in order
-            const uint32_t m = min((uint32_t)PF, nb - k0);
-            Map mr[PF], mw[PF];
-            float ps[PF];
+        for (uint32_t g0 = 0; g0 < nb; g0 += RP_FOLD_GROUP) {
+            const uint32_t g1 = min(nb, g0 + RP_FOLD_GROUP);
+            Map sr = ident, sw = ident;
+            float sp = 0.0f;
+            for (uint32_t k0 = g0; k0 < g1; k0 += PF) {  // records are fetched PF at a time, folded in order
+                const uint32_t m = min((uint32_t)PF, g1 - k0);
+                Map mr[PF], mw[PF];
+                float ps[PF];
 #pragma unroll
-            for (uint32_t u = 0; u < PF; ++u) {
-                const unsigned char* rec = rec0 + (size_t)(k0 + (u < m ? u : 0u)) * entry_bytes;
-                const uint32_t* hdr = reinterpret_cast<const uint32_t*>(rec);
-                nact = hdr[3];
-                ps[u] = rp_u2f(hdr[2]);
-                mr[u] = a < A ? reinterpret_cast<const Map*>(rec + 16)[a] : ident;
-                mw[u] = a < A ? reinterpret_cast<const Map*>(rec + 16)[A + a] : ident;
-            }
+                for (uint32_t u = 0; u < PF; ++u) {
+                    const unsigned char* rec = rec0 + (size_t)(k0 + (u < m ? u : 0u)) * entry_bytes;
+                    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(rec);
+                    nact = hdr[3];
+                    ps[u] = rp_u2f(hdr[2]);
+                    mr[u] = a < A ? reinterpret_cast<const Map*>(rec + 16)[a] : ident;
+                    mw[u] = a < A ? reinterpret_cast<const Map*>(rec + 16)[A + a] : ident;
+                }
 #pragma unroll
-            for (uint32_t u = 0; u < PF; ++u) {
-                if (u >= m) break;
-                tr = map_compose(tr, mr[u]);
-                tw = map_compose(tw, mw[u]);
-                tp += ps[u];
+                for (uint32_t u = 0; u < PF; ++u) {
+                    if (u >= m) break;
+                    sr = map_compose(sr, mr[u]);
+                    sw = map_compose(sw, mw[u]);
+                    sp += ps[u];
+                }
             }
+            tr = map_compose(tr, sr);
+            tw = map_compose(tw, sw);
+            tp += sp;
         }
         unsigned char* ent = entries + (size_t)g * entry_bytes;
         if (a == 0) {
@@ -268,6 +288,72 @@ __global__ __launch_bounds__(256) void k_seg_fold(SparseParams p, Segments sg, c
             mr[a] = tr;
             mr[A + a] = tw;
         }
+    }
+}
+
+// hot rows (more than RP_FOLD_GROUP blocks): one workgroup per row, the groups of the two-level fold in parallel —
+// thread (slot s, cell c) folds the records of group g0 + s, then the cell threads fold the group maps in order
+__global__ __launch_bounds__(256) void k_hot_fold(SparseParams p, Segments sg, const uint32_t* nblk, const uint32_t* boff,
+                                                  unsigned char* entries, const unsigned char* blocks, uint32_t entry_bytes,
+                                                  const uint32_t* hot, const uint32_t* n_hot, uint32_t hot_cap) {
+    __shared__ __attribute__((aligned(16))) Map sup[256];
+    __shared__ float supp[8];
+    const uint32_t A = p.A, W2 = 2 * A;
+    const uint32_t tid = threadIdx.x, c = tid % 32u, s = tid / 32u;  // 8 slots x 32 cell lanes (2A <= 32)
+    const float NEG_INF = rp_u2f(0xff800000u);
+    const Map ident{1.0f, 0.0f, NEG_INF, 0u};
+    const uint32_t nh = min(*n_hot, hot_cap);
+    for (uint32_t hi = blockIdx.x; hi < nh; hi += gridDim.x) {
+        const uint32_t g = hot[hi];
+        const uint32_t nb = nblk[g], ngrp = (nb + RP_FOLD_GROUP - 1) / RP_FOLD_GROUP;
+        const unsigned char* rec0 = blocks + (size_t)boff[g] * entry_bytes;
+        const uint32_t nact = reinterpret_cast<const uint32_t*>(rec0)[3];
+        Map tot = ident;
+        float tp = 0.0f;
+        for (uint32_t g0 = 0; g0 < ngrp; g0 += 8) {
+            const uint32_t grp = g0 + s;
+            if (grp < ngrp) {
+                const uint32_t k_lo = grp * RP_FOLD_GROUP, k_hi = min(nb, k_lo + RP_FOLD_GROUP);
+                Map m = ident;
+                float gp = 0.0f;
+                for (uint32_t k0 = k_lo; k0 < k_hi; k0 += PF) {
+                    const uint32_t cnt = min((uint32_t)PF, k_hi - k0);
+                    Map mm[PF];
+                    float pp[PF];
+#pragma unroll
+                    for (uint32_t u = 0; u < PF; ++u) {
+                        const unsigned char* rec = rec0 + (size_t)(k0 + (u < cnt ? u : 0u)) * entry_bytes;
+                        mm[u] = c < W2 ? reinterpret_cast<const Map*>(rec + 16)[c] : ident;
+                        pp[u] = rp_u2f(reinterpret_cast<const uint32_t*>(rec)[2]);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < PF; ++u) {
+                        if (u >= cnt) break;
+                        m = map_compose(m, mm[u]);
+                        gp += pp[u];
+                    }
+                }
+                sup[s * 32u + c] = m;
+                if (c == 0) supp[s] = gp;
+            }
+            __syncthreads();
+            const uint32_t have = min(8u, ngrp - g0);
+            if (tid < W2) {
+                for (uint32_t k = 0; k < have; ++k) tot = map_compose(tot, sup[k * 32u + tid]);
+            } else if (tid == 32u) {
+                for (uint32_t k = 0; k < have; ++k) tp += supp[k];
+            }
+            __syncthreads();
+        }
+        unsigned char* ent = entries + (size_t)g * entry_bytes;
+        if (tid == 32u) {
+            uint32_t* hdr = reinterpret_cast<uint32_t*>(ent);
+            hdr[0] = sg.rows[g];
+            hdr[1] = sg.counts[g];
+            hdr[2] = rp_f2u(tp);
+            hdr[3] = nact;
+        }
+        if (tid < W2) reinterpret_cast<Map*>(ent + 16)[tid] = tot;
     }
 }
 
@@ -361,6 +447,7 @@ struct rp_profile {
     uint32_t *iota = nullptr, *keys_out = nullptr, *perm = nullptr, *seg_rows = nullptr, *seg_counts = nullptr,
              *seg_offsets = nullptr, *n_segs = nullptr, *ent_rows = nullptr, *nblk = nullptr, *boff = nullptr;
     unsigned char* blocks = nullptr;   // block records of multi-block rows
+    uint32_t* hot = nullptr;           // [HOT_CAP + 1] rows with more than RP_FOLD_GROUP blocks; last slot = counter
     float *srt_regret = nullptr, *srt_policy = nullptr, *srt_payoff = nullptr;  // the batch in sorted order (ordered mode)
     uint16_t* srt_expanded = nullptr;
     void* cub_tmp = nullptr;
@@ -513,7 +600,11 @@ static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch
     const uint32_t mb = max_blocks_of(n);
     hipLaunchKernelGGL(k_block_maps_sparse, dim3(group_blocks(mb)), dim3(256), 0, h->stream, p, b, sg, h->nblk, h->boff, entries,
                        h->blocks, eb, mb);
-    hipLaunchKernelGGL(k_seg_fold, dim3(group_blocks(n)), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb);
+    HIP_TRY(hipMemsetAsync(h->hot + HOT_CAP, 0, 4, h->stream));
+    hipLaunchKernelGGL(k_seg_fold, dim3(group_blocks(n)), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb,
+                       h->hot, h->hot + HOT_CAP, (uint32_t)HOT_CAP);
+    hipLaunchKernelGGL(k_hot_fold, dim3(64), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb, h->hot,
+                       h->hot + HOT_CAP, (uint32_t)HOT_CAP);
     HIP_TRY(hipGetLastError());
     return RP_OK;
 }
@@ -552,6 +643,7 @@ int rp_profile_create(int device, uint64_t n_rows, uint32_t max_actions, rp_regr
     PF_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     PF_TRY(hipMalloc(&h->tab, (size_t)n_rows * 4u * max_actions * 4u));
     PF_TRY(hipMalloc(&h->n_segs, 4));
+    PF_TRY(hipMalloc(&h->hot, (HOT_CAP + 1) * 4));
     float* d_def = nullptr;
     std::vector<float> def(max_actions, 0.0f);
     if (default_regret) def.assign(default_regret, default_regret + max_actions);
@@ -581,6 +673,7 @@ int rp_profile_destroy(rp_profile* h) {
     free_workspace(h);
     if (h->tab) (void)hipFree(h->tab);
     if (h->n_segs) (void)hipFree(h->n_segs);
+    if (h->hot) (void)hipFree(h->hot);
     if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return RP_OK;

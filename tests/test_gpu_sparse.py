@@ -54,6 +54,25 @@ def test_composed_apply_and_entries_bit_exact(gpu, regret, weight, A):
     same(g.rows(np.arange(n_rows)), o.rows(np.arange(n_rows)))
 
 
+def test_hot_rows_fold_their_block_groups_in_parallel_bit_exact(gpu):
+    # 40 rows, 60 000 touches: the popular rows collect > RP_FOLD_GROUP * RP_SPARSE_BLOCK touches (k_hot_fold)
+    n_rows, A = 40, 9
+    g = SparseProfile(n_rows, A, "linear", "linear")
+    o = oracle.OracleProfile(n_rows, A, "linear", "linear")
+    for e in range(3):
+        batch = synthetic_batch(60000, n_rows, A, seed=50 + e)
+        assert np.bincount(batch[0]).max() > 64 * 64 * 2
+        db = DeviceBatch(*batch)
+        buf = torch.zeros(db.n * g.entry_bytes(), dtype=torch.uint8, device="cuda")
+        n = g.summarize(db, buf.data_ptr())
+        exp = o.summarize(batch)
+        assert np.array_equal(buf[: n * g.entry_bytes()].cpu().numpy(), exp), "summary entries differ"
+        g.apply(db, "composed")
+        o.fold(exp)
+    g.sync()
+    same(g.rows(np.arange(n_rows)), o.rows(np.arange(n_rows)))
+
+
 def test_fold_of_several_ranks_in_rank_order_bit_exact(gpu):
     n_rows, A, world = 400, 7, 3
     g = SparseProfile(n_rows, A, "linear", "linear")
