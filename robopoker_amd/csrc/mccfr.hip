@@ -281,9 +281,10 @@ __global__ __launch_bounds__(256) void k_traverse(DevGame g, DevTables t, DevScr
             dc.info[slot * D + lane] = info;
             dc.mask[slot * D + lane] = expanded;
             dc.payoff[slot * D + lane] = payoff;
-            dc.slotmap[(size_t)info * D + lane] = (uint8_t)(slot + 1);
+            if (dc.slotmap) dc.slotmap[(size_t)info * D + lane] = (uint8_t)(slot + 1);
         }
     }
+    dc.ndec[lane] = (uint8_t)ndec;
     // Metrics: nodes / infos (metrics/mod.rs:21-80; solver.rs:273)
     atomicAdd(&p.counters[0], (unsigned long long)nn);
     atomicAdd(&p.counters[1], (unsigned long long)ndec);
@@ -553,10 +554,11 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
             dc.info[slot * D + lane] = info;
             dc.mask[slot * D + lane] = expanded;
             dc.payoff[slot * D + lane] = payoff;
-            dc.slotmap[(size_t)info * D + lane] = (uint8_t)(slot + 1);
+            if (dc.slotmap) dc.slotmap[(size_t)info * D + lane] = (uint8_t)(slot + 1);
         }
     }
 #undef L
+    dc.ndec[lane] = (uint8_t)ndec;
     atomicAdd(&p.counters[0], (unsigned long long)nn);
     atomicAdd(&p.counters[1], (unsigned long long)ndec);
     if (err) atomicOr(&p.counters[2], (unsigned long long)err);
@@ -691,6 +693,84 @@ __global__ __launch_bounds__(CH_THREADS) void k_compact(DevGame g, DevDecisions 
         so.mask[pos] = dc.mask[slot * dc.stride + tree];
         so.payoff[pos] = dc.payoff[slot * dc.stride + tree];
         rank += 1;
+    }
+}
+
+// ---- small games (n_infos <= SM_INFOS): the same stable counting sort without the per-infoset slot map --------
+// One workgroup per chunk of CH_TREES trees.  A tree's Decisions are marked in an LDS bitmap [infoset][tree]; the
+// rank of a Decisions inside its (chunk, infoset) bucket — its place in tree-id order — is a prefix popcount of that
+// bitmap row.  Every Decisions is read once; nothing is scanned per infoset.
+#define SM_INFOS 256u
+#define SM_WORDS (CH_TREES / 32u)
+__device__ __forceinline__ void chunk_bitmap(const DevDecisions& dc, uint32_t n_infos, uint32_t chunk, uint32_t batch,
+                                             uint32_t* bits) {
+    for (uint32_t e = threadIdx.x; e < n_infos * SM_WORDS; e += CH_THREADS) bits[e] = 0;
+    __syncthreads();
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t lt = threadIdx.x + k * CH_THREADS, tree = chunk * CH_TREES + lt;  // coalesced over threads
+        if (tree >= batch) continue;
+        const uint32_t nd = dc.ndec[tree];
+        for (uint32_t slot = 0; slot < nd; ++slot)
+            atomicOr(&bits[dc.info[slot * dc.stride + tree] * SM_WORDS + (lt >> 5)], 1u << (lt & 31u));
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(CH_THREADS) void k_count_small(DevGame g, DevDecisions dc, DevSorted so, StepParams p) {
+    __shared__ uint32_t bits[SM_INFOS * SM_WORDS];
+    const uint32_t chunk = blockIdx.x;
+    chunk_bitmap(dc, g.n_infos, chunk, p.batch, bits);
+    for (uint32_t info = threadIdx.x; info < g.n_infos; info += CH_THREADS) {
+        uint32_t c = 0;
+        for (uint32_t w = 0; w < SM_WORDS; ++w) c += __popc(bits[info * SM_WORDS + w]);
+        so.counts[(size_t)info * so.n_chunks + chunk] = c;
+    }
+}
+__global__ __launch_bounds__(CH_THREADS) void k_compact_small(DevGame g, DevDecisions dc, DevSorted so, StepParams p) {
+    __shared__ uint32_t bits[SM_INFOS * SM_WORDS];
+    __shared__ uint16_t pre[SM_INFOS * SM_WORDS];  // trees of the chunk before word w that visited the infoset
+    __shared__ uint32_t base[SM_INFOS];            // first position of the (chunk, infoset) bucket
+    __shared__ uint32_t wave_tot[CH_THREADS / 64];
+    const uint32_t chunk = blockIdx.x;
+    chunk_bitmap(dc, g.n_infos, chunk, p.batch, bits);
+    for (uint32_t info = threadIdx.x; info < g.n_infos; info += CH_THREADS) {
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < SM_WORDS; ++w) {
+            pre[info * SM_WORDS + w] = (uint16_t)run;
+            run += __popc(bits[info * SM_WORDS + w]);
+        }
+    }
+    {   // bucket base = sum of the lengths of all lower infosets + this chunk's offset inside the infoset's segment
+        const uint32_t info = threadIdx.x;  // n_infos <= SM_INFOS == CH_THREADS
+        const uint32_t v = info < g.n_infos ? so.total[info] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_exscan(v, wave_tot, &tot);
+        if (info < g.n_infos) base[info] = ex + so.offs[(size_t)info * so.n_chunks + chunk];
+    }
+    __syncthreads();
+    const uint32_t A = g.A;
+    const float tf = (float)p.epoch;
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t lt = threadIdx.x + k * CH_THREADS, tree = chunk * CH_TREES + lt;
+        if (tree >= p.batch) continue;
+        const uint32_t nd = dc.ndec[tree];
+        for (uint32_t slot = 0; slot < nd; ++slot) {
+            const uint32_t info = dc.info[slot * dc.stride + tree];
+            const uint32_t nact = g.info_actions[info];
+            const uint32_t rank = pre[info * SM_WORDS + (lt >> 5)] + __popc(bits[info * SM_WORDS + (lt >> 5)] & ((1u << (lt & 31u)) - 1u));
+            const size_t pos = (size_t)base[info] + rank;
+            for (uint32_t a = 0; a < A; ++a) {
+                float rd = 0.0f, wd = 0.0f;
+                if (a < nact) {
+                    rd = dc.regret[(slot * A + a) * dc.stride + tree];
+                    const float sg = dc.policy[(slot * A + a) * dc.stride + tree];
+                    wd = p.W == RP_WEIGHT_LINEAR ? sg * tf : (p.W == RP_WEIGHT_QUADRATIC ? sg * tf * tf : sg);
+                }
+                so.rw[pos * 2 * A + a] = rd;
+                so.rw[pos * 2 * A + A + a] = wd;
+            }
+            so.mask[pos] = dc.mask[slot * dc.stride + tree];
+            so.payoff[pos] = dc.payoff[slot * dc.stride + tree];
+        }
     }
 }
 
@@ -1252,7 +1332,9 @@ int alloc_batch_buffers(rp_mccfr* h, uint32_t batch) {
     dc.stride = stride;
     dc.maxdec = h->maxdec;
     const size_t slot_words = (size_t)dc.maxdec * stride;
-    const size_t dec_bytes = (3 * slot_words + 2 * slot_words * A) * 4 + (size_t)h->tbl.n_infos * stride;
+    // chunk-local sort: no per-infoset slot map (RP_MCCFR_SLOTMAP=1 forces the large-game path, for tests)
+    const bool small = h->tbl.n_infos <= SM_INFOS && !getenv("RP_MCCFR_SLOTMAP");
+    const size_t dec_bytes = (3 * slot_words + 2 * slot_words * A) * 4 + (small ? 0 : (size_t)h->tbl.n_infos * stride) + stride;
     HIP_TRY(hipMalloc(&h->d_dec, dec_bytes));
     uint32_t* d = reinterpret_cast<uint32_t*>(h->d_dec);
     dc.info = d; d += slot_words;
@@ -1260,7 +1342,8 @@ int alloc_batch_buffers(rp_mccfr* h, uint32_t batch) {
     dc.payoff = reinterpret_cast<float*>(d); d += slot_words;
     dc.regret = reinterpret_cast<float*>(d); d += slot_words * A;
     dc.policy = reinterpret_cast<float*>(d); d += slot_words * A;
-    dc.slotmap = reinterpret_cast<uint8_t*>(d);
+    dc.ndec = reinterpret_cast<uint8_t*>(d);
+    dc.slotmap = small ? nullptr : dc.ndec + stride;
     // tree-ordered segments: at most maxdec Decisions per tree
     if (h->d_sorted) HIP_TRY(hipFree(h->d_sorted));
     h->d_sorted = nullptr;
@@ -1337,7 +1420,7 @@ bool traverse_fits_lds(const rp_mccfr* h) {
 }
 
 int launch_traverse(rp_mccfr* h, const StepParams& p) {
-    HIP_TRY(hipMemsetAsync(h->dc.slotmap, 0, (size_t)h->tbl.n_infos * h->dc.stride, h->stream));
+    if (h->dc.slotmap) HIP_TRY(hipMemsetAsync(h->dc.slotmap, 0, (size_t)h->tbl.n_infos * h->dc.stride, h->stream));
     clock_begin(h, h->clk_traverse);
     if (h->use_lds_traverse) {
         hipLaunchKernelGGL(k_prepare_infos, dim3((h->tbl.n_infos + 63) / 64), dim3(64), 0, h->stream, h->g, h->t, p, h->itab);
@@ -1357,9 +1440,15 @@ int launch_sort(rp_mccfr* h, const StepParams& p) {
     const uint32_t nchunks = (h->batch + CH_TREES - 1) / CH_TREES;
     h->so.n_chunks = nchunks;
     clock_begin(h, h->clk_compact);
-    hipLaunchKernelGGL(k_count, dim3(nchunks, h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
-    hipLaunchKernelGGL(k_scan, dim3(h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->so, p);
-    hipLaunchKernelGGL(k_compact, dim3(nchunks, h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
+    if (!h->dc.slotmap) {
+        hipLaunchKernelGGL(k_count_small, dim3(nchunks), dim3(CH_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
+        hipLaunchKernelGGL(k_scan, dim3(h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->so, p);
+        hipLaunchKernelGGL(k_compact_small, dim3(nchunks), dim3(CH_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
+    } else {
+        hipLaunchKernelGGL(k_count, dim3(nchunks, h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
+        hipLaunchKernelGGL(k_scan, dim3(h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->so, p);
+        hipLaunchKernelGGL(k_compact, dim3(nchunks, h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
+    }
     clock_end(h, h->clk_compact);
     HIP_TRY(hipGetLastError());
     return RP_OK;

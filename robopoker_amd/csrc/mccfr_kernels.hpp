@@ -58,7 +58,8 @@ struct DevDecisions {
     float* payoff;      // [maxdec][stride]
     float* regret;      // [maxdec][A][stride]
     float* policy;      // [maxdec][A][stride]
-    uint8_t* slotmap;   // [n_infos][stride]  slot + 1 of the tree's Decisions for that infoset, 0 = none
+    uint8_t* slotmap;   // [n_infos][stride]  slot + 1 of the tree's Decisions for that infoset, 0 = none (large games)
+    uint8_t* ndec;      // [stride]           Decisions produced by the tree
     size_t stride;
     uint32_t maxdec;
 };

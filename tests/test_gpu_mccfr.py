@@ -96,6 +96,21 @@ def test_hbm_scratch_traversal_variant_is_identical(gpu, monkeypatch):
     assert a.counters() == b.counters() == ora.counters()
 
 
+def test_slotmap_sort_variant_for_large_games_is_identical(gpu, monkeypatch):
+    # games with more than 256 infosets sort their Decisions through a per-infoset slot map; force that path on Leduc
+    g = Game("leduc")
+    monkeypatch.setenv("RP_MCCFR_SLOTMAP", "1")
+    a = Solver(g, "linear", "linear", "pluribus", batch=3000, seed=5)
+    monkeypatch.delenv("RP_MCCFR_SLOTMAP")
+    b = Solver(g, "linear", "linear", "pluribus", batch=3000, seed=5)
+    for _ in range(6):
+        a.step()
+        b.step()
+    ra, rb = a.export(), b.export()
+    for f in ("visits", "regret", "weight", "payoff"):
+        assert np.array_equal(ra[f].view(np.uint32), rb[f].view(np.uint32)), f
+
+
 @pytest.mark.parametrize("batch", [1, 63, 64, 65, 1024, 1025, 5000])
 def test_batch_size_edges(gpu, batch):
     g = Game("leduc")
