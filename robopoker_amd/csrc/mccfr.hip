@@ -350,8 +350,7 @@ __device__ __forceinline__ uint32_t d_sample_mask_tab(const DevGame& g, const De
     uint32_t mask = it.keep[info] & all;
     if (p.S == RP_SAMPLING_PLURIBUS) {
         for (uint32_t a = 0; a < n; ++a) {
-            const uint4 c = g.states[g.children[off + a]];
-            if ((c.x & 0xffu) == RP_TURN_TERMINAL) mask |= 1u << a;
+            if ((g.kids[off + a].x & 0xffu) == RP_TURN_TERMINAL) mask |= 1u << a;
         }
     }
     return mask ? mask : all;
@@ -387,27 +386,26 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
     float* nv = nfs + (size_t)maxn * 64;                             // [maxn][64] leaf: payoff; internal: child-value sum
     float* tv = nv + (size_t)maxn * 64;                              // [A][64]
     // build phase: the DFS stack; evaluation phase: per-root reach prefixes of internal nodes (same storage)
-    uint32_t* ss = reinterpret_cast<uint32_t*>(tv + (size_t)g.A * 64);  // [maxs][64] stack: state
-    uint32_t* sm = ss + (size_t)maxs * 64;                           // [maxs][64] stack: parent | edge << 6 | ptype << 10
-    float* sfr = reinterpret_cast<float*>(sm + (size_t)maxs * 64);
-    float* sfs = sfr + (size_t)maxs * 64;
+    uint32_t* ss = reinterpret_cast<uint32_t*>(tv + (size_t)g.A * 64);  // [maxs][6][64] stack: child record x,y,z,w | meta | frel
     float* xr = reinterpret_cast<float*>(ss);                        // [maxn][64] relative reach root's child -> node
     float* xs = xr + (size_t)maxn * 64;                              // [maxn][64] sampling reach root's child -> node
     if (lane >= p.batch) return;
     const uint64_t tree_id = p.tree_base + lane;
     uint32_t err = 0;
 #define L(arr, slot) arr[(slot)*64 + ln]
+#define STK(e, f) ss[((e)*6u + (f)) * 64u + ln]
 
     // ---- TreeBuilder::build (builder.rs:74-87,141-161): pop-last DFS -----------------------------
-    // the last child pushed is the next node popped, so it is carried in registers instead of through the stack
+    // A node arrives as its RECORD (DevGame::kids): the records of all sampled children are requested together
+    // when their parent is expanded, so a tree pays one L2 round trip per internal node, not two or three per node.
+    // The last child pushed is the next node popped: it is carried in registers instead of through the stack.
     uint32_t nn = 0, sp = 0;
-    uint32_t cur_state = g.root;
+    uint4 rec = g.root_rec;
     uint32_t cur_in = LM_NO_PARENT | (PT_NONE << 10);
     float cur_frel = 1.0f, cur_fsmp = 1.0f;
     unsigned long long wmask = 0;  // walker decision nodes
     for (;;) {
-        const uint4 st = g.states[cur_state];
-        const uint32_t turn = st.x & 0xffu, nch = (st.x >> 8) & 0xffu, info = st.y, off = st.z;
+        const uint32_t turn = rec.x & 0xffu, nch = (rec.x >> 8) & 0xffu, info = rec.y, off = rec.z;
         const uint32_t me = nn;
         if (nn >= maxn) {
             err |= ERR_NODE_CAPACITY;
@@ -421,11 +419,12 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
         nn += 1;
         if (nch > 0) {
             if (is_walker) wmask |= 1ull << me;
-            uint32_t mask = d_sample_mask_tab(g, it, p, tree_id, cur_state, turn, nch, info, off);
+            uint32_t mask = d_sample_mask_tab(g, it, p, tree_id, rec.w, turn, nch, info, off);
             const bool chance = turn == RP_TURN_CHANCE;
             const uint32_t ptype = chance ? PT_CHANCE : (is_walker ? PT_WALKER : PT_OPP);
             const uint32_t last = 31u - (uint32_t)__builtin_clz(mask);
             mask &= ~(1u << last);
+            rec = g.kids[off + last];
             while (mask) {
                 const uint32_t k = (uint32_t)__builtin_ctz(mask);
                 mask &= mask - 1u;
@@ -433,27 +432,30 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     err |= ERR_STACK_CAPACITY;
                     break;
                 }
-                L(ss, sp) = g.children[off + k];
-                L(sm, sp) = me | (k << 6) | (ptype << 10);
-                L(sfr, sp) = it.sigma[info * g.A + k];  // only walker nodes push more than one child
-                L(sfs, sp) = 1.0f;
+                const uint4 kr = g.kids[off + k];
+                STK(sp, 0) = kr.x;
+                STK(sp, 1) = kr.y;
+                STK(sp, 2) = kr.z;
+                STK(sp, 3) = kr.w;
+                STK(sp, 4) = me | (k << 6) | (ptype << 10);
+                STK(sp, 5) = rp_f2u(it.sigma[info * g.A + k]);  // only walker nodes push more than one child: fsmp = 1
                 sp += 1;
             }
             if (err) break;
-            cur_state = g.children[off + last];
             cur_in = me | (last << 6) | (ptype << 10);
             cur_frel = chance ? 1.0f : it.sigma[info * g.A + last];
             cur_fsmp = ptype == PT_OPP ? it.q[info * g.A + last] : 1.0f;
             continue;
         }
-        L(nv, me) = g.payoffs[off * g.n_players + p.walker];
+        L(nv, me) = g.n_players == 2 ? rp_u2f(p.walker == 0 ? rec.y : rec.z) : g.payoffs[off * g.n_players + p.walker];
         if (sp == 0) break;
         sp -= 1;
-        cur_state = L(ss, sp);
-        cur_in = L(sm, sp);
-        cur_frel = L(sfr, sp);
-        cur_fsmp = L(sfs, sp);
+        rec = make_uint4(STK(sp, 0), STK(sp, 1), STK(sp, 2), STK(sp, 3));
+        cur_in = STK(sp, 4);
+        cur_frel = rp_u2f(STK(sp, 5));
+        cur_fsmp = 1.0f;
     }
+#undef STK
 
     // ---- Tree::partition + CfrFlow::dfs per walker infoset (tree.rs:88-98, flow.rs:64-87) --------
     uint32_t ndec = 0;
@@ -1233,6 +1235,7 @@ struct rp_mccfr {
     DevDecisions dc{};
     void* d_states = nullptr;
     void* d_children = nullptr;
+    void* d_kids = nullptr;
     void* d_payoffs = nullptr;
     void* d_info_actions = nullptr;
     void* d_info_player = nullptr;
@@ -1411,7 +1414,7 @@ void clock_drain(KernelClock& c) {
 }
 
 size_t traverse_lds_bytes(const rp_mccfr* h) {
-    const size_t shared = std::max<size_t>(2 * (size_t)h->sc.maxn, 4 * (size_t)h->sc.maxs);  // stack, then reach prefixes
+    const size_t shared = std::max<size_t>(2 * (size_t)h->sc.maxn, 6 * (size_t)h->sc.maxs);  // stack, then reach prefixes
     return ((size_t)4 * h->sc.maxn + shared + h->tbl.max_actions) * 64 * 4;
 }
 bool traverse_fits_lds(const rp_mccfr* h) {
@@ -1594,6 +1597,20 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
     CREATE_TRY(hipMemcpy(h->d_states, packed.data(), packed.size() * sizeof(uint4), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(&h->d_children, h->children.size() * 4));
     CREATE_TRY(hipMemcpy(h->d_children, h->children.data(), h->children.size() * 4, hipMemcpyHostToDevice));
+    // child records: one load on arrival at a node instead of children[] -> states[] -> payoffs[]
+    std::vector<uint4> kids(h->children.size());
+    for (size_t c = 0; c < h->children.size(); ++c) {
+        const uint32_t sid = h->children[c];
+        uint4 r = packed[sid];
+        r.w = sid;
+        if (game->states[sid].n_children == 0 && game->n_players == 2) {
+            r.y = rp_f2u(h->payoffs[(size_t)game->states[sid].offset * 2 + 0]);
+            r.z = rp_f2u(h->payoffs[(size_t)game->states[sid].offset * 2 + 1]);
+        }
+        kids[c] = r;
+    }
+    CREATE_TRY(hipMalloc(&h->d_kids, std::max<size_t>(kids.size(), 1) * sizeof(uint4)));
+    CREATE_TRY(hipMemcpy(h->d_kids, kids.data(), kids.size() * sizeof(uint4), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(&h->d_payoffs, h->payoffs.size() * 4));
     CREATE_TRY(hipMemcpy(h->d_payoffs, h->payoffs.data(), h->payoffs.size() * 4, hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(&h->d_info_actions, game->n_infos));
@@ -1602,6 +1619,9 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
     CREATE_TRY(hipMemcpy(h->d_info_player, h->info_player.data(), game->n_infos, hipMemcpyHostToDevice));
     h->g.states = reinterpret_cast<const uint4*>(h->d_states);
     h->g.children = reinterpret_cast<const uint32_t*>(h->d_children);
+    h->g.kids = reinterpret_cast<const uint4*>(h->d_kids);
+    h->g.root_rec = packed[game->train_root];
+    h->g.root_rec.w = game->train_root;
     h->g.payoffs = reinterpret_cast<const float*>(h->d_payoffs);
     h->g.info_actions = reinterpret_cast<const uint8_t*>(h->d_info_actions);
     h->g.info_player = reinterpret_cast<const uint8_t*>(h->d_info_player);
@@ -1660,7 +1680,7 @@ int rp_mccfr_destroy(rp_mccfr* h) {
     clock_drain(h->clk_traverse);
     clock_drain(h->clk_compact);
     clock_drain(h->clk_update);
-    void* ptrs[] = {h->d_states, h->d_children, h->d_payoffs, h->d_info_actions, h->d_info_player, h->d_scratch,
+    void* ptrs[] = {h->d_states, h->d_children, h->d_kids, h->d_payoffs, h->d_info_actions, h->d_info_player, h->d_scratch,
                     h->d_dec, h->d_sorted, h->d_bmaps, h->d_itab, h->d_summary, h->d_counters, h->t.regret, h->t.weight, h->t.payoff, h->t.visits};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

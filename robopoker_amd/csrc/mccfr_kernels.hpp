@@ -13,6 +13,8 @@ namespace rp {
 struct DevGame {
     const uint4* states;
     const uint32_t* children;
+    const uint4* kids;            // [n_children] the child's state record, w = its state id; a terminal child of a
+                                  // two-player game carries its payoffs in y, z (no further load on arrival)
     const float* payoffs;         // [n_terminals][n_players]
     const uint8_t* info_actions;  // [n_infos]
     const uint8_t* info_player;   // [n_infos]
@@ -20,6 +22,7 @@ struct DevGame {
     uint32_t n_infos;
     uint32_t A;                   // table row stride (max_actions)
     uint32_t root;                // train_root
+    uint4 root_rec;               // states[root] with w = root
 };
 
 // regret/strategy tables, SoA by field, row-major [info][A] (Encounter, solver/encounter.rs:22-27)
