@@ -124,3 +124,38 @@ def test_composed_rejects_sign_dependent_discount_and_bad_arguments(gpu):
         SparseProfile(64, 17)
     with pytest.raises(_lib.RpError):
         g.rows([64])
+
+
+def test_full_size_table_properties(gpu):
+    # BASELINE configs[3] scale: 2^27 rows x 9 actions (19.3 GB in HBM), one 192 000-Decision Zipf batch per mode.
+    # Size-independent properties: visits count the touches exactly, untouched rows keep the default Encounter,
+    # ordered and composed agree within the stated tolerance.
+    n_rows, A, n = 1 << 27, 9, 192000
+    dr = np.array([100, 10, 0, 50, 0, 0, 0, 0, 0], dtype=np.float32)
+    batch = synthetic_batch(n, n_rows, A, seed=4)
+    db = DeviceBatch(*batch)
+    touched, counts = np.unique(batch[0], return_counts=True)
+    results = {}
+    for mode in ("ordered", "composed"):
+        g = SparseProfile(n_rows, A, "linear", "linear", default_regret=dr, max_batch=n)
+        g.set_epoch(7)
+        g.apply(db, mode)
+        g.sync()
+        rows = g.rows(touched)
+        nact = batch[1][np.searchsorted(np.sort(batch[0]), touched)]  # any touch of the row: |choices| is per row
+        order = np.argsort(batch[0], kind="stable")
+        nact = batch[1][order][np.concatenate([[0], np.cumsum(counts)[:-1]])]
+        for i in (0, len(touched) // 2, len(touched) - 1, int(np.argmax(counts))):
+            assert np.all(rows["visits"][i, : nact[i]] == counts[i])
+            assert np.all(rows["visits"][i, nact[i]:] == 0)
+        assert int(rows["visits"][:, 0].sum()) == n
+        probe = np.setdiff1d(np.array([0, 1, 12345678, n_rows - 1], dtype=np.uint32), touched)
+        if probe.size:
+            un = g.rows(probe)
+            assert np.all(un["visits"] == 0) and np.all(un["weight"] == 0) and np.all(un["payoff"] == 0)
+            assert np.array_equal(un["regret"], np.tile(dr, (probe.size, 1)))
+        assert g.epoch() == 8
+        results[mode] = rows
+        g.close()
+    for f in ("regret", "weight", "payoff"):
+        assert np.allclose(results["ordered"][f], results["composed"][f], rtol=2e-4, atol=1e-2), f
