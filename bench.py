@@ -130,6 +130,31 @@ def side_rate(args, g, local_rank, mode, steps=10):
     return (i1 - i0) / dt
 
 
+def init_rccl(rank, world):
+    """init_process_group + communicator creation with fd 1 pointed at stderr: RCCL prints a version banner to stdout
+    when the communicator is created, and stdout must carry exactly one JSON line."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        warm = torch.zeros(1, device="cuda")
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
+    finally:
+        import ctypes
+
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)  # the banner sits in the C library's stdout buffer: flush it to stderr now
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def kmeans_sharded(rank, world, local_rank, n_points=16384, K=256, bins=256, iters=2):
     """The k-means exchange on real GPUs: every rank owns `n_points` flop-like histograms (weak scaling), k-means++ draws
     through the exact integer prefix over ranks, one all-reduce(sum) of the integer centroid sums per Elkan iteration
@@ -191,9 +216,7 @@ def nlhe_synth(args, rank, world, local_rank):
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.force_sharded
     if sharded:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        init_rccl(rank, world)
     A = 9
     prof = SparseProfile(args.rows, A, "linear", "linear", max_batch=args.decisions * (world if sharded else 1), device=local_rank)
     host = [synthetic_batch(args.decisions, args.rows, A, seed=args.seed + 17 * rank + k) for k in range(4)]
@@ -300,9 +323,7 @@ def main():
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        init_rccl(rank, world)
 
     g = Game(args.game)
     A = g.max_actions
@@ -354,13 +375,6 @@ def main():
         dist.all_reduce(ti, op=dist.ReduceOp.SUM)
         infos = int(ti.item())
 
-    km_sharded = None
-    if sharded_mode and not args.no_kmeans:
-        try:  # the secondary measurement must never take the MCCFR line down with it
-            km_sharded = kmeans_sharded(rank, world, local_rank)
-        except Exception as exc:  # noqa: BLE001
-            km_sharded = {"error": f"{type(exc).__name__}: {exc}"}
-
     if rank == 0:
         # dominant kernel vs the HBM roofline.  Algorithmic bytes per infoset-update = key 24 B + A*16 B read
         # + A*16 B written = 24 + 32*A; the kernel that realises the update is "update".
@@ -411,15 +425,28 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args)
         else:
             line["cpu_baseline"] = None
-        if km_sharded is not None:
-            line["kmeans"] = km_sharded
-        elif world == 1 and not args.no_kmeans:
+        if world == 1 and not args.force_sharded and not args.no_kmeans:
             km = kmeans_secondary(args)
             if km is not None:
                 line["kmeans"] = km
         print(json.dumps(line), flush=True)
 
     solver.close()
+    if sharded_mode and not args.no_kmeans:
+        # The k-means exchange on the same ranks, AFTER the contract line is out (stdout carries exactly one JSON
+        # line; this result goes to stderr).  A watchdog ends the process cleanly if a collective ever hangs.
+        import threading
+
+        guard = threading.Timer(240.0, lambda: os._exit(0))
+        guard.daemon = True
+        guard.start()
+        try:
+            km = kmeans_sharded(rank, world, local_rank)
+        except Exception as exc:  # noqa: BLE001
+            km = {"error": f"{type(exc).__name__}: {exc}"}
+        if rank == 0:
+            print("kmeans_sharded: " + json.dumps(km), file=sys.stderr, flush=True)
+        guard.cancel()
     if sharded_mode:
         dist.barrier()
         dist.destroy_process_group()
