@@ -111,6 +111,26 @@ __device__ uint32_t d_sample_mask(const DevGame& g, const DevTables& t, const St
 
 __device__ __forceinline__ uint32_t lane_of() { return threadIdx.x & 63u; }
 
+// Metrics (metrics/mod.rs:21-80; solver.rs:273): nodes / infos, one atomic per WAVE — a million lanes adding to the
+// same two addresses would serialise in the L2 atomic unit
+__device__ __forceinline__ void count_metrics(const StepParams& p, uint32_t nn, uint32_t ndec, uint32_t err) {
+    if (__ballot(1) == ~0ull) {
+        uint32_t a = nn, b = ndec;
+        for (int d = 32; d > 0; d >>= 1) {
+            a += __shfl_xor(a, d, 64);
+            b += __shfl_xor(b, d, 64);
+        }
+        if (lane_of() == 0) {
+            atomicAdd(&p.counters[0], (unsigned long long)a);
+            atomicAdd(&p.counters[1], (unsigned long long)b);
+        }
+    } else {  // the ragged last wave
+        atomicAdd(&p.counters[0], (unsigned long long)nn);
+        atomicAdd(&p.counters[1], (unsigned long long)ndec);
+    }
+    if (err) atomicOr(&p.counters[2], (unsigned long long)err);
+}
+
 #define META_PARENT(m) ((m)&0xffu)
 #define META_EDGE(m) (((m) >> 8) & 0xffu)
 #define META_PTYPE(m) (((m) >> 16) & 3u)
@@ -286,9 +306,7 @@ __global__ __launch_bounds__(256) void k_traverse(DevGame g, DevTables t, DevScr
     }
     dc.ndec[lane] = (uint8_t)ndec;
     // Metrics: nodes / infos (metrics/mod.rs:21-80; solver.rs:273)
-    atomicAdd(&p.counters[0], (unsigned long long)nn);
-    atomicAdd(&p.counters[1], (unsigned long long)ndec);
-    if (err) atomicOr(&p.counters[2], (unsigned long long)err);
+    count_metrics(p, nn, ndec, err);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -375,8 +393,9 @@ __device__ __forceinline__ uint32_t d_sample_mask_tab(const DevGame& g, const De
 #define LM_INFO(m) ((m) >> 19)
 #define LM_NO_PARENT 63u
 
+template <bool TVREG>  // TVREG: at most 4 actions, the per-action values of a root live in registers, not LDS
 __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, DevDecisions dc, StepParams p, uint32_t maxn,
-                                                     uint32_t maxs) {
+                                                     uint32_t maxs, uint32_t maxi) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t ln = threadIdx.x;
     const uint32_t lane = blockIdx.x * 64 + ln;
@@ -384,16 +403,36 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
     float* nfr = reinterpret_cast<float*>(nm + (size_t)maxn * 64);   // [maxn][64] relative-reach factor of the incoming edge
     float* nfs = nfr + (size_t)maxn * 64;                            // [maxn][64] sampling-reach factor of the incoming edge
     float* nv = nfs + (size_t)maxn * 64;                             // [maxn][64] leaf: payoff; internal: child-value sum
-    float* tv = nv + (size_t)maxn * 64;                              // [A][64]
+    float* tv = nv + (size_t)maxn * 64;                              // [A][64] (absent when TVREG)
+    float tvr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto tv_set = [&](uint32_t e, float v) {
+        if (TVREG) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) tvr[q] = e == q ? v : tvr[q];
+        } else {
+            tv[e * 64 + ln] = v;
+        }
+    };
+    auto tv_get = [&](uint32_t e) -> float {
+        if (TVREG) {
+            float r = tvr[0];
+#pragma unroll
+            for (uint32_t q = 1; q < 4; ++q) r = e == q ? tvr[q] : r;
+            return r;
+        }
+        return tv[e * 64 + ln];
+    };
     // build phase: the DFS stack; evaluation phase: per-root reach prefixes of internal nodes (same storage)
-    uint32_t* ss = reinterpret_cast<uint32_t*>(tv + (size_t)g.A * 64);  // [maxs][6][64] stack: child record x,y,z,w | meta | frel
-    float* xr = reinterpret_cast<float*>(ss);                        // [maxn][64] relative reach root's child -> node
-    float* xs = xr + (size_t)maxn * 64;                              // [maxn][64] sampling reach root's child -> node
+    uint32_t* ss = reinterpret_cast<uint32_t*>(tv + (TVREG ? 0 : (size_t)g.A * 64));  // [maxs][5][64] stack: record x | meta << 16, y, z, w, frel
+    // reach prefixes exist for INTERNAL nodes only: slot = rank of the node among the internal nodes (popcount of a
+    // register mask), which keeps a Leduc tree at 128 dwords per lane = 5 waves per CU
+    float* xr = reinterpret_cast<float*>(ss);                        // [maxi][64] relative reach root's child -> node
+    float* xs = xr + (size_t)maxi * 64;                              // [maxi][64] sampling reach root's child -> node
     if (lane >= p.batch) return;
     const uint64_t tree_id = p.tree_base + lane;
     uint32_t err = 0;
 #define L(arr, slot) arr[(slot)*64 + ln]
-#define STK(e, f) ss[((e)*6u + (f)) * 64u + ln]
+#define STK(e, f) ss[((e)*5u + (f)) * 64u + ln]
 
     // ---- TreeBuilder::build (builder.rs:74-87,141-161): pop-last DFS -----------------------------
     // A node arrives as its RECORD (DevGame::kids): the records of all sampled children are requested together
@@ -404,6 +443,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
     uint32_t cur_in = LM_NO_PARENT | (PT_NONE << 10);
     float cur_frel = 1.0f, cur_fsmp = 1.0f;
     unsigned long long wmask = 0;  // walker decision nodes
+    unsigned long long imask = 0;  // internal nodes
     for (;;) {
         const uint32_t turn = rec.x & 0xffu, nch = (rec.x >> 8) & 0xffu, info = rec.y, off = rec.z;
         const uint32_t me = nn;
@@ -418,6 +458,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
         L(nfs, me) = cur_fsmp;
         nn += 1;
         if (nch > 0) {
+            imask |= 1ull << me;
             if (is_walker) wmask |= 1ull << me;
             uint32_t mask = d_sample_mask_tab(g, it, p, tree_id, rec.w, turn, nch, info, off);
             const bool chance = turn == RP_TURN_CHANCE;
@@ -433,12 +474,11 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     break;
                 }
                 const uint4 kr = g.kids[off + k];
-                STK(sp, 0) = kr.x;
+                STK(sp, 0) = kr.x | ((me | (k << 6) | (ptype << 10)) << 16);
                 STK(sp, 1) = kr.y;
                 STK(sp, 2) = kr.z;
                 STK(sp, 3) = kr.w;
-                STK(sp, 4) = me | (k << 6) | (ptype << 10);
-                STK(sp, 5) = rp_f2u(it.sigma[info * g.A + k]);  // only walker nodes push more than one child: fsmp = 1
+                STK(sp, 4) = rp_f2u(it.sigma[info * g.A + k]);  // only walker nodes push more than one child: fsmp = 1
                 sp += 1;
             }
             if (err) break;
@@ -450,15 +490,18 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
         L(nv, me) = g.n_players == 2 ? rp_u2f(p.walker == 0 ? rec.y : rec.z) : g.payoffs[off * g.n_players + p.walker];
         if (sp == 0) break;
         sp -= 1;
-        rec = make_uint4(STK(sp, 0), STK(sp, 1), STK(sp, 2), STK(sp, 3));
-        cur_in = STK(sp, 4);
-        cur_frel = rp_u2f(STK(sp, 5));
+        const uint32_t xm = STK(sp, 0);
+        rec = make_uint4(xm & 0xffffu, STK(sp, 1), STK(sp, 2), STK(sp, 3));
+        cur_in = xm >> 16;
+        cur_frel = rp_u2f(STK(sp, 4));
         cur_fsmp = 1.0f;
     }
 #undef STK
 
     // ---- Tree::partition + CfrFlow::dfs per walker infoset (tree.rs:88-98, flow.rs:64-87) --------
+#define ISLOT(n) ((uint32_t)__popcll(imask & ((1ull << (n)) - 1ull)))
     uint32_t ndec = 0;
+    if (nn - (uint32_t)__popcll(imask) > maxn || (uint32_t)__popcll(imask) > maxi) err |= ERR_NODE_CAPACITY;
     if (!err) {
         unsigned long long todo = wmask;
         while (todo) {
@@ -491,11 +534,13 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     if (LM_LEAF(mn)) continue;
                     float rel = 1.0f, smp = 1.0f;
                     if (par != j) {
-                        rel = L(xr, par) * L(nfr, n);
-                        smp = L(xs, par) * L(nfs, n);
+                        const uint32_t ps = ISLOT(par);
+                        rel = L(xr, ps) * L(nfr, n);
+                        smp = L(xs, ps) * L(nfs, n);
                     }
-                    L(xr, n) = rel;
-                    L(xs, n) = smp;
+                    const uint32_t ns = ISLOT(n);
+                    L(xr, ns) = rel;
+                    L(xs, ns) = smp;
                     L(nv, n) = 0.0f;
                 }
                 // bottom-up: descending node index adds children in choices() order (node.rs:103-107)
@@ -507,13 +552,14 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     if (LM_LEAF(mn)) {
                         float rel = 1.0f, smp = 1.0f;
                         if (par != j) {
-                            rel = L(xr, par) * L(nfr, n);
-                            smp = L(xs, par) * L(nfs, n);
+                            const uint32_t ps = ISLOT(par);
+                            rel = L(xr, ps) * L(nfr, n);
+                            smp = L(xs, ps) * L(nfs, n);
                         }
                         v = rel / smp * v;
                     }
                     if (par == j) {
-                        L(tv, LM_EDGE(mn)) = v;
+                        tv_set(LM_EDGE(mn), v);
                         kids |= 1u << LM_EDGE(mn);
                     } else {
                         L(nv, par) = L(nv, par) + v;
@@ -535,8 +581,8 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                 float ev = 0.0f;
                 for (uint32_t a = 0; a < nact; ++a) {
                     if (!((kids >> a) & 1u)) continue;
-                    const float u = reach * L(tv, a);
-                    L(tv, a) = u;
+                    const float u = reach * tv_get(a);
+                    tv_set(a, u);
                     ev += it.sigma[info * g.A + a] * u;
                 }
                 payoff += ev;
@@ -545,7 +591,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     const size_t k = (slot * g.A + a) * D + lane;
                     // first root of the span writes, later roots accumulate (0 + x = x exactly)
                     const float prev = (expanded >> a) & 1u ? dc.regret[k] : 0.0f;
-                    dc.regret[k] = prev + (L(tv, a) - ev);
+                    dc.regret[k] = prev + (tv_get(a) - ev);
                 }
                 expanded |= kids;
             }
@@ -560,10 +606,9 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
         }
     }
 #undef L
+#undef ISLOT
     dc.ndec[lane] = (uint8_t)ndec;
-    atomicAdd(&p.counters[0], (unsigned long long)nn);
-    atomicAdd(&p.counters[1], (unsigned long long)ndec);
-    if (err) atomicOr(&p.counters[2], (unsigned long long)err);
+    count_metrics(p, nn, ndec, err);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1244,6 +1289,7 @@ struct rp_mccfr {
     void* d_summary = nullptr;
     void* d_sorted = nullptr;
     void* d_bmaps = nullptr;
+    uint32_t maxint = 1;  // most internal nodes of a sampled tree
     void* d_itab = nullptr;
     DevInfoTab itab{};
     DevSorted so{};
@@ -1275,9 +1321,9 @@ size_t summary_bytes_of(const rp_mccfr* h) {
 }
 
 // largest number of walker nodes / stack entries an externally sampled tree can have
-void sampled_tree_bounds(const rp_mccfr* h, uint32_t* maxdec, uint32_t* maxstack) {
+void sampled_tree_bounds(const rp_mccfr* h, uint32_t* maxdec, uint32_t* maxstack, uint32_t* maxint) {
     const rp_game_table& t = h->tbl;
-    uint32_t best_dec = 1, best_stack = 1;
+    uint32_t best_dec = 1, best_stack = 1, best_int = 1;
     for (uint32_t w = 0; w < t.n_players; ++w) {
         std::function<uint32_t(uint32_t)> wn = [&](uint32_t s) -> uint32_t {
             const rp_state& st = h->states[s];
@@ -1297,11 +1343,24 @@ void sampled_tree_bounds(const rp_mccfr* h, uint32_t* maxdec, uint32_t* maxstack
             uint32_t pushed = st.turn == w ? st.n_children : 1u;
             return pushed - 1 + std::max(deepest, 1u);
         };
+        // internal (expanded) nodes of a sampled tree
+        std::function<uint32_t(uint32_t)> ins = [&](uint32_t s) -> uint32_t {
+            const rp_state& st = h->states[s];
+            if (!st.n_children) return 0;
+            uint32_t acc = 0;
+            for (uint32_t k = 0; k < st.n_children; ++k) {
+                uint32_t c = ins(h->children[st.offset + k]);
+                acc = st.turn == w ? acc + c : std::max(acc, c);
+            }
+            return acc + 1;
+        };
+        best_int = std::max(best_int, ins(t.train_root));
         best_dec = std::max(best_dec, wn(t.train_root));
         best_stack = std::max(best_stack, stk(t.train_root));
     }
     *maxdec = best_dec;
     *maxstack = best_stack + 1;
+    *maxint = best_int;
 }
 
 int alloc_batch_buffers(rp_mccfr* h, uint32_t batch) {
@@ -1414,10 +1473,11 @@ void clock_drain(KernelClock& c) {
 }
 
 size_t traverse_lds_bytes(const rp_mccfr* h) {
-    const size_t shared = std::max<size_t>(2 * (size_t)h->sc.maxn, 6 * (size_t)h->sc.maxs);  // stack, then reach prefixes
-    return ((size_t)4 * h->sc.maxn + shared + h->tbl.max_actions) * 64 * 4;
+    const size_t shared = std::max<size_t>(2 * (size_t)h->maxint, 5 * (size_t)h->sc.maxs);  // stack, then reach prefixes
+    return ((size_t)4 * h->sc.maxn + shared + (h->tbl.max_actions <= 4 ? 0 : h->tbl.max_actions)) * 64 * 4;
 }
 bool traverse_fits_lds(const rp_mccfr* h) {
+    if (getenv("RP_DEBUG")) fprintf(stderr, "traverse: maxn=%u maxs=%u maxint=%u lds=%zu B/wave\n", h->sc.maxn, h->sc.maxs, h->maxint, traverse_lds_bytes(h));
     return h->sc.maxn <= 62 && h->tbl.max_depth <= 10 && h->tbl.n_infos <= 8191 && h->tbl.max_actions <= 16 &&
            traverse_lds_bytes(h) <= 64 * 1024;
 }
@@ -1427,8 +1487,14 @@ int launch_traverse(rp_mccfr* h, const StepParams& p) {
     clock_begin(h, h->clk_traverse);
     if (h->use_lds_traverse) {
         hipLaunchKernelGGL(k_prepare_infos, dim3((h->tbl.n_infos + 63) / 64), dim3(64), 0, h->stream, h->g, h->t, p, h->itab);
-        hipLaunchKernelGGL(k_traverse_lds, dim3((h->batch + 63) / 64), dim3(64), traverse_lds_bytes(h), h->stream, h->g, h->itab,
-                           h->dc, p, h->sc.maxn, h->sc.maxs);
+        const char* pad = getenv("RP_TRAV_PAD_LDS");  // occupancy experiments
+        const size_t lds = traverse_lds_bytes(h) + (pad ? atoi(pad) : 0);
+        if (h->tbl.max_actions <= 4)
+            hipLaunchKernelGGL(k_traverse_lds<true>, dim3((h->batch + 63) / 64), dim3(64), lds, h->stream, h->g, h->itab, h->dc, p,
+                               h->sc.maxn, h->sc.maxs, h->maxint);
+        else
+            hipLaunchKernelGGL(k_traverse_lds<false>, dim3((h->batch + 63) / 64), dim3(64), lds, h->stream, h->g, h->itab, h->dc, p,
+                               h->sc.maxn, h->sc.maxs, h->maxint);
     } else {
         const uint32_t threads = 256, blocks = (h->batch + threads - 1) / threads;
         hipLaunchKernelGGL(k_traverse, dim3(blocks), dim3(threads), 0, h->stream, h->g, h->t, h->sc, h->dc, p);
@@ -1651,7 +1717,7 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
         h->itab.keep = reinterpret_cast<uint32_t*>(f + 3 * cells + game->n_infos);
     }
     uint32_t maxstack = 1;
-    sampled_tree_bounds(h, &h->maxdec, &maxstack);
+    sampled_tree_bounds(h, &h->maxdec, &maxstack, &h->maxint);
     h->sc.maxn = game->max_tree_nodes;
     h->sc.maxs = maxstack;
     if (h->maxdec > 254) {
