@@ -154,8 +154,16 @@ __global__ void k_block_counts(const uint32_t* counts, const uint32_t* n_segs, u
     if (g < n) nblk[g] = g < *n_segs ? (counts[g] + RP_SPARSE_BLOCK - 1u) / RP_SPARSE_BLOCK : 0u;
 }
 
+// block -> row index, so that a block's group finds its row with one load
+__global__ void k_block_index(const uint32_t* nblk, const uint32_t* boff, const uint32_t* n_segs, uint32_t* blkseg) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= *n_segs) return;
+    const uint32_t nb = nblk[g], base = boff[g];
+    for (uint32_t k = 0; k < nb; ++k) blkseg[base + k] = g;
+}
+
 __global__ __launch_bounds__(256) void k_block_maps_sparse(SparseParams p, DevBatch b, Segments sg, const uint32_t* nblk,
-                                                           const uint32_t* boff, unsigned char* entries,
+                                                           const uint32_t* boff, const uint32_t* blkseg, unsigned char* entries,
                                                            unsigned char* blocks, uint32_t entry_bytes, uint32_t max_blocks) {
     const uint32_t n_segs = *sg.n_segs;
     if (n_segs == 0) return;
@@ -166,13 +174,7 @@ __global__ __launch_bounds__(256) void k_block_maps_sparse(SparseParams p, DevBa
     const Map ident{1.0f, 0.0f, NEG_INF, 0u};
     for (uint32_t bi = (blockIdx.x * blockDim.x + threadIdx.x) / GROUP; bi < total && bi < max_blocks;
          bi += gridDim.x * blockDim.x / GROUP) {
-        // segment of block bi: last g with boff[g] <= bi
-        uint32_t lo = 0, hi = n_segs - 1;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1u) >> 1;
-            if (boff[mid] <= bi) lo = mid; else hi = mid - 1u;
-        }
-        const uint32_t g = lo, blk = bi - boff[g];
+        const uint32_t g = blkseg[bi], blk = bi - boff[g];
         const uint32_t cnt = sg.counts[g];
         const uint32_t t_lo = blk * RP_SPARSE_BLOCK, t_hi = min(cnt, t_lo + RP_SPARSE_BLOCK);
         const uint32_t off = sg.offsets[g];
@@ -447,6 +449,7 @@ struct rp_profile {
     uint32_t *iota = nullptr, *keys_out = nullptr, *perm = nullptr, *seg_rows = nullptr, *seg_counts = nullptr,
              *seg_offsets = nullptr, *n_segs = nullptr, *ent_rows = nullptr, *nblk = nullptr, *boff = nullptr;
     unsigned char* blocks = nullptr;   // block records of multi-block rows
+    uint32_t* blkseg = nullptr;        // [max blocks] row index of every block
     uint32_t* hot = nullptr;           // [HOT_CAP + 1] rows with more than RP_FOLD_GROUP blocks; last slot = counter
     float *srt_regret = nullptr, *srt_policy = nullptr, *srt_payoff = nullptr;  // the batch in sorted order (ordered mode)
     uint16_t* srt_expanded = nullptr;
@@ -489,12 +492,14 @@ static void sp_drain(SpClock& c) {
 
 static void free_workspace(rp_profile* h) {
     for (void* p : {(void*)h->iota, (void*)h->keys_out, (void*)h->perm, (void*)h->seg_rows, (void*)h->seg_counts,
-                    (void*)h->seg_offsets, (void*)h->ent_rows, (void*)h->nblk, (void*)h->boff, (void*)h->blocks, h->cub_tmp,
+                    (void*)h->seg_offsets, (void*)h->ent_rows, (void*)h->nblk, (void*)h->boff, (void*)h->blocks, (void*)h->blkseg,
+                    h->cub_tmp,
                     (void*)h->entries, (void*)h->srt_regret, (void*)h->srt_policy, (void*)h->srt_payoff,
                     (void*)h->srt_expanded})
         if (p) (void)hipFree(p);
     h->iota = h->keys_out = h->perm = h->seg_rows = h->seg_counts = h->seg_offsets = h->ent_rows = h->nblk = h->boff = nullptr;
     h->blocks = nullptr;
+    h->blkseg = nullptr;
     h->srt_regret = h->srt_policy = h->srt_payoff = nullptr;
     h->srt_expanded = nullptr;
     h->cub_tmp = nullptr;
@@ -523,6 +528,7 @@ static int ensure_capacity(rp_profile* h, uint32_t n) {
     HIP_TRY(hipMalloc(&h->nblk, (size_t)cap * 4));
     HIP_TRY(hipMalloc(&h->boff, (size_t)cap * 4));
     HIP_TRY(hipMalloc(&h->blocks, (size_t)max_blocks_of(cap) * entry_bytes_of(h)));
+    HIP_TRY(hipMalloc(&h->blkseg, (size_t)max_blocks_of(cap) * 4));
     size_t s1 = 0, s2 = 0, s3 = 0;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, s1, h->iota, h->keys_out, h->iota, h->perm, (int)cap, 0, 32, h->stream));
     HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, s2, h->keys_out, h->seg_rows, h->seg_counts, h->n_segs, (int)cap, h->stream));
@@ -598,8 +604,9 @@ static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch
     size_t tmp = h->cub_bytes;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp, tmp, h->nblk, h->boff, (int)n, h->stream));
     const uint32_t mb = max_blocks_of(n);
-    hipLaunchKernelGGL(k_block_maps_sparse, dim3(group_blocks(mb)), dim3(256), 0, h->stream, p, b, sg, h->nblk, h->boff, entries,
-                       h->blocks, eb, mb);
+    hipLaunchKernelGGL(k_block_index, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->nblk, h->boff, h->n_segs, h->blkseg);
+    hipLaunchKernelGGL(k_block_maps_sparse, dim3(group_blocks(mb)), dim3(256), 0, h->stream, p, b, sg, h->nblk, h->boff, h->blkseg,
+                       entries, h->blocks, eb, mb);
     HIP_TRY(hipMemsetAsync(h->hot + HOT_CAP, 0, 4, h->stream));
     hipLaunchKernelGGL(k_seg_fold, dim3(group_blocks(n)), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb,
                        h->hot, h->hot + HOT_CAP, (uint32_t)HOT_CAP);
