@@ -393,16 +393,18 @@ __device__ __forceinline__ uint32_t d_sample_mask_tab(const DevGame& g, const De
 #define LM_INFO(m) ((m) >> 19)
 #define LM_NO_PARENT 63u
 
-template <bool TVREG>  // TVREG: at most 4 actions, the per-action values of a root live in registers, not LDS
+// TVREG:  at most 4 actions, the per-action values of a root live in registers, not LDS.
+// TABLDS: the per-infoset sigma / q tables fit in LDS (a copy per wave); otherwise they are read through L1.
+// A node is TWO dwords (meta, value): the reach factor of its incoming edge is not stored but looked up as
+// table[infoset(parent)][edge] whenever a sweep needs it.  Leduc: 78 dwords per lane + 1.9 KB of tables = 7 waves/CU.
+template <bool TVREG, bool TABLDS>
 __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, DevDecisions dc, StepParams p, uint32_t maxn,
                                                      uint32_t maxs, uint32_t maxi) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t ln = threadIdx.x;
     const uint32_t lane = blockIdx.x * 64 + ln;
     uint32_t* nm = lds;                                              // [maxn][64] meta
-    float* nfr = reinterpret_cast<float*>(nm + (size_t)maxn * 64);   // [maxn][64] relative-reach factor of the incoming edge
-    float* nfs = nfr + (size_t)maxn * 64;                            // [maxn][64] sampling-reach factor of the incoming edge
-    float* nv = nfs + (size_t)maxn * 64;                             // [maxn][64] leaf: payoff; internal: child-value sum
+    float* nv = reinterpret_cast<float*>(nm + (size_t)maxn * 64);    // [maxn][64] leaf: payoff; internal: child-value sum
     float* tv = nv + (size_t)maxn * 64;                              // [A][64] (absent when TVREG)
     float tvr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     auto tv_set = [&](uint32_t e, float v) {
@@ -423,16 +425,38 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
         return tv[e * 64 + ln];
     };
     // build phase: the DFS stack; evaluation phase: per-root reach prefixes of internal nodes (same storage)
-    uint32_t* ss = reinterpret_cast<uint32_t*>(tv + (TVREG ? 0 : (size_t)g.A * 64));  // [maxs][5][64] stack: record x | meta << 16, y, z, w, frel
+    uint32_t* ss = reinterpret_cast<uint32_t*>(tv + (TVREG ? 0 : (size_t)g.A * 64));  // [maxs][4][64] stack: record x | meta << 16, y, z, w
     // reach prefixes exist for INTERNAL nodes only: slot = rank of the node among the internal nodes (popcount of a
-    // register mask), which keeps a Leduc tree at 128 dwords per lane = 5 waves per CU
+    // register mask)
     float* xr = reinterpret_cast<float*>(ss);                        // [maxi][64] relative reach root's child -> node
     float* xs = xr + (size_t)maxi * 64;                              // [maxi][64] sampling reach root's child -> node
+    const uint32_t shared_rows = max(2u * maxi, 4u * maxs);
+    float* tab = reinterpret_cast<float*>(ss) + (size_t)shared_rows * 64;  // [2][n_infos * A] sigma, q (TABLDS)
+    const uint32_t cells = g.n_infos * g.A;
+    if (TABLDS) {
+        for (uint32_t e = ln; e < cells; e += 64) {
+            tab[e] = it.sigma[e];
+            tab[cells + e] = it.q[e];
+        }
+        __syncthreads();
+    }
+    auto SIG = [&](uint32_t e) -> float { return TABLDS ? tab[e] : it.sigma[e]; };
+    auto QQ = [&](uint32_t e) -> float { return TABLDS ? tab[cells + e] : it.q[e]; };
     if (lane >= p.batch) return;
     const uint64_t tree_id = p.tree_base + lane;
     uint32_t err = 0;
 #define L(arr, slot) arr[(slot)*64 + ln]
-#define STK(e, f) ss[((e)*5u + (f)) * 64u + ln]
+#define STK(e, f) ss[((e)*4u + (f)) * 64u + ln]
+    // reach factors of the edge into a node (meta mn): sigma / q of the parent's infoset at the node's edge
+    auto fr_of = [&](uint32_t mn) -> float {
+        const uint32_t pt = LM_PTYPE(mn);
+        if (pt != PT_WALKER && pt != PT_OPP) return 1.0f;
+        return SIG(LM_INFO(L(nm, LM_PARENT(mn))) * g.A + LM_EDGE(mn));
+    };
+    auto fs_of = [&](uint32_t mn) -> float {
+        if (LM_PTYPE(mn) != PT_OPP) return 1.0f;
+        return QQ(LM_INFO(L(nm, LM_PARENT(mn))) * g.A + LM_EDGE(mn));
+    };
 
     // ---- TreeBuilder::build (builder.rs:74-87,141-161): pop-last DFS -----------------------------
     // A node arrives as its RECORD (DevGame::kids): the records of all sampled children are requested together
@@ -441,7 +465,6 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
     uint32_t nn = 0, sp = 0;
     uint4 rec = g.root_rec;
     uint32_t cur_in = LM_NO_PARENT | (PT_NONE << 10);
-    float cur_frel = 1.0f, cur_fsmp = 1.0f;
     unsigned long long wmask = 0;  // walker decision nodes
     unsigned long long imask = 0;  // internal nodes
     for (;;) {
@@ -454,8 +477,6 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
         const bool is_walker = turn == p.walker;
         L(nm, me) = cur_in | ((nch == 0 ? 1u : 0u) << 12) | ((is_walker ? 1u : 0u) << 13) | (nch << 14) |
                     ((turn < RP_TURN_CHANCE ? info : 0u) << 19);
-        L(nfr, me) = cur_frel;
-        L(nfs, me) = cur_fsmp;
         nn += 1;
         if (nch > 0) {
             imask |= 1ull << me;
@@ -478,13 +499,10 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                 STK(sp, 1) = kr.y;
                 STK(sp, 2) = kr.z;
                 STK(sp, 3) = kr.w;
-                STK(sp, 4) = rp_f2u(it.sigma[info * g.A + k]);  // only walker nodes push more than one child: fsmp = 1
                 sp += 1;
             }
             if (err) break;
             cur_in = me | (last << 6) | (ptype << 10);
-            cur_frel = chance ? 1.0f : it.sigma[info * g.A + last];
-            cur_fsmp = ptype == PT_OPP ? it.q[info * g.A + last] : 1.0f;
             continue;
         }
         L(nv, me) = g.n_players == 2 ? rp_u2f(p.walker == 0 ? rec.y : rec.z) : g.payoffs[off * g.n_players + p.walker];
@@ -493,8 +511,6 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
         const uint32_t xm = STK(sp, 0);
         rec = make_uint4(xm & 0xffffu, STK(sp, 1), STK(sp, 2), STK(sp, 3));
         cur_in = xm >> 16;
-        cur_frel = rp_u2f(STK(sp, 4));
-        cur_fsmp = 1.0f;
     }
 #undef STK
 
@@ -535,8 +551,8 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     float rel = 1.0f, smp = 1.0f;
                     if (par != j) {
                         const uint32_t ps = ISLOT(par);
-                        rel = L(xr, ps) * L(nfr, n);
-                        smp = L(xs, ps) * L(nfs, n);
+                        rel = L(xr, ps) * fr_of(mn);
+                        smp = L(xs, ps) * fs_of(mn);
                     }
                     const uint32_t ns = ISLOT(n);
                     L(xr, ns) = rel;
@@ -553,8 +569,8 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                         float rel = 1.0f, smp = 1.0f;
                         if (par != j) {
                             const uint32_t ps = ISLOT(par);
-                            rel = L(xr, ps) * L(nfr, n);
-                            smp = L(xs, ps) * L(nfs, n);
+                            rel = L(xr, ps) * fr_of(mn);
+                            smp = L(xs, ps) * fs_of(mn);
                         }
                         v = rel / smp * v;
                     }
@@ -572,8 +588,8 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     const uint32_t par = LM_PARENT(mn);
                     if (par == LM_NO_PARENT) break;
                     if (LM_PTYPE(mn) == PT_OPP) {
-                        cf = cf * L(nfr, n);
-                        sm_ = sm_ * L(nfs, n);
+                        cf = cf * fr_of(mn);
+                        sm_ = sm_ * fs_of(mn);
                     }
                     n = par;
                 }
@@ -583,7 +599,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     if (!((kids >> a) & 1u)) continue;
                     const float u = reach * tv_get(a);
                     tv_set(a, u);
-                    ev += it.sigma[info * g.A + a] * u;
+                    ev += SIG(info * g.A + a) * u;
                 }
                 payoff += ev;
                 for (uint32_t a = 0; a < nact; ++a) {
@@ -596,7 +612,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                 expanded |= kids;
             }
             for (uint32_t a = 0; a < nact; ++a) {  // policy_vector = iterated_distribution (profile.rs:47-51)
-                dc.policy[(slot * g.A + a) * D + lane] = it.sigma[info * g.A + a];
+                dc.policy[(slot * g.A + a) * D + lane] = SIG(info * g.A + a);
                 if (!((expanded >> a) & 1u)) dc.regret[(slot * g.A + a) * D + lane] = 0.0f;
             }
             dc.info[slot * D + lane] = info;
@@ -1472,9 +1488,12 @@ void clock_drain(KernelClock& c) {
     c.pending.clear();
 }
 
+// the per-infoset sigma / q tables ride in LDS when they are small (a copy per wave)
+bool traverse_tables_in_lds(const rp_mccfr* h) { return (size_t)2 * h->tbl.n_infos * h->tbl.max_actions * 4 <= 4096; }
 size_t traverse_lds_bytes(const rp_mccfr* h) {
-    const size_t shared = std::max<size_t>(2 * (size_t)h->maxint, 5 * (size_t)h->sc.maxs);  // stack, then reach prefixes
-    return ((size_t)4 * h->sc.maxn + shared + (h->tbl.max_actions <= 4 ? 0 : h->tbl.max_actions)) * 64 * 4;
+    const size_t shared = std::max<size_t>(2 * (size_t)h->maxint, 4 * (size_t)h->sc.maxs);  // stack, then reach prefixes
+    return ((size_t)2 * h->sc.maxn + shared + (h->tbl.max_actions <= 4 ? 0 : h->tbl.max_actions)) * 64 * 4 +
+           (traverse_tables_in_lds(h) ? (size_t)2 * h->tbl.n_infos * h->tbl.max_actions * 4 : 0);
 }
 bool traverse_fits_lds(const rp_mccfr* h) {
     if (getenv("RP_DEBUG")) fprintf(stderr, "traverse: maxn=%u maxs=%u maxint=%u lds=%zu B/wave\n", h->sc.maxn, h->sc.maxs, h->maxint, traverse_lds_bytes(h));
@@ -1489,12 +1508,15 @@ int launch_traverse(rp_mccfr* h, const StepParams& p) {
         hipLaunchKernelGGL(k_prepare_infos, dim3((h->tbl.n_infos + 63) / 64), dim3(64), 0, h->stream, h->g, h->t, p, h->itab);
         const char* pad = getenv("RP_TRAV_PAD_LDS");  // occupancy experiments
         const size_t lds = traverse_lds_bytes(h) + (pad ? atoi(pad) : 0);
-        if (h->tbl.max_actions <= 4)
-            hipLaunchKernelGGL(k_traverse_lds<true>, dim3((h->batch + 63) / 64), dim3(64), lds, h->stream, h->g, h->itab, h->dc, p,
-                               h->sc.maxn, h->sc.maxs, h->maxint);
-        else
-            hipLaunchKernelGGL(k_traverse_lds<false>, dim3((h->batch + 63) / 64), dim3(64), lds, h->stream, h->g, h->itab, h->dc, p,
-                               h->sc.maxn, h->sc.maxs, h->maxint);
+        const dim3 grid((h->batch + 63) / 64), block(64);
+        const bool tvreg = h->tbl.max_actions <= 4, tablds = traverse_tables_in_lds(h);
+#define LAUNCH_TRAVERSE(TV, TB) \
+    hipLaunchKernelGGL((k_traverse_lds<TV, TB>), grid, block, lds, h->stream, h->g, h->itab, h->dc, p, h->sc.maxn, h->sc.maxs, h->maxint)
+        if (tvreg && tablds) LAUNCH_TRAVERSE(true, true);
+        else if (tvreg) LAUNCH_TRAVERSE(true, false);
+        else if (tablds) LAUNCH_TRAVERSE(false, true);
+        else LAUNCH_TRAVERSE(false, false);
+#undef LAUNCH_TRAVERSE
     } else {
         const uint32_t threads = 256, blocks = (h->batch + threads - 1) / threads;
         hipLaunchKernelGGL(k_traverse, dim3(blocks), dim3(threads), 0, h->stream, h->g, h->t, h->sc, h->dc, p);
