@@ -188,8 +188,6 @@ typedef struct ora_kmeans {
     float* lower_store;
     uint8_t* prior; /* Prior<N> (prior.rs:20) */
     float* pot;     /* k-means++ potentials */
-    float* pw;      /* pairwise scratch of a split step */
-    ora_hist* nc;   /* partial centroid sums of a split step */
     int has_prior;
 } ora_kmeans;
 
@@ -236,7 +234,7 @@ ORA_API ora_kmeans* ora_kmeans_create(uint32_t K, uint64_t N, uint32_t bins, con
 ORA_API void ora_kmeans_destroy(ora_kmeans* h) {
     if (!h) return;
     free(h->tri); free(h->points); free(h->self_p); free(h->cent); free(h->self_c);
-    free(h->bounds); free(h->lower_store); free(h->prior); free(h->pot); free(h->pw); free(h->nc); free(h);
+    free(h->bounds); free(h->lower_store); free(h->prior); free(h->pot); free(h);
 }
 
 ORA_API void ora_kmeans_set_centroids(ora_kmeans* h, const uint64_t* idx) {
