@@ -396,7 +396,7 @@ __device__ __forceinline__ uint32_t d_sample_mask_tab(const DevGame& g, const De
 // TVREG:  at most 4 actions, the per-action values of a root live in registers, not LDS.
 // TABLDS: the per-infoset sigma / q tables fit in LDS (a copy per wave); otherwise they are read through L1.
 // A node is TWO dwords (meta, value): the reach factor of its incoming edge is not stored but looked up as
-// table[infoset(parent)][edge] whenever a sweep needs it.  Leduc: 78 dwords per lane + 1.9 KB of tables = 7 waves/CU.
+// table[infoset(parent)][edge] whenever a sweep needs it.  Leduc: 78 dwords per lane = 8 waves/CU.
 template <bool TVREG, bool TABLDS>
 __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, DevDecisions dc, StepParams p, uint32_t maxn,
                                                      uint32_t maxs, uint32_t maxi) {
@@ -1488,8 +1488,11 @@ void clock_drain(KernelClock& c) {
     c.pending.clear();
 }
 
-// the per-infoset sigma / q tables ride in LDS when they are small (a copy per wave)
-bool traverse_tables_in_lds(const rp_mccfr* h) { return (size_t)2 * h->tbl.n_infos * h->tbl.max_actions * 4 <= 4096; }
+// The per-infoset sigma / q tables can ride in LDS (a copy per wave) when they are small; measured on Leduc the L1 path
+// at 8 waves/CU beats the LDS copy at 7 (0.54 vs 0.57 ms per 2^20 trees), so LDS is opt-in (RP_TRAV_TAB_LDS=1).
+bool traverse_tables_in_lds(const rp_mccfr* h) {
+    return (size_t)2 * h->tbl.n_infos * h->tbl.max_actions * 4 <= 4096 && getenv("RP_TRAV_TAB_LDS");
+}
 size_t traverse_lds_bytes(const rp_mccfr* h) {
     const size_t shared = std::max<size_t>(2 * (size_t)h->maxint, 4 * (size_t)h->sc.maxs);  // stack, then reach prefixes
     return ((size_t)2 * h->sc.maxn + shared + (h->tbl.max_actions <= 4 ? 0 : h->tbl.max_actions)) * 64 * 4 +
