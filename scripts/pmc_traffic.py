@@ -31,7 +31,7 @@ def main():
     write = per_kernel(write_csv, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
-        if not k.startswith("rp::"):
+        if "rp::" not in k:
             continue
         fk, wk = fetch.get(k, 0.0), write.get(k, 0.0)
         kernels[k] = {"fetch_kb_raw": fk, "write_kb_raw": wk, "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
