@@ -192,6 +192,23 @@ def kmeans_sharded(rank, world, local_rank, n_points=16384, K=256, bins=256, ite
             "kmeanspp_s": t_kpp}
 
 
+def convergence(args, g, local_rank, batch=1 << 16, epochs=512):
+    """That the measured configuration actually solves the game: exploitability of the average strategy after a short
+    run in the benchmarked update mode (the reference's Leduc test asserts < 0.08, crates/leduc/src/solver.rs:105-123)."""
+    from robopoker_amd.mccfr import Solver
+
+    s = Solver(g, args.regret, args.weight, args.sampling, batch=batch, seed=args.seed, device=local_rank)
+    s.set_update_mode(args.update)
+    t0 = time.perf_counter()
+    s.solve(batch * epochs)
+    s.sync()
+    dt = time.perf_counter() - t0
+    out = {"exploitability": s.exploitability(), "epochs": epochs, "batch": batch, "trees": batch * epochs, "seconds": dt,
+           "update": args.update, "reference_threshold": 0.08}
+    s.close()
+    return out
+
+
 def kmeans_secondary(args):
     try:
         from robopoker_amd import lloyd
@@ -421,6 +438,8 @@ def main():
             },
             "other_update_mode": {"update": other, "value": other_rate, "unit": "infoset-updates/s"},
         }
+        if world == 1 and not args.force_sharded and args.game == "leduc":
+            line["convergence"] = convergence(args, g, local_rank)
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args)
         else:

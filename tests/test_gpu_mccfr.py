@@ -213,6 +213,18 @@ def test_leduc_converges_like_the_reference(gpu):
     assert dev.exploitability() < 0.080
 
 
+@pytest.mark.parametrize("batch,epochs", [(4096, 1024), (1 << 18, 256)])
+def test_leduc_converges_in_composed_mode(gpu, batch, epochs):
+    # the re-associated update solves the game too: same threshold as the reference's test, at the batch sizes the
+    # benchmark runs (an epoch = one batch; large batches need far fewer epochs than the reference's batch of 1)
+    g = Game("leduc")
+    dev = Solver(g, "floored", "linear", "external", batch=batch, seed=18)
+    dev.set_update_mode("composed")
+    dev.solve(batch * epochs)
+    assert dev.epoch == epochs
+    assert dev.exploitability() < 0.080
+
+
 def test_kuhn_nash_on_device(gpu):
     g = Game("kuhn")
     dev = Solver(g, "floored", "linear", "external", batch=1024, seed=7)
