@@ -153,12 +153,19 @@ __device__ __forceinline__ float softmin_fold(float s, const SoftminGroup& gq) {
     s += e0.x; s += e0.y; s += e1.x; s += e1.y; s += e2.x; s += e2.y; s += e3.x; s += e3.y;
     return s;
 }
+template <bool PIPE = true>
 __device__ __forceinline__ float softmin_sum(const uint16_t* sup, const float* pot, uint32_t cnt,
                                               __amdgpu_buffer_rsrc_t rt, uint32_t bins, uint32_t xi) {
     const uint32_t rowb = bins * 4u, xoff = xi * 4u;
     float s = 0.0f;
     uint32_t j = 0;
-    if (cnt >= 8) {  // software pipeline: the loads of group j+8 are in flight while group j is exponentiated
+    if (!PIPE) {  // one group in flight: 16 fewer VGPRs (the two-point kernels keep 7 waves per SIMD with it)
+        for (; j + 8 <= cnt; j += 8) {
+            SoftminGroup cur;
+            softmin_fetch(cur, sup, pot, j, rt, rowb, xoff);
+            s = softmin_fold(s, cur);
+        }
+    } else if (cnt >= 8) {  // software pipeline: the loads of group j+8 are in flight while group j is exponentiated
         SoftminGroup cur, nxt;
         softmin_fetch(cur, sup, pot, 0, rt, rowb, xoff);
         for (j = 8; j + 8 <= cnt; j += 8) {
@@ -250,6 +257,189 @@ __device__ __forceinline__ float wave_divergence(WaveLds& w, uint32_t m, uint32_
     const float xy = wave_sinkhorn_cost(w, m, n, M);
     if (lane_id() == 0) atomicAdd(&M.stats[0], 1ull);
     return rp_maxf(xy - 0.5f * selfA - 0.5f * selfB, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// TWO points against ONE centroid in one wavefront.
+//
+// A point has few support bins (<= 47, 28 on average): in the half-iteration whose rows are the point's bins a
+// lane-per-row mapping leaves more than half of the wave idle while it walks the centroid's (up to 256) bins.  When two
+// points with <= 32 bins each meet the SAME centroid, lanes 0..31 take the rows of the first point and lanes 32..63
+// those of the second: the column walk (row offsets of C/T: wave uniform) is shared, only the potential they read
+// differs per half.  The other half-iteration (rows = centroid bins) runs once per point as before.  Each solve keeps
+// its own iteration count: a converged pair is frozen while the other finishes.  Every float operation of a solve is
+// the one wave_sinkhorn_cost performs, in the same order.
+// ------------------------------------------------------------------------------------------------
+#define PAIR_ROWS 32u
+struct __attribute__((aligned(16))) PairLds {
+    uint16_t supC[MAXB];          // centroid support
+    float lnC[MAXB];
+    float potC[2][MAXB];          // centroid-side potential of each solve
+    float tmpC[2][MAXB];
+    uint16_t supP[2][PAIR_ROWS];  // the two points
+    float lnP[2][PAIR_ROWS];
+    float potP[2][PAIR_ROWS];
+    float tmpP[2][PAIR_ROWS];
+};
+
+// cost[h] = OT(centroid, point h) if centroid_is_A else OT(point h, centroid); all lanes return both values
+__device__ __forceinline__ void wave_sinkhorn_cost2(PairLds& w, uint32_t m, const uint32_t n[2], const Metric& M,
+                                                    bool centroid_is_A, float cost_out[2]) {
+    const uint32_t lane = lane_id(), half = lane >> 5, r = lane & 31u;
+    const uint32_t bins = M.bins;
+    const __amdgpu_buffer_rsrc_t rt = rt_resource(M);
+    cost_out[0] = cost_out[1] = 0.0f;
+    if (m == 0) return;
+    bool active[2] = {n[0] > 0, n[1] > 0};
+    uint32_t iters_done[2] = {0, 0};
+    const float lc = rp_logf(1.0f / (float)m);
+    for (uint32_t h = 0; h < 2; ++h) {
+        for (uint32_t i = lane; i < m; i += 64) w.potC[h][i] = lc;
+        if (n[h] > 0 && lane < n[h]) w.potP[h][lane] = rp_logf(1.0f / (float)n[h]);
+    }
+    __syncthreads();
+    const uint32_t nh = n[half];
+    // rows = centroid bins, one solve at a time (columns = that point's bins)
+    auto centroid_rows = [&](uint32_t h) {
+        for (uint32_t i0 = 0; i0 < m; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool act = i < m;
+            const uint32_t x = act ? w.supC[i] : w.supC[0];
+            const float s = softmin_sum<false>(w.supP[h], w.potP[h], n[h], rt, bins, x);
+            if (act) {
+                const float nv = w.lnC[i] - rp_logf(s);
+                w.tmpC[h][i] = rp_absf(rp_expf(nv) - rp_expf(w.potC[h][i]));
+                w.potC[h][i] = nv;
+            }
+        }
+    };
+    // rows = point bins, both solves at once (columns = the centroid's bins, potential per half)
+    auto point_rows = [&]() {
+        const bool valid = r < nh && (half ? active[1] : active[0]);
+        const uint32_t y = w.supP[half][r < nh ? r : 0u];
+        const float s = softmin_sum<false>(w.supC, w.potC[half], m, rt, bins, y);
+        if (valid) {
+            const float nv = w.lnP[half][r] - rp_logf(s);
+            w.tmpP[half][r] = rp_absf(rp_expf(nv) - rp_expf(w.potP[half][r]));
+            w.potP[half][r] = nv;
+        }
+    };
+    auto err_centroid = [&]() -> float {  // lanes of half h: sum over the centroid rows of solve h
+        float e = 0.0f;
+        const float* t = w.tmpC[half];
+        for (uint32_t i = 0; i < m; ++i) e += t[i];
+        return e;
+    };
+    auto err_point = [&]() -> float {
+        float e = 0.0f;
+        const float* t = w.tmpP[half];
+        const uint32_t nmax = max(n[0], n[1]);
+        for (uint32_t j = 0; j < nmax; ++j) e += j < nh ? t[j] : 0.0f;  // x + 0.0f = x (x >= 0)
+        return e;
+    };
+    for (uint32_t t = 0; t < M.iters; ++t) {
+        float lhs_err, rhs_err;
+        if (centroid_is_A) {  // lhs updates the centroid side, rhs the point side (Gauss-Seidel, sinkhorn.rs:80-87)
+            if (active[0]) centroid_rows(0);
+            if (active[1]) centroid_rows(1);
+            __syncthreads();
+            lhs_err = err_centroid();
+            __syncthreads();
+            point_rows();
+            __syncthreads();
+            rhs_err = err_point();
+            __syncthreads();
+        } else {
+            point_rows();
+            __syncthreads();
+            lhs_err = err_point();
+            __syncthreads();
+            if (active[0]) centroid_rows(0);
+            if (active[1]) centroid_rows(1);
+            __syncthreads();
+            rhs_err = err_centroid();
+            __syncthreads();
+        }
+        const float tot = lhs_err + rhs_err;
+        const float tot0 = __shfl(tot, 0, 64), tot1 = __shfl(tot, 32, 64);
+        if (active[0] && tot0 < M.tol) { active[0] = false; iters_done[0] = t + 1; }
+        if (active[1] && tot1 < M.tol) { active[1] = false; iters_done[1] = t + 1; }
+        if (!active[0] && !active[1]) break;
+    }
+    for (uint32_t h = 0; h < 2; ++h)
+        if (active[h]) iters_done[h] = M.iters;
+    if (lane == 0) {
+        atomicAdd(&M.stats[1], (unsigned long long)iters_done[0] * (n[0] > 0) + (unsigned long long)iters_done[1] * (n[1] > 0));
+        atomicAdd(&M.stats[2], (unsigned long long)(2 * iters_done[0] + 1) * m * n[0] + (unsigned long long)(2 * iters_done[1] + 1) * m * n[1]);
+    }
+    // cost(): A-major left fold of coupling * distance (sinkhorn.rs:206-217), one solve per half
+    float cost = 0.0f;
+    if (centroid_is_A) {
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint32_t x = w.supC[i];
+            const float fi = w.potC[half][i];
+            if (r < nh) {
+                const uint32_t y = w.supP[half][r];
+                w.tmpP[half][r] = rp_expf(fi + w.potP[half][r] - M.Rt[x * bins + y]) * M.Cm[x * bins + y];
+            }
+            __syncthreads();
+            for (uint32_t j = 0; j < nh; ++j) cost += w.tmpP[half][j];
+            __syncthreads();
+        }
+    } else {
+        const uint32_t nmax = max(n[0], n[1]);
+        for (uint32_t i = 0; i < nmax; ++i) {
+            for (uint32_t h = 0; h < 2; ++h) {
+                if (i >= n[h]) continue;
+                const uint32_t x = w.supP[h][i];
+                const float fi = w.potP[h][i];
+                for (uint32_t j = lane; j < m; j += 64) {
+                    const uint32_t y = w.supC[j];
+                    w.tmpC[h][j] = rp_expf(fi + w.potC[h][j] - M.Rt[x * bins + y]) * M.Cm[x * bins + y];
+                }
+            }
+            __syncthreads();
+            if (i < nh) {
+                const float* t = w.tmpC[half];
+                for (uint32_t j = 0; j < m; ++j) cost += t[j];
+            }
+            __syncthreads();
+        }
+    }
+    cost_out[0] = __shfl(cost, 0, 64);
+    cost_out[1] = __shfl(cost, 32, 64);
+}
+
+// support of a dense histogram into the pair slot h (at most PAIR_ROWS bins, guaranteed by the pairing list)
+template <typename CT>
+__device__ uint32_t pair_load_hist(const CT* counts, uint32_t weight, uint32_t bins, uint16_t* sup, float* lnd) {
+    const uint32_t lane = lane_id();
+    const float fw = (float)weight;
+    uint32_t base = 0;
+    for (uint32_t q = 0; q * 64 < bins; ++q) {
+        const uint32_t b = q * 64 + lane;
+        const uint32_t c = b < bins ? (uint32_t)counts[b] : 0u;
+        const bool has = c > 0;
+        const unsigned long long mask = __ballot(has);
+        if (has) {
+            const uint32_t rr = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (rr < PAIR_ROWS) {
+                sup[rr] = (uint16_t)b;
+                lnd[rr] = rp_logf((float)c / fw);
+            }
+        }
+        base += __popcll(mask);
+    }
+    __syncthreads();
+    return base;
+}
+
+__global__ __launch_bounds__(64) void k_point_support(Points P, uint32_t bins, uint8_t* nsup) {
+    const uint64_t i = blockIdx.x;
+    uint32_t c = 0;
+    for (uint32_t b = lane_id(); b < bins; b += 64) c += P.counts[i * P.stride + b] > 0;
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+    if (lane_id() == 0) nsup[i] = (uint8_t)min(c, 255u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -360,9 +550,9 @@ struct Bounds {
 };
 
 __global__ __launch_bounds__(64) void k_neighbor(Points P, CentroidSet cs, uint32_t K, Metric M, int kind,
-                                                 uint8_t* out_j, float* out_d, Bounds init) {
+                                                 uint8_t* out_j, float* out_d, Bounds init, const uint32_t* only) {
     __shared__ WaveLds w;
-    const uint64_t i = blockIdx.x;
+    const uint64_t i = only ? only[blockIdx.x] : blockIdx.x;  // `only`: the points k_neighbor2 does not take
     const uint32_t lane = lane_id();
     uint32_t bj = 0;
     float bd = 0.0f;
@@ -415,6 +605,71 @@ __global__ __launch_bounds__(64) void k_neighbor(Points P, CentroidSet cs, uint3
     }
     if (init.lower)
         for (uint32_t k = lane; k < K; k += 64) init.lower[i * K + k] = 0.0f;
+}
+
+// Elkan::neighbor for TWO points per wavefront (both with <= PAIR_ROWS support bins), Sinkhorn metric
+__global__ __launch_bounds__(64) void k_neighbor2(Points P, CentroidSet cs, uint32_t K, Metric M, const uint32_t* pairs,
+                                                  uint8_t* out_j, float* out_d, Bounds init) {
+    __shared__ PairLds w;
+    const uint32_t lane = lane_id();
+    const uint64_t ip[2] = {pairs[2 * blockIdx.x], pairs[2 * blockIdx.x + 1]};
+    uint32_t n[2];
+    float sp[2];
+    for (uint32_t h = 0; h < 2; ++h) {
+        n[h] = pair_load_hist(P.counts + ip[h] * P.stride, P.weight[ip[h]], M.bins, w.supP[h], w.lnP[h]);
+        sp[h] = P.self[ip[h]];
+    }
+    uint32_t bj[2] = {0, 0};
+    float bd[2] = {0.0f, 0.0f};
+    for (uint32_t k = 0; k < K; ++k) {
+        const uint32_t m = wave_load_centroid(cs, k, w.supC, w.lnC);
+        float xy[2];
+        wave_sinkhorn_cost2(w, m, n, M, true, xy);  // distance(centroid, point)
+        const float sc = cs.self[k];
+        for (uint32_t h = 0; h < 2; ++h) {
+            const float d = rp_maxf(xy[h] - 0.5f * sc - 0.5f * sp[h], 0.0f);
+            if (k == 0 || d < bd[h]) {
+                bj[h] = k;
+                bd[h] = d;
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0) atomicAdd(&M.stats[0], 2ull * K);
+    if (lane < 2) {
+        const uint64_t i = ip[lane];
+        const uint32_t j = lane ? bj[1] : bj[0];
+        const float d = lane ? bd[1] : bd[0];
+        if (out_j) out_j[i] = (uint8_t)j;
+        if (out_d) out_d[i] = d;
+        if (init.j) {
+            init.j[i] = (uint8_t)j;
+            init.u[i] = d;
+            init.stale[i] = 0;
+        }
+    }
+    if (init.lower)
+        for (uint32_t h = 0; h < 2; ++h)
+            for (uint32_t k = lane; k < K; k += 64) init.lower[ip[h] * K + k] = 0.0f;
+}
+
+// k-means++ potentials for two points per wavefront: potentials <- min(potentials, d(new centroid, point)^2)
+__global__ __launch_bounds__(64) void k_kpp_update2(Points P, CentroidSet cs, uint32_t k, Metric M, const uint32_t* pairs,
+                                                    float* pot) {
+    __shared__ PairLds w;
+    const uint64_t ip[2] = {pairs[2 * blockIdx.x], pairs[2 * blockIdx.x + 1]};
+    uint32_t n[2];
+    const uint32_t m = wave_load_centroid(cs, k, w.supC, w.lnC);
+    for (uint32_t h = 0; h < 2; ++h) n[h] = pair_load_hist(P.counts + ip[h] * P.stride, P.weight[ip[h]], M.bins, w.supP[h], w.lnP[h]);
+    float xy[2];
+    wave_sinkhorn_cost2(w, m, n, M, true, xy);
+    const uint32_t lane = lane_id();
+    if (lane == 0) atomicAdd(&M.stats[0], 2ull);
+    if (lane < 2) {
+        const uint64_t i = ip[lane];
+        const float d = rp_maxf((lane ? xy[1] : xy[0]) - 0.5f * cs.self[k] - 0.5f * P.self[i], 0.0f);
+        pot[i] = rp_minf(d * d, pot[i]);
+    }
 }
 
 // Elkan::pairwises for the variation metric: one LANE per ordered pair (a, b), b fastest so the transposed density
@@ -1024,9 +1279,9 @@ __global__ __launch_bounds__(1024) void k_kpp_pick(float* pot, uint64_t N, const
 }
 // potentials <- min(potentials, d(new centroid, point)^2) (layer.rs:170-178): distance(&x, h), centroid first
 __global__ __launch_bounds__(64) void k_kpp_update(Points P, CentroidSet cs, uint32_t k, uint32_t K, Metric M, int kind,
-                                                   float* pot) {
+                                                   float* pot, const uint32_t* only) {
     __shared__ WaveLds w;
-    const uint64_t i = blockIdx.x;
+    const uint64_t i = only ? only[blockIdx.x] : blockIdx.x;
     float d;
     if (kind == RP_METRIC_SINKHORN) {
         const uint32_t m = wave_load_centroid(cs, k, w.supA, w.lnA);
@@ -1169,6 +1424,9 @@ struct rp_kmeans {
     float* drift = nullptr;
     float* pot = nullptr;
     float* pdist = nullptr;
+    uint32_t* pairs = nullptr;    // [n_pairs][2] points with <= PAIR_ROWS support bins, two per wavefront (Sinkhorn)
+    uint32_t* singles = nullptr;  // [n_singles] the other points
+    uint64_t n_pairs = 0, n_singles = 0;
     unsigned long long* bsum = nullptr;
     unsigned long long* scal = nullptr;  // [0] picked, [1] moved
     unsigned long long* sizes = nullptr; // [K]
@@ -1336,6 +1594,28 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         KM_HIP(hipMemsetAsync(d_self, 0, N * 4, h->stream));
     }
     KM_HIP(hipStreamSynchronize(h->stream));
+    if (kind == RP_METRIC_SINKHORN && !getenv("RP_LLOYD_NO_PAIRS")) {
+        // pairing list: points with at most PAIR_ROWS support bins go two per wavefront (k_neighbor2, k_kpp_update2)
+        uint8_t* d_ns = nullptr;
+        KM_TRY(dev_alloc(h, &d_ns, N));
+        hipLaunchKernelGGL(k_point_support, dim3((unsigned)N), dim3(64), 0, h->stream, h->P, bins, d_ns);
+        KM_HIP(hipGetLastError());
+        std::vector<uint8_t> ns(N);
+        KM_HIP(hipMemcpyAsync(ns.data(), d_ns, N, hipMemcpyDeviceToHost, h->stream));  // same (non-blocking) stream as the kernel
+        KM_HIP(hipStreamSynchronize(h->stream));
+        std::vector<uint32_t> small, rest;
+        for (uint64_t i = 0; i < N; ++i) (ns[i] <= PAIR_ROWS ? small : rest).push_back((uint32_t)i);
+        if (small.size() & 1u) {
+            rest.push_back(small.back());
+            small.pop_back();
+        }
+        h->n_pairs = small.size() / 2;
+        h->n_singles = rest.size();
+        KM_TRY(dev_alloc(h, &h->pairs, small.size()));
+        KM_TRY(dev_alloc(h, &h->singles, rest.size()));
+        if (!small.empty()) KM_HIP(hipMemcpy(h->pairs, small.data(), small.size() * 4, hipMemcpyHostToDevice));
+        if (!rest.empty()) KM_HIP(hipMemcpy(h->singles, rest.data(), rest.size() * 4, hipMemcpyHostToDevice));
+    }
 #undef KM_TRY
 #undef KM_HIP
     *out = h;
@@ -1358,9 +1638,15 @@ int launch_neighbor(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init) {
     if (h->kind == RP_METRIC_VARIATION && h->bins == 101)  // turn layer: register-resident centroid CDFs
         hipLaunchKernelGGL(k_neighbor_var<101>, dim3((unsigned)((h->N + VB - 1) / VB)), dim3(256), 0, h->stream, h->P,
                            h->cs[h->cur], h->K, h->M, out_j, out_d, init);
-    else
+    else if (h->kind == RP_METRIC_SINKHORN && h->n_pairs) {
+        hipLaunchKernelGGL(k_neighbor2, dim3((unsigned)h->n_pairs), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->pairs,
+                           out_j, out_d, init);
+        if (h->n_singles)
+            hipLaunchKernelGGL(k_neighbor, dim3((unsigned)h->n_singles), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M,
+                               h->kind, out_j, out_d, init, h->singles);
+    } else
         hipLaunchKernelGGL(k_neighbor, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->kind, out_j,
-                           out_d, init);
+                           out_d, init, (const uint32_t*)nullptr);
     ck_end(h, CK_NEIGHBOR);
     HIP_TRY(hipGetLastError());
     return RP_OK;
@@ -1517,7 +1803,18 @@ int rp_kmeans_kpp_update(rp_kmeans* h, uint32_t k) {
         hipLaunchKernelGGL(k_kpp_update_var, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->P, h->cs[h->cur], k, h->K,
                            h->M, h->pot);
     else
-        hipLaunchKernelGGL(k_kpp_update, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->K, h->M, h->kind, h->pot);
+    {
+        if (h->n_pairs) {
+            hipLaunchKernelGGL(k_kpp_update2, dim3((unsigned)h->n_pairs), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->M, h->pairs,
+                               h->pot);
+            if (h->n_singles)
+                hipLaunchKernelGGL(k_kpp_update, dim3((unsigned)h->n_singles), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->K,
+                                   h->M, h->kind, h->pot, h->singles);
+        } else {
+            hipLaunchKernelGGL(k_kpp_update, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->K, h->M, h->kind,
+                               h->pot, (const uint32_t*)nullptr);
+        }
+    }
     ck_end(h, CK_KPP);
     HIP_TRY(hipGetLastError());
     if (k + 1 == h->K) {

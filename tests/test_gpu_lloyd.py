@@ -195,3 +195,30 @@ def test_flop_config_slice_properties(gpu):
     for k in range(K):  # recompute() == sum of members, checked on the host
         assert np.array_equal(c[k], pts[j1 == k].astype(np.uint32).sum(axis=0))
     assert np.all(lo >= 0) and np.all(drift >= 0) and 0.0 <= moved <= 1.0
+
+
+def test_two_points_per_wavefront_equals_one_point_per_wavefront(gpu, monkeypatch):
+    # Points with <= 32 support bins are solved two per wavefront against a shared centroid (k_neighbor2 /
+    # k_kpp_update2); the rest, and everything under RP_LLOYD_NO_PAIRS=1, one per wavefront.  Large enough that the
+    # pairing list is built while the GPU is busy (a missing stream sync once mis-classified late points).
+    N, K, bins = 60000, 48, 256
+    pts = flop_like_points(N, bins=bins, mass=47, seed=3)
+    tri = smooth_metric(bins, 1)
+
+    def run(no_pairs):
+        if no_pairs:
+            monkeypatch.setenv("RP_LLOYD_NO_PAIRS", "1")
+        else:
+            monkeypatch.delenv("RP_LLOYD_NO_PAIRS", raising=False)
+        layer = lloyd.Layer(K, pts, "sinkhorn", tri, seed=11)
+        chosen = np.asarray(layer.init_centroids())
+        layer.init_bounds()
+        layer.step()
+        bucket, dist = layer.lookup()
+        return chosen, np.asarray(bucket), np.asarray(dist)
+
+    c1, b1, d1 = run(True)
+    c2, b2, d2 = run(False)
+    assert np.array_equal(c1, c2), "k-means++ picks differ"
+    assert np.array_equal(b1, b2)
+    assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
