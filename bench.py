@@ -87,6 +87,34 @@ def cpu_baseline(args):
     }
 
 
+def cpu_baseline_all_cores(args, seconds=5.0):
+    """The same CPU port on every physical core at once: P independent solver processes (scripts/cpu_worker.py) —
+    tree-parallel traversal with a free update and no synchronisation, i.e. an upper bound of the reference's rayon
+    batch() + sequential update."""
+    import subprocess
+
+    procs = max(1, (os.cpu_count() or 2) // 2)
+    if procs < 2:
+        return None
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "cpu_worker.py"), args.game, args.regret, args.weight, args.sampling,
+           "4096"]
+    running = [subprocess.Popen(cmd + [str(args.seed + 1000 + k), str(seconds)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                text=True) for k in range(procs)]
+    total, done = 0.0, 0
+    deadline = time.time() + seconds + 90.0
+    for p in running:
+        try:
+            out, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
+            u, dt = out.split()[:2]
+            total += float(u) / float(dt)
+            done += 1
+        except Exception:  # noqa: BLE001  (a straggler or a failed worker only lowers the reported figure)
+            p.kill()
+    return {"value": total, "unit": "infoset-updates/s", "cores": done, "kind": "port",
+            "sample": f"{done} independent oracle solver processes (one per physical core), {seconds:.0f} s each, batch 4096: an "
+                      "upper bound of a tree-parallel batch() with a free sequential update"}
+
+
 KERNEL_GROUPS = {
     "traverse": ("k_prepare_infos", "k_traverse"),
     "compact": ("k_count", "k_scan", "k_compact"),
@@ -442,6 +470,10 @@ def main():
             line["convergence"] = convergence(args, g, local_rank)
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args)
+            try:
+                line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args, seconds=min(5.0, args.cpu_seconds))
+            except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
+                line["cpu_baseline_all_cores"] = {"error": f"{type(exc).__name__}: {exc}"}
         else:
             line["cpu_baseline"] = None
         if world == 1 and not args.force_sharded and not args.no_kmeans:
