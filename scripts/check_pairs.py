@@ -1,3 +1,5 @@
+"""Debug aid: lookups and k-means++ picks with two points per wavefront vs one (RP_LLOYD_NO_PAIRS=1) must be identical.
+usage: [KPP_K=32] python scripts/check_pairs.py [N]"""
 import os, sys
 R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,'tests'))
 import numpy as np
