@@ -27,6 +27,7 @@ namespace rp {
 
 #define GROUP 16u  // lanes per row (max_actions <= 16)
 #define PF 8       // touches fetched ahead of the sequential chain
+#define HOT_TOUCHES 128u  // ordered mode: rows with more touches than this go to k_apply_hot
 #define HOT_CAP 4096  // rows per batch folded by k_hot_fold; further hot rows fold (serially) in k_seg_fold
 
 struct SparseParams {
@@ -95,12 +96,22 @@ __device__ __forceinline__ void fetch_chunk(TouchChunk& c, const SortedBatch& sb
         c.ev_mask |= (((uint32_t)sb.expanded[t] >> a) & 1u) << u;
     }
 }
-__global__ __launch_bounds__(256) void k_apply_ordered(SparseParams p, DevBatch b, Segments sg, SortedBatch sb) {
+__global__ __launch_bounds__(256) void k_apply_ordered(SparseParams p, DevBatch b, Segments sg, SortedBatch sb, uint32_t* hot,
+                                                       uint32_t* n_hot, uint32_t hot_cap) {
     const uint32_t n_segs = *sg.n_segs;
     const uint32_t a = threadIdx.x % GROUP;
     const uint32_t A = p.A;
     for (uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / GROUP; g < n_segs; g += gridDim.x * blockDim.x / GROUP) {
         const uint32_t off = sg.offsets[g], cnt = sg.counts[g];
+        if (cnt > HOT_TOUCHES) {  // a hot row: its chain gets a wavefront of its own and LDS-staged inputs (k_apply_hot)
+            uint32_t slot = hot_cap;
+            if (a == 0) slot = atomicAdd(n_hot, 1u);
+            slot = __shfl(slot, (int)(threadIdx.x & 48u), 64);
+            if (slot < hot_cap) {
+                if (a == 0) hot[slot] = g;
+                continue;
+            }
+        }
         float* row = p.tab + (size_t)sg.rows[g] * 4u * A;
         const uint32_t nact = b.nact[sg.perm[off]];
         const bool mine = a < nact;
@@ -136,6 +147,169 @@ __global__ __launch_bounds__(256) void k_apply_ordered(SparseParams p, DevBatch 
             row[2 * A + a] = ev;
             reinterpret_cast<uint32_t*>(row)[3 * A + a] = v;
         }
+    }
+}
+
+// ORDERED, hot rows: one wavefront per row.  All 64 lanes stage the next tile of HT touches (coalesced, from the
+// sorted batch) in LDS while the chain lanes (lane a = action a) apply the current tile in order: the chain never
+// waits for global memory, its length is the only cost (the reference's sequential semantics).
+#define HT 64u
+// Two wavefronts per hot row: wave 0 runs the regret and weight chains (lane a = action a), wave 1 the Welford payoff
+// chain — two short instruction streams on two SIMDs instead of one long one (a lone wave is issue-latency bound).
+template <bool SIGNED>  // SIGNED: the regret discount depends on the accumulator's sign (Discounted / Asymmetric)
+__global__ __launch_bounds__(128) void k_apply_hot(SparseParams p, DevBatch b, Segments sg, SortedBatch sb, const uint32_t* hot,
+                                                   const uint32_t* n_hot, uint32_t hot_cap) {
+    __shared__ float treg[2][HT * GROUP], tpol[2][HT * GROUP], tpay[2][HT], trcp[2][HT], tden[2][HT];
+    __shared__ uint32_t texp[2][HT];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, A = p.A;
+    const uint32_t nh = min(*n_hot, hot_cap);
+    // The schedules as one instruction stream: acc <- max(acc * d + delta, floor).  x * 1.0f is exact, so Summed /
+    // Floored / Constant are the same stream with d = 1; the discount is per-epoch (by sign for Discounted /
+    // Asymmetric: regret/{linear,discounted,asymmetric}.rs) and is hoisted out of the chain.
+    const float lin = p.tf / (p.tf + 1.0f);
+    float dpos = 1.0f, dneg = 1.0f, dzero = 1.0f;
+    if (p.R == RP_REGRET_LINEAR) dpos = dneg = dzero = lin;
+    else if (p.R == RP_REGRET_ASYMMETRIC) dneg = dzero = lin;
+    else if (p.R == RP_REGRET_DISCOUNTED) {
+        const float xp = rp_pow15(p.tf / 1.0f), xn = rp_pow05(p.tf / 1.0f), xz = p.tf / 1.0f;
+        dpos = xp / (xp + 1.0f);
+        dneg = xn / (xn + 1.0f);
+        dzero = xz / (xz + 1.0f);
+    }
+    const float dw = p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f;
+    for (uint32_t hi = blockIdx.x; hi < nh; hi += gridDim.x) {
+        const uint32_t g = hot[hi];
+        const uint32_t off = sg.offsets[g], cnt = sg.counts[g];
+        float* row = p.tab + (size_t)sg.rows[g] * 4u * A;
+        const uint32_t nact = b.nact[sg.perm[off]];
+        const bool mine = lane < nact;
+        float r = 0.0f, w = 0.0f, ev = 0.0f;
+        uint32_t v = 0;
+        if (mine) {
+            r = row[lane];
+            w = row[A + lane];
+            ev = row[2 * A + lane];
+            v = reinterpret_cast<const uint32_t*>(row)[3 * A + lane];
+        }
+        // every action of a row is visited together, so its cells share `visits`: the Welford divisors are known in
+        // advance; divisor and reciprocal are prepared by the staging lanes (rp_div_by_recip: the exact quotient
+        // without a division on the chain).  A row that breaks the invariant divides plainly.
+        const uint32_t v0 = __builtin_amdgcn_readfirstlane(v);
+        const bool shared_v = __ballot(mine && v != v0) == 0ull;
+        // Staging is split so that global latency hides behind the chains: the loads of tile k+1 are issued into
+        // registers before the chains over tile k, and committed to LDS after them.  128 threads share the work.
+        float lr[GROUP / 2], lp[GROUP / 2], lpay = 0.0f;
+        uint32_t lexp = 0;
+        auto stage_load = [&](uint32_t t0) {
+            const uint32_t m = min(HT, cnt - t0);
+#pragma unroll
+            for (uint32_t k = 0; k < GROUP / 2; ++k) {
+                const uint32_t e = k * 128u + tid;
+                const bool in = e < m * A;
+                lr[k] = in ? sb.regret[(size_t)(off + t0) * A + e] : 0.0f;
+                lp[k] = in ? sb.policy[(size_t)(off + t0) * A + e] : 0.0f;
+            }
+            if (tid < m) {
+                lpay = sb.payoff[off + t0 + tid];
+                lexp = sb.expanded[off + t0 + tid];
+            }
+        };
+        auto stage_store = [&](uint32_t buf, uint32_t t0) {
+            const uint32_t m = min(HT, cnt - t0);
+#pragma unroll
+            for (uint32_t k = 0; k < GROUP / 2; ++k) {
+                const uint32_t e = k * 128u + tid;
+                if (e < m * A) {
+                    treg[buf][e] = lr[k];
+                    tpol[buf][e] = p.W == RP_WEIGHT_LINEAR ? lp[k] * p.tf : (p.W == RP_WEIGHT_QUADRATIC ? lp[k] * p.tf * p.tf : lp[k]);
+                }
+            }
+            if (tid < m) {
+                const float den = (float)(v0 + t0 + tid + 1u);
+                tpay[buf][tid] = lpay;
+                texp[buf][tid] = lexp;
+                tden[buf][tid] = den;
+                trcp[buf][tid] = 1.0f / den;
+            }
+        };
+        stage_load(0);
+        stage_store(0, 0);
+        __syncthreads();
+        uint32_t buf = 0;
+        for (uint32_t t0 = 0; t0 < cnt; t0 += HT) {
+            const uint32_t m = min(HT, cnt - t0);
+            const bool more = t0 + HT < cnt;
+            if (more) stage_load(t0 + HT);
+            if (mine && wave == 0) {  // regret + weight
+                uint32_t u = 0;
+                for (; u + PF <= m; u += PF) {
+                    float dv[PF], sv[PF];
+                    uint32_t em = 0;
+#pragma unroll
+                    for (uint32_t q = 0; q < PF; ++q) {
+                        dv[q] = treg[buf][(u + q) * A + lane];
+                        sv[q] = tpol[buf][(u + q) * A + lane];
+                        em |= ((texp[buf][u + q] >> lane) & 1u) << q;
+                    }
+#pragma unroll
+                    for (uint32_t q = 0; q < PF; ++q) {
+                        const float d = SIGNED ? (r > 0.0f ? dpos : (r < 0.0f ? dneg : dzero)) : dpos;
+                        const float rn = rp_maxf(r * d + dv[q], p.floor_r);
+                        r = ((em >> q) & 1u) ? rn : r;
+                        w = rp_maxf(w * dw + sv[q], RP_EPSILON);
+                    }
+                }
+                for (; u < m; ++u) {
+                    if ((texp[buf][u] >> lane) & 1u) {
+                        const float d = SIGNED ? (r > 0.0f ? dpos : (r < 0.0f ? dneg : dzero)) : dpos;
+                        r = rp_maxf(r * d + treg[buf][u * A + lane], p.floor_r);
+                    }
+                    w = rp_maxf(w * dw + tpol[buf][u * A + lane], RP_EPSILON);
+                }
+            }
+            if (mine && wave == 1) {  // payoff + visits: ev += (x - ev) / (visits + 1)  (solver.rs:174-192)
+                const float ev_in = ev;
+                bool bad = !shared_v;  // the reciprocal quotient is exact unless a tiny numerator breaks its precondition
+                uint32_t u = 0;
+                for (; u + PF <= m; u += PF) {
+                    float pv[PF], rc[PF], dn[PF];
+#pragma unroll
+                    for (uint32_t q = 0; q < PF; ++q) {
+                        pv[q] = tpay[buf][u + q];
+                        rc[q] = trcp[buf][u + q];
+                        dn[q] = tden[buf][u + q];
+                    }
+#pragma unroll
+                    for (uint32_t q = 0; q < PF; ++q) {
+                        const float num = pv[q] - ev;
+                        bad = bad || !rp_div_by_recip_ok(num);
+                        ev += rp_div_by_recip(num, dn[q], rc[q]);
+                    }
+                }
+                for (; u < m; ++u) {
+                    const float num = tpay[buf][u] - ev;
+                    bad = bad || !rp_div_by_recip_ok(num);
+                    ev += rp_div_by_recip(num, tden[buf][u], trcp[buf][u]);
+                }
+                if (bad) {  // replay the tile with IEEE divisions (none observed)
+                    ev = ev_in;
+                    for (uint32_t q = 0; q < m; ++q) ev += (tpay[buf][q] - ev) / (float)(v + q + 1u);
+                }
+                v += m;
+            }
+            if (more) stage_store(buf ^ 1u, t0 + HT);
+            __syncthreads();
+            buf ^= 1u;
+        }
+        if (mine && wave == 0) {
+            row[lane] = r;
+            row[A + lane] = w;
+        }
+        if (mine && wave == 1) {
+            row[2 * A + lane] = ev;
+            reinterpret_cast<uint32_t*>(row)[3 * A + lane] = v;
+        }
+        __syncthreads();
     }
 }
 
@@ -703,7 +877,15 @@ int rp_profile_apply(rp_profile* h, const rp_decisions* batch, rp_update_mode mo
             const SortedBatch sb{h->srt_regret, h->srt_policy, h->srt_payoff, h->srt_expanded};
             hipLaunchKernelGGL(k_permute, dim3((unsigned)(((uint64_t)batch->n * h->A + 255) / 256)), dim3(256), 0, h->stream, b,
                                h->perm, batch->n, h->A, sb);
-            hipLaunchKernelGGL(k_apply_ordered, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, b, sg, sb);
+            HIP_TRY(hipMemsetAsync(h->hot + HOT_CAP, 0, 4, h->stream));
+            hipLaunchKernelGGL(k_apply_ordered, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, b, sg, sb, h->hot,
+                               h->hot + HOT_CAP, (uint32_t)HOT_CAP);
+            if (h->R == RP_REGRET_DISCOUNTED || h->R == RP_REGRET_ASYMMETRIC)
+                hipLaunchKernelGGL(k_apply_hot<true>, dim3(256), dim3(128), 0, h->stream, p, b, sg, sb, h->hot, h->hot + HOT_CAP,
+                                   (uint32_t)HOT_CAP);
+            else
+                hipLaunchKernelGGL(k_apply_hot<false>, dim3(256), dim3(128), 0, h->stream, p, b, sg, sb, h->hot, h->hot + HOT_CAP,
+                                   (uint32_t)HOT_CAP);
         } else {
             const uint32_t eb = (uint32_t)entry_bytes_of(h);
             if ((rc = launch_summarize(h, p, b, sg, batch->n, h->entries))) return rc;
