@@ -337,8 +337,9 @@ __global__ void k_block_index(const uint32_t* nblk, const uint32_t* boff, const 
 }
 
 __global__ __launch_bounds__(256) void k_block_maps_sparse(SparseParams p, DevBatch b, Segments sg, const uint32_t* nblk,
-                                                           const uint32_t* boff, const uint32_t* blkseg, unsigned char* entries,
-                                                           unsigned char* blocks, uint32_t entry_bytes, uint32_t max_blocks) {
+                                                           const uint32_t* boff, const uint32_t* blkseg, SortedBatch sb,
+                                                           unsigned char* entries, unsigned char* blocks, uint32_t entry_bytes,
+                                                           uint32_t max_blocks) {
     const uint32_t n_segs = *sg.n_segs;
     if (n_segs == 0) return;
     const uint32_t total = boff[n_segs - 1] + nblk[n_segs - 1];
@@ -356,27 +357,22 @@ __global__ __launch_bounds__(256) void k_block_maps_sparse(SparseParams p, DevBa
         const bool mine = a < nact;
         Map br = ident, bw = ident;
         float bp = 0.0f;
+        // touches of a row are contiguous in the sorted batch: chunk k+1 is in flight while chunk k is composed
+        TouchChunk cur, nxt;
+        fetch_chunk(cur, sb, off + t_lo, min((uint32_t)PF, t_hi - t_lo), A, a, mine);
         for (uint32_t t0 = t_lo; t0 < t_hi; t0 += PF) {
             const uint32_t m = min((uint32_t)PF, t_hi - t0);
-            float dv[PF], sv[PF], pv[PF];
-            uint32_t ev_mask = 0;
-#pragma unroll
-            for (uint32_t u = 0; u < PF; ++u) {
-                const uint32_t idx = sg.perm[off + t0 + (u < m ? u : 0u)];
-                dv[u] = mine ? b.regret[(size_t)idx * A + a] : 0.0f;
-                sv[u] = mine ? b.policy[(size_t)idx * A + a] : 0.0f;
-                pv[u] = b.payoff[idx];
-                ev_mask |= ((b.expanded[idx] >> a) & 1u) << u;
-            }
+            if (t0 + PF < t_hi) fetch_chunk(nxt, sb, off + t0 + PF, min((uint32_t)PF, t_hi - t0 - PF), A, a, mine);
 #pragma unroll
             for (uint32_t u = 0; u < PF; ++u) {
                 if (u >= m) break;
                 if (mine) {
-                    if ((ev_mask >> u) & 1u) map_touch(br, p.dr, dv[u], p.floor_r);
-                    map_touch(bw, p.dw, composed_wdelta(p.W, sv[u], p.tf), RP_EPSILON);
+                    if ((cur.ev_mask >> u) & 1u) map_touch(br, p.dr, cur.dv[u], p.floor_r);
+                    map_touch(bw, p.dw, composed_wdelta(p.W, cur.sv[u], p.tf), RP_EPSILON);
                 }
-                bp += pv[u];
+                bp += cur.pv[u];
             }
+            cur = nxt;
         }
         // a row with a single block is final: group = total = compose(identity, block) = block
         const bool single = nblk[g] == 1u;
@@ -779,7 +775,9 @@ static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp, tmp, h->nblk, h->boff, (int)n, h->stream));
     const uint32_t mb = max_blocks_of(n);
     hipLaunchKernelGGL(k_block_index, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->nblk, h->boff, h->n_segs, h->blkseg);
-    hipLaunchKernelGGL(k_block_maps_sparse, dim3(group_blocks(mb)), dim3(256), 0, h->stream, p, b, sg, h->nblk, h->boff, h->blkseg,
+    const SortedBatch sb{h->srt_regret, h->srt_policy, h->srt_payoff, h->srt_expanded};
+    hipLaunchKernelGGL(k_permute, dim3((unsigned)(((uint64_t)n * h->A + 255) / 256)), dim3(256), 0, h->stream, b, h->perm, n, h->A, sb);
+    hipLaunchKernelGGL(k_block_maps_sparse, dim3(group_blocks(mb)), dim3(256), 0, h->stream, p, b, sg, h->nblk, h->boff, h->blkseg, sb,
                        entries, h->blocks, eb, mb);
     HIP_TRY(hipMemsetAsync(h->hot + HOT_CAP, 0, 4, h->stream));
     hipLaunchKernelGGL(k_seg_fold, dim3(group_blocks(n)), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb,
