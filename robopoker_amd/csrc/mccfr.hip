@@ -1128,7 +1128,19 @@ __global__ __launch_bounds__(128) void k_block_maps(DevGame g, DevSorted so, Ste
     if (wave == 0) {
         const size_t e0 = base * W2;
         const uint32_t nfl = n * W2;
-        for (uint32_t k = lane; k < nfl; k += 64) tile[(k % W2) * TP + k / W2] = so.rw[e0 + k];
+        {   // all loads first, then the LDS commits: one global round trip for the tile, not one per 64 floats
+            float lr[TILE_FLOATS / 64];
+#pragma unroll
+            for (uint32_t q = 0; q < TILE_FLOATS / 64; ++q) {
+                const uint32_t k = lane + 64 * q;
+                lr[q] = k < nfl ? so.rw[e0 + k] : 0.0f;
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < TILE_FLOATS / 64; ++q) {
+                const uint32_t k = lane + 64 * q;
+                if (k < nfl) tile[(k % W2) * TP + k / W2] = lr[q];
+            }
+        }
         if (PRUNED)
             for (uint32_t k = lane; k < n; k += 64) mtile[k] = so.mask[base + k];
         __builtin_amdgcn_wave_barrier();
