@@ -52,6 +52,10 @@ def parse():
                          "ordered: the reference's sequential tree-id order exactly (N=1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-oracle baseline sample length (0 = skip)")
     ap.add_argument("--no-kmeans", action="store_true", help="skip the secondary k-means measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed MCCFR loop (no other-mode rate, convergence run, k-means or CPU baselines): the "
+                         "command profiled by scripts/profile_round.sh, so that rocprof's per-kernel averages are those of "
+                         "the timed region")
     ap.add_argument("--kmeans", default="slice", choices=["slice", "flop", "turn"],
                     help="k-means measurement in the `kmeans` object: a bounded flop-layer slice (default, ~10 s), or a "
                          "FULL-size configuration (flop: BASELINE configs[2], ~4 min; turn: one GPU's share of configs[4])")
@@ -345,6 +349,8 @@ def nlhe_synth(args, rank, world, local_rank):
 
 def main():
     args = parse()
+    if args.no_extras:
+        args.no_kmeans, args.cpu_seconds = True, 0.0
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -431,7 +437,7 @@ def main():
         achieved = per_launch_updates * bytes_per_update / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic, traffic_src = profiled_traffic((dom, args.update), args.batch)
         other = "ordered" if args.update == "composed" else "composed"
-        other_rate = side_rate(args, g, local_rank, other) if world == 1 and not args.force_sharded else None
+        other_rate = side_rate(args, g, local_rank, other) if world == 1 and not args.force_sharded and not args.no_extras else None
         line = {
             "metric": "mccfr_infoset_updates_per_sec",
             "value": infos / dt,
@@ -466,7 +472,7 @@ def main():
             },
             "other_update_mode": {"update": other, "value": other_rate, "unit": "infoset-updates/s"},
         }
-        if world == 1 and not args.force_sharded and args.game == "leduc":
+        if world == 1 and not args.force_sharded and args.game == "leduc" and not args.no_extras:
             line["convergence"] = convergence(args, g, local_rank)
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args)

@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-kmeans --cpu-seconds 0 --steps 20 --warmup 3"
+BENCH="python $REPO/bench.py --no-extras --steps 40 --warmup 5"
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $BENCH > $OUT/kt.log 2>&1
 python $REPO/scripts/rocpd_summary.py $(ls $OUT/kt/*.db | head -1) $OUT/${TAG}_bench_kernel_stats.txt "$BENCH" > /dev/null
 grep -o '{"metric.*' $OUT/kt.log > $OUT/${TAG}_bench_line_under_rocprof.json
@@ -19,7 +19,7 @@ python $REPO/scripts/pmc_traffic.py $OUT/fetch/pmc_counter_collection.csv $OUT/w
 # the other two kernel families: k-means (flop-layer slice) and the sparse profile
 rocprofv3 --kernel-trace --stats -d $OUT/kl -o kl -- python $REPO/scripts/quick_lloyd.py 8192 > $OUT/kl.log 2>&1
 python $REPO/scripts/rocpd_summary.py $(ls $OUT/kl/*.db | head -1) $OUT/${TAG}_lloyd_kernel_stats.txt "python scripts/quick_lloyd.py 8192 (flop-layer slice: N=8192, K=256, bins=256, init_bounds + 2 Elkan iterations)" > /dev/null
-SP="python $REPO/bench.py --workload nlhe-synth --cpu-seconds 0 --steps 20 --warmup 3"
+SP="python $REPO/bench.py --workload nlhe-synth --cpu-seconds 0 --steps 40 --warmup 5"
 rocprofv3 --kernel-trace --stats -d $OUT/ks -o ks -- $SP > $OUT/ks.log 2>&1
 python $REPO/scripts/rocpd_summary.py $(ls $OUT/ks/*.db | head -1) $OUT/${TAG}_sparse_kernel_stats.txt "$SP" > /dev/null
 cat $OUT/${TAG}_bench_kernel_stats.txt
