@@ -222,3 +222,28 @@ def test_two_points_per_wavefront_equals_one_point_per_wavefront(gpu, monkeypatc
     assert np.array_equal(c1, c2), "k-means++ picks differ"
     assert np.array_equal(b1, b2)
     assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
+
+
+@pytest.mark.parametrize("temperature,iterations,tolerance", [(0.025, 128, 5e-4), (0.1, 64, 1e-3), (0.01, 200, 1e-5),
+                                                              (0.5, 8, 1e-9)])
+def test_sinkhorn_hyper_parameter_corners_bit_exact(gpu, temperature, iterations, tolerance):
+    # T, the iteration cap and the tolerance of Sinkhorn (sinkhorn.rs:77-92,129-139): cost, divergence and the
+    # iteration count itself must match the oracle bit for bit; T = 0.01 drives exp arguments to -100 (the
+    # MIN_POSITIVE clamp), 8 iterations with a tiny tolerance exercises the cap
+    rng = np.random.default_rng(5)
+    bins, pairs = 64, 24
+    tri = random_metric(bins, rng)
+    mu = np.zeros((pairs, bins), dtype=np.uint32)
+    nu = np.zeros((pairs, bins), dtype=np.uint32)
+    for p in range(pairs):
+        for h in (mu, nu):
+            sup = rng.choice(bins, size=rng.integers(1, 40), replace=False)
+            h[p, sup] = rng.integers(1, 9, size=sup.size)
+    hp = oracle.default_sinkhorn()
+    hp.temperature, hp.iterations, hp.tolerance = temperature, iterations, tolerance
+    d = lloyd.sinkhorn_divergence(mu, nu, tri, hp)
+    c, it = lloyd.sinkhorn_cost(mu, nu, tri, hp)
+    for p in range(pairs):
+        assert bits(d[p]) == bits(oracle.sinkhorn_divergence(mu[p], nu[p], tri, hp)), p
+        ec, eit = oracle.sinkhorn_cost(mu[p], nu[p], tri, hp)
+        assert bits(c[p]) == bits(ec) and it[p] == eit, p

@@ -96,6 +96,35 @@ def test_hbm_scratch_traversal_variant_is_identical(gpu, monkeypatch):
     assert a.counters() == b.counters() == ora.counters()
 
 
+@pytest.mark.parametrize("mode", ["ordered", "composed"])
+@pytest.mark.parametrize("overrides", [
+    dict(temperature=0.5, smoothing=0.25, curiosity=0.2),         # sampling distribution far from the defaults
+    dict(temperature=4.0, smoothing=8.0, curiosity=0.001),
+    dict(prune_threshold=-5.0, prune_explore=0.5, prune_warmup=2),  # pruning bites within a few epochs
+    dict(regret_min=-2.0),                                          # the Linear/Discounted floor is hit
+])
+def test_hyper_parameter_corners_bit_exact(gpu, mode, overrides):
+    # every constant of rp_hyper (flow.rs:24-59 sampling, pruning.rs / pluribus.rs, regret/mod.rs floor) moves the tables
+    g = Game("leduc")
+    hp = oracle.default_hyper()
+    for k, v in overrides.items():
+        setattr(hp, k, v)
+    regret, sampling = ("linear", "pluribus") if "prune_threshold" in overrides else ("linear", "external")
+    dev = Solver(g, regret, "linear", sampling, batch=700, seed=9, hyper=hp)
+    ora = oracle.OracleSolver(g, regret, "linear", sampling, batch=700, seed=9, hyper=hp)
+    if mode == "composed":
+        dev.set_update_mode("composed")
+    for _ in range(8):
+        dev.step()
+        if mode == "composed":
+            ora.step_world(1)
+        else:
+            ora.step()
+    a, b = dev.export(), ora.export()
+    for f in ("visits", "regret", "weight", "payoff"):
+        assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), f
+
+
 def test_slotmap_sort_variant_for_large_games_is_identical(gpu, monkeypatch):
     # games with more than 256 infosets sort their Decisions through a per-infoset slot map; force that path on Leduc
     g = Game("leduc")
