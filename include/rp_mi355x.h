@@ -158,12 +158,12 @@ typedef enum rp_update_mode {
     RP_UPDATE_COMPOSED = 1 /* per-key composed (a,b,floor) maps; used for the multi-GPU exchange         */
 } rp_update_mode;
 
-/* Composed update: the tree-ordered touches of an infoset are cut into blocks of rp_compose_block(A)
- * consecutive Decisions; each block is composed sequentially from the identity into a map
- * F(x) = max(a x + b, m) per table cell, the block maps are then composed in block order, and the result is
- * applied to the table (rank by rank in the multi-GPU exchange).  Exact in real arithmetic; in f32 it is a
- * fixed re-association of the reference's sequential update (tests state the tolerance). */
-static inline uint32_t rp_compose_block(uint32_t max_actions) { return (1024u / (2u * max_actions)) & ~3u; }
+/* Composed update: a BLOCK is the set of Decisions of one infoset produced by one chunk of RP_COMPOSE_CHUNK
+ * consecutive trees (of this rank); it is composed sequentially, in tree-id order, from the identity into a map
+ * F(x) = max(a x + b, m) per table cell; the blocks of an infoset are then folded in chunk order and the result is
+ * applied to the table (rank by rank in the multi-GPU exchange).  Exact in real arithmetic; in f32 it is a fixed
+ * re-association of the reference's sequential update (tests state the tolerance). */
+#define RP_COMPOSE_CHUNK 256u
 /* The block maps of a cell are folded sequentially inside groups of RP_FOLD_GROUP consecutive blocks, the group maps
  * sequentially into the cell's map: a fixed two-level shape, so that the groups of a hot infoset (or hot row of the
  * sparse profile) fold in parallel on the device and the oracle can restate the association exactly. */

@@ -564,66 +564,59 @@ static void map_touch(ora_map* mp, float d, float delta, float floor_v) {
 static const ora_map MAP_ID = {1.0f, 0.0f, -INFINITY, 0};
 
 /* rp_mccfr_step_local: this rank's trees [rank*B, (rank+1)*B) against the current table -> composed maps.
- * Blocks of rp_compose_block(A) consecutive Decisions of one infoset (include/rp_mi355x.h). */
+ * A BLOCK is the set of Decisions of one infoset produced by one chunk of RP_COMPOSE_CHUNK consecutive trees of the
+ * rank, composed sequentially in tree order from the identity; the blocks of an infoset are folded in chunk order,
+ * RP_FOLD_GROUP chunks to a group, groups in order (include/rp_mi355x.h).  An infoset that a chunk did not visit
+ * contributes the identity map and a zero payoff sum, which change nothing. */
 ORA_API int ora_mccfr_step_local(ora_mccfr* h, uint32_t rank, void* blob) {
     float dr, dw;
     if (composed_discount(h, &dr, &dw)) return -1;
     uint32_t A = h->g.max_actions, NI = h->g.n_infos;
-    uint32_t T = rp_compose_block(A);
     size_t cells = (size_t)NI * A;
     float floor_r = regret_floor(h);
     ora_cell* cell = (ora_cell*)blob;
     ora_isum* sums = (ora_isum*)((unsigned char*)blob + cells * sizeof(ora_cell));
-    ora_map* blk_r = (ora_map*)malloc(cells * sizeof(ora_map));
+    ora_map* blk_r = (ora_map*)malloc(cells * sizeof(ora_map));   /* open chunk */
     ora_map* blk_w = (ora_map*)malloc(cells * sizeof(ora_map));
+    ora_map* sup_r = (ora_map*)malloc(cells * sizeof(ora_map));   /* open group of RP_FOLD_GROUP chunks */
+    ora_map* sup_w = (ora_map*)malloc(cells * sizeof(ora_map));
     ora_map* tot_r = (ora_map*)malloc(cells * sizeof(ora_map));
     ora_map* tot_w = (ora_map*)malloc(cells * sizeof(ora_map));
-    ora_map* sup_r = (ora_map*)malloc(cells * sizeof(ora_map));   /* open group of RP_FOLD_GROUP blocks */
-    ora_map* sup_w = (ora_map*)malloc(cells * sizeof(ora_map));
-    uint32_t* pos = (uint32_t*)calloc(NI, 4);       /* position of the next Decisions inside its infoset's segment */
-    float* blk_p = (float*)calloc(NI, 4);           /* payoff sum of the open block */
-    uint32_t* blk_pn = (uint32_t*)calloc(NI, 4);
-    float* sup_p = (float*)calloc(NI, 4);           /* payoff sum of the open group */
-    uint32_t* sup_pn = (uint32_t*)calloc(NI, 4);
-    uint32_t* sup_nb = (uint32_t*)calloc(NI, 4);    /* blocks folded into the open group */
+    float* blk_p = (float*)calloc(NI, 4);
+    float* sup_p = (float*)calloc(NI, 4);
     float* tot_p = (float*)calloc(NI, 4);
     uint32_t* tot_pn = (uint32_t*)calloc(NI, 4);
     for (size_t c = 0; c < cells; ++c) blk_r[c] = blk_w[c] = sup_r[c] = sup_w[c] = tot_r[c] = tot_w[c] = MAP_ID;
     h->ndec = 0;
-    batch_range(h, (uint64_t)rank * h->batch, h->batch);
+    uint64_t first = (uint64_t)rank * h->batch;
+    batch_range(h, first, h->batch);
+    uint32_t n_chunks = (h->batch + RP_COMPOSE_CHUNK - 1) / RP_COMPOSE_CHUNK;
+    uint32_t open = 0; /* chunk being filled */
     for (uint64_t i = 0; i <= h->ndec; ++i) {
-        /* close finished blocks: before a Decisions that opens a new block of its infoset, and at the end.  Block
-         * maps are folded sequentially into a group of RP_FOLD_GROUP blocks, groups sequentially into the total
-         * (the device folds the groups of an infoset in parallel). */
-        for (uint32_t info = 0; info < NI; ++info) {
-            int last = i == h->ndec;
-            int opens = !last && h->dec[i].info == info && pos[info] > 0 && pos[info] % T == 0;
-            if (!(last || opens)) continue;
-            if (blk_pn[info] != 0) {
+        uint32_t c = i < h->ndec ? (uint32_t)((h->dec[i].tree - first) / RP_COMPOSE_CHUNK) : n_chunks;
+        while (open < c) { /* close chunk `open` (left folds from the identity / 0.0f, like the device) */
+            for (uint32_t info = 0; info < NI; ++info) {
                 for (uint32_t a = 0; a < A; ++a) {
                     size_t k = (size_t)info * A + a;
                     sup_r[k] = map_compose(sup_r[k], blk_r[k]);
                     sup_w[k] = map_compose(sup_w[k], blk_w[k]);
                     blk_r[k] = blk_w[k] = MAP_ID;
                 }
-                sup_p[info] += blk_p[info]; /* left folds from 0.0f, like the device */
-                sup_pn[info] += blk_pn[info];
-                sup_nb[info] += 1;
+                sup_p[info] += blk_p[info];
                 blk_p[info] = 0.0f;
-                blk_pn[info] = 0;
             }
-            if (sup_nb[info] == RP_FOLD_GROUP || (last && sup_nb[info] > 0)) {
-                for (uint32_t a = 0; a < A; ++a) {
-                    size_t k = (size_t)info * A + a;
-                    tot_r[k] = map_compose(tot_r[k], sup_r[k]);
-                    tot_w[k] = map_compose(tot_w[k], sup_w[k]);
-                    sup_r[k] = sup_w[k] = MAP_ID;
+            open += 1;
+            if (open % RP_FOLD_GROUP == 0 || open == n_chunks) { /* close the group */
+                for (uint32_t info = 0; info < NI; ++info) {
+                    for (uint32_t a = 0; a < A; ++a) {
+                        size_t k = (size_t)info * A + a;
+                        tot_r[k] = map_compose(tot_r[k], sup_r[k]);
+                        tot_w[k] = map_compose(tot_w[k], sup_w[k]);
+                        sup_r[k] = sup_w[k] = MAP_ID;
+                    }
+                    tot_p[info] += sup_p[info];
+                    sup_p[info] = 0.0f;
                 }
-                tot_p[info] += sup_p[info];
-                tot_pn[info] += sup_pn[info];
-                sup_p[info] = 0.0f;
-                sup_pn[info] = 0;
-                sup_nb[info] = 0;
             }
         }
         if (i == h->ndec) break;
@@ -634,8 +627,7 @@ ORA_API int ora_mccfr_step_local(ora_mccfr* h, uint32_t rank, void* blob) {
             map_touch(&blk_w[k], dw, composed_wdelta(h, d->policy[a]), RP_EPSILON);
         }
         blk_p[d->info] += d->payoff;
-        blk_pn[d->info] += 1;
-        pos[d->info] += 1;
+        tot_pn[d->info] += 1;
     }
     for (size_t c = 0; c < cells; ++c) {
         cell[c].ra = tot_r[c].a; cell[c].rb = tot_r[c].b; cell[c].rm = tot_r[c].m; cell[c].rn = tot_r[c].n;
@@ -645,8 +637,8 @@ ORA_API int ora_mccfr_step_local(ora_mccfr* h, uint32_t rank, void* blob) {
         sums[info].count = tot_pn[info];
         sums[info].psum = tot_p[info];
     }
-    free(blk_r); free(blk_w); free(sup_r); free(sup_w); free(tot_r); free(tot_w); free(pos); free(blk_p); free(blk_pn);
-    free(sup_p); free(sup_pn); free(sup_nb); free(tot_p); free(tot_pn);
+    free(blk_r); free(blk_w); free(sup_r); free(sup_w); free(tot_r); free(tot_w);
+    free(blk_p); free(sup_p); free(tot_p); free(tot_pn);
     return 0;
 }
 

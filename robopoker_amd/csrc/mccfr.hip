@@ -640,8 +640,9 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
 //   k_chain    per infoset: stream the segment through LDS tiles and apply the touches sequentially,
 //              one lane per table cell (the reference's order-dependent semantics, bit for bit)
 // ------------------------------------------------------------------------------------------------
-#define CH_TREES 1024u   // trees per compaction chunk
-#define CH_THREADS 256u
+#define CH_TREES 256u     // trees per compaction chunk == RP_COMPOSE_CHUNK (a block of the composed update)
+#define CH_THREADS 256u   // small-game kernels: one tree per thread
+#define SLOT_THREADS (CH_TREES / 4u)  // slot-map kernels: four slot-map bytes per thread
 
 struct DevSorted {
     float* rw;         // [cap][2A]  per Decisions: regret delta a=0..A-1, then weight delta a=0..A-1
@@ -666,7 +667,7 @@ __device__ __forceinline__ uint32_t chunk_slots(const DevDecisions& dc, uint32_t
 __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t v) {
     return ((v & 0xffu) != 0) + ((v & 0xff00u) != 0) + ((v & 0xff0000u) != 0) + ((v & 0xff000000u) != 0);
 }
-// block-wide exclusive scan over CH_THREADS threads in thread order; returns (exclusive prefix, total)
+// block-wide exclusive scan over the blockDim.x threads in thread order; returns (exclusive prefix, total)
 __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* wave_tot, uint32_t* total) {
     const uint32_t tid = threadIdx.x;
     uint32_t incl = v;
@@ -677,7 +678,7 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* wave_tot,
     if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
     __syncthreads();
     uint32_t wbase = 0, tot = 0;
-    for (uint32_t w = 0; w < CH_THREADS / 64; ++w) {
+    for (uint32_t w = 0; w < blockDim.x / 64; ++w) {
         const uint32_t c = wave_tot[w];
         if (w < (tid >> 6)) wbase += c;
         tot += c;
@@ -687,7 +688,7 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* wave_tot,
     return wbase + incl - v;
 }
 
-__global__ __launch_bounds__(CH_THREADS) void k_count(DevGame g, DevDecisions dc, DevSorted so, StepParams p) {
+__global__ __launch_bounds__(SLOT_THREADS) void k_count(DevGame g, DevDecisions dc, DevSorted so, StepParams p) {
     __shared__ uint32_t wave_tot[CH_THREADS / 64];
     const uint32_t info = blockIdx.y, chunk = blockIdx.x;
     if (g.info_player[info] != p.walker) return;
@@ -696,7 +697,11 @@ __global__ __launch_bounds__(CH_THREADS) void k_count(DevGame g, DevDecisions dc
     for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
     if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0) so.counts[(size_t)info * so.n_chunks + chunk] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    if (threadIdx.x == 0) {
+        uint32_t c = 0;
+        for (uint32_t w = 0; w < blockDim.x / 64; ++w) c += wave_tot[w];
+        so.counts[(size_t)info * so.n_chunks + chunk] = c;
+    }
 }
 
 __global__ __launch_bounds__(CH_THREADS) void k_scan(DevGame g, DevSorted so, StepParams p) {
@@ -718,18 +723,22 @@ __global__ __launch_bounds__(CH_THREADS) void k_scan(DevGame g, DevSorted so, St
     if (threadIdx.x == 0) so.total[info] = carry;
 }
 
-__global__ __launch_bounds__(CH_THREADS) void k_compact(DevGame g, DevDecisions dc, DevSorted so, StepParams p) {
+__global__ __launch_bounds__(SLOT_THREADS) void k_compact(DevGame g, DevDecisions dc, DevSorted so, StepParams p) {
     __shared__ uint32_t wave_tot[CH_THREADS / 64];
     __shared__ uint32_t sh_base;
     const uint32_t info = blockIdx.y, chunk = blockIdx.x;
     if (g.info_player[info] != p.walker) return;
     // segment base = sum of the lengths of all lower infosets
     uint32_t part = 0;
-    for (uint32_t i = threadIdx.x; i < info; i += CH_THREADS) part += so.total[i];
+    for (uint32_t i = threadIdx.x; i < info; i += blockDim.x) part += so.total[i];
     for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
     if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = part;
     __syncthreads();
-    if (threadIdx.x == 0) sh_base = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3] + so.offs[(size_t)info * so.n_chunks + chunk];
+    if (threadIdx.x == 0) {
+        uint32_t b0 = so.offs[(size_t)info * so.n_chunks + chunk];
+        for (uint32_t w = 0; w < blockDim.x / 64; ++w) b0 += wave_tot[w];
+        sh_base = b0;
+    }
     __syncthreads();
     const uint32_t A = g.A, nact = g.info_actions[info];
     const uint32_t t0 = chunk * CH_TREES + threadIdx.x * 4;
@@ -764,13 +773,14 @@ __global__ __launch_bounds__(CH_THREADS) void k_compact(DevGame g, DevDecisions 
 // rank of a Decisions inside its (chunk, infoset) bucket — its place in tree-id order — is a prefix popcount of that
 // bitmap row.  Every Decisions is read once; nothing is scanned per infoset.
 #define SM_INFOS 256u
+static_assert(CH_TREES == RP_COMPOSE_CHUNK, "a block of the composed update is one compaction chunk of trees");
 #define SM_WORDS (CH_TREES / 32u)
 __device__ __forceinline__ void chunk_bitmap(const DevDecisions& dc, uint32_t n_infos, uint32_t chunk, uint32_t batch,
                                              uint32_t* bits) {
     for (uint32_t e = threadIdx.x; e < n_infos * SM_WORDS; e += CH_THREADS) bits[e] = 0;
     __syncthreads();
-    for (uint32_t k = 0; k < 4; ++k) {
-        const uint32_t lt = threadIdx.x + k * CH_THREADS, tree = chunk * CH_TREES + lt;  // coalesced over threads
+    for (uint32_t lt = threadIdx.x; lt < CH_TREES; lt += CH_THREADS) {
+        const uint32_t tree = chunk * CH_TREES + lt;  // coalesced over threads
         if (tree >= batch) continue;
         const uint32_t nd = dc.ndec[tree];
         for (uint32_t slot = 0; slot < nd; ++slot)
@@ -812,8 +822,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_compact_small(DevGame g, DevDeci
     __syncthreads();
     const uint32_t A = g.A;
     const float tf = (float)p.epoch;
-    for (uint32_t k = 0; k < 4; ++k) {
-        const uint32_t lt = threadIdx.x + k * CH_THREADS, tree = chunk * CH_TREES + lt;
+    for (uint32_t lt = threadIdx.x; lt < CH_TREES; lt += CH_THREADS) {
+        const uint32_t tree = chunk * CH_TREES + lt;
         if (tree >= p.batch) continue;
         const uint32_t nd = dc.ndec[tree];
         for (uint32_t slot = 0; slot < nd; ++slot) {
@@ -1108,27 +1118,36 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
 //   k_combine     one wave per infoset: the block maps composed in block order -> Cell / InfoSum blob
 // ------------------------------------------------------------------------------------------------
 // Map / map_compose live in mccfr_kernels.hpp
+// block = the Decisions of infoset blockIdx.y produced by chunk blockIdx.x (RP_COMPOSE_CHUNK == CH_TREES trees):
+// in the sorted layout a contiguous group.  Large games (per-infoset slot map); small games fuse the sort away, below.
 template <bool PRUNED>
 __global__ __launch_bounds__(128) void k_block_maps(DevGame g, DevSorted so, StepParams p, Map* bmaps, float* bpsum,
-                                                    uint32_t nblk_max) {
+                                                    uint32_t* bcnt, uint32_t nblk_max) {
     __shared__ __attribute__((aligned(16))) float tile[TILE_FLOATS + 2 * RP_MAX_ACTIONS * TILE_PAD];
     __shared__ uint32_t mtile[TILE_FLOATS / 2];
     __shared__ __attribute__((aligned(16))) float ptile[TILE_FLOATS / 2];
     const uint32_t info = blockIdx.y, blk = blockIdx.x;
     if (g.info_player[info] != p.walker) return;
-    const uint32_t len = so.total[info];
     const uint32_t A = g.A, nact = g.info_actions[info], W2 = 2 * A;
-    const uint32_t T = compose_block(A);
-    if (blk * T >= len) return;
-    const uint32_t n = min(T, len - blk * T);
+    const uint32_t T = compose_block(A);  // touches per LDS tile
+    const uint32_t n = so.counts[(size_t)info * so.n_chunks + blk];
     const uint32_t TP = T + TILE_PAD;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const size_t base = seg_base(so, info) + (size_t)blk * T;
+    const size_t base = seg_base(so, info) + so.offs[(size_t)info * so.n_chunks + blk];
     const float NEG_INF = rp_u2f(0xff800000u);
-    if (wave == 0) {
-        const size_t e0 = base * W2;
-        const uint32_t nfl = n * W2;
-        {   // all loads first, then the LDS commits: one global round trip for the tile, not one per 64 floats
+    const bool isreg = lane < A;
+    const uint32_t a = lane % A;
+    const bool chain = lane < W2 && a < nact;
+    const float tf = (float)p.epoch;
+    const float fl = isreg ? regret_floor_of(p.R, p.regret_min) : RP_EPSILON;
+    const float d = isreg ? (p.R == RP_REGRET_LINEAR ? tf / (tf + 1.0f) : 1.0f) : (p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f);
+    float ma = 1.0f, mb = 0.0f, mm = NEG_INF, psum = 0.0f;
+    uint32_t cnt = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += T) {  // the chain runs through the block tile by tile
+        const uint32_t m = min(T, n - t0);
+        if (wave == 0) {
+            const size_t e0 = (base + t0) * W2;
+            const uint32_t nfl = m * W2;
             float lr[TILE_FLOATS / 64];
 #pragma unroll
             for (uint32_t q = 0; q < TILE_FLOATS / 64; ++q) {
@@ -1140,23 +1159,15 @@ __global__ __launch_bounds__(128) void k_block_maps(DevGame g, DevSorted so, Ste
                 const uint32_t k = lane + 64 * q;
                 if (k < nfl) tile[(k % W2) * TP + k / W2] = lr[q];
             }
+            if (PRUNED)
+                for (uint32_t k = lane; k < m; k += 64) mtile[k] = so.mask[base + t0 + k];
+        } else {
+            for (uint32_t k = lane; k < m; k += 64) ptile[k] = so.payoff[base + t0 + k];
         }
-        if (PRUNED)
-            for (uint32_t k = lane; k < n; k += 64) mtile[k] = so.mask[base + k];
-        __builtin_amdgcn_wave_barrier();
         __syncthreads();
-        const bool isreg = lane < A;
-        const uint32_t a = lane % A;
-        const bool chain = lane < W2 && a < nact;
-        const float tf = (float)p.epoch;
-        const float fl = isreg ? regret_floor_of(p.R, p.regret_min) : RP_EPSILON;
-        const float d = isreg ? (p.R == RP_REGRET_LINEAR ? tf / (tf + 1.0f) : 1.0f)
-                              : (p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f);
-        float ma = 1.0f, mb = 0.0f, mm = NEG_INF;
-        uint32_t cnt = 0;
-        if (chain) {
+        if (wave == 0 && chain) {
             const float* row = tile + lane * TP;
-            for (uint32_t i = 0; i < n; ++i) {
+            for (uint32_t i = 0; i < m; ++i) {
                 const float delta = row[i];
                 const bool skip = PRUNED && isreg && !((mtile[i] >> a) & 1u);
                 // first touch of the block: (d, delta, floor); then a <- a d, b <- b d + delta, m <- max(m d + delta, floor)
@@ -1169,16 +1180,110 @@ __global__ __launch_bounds__(128) void k_block_maps(DevGame g, DevSorted so, Ste
                 cnt += skip ? 0u : 1u;
             }
         }
-        if (lane < W2) bmaps[((size_t)info * nblk_max + blk) * W2 + lane] = Map{ma, mb, mm, chain ? cnt : 0u};
-    } else {
-        for (uint32_t k = lane; k < n; k += 64) ptile[k] = so.payoff[base + k];
-        __builtin_amdgcn_wave_barrier();
+        if (wave == 1 && lane == 0)
+            for (uint32_t i = 0; i < m; ++i) psum += ptile[i];
         __syncthreads();
-        if (lane == 0) {
-            float s = 0.0f;
-            for (uint32_t i = 0; i < n; ++i) s += ptile[i];
-            bpsum[(size_t)info * nblk_max + blk] = s;
+    }
+    const size_t slot = (size_t)info * nblk_max + blk;
+    if (wave == 0 && lane < W2) bmaps[slot * W2 + lane] = Map{ma, mb, mm, chain ? cnt : 0u};
+    if (wave == 1 && lane == 0) {
+        bpsum[slot] = psum;
+        bcnt[slot] = n;
+    }
+}
+
+// Small games: block maps straight from the lane-interleaved Decisions of one chunk — no sorted copy in HBM at all.
+// One thread per tree.  The chunk's Decisions get their place in per-infoset, tree-ordered lists (LDS bitmap + prefix
+// popcount, as k_compact_small); then, cell by cell, every thread drops its trees' values at those places in an LDS
+// array (global reads coalesced over trees) and one thread per infoset composes its list sequentially out of LDS.
+template <bool PRUNED>
+__global__ __launch_bounds__(CH_THREADS) void k_chunk_maps(DevGame g, DevDecisions dc, StepParams p, Map* bmaps, float* bpsum,
+                                                           uint32_t* bcnt, uint32_t nblk_max) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cm_lds[];
+    __shared__ uint32_t wave_tot[CH_THREADS / 64];
+    const uint32_t NI = g.n_infos, A = g.A, W2 = 2 * A, chunk = blockIdx.x, tid = threadIdx.x, MD = dc.maxdec;
+    uint32_t* bits = cm_lds;                                              // [NI][SM_WORDS]
+    uint32_t* lcount = bits + NI * SM_WORDS;                              // [SM_INFOS]
+    uint32_t* lbase = lcount + SM_INFOS;                                  // [SM_INFOS]
+    float* vals = reinterpret_cast<float*>(lbase + SM_INFOS);             // [MD * CH_TREES] one cell's values, list order
+    uint16_t* pre = reinterpret_cast<uint16_t*>(vals + MD * CH_TREES);    // [NI][SM_WORDS]
+    uint16_t* posl = pre + NI * SM_WORDS;                                 // [MD][CH_TREES] list position of (slot, tree)
+    uint16_t* lmask = posl + MD * CH_TREES;                               // [MD * CH_TREES] expanded-edge masks (PRUNED)
+    chunk_bitmap(dc, NI, chunk, p.batch, bits);
+    for (uint32_t info = tid; info < NI; info += CH_THREADS) {
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < SM_WORDS; ++w) {
+            pre[info * SM_WORDS + w] = (uint16_t)run;
+            run += __popc(bits[info * SM_WORDS + w]);
         }
+        lcount[info] = run;
+    }
+    __syncthreads();
+    {
+        uint32_t tot;
+        const uint32_t ex = block_exscan(tid < NI ? lcount[tid] : 0u, wave_tot, &tot);  // NI <= SM_INFOS == CH_THREADS
+        if (tid < NI) lbase[tid] = ex;
+    }
+    __syncthreads();
+    const uint32_t lt = tid, tree = chunk * CH_TREES + lt;  // CH_TREES == CH_THREADS: one tree per thread
+    const uint32_t nd = tree < p.batch ? dc.ndec[tree] : 0u;
+    for (uint32_t slot = 0; slot < nd; ++slot) {
+        const uint32_t info = dc.info[slot * dc.stride + tree];
+        const uint32_t rank = pre[info * SM_WORDS + (lt >> 5)] + __popc(bits[info * SM_WORDS + (lt >> 5)] & ((1u << (lt & 31u)) - 1u));
+        const uint32_t pos = lbase[info] + rank;
+        posl[slot * CH_TREES + lt] = (uint16_t)pos;
+        if (PRUNED) lmask[pos] = (uint16_t)dc.mask[slot * dc.stride + tree];
+    }
+    const float NEG_INF = rp_u2f(0xff800000u);
+    const float tf = (float)p.epoch;
+    const uint32_t info = tid;  // chain phase: thread i = infoset i
+    const bool mine = info < NI && g.info_player[info < NI ? info : 0u] == p.walker;
+    const uint32_t nact = mine ? g.info_actions[info] : 0u;
+    const uint32_t n = mine ? lcount[info] : 0u, base = mine ? lbase[info] : 0u;
+    const size_t slot_out = (size_t)info * nblk_max + chunk;
+    for (uint32_t c = 0; c <= W2; ++c) {  // regret cells, weight cells, then the payoff sum
+        const bool isreg = c < A, ispay = c == W2;
+        const uint32_t a = c % A;
+        __syncthreads();  // the previous cell's chains are done with `vals`
+        for (uint32_t slot = 0; slot < nd; ++slot) {
+            float v;
+            if (ispay) v = dc.payoff[slot * dc.stride + tree];
+            else if (isreg) v = dc.regret[(slot * A + a) * dc.stride + tree];
+            else {
+                const float sg = dc.policy[(slot * A + a) * dc.stride + tree];
+                v = p.W == RP_WEIGHT_LINEAR ? sg * tf : (p.W == RP_WEIGHT_QUADRATIC ? sg * tf * tf : sg);
+            }
+            vals[posl[slot * CH_TREES + lt]] = v;
+        }
+        __syncthreads();
+        if (!mine) continue;
+        if (ispay) {  // payoff sum of the block, left fold from 0.0f
+            float sum = 0.0f;
+            for (uint32_t e = 0; e < n; ++e) sum += vals[base + e];
+            bpsum[slot_out] = sum;
+            bcnt[slot_out] = n;
+            continue;
+        }
+        const bool chain = a < nact;
+        const float fl = isreg ? regret_floor_of(p.R, p.regret_min) : RP_EPSILON;
+        const float d = isreg ? (p.R == RP_REGRET_LINEAR ? tf / (tf + 1.0f) : 1.0f) : (p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f);
+        float ma = 1.0f, mb = 0.0f, mm = NEG_INF;
+        uint32_t cnt = 0;
+        if (chain) {
+            for (uint32_t e = 0; e < n; ++e) {
+                const float delta = vals[base + e];
+                const bool skip = PRUNED && isreg && !((lmask[base + e] >> a) & 1u);
+                // first touch of the block: (d, delta, floor); then a <- a d, b <- b d + delta, m <- max(m d + delta, floor)
+                const float na = cnt ? ma * d : d;
+                const float nb = cnt ? mb * d + delta : delta;
+                const float nm = cnt ? rp_maxf(mm * d + delta, fl) : fl;
+                ma = skip ? ma : na;
+                mb = skip ? mb : nb;
+                mm = skip ? mm : nm;
+                cnt += skip ? 0u : 1u;
+            }
+        }
+        bmaps[slot_out * W2 + c] = Map{ma, mb, mm, chain ? cnt : 0u};
     }
 }
 
@@ -1186,17 +1291,16 @@ __global__ __launch_bounds__(128) void k_block_maps(DevGame g, DevSorted so, Ste
 // the RP_FOLD_GROUP consecutive block maps of group g = g0 + s sequentially — 256 / 2A groups in parallel, loads
 // CB_PF ahead of the chain — then the 2A cell threads fold the group maps in group order.
 #define CB_PF 8
-__global__ __launch_bounds__(256) void k_combine(DevGame g, DevSorted so, StepParams p, const Map* bmaps, const float* bpsum,
+__global__ __launch_bounds__(256) void k_combine(DevGame g, StepParams p, const Map* bmaps, const float* bpsum, const uint32_t* bcnt,
                                                  uint32_t nblk_max, Cell* cells, InfoSum* sums) {
     __shared__ __attribute__((aligned(16))) Map sup[256];
     __shared__ float supp[256];
+    __shared__ uint32_t supc[256];
     const uint32_t info = blockIdx.x, tid = threadIdx.x;
     const uint32_t A = g.A, W2 = 2 * A;
     const float NEG_INF = rp_u2f(0xff800000u);
     const bool walker = g.info_player[info] == p.walker;
-    const uint32_t len = walker ? so.total[info] : 0u;
-    const uint32_t T = compose_block(A);
-    const uint32_t nb = (len + T - 1) / T;
+    const uint32_t nb = walker ? (p.batch + RP_COMPOSE_CHUNK - 1) / RP_COMPOSE_CHUNK : 0u;  // one block per chunk of trees
     const uint32_t ngrp = (nb + RP_FOLD_GROUP - 1) / RP_FOLD_GROUP;
     const uint32_t NS = 256u / W2, c = tid % W2, s = tid / W2;
     const Map ident{1.0f, 0.0f, NEG_INF, 0u};
@@ -1204,37 +1308,49 @@ __global__ __launch_bounds__(256) void k_combine(DevGame g, DevSorted so, StepPa
     const float* psrc = bpsum + (size_t)info * nblk_max;
     Map tot = ident;
     float ps = 0.0f;
+    const uint32_t* csrc = bcnt + (size_t)info * nblk_max;
+    uint32_t len = 0;
     for (uint32_t g0 = 0; g0 < ngrp; g0 += NS) {
         const uint32_t grp = g0 + s;
         if (s < NS && grp < ngrp) {
             const uint32_t b_lo = grp * RP_FOLD_GROUP, b_hi = min(nb, b_lo + RP_FOLD_GROUP);
             Map m = ident;
             float gp = 0.0f;
+            uint32_t gc = 0;
             for (uint32_t b0 = b_lo; b0 < b_hi; b0 += CB_PF) {
                 const uint32_t cnt = min((uint32_t)CB_PF, b_hi - b0);
                 Map mm[CB_PF];
                 float pp[CB_PF];
+                uint32_t cc[CB_PF];
 #pragma unroll
                 for (uint32_t q = 0; q < CB_PF; ++q) {
                     mm[q] = q < cnt ? src[(size_t)(b0 + q) * W2 + c] : ident;
                     pp[q] = (c == 0 && q < cnt) ? psrc[b0 + q] : 0.0f;
+                    cc[q] = (c == 0 && q < cnt) ? csrc[b0 + q] : 0u;
                 }
 #pragma unroll
                 for (uint32_t q = 0; q < CB_PF; ++q) {
                     if (q >= cnt) break;
                     m = map_compose(m, mm[q]);
                     gp += pp[q];
+                    gc += cc[q];
                 }
             }
             sup[s * W2 + c] = m;
-            if (c == 0) supp[s] = gp;
+            if (c == 0) {
+                supp[s] = gp;
+                supc[s] = gc;
+            }
         }
         __syncthreads();
         const uint32_t have = min(NS, ngrp - g0);
         if (tid < W2) {
             for (uint32_t k = 0; k < have; ++k) tot = map_compose(tot, sup[k * W2 + tid]);
         } else if (tid == W2) {
-            for (uint32_t k = 0; k < have; ++k) ps += supp[k];
+            for (uint32_t k = 0; k < have; ++k) {
+                ps += supp[k];
+                len += supc[k];
+            }
         }
         __syncthreads();
     }
@@ -1391,6 +1507,7 @@ void sampled_tree_bounds(const rp_mccfr* h, uint32_t* maxdec, uint32_t* maxstack
     *maxint = best_int;
 }
 
+size_t chunk_maps_lds_bytes(const rp_mccfr* h);
 int alloc_batch_buffers(rp_mccfr* h, uint32_t batch) {
     if (batch <= h->capacity) return RP_OK;
     if (h->d_scratch) HIP_TRY(hipFree(h->d_scratch));
@@ -1423,7 +1540,7 @@ int alloc_batch_buffers(rp_mccfr* h, uint32_t batch) {
     dc.maxdec = h->maxdec;
     const size_t slot_words = (size_t)dc.maxdec * stride;
     // chunk-local sort: no per-infoset slot map (RP_MCCFR_SLOTMAP=1 forces the large-game path, for tests)
-    const bool small = h->tbl.n_infos <= SM_INFOS && !getenv("RP_MCCFR_SLOTMAP");
+    const bool small = h->tbl.n_infos <= SM_INFOS && chunk_maps_lds_bytes(h) <= 64 * 1024 && !getenv("RP_MCCFR_SLOTMAP");
     const size_t dec_bytes = (3 * slot_words + 2 * slot_words * A) * 4 + (small ? 0 : (size_t)h->tbl.n_infos * stride) + stride;
     HIP_TRY(hipMalloc(&h->d_dec, dec_bytes));
     uint32_t* d = reinterpret_cast<uint32_t*>(h->d_dec);
@@ -1453,8 +1570,8 @@ int alloc_batch_buffers(rp_mccfr* h, uint32_t batch) {
     // per-(infoset, block) maps of the composed update
     if (h->d_bmaps) HIP_TRY(hipFree(h->d_bmaps));
     h->d_bmaps = nullptr;
-    const size_t nblk_max = (stride + rp_compose_block(A) - 1) / rp_compose_block(A);
-    HIP_TRY(hipMalloc(&h->d_bmaps, (size_t)h->tbl.n_infos * nblk_max * (2 * A * sizeof(Map) + sizeof(float))));
+    const size_t nblk_max = (stride + RP_COMPOSE_CHUNK - 1) / RP_COMPOSE_CHUNK;
+    HIP_TRY(hipMalloc(&h->d_bmaps, (size_t)h->tbl.n_infos * nblk_max * (2 * A * sizeof(Map) + sizeof(float) + sizeof(uint32_t))));
     h->capacity = batch;
     return RP_OK;
 }
@@ -1551,9 +1668,9 @@ int launch_sort(rp_mccfr* h, const StepParams& p) {
         hipLaunchKernelGGL(k_scan, dim3(h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->so, p);
         hipLaunchKernelGGL(k_compact_small, dim3(nchunks), dim3(CH_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
     } else {
-        hipLaunchKernelGGL(k_count, dim3(nchunks, h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
+        hipLaunchKernelGGL(k_count, dim3(nchunks, h->tbl.n_infos), dim3(SLOT_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
         hipLaunchKernelGGL(k_scan, dim3(h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->so, p);
-        hipLaunchKernelGGL(k_compact, dim3(nchunks, h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
+        hipLaunchKernelGGL(k_compact, dim3(nchunks, h->tbl.n_infos), dim3(SLOT_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
     }
     clock_end(h, h->clk_compact);
     HIP_TRY(hipGetLastError());
@@ -1575,20 +1692,40 @@ int launch_chain(rp_mccfr* h, const StepParams& p) {
     return RP_OK;
 }
 
+// block bookkeeping of the composed update: one block per (infoset, chunk of RP_COMPOSE_CHUNK trees)
+uint32_t chunks_of(size_t trees) { return (uint32_t)((trees + RP_COMPOSE_CHUNK - 1) / RP_COMPOSE_CHUNK); }
+size_t chunk_maps_lds_bytes(const rp_mccfr* h) {
+    const size_t NI = h->tbl.n_infos;
+    return NI * SM_WORDS * 4 + 2 * SM_INFOS * 4 + (size_t)CH_TREES * h->maxdec * 4 + NI * SM_WORDS * 2 +
+           2 * (size_t)CH_TREES * h->maxdec * 2;
+}
+
+// Decisions of the batch -> one composed map per table cell (+ payoff sum and count per infoset) in `blob_dev`.
+// Small games compose straight from the traversal's output; large ones from the sorted segments (launch_sort first).
 int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev) {
     unsigned char* blob = reinterpret_cast<unsigned char*>(blob_dev);
     Cell* cells = reinterpret_cast<Cell*>(blob);
     InfoSum* sums = reinterpret_cast<InfoSum*>(blob + (size_t)h->tbl.n_infos * h->tbl.max_actions * sizeof(Cell));
-    const uint32_t A = h->tbl.max_actions, T = rp_compose_block(A);
-    const uint32_t nblk_max = (uint32_t)((h->dc.stride + T - 1) / T), nblk = (h->batch + T - 1) / T;
+    const uint32_t A = h->tbl.max_actions;
+    const uint32_t nblk_max = chunks_of(h->dc.stride), nblk = chunks_of(h->batch);
+    const size_t slots = (size_t)h->tbl.n_infos * nblk_max;
     Map* bmaps = reinterpret_cast<Map*>(h->d_bmaps);
-    float* bpsum = reinterpret_cast<float*>(bmaps + (size_t)h->tbl.n_infos * nblk_max * 2 * A);
+    float* bpsum = reinterpret_cast<float*>(bmaps + slots * 2 * A);
+    uint32_t* bcnt = reinterpret_cast<uint32_t*>(bpsum + slots);
+    const bool pruned = h->S != RP_SAMPLING_EXTERNAL;
     clock_begin(h, h->clk_update);
-    if (h->S != RP_SAMPLING_EXTERNAL)
-        hipLaunchKernelGGL((k_block_maps<true>), dim3(nblk, h->tbl.n_infos), dim3(128), 0, h->stream, h->g, h->so, p, bmaps, bpsum, nblk_max);
-    else
-        hipLaunchKernelGGL((k_block_maps<false>), dim3(nblk, h->tbl.n_infos), dim3(128), 0, h->stream, h->g, h->so, p, bmaps, bpsum, nblk_max);
-    hipLaunchKernelGGL(k_combine, dim3(h->tbl.n_infos), dim3(256), 0, h->stream, h->g, h->so, p, bmaps, bpsum, nblk_max, cells, sums);
+    if (!h->dc.slotmap) {
+        const size_t lds = chunk_maps_lds_bytes(h);
+        if (pruned)
+            hipLaunchKernelGGL((k_chunk_maps<true>), dim3(nblk), dim3(CH_THREADS), lds, h->stream, h->g, h->dc, p, bmaps, bpsum, bcnt, nblk_max);
+        else
+            hipLaunchKernelGGL((k_chunk_maps<false>), dim3(nblk), dim3(CH_THREADS), lds, h->stream, h->g, h->dc, p, bmaps, bpsum, bcnt, nblk_max);
+    } else if (pruned) {
+        hipLaunchKernelGGL((k_block_maps<true>), dim3(nblk, h->tbl.n_infos), dim3(128), 0, h->stream, h->g, h->so, p, bmaps, bpsum, bcnt, nblk_max);
+    } else {
+        hipLaunchKernelGGL((k_block_maps<false>), dim3(nblk, h->tbl.n_infos), dim3(128), 0, h->stream, h->g, h->so, p, bmaps, bpsum, bcnt, nblk_max);
+    }
+    hipLaunchKernelGGL(k_combine, dim3(h->tbl.n_infos), dim3(256), 0, h->stream, h->g, p, bmaps, bpsum, bcnt, nblk_max, cells, sums);
     clock_end(h, h->clk_update);
     HIP_TRY(hipGetLastError());
     return RP_OK;
@@ -1597,7 +1734,10 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev) {
 int enqueue_step(rp_mccfr* h) {
     const StepParams p = make_params(h);
     int rc = launch_traverse(h, p);
-    if (rc || (rc = launch_sort(h, p))) return rc;
+    if (rc) return rc;
+    // the ordered chains and the large-game composed path read the sorted segments; small games compose from the
+    // traversal's output directly
+    if ((h->mode == RP_UPDATE_ORDERED || h->dc.slotmap) && (rc = launch_sort(h, p))) return rc;
     if (h->mode == RP_UPDATE_ORDERED) {
         if ((rc = launch_chain(h, p))) return rc;
     } else {
@@ -2031,7 +2171,8 @@ int rp_mccfr_step_local(rp_mccfr* h, void* summary_dev) {
     if (rc) return rc;
     if ((rc = composed_supported(h))) return rc;
     const StepParams p = make_params(h);
-    if ((rc = launch_traverse(h, p)) || (rc = launch_sort(h, p))) return rc;
+    if ((rc = launch_traverse(h, p))) return rc;
+    if (h->dc.slotmap && (rc = launch_sort(h, p))) return rc;
     return launch_summarize(h, p, summary_dev);
 }
 

@@ -145,7 +145,7 @@ struct Map {
     float a, b, m;
     uint32_t n;
 };
-// include/rp_mi355x.h rp_compose_block, callable from device code
+// touches per LDS tile of the block-map chains
 __host__ __device__ inline uint32_t compose_block(uint32_t max_actions) { return (1024u / (2u * max_actions)) & ~3u; }
 __device__ __forceinline__ Map map_compose(const Map& first, const Map& second) {  // `first` is applied first
     if (second.n == 0) return first;

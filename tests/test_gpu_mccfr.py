@@ -161,7 +161,10 @@ def test_slotmap_sort_variant_for_large_games_is_identical(gpu, monkeypatch):
     a = Solver(g, "linear", "linear", "pluribus", batch=3000, seed=5)
     monkeypatch.delenv("RP_MCCFR_SLOTMAP")
     b = Solver(g, "linear", "linear", "pluribus", batch=3000, seed=5)
-    for _ in range(6):
+    for k in range(6):
+        if k == 3:  # both update modes go through the sorted segments on the large-game path
+            a.set_update_mode("composed")
+            b.set_update_mode("composed")
         a.step()
         b.step()
     ra, rb = a.export(), b.export()
