@@ -204,7 +204,7 @@ def test_import_export_roundtrip_and_resume(gpu):
     ("kuhn", "linear", "constant", "prunable", 4097)])
 def test_composed_mode_matches_oracle_world_semantics(gpu, game, regret, weight, sampling, batch):
     # single-GPU composed update == the oracle's model of the blocked composition (world = 1), bit for bit;
-    # batches large enough that hot infosets span several rp_compose_block(A) blocks
+    # batches of several RP_COMPOSE_CHUNK-tree chunks: every infoset folds several blocks
     g = Game(game)
     hp = oracle.default_hyper()
     hp.prune_warmup = 2

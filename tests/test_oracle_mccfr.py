@@ -169,7 +169,7 @@ def test_first_epoch_semantics(kuhn):
 def test_composed_world_update_matches_ordered_within_tolerance(leduc):
     # the multi-GPU exchange semantics (ora_mccfr_step_world) against plain ordered steps on the same
     # world*B trees: identical sampling, fp32-reassociation-level difference in the tables
-    B, world = 1500, 4  # hot infosets span several rp_compose_block(A) = 256-touch blocks per rank
+    B, world = 1500, 4  # several RP_COMPOSE_CHUNK-tree chunks (= blocks per infoset) per rank
     a = oracle.OracleSolver(leduc, "linear", "linear", "external", batch=B * world, seed=11)
     b = oracle.OracleSolver(leduc, "linear", "linear", "external", batch=B, seed=11)
     for _ in range(6):
