@@ -1638,8 +1638,7 @@ int launch_traverse(rp_mccfr* h, const StepParams& p) {
     clock_begin(h, h->clk_traverse);
     if (h->use_lds_traverse) {
         hipLaunchKernelGGL(k_prepare_infos, dim3((h->tbl.n_infos + 63) / 64), dim3(64), 0, h->stream, h->g, h->t, p, h->itab);
-        const char* pad = getenv("RP_TRAV_PAD_LDS");  // occupancy experiments
-        const size_t lds = traverse_lds_bytes(h) + (pad ? atoi(pad) : 0);
+        const size_t lds = traverse_lds_bytes(h);
         const dim3 grid((h->batch + 63) / 64), block(64);
         const bool tvreg = h->tbl.max_actions <= 4, tablds = traverse_tables_in_lds(h);
 #define LAUNCH_TRAVERSE(TV, TB) \
