@@ -12,11 +12,13 @@ from robopoker_amd.parallel import rp_mulhi64, rp_stream
 pytestmark = pytest.mark.gpu
 
 
-def test_mccfr_two_shards_on_one_gpu_match_world_model(gpu):
+@pytest.mark.parametrize("B,world", [(500, 2), (700, 8)])
+def test_mccfr_shards_on_one_gpu_match_world_model(gpu, B, world):
+    # `world` handles play the ranks of one node (the driver's 8-GPU run is world = 8): every replica must end each
+    # step with the oracle's world-model table, bit for bit
     import torch
 
     g = Game("leduc")
-    B, world = 500, 2
     devs = [Solver(g, "floored", "linear", "external", batch=B, seed=33) for _ in range(world)]
     for r, d in enumerate(devs):
         d.set_shard(r, world)
