@@ -41,7 +41,7 @@ def parse():
                          "NLHE-scale infoset batches through the sparse profile (SURVEY.md §8d config 4)")
     ap.add_argument("--rows", type=int, default=1 << 27, help="nlhe-synth: table rows (infoset slots)")
     ap.add_argument("--decisions", type=int, default=128 * 1500, help="nlhe-synth: Decisions per step per GPU")
-    ap.add_argument("--game", default="leduc", choices=["leduc", "kuhn", "rps"])
+    ap.add_argument("--game", default="leduc", choices=["leduc", "kuhn", "rps", "leduc_wide"])
     ap.add_argument("--regret", default="floored")
     ap.add_argument("--weight", default="linear")
     ap.add_argument("--sampling", default="external")

@@ -139,7 +139,9 @@ typedef struct rp_game_table {
 } rp_game_table;
 
 /* Built-in game models (crates/kuhn, crates/leduc, crates/roshambo), owned by the library. */
-typedef enum rp_game_kind { RP_GAME_KUHN = 0, RP_GAME_LEDUC = 1, RP_GAME_RPS = 2 } rp_game_kind;
+/* RP_GAME_LEDUC_WIDE is synthetic (not a reference game): Leduc's rules over seven ranks, 616 infosets — it exists to
+ * exercise the large-game kernels (more than 256 infosets) with a game the oracle can also play */
+typedef enum rp_game_kind { RP_GAME_KUHN = 0, RP_GAME_LEDUC = 1, RP_GAME_RPS = 2, RP_GAME_LEDUC_WIDE = 3 } rp_game_kind;
 typedef struct rp_game rp_game;
 RP_API int rp_game_create(rp_game_kind kind, rp_game** out);
 RP_API int rp_game_view(const rp_game* g, rp_game_table* out); /* pointers valid until destroy */

@@ -27,7 +27,7 @@ RP_NO_INFO = 0xFFFFFFFF
 REGRET = {"summed": 0, "linear": 1, "discounted": 2, "floored": 3, "asymmetric": 4}
 WEIGHT = {"constant": 0, "linear": 1, "quadratic": 2, "exponential": 3}
 SAMPLING = {"external": 0, "prunable": 1, "pluribus": 2}
-GAME = {"kuhn": 0, "leduc": 1, "rps": 2}
+GAME = {"kuhn": 0, "leduc": 1, "rps": 2, "leduc_wide": 3}
 DIST = {"iterated": 0, "averaged": 1, "sampling": 2}
 METRIC = {"sinkhorn": 0, "variation": 1}
 UPDATE = {"ordered": 0, "composed": 1}

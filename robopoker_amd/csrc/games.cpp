@@ -63,8 +63,11 @@ struct Builder {
     void set_child(uint32_t parent, uint32_t k, uint32_t child) { children[states[parent].offset + k] = child; }
 };
 
-const char* RANKS = "JQK";
-inline int rank_of(int card) { return card / 2; }  // Card::ALL = J0 J1 Q0 Q1 K0 K1 (card.rs)
+// Card::ALL = J0 J1 Q0 Q1 K0 K1 (card.rs): two suits per rank.  The reference games have three ranks; the synthetic
+// "wide" Leduc (RP_GAME_LEDUC_WIDE, same rules) has seven, which pushes the infoset count past 256.
+thread_local int g_cards = 6;
+thread_local const char* RANKS = "JQK";
+inline int rank_of(int card) { return card / 2; }
 
 // ------------------------------------------------------------------ Kuhn
 // Node::{Open, Check, Bet, CheckBet, Over} kuhn/src/game.rs:7-15; apply :131-151; payoff :35-64
@@ -111,12 +114,12 @@ uint32_t kuhn_node(Builder& b, int c0, int c1, KuhnNode node) {
 // root() = uniform ordered pair of distinct cards (game.rs:115-123) = the same two chance draws.
 template <class F>
 uint32_t deal_prefix(Builder& b, F first_decision) {
-    uint32_t start = b.inner(RP_TURN_CHANCE, 6, RP_NO_INFO);
-    for (int c0 = 0; c0 < 6; ++c0) {
-        uint32_t dealt = b.inner(RP_TURN_CHANCE, 5, RP_NO_INFO);
+    uint32_t start = b.inner(RP_TURN_CHANCE, (uint8_t)g_cards, RP_NO_INFO);
+    for (int c0 = 0; c0 < g_cards; ++c0) {
+        uint32_t dealt = b.inner(RP_TURN_CHANCE, (uint8_t)(g_cards - 1), RP_NO_INFO);
         b.set_child(start, (uint32_t)c0, dealt);
         uint32_t k = 0;
-        for (int c1 = 0; c1 < 6; ++c1) {
+        for (int c1 = 0; c1 < g_cards; ++c1) {
             if (c1 == c0) continue;
             b.set_child(dealt, k++, first_decision(c0, c1));
         }
@@ -203,9 +206,9 @@ uint32_t leduc_r2(Builder& b, int c0, int c1, int board, Spot r1, Spot r2) {
 }
 // Node::Deal(spot): chance over the 4 undealt cards in Card::ALL order (game.rs:152-161)
 uint32_t leduc_deal(Builder& b, int c0, int c1, Spot r1) {
-    uint32_t s = b.inner(RP_TURN_CHANCE, 4, RP_NO_INFO);
+    uint32_t s = b.inner(RP_TURN_CHANCE, (uint8_t)(g_cards - 2), RP_NO_INFO);
     uint32_t k = 0;
-    for (int c = 0; c < 6; ++c) {
+    for (int c = 0; c < g_cards; ++c) {
         if (c == c0 || c == c1) continue;
         b.set_child(s, k++, leduc_r2(b, c0, c1, c, r1, S_OPEN));
     }
@@ -332,6 +335,13 @@ int rp_game_create(rp_game_kind kind, rp_game** out) {
             break;
         case RP_GAME_LEDUC:
             root = deal_prefix(g->b, [&](int c0, int c1) { return leduc_r1(g->b, c0, c1, S_OPEN); });
+            break;
+        case RP_GAME_LEDUC_WIDE:  // synthetic: Leduc's rules over seven ranks (14 cards): 616 infosets
+            g_cards = 14;
+            RANKS = "789TJQK";
+            root = deal_prefix(g->b, [&](int c0, int c1) { return leduc_r1(g->b, c0, c1, S_OPEN); });
+            g_cards = 6;
+            RANKS = "JQK";
             break;
         case RP_GAME_RPS:
             root = rps_build(g->b);

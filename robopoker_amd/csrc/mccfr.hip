@@ -768,11 +768,11 @@ __global__ __launch_bounds__(SLOT_THREADS) void k_compact(DevGame g, DevDecision
     }
 }
 
-// ---- small games (n_infos <= SM_INFOS): the same stable counting sort without the per-infoset slot map --------
+// ---- games whose per-chunk bitmap fits in LDS (56 B per infoset): the same stable counting sort without the
+// per-infoset slot map in HBM --------
 // One workgroup per chunk of CH_TREES trees.  A tree's Decisions are marked in an LDS bitmap [infoset][tree]; the
 // rank of a Decisions inside its (chunk, infoset) bucket — its place in tree-id order — is a prefix popcount of that
 // bitmap row.  Every Decisions is read once; nothing is scanned per infoset.
-#define SM_INFOS 256u
 static_assert(CH_TREES == RP_COMPOSE_CHUNK, "a block of the composed update is one compaction chunk of trees");
 #define SM_WORDS (CH_TREES / 32u)
 __device__ __forceinline__ void chunk_bitmap(const DevDecisions& dc, uint32_t n_infos, uint32_t chunk, uint32_t batch,
@@ -788,8 +788,21 @@ __device__ __forceinline__ void chunk_bitmap(const DevDecisions& dc, uint32_t n_
     }
     __syncthreads();
 }
+// exclusive scan of in[0..n) into out[0..n) (both LDS), any n, by the whole workgroup
+__device__ __forceinline__ void lds_exscan(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* wave_tot) {
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < n; b0 += blockDim.x) {
+        const uint32_t i = b0 + threadIdx.x;
+        uint32_t tot;
+        const uint32_t ex = block_exscan(i < n ? in[i] : 0u, wave_tot, &tot);
+        if (i < n) out[i] = carry + ex;
+        carry += tot;
+    }
+    __syncthreads();
+}
 __global__ __launch_bounds__(CH_THREADS) void k_count_small(DevGame g, DevDecisions dc, DevSorted so, StepParams p) {
-    __shared__ uint32_t bits[SM_INFOS * SM_WORDS];
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm_lds[];
+    uint32_t* bits = sm_lds;  // [n_infos][SM_WORDS]
     const uint32_t chunk = blockIdx.x;
     chunk_bitmap(dc, g.n_infos, chunk, p.batch, bits);
     for (uint32_t info = threadIdx.x; info < g.n_infos; info += CH_THREADS) {
@@ -799,10 +812,13 @@ __global__ __launch_bounds__(CH_THREADS) void k_count_small(DevGame g, DevDecisi
     }
 }
 __global__ __launch_bounds__(CH_THREADS) void k_compact_small(DevGame g, DevDecisions dc, DevSorted so, StepParams p) {
-    __shared__ uint32_t bits[SM_INFOS * SM_WORDS];
-    __shared__ uint16_t pre[SM_INFOS * SM_WORDS];  // trees of the chunk before word w that visited the infoset
-    __shared__ uint32_t base[SM_INFOS];            // first position of the (chunk, infoset) bucket
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm_lds[];
     __shared__ uint32_t wave_tot[CH_THREADS / 64];
+    const uint32_t NI = g.n_infos;
+    uint32_t* bits = sm_lds;                                        // [NI][SM_WORDS]
+    uint32_t* base = bits + NI * SM_WORDS;                          // [NI] first position of the (chunk, infoset) bucket
+    uint32_t* tots = base + NI;                                     // [NI] segment lengths
+    uint16_t* pre = reinterpret_cast<uint16_t*>(tots + NI);         // [NI][SM_WORDS] trees before word w that visited the infoset
     const uint32_t chunk = blockIdx.x;
     chunk_bitmap(dc, g.n_infos, chunk, p.batch, bits);
     for (uint32_t info = threadIdx.x; info < g.n_infos; info += CH_THREADS) {
@@ -812,13 +828,11 @@ __global__ __launch_bounds__(CH_THREADS) void k_compact_small(DevGame g, DevDeci
             run += __popc(bits[info * SM_WORDS + w]);
         }
     }
-    {   // bucket base = sum of the lengths of all lower infosets + this chunk's offset inside the infoset's segment
-        const uint32_t info = threadIdx.x;  // n_infos <= SM_INFOS == CH_THREADS
-        const uint32_t v = info < g.n_infos ? so.total[info] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_exscan(v, wave_tot, &tot);
-        if (info < g.n_infos) base[info] = ex + so.offs[(size_t)info * so.n_chunks + chunk];
-    }
+    // bucket base = sum of the lengths of all lower infosets + this chunk's offset inside the infoset's segment
+    for (uint32_t info = threadIdx.x; info < NI; info += CH_THREADS) tots[info] = so.total[info];
+    __syncthreads();
+    lds_exscan(tots, base, NI, wave_tot);
+    for (uint32_t info = threadIdx.x; info < NI; info += CH_THREADS) base[info] += so.offs[(size_t)info * so.n_chunks + chunk];
     __syncthreads();
     const uint32_t A = g.A;
     const float tf = (float)p.epoch;
@@ -1203,9 +1217,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chunk_maps(DevGame g, DevDecisio
     __shared__ uint32_t wave_tot[CH_THREADS / 64];
     const uint32_t NI = g.n_infos, A = g.A, W2 = 2 * A, chunk = blockIdx.x, tid = threadIdx.x, MD = dc.maxdec;
     uint32_t* bits = cm_lds;                                              // [NI][SM_WORDS]
-    uint32_t* lcount = bits + NI * SM_WORDS;                              // [SM_INFOS]
-    uint32_t* lbase = lcount + SM_INFOS;                                  // [SM_INFOS]
-    float* vals = reinterpret_cast<float*>(lbase + SM_INFOS);             // [MD * CH_TREES] one cell's values, list order
+    uint32_t* lcount = bits + NI * SM_WORDS;                              // [NI]
+    uint32_t* lbase = lcount + NI;                                        // [NI]
+    float* vals = reinterpret_cast<float*>(lbase + NI);                   // [MD * CH_TREES] one cell's values, list order
     uint16_t* pre = reinterpret_cast<uint16_t*>(vals + MD * CH_TREES);    // [NI][SM_WORDS]
     uint16_t* posl = pre + NI * SM_WORDS;                                 // [MD][CH_TREES] list position of (slot, tree)
     uint16_t* lmask = posl + MD * CH_TREES;                               // [MD * CH_TREES] expanded-edge masks (PRUNED)
@@ -1219,12 +1233,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chunk_maps(DevGame g, DevDecisio
         lcount[info] = run;
     }
     __syncthreads();
-    {
-        uint32_t tot;
-        const uint32_t ex = block_exscan(tid < NI ? lcount[tid] : 0u, wave_tot, &tot);  // NI <= SM_INFOS == CH_THREADS
-        if (tid < NI) lbase[tid] = ex;
-    }
-    __syncthreads();
+    lds_exscan(lcount, lbase, NI, wave_tot);
     const uint32_t lt = tid, tree = chunk * CH_TREES + lt;  // CH_TREES == CH_THREADS: one tree per thread
     const uint32_t nd = tree < p.batch ? dc.ndec[tree] : 0u;
     for (uint32_t slot = 0; slot < nd; ++slot) {
@@ -1236,11 +1245,6 @@ __global__ __launch_bounds__(CH_THREADS) void k_chunk_maps(DevGame g, DevDecisio
     }
     const float NEG_INF = rp_u2f(0xff800000u);
     const float tf = (float)p.epoch;
-    const uint32_t info = tid;  // chain phase: thread i = infoset i
-    const bool mine = info < NI && g.info_player[info < NI ? info : 0u] == p.walker;
-    const uint32_t nact = mine ? g.info_actions[info] : 0u;
-    const uint32_t n = mine ? lcount[info] : 0u, base = mine ? lbase[info] : 0u;
-    const size_t slot_out = (size_t)info * nblk_max + chunk;
     for (uint32_t c = 0; c <= W2; ++c) {  // regret cells, weight cells, then the payoff sum
         const bool isreg = c < A, ispay = c == W2;
         const uint32_t a = c % A;
@@ -1256,34 +1260,38 @@ __global__ __launch_bounds__(CH_THREADS) void k_chunk_maps(DevGame g, DevDecisio
             vals[posl[slot * CH_TREES + lt]] = v;
         }
         __syncthreads();
-        if (!mine) continue;
-        if (ispay) {  // payoff sum of the block, left fold from 0.0f
-            float sum = 0.0f;
-            for (uint32_t e = 0; e < n; ++e) sum += vals[base + e];
-            bpsum[slot_out] = sum;
-            bcnt[slot_out] = n;
-            continue;
-        }
-        const bool chain = a < nact;
-        const float fl = isreg ? regret_floor_of(p.R, p.regret_min) : RP_EPSILON;
-        const float d = isreg ? (p.R == RP_REGRET_LINEAR ? tf / (tf + 1.0f) : 1.0f) : (p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f);
-        float ma = 1.0f, mb = 0.0f, mm = NEG_INF;
-        uint32_t cnt = 0;
-        if (chain) {
-            for (uint32_t e = 0; e < n; ++e) {
-                const float delta = vals[base + e];
-                const bool skip = PRUNED && isreg && !((lmask[base + e] >> a) & 1u);
-                // first touch of the block: (d, delta, floor); then a <- a d, b <- b d + delta, m <- max(m d + delta, floor)
-                const float na = cnt ? ma * d : d;
-                const float nb = cnt ? mb * d + delta : delta;
-                const float nm = cnt ? rp_maxf(mm * d + delta, fl) : fl;
-                ma = skip ? ma : na;
-                mb = skip ? mb : nb;
-                mm = skip ? mm : nm;
-                cnt += skip ? 0u : 1u;
+        for (uint32_t info = tid; info < NI; info += CH_THREADS) {  // chain phase: one thread per infoset
+            if (g.info_player[info] != p.walker) continue;
+            const uint32_t n = lcount[info], base = lbase[info];
+            const size_t slot_out = (size_t)info * nblk_max + chunk;
+            if (ispay) {  // payoff sum of the block, left fold from 0.0f
+                float sum = 0.0f;
+                for (uint32_t e = 0; e < n; ++e) sum += vals[base + e];
+                bpsum[slot_out] = sum;
+                bcnt[slot_out] = n;
+                continue;
             }
+            const bool chain = a < g.info_actions[info];
+            const float fl = isreg ? regret_floor_of(p.R, p.regret_min) : RP_EPSILON;
+            const float d = isreg ? (p.R == RP_REGRET_LINEAR ? tf / (tf + 1.0f) : 1.0f) : (p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f);
+            float ma = 1.0f, mb = 0.0f, mm = NEG_INF;
+            uint32_t cnt = 0;
+            if (chain) {
+                for (uint32_t e = 0; e < n; ++e) {
+                    const float delta = vals[base + e];
+                    const bool skip = PRUNED && isreg && !((lmask[base + e] >> a) & 1u);
+                    // first touch of the block: (d, delta, floor); then a <- a d, b <- b d + delta, m <- max(m d + delta, floor)
+                    const float na = cnt ? ma * d : d;
+                    const float nb = cnt ? mb * d + delta : delta;
+                    const float nm = cnt ? rp_maxf(mm * d + delta, fl) : fl;
+                    ma = skip ? ma : na;
+                    mb = skip ? mb : nb;
+                    mm = skip ? mm : nm;
+                    cnt += skip ? 0u : 1u;
+                }
+            }
+            bmaps[slot_out * W2 + c] = Map{ma, mb, mm, chain ? cnt : 0u};
         }
-        bmaps[slot_out * W2 + c] = Map{ma, mb, mm, chain ? cnt : 0u};
     }
 }
 
@@ -1540,7 +1548,7 @@ int alloc_batch_buffers(rp_mccfr* h, uint32_t batch) {
     dc.maxdec = h->maxdec;
     const size_t slot_words = (size_t)dc.maxdec * stride;
     // chunk-local sort: no per-infoset slot map (RP_MCCFR_SLOTMAP=1 forces the large-game path, for tests)
-    const bool small = h->tbl.n_infos <= SM_INFOS && chunk_maps_lds_bytes(h) <= 64 * 1024 && !getenv("RP_MCCFR_SLOTMAP");
+    const bool small = chunk_maps_lds_bytes(h) <= 64 * 1024 && !getenv("RP_MCCFR_SLOTMAP");
     const size_t dec_bytes = (3 * slot_words + 2 * slot_words * A) * 4 + (small ? 0 : (size_t)h->tbl.n_infos * stride) + stride;
     HIP_TRY(hipMalloc(&h->d_dec, dec_bytes));
     uint32_t* d = reinterpret_cast<uint32_t*>(h->d_dec);
@@ -1663,9 +1671,11 @@ int launch_sort(rp_mccfr* h, const StepParams& p) {
     h->so.n_chunks = nchunks;
     clock_begin(h, h->clk_compact);
     if (!h->dc.slotmap) {
-        hipLaunchKernelGGL(k_count_small, dim3(nchunks), dim3(CH_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
+        const size_t NI = h->tbl.n_infos;
+        hipLaunchKernelGGL(k_count_small, dim3(nchunks), dim3(CH_THREADS), NI * SM_WORDS * 4, h->stream, h->g, h->dc, h->so, p);
         hipLaunchKernelGGL(k_scan, dim3(h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->so, p);
-        hipLaunchKernelGGL(k_compact_small, dim3(nchunks), dim3(CH_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
+        hipLaunchKernelGGL(k_compact_small, dim3(nchunks), dim3(CH_THREADS), NI * SM_WORDS * 4 + 2 * NI * 4 + NI * SM_WORDS * 2,
+                           h->stream, h->g, h->dc, h->so, p);
     } else {
         hipLaunchKernelGGL(k_count, dim3(nchunks, h->tbl.n_infos), dim3(SLOT_THREADS), 0, h->stream, h->g, h->dc, h->so, p);
         hipLaunchKernelGGL(k_scan, dim3(h->tbl.n_infos), dim3(CH_THREADS), 0, h->stream, h->g, h->so, p);
@@ -1695,7 +1705,7 @@ int launch_chain(rp_mccfr* h, const StepParams& p) {
 uint32_t chunks_of(size_t trees) { return (uint32_t)((trees + RP_COMPOSE_CHUNK - 1) / RP_COMPOSE_CHUNK); }
 size_t chunk_maps_lds_bytes(const rp_mccfr* h) {
     const size_t NI = h->tbl.n_infos;
-    return NI * SM_WORDS * 4 + 2 * SM_INFOS * 4 + (size_t)CH_TREES * h->maxdec * 4 + NI * SM_WORDS * 2 +
+    return NI * SM_WORDS * 4 + 2 * NI * 4 + (size_t)CH_TREES * h->maxdec * 4 + NI * SM_WORDS * 2 +
            2 * (size_t)CH_TREES * h->maxdec * 2;
 }
 

@@ -154,6 +154,30 @@ def test_long_run_stays_bit_exact(gpu, mode, game, regret, weight, sampling):
     assert dev.counters() == ora.counters()
 
 
+@pytest.mark.parametrize("mode", ["ordered", "composed"])
+@pytest.mark.parametrize("regret,weight,sampling", [("floored", "linear", "external"), ("linear", "quadratic", "pluribus")])
+def test_wide_leduc_takes_the_large_game_path_bit_exact(gpu, mode, regret, weight, sampling):
+    # 616 infosets (> 256): per-infoset slot map, k_count / k_compact, k_block_maps over (infoset, chunk) groups
+    g = Game("leduc_wide")
+    assert g.n_infos == 616
+    hp = oracle.default_hyper()
+    hp.prune_warmup = 3
+    dev = Solver(g, regret, weight, sampling, batch=1500, seed=77, hyper=hp)
+    ora = oracle.OracleSolver(g, regret, weight, sampling, batch=1500, seed=77, hyper=hp)
+    if mode == "composed":
+        dev.set_update_mode("composed")
+    for _ in range(10):
+        dev.step()
+        if mode == "composed":
+            ora.step_world(1)
+        else:
+            ora.step()
+    a, b = dev.export(), ora.export()
+    for f in ("visits", "regret", "weight", "payoff"):
+        assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), f
+    assert dev.counters() == ora.counters()
+
+
 def test_slotmap_sort_variant_for_large_games_is_identical(gpu, monkeypatch):
     # games with more than 256 infosets sort their Decisions through a per-infoset slot map; force that path on Leduc
     g = Game("leduc")
