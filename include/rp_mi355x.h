@@ -380,6 +380,56 @@ RP_API int rp_sinkhorn_cost(uint32_t bins, uint64_t pairs, const uint32_t* mu, c
 RP_API int rp_equity_variation(uint32_t bins, uint64_t pairs, const uint32_t* x, const uint32_t* y, int device,
                                float* out);
 
+/* =================================================================================================
+ * Abstraction inputs: what feeds the k-means layers above.
+ *   crates/deuce/src — cards, hand strength, river equity, suit isomorphism and its iterator;
+ *   crates/lloyd/src/lookup.rs — the (isomorphism -> abstraction) table and its projection onto the
+ *   previous street's histograms (the k-means points).
+ * Encodings are the reference's: card = rank * 4 + suit (card.rs:16-20; rank 0 = Two .. 12 = Ace, suit
+ * c, d, h, s = 0..3); Hand = u64 bit set of cards (hand.rs:7); Observation as i64 = one byte
+ * (card + 1) per card, public cards then pocket cards, each ascending, first card most significant
+ * (observation.rs:132-165) — the `obs BIGINT` column of the reference's tables.
+ * `*_dev` arguments are DEVICE pointers the caller has finished writing; calls return after the
+ * device finished.  Bulk work shards across GPUs by pocket range / observation slice, no exchange.
+ * ================================================================================================= */
+typedef enum rp_street { RP_STREET_PREF = 0, RP_STREET_FLOP = 1, RP_STREET_TURN = 2, RP_STREET_RIVE = 3 } rp_street;
+
+/* Strength::from(Hand) (strength.rs:18-32 = Evaluator::find_ranking + find_kickers, evaluator.rs:38-72) for n
+ * hands of 5..7 cards (host arrays).  key = variant << 21 | rank1 << 17 | rank2 << 13 | kickers, variant in the
+ * default build's Ranking order (ranking.rs:17-29: HighCard 0 .. StraightFlush 8; Flush above FullHouse as
+ * declared there): integer order of keys == the reference's derived Ord on Strength. */
+RP_API int rp_hand_strength(int device, uint64_t n, const uint64_t* hands, uint32_t* keys);
+/* i64::from(Isomorphism::from(Observation::from(obs))) (isomorphism.rs:8-14, permutation.rs:9-71), host arrays */
+RP_API int rp_obs_canonical(int device, uint64_t n, const int64_t* obs, int64_t* canon);
+/* IsomorphismIterator::from(street) (isomorphism_iter.rs:7-26 over observation_iter.rs:13-104), restricted to the
+ * pockets numbered [pocket_lo, pocket_hi) of the 1326 two-card hands in ascending bit-set order (the iterator's outer
+ * loop).  Writes the canonical observations, in the iterator's order, to obs_dev[0..min(*n, cap)) and the number
+ * there are to *n; obs_dev may be NULL to count.  All pockets: 169 / 1 286 792 / 13 960 050 / 123 156 254
+ * (street.rs:120-127). */
+RP_API int rp_isomorphisms(int device, int street, uint32_t pocket_lo, uint32_t pocket_hi, int64_t* obs_dev,
+                           uint64_t cap, uint64_t* n);
+/* Observation::equity (observation.rs:45-63) of n river observations: wins / (wins + losses) over the 990 opposing
+ * holes, 0.5 when every showdown ties; bucket = Abstraction::from(Probability)'s index (kicker/src/abstraction.rs:
+ * 61-63,93-99: round(p * 100)) = Lookup::grow(Street::Rive) (lookup.rs:172-178).  Either output may be NULL. */
+RP_API int rp_river_equity(int device, uint64_t n, const int64_t* obs_dev, float* equity_dev, uint8_t* bucket_dev);
+
+/* Lookup (lookup.rs:9-25): `n` isomorphisms of one street with their abstraction indices, in
+ * IsomorphismIterator order (checked).  The table is copied. */
+typedef struct rp_lookup rp_lookup;
+RP_API int rp_lookup_create(int device, int street, uint64_t n, const int64_t* obs_dev, const uint8_t* abs_dev,
+                            rp_lookup** out);
+RP_API int rp_lookup_destroy(rp_lookup* h);
+/* Lookup::lookup(&Isomorphism::from(obs)) for n observations of the table's street (any suit labelling).  A miss
+ * is RP_ERR_INVALID (the reference panics, lookup.rs:24). */
+RP_API int rp_lookup_get(rp_lookup* h, uint64_t n, const int64_t* obs_dev, uint8_t* abs_dev);
+/* Lookup::projections / future (lookup.rs:27-45): for each of n observations of the PREVIOUS street, the histogram
+ * of the table's abstractions over its children (Observation::children, observation.rs:35-40: 47 turns of a flop,
+ * 46 rivers of a turn), Histogram::from(Vec<Abstraction>) (histogram.rs:207-212).  hist_dev[n][bins] u8 — the
+ * `counts` layout of rp_kmeans_create_device. */
+RP_API int rp_lookup_project(rp_lookup* h, uint64_t n, const int64_t* obs_dev, uint32_t bins, uint8_t* hist_dev);
+/* device time of the calling thread's last call in this section, from HIP events around its launches */
+RP_API int rp_deuce_kernel_ms(double* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -207,6 +207,15 @@ _SIGNATURES = {
          C.c_void_p],
     ),
     "rp_equity_variation": (C.c_int, [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "rp_hand_strength": (C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "rp_obs_canonical": (C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "rp_isomorphisms": (C.c_int, [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "rp_river_equity": (C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rp_lookup_create": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rp_lookup_destroy": (C.c_int, [C.c_void_p]),
+    "rp_lookup_get": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "rp_lookup_project": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rp_deuce_kernel_ms": (C.c_int, [C.POINTER(C.c_double)]),
 }
 
 _lib = None

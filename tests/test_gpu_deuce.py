@@ -1,0 +1,196 @@
+"""MI355X parity of the abstraction inputs (robopoker_amd/csrc/deuce.hip) against the CPU oracle and the reference's
+published counts.  Integer work: every comparison is exact; the one float (river equity) is compared bit for bit."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import oracle_deuce as od  # noqa: E402
+from test_oracle_deuce import EVALUATOR_KATS, ISOMORPHISM_KATS  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def deuce():
+    from robopoker_amd import deuce as d
+    return d
+
+
+def _random_obs(rng, n_board):
+    cards = rng.sample(range(52), 2 + n_board)
+    return sum(1 << c for c in cards[:2]), sum(1 << c for c in cards[2:])
+
+
+def test_strength_matches_oracle(deuce):
+    rng = random.Random(1)
+    hands = [od.hand(k[0]) for k in EVALUATOR_KATS]
+    for size in (5, 6, 7):
+        hands += [sum(1 << c for c in rng.sample(range(52), size)) for _ in range(60000)]
+    # hands dense in one suit / few ranks: flushes, straight flushes, quads and full houses are rare at random
+    for _ in range(20000):
+        suit = rng.randrange(4)
+        ranks = rng.sample(range(13), rng.randint(4, 7))
+        h = sum(1 << (r * 4 + suit) for r in ranks)
+        while bin(h).count("1") < 7:
+            h |= 1 << rng.randrange(52)
+        if bin(h).count("1") == 7:
+            hands.append(h)
+    for _ in range(20000):
+        ranks = rng.sample(range(13), 3)
+        pool = [r * 4 + s for r in ranks for s in range(4)]
+        hands.append(sum(1 << c for c in rng.sample(pool, 7)))
+    got = deuce.hand_strength(hands)
+    want = np.array([od.strength_key(h) for h in hands], dtype=np.uint32)
+    assert np.array_equal(got, want)
+    assert len(set((want >> 21).tolist())) == 9  # every ranking variant occurred
+
+
+def test_canonical_matches_oracle(deuce):
+    rng = random.Random(2)
+    obs = [od.obs_i64(*od.obs(a)) for pair in ISOMORPHISM_KATS for a in pair]
+    for n_board in (0, 3, 4, 5):
+        obs += [od.obs_i64(*_random_obs(rng, n_board)) for _ in range(20000)]
+    got = deuce.canonical(obs)
+    want = np.array([od.obs_i64(*od.isomorphism(*od.obs_from_i64(o))) for o in obs], dtype=np.int64)
+    assert np.array_equal(got, want)
+    assert np.array_equal(deuce.canonical(got), got)  # idempotent
+
+
+def test_isomorphism_counts_are_the_references(deuce):
+    # street.rs:120-127
+    for street, n in zip(("pref", "flop", "turn", "rive"), deuce.N_ISOMORPHISMS):
+        assert deuce.count_isomorphisms(street) == n
+
+
+def test_isomorphism_lists_match_oracle(deuce):
+    assert np.array_equal(deuce.isomorphisms("pref").cpu().numpy(), od.isomorphisms("pref"))
+    assert np.array_equal(deuce.isomorphisms("flop").cpu().numpy(), od.isomorphisms("flop"))
+    assert np.array_equal(deuce.isomorphisms("turn", 100, 104).cpu().numpy(), od.isomorphisms("turn", 100, 104))
+    assert np.array_equal(deuce.isomorphisms("turn", 1300, 1326).cpu().numpy(), od.isomorphisms("turn", 1300, 1326))
+    assert np.array_equal(deuce.isomorphisms("rive", 700, 701).cpu().numpy(), od.isomorphisms("rive", 700, 701))
+    assert deuce.isomorphisms("rive", 5, 5).numel() == 0
+
+
+def test_isomorphism_shards_concatenate(deuce):
+    whole = deuce.isomorphisms("turn")
+    assert whole.numel() == 13_960_050
+    parts = [deuce.isomorphisms("turn", *deuce.shard_pockets(r, 8)) for r in range(8)]
+    assert torch.equal(torch.cat(parts), whole)
+    assert bool((deuce.canonical(whole[::5003].cpu().numpy()) == whole[::5003].cpu().numpy()).all())
+
+
+def test_river_equity_matches_oracle(deuce):
+    rng = random.Random(3)
+    cases = [od.obs("2c 2d~Ts Js Qs Ks As"), od.obs("Ah Ad~As Ac Kd 7h 2c"), od.obs("2c 3d~5h 7s 9c Jd Kh")]
+    cases += [_random_obs(rng, 5) for _ in range(3000)]
+    obs = torch.tensor([od.obs_i64(*c) for c in cases], dtype=torch.int64, device="cuda")
+    e, b = deuce.river_equity(obs)
+    want = [od.river_equity(*c)[0] for c in cases]
+    assert np.array_equal(e.cpu().numpy().view(np.uint32), np.array(want, dtype=np.float32).view(np.uint32))
+    assert np.array_equal(b.cpu().numpy(), np.array([od.quantize(w) for w in want], dtype=np.uint8))
+    assert e[0].item() == 0.5 and e[1].item() == 1.0
+
+
+def test_river_equity_rejects_other_streets(deuce):
+    from robopoker_amd._lib import RpError
+    obs = torch.tensor([od.obs_i64(*_random_obs(random.Random(4), 4))], dtype=torch.int64, device="cuda")
+    with pytest.raises(RpError):
+        deuce.river_equity(obs)
+
+
+@pytest.fixture(scope="module")
+def river(deuce):
+    """Lookup::grow(Street::Rive): all 123 156 254 river isomorphisms with their quantised equity."""
+    obs = deuce.isomorphisms("rive")
+    e, b = deuce.river_equity(obs)
+    return obs, e, b, deuce.Lookup("rive", obs, b)
+
+
+def test_river_table_properties(deuce, river):
+    obs, e, b, _ = river
+    assert obs.numel() == 123_156_254
+    assert float(e.min()) >= 0.0 and float(e.max()) <= 1.0 and int(b.max()) == 100
+    # quantise(equity) is the bucket everywhere (abstraction.rs:61-63)
+    x = e * 100.0
+    fl = torch.floor(x)
+    assert torch.equal(torch.where(x - fl >= 0.5, fl + 1.0, fl).to(torch.uint8), b)  # f32::round: half away from zero
+    # a sample against the oracle
+    idx = torch.arange(0, obs.numel(), 61_578, device="cuda")
+    sample = obs[idx].cpu().numpy()
+    want = np.array([od.river_equity(*od.obs_from_i64(int(o)))[0] for o in sample], dtype=np.float32)
+    assert np.array_equal(e[idx].cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_lookup_finds_any_suit_labelling(deuce, river):
+    _, _, _, table = river
+    rng = random.Random(5)
+    cases = [_random_obs(rng, 5) for _ in range(2000)]
+    obs = torch.tensor([od.obs_i64(*c) for c in cases], dtype=torch.int64, device="cuda")
+    got = table.lookup(obs).cpu().numpy()
+    want = np.array([od.quantize(od.river_equity(*c)[0]) for c in cases], dtype=np.uint8)
+    assert np.array_equal(got, want)
+
+
+def test_turn_points_match_the_definition(deuce, river):
+    """Lookup::projections for the turn layer: histograms over the 101 river buckets (lookup.rs:27-45)."""
+    _, _, _, table = river
+    turn = deuce.isomorphisms("turn")
+    pts = table.projections(turn, deuce.RIVER_BUCKETS)
+    assert pts.shape == (13_960_050, 101)
+    assert bool((pts.sum(dim=1, dtype=torch.int32) == 46).all())  # Street::Turn.n_children() (street.rs:112-118)
+    idx = torch.arange(0, turn.numel(), 46_533, device="cuda")
+    want = od.project_river(turn[idx].cpu().numpy())
+    assert np.array_equal(pts[idx].cpu().numpy().astype(np.uint32), want)
+
+
+def test_flop_points_match_oracle_through_a_turn_table(deuce):
+    """Lookup::projections for the flop layer, with a synthetic (hashed) turn abstraction of 200 clusters."""
+    turn = deuce.isomorphisms("turn")
+    abs_ = (((turn * 2654435761) >> 20) % 200).to(torch.uint8)  # any deterministic labelling
+    table = deuce.Lookup("turn", turn, abs_)
+    flop = deuce.isomorphisms("flop")
+    pts = table.projections(flop, 200)
+    assert bool((pts.sum(dim=1, dtype=torch.int32) == 47).all())  # Street::Flop.n_children()
+    idx = torch.arange(0, flop.numel(), 2_573, device="cuda")
+    want = od.project(flop[idx].cpu().numpy(), turn.cpu().numpy(), abs_.cpu().numpy(), 200)
+    assert np.array_equal(pts[idx].cpu().numpy().astype(np.uint32), want)
+    from robopoker_amd._lib import RpError
+    with pytest.raises(RpError):  # bucket indices do not fit the requested histogram
+        table.projections(flop[:100], 100)
+    with pytest.raises(RpError):  # turn observations have no children in a turn table
+        table.projections(turn[:100], 200)
+
+
+def test_lookup_rejects_tables_out_of_iterator_order(deuce):
+    from robopoker_amd._lib import RpError
+    flop = deuce.isomorphisms("flop")
+    abs_ = torch.zeros(flop.numel(), dtype=torch.uint8, device="cuda")
+    deuce.Lookup("flop", flop, abs_).close()
+    with pytest.raises(RpError):
+        deuce.Lookup("flop", flop.flip(0), abs_)
+    with pytest.raises(RpError):
+        deuce.Lookup("turn", flop, abs_)
+
+
+def test_turn_points_feed_the_kmeans_layer(deuce, river):
+    """The projection's output is the `counts` layout of rp_kmeans_create_device: cluster a slice with the variation
+    metric on the GPU and on the oracle, from the same seeds -> identical assignments."""
+    import oracle
+    from robopoker_amd.lloyd import Layer
+    _, _, _, table = river
+    turn = deuce.isomorphisms("turn")[:5000].contiguous()
+    pts = table.projections(turn, deuce.RIVER_BUCKETS)
+    assert pts.shape[0] > 4096
+    n = 4096
+    pts = pts[:n].contiguous()
+    host = pts.cpu().numpy()
+    g = Layer(8, None, kind="variation", seed=9, counts_dev_ptr=pts.data_ptr(), shape=tuple(pts.shape))
+    o = oracle.OracleKmeans(8, host, kind="variation", seed=9)
+    g.init_centroids(), o.init_centroids()
+    g.init_bounds(), o.init_bounds()
+    for _ in range(3):
+        g.step(), o.step()
+    assert np.array_equal(g.assign()[0], o.assign()[0])
