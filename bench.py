@@ -254,6 +254,28 @@ def kmeans_secondary(args):
     return out
 
 
+def abstraction_inputs(args, local_rank):
+    """SURVEY §8f row f2 at full size on this GPU, with the oracle's river equity timed on one host core beside it."""
+    from robopoker_amd import deuce
+
+    out = deuce.bench_inputs(local_rank)
+    if args.cpu_seconds > 0:
+        import random
+
+        import oracle_deuce as od
+
+        rng = random.Random(args.seed)
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < min(args.cpu_seconds, 3.0):
+            cards = rng.sample(range(52), 7)
+            od.river_equity(sum(1 << c for c in cards[:2]), sum(1 << c for c in cards[2:]))
+            n += 1
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n * 990 / dt, "unit": "showdowns/s", "cores": 1, "kind": "port",
+                               "sample": f"{n} random river observations x 990 opposing holes (oracle/rp_oracle_deuce.c)"}
+    return out
+
+
 def nlhe_synth(args, rank, world, local_rank):
     """2^27-row table (A <= 9), 128 x 1500 Zipf(1.1)-popular Decisions per step per GPU,
     LinearRegret / LinearWeight, exchanged every step.  One step = one Solver::step worth of updates."""
@@ -486,6 +508,11 @@ def main():
             km = kmeans_secondary(args)
             if km is not None:
                 line["kmeans"] = km
+        if world == 1 and not args.force_sharded and not args.no_extras:
+            try:
+                line["abstraction_inputs"] = abstraction_inputs(args, local_rank)
+            except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
+                line["abstraction_inputs"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(line), flush=True)
 
     solver.close()

@@ -155,3 +155,38 @@ class Lookup:
         if obs.numel():
             _lib.check(self._lib.rp_lookup_project(self._h, obs.numel(), obs.data_ptr(), bins, out.data_ptr()))
         return out
+
+
+def bench_inputs(device=0) -> dict:
+    """Full-size pass over the abstraction inputs on one GPU: every street's isomorphism list, the river table
+    (123 156 254 equities), the turn layer's points from it, and the flop layer's points through a stand-in turn table.
+    Device times come from HIP events inside the library (rp_deuce_kernel_ms)."""
+    out = {}
+    lists = {}
+    for street in ("flop", "turn", "rive"):
+        lists[street] = isomorphisms(street, device=device)
+        out[f"isomorphisms_{street}"] = {"n": lists[street].numel(), "device_ms": round(kernel_ms(), 3)}
+    river = lists["rive"]
+    _, bucket = river_equity(river)
+    ms = kernel_ms()
+    # VALU issue model: one wave64 VALU instruction per SIMD per 4 cycles; 256 CUs x 4 SIMDs x 2.4 GHz
+    out["river_equity"] = {"n": river.numel(), "device_ms": round(ms, 3), "showdowns_per_s": river.numel() * 990 / (ms * 1e-3),
+                           "observations_per_s": river.numel() / (ms * 1e-3),
+                           "simd_cycles_per_showdown_round": ms * 1e-3 * 256 * 4 * 2.4e9 / (river.numel() * 16)}
+    table = Lookup("rive", river, bucket)
+    pts = table.projections(lists["turn"], RIVER_BUCKETS)
+    ms = kernel_ms()
+    rows = int((pts.sum(dim=1, dtype=torch.int32) == 46).sum().item())
+    out["project_turn"] = {"n": lists["turn"].numel(), "device_ms": round(ms, 3), "points_per_s": lists["turn"].numel() / (ms * 1e-3),
+                           "lookups_per_s": lists["turn"].numel() * 46 / (ms * 1e-3), "rows_summing_to_46": rows,
+                           "hbm_gb_per_s": (lists["turn"].numel() * (8 + 101)) / (ms * 1e-3) / 1e9}
+    del pts
+    table.close()
+    stand_in = (((lists["turn"] * 2654435761) >> 20) % 200).to(torch.uint8)
+    t2 = Lookup("turn", lists["turn"], stand_in)
+    pts = t2.projections(lists["flop"], 200)
+    ms = kernel_ms()
+    out["project_flop"] = {"n": lists["flop"].numel(), "device_ms": round(ms, 3), "points_per_s": lists["flop"].numel() / (ms * 1e-3),
+                           "table": "stand-in labels (the turn layer's clustering is the k-means path's output)"}
+    t2.close()
+    return out

@@ -1,0 +1,122 @@
+"""The hierarchical clustering pipeline on one GPU: the order of ``forge::PreTraining::cluster``
+(crates/forge/src/pretraining.rs:37-44) and the steps of ``lloyd::Layer::cluster`` (crates/lloyd/src/layer.rs:195-248).
+
+    river   Lookup::grow(Street::Rive): every river isomorphism -> its quantised equity         (deuce.river_equity)
+    turn    points = river lookup projected onto the turn isomorphisms (histograms over the 101 equity buckets);
+            k-means++ / init_bounds / 32 Elkan iterations under Equity::variation; lookup, metric, future
+    flop    points = turn lookup projected onto the flop isomorphisms (histograms over the 256 turn clusters);
+            the same steps under Sinkhorn EMD over the turn layer's metric
+    preflop Lookup::grow(Street::Pref): isomorphism k -> abstraction k (lookup.rs:179-184)
+
+Everything between the streets stays in HBM: the projection writes the points in the layout
+``rp_kmeans_create_device`` reads.  ``Artifacts`` mirrors lloyd/src/artifacts.rs:11-18 {lookup, metric, future}.
+Seeds are this build's own (the reference seeds its k-means++ from SipHash(street), layer.rs:156-158; SURVEY §8c:
+RNG parity with the Rust crates is unpinned) — parity is GPU <-> oracle on the same inputs.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import deuce
+from .lloyd import Layer
+
+K_CLUSTERS = {"flop": 256, "turn": 256}   # pokerkit KMEANS_{FLOP,TURN}_CLUSTER_COUNT (lib.rs:187-189)
+ITERATIONS = {"flop": 32, "turn": 32}     # KmeansHyperParams::DEFAULT (lloyd/src/hyperparams/kmeans.rs:18-24)
+
+
+@dataclass
+class Artifacts:
+    """lloyd::Artifacts for one street.  lookup: (obs int64[n] on the device, abstraction index uint8[n]);
+    metric: normalised triangular distances float32[K(K-1)/2] (None on the river / preflop);
+    future: centroid histograms uint32[K][bins] with their weights (None on the river / preflop)."""
+    street: str
+    obs: torch.Tensor
+    abstraction: torch.Tensor
+    metric: np.ndarray | None = None
+    future: np.ndarray | None = None
+    future_weight: np.ndarray | None = None
+    timings: dict = field(default_factory=dict)
+
+
+def cluster_river(device=0) -> Artifacts:
+    t0 = time.perf_counter()
+    obs = deuce.isomorphisms("rive", device=device)
+    t_iso = deuce.kernel_ms()
+    _, bucket = deuce.river_equity(obs)
+    t_eq = deuce.kernel_ms()
+    return Artifacts("rive", obs, bucket, timings={"isomorphisms_ms": t_iso, "equity_ms": t_eq, "wall_s": time.perf_counter() - t0})
+
+
+def cluster_preflop(device=0) -> Artifacts:
+    obs = deuce.isomorphisms("pref", device=device)
+    return Artifacts("pref", obs, torch.arange(obs.numel(), dtype=torch.uint8, device=obs.device))
+
+
+def cluster_layer(street: str, below: Artifacts, tri=None, K=None, iterations=None, seed=None, log=None, limit=None) -> Artifacts:
+    """Layer::cluster for the turn (below = river artifacts) or the flop (below = turn artifacts, tri = its metric)."""
+    assert (street, below.street) in (("turn", "rive"), ("flop", "turn"))
+    K = K or K_CLUSTERS[street]
+    iterations = ITERATIONS[street] if iterations is None else iterations
+    bins = deuce.RIVER_BUCKETS if street == "turn" else int(below.abstraction.max().item()) + 1
+    kind = "variation" if street == "turn" else "sinkhorn"
+    dev = below.obs.device
+    say = log or (lambda m: None)
+    tm = {}
+    t0 = time.perf_counter()
+    obs = deuce.isomorphisms(street, device=dev.index or 0)
+    if limit:
+        obs = obs[:limit].contiguous()
+    table = deuce.Lookup(below.street, below.obs, below.abstraction)
+    points = table.projections(obs, bins)
+    tm["project_ms"] = deuce.kernel_ms()
+    table.close()
+    tm["hydrate_s"] = time.perf_counter() - t0
+    say(f"{street}: {obs.numel()} points x {bins} bins projected in {tm['project_ms']:.1f} ms")
+    t0 = time.perf_counter()
+    layer = Layer(K, None, kind, tri, seed=deuce.STREETS[street] if seed is None else seed, device=dev.index or 0,
+                  counts_dev_ptr=points.data_ptr(), shape=tuple(points.shape))
+    tm["create_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    layer.init_centroids()
+    tm["init_s"] = time.perf_counter() - t0
+    say(f"{street}: k-means++ {tm['init_s']:.2f} s")
+    t0 = time.perf_counter()
+    layer.init_bounds()
+    tm["bound_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    moved = []
+    for it in range(iterations):
+        t1 = time.perf_counter()
+        _, _, re = layer.step()
+        moved.append(float(re))
+        say(f"{street}: iteration {it} {time.perf_counter() - t1:.3f} s reassigned {re:.5f}")
+    tm["iterate_s"] = time.perf_counter() - t0
+    tm["reassigned"] = moved
+    t0 = time.perf_counter()
+    bucket, _ = layer.lookup()
+    tm["lookup_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    metric = layer.metric()
+    tm["metric_s"] = time.perf_counter() - t0
+    future, weight = layer.centroids()
+    tm["rms"] = layer.rms()
+    tm["distances"], tm["sinkhorn_iterations"] = layer.stats()
+    layer.close()
+    del points
+    return Artifacts(street, obs, torch.from_numpy(bucket).to(dev), metric, future, weight, tm)
+
+
+def run(device=0, log=None, flop_iterations=None, turn_iterations=None) -> dict[str, Artifacts]:
+    """PreTraining::run's clustering order: river, turn, flop, preflop (pretraining.rs:24-44, Street::all().rev())."""
+    out = {}
+    out["rive"] = cluster_river(device)
+    if log:
+        log(f"river: {out['rive'].obs.numel()} isomorphisms, equity {out['rive'].timings['equity_ms']:.0f} ms")
+    out["turn"] = cluster_layer("turn", out["rive"], iterations=turn_iterations, log=log)
+    out["flop"] = cluster_layer("flop", out["turn"], tri=out["turn"].metric, iterations=flop_iterations, log=log)
+    out["pref"] = cluster_preflop(device)
+    return out
