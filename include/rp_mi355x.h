@@ -430,6 +430,29 @@ RP_API int rp_lookup_project(rp_lookup* h, uint64_t n, const int64_t* obs_dev, u
 /* device time of the calling thread's last call in this section, from HIP events around its launches */
 RP_API int rp_deuce_kernel_ms(double* ms);
 
+/* =================================================================================================
+ * Artifact files: what the reference streams to PostgreSQL, written as files in the same
+ * byte format — daybook::Streamable::stream (daybook/src/traits/streamable.rs:36-46) over
+ * tokio_postgres::binary_copy::BinaryCopyInWriter, i.e. PostgreSQL's binary COPY format: load with
+ *     COPY isomorphism (obs, abs) FROM '<file>' (FORMAT binary)       etc.
+ * Host code, host arrays.
+ * ================================================================================================= */
+/* Generic writer / reader, struct-of-arrays.  `types`: one character per column — 'h' int2, 'i' int4, 'q' int8,
+ * 'f' float4 (the shapes of daybook/src/traits/row.rs:21-57 are "qh", "if", "hhf", "qhqqfffi").  columns[c] points
+ * at n_rows values of column c.  read(): fills up to `cap` rows (columns may be NULL to count) and reports *n_rows. */
+RP_API int rp_pgcopy_write(const char* path, const char* types, uint64_t n_rows, const void* const* columns);
+RP_API int rp_pgcopy_read(const char* path, const char* types, uint64_t cap, void* const* columns, uint64_t* n_rows);
+/* Lookup rows (lloyd/src/lookup.rs:141-147): (obs i64, abs i16 = street << 8 | index) in table order */
+RP_API int rp_artifact_write_lookup(const char* path, int street, uint64_t n, const int64_t* obs,
+                                    const uint8_t* abs_index);
+/* Metric rows (lloyd/src/metric.rs:219-226, distances.rs:69-84): (tri i32 = street << 30 | t, dx f32), t ascending;
+ * tri[] as rp_kmeans_metric returns it */
+RP_API int rp_artifact_write_metric(const char* path, int street, uint32_t K, const float* tri);
+/* Future rows (lloyd/src/future.rs:99-111): per abstraction, its centroid's distribution() (bins.rs:113-117: density
+ * descending, stable) as (prev i16, next i16, dx f32); counts/weight as rp_kmeans_centroids returns them */
+RP_API int rp_artifact_write_transitions(const char* path, int street, uint32_t K, uint32_t bins,
+                                         const uint32_t* counts, const uint64_t* weight);
+
 #ifdef __cplusplus
 }
 #endif

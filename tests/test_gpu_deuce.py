@@ -194,3 +194,36 @@ def test_turn_points_feed_the_kmeans_layer(deuce, river):
     for _ in range(3):
         g.step(), o.step()
     assert np.array_equal(g.assign()[0], o.assign()[0])
+
+
+def test_pretraining_layer_and_artifact_files(deuce, river, tmp_path):
+    """Layer::cluster on a slice of the real turn points (robopoker_amd.pretraining), against the oracle driven through
+    the same steps, then the artifacts through the reference's row format and back."""
+    import oracle
+    from robopoker_amd import formats, pretraining
+    obs, _, bucket, _ = river
+    below = pretraining.Artifacts("rive", obs, bucket)
+    art = pretraining.cluster_layer("turn", below, K=12, iterations=3, seed=4, limit=6000)
+    assert art.obs.numel() == 6000 and art.metric.shape == (12 * 11 // 2,) and art.future.shape == (12, 101)
+    table = deuce.Lookup("rive", obs, bucket)
+    pts = table.projections(art.obs, deuce.RIVER_BUCKETS).cpu().numpy()
+    o = oracle.OracleKmeans(12, pts, kind="variation", seed=4)
+    o.init_centroids(), o.init_bounds()
+    for _ in range(3):
+        o.step()
+    assert np.array_equal(art.abstraction.cpu().numpy(), o.assign()[0])
+    assert np.array_equal(art.metric.view(np.uint32), o.metric().view(np.uint32))
+    oc, ow = o.centroids()
+    assert np.array_equal(art.future, oc) and np.array_equal(art.future_weight, ow)
+    files = formats.save_artifacts(str(tmp_path), art)
+    o2, a2 = formats.read_rows(files["lookup"], "qh")
+    assert np.array_equal(o2, art.obs.cpu().numpy())
+    assert np.array_equal(a2, (2 << 8) | art.abstraction.cpu().numpy().astype(np.int16))
+    t2, d2 = formats.read_rows(files["metric"], "if")
+    assert np.array_equal(d2, art.metric) and np.array_equal(t2.view(np.uint32), (2 << 30) | np.arange(66, dtype=np.uint32))
+    prev, nxt, dx = formats.read_rows(files["transitions"], "hhf")
+    assert set(prev.tolist()) <= {2 << 8 | k for k in range(12)} and (nxt >> 8 == 3).all()
+    for k in range(12):  # each centroid's transition probabilities sum to one and come sorted
+        mine = dx[prev == (2 << 8 | k)]
+        if len(mine):
+            assert abs(float(mine.sum()) - 1.0) < 1e-4 and (np.diff(mine) <= 0).all()
