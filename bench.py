@@ -256,9 +256,17 @@ def kmeans_secondary(args):
 
 def abstraction_inputs(args, local_rank):
     """SURVEY §8f row f2 at full size on this GPU, with the oracle's river equity timed on one host core beside it."""
-    from robopoker_amd import deuce
+    # in a child process: robopoker_amd.deuce keeps its bulk arrays in torch tensors, and torch must be imported before
+    # a process makes its first HIP call (one HIP runtime per process) — this process already runs the solver
+    import subprocess
 
-    out = deuce.bench_inputs(local_rank)
+    code = ("import json, torch; from robopoker_amd import deuce; "
+            f"print('ABSTRACTION ' + json.dumps(deuce.bench_inputs({int(local_rank)})))")
+    res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("ABSTRACTION ")]
+    if res.returncode != 0 or not lines:
+        raise RuntimeError(f"child exited {res.returncode}: {res.stderr.strip()[-300:]}")
+    out = json.loads(lines[-1][len("ABSTRACTION "):])
     if args.cpu_seconds > 0:
         import random
 
