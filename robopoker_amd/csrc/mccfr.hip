@@ -775,6 +775,7 @@ __global__ __launch_bounds__(SLOT_THREADS) void k_compact(DevGame g, DevDecision
 // bitmap row.  Every Decisions is read once; nothing is scanned per infoset.
 static_assert(CH_TREES == RP_COMPOSE_CHUNK, "a block of the composed update is one compaction chunk of trees");
 #define SM_WORDS (CH_TREES / 32u)
+#define CM_PASSES 4u  // k_chunk_maps: infosets per thread; 4 * 256 infosets * 56 B is past its 64 KB LDS budget
 __device__ __forceinline__ void chunk_bitmap(const DevDecisions& dc, uint32_t n_infos, uint32_t chunk, uint32_t batch,
                                              uint32_t* bits) {
     for (uint32_t e = threadIdx.x; e < n_infos * SM_WORDS; e += CH_THREADS) bits[e] = 0;
@@ -1210,7 +1211,7 @@ __global__ __launch_bounds__(128) void k_block_maps(DevGame g, DevSorted so, Ste
 // One thread per tree.  The chunk's Decisions get their place in per-infoset, tree-ordered lists (LDS bitmap + prefix
 // popcount, as k_compact_small); then, cell by cell, every thread drops its trees' values at those places in an LDS
 // array (global reads coalesced over trees) and one thread per infoset composes its list sequentially out of LDS.
-template <bool PRUNED>
+template <bool PRUNED, uint32_t PASSES>
 __global__ __launch_bounds__(CH_THREADS) void k_chunk_maps(DevGame g, DevDecisions dc, StepParams p, Map* bmaps, float* bpsum,
                                                            uint32_t* bcnt, uint32_t nblk_max) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cm_lds[];
@@ -1245,6 +1246,16 @@ __global__ __launch_bounds__(CH_THREADS) void k_chunk_maps(DevGame g, DevDecisio
     }
     const float NEG_INF = rp_u2f(0xff800000u);
     const float tf = (float)p.epoch;
+    // chain phase: thread t owns infosets t, t + 256, ... (PASSES = 1 when the game has at most 256 infosets)
+    uint32_t my_nact[PASSES], my_n[PASSES], my_base[PASSES];
+#pragma unroll
+    for (uint32_t q = 0; q < PASSES; ++q) {
+        const uint32_t info = tid + q * CH_THREADS;
+        const bool mine = info < NI && g.info_player[info < NI ? info : 0u] == p.walker;
+        my_nact[q] = mine ? g.info_actions[info] : 0u;  // 0: not this walker's infoset
+        my_n[q] = mine ? lcount[info] : 0u;
+        my_base[q] = mine ? lbase[info] : 0u;
+    }
     for (uint32_t c = 0; c <= W2; ++c) {  // regret cells, weight cells, then the payoff sum
         const bool isreg = c < A, ispay = c == W2;
         const uint32_t a = c % A;
@@ -1260,9 +1271,11 @@ __global__ __launch_bounds__(CH_THREADS) void k_chunk_maps(DevGame g, DevDecisio
             vals[posl[slot * CH_TREES + lt]] = v;
         }
         __syncthreads();
-        for (uint32_t info = tid; info < NI; info += CH_THREADS) {  // chain phase: one thread per infoset
-            if (g.info_player[info] != p.walker) continue;
-            const uint32_t n = lcount[info], base = lbase[info];
+#pragma unroll
+        for (uint32_t q = 0; q < PASSES; ++q) {
+            const uint32_t info = tid + q * CH_THREADS;
+            if (!my_nact[q]) continue;
+            const uint32_t n = my_n[q], base = my_base[q];
             const size_t slot_out = (size_t)info * nblk_max + chunk;
             if (ispay) {  // payoff sum of the block, left fold from 0.0f
                 float sum = 0.0f;
@@ -1271,7 +1284,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chunk_maps(DevGame g, DevDecisio
                 bcnt[slot_out] = n;
                 continue;
             }
-            const bool chain = a < g.info_actions[info];
+            const bool chain = a < my_nact[q];
             const float fl = isreg ? regret_floor_of(p.R, p.regret_min) : RP_EPSILON;
             const float d = isreg ? (p.R == RP_REGRET_LINEAR ? tf / (tf + 1.0f) : 1.0f) : (p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f);
             float ma = 1.0f, mb = 0.0f, mm = NEG_INF;
@@ -1548,7 +1561,7 @@ int alloc_batch_buffers(rp_mccfr* h, uint32_t batch) {
     dc.maxdec = h->maxdec;
     const size_t slot_words = (size_t)dc.maxdec * stride;
     // chunk-local sort: no per-infoset slot map (RP_MCCFR_SLOTMAP=1 forces the large-game path, for tests)
-    const bool small = chunk_maps_lds_bytes(h) <= 64 * 1024 && !getenv("RP_MCCFR_SLOTMAP");
+    const bool small = chunk_maps_lds_bytes(h) <= 64 * 1024 && h->tbl.n_infos <= CM_PASSES * CH_THREADS && !getenv("RP_MCCFR_SLOTMAP");
     const size_t dec_bytes = (3 * slot_words + 2 * slot_words * A) * 4 + (small ? 0 : (size_t)h->tbl.n_infos * stride) + stride;
     HIP_TRY(hipMalloc(&h->d_dec, dec_bytes));
     uint32_t* d = reinterpret_cast<uint32_t*>(h->d_dec);
@@ -1725,10 +1738,14 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev) {
     clock_begin(h, h->clk_update);
     if (!h->dc.slotmap) {
         const size_t lds = chunk_maps_lds_bytes(h);
-        if (pruned)
-            hipLaunchKernelGGL((k_chunk_maps<true>), dim3(nblk), dim3(CH_THREADS), lds, h->stream, h->g, h->dc, p, bmaps, bpsum, bcnt, nblk_max);
-        else
-            hipLaunchKernelGGL((k_chunk_maps<false>), dim3(nblk), dim3(CH_THREADS), lds, h->stream, h->g, h->dc, p, bmaps, bpsum, bcnt, nblk_max);
+#define LAUNCH_CHUNK_MAPS(PR, PS) \
+    hipLaunchKernelGGL((k_chunk_maps<PR, PS>), dim3(nblk), dim3(CH_THREADS), lds, h->stream, h->g, h->dc, p, bmaps, bpsum, bcnt, nblk_max)
+        const bool one = h->tbl.n_infos <= CH_THREADS;
+        if (pruned && one) LAUNCH_CHUNK_MAPS(true, 1);
+        else if (pruned) LAUNCH_CHUNK_MAPS(true, CM_PASSES);
+        else if (one) LAUNCH_CHUNK_MAPS(false, 1);
+        else LAUNCH_CHUNK_MAPS(false, CM_PASSES);
+#undef LAUNCH_CHUNK_MAPS
     } else if (pruned) {
         hipLaunchKernelGGL((k_block_maps<true>), dim3(nblk, h->tbl.n_infos), dim3(128), 0, h->stream, h->g, h->so, p, bmaps, bpsum, bcnt, nblk_max);
     } else {
