@@ -266,10 +266,11 @@ def bench_slice(n_points: int = 16384, K: int = 256, bins: int = 256, iters: int
     sc_ms, sc_n = layer.kernel_time("selfcost")
     layer.profile(False)
     sinkhorn_s = (step_ms + pw_ms + dr_ms + sc_ms) * 1e-3
-    # VALU issue roofline: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction x 64 lanes = 3.93e13
-    # lane-instructions/s; one softmin term costs 13.25 VALU instructions in the shipped ISA (106 per 8 terms: sub,
-    # clamp, packed exp polynomial, ldexp, floor, sequential add), i.e. 2.97e12 terms/s with every lane busy.
-    valu_peak_exps = 256 * 4 * 2.4e9 / 4.0 * 64 / 13.25
+    # VALU issue roofline from the chip's MEASURED sustained rates (profiles/r01_valu_issue_rates.txt, scripts/ubench):
+    # 8.2e11 plain wave64 VALU instructions/s; a packed f32 instruction costs 2.12 plain ones.  One block of 8 softmin
+    # terms is 106 VALU instructions in the shipped ISA, 44 of them packed (sub, clamp, exp polynomial, ldexp, floor,
+    # sequential add) = 155.3 plain-equivalents, i.e. 2.70e12 terms/s with every lane busy.
+    valu_peak_exps = 8.2e11 * 64 * 8 / (44 * 2.12 + 62)
     exps = e1 - e0
     bd_avg_s = bd_ms / max(bd_n, 1) * 1e-3
     out = {
@@ -286,7 +287,7 @@ def bench_slice(n_points: int = 16384, K: int = 256, bins: int = 256, iters: int
         "roofline_sinkhorn": {"bound": "valu-exp", "achieved": exps / sinkhorn_s if sinkhorn_s > 0 else 0.0,
                               "peak": valu_peak_exps, "unit": "exp/s",
                               "frac": (exps / sinkhorn_s) / valu_peak_exps if sinkhorn_s > 0 else 0.0,
-                              "note": "bit-reproducible software exp on the packed-f32 pipe, 13.25 VALU instr per softmin term; "
+                              "note": "bit-reproducible software exp, 106 VALU instr (44 packed) per 8 softmin terms against the measured VALU issue rate; "
                                       "lanes are rows of one support (<= 47 of 64 busy on the point side)"},
         "roofline_bounds": {"bound": "hbm", "achieved": (n_points * K * 8) / bd_avg_s / 1e9 if bd_avg_s > 0 else 0.0,
                             "peak": 8000.0, "unit": "GB/s",

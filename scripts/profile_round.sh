@@ -22,4 +22,24 @@ python $REPO/scripts/rocpd_summary.py $(ls $OUT/kl/*.db | head -1) $OUT/${TAG}_l
 SP="python $REPO/bench.py --workload nlhe-synth --cpu-seconds 0 --steps 40 --warmup 5"
 rocprofv3 --kernel-trace --stats -d $OUT/ks -o ks -- $SP > $OUT/ks.log 2>&1
 python $REPO/scripts/rocpd_summary.py $(ls $OUT/ks/*.db | head -1) $OUT/${TAG}_sparse_kernel_stats.txt "$SP" > /dev/null
+# the abstraction inputs at full size (isomorphism iterator, river equity, projections), and the VALU counters of the
+# river-equity kernel (own pass, kernel-trace only)
+DQ="python $REPO/scripts/quick_deuce.py"
+PYTHONPATH=$REPO rocprofv3 --kernel-trace --stats -d $OUT/kd -o kd -- $DQ > $OUT/kd.log 2>&1
+python $REPO/scripts/rocpd_summary.py $(ls $OUT/kd/*.db | head -1) $OUT/${TAG}_deuce_kernel_stats.txt "PYTHONPATH=. python scripts/quick_deuce.py (all four isomorphism lists; 123 156 254 river equities x2; turn and flop projections x2)" > /dev/null
+PYTHONPATH=$REPO rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY \
+  --kernel-trace --output-format csv -d $OUT/pd -o pmc -- $DQ > $OUT/pd.log 2>&1
+python - <<PY > $OUT/${TAG}_deuce_valu_counters.txt
+import csv, collections
+rows = list(csv.DictReader(open("$OUT/pd/pmc_counter_collection.csv")))
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
+for r in rows:
+    k = r["Kernel_Name"].split("(")[0]
+    if "rp::" not in k: continue
+    agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Counter_Name"] == "SQ_WAVES": calls[k] += 1
+print("# rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY (sums over dispatches) of: PYTHONPATH=. python scripts/quick_deuce.py")
+for k, v in agg.items():
+    print(k, calls[k], "dispatches", {c: f"{x:.4e}" for c, x in sorted(v.items())})
+PY
 cat $OUT/${TAG}_bench_kernel_stats.txt
