@@ -120,3 +120,95 @@ def run(device=0, log=None, flop_iterations=None, turn_iterations=None) -> dict[
     out["flop"] = cluster_layer("flop", out["turn"], tri=out["turn"].metric, iterations=flop_iterations, log=log)
     out["pref"] = cluster_preflop(device)
     return out
+
+
+# ---- one process per GPU (BASELINE configs[4]: point-sharded k-means across the GPUs of a node) ---------
+def _slice(n: int, rank: int, world: int) -> tuple[int, int, int]:
+    """Contiguous, equal-width index slices of an isomorphism list: (lo, hi, width); the last may be short."""
+    width = (n + world - 1) // world
+    lo = min(n, rank * width)
+    return lo, min(n, lo + width), width
+
+
+def _gather_u8(mine: torch.Tensor, width: int, n: int, group) -> torch.Tensor:
+    """All-gather equal-width uint8 slices (the last padded) back into the list's order."""
+    import torch.distributed as dist
+
+    from .parallel import _all_gather_bytes
+    world = dist.get_world_size(group)
+    pad = torch.zeros(width, dtype=torch.uint8, device=mine.device)
+    pad[: mine.numel()] = mine
+    out = torch.empty(width * world, dtype=torch.uint8, device=mine.device)
+    _all_gather_bytes(out, pad, group)
+    return out[:n].contiguous()
+
+
+def cluster_river_sharded(device, group=None) -> Artifacts:
+    """Every rank lists the river isomorphisms (24 ms), evaluates ITS slice, and the 1-byte buckets are all-gathered."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    obs = deuce.isomorphisms("rive", device=device)
+    lo, hi, width = _slice(obs.numel(), rank, world)
+    _, mine = deuce.river_equity(obs[lo:hi].contiguous())
+    t_eq = deuce.kernel_ms()
+    return Artifacts("rive", obs, _gather_u8(mine, width, obs.numel(), group), timings={"equity_ms": t_eq, "slice": [lo, hi]})
+
+
+def cluster_layer_sharded(street: str, below: Artifacts, tri=None, K=None, iterations=None, seed=None, log=None, group=None,
+                          limit=None) -> Artifacts:
+    """Layer::cluster with the points (and their Elkan bounds) sharded by rank: the table of the street below is
+    replicated, each rank projects and owns a contiguous slice of this street's isomorphisms, centroid sums are
+    all-reduced every iteration (robopoker_amd.parallel.ShardedLayer), the final assignments are all-gathered."""
+    import torch.distributed as dist
+
+    from .parallel import ShardedLayer
+    assert (street, below.street) in (("turn", "rive"), ("flop", "turn"))
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    K = K or K_CLUSTERS[street]
+    iterations = ITERATIONS[street] if iterations is None else iterations
+    bins = deuce.RIVER_BUCKETS if street == "turn" else int(below.abstraction.max().item()) + 1
+    kind = "variation" if street == "turn" else "sinkhorn"
+    dev = below.obs.device
+    say = (lambda m: log(f"[rank {rank}] {m}")) if log else (lambda m: None)
+    tm = {}
+    obs = deuce.isomorphisms(street, device=dev.index or 0)
+    if limit:
+        obs = obs[:limit].contiguous()
+    lo, hi, width = _slice(obs.numel(), rank, world)
+    table = deuce.Lookup(below.street, below.obs, below.abstraction)
+    points = table.projections(obs[lo:hi].contiguous(), bins)
+    tm["project_ms"] = deuce.kernel_ms()
+    table.close()
+    seed = deuce.STREETS[street] if seed is None else seed
+    engine = Layer(K, None, kind, tri, seed=seed, device=dev.index or 0, counts_dev_ptr=points.data_ptr(), shape=tuple(points.shape))
+    layer = ShardedLayer(engine, K, bins, seed, device=str(dev), group=group)
+    t0 = time.perf_counter()
+    layer.init_centroids()
+    tm["init_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    layer.init_bounds()
+    tm["bound_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for it in range(iterations):
+        t1 = time.perf_counter()
+        _, _, re = layer.step()
+        say(f"{street}: iteration {it} {time.perf_counter() - t1:.3f} s reassigned {re:.5f}")
+    tm["iterate_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    mine, _ = engine.lookup()
+    bucket = _gather_u8(torch.from_numpy(mine).to(dev), width, obs.numel(), group)
+    tm["lookup_s"] = time.perf_counter() - t0
+    metric = engine.metric()
+    future, weight = engine.centroids()
+    engine.close()
+    return Artifacts(street, obs, bucket, metric, future, weight, tm)
+
+
+def run_sharded(device=0, group=None, log=None, flop_iterations=None, turn_iterations=None) -> dict[str, Artifacts]:
+    """``run`` with one process per GPU (launch with torch.distributed.run; backend nccl = RCCL over xGMI).  Every rank
+    returns the same artifacts."""
+    out = {"rive": cluster_river_sharded(device, group)}
+    out["turn"] = cluster_layer_sharded("turn", out["rive"], iterations=turn_iterations, log=log, group=group)
+    out["flop"] = cluster_layer_sharded("flop", out["turn"], tri=out["turn"].metric, iterations=flop_iterations, log=log, group=group)
+    out["pref"] = cluster_preflop(device)
+    return out

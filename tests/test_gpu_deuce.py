@@ -227,3 +227,32 @@ def test_pretraining_layer_and_artifact_files(deuce, river, tmp_path):
         mine = dx[prev == (2 << 8 | k)]
         if len(mine):
             assert abs(float(mine.sum()) - 1.0) < 1e-4 and (np.diff(mine) <= 0).all()
+
+
+def test_sharded_pretraining_matches_single_process(deuce, river):
+    """robopoker_amd.pretraining's one-process-per-GPU path (RCCL group of one rank here; the 8-GPU launch is the same
+    code with eight slices): artifacts equal to the single-process layer, bit for bit."""
+    import torch.distributed as dist
+    from robopoker_amd import pretraining
+    obs, _, bucket, _ = river
+    below = pretraining.Artifacts("rive", obs, bucket)
+    single = pretraining.cluster_layer("turn", below, K=10, iterations=3, seed=6, limit=5000)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+    try:
+        torch.cuda.set_device(0)
+        sharded = pretraining.cluster_layer_sharded("turn", below, K=10, iterations=3, seed=6, limit=5000)
+        riv = pretraining.cluster_river_sharded(0)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert torch.equal(sharded.abstraction, single.abstraction)
+    assert np.array_equal(sharded.metric.view(np.uint32), single.metric.view(np.uint32))
+    assert np.array_equal(sharded.future, single.future) and np.array_equal(sharded.future_weight, single.future_weight)
+    assert torch.equal(riv.abstraction, bucket)
+    # slices of a list tile it exactly, whatever the world size
+    for world in (2, 3, 8):
+        cuts = [pretraining._slice(13_960_050, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == 13_960_050
+        assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:])) and len({c[2] for c in cuts}) == 1
