@@ -321,6 +321,7 @@ struct DevInfoTab {
     float* cum;      // [n_infos][A] inclusive cumulative of max(q, EPSILON)
     float* total;    // [n_infos]
     uint32_t* keep;  // [n_infos] edges with cum_regret > prune_threshold
+    float2* sq;      // [n_infos][A] (sigma, q) side by side: one load per edge in the traversal's sweeps
 };
 
 __global__ void k_prepare_infos(DevGame g, DevTables t, StepParams p, DevInfoTab it) {
@@ -336,6 +337,7 @@ __global__ void k_prepare_infos(DevGame g, DevTables t, StepParams p, DevInfoTab
         it.sigma[info * A + a] = d_regret(t, A, info, a) / rd;
         const float qa = d_sampling_weight(t, A, info, a, denom, p) / z;
         it.q[info * A + a] = qa;
+        it.sq[info * A + a] = make_float2(it.sigma[info * A + a], qa);
         total += rp_maxf(qa, RP_EPSILON);
         it.cum[info * A + a] = total;
         if (t.regret[info * A + a] > p.prune_threshold) keep |= 1u << a;
@@ -441,21 +443,20 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
         __syncthreads();
     }
     auto SIG = [&](uint32_t e) -> float { return TABLDS ? tab[e] : it.sigma[e]; };
-    auto QQ = [&](uint32_t e) -> float { return TABLDS ? tab[cells + e] : it.q[e]; };
     if (lane >= p.batch) return;
     const uint64_t tree_id = p.tree_base + lane;
     uint32_t err = 0;
 #define L(arr, slot) arr[(slot)*64 + ln]
 #define STK(e, f) ss[((e)*4u + (f)) * 64u + ln]
     // reach factors of the edge into a node (meta mn): sigma / q of the parent's infoset at the node's edge
-    auto fr_of = [&](uint32_t mn) -> float {
+    // (sigma, q) of the edge into a node: (1, 1) below chance, (sigma, 1) below the walker, (sigma, q) below an opponent
+    auto f_of = [&](uint32_t mn) -> float2 {
         const uint32_t pt = LM_PTYPE(mn);
-        if (pt != PT_WALKER && pt != PT_OPP) return 1.0f;
-        return SIG(LM_INFO(L(nm, LM_PARENT(mn))) * g.A + LM_EDGE(mn));
-    };
-    auto fs_of = [&](uint32_t mn) -> float {
-        if (LM_PTYPE(mn) != PT_OPP) return 1.0f;
-        return QQ(LM_INFO(L(nm, LM_PARENT(mn))) * g.A + LM_EDGE(mn));
+        if (pt != PT_WALKER && pt != PT_OPP) return make_float2(1.0f, 1.0f);
+        const uint32_t e = LM_INFO(L(nm, LM_PARENT(mn))) * g.A + LM_EDGE(mn);
+        float2 f = TABLDS ? make_float2(tab[e], tab[cells + e]) : it.sq[e];
+        if (pt != PT_OPP) f.y = 1.0f;
+        return f;
     };
 
     // ---- TreeBuilder::build (builder.rs:74-87,141-161): pop-last DFS -----------------------------
@@ -542,8 +543,10 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                 // top-down over the (contiguous) subtree of j: reach products from j's child (flow.rs:195-212),
                 // which start at 1 there; internal nodes also start their child-value sum at 0
                 uint32_t end = j;
+                uint32_t mn_next = L(nm, j + 1);  // one node ahead of the sweep (the slot past the tree is readable LDS)
                 for (uint32_t n = j + 1; n < nn; ++n) {
-                    const uint32_t mn = L(nm, n);
+                    const uint32_t mn = mn_next;
+                    mn_next = L(nm, n + 1);
                     const uint32_t par = LM_PARENT(mn);
                     if (par < j) break;
                     end = n;
@@ -551,8 +554,9 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     float rel = 1.0f, smp = 1.0f;
                     if (par != j) {
                         const uint32_t ps = ISLOT(par);
-                        rel = L(xr, ps) * fr_of(mn);
-                        smp = L(xs, ps) * fs_of(mn);
+                        const float2 f = f_of(mn);
+                        rel = L(xr, ps) * f.x;
+                        smp = L(xs, ps) * f.y;
                     }
                     const uint32_t ns = ISLOT(n);
                     L(xr, ns) = rel;
@@ -561,16 +565,21 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                 }
                 // bottom-up: descending node index adds children in choices() order (node.rs:103-107)
                 uint32_t kids = 0;
+                uint32_t mn_prev = L(nm, end);
+                float v_prev = L(nv, end);
                 for (uint32_t n = end; n > j; --n) {
-                    const uint32_t mn = L(nm, n);
+                    const uint32_t mn = mn_prev;
                     const uint32_t par = LM_PARENT(mn);
-                    float v = L(nv, n);
+                    float v = v_prev;
+                    mn_prev = L(nm, n - 1);  // one node ahead; its value is patched below if this node is its child
+                    v_prev = L(nv, n - 1);
                     if (LM_LEAF(mn)) {
                         float rel = 1.0f, smp = 1.0f;
                         if (par != j) {
                             const uint32_t ps = ISLOT(par);
-                            rel = L(xr, ps) * fr_of(mn);
-                            smp = L(xs, ps) * fs_of(mn);
+                            const float2 f = f_of(mn);
+                            rel = L(xr, ps) * f.x;
+                            smp = L(xs, ps) * f.y;
                         }
                         v = rel / smp * v;
                     }
@@ -578,7 +587,9 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                         tv_set(LM_EDGE(mn), v);
                         kids |= 1u << LM_EDGE(mn);
                     } else {
-                        L(nv, par) = L(nv, par) + v;
+                        const float sum = (par == n - 1 ? v_prev : L(nv, par)) + v;
+                        L(nv, par) = sum;
+                        if (par == n - 1) v_prev = sum;
                     }
                 }
                 // ancestor_reach (flow.rs:166-174)
@@ -588,8 +599,9 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     const uint32_t par = LM_PARENT(mn);
                     if (par == LM_NO_PARENT) break;
                     if (LM_PTYPE(mn) == PT_OPP) {
-                        cf = cf * fr_of(mn);
-                        sm_ = sm_ * fs_of(mn);
+                        const float2 f = f_of(mn);
+                        cf = cf * f.x;
+                        sm_ = sm_ * f.y;
                     }
                     n = par;
                 }
@@ -1910,7 +1922,7 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
     CREATE_TRY(hipMalloc(&h->d_counters, 3 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(h->d_counters, 0, 3 * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(&h->d_summary, summary_bytes_of(h)));
-    CREATE_TRY(hipMalloc(&h->d_itab, (3 * cells + 2 * (size_t)game->n_infos) * 4));
+    CREATE_TRY(hipMalloc(&h->d_itab, (5 * cells + 2 * (size_t)game->n_infos + 2) * 4));
     {
         float* f = reinterpret_cast<float*>(h->d_itab);
         h->itab.sigma = f;
@@ -1918,6 +1930,8 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
         h->itab.cum = f + 2 * cells;
         h->itab.total = f + 3 * cells;
         h->itab.keep = reinterpret_cast<uint32_t*>(f + 3 * cells + game->n_infos);
+        const size_t used = 3 * cells + 2 * (size_t)game->n_infos;
+        h->itab.sq = reinterpret_cast<float2*>(f + ((used + 1) & ~(size_t)1));  // 8-byte aligned
     }
     uint32_t maxstack = 1;
     sampled_tree_bounds(h, &h->maxdec, &maxstack, &h->maxint);
