@@ -391,7 +391,7 @@ __device__ __forceinline__ uint32_t d_sample_mask_tab(const DevGame& g, const De
 #define LM_PTYPE(m) (((m) >> 10) & 3u)
 #define LM_LEAF(m) (((m) >> 12) & 1u)
 #define LM_WALKER(m) (((m) >> 13) & 1u)
-#define LM_NACT(m) (((m) >> 14) & 31u)
+#define LM_ISLOT(m) (((m) >> 14) & 31u)  // internal nodes: rank among the internal nodes (their reach-prefix slot)
 #define LM_INFO(m) ((m) >> 19)
 #define LM_NO_PARENT 63u
 
@@ -450,10 +450,11 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
 #define STK(e, f) ss[((e)*4u + (f)) * 64u + ln]
     // reach factors of the edge into a node (meta mn): sigma / q of the parent's infoset at the node's edge
     // (sigma, q) of the edge into a node: (1, 1) below chance, (sigma, 1) below the walker, (sigma, q) below an opponent
-    auto f_of = [&](uint32_t mn) -> float2 {
+    // mp: the meta of mn's parent
+    auto f_of = [&](uint32_t mn, uint32_t mp) -> float2 {
         const uint32_t pt = LM_PTYPE(mn);
         if (pt != PT_WALKER && pt != PT_OPP) return make_float2(1.0f, 1.0f);
-        const uint32_t e = LM_INFO(L(nm, LM_PARENT(mn))) * g.A + LM_EDGE(mn);
+        const uint32_t e = LM_INFO(mp) * g.A + LM_EDGE(mn);
         float2 f = TABLDS ? make_float2(tab[e], tab[cells + e]) : it.sq[e];
         if (pt != PT_OPP) f.y = 1.0f;
         return f;
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
     uint4 rec = g.root_rec;
     uint32_t cur_in = LM_NO_PARENT | (PT_NONE << 10);
     unsigned long long wmask = 0;  // walker decision nodes
-    unsigned long long imask = 0;  // internal nodes
+    uint32_t n_int = 0;            // internal nodes so far
     for (;;) {
         const uint32_t turn = rec.x & 0xffu, nch = (rec.x >> 8) & 0xffu, info = rec.y, off = rec.z;
         const uint32_t me = nn;
@@ -476,11 +477,11 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
             break;
         }
         const bool is_walker = turn == p.walker;
-        L(nm, me) = cur_in | ((nch == 0 ? 1u : 0u) << 12) | ((is_walker ? 1u : 0u) << 13) | (nch << 14) |
+        L(nm, me) = cur_in | ((nch == 0 ? 1u : 0u) << 12) | ((is_walker ? 1u : 0u) << 13) | ((n_int & 31u) << 14) |
                     ((turn < RP_TURN_CHANCE ? info : 0u) << 19);
         nn += 1;
         if (nch > 0) {
-            imask |= 1ull << me;
+            n_int += 1;
             if (is_walker) wmask |= 1ull << me;
             uint32_t mask = d_sample_mask_tab(g, it, p, tree_id, rec.w, turn, nch, info, off);
             const bool chance = turn == RP_TURN_CHANCE;
@@ -516,9 +517,8 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
 #undef STK
 
     // ---- Tree::partition + CfrFlow::dfs per walker infoset (tree.rs:88-98, flow.rs:64-87) --------
-#define ISLOT(n) ((uint32_t)__popcll(imask & ((1ull << (n)) - 1ull)))
     uint32_t ndec = 0;
-    if (nn - (uint32_t)__popcll(imask) > maxn || (uint32_t)__popcll(imask) > maxi) err |= ERR_NODE_CAPACITY;
+    if (n_int > maxi || n_int > 32u) err |= ERR_NODE_CAPACITY;
     if (!err) {
         unsigned long long todo = wmask;
         while (todo) {
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                 err |= ERR_DEC_CAPACITY;
                 break;
             }
-            const uint32_t nact = LM_NACT(mi);
+            const uint32_t nact = g.info_actions[info];
             const uint32_t slot = ndec++;
             const size_t D = dc.stride;
             float payoff = 0.0f;
@@ -553,12 +553,12 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     if (LM_LEAF(mn)) continue;
                     float rel = 1.0f, smp = 1.0f;
                     if (par != j) {
-                        const uint32_t ps = ISLOT(par);
-                        const float2 f = f_of(mn);
+                        const uint32_t mp = L(nm, par), ps = LM_ISLOT(mp);
+                        const float2 f = f_of(mn, mp);
                         rel = L(xr, ps) * f.x;
                         smp = L(xs, ps) * f.y;
                     }
-                    const uint32_t ns = ISLOT(n);
+                    const uint32_t ns = LM_ISLOT(mn);
                     L(xr, ns) = rel;
                     L(xs, ns) = smp;
                     L(nv, n) = 0.0f;
@@ -576,8 +576,8 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     if (LM_LEAF(mn)) {
                         float rel = 1.0f, smp = 1.0f;
                         if (par != j) {
-                            const uint32_t ps = ISLOT(par);
-                            const float2 f = f_of(mn);
+                            const uint32_t mp = L(nm, par), ps = LM_ISLOT(mp);
+                            const float2 f = f_of(mn, mp);
                             rel = L(xr, ps) * f.x;
                             smp = L(xs, ps) * f.y;
                         }
@@ -594,16 +594,16 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                 }
                 // ancestor_reach (flow.rs:166-174)
                 float cf = 1.0f, sm_ = 1.0f;
-                for (uint32_t n = j;;) {
-                    const uint32_t mn = L(nm, n);
+                for (uint32_t mn = L(nm, j);;) {
                     const uint32_t par = LM_PARENT(mn);
                     if (par == LM_NO_PARENT) break;
+                    const uint32_t mp = L(nm, par);
                     if (LM_PTYPE(mn) == PT_OPP) {
-                        const float2 f = f_of(mn);
+                        const float2 f = f_of(mn, mp);
                         cf = cf * f.x;
                         sm_ = sm_ * f.y;
                     }
-                    n = par;
+                    mn = mp;
                 }
                 const float reach = cf / sm_;
                 float ev = 0.0f;
@@ -634,7 +634,6 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
         }
     }
 #undef L
-#undef ISLOT
     dc.ndec[lane] = (uint8_t)ndec;
     count_metrics(p, nn, ndec, err);
 }
@@ -1662,7 +1661,7 @@ size_t traverse_lds_bytes(const rp_mccfr* h) {
 }
 bool traverse_fits_lds(const rp_mccfr* h) {
     if (getenv("RP_DEBUG")) fprintf(stderr, "traverse: maxn=%u maxs=%u maxint=%u lds=%zu B/wave\n", h->sc.maxn, h->sc.maxs, h->maxint, traverse_lds_bytes(h));
-    return h->sc.maxn <= 62 && h->tbl.max_depth <= 10 && h->tbl.n_infos <= 8191 && h->tbl.max_actions <= 16 &&
+    return h->sc.maxn <= 62 && h->maxint <= 32 && h->tbl.max_depth <= 10 && h->tbl.n_infos <= 8191 && h->tbl.max_actions <= 16 &&
            traverse_lds_bytes(h) <= 64 * 1024;
 }
 
