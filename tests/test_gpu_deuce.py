@@ -256,3 +256,35 @@ def test_sharded_pretraining_matches_single_process(deuce, river):
         cuts = [pretraining._slice(13_960_050, r, world) for r in range(world)]
         assert cuts[0][0] == 0 and cuts[-1][1] == 13_960_050
         assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:])) and len({c[2] for c in cuts}) == 1
+
+
+def test_edge_cases_of_the_abstraction_inputs(deuce, river):
+    import ctypes as C
+    from robopoker_amd import _lib
+    from robopoker_amd._lib import RpError
+    lib = _lib.load()
+    # empty inputs are fine and touch nothing
+    assert deuce.hand_strength([]).size == 0 and deuce.canonical([]).size == 0
+    e, b = deuce.river_equity(torch.empty(0, dtype=torch.int64, device="cuda"))
+    assert e.numel() == 0 and b.numel() == 0
+    # a short output buffer gets the first `cap` isomorphisms and the full count
+    whole = deuce.isomorphisms("flop")
+    part = torch.full((1000,), -1, dtype=torch.int64, device="cuda")
+    n = C.c_uint64()
+    torch.cuda.synchronize()
+    _lib.check(lib.rp_isomorphisms(0, 1, 0, 1326, part.data_ptr(), 600, C.byref(n)))
+    assert n.value == 1_286_792 and torch.equal(part[:600], whole[:600]) and bool((part[600:] == -1).all())
+    # out-of-range street, inverted pocket range
+    assert lib.rp_isomorphisms(0, 7, 0, 1326, None, 0, C.byref(n)) != 0
+    _lib.check(lib.rp_isomorphisms(0, 2, 900, 100, None, 0, C.byref(n)))
+    assert n.value == 0
+    # a lookup miss is an error, as the reference's expect() (lookup.rs:24): a flop observation in the river table
+    _, _, _, table = river
+    with pytest.raises(RpError):
+        table.lookup(whole[:4].contiguous())
+    # strength keys of every 5-card hand: 7462 distinct classes in standard poker; the reference's flush (top card only)
+    # and straight-flush conventions merge some, so just pin the count this evaluator yields against the oracle's
+    rng = random.Random(9)
+    sample = [sum(1 << c for c in rng.sample(range(52), 5)) for _ in range(50000)]
+    keys = deuce.hand_strength(sample)
+    assert len(set(keys.tolist())) == len({od.strength_key(h) for h in sample})
