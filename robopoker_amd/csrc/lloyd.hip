@@ -120,6 +120,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rt_resource(const Metric& M) {
 __device__ __forceinline__ float rt_load(__amdgpu_buffer_rsrc_t rt, uint32_t col_bytes, uint32_t row_bytes) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, (int)col_bytes, (int)row_bytes, 0));
 }
+// left fold t[0] + t[1] + ... + t[n-1] from 0.0f in index order, reading four floats per LDS access (t 16-B aligned;
+// the array extends to a multiple of four)
+__device__ __forceinline__ float lds_sum_in_order(const float* t, uint32_t n) {
+    float e = 0.0f;
+    uint32_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(t + i);
+        e += v.x; e += v.y; e += v.z; e += v.w;
+    }
+    if (i < n) {
+        const float4 v = *reinterpret_cast<const float4*>(t + i);
+        e += v.x;
+        if (i + 1 < n) e += v.y;
+        if (i + 2 < n) e += v.z;
+    }
+    return e;
+}
 struct SoftminGroup {  // 8 consecutive terms: potentials + the C/T entries of this lane's column
     float4 p0, p1;
     float r[8];
@@ -153,6 +170,32 @@ __device__ __forceinline__ float softmin_fold(float s, const SoftminGroup& gq) {
     s += e0.x; s += e0.y; s += e1.x; s += e1.y; s += e2.x; s += e2.y; s += e3.x; s += e3.y;
     return s;
 }
+// the first r (1..7, wave uniform) terms of a group
+__device__ __forceinline__ float softmin_fold_first(float s, const SoftminGroup& gq, uint32_t r) {
+    rp_f2 e0, e1, e2, e3;
+    e0.x = gq.p0.x - gq.r[0]; e0.y = gq.p0.y - gq.r[1];
+    e1.x = gq.p0.z - gq.r[2]; e1.y = gq.p0.w - gq.r[3];
+    e2.x = gq.p1.x - gq.r[4]; e2.y = gq.p1.y - gq.r[5];
+    e3.x = gq.p1.z - gq.r[6]; e3.y = gq.p1.w - gq.r[7];
+    e0 = rp_exp_floor2(e0);
+    s += e0.x;
+    if (r > 1) s += e0.y;
+    if (r > 2) {
+        e1 = rp_exp_floor2(e1);
+        s += e1.x;
+        if (r > 3) s += e1.y;
+    }
+    if (r > 4) {
+        e2 = rp_exp_floor2(e2);
+        s += e2.x;
+        if (r > 5) s += e2.y;
+    }
+    if (r > 6) {
+        e3 = rp_exp_floor2(e3);
+        s += e3.x;
+    }
+    return s;
+}
 template <bool PIPE = true>
 __device__ __forceinline__ float softmin_sum(const uint16_t* sup, const float* pot, uint32_t cnt,
                                               __amdgpu_buffer_rsrc_t rt, uint32_t bins, uint32_t xi) {
@@ -175,9 +218,14 @@ __device__ __forceinline__ float softmin_sum(const uint16_t* sup, const float* p
         }
         s = softmin_fold(s, cur);
     }
-    for (; j < cnt; ++j) {
-        const uint32_t y = __builtin_amdgcn_readfirstlane((uint32_t)sup[j]);
-        s += rp_exp_floor(pot[j] - rt_load(rt, xoff, y * rowb));
+    if (j < cnt) {
+        // 1..7 terms left: one more group with its eight loads in flight together, of which only the first cnt - j are
+        // added (the others read whatever follows in the LDS arrays: a bin past the table is an out-of-range buffer
+        // load, which returns 0).  rp_exp_floor2 == rp_exp_floor on every input (rp_math_exp_sweep), so a term's value
+        // is the scalar path's.
+        SoftminGroup last;
+        softmin_fetch(last, sup, pot, j, rt, rowb, xoff);
+        s = softmin_fold_first(s, last, cnt - j);
     }
     return s;
 }
@@ -206,8 +254,7 @@ __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint
             }
         }
         __syncthreads();
-        float lhs_err = 0.0f;
-        for (uint32_t i = 0; i < m; ++i) lhs_err += w.tmp[i];
+        const float lhs_err = lds_sum_in_order(w.tmp, m);
         __syncthreads();
         // rhs(): sees the fresh lhs (Gauss-Seidel, sinkhorn.rs:80-87)
         for (uint32_t j0 = 0; j0 < n; j0 += 64) {
@@ -222,8 +269,7 @@ __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint
             }
         }
         __syncthreads();
-        float rhs_err = 0.0f;
-        for (uint32_t j = 0; j < n; ++j) rhs_err += w.tmp[j];
+        const float rhs_err = lds_sum_in_order(w.tmp, n);
         __syncthreads();
         if (lhs_err + rhs_err < M.tol) {
             t += 1;
@@ -260,45 +306,65 @@ __device__ __forceinline__ float wave_divergence(WaveLds& w, uint32_t m, uint32_
 }
 
 // ------------------------------------------------------------------------------------------------
-// TWO points against ONE centroid in one wavefront.
+// G = 2 or 4 points against ONE centroid in one wavefront.
 //
-// A point has few support bins (<= 47, 28 on average): in the half-iteration whose rows are the point's bins a
-// lane-per-row mapping leaves more than half of the wave idle while it walks the centroid's (up to 256) bins.  When two
-// points with <= 32 bins each meet the SAME centroid, lanes 0..31 take the rows of the first point and lanes 32..63
-// those of the second: the column walk (row offsets of C/T: wave uniform) is shared, only the potential they read
-// differs per half.  The other half-iteration (rows = centroid bins) runs once per point as before.  Each solve keeps
-// its own iteration count: a converged pair is frozen while the other finishes.  Every float operation of a solve is
-// the one wave_sinkhorn_cost performs, in the same order.
+// A point has few support bins (synthetic flop-like points: <= 47, 28 on average; the REAL flop points: 11 on average,
+// 27 at most): in the half-iteration whose rows are the point's bins a lane-per-row mapping leaves most of the wave
+// idle while it walks the centroid's (up to 256) bins.  When G points with <= 64 / G bins each meet the SAME centroid,
+// lane group g takes the rows of point g: the column walk (row offsets of C/T: wave uniform) is shared, only the
+// potential a group reads differs.  The other half-iteration (rows = centroid bins) runs once per point as before.
+// Each solve keeps its own iteration count: a converged solve is frozen while the others finish.  Every float
+// operation of a solve is the one wave_sinkhorn_cost performs, in the same order.
 // ------------------------------------------------------------------------------------------------
 #define PAIR_ROWS 32u
-struct __attribute__((aligned(16))) PairLds {
-    uint16_t supC[MAXB];          // centroid support
+#define QUAD_ROWS 16u
+template <uint32_t G>
+struct __attribute__((aligned(16))) GroupLds {
+    static constexpr uint32_t ROWS = 64u / G;
+    uint16_t supC[MAXB];       // centroid support
     float lnC[MAXB];
-    float potC[2][MAXB];          // centroid-side potential of each solve
-    float tmpC[2][MAXB];
-    uint16_t supP[2][PAIR_ROWS];  // the two points
-    float lnP[2][PAIR_ROWS];
-    float potP[2][PAIR_ROWS];
-    float tmpP[2][PAIR_ROWS];
+    float potC[G][MAXB];       // centroid-side potential of each solve
+    float tmpC[G][MAXB];
+    uint16_t supP[G][ROWS];    // the G points
+    float lnP[G][ROWS];
+    float potP[G][ROWS];
+    float tmpP[G][ROWS];
 };
+// v[g] for a lane-varying g (small arrays stay in registers)
+template <uint32_t G, typename T>
+__device__ __forceinline__ T pick(const T (&v)[G], uint32_t g) {
+    T r = v[0];
+#pragma unroll
+    for (uint32_t h = 1; h < G; ++h) r = g == h ? v[h] : r;
+    return r;
+}
 
-// cost[h] = OT(centroid, point h) if centroid_is_A else OT(point h, centroid); all lanes return both values
-__device__ __forceinline__ void wave_sinkhorn_cost2(PairLds& w, uint32_t m, const uint32_t n[2], const Metric& M,
-                                                    bool centroid_is_A, float cost_out[2]) {
-    const uint32_t lane = lane_id(), half = lane >> 5, r = lane & 31u;
+// cost[h] = OT(centroid, point h) if centroid_is_A else OT(point h, centroid); all lanes return all G values
+template <uint32_t G>
+__device__ __forceinline__ void wave_sinkhorn_costG(GroupLds<G>& w, uint32_t m, const uint32_t (&n)[G], const Metric& M,
+                                                    bool centroid_is_A, float (&cost_out)[G]) {
+    constexpr uint32_t ROWS = 64u / G;
+    const uint32_t lane = lane_id(), grp = lane / ROWS, r = lane % ROWS;
     const uint32_t bins = M.bins;
     const __amdgpu_buffer_rsrc_t rt = rt_resource(M);
-    cost_out[0] = cost_out[1] = 0.0f;
+#pragma unroll
+    for (uint32_t h = 0; h < G; ++h) cost_out[h] = 0.0f;
     if (m == 0) return;
-    bool active[2] = {n[0] > 0, n[1] > 0};
-    uint32_t iters_done[2] = {0, 0};
+    bool active[G];
+    uint32_t iters_done[G];
     const float lc = rp_logf(1.0f / (float)m);
-    for (uint32_t h = 0; h < 2; ++h) {
+#pragma unroll
+    for (uint32_t h = 0; h < G; ++h) {
+        active[h] = n[h] > 0;
+        iters_done[h] = 0;
         for (uint32_t i = lane; i < m; i += 64) w.potC[h][i] = lc;
         if (n[h] > 0 && lane < n[h]) w.potP[h][lane] = rp_logf(1.0f / (float)n[h]);
     }
     __syncthreads();
-    const uint32_t nh = n[half];
+    const uint32_t nh = pick<G>(n, grp);
+    uint32_t nmax = 0;
+#pragma unroll
+    for (uint32_t h = 0; h < G; ++h) nmax = max(nmax, n[h]);
     // rows = centroid bins, one solve at a time (columns = that point's bins)
     auto centroid_rows = [&](uint32_t h) {
         for (uint32_t i0 = 0; i0 < m; i0 += 64) {
@@ -313,35 +379,27 @@ __device__ __forceinline__ void wave_sinkhorn_cost2(PairLds& w, uint32_t m, cons
             }
         }
     };
-    // rows = point bins, both solves at once (columns = the centroid's bins, potential per half)
+    // rows = point bins, all solves at once (columns = the centroid's bins, potential per lane group)
     auto point_rows = [&]() {
-        const bool valid = r < nh && (half ? active[1] : active[0]);
-        const uint32_t y = w.supP[half][r < nh ? r : 0u];
-        const float s = softmin_sum<false>(w.supC, w.potC[half], m, rt, bins, y);
+        const bool valid = r < nh && pick<G>(active, grp);
+        const uint32_t y = w.supP[grp][r < nh ? r : 0u];
+        const float s = softmin_sum<false>(w.supC, w.potC[grp], m, rt, bins, y);
         if (valid) {
-            const float nv = w.lnP[half][r] - rp_logf(s);
-            w.tmpP[half][r] = rp_absf(rp_expf(nv) - rp_expf(w.potP[half][r]));
-            w.potP[half][r] = nv;
+            const float nv = w.lnP[grp][r] - rp_logf(s);
+            w.tmpP[grp][r] = rp_absf(rp_expf(nv) - rp_expf(w.potP[grp][r]));
+            w.potP[grp][r] = nv;
         }
     };
-    auto err_centroid = [&]() -> float {  // lanes of half h: sum over the centroid rows of solve h
-        float e = 0.0f;
-        const float* t = w.tmpC[half];
-        for (uint32_t i = 0; i < m; ++i) e += t[i];
-        return e;
+    auto err_centroid = [&]() -> float {  // lanes of group g: sum over the centroid rows of solve g
+        return lds_sum_in_order(w.tmpC[grp], m);
     };
-    auto err_point = [&]() -> float {
-        float e = 0.0f;
-        const float* t = w.tmpP[half];
-        const uint32_t nmax = max(n[0], n[1]);
-        for (uint32_t j = 0; j < nmax; ++j) e += j < nh ? t[j] : 0.0f;  // x + 0.0f = x (x >= 0)
-        return e;
-    };
+    auto err_point = [&]() -> float { return lds_sum_in_order(w.tmpP[grp], nh); };
     for (uint32_t t = 0; t < M.iters; ++t) {
         float lhs_err, rhs_err;
         if (centroid_is_A) {  // lhs updates the centroid side, rhs the point side (Gauss-Seidel, sinkhorn.rs:80-87)
-            if (active[0]) centroid_rows(0);
-            if (active[1]) centroid_rows(1);
+#pragma unroll
+            for (uint32_t h = 0; h < G; ++h)
+                if (active[h]) centroid_rows(h);
             __syncthreads();
             lhs_err = err_centroid();
             __syncthreads();
@@ -354,42 +412,55 @@ __device__ __forceinline__ void wave_sinkhorn_cost2(PairLds& w, uint32_t m, cons
             __syncthreads();
             lhs_err = err_point();
             __syncthreads();
-            if (active[0]) centroid_rows(0);
-            if (active[1]) centroid_rows(1);
+#pragma unroll
+            for (uint32_t h = 0; h < G; ++h)
+                if (active[h]) centroid_rows(h);
             __syncthreads();
             rhs_err = err_centroid();
             __syncthreads();
         }
         const float tot = lhs_err + rhs_err;
-        const float tot0 = __shfl(tot, 0, 64), tot1 = __shfl(tot, 32, 64);
-        if (active[0] && tot0 < M.tol) { active[0] = false; iters_done[0] = t + 1; }
-        if (active[1] && tot1 < M.tol) { active[1] = false; iters_done[1] = t + 1; }
-        if (!active[0] && !active[1]) break;
+        bool any = false;
+#pragma unroll
+        for (uint32_t h = 0; h < G; ++h) {
+            const float th = __shfl(tot, (int)(h * ROWS), 64);
+            if (active[h] && th < M.tol) {
+                active[h] = false;
+                iters_done[h] = t + 1;
+            }
+            any = any || active[h];
+        }
+        if (!any) break;
     }
-    for (uint32_t h = 0; h < 2; ++h)
+    unsigned long long its = 0, exps = 0;
+#pragma unroll
+    for (uint32_t h = 0; h < G; ++h) {
         if (active[h]) iters_done[h] = M.iters;
-    if (lane == 0) {
-        atomicAdd(&M.stats[1], (unsigned long long)iters_done[0] * (n[0] > 0) + (unsigned long long)iters_done[1] * (n[1] > 0));
-        atomicAdd(&M.stats[2], (unsigned long long)(2 * iters_done[0] + 1) * m * n[0] + (unsigned long long)(2 * iters_done[1] + 1) * m * n[1]);
+        its += (unsigned long long)iters_done[h] * (n[h] > 0);
+        exps += (unsigned long long)(2 * iters_done[h] + 1) * m * n[h];
     }
-    // cost(): A-major left fold of coupling * distance (sinkhorn.rs:206-217), one solve per half
+    if (lane == 0) {
+        atomicAdd(&M.stats[1], its);
+        atomicAdd(&M.stats[2], exps);
+    }
+    // cost(): A-major left fold of coupling * distance (sinkhorn.rs:206-217), one solve per lane group
     float cost = 0.0f;
     if (centroid_is_A) {
         for (uint32_t i = 0; i < m; ++i) {
             const uint32_t x = w.supC[i];
-            const float fi = w.potC[half][i];
+            const float fi = w.potC[grp][i];
             if (r < nh) {
-                const uint32_t y = w.supP[half][r];
-                w.tmpP[half][r] = rp_expf(fi + w.potP[half][r] - M.Rt[x * bins + y]) * M.Cm[x * bins + y];
+                const uint32_t y = w.supP[grp][r];
+                w.tmpP[grp][r] = rp_expf(fi + w.potP[grp][r] - M.Rt[x * bins + y]) * M.Cm[x * bins + y];
             }
             __syncthreads();
-            for (uint32_t j = 0; j < nh; ++j) cost += w.tmpP[half][j];
+            for (uint32_t j = 0; j < nh; ++j) cost += w.tmpP[grp][j];
             __syncthreads();
         }
     } else {
-        const uint32_t nmax = max(n[0], n[1]);
         for (uint32_t i = 0; i < nmax; ++i) {
-            for (uint32_t h = 0; h < 2; ++h) {
+#pragma unroll
+            for (uint32_t h = 0; h < G; ++h) {
                 if (i >= n[h]) continue;
                 const uint32_t x = w.supP[h][i];
                 const float fi = w.potP[h][i];
@@ -400,19 +471,19 @@ __device__ __forceinline__ void wave_sinkhorn_cost2(PairLds& w, uint32_t m, cons
             }
             __syncthreads();
             if (i < nh) {
-                const float* t = w.tmpC[half];
+                const float* t = w.tmpC[grp];
                 for (uint32_t j = 0; j < m; ++j) cost += t[j];
             }
             __syncthreads();
         }
     }
-    cost_out[0] = __shfl(cost, 0, 64);
-    cost_out[1] = __shfl(cost, 32, 64);
+#pragma unroll
+    for (uint32_t h = 0; h < G; ++h) cost_out[h] = __shfl(cost, (int)(h * ROWS), 64);
 }
 
-// support of a dense histogram into the pair slot h (at most PAIR_ROWS bins, guaranteed by the pairing list)
+// support of a dense histogram into a group slot (at most `rows` bins, guaranteed by the grouping lists)
 template <typename CT>
-__device__ uint32_t pair_load_hist(const CT* counts, uint32_t weight, uint32_t bins, uint16_t* sup, float* lnd) {
+__device__ uint32_t pair_load_hist(const CT* counts, uint32_t weight, uint32_t bins, uint16_t* sup, float* lnd, uint32_t rows) {
     const uint32_t lane = lane_id();
     const float fw = (float)weight;
     uint32_t base = 0;
@@ -423,7 +494,7 @@ __device__ uint32_t pair_load_hist(const CT* counts, uint32_t weight, uint32_t b
         const unsigned long long mask = __ballot(has);
         if (has) {
             const uint32_t rr = base + __popcll(mask & ((1ull << lane) - 1ull));
-            if (rr < PAIR_ROWS) {
+            if (rr < rows) {
                 sup[rr] = (uint16_t)b;
                 lnd[rr] = rp_logf((float)c / fw);
             }
@@ -552,7 +623,7 @@ struct Bounds {
 __global__ __launch_bounds__(64) void k_neighbor(Points P, CentroidSet cs, uint32_t K, Metric M, int kind,
                                                  uint8_t* out_j, float* out_d, Bounds init, const uint32_t* only) {
     __shared__ WaveLds w;
-    const uint64_t i = only ? only[blockIdx.x] : blockIdx.x;  // `only`: the points k_neighbor2 does not take
+    const uint64_t i = only ? only[blockIdx.x] : blockIdx.x;  // `only`: the points the grouped kernels do not take
     const uint32_t lane = lane_id();
     uint32_t bj = 0;
     float bd = 0.0f;
@@ -607,26 +678,32 @@ __global__ __launch_bounds__(64) void k_neighbor(Points P, CentroidSet cs, uint3
         for (uint32_t k = lane; k < K; k += 64) init.lower[i * K + k] = 0.0f;
 }
 
-// Elkan::neighbor for TWO points per wavefront (both with <= PAIR_ROWS support bins), Sinkhorn metric
-__global__ __launch_bounds__(64) void k_neighbor2(Points P, CentroidSet cs, uint32_t K, Metric M, const uint32_t* pairs,
+// Elkan::neighbor for G points per wavefront (each with <= 64 / G support bins), Sinkhorn metric
+template <uint32_t G>
+__global__ __launch_bounds__(64) void k_neighborG(Points P, CentroidSet cs, uint32_t K, Metric M, const uint32_t* groups,
                                                   uint8_t* out_j, float* out_d, Bounds init) {
-    __shared__ PairLds w;
+    __shared__ GroupLds<G> w;
     const uint32_t lane = lane_id();
-    const uint64_t ip[2] = {pairs[2 * blockIdx.x], pairs[2 * blockIdx.x + 1]};
-    uint32_t n[2];
-    float sp[2];
-    for (uint32_t h = 0; h < 2; ++h) {
-        n[h] = pair_load_hist(P.counts + ip[h] * P.stride, P.weight[ip[h]], M.bins, w.supP[h], w.lnP[h]);
+    uint64_t ip[G];
+    uint32_t n[G];
+    float sp[G];
+#pragma unroll
+    for (uint32_t h = 0; h < G; ++h) {
+        ip[h] = groups[G * blockIdx.x + h];
+        n[h] = pair_load_hist(P.counts + ip[h] * P.stride, P.weight[ip[h]], M.bins, w.supP[h], w.lnP[h], GroupLds<G>::ROWS);
         sp[h] = P.self[ip[h]];
     }
-    uint32_t bj[2] = {0, 0};
-    float bd[2] = {0.0f, 0.0f};
+    uint32_t bj[G];
+    float bd[G];
+#pragma unroll
+    for (uint32_t h = 0; h < G; ++h) bj[h] = 0, bd[h] = 0.0f;
     for (uint32_t k = 0; k < K; ++k) {
         const uint32_t m = wave_load_centroid(cs, k, w.supC, w.lnC);
-        float xy[2];
-        wave_sinkhorn_cost2(w, m, n, M, true, xy);  // distance(centroid, point)
+        float xy[G];
+        wave_sinkhorn_costG<G>(w, m, n, M, true, xy);  // distance(centroid, point)
         const float sc = cs.self[k];
-        for (uint32_t h = 0; h < 2; ++h) {
+#pragma unroll
+        for (uint32_t h = 0; h < G; ++h) {
             const float d = rp_maxf(xy[h] - 0.5f * sc - 0.5f * sp[h], 0.0f);
             if (k == 0 || d < bd[h]) {
                 bj[h] = k;
@@ -635,11 +712,11 @@ __global__ __launch_bounds__(64) void k_neighbor2(Points P, CentroidSet cs, uint
         }
         __syncthreads();
     }
-    if (lane == 0) atomicAdd(&M.stats[0], 2ull * K);
-    if (lane < 2) {
-        const uint64_t i = ip[lane];
-        const uint32_t j = lane ? bj[1] : bj[0];
-        const float d = lane ? bd[1] : bd[0];
+    if (lane == 0) atomicAdd(&M.stats[0], (unsigned long long)G * K);
+    if (lane < G) {
+        const uint64_t i = pick<G>(ip, lane);
+        const uint32_t j = pick<G>(bj, lane);
+        const float d = pick<G>(bd, lane);
         if (out_j) out_j[i] = (uint8_t)j;
         if (out_d) out_d[i] = d;
         if (init.j) {
@@ -649,25 +726,31 @@ __global__ __launch_bounds__(64) void k_neighbor2(Points P, CentroidSet cs, uint
         }
     }
     if (init.lower)
-        for (uint32_t h = 0; h < 2; ++h)
+#pragma unroll
+        for (uint32_t h = 0; h < G; ++h)
             for (uint32_t k = lane; k < K; k += 64) init.lower[ip[h] * K + k] = 0.0f;
 }
 
-// k-means++ potentials for two points per wavefront: potentials <- min(potentials, d(new centroid, point)^2)
-__global__ __launch_bounds__(64) void k_kpp_update2(Points P, CentroidSet cs, uint32_t k, Metric M, const uint32_t* pairs,
+// k-means++ potentials for G points per wavefront: potentials <- min(potentials, d(new centroid, point)^2)
+template <uint32_t G>
+__global__ __launch_bounds__(64) void k_kpp_updateG(Points P, CentroidSet cs, uint32_t k, Metric M, const uint32_t* groups,
                                                     float* pot) {
-    __shared__ PairLds w;
-    const uint64_t ip[2] = {pairs[2 * blockIdx.x], pairs[2 * blockIdx.x + 1]};
-    uint32_t n[2];
+    __shared__ GroupLds<G> w;
+    uint64_t ip[G];
+    uint32_t n[G];
     const uint32_t m = wave_load_centroid(cs, k, w.supC, w.lnC);
-    for (uint32_t h = 0; h < 2; ++h) n[h] = pair_load_hist(P.counts + ip[h] * P.stride, P.weight[ip[h]], M.bins, w.supP[h], w.lnP[h]);
-    float xy[2];
-    wave_sinkhorn_cost2(w, m, n, M, true, xy);
+#pragma unroll
+    for (uint32_t h = 0; h < G; ++h) {
+        ip[h] = groups[G * blockIdx.x + h];
+        n[h] = pair_load_hist(P.counts + ip[h] * P.stride, P.weight[ip[h]], M.bins, w.supP[h], w.lnP[h], GroupLds<G>::ROWS);
+    }
+    float xy[G];
+    wave_sinkhorn_costG<G>(w, m, n, M, true, xy);
     const uint32_t lane = lane_id();
-    if (lane == 0) atomicAdd(&M.stats[0], 2ull);
-    if (lane < 2) {
-        const uint64_t i = ip[lane];
-        const float d = rp_maxf((lane ? xy[1] : xy[0]) - 0.5f * cs.self[k] - 0.5f * P.self[i], 0.0f);
+    if (lane == 0) atomicAdd(&M.stats[0], (unsigned long long)G);
+    if (lane < G) {
+        const uint64_t i = pick<G>(ip, lane);
+        const float d = rp_maxf(pick<G>(xy, lane) - 0.5f * cs.self[k] - 0.5f * P.self[i], 0.0f);
         pot[i] = rp_minf(d * d, pot[i]);
     }
 }
@@ -1424,9 +1507,10 @@ struct rp_kmeans {
     float* drift = nullptr;
     float* pot = nullptr;
     float* pdist = nullptr;
-    uint32_t* pairs = nullptr;    // [n_pairs][2] points with <= PAIR_ROWS support bins, two per wavefront (Sinkhorn)
+    uint32_t* quads = nullptr;    // [n_quads][4] points with <= QUAD_ROWS support bins, four per wavefront (Sinkhorn)
+    uint32_t* pairs = nullptr;    // [n_pairs][2] points with <= PAIR_ROWS support bins, two per wavefront
     uint32_t* singles = nullptr;  // [n_singles] the other points
-    uint64_t n_pairs = 0, n_singles = 0;
+    uint64_t n_quads = 0, n_pairs = 0, n_singles = 0;
     unsigned long long* bsum = nullptr;
     unsigned long long* scal = nullptr;  // [0] picked, [1] moved
     unsigned long long* sizes = nullptr; // [K]
@@ -1595,7 +1679,6 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
     }
     KM_HIP(hipStreamSynchronize(h->stream));
     if (kind == RP_METRIC_SINKHORN && !getenv("RP_LLOYD_NO_PAIRS")) {
-        // pairing list: points with at most PAIR_ROWS support bins go two per wavefront (k_neighbor2, k_kpp_update2)
         uint8_t* d_ns = nullptr;
         KM_TRY(dev_alloc(h, &d_ns, N));
         hipLaunchKernelGGL(k_point_support, dim3((unsigned)N), dim3(64), 0, h->stream, h->P, bins, d_ns);
@@ -1603,16 +1686,26 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         std::vector<uint8_t> ns(N);
         KM_HIP(hipMemcpyAsync(ns.data(), d_ns, N, hipMemcpyDeviceToHost, h->stream));  // same (non-blocking) stream as the kernel
         KM_HIP(hipStreamSynchronize(h->stream));
-        std::vector<uint32_t> small, rest;
-        for (uint64_t i = 0; i < N; ++i) (ns[i] <= PAIR_ROWS ? small : rest).push_back((uint32_t)i);
+        // grouping lists: <= QUAD_ROWS bins -> four per wavefront, <= PAIR_ROWS -> two, the others one
+        std::vector<uint32_t> tiny, small, rest;
+        // four per wavefront was measured slower than two on the real flop points (profiles/): opt-in
+        const bool no_quads = getenv("RP_LLOYD_QUADS") == nullptr;
+        for (uint64_t i = 0; i < N; ++i) (ns[i] <= QUAD_ROWS && !no_quads ? tiny : (ns[i] <= PAIR_ROWS ? small : rest)).push_back((uint32_t)i);
+        while (tiny.size() & 3u) {
+            small.push_back(tiny.back());
+            tiny.pop_back();
+        }
         if (small.size() & 1u) {
             rest.push_back(small.back());
             small.pop_back();
         }
+        h->n_quads = tiny.size() / 4;
         h->n_pairs = small.size() / 2;
         h->n_singles = rest.size();
+        KM_TRY(dev_alloc(h, &h->quads, tiny.size()));
         KM_TRY(dev_alloc(h, &h->pairs, small.size()));
         KM_TRY(dev_alloc(h, &h->singles, rest.size()));
+        if (!tiny.empty()) KM_HIP(hipMemcpy(h->quads, tiny.data(), tiny.size() * 4, hipMemcpyHostToDevice));
         if (!small.empty()) KM_HIP(hipMemcpy(h->pairs, small.data(), small.size() * 4, hipMemcpyHostToDevice));
         if (!rest.empty()) KM_HIP(hipMemcpy(h->singles, rest.data(), rest.size() * 4, hipMemcpyHostToDevice));
     }
@@ -1638,9 +1731,13 @@ int launch_neighbor(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init) {
     if (h->kind == RP_METRIC_VARIATION && h->bins == 101)  // turn layer: register-resident centroid CDFs
         hipLaunchKernelGGL(k_neighbor_var<101>, dim3((unsigned)((h->N + VB - 1) / VB)), dim3(256), 0, h->stream, h->P,
                            h->cs[h->cur], h->K, h->M, out_j, out_d, init);
-    else if (h->kind == RP_METRIC_SINKHORN && h->n_pairs) {
-        hipLaunchKernelGGL(k_neighbor2, dim3((unsigned)h->n_pairs), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->pairs,
-                           out_j, out_d, init);
+    else if (h->kind == RP_METRIC_SINKHORN && (h->n_pairs || h->n_quads)) {
+        if (h->n_quads)
+            hipLaunchKernelGGL(k_neighborG<4>, dim3((unsigned)h->n_quads), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M,
+                               h->quads, out_j, out_d, init);
+        if (h->n_pairs)
+            hipLaunchKernelGGL(k_neighborG<2>, dim3((unsigned)h->n_pairs), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M,
+                               h->pairs, out_j, out_d, init);
         if (h->n_singles)
             hipLaunchKernelGGL(k_neighbor, dim3((unsigned)h->n_singles), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M,
                                h->kind, out_j, out_d, init, h->singles);
@@ -1804,9 +1901,13 @@ int rp_kmeans_kpp_update(rp_kmeans* h, uint32_t k) {
                            h->M, h->pot);
     else
     {
-        if (h->n_pairs) {
-            hipLaunchKernelGGL(k_kpp_update2, dim3((unsigned)h->n_pairs), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->M, h->pairs,
-                               h->pot);
+        if (h->n_pairs || h->n_quads) {
+            if (h->n_quads)
+                hipLaunchKernelGGL(k_kpp_updateG<4>, dim3((unsigned)h->n_quads), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->M,
+                                   h->quads, h->pot);
+            if (h->n_pairs)
+                hipLaunchKernelGGL(k_kpp_updateG<2>, dim3((unsigned)h->n_pairs), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->M,
+                                   h->pairs, h->pot);
             if (h->n_singles)
                 hipLaunchKernelGGL(k_kpp_update, dim3((unsigned)h->n_singles), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->K,
                                    h->M, h->kind, h->pot, h->singles);
