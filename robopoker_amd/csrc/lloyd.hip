@@ -196,6 +196,46 @@ __device__ __forceinline__ float softmin_fold_first(float s, const SoftminGroup&
     }
     return s;
 }
+// softmin_sum with a PER-LANE walk: each lane folds the cnt terms of ITS OWN (sup, pot) arrays (lane groups of a
+// wavefront working on different solves), so the C/T row offset is a VGPR.  Same terms, same order as softmin_sum.
+__device__ __forceinline__ float softmin_sum_lane(const uint16_t* sup, const float* pot, uint32_t cnt,
+                                                   __amdgpu_buffer_rsrc_t rt, uint32_t bins, uint32_t xi) {
+    const uint32_t rowb = bins * 4u, xoff = xi * 4u;
+    float s = 0.0f;
+    for (uint32_t j = 0; j < cnt; j += 8) {
+        const uint4 sp = *reinterpret_cast<const uint4*>(sup + j);
+        SoftminGroup gq;
+        gq.p0 = *reinterpret_cast<const float4*>(pot + j);
+        gq.p1 = *reinterpret_cast<const float4*>(pot + j + 4);
+        gq.r[0] = rt_load(rt, (sp.x & 0xffffu) * rowb + xoff, 0);
+        gq.r[1] = rt_load(rt, (sp.x >> 16) * rowb + xoff, 0);
+        gq.r[2] = rt_load(rt, (sp.y & 0xffffu) * rowb + xoff, 0);
+        gq.r[3] = rt_load(rt, (sp.y >> 16) * rowb + xoff, 0);
+        gq.r[4] = rt_load(rt, (sp.z & 0xffffu) * rowb + xoff, 0);
+        gq.r[5] = rt_load(rt, (sp.z >> 16) * rowb + xoff, 0);
+        gq.r[6] = rt_load(rt, (sp.w & 0xffffu) * rowb + xoff, 0);
+        gq.r[7] = rt_load(rt, (sp.w >> 16) * rowb + xoff, 0);
+        rp_f2 e0, e1, e2, e3;
+        e0.x = gq.p0.x - gq.r[0]; e0.y = gq.p0.y - gq.r[1];
+        e1.x = gq.p0.z - gq.r[2]; e1.y = gq.p0.w - gq.r[3];
+        e2.x = gq.p1.x - gq.r[4]; e2.y = gq.p1.y - gq.r[5];
+        e3.x = gq.p1.z - gq.r[6]; e3.y = gq.p1.w - gq.r[7];
+        e0 = rp_exp_floor2(e0);
+        e1 = rp_exp_floor2(e1);
+        e2 = rp_exp_floor2(e2);
+        e3 = rp_exp_floor2(e3);
+        const uint32_t r = cnt - j;  // this lane's terms left (>= 1)
+        s += e0.x;
+        s = r > 1 ? s + e0.y : s;
+        s = r > 2 ? s + e1.x : s;
+        s = r > 3 ? s + e1.y : s;
+        s = r > 4 ? s + e2.x : s;
+        s = r > 5 ? s + e2.y : s;
+        s = r > 6 ? s + e3.x : s;
+        s = r > 7 ? s + e3.y : s;
+    }
+    return s;
+}
 template <bool PIPE = true>
 __device__ __forceinline__ float softmin_sum(const uint16_t* sup, const float* pot, uint32_t cnt,
                                               __amdgpu_buffer_rsrc_t rt, uint32_t bins, uint32_t xi) {
@@ -379,6 +419,19 @@ __device__ __forceinline__ void wave_sinkhorn_costG(GroupLds<G>& w, uint32_t m, 
             }
         }
     };
+    // the same for a centroid with <= ROWS bins: all solves at once, lane (g, i) = row i of the centroid in solve g,
+    // walking point g's bins (per-lane C/T row offsets)
+    const bool small_centroid = m <= ROWS;
+    auto centroid_rows_all = [&]() {
+        const bool valid = r < m && pick<G>(active, grp);
+        const uint32_t x = w.supC[r < m ? r : 0u];
+        const float s = softmin_sum_lane(w.supP[grp], w.potP[grp], valid ? nh : 0u, rt, bins, x);
+        if (valid) {
+            const float nv = w.lnC[r] - rp_logf(s);
+            w.tmpC[grp][r] = rp_absf(rp_expf(nv) - rp_expf(w.potC[grp][r]));
+            w.potC[grp][r] = nv;
+        }
+    };
     // rows = point bins, all solves at once (columns = the centroid's bins, potential per lane group)
     auto point_rows = [&]() {
         const bool valid = r < nh && pick<G>(active, grp);
@@ -397,9 +450,11 @@ __device__ __forceinline__ void wave_sinkhorn_costG(GroupLds<G>& w, uint32_t m, 
     for (uint32_t t = 0; t < M.iters; ++t) {
         float lhs_err, rhs_err;
         if (centroid_is_A) {  // lhs updates the centroid side, rhs the point side (Gauss-Seidel, sinkhorn.rs:80-87)
+            if (small_centroid) centroid_rows_all();
+            else
 #pragma unroll
-            for (uint32_t h = 0; h < G; ++h)
-                if (active[h]) centroid_rows(h);
+                for (uint32_t h = 0; h < G; ++h)
+                    if (active[h]) centroid_rows(h);
             __syncthreads();
             lhs_err = err_centroid();
             __syncthreads();
@@ -412,9 +467,11 @@ __device__ __forceinline__ void wave_sinkhorn_costG(GroupLds<G>& w, uint32_t m, 
             __syncthreads();
             lhs_err = err_point();
             __syncthreads();
+            if (small_centroid) centroid_rows_all();
+            else
 #pragma unroll
-            for (uint32_t h = 0; h < G; ++h)
-                if (active[h]) centroid_rows(h);
+                for (uint32_t h = 0; h < G; ++h)
+                    if (active[h]) centroid_rows(h);
             __syncthreads();
             rhs_err = err_centroid();
             __syncthreads();
@@ -1688,8 +1745,7 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         KM_HIP(hipStreamSynchronize(h->stream));
         // grouping lists: <= QUAD_ROWS bins -> four per wavefront, <= PAIR_ROWS -> two, the others one
         std::vector<uint32_t> tiny, small, rest;
-        // four per wavefront was measured slower than two on the real flop points (profiles/): opt-in
-        const bool no_quads = getenv("RP_LLOYD_QUADS") == nullptr;
+        const bool no_quads = getenv("RP_LLOYD_NO_QUADS") != nullptr;
         for (uint64_t i = 0; i < N; ++i) (ns[i] <= QUAD_ROWS && !no_quads ? tiny : (ns[i] <= PAIR_ROWS ? small : rest)).push_back((uint32_t)i);
         while (tiny.size() & 3u) {
             small.push_back(tiny.back());

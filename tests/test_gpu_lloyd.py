@@ -197,19 +197,34 @@ def test_flop_config_slice_properties(gpu):
     assert np.all(lo >= 0) and np.all(drift >= 0) and 0.0 <= moved <= 1.0
 
 
-def test_two_points_per_wavefront_equals_one_point_per_wavefront(gpu, monkeypatch):
-    # Points with <= 32 support bins are solved two per wavefront against a shared centroid (k_neighbor2 /
-    # k_kpp_update2); the rest, and everything under RP_LLOYD_NO_PAIRS=1, one per wavefront.  Large enough that the
-    # pairing list is built while the GPU is busy (a missing stream sync once mis-classified late points).
+@pytest.mark.parametrize("small_supports", [False, True])
+def test_points_per_wavefront_groupings_agree(gpu, monkeypatch, small_supports):
+    # Points with <= 16 support bins are solved four per wavefront against a shared centroid, those with <= 32 two per
+    # wavefront (k_neighborG / k_kpp_updateG), the rest one; RP_LLOYD_NO_QUADS=1 / RP_LLOYD_NO_PAIRS=1 switch the
+    # groupings off.  Every grouping performs the same float operations per solve: identical picks, buckets and
+    # distances.  Large enough that the lists are built while the GPU is busy (a missing stream sync once
+    # mis-classified late points).  small_supports: like the real flop points (<= 27 bins, ~11 on average), so
+    # that most points take the four-per-wavefront path and centroids the shared centroid-row pass.
     N, K, bins = 60000, 48, 256
-    pts = flop_like_points(N, bins=bins, mass=47, seed=3)
+    if small_supports:
+        rng = np.random.default_rng(8)
+        pts = np.zeros((N, bins), dtype=np.uint8)
+        for i in range(N):
+            k = int(rng.integers(1, 28))
+            sup = rng.choice(bins, size=k, replace=False)
+            pts[i, sup] = 1
+            extra = rng.choice(sup, size=47 - k, replace=True)
+            np.add.at(pts[i], extra, 1)
+        assert (pts.sum(axis=1) == 47).all()
+    else:
+        pts = flop_like_points(N, bins=bins, mass=47, seed=3)
     tri = smooth_metric(bins, 1)
 
-    def run(no_pairs):
-        if no_pairs:
-            monkeypatch.setenv("RP_LLOYD_NO_PAIRS", "1")
-        else:
-            monkeypatch.delenv("RP_LLOYD_NO_PAIRS", raising=False)
+    def run(env):
+        for v in ("RP_LLOYD_NO_PAIRS", "RP_LLOYD_NO_QUADS"):
+            monkeypatch.delenv(v, raising=False)
+        if env:
+            monkeypatch.setenv(env, "1")
         layer = lloyd.Layer(K, pts, "sinkhorn", tri, seed=11)
         chosen = np.asarray(layer.init_centroids())
         layer.init_bounds()
@@ -217,11 +232,12 @@ def test_two_points_per_wavefront_equals_one_point_per_wavefront(gpu, monkeypatc
         bucket, dist = layer.lookup()
         return chosen, np.asarray(bucket), np.asarray(dist)
 
-    c1, b1, d1 = run(True)
-    c2, b2, d2 = run(False)
-    assert np.array_equal(c1, c2), "k-means++ picks differ"
-    assert np.array_equal(b1, b2)
-    assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
+    c1, b1, d1 = run("RP_LLOYD_NO_PAIRS")
+    for env in (None, "RP_LLOYD_NO_QUADS"):
+        c2, b2, d2 = run(env)
+        assert np.array_equal(c1, c2), "k-means++ picks differ"
+        assert np.array_equal(b1, b2)
+        assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
 
 
 @pytest.mark.parametrize("temperature,iterations,tolerance", [(0.025, 128, 5e-4), (0.1, 64, 1e-3), (0.01, 200, 1e-5),
