@@ -952,6 +952,89 @@ __global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uin
 }
 
 // ------------------------------------------------------------------------------------------------
+// The stale-bound refresh of step_elkan (elkan.rs:113-117: u = l[j] = distance(x, c_j)) as its own, grouped pass.
+// Every point that passes the filter with a stale bound needs exactly this one distance before its candidate loop, and
+// all the points of a cluster need it against the SAME centroid: they are bucketed by assignment and solved two per
+// wavefront (wave_sinkhorn_costG<2>, point first).  k_elkan_step then finds them fresh.  A point whose refreshed bound
+// no longer passes the filter has no candidates either (mid[j] = min_k P[j][k] / 2), so skipping its loop changes
+// nothing.  Which two points share a wavefront is decided by atomics and does not matter: a solve's operations do not
+// depend on its partner.
+// ------------------------------------------------------------------------------------------------
+struct Refresh {
+    const uint8_t* nsup;  // [N] support sizes
+    uint32_t* count;      // [K]   points needing a refresh per cluster, then the fill cursor
+    uint32_t* offset;     // [K+1] start of each cluster's (even-padded) bucket; offset[K] = entries in the list
+    uint32_t* list;       // [N + 2K] point indices, 0xffffffff = padding
+};
+__device__ __forceinline__ bool needs_refresh(const Bounds& B, const Refresh& R, const float* mid, uint64_t i) {
+    return B.stale[i] && B.u[i] > mid[B.j[i]] && R.nsup[i] <= PAIR_ROWS;
+}
+__global__ __launch_bounds__(256) void k_refresh_count(Bounds B, Refresh R, const float* mid, uint64_t N, uint32_t K) {
+    __shared__ uint32_t c[MAXB];
+    for (uint32_t k = threadIdx.x; k < K; k += 256) c[k] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (uint64_t)gridDim.x * 256)
+        if (needs_refresh(B, R, mid, i)) atomicAdd(&c[B.j[i]], 1u);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < K; k += 256)
+        if (c[k]) atomicAdd(&R.count[k], c[k]);
+}
+__global__ void k_refresh_offsets(Refresh R, uint32_t K) {  // one thread: K <= 256
+    uint32_t at = 0;
+    for (uint32_t k = 0; k < K; ++k) {
+        R.offset[k] = at;
+        at += (R.count[k] + 1u) & ~1u;
+        R.count[k] = 0;  // becomes the fill cursor
+    }
+    R.offset[K] = at;
+}
+__global__ __launch_bounds__(256) void k_refresh_fill(Bounds B, Refresh R, const float* mid, uint64_t N) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (uint64_t)gridDim.x * 256)
+        if (needs_refresh(B, R, mid, i)) {
+            const uint32_t j = B.j[i];
+            R.list[R.offset[j] + atomicAdd(&R.count[j], 1u)] = (uint32_t)i;
+        }
+}
+__global__ __launch_bounds__(64) void k_refresh_pairs(Points P, CentroidSet cs, uint32_t K, Metric M, Bounds B, Refresh R) {
+    __shared__ GroupLds<2> w;
+    const uint32_t e0 = 2u * blockIdx.x;
+    if (e0 >= R.offset[K]) return;
+    uint32_t lo = 0, hi = K;  // the cluster whose bucket holds entry e0: last k with offset[k] <= e0
+    while (hi - lo > 1) {
+        const uint32_t mid_k = (lo + hi) / 2;
+        if (R.offset[mid_k] <= e0) lo = mid_k;
+        else hi = mid_k;
+    }
+    const uint32_t j = lo;
+    uint32_t ip[2], n[2];
+    float sp[2];
+    const uint32_t m = wave_load_centroid(cs, j, w.supC, w.lnC);
+#pragma unroll
+    for (uint32_t h = 0; h < 2; ++h) {
+        ip[h] = R.list[e0 + h];
+        const bool real = ip[h] != 0xffffffffu;
+        const uint64_t i = real ? ip[h] : 0;
+        const uint32_t got = pair_load_hist(P.counts + i * P.stride, P.weight[i], M.bins, w.supP[h], w.lnP[h], PAIR_ROWS);
+        n[h] = real ? got : 0u;
+        sp[h] = P.self[i];
+    }
+    float xy[2];
+    wave_sinkhorn_costG<2>(w, m, n, M, false, xy);  // distance(point, centroid)
+    const uint32_t lane = lane_id();
+    const float sc = cs.self[j];
+    if (lane < 2) {
+        const uint32_t i = lane ? ip[1] : ip[0];
+        if (i != 0xffffffffu) {
+            const float d = rp_maxf((lane ? xy[1] : xy[0]) - 0.5f * (lane ? sp[1] : sp[0]) - 0.5f * sc, 0.0f);
+            B.u[i] = d;
+            B.lower[(uint64_t)i * K + j] = d;
+            B.stale[i] = 0;
+            atomicAdd(&M.stats[0], 1ull);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Equity::variation against ALL K centroids with the centroid CDFs in REGISTERS (turn layer: bins = 101).
 //
 // Workgroup = 4 waves x VB points.  Wave q owns centroids q*64 + lane: its CDF column (BINS running sums of the
@@ -1568,6 +1651,7 @@ struct rp_kmeans {
     uint32_t* pairs = nullptr;    // [n_pairs][2] points with <= PAIR_ROWS support bins, two per wavefront
     uint32_t* singles = nullptr;  // [n_singles] the other points
     uint64_t n_quads = 0, n_pairs = 0, n_singles = 0;
+    Refresh refresh{};            // grouped stale-bound refresh (Sinkhorn; null nsup = off)
     unsigned long long* bsum = nullptr;
     unsigned long long* scal = nullptr;  // [0] picked, [1] moved
     unsigned long long* sizes = nullptr; // [K]
@@ -1746,6 +1830,12 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         // grouping lists: <= QUAD_ROWS bins -> four per wavefront, <= PAIR_ROWS -> two, the others one
         std::vector<uint32_t> tiny, small, rest;
         const bool no_quads = getenv("RP_LLOYD_NO_QUADS") != nullptr;
+        if (!getenv("RP_LLOYD_NO_REFRESH_PASS")) {
+            h->refresh.nsup = d_ns;
+            KM_TRY(dev_alloc(h, &h->refresh.count, (size_t)K));
+            KM_TRY(dev_alloc(h, &h->refresh.offset, (size_t)K + 1));
+            KM_TRY(dev_alloc(h, &h->refresh.list, (size_t)N + 2 * (size_t)K));
+        }
         for (uint64_t i = 0; i < N; ++i) (ns[i] <= QUAD_ROWS && !no_quads ? tiny : (ns[i] <= PAIR_ROWS ? small : rest)).push_back((uint32_t)i);
         while (tiny.size() & 3u) {
             small.push_back(tiny.back());
@@ -1828,9 +1918,20 @@ int step_front(rp_kmeans* h) {
     if (h->kind == RP_METRIC_VARIATION && h->bins == 101)
         hipLaunchKernelGGL(k_elkan_step_var<101>, dim3((unsigned)((h->N + VB - 1) / VB)), dim3(256), 0, h->stream, h->P, h->cs[cur],
                            h->K, h->M, h->B, h->pairw, h->mid);
-    else
+    else {
+        if (h->kind == RP_METRIC_SINKHORN && h->refresh.nsup) {
+            const size_t entries = (size_t)h->N + 2 * (size_t)h->K;
+            HIP_TRY(hipMemsetAsync(h->refresh.count, 0, (size_t)h->K * 4, h->stream));
+            HIP_TRY(hipMemsetAsync(h->refresh.list, 0xff, entries * 4, h->stream));
+            hipLaunchKernelGGL(k_refresh_count, dim3(1024), dim3(256), 0, h->stream, h->B, h->refresh, h->mid, h->N, h->K);
+            hipLaunchKernelGGL(k_refresh_offsets, dim3(1), dim3(1), 0, h->stream, h->refresh, h->K);
+            hipLaunchKernelGGL(k_refresh_fill, dim3(1024), dim3(256), 0, h->stream, h->B, h->refresh, h->mid, h->N);
+            hipLaunchKernelGGL(k_refresh_pairs, dim3((unsigned)(entries / 2 + 1)), dim3(64), 0, h->stream, h->P, h->cs[cur], h->K, h->M,
+                               h->B, h->refresh);
+        }
         hipLaunchKernelGGL(k_elkan_step, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[cur], h->K, h->M, h->kind, h->B,
                            h->pairw, h->mid);
+    }
     ck_end(h, CK_STEP);
     HIP_TRY(hipGetLastError());
     return launch_recompute(h, h->B.j, cur ^ 1);
