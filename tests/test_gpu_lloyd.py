@@ -200,8 +200,8 @@ def test_flop_config_slice_properties(gpu):
 @pytest.mark.parametrize("small_supports", [False, True])
 def test_points_per_wavefront_groupings_agree(gpu, monkeypatch, small_supports):
     # Points with <= 16 support bins are solved four per wavefront against a shared centroid, those with <= 32 two per
-    # wavefront (k_neighborG / k_kpp_updateG), the rest one; RP_LLOYD_NO_QUADS=1 / RP_LLOYD_NO_PAIRS=1 switch the
-    # groupings off.  Every grouping performs the same float operations per solve: identical picks, buckets and
+    # wavefront (k_neighborG / k_kpp_updateG, k_refresh_pairs), the rest one; RP_LLOYD_NO_QUADS=1 / RP_LLOYD_NO_PAIRS=1 /
+    # RP_LLOYD_NO_REFRESH_PASS=1 switch the groupings off.  Every grouping performs the same float operations per solve: identical picks, buckets and
     # distances.  Large enough that the lists are built while the GPU is busy (a missing stream sync once
     # mis-classified late points).  small_supports: like the real flop points (<= 27 bins, ~11 on average), so
     # that most points take the four-per-wavefront path and centroids the shared centroid-row pass.
@@ -221,7 +221,7 @@ def test_points_per_wavefront_groupings_agree(gpu, monkeypatch, small_supports):
     tri = smooth_metric(bins, 1)
 
     def run(env):
-        for v in ("RP_LLOYD_NO_PAIRS", "RP_LLOYD_NO_QUADS"):
+        for v in ("RP_LLOYD_NO_PAIRS", "RP_LLOYD_NO_QUADS", "RP_LLOYD_NO_REFRESH_PASS"):
             monkeypatch.delenv(v, raising=False)
         if env:
             monkeypatch.setenv(env, "1")
@@ -229,11 +229,12 @@ def test_points_per_wavefront_groupings_agree(gpu, monkeypatch, small_supports):
         chosen = np.asarray(layer.init_centroids())
         layer.init_bounds()
         layer.step()
+        layer.step()  # the second iteration starts from stale bounds: the grouped refresh pass runs
         bucket, dist = layer.lookup()
         return chosen, np.asarray(bucket), np.asarray(dist)
 
     c1, b1, d1 = run("RP_LLOYD_NO_PAIRS")
-    for env in (None, "RP_LLOYD_NO_QUADS"):
+    for env in (None, "RP_LLOYD_NO_QUADS", "RP_LLOYD_NO_REFRESH_PASS"):
         c2, b2, d2 = run(env)
         assert np.array_equal(c1, c2), "k-means++ picks differ"
         assert np.array_equal(b1, b2)
