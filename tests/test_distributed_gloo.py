@@ -136,6 +136,20 @@ def _profile_worker(rank, port, out):
     dist.destroy_process_group()
 
 
+def _pretraining_gather_worker(rank, port, out):
+    # the list plumbing of the sharded abstraction pipeline (robopoker_amd/pretraining.py): contiguous equal-width
+    # slices of an isomorphism list, the last one short; 1-byte results all-gathered back into list order
+    _init(rank, port)
+    from robopoker_amd import pretraining
+    ok = True
+    for n in (1001, 1000, 7, 2):
+        whole = (torch.arange(n, dtype=torch.int64) * 37 % 251).to(torch.uint8)
+        lo, hi, width = pretraining._slice(n, rank, WORLD)
+        got = pretraining._gather_u8(whole[lo:hi].clone(), width, n, None)
+        ok = ok and bool(torch.equal(got, whole))
+    out.put((rank, ok))
+
+
 def _run(fn, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -175,3 +189,8 @@ def test_sharded_kmeans_two_ranks_equals_single_process(kind):
 def test_sharded_sparse_profile_two_ranks_equals_world_model():
     res = _run(_profile_worker)
     assert res == {"profile": True, "profile-replica": True}
+
+
+def test_sharded_pretraining_slices_and_gathers_two_ranks():
+    res = _run(_pretraining_gather_worker)
+    assert res == {0: True, 1: True}
