@@ -182,6 +182,20 @@ RP_API int rp_mccfr_step(rp_mccfr* h);
 RP_API int rp_mccfr_solve(rp_mccfr* h, uint64_t trees);
 /* Solver::spend (solver.rs:130-137) */
 RP_API int rp_mccfr_spend(rp_mccfr* h, double seconds, uint64_t* iterations, double* elapsed);
+/* Trainer::train (crates/forge/src/trainer.rs:18-66) over this solver: loop { step; checkpoint; flush; interrupt? }.
+ * A checkpoint fires when `log_interval` seconds passed since the last one (Metrics::checkpoint, mccfr/src/metrics/
+ * mod.rs:67-80: rate = new infos / max(1, whole seconds)); its line is Checkpoint's Display (metrics/checkpoint.rs:
+ * 39-50): "batch E", "nodes N", "infos I", "I/sec R.R", each left-aligned in 20 columns.  A flush event fires every
+ * `flush_interval` seconds (TrainingHyperParams defaults: 60 s and 30 min, hyperparams/training.rs:50-54); the
+ * callback may export the table there (rp_mccfr_export).  The loop ends when *interrupt becomes non-zero
+ * (pokerkit::interrupted), after max_steps (0 = unbounded) or max_seconds (<= 0 = unbounded); `summary` receives
+ * Progress::summary (progress.rs:24-26).  Counters are read from the device only when a checkpoint is due. */
+typedef struct rp_checkpoint { uint64_t epoch, nodes, infos; double rate; } rp_checkpoint;
+typedef enum rp_train_event { RP_TRAIN_CHECKPOINT = 0, RP_TRAIN_FLUSH = 1 } rp_train_event;
+typedef void (*rp_train_event_fn)(int event, const rp_checkpoint* cp, const char* line, void* user);
+RP_API int rp_mccfr_train(rp_mccfr* h, uint64_t max_steps, double max_seconds, double log_interval,
+                          double flush_interval, rp_train_event_fn on_event, void* user,
+                          const volatile int* interrupt, char* summary, size_t summary_cap);
 /* enqueue `steps` steps on the stream without host synchronisation (FastSession::step loop shape) */
 RP_API int rp_mccfr_step_async(rp_mccfr* h, uint32_t steps);
 RP_API int rp_mccfr_sync(rp_mccfr* h);

@@ -2028,6 +2028,62 @@ int rp_mccfr_spend(rp_mccfr* h, double seconds, uint64_t* iterations, double* el
     return RP_OK;
 }
 
+// Checkpoint's Display / Progress::format (metrics/checkpoint.rs:39-50, progress.rs:8-18): four 20-column fields
+static void format_progress(char* buf, size_t cap, uint64_t epoch, uint64_t nodes, uint64_t infos, double rate) {
+    char f[4][48];
+    snprintf(f[0], sizeof f[0], "batch %llu", (unsigned long long)epoch);
+    snprintf(f[1], sizeof f[1], "nodes %llu", (unsigned long long)nodes);
+    snprintf(f[2], sizeof f[2], "infos %llu", (unsigned long long)infos);
+    snprintf(f[3], sizeof f[3], "I/sec %.1f", rate);
+    snprintf(buf, cap, "%-20s%-20s%-20s%-20s", f[0], f[1], f[2], f[3]);
+}
+
+int rp_mccfr_train(rp_mccfr* h, uint64_t max_steps, double max_seconds, double log_interval, double flush_interval,
+                   rp_train_event_fn on_event, void* user, const volatile int* interrupt, char* summary, size_t summary_cap) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_mccfr_train: NULL handle");
+    using clock = std::chrono::steady_clock;
+    const auto start = clock::now();
+    auto prior = start, flushed = start;
+    uint64_t prior_infos = 0, steps = 0, nodes = 0, infos = 0;
+    auto secs_since = [](clock::time_point t) { return std::chrono::duration<double>(clock::now() - t).count(); };
+    for (;;) {
+        int rc = rp_mccfr_step(h);  // Trainer::train: step, then checkpoint, then flush, then the interrupt test
+        if (rc) return rc;
+        steps += 1;
+        if (secs_since(prior) >= log_interval) {  // Metrics::checkpoint (metrics/mod.rs:67-80)
+            if ((rc = rp_mccfr_counters(h, &nodes, &infos))) return rc;
+            const double secs = std::max(1.0, std::floor(secs_since(prior)));  // elapsed().as_secs().max(1)
+            rp_checkpoint cp{h->epoch, nodes, infos, (double)(infos - prior_infos) / secs};
+            prior = clock::now();
+            prior_infos = infos;
+            if (on_event) {
+                char line[96];
+                format_progress(line, sizeof line, cp.epoch, cp.nodes, cp.infos, cp.rate);
+                on_event(RP_TRAIN_CHECKPOINT, &cp, line, user);
+            }
+        }
+        if (secs_since(flushed) >= flush_interval) {  // FastSession::flush cadence (forge/src/fast.rs:97-125)
+            flushed = clock::now();
+            if (on_event) {
+                rp_checkpoint cp{h->epoch, nodes, infos, 0.0};
+                on_event(RP_TRAIN_FLUSH, &cp, "", user);
+            }
+        }
+        const bool stop = (interrupt && *interrupt) || (max_steps && steps >= max_steps) ||
+                          (max_seconds > 0.0 && secs_since(start) >= max_seconds);
+        if (stop) break;
+    }
+    int rc = rp_mccfr_counters(h, &nodes, &infos);
+    if (rc) return rc;
+    if (summary && summary_cap) {  // Progress::summary (progress.rs:24-26): rate over the whole run
+        char line[96];
+        const double secs = std::max(1.0, std::floor(secs_since(start)));
+        format_progress(line, sizeof line, h->epoch, nodes, infos, (double)infos / secs);
+        snprintf(summary, summary_cap, "training stopped\n%s", line);
+    }
+    return RP_OK;
+}
+
 int rp_mccfr_epoch(rp_mccfr* h, uint64_t* epoch) {
     if (!h || !epoch) return rp::fail(RP_ERR_INVALID, "rp_mccfr_epoch: NULL argument");
     *epoch = h->epoch;

@@ -68,6 +68,31 @@ class Solver:
         _lib.check(self._lib.rp_mccfr_spend(self._h, seconds, C.byref(it), C.byref(el)))
         return it.value, el.value
 
+    def train(self, max_steps=0, max_seconds=0.0, log_interval=60.0, flush_interval=1800.0, on_checkpoint=None,
+              on_flush=None, interrupt=None):
+        """``Trainer::train`` (crates/forge/src/trainer.rs:18-66): loop { step; checkpoint; flush; interrupt? } in the
+        library.  ``on_checkpoint(dict, line)`` gets the Checkpoint and its display line, ``on_flush(dict)`` fires at
+        the flush cadence, ``interrupt`` is a ctypes c_int the caller may set to stop.  Returns Progress::summary."""
+        EVENT = C.CFUNCTYPE(None, C.c_int, C.c_void_p, C.c_char_p, C.c_void_p)
+
+        class Checkpoint(C.Structure):
+            _fields_ = [("epoch", C.c_uint64), ("nodes", C.c_uint64), ("infos", C.c_uint64), ("rate", C.c_double)]
+
+        def cb(event, cp, line, _user):
+            c = C.cast(cp, C.POINTER(Checkpoint)).contents
+            d = {"epoch": c.epoch, "nodes": c.nodes, "infos": c.infos, "rate": c.rate}
+            if event == 0 and on_checkpoint:
+                on_checkpoint(d, line.decode())
+            if event == 1 and on_flush:
+                on_flush(d)
+
+        fn = EVENT(cb)
+        buf = C.create_string_buffer(256)
+        _lib.check(self._lib.rp_mccfr_train(self._h, int(max_steps), float(max_seconds), float(log_interval),
+                                            float(flush_interval), C.cast(fn, C.c_void_p), None,
+                                            C.byref(interrupt) if interrupt is not None else None, buf, len(buf)))
+        return buf.value.decode()
+
     def exploitability(self) -> float:
         out = C.c_float()
         _lib.check(self._lib.rp_mccfr_exploitability(self._h, C.byref(out)))

@@ -319,3 +319,36 @@ def test_kuhn_nash_on_device(gpu):
     assert pol("J|B", 0) > 0.95 and pol("K|B", 1) > 0.95 and pol("K|X", 1) > 0.95
     assert abs(pol("J|", 1) - 9 / 31) < 0.05 and abs(pol("K|", 1) - 27 / 31) < 0.05
     assert abs(pol("Q|XB", 1) - 23 / 31) < 0.05 and abs(pol("J|X", 1) - 9 / 31) < 0.05
+
+
+def test_trainer_loop_checkpoints_and_summary(gpu):
+    # Trainer::train over the solver (trainer.rs:18-66): a checkpoint every step (log interval 0), the Checkpoint
+    # display of metrics/checkpoint.rs:39-50, rate = new infos / max(1, whole seconds) (metrics/mod.rs:67-80),
+    # Progress::summary at the end (progress.rs:24-26); the table is the one plain step() calls produce
+    g = Game("leduc")
+    a = Solver(g, "floored", "linear", "external", batch=256, seed=5)
+    b = Solver(g, "floored", "linear", "external", batch=256, seed=5)
+    seen, flushes = [], []
+    summary = a.train(max_steps=12, log_interval=0.0, flush_interval=0.0,
+                      on_checkpoint=lambda cp, line: seen.append((cp, line)), on_flush=lambda cp: flushes.append(cp))
+    for _ in range(12):
+        b.step()
+    ea, eb = a.export(), b.export()
+    for f in ("visits", "regret", "weight", "payoff"):
+        assert np.array_equal(ea[f].view(np.uint32), eb[f].view(np.uint32))
+    assert len(seen) == 12 and len(flushes) == 12 and [cp["epoch"] for cp, _ in seen] == list(range(1, 13))
+    prev = 0
+    for cp, line in seen:
+        assert cp["infos"] >= prev and cp["rate"] == float(cp["infos"] - prev)  # whole seconds < 1 -> divided by 1
+        prev = cp["infos"]
+        want = "".join(f"{x:<20}" for x in (f"batch {cp['epoch']}", f"nodes {cp['nodes']}", f"infos {cp['infos']}",
+                                            f"I/sec {cp['rate']:.1f}"))
+        assert line == want
+    nodes, infos = a.counters()
+    assert summary == "training stopped\n" + "".join(
+        f"{x:<20}" for x in (f"batch 12", f"nodes {nodes}", f"infos {infos}", f"I/sec {float(infos):.1f}"))
+    # the interrupt flag stops the loop after the step in flight
+    import ctypes
+    stop = ctypes.c_int(1)
+    a.train(interrupt=stop)
+    assert a.epoch == 13
