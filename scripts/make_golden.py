@@ -97,9 +97,38 @@ def kmeans_cases():
     return out
 
 
+def deuce_cases():
+    """Abstraction inputs: strength keys, canonical forms, river equities (raw f32 bits) and buckets, the head and a
+    checksum of each street's isomorphism list, a few turn histograms."""
+    import random
+
+    import oracle_deuce as od
+    rng = random.Random(2024)
+    hands = [sum(1 << c for c in rng.sample(range(52), k)) for k in (5, 6, 7) for _ in range(40)]
+    obs = []
+    for n_board in (0, 3, 4, 5):
+        for _ in range(25):
+            cards = rng.sample(range(52), 2 + n_board)
+            obs.append(od.obs_i64(sum(1 << c for c in cards[:2]), sum(1 << c for c in cards[2:])))
+    river = [o for o in obs if len([b for b in range(8) if (o >> (8 * b)) & 0xff]) == 7]
+    eq = [od.river_equity(*od.obs_from_i64(o)) for o in river]
+    lists = {}
+    for street, hi in (("pref", 1326), ("flop", 1326), ("turn", 160)):
+        v = od.isomorphisms(street, 0, hi)
+        lists[street] = dict(pockets=[0, hi], n=int(v.size), head=v[:12].tolist(), tail=v[-4:].tolist(),
+                             xor=int(np.bitwise_xor.reduce(v)), sum_mod=int(v.astype(np.uint64).sum() % (1 << 61)))
+    turn = od.isomorphisms("turn", 1200, 1210)[:6]
+    return dict(hands=hands, strength_keys=[od.strength_key(h) for h in hands], obs=obs,
+                canonical=[od.obs_i64(*od.isomorphism(*od.obs_from_i64(o))) for o in obs], river=river,
+                equity_bits=bits([e[0] for e in eq]), won=[e[1] for e in eq], total=[e[2] for e in eq],
+                bucket=[od.quantize(e[0]) for e in eq], lists=lists, turn=turn.tolist(),
+                turn_histograms=od.project_river(turn).tolist())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    for name, data in [("mccfr_tables.json", mccfr_cases()), ("sinkhorn.json", sinkhorn_cases()), ("kmeans.json", kmeans_cases())]:
+    for name, data in [("mccfr_tables.json", mccfr_cases()), ("sinkhorn.json", sinkhorn_cases()), ("kmeans.json", kmeans_cases()),
+                       ("deuce.json", deuce_cases())]:
         with open(os.path.join(OUT, name), "w") as f:
             json.dump(data, f, separators=(",", ":"))
         print(name, os.path.getsize(os.path.join(OUT, name)), "bytes")

@@ -137,3 +137,49 @@ def test_device_reproduces_kmeans_golden(gpu, case):
     hp = oracle.default_sinkhorn()
     hp.iterations = case["sinkhorn_iterations"]
     _run_kmeans(lloyd.Layer(case["K"], pts, case["kind"], tri, hp=hp, seed=case["seed"]), case)
+
+
+def _deuce_from_oracle():
+    import oracle_deuce as od
+    g = load("deuce.json")
+    assert [od.strength_key(h) for h in g["hands"]] == g["strength_keys"]
+    assert [od.obs_i64(*od.isomorphism(*od.obs_from_i64(o))) for o in g["obs"]] == g["canonical"]
+    eq = [od.river_equity(*od.obs_from_i64(o)) for o in g["river"]]
+    assert bits([e[0] for e in eq]) == g["equity_bits"]
+    assert [e[1] for e in eq] == g["won"] and [e[2] for e in eq] == g["total"]
+    assert [od.quantize(e[0]) for e in eq] == g["bucket"]
+    for street, want in g["lists"].items():
+        v = od.isomorphisms(street, *want["pockets"])
+        _check_list(v, want)
+    assert od.project_river(g["turn"]).tolist() == g["turn_histograms"]
+
+
+def _check_list(v, want):
+    assert int(v.size) == want["n"] and v[:12].tolist() == want["head"] and v[-4:].tolist() == want["tail"]
+    assert int(np.bitwise_xor.reduce(v)) == want["xor"]
+    assert int(v.astype(np.uint64).sum() % (1 << 61)) == want["sum_mod"]
+
+
+def test_oracle_reproduces_deuce_golden():
+    _deuce_from_oracle()
+
+
+@pytest.mark.gpu
+def test_device_reproduces_deuce_golden(gpu):
+    torch = pytest.importorskip("torch")
+    from robopoker_amd import deuce
+
+    g = load("deuce.json")
+    assert deuce.hand_strength(g["hands"]).tolist() == g["strength_keys"]
+    assert deuce.canonical(g["obs"]).tolist() == g["canonical"]
+    river = torch.tensor(g["river"], dtype=torch.int64, device="cuda")
+    e, b = deuce.river_equity(river)
+    assert bits(e.cpu().numpy()) == g["equity_bits"] and b.cpu().tolist() == g["bucket"]
+    for street, want in g["lists"].items():
+        _check_list(deuce.isomorphisms(street, *want["pockets"]).cpu().numpy(), want)
+    # the turn histograms through the full river table
+    obs = deuce.isomorphisms("rive")
+    _, bucket = deuce.river_equity(obs)
+    table = deuce.Lookup("rive", obs, bucket)
+    turn = torch.tensor(g["turn"], dtype=torch.int64, device="cuda")
+    assert table.projections(turn, 101).cpu().numpy().astype(np.uint32).tolist() == g["turn_histograms"]
