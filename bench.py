@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1 << 20, help="trees per step per GPU (Solver::batch_size)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --batch trees per step on EVERY GPU; strong: --batch trees per step in total, "
+                         "split across the GPUs (north_star's strong-scaling figure)")
     ap.add_argument("--workload", default="leduc", choices=["leduc", "nlhe-synth"],
                     help="leduc: BASELINE configs[1] (default, the quoted metric); nlhe-synth: configs[3]'s synthetic "
                          "NLHE-scale infoset batches through the sparse profile (SURVEY.md §8d config 4)")
@@ -408,6 +411,8 @@ def main():
 
     g = Game(args.game)
     A = g.max_actions
+    if args.scaling == "strong":
+        args.batch = max(64, args.batch // world)  # per-GPU share of a fixed global batch
     solver = Solver(g, args.regret, args.weight, args.sampling, batch=args.batch, seed=args.seed, device=local_rank)
     solver.set_update_mode(args.update)
 
@@ -477,7 +482,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
