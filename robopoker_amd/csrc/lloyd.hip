@@ -40,7 +40,15 @@ struct Metric {
     uint32_t iters;
     float tol;
     unsigned long long* stats;  // [0] distances, [1] sinkhorn iterations, [2] exp evaluations of the softmin/cost loops
+    uint32_t stat_stripes;      // the counters are striped over this many 128-byte lines (STAT): every wavefront adds to
+                                // them once per solve, and adds to ONE address serialise at its L2 channel (~9 ns each)
 };
+#define STAT_STRIDE 16u  // u64 per stripe
+#define KM_STAT_STRIPES 256u
+__device__ __forceinline__ unsigned long long* STAT(const Metric& M, uint32_t k) {
+    return M.stats + (size_t)(blockIdx.x % M.stat_stripes) * STAT_STRIDE + k;
+}
+
 
 // one prepared centroid set: integer sums + the derived support / log-density tables
 struct CentroidSet {
@@ -317,8 +325,8 @@ __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint
         }
     }
     if (lane == 0) {
-        atomicAdd(&M.stats[1], (unsigned long long)t);
-        atomicAdd(&M.stats[2], (unsigned long long)(2 * t + 1) * m * n);
+        atomicAdd(STAT(M, 1), (unsigned long long)t);
+        atomicAdd(STAT(M, 2), (unsigned long long)(2 * t + 1) * m * n);
     }
     // cost(): x-major left fold of coupling * distance (sinkhorn.rs:206-217)
     float cost = 0.0f;
@@ -341,7 +349,7 @@ __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint
 __device__ __forceinline__ float wave_divergence(WaveLds& w, uint32_t m, uint32_t n, float selfA, float selfB,
                                                  const Metric& M) {
     const float xy = wave_sinkhorn_cost(w, m, n, M);
-    if (lane_id() == 0) atomicAdd(&M.stats[0], 1ull);
+    if (lane_id() == 0) atomicAdd(STAT(M, 0), 1ull);
     return rp_maxf(xy - 0.5f * selfA - 0.5f * selfB, 0.0f);
 }
 
@@ -497,8 +505,8 @@ __device__ __forceinline__ void wave_sinkhorn_costG(GroupLds<G>& w, uint32_t m, 
         exps += (unsigned long long)(2 * iters_done[h] + 1) * m * n[h];
     }
     if (lane == 0) {
-        atomicAdd(&M.stats[1], its);
-        atomicAdd(&M.stats[2], exps);
+        atomicAdd(STAT(M, 1), its);
+        atomicAdd(STAT(M, 2), exps);
     }
     // cost(): A-major left fold of coupling * distance (sinkhorn.rs:206-217), one solve per lane group
     float cost = 0.0f;
@@ -664,7 +672,7 @@ __device__ void wave_variation_all(const float* pd, const CentroidSet& cs, uint3
         }
         d[q] = s;
     }
-    if (lane == 0) atomicAdd(&M.stats[0], (unsigned long long)K);
+    if (lane == 0) atomicAdd(STAT(M, 0), (unsigned long long)K);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(64) void k_neighborG(Points P, CentroidSet cs, uint
         }
         __syncthreads();
     }
-    if (lane == 0) atomicAdd(&M.stats[0], (unsigned long long)G * K);
+    if (lane == 0) atomicAdd(STAT(M, 0), (unsigned long long)G * K);
     if (lane < G) {
         const uint64_t i = pick<G>(ip, lane);
         const uint32_t j = pick<G>(bj, lane);
@@ -804,7 +812,7 @@ __global__ __launch_bounds__(64) void k_kpp_updateG(Points P, CentroidSet cs, ui
     float xy[G];
     wave_sinkhorn_costG<G>(w, m, n, M, true, xy);
     const uint32_t lane = lane_id();
-    if (lane == 0) atomicAdd(&M.stats[0], (unsigned long long)G);
+    if (lane == 0) atomicAdd(STAT(M, 0), (unsigned long long)G);
     if (lane < G) {
         const uint64_t i = pick<G>(ip, lane);
         const float d = rp_maxf(pick<G>(xy, lane) - 0.5f * cs.self[k] - 0.5f * P.self[i], 0.0f);
@@ -829,7 +837,7 @@ __global__ __launch_bounds__(256) void k_pairwise_var(CentroidSet cs, uint32_t K
         d = s / (float)M.bins;
     }
     pairw[e] = d;
-    if (e == 0) atomicAdd(&M.stats[0], (unsigned long long)K * (K - 1));
+    if (e == 0) atomicAdd(STAT(M, 0), (unsigned long long)K * (K - 1));
 }
 
 // Elkan::pairwises (elkan.rs:80-93): both orders; one wave per ordered pair
@@ -850,7 +858,7 @@ __global__ __launch_bounds__(64) void k_pairwise(CentroidSet cs, uint32_t K, Met
                 s += rp_absf(cx - cy);
             }
             d = s / (float)M.bins;
-            if (lane_id() == 0) atomicAdd(&M.stats[0], 1ull);
+            if (lane_id() == 0) atomicAdd(STAT(M, 0), 1ull);
         }
     }
     if (lane_id() == 0) pairw[(size_t)a * K + b] = d;
@@ -1029,7 +1037,7 @@ __global__ __launch_bounds__(64) void k_refresh_pairs(Points P, CentroidSet cs, 
             B.u[i] = d;
             B.lower[(uint64_t)i * K + j] = d;
             B.stale[i] = 0;
-            atomicAdd(&M.stats[0], 1ull);
+            atomicAdd(STAT(M, 0), 1ull);
         }
     }
 }
@@ -1144,7 +1152,7 @@ __global__ __launch_bounds__(256) void k_neighbor_var(Points P, CentroidSet cs, 
             init.u[i] = best;
             init.stale[i] = 0;
         }
-        atomicAdd(&M.stats[0], (unsigned long long)K);
+        atomicAdd(STAT(M, 0), (unsigned long long)K);
     }
     if (init.lower)
         for (uint64_t e = tid; e < (uint64_t)np * K; e += 256) init.lower[i0 * K + e] = 0.0f;
@@ -1184,7 +1192,7 @@ __global__ __launch_bounds__(256) void k_elkan_step_var(Points P, CentroidSet cs
     __syncthreads();
     // (skipping a wave's 64 centroids when none of them can become a candidate was measured: candidates are spread
     // over all four waves, the test costs more than it saves)
-    if (tid == 0) atomicAdd(&M.stats[0], (unsigned long long)K * na);
+    if (tid == 0) atomicAdd(STAT(M, 0), (unsigned long long)K * na);
     for (uint32_t a = q; a < na; a += 4) {  // one wave per point, as k_elkan_step
         const uint64_t i = i0 + L.active[a];
         uint32_t j = B.j[i];
@@ -1343,7 +1351,7 @@ __global__ __launch_bounds__(64) void k_drift(CentroidSet nw, CentroidSet old, u
             s += rp_absf(cx - cy);
         }
         d = s / (float)M.bins;
-        if (lane_id() == 0) atomicAdd(&M.stats[0], 1ull);
+        if (lane_id() == 0) atomicAdd(STAT(M, 0), 1ull);
     }
     if (lane_id() == 0) drift[k] = d;
 }
@@ -1397,7 +1405,7 @@ __global__ __launch_bounds__(64) void k_point_dist(Points P, CentroidSet cs, uin
             s += rp_absf(cx - cy);
         }
         d = s / (float)M.bins;
-        if (lane_id() == 0) atomicAdd(&M.stats[0], 1ull);
+        if (lane_id() == 0) atomicAdd(STAT(M, 0), 1ull);
     }
     if (lane_id() == 0) out[i] = d;
 }
@@ -1420,14 +1428,14 @@ __device__ __forceinline__ float lane_variation(const Points& P, uint64_t i, con
 }
 __global__ __launch_bounds__(256) void k_kpp_update_var(Points P, CentroidSet cs, uint32_t k, uint32_t K, Metric M, float* pot) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) atomicAdd(&M.stats[0], (unsigned long long)P.N);
+    if (i == 0) atomicAdd(STAT(M, 0), (unsigned long long)P.N);
     if (i >= P.N) return;
     const float d = lane_variation(P, i, cs, K, k, M.bins);
     pot[i] = rp_minf(d * d, pot[i]);
 }
 __global__ __launch_bounds__(256) void k_point_dist_var(Points P, CentroidSet cs, uint32_t K, Metric M, const uint8_t* j, float* out) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) atomicAdd(&M.stats[0], (unsigned long long)P.N);
+    if (i == 0) atomicAdd(STAT(M, 0), (unsigned long long)P.N);
     if (i >= P.N) return;
     out[i] = lane_variation(P, i, cs, K, j[i], M.bins);
 }
@@ -1519,7 +1527,7 @@ __global__ __launch_bounds__(64) void k_kpp_update(Points P, CentroidSet cs, uin
             s += rp_absf(cx - cy);
         }
         d = s / (float)M.bins;
-        if (lane_id() == 0) atomicAdd(&M.stats[0], 1ull);
+        if (lane_id() == 0) atomicAdd(STAT(M, 0), 1ull);
     }
     if (lane_id() == 0) pot[i] = rp_minf(d * d, pot[i]);
 }
@@ -1789,9 +1797,9 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         KM_HIP(hipMemcpy(d_C, C.data(), C.size() * 4, hipMemcpyHostToDevice));
         KM_HIP(hipMemcpy(d_R, R.data(), R.size() * 4, hipMemcpyHostToDevice));
     }
-    KM_TRY(dev_alloc(h, &h->stats, 4));
-    KM_HIP(hipMemset(h->stats, 0, 32));
-    h->M = Metric{d_C, d_R, bins, h->hp.iterations, h->hp.tolerance, h->stats};
+    KM_TRY(dev_alloc(h, &h->stats, (size_t)KM_STAT_STRIPES * STAT_STRIDE));
+    KM_HIP(hipMemset(h->stats, 0, (size_t)KM_STAT_STRIPES * STAT_STRIDE * 8));
+    h->M = Metric{d_C, d_R, bins, h->hp.iterations, h->hp.tolerance, h->stats, KM_STAT_STRIPES};
     KM_TRY(alloc_centroid_set(h, &h->cs[0]));
     KM_TRY(alloc_centroid_set(h, &h->cs[1]));
     KM_TRY(dev_alloc(h, &h->B.j, N));
@@ -2291,12 +2299,22 @@ int rp_kmeans_rms(rp_kmeans* h, float* out) {
     return RP_OK;
 }
 
+static int read_stats(rp_kmeans* h, unsigned long long s[3]) {
+    std::vector<unsigned long long> all((size_t)KM_STAT_STRIPES * STAT_STRIDE);
+    HIP_TRY(hipMemcpyAsync(all.data(), h->stats, all.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    s[0] = s[1] = s[2] = 0;
+    for (uint32_t q = 0; q < KM_STAT_STRIPES; ++q)
+        for (uint32_t k = 0; k < 3; ++k) s[k] += all[(size_t)q * STAT_STRIDE + k];
+    return RP_OK;
+}
+
 int rp_kmeans_stats(rp_kmeans* h, uint64_t* distances, uint64_t* sinkhorn_iterations) {
     if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_stats: NULL handle");
     HIP_TRY(hipSetDevice(h->device));
-    unsigned long long s[2];
-    HIP_TRY(hipMemcpyAsync(s, h->stats, 16, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    unsigned long long s[3];
+    int rc = read_stats(h, s);
+    if (rc) return rc;
     if (distances) *distances = s[0];
     if (sinkhorn_iterations) *sinkhorn_iterations = s[1];
     return RP_OK;
@@ -2305,10 +2323,10 @@ int rp_kmeans_stats(rp_kmeans* h, uint64_t* distances, uint64_t* sinkhorn_iterat
 int rp_kmeans_exp_evals(rp_kmeans* h, uint64_t* evals) {
     if (!h || !evals) return rp::fail(RP_ERR_INVALID, "rp_kmeans_exp_evals: NULL argument");
     HIP_TRY(hipSetDevice(h->device));
-    unsigned long long v = 0;
-    HIP_TRY(hipMemcpyAsync(&v, h->stats + 2, 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    *evals = v;
+    unsigned long long s[3];
+    int rc = read_stats(h, s);
+    if (rc) return rc;
+    *evals = s[2];
     return RP_OK;
 }
 
@@ -2384,7 +2402,7 @@ int pair_common(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_
     HIP_TRY(hipMemcpy(dR, R.data(), R.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dmu, mu, hb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dnu, nu, hb, hipMemcpyHostToDevice));
-    Metric M{dC, dR, bins, hh.iterations, hh.tolerance, dstats};
+    Metric M{dC, dR, bins, hh.iterations, hh.tolerance, dstats, 1u};
     hipLaunchKernelGGL(k_pair_sinkhorn, dim3((unsigned)pairs), dim3(64), 0, 0, dmu, dnu, M, divergence, dout, (uint32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, dout, pairs * 4, hipMemcpyDeviceToHost));

@@ -113,7 +113,12 @@ __device__ __forceinline__ uint32_t lane_of() { return threadIdx.x & 63u; }
 
 // Metrics (metrics/mod.rs:21-80; solver.rs:273): nodes / infos, one atomic per WAVE — a million lanes adding to the
 // same two addresses would serialise in the L2 atomic unit
+// The counters are STRIPED: 16 384 waves adding to ONE address serialise at its L2 channel (~9 ns per atomic: 0.29 ms
+// of a 0.52 ms launch was spent there, found by ablation); stripe s owns its own 128-byte line, the host sums them.
+#define METRIC_STRIPES 256u
+#define METRIC_STRIDE 16u  // u64 per stripe (128 B)
 __device__ __forceinline__ void count_metrics(const StepParams& p, uint32_t nn, uint32_t ndec, uint32_t err) {
+    unsigned long long* c = p.counters + (size_t)(blockIdx.x % METRIC_STRIPES) * METRIC_STRIDE;
     if (__ballot(1) == ~0ull) {
         uint32_t a = nn, b = ndec;
         for (int d = 32; d > 0; d >>= 1) {
@@ -121,14 +126,14 @@ __device__ __forceinline__ void count_metrics(const StepParams& p, uint32_t nn, 
             b += __shfl_xor(b, d, 64);
         }
         if (lane_of() == 0) {
-            atomicAdd(&p.counters[0], (unsigned long long)a);
-            atomicAdd(&p.counters[1], (unsigned long long)b);
+            atomicAdd(&c[0], (unsigned long long)a);
+            atomicAdd(&c[1], (unsigned long long)b);
         }
     } else {  // the ragged last wave
-        atomicAdd(&p.counters[0], (unsigned long long)nn);
-        atomicAdd(&p.counters[1], (unsigned long long)ndec);
+        atomicAdd(&c[0], (unsigned long long)nn);
+        atomicAdd(&c[1], (unsigned long long)ndec);
     }
-    if (err) atomicOr(&p.counters[2], (unsigned long long)err);
+    if (err) atomicOr(&c[2], (unsigned long long)err);
 }
 
 #define META_PARENT(m) ((m)&0xffu)
@@ -459,6 +464,22 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
         if (pt != PT_OPP) f.y = 1.0f;
         return f;
     };
+    // the same lookup issued AHEAD of its use, for metas that may lie past the subtree (stale LDS): a bounds-checked
+    // buffer load (out of range -> 0) of the raw (sigma, q) pair; f_fix applies the parent-type rule once it is used
+    const __amdgpu_buffer_rsrc_t sq_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(it.sq), 0, (int)(cells * 8u), 0x00020000);
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    auto f_issue = [&](uint32_t mn, uint32_t mp) -> float2 {
+        const uint32_t e = LM_INFO(mp) * g.A + LM_EDGE(mn);
+        if (TABLDS) return make_float2(tab[e < cells ? e : 0u], tab[cells + (e < cells ? e : 0u)]);
+        const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(sq_rsrc, (int)(e * 8u), 0, 0);
+        return make_float2(rp_u2f(raw.x), rp_u2f(raw.y));
+    };
+    auto f_fix = [&](uint32_t mn, float2 f) -> float2 {
+        const uint32_t pt = LM_PTYPE(mn);
+        if (pt != PT_WALKER && pt != PT_OPP) return make_float2(1.0f, 1.0f);
+        if (pt != PT_OPP) f.y = 1.0f;
+        return f;
+    };
 
     // ---- TreeBuilder::build (builder.rs:74-87,141-161): pop-last DFS -----------------------------
     // A node arrives as its RECORD (DevGame::kids): the records of all sampled children are requested together
@@ -517,6 +538,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
 #undef STK
 
     // ---- Tree::partition + CfrFlow::dfs per walker infoset (tree.rs:88-98, flow.rs:64-87) --------
+    const bool fuse = g.A <= 2;  // every node has at most two children
     uint32_t ndec = 0;
     if (n_int > maxi || n_int > 32u) err |= ERR_NODE_CAPACITY;
     if (!err) {
@@ -542,21 +564,47 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                 todo &= ~(1ull << j);
                 // top-down over the (contiguous) subtree of j: reach products from j's child (flow.rs:195-212),
                 // which start at 1 there; internal nodes also start their child-value sum at 0
+                // With at most two children per node (fuse) a sum of child values does not depend on the order of its
+                // additions (0 + x = x, x + y = y + x exactly), so a leaf hands its value to its parent right here and
+                // the bottom-up sweep only moves the internal nodes' sums: one factor lookup per node instead of two.
+                // The sweep is a three-stage software pipeline: while node n is processed, the factor pair of node n + 1,
+                // the parent meta of node n + 2 and the meta of node n + 3 are in flight (a lone wave per SIMD pays every
+                // LDS / L1 round trip in full otherwise).  Stages may run past the subtree: they only read.
                 uint32_t end = j;
-                uint32_t mn_next = L(nm, j + 1);  // one node ahead of the sweep (the slot past the tree is readable LDS)
+                uint32_t kids = 0;
+                uint32_t mnA = L(nm, j + 1), mnB = L(nm, j + 2), mnC = L(nm, j + 3);
+                uint32_t mpA = L(nm, LM_PARENT(mnA)), mpB = L(nm, LM_PARENT(mnB));
+                float2 fA = f_issue(mnA, mpA);
                 for (uint32_t n = j + 1; n < nn; ++n) {
-                    const uint32_t mn = mn_next;
-                    mn_next = L(nm, n + 1);
+                    const uint32_t mn = mnA, mp = mpA;
+                    const float2 fraw = fA;
+                    fA = f_issue(mnB, mpB);
+                    mpA = mpB;
+                    mpB = L(nm, LM_PARENT(mnC));
+                    mnA = mnB;
+                    mnB = mnC;
+                    mnC = L(nm, n + 3);
                     const uint32_t par = LM_PARENT(mn);
                     if (par < j) break;
                     end = n;
-                    if (LM_LEAF(mn)) continue;
+                    const bool leaf = LM_LEAF(mn);
+                    if (leaf && !fuse) continue;
                     float rel = 1.0f, smp = 1.0f;
                     if (par != j) {
-                        const uint32_t mp = L(nm, par), ps = LM_ISLOT(mp);
-                        const float2 f = f_of(mn, mp);
+                        const uint32_t ps = LM_ISLOT(mp);
+                        const float2 f = f_fix(mn, fraw);
                         rel = L(xr, ps) * f.x;
                         smp = L(xs, ps) * f.y;
+                    }
+                    if (leaf) {
+                        const float v = rel / smp * L(nv, n);
+                        if (par == j) {
+                            tv_set(LM_EDGE(mn), v);
+                            kids |= 1u << LM_EDGE(mn);
+                        } else {
+                            L(nv, par) = L(nv, par) + v;
+                        }
+                        continue;
                     }
                     const uint32_t ns = LM_ISLOT(mn);
                     L(xr, ns) = rel;
@@ -564,7 +612,6 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     L(nv, n) = 0.0f;
                 }
                 // bottom-up: descending node index adds children in choices() order (node.rs:103-107)
-                uint32_t kids = 0;
                 uint32_t mn_prev = L(nm, end);
                 float v_prev = L(nv, end);
                 for (uint32_t n = end; n > j; --n) {
@@ -573,6 +620,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
                     float v = v_prev;
                     mn_prev = L(nm, n - 1);  // one node ahead; its value is patched below if this node is its child
                     v_prev = L(nv, n - 1);
+                    if (fuse && LM_LEAF(mn)) continue;  // already with its parent
                     if (LM_LEAF(mn)) {
                         float rel = 1.0f, smp = 1.0f;
                         if (par != j) {
@@ -1788,10 +1836,24 @@ int enqueue_step(rp_mccfr* h) {
     return RP_OK;
 }
 
+// nodes, infos, error flags: the sums (resp. the OR) over the stripes
+int read_counters(rp_mccfr* h, unsigned long long c[3]) {
+    std::vector<unsigned long long> all((size_t)METRIC_STRIPES * METRIC_STRIDE);
+    HIP_TRY(hipMemcpyAsync(all.data(), h->d_counters, all.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    c[0] = c[1] = c[2] = 0;
+    for (uint32_t s = 0; s < METRIC_STRIPES; ++s) {
+        c[0] += all[(size_t)s * METRIC_STRIDE];
+        c[1] += all[(size_t)s * METRIC_STRIDE + 1];
+        c[2] |= all[(size_t)s * METRIC_STRIDE + 2];
+    }
+    return RP_OK;
+}
+
 int check_device_errors(rp_mccfr* h) {
     unsigned long long c[3];
-    HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    int rc = read_counters(h, c);
+    if (rc) return rc;
     if (c[2]) return rp::fail(RP_ERR_CAPACITY, "mccfr kernel capacity exceeded (flags %llu): nodes/stack/decisions", c[2]);
     return RP_OK;
 }
@@ -1918,8 +1980,8 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
     CREATE_TRY(hipMemset(h->t.weight, 0, cells * 4));
     CREATE_TRY(hipMemset(h->t.payoff, 0, cells * 4));
     CREATE_TRY(hipMemset(h->t.visits, 0, cells * 4));
-    CREATE_TRY(hipMalloc(&h->d_counters, 3 * sizeof(unsigned long long)));
-    CREATE_TRY(hipMemset(h->d_counters, 0, 3 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(&h->d_counters, (size_t)METRIC_STRIPES * METRIC_STRIDE * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemset(h->d_counters, 0, (size_t)METRIC_STRIPES * METRIC_STRIDE * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(&h->d_summary, summary_bytes_of(h)));
     CREATE_TRY(hipMalloc(&h->d_itab, (5 * cells + 2 * (size_t)game->n_infos + 2) * 4));
     {
@@ -2095,8 +2157,7 @@ int rp_mccfr_counters(rp_mccfr* h, uint64_t* nodes, uint64_t* infos) {
     int rc = set_device(h);
     if (rc) return rc;
     unsigned long long c[3];
-    HIP_TRY(hipMemcpyAsync(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if ((rc = read_counters(h, c))) return rc;
     if (nodes) *nodes = c[0];
     if (infos) *infos = c[1];
     return RP_OK;
