@@ -1,0 +1,379 @@
+/* CPU oracle for the no-limit hold'em rules engine (first step: the oracle).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (robopoker_amd/, include/) includes, links or calls this file.
+ * There is no device-side NLHE engine yet: this restatement and its known-answer tests (tests/test_oracle_nlhe.py,
+ * the data of the reference's own unit tests in crates/kicker/src/{game,showdown}.rs) are what the engine will be
+ * built against.
+ *
+ * A plain-C restatement of crates/kicker/src/game.rs (GameN<P>: the betting state machine, legal actions, street
+ * advance, hand rotation), seat.rs, action.rs, turn.rs, pnl.rs / settlement.rs / showdown.rs (side-pot settlement),
+ * written from their behaviour; every function cites the reference file:line it follows.  Chips are i16 as in the
+ * reference (pokerkit/src/lib.rs:28); blinds 1 / 2, default stack 200 (lib.rs:62-66).  Hole cards and dealt boards
+ * are INPUTS here (the reference draws them from its thread RNG).
+ */
+#include <stdint.h>
+#include <string.h>
+
+#define ORA_API __attribute__((visibility("default")))
+#define MAXP 10
+#define S_BLIND 1
+#define B_BLIND 2
+
+uint32_t ora_strength_key(uint64_t hand); /* oracle/rp_oracle_deuce.c */
+
+enum { BETTING = 0, SHOVING = 1, FOLDING = 2 };                                      /* seat.rs:79-84 */
+enum { A_DRAW = 0, A_FOLD, A_CALL, A_CHECK, A_RAISE, A_SHOVE, A_BLIND };             /* action.rs:8-16 */
+enum { T_TERMINAL = -2, T_CHANCE = -1 };                                             /* turn.rs:2-6; >= 0: Choice(i) */
+
+typedef struct {
+    int32_t state;
+    int16_t stack, stake, spent;
+    uint64_t cards;
+} ora_seat;
+typedef struct {
+    int32_t n;      /* P */
+    int32_t dealer; /* game.rs:30-36 */
+    int32_t ticker;
+    int16_t pot;
+    uint64_t board;
+    ora_seat seats[MAXP];
+} ora_game;
+typedef struct {
+    int32_t kind;
+    int16_t chips;
+    uint64_t cards;
+} ora_action;
+
+static int popc(uint64_t x) { return __builtin_popcountll(x); }
+static int street_of(const ora_game* g) { /* Board::street: 0, 3, 4, 5 cards */
+    switch (popc(g->board)) {
+        case 0: return 0;
+        case 3: return 1;
+        case 4: return 2;
+        default: return 3;
+    }
+}
+static int actor_idx(const ora_game* g) { return (g->dealer + g->ticker) % g->n; } /* game.rs:656-658 */
+static const ora_seat* actor(const ora_game* g) { return &g->seats[actor_idx(g)]; }
+static int16_t max_stake(const ora_game* g) { /* game.rs:693-695 */
+    int16_t m = g->seats[0].stake;
+    for (int i = 1; i < g->n; ++i)
+        if (g->seats[i].stake > m) m = g->seats[i].stake;
+    return m;
+}
+
+/* ---- predicates (game.rs:463-532) ---------------------------------------------------------------------------- */
+static int everyone_touched(const ora_game* g) { /* :489-492 */
+    const int offset = g->n == 2 ? 1 : 2;
+    return g->ticker > g->n + (street_of(g) == 0 ? offset : 0);
+}
+static int everyone_matched(const ora_game* g) { /* :494-500 */
+    const int16_t stake = max_stake(g);
+    for (int i = 0; i < g->n; ++i)
+        if (g->seats[i].state == BETTING && g->seats[i].stake != stake) return 0;
+    return 1;
+}
+static int everyone_shoving(const ora_game* g) { /* :502-507 */
+    for (int i = 0; i < g->n; ++i)
+        if (g->seats[i].state != FOLDING && g->seats[i].state != SHOVING) return 0;
+    return 1;
+}
+static int everyone_folding(const ora_game* g) { /* :509-511 */
+    int alive = 0;
+    for (int i = 0; i < g->n; ++i) alive += g->seats[i].state != FOLDING;
+    return alive == 1;
+}
+static int everyone_calling(const ora_game* g) { return everyone_touched(g) && everyone_matched(g); }
+static int everyone_alright(const ora_game* g) { return everyone_calling(g) || everyone_folding(g) || everyone_shoving(g); }
+static int must_stop(const ora_game* g) { return street_of(g) == 3 ? everyone_alright(g) : everyone_folding(g); } /* :465-471 */
+static int must_deal(const ora_game* g) { return street_of(g) != 3 && everyone_alright(g); }                      /* :473-475 */
+static int must_post(const ora_game* g) { return street_of(g) == 0 && g->pot < S_BLIND + B_BLIND; }               /* :477-479 */
+static int turn_of(const ora_game* g) { /* game.rs:166-174 */
+    if (must_stop(g)) return T_TERMINAL;
+    if (must_deal(g)) return T_CHANCE;
+    return actor_idx(g);
+}
+static int16_t to_call(const ora_game* g) { return (int16_t)(max_stake(g) - actor(g)->stake); } /* :537-539 */
+static int16_t to_post(const ora_game* g) {                                                     /* :541-548 */
+    const int16_t want = g->pot < S_BLIND ? S_BLIND : B_BLIND;
+    return want < actor(g)->stack ? want : actor(g)->stack;
+}
+static int16_t to_shove(const ora_game* g) { return actor(g)->stack; } /* :550-552 */
+static int16_t to_raise(const ora_game* g) {                           /* :556-576 */
+    int16_t most = 0, next = 0;
+    for (int i = 0; i < g->n; ++i) {
+        if (g->seats[i].state == FOLDING) continue;
+        const int16_t s = g->seats[i].stake;
+        if (s > most) next = most, most = s;
+        else if (s > next) next = s;
+    }
+    const int16_t relative = (int16_t)(most - actor(g)->stake), marginal = (int16_t)(most - next);
+    return (int16_t)(relative + (marginal > B_BLIND ? marginal : B_BLIND));
+}
+static int is_choice(const ora_game* g) { return turn_of(g) >= 0; }
+static int may_fold(const ora_game* g) { return is_choice(g) && to_call(g) > 0; }                             /* :513-515 */
+static int may_call(const ora_game* g) { return is_choice(g) && may_fold(g) && to_call(g) < to_shove(g); }    /* :517-519 */
+static int may_check(const ora_game* g) { return is_choice(g) && max_stake(g) == actor(g)->stake; }           /* :521-523 */
+static int may_raise(const ora_game* g) { return is_choice(g) && to_raise(g) < to_shove(g); }                 /* :525-527 */
+static int may_shove(const ora_game* g) { return is_choice(g) && to_shove(g) > 0; }                           /* :529-531 */
+
+static uint64_t deck_of(const ora_game* g) { /* game.rs:644-650 */
+    uint64_t removed = g->board;
+    for (int i = 0; i < g->n; ++i) removed |= g->seats[i].cards;
+    return ~removed & 0x000FFFFFFFFFFFFFull;
+}
+static int n_revealed_next(int street) { return street == 0 ? 3 : 1; } /* deuce/src/street.rs:75-82 */
+
+/* ---- legal / is_allowed (game.rs:253-319) ------------------------------------------------------------------- */
+/* Options in the reference's order: raise, shove, call, fold, check; a chance node has no enumerable action here (the
+ * reference returns one random draw), a node that must post returns the blind. */
+ORA_API int ora_nlhe_legal(const ora_game* g, ora_action* out) {
+    int n = 0;
+    if (must_stop(g)) return 0;
+    if (must_deal(g)) return 0;
+    if (must_post(g)) {
+        out[n++] = (ora_action){A_BLIND, to_post(g), 0};
+        return n;
+    }
+    if (may_raise(g)) out[n++] = (ora_action){A_RAISE, to_raise(g), 0};
+    if (may_shove(g)) out[n++] = (ora_action){A_SHOVE, to_shove(g), 0};
+    if (may_call(g)) out[n++] = (ora_action){A_CALL, to_call(g), 0};
+    if (may_fold(g)) out[n++] = (ora_action){A_FOLD, 0, 0};
+    if (may_check(g)) out[n++] = (ora_action){A_CHECK, 0, 0};
+    return n;
+}
+ORA_API int ora_nlhe_is_allowed(const ora_game* g, const ora_action* a) {
+    if (a->kind == A_RAISE)
+        return may_raise(g) && !must_stop(g) && !must_deal(g) && a->chips >= to_raise(g) && a->chips < to_shove(g);
+    if (a->kind == A_DRAW)
+        return must_deal(g) && !must_stop(g) && (a->cards & ~deck_of(g)) == 0 && popc(a->cards) == n_revealed_next(street_of(g));
+    ora_action opts[8];
+    const int n = ora_nlhe_legal(g, opts);
+    for (int i = 0; i < n; ++i)
+        if (opts[i].kind == a->kind && (a->kind == A_FOLD || a->kind == A_CHECK || opts[i].chips == a->chips)) return 1;
+    return 0;
+}
+
+/* ---- act (game.rs:387-461) ---------------------------------------------------------------------------------- */
+static void next_player(ora_game* g) { /* :448-460 */
+    if (everyone_alright(g)) return;
+    for (;;) {
+        g->ticker += 1;
+        if (actor(g)->state == BETTING) break;
+    }
+}
+static void force_act(ora_game* g, const ora_action* a) { /* :395-414 */
+    ora_seat* s = &g->seats[actor_idx(g)];
+    switch (a->kind) {
+        case A_CHECK: next_player(g); break;
+        case A_FOLD:
+            s->state = FOLDING;
+            next_player(g);
+            break;
+        case A_CALL: case A_BLIND: case A_RAISE: case A_SHOVE: /* bet (:416-423), allin (:425-427) */
+            g->pot = (int16_t)(g->pot + a->chips);
+            s->stack = (int16_t)(s->stack - a->chips);
+            s->stake = (int16_t)(s->stake + a->chips);
+            s->spent = (int16_t)(s->spent + a->chips);
+            if (s->stack == 0) s->state = SHOVING;
+            next_player(g);
+            break;
+        case A_DRAW: /* show (:433-436), next_player, next_street (:442-446) */
+            g->ticker = 0;
+            g->board |= a->cards;
+            next_player(g);
+            for (int i = 0; i < g->n; ++i) g->seats[i].stake = 0;
+            break;
+    }
+}
+ORA_API int ora_nlhe_apply(ora_game* g, const ora_action* a) { /* try_apply (:241-250): 0 ok, 1 illegal */
+    if (!ora_nlhe_is_allowed(g, a)) return 1;
+    force_act(g, a);
+    return 0;
+}
+ORA_API void ora_nlhe_force_apply(ora_game* g, const ora_action* a) { force_act(g, a); }
+
+/* ---- construction (game.rs:59-85) --------------------------------------------------------------------------- */
+ORA_API void ora_nlhe_preblind(ora_game* g, int n, int dealer, const int16_t* stacks, const uint64_t* holes) {
+    memset(g, 0, sizeof *g);
+    g->n = n;
+    g->dealer = dealer;
+    g->ticker = n != 2;
+    for (int i = 0; i < n; ++i) g->seats[i] = (ora_seat){BETTING, stacks[i], 0, 0, holes[i]};
+}
+static void post(ora_game* g) {
+    const ora_action b = {A_BLIND, to_post(g), 0};
+    force_act(g, &b);
+}
+ORA_API void ora_nlhe_from_start(ora_game* g, int n, int dealer, const int16_t* stacks, const uint64_t* holes) {
+    ora_nlhe_preblind(g, n, dealer, stacks, holes);
+    post(g);
+    post(g);
+}
+
+/* ---- queries -------------------------------------------------------------------------------------------------- */
+ORA_API int ora_nlhe_turn(const ora_game* g) { return turn_of(g); }
+ORA_API int ora_nlhe_street(const ora_game* g) { return street_of(g); }
+/* which: 0 must_stop 1 must_deal 2 must_post 3 alright 4 calling 5 touched 6 matched 7 shoving 8 folding
+ *        9 may_fold 10 may_call 11 may_check 12 may_raise 13 may_shove 14 is_showdown (game.rs:618-620) */
+ORA_API int ora_nlhe_predicate(const ora_game* g, int which) {
+    switch (which) {
+        case 0: return must_stop(g);
+        case 1: return must_deal(g);
+        case 2: return must_post(g);
+        case 3: return everyone_alright(g);
+        case 4: return everyone_calling(g);
+        case 5: return everyone_touched(g);
+        case 6: return everyone_matched(g);
+        case 7: return everyone_shoving(g);
+        case 8: return everyone_folding(g);
+        case 9: return may_fold(g);
+        case 10: return may_call(g);
+        case 11: return may_check(g);
+        case 12: return may_raise(g);
+        case 13: return may_shove(g);
+        case 14: {
+            int active = 0;
+            for (int i = 0; i < g->n; ++i) active += g->seats[i].state != FOLDING;
+            return active > 1;
+        }
+    }
+    return -1;
+}
+/* which: 0 to_call 1 to_post 2 to_shove 3 to_raise 4 total (:675-677) 5 effective (:682-684) */
+ORA_API int ora_nlhe_amount(const ora_game* g, int which) {
+    switch (which) {
+        case 0: return to_call(g);
+        case 1: return to_post(g);
+        case 2: return to_shove(g);
+        case 3: return to_raise(g);
+        case 4: {
+            int t = g->pot;
+            for (int i = 0; i < g->n; ++i) t += g->seats[i].stack;
+            return t;
+        }
+        case 5: {
+            int e = g->seats[0].stack;
+            for (int i = 1; i < g->n; ++i)
+                if (g->seats[i].stack < e) e = g->seats[i].stack;
+            return e;
+        }
+    }
+    return -1;
+}
+
+/* ---- showdown (showdown.rs:36-109, settlement.rs, pnl.rs) ----------------------------------------------------- */
+typedef struct {
+    int32_t reward, risked, status;
+    uint32_t strength;
+} payout_t;
+/* Showdown::settle over (risked, status, strength) triples; reward[] receives each seat's winnings */
+ORA_API void ora_showdown_settle(int n, const int16_t* risked, const int32_t* status, const uint32_t* strength, int32_t* reward) {
+    payout_t p[MAXP];
+    for (int i = 0; i < n; ++i) p[i] = (payout_t){0, risked[i], status[i], strength[i]};
+    uint32_t best = 0xffffffffu; /* Ranking::MAX */
+    int32_t distributing = 0, distributed = 0;
+    for (;;) {
+        /* strongest (:54-62): the best hand below `best` among the players still in */
+        int found = 0;
+        uint32_t top = 0;
+        for (int i = 0; i < n; ++i)
+            if (p[i].strength < best && p[i].status != FOLDING && (!found || p[i].strength > top)) found = 1, top = p[i].strength;
+        if (!found) break;
+        best = top;
+        for (;;) {
+            /* remaining (:64-73) */
+            distributed = distributing;
+            int any = 0;
+            int32_t amount = 0;
+            for (int i = 0; i < n; ++i)
+                if (p[i].strength == best && p[i].risked > distributed && p[i].status != FOLDING && (!any || p[i].risked < amount))
+                    any = 1, amount = p[i].risked;
+            if (!any) break;
+            distributing = amount;
+            /* winnings (:75-82) + distribute (:84-102) */
+            int32_t chips = 0;
+            for (int i = 0; i < n; ++i) {
+                const int32_t s = p[i].risked < distributing ? p[i].risked : distributing;
+                chips += s - distributed > 0 ? s - distributed : 0;
+            }
+            int winners[MAXP], nw = 0;
+            for (int i = 0; i < n; ++i)
+                if (p[i].status != FOLDING && p[i].strength == best && p[i].risked > distributed) winners[nw++] = i;
+            const int32_t share = chips / nw, bonus = chips % nw;
+            for (int w = 0; w < nw; ++w) p[winners[w]].reward += share;
+            for (int w = 0; w < nw && w < bonus; ++w) p[winners[w]].reward += 1;
+            /* is_complete (:104-108) */
+            int32_t staked = 0, paid = 0;
+            for (int i = 0; i < n; ++i) staked += p[i].risked, paid += p[i].reward;
+            if (staked == paid) goto done;
+        }
+    }
+done:
+    for (int i = 0; i < n; ++i) reward[i] = p[i].reward;
+}
+/* GameN::settlements (game.rs:613-634): reward per seat at a terminal state; returns 1 if the state is not terminal */
+ORA_API int ora_nlhe_settlements(const ora_game* g, int32_t* reward) {
+    if (!must_stop(g)) return 1;
+    int16_t risked[MAXP];
+    int32_t status[MAXP];
+    uint32_t strength[MAXP];
+    for (int i = 0; i < g->n; ++i) {
+        risked[i] = g->seats[i].spent;
+        status[i] = g->seats[i].state;
+        strength[i] = ora_strength_key(g->seats[i].cards | g->board);
+    }
+    ora_showdown_settle(g->n, risked, status, strength, reward);
+    return 0;
+}
+/* GameN::continuation (game.rs:327-342 with give_chips / wipe_* / move_button :344-381): the next hand, or 0 when a
+ * player could no longer post the big blind; new hole cards are inputs */
+ORA_API int ora_nlhe_continuation(ora_game* g, const uint64_t* holes) {
+    int32_t reward[MAXP];
+    if (ora_nlhe_settlements(g, reward)) return 0;
+    for (int i = 0; i < g->n; ++i)
+        if (g->seats[i].stack + reward[i] < B_BLIND) return 0;
+    for (int i = 0; i < g->n; ++i) {
+        g->seats[i].stack = (int16_t)(g->seats[i].stack + reward[i]);
+        g->seats[i].state = BETTING;
+        g->seats[i].cards = holes[i];
+        g->seats[i].stake = 0;
+        g->seats[i].spent = 0;
+    }
+    g->pot = 0;
+    g->board = 0;
+    g->dealer = (g->dealer + 1) % g->n;
+    g->ticker = g->n != 2;
+    post(g);
+    post(g);
+    return 1;
+}
+
+/* GameN::snap (game.rs:835-854): the nearest legal action */
+static ora_action passive(const ora_game* g) { return (ora_action){may_check(g) ? A_CHECK : A_FOLD, 0, 0}; }
+ORA_API ora_action ora_nlhe_snap(const ora_game* g, ora_action a) {
+    const ora_action shove = {A_SHOVE, to_shove(g), 0}, calls = {A_CALL, to_call(g), 0}, raise = {A_RAISE, to_raise(g), 0};
+    switch (a.kind) {
+        case A_RAISE:
+            if (a.chips >= to_shove(g)) return ora_nlhe_snap(g, shove);
+            if (!may_raise(g)) return ora_nlhe_snap(g, shove);
+            if (a.chips < to_raise(g)) return raise;
+            return a;
+        case A_SHOVE:
+            if (may_shove(g)) return shove;
+            if (may_call(g)) return calls;
+            return passive(g);
+        case A_CALL:
+            if (may_call(g)) return calls;
+            if (may_shove(g)) return shove;
+            return passive(g);
+        case A_CHECK:
+            if (may_check(g)) return a;
+            if (may_call(g)) return calls;
+            return (ora_action){A_FOLD, 0, 0};
+        case A_FOLD:
+            if (may_fold(g)) return a;
+            return (ora_action){A_CHECK, 0, 0};
+        default: return a;
+    }
+}
