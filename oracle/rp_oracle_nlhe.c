@@ -377,3 +377,147 @@ ORA_API ora_action ora_nlhe_snap(const ora_game* g, ora_action a) {
         default: return a;
     }
 }
+
+/* ================================================================================================================
+ * The action abstraction (crates/kicker/src/edge.rs, size.rs, odds.rs, path.rs; grids in pokerkit/src/lib.rs:81-151).
+ * An Edge travels as its u8 code (edge.rs:101-120): 1 Draw, 2 Fold, 3 Check, 4 Call, 5 Shove, 6..9 Open(OPENS[c-6] big
+ * blinds), 10..19 Raise(RAISES[c-10] of the pot).  Pluribus regime (pokerkit/src/regime.rs:20-24, the default).
+ * ================================================================================================================ */
+enum { E_DRAW = 1, E_FOLD = 2, E_CHECK = 3, E_CALL = 4, E_SHOVE = 5, E_OPEN0 = 6, E_RAISE0 = 10 };
+#define MAX_RAISE_REPEATS 3 /* lib.rs:68 */
+#define MAX_PATH_EDGES 12   /* lib.rs:73 */
+static const int16_t OPENS[4] = {2, 3, 4, 5};                                                                /* lib.rs:81 */
+static const int16_t RAISES[10][2] = {{1, 4}, {1, 3}, {1, 2}, {2, 3}, {3, 4}, {1, 1}, {5, 4}, {3, 2}, {2, 1}, {3, 1}}; /* :86-97 */
+static const int8_t PLURIBUS[12][6] = { /* lib.rs:138-151: indices into RAISES, -1 terminated; row = street*3 + min(depth, 2) */
+    {-1}, {5, 8, -1}, {5, -1}, {0, 2, 4, 5, 8, -1}, {2, 5, -1}, {5, -1}, {1, 2, 5, 8, -1}, {5, 8, -1}, {5, -1}, {1, 2, 5, 8, -1},
+    {5, 8, -1}, {5, -1}};
+
+/* Edge::raises = Size::raises (edge.rs:77-85, size.rs:113-138): the raise edges offered at (street, depth) */
+ORA_API int ora_edge_raises(int street, int depth, uint8_t* out) {
+    int n = 0;
+    if (depth > MAX_RAISE_REPEATS) return 0;
+    if (street == 0 && depth == 0) {
+        for (int i = 0; i < 4; ++i) out[n++] = (uint8_t)(E_OPEN0 + i);
+        return n;
+    }
+    const int8_t* row = PLURIBUS[street * 3 + (depth > 2 ? 2 : depth)];
+    for (int i = 0; row[i] >= 0; ++i) out[n++] = (uint8_t)(E_RAISE0 + row[i]);
+    return n;
+}
+/* Edge::into_chips (edge.rs:86-92): Open(n) -> n big blinds; Raise(odds) -> (pot as f32 * (n as f32 / d as f32)) as i16 */
+ORA_API int16_t ora_edge_into_chips(uint8_t edge, int16_t pot) {
+    if (edge >= E_OPEN0 && edge < E_RAISE0) return (int16_t)(OPENS[edge - E_OPEN0] * B_BLIND);
+    if (edge >= E_RAISE0 && edge < E_RAISE0 + 10) {
+        const float odds = (float)RAISES[edge - E_RAISE0][0] / (float)RAISES[edge - E_RAISE0][1];
+        return (int16_t)((float)pot * odds);
+    }
+    return 0;
+}
+/* From<Edge> for u64 / From<u64> for Edge (edge.rs:122-160): the `edge BIGINT` column of the blueprint table */
+ORA_API uint64_t ora_edge_to_u64(uint8_t e) {
+    switch (e) {
+        case E_DRAW: return 0;
+        case E_FOLD: return 1;
+        case E_CHECK: return 2;
+        case E_CALL: return 3;
+        case E_SHOVE: return 5;
+    }
+    if (e >= E_OPEN0 && e < E_RAISE0) return 6ull | ((uint64_t)OPENS[e - E_OPEN0] << 3);
+    return 4ull | ((uint64_t)RAISES[e - E_RAISE0][0] << 3) | ((uint64_t)RAISES[e - E_RAISE0][1] << 11);
+}
+ORA_API uint8_t ora_edge_from_u64(uint64_t v) { /* 0 = not an edge of the current grids */
+    const uint32_t n = (uint32_t)(v >> 3) & 0xff, d = (uint32_t)(v >> 11) & 0xff;
+    switch (v & 7) {
+        case 0: return E_DRAW;
+        case 1: return E_FOLD;
+        case 2: return E_CHECK;
+        case 3: return E_CALL;
+        case 5: return E_SHOVE;
+        case 6:
+            for (int i = 0; i < 4; ++i)
+                if (OPENS[i] == (int16_t)n) return (uint8_t)(E_OPEN0 + i);
+            return 0;
+        case 4:
+            if (v & (1ull << 19)) { /* the old big-blind encoding (edge.rs:131-134) */
+                for (int i = 0; i < 4; ++i)
+                    if (OPENS[i] == (int16_t)n) return (uint8_t)(E_OPEN0 + i);
+                return 0;
+            }
+            for (int i = 0; i < 10; ++i)
+                if (RAISES[i][0] == (int16_t)n && RAISES[i][1] == (int16_t)d) return (uint8_t)(E_RAISE0 + i);
+            return 0;
+    }
+    return 0;
+}
+/* Path: up to 12 edges, 5 bits each, first edge in the low bits (path.rs:146-175) */
+ORA_API uint64_t ora_path_pack(const uint8_t* edges, int n) {
+    uint64_t p = 0;
+    for (int i = 0; i < n && i < MAX_PATH_EDGES; ++i) p |= (uint64_t)edges[i] << (5 * i);
+    return p;
+}
+ORA_API int ora_path_unpack(uint64_t p, uint8_t* edges) { /* Iterator for Path (path.rs:128-139) */
+    int n = 0;
+    while (p != 0 && (p & 0x1f) != 0) {
+        edges[n++] = (uint8_t)(p & 0x1f);
+        p >>= 5;
+    }
+    return n;
+}
+ORA_API int ora_path_length(uint64_t p) { return (68 - (p ? __builtin_clzll(p) : 64)) / 5; } /* path.rs:9-11 */
+/* Path::aggression (path.rs:12-18): raises and shoves since the last chance edge */
+ORA_API int ora_path_aggression(uint64_t p) {
+    uint8_t e[MAX_PATH_EDGES + 1];
+    const int n = ora_path_unpack(p, e);
+    int a = 0;
+    for (int i = n - 1; i >= 0 && e[i] != E_DRAW; --i) a += e[i] == E_SHOVE || e[i] >= E_OPEN0;
+    return a;
+}
+/* GameN::choices (game.rs:724-739): legal() with the raise unfolded into the grid of (street, depth), as a Path */
+ORA_API uint64_t ora_nlhe_choices(const ora_game* g, int depth) {
+    ora_action opts[8];
+    uint8_t edges[32];
+    int n = 0;
+    const int k = ora_nlhe_legal(g, opts);
+    for (int i = 0; i < k; ++i) {
+        switch (opts[i].kind) {
+            case A_RAISE: n += ora_edge_raises(street_of(g), depth, edges + n); break;
+            case A_FOLD: edges[n++] = E_FOLD; break;
+            case A_CHECK: edges[n++] = E_CHECK; break;
+            case A_CALL: edges[n++] = E_CALL; break;
+            case A_SHOVE: edges[n++] = E_SHOVE; break;
+            default: break; /* blinds are not in any MCCFR tree (edge.rs:66) */
+        }
+    }
+    return ora_path_pack(edges, n);
+}
+/* GameN::actionize (game.rs:741-753); a Draw edge needs the cards from the caller */
+ORA_API ora_action ora_nlhe_actionize(const ora_game* g, uint8_t edge, uint64_t draw_cards) {
+    switch (edge) {
+        case E_FOLD: return (ora_action){A_FOLD, 0, 0};
+        case E_DRAW: return (ora_action){A_DRAW, 0, draw_cards};
+        case E_CALL: return (ora_action){A_CALL, to_call(g), 0};
+        case E_CHECK: return (ora_action){A_CHECK, 0, 0};
+        case E_SHOVE: return (ora_action){A_SHOVE, to_shove(g), 0};
+    }
+    return (ora_action){A_RAISE, ora_edge_into_chips(edge, g->pot), 0};
+}
+/* GameN::edgify with snap_to_edge (game.rs:754-766,826-833): the grid edge nearest in chips, first one on ties */
+ORA_API uint8_t ora_nlhe_edgify(const ora_game* g, const ora_action* a, int depth) {
+    switch (a->kind) {
+        case A_FOLD: return E_FOLD;
+        case A_CHECK: return E_CHECK;
+        case A_DRAW: return E_DRAW;
+        case A_CALL: case A_BLIND: return E_CALL;
+        case A_SHOVE: return E_SHOVE;
+    }
+    uint8_t grid[8];
+    const int n = ora_edge_raises(street_of(g), depth, grid);
+    if (n == 0) return E_SHOVE;
+    int best = 0, best_gap = 1 << 30;
+    for (int i = 0; i < n; ++i) {
+        int gap = (int)ora_edge_into_chips(grid[i], g->pot) - (int)a->chips;
+        if (gap < 0) gap = -gap;
+        if (gap < best_gap) best = i, best_gap = gap;
+    }
+    return grid[best];
+}

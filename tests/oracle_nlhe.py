@@ -64,8 +64,61 @@ def lib():
         o.ora_nlhe_snap.restype = ActionStruct
         o.ora_nlhe_snap.argtypes = [G, ActionStruct]
         o.ora_showdown_settle.argtypes = [C.c_int, C.POINTER(C.c_int16), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
+        o.ora_edge_raises.restype = C.c_int
+        o.ora_edge_raises.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+        o.ora_edge_into_chips.restype = C.c_int16
+        o.ora_edge_into_chips.argtypes = [C.c_uint8, C.c_int16]
+        o.ora_edge_to_u64.restype = C.c_uint64
+        o.ora_edge_to_u64.argtypes = [C.c_uint8]
+        o.ora_edge_from_u64.restype = C.c_uint8
+        o.ora_edge_from_u64.argtypes = [C.c_uint64]
+        o.ora_path_pack.restype = C.c_uint64
+        o.ora_path_pack.argtypes = [C.POINTER(C.c_uint8), C.c_int]
+        o.ora_path_unpack.restype = C.c_int
+        o.ora_path_unpack.argtypes = [C.c_uint64, C.POINTER(C.c_uint8)]
+        o.ora_path_length.restype = C.c_int
+        o.ora_path_length.argtypes = [C.c_uint64]
+        o.ora_path_aggression.restype = C.c_int
+        o.ora_path_aggression.argtypes = [C.c_uint64]
+        o.ora_nlhe_choices.restype = C.c_uint64
+        o.ora_nlhe_choices.argtypes = [G, C.c_int]
+        o.ora_nlhe_actionize.restype = ActionStruct
+        o.ora_nlhe_actionize.argtypes = [G, C.c_uint8, C.c_uint64]
+        o.ora_nlhe_edgify.restype = C.c_uint8
+        o.ora_nlhe_edgify.argtypes = [G, A, C.c_int]
         _o = o
     return _o
+
+
+# ---- Edge codes (edge.rs:101-120) -----------------------------------------------------------------------------------
+E_DRAW, E_FOLD, E_CHECK, E_CALL, E_SHOVE = 1, 2, 3, 4, 5
+OPENS = [2, 3, 4, 5]
+RAISES = [(1, 4), (1, 3), (1, 2), (2, 3), (3, 4), (1, 1), (5, 4), (3, 2), (2, 1), (3, 1)]
+
+
+def Open(n):
+    return 6 + OPENS.index(n)
+
+
+def RaiseOdds(n, d):
+    return 10 + RAISES.index((n, d))
+
+
+def edge_raises(street, depth):
+    out = (C.c_uint8 * 8)()
+    k = lib().ora_edge_raises(street, depth, out)
+    return list(out[:k])
+
+
+def path_pack(edges):
+    arr = (C.c_uint8 * max(len(edges), 1))(*edges)
+    return lib().ora_path_pack(arr, len(edges))
+
+
+def path_unpack(p):
+    out = (C.c_uint8 * 13)()
+    k = lib().ora_path_unpack(p, out)
+    return list(out[:k])
 
 
 def Action(kind, chips=0, cards=0):
@@ -169,6 +222,16 @@ class Game:
     def snap(self, a):
         r = lib().ora_nlhe_snap(C.byref(self._s), ActionStruct(*a))
         return (r.kind, r.chips if r.kind not in (FOLD, CHECK) else 0, r.cards)
+
+    def choices(self, depth):
+        return path_unpack(lib().ora_nlhe_choices(C.byref(self._s), depth))
+
+    def actionize(self, edge, cards=0):
+        r = lib().ora_nlhe_actionize(C.byref(self._s), edge, cards)
+        return (r.kind, r.chips if r.kind not in (FOLD, CHECK) else 0, r.cards)
+
+    def edgify(self, a, depth):
+        return lib().ora_nlhe_edgify(C.byref(self._s), C.byref(ActionStruct(*a)), depth)
 
     # the actions of game.rs:577-595
     raise_ = property(lambda self: Raise(self.to_raise))

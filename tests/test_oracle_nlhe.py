@@ -360,3 +360,60 @@ def test_random_playouts_conserve_chips_and_stay_legal():
                 assert opts and all(g.is_allowed(a) for a in opts)
                 g = g.apply(rng.choice(opts))
             assert g.total == total
+
+
+# ---- the action abstraction (edge.rs, size.rs, path.rs, game.rs:724-766) -------------------------------------------
+def test_edge_codes_round_trip():  # edge.rs:284-302 bijective_u8 / bijective_u64, :325-332 backwards_compat_u64_bbs
+    lib = on.lib()
+    for e in range(1, 20):
+        assert lib.ora_edge_from_u64(lib.ora_edge_to_u64(e)) == e
+    assert lib.ora_edge_to_u64(on.Open(5)) == 6 | 5 << 3 and lib.ora_edge_to_u64(on.RaiseOdds(3, 2)) == 4 | 3 << 3 | 2 << 11
+    assert lib.ora_edge_from_u64(4 | 1 << 19 | 5 << 3) == on.Open(5) and lib.ora_edge_from_u64(4 | 1 << 19 | 2 << 3) == on.Open(2)
+
+
+def test_raise_grids():  # edge.rs:333-347, size.rs:113-138, pokerkit/src/lib.rs:138-151
+    assert on.edge_raises(0, 0) == [on.Open(n) for n in (2, 3, 4, 5)]
+    for street in (1, 2, 3):
+        for depth in range(3):
+            assert all(e >= 10 for e in on.edge_raises(street, depth))
+    assert on.edge_raises(1, 0) == [on.RaiseOdds(*r) for r in ((1, 4), (1, 2), (3, 4), (1, 1), (2, 1))]
+    assert on.edge_raises(0, 1) == [on.RaiseOdds(1, 1), on.RaiseOdds(2, 1)] and on.edge_raises(3, 7) == []
+    assert on.edge_raises(2, 2) == on.edge_raises(2, 3) == [on.RaiseOdds(1, 1)]  # depth >= 2 collapses, > 3 is empty
+    lib = on.lib()
+    assert lib.ora_edge_into_chips(on.Open(3), 100) == 6  # big blinds, whatever the pot
+    assert [lib.ora_edge_into_chips(on.RaiseOdds(n, d), 10) for n, d in on.RAISES] == [2, 3, 5, 6, 7, 10, 12, 15, 20, 30]
+
+
+def test_path_packing():  # path.rs:178-262
+    import random
+    rng = random.Random(1)
+    assert on.path_pack([]) == 0 and on.path_unpack(0) == []
+    for n in range(13):
+        edges = [rng.randrange(1, 20) for _ in range(n)]
+        p = on.path_pack(edges)
+        assert on.path_unpack(p) == edges and on.lib().ora_path_length(p) == n
+    assert len(on.path_unpack(on.path_pack([2] * 20))) == 12  # MAX_PATH_EDGES
+    D, R12, C_, X, R11, S, F = on.E_DRAW, on.RaiseOdds(1, 2), on.E_CALL, on.E_CHECK, on.RaiseOdds(1, 1), on.E_SHOVE, on.E_FOLD
+    assert on.lib().ora_path_aggression(on.path_pack([D, R12, C_, C_, D, X, X, X, D, R11, S, F])) == 2  # path.rs:234-262
+    assert on.lib().ora_path_aggression(on.path_pack([D, X, X, X])) == 0
+
+
+def test_choices_actionize_edgify():  # game.rs:724-766,826-833 and the Snap cases of :1803-1812,1897-1906
+    g = Game.root()
+    # the dealer facing the big blind: four opens, then shove, call, fold (legal()'s order with the raise unfolded)
+    assert g.choices(0) == [on.Open(2), on.Open(3), on.Open(4), on.Open(5), on.E_SHOVE, on.E_CALL, on.E_FOLD]
+    assert g.choices(4) == [on.E_SHOVE, on.E_CALL, on.E_FOLD]  # past MAX_RAISE_REPEATS only the shove is aggressive
+    assert g.actionize(on.Open(3)) == Raise(6) and g.actionize(on.E_CALL) == Call(1) and g.actionize(on.E_SHOVE) == Shove(STACK - 1)
+    for chips, edge in ((4, on.Open(2)), (6, on.Open(3)), (8, on.Open(4)), (10, on.Open(5)), (16, on.Open(5)), (2, on.Open(2)),
+                        (20, on.Open(5)), (7, on.Open(3))):  # 7 lies between two opens: the first of equal gaps
+        assert g.edgify(Raise(chips), 0) == edge
+    assert g.edgify(Fold, 0) == on.E_FOLD and g.edgify(Call(1), 0) == on.E_CALL and g.edgify(on.Blind(2), 0) == on.E_CALL
+    assert g.edgify(Raise(50), 4) == on.E_SHOVE  # no raise grid at that depth (game.rs:829-832 unwrap_or(Shove))
+    flop = g.apply(Call(1)).apply(Check)
+    flop = flop.apply(Draw(flop.deal()))
+    assert flop.choices(0) == [on.RaiseOdds(*r) for r in ((1, 4), (1, 2), (3, 4), (1, 1), (2, 1))] + [on.E_SHOVE, on.E_CHECK]
+    assert flop.actionize(on.RaiseOdds(3, 4)) == Raise(3) and flop.edgify(Raise(4), 0) == on.RaiseOdds(1, 1)
+    # every abstract choice is a legal concrete action after snapping to the rules (the trainer's apply path)
+    for e in flop.choices(0):
+        a = flop.snap(flop.actionize(e))
+        assert flop.is_allowed(a)
