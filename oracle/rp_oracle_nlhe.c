@@ -521,3 +521,50 @@ ORA_API uint8_t ora_nlhe_edgify(const ora_game* g, const ora_action* a, int dept
     }
     return grid[best];
 }
+
+/* ================================================================================================================
+ * The NLHE instance of the solver's game / info interfaces (crates/nlhe/src/game.rs, info.rs, encoder.rs).
+ * ================================================================================================================ */
+/* NlheGame::apply (nlhe/src/game.rs:33-53): an abstract edge on the concrete game.  A choice edge met at a chance
+ * node first deals the pending streets (the reference draws them at random: `draws` supplies them here, one entry
+ * per street dealt, consumed in order); a Draw edge off a chance node is a no-op; the action is snapped to the
+ * rules.  Returns the number of entries of `draws` consumed, or -1 when the snapped action is not allowed. */
+ORA_API int ora_nlhe_apply_edge(ora_game* g, uint8_t edge, const uint64_t* draws) {
+    int used = 0;
+    if (turn_of(g) == T_TERMINAL) return 0;
+    if (edge != E_DRAW) {
+        while (turn_of(g) == T_CHANCE) {
+            const ora_action d = {A_DRAW, 0, draws[used++]};
+            force_act(g, &d);
+        }
+        if (turn_of(g) == T_TERMINAL) return used;
+    }
+    if (edge == E_DRAW && turn_of(g) != T_CHANCE) return used;
+    ora_action a = ora_nlhe_actionize(g, edge, edge == E_DRAW ? draws[used] : 0);
+    if (edge == E_DRAW) used += 1;
+    a = ora_nlhe_snap(g, a);
+    if (!ora_nlhe_is_allowed(g, &a)) return -1;
+    force_act(g, &a);
+    return used;
+}
+/* NlheGame::payoff (nlhe/src/game.rs:59-65): settlement.won() of a seat at a terminal state */
+ORA_API int ora_nlhe_payoff(const ora_game* g, int seat, float* out) {
+    int32_t reward[MAXP];
+    if (ora_nlhe_settlements(g, reward)) return 1;
+    *out = (float)(reward[seat] - g->seats[seat].spent);
+    return 0;
+}
+/* NlheInfo::from((Path, Abstraction, Path)) (nlhe/src/info.rs:72-86) with the choices of encoder.rs:44-52 /
+ * info.rs:88-103: the key is (past = the choice edges since the last chance edge, present = the bucket of the actor's
+ * observation, choices = GameN::choices(past.aggression())); columns past BIGINT, present SMALLINT, choices BIGINT
+ * (nlhe/src/profile.rs:20-31).  `history`: every edge since the root, chance edges included. */
+ORA_API void ora_nlhe_info(const ora_game* g, uint64_t history, uint64_t* past, uint64_t* choices) {
+    uint8_t e[MAX_PATH_EDGES + 1], tail[MAX_PATH_EDGES + 1];
+    const int n = ora_path_unpack(history, e);
+    int k = n;
+    while (k > 0 && e[k - 1] != E_DRAW) --k; /* rev().take_while(is_choice) ... rev() */
+    int m = 0;
+    for (int i = k; i < n; ++i) tail[m++] = e[i];
+    *past = ora_path_pack(tail, m);
+    *choices = ora_nlhe_choices(g, ora_path_aggression(*past));
+}

@@ -86,6 +86,11 @@ def lib():
         o.ora_nlhe_actionize.argtypes = [G, C.c_uint8, C.c_uint64]
         o.ora_nlhe_edgify.restype = C.c_uint8
         o.ora_nlhe_edgify.argtypes = [G, A, C.c_int]
+        o.ora_nlhe_apply_edge.restype = C.c_int
+        o.ora_nlhe_apply_edge.argtypes = [G, C.c_uint8, C.POINTER(C.c_uint64)]
+        o.ora_nlhe_payoff.restype = C.c_int
+        o.ora_nlhe_payoff.argtypes = [G, C.c_int, C.POINTER(C.c_float)]
+        o.ora_nlhe_info.argtypes = [G, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _o = o
     return _o
 
@@ -232,6 +237,32 @@ class Game:
 
     def edgify(self, a, depth):
         return lib().ora_nlhe_edgify(C.byref(self._s), C.byref(ActionStruct(*a)), depth)
+
+    def apply_edge(self, edge):
+        """NlheGame::apply (nlhe/src/game.rs:33-53): pending streets are dealt from the seeded deck."""
+        g = self._copy()
+        draws = (C.c_uint64 * 4)()
+        probe = g._copy()
+        for i in range(4):  # cards for every street that could be dealt on the way
+            if probe.turn != CHANCE:
+                break
+            draws[i] = probe.deal()
+            probe = probe.apply(Draw(draws[i]))
+        if lib().ora_nlhe_apply_edge(C.byref(g._s), edge, draws) < 0:
+            raise ValueError(f"edge {edge} not applicable")
+        return g
+
+    def payoff(self, seat):
+        out = C.c_float()
+        if lib().ora_nlhe_payoff(C.byref(self._s), seat, C.byref(out)):
+            raise ValueError("non terminal game state")
+        return out.value
+
+    def info(self, history_edges):
+        """(past, choices) of NlheInfo for the edges played since the root (nlhe/src/info.rs:72-103)."""
+        past, choices = C.c_uint64(), C.c_uint64()
+        lib().ora_nlhe_info(C.byref(self._s), path_pack(history_edges), C.byref(past), C.byref(choices))
+        return path_unpack(past.value), path_unpack(choices.value)
 
     # the actions of game.rs:577-595
     raise_ = property(lambda self: Raise(self.to_raise))

@@ -417,3 +417,74 @@ def test_choices_actionize_edgify():  # game.rs:724-766,826-833 and the Snap cas
     for e in flop.choices(0):
         a = flop.snap(flop.actionize(e))
         assert flop.is_allowed(a)
+
+
+# ---- the solver-facing NLHE types (nlhe/src/game.rs, info.rs) ------------------------------------------------------
+def test_every_legal_raise_lands_on_a_trained_edge():  # nlhe/src/info.rs:153-198,250-263
+    root = Game.root()
+    flop = root.apply(Call(1)).apply(Check)
+    flop = flop.apply(Draw(flop.deal()))
+    turn = flop.apply(Check).apply(Check)
+    turn = turn.apply(Draw(turn.deal()))
+    for g in (root, flop, turn):
+        trained = set(g.choices(0))
+        for amount in range(g.to_raise, g.to_shove):
+            assert g.edgify(Raise(amount), 0) in trained
+
+
+def test_roundtrip_edgify_actionize():  # nlhe/src/info.rs:238-248
+    g = Game.root()
+    for a1 in g.legal():
+        e1 = g.edgify(a1, 0)
+        assert g.edgify(g.actionize(e1), 0) == e1
+
+
+def test_aggression():  # nlhe/src/info.rs:200-224
+    D, X, C_, S = on.E_DRAW, on.E_CHECK, on.E_CALL, on.E_SHOVE
+    agg = lambda edges: on.lib().ora_path_aggression(on.path_pack(edges))  # noqa: E731
+    assert agg([D, on.RaiseOdds(1, 1), C_, D, X, on.RaiseOdds(1, 2), S]) == 2
+    assert agg([on.RaiseOdds(1, 1), on.RaiseOdds(1, 2), S]) == 3
+    assert agg([X, C_, X]) == 0
+
+
+def test_info_key_keeps_the_current_street_and_live_choices():  # nlhe/src/info.rs:72-103,265-297
+    g = Game.root()
+    history = []
+    for e in (on.E_CALL, on.E_CHECK):
+        g = g.apply_edge(e)
+        history.append(e)
+    assert g.turn == CHANCE
+    g = g.apply_edge(on.RaiseOdds(1, 1))  # a choice edge at a chance node deals the flop first (game.rs:40-46)
+    history += [on.E_DRAW, on.RaiseOdds(1, 1)]
+    assert g.street == 1 and g.pot == 8
+    past, choices = g.info(history)
+    assert past == [on.RaiseOdds(1, 1)]  # only the choice edges since the last chance edge
+    assert choices == g.choices(1)      # one raise so far on this street
+    assert choices == [on.RaiseOdds(1, 2), on.RaiseOdds(1, 1), on.E_SHOVE, on.E_CALL, on.E_FOLD]
+    # a Draw edge off a chance node changes nothing (game.rs:47-49); a terminal game ignores edges (game.rs:37-39)
+    assert g.apply_edge(on.E_DRAW).pot == g.pot and g.apply_edge(on.E_DRAW).turn == g.turn
+    done = g.apply_edge(on.E_FOLD)
+    assert done.turn == TERMINAL and done.apply_edge(on.E_CALL).turn == TERMINAL
+    assert done.payoff(0) == -done.payoff(1) and abs(done.payoff(0)) == 2.0  # the folder had put in two chips
+
+
+def test_abstract_playouts_reach_terminal_states_that_settle():
+    # the trainer's path end to end: choices -> apply_edge (deal / actionize / snap / apply) -> payoff; zero-sum heads up
+    import random
+    rng = random.Random(9)
+    for trial in range(200):
+        g, history = Game.root(seed=trial), []
+        for _ in range(60):
+            if g.turn == TERMINAL:
+                break
+            if g.turn == CHANCE:
+                g = g.apply_edge(on.E_DRAW)
+                history = (history + [on.E_DRAW])[-12:]
+                continue
+            past, choices = g.info(history)
+            assert choices, "a choice node offers at least one edge"
+            e = rng.choice(choices)
+            g = g.apply_edge(e)
+            history = (history + [e])[-12:]
+        assert g.turn == TERMINAL
+        assert g.payoff(0) + g.payoff(1) == 0.0
