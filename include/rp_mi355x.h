@@ -467,6 +467,19 @@ RP_API int rp_artifact_write_metric(const char* path, int street, uint32_t K, co
 RP_API int rp_artifact_write_transitions(const char* path, int street, uint32_t K, uint32_t bins,
                                          const uint32_t* counts, const uint64_t* weight);
 
+/* =================================================================================================
+ * The NLHE rules engine on the device (first device step).  The betting state machine of
+ * kicker::GameN<P> (crates/kicker/src/game.rs), the action abstraction (edge.rs, size.rs: Pluribus grids) with
+ * NlheGame::apply's actionize + snap (crates/nlhe/src/game.rs:33-53) and Showdown::settle (showdown.rs) run as
+ * device functions; this entry point plays `n_games` random abstract hands of `n_players` (2..10, 200-chip stacks,
+ * blinds 1 / 2, dealer = game % n_players), one lane per game: deals and choices from rp_node_hash(seed, 0, game,
+ * counter) (rp_math.h).  payoffs_dev[game][seat] = NlheGame::payoff (settlement.won()), digests_dev[game] folds every
+ * intermediate state, steps_dev[game] = actions taken (0xffffffff if the hand did not finish in max_steps).  The
+ * MCCFR traversal over this engine is not built yet.
+ * ================================================================================================= */
+RP_API int rp_nlhe_playouts(int device, uint32_t n_players, uint64_t n_games, uint64_t seed, uint32_t max_steps,
+                            float* payoffs_dev, uint64_t* digests_dev, uint32_t* steps_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -568,3 +568,75 @@ ORA_API void ora_nlhe_info(const ora_game* g, uint64_t history, uint64_t* past, 
     *past = ora_path_pack(tail, m);
     *choices = ora_nlhe_choices(g, ora_path_aggression(*past));
 }
+
+/* ================================================================================================================
+ * The playout driver of robopoker_amd/csrc/nlhe.hip (rp_nlhe_playouts), restated over THIS file's rules: deals and
+ * choices come from the shared random-number contract (include/rp_math.h: rp_node_hash(seed, 0, game, counter),
+ * rp_pick_uniform), every intermediate state is folded into a digest.  Used by tests/test_gpu_nlhe.py.
+ * ================================================================================================================ */
+#include "../include/rp_math.h"
+
+static uint64_t playout_draw(uint64_t deck, int k, uint64_t seed, uint64_t game, uint32_t* counter) {
+    uint64_t out = 0;
+    for (int c = 0; c < k; ++c) {
+        const uint32_t pick = rp_pick_uniform(rp_node_hash(seed, 0, game, (*counter)++), (uint32_t)popc(deck));
+        uint64_t d = deck;
+        for (uint32_t s = 0; s < pick; ++s) d &= d - 1;
+        const uint64_t card = d & (~d + 1);
+        out |= card;
+        deck &= ~card;
+    }
+    return out;
+}
+static uint64_t playout_digest(uint64_t h, const ora_game* g) {
+    h = rp_mix64(h ^ ((uint64_t)(uint32_t)g->pot | (uint64_t)(uint32_t)g->ticker << 20 | (uint64_t)(uint32_t)g->dealer << 40));
+    h = rp_mix64(h ^ g->board);
+    for (int i = 0; i < g->n; ++i)
+        h = rp_mix64(h ^ ((uint64_t)(uint32_t)g->seats[i].stack | (uint64_t)(uint32_t)g->seats[i].stake << 16 |
+                          (uint64_t)(uint32_t)g->seats[i].spent << 32 | (uint64_t)(uint32_t)g->seats[i].state << 48));
+    return h;
+}
+ORA_API void ora_nlhe_playout(int n, uint64_t game, uint64_t seed, uint32_t max_steps, float* payoffs, uint64_t* digest, uint32_t* steps_out) {
+    uint32_t counter = 0;
+    int16_t stacks[MAXP];
+    uint64_t holes[MAXP], deck = 0x000FFFFFFFFFFFFFull;
+    for (int i = 0; i < n; ++i) {
+        stacks[i] = 200;
+        holes[i] = playout_draw(deck, 2, seed, game, &counter);
+        deck &= ~holes[i];
+    }
+    ora_game g;
+    ora_nlhe_from_start(&g, n, (int)(game % (uint64_t)n), stacks, holes);
+    uint64_t h = playout_digest(seed ^ game, &g);
+    int depth = 0;
+    uint32_t steps = 0;
+    for (; steps < max_steps; ++steps) {
+        const int t = turn_of(&g);
+        if (t == T_TERMINAL) break;
+        if (t == T_CHANCE) {
+            const ora_action d = {A_DRAW, 0, playout_draw(deck_of(&g), street_of(&g) == 0 ? 3 : 1, seed, game, &counter)};
+            if (ora_nlhe_apply(&g, &d)) break;
+            depth = 0;
+        } else {
+            uint8_t edges[MAX_PATH_EDGES + 1];
+            const int k = ora_path_unpack(ora_nlhe_choices(&g, depth), edges);
+            if (k == 0) break;
+            const uint8_t e = edges[rp_pick_uniform(rp_node_hash(seed, 0, game, counter++), (uint32_t)k)];
+            ora_action a = ora_nlhe_snap(&g, ora_nlhe_actionize(&g, e, 0));
+            if (ora_nlhe_apply(&g, &a)) {
+                h = rp_mix64(h ^ 0xbadbadbadull);
+                break;
+            }
+            depth += e == E_SHOVE || e >= E_OPEN0;
+        }
+        h = playout_digest(h, &g);
+    }
+    const int done = turn_of(&g) == T_TERMINAL;
+    for (int i = 0; i < n; ++i) {
+        float v = 0.0f;
+        if (done) ora_nlhe_payoff(&g, i, &v);
+        payoffs[i] = v;
+    }
+    *digest = h;
+    *steps_out = done ? steps : 0xffffffffu;
+}

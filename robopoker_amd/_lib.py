@@ -209,6 +209,7 @@ _SIGNATURES = {
     "rp_equity_variation": (C.c_int, [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "rp_mccfr_train": (C.c_int, [C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "rp_nlhe_playouts": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rp_hand_strength": (C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rp_obs_canonical": (C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rp_isomorphisms": (C.c_int, [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
