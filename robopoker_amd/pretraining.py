@@ -51,9 +51,44 @@ def cluster_river(device=0) -> Artifacts:
     return Artifacts("rive", obs, bucket, timings={"isomorphisms_ms": t_iso, "equity_ms": t_eq, "wall_s": time.perf_counter() - t0})
 
 
-def cluster_preflop(device=0) -> Artifacts:
+def cluster_preflop(device=0, flop: Artifacts | None = None, flop_metric=None) -> Artifacts:
+    """PrefLayer::cluster (forge/src/pretraining.rs:40-43; K = N = 169, no k-means iterations): the lookup is
+    Lookup::grow(Street::Pref) (isomorphism k -> abstraction k, lookup.rs:179-184).  With the flop artifacts the layer's
+    metric() and future() are produced too (layer.rs:85-114): the 169 preflop histograms are the projections of the flop
+    lookup over all 19 600 flops of a pocket (Lookup::future: children enumerated here, bucket lookups on the device
+    through rp_lookup_get), their pairwise distance (emd(x, y) + emd(y, x)) / 2 under the flop layer's metric
+    (rp_sinkhorn_divergence), normalised by the maximum (Metric::from, metric.rs:127-141)."""
+    import itertools
+
+    from .lloyd import sinkhorn_divergence
     obs = deuce.isomorphisms("pref", device=device)
-    return Artifacts("pref", obs, torch.arange(obs.numel(), dtype=torch.uint8, device=obs.device))
+    art = Artifacts("pref", obs, torch.arange(obs.numel(), dtype=torch.uint8, device=obs.device))
+    if flop is None:
+        return art
+    t0 = time.perf_counter()
+    bins = int(flop.abstraction.max().item()) + 1
+    table = deuce.Lookup("flop", flop.obs, flop.abstraction)
+    combos = np.array(list(itertools.combinations(range(50), 3)), dtype=np.int64)  # boards as indices into the 50 other cards
+    hist = np.zeros((obs.numel(), bins), dtype=np.uint32)
+    for k, o in enumerate(obs.cpu().tolist()):
+        p1, p0 = (o & 0xff) - 1, ((o >> 8) & 0xff) - 1  # pocket cards, ascending: p0 < p1 (observation.rs:132-141)
+        rest = np.array([c for c in range(52) if c not in (p0, p1)], dtype=np.int64)
+        c = rest[combos] + 1  # (19600, 3), each row ascending
+        child = (c[:, 0] << 32) | (c[:, 1] << 24) | (c[:, 2] << 16) | ((p0 + 1) << 8) | (p1 + 1)
+        b = table.lookup(torch.from_numpy(child).to(obs.device)).cpu().numpy()
+        hist[k] = np.bincount(b, minlength=bins).astype(np.uint32)
+    table.close()
+    K = obs.numel()
+    tri = np.zeros(K * (K - 1) // 2, dtype=np.float32)
+    if flop_metric is not None:
+        hi, lo = np.array([(i, j) for i in range(K) for j in range(i)], dtype=np.int64).T
+        d = (sinkhorn_divergence(hist[hi], hist[lo], flop_metric, device=device)
+             + sinkhorn_divergence(hist[lo], hist[hi], flop_metric, device=device)) / np.float32(2.0)
+        tri[hi * (hi - 1) // 2 + lo] = d  # Pair::merge (pair.rs:36-39)
+        tri = tri / tri.max()
+    art.metric, art.future, art.future_weight = tri, hist, hist.sum(axis=1).astype(np.uint64)
+    art.timings = {"preflop_s": time.perf_counter() - t0}
+    return art
 
 
 def cluster_layer(street: str, below: Artifacts, tri=None, K=None, iterations=None, seed=None, log=None, limit=None) -> Artifacts:
@@ -118,7 +153,7 @@ def run(device=0, log=None, flop_iterations=None, turn_iterations=None) -> dict[
         log(f"river: {out['rive'].obs.numel()} isomorphisms, equity {out['rive'].timings['equity_ms']:.0f} ms")
     out["turn"] = cluster_layer("turn", out["rive"], iterations=turn_iterations, log=log)
     out["flop"] = cluster_layer("flop", out["turn"], tri=out["turn"].metric, iterations=flop_iterations, log=log)
-    out["pref"] = cluster_preflop(device)
+    out["pref"] = cluster_preflop(device, out["flop"], out["flop"].metric)
     return out
 
 
