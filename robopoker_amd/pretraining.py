@@ -245,5 +245,5 @@ def run_sharded(device=0, group=None, log=None, flop_iterations=None, turn_itera
     out = {"rive": cluster_river_sharded(device, group)}
     out["turn"] = cluster_layer_sharded("turn", out["rive"], iterations=turn_iterations, log=log, group=group)
     out["flop"] = cluster_layer_sharded("flop", out["turn"], tri=out["turn"].metric, iterations=flop_iterations, log=log, group=group)
-    out["pref"] = cluster_preflop(device)
+    out["pref"] = cluster_preflop(device, out["flop"], out["flop"].metric)  # 169 points: every rank computes them
     return out
