@@ -368,9 +368,30 @@ RP_API int rp_kmeans_rms(rp_kmeans* h, float* out);
 RP_API int rp_kmeans_stats(rp_kmeans* h, uint64_t* distances, uint64_t* sinkhorn_iterations);
 /* exp evaluations spent in Sinkhorn softmin / cost loops so far: sum over solves of (2*iterations + 1) * m * n */
 RP_API int rp_kmeans_exp_evals(rp_kmeans* h, uint64_t* evals);
+/* The MFMA Sinkhorn bound in front of the N x K neighbor passes of a Sinkhorn layer (init_bounds, assign, step_naive):
+ * a scaling-domain iteration u = mu ./ (K v), v = nu ./ (K^T u), K = exp(-C/T), on v_mfma_f32_16x16x4_f32 gives every
+ * (point, centroid) pair an interval that contains the value Sinkhorn::divergence (sinkhorn.rs:166-171) returns; the
+ * centroids whose lower bound exceeds the smallest upper bound are discarded and the bit-faithful kernel runs on the
+ * survivors only, in ascending centroid order — buckets, distances and tie-breaks are those of the unpruned loop
+ * (elkan.rs:68-77).  Environment: RP_LLOYD_NO_MFMA_BOUND=1 switches it off; RP_LLOYD_AUDIT=1 also runs the unpruned
+ * pass and counts the points on which the two disagree (audit_mismatches; must stay 0). */
+typedef struct rp_prune_stats {
+    uint32_t enabled;          /* 0: the layer runs every distance through the bit-faithful kernel */
+    uint32_t reserved;
+    uint64_t points;           /* points that went through the bound (all neighbor passes so far) */
+    uint64_t candidates;       /* points * K */
+    uint64_t survivors;        /* (point, centroid) pairs handed to the bit-faithful kernel */
+    uint64_t block_iterations; /* MFMA work: iterations of a 16-centroid column block (each 2 * 16 * ceil(n/16) * 4 MFMAs of 2048 flop) */
+    uint64_t cost_passes;      /* extra K.*C contractions for the cost of an iterate inside the stopping window */
+    uint64_t audited_points;   /* RP_LLOYD_AUDIT: points compared with the unpruned pass */
+    uint64_t audit_mismatches; /* ... and how many differed in bucket or distance bits */
+} rp_prune_stats;
+RP_API int rp_kmeans_prune_stats(rp_kmeans* h, rp_prune_stats* out);
+/* the divergence intervals of the bound against the current centroids: lo[N*K], hi[N*K] (tests / diagnostics) */
+RP_API int rp_kmeans_bound_intervals(rp_kmeans* h, float* lo, float* hi);
 RP_API int rp_kmeans_set_stream(rp_kmeans* h, void* hip_stream);
 RP_API int rp_kmeans_profile(rp_kmeans* h, int enable);
-/* name in {"pairwise","step","recompute","bounds","neighbor","selfcost","kpp"} */
+/* name in {"pairwise","step","recompute","bounds","neighbor","selfcost","kpp","drift","mfma_bound"} */
 RP_API int rp_kmeans_kernel_time(rp_kmeans* h, const char* name, double* total_ms, uint64_t* launches);
 
 /* ---- multi-GPU: points sharded by rank, integer centroid sums all-reduced ----------

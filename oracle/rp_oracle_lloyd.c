@@ -57,8 +57,28 @@ static uint64_t g_sinkhorn_iters = 0;
 static uint64_t g_distances = 0;
 
 /* Sinkhorn::from(..).minimize().cost() (sinkhorn.rs:77-92,194-230) */
+static float sinkhorn_cost_traced(uint32_t bins, const ora_hist* mu, const ora_hist* nu, const float* tri,
+                                  const rp_sinkhorn_hp* hp, uint32_t* iters_out, float* trace_err, float* trace_cost);
 static float sinkhorn_cost(uint32_t bins, const ora_hist* mu, const ora_hist* nu, const float* tri,
                            const rp_sinkhorn_hp* hp, uint32_t* iters_out) {
+    return sinkhorn_cost_traced(bins, mu, nu, tri, hp, iters_out, NULL, NULL);
+}
+/* x-major sum of coupling * distance (sinkhorn.rs:206-217) for the potentials (lhs, rhs) */
+static float coupling_cost(const float* tri, const uint32_t* sx, uint32_t m, const uint32_t* sy, uint32_t n,
+                           const float* lhs, const float* rhs, float T) {
+    float cost = 0.0f;
+    for (uint32_t i = 0; i < m; ++i)
+        for (uint32_t j = 0; j < n; ++j) {
+            float c = raw_distance(tri, sx[i], sy[j]);
+            cost += rp_expf(lhs[i] + rhs[j] - c / T) * c;
+        }
+    return cost;
+}
+/* trace_err / trace_cost (tests only, each hp->iterations long): the stopping statistic lhs_err + rhs_err of every
+ * iteration and the cost the solve would return had it stopped there; with a trace the loop does not stop early, the
+ * returned cost and *iters_out are still those of the reference's stopping rule. */
+static float sinkhorn_cost_traced(uint32_t bins, const ora_hist* mu, const ora_hist* nu, const float* tri,
+                                  const rp_sinkhorn_hp* hp, uint32_t* iters_out, float* trace_err, float* trace_cost) {
     uint32_t sx[ORA_MAXBINS], sy[ORA_MAXBINS];
     uint32_t m = 0, n = 0;
     for (uint32_t i = 0; i < bins; ++i) { /* Bins::support ascending (bins.rs:84-88) */
@@ -73,7 +93,9 @@ static float sinkhorn_cost(uint32_t bins, const ora_hist* mu, const ora_hist* nu
     for (uint32_t i = 0; i < m; ++i) lhs[i] = lu;
     for (uint32_t j = 0; j < n; ++j) rhs[j] = ru;
     float T = hp->temperature;
-    uint32_t t;
+    uint32_t t, stop_t = 0;
+    int stopped = 0;
+    float stop_cost = 0.0f;
     for (t = 0; t < hp->iterations; ++t) {
         /* lhs (sinkhorn.rs:94-102) via softmin (sinkhorn.rs:119-128) */
         float lhs_err = 0.0f;
@@ -100,17 +122,25 @@ static float sinkhorn_cost(uint32_t bins, const ora_hist* mu, const ora_hist* nu
         for (uint32_t j = 0; j < n; ++j) rhs_err += rp_absf(rp_expf(nxt[j]) - rp_expf(rhs[j]));
         for (uint32_t j = 0; j < n; ++j) rhs[j] = nxt[j];
         g_sinkhorn_iters += 1;
+        if (trace_err) {
+            trace_err[t] = lhs_err + rhs_err;
+            trace_cost[t] = coupling_cost(tri, sx, m, sy, n, lhs, rhs, T);
+            if (!stopped && lhs_err + rhs_err < hp->tolerance) {
+                stopped = 1;
+                stop_t = t + 1;
+                stop_cost = trace_cost[t];
+            }
+            continue;
+        }
         if (lhs_err + rhs_err < hp->tolerance) { t += 1; break; }
+    }
+    if (trace_err && stopped) {
+        if (iters_out) *iters_out = stop_t;
+        return stop_cost;
     }
     if (iters_out) *iters_out = t;
     /* cost (sinkhorn.rs:206-217): x-major sum of coupling * distance */
-    float cost = 0.0f;
-    for (uint32_t i = 0; i < m; ++i)
-        for (uint32_t j = 0; j < n; ++j) {
-            float c = raw_distance(tri, sx[i], sy[j]);
-            cost += rp_expf(lhs[i] + rhs[j] - c / T) * c;
-        }
-    return cost;
+    return coupling_cost(tri, sx, m, sy, n, lhs, rhs, T);
 }
 
 /* Sinkhorn::divergence (sinkhorn.rs:166-171) with the self terms passed in (self_cost :175-191 memoises
@@ -148,6 +178,14 @@ ORA_API float ora_sinkhorn_cost(uint32_t bins, const uint32_t* mu, const uint32_
     hist_from_u32(&a, bins, mu);
     hist_from_u32(&b, bins, nu);
     return sinkhorn_cost(bins, &a, &b, tri, hp, iters);
+}
+/* tests only: per-iteration stopping statistic and would-be cost (see sinkhorn_cost_traced) */
+ORA_API float ora_sinkhorn_trace(uint32_t bins, const uint32_t* mu, const uint32_t* nu, const float* tri,
+                                 const rp_sinkhorn_hp* hp, uint32_t* iters, float* trace_err, float* trace_cost) {
+    ora_hist a, b;
+    hist_from_u32(&a, bins, mu);
+    hist_from_u32(&b, bins, nu);
+    return sinkhorn_cost_traced(bins, &a, &b, tri, hp, iters, trace_err, trace_cost);
 }
 ORA_API float ora_sinkhorn_divergence(uint32_t bins, const uint32_t* mu, const uint32_t* nu, const float* tri,
                                       const rp_sinkhorn_hp* hp) {

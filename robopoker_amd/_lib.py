@@ -105,6 +105,13 @@ class RpError(RuntimeError):
 
 
 # every symbol include/rp_mi355x.h declares (tests/test_abi.py checks the list against the header)
+class PruneStats(C.Structure):
+    """rp_prune_stats (include/rp_mi355x.h): what the MFMA Sinkhorn bound discarded and what it cost"""
+    _fields_ = [("enabled", C.c_uint32), ("reserved", C.c_uint32), ("points", C.c_uint64), ("candidates", C.c_uint64),
+                ("survivors", C.c_uint64), ("block_iterations", C.c_uint64), ("cost_passes", C.c_uint64),
+                ("audited_points", C.c_uint64), ("audit_mismatches", C.c_uint64)]
+
+
 _SIGNATURES = {
     "rp_last_error": (C.c_char_p, []),
     "rp_device_count": (C.c_int, []),
@@ -191,6 +198,8 @@ _SIGNATURES = {
     "rp_kmeans_rms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rp_kmeans_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rp_kmeans_exp_evals": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rp_kmeans_prune_stats": (C.c_int, [C.c_void_p, C.POINTER(PruneStats)]),
+    "rp_kmeans_bound_intervals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rp_kmeans_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_kmeans_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "rp_kmeans_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

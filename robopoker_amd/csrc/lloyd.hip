@@ -58,6 +58,7 @@ struct CentroidSet {
     uint16_t* sup;     // [K][MAXB] support bins ascending
     float* lnd;        // [K][MAXB] ln(density) on the support
     float* dens;       // [bins][K] density, transposed (variation path)
+    float* densR;      // [K][256] density by centroid, 0 off the support and past `bins` (the MFMA bound's mu operand)
     float* self;       // [K] OT(c,c)
 };
 
@@ -80,6 +81,8 @@ struct __attribute__((aligned(16))) WaveLds {
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+#include "sinkhorn_bound.hpp"
 
 // Bins::support + Bins::density (bins.rs:58-60,84-88) of a dense histogram into LDS; returns the support size
 template <typename CT>
@@ -619,6 +622,8 @@ __global__ __launch_bounds__(64) void k_prepare_centroids(CentroidSet cs, uint32
     }
     for (uint32_t b = lane_id(); b < bins; b += 64)
         cs.dens[(size_t)b * K + k] = (float)cs.counts[(size_t)k * bins + b] / (float)wt;  // NaN for an empty cluster, as in the reference
+    for (uint32_t b = lane_id(); b < bins; b += 64)
+        cs.densR[(size_t)k * MAXB + b] = wt ? (float)cs.counts[(size_t)k * bins + b] / (float)wt : 0.0f;
     if (lane_id() == 0) cs.n[k] = m;
     __syncthreads();
     float self = 0.0f;
@@ -741,6 +746,63 @@ __global__ __launch_bounds__(64) void k_neighbor(Points P, CentroidSet cs, uint3
     }
     if (init.lower)
         for (uint32_t k = lane; k < K; k += 64) init.lower[i * K + k] = 0.0f;
+}
+
+// Elkan::neighbor over the survivors of the MFMA bound (sinkhorn_bound.hpp): the centroids whose bit is set in the
+// point's 256-bit mask, in ascending index, first minimum wins (elkan.rs:68-77: min_by keeps the first) — the unpruned
+// loop's result bit for bit as long as every minimiser survives.  `audit_*`: RP_LLOYD_AUDIT compares with the unpruned
+// pass instead of writing.
+__global__ __launch_bounds__(64) void k_neighbor_masked(Points P, CentroidSet cs, uint32_t K, Metric M, const unsigned long long* mask,
+                                                        uint8_t* out_j, float* out_d, Bounds init) {
+    __shared__ WaveLds w;
+    const uint64_t i = blockIdx.x;
+    const uint32_t lane = lane_id();
+    const uint32_t n = wave_load_hist(P.counts + i * P.stride, P.weight[i], M.bins, w.supB, w.lnB);
+    const float sp = P.self[i];
+    uint32_t bj = 0;
+    float bd = 0.0f;
+    bool first = true;
+    for (uint32_t q = 0; q < 4; ++q) {
+        unsigned long long bits = mask[i * 4 + q];
+        while (bits) {
+            const uint32_t k = q * 64 + (uint32_t)__builtin_ctzll(bits);
+            bits &= bits - 1;
+            if (k >= K) break;
+            const uint32_t m = wave_load_centroid(cs, k, w.supA, w.lnA);
+            const float d = wave_divergence(w, m, n, cs.self[k], sp, M);  // distance(centroid, point)
+            if (first || d < bd) {
+                bj = k;
+                bd = d;
+                first = false;
+            }
+            __syncthreads();
+        }
+    }
+    if (lane == 0) {
+        if (out_j) out_j[i] = (uint8_t)bj;
+        if (out_d) out_d[i] = bd;
+        if (init.j) {
+            init.j[i] = (uint8_t)bj;
+            init.u[i] = bd;
+            init.stale[i] = 0;
+        }
+    }
+    if (init.lower)
+        for (uint32_t k = lane; k < K; k += 64) init.lower[i * K + k] = 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_mask_all(const uint32_t* list, uint32_t n, unsigned long long* mask) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    for (int q = 0; q < 4; ++q) mask[(size_t)list[e] * 4 + q] = ~0ull;
+}
+
+// RP_LLOYD_AUDIT: count the points on which two neighbor passes disagree (bucket or distance bits)
+__global__ __launch_bounds__(256) void k_audit_compare(const uint8_t* ja, const float* da, const uint8_t* jb, const float* db, uint64_t N,
+                                                       unsigned long long* bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    if (ja[i] != jb[i] || __float_as_uint(da[i]) != __float_as_uint(db[i])) atomicAdd(bad, 1ull);
 }
 
 // Elkan::neighbor for G points per wavefront (each with <= 64 / G support bins), Sinkhorn metric
@@ -1629,8 +1691,8 @@ struct Clock {
     double total_ms = 0.0;
     uint64_t launches = 0;
 };
-const char* const CLOCK_NAMES[] = {"pairwise", "step", "recompute", "bounds", "neighbor", "selfcost", "kpp", "drift"};
-enum { CK_PAIRWISE, CK_STEP, CK_RECOMPUTE, CK_BOUNDS, CK_NEIGHBOR, CK_SELF, CK_KPP, CK_DRIFT, CK_COUNT };
+const char* const CLOCK_NAMES[] = {"pairwise", "step", "recompute", "bounds", "neighbor", "selfcost", "kpp", "drift", "mfma_bound"};
+enum { CK_PAIRWISE, CK_STEP, CK_RECOMPUTE, CK_BOUNDS, CK_NEIGHBOR, CK_SELF, CK_KPP, CK_DRIFT, CK_BOUND, CK_COUNT };
 }  // namespace
 
 struct rp_kmeans {
@@ -1660,6 +1722,21 @@ struct rp_kmeans {
     uint32_t* singles = nullptr;  // [n_singles] the other points
     uint64_t n_quads = 0, n_pairs = 0, n_singles = 0;
     Refresh refresh{};            // grouped stale-bound refresh (Sinkhorn; null nsup = off)
+    // the MFMA bound in front of the neighbor passes (sinkhorn_bound.hpp)
+    bool sb_on = false, sb_audit = false;
+    SbParams sb{};
+    uint32_t* sb_list[4] = {nullptr, nullptr, nullptr, nullptr};  // points by ceil(support / 16) = 1..4
+    uint32_t sb_count[4] = {0, 0, 0, 0};
+    uint32_t* sb_big = nullptr;   // points with more than SB_MAXROWS bins: never pruned
+    uint32_t sb_nbig = 0;
+    unsigned int* sb_cursor = nullptr;      // [4]
+    unsigned long long* sb_mask = nullptr;  // [N][4]
+    unsigned long long* sb_stats = nullptr; // striped: survivors, points, column-block iterations, cost passes
+    unsigned long long* sb_bad = nullptr;   // [1] audit disagreements
+    uint8_t* audit_j = nullptr;
+    float* audit_d = nullptr;
+    float* sb_d = nullptr;
+    uint64_t sb_audited = 0;
     unsigned long long* bsum = nullptr;
     unsigned long long* scal = nullptr;  // [0] picked, [1] moved
     unsigned long long* sizes = nullptr; // [K]
@@ -1717,6 +1794,8 @@ int alloc_centroid_set(rp_kmeans* h, CentroidSet* cs) {
     if ((rc = dev_alloc(h, &cs->sup, (size_t)h->K * MAXB))) return rc;
     if ((rc = dev_alloc(h, &cs->lnd, (size_t)h->K * MAXB))) return rc;
     if ((rc = dev_alloc(h, &cs->dens, (size_t)h->K * h->bins))) return rc;
+    if ((rc = dev_alloc(h, &cs->densR, (size_t)h->K * MAXB))) return rc;
+    HIP_TRY(hipMemset(cs->densR, 0, (size_t)h->K * MAXB * 4));
     if ((rc = dev_alloc(h, &cs->self, h->K))) return rc;
     return RP_OK;
 }
@@ -1827,14 +1906,69 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         KM_HIP(hipMemsetAsync(d_self, 0, N * 4, h->stream));
     }
     KM_HIP(hipStreamSynchronize(h->stream));
-    if (kind == RP_METRIC_SINKHORN && !getenv("RP_LLOYD_NO_PAIRS")) {
-        uint8_t* d_ns = nullptr;
+    std::vector<uint8_t> ns;
+    uint8_t* d_ns = nullptr;
+    if (kind == RP_METRIC_SINKHORN) {
         KM_TRY(dev_alloc(h, &d_ns, N));
         hipLaunchKernelGGL(k_point_support, dim3((unsigned)N), dim3(64), 0, h->stream, h->P, bins, d_ns);
         KM_HIP(hipGetLastError());
-        std::vector<uint8_t> ns(N);
+        ns.resize(N);
         KM_HIP(hipMemcpyAsync(ns.data(), d_ns, N, hipMemcpyDeviceToHost, h->stream));  // same (non-blocking) stream as the kernel
         KM_HIP(hipStreamSynchronize(h->stream));
+    }
+    if (kind == RP_METRIC_SINKHORN && !getenv("RP_LLOYD_NO_MFMA_BOUND")) {
+        // the MFMA bound (sinkhorn_bound.hpp): K = exp(-C/T) padded to 256 x 256, point lists by ceil(support / 16)
+        std::vector<float> Km((size_t)MAXB * MAXB, 1.0f);
+        for (uint32_t x = 0; x < bins; ++x)
+            for (uint32_t y = 0; y < bins; ++y) {
+                const float c = x == y ? 0.0f : tri_metric[rp_tri_index(x, y)];
+                Km[(size_t)x * MAXB + y] = (float)std::exp(-(double)c / (double)h->hp.temperature);
+            }
+        float* d_K = nullptr;
+        KM_TRY(dev_alloc(h, &d_K, Km.size()));
+        KM_HIP(hipMemcpy(d_K, Km.data(), Km.size() * 4, hipMemcpyHostToDevice));
+        auto envf = [](const char* name, float dflt) {
+            const char* v = getenv(name);
+            return v ? (float)atof(v) : dflt;
+        };
+        h->sb.Kmat = d_K;
+        h->sb.neg_t_ln2 = -h->hp.temperature * 0.6931472f;
+        h->sb.tol = h->hp.tolerance;
+        h->sb.iters = h->hp.iterations;
+        h->sb.kappa = envf("RP_SB_KAPPA", 2.0f);
+        h->sb.rho = envf("RP_SB_RHO", 1.25f);
+        h->sb.dc_abs = envf("RP_SB_DC_ABS", 4e-6f);
+        h->sb.dc_rel = envf("RP_SB_DC_REL", 4e-5f);
+        h->sb.flat = envf("RP_SB_FLAT", 4.0f);
+        std::vector<uint32_t> cls[4], big;
+        for (uint64_t i = 0; i < N; ++i) {
+            // k_point_support saturates at 255 bins; 0 (an empty histogram) is left to the exact kernel as well
+            const uint32_t t = ns[i] == 0 || ns[i] > SB_MAXROWS ? 4u : (uint32_t)(ns[i] - 1) / 16u;
+            (t < 4 ? cls[t] : big).push_back((uint32_t)i);
+        }
+        for (int t = 0; t < 4; ++t) {
+            h->sb_count[t] = (uint32_t)cls[t].size();
+            KM_TRY(dev_alloc(h, &h->sb_list[t], cls[t].size()));
+            if (!cls[t].empty()) KM_HIP(hipMemcpy(h->sb_list[t], cls[t].data(), cls[t].size() * 4, hipMemcpyHostToDevice));
+        }
+        h->sb_nbig = (uint32_t)big.size();
+        KM_TRY(dev_alloc(h, &h->sb_big, big.size()));
+        if (!big.empty()) KM_HIP(hipMemcpy(h->sb_big, big.data(), big.size() * 4, hipMemcpyHostToDevice));
+        KM_TRY(dev_alloc(h, &h->sb_cursor, 4));
+        KM_TRY(dev_alloc(h, &h->sb_mask, (size_t)N * 4));
+        KM_TRY(dev_alloc(h, &h->sb_stats, (size_t)KM_STAT_STRIPES * STAT_STRIDE));
+        KM_HIP(hipMemset(h->sb_stats, 0, (size_t)KM_STAT_STRIPES * STAT_STRIDE * 8));
+        KM_TRY(dev_alloc(h, &h->sb_bad, 1));
+        KM_HIP(hipMemset(h->sb_bad, 0, 8));
+        KM_TRY(dev_alloc(h, &h->sb_d, N));
+        h->sb_audit = getenv("RP_LLOYD_AUDIT") != nullptr;
+        if (h->sb_audit) {
+            KM_TRY(dev_alloc(h, &h->audit_j, N));
+            KM_TRY(dev_alloc(h, &h->audit_d, N));
+        }
+        h->sb_on = true;
+    }
+    if (kind == RP_METRIC_SINKHORN && !getenv("RP_LLOYD_NO_PAIRS")) {
         // grouping lists: <= QUAD_ROWS bins -> four per wavefront, <= PAIR_ROWS -> two, the others one
         std::vector<uint32_t> tiny, small, rest;
         const bool no_quads = getenv("RP_LLOYD_NO_QUADS") != nullptr;
@@ -1880,7 +2014,8 @@ int need_bounds(const rp_kmeans* h, const char* who) {
     return RP_OK;
 }
 
-int launch_neighbor(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init) {
+// every (point, centroid) distance through the bit-faithful kernels: the reference's loop as it stands
+int launch_neighbor_full(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init) {
     ck_begin(h, CK_NEIGHBOR);
     if (h->kind == RP_METRIC_VARIATION && h->bins == 101)  // turn layer: register-resident centroid CDFs
         hipLaunchKernelGGL(k_neighbor_var<101>, dim3((unsigned)((h->N + VB - 1) / VB)), dim3(256), 0, h->stream, h->P,
@@ -1900,6 +2035,55 @@ int launch_neighbor(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init) {
                            out_d, init, (const uint32_t*)nullptr);
     ck_end(h, CK_NEIGHBOR);
     HIP_TRY(hipGetLastError());
+    return RP_OK;
+}
+
+// the MFMA bound over every point (one launch per support class), leaving the survivor masks in h->sb_mask
+int launch_bound(rp_kmeans* h, float* dbg_lo, float* dbg_hi) {
+    HIP_TRY(hipMemsetAsync(h->sb_cursor, 0, 16, h->stream));
+    const CentroidSet& cs = h->cs[h->cur];
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    ck_begin(h, CK_BOUND);
+    for (int t = 3; t >= 0; --t) {  // the longest-running class first
+        const uint32_t n = h->sb_count[t];
+        if (!n) continue;
+        const dim3 grid(std::min<uint32_t>(n, (uint32_t)cus)), block(SB_THREADS);
+#define SB_LAUNCH(NT)                                                                                                      \
+    hipLaunchKernelGGL(k_sinkhorn_bound<NT>, grid, block, 0, h->stream, h->P, cs, h->K, h->bins, h->sb, h->sb_list[t], n, \
+                       h->sb_cursor + t, h->sb_mask, dbg_lo, dbg_hi, h->sb_stats)
+        if (t == 0) SB_LAUNCH(1);
+        else if (t == 1) SB_LAUNCH(2);
+        else if (t == 2) SB_LAUNCH(3);
+        else SB_LAUNCH(4);
+#undef SB_LAUNCH
+    }
+    if (h->sb_nbig) hipLaunchKernelGGL(k_mask_all, dim3((h->sb_nbig + 255) / 256), dim3(256), 0, h->stream, h->sb_big, h->sb_nbig, h->sb_mask);
+    ck_end(h, CK_BOUND);
+    HIP_TRY(hipGetLastError());
+    return RP_OK;
+}
+
+// Elkan::neighbor for every point (init_bounds / Layer::lookup / step_naive).  Sinkhorn layers: the MFMA bound discards
+// the centroids that cannot be the argmin, the bit-faithful kernel runs on the survivors (same bits).
+int launch_neighbor(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init) {
+    if (!h->sb_on) return launch_neighbor_full(h, out_j, out_d, init);
+    int rc = launch_bound(h, nullptr, nullptr);
+    if (rc) return rc;
+    float* dd = out_d ? out_d : h->sb_d;
+    ck_begin(h, CK_NEIGHBOR);
+    hipLaunchKernelGGL(k_neighbor_masked, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->sb_mask,
+                       out_j, dd, init);
+    ck_end(h, CK_NEIGHBOR);
+    HIP_TRY(hipGetLastError());
+    if (h->sb_audit && out_j) {  // RP_LLOYD_AUDIT: the unpruned pass next to it; disagreements are counted, never corrected
+        Bounds none{};
+        if ((rc = launch_neighbor_full(h, h->audit_j, h->audit_d, none))) return rc;
+        hipLaunchKernelGGL(k_audit_compare, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, out_j, dd, h->audit_j,
+                           h->audit_d, h->N, h->sb_bad);
+        HIP_TRY(hipGetLastError());
+        h->sb_audited += h->N;
+    }
     return RP_OK;
 }
 
@@ -2327,6 +2511,61 @@ int rp_kmeans_exp_evals(rp_kmeans* h, uint64_t* evals) {
     int rc = read_stats(h, s);
     if (rc) return rc;
     *evals = s[2];
+    return RP_OK;
+}
+
+int rp_kmeans_prune_stats(rp_kmeans* h, rp_prune_stats* out) {
+    if (!h || !out) return rp::fail(RP_ERR_INVALID, "rp_kmeans_prune_stats: NULL argument");
+    memset(out, 0, sizeof(*out));
+    out->enabled = h->sb_on ? 1u : 0u;
+    if (!h->sb_on) return RP_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<unsigned long long> all((size_t)KM_STAT_STRIPES * STAT_STRIDE);
+    unsigned long long bad = 0;
+    HIP_TRY(hipMemcpyAsync(all.data(), h->sb_stats, all.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&bad, h->sb_bad, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    unsigned long long s[4] = {0, 0, 0, 0};
+    for (uint32_t q = 0; q < KM_STAT_STRIPES; ++q)
+        for (uint32_t k = 0; k < 4; ++k) s[k] += all[(size_t)q * STAT_STRIDE + k];
+    out->survivors = s[0];
+    out->points = s[1];
+    out->candidates = s[1] * h->K;
+    out->block_iterations = s[2];
+    out->cost_passes = s[3];
+    out->audited_points = h->sb_audited;
+    out->audit_mismatches = bad;
+    return RP_OK;
+}
+
+int rp_kmeans_bound_intervals(rp_kmeans* h, float* lo, float* hi) {
+    if (!h || !lo || !hi) return rp::fail(RP_ERR_INVALID, "rp_kmeans_bound_intervals: NULL argument");
+    if (!h->sb_on) return rp::fail(RP_ERR_UNSUPPORTED, "rp_kmeans_bound_intervals: the layer has no MFMA bound (variation metric, or switched off)");
+    int rc = need_centroids(h, "rp_kmeans_bound_intervals");
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    float *d_lo = nullptr, *d_hi = nullptr;
+    const size_t cells = (size_t)h->N * h->K;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_lo), cells * 4));
+    if (hipMalloc(reinterpret_cast<void**>(&d_hi), cells * 4) != hipSuccess) {
+        (void)hipFree(d_lo);
+        return rp::fail(RP_ERR_HIP, "rp_kmeans_bound_intervals: out of device memory");
+    }
+    // points outside the bound's support classes keep [0, inf)
+    std::vector<float> zeros(cells, 0.0f), infs(cells, INFINITY);
+    (void)hipMemcpyAsync(d_lo, zeros.data(), cells * 4, hipMemcpyHostToDevice, h->stream);
+    (void)hipMemcpyAsync(d_hi, infs.data(), cells * 4, hipMemcpyHostToDevice, h->stream);
+    rc = launch_bound(h, d_lo, d_hi);
+    if (!rc) {
+        (void)hipMemcpyAsync(lo, d_lo, cells * 4, hipMemcpyDeviceToHost, h->stream);
+        (void)hipMemcpyAsync(hi, d_hi, cells * 4, hipMemcpyDeviceToHost, h->stream);
+    }
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_lo);
+    (void)hipFree(d_hi);
+    ck_drain(h);
+    if (rc) return rc;
+    if (e != hipSuccess) return rp::fail(RP_ERR_HIP, "rp_kmeans_bound_intervals: %s", hipGetErrorString(e));
     return RP_OK;
 }
 

@@ -1,0 +1,355 @@
+// sinkhorn_bound.hpp — the MFMA path of the lloyd pipeline: a scaling-domain Sinkhorn *bound* in front of the N x K
+// neighbor passes (Elkan::init_bounds elkan.rs:39-47, Elkan::neighbor :68-77, Layer::lookup layer.rs:62-82).
+// Included by lloyd.hip inside namespace rp, after Points / CentroidSet / Metric.
+//
+// WHAT IT IS.  The reference's distance is Sinkhorn::divergence (sinkhorn.rs:166-171) whose cross term is the cost of a
+// log-domain Gauss-Seidel solve stopped by an L1 test on exp(potential) (sinkhorn.rs:77-139).  The bit-faithful kernel
+// (wave_sinkhorn_cost) reproduces it float for float and is exp-bound.  The SAME iteration in the scaling domain,
+//      u = mu ./ (K v),   v = nu ./ (K^T u),   K = exp(-C / T)    (u = exp(lhs), v = exp(rhs)),
+// is two dense contractions per iteration with a K shared by every pair, i.e. GEMMs: for ONE point (nu, <= 64 support bins)
+// against ALL centroids (mu_j, j < 256)
+//      S[x][j] = sum_y K[x][y] V[y][j]      (256 x n_p) . (n_p x 256)
+//      R[y][j] = sum_x K[y][x] U[x][j]      (n_p x 256) . (256 x 256)
+// on v_mfma_f32_16x16x4_f32 (exact f32 products, the guide's 157.3 TF path).  It cannot be bit-faithful to the log-domain
+// left folds, so it is not a replacement: it yields, per (point, centroid), an INTERVAL [lo, hi] that contains the value
+// the faithful kernel would return, and a centroid whose lo exceeds the smallest hi cannot be the argmin.  Only the
+// survivors (1.0x per point on the flop layer) go through the faithful kernel, in ascending centroid order, so buckets,
+// distances and tie-breaks are bit-identical to the unpruned pass.
+//
+// WHY THE INTERVAL HOLDS (DESIGN.md §4b has the measurements behind every constant).
+//  (1) Same trajectory.  Both computations iterate the same contraction from the same start (Potential::uniform) in the
+//      same Gauss-Seidel order; f32 scaling-domain and f32 log-domain iterates differ from the real-number trajectory by
+//      rounding only.  Measured against a float64 restatement: |cost_t(oracle) - cost_t(f64)| <= 4.5e-6 * cost at every
+//      iteration t, the scaling-domain f32 iterate the same; the margin used is dc = dc_abs + dc_rel * cost (4e-6, 4e-5).
+//  (2) Unknown stopping time.  The reference stops at the first t with err_t < tol, where err_t = sum |exp(f') - exp(f)|
+//      is evaluated on f32 LOG potentials: its rounding noise is about sum_x u_x (|ln u_x| + c) 2^-23, which for far pairs
+//      (u ~ 1e7) dwarfs tol, so the stop can come "early" (the log potentials stall bitwise) or never (128 iterations).
+//      The bound therefore does not predict the stop.  It tracks a noise bound N_t (an over-estimate: kappa times the
+//      measured worst case) and takes the cost range over EVERY iteration at which the reference could stop:
+//         window = [ first t with err_t - N_t < tol * rho ,  first t with (err_t + N_t) * rho < tol ]   (or the cap, or
+//      the iteration at which the scaling iterate itself stops moving).  lo/hi = min/max of the cost over the window -/+ dc.
+//  A too-large N_t, rho or dc only widens intervals (more survivors, never a wrong answer).  RP_LLOYD_AUDIT=1 runs the
+//  unpruned pass next to the pruned one and counts disagreements (rp_kmeans_prune_stats); the GPU tests do that.
+//
+// MAPPING.  One workgroup (8 wavefronts) per point; wave w owns centroids 32w .. 32w+31 as two column blocks of 16.
+//  K[sup_y][.] of the point's support is gathered once into LDS in both orientations (row strides 264 / 72 floats:
+//  conflict-free ds_read_b128 for the A operands).  U, V live in registers in the MFMA C/D layout, which IS the B-operand
+//  layout of the next contraction when the k index is permuted (row 4g + r of an accumulator feeds k = g of step r), so
+//  the two GEMMs chain without any data movement: U never exists in memory.  Per wave: U_old 128 VGPRs (needed for the
+//  stopping statistic), V 8*NT, accumulators 4*NT + 8.  mu_j(x) streams from L2 (256 KB table, b128 per lane).
+#pragma once
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SB_THREADS 512
+#define SB_KS 264       // ksub  row stride in floats: 264 mod 64 = 8  -> the 16 lanes of a ds_read_b128 group hit 64 banks once
+#define SB_KT 72        // ksubT row stride in floats:  72 mod 64 = 8
+#define SB_MAXROWS 64   // a point with more support bins than this is not pruned (all its centroids go to the exact kernel)
+#define SB_EPS23 1.1920929e-7f
+
+struct SbParams {
+    const float* Kmat;  // [256][256] exp(-C/T); 1.0 outside the bins x bins block
+    float neg_t_ln2;    // C = neg_t_ln2 * log2(K)
+    float tol;
+    uint32_t iters;
+    float kappa;   // multiplier of the stopping-statistic noise model
+    float rho;     // slack factor of the stopping window (>= 1)
+    float dc_abs;  // cost margin: dc_abs + dc_rel * cost
+    float dc_rel;
+    float flat;    // the scaling iterate counts as stationary when err <= flat * 2^-23 * (sum u + sum v), twice in a row
+};
+
+struct __attribute__((aligned(16))) SbLds {
+    float ksub[SB_MAXROWS * SB_KS];  // [y][x] = K[sup_y][x]
+    float ksubT[256 * SB_KT];        // [x][y]
+    float b[SB_MAXROWS];             // nu(sup_y), 0 on the padding rows
+    float dlo[256];
+    float dhi[256];
+    float red[8];
+    uint32_t sup[SB_MAXROWS];
+    uint32_t np;
+    uint32_t item;
+};
+
+__device__ __forceinline__ f32x4 sb_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float sb_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// reductions over the four lanes (g = 0..3) that share a centroid column
+__device__ __forceinline__ float sb_sum4(float x) {
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+__device__ __forceinline__ float sb_max4(float x) {
+    x = fmaxf(x, __shfl_xor(x, 16, 64));
+    x = fmaxf(x, __shfl_xor(x, 32, 64));
+    return x;
+}
+
+// One Gauss-Seidel iteration for a block of 16 centroid columns: U <- mu ./ (K V), then V <- nu ./ (K^T U).
+// uo: U of the previous iteration in C/D layout (lane (c, g), register r of tile xt = U[16 xt + 4g + r][column c]);
+// v likewise over the point's rows.  drow = this lane's centroid density row (256 floats, zero off the support).
+template <int NT>
+__device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], const float* __restrict__ drow, const SbLds& L, uint32_t c,
+                                           uint32_t g, float& err, float& sumu, float& umax, float& sumv, float& vmax) {
+    f32x4 racc[NT];
+#pragma unroll
+    for (int yt = 0; yt < NT; ++yt) racc[yt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float eu = 0.0f, su = 0.0f, mu_ = 0.0f;
+    const float* kt = &L.ksubT[c * SB_KT + 4 * g];
+    const float* ks = &L.ksub[c * SB_KS + 4 * g];
+    f32x4 mnext = *reinterpret_cast<const f32x4*>(drow + 4 * g);
+#pragma unroll
+    for (int xt = 0; xt < 16; ++xt) {
+        const f32x4 m0 = mnext;
+        if (xt + 1 < 16) mnext = *reinterpret_cast<const f32x4*>(drow + (xt + 1) * 16 + 4 * g);  // one tile ahead (L2 latency)
+        f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int yt = 0; yt < NT; ++yt) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(kt + xt * 16 * SB_KT + yt * 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s0 = sb_mfma(a0[r], v[yt][r], s0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float u0 = m0[r] * sb_rcp(fmaxf(s0[r], 1e-37f));
+            eu += fabsf(u0 - uo[xt][r]);
+            su += u0;
+            mu_ = fmaxf(mu_, u0);
+            uo[xt][r] = u0;
+        }
+#pragma unroll
+        for (int yt = 0; yt < NT; ++yt) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ks + yt * 16 * SB_KS + xt * 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) racc[yt] = sb_mfma(a0[r], uo[xt][r], racc[yt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the tiles apart: hoisting the next tiles' operands costs more registers than the wave has
+    }
+    float ev = 0.0f, sv = 0.0f, mv = 0.0f;
+#pragma unroll
+    for (int yt = 0; yt < NT; ++yt) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(&L.b[yt * 16 + 4 * g]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float vn = bq[r] * sb_rcp(fmaxf(racc[yt][r], 1e-37f));
+            ev += fabsf(vn - v[yt][r]);
+            sv += vn;
+            mv = fmaxf(mv, vn);
+            v[yt][r] = vn;
+        }
+    }
+    err = sb_sum4(eu) + sb_sum4(ev);
+    sumu = sb_sum4(su);
+    sumv = sb_sum4(sv);
+    umax = sb_max4(mu_);
+    vmax = sb_max4(mv);
+}
+
+// cost of the current iterate: sum_y v_y sum_x K[y][x] C[y][x] u_x, with C recovered from K (C = -T ln K)
+template <int NT>
+__device__ __forceinline__ float sb_cost(const f32x4 (&uo)[16], const f32x4 (&v)[NT], const SbLds& L, uint32_t c, uint32_t g,
+                                         float neg_t_ln2) {
+    f32x4 w[NT];
+#pragma unroll
+    for (int yt = 0; yt < NT; ++yt) w[yt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int xt = 0; xt < 16; ++xt) {
+        const float* ks = &L.ksub[c * SB_KS + xt * 16 + 4 * g];
+#pragma unroll
+        for (int yt = 0; yt < NT; ++yt) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ks + yt * 16 * SB_KS);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float kc = a[r] * (neg_t_ln2 * __builtin_amdgcn_logf(a[r]));
+                w[yt] = sb_mfma(kc, uo[xt][r], w[yt]);
+            }
+        }
+    }
+    float part = 0.0f;
+#pragma unroll
+    for (int yt = 0; yt < NT; ++yt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part += v[yt][r] * w[yt][r];
+    return sb_sum4(part);
+}
+
+struct SbCol {  // per-column window state (replicated in the four lanes of the column)
+    float wmin, wmax, nb_prev;
+    int flatc;
+    bool opened, done;
+};
+
+// pstats: [0] survivors, [1] points, [2] column-block iterations, [3] cost passes   (striped like Metric::stats)
+template <int NT>
+__global__ __launch_bounds__(SB_THREADS, 2) void k_sinkhorn_bound(Points P, CentroidSet cs, uint32_t K, uint32_t bins, SbParams prm,
+                                                                   const uint32_t* list, uint32_t count, unsigned int* cursor,
+                                                                   unsigned long long* mask_out, float* dbg_lo, float* dbg_hi,
+                                                                   unsigned long long* pstats) {
+    __shared__ SbLds L;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t c = lane & 15u, g = lane >> 4;
+    unsigned long long my_cb_iters = 0, my_cost_passes = 0;
+    for (;;) {
+        __syncthreads();  // the previous point's LDS is no longer read
+        if (tid == 0) L.item = atomicAdd(cursor, 1u);
+        __syncthreads();
+        const uint32_t item = L.item;
+        if (item >= count) break;
+        const uint64_t i = list[item];
+        // ---- the point: support (ascending bins), densities, K rows in both orientations
+        if (wave == 0) {
+            const uint8_t* counts = P.counts + i * P.stride;
+            const float fw = (float)P.weight[i];
+            uint32_t base = 0;
+            for (uint32_t q = 0; q * 64 < bins; ++q) {
+                const uint32_t bb = q * 64 + lane;
+                const uint32_t cc = bb < bins ? (uint32_t)counts[bb] : 0u;
+                const bool has = cc > 0;
+                const unsigned long long m = __ballot(has);
+                if (has) {
+                    const uint32_t r = base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (r < SB_MAXROWS) {
+                        L.sup[r] = bb;
+                        L.b[r] = (float)cc / fw;  // Bins::density (bins.rs:58-60)
+                    }
+                }
+                base += __popcll(m);
+            }
+            if (lane == 0) L.np = base;
+        }
+        __syncthreads();
+        const uint32_t np = L.np;
+        if (np == 0 || np > NT * 16) {  // not a point of this list's class: leave it to the exact kernel, unpruned
+            if (tid < 4) mask_out[i * 4 + tid] = ~0ull;
+            continue;
+        }
+        if (tid >= np && tid < NT * 16) {
+            L.sup[tid] = L.sup[0];
+            L.b[tid] = 0.0f;
+        }
+        __syncthreads();
+        for (uint32_t e = tid; e < NT * 16 * 256; e += SB_THREADS) {
+            const uint32_t y = e >> 8, x = e & 255u;
+            const float k = prm.Kmat[L.sup[y] * 256u + x];
+            L.ksub[y * SB_KS + x] = k;
+            L.ksubT[x * SB_KT + y] = k;
+        }
+        __syncthreads();
+        // ---- this wave's 2 x 16 centroid columns
+        f32x4 uo0[16], uo1[16], v0[NT], v1[NT];
+        const uint32_t j0 = wave * 32 + c, j1 = j0 + 16;
+        const uint32_t jc0 = j0 < K ? j0 : K - 1, jc1 = j1 < K ? j1 : K - 1;
+        const uint32_t mj0 = cs.n[jc0], mj1 = cs.n[jc1];
+        const bool valid0 = j0 < K && mj0 > 0, valid1 = j1 < K && mj1 > 0;
+        const float* drow0 = cs.densR + (size_t)jc0 * 256;
+        const float* drow1 = cs.densR + (size_t)jc1 * 256;
+        {   // Potential::uniform (phi.rs:34-39): exp(lhs) = 1/|supp mu| on the support, exp(rhs) = 1/|supp nu|
+            const float iu0 = 1.0f / (float)(mj0 ? mj0 : 1u), iu1 = 1.0f / (float)(mj1 ? mj1 : 1u), iv = 1.0f / (float)np;
+#pragma unroll
+            for (int xt = 0; xt < 16; ++xt) {
+                const f32x4 d0 = *reinterpret_cast<const f32x4*>(drow0 + xt * 16 + 4 * g);
+                const f32x4 d1 = *reinterpret_cast<const f32x4*>(drow1 + xt * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    uo0[xt][r] = d0[r] > 0.0f ? iu0 : 0.0f;
+                    uo1[xt][r] = d1[r] > 0.0f ? iu1 : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int yt = 0; yt < NT; ++yt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float vi = (uint32_t)(yt * 16 + 4 * g + r) < np ? iv : 0.0f;
+                    v0[yt][r] = vi;
+                    v1[yt][r] = vi;
+                }
+        }
+        SbCol st0, st1;
+        const float nb0 = SB_EPS23 * (8.0f + 0.37f * (float)np);
+        st0.wmin = st1.wmin = __builtin_inff();
+        st0.wmax = st1.wmax = -__builtin_inff();
+        st0.nb_prev = nb0 + SB_EPS23 * 0.37f * (float)mj0;
+        st1.nb_prev = nb0 + SB_EPS23 * 0.37f * (float)mj1;
+        st0.flatc = st1.flatc = 0;
+        st0.opened = st1.opened = false;
+        st0.done = !valid0;
+        st1.done = !valid1;
+        auto advance = [&](f32x4 (&uo)[16], f32x4 (&v)[NT], const float* drow, SbCol& st, uint32_t mj, bool last) {
+            float err, sumu, umax, sumv, vmax;
+            sb_iterate<NT>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax);
+            my_cb_iters += 1;
+            const float ln2 = 0.6931472f;
+            const float lu = fmaxf(__builtin_amdgcn_logf(umax) * ln2, 0.0f), lv = fmaxf(__builtin_amdgcn_logf(vmax) * ln2, 0.0f);
+            const float nb = SB_EPS23 * (sumu * (lu + 4.0f) + 0.37f * (float)mj + sumv * (lv + 4.0f) + 0.37f * (float)np);
+            const float noise = prm.kappa * (nb + st.nb_prev);
+            st.nb_prev = nb;
+            const bool possible = last || (err - noise < prm.tol * prm.rho);
+            const bool certain = last || ((err + noise) * prm.rho < prm.tol);
+            const bool flat = err <= prm.flat * SB_EPS23 * (sumu + sumv);
+            const bool want = !st.done && (possible || flat);
+            if (__ballot(want)) {  // wave uniform: one more contraction with K .* C for the cost of this iterate
+                const float cost = sb_cost<NT>(uo, v, L, c, g, prm.neg_t_ln2);
+                my_cost_passes += 1;
+                if (want) {
+                    // a non-finite cost (under/overflow of the scaling form) poisons the window: the column survives
+                    st.wmin = cost == cost ? fminf(st.wmin, cost) : -__builtin_inff();
+                    st.wmax = cost == cost ? fmaxf(st.wmax, cost) : __builtin_inff();
+                    st.opened = true;
+                }
+            }
+            st.flatc = flat ? st.flatc + 1 : 0;
+            if (certain || st.flatc >= 2) st.done = true;
+        };
+        for (uint32_t t = 0; t < prm.iters; ++t) {
+            const bool act0 = __ballot(!st0.done) != 0, act1 = __ballot(!st1.done) != 0;
+            if (!act0 && !act1) break;
+            const bool last = t + 1 == prm.iters;
+            if (act0) advance(uo0, v0, drow0, st0, mj0, last);
+            if (act1) advance(uo1, v1, drow1, st1, mj1, last);
+        }
+        // ---- intervals of the divergence (sinkhorn.rs:166-171): the same three f32 operations, monotone in the cost
+        const float sp = P.self[i];
+        auto finish = [&](const SbCol& st, bool valid, uint32_t j, uint32_t jc) {
+            float lo = 0.0f, hi = __builtin_inff();
+            if (valid && st.opened) {
+                const float cl = st.wmin - (prm.dc_abs + prm.dc_rel * fabsf(st.wmin));
+                const float ch = st.wmax + (prm.dc_abs + prm.dc_rel * fabsf(st.wmax));
+                const float sc = cs.self[jc];
+                if (cl == cl && cl > -__builtin_inff()) lo = rp_maxf(cl - 0.5f * sc - 0.5f * sp, 0.0f);
+                if (ch == ch) hi = rp_maxf(ch - 0.5f * sc - 0.5f * sp, 0.0f);
+            }
+            if (g == 0 && j < 256) {
+                L.dlo[j] = j < K ? lo : __builtin_inff();
+                L.dhi[j] = hi;
+            }
+        };
+        finish(st0, valid0, j0, jc0);
+        finish(st1, valid1, j1, jc1);
+        __syncthreads();
+        // ---- survivors: every centroid whose lower bound does not exceed the smallest upper bound
+        if (tid < 256) {
+            float ub = tid < K ? L.dhi[tid] : __builtin_inff();
+            for (int o = 32; o > 0; o >>= 1) ub = fminf(ub, __shfl_xor(ub, o, 64));
+            if (lane == 0) L.red[wave] = ub;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const float ub = fminf(fminf(L.red[0], L.red[1]), fminf(L.red[2], L.red[3]));
+            const bool keep = tid < K && !(L.dlo[tid] > ub);
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) {
+                mask_out[i * 4 + wave] = m;
+                atomicAdd(pstats + (size_t)(blockIdx.x % KM_STAT_STRIPES) * STAT_STRIDE + 0, (unsigned long long)__popcll(m));
+            }
+            if (dbg_lo && tid < K) {
+                dbg_lo[i * K + tid] = L.dlo[tid];
+                dbg_hi[i * K + tid] = L.dhi[tid];
+            }
+        }
+        if (tid == 0) atomicAdd(pstats + (size_t)(blockIdx.x % KM_STAT_STRIPES) * STAT_STRIDE + 1, 1ull);
+    }
+    if (lane == 0) {
+        atomicAdd(pstats + (size_t)(blockIdx.x % KM_STAT_STRIPES) * STAT_STRIDE + 2, my_cb_iters);
+        atomicAdd(pstats + (size_t)(blockIdx.x % KM_STAT_STRIPES) * STAT_STRIDE + 3, my_cost_passes);
+    }
+}

@@ -143,6 +143,19 @@ class Layer:
         _lib.check(self._lib.rp_kmeans_exp_evals(self._h, C.byref(v)))
         return v.value
 
+    def prune_stats(self) -> dict:
+        """what the MFMA Sinkhorn bound in front of the neighbor passes discarded (rp_prune_stats)"""
+        st = _lib.PruneStats()
+        _lib.check(self._lib.rp_kmeans_prune_stats(self._h, C.byref(st)))
+        return {name: getattr(st, name) for name, _ in st._fields_ if name != "reserved"}
+
+    def bound_intervals(self):
+        """(lo, hi), each (N, K): the bound's interval for distance(centroid k, point i) against the current centroids"""
+        lo = np.zeros((self.N, self.K), dtype=np.float32)
+        hi = np.zeros((self.N, self.K), dtype=np.float32)
+        _lib.check(self._lib.rp_kmeans_bound_intervals(self._h, _p(lo), _p(hi)))
+        return lo, hi
+
     # ---- multi-GPU exchange (SURVEY §8e) --------------------------------------------------------
     def partial_bytes(self) -> int:
         n = C.c_size_t()

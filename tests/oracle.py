@@ -69,6 +69,8 @@ def load() -> C.CDLL:
     # lloyd
     o.ora_sinkhorn_cost.restype = C.c_float
     o.ora_sinkhorn_cost.argtypes = [C.c_uint32, vp, vp, vp, C.POINTER(_lib.SinkhornHP), C.POINTER(C.c_uint32)]
+    o.ora_sinkhorn_trace.restype = C.c_float
+    o.ora_sinkhorn_trace.argtypes = [C.c_uint32, vp, vp, vp, C.POINTER(_lib.SinkhornHP), C.POINTER(C.c_uint32), vp, vp]
     o.ora_sinkhorn_divergence.restype = C.c_float
     o.ora_sinkhorn_divergence.argtypes = [C.c_uint32, vp, vp, vp, C.POINTER(_lib.SinkhornHP)]
     o.ora_equity_variation.restype = C.c_float
@@ -307,6 +309,19 @@ def sinkhorn_cost(mu, nu, tri, hp=None, bins=None):
     it = C.c_uint32()
     c = load().ora_sinkhorn_cost(bins or mu.size, _p(mu), _p(nu), _p(tri), C.byref(hp), C.byref(it))
     return c, it.value
+
+
+def sinkhorn_trace(mu, nu, tri, hp=None, bins=None):
+    """cost, iterations, and per iteration: the stopping statistic and the cost had the solve stopped there."""
+    hp = hp or default_sinkhorn()
+    mu = np.ascontiguousarray(mu, dtype=np.uint32)
+    nu = np.ascontiguousarray(nu, dtype=np.uint32)
+    tri = np.ascontiguousarray(tri, dtype=np.float32)
+    it = C.c_uint32()
+    errs = np.zeros(hp.iterations, dtype=np.float32)
+    costs = np.zeros(hp.iterations, dtype=np.float32)
+    c = load().ora_sinkhorn_trace(bins or mu.size, _p(mu), _p(nu), _p(tri), C.byref(hp), C.byref(it), _p(errs), _p(costs))
+    return c, it.value, errs, costs
 
 
 def sinkhorn_divergence(mu, nu, tri, hp=None, bins=None):

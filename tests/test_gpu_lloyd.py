@@ -264,3 +264,105 @@ def test_sinkhorn_hyper_parameter_corners_bit_exact(gpu, temperature, iterations
         assert bits(d[p]) == bits(oracle.sinkhorn_divergence(mu[p], nu[p], tri, hp)), p
         ec, eit = oracle.sinkhorn_cost(mu[p], nu[p], tri, hp)
         assert bits(c[p]) == bits(ec) and it[p] == eit, p
+
+
+# ---- the MFMA Sinkhorn bound in front of the neighbor passes (sinkhorn_bound.hpp) --------------------
+def _dense_centroid_layers(N, K, bins, mass, seed, iters=None):
+    """a device layer and an oracle layer whose centroids are SUMS of point groups (broad supports, like converged
+    centroids) for the even k and single points for the odd k (sparse, like k-means++ seeds)"""
+    pts = flop_like_points(N, bins=bins, mass=mass, seed=seed)
+    tri = smooth_metric(bins, seed)
+    hp = oracle.default_sinkhorn()
+    if iters:
+        hp.iterations = iters
+    dev = lloyd.Layer(K, pts, "sinkhorn", tri, hp=hp, seed=seed)
+    ora = oracle.OracleKmeans(K, pts, "sinkhorn", tri, hp=hp, seed=seed)
+    rng = np.random.default_rng(seed)
+    start = rng.choice(N, size=K, replace=False).astype(np.uint64)
+    cents = np.zeros((K, bins), dtype=np.uint32)
+    order = np.argsort(pts.astype(np.int64) @ np.arange(bins))  # neighbours in the 1-d embedding
+    for k in range(K):
+        if k % 2:
+            cents[k] = pts[start[k]]
+        else:
+            lo = int(rng.integers(0, N - 12))
+            cents[k] = pts[order[lo:lo + 12]].astype(np.uint32).sum(axis=0)
+    for km in (dev, ora):
+        km.set_centroids(start)
+        for k in range(K):
+            km.set_centroid(k, cents[k])
+    return dev, ora, pts, cents, tri, hp
+
+
+@pytest.mark.parametrize("N,K,bins,mass,iters", [(64, 40, 64, 30, None), (40, 37, 256, 47, None), (48, 20, 101, 20, 12)])
+def test_mfma_bound_intervals_contain_the_oracle(gpu, N, K, bins, mass, iters):
+    # every interval of the scaling-domain bound must contain the value the bit-faithful solve returns (the oracle's
+    # Sinkhorn::divergence, centroid first as in Elkan::neighbor), be tight for typical pairs, and leave few survivors
+    dev, ora, pts, cents, tri, hp = _dense_centroid_layers(N, K, bins, mass, seed=N + K, iters=iters)
+    lo, hi = dev.bound_intervals()
+    assert lo.shape == (N, K) and np.all(lo >= 0) and np.all(hi >= lo)
+    exact = np.zeros((N, K), dtype=np.float32)
+    for i in range(N):
+        for k in range(K):
+            exact[i, k] = oracle.sinkhorn_divergence(cents[k], pts[i].astype(np.uint32), tri, hp, bins)
+    bad = np.argwhere((exact < lo) | (exact > hi))
+    assert bad.size == 0, f"{len(bad)} intervals miss the exact value, first {bad[:3]}: " \
+                          f"{[(lo[i, k], exact[i, k], hi[i, k]) for i, k in bad[:3]]}"
+    finite = np.isfinite(hi)
+    assert finite.mean() > 0.99
+    assert np.median((hi - lo)[finite]) < 2e-4  # typical width: the margin, not the stopping window
+    survivors = (lo <= hi.min(axis=1, keepdims=True)).sum(axis=1)
+    assert survivors.mean() < 3.0, survivors
+    # the pruned passes themselves: identical buckets and distances
+    b1, d1 = dev.lookup()
+    b2, d2 = ora.assign()
+    assert np.array_equal(b1, b2) and np.array_equal(bits(d1), bits(d2))
+    st = dev.prune_stats()
+    assert st["enabled"] == 1 and st["survivors"] < st["candidates"] // 4
+
+
+def test_mfma_bound_audit_against_the_unpruned_pass(gpu, monkeypatch):
+    # RP_LLOYD_AUDIT=1: every pruned neighbor pass is followed by the unpruned one and compared point by point on the
+    # device (the "debug build" of the prune); k-means++ picks, init_bounds, two Elkan iterations, lookup at the
+    # configured shape K = 256, bins = 256
+    monkeypatch.setenv("RP_LLOYD_AUDIT", "1")
+    N, K, bins = 3000, 256, 256
+    pts = flop_like_points(N, bins=bins, mass=47, seed=0xF10F)
+    tri = smooth_metric(bins, 1)
+    dev = lloyd.Layer(K, pts, "sinkhorn", tri, seed=5)
+    dev.set_centroids(np.random.default_rng(5).choice(N, size=K, replace=False).astype(np.uint64))
+    dev.init_bounds()
+    dev.step()
+    dev.step()
+    dev.lookup()
+    st = dev.prune_stats()
+    assert st["audited_points"] == 2 * N and st["audit_mismatches"] == 0, st
+    assert st["survivors"] < 2 * st["points"], st  # ~1 survivor per point
+    monkeypatch.delenv("RP_LLOYD_AUDIT")
+    monkeypatch.setenv("RP_LLOYD_NO_MFMA_BOUND", "1")
+    ref = lloyd.Layer(K, pts, "sinkhorn", tri, seed=5)
+    assert ref.prune_stats()["enabled"] == 0
+
+
+def test_mfma_bound_handles_degenerate_inputs(gpu):
+    # K not a multiple of 16, fewer bins than a tile, a point with a single bin, an empty centroid, a hot temperature
+    # (K ~ 1) and a cold one whose exp(-C/T) underflows (intervals open up, nothing may be pruned wrongly)
+    for temperature in (0.025, 2.0, 0.0005):
+        rng = np.random.default_rng(3)
+        bins, K, N = 9, 5, 33
+        pts = np.zeros((N, bins), dtype=np.uint8)
+        for i in range(N):
+            sup = rng.choice(bins, size=int(rng.integers(1, bins + 1)), replace=False)
+            pts[i, sup] = rng.integers(1, 6, size=sup.size)
+        tri = random_metric(bins, rng)
+        hp = oracle.default_sinkhorn()
+        hp.temperature = temperature
+        dev = lloyd.Layer(K, pts, "sinkhorn", tri, hp=hp, seed=1)
+        ora = oracle.OracleKmeans(K, pts, "sinkhorn", tri, hp=hp, seed=1)
+        start = np.array([0, 1, 2, 3, 3], dtype=np.uint64)
+        for km in (dev, ora):
+            km.set_centroids(start)
+            km.set_centroid(4, np.zeros(bins, dtype=np.uint32))  # empty cluster: divergence 0 to everything
+        b1, d1 = dev.lookup()
+        b2, d2 = ora.assign()
+        assert np.array_equal(b1, b2) and np.array_equal(bits(d1), bits(d2)), temperature
