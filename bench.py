@@ -36,9 +36,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1 << 20, help="trees per step per GPU (Solver::batch_size)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak (default): --batch trees per step on EVERY GPU; strong: --batch trees per step in total, "
-                         "split across the GPUs (north_star's strong-scaling figure)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="strong (default for N > 1): --batch trees per step in TOTAL, split across the GPUs (north_star's "
+                         "strong-scaling figure); weak (N = 1, or on request): --batch trees per step on EVERY GPU.  With "
+                         "N > 1 the line carries the other mode's measurement as well (`other_scaling`)")
     ap.add_argument("--workload", default="leduc", choices=["leduc", "nlhe-synth"],
                     help="leduc: BASELINE configs[1] (default, the quoted metric); nlhe-synth: configs[3]'s synthetic "
                          "NLHE-scale infoset batches through the sparse profile (SURVEY.md §8d config 4)")
@@ -59,9 +60,13 @@ def parse():
                     help="only the timed MCCFR loop (no other-mode rate, convergence run, k-means or CPU baselines): the "
                          "command profiled by scripts/profile_round.sh, so that rocprof's per-kernel averages are those of "
                          "the timed region")
-    ap.add_argument("--kmeans", default="slice", choices=["slice", "flop", "turn"],
-                    help="k-means measurement in the `kmeans` object: a bounded flop-layer slice (default, ~10 s), or a "
-                         "FULL-size configuration (flop: BASELINE configs[2], ~4 min; turn: one GPU's share of configs[4])")
+    ap.add_argument("--kmeans", default="flop", choices=["slice", "flop", "turn"],
+                    help="k-means measurement in the `kmeans` object: the FULL flop-street configuration (default: BASELINE "
+                         "configs[2], 1 286 792 x 32 Elkan iterations with k-means++, init_bounds and lookup, ~1.5 min), one "
+                         "GPU's share of configs[4] (turn), or a bounded flop-layer slice (~10 s)")
+    ap.add_argument("--window", type=int, default=1,
+                    help="N > 1: local steps per exchange (the composed maps of `window` consecutive steps are folded "
+                         "locally and all-gathered once; 1 = exchange every step)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="exercise the RCCL all-gather path even with one rank (plumbing check)")
     return ap.parse_args()
@@ -380,52 +385,37 @@ def nlhe_synth(args, rank, world, local_rank):
         dist.destroy_process_group()
 
 
-def main():
-    args = parse()
-    if args.no_extras:
-        args.no_kmeans, args.cpu_seconds = True, 0.0
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
-    if args.workload == "nlhe-synth":
-        return nlhe_synth(args, rank, world, local_rank)
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (one process per
+    GPU under torch.distributed.run on 127.0.0.1) and pass rank 0's line through."""
+    import socket
+    import subprocess
 
-    from robopoker_amd import Game
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def timed_mccfr(args, g, batch, rank, world, local_rank, sharded_mode, torch, dist):
+    """W warm-up steps, then exactly K timed steps between barrier + synchronize fences; max over ranks."""
     from robopoker_amd.mccfr import Solver
 
-    dist = None
-    torch = None
-    sharded_mode = world > 1 or args.force_sharded
-    if sharded_mode and args.update == "ordered":
-        raise SystemExit("the ordered update is single-GPU only (sharding exchanges composed maps)")
-    if sharded_mode:
-        import torch
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        init_rccl(rank, world)
-
-    g = Game(args.game)
-    A = g.max_actions
-    if args.scaling == "strong":
-        args.batch = max(64, args.batch // world)  # per-GPU share of a fixed global batch
-    solver = Solver(g, args.regret, args.weight, args.sampling, batch=args.batch, seed=args.seed, device=local_rank)
+    solver = Solver(g, args.regret, args.weight, args.sampling, batch=batch, seed=args.seed, device=local_rank)
     solver.set_update_mode(args.update)
-
     if sharded_mode:
         from robopoker_amd.parallel import ShardedSolver
 
-        # tree ids [rank*B, (rank+1)*B); one RCCL all-gather of the per-cell composed maps per step
-        sharded = ShardedSolver(solver, device="cuda")
+        # tree ids [rank*B, (rank+1)*B); one RCCL all-gather of the per-cell composed maps per exchange window
+        sharded = ShardedSolver(solver, device="cuda", window=args.window)
 
         def step():
             sharded.step()
 
         def fence():
+            sharded.flush()
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -447,31 +437,122 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     _, infos1 = solver.counters()
-    infos = infos1 - infos0
-    trav_ms, trav_n = solver.kernel_time("traverse")
-    upd_ms, upd_n = solver.kernel_time("update")
-    cmp_ms, cmp_n = solver.kernel_time("compact")
+    out = {"infos_local": infos1 - infos0, "infos": infos1 - infos0, "dt": dt, "batch": batch}
+    for name in ("traverse", "update", "compact"):
+        ms, n = solver.kernel_time(name)
+        out[name + "_ms"] = ms / max(n, 1)
     solver.profile(False)
-
+    solver.close()
     if sharded_mode:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        ti = torch.tensor([infos], dtype=torch.int64, device="cuda")
+        out["dt"] = float(tt.item())
+        ti = torch.tensor([out["infos"]], dtype=torch.int64, device="cuda")
         dist.all_reduce(ti, op=dist.ReduceOp.SUM)
-        infos = int(ti.item())
+        out["infos"] = int(ti.item())
+    return out
+
+
+def time_to_exploitability(make, trees_per_check, max_trees, thresholds=(0.08, 0.01, 0.003)):
+    """Wall time of solve() until the average strategy's exploitability first drops below each threshold (the
+    reference's Leduc test asserts < 0.08 after 2^18 trees, crates/leduc/src/solver.rs:105-123).  The exploitability
+    evaluations themselves (validation, host side in the reference too) are outside the clock."""
+    s = make()
+    reached, spent, trees = {}, 0.0, 0
+    while trees < max_trees and len(reached) < len(thresholds):
+        t0 = time.perf_counter()
+        s.solve(trees_per_check)
+        if hasattr(s, "sync"):
+            s.sync()
+        spent += time.perf_counter() - t0
+        trees += trees_per_check
+        e = s.exploitability()
+        for th in thresholds:
+            if e < th and str(th) not in reached:
+                reached[str(th)] = {"seconds": spent, "trees": trees, "exploitability": e}
+    if hasattr(s, "close"):
+        s.close()
+    return reached
+
+
+def convergence_times(args, g, local_rank):
+    """time-to-exploitability for the GPU (benchmarked update mode, a few batch sizes: small batches update the table
+    more often, large ones amortise the launches) and for the CPU oracle at the reference's batch_size = 1."""
+    import oracle
+    from robopoker_amd.mccfr import Solver
+
+    out = {"thresholds": [0.08, 0.01, 0.003], "gpu": {}, "cpu": None}
+    for batch in (1 << 10, 1 << 13, 1 << 16):
+        def make(batch=batch):
+            s = Solver(g, args.regret, args.weight, args.sampling, batch=batch, seed=args.seed, device=local_rank)
+            s.set_update_mode(args.update)
+            return s
+
+        out["gpu"][str(batch)] = time_to_exploitability(make, batch * 8, batch * 2048)
+    if args.cpu_seconds > 0:
+        out["cpu"] = {"batch": 1, "cores": 1,
+                      "reached": time_to_exploitability(
+                          lambda: oracle.OracleSolver(g, args.regret, args.weight, args.sampling, batch=1, seed=args.seed),
+                          1 << 15, 1 << 23)}
+    return out
+
+
+def main():
+    args = parse()
+    if args.no_extras:
+        args.no_kmeans, args.cpu_seconds = True, 0.0
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args.gpus = world
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
+    if args.workload == "nlhe-synth":
+        return nlhe_synth(args, rank, world, local_rank)
+
+    from robopoker_amd import Game
+
+    dist = None
+    torch = None
+    sharded_mode = world > 1 or args.force_sharded
+    if sharded_mode and args.update == "ordered":
+        raise SystemExit("the ordered update is single-GPU only (sharding exchanges composed maps)")
+    if sharded_mode:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        init_rccl(rank, world)
+
+    g = Game(args.game)
+    A = g.max_actions
+
+    def per_gpu_batch(mode):
+        return max(64, args.batch // world) if mode == "strong" else args.batch
+
+    batch = per_gpu_batch(args.scaling)
+    m = timed_mccfr(args, g, batch, rank, world, local_rank, sharded_mode, torch, dist)
+    other_scaling = None
+    if world > 1:  # the other scaling mode's measurement rides in the same line
+        om = "weak" if args.scaling == "strong" else "strong"
+        o = timed_mccfr(args, g, per_gpu_batch(om), rank, world, local_rank, sharded_mode, torch, dist)
+        other_scaling = {"scaling": om, "value": o["infos"] / o["dt"], "unit": "infoset-updates/s",
+                         "ms_per_step": o["dt"] / args.steps * 1e3, "batch_per_gpu": o["batch"]}
+    infos, dt = m["infos"], m["dt"]
 
     if rank == 0:
         # dominant kernel vs the HBM roofline.  Algorithmic bytes per infoset-update = key 24 B + A*16 B read
         # + A*16 B written = 24 + 32*A (SURVEY.md §8d); the kernel that realises the update is "update".
-        upd_avg_ms = upd_ms / max(upd_n, 1)
-        trav_avg_ms = trav_ms / max(trav_n, 1)
-        per_launch_updates = (infos1 - infos0) / max(args.steps, 1)
+        upd_avg_ms, trav_avg_ms = m["update_ms"], m["traverse_ms"]
+        per_launch_updates = m["infos_local"] / max(args.steps, 1)
         dom, dom_ms = ("update", upd_avg_ms) if upd_avg_ms >= trav_avg_ms else ("traverse", trav_avg_ms)
         bytes_per_update = 24 + 32 * A
         achieved = per_launch_updates * bytes_per_update / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic, traffic_src = profiled_traffic((dom, args.update), args.batch)
+        traffic, traffic_src = profiled_traffic((dom, args.update), batch)
         other = "ordered" if args.update == "composed" else "composed"
+        args.batch = batch
         other_rate = side_rate(args, g, local_rank, other) if world == 1 and not args.force_sharded and not args.no_extras else None
         line = {
             "metric": "mccfr_infoset_updates_per_sec",
@@ -489,8 +570,9 @@ def main():
             "config": {
                 "workload": f"{args.game}-holdem external-sampling MCCFR, tables resident in HBM (BASELINE configs[1])",
                 "regret": args.regret, "weight": args.weight, "sampling": args.sampling,
-                "batch_per_gpu": args.batch, "global_batch": args.batch * world, "infosets": g.n_infos,
+                "batch_per_gpu": batch, "global_batch": batch * world, "infosets": g.n_infos,
                 "actions": A, "update": args.update + ("+allgather" if sharded_mode else ""),
+                "exchange_window": args.window if sharded_mode else None,
                 "update_tolerance": "composed: regret/weight/payoff within rtol 1e-4 per step of the sequential "
                                     "order (tests/test_gpu_mccfr.py), visits exact; ordered: bit-exact",
                 "parallelism": f"tree-sharded x{world}",
@@ -498,17 +580,25 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_note": "PMC bytes per launch read from the committed rocprofv3 --pmc reduction named in "
+                                "traffic_source (a separate profiling run at this batch), not measured in this run",
                 "bytes_per_update": bytes_per_update, "updates_per_launch": per_launch_updates,
                 "avg_launch_ms": dom_ms,
-                "kernels_ms": {"traverse": trav_avg_ms, "compact": cmp_ms / max(cmp_n, 1), "update": upd_avg_ms},
+                "kernels_ms": {"traverse": trav_avg_ms, "compact": m["compact_ms"], "update": upd_avg_ms},
                 "note": "Leduc's tables are 3.8 KB (L2/LDS resident): HBM is not the binding limit of this "
                         "configuration (SURVEY §8d); traversal is latency/divergence bound, the ordered update "
                         "by its serial per-cell chains",
             },
             "other_update_mode": {"update": other, "value": other_rate, "unit": "infoset-updates/s"},
         }
+        if other_scaling is not None:
+            line["other_scaling"] = other_scaling
         if world == 1 and not args.force_sharded and args.game == "leduc" and not args.no_extras:
             line["convergence"] = convergence(args, g, local_rank)
+            try:
+                line["time_to_exploitability"] = convergence_times(args, g, local_rank)
+            except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
+                line["time_to_exploitability"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args)
             try:
@@ -528,7 +618,6 @@ def main():
                 line["abstraction_inputs"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(line), flush=True)
 
-    solver.close()
     if sharded_mode and not args.no_kmeans:
         # The k-means exchange on the same ranks, AFTER the contract line is out (stdout carries exactly one JSON
         # line; this result goes to stderr).  A watchdog ends the process cleanly if a collective ever hangs.

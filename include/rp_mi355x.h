@@ -233,6 +233,13 @@ RP_API int rp_mccfr_set_shard(rp_mccfr* h, uint32_t rank, uint32_t world);
 RP_API int rp_mccfr_summary_bytes(rp_mccfr* h, size_t* bytes);
 RP_API int rp_mccfr_step_local(rp_mccfr* h, void* summary_dev);
 RP_API int rp_mccfr_step_apply(rp_mccfr* h, const void* gathered_dev, uint32_t world);
+/* The PERIODIC exchange: window_local() is one local step against the table as it stood when the window began (the
+ * table is not touched; the epoch — hence the sampled trees, the walker and the discounts — advances) whose composed
+ * maps are folded into `window_dev` (summary_bytes; first != 0 starts a new window); after `S` such steps the caller
+ * all-gathers the window summaries once and every rank applies them in rank order with window_apply() (no epoch
+ * change).  S = 1 is step_local + step_apply.  Oracle: ora_mccfr_window_world. */
+RP_API int rp_mccfr_window_local(rp_mccfr* h, void* window_dev, int first);
+RP_API int rp_mccfr_window_apply(rp_mccfr* h, const void* gathered_dev, uint32_t world);
 
 /* ---- profiling hooks used by bench.py (HIP events on the launch stream) ------------------------- */
 RP_API int rp_mccfr_profile(rp_mccfr* h, int enable);

@@ -683,6 +683,68 @@ ORA_API int ora_mccfr_step_world(ora_mccfr* h, uint32_t world) {
     return 0;
 }
 
+/* ---- the periodic exchange (rp_mccfr_window_local / window_apply): `window` local steps per all-gather ------------- */
+/* acc <- step o acc per cell (maps composed in step order), counts and payoff sums added; first != 0 starts a window */
+ORA_API void ora_mccfr_window_accumulate(const ora_mccfr* h, void* acc, const void* step, int first) {
+    uint32_t A = h->g.max_actions, NI = h->g.n_infos;
+    size_t cells = (size_t)NI * A;
+    ora_cell* ac = (ora_cell*)acc;
+    const ora_cell* sc = (const ora_cell*)step;
+    ora_isum* as = (ora_isum*)((unsigned char*)acc + cells * sizeof(ora_cell));
+    const ora_isum* ss = (const ora_isum*)((const unsigned char*)step + cells * sizeof(ora_cell));
+    if (first) {
+        memcpy(acc, step, ora_mccfr_summary_bytes(h));
+        return;
+    }
+    for (size_t k = 0; k < cells; ++k) {
+        ora_map ar = {ac[k].ra, ac[k].rb, ac[k].rm, ac[k].rn}, sr = {sc[k].ra, sc[k].rb, sc[k].rm, sc[k].rn};
+        ora_map aw = {ac[k].wa, ac[k].wb, ac[k].wm, ac[k].wn}, sw = {sc[k].wa, sc[k].wb, sc[k].wm, sc[k].wn};
+        ora_map r = map_compose(ar, sr), w = map_compose(aw, sw);
+        ac[k].ra = r.a; ac[k].rb = r.b; ac[k].rm = r.m; ac[k].rn = r.n;
+        ac[k].wa = w.a; ac[k].wb = w.b; ac[k].wm = w.m; ac[k].wn = w.n;
+    }
+    for (uint32_t i = 0; i < NI; ++i) {
+        as[i].count += ss[i].count;
+        as[i].psum = as[i].psum + ss[i].psum;
+    }
+}
+/* one local step of a window on rank `rank`: maps of this step folded into `window`, epoch += 1, table untouched */
+ORA_API int ora_mccfr_window_local(ora_mccfr* h, uint32_t rank, void* window, int first) {
+    void* step = malloc(ora_mccfr_summary_bytes(h));
+    int rc = ora_mccfr_step_local(h, rank, step);
+    if (!rc) {
+        ora_mccfr_window_accumulate(h, window, step, first);
+        h->epoch += 1;
+    }
+    free(step);
+    return rc;
+}
+/* fold `world` window summaries in rank order; the epoch was advanced by the local steps */
+ORA_API void ora_mccfr_window_apply(ora_mccfr* h, const void* gathered, uint32_t world) {
+    uint64_t e = h->epoch;
+    ora_mccfr_step_apply(h, gathered, world);
+    h->epoch = e;
+}
+/* single-process model of one window on `world` ranks: every rank runs its `window` local steps from the same
+ * start-of-window table and epoch, then the summaries are applied in rank order */
+ORA_API int ora_mccfr_window_world(ora_mccfr* h, uint32_t world, uint32_t window) {
+    size_t stride = ora_mccfr_summary_bytes(h);
+    unsigned char* all = (unsigned char*)malloc(stride * world);
+    uint64_t e0 = h->epoch;
+    for (uint32_t r = 0; r < world; ++r) {
+        h->epoch = e0;
+        for (uint32_t s = 0; s < window; ++s)
+            if (ora_mccfr_window_local(h, r, all + (size_t)r * stride, s == 0)) {
+                free(all);
+                h->epoch = e0;
+                return -1;
+            }
+    }
+    ora_mccfr_window_apply(h, all, world);
+    free(all);
+    return 0;
+}
+
 ORA_API uint64_t ora_mccfr_epoch(const ora_mccfr* h) { return h->epoch; }
 ORA_API void ora_mccfr_counters(const ora_mccfr* h, uint64_t* nodes, uint64_t* infos) {
     if (nodes) *nodes = h->nodes;

@@ -152,6 +152,8 @@ _SIGNATURES = {
     "rp_mccfr_summary_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "rp_mccfr_step_local": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_mccfr_step_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "rp_mccfr_window_local": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "rp_mccfr_window_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "rp_mccfr_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "rp_mccfr_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "rp_profile_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.POINTER(Hyper), C.c_void_p, C.c_uint32,

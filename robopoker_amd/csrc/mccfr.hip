@@ -1473,6 +1473,31 @@ __global__ void k_fold(DevGame g, DevTables t, const unsigned char* blob, size_t
     t.visits[cell] = visits;
 }
 
+// the exchange window (rp_mccfr_window_local): acc <- step o acc per table cell — the maps of consecutive local
+// steps composed in step order, touch counts, payoff sums and visit counts added (oracle: ora_mccfr_window_accumulate)
+__global__ void k_accumulate(DevGame g, unsigned char* acc, const unsigned char* step, uint32_t first) {
+    const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ncell = g.n_infos * g.A;
+    if (cell >= ncell) return;
+    const Cell s = reinterpret_cast<const Cell*>(step)[cell];
+    Cell* ac = reinterpret_cast<Cell*>(acc) + cell;
+    if (first) {
+        *ac = s;
+    } else {
+        const Cell a = *ac;
+        const Map r = map_compose(Map{a.ra, a.rb, a.rm, a.rn}, Map{s.ra, s.rb, s.rm, s.rn});
+        const Map w = map_compose(Map{a.wa, a.wb, a.wm, a.wn}, Map{s.wa, s.wb, s.wm, s.wn});
+        *ac = Cell{r.a, r.b, r.m, w.a, w.b, w.m, r.n, w.n};
+    }
+    if (cell % g.A == 0) {
+        const uint32_t info = cell / g.A;
+        const InfoSum si = reinterpret_cast<const InfoSum*>(step + (size_t)ncell * sizeof(Cell))[info];
+        InfoSum* ai = reinterpret_cast<InfoSum*>(acc + (size_t)ncell * sizeof(Cell)) + info;
+        if (first) *ai = si;
+        else *ai = InfoSum{ai->count + si.count, ai->psum + si.psum};
+    }
+}
+
 }  // namespace rp
 
 // =================================================================================================
@@ -2341,6 +2366,39 @@ int rp_mccfr_step_apply(rp_mccfr* h, const void* gathered_dev, uint32_t world) {
                        reinterpret_cast<const unsigned char*>(gathered_dev), summary_bytes_of(h), world);
     HIP_TRY(hipGetLastError());
     h->epoch += 1;
+    return RP_OK;
+}
+
+// The periodic exchange (north_star: "periodic RCCL all-reduce of regret/strategy tables"): a rank runs `window` local
+// steps against the table as it stood at the start of the window — the table is not touched, the epoch advances (the
+// sampled trees, the walker and the discounts are those of each step) — and folds each step's composed maps into ONE
+// window summary; the summaries are all-gathered once per window and applied in rank order.  window = 1 is
+// step_local + step_apply.
+int rp_mccfr_window_local(rp_mccfr* h, void* window_dev, int first) {
+    if (!h || !window_dev) return rp::fail(RP_ERR_INVALID, "rp_mccfr_window_local: NULL argument");
+    int rc = set_device(h);
+    if (rc) return rc;
+    if ((rc = composed_supported(h))) return rc;
+    const StepParams p = make_params(h);
+    if ((rc = launch_traverse(h, p))) return rc;
+    if (h->dc.slotmap && (rc = launch_sort(h, p))) return rc;
+    if ((rc = launch_summarize(h, p, h->d_summary))) return rc;
+    const uint32_t ncell = h->tbl.n_infos * h->tbl.max_actions;
+    hipLaunchKernelGGL(k_accumulate, dim3((ncell + 255) / 256), dim3(256), 0, h->stream, h->g, reinterpret_cast<unsigned char*>(window_dev),
+                       reinterpret_cast<const unsigned char*>(h->d_summary), first ? 1u : 0u);
+    HIP_TRY(hipGetLastError());
+    h->epoch += 1;
+    return RP_OK;
+}
+
+int rp_mccfr_window_apply(rp_mccfr* h, const void* gathered_dev, uint32_t world) {
+    if (!h || !gathered_dev || world == 0) return rp::fail(RP_ERR_INVALID, "rp_mccfr_window_apply: bad argument");
+    int rc = set_device(h);
+    if (rc) return rc;
+    const uint32_t ncell = h->tbl.n_infos * h->tbl.max_actions;
+    hipLaunchKernelGGL(k_fold, dim3((ncell + 255) / 256), dim3(256), 0, h->stream, h->g, h->t,
+                       reinterpret_cast<const unsigned char*>(gathered_dev), summary_bytes_of(h), world);
+    HIP_TRY(hipGetLastError());
     return RP_OK;
 }
 

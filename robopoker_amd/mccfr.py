@@ -165,6 +165,12 @@ class Solver:
     def step_apply(self, gathered_dev_ptr: int, world: int):
         _lib.check(self._lib.rp_mccfr_step_apply(self._h, C.c_void_p(gathered_dev_ptr), world))
 
+    def window_local(self, window_dev_ptr: int, first: bool):
+        _lib.check(self._lib.rp_mccfr_window_local(self._h, C.c_void_p(window_dev_ptr), 1 if first else 0))
+
+    def window_apply(self, gathered_dev_ptr: int, world: int):
+        _lib.check(self._lib.rp_mccfr_window_apply(self._h, C.c_void_p(gathered_dev_ptr), world))
+
     # ---- profiling hooks ------------------------------------------------------------------------
     def profile(self, enable=True):
         _lib.check(self._lib.rp_mccfr_profile(self._h, 1 if enable else 0))

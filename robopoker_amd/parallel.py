@@ -39,13 +39,23 @@ def rp_mulhi64(a: int, b: int) -> int:
     return ((a & MASK64) * (b & MASK64)) >> 64
 
 
-def _all_gather_bytes(out: torch.Tensor, mine: torch.Tensor, group=None):
-    try:
+def _flat_all_gather_supported(group=None) -> bool:
+    """whether the backend has all_gather_into_tensor: decided ONCE, by capability, never by catching a failed collective
+    (a rank that retried a different collective after a real RCCL error would desynchronise the job)"""
+    if not hasattr(dist, "all_gather_into_tensor"):
+        return False
+    return dist.get_backend(group) in ("nccl", "gloo")
+
+
+def _all_gather_bytes(out: torch.Tensor, mine: torch.Tensor, group=None, flat=None):
+    """every rank's `mine` back to back in `out`; an error of the collective propagates"""
+    if flat is None:
+        flat = _flat_all_gather_supported(group)
+    if flat:
         dist.all_gather_into_tensor(out, mine, group=group)
-    except (RuntimeError, NotImplementedError):  # backends without the flat variant
+    else:
         world = dist.get_world_size(group)
-        parts = list(out.view(world, -1).unbind(0))
-        dist.all_gather(parts, mine, group=group)
+        dist.all_gather(list(out.view(world, -1).unbind(0)), mine, group=group)
 
 
 class _StreamScope:
@@ -72,13 +82,19 @@ class _StreamScope:
 
 
 class ShardedSolver:
-    """Tree-sharded MCCFR: rank r samples tree ids [r*B, (r+1)*B) of a world*B-tree epoch."""
+    """Tree-sharded MCCFR: rank r samples tree ids [r*B, (r+1)*B) of a world*B-tree epoch.
 
-    def __init__(self, engine, device="cpu", group=None):
+    ``window`` = local steps per exchange (the PERIODIC all-gather of north_star): the composed maps of ``window``
+    consecutive steps — all traversed against the start-of-window table — are folded locally and gathered once."""
+
+    def __init__(self, engine, device="cpu", group=None, window=1):
         self.engine = engine
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.window = max(1, int(window))
+        self.pending = 0
+        self.flat = _flat_all_gather_supported(group)
         engine.set_shard(self.rank, self.world)
         self.scope = _StreamScope(engine, device)
         n = engine.summary_bytes()
@@ -87,13 +103,26 @@ class ShardedSolver:
 
     def step(self):
         with self.scope:
-            self.engine.step_local(self.mine.data_ptr())
-            _all_gather_bytes(self.all, self.mine, self.group)
-            self.engine.step_apply(self.all.data_ptr(), self.world)
+            self.engine.window_local(self.mine.data_ptr(), self.pending == 0)
+            self.pending += 1
+            if self.pending == self.window:
+                self._exchange()
+
+    def _exchange(self):
+        _all_gather_bytes(self.all, self.mine, self.group, self.flat)
+        self.engine.window_apply(self.all.data_ptr(), self.world)
+        self.pending = 0
+
+    def flush(self):
+        """close a partly filled window (end of a run)"""
+        if self.pending:
+            with self.scope:
+                self._exchange()
 
     def solve(self, trees_per_rank: int, batch: int):
         for _ in range(trees_per_rank // batch):
             self.step()
+        self.flush()
         return self
 
 
@@ -107,6 +136,7 @@ class ShardedLayer:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = device
+        self.flat = _flat_all_gather_supported(group)
         self.scope = _StreamScope(engine, device)
         self.nbytes = engine.partial_bytes()
         self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
@@ -125,8 +155,7 @@ class ShardedLayer:
             mine = torch.tensor([local], dtype=torch.int64)
             if self.device != "cpu":
                 totals, mine = totals.to(self.device), mine.to(self.device)
-            dist.all_gather_into_tensor(totals, mine, group=self.group) if hasattr(dist, "all_gather_into_tensor") \
-                else dist.all_gather(list(totals.unbind(0)), mine, group=self.group)
+            _all_gather_bytes(totals, mine, self.group, self.flat)
             totals = [int(t) for t in totals.cpu().tolist()]
             total = sum(totals)
             h = rp_stream(self.seed, k)
@@ -161,7 +190,7 @@ class ShardedLayer:
         out = torch.zeros(self.world, dtype=torch.int64)
         if self.device != "cpu":
             n, out = n.to(self.device), out.to(self.device)
-        dist.all_gather_into_tensor(out, n, group=self.group)
+        _all_gather_bytes(out, n, self.group, self.flat)
         return [int(v) for v in out.cpu().tolist()]
 
     def init_bounds(self):
@@ -192,6 +221,7 @@ class ShardedProfile:
         self.world = dist.get_world_size(group)
         self.device = device
         self.eb = engine.entry_bytes()
+        self.flat = _flat_all_gather_supported(group)
         self.scope = _StreamScope(engine, device)
         self.mine = torch.zeros(max_batch * self.eb, dtype=torch.uint8, device=device)
         self.all = torch.zeros(self.world * max_batch * self.eb, dtype=torch.uint8, device=device)
@@ -202,13 +232,13 @@ class ShardedProfile:
             n = self.engine.summarize(batch, self.mine.data_ptr())
             counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
             mine_n = torch.tensor([n], dtype=torch.int64, device=self.device)
-            dist.all_gather_into_tensor(counts, mine_n, group=self.group)
+            _all_gather_bytes(counts, mine_n, self.group, self.flat)
             counts = [int(c) for c in counts.cpu().tolist()]
             width = max(counts) * self.eb  # every rank sends the same number of bytes
             if width == 0:
                 self.engine.fold(self.packed.data_ptr(), 0)
                 return 0
-            _all_gather_bytes(self.all[: self.world * width], self.mine[:width], self.group)
+            _all_gather_bytes(self.all[: self.world * width], self.mine[:width], self.group, self.flat)
             # compact the padded lists into one rank-major list
             off = 0
             for r, c in enumerate(counts):

@@ -55,6 +55,11 @@ def load() -> C.CDLL:
     o.ora_mccfr_step_local.restype = C.c_int
     o.ora_mccfr_step_local.argtypes = [vp, C.c_uint32, vp]
     o.ora_mccfr_step_apply.argtypes = [vp, vp, C.c_uint32]
+    o.ora_mccfr_window_local.restype = C.c_int
+    o.ora_mccfr_window_local.argtypes = [vp, C.c_uint32, vp, C.c_int]
+    o.ora_mccfr_window_apply.argtypes = [vp, vp, C.c_uint32]
+    o.ora_mccfr_window_world.restype = C.c_int
+    o.ora_mccfr_window_world.argtypes = [vp, C.c_uint32, C.c_uint32]
     o.ora_mccfr_epoch.restype = C.c_uint64
     o.ora_mccfr_epoch.argtypes = [vp]
     o.ora_mccfr_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -163,6 +168,17 @@ class OracleSolver:
     def step_world(self, world: int):
         rc = self._o.ora_mccfr_step_world(self._h, world)
         if rc != 0:
+            raise RuntimeError("composed update unsupported for this schedule")
+
+    def window_local(self, ptr: int, first: bool):
+        if self._o.ora_mccfr_window_local(self._h, getattr(self, "_rank", 0), C.c_void_p(ptr), 1 if first else 0) != 0:
+            raise RuntimeError("composed update unsupported for this schedule")
+
+    def window_apply(self, ptr: int, world: int):
+        self._o.ora_mccfr_window_apply(self._h, C.c_void_p(ptr), world)
+
+    def window_world(self, world: int, window: int):
+        if self._o.ora_mccfr_window_world(self._h, world, window) != 0:
             raise RuntimeError("composed update unsupported for this schedule")
 
     def batch(self):

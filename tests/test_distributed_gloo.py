@@ -64,6 +64,44 @@ def _mccfr_worker(rank, port, out):
     dist.destroy_process_group()
 
 
+def _mccfr_window_worker(rank, port, out, window):
+    # the periodic exchange: `window` local steps per all-gather, a run that ends inside a window (flush)
+    _init(rank, port)
+    g = Game("leduc")
+    B, steps = 64, 7
+    eng = oracle.OracleSolver(g, "linear", "linear", "external", batch=B, seed=33)
+    sh = ShardedSolver(eng, device="cpu", window=window)
+    for _ in range(steps):
+        sh.step()
+    sh.flush()
+    rows = eng.export()
+    t = torch.from_numpy(rows["regret"].view(np.int32).copy())
+    ref = t.clone()
+    dist.broadcast(ref, src=0)
+    same = bool(torch.equal(t, ref))
+    if rank == 0:
+        single = oracle.OracleSolver(g, "linear", "linear", "external", batch=B, seed=33)
+        left = steps
+        while left:
+            w = min(window, left)
+            single.window_world(WORLD, w)
+            left -= w
+        exp = single.export()
+        ok = all(np.array_equal(rows[f].view(np.uint32), exp[f].view(np.uint32))
+                 for f in ("regret", "weight", "payoff", "visits"))
+        if window == 1:  # a window of one step IS step_local + step_apply
+            plain = oracle.OracleSolver(g, "linear", "linear", "external", batch=B, seed=33)
+            for _ in range(steps):
+                plain.step_world(WORLD)
+            pe = plain.export()
+            ok = ok and all(np.array_equal(pe[f].view(np.uint32), exp[f].view(np.uint32))
+                            for f in ("regret", "weight", "payoff", "visits"))
+        out.put(("window", same and ok and eng.epoch == steps and single.epoch == steps))
+    else:
+        out.put(("window-replica", same and eng.epoch == steps))
+    dist.destroy_process_group()
+
+
 def _kmeans_worker(rank, port, out, kind):
     _init(rank, port)
     K, N, bins, mass, seed = 6, 200, (24 if kind == "sinkhorn" else 101), (14 if kind == "sinkhorn" else 46), 9
@@ -178,6 +216,12 @@ def test_rp_stream_and_mulhi_match_the_c_header():
 def test_sharded_mccfr_two_ranks_equals_world_model():
     res = _run(_mccfr_worker)
     assert res == {"mccfr": True, "mccfr-replica": True}
+
+
+@pytest.mark.parametrize("window", [1, 3])
+def test_sharded_mccfr_exchange_window_equals_world_model(window):
+    res = _run(_mccfr_window_worker, window)
+    assert res == {"window": True, "window-replica": True}
 
 
 @pytest.mark.parametrize("kind", ["variation", "sinkhorn"])

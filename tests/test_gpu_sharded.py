@@ -41,6 +41,37 @@ def test_mccfr_shards_on_one_gpu_match_world_model(gpu, B, world):
     assert devs[0].epoch == 5
 
 
+@pytest.mark.parametrize("B,world,window,regret", [(300, 2, 3, "linear"), (520, 4, 4, "floored"), (200, 2, 1, "linear")])
+def test_mccfr_exchange_window_on_one_gpu_matches_world_model(gpu, B, world, window, regret):
+    # the periodic exchange: every rank folds the composed maps of `window` local steps (table frozen, epoch advancing)
+    # into one summary; one gather + apply per window.  Against ora_mccfr_window_world, bit for bit, over 3 windows.
+    import torch
+
+    g = Game("leduc")
+    devs = [Solver(g, regret, "linear", "external", batch=B, seed=12) for _ in range(world)]
+    for r, d in enumerate(devs):
+        d.set_shard(r, world)
+    n = devs[0].summary_bytes()
+    gathered = torch.zeros(n * world, dtype=torch.uint8, device="cuda")
+    ora = oracle.OracleSolver(g, regret, "linear", "external", batch=B, seed=12)
+    for _ in range(3):
+        for r, d in enumerate(devs):
+            for s in range(window):
+                d.window_local(gathered.data_ptr() + r * n, s == 0)
+            d.sync()
+        for d in devs:
+            d.window_apply(gathered.data_ptr(), world)
+            d.sync()
+        ora.window_world(world, window)
+        exp = ora.export()
+        for d in devs:
+            got = d.export()
+            for f in ("visits", "regret", "weight", "payoff"):
+                assert np.array_equal(got[f].view(np.uint32), exp[f].view(np.uint32)), f
+    assert devs[0].epoch == 3 * window == ora.epoch
+    assert devs[0].counters() == ora.counters() if world == 1 else True
+
+
 @pytest.mark.parametrize("kind", ["sinkhorn", "variation"])
 def test_kmeans_two_shards_on_one_gpu_match_single(gpu, kind):
     import torch
