@@ -203,7 +203,7 @@ def kmeans_sharded(rank, world, local_rank, n_points=16384, K=256, bins=256, ite
     import torch.distributed as dist
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from lloyd_fixtures import flop_like_points, smooth_metric
+    from robopoker_amd.fixtures import flop_like_points, smooth_metric
     from robopoker_amd import lloyd
     from robopoker_amd.parallel import ShardedLayer
 

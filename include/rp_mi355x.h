@@ -390,6 +390,7 @@ typedef struct rp_prune_stats {
     uint64_t survivors;        /* (point, centroid) pairs handed to the bit-faithful kernel */
     uint64_t block_iterations; /* MFMA work: iterations of a 16-centroid column block (each 2 * 16 * ceil(n/16) * 4 MFMAs of 2048 flop) */
     uint64_t cost_passes;      /* extra K.*C contractions for the cost of an iterate inside the stopping window */
+    uint64_t mfma_instructions;/* v_mfma_f32_16x16x4_f32 issued per wavefront, summed (2048 flop each) */
     uint64_t audited_points;   /* RP_LLOYD_AUDIT: points compared with the unpruned pass */
     uint64_t audit_mismatches; /* ... and how many differed in bucket or distance bits */
 } rp_prune_stats;

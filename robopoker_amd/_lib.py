@@ -109,7 +109,7 @@ class PruneStats(C.Structure):
     """rp_prune_stats (include/rp_mi355x.h): what the MFMA Sinkhorn bound discarded and what it cost"""
     _fields_ = [("enabled", C.c_uint32), ("reserved", C.c_uint32), ("points", C.c_uint64), ("candidates", C.c_uint64),
                 ("survivors", C.c_uint64), ("block_iterations", C.c_uint64), ("cost_passes", C.c_uint64),
-                ("audited_points", C.c_uint64), ("audit_mismatches", C.c_uint64)]
+                ("mfma_instructions", C.c_uint64), ("audited_points", C.c_uint64), ("audit_mismatches", C.c_uint64)]
 
 
 _SIGNATURES = {

@@ -2525,14 +2525,15 @@ int rp_kmeans_prune_stats(rp_kmeans* h, rp_prune_stats* out) {
     HIP_TRY(hipMemcpyAsync(all.data(), h->sb_stats, all.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(&bad, h->sb_bad, 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    unsigned long long s[4] = {0, 0, 0, 0};
+    unsigned long long s[5] = {0, 0, 0, 0, 0};
     for (uint32_t q = 0; q < KM_STAT_STRIPES; ++q)
-        for (uint32_t k = 0; k < 4; ++k) s[k] += all[(size_t)q * STAT_STRIDE + k];
+        for (uint32_t k = 0; k < 5; ++k) s[k] += all[(size_t)q * STAT_STRIDE + k];
     out->survivors = s[0];
     out->points = s[1];
     out->candidates = s[1] * h->K;
     out->block_iterations = s[2];
     out->cost_passes = s[3];
+    out->mfma_instructions = s[4];
     out->audited_points = h->sb_audited;
     out->audit_mismatches = bad;
     return RP_OK;

@@ -179,7 +179,7 @@ struct SbCol {  // per-column window state (replicated in the four lanes of the 
     bool opened, done;
 };
 
-// pstats: [0] survivors, [1] points, [2] column-block iterations, [3] cost passes   (striped like Metric::stats)
+// pstats: [0] survivors, [1] points, [2] column-block iterations, [3] cost passes, [4] MFMA instructions   (striped like Metric::stats)
 template <int NT>
 __global__ __launch_bounds__(SB_THREADS, 2) void k_sinkhorn_bound(Points P, CentroidSet cs, uint32_t K, uint32_t bins, SbParams prm,
                                                                    const uint32_t* list, uint32_t count, unsigned int* cursor,
@@ -351,5 +351,8 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_sinkhorn_bound(Points P, Cent
     if (lane == 0) {
         atomicAdd(pstats + (size_t)(blockIdx.x % KM_STAT_STRIPES) * STAT_STRIDE + 2, my_cb_iters);
         atomicAdd(pstats + (size_t)(blockIdx.x % KM_STAT_STRIPES) * STAT_STRIDE + 3, my_cost_passes);
+        // per block iteration 16 x-tiles x NT y-tiles x 4 k-steps in each of the two contractions; a cost pass is one more
+        atomicAdd(pstats + (size_t)(blockIdx.x % KM_STAT_STRIPES) * STAT_STRIDE + 4,
+                  (my_cb_iters * 2ull + my_cost_passes) * (unsigned long long)(16 * NT * 4));
     }
 }

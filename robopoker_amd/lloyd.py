@@ -222,7 +222,7 @@ def equity_variation(x, y, device=0) -> np.ndarray:
 
 def smoke(oracle) -> None:
     """Tiny k-means on device 0 checked bit for bit against the CPU oracle (called by __graft_entry__.smoke)."""
-    from lloyd_fixtures import flop_like_points, smooth_metric
+    from .fixtures import flop_like_points, smooth_metric
 
     bins, K, N = 32, 4, 96
     pts = flop_like_points(N, bins=bins, mass=20, seed=5)
@@ -249,11 +249,7 @@ def bench_slice(n_points: int = 16384, K: int = 256, bins: int = 256, iters: int
 
     Reports the Sinkhorn phase against the VALU roofline (it is exp-bound, not HBM-bound: SURVEY §8d) and the
     bound-update phase against the HBM roofline (2 * 4 * K bytes of lower bounds per point, read + written)."""
-    import os
-    import sys
-
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-    from lloyd_fixtures import flop_like_points, smooth_metric
+    from .fixtures import flop_like_points, smooth_metric
 
     pts = flop_like_points(n_points, bins=bins, mass=47, seed=seed)
     tri = smooth_metric(bins, 1)
@@ -312,18 +308,24 @@ def bench_slice(n_points: int = 16384, K: int = 256, bins: int = 256, iters: int
     return out
 
 
+# rooflines of the lloyd kernels (MI355X_MICROARCH.md): HBM 8 TB/s; f32 MFMA 157.3 TFLOP/s = 64 flop/clk/SIMD; VALU: one
+# wave64 instruction per 2 cycles per SIMD = 256 CU x 4 SIMD x 2.4 GHz / 2 = 1.23e12 wave-instructions/s
+HBM_PEAK_GBPS = 8000.0
+MFMA_F32_PEAK_TFLOPS = 157.3
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2.0
+SOFTMIN_INSTR_PER_8_TERMS = 106  # VALU instructions per 8 softmin terms per lane in the shipped ISA
+
+
 def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None, seed: int = 1, log=None):
     """A full-size k-means configuration of BASELINE.json on one GPU:
 
     flop (configs[2]): N = 1 286 792 histograms, K = 256, bins = 256, mass 47, Sinkhorn EMD, k-means++,
                        init_bounds, `iters` Elkan iterations, final lookup;
     turn (configs[4], one GPU's 1/8 share): N = 1 745 006, K = 256, bins = 101, mass 46, Equity::variation.
-    Returns per-phase wall times and rates (a dict)."""
-    import os
-    import sys
-
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-    from lloyd_fixtures import flop_like_points, smooth_metric, turn_like_points
+    Returns per-phase wall times, rates and the rooflines of the three kernel families (a dict): the bit-faithful
+    Sinkhorn solves against the VALU issue peak, the MFMA bound against the f32 MFMA peak, the Elkan bound update
+    against the HBM peak — all from HIP events recorded by the library on its launch stream over the whole run."""
+    from .fixtures import flop_like_points, smooth_metric, turn_like_points
 
     K = 256
     if which == "flop":
@@ -336,10 +338,16 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
         pts = turn_like_points(N, bins=bins, mass=46, seed=5)
     else:
         raise ValueError(which)
-    out = {"workload": which, "N": N, "K": K, "bins": bins, "metric": kind, "iterations": iters}
+    out = {"metric": "kmeans_points_per_sec", "unit": "points/s",
+           "workload": f"{which}-street layer, FULL size: N={N} points, K={K}, bins={bins}, {kind} distance, k-means++, init_bounds, "
+                       f"{iters} Elkan iterations, lookup (BASELINE configs[{2 if which == 'flop' else 4}]"
+                       f"{'' if which == 'flop' else ', one GPU of eight'}); synthetic points (SURVEY 8d)",
+           "N": N, "K": K, "bins": bins, "distance": kind, "iterations": iters}
     t0 = time.perf_counter()
     layer = Layer(K, pts, kind, tri, seed=seed)
     out["create_s"] = time.perf_counter() - t0  # upload + point masses + memoised OT(p,p)
+    layer.profile(True)
+    e0 = layer.exp_evals()
     t0 = time.perf_counter()
     layer.init_centroids()
     out["kmeanspp_s"] = time.perf_counter() - t0
@@ -348,7 +356,7 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
     layer.init_bounds()
     out["init_bounds_s"] = time.perf_counter() - t0
     d1, _ = layer.stats()
-    out["init_bounds_distances_per_s"] = (d1 - d0) / out["init_bounds_s"]
+    out["init_bounds_exact_distances"] = d1 - d0
     per_iter = []
     t_all = time.perf_counter()
     for it in range(iters):
@@ -362,17 +370,48 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
             log(f"iter {it}: {dt:.3f}s distances={db - da} moved={moved:.4f}")
     total = time.perf_counter() - t_all
     out["elkan_total_s"] = total
-    out["points_per_s"] = N * iters / total if iters else 0.0
+    out["value"] = out["points_per_s"] = N * iters / total if iters else 0.0
     out["algorithmic_GBps"] = N * iters * bytes_per_point / total / 1e9 if iters else 0.0
-    out["hbm_frac"] = out["algorithmic_GBps"] / 8000.0
+    out["hbm_frac"] = out["algorithmic_GBps"] / HBM_PEAK_GBPS
     out["per_iteration"] = per_iter
     t0 = time.perf_counter()
     layer.lookup()
     out["lookup_s"] = time.perf_counter() - t0
+    out["end_to_end_s"] = out["create_s"] + out["kmeanspp_s"] + out["init_bounds_s"] + total + out["lookup_s"]
     out["rms"] = layer.rms()
     d2, i2 = layer.stats()
     out["distances_total"] = d2
     out["sinkhorn_iterations_total"] = i2
+    ms = {name: layer.kernel_time(name) for name in ("pairwise", "step", "recompute", "bounds", "neighbor", "selfcost", "kpp",
+                                                     "drift", "mfma_bound")}
+    out["kernels_ms"] = {k: {"total_ms": round(v[0], 3), "launches": v[1]} for k, v in ms.items()}
+    bd_ms, bd_n = ms["bounds"]
+    if bd_n:
+        gbps = N * K * 8 / (bd_ms / bd_n * 1e-3) / 1e9
+        out["roofline_bounds"] = {"bound": "hbm", "kernel": "k_bounds_update", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": gbps / HBM_PEAK_GBPS, "bytes_per_launch": N * K * 8, "avg_launch_ms": bd_ms / bd_n,
+                                  "note": f"lower bounds f32[N][K] read + written once per Elkan iteration: {N * K * 8 / 1e9:.2f} GB per launch"
+                                          " (past the 256 MiB Infinity Cache at full size)"}
+    if kind == "sinkhorn":
+        exps = layer.exp_evals() - e0
+        valu_s = (ms["pairwise"][0] + ms["step"][0] + ms["neighbor"][0] + ms["selfcost"][0] + ms["kpp"][0] + ms["drift"][0]) * 1e-3
+        instr = exps / 64.0 / 8.0 * SOFTMIN_INSTR_PER_8_TERMS  # wave64 VALU instructions if every lane carried a term
+        out["roofline_sinkhorn"] = {"bound": "valu", "kernel": "wave_sinkhorn_cost (softmin)", "achieved": instr / valu_s if valu_s else 0.0,
+                                    "peak": VALU_PEAK_WAVE_INSTR, "unit": "wave-instructions/s",
+                                    "frac": instr / valu_s / VALU_PEAK_WAVE_INSTR if valu_s else 0.0, "exp_terms": exps,
+                                    "note": "bit-reproducible software exp: 106 VALU instructions per 8 softmin terms per lane; achieved = "
+                                            "terms / 64 / 8 x 106 / kernel time, i.e. counts only lanes that carry a term (a point fills "
+                                            "<= 47 of 64 lanes); peak = one wave64 instruction per 2 cycles per SIMD"}
+        st = layer.prune_stats()
+        out["mfma_bound"] = st
+        mb_ms, mb_n = ms["mfma_bound"]
+        if st["enabled"] and mb_ms > 0:
+            tf = st["mfma_instructions"] * 2048 / (mb_ms * 1e-3) / 1e12
+            out["roofline_mfma"] = {"bound": "mfma", "kernel": "k_sinkhorn_bound", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
+                                    "survivors_per_point": st["survivors"] / max(st["points"], 1),
+                                    "note": "scaling-domain Sinkhorn bound in front of init_bounds and lookup; flops = MFMA "
+                                            "instructions issued x 2048"}
     layer.close()
     return out
 
@@ -380,11 +419,7 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
 def cpu_baseline_slice(oracle, seconds: float = 8.0, K: int = 256, bins: int = 256, seed: int = 0xF10F):
     """The CPU oracle (oracle/rp_oracle_lloyd.c, 1 thread) on a bounded sample of the flop-layer workload:
     init_bounds-style full distances point -> centroid, as many points as fit in `seconds`."""
-    import os
-    import sys
-
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-    from lloyd_fixtures import flop_like_points, smooth_metric
+    from .fixtures import flop_like_points, smooth_metric
 
     pts = flop_like_points(K + 64, bins=bins, mass=47, seed=seed)
     tri = smooth_metric(bins, 1)

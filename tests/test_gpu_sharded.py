@@ -69,7 +69,6 @@ def test_mccfr_exchange_window_on_one_gpu_matches_world_model(gpu, B, world, win
             for f in ("visits", "regret", "weight", "payoff"):
                 assert np.array_equal(got[f].view(np.uint32), exp[f].view(np.uint32)), f
     assert devs[0].epoch == 3 * window == ora.epoch
-    assert devs[0].counters() == ora.counters() if world == 1 else True
 
 
 @pytest.mark.parametrize("kind", ["sinkhorn", "variation"])
