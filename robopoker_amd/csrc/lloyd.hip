@@ -858,24 +858,88 @@ __global__ __launch_bounds__(64) void k_neighborG(Points P, CentroidSet cs, uint
             for (uint32_t k = lane; k < K; k += 64) init.lower[ip[h] * K + k] = 0.0f;
 }
 
-// k-means++ potentials for G points per wavefront: potentials <- min(potentials, d(new centroid, point)^2)
+// ------------------------------------------------------------------------------------------------
+// The column-marginal bound (rigorous): after the rhs update that ends every Sinkhorn iteration the coupling
+// pi(x, y) = exp(f(x) + g(y) - C/T) has column sums nu(y) — by construction of g, whatever the iteration count — so
+//     cost = sum_y sum_x pi(x, y) C(x, y)  >=  sum_y nu(y) min_{x in supp mu} C(x, y).
+// In f32 the column sums hold to ~1e-5 (exp/ln rounding at arguments up to C/T) and the x-major cost sum to ~1e-4
+// relative in the worst case: the bound is used with the factor KPP_LB_SAFETY and only when max C / T <= 64 (no term near
+// the MIN_POSITIVE clamp).  k-means++ (layer.rs:170-178) updates potentials <- min(potentials, d^2): a point whose bound
+// already gives d^2 >= potential keeps its potential without the solve.
+// ------------------------------------------------------------------------------------------------
+#define KPP_LB_SAFETY 0.999f
+#define KPP_LB_SLACK 1e-6f
+__global__ __launch_bounds__(256) void k_minc(CentroidSet cs, uint32_t k, Metric M, float* minc) {
+    const uint32_t y = threadIdx.x, n = cs.n[k];
+    if (y >= M.bins) return;
+    float m = n ? rp_u2f(0x7f800000u) : 0.0f;
+    for (uint32_t i = 0; i < n; ++i) m = fminf(m, M.Cm[(size_t)cs.sup[(size_t)k * MAXB + i] * M.bins + y]);
+    minc[y] = m;
+}
+struct KppLists {
+    uint32_t* list[3];     // active points that are solved four / two / one per wavefront
+    unsigned int* count;   // [3]
+};
+// 16 lanes per point: the bound, the test against the potential, the point's place in its class list
+__global__ __launch_bounds__(1024) void k_kpp_filter(Points P, CentroidSet cs, uint32_t k, Metric M, const float* minc, const float* pot,
+                                                     const uint8_t* nsup, KppLists out, uint32_t quad_rows, uint32_t pair_rows) {
+    __shared__ unsigned int cnt[3], base[3];
+    __shared__ float mc[MAXB];
+    const uint32_t tid = threadIdx.x, sub = tid & 15u;
+    if (tid < 3) cnt[tid] = 0;
+    for (uint32_t b = tid; b < M.bins; b += 1024) mc[b] = minc[b];
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + (tid >> 4);
+    const bool real = i < P.N;
+    float acc = 0.0f;
+    if (real) {
+        const uint8_t* row = P.counts + i * P.stride;
+        for (uint32_t b = sub; b < M.bins; b += 16) acc += (float)row[b] * mc[b];
+    }
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    uint32_t cls = 3, slot = 0;
+    if (real && sub == 0) {
+        const float lb = (acc / (float)P.weight[i]) * KPP_LB_SAFETY - KPP_LB_SLACK;
+        const float d = rp_maxf(lb - 0.5f * cs.self[k] - 0.5f * P.self[i], 0.0f);
+        if (!(d * d >= pot[i])) {  // the solve may lower the potential (NaN counts as "may")
+            const uint32_t ns = nsup[i];
+            cls = (quad_rows && ns <= quad_rows) ? 0u : ((pair_rows && ns <= pair_rows) ? 1u : 2u);
+            slot = atomicAdd(&cnt[cls], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < 3) base[tid] = cnt[tid] ? atomicAdd(&out.count[tid], cnt[tid]) : 0u;
+    __syncthreads();
+    if (cls < 3) out.list[cls][base[cls] + slot] = (uint32_t)i;
+}
+
+// k-means++ potentials for G points per wavefront: potentials <- min(potentials, d(new centroid, point)^2).
+// `count`: number of valid entries of `groups` (the filtered lists of k_kpp_filter), NULL = every group is full.
 template <uint32_t G>
 __global__ __launch_bounds__(64) void k_kpp_updateG(Points P, CentroidSet cs, uint32_t k, Metric M, const uint32_t* groups,
-                                                    float* pot) {
+                                                    const unsigned int* count, float* pot) {
     __shared__ GroupLds<G> w;
+    const uint32_t have = count ? *count : 0xffffffffu;
+    if (G * blockIdx.x >= have) return;
     uint64_t ip[G];
     uint32_t n[G];
+    bool real[G];
     const uint32_t m = wave_load_centroid(cs, k, w.supC, w.lnC);
 #pragma unroll
     for (uint32_t h = 0; h < G; ++h) {
-        ip[h] = groups[G * blockIdx.x + h];
-        n[h] = pair_load_hist(P.counts + ip[h] * P.stride, P.weight[ip[h]], M.bins, w.supP[h], w.lnP[h], GroupLds<G>::ROWS);
+        real[h] = G * blockIdx.x + h < have;
+        ip[h] = real[h] ? groups[G * blockIdx.x + h] : groups[G * blockIdx.x];
+        const uint32_t got = pair_load_hist(P.counts + ip[h] * P.stride, P.weight[ip[h]], M.bins, w.supP[h], w.lnP[h], GroupLds<G>::ROWS);
+        n[h] = real[h] ? got : 0u;
     }
     float xy[G];
     wave_sinkhorn_costG<G>(w, m, n, M, true, xy);
     const uint32_t lane = lane_id();
-    if (lane == 0) atomicAdd(STAT(M, 0), (unsigned long long)G);
-    if (lane < G) {
+    uint32_t nreal = 0;
+#pragma unroll
+    for (uint32_t h = 0; h < G; ++h) nreal += real[h];
+    if (lane == 0) atomicAdd(STAT(M, 0), (unsigned long long)nreal);
+    if (lane < G && pick<G>(real, lane)) {
         const uint64_t i = pick<G>(ip, lane);
         const float d = rp_maxf(pick<G>(xy, lane) - 0.5f * cs.self[k] - 0.5f * P.self[i], 0.0f);
         pot[i] = rp_minf(d * d, pot[i]);
@@ -1572,8 +1636,9 @@ __global__ __launch_bounds__(1024) void k_kpp_pick(float* pot, uint64_t N, const
 }
 // potentials <- min(potentials, d(new centroid, point)^2) (layer.rs:170-178): distance(&x, h), centroid first
 __global__ __launch_bounds__(64) void k_kpp_update(Points P, CentroidSet cs, uint32_t k, uint32_t K, Metric M, int kind,
-                                                   float* pot, const uint32_t* only) {
+                                                   float* pot, const uint32_t* only, const unsigned int* count) {
     __shared__ WaveLds w;
+    if (count && blockIdx.x >= *count) return;
     const uint64_t i = only ? only[blockIdx.x] : blockIdx.x;
     float d;
     if (kind == RP_METRIC_SINKHORN) {
@@ -1722,6 +1787,12 @@ struct rp_kmeans {
     uint32_t* singles = nullptr;  // [n_singles] the other points
     uint64_t n_quads = 0, n_pairs = 0, n_singles = 0;
     Refresh refresh{};            // grouped stale-bound refresh (Sinkhorn; null nsup = off)
+    // k-means++ with the column-marginal bound (k_kpp_filter): per round, only the points whose potential can still drop
+    bool kpp_lb = false;
+    uint8_t* d_nsup = nullptr;
+    float* minc = nullptr;        // [bins]
+    KppLists kpp{};
+    uint64_t kpp_cap[3] = {0, 0, 0};  // points per support class (<= QUAD_ROWS, <= PAIR_ROWS, more): grid bounds
     // the MFMA bound in front of the neighbor passes (sinkhorn_bound.hpp)
     bool sb_on = false, sb_audit = false;
     SbParams sb{};
@@ -1915,6 +1986,18 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         ns.resize(N);
         KM_HIP(hipMemcpyAsync(ns.data(), d_ns, N, hipMemcpyDeviceToHost, h->stream));  // same (non-blocking) stream as the kernel
         KM_HIP(hipStreamSynchronize(h->stream));
+    }
+    if (kind == RP_METRIC_SINKHORN && !getenv("RP_LLOYD_NO_KPP_BOUND")) {
+        float cmax = 0.0f;
+        for (size_t t = 0; t < (size_t)bins * (bins - 1) / 2; ++t) cmax = std::max(cmax, tri_metric[t]);
+        if (cmax / h->hp.temperature <= 64.0f) {  // no softmin term near the MIN_POSITIVE clamp: column sums are nu to ~1e-5
+            h->d_nsup = d_ns;
+            KM_TRY(dev_alloc(h, &h->minc, MAXB));
+            for (int c = 0; c < 3; ++c) KM_TRY(dev_alloc(h, &h->kpp.list[c], (size_t)N + 4));
+            KM_TRY(dev_alloc(h, &h->kpp.count, 4));
+            for (uint64_t i = 0; i < N; ++i) h->kpp_cap[ns[i] <= QUAD_ROWS ? 0 : (ns[i] <= PAIR_ROWS ? 1 : 2)] += 1;
+            h->kpp_lb = true;
+        }
     }
     if (kind == RP_METRIC_SINKHORN && !getenv("RP_LLOYD_NO_MFMA_BOUND")) {
         // the MFMA bound (sinkhorn_bound.hpp): K = exp(-C/T) padded to 256 x 256, point lists by ceil(support / 16)
@@ -2248,21 +2331,40 @@ int rp_kmeans_kpp_update(rp_kmeans* h, uint32_t k) {
     if (h->kind == RP_METRIC_VARIATION)
         hipLaunchKernelGGL(k_kpp_update_var, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->P, h->cs[h->cur], k, h->K,
                            h->M, h->pot);
-    else
-    {
+    else if (h->kpp_lb) {
+        // the column-marginal bound first: only points whose potential can still drop are solved, regrouped by support class
+        const bool grouped = h->n_pairs || h->n_quads;
+        const uint32_t qrows = grouped && h->n_quads ? QUAD_ROWS : 0u, prows = grouped ? PAIR_ROWS : 0u;
+        HIP_TRY(hipMemsetAsync(h->kpp.count, 0, 16, h->stream));
+        hipLaunchKernelGGL(k_minc, dim3(1), dim3(256), 0, h->stream, h->cs[h->cur], k, h->M, h->minc);
+        hipLaunchKernelGGL(k_kpp_filter, dim3((unsigned)((h->N + 63) / 64)), dim3(1024), 0, h->stream, h->P, h->cs[h->cur], k, h->M,
+                           h->minc, h->pot, h->d_nsup, h->kpp, qrows, prows);
+        // grids sized for the worst case (every eligible point active); surplus wavefronts leave at once
+        const uint64_t cap4 = qrows ? h->kpp_cap[0] : 0, cap2 = prows ? h->kpp_cap[1] + (qrows ? 0 : h->kpp_cap[0]) : 0,
+                       cap1 = h->N - cap4 - cap2;
+        if (cap4)
+            hipLaunchKernelGGL(k_kpp_updateG<4>, dim3((unsigned)((cap4 + 3) / 4)), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->M,
+                               h->kpp.list[0], h->kpp.count + 0, h->pot);
+        if (cap2)
+            hipLaunchKernelGGL(k_kpp_updateG<2>, dim3((unsigned)((cap2 + 1) / 2)), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->M,
+                               h->kpp.list[1], h->kpp.count + 1, h->pot);
+        if (cap1)
+            hipLaunchKernelGGL(k_kpp_update, dim3((unsigned)cap1), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->K, h->M, h->kind,
+                               h->pot, h->kpp.list[2], h->kpp.count + 2);
+    } else {
         if (h->n_pairs || h->n_quads) {
             if (h->n_quads)
                 hipLaunchKernelGGL(k_kpp_updateG<4>, dim3((unsigned)h->n_quads), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->M,
-                                   h->quads, h->pot);
+                                   h->quads, (const unsigned int*)nullptr, h->pot);
             if (h->n_pairs)
                 hipLaunchKernelGGL(k_kpp_updateG<2>, dim3((unsigned)h->n_pairs), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->M,
-                                   h->pairs, h->pot);
+                                   h->pairs, (const unsigned int*)nullptr, h->pot);
             if (h->n_singles)
                 hipLaunchKernelGGL(k_kpp_update, dim3((unsigned)h->n_singles), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->K,
-                                   h->M, h->kind, h->pot, h->singles);
+                                   h->M, h->kind, h->pot, h->singles, (const unsigned int*)nullptr);
         } else {
             hipLaunchKernelGGL(k_kpp_update, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->K, h->M, h->kind,
-                               h->pot, (const uint32_t*)nullptr);
+                               h->pot, (const uint32_t*)nullptr, (const unsigned int*)nullptr);
         }
     }
     ck_end(h, CK_KPP);

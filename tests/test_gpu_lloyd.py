@@ -221,7 +221,7 @@ def test_points_per_wavefront_groupings_agree(gpu, monkeypatch, small_supports):
     tri = smooth_metric(bins, 1)
 
     def run(env):
-        for v in ("RP_LLOYD_NO_PAIRS", "RP_LLOYD_NO_QUADS", "RP_LLOYD_NO_REFRESH_PASS"):
+        for v in ("RP_LLOYD_NO_PAIRS", "RP_LLOYD_NO_QUADS", "RP_LLOYD_NO_REFRESH_PASS", "RP_LLOYD_NO_KPP_BOUND", "RP_LLOYD_NO_MFMA_BOUND"):
             monkeypatch.delenv(v, raising=False)
         if env:
             monkeypatch.setenv(env, "1")
@@ -234,7 +234,8 @@ def test_points_per_wavefront_groupings_agree(gpu, monkeypatch, small_supports):
         return chosen, np.asarray(bucket), np.asarray(dist)
 
     c1, b1, d1 = run("RP_LLOYD_NO_PAIRS")
-    for env in (None, "RP_LLOYD_NO_QUADS", "RP_LLOYD_NO_REFRESH_PASS"):
+    # ... and the two prunes (k-means++ column-marginal bound, MFMA bound of the neighbor passes) against their absence
+    for env in (None, "RP_LLOYD_NO_QUADS", "RP_LLOYD_NO_REFRESH_PASS", "RP_LLOYD_NO_KPP_BOUND", "RP_LLOYD_NO_MFMA_BOUND"):
         c2, b2, d2 = run(env)
         assert np.array_equal(c1, c2), "k-means++ picks differ"
         assert np.array_equal(b1, b2)
