@@ -183,3 +183,68 @@ def test_device_reproduces_deuce_golden(gpu):
     table = deuce.Lookup("rive", obs, bucket)
     turn = torch.tensor(g["turn"], dtype=torch.int64, device="cuda")
     assert table.projections(turn, 101).cpu().numpy().astype(np.uint32).tolist() == g["turn_histograms"]
+
+
+# ------------------------------------------------------------------------------------------------ configured shapes
+# tests/golden/{mccfr_composed_big,kmeans_k256}.json (scripts/make_golden_big.py): oracle outputs at the shapes bench.py
+# runs, which no per-test oracle run can afford — the composed update's two-level fold over 1024 chunks of a 2^18-tree
+# batch; Elkan over Sinkhorn EMD at K = 256, bins = 256.
+def _sha(a):
+    import hashlib
+
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _big(name):
+    path = os.path.join(GOLD, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated (scripts/make_golden_big.py)")
+    return load(name)
+
+
+def test_oracle_reproduces_big_composed_golden():
+    case = _big("mccfr_composed_big.json")[1]  # the 2^17-tree case keeps the CPU suite short
+    s = oracle.OracleSolver(Game(case["game"]), case["regret"], case["weight"], case["sampling"], batch=case["batch"], seed=case["seed"])
+    for _ in range(case["steps"]):
+        s.step_world(1)
+    _check_tables(s.export(), case)
+    assert list(s.counters()) == case["counters"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("index", [0, 1])
+def test_device_reproduces_big_composed_golden(gpu, index):
+    from robopoker_amd.mccfr import Solver
+
+    case = _big("mccfr_composed_big.json")[index]
+    s = Solver(Game(case["game"]), case["regret"], case["weight"], case["sampling"], batch=case["batch"], seed=case["seed"])
+    s.set_update_mode("composed")
+    for _ in range(case["steps"]):
+        s.step()
+    _check_tables(s.export(), case)
+    assert list(s.counters()) == case["counters"]
+
+
+@pytest.mark.gpu
+def test_device_reproduces_kmeans_k256_golden(gpu):
+    from robopoker_amd import lloyd
+
+    case = _big("kmeans_k256.json")
+    pts = flop_like_points(case["N"], bins=case["bins"], mass=47, seed=case["seed"])
+    km = lloyd.Layer(case["K"], pts, "sinkhorn", smooth_metric(case["bins"], 1), seed=case["seed"])
+    km.set_centroids(np.array(case["start"], dtype=np.uint64))
+    km.init_bounds()
+    j, u, lo = km.bounds()
+    assert j.tolist() == case["init_j"] and bits(u) == case["init_u_bits"] and _sha(lo.view(np.uint32)) == case["init_lower_sha"]
+    for want in case["steps"]:
+        d, sizes, moved = km.step()
+        assert bits(d) == want["drift_bits"] and sizes.tolist() == want["sizes"] and moved == want["moved"]
+        j, u, lo = km.bounds()
+        assert _sha(j) == want["j_sha"] and _sha(u.view(np.uint32)) == want["u_sha"] and _sha(lo.view(np.uint32)) == want["lower_sha"]
+    b, dist = km.lookup()
+    assert b.tolist() == case["buckets"] and bits(dist) == case["distance_bits"]
+    c, w = km.centroids()
+    assert w.tolist() == case["centroid_weight"] and _sha(c.astype(np.uint32)) == case["centroid_sha"]
+    assert bits([km.rms()])[0] == case["rms_bits"]
+    st = km.prune_stats()
+    assert st["enabled"] == 1 and st["survivors"] < 2 * st["points"]
