@@ -14,6 +14,18 @@
  * machine without one returns RP_ERR_NO_DEVICE.
  *
  * Arithmetic (exp/ln/pow, RNG, summation orders) is specified in rp_math.h and DESIGN.md.
+ *
+ * COMPILED LIMITS (a call outside them fails with RP_ERR_INVALID / RP_ERR_CAPACITY / RP_ERR_UNSUPPORTED, never silently):
+ *   mccfr    max_actions <= 16 (RP_MAX_ACTIONS); a sampled tree has < 255 nodes (rp_game_table.max_tree_nodes) and each tree
+ *            emits at most 255 Decisions.  Games with <= 62 nodes per sampled tree, depth <= 10, <= 32 internal nodes and
+ *            <= 8191 infosets (Kuhn, Leduc, RPS, the wide Leduc) take the LDS-resident traversal; larger ones its HBM-scratch
+ *            variant.  NLHE-sized trees (10^3-10^4 nodes) are NOT reachable through rp_game_table: see rp_nlhe_* below.
+ *   profile  (rp_profile_*) max_actions <= 16, rows < 2^32, Decisions per batch < 2^31.
+ *   lloyd    K <= 256 and bins <= 256 (an Abstraction index is 8 bits, kicker/src/abstraction.rs:22-23), counts are u8
+ *            (a point's mass per bin <= 255; the flop / turn layers have mass 47 / 46), N < 2^32.  The MFMA bound prunes
+ *            points with 1..64 support bins; others go through the unpruned kernels.
+ *   sampling Discounted / Asymmetric regret have a sign-dependent discount: ordered update only (composed, sharded and
+ *            windowed steps return RP_ERR_UNSUPPORTED).
  */
 #ifndef RP_MI355X_H
 #define RP_MI355X_H
@@ -419,6 +431,12 @@ RP_API int rp_sinkhorn_divergence(uint32_t bins, uint64_t pairs, const uint32_t*
 RP_API int rp_sinkhorn_cost(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_t* nu,
                             const float* tri_metric, const rp_sinkhorn_hp* hp, int device, float* out,
                             uint32_t* iterations);
+/* impl Coupling for Sinkhorn (monge/src/coupling.rs:23-51; lloyd/src/sinkhorn.rs:194-218): minimize() one pair, then
+ * flow(x, y) = coupling(x, y) * raw_distance(x, y) with coupling = exp(lhs(x) + rhs(y) - C/T) (sinkhorn.rs:114-116).
+ * flow[bins*bins] row-major over (x, y), 0 outside supp(mu) x supp(nu); coupling (same shape) may be NULL.  The x-major
+ * left fold of `flow` is cost() (sinkhorn.rs:206-217) bit for bit. */
+RP_API int rp_sinkhorn_flow(uint32_t bins, const uint32_t* mu, const uint32_t* nu, const float* tri_metric,
+                            const rp_sinkhorn_hp* hp, int device, float* flow, float* coupling);
 /* Equity::variation (equity.rs:41-53) for P pairs of `bins`-bin histograms (bins = 101 on the turn layer) */
 RP_API int rp_equity_variation(uint32_t bins, uint64_t pairs, const uint32_t* x, const uint32_t* y, int device,
                                float* out);

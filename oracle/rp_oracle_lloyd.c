@@ -187,6 +187,52 @@ ORA_API float ora_sinkhorn_trace(uint32_t bins, const uint32_t* mu, const uint32
     hist_from_u32(&b, bins, nu);
     return sinkhorn_cost_traced(bins, &a, &b, tri, hp, iters, trace_err, trace_cost);
 }
+/* Coupling::flow for every (x, y) of one minimised pair (sinkhorn.rs:114-116,202-204); dense bins*bins outputs, zero
+ * outside the supports; coupling may be NULL */
+ORA_API void ora_sinkhorn_flow(uint32_t bins, const uint32_t* mu_c, const uint32_t* nu_c, const float* tri, const rp_sinkhorn_hp* hp,
+                               float* flow, float* coupling) {
+    ora_hist mu, nu;
+    hist_from_u32(&mu, bins, mu_c);
+    hist_from_u32(&nu, bins, nu_c);
+    memset(flow, 0, (size_t)bins * bins * 4);
+    if (coupling) memset(coupling, 0, (size_t)bins * bins * 4);
+    uint32_t sx[ORA_MAXBINS], sy[ORA_MAXBINS], m = 0, n = 0;
+    for (uint32_t i = 0; i < bins; ++i) {
+        if (mu.counts[i] > 0) sx[m++] = i;
+        if (nu.counts[i] > 0) sy[n++] = i;
+    }
+    if (m == 0 || n == 0) return;
+    /* the same minimisation as sinkhorn_cost_traced, potentials kept */
+    float lhs[ORA_MAXBINS], rhs[ORA_MAXBINS], nxt[ORA_MAXBINS];
+    float lu = rp_logf(1.0f / (float)m), ru = rp_logf(1.0f / (float)n), T = hp->temperature;
+    for (uint32_t i = 0; i < m; ++i) lhs[i] = lu;
+    for (uint32_t j = 0; j < n; ++j) rhs[j] = ru;
+    for (uint32_t t = 0; t < hp->iterations; ++t) {
+        float le = 0.0f, re = 0.0f;
+        for (uint32_t i = 0; i < m; ++i) {
+            float s = 0.0f;
+            for (uint32_t j = 0; j < n; ++j) s += rp_maxf(rp_expf(rhs[j] - raw_distance(tri, sx[i], sy[j]) / T), RP_EPSILON);
+            nxt[i] = rp_logf(h_density(&mu, sx[i])) - rp_logf(s);
+        }
+        for (uint32_t i = 0; i < m; ++i) le += rp_absf(rp_expf(nxt[i]) - rp_expf(lhs[i]));
+        for (uint32_t i = 0; i < m; ++i) lhs[i] = nxt[i];
+        for (uint32_t j = 0; j < n; ++j) {
+            float s = 0.0f;
+            for (uint32_t i = 0; i < m; ++i) s += rp_maxf(rp_expf(lhs[i] - raw_distance(tri, sy[j], sx[i]) / T), RP_EPSILON);
+            nxt[j] = rp_logf(h_density(&nu, sy[j])) - rp_logf(s);
+        }
+        for (uint32_t j = 0; j < n; ++j) re += rp_absf(rp_expf(nxt[j]) - rp_expf(rhs[j]));
+        for (uint32_t j = 0; j < n; ++j) rhs[j] = nxt[j];
+        if (le + re < hp->tolerance) break;
+    }
+    for (uint32_t i = 0; i < m; ++i)
+        for (uint32_t j = 0; j < n; ++j) {
+            float c = raw_distance(tri, sx[i], sy[j]);
+            float pi = rp_expf(lhs[i] + rhs[j] - c / T);
+            if (coupling) coupling[(size_t)sx[i] * bins + sy[j]] = pi;
+            flow[(size_t)sx[i] * bins + sy[j]] = pi * c;
+        }
+}
 ORA_API float ora_sinkhorn_divergence(uint32_t bins, const uint32_t* mu, const uint32_t* nu, const float* tri,
                                       const rp_sinkhorn_hp* hp) {
     ora_hist a, b;

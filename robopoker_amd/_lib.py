@@ -217,6 +217,7 @@ _SIGNATURES = {
         [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SinkhornHP), C.c_int, C.c_void_p,
          C.c_void_p],
     ),
+    "rp_sinkhorn_flow": (C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SinkhornHP), C.c_int, C.c_void_p, C.c_void_p]),
     "rp_equity_variation": (C.c_int, [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "rp_mccfr_train": (C.c_int, [C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),

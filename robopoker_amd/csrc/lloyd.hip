@@ -1702,6 +1702,33 @@ __global__ __launch_bounds__(64) void k_pair_sinkhorn(const uint32_t* mu, const 
     if (lane == 0) out[p] = r;
     (void)before;
 }
+// Coupling::flow (monge/src/coupling.rs:23-51 as Sinkhorn implements it, sinkhorn.rs:114-116,202-204) of ONE minimised pair:
+// coupling(x, y) = exp(lhs(x) + rhs(y) - C/T) and flow = coupling * C on supp(mu) x supp(nu), 0 elsewhere
+__global__ __launch_bounds__(64) void k_pair_flow(const uint32_t* mu, const uint32_t* nu, Metric M, float* flow, float* coupling) {
+    __shared__ WaveLds w;
+    const uint32_t bins = M.bins, lane = lane_id();
+    uint32_t wa = 0, wb = 0;
+    for (uint32_t b = lane; b < bins; b += 64) {
+        wa += mu[b];
+        wb += nu[b];
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        wa += __shfl_xor(wa, d, 64);
+        wb += __shfl_xor(wb, d, 64);
+    }
+    const uint32_t m = wave_load_hist(mu, wa, bins, w.supA, w.lnA);
+    const uint32_t n = wave_load_hist(nu, wb, bins, w.supB, w.lnB);
+    (void)wave_sinkhorn_cost(w, m, n, M);  // leaves the minimised potentials in w.f / w.g
+    for (uint32_t i = 0; i < m; ++i) {
+        const uint32_t x = w.supA[i];
+        for (uint32_t j = lane; j < n; j += 64) {
+            const uint32_t y = w.supB[j];
+            const float pi = rp_expf(w.f[i] + w.g[j] - M.Rt[x * bins + y]);
+            if (coupling) coupling[x * bins + y] = pi;
+            flow[x * bins + y] = pi * M.Cm[x * bins + y];
+        }
+    }
+}
 // iteration counts need a private counter per pair: a second tiny variant keeps the hot kernel lean
 __global__ __launch_bounds__(64) void k_pair_iters(const uint32_t* mu, const uint32_t* nu, Metric M, unsigned long long* scratch,
                                                    uint32_t* iters_out) {
@@ -2770,6 +2797,41 @@ int rp_sinkhorn_divergence(uint32_t bins, uint64_t pairs, const uint32_t* mu, co
 int rp_sinkhorn_cost(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_t* nu, const float* tri_metric,
                      const rp_sinkhorn_hp* hp, int device, float* out, uint32_t* iterations) {
     return pair_common(bins, pairs, mu, nu, tri_metric, hp, device, out, iterations, 0);
+}
+int rp_sinkhorn_flow(uint32_t bins, const uint32_t* mu, const uint32_t* nu, const float* tri, const rp_sinkhorn_hp* hp, int device,
+                     float* flow, float* coupling) {
+    if (!mu || !nu || !flow || bins == 0 || bins > MAXB || (!tri && bins > 1)) return rp::fail(RP_ERR_INVALID, "rp_sinkhorn_flow: bad argument");
+    if (rp_device_count() <= 0) return rp::fail(RP_ERR_NO_DEVICE, "rp_sinkhorn_flow: no HIP device visible; no CPU fallback");
+    rp_sinkhorn_hp hh;
+    if (hp) hh = *hp; else rp_sinkhorn_hp_default(&hh);
+    HIP_TRY(hipSetDevice(device));
+    const size_t cells = (size_t)bins * bins;
+    std::vector<float> C(cells, 0.0f), R(cells, 0.0f);
+    for (uint32_t x = 0; x < bins; ++x)
+        for (uint32_t y = 0; y < bins; ++y) {
+            const float c = x == y ? 0.0f : tri[rp_tri_index(x, y)];
+            C[(size_t)x * bins + y] = c;
+            R[(size_t)x * bins + y] = c / hh.temperature;
+        }
+    float* buf = nullptr;  // C | R | flow | coupling
+    uint32_t* hist = nullptr;
+    unsigned long long* dstats = nullptr;
+    HIP_TRY(hipMalloc(&buf, cells * 4 * 4));
+    HIP_TRY(hipMalloc(&hist, (size_t)bins * 8));
+    HIP_TRY(hipMalloc(&dstats, 32));
+    HIP_TRY(hipMemset(dstats, 0, 32));
+    HIP_TRY(hipMemset(buf + 2 * cells, 0, cells * 8));
+    HIP_TRY(hipMemcpy(buf, C.data(), cells * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(buf + cells, R.data(), cells * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(hist, mu, (size_t)bins * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(hist + bins, nu, (size_t)bins * 4, hipMemcpyHostToDevice));
+    Metric M{buf, buf + cells, bins, hh.iterations, hh.tolerance, dstats, 1u};
+    hipLaunchKernelGGL(k_pair_flow, dim3(1), dim3(64), 0, 0, hist, hist + bins, M, buf + 2 * cells, buf + 3 * cells);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(flow, buf + 2 * cells, cells * 4, hipMemcpyDeviceToHost));
+    if (coupling) HIP_TRY(hipMemcpy(coupling, buf + 3 * cells, cells * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(buf); (void)hipFree(hist); (void)hipFree(dstats);
+    return RP_OK;
 }
 int rp_equity_variation(uint32_t bins, uint64_t pairs, const uint32_t* x, const uint32_t* y, int device, float* out) {
     if (!x || !y || !out || pairs == 0 || bins == 0) return rp::fail(RP_ERR_INVALID, "rp_equity_variation: bad argument");

@@ -211,6 +211,20 @@ def sinkhorn_cost(mu, nu, tri, hp=None, device=0):
     return out, it
 
 
+def sinkhorn_flow(mu, nu, tri, hp=None, device=0):
+    """``impl Coupling for Sinkhorn`` (sinkhorn.rs:194-218): minimise one pair, return (flow, coupling), each (bins, bins);
+    the x-major left fold of ``flow`` is ``cost()``."""
+    mu = np.ascontiguousarray(mu, dtype=np.uint32)
+    nu = np.ascontiguousarray(nu, dtype=np.uint32)
+    tri = np.ascontiguousarray(tri, dtype=np.float32)
+    hp = hp or default_sinkhorn()
+    bins = mu.size
+    flow = np.zeros((bins, bins), dtype=np.float32)
+    coupling = np.zeros((bins, bins), dtype=np.float32)
+    _lib.check(_lib.load().rp_sinkhorn_flow(bins, _p(mu), _p(nu), _p(tri), C.byref(hp), device, _p(flow), _p(coupling)))
+    return flow, coupling
+
+
 def equity_variation(x, y, device=0) -> np.ndarray:
     """``Equity::variation`` (equity.rs:41-53) for P pairs of equal-width histograms."""
     x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.uint32)

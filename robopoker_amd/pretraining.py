@@ -69,14 +69,16 @@ def cluster_preflop(device=0, flop: Artifacts | None = None, flop_metric=None) -
     bins = int(flop.abstraction.max().item()) + 1
     table = deuce.Lookup("flop", flop.obs, flop.abstraction)
     combos = np.array(list(itertools.combinations(range(50), 3)), dtype=np.int64)  # boards as indices into the 50 other cards
-    hist = np.zeros((obs.numel(), bins), dtype=np.uint32)
-    for k, o in enumerate(obs.cpu().tolist()):
+    # all 169 x 19 600 children in ONE device lookup (a host loop of 169 round trips before)
+    pockets = obs.cpu().tolist()
+    children = np.empty((len(pockets), combos.shape[0]), dtype=np.int64)
+    for k, o in enumerate(pockets):
         p1, p0 = (o & 0xff) - 1, ((o >> 8) & 0xff) - 1  # pocket cards, ascending: p0 < p1 (observation.rs:132-141)
         rest = np.array([c for c in range(52) if c not in (p0, p1)], dtype=np.int64)
         c = rest[combos] + 1  # (19600, 3), each row ascending
-        child = (c[:, 0] << 32) | (c[:, 1] << 24) | (c[:, 2] << 16) | ((p0 + 1) << 8) | (p1 + 1)
-        b = table.lookup(torch.from_numpy(child).to(obs.device)).cpu().numpy()
-        hist[k] = np.bincount(b, minlength=bins).astype(np.uint32)
+        children[k] = (c[:, 0] << 32) | (c[:, 1] << 24) | (c[:, 2] << 16) | ((p0 + 1) << 8) | (p1 + 1)
+    buckets = table.lookup(torch.from_numpy(children.reshape(-1)).to(obs.device)).cpu().numpy().reshape(children.shape)
+    hist = np.stack([np.bincount(b, minlength=bins) for b in buckets]).astype(np.uint32)
     table.close()
     K = obs.numel()
     tri = np.zeros(K * (K - 1) // 2, dtype=np.float32)
@@ -85,7 +87,8 @@ def cluster_preflop(device=0, flop: Artifacts | None = None, flop_metric=None) -
         d = (sinkhorn_divergence(hist[hi], hist[lo], flop_metric, device=device)
              + sinkhorn_divergence(hist[lo], hist[hi], flop_metric, device=device)) / np.float32(2.0)
         tri[hi * (hi - 1) // 2 + lo] = d  # Pair::merge (pair.rs:36-39)
-        tri = tri / tri.max()
+        # Metric::from normalises by fold(f32::MIN_POSITIVE, f32::max) (metric.rs:127-141): an all-zero distance set stays 0, never NaN
+        tri = tri / max(tri.max(), np.finfo(np.float32).tiny)
     art.metric, art.future, art.future_weight = tri, hist, hist.sum(axis=1).astype(np.uint64)
     art.timings = {"preflop_s": time.perf_counter() - t0}
     return art

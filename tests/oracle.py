@@ -76,6 +76,7 @@ def load() -> C.CDLL:
     o.ora_sinkhorn_cost.argtypes = [C.c_uint32, vp, vp, vp, C.POINTER(_lib.SinkhornHP), C.POINTER(C.c_uint32)]
     o.ora_sinkhorn_trace.restype = C.c_float
     o.ora_sinkhorn_trace.argtypes = [C.c_uint32, vp, vp, vp, C.POINTER(_lib.SinkhornHP), C.POINTER(C.c_uint32), vp, vp]
+    o.ora_sinkhorn_flow.argtypes = [C.c_uint32, vp, vp, vp, C.POINTER(_lib.SinkhornHP), vp, vp]
     o.ora_sinkhorn_divergence.restype = C.c_float
     o.ora_sinkhorn_divergence.argtypes = [C.c_uint32, vp, vp, vp, C.POINTER(_lib.SinkhornHP)]
     o.ora_equity_variation.restype = C.c_float
@@ -338,6 +339,17 @@ def sinkhorn_trace(mu, nu, tri, hp=None, bins=None):
     costs = np.zeros(hp.iterations, dtype=np.float32)
     c = load().ora_sinkhorn_trace(bins or mu.size, _p(mu), _p(nu), _p(tri), C.byref(hp), C.byref(it), _p(errs), _p(costs))
     return c, it.value, errs, costs
+
+
+def sinkhorn_flow(mu, nu, tri, hp=None):
+    hp = hp or default_sinkhorn()
+    mu = np.ascontiguousarray(mu, dtype=np.uint32)
+    nu = np.ascontiguousarray(nu, dtype=np.uint32)
+    tri = np.ascontiguousarray(tri, dtype=np.float32)
+    flow = np.zeros((mu.size, mu.size), dtype=np.float32)
+    coupling = np.zeros((mu.size, mu.size), dtype=np.float32)
+    load().ora_sinkhorn_flow(mu.size, _p(mu), _p(nu), _p(tri), C.byref(hp), _p(flow), _p(coupling))
+    return flow, coupling
 
 
 def sinkhorn_divergence(mu, nu, tri, hp=None, bins=None):

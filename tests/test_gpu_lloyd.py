@@ -367,3 +367,14 @@ def test_mfma_bound_handles_degenerate_inputs(gpu):
         b1, d1 = dev.lookup()
         b2, d2 = ora.assign()
         assert np.array_equal(b1, b2) and np.array_equal(bits(d1), bits(d2)), temperature
+
+
+def test_coupling_flow_bit_exact(gpu):
+    # rp_sinkhorn_flow (monge Coupling::flow as Sinkhorn implements it): every cell of flow and coupling
+    bins = 40
+    tri = smooth_metric(bins, 4)
+    pts = flop_like_points(6, bins=bins, mass=25, seed=6).astype(np.uint32)
+    for a, b in ((pts[0], pts[1]), (pts[2], pts[2]), (pts[3], pts[5])):
+        f1, c1 = lloyd.sinkhorn_flow(a, b, tri)
+        f2, c2 = oracle.sinkhorn_flow(a, b, tri)
+        assert np.array_equal(bits(f1), bits(f2)) and np.array_equal(bits(c1), bits(c2))

@@ -206,3 +206,25 @@ def test_kmeans_step_reports(tmp_path):
     assert km.rms() <= rms0 + 1e-6
     tri = km.metric()
     assert tri.max() == pytest.approx(1.0) and tri.min() >= 0
+
+
+def test_coupling_flow_folds_to_the_cost_and_has_the_marginals():
+    # impl Coupling for Sinkhorn (sinkhorn.rs:194-218): cost() is the x-major left fold of flow(x, y); after minimize()
+    # the coupling's column sums are nu (the last half-iteration updates rhs) and its row sums are mu up to the tolerance
+    import oracle as O
+    from lloyd_fixtures import flop_like_points, smooth_metric
+
+    bins = 48
+    tri = smooth_metric(bins, 2)
+    pts = flop_like_points(6, bins=bins, mass=30, seed=12).astype(np.uint32)
+    for a, b in ((pts[0], pts[1]), (pts[2], pts[3]), (pts[4], pts[4])):
+        flow, pi = O.sinkhorn_flow(a, b, tri)
+        cost, _ = O.sinkhorn_cost(a, b, tri, bins=bins)
+        acc = np.float32(0.0)
+        for x in np.flatnonzero(a):
+            for y in np.flatnonzero(b):
+                acc = np.float32(acc + flow[x, y])
+        assert acc.view(np.uint32) == np.float32(cost).view(np.uint32)
+        assert np.allclose(pi.sum(axis=0), b / b.sum(), atol=2e-5)
+        assert np.allclose(pi.sum(axis=1), a / a.sum(), atol=2e-3)
+        assert np.all(flow[a == 0] == 0) and np.all(flow[:, b == 0] == 0)
