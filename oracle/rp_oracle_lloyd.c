@@ -25,6 +25,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../include/rp_math.h"
 #include "../include/rp_mi355x.h"
@@ -55,6 +58,18 @@ static void ora_hp_default(rp_sinkhorn_hp* out) {
 
 static uint64_t g_sinkhorn_iters = 0;
 static uint64_t g_distances = 0;
+/* CPU-baseline threading (bench.py's all-core figure): the reference's point-parallel structure — rayon par_iter over
+ * points in init_bounds / step_elkan / lookup and over centroid pairs in pairwises (elkan.rs:39-47,80-93,153-168) —
+ * as OpenMP loops.  Every distance is a pure function of its two histograms, so results do not depend on the count. */
+static int g_threads = 1;
+ORA_API void ora_lloyd_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+ORA_API int ora_lloyd_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 /* Sinkhorn::from(..).minimize().cost() (sinkhorn.rs:77-92,194-230) */
 static float sinkhorn_cost_traced(uint32_t bins, const ora_hist* mu, const ora_hist* nu, const float* tri,
@@ -121,6 +136,7 @@ static float sinkhorn_cost_traced(uint32_t bins, const ora_hist* mu, const ora_h
         }
         for (uint32_t j = 0; j < n; ++j) rhs_err += rp_absf(rp_expf(nxt[j]) - rp_expf(rhs[j]));
         for (uint32_t j = 0; j < n; ++j) rhs[j] = nxt[j];
+#pragma omp atomic
         g_sinkhorn_iters += 1;
         if (trace_err) {
             trace_err[t] = lhs_err + rhs_err;
@@ -148,6 +164,7 @@ static float sinkhorn_cost_traced(uint32_t bins, const ora_hist* mu, const ora_h
 static float divergence_with(uint32_t bins, const ora_hist* mu, float xx, const ora_hist* nu, float yy,
                              const float* tri, const rp_sinkhorn_hp* hp) {
     float xy = sinkhorn_cost(bins, mu, nu, tri, hp, NULL);
+#pragma omp atomic
     g_distances += 1;
     return rp_maxf(xy - 0.5f * xx - 0.5f * yy, 0.0f);
 }
@@ -160,6 +177,7 @@ static float variation(uint32_t bins, const ora_hist* x, const ora_hist* y) {
         cdf_y += h_density(y, i);
         sum += rp_absf(cdf_x - cdf_y);
     }
+#pragma omp atomic
     g_distances += 1;
     return sum / (float)bins;
 }
@@ -391,6 +409,7 @@ static void neighbor(const ora_kmeans* h, uint64_t i, uint32_t* jo, float* dout)
 
 /* Elkan::init_bounds (elkan.rs:39-47) + Bounds::from (bounds.rs:111-120) */
 ORA_API void ora_kmeans_init_bounds(ora_kmeans* h) {
+#pragma omp parallel for schedule(dynamic, 8) num_threads(g_threads) if (g_threads > 1)
     for (uint64_t i = 0; i < h->N; ++i) {
         ora_bound* b = &h->bounds[i];
         neighbor(h, i, &b->j, &b->error);
@@ -419,9 +438,11 @@ ORA_API void ora_kmeans_step_local(ora_kmeans* h, void* partial) {
     float* pw = (float*)malloc(4 * (size_t)K * K);
     float* mid = (float*)malloc(4 * K);
     /* pairwises (elkan.rs:80-93): both orders, not symmetrised */
-    for (uint32_t i = 0; i < K; ++i)
-        for (uint32_t j = 0; j < K; ++j)
-            pw[i * K + j] = (i == j) ? 0.0f : dist(h, &h->cent[i], h->self_c[i], &h->cent[j], h->self_c[j]);
+#pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads) if (g_threads > 1)
+    for (uint32_t e = 0; e < K * K; ++e) {
+        uint32_t i = e / K, j = e % K;
+        pw[i * K + j] = (i == j) ? 0.0f : dist(h, &h->cent[i], h->self_c[i], &h->cent[j], h->self_c[j]);
+    }
     /* midpoints (elkan.rs:96-105) */
     for (uint32_t i = 0; i < K; ++i) {
         float r = RP_F32_MAX;
@@ -429,6 +450,7 @@ ORA_API void ora_kmeans_step_local(ora_kmeans* h, void* partial) {
             if (j != i) r = rp_minf(r, pw[i * K + j] * 0.5f);
         mid[i] = r;
     }
+#pragma omp parallel for schedule(dynamic, 8) num_threads(g_threads) if (g_threads > 1)
     for (uint64_t i = 0; i < h->N; ++i) {
         ora_bound* b = &h->bounds[i];
         if (!(b->error > mid[b->j])) continue; /* filter u > s[j] (elkan.rs:159) */
@@ -485,7 +507,9 @@ ORA_API void ora_kmeans_step_finish(ora_kmeans* h, const void* reduced, float* d
     /* drift (elkan.rs:108-110): distance(new, old) */
     float* drift = (float*)malloc(4 * K);
     float* self_n = (float*)malloc(4 * K);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads) if (g_threads > 1)
     for (uint32_t j = 0; j < K; ++j) self_n[j] = point_self(h, &nc[j]);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads) if (g_threads > 1)
     for (uint32_t j = 0; j < K; ++j) drift[j] = dist(h, &nc[j], self_n[j], &h->cent[j], h->self_c[j]);
     /* Bounds::update (bounds.rs:69-77) */
     for (uint64_t i = 0; i < h->N; ++i) {
@@ -533,6 +557,7 @@ ORA_API void ora_kmeans_step_naive(ora_kmeans* h) {
 
 /* Layer::lookup (layer.rs:62-82) */
 ORA_API void ora_kmeans_assign(const ora_kmeans* h, uint8_t* bucket, float* distance) {
+#pragma omp parallel for schedule(dynamic, 8) num_threads(g_threads) if (g_threads > 1)
     for (uint64_t i = 0; i < h->N; ++i) {
         uint32_t j;
         float d;

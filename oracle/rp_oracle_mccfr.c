@@ -482,6 +482,39 @@ ORA_API void ora_mccfr_step(ora_mccfr* h) {
     h->epoch += 1;
 }
 
+/* Solver::step with the reference's parallel structure (solver.rs:225-250: rayon over the trees of a batch, then the
+ * sequential update on one thread): `threads` workers traverse contiguous tree-id ranges into private Decisions lists,
+ * which are applied in tree-id order — the same result as ora_mccfr_step, bit for bit (the batch is pure w.r.t. the
+ * profile).  bench.py's all-core CPU baseline. */
+ORA_API void ora_mccfr_step_mt(ora_mccfr* h, uint32_t threads) {
+    if (threads < 2) {
+        ora_mccfr_step(h);
+        return;
+    }
+    ora_mccfr* shadow = (ora_mccfr*)malloc(sizeof(ora_mccfr) * threads);
+    for (uint32_t t = 0; t < threads; ++t) {
+        shadow[t] = *h; /* shares the game and the tables (read only here); private scratch and counters */
+        memset(&shadow[t].tree, 0, sizeof(ora_tree));
+        shadow[t].dec = NULL;
+        shadow[t].ndec = shadow[t].capdec = 0;
+        shadow[t].nodes = shadow[t].infos = 0;
+    }
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+    for (uint32_t t = 0; t < threads; ++t) {
+        uint64_t lo = (uint64_t)h->batch * t / threads, hi = (uint64_t)h->batch * (t + 1) / threads;
+        batch_range(&shadow[t], lo, hi - lo);
+    }
+    for (uint32_t t = 0; t < threads; ++t) {
+        for (uint64_t i = 0; i < shadow[t].ndec; ++i) apply_decision(h, &shadow[t].dec[i]);
+        h->nodes += shadow[t].nodes;
+        h->infos += shadow[t].infos;
+        free(shadow[t].tree.nodes);
+        free(shadow[t].dec);
+    }
+    free(shadow);
+    h->epoch += 1;
+}
+
 ORA_API void ora_mccfr_solve(ora_mccfr* h, uint64_t trees) {
     for (uint64_t i = 0; i < trees / h->batch; ++i) ora_mccfr_step(h);
 }

@@ -318,8 +318,60 @@ def bench_slice(n_points: int = 16384, K: int = 256, bins: int = 256, iters: int
         "kernels_ms": {"step": step_ms / max(step_n, 1), "pairwise": pw_ms / max(pw_n, 1),
                        "bounds": bd_ms / max(bd_n, 1), "drift": dr_ms / max(dr_n, 1)},
     }
+    if kind == "sinkhorn":
+        out["_centroids"] = layer.centroids()[0]  # for the CPU baseline's pairwise sample; removed before printing
     layer.close()
     return out
+
+
+def cpu_baseline_full(oracle, gpu_out, centroids, threads=None):
+    """The CPU oracle with the reference's parallel structure (rayon par_iter over points and over centroid pairs ->
+    OpenMP, oracle/rp_oracle_lloyd.c) on all host cores, on a BOUNDED sample of the full flop configuration, composed into
+    the full-size Elkan iteration it stands for:
+
+      rate  = point-centroid Sinkhorn solves per second (init_bounds of 768 sample points against 48 of the converged
+              centroids the GPU run ended with);
+      t_pw  = the pairwise pass of those 48 centroids (48 x 47 solves), scaled by (K (K - 1)) / (48 x 47) to K = 256;
+      one full-size iteration = t_pw + (distances the GPU run's steady-state iteration evaluated) / rate.
+
+    The algorithm and the distance counts are the GPU run's (the two are bit-identical), only the clock is the CPU's."""
+    import os
+
+    from .fixtures import flop_like_points, smooth_metric
+
+    threads = threads or max(1, (os.cpu_count() or 2) // 2)
+    K, Ks, Ns, bins = gpu_out["K"], 48, 768, gpu_out["bins"]
+    pts = flop_like_points(Ns, bins=bins, mass=47, seed=0xF10F)
+    oracle.lloyd_set_threads(threads)
+    try:
+        km = oracle.OracleKmeans(Ks, pts, "sinkhorn", smooth_metric(bins, 1), seed=1)
+        km.set_centroids(np.arange(Ks, dtype=np.uint64))
+        pick = np.linspace(0, K - 1, Ks).astype(int)
+        for k, src in enumerate(pick):
+            km.set_centroid(k, centroids[src])
+        t0 = time.perf_counter()
+        km.init_bounds()
+        t_ib = time.perf_counter() - t0
+        rate = Ns * Ks / t_ib
+        d0, _ = oracle.lloyd_stats()
+        t0 = time.perf_counter()
+        km.step()
+        t_step = time.perf_counter() - t0
+        d1, _ = oracle.lloyd_stats()
+    finally:
+        oracle.lloyd_set_threads(1)
+    pair_solves = Ks * (Ks - 1)
+    t_pw_sample = max(t_step - max(d1 - d0 - pair_solves - Ks, 0) / rate, 0.0)
+    t_pw = t_pw_sample * (K * (K - 1)) / pair_solves
+    per_iter = gpu_out["per_iteration"]
+    d_iter = float(np.median([it["distances"] for it in per_iter[len(per_iter) // 2:]])) - K * (K - 1) - K if per_iter else 0.0
+    t_iter = t_pw + max(d_iter, 0.0) / rate
+    return {"value": gpu_out["N"] / t_iter if t_iter > 0 else 0.0, "unit": "points/s", "cores": threads, "kind": "port",
+            "distances_per_s": rate, "pairwise_s_at_K256": t_pw, "iteration_s_at_full_size": t_iter,
+            "sample": f"oracle/rp_oracle_lloyd.c, OpenMP x{threads}: init_bounds of {Ns} points x {Ks} converged centroids "
+                      f"({Ns * Ks} solves in {t_ib:.1f} s) and one Elkan step ({pair_solves} centroid-pair solves, {t_step:.1f} s); "
+                      f"composed to a full-size iteration: pairwise x{K * (K - 1) / pair_solves:.1f} + {int(max(d_iter, 0))} "
+                      f"point-centroid solves (the GPU run's steady-state count) at the measured rate"}
 
 
 # rooflines of the lloyd kernels (MI355X_MICROARCH.md): HBM 8 TB/s; f32 MFMA 157.3 TFLOP/s = 64 flop/clk/SIMD; VALU: one

@@ -46,6 +46,9 @@ def load() -> C.CDLL:
     o.ora_mccfr_destroy.argtypes = [vp]
     o.ora_mccfr_step.argtypes = [vp]
     o.ora_mccfr_solve.argtypes = [vp, C.c_uint64]
+    o.ora_mccfr_step_mt.argtypes = [vp, C.c_uint32]
+    o.ora_lloyd_set_threads.argtypes = [C.c_int]
+    o.ora_lloyd_max_threads.restype = C.c_int
     o.ora_mccfr_batch.restype = C.c_uint64
     o.ora_mccfr_batch.argtypes = [vp, C.POINTER(C.POINTER(Decision))]
     o.ora_mccfr_step_world.restype = C.c_int
@@ -148,6 +151,10 @@ class OracleSolver:
     def solve(self, trees: int):
         self._o.ora_mccfr_solve(self._h, trees)
         return self
+
+    def step_mt(self, threads: int):
+        """Solver::step with the reference's tree-parallel batch() on `threads` host threads (CPU baseline)"""
+        self._o.ora_mccfr_step_mt(self._h, threads)
 
     # ---- the sharded surface of the C-ABI (rp_mccfr_set_shard / step_local / step_apply), host pointers ----
     def set_shard(self, rank: int, world: int):
@@ -471,6 +478,15 @@ class OracleKmeans:
 
     def rms(self) -> float:
         return self._o.ora_kmeans_rms(self._h)
+
+
+def lloyd_set_threads(n: int):
+    """threads of the oracle's point-parallel k-means loops (CPU baseline; results do not depend on it)"""
+    load().ora_lloyd_set_threads(n)
+
+
+def max_threads() -> int:
+    return load().ora_lloyd_max_threads()
 
 
 def lloyd_stats(reset=False):

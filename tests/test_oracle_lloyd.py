@@ -228,3 +228,27 @@ def test_coupling_flow_folds_to_the_cost_and_has_the_marginals():
         assert np.allclose(pi.sum(axis=0), b / b.sum(), atol=2e-5)
         assert np.allclose(pi.sum(axis=1), a / a.sum(), atol=2e-3)
         assert np.all(flow[a == 0] == 0) and np.all(flow[:, b == 0] == 0)
+
+
+def test_point_parallel_kmeans_equals_the_sequential_oracle():
+    # ora_lloyd_set_threads (bench.py's all-core CPU baseline: rayon par_iter over points / centroid pairs) changes nothing
+    import oracle as O
+    from lloyd_fixtures import flop_like_points, smooth_metric
+
+    pts = flop_like_points(160, bins=32, mass=20, seed=3)
+    tri = smooth_metric(32, 3)
+    hp = O.default_sinkhorn()
+    hp.iterations = 12
+    runs = []
+    for threads in (1, 4):
+        O.lloyd_set_threads(threads)
+        km = O.OracleKmeans(6, pts, "sinkhorn", tri, hp=hp, seed=2)
+        km.init_centroids()
+        km.init_bounds()
+        drift = [km.step()[0].copy() for _ in range(3)]
+        runs.append((km.bounds(), drift, km.assign()))
+    O.lloyd_set_threads(1)
+    (b1, d1, a1), (b2, d2, a2) = runs
+    assert all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(b1, b2))
+    assert all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(d1, d2))
+    assert np.array_equal(a1[0], a2[0]) and np.array_equal(a1[1].view(np.uint32), a2[1].view(np.uint32))

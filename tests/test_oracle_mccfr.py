@@ -195,3 +195,18 @@ def test_division_by_reciprocal_is_exact():
     o.ora_div_unproven.restype = C.c_uint64
     # the single-correction quotient carries an exact proof; "not proven" (-> plain division) must stay rare
     assert o.ora_div_unproven() < 40_000_000 * 1e-3
+
+
+def test_tree_parallel_step_equals_the_sequential_step():
+    # ora_mccfr_step_mt (bench.py's all-core CPU baseline: the reference's rayon batch() + sequential update) must be the
+    # sequential oracle bit for bit, whatever the thread count
+    g = Game("leduc")
+    a = oracle.OracleSolver(g, "linear", "linear", "pluribus", batch=777, seed=3)
+    b = oracle.OracleSolver(g, "linear", "linear", "pluribus", batch=777, seed=3)
+    for threads in (2, 3, 8, 5):
+        a.step()
+        b.step_mt(threads)
+    ra, rb = a.export(), b.export()
+    for f in ("regret", "weight", "payoff", "visits"):
+        assert np.array_equal(ra[f].view(np.uint32), rb[f].view(np.uint32)), f
+    assert a.counters() == b.counters() and a.epoch == b.epoch
