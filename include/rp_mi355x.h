@@ -253,6 +253,23 @@ RP_API int rp_mccfr_step_apply(rp_mccfr* h, const void* gathered_dev, uint32_t w
 RP_API int rp_mccfr_window_local(rp_mccfr* h, void* window_dev, int first);
 RP_API int rp_mccfr_window_apply(rp_mccfr* h, const void* gathered_dev, uint32_t world);
 
+/* ---- rp_comm: the RCCL communicator of a one-process-per-GPU job, for hosts without torch.distributed (a Rust or C
+ * trainer).  Rank 0 calls rp_comm_unique_id and ships the 128 bytes to the other ranks by its own means (MPI, a socket,
+ * a file); every rank then calls rp_comm_create (ncclCommInitRank: collective, blocks until all ranks arrive).  A host that
+ * already owns an ncclComm_t wraps it with rp_comm_adopt (not destroyed by rp_comm_destroy).  librccl is loaded on the
+ * first rp_comm_* call.  SURVEY §8b: rp_mccfr_allreduce(h, rp_comm*). */
+#define RP_COMM_ID_BYTES 128
+typedef struct rp_comm rp_comm;
+RP_API int rp_comm_unique_id(uint8_t* id /* [RP_COMM_ID_BYTES] */);
+RP_API int rp_comm_create(const uint8_t* id, int rank, int world, int device, rp_comm** out);
+RP_API int rp_comm_adopt(void* nccl_comm, int rank, int world, int device, rp_comm** out);
+RP_API int rp_comm_destroy(rp_comm* c);
+/* `steps` Solver::step's of a tree-sharded job (rank = the communicator's): exchange windows of `window` local steps
+ * (rp_mccfr_window_local), ONE ncclAllGather of the window summaries per window on the solver's stream, then
+ * rp_mccfr_window_apply — no host synchronisation inside; a trailing partial window is exchanged too.  Calls
+ * rp_mccfr_set_shard(rank, world) itself.  Every rank must pass the same steps / window. */
+RP_API int rp_mccfr_step_comm(rp_mccfr* h, rp_comm* c, uint32_t steps, uint32_t window);
+
 /* ---- profiling hooks used by bench.py (HIP events on the launch stream) ------------------------- */
 RP_API int rp_mccfr_profile(rp_mccfr* h, int enable);
 /* name in {"traverse","compact","update"}; total milliseconds and launch count since profiling was enabled */
@@ -419,6 +436,9 @@ RP_API int rp_kmeans_kernel_time(rp_kmeans* h, const char* name, double* total_m
  * partial_dev (K*bins u32 counts, K u64 weights, K u64 sizes: partial_bytes()).  After an
  * all-reduce(sum) over ranks, step_finish() installs the centroids, computes drift and updates bounds. */
 RP_API int rp_kmeans_partial_bytes(rp_kmeans* h, size_t* bytes);
+/* Kmeans::next of a point-sharded job over an rp_comm: step_local, ncclAllReduce(sum) of the integer centroid sums
+ * (u32 block and u64 block of the partial, in place, on the layer's stream), step_finish. */
+RP_API int rp_kmeans_step_comm(rp_kmeans* h, rp_comm* c, float* drift, uint64_t* sizes, double* reassigned);
 RP_API int rp_kmeans_step_local(rp_kmeans* h, void* partial_dev);
 RP_API int rp_kmeans_step_finish(rp_kmeans* h, const void* reduced_dev, float* drift, uint64_t* sizes,
                                  double* reassigned);

@@ -154,6 +154,12 @@ _SIGNATURES = {
     "rp_mccfr_step_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "rp_mccfr_window_local": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rp_mccfr_window_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "rp_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "rp_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "rp_comm_adopt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "rp_comm_destroy": (C.c_int, [C.c_void_p]),
+    "rp_mccfr_step_comm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "rp_kmeans_step_comm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "rp_mccfr_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "rp_mccfr_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "rp_profile_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.POINTER(Hyper), C.c_void_p, C.c_uint32,

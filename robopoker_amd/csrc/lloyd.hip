@@ -1815,6 +1815,7 @@ struct rp_kmeans {
     uint64_t n_quads = 0, n_pairs = 0, n_singles = 0;
     Refresh refresh{};            // grouped stale-bound refresh (Sinkhorn; null nsup = off)
     // k-means++ with the column-marginal bound (k_kpp_filter): per round, only the points whose potential can still drop
+    unsigned char* comm_partial = nullptr;  // rp_kmeans_step_comm's exchange buffer
     bool kpp_lb = false;
     uint8_t* d_nsup = nullptr;
     float* minc = nullptr;        // [bins]
@@ -2508,6 +2509,24 @@ int rp_kmeans_step_finish(rp_kmeans* h, const void* reduced_dev, float* drift, u
     HIP_TRY(hipMemcpyAsync(h->cs[nxt].weight, in + cb, wb, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->sizes, in + partial_sizes_offset(h), (size_t)h->K * 8, hipMemcpyDeviceToDevice, h->stream));
     return step_back(h, drift, sizes, reassigned);
+}
+
+int rp_kmeans_step_comm(rp_kmeans* h, rp_comm* c, float* drift, uint64_t* sizes, double* reassigned) {
+    if (!h || !c) return rp::fail(RP_ERR_INVALID, "rp_kmeans_step_comm: NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t nb = partial_sizes_offset(h) + (size_t)h->K * 8;
+    if (!h->comm_partial) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, nb));
+        h->allocs.push_back(p);
+        h->comm_partial = reinterpret_cast<unsigned char*>(p);
+    }
+    int rc = rp_kmeans_step_local(h, h->comm_partial);
+    if (rc) return rc;
+    // exact integers, order free: the u32 block (counts, weights) and the u64 block (sizes) of the partial
+    if ((rc = rp::comm_all_reduce_sum(c, h->comm_partial, (size_t)h->K * h->bins + h->K, 0, h->stream))) return rc;
+    if ((rc = rp::comm_all_reduce_sum(c, h->comm_partial + partial_sizes_offset(h), h->K, 1, h->stream))) return rc;
+    return rp_kmeans_step_finish(h, h->comm_partial, drift, sizes, reassigned);
 }
 
 int rp_kmeans_step_naive(rp_kmeans* h) {

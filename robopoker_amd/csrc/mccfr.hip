@@ -1536,6 +1536,8 @@ struct rp_mccfr {
     void* d_scratch = nullptr;
     void* d_dec = nullptr;
     void* d_summary = nullptr;
+    void* d_window = nullptr;      // rp_mccfr_step_comm: this rank's window summary, then every rank's (all-gathered)
+    uint32_t window_world = 0;
     void* d_sorted = nullptr;
     void* d_bmaps = nullptr;
     uint32_t maxint = 1;  // most internal nodes of a sampled tree
@@ -2050,7 +2052,8 @@ int rp_mccfr_destroy(rp_mccfr* h) {
     clock_drain(h->clk_compact);
     clock_drain(h->clk_update);
     void* ptrs[] = {h->d_states, h->d_children, h->d_kids, h->d_payoffs, h->d_info_actions, h->d_info_player, h->d_scratch,
-                    h->d_dec, h->d_sorted, h->d_bmaps, h->d_itab, h->d_summary, h->d_counters, h->t.regret, h->t.weight, h->t.payoff, h->t.visits};
+                    h->d_dec, h->d_sorted, h->d_bmaps, h->d_itab, h->d_summary, h->d_window, h->d_counters, h->t.regret, h->t.weight, h->t.payoff,
+                    h->t.visits};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -2399,6 +2402,37 @@ int rp_mccfr_window_apply(rp_mccfr* h, const void* gathered_dev, uint32_t world)
     hipLaunchKernelGGL(k_fold, dim3((ncell + 255) / 256), dim3(256), 0, h->stream, h->g, h->t,
                        reinterpret_cast<const unsigned char*>(gathered_dev), summary_bytes_of(h), world);
     HIP_TRY(hipGetLastError());
+    return RP_OK;
+}
+
+int rp_mccfr_step_comm(rp_mccfr* h, rp_comm* c, uint32_t steps, uint32_t window) {
+    if (!h || !c) return rp::fail(RP_ERR_INVALID, "rp_mccfr_step_comm: NULL argument");
+    if (window == 0) window = 1;
+    int rc = set_device(h);
+    if (rc) return rc;
+    if ((rc = composed_supported(h))) return rc;
+    const uint32_t world = (uint32_t)rp::comm_world(c);
+    h->rank = (uint32_t)rp::comm_rank(c);
+    h->world = world;
+    const size_t nb = summary_bytes_of(h);
+    if (!h->d_window || h->window_world != world) {  // [mine][all ranks]
+        if (h->d_window) (void)hipFree(h->d_window);
+        h->d_window = nullptr;
+        HIP_TRY(hipMalloc(&h->d_window, nb * (world + 1)));
+        h->window_world = world;
+    }
+    unsigned char* mine = reinterpret_cast<unsigned char*>(h->d_window);
+    unsigned char* all = mine + nb;
+    uint32_t pending = 0;
+    for (uint32_t s = 0; s < steps; ++s) {
+        if ((rc = rp_mccfr_window_local(h, mine, pending == 0))) return rc;
+        pending += 1;
+        if (pending == window || s + 1 == steps) {
+            if ((rc = rp::comm_all_gather(c, mine, all, nb, h->stream))) return rc;
+            if ((rc = rp_mccfr_window_apply(h, all, world))) return rc;
+            pending = 0;
+        }
+    }
     return RP_OK;
 }
 

@@ -20,4 +20,14 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
 }  // namespace rp
 
+// comm.cpp: the collectives behind rp_comm, enqueued on the caller's HIP stream
+struct rp_comm;
+struct ihipStream_t;
+namespace rp {
+int comm_world(const rp_comm* c);
+int comm_rank(const rp_comm* c);
+int comm_all_gather(rp_comm* c, const void* send, void* recv, size_t bytes, ihipStream_t* stream);
+int comm_all_reduce_sum(rp_comm* c, void* buf, size_t count, int kind /* 0 = i32, 1 = i64 */, ihipStream_t* stream);
+}  // namespace rp
+
 #endif

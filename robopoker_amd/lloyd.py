@@ -173,6 +173,14 @@ class Layer:
                                                    C.byref(re)))
         return drift, sizes, re.value
 
+    def step_comm(self, comm):
+        """Kmeans::next of a point-sharded job over an ``rp_comm``: integer centroid sums all-reduced by the library"""
+        drift = np.zeros(self.K, dtype=np.float32)
+        sizes = np.zeros(self.K, dtype=np.uint64)
+        re = C.c_double()
+        _lib.check(self._lib.rp_kmeans_step_comm(self._h, comm.handle, _p(drift), _p(sizes), C.byref(re)))
+        return drift, sizes, re.value
+
     def set_stream(self, hip_stream_ptr):
         _lib.check(self._lib.rp_kmeans_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
 

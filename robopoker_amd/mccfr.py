@@ -171,6 +171,11 @@ class Solver:
     def window_apply(self, gathered_dev_ptr: int, world: int):
         _lib.check(self._lib.rp_mccfr_window_apply(self._h, C.c_void_p(gathered_dev_ptr), world))
 
+    def step_comm(self, comm, steps: int, window: int = 1):
+        """``steps`` sharded steps over an ``rp_comm`` (robopoker_amd.parallel.Comm): exchange windows of ``window`` local
+        steps, one ncclAllGather per window on the solver's stream, no host work in between"""
+        _lib.check(self._lib.rp_mccfr_step_comm(self._h, comm.handle, steps, window))
+
     # ---- profiling hooks ------------------------------------------------------------------------
     def profile(self, enable=True):
         _lib.check(self._lib.rp_mccfr_profile(self._h, 1 if enable else 0))

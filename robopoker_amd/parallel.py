@@ -58,6 +58,54 @@ def _all_gather_bytes(out: torch.Tensor, mine: torch.Tensor, group=None, flat=No
         dist.all_gather(list(out.view(world, -1).unbind(0)), mine, group=group)
 
 
+class Comm:
+    """rp_comm: the library's own RCCL communicator (csrc/comm.cpp) — what a host without torch.distributed uses.  Here the
+    128-byte id travels over torch.distributed's broadcast; a Rust / C host ships it by MPI, a socket or a file."""
+
+    def __init__(self, rank: int, world: int, device: int, unique_id: bytes):
+        import ctypes as C
+
+        from . import _lib
+
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _lib.check(self._lib.rp_comm_create(buf, rank, world, device, C.byref(self._h)))
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        from . import _lib
+
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.load().rp_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_process_group(cls, device: int, group=None):
+        """rank 0 makes the id, torch.distributed broadcasts it, every rank joins (collective)"""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        on_gpu = dist.get_backend(group) == "nccl"
+        t = torch.zeros(128, dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, src=0, group=group)
+        return cls(rank, world, device, bytes(t.cpu().numpy().tobytes()))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rp_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
 class _StreamScope:
     """On a GPU the engine's kernels and the collectives must share ONE stream so they are ordered without host
     synchronisation: a dedicated (non-null) torch stream is handed to the engine and made current around every

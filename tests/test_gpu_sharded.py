@@ -130,3 +130,38 @@ def test_kmeans_two_shards_on_one_gpu_match_single(gpu, kind):
         j, u, _ = s.bounds()
         assert np.array_equal(j, sj[cuts[r]:cuts[r + 1]])
         assert np.array_equal(u.view(np.uint32), su[cuts[r]:cuts[r + 1]].view(np.uint32))
+
+
+def test_native_rccl_comm_world_of_one(gpu):
+    # rp_comm (csrc/comm.cpp): the library's own RCCL communicator, as a non-Python host would use it — unique id, join,
+    # ncclAllGather / ncclAllReduce on the solver's and the layer's streams.  One GPU here, so a world of one rank: the
+    # collectives are real RCCL calls, the results must be the world-model's (oracle) resp. the unsharded step's, bitwise.
+    from robopoker_amd.parallel import Comm
+
+    comm = Comm(0, 1, 0, Comm.unique_id())
+    g = Game("leduc")
+    dev = Solver(g, "linear", "linear", "external", batch=640, seed=3)
+    ora = oracle.OracleSolver(g, "linear", "linear", "external", batch=640, seed=3)
+    dev.step_comm(comm, steps=7, window=3)  # windows of 3, 3 and a trailing 1
+    dev.sync()
+    for w in (3, 3, 1):
+        ora.window_world(1, w)
+    got, exp = dev.export(), ora.export()
+    for f in ("visits", "regret", "weight", "payoff"):
+        assert np.array_equal(got[f].view(np.uint32), exp[f].view(np.uint32)), f
+    assert dev.epoch == 7 and dev.counters() == ora.counters()
+    # k-means: step_comm == step
+    pts = flop_like_points(400, bins=32, mass=20, seed=2)
+    tri = smooth_metric(32, 2)
+    hp = oracle.default_sinkhorn()
+    hp.iterations = 12
+    a = lloyd.Layer(6, pts, "sinkhorn", tri, hp=hp, seed=2)
+    b = lloyd.Layer(6, pts, "sinkhorn", tri, hp=hp, seed=2)
+    for km in (a, b):
+        km.init_centroids()
+        km.init_bounds()
+    for _ in range(3):
+        d1, s1, m1 = a.step_comm(comm)
+        d2, s2, m2 = b.step()
+        assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32)) and np.array_equal(s1, s2) and m1 == m2
+    comm.close()
