@@ -312,6 +312,8 @@ RP_API int rp_profile_epoch(const rp_profile* h, uint64_t* epoch);
 RP_API int rp_profile_set_epoch(rp_profile* h, uint64_t epoch);
 /* out[i*max_actions + a] = Encounter of (rows[i], action a); rows is a HOST array */
 RP_API int rp_profile_get_rows(rp_profile* h, uint64_t n, const uint32_t* rows, rp_encounter* out);
+/* overwrite rows from the host (hydrate / resynchronisation): in[i*max_actions + a] -> (rows[i], action a) */
+RP_API int rp_profile_set_rows(rp_profile* h, uint64_t n, const uint32_t* rows, const rp_encounter* in);
 RP_API int rp_profile_set_stream(rp_profile* h, void* hip_stream);
 /* multi-GPU: bytes of one summary entry (16 + 2*max_actions*16), and the two halves of a sharded step.
  * summarize: this rank's batch -> entries sorted by row in `entries_dev` (capacity >= batch->n entries);
@@ -324,6 +326,38 @@ RP_API int rp_profile_fold(rp_profile* h, const void* entries_dev, uint32_t n_en
 /* name in {"sort","apply"}: HIP-event milliseconds since rp_profile_profile(h, 1) */
 RP_API int rp_profile_profile(rp_profile* h, int enable);
 RP_API int rp_profile_kernel_time(rp_profile* h, const char* name, double* total_ms, uint64_t* launches);
+
+/* ===================================================================== nlhe ==
+ * The blueprint trainer's solver: mccfr!(Nlhe, NlheEncoder, NlheTurn, NlheEdge, NlheGame, NlheInfo, 128)
+ * (crates/nlhe/src/solver.rs:11) — external-sampling MCCFR over heads-up no-limit hold'em, the game generated on the
+ * device (kicker::Game rules, the Pluribus action abstraction), infosets keyed by NlheInfo = (subgame Path, abstraction
+ * bucket, choices Path) (nlhe/src/info.rs:145-160; columns past BIGINT, present SMALLINT, choices BIGINT of the blueprint
+ * table, nlhe/src/profile.rs:20-31) and hashed to rows of an rp_profile table.  The encoder's isomorphism -> abstraction
+ * map (NlheEncoder, nlhe/src/encoder.rs:30-36) is the four rp_lookup tables the clustering pipeline produces
+ * (tables[street], street = 0 pref .. 3 river); tables = NULL selects a hash of the canonical observation (tests).
+ * 2^cap_log2 table rows of 9 actions (144 B each); batch = trees per step (0 = the reference's 128).  External sampling,
+ * 2 players, stacks of 100 big blinds.  Oracle: oracle/rp_oracle_nlmc.c. */
+typedef struct rp_nlhe rp_nlhe;
+typedef struct rp_lookup rp_lookup;
+RP_API int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weight_kind weight, const rp_hyper* hp,
+                          uint64_t seed, uint32_t batch, const rp_lookup* const* tables, rp_nlhe** out);
+RP_API int rp_nlhe_destroy(rp_nlhe* h);
+/* Solver::step (solver.rs:96-105): the batch's trees, their Decisions, the table update (ordered or composed), epoch += 1 */
+RP_API int rp_nlhe_step(rp_nlhe* h, rp_update_mode mode);
+/* Solver::batch (solver.rs:225-250) alone, for inspection: the Decisions of the current epoch in tree order, each with
+ * the infoset behind its row; *n = their number, at most `cap` are copied out; any output may be NULL.
+ * regret / policy: [n][9]. */
+RP_API int rp_nlhe_batch(rp_nlhe* h, uint32_t cap, uint32_t* n, uint32_t* tree, uint64_t* past, uint32_t* present, uint64_t* choices,
+                         uint8_t* n_actions, uint16_t* expanded, float* regret, float* policy, float* payoff);
+RP_API int rp_nlhe_epoch(rp_nlhe* h, uint64_t* epoch);
+/* nodes / infos: Solver::inc_nodes / inc_infos (solver.rs:252-275); keys: infosets in the table */
+RP_API int rp_nlhe_counters(rp_nlhe* h, uint64_t* nodes, uint64_t* infos, uint64_t* keys);
+/* NlheProfile::rows (nlhe/src/profile.rs:144-163) without the edge expansion: every infoset with its 9 Encounters
+ * (slot a = the a-th edge of `choices`); *n = infosets in the table, at most `cap` are copied */
+RP_API int rp_nlhe_export(rp_nlhe* h, uint64_t cap, uint64_t* n, uint64_t* past, uint32_t* present, uint64_t* choices, rp_encounter* enc);
+/* Hydrate (profile.rs:90-141): load Encounters by infoset; sets the epoch */
+RP_API int rp_nlhe_import(rp_nlhe* h, uint64_t n, const uint64_t* past, const uint32_t* present, const uint64_t* choices,
+                          const rp_encounter* enc, uint64_t epoch);
 
 /* ===================================================================== lloyd ==
  * crates/elkan: Elkan<K,N> (elkan.rs:27-207), Bounds (bounds.rs:19-120), Prior::tally (prior.rs:35-47)

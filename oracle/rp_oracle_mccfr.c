@@ -1024,6 +1024,17 @@ ORA_API void ora_profile_get(const ora_mccfr* h, uint32_t row, rp_encounter* out
     }
 }
 ORA_API void ora_profile_set_epoch(ora_mccfr* h, uint64_t e) { h->epoch = e; }
+/* overwrite one row (rp_oracle_nlmc.c: a freshly met infoset starts at its edge-wise default regrets; resynchronisation) */
+void ora_profile_set_row(ora_mccfr* h, uint32_t row, const rp_encounter* in) {
+    uint32_t A = h->g.max_actions;
+    for (uint32_t a = 0; a < A; ++a) {
+        size_t k = (size_t)row * A + a;
+        h->weight[k] = in[a].weight;
+        h->regret[k] = in[a].regret;
+        h->payoff[k] = in[a].payoff;
+        h->visits[k] = in[a].visits;
+    }
+}
 
 /* summary entry: [row u32][count u32][psum f32][n_actions u32][regret maps A x {a,b,m,n}][weight maps A x {a,b,m,n}] */
 ORA_API size_t ora_profile_entry_bytes(const ora_mccfr* h) { return 16 + (size_t)2 * h->g.max_actions * sizeof(ora_map); }

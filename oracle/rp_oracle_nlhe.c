@@ -14,35 +14,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#define ORA_API __attribute__((visibility("default")))
-#define MAXP 10
-#define S_BLIND 1
-#define B_BLIND 2
-
-uint32_t ora_strength_key(uint64_t hand); /* oracle/rp_oracle_deuce.c */
-
-enum { BETTING = 0, SHOVING = 1, FOLDING = 2 };                                      /* seat.rs:79-84 */
-enum { A_DRAW = 0, A_FOLD, A_CALL, A_CHECK, A_RAISE, A_SHOVE, A_BLIND };             /* action.rs:8-16 */
-enum { T_TERMINAL = -2, T_CHANCE = -1 };                                             /* turn.rs:2-6; >= 0: Choice(i) */
-
-typedef struct {
-    int32_t state;
-    int16_t stack, stake, spent;
-    uint64_t cards;
-} ora_seat;
-typedef struct {
-    int32_t n;      /* P */
-    int32_t dealer; /* game.rs:30-36 */
-    int32_t ticker;
-    int16_t pot;
-    uint64_t board;
-    ora_seat seats[MAXP];
-} ora_game;
-typedef struct {
-    int32_t kind;
-    int16_t chips;
-    uint64_t cards;
-} ora_action;
+#include "rp_oracle_nlhe.h"
 
 static int popc(uint64_t x) { return __builtin_popcountll(x); }
 static int street_of(const ora_game* g) { /* Board::street: 0, 3, 4, 5 cards */
@@ -383,9 +355,7 @@ ORA_API ora_action ora_nlhe_snap(const ora_game* g, ora_action a) {
  * An Edge travels as its u8 code (edge.rs:101-120): 1 Draw, 2 Fold, 3 Check, 4 Call, 5 Shove, 6..9 Open(OPENS[c-6] big
  * blinds), 10..19 Raise(RAISES[c-10] of the pot).  Pluribus regime (pokerkit/src/regime.rs:20-24, the default).
  * ================================================================================================================ */
-enum { E_DRAW = 1, E_FOLD = 2, E_CHECK = 3, E_CALL = 4, E_SHOVE = 5, E_OPEN0 = 6, E_RAISE0 = 10 };
 #define MAX_RAISE_REPEATS 3 /* lib.rs:68 */
-#define MAX_PATH_EDGES 12   /* lib.rs:73 */
 static const int16_t OPENS[4] = {2, 3, 4, 5};                                                                /* lib.rs:81 */
 static const int16_t RAISES[10][2] = {{1, 4}, {1, 3}, {1, 2}, {2, 3}, {3, 4}, {1, 1}, {5, 4}, {3, 2}, {2, 1}, {3, 1}}; /* :86-97 */
 static const int8_t PLURIBUS[12][6] = { /* lib.rs:138-151: indices into RAISES, -1 terminated; row = street*3 + min(depth, 2) */

@@ -227,6 +227,16 @@ _SIGNATURES = {
     "rp_equity_variation": (C.c_int, [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "rp_mccfr_train": (C.c_int, [C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "rp_nlhe_create": (C.c_int, [C.c_int, C.c_uint32, C.c_int, C.c_int, C.POINTER(Hyper), C.c_uint64, C.c_uint32, C.c_void_p,
+                                 C.POINTER(C.c_void_p)]),
+    "rp_nlhe_destroy": (C.c_int, [C.c_void_p]),
+    "rp_nlhe_step": (C.c_int, [C.c_void_p, C.c_int]),
+    "rp_nlhe_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)] + [C.c_void_p] * 9),
+    "rp_nlhe_epoch": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rp_nlhe_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rp_nlhe_export": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rp_nlhe_import": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "rp_profile_set_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rp_nlhe_playouts": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rp_hand_strength": (C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rp_obs_canonical": (C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),

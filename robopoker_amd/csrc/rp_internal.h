@@ -13,6 +13,8 @@
 #define RP_STR2(x) #x
 #define RP_STR(x) RP_STR2(x)
 
+struct ihipStream_t;
+
 namespace rp {
 
 // records the message for rp_last_error() and returns the code
@@ -20,9 +22,18 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
 }  // namespace rp
 
+// sparse.hip / deuce.hip: what nlmc.hip needs of the profile and of the encoder tables
+struct rp_profile;
+struct rp_lookup;
+namespace rp {
+float* profile_table(rp_profile* h);
+ihipStream_t* profile_stream(rp_profile* h);
+uint64_t profile_epoch(const rp_profile* h);
+int lookup_view(const rp_lookup* t, const uint64_t** keys, const uint8_t** abs_, uint64_t* n, int* street);
+}  // namespace rp
+
 // comm.cpp: the collectives behind rp_comm, enqueued on the caller's HIP stream
 struct rp_comm;
-struct ihipStream_t;
 namespace rp {
 int comm_world(const rp_comm* c);
 int comm_rank(const rp_comm* c);

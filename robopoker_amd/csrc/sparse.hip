@@ -632,6 +632,11 @@ struct rp_profile {
 
 namespace rp {
 
+// nlmc.hip: the NLHE traversal reads (and initialises the rows of) the table it feeds
+float* profile_table(rp_profile* h) { return h->tab; }
+hipStream_t profile_stream(rp_profile* h) { return h->stream; }
+uint64_t profile_epoch(const rp_profile* h) { return h->epoch; }
+
 static size_t entry_bytes_of(const rp_profile* h) { return 16 + (size_t)2 * h->A * sizeof(Map); }
 // sum over rows of ceil(count / RP_SPARSE_BLOCK) <= rows + n / RP_SPARSE_BLOCK <= n + n / RP_SPARSE_BLOCK
 static uint32_t max_blocks_of(uint32_t n) { return n + n / RP_SPARSE_BLOCK + 1u; }
@@ -932,6 +937,27 @@ int rp_profile_get_rows(rp_profile* h, uint64_t n, const uint32_t* rows, rp_enco
     HIP_TRY(hipStreamSynchronize(h->stream));
     (void)hipFree(d_rows);
     (void)hipFree(d_out);
+    return RP_OK;
+}
+
+int rp_profile_set_rows(rp_profile* h, uint64_t n, const uint32_t* rows, const rp_encounter* in) {
+    if (!h || (n && (!rows || !in))) return rp::fail(RP_ERR_INVALID, "rp_profile_set_rows: null argument");
+    if (n == 0) return RP_OK;
+    for (uint64_t i = 0; i < n; ++i)
+        if (rows[i] >= h->n_rows) return rp::fail(RP_ERR_INVALID, "rp_profile_set_rows: row %u out of range", rows[i]);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<float> row(4u * h->A);
+    for (uint64_t i = 0; i < n; ++i) {  // a resynchronisation path (tests, hydrate): one small copy per row
+        for (uint32_t a = 0; a < h->A; ++a) {
+            const rp_encounter& e = in[i * h->A + a];
+            row[a] = e.regret;
+            row[h->A + a] = e.weight;
+            row[2 * h->A + a] = e.payoff;
+            memcpy(&row[3 * h->A + a], &e.visits, 4);
+        }
+        HIP_TRY(hipMemcpy(h->tab + (size_t)rows[i] * 4u * h->A, row.data(), row.size() * 4, hipMemcpyHostToDevice));
+    }
     return RP_OK;
 }
 

@@ -2,9 +2,90 @@
 abstract hands played by the device-side restatement of ``kicker::GameN`` / ``NlheGame::apply`` / ``Showdown::settle``."""
 from __future__ import annotations
 
+import ctypes as C
+
+import numpy as np
 import torch  # before the first HIP call of librp_mi355x.so: one HIP runtime per process
 
 from . import _lib
+
+A = 9  # widest NLHE infoset (pokerkit/src/lib.rs:130-133)
+ENC_DTYPE = np.dtype([("weight", "<f4"), ("regret", "<f4"), ("payoff", "<f4"), ("visits", "<u4")])
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class NlheSolver:
+    """``mccfr!(Nlhe, NlheEncoder, NlheTurn, NlheEdge, NlheGame, NlheInfo, 128)`` (crates/nlhe/src/solver.rs:11) on one
+    MI355X: ``step`` = ``Solver::step``, ``batch`` = ``Solver::batch`` (inspection), ``export`` / ``load`` = the blueprint
+    rows by NlheInfo.  ``tables``: the encoder's four ``deuce.Lookup`` (pref, flop, turn, river); None = hash encoder."""
+
+    def __init__(self, cap_log2=20, regret="linear", weight="linear", batch=128, seed=0, hyper=None, tables=None, device=0):
+        self._lib = _lib.load()
+        self.hp = hyper
+        if self.hp is None:
+            self.hp = _lib.Hyper()
+            self._lib.rp_hyper_default(C.byref(self.hp))
+        self.batch_size = batch
+        self._tables = tables
+        tab = None
+        if tables is not None:
+            arr = (C.c_void_p * 4)(*[t._h for t in tables])
+            tab = C.cast(arr, C.c_void_p)
+            self._tab_arr = arr
+        self._h = C.c_void_p()
+        _lib.check(self._lib.rp_nlhe_create(device, cap_log2, _lib.REGRET[regret], _lib.WEIGHT[weight], C.byref(self.hp), seed, batch,
+                                            tab, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rp_nlhe_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def step(self, mode="ordered"):
+        _lib.check(self._lib.rp_nlhe_step(self._h, _lib.UPDATE[mode]))
+
+    def batch(self, cap=1 << 22):
+        n = C.c_uint32()
+        _lib.check(self._lib.rp_nlhe_batch(self._h, 0, C.byref(n), *([None] * 9)))
+        m = min(cap, n.value)
+        out = dict(n=n.value, tree=np.zeros(m, np.uint32), past=np.zeros(m, np.uint64), present=np.zeros(m, np.uint32),
+                   choices=np.zeros(m, np.uint64), n_actions=np.zeros(m, np.uint8), expanded=np.zeros(m, np.uint16),
+                   regret=np.zeros((m, A), np.float32), policy=np.zeros((m, A), np.float32), payoff=np.zeros(m, np.float32))
+        _lib.check(self._lib.rp_nlhe_batch(self._h, m, C.byref(n), _p(out["tree"]), _p(out["past"]), _p(out["present"]), _p(out["choices"]),
+                                           _p(out["n_actions"]), _p(out["expanded"]), _p(out["regret"]), _p(out["policy"]), _p(out["payoff"])))
+        return out
+
+    @property
+    def epoch(self) -> int:
+        e = C.c_uint64()
+        _lib.check(self._lib.rp_nlhe_epoch(self._h, C.byref(e)))
+        return e.value
+
+    def counters(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _lib.check(self._lib.rp_nlhe_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def export(self):
+        n = C.c_uint64()
+        _lib.check(self._lib.rp_nlhe_export(self._h, 0, C.byref(n), None, None, None, None))
+        m = n.value
+        past, present, choices = np.zeros(m, np.uint64), np.zeros(m, np.uint32), np.zeros(m, np.uint64)
+        enc = np.zeros((m, A), dtype=ENC_DTYPE)
+        _lib.check(self._lib.rp_nlhe_export(self._h, m, C.byref(n), _p(past), _p(present), _p(choices), _p(enc)))
+        return past, present, choices, enc
+
+    def load(self, past, present, choices, enc, epoch: int):
+        past, present, choices = (np.ascontiguousarray(past, np.uint64), np.ascontiguousarray(present, np.uint32),
+                                  np.ascontiguousarray(choices, np.uint64))
+        enc = np.ascontiguousarray(enc, dtype=ENC_DTYPE)
+        _lib.check(self._lib.rp_nlhe_import(self._h, past.size, _p(past), _p(present), _p(choices), _p(enc), epoch))
+
 
 
 def playouts(n_players: int, n_games: int, seed: int, max_steps: int = 200, device: int = 0):

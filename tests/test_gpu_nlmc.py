@@ -1,0 +1,76 @@
+"""GPU parity of the NLHE MCCFR traversal (robopoker_amd/csrc/nlmc.hip, rp_nlhe_*) against oracle/rp_oracle_nlmc.c.
+
+Integer state — which trees are sampled (hole cards, boards, opponent actions), every infoset key, the Decisions' order,
+action counts and expanded masks, the counters, the visits — must be IDENTICAL.  The policy vector is the same float
+operations on both sides: identical bits.  Regret vectors and infoset values come from the factorised evaluation
+D(node) = sum f(edge) D(child) on the device and from the reference's per-leaf reach products in the oracle (flow.rs:182-216):
+the same real number, a different f32 association — stated tolerance rtol 2e-4 / atol 2e-3 chips."""
+import numpy as np
+import pytest
+
+import oracle_nlmc as M
+from robopoker_amd.nlhe import NlheSolver
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_batch(d, o):
+    assert d["n"] == o["n"]
+    n = d["n"]
+    assert np.array_equal(d["tree"][:n], o["tree"][:n].astype(np.uint32))
+    assert np.array_equal(d["n_actions"], o["n_actions"]) and np.array_equal(d["expanded"], o["expanded"])
+    assert np.array_equal(d["policy"].view(np.uint32), o["policy"].view(np.uint32))
+    np.testing.assert_allclose(d["regret"], o["regret"], rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(d["payoff"], o["payoff"], rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("batch,seed", [(64, 5), (300, 12)])
+def test_first_batch_equals_the_oracle(gpu, batch, seed):
+    dev = NlheSolver(cap_log2=18, batch=batch, seed=seed)
+    ora = M.OracleNlhe(cap_log2=18, batch=batch, seed=seed)
+    d, o = dev.batch(), ora.batch()
+    # rows differ between the two tables (insertion order); the infosets behind them must not
+    past, present, choices, _ = ora.export()
+    # the oracle's batch carries rows of ITS table: translate through its export order (slot order = row order)
+    _same_batch(d, o)
+    okeys = sorted(zip(past.tolist(), present.tolist(), choices.tolist()))
+    dp, db, dc, _ = dev.export()
+    assert sorted(zip(dp.tolist(), db.tolist(), dc.tolist())) == okeys
+    # and Decision by Decision the same infoset
+    omap = {}
+    for k, (p, b, c) in enumerate(zip(past, present, choices)):
+        omap[k] = (int(p), int(b), int(c))
+    assert dev.counters()[2] == ora.counters()[2]
+
+
+def test_steps_with_resynchronisation_track_the_oracle(gpu):
+    # four Solver::steps (both walkers twice).  After each: the same infosets, identical visits, regrets / weights / payoffs
+    # within the stated tolerance; then the device table is overwritten with the oracle's so the NEXT step samples the same
+    # opponent actions on both sides (a sampled edge is a threshold test on f32 weights).
+    batch = 128  # the reference's batch_size (nlhe/src/solver.rs:11)
+    dev = NlheSolver(cap_log2=18, regret="linear", weight="linear", batch=batch, seed=21)
+    ora = M.OracleNlhe(cap_log2=18, regret="linear", weight="linear", batch=batch, seed=21)
+    for step in range(4):
+        _same_batch(dev.batch(), ora.batch())
+        dev.step("ordered")
+        ora.step()
+        dm, om = M.as_map(*dev.export()), M.as_map(*ora.export())
+        assert dm.keys() == om.keys()
+        for k in om:
+            assert np.array_equal(dm[k]["visits"], om[k]["visits"]), (step, k)
+            np.testing.assert_allclose(dm[k]["regret"], om[k]["regret"], rtol=2e-4, atol=5e-3)
+            np.testing.assert_allclose(dm[k]["weight"], om[k]["weight"], rtol=2e-4, atol=1e-5)
+            np.testing.assert_allclose(dm[k]["payoff"], om[k]["payoff"], rtol=2e-4, atol=5e-3)
+        assert dev.counters() == ora.counters() and dev.epoch == ora.epoch == step + 1
+        dev.load(*ora.export(), epoch=ora.epoch)
+
+
+def test_large_batch_runs_and_conserves_visits(gpu):
+    # a GPU-sized batch (the reference's 128 trees fill two wavefronts): every Decisions lands on its infoset exactly once
+    dev = NlheSolver(cap_log2=21, batch=8192, seed=2)
+    for _ in range(2):
+        dev.step("composed")
+    nodes, infos, keys = dev.counters()
+    past, present, choices, enc = dev.export()
+    assert len(past) == keys and int(enc["visits"][:, 0].sum()) == infos
+    assert 100 * 8192 * 2 < nodes < 1500 * 8192 * 2 and dev.epoch == 2

@@ -1,0 +1,92 @@
+"""The NLHE MCCFR oracle (oracle/rp_oracle_nlmc.c): structural properties of the Decisions it produces and of the table it
+trains.  (The rules underneath are pinned to the reference's unit tests in test_oracle_nlhe.py; the generic MCCFR loop to
+the reference's Kuhn / Leduc thresholds in test_oracle_mccfr.py — this file checks the NLHE instance of both.)"""
+import numpy as np
+
+import oracle_nlhe as rules
+import oracle_nlmc as M
+
+
+def _edges(path):
+    out = []
+    while path and (path & 0x1f):
+        out.append(path & 0x1f)
+        path >>= 5
+    return out
+
+
+def test_first_batch_decisions_are_well_formed():
+    s = M.OracleNlhe(cap_log2=16, batch=48, seed=11)
+    b = s.batch()
+    assert b["n"] > 48  # a few dozen walker infosets per tree
+    past, present, choices, enc = s.export()
+    keyed = M.as_map(past, present, choices, enc)
+    assert len(keyed) == s.counters()[2]
+    for i in range(b["n"]):
+        n = int(b["n_actions"][i])
+        assert 2 <= n <= M.A and b["expanded"][i] == (1 << n) - 1  # external sampling expands every walker edge
+        pol, reg = b["policy"][i, :n], b["regret"][i, :n]
+        assert abs(float(pol.sum()) - 1.0) < 1e-5 and np.all(pol > 0)
+        assert np.all(b["policy"][i, n:] == 0) and np.all(b["regret"][i, n:] == 0)
+        # regret_a = cfv_a - ev with ev = sum sigma_a cfv_a per root: the policy-weighted regret vanishes (summed over a span too)
+        assert abs(float((pol * reg).sum())) < 2e-3 * max(1.0, float(np.abs(reg).max()))
+        assert abs(float(b["payoff"][i])) <= 400.0 * 64  # |payoff| <= the stacks times the span
+    # trees are emitted in tree order
+    assert np.all(np.diff(b["tree"].astype(np.int64)) >= 0) and b["tree"].max() < 48
+
+
+def test_infoset_keys_follow_the_reference_layout():
+    # NlheInfo (nlhe/src/info.rs:145-160): past = the choice edges of the current street (never a Draw), choices = the edges
+    # offered there, in legal() order (raises, shove, call, fold | check); the bucket is below the street's bucket count
+    s = M.OracleNlhe(cap_log2=16, batch=64, seed=3)
+    s.step()
+    past, present, choices, enc = s.export()
+    assert len(past) > 500
+    for p, b, c in zip(past, present, choices):
+        pe, ce = _edges(int(p)), _edges(int(c))
+        assert 1 not in pe and 1 not in ce and 2 <= len(ce) <= M.A and b < 256
+        assert len(set(ce)) == len(ce)
+        raises = [e for e in ce if e >= 6]
+        assert ce[: len(raises)] == raises  # the raise grid comes first (game.rs:253-283)
+        assert not (2 in ce and 3 in ce)  # fold and check exclude each other
+    # a fresh infoset starts at the edge-wise bias (kicker/src/edge.rs:61-72, bias.rs:47-70)
+    fresh = enc["visits"].sum(axis=1) == 0
+    assert fresh.any()
+    bias = {2: 100.0, 3: 50.0, 4: 50.0, 5: 0.0}
+    for c, row in zip(choices[fresh], enc[fresh]):
+        for a, e in enumerate(_edges(int(c))):
+            assert row["regret"][a] == bias.get(e, 10.0) and row["weight"][a] == 0.0
+
+
+def test_steps_are_deterministic_and_counters_add_up():
+    a = M.OracleNlhe(cap_log2=17, batch=32, seed=7)
+    b = M.OracleNlhe(cap_log2=17, batch=32, seed=7)
+    for _ in range(3):
+        a.step()
+        b.step()
+    ea, eb = M.as_map(*a.export()), M.as_map(*b.export())
+    assert ea.keys() == eb.keys() and a.counters() == b.counters() and a.epoch == 3
+    for k in ea:
+        assert ea[k].tobytes() == eb[k].tobytes()
+    nodes, infos, keys = a.counters()
+    visits = sum(int(v["visits"][0]) for v in ea.values())
+    assert visits == infos  # every Decisions touches its infoset once (solver.rs:187-192)
+    assert nodes > infos > 0 and keys >= len([1 for v in ea.values() if v["visits"][0]])
+
+
+def test_hash_encoder_uses_the_canonical_observation():
+    # suit-isomorphic observations must share a bucket: (As Kh | 2c 7d Jh) and its image under a suit permutation
+    o = M.lib()
+    import oracle_deuce as od
+
+    def bucket(street, pocket, board):
+        cp, cb = od.isomorphism(pocket, board)
+        return o.ora_nlmc_hash_bucket(street, od.obs_i64(cp, cb))
+
+    def card(rank, suit):
+        return 1 << (4 * rank + suit)
+
+    p1, b1 = card(12, 3) | card(11, 2), card(0, 0) | card(5, 1) | card(9, 2)
+    p2, b2 = card(12, 0) | card(11, 1), card(0, 3) | card(5, 2) | card(9, 1)  # suits 3->0, 2->1, 0->3, 1->2
+    assert bucket(1, p1, b1) == bucket(1, p2, b2)
+    assert rules is not None
