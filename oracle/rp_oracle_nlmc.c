@@ -128,9 +128,10 @@ static uint32_t abstraction(const ora_nlmc* h, const ora_game* g, int seat) {
     uint64_t cp, cb;
     const int street = ora_nlhe_street(g);
     ora_isomorphism(g->seats[seat].cards, g->board, &cp, &cb);
-    if (h->encoder == 0) return ora_nlmc_hash_bucket(street, ora_obs_to_i64(cp, cb));
+    /* Abstraction = [8 bits street][8 bits index] (kicker/src/abstraction.rs:14-24,70-76): the `present SMALLINT` column */
+    if (h->encoder == 0) return ((uint32_t)street << 8) | ora_nlmc_hash_bucket(street, ora_obs_to_i64(cp, cb));
     const int64_t at = ora_lookup_index(h->tab_obs[street], h->tab_n[street], cp, cb);
-    return at < 0 ? 0xffffu : h->tab_abs[street][at]; /* the reference panics on a miss: 0xffff never matches a trained row */
+    return at < 0 ? 0xffffu : (((uint32_t)street << 8) | (h->tab_abs[street][at] & 0xffu)); /* the reference panics on a miss */
 }
 
 static uint64_t draw_cards(uint64_t deck, int k, const ora_nlmc* h, uint64_t epoch, uint64_t tree, uint64_t key) {

@@ -157,16 +157,16 @@ __device__ __forceinline__ uint64_t nl_draw(uint64_t deck, int k, const NlParams
     }
     return out;
 }
-// NlheEncoder::abstraction (nlhe/src/encoder.rs:30-36)
+// NlheEncoder::abstraction (nlhe/src/encoder.rs:30-36); Abstraction = [8 bits street][8 bits index] (kicker/src/abstraction.rs:14-24)
 __device__ __forceinline__ uint32_t nl_bucket(const NlParams& p, int street, uint64_t pocket, uint64_t board) {
     uint64_t cp, cb;
     canonical(pocket, board, &cp, &cb);
     if (p.encoder == 0) {
         const uint32_t nb = street == 0 ? 169u : (street == 3 ? 101u : 256u);
-        return (uint32_t)(rp_mix64((uint64_t)obs_encode(cp, cb) ^ (0x51ed270b5ull * (uint64_t)(street + 1))) % nb);
+        return ((uint32_t)street << 8) | (uint32_t)(rp_mix64((uint64_t)obs_encode(cp, cb) ^ (0x51ed270b5ull * (uint64_t)(street + 1))) % nb);
     }
     const int64_t at = table_find(p.tkeys[street], p.tn[street], search_key(cp, cb));
-    return at < 0 ? 0xffffu : (uint32_t)p.tabs[street][at];
+    return at < 0 ? 0xffffu : (((uint32_t)street << 8) | (uint32_t)p.tabs[street][at]);
 }
 
 // stack entry: [0..4] packed game, [5] parent | slot << 13 | edge << 17 | depth << 22 | plen << 25, [6,7] past, [8,9] hkey, [10] fac

@@ -44,7 +44,7 @@ def test_infoset_keys_follow_the_reference_layout():
     assert len(past) > 500
     for p, b, c in zip(past, present, choices):
         pe, ce = _edges(int(p)), _edges(int(c))
-        assert 1 not in pe and 1 not in ce and 2 <= len(ce) <= M.A and b < 256
+        assert 1 not in pe and 1 not in ce and 2 <= len(ce) <= M.A and (b >> 8) <= 3 and (b & 0xff) < (169, 256, 256, 101)[b >> 8]
         assert len(set(ce)) == len(ce)
         raises = [e for e in ce if e >= 6]
         assert ce[: len(raises)] == raises  # the raise grid comes first (game.rs:253-283)
