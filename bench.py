@@ -40,9 +40,12 @@ def parse():
                     help="strong (default for N > 1): --batch trees per step in TOTAL, split across the GPUs (north_star's "
                          "strong-scaling figure); weak (N = 1, or on request): --batch trees per step on EVERY GPU.  With "
                          "N > 1 the line carries the other mode's measurement as well (`other_scaling`)")
-    ap.add_argument("--workload", default="leduc", choices=["leduc", "nlhe-synth"],
-                    help="leduc: BASELINE configs[1] (default, the quoted metric); nlhe-synth: configs[3]'s synthetic "
-                         "NLHE-scale infoset batches through the sparse profile (SURVEY.md §8d config 4)")
+    ap.add_argument("--workload", default="leduc", choices=["leduc", "nlhe-synth", "nlhe"],
+                    help="leduc: BASELINE configs[1] (default, the quoted metric); nlhe: the blueprint trainer's own step — "
+                         "external-sampling MCCFR over heads-up NLHE generated on the device (rp_nlhe_*, BASELINE configs[3] on "
+                         "one GPU); nlhe-synth: synthetic NLHE-scale infoset batches through the sparse profile (SURVEY §8d config 4)")
+    ap.add_argument("--nlhe-batch", type=int, default=16384, help="nlhe: trees per step (the reference's batch_size is 128)")
+    ap.add_argument("--nlhe-cap", type=int, default=24, help="nlhe: log2 of the infoset table's rows")
     ap.add_argument("--rows", type=int, default=1 << 27, help="nlhe-synth: table rows (infoset slots)")
     ap.add_argument("--decisions", type=int, default=128 * 1500, help="nlhe-synth: Decisions per step per GPU")
     ap.add_argument("--game", default="leduc", choices=["leduc", "kuhn", "rps", "leduc_wide"])
@@ -506,6 +509,66 @@ def convergence_times(args, g, local_rank):
     return out
 
 
+def nlhe_real(args, local_rank):
+    """BASELINE configs[3] on one GPU: Solver::step of the NLHE blueprint solver (trees generated, traversed and applied on
+    the device), infoset-updates (= Decisions, the reference's `infos` counter) per second; the reference's batch of 128
+    trees beside the GPU-sized one; the CPU oracle on one host thread as the baseline."""
+    import torch  # noqa: F401  (one HIP runtime per process)
+
+    from robopoker_amd.nlhe import NlheSolver
+
+    def run(batch, steps, warmup):
+        s = NlheSolver(cap_log2=args.nlhe_cap, regret="linear", weight="linear", batch=batch, seed=args.seed, device=local_rank)
+        for _ in range(warmup):
+            s.step(args.update)
+        n0, i0, _ = s.counters()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s.step(args.update)
+        n1, i1, keys = s.counters()  # counters() synchronises the stream
+        dt = time.perf_counter() - t0
+        s.close()
+        return {"infos": i1 - i0, "nodes": n1 - n0, "dt": dt, "keys": keys}
+
+    big = run(args.nlhe_batch, args.steps, args.warmup)
+    ref = run(128, max(args.steps, 20), 3)
+    line = {
+        "metric": "mccfr_infoset_updates_per_sec", "value": big["infos"] / big["dt"], "unit": "infoset-updates/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": big["dt"] / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "heads-up NLHE blueprint MCCFR (BASELINE configs[3] on one GPU): trees generated on the device, "
+                               "hash encoder (no trained abstraction), external sampling, linear regret / linear weight",
+                   "batch_per_gpu": args.nlhe_batch, "table_rows": 1 << args.nlhe_cap, "max_actions": 9, "update": args.update,
+                   "infosets_in_table": big["keys"]},
+        "trees_per_s": args.nlhe_batch * args.steps / big["dt"], "nodes_per_s": big["nodes"] / big["dt"],
+        "nodes_per_tree": big["nodes"] / (args.nlhe_batch * args.steps), "infos_per_tree": big["infos"] / (args.nlhe_batch * args.steps),
+        "reference_batch_128": {"value": ref["infos"] / ref["dt"], "unit": "infoset-updates/s",
+                                "ms_per_step": ref["dt"] / max(args.steps, 20) * 1e3,
+                                "note": "nlhe/src/solver.rs:11 batch_size = 128: two wavefronts of a lane-per-tree traversal"},
+        "roofline": {"bound": "hbm", "kernel": "k_nlhe_traverse", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
+                     "traffic": None, "note": "first device version: one lane per tree, latency / divergence bound; not priced "
+                                              "against a roofline yet (DESIGN §3c)"},
+    }
+    if args.cpu_seconds > 0:
+        import oracle_nlmc
+
+        o = oracle_nlmc.OracleNlhe(cap_log2=min(args.nlhe_cap, 22), regret="linear", weight="linear", batch=128, seed=args.seed)
+        o.step()
+        _, i0, _ = o.counters()
+        t0 = time.perf_counter()
+        steps = 0
+        while time.perf_counter() - t0 < args.cpu_seconds:
+            o.step()
+            steps += 1
+        dtc = time.perf_counter() - t0
+        _, i1, _ = o.counters()
+        line["cpu_baseline"] = {"value": (i1 - i0) / dtc, "unit": "infoset-updates/s", "cores": 1, "kind": "port",
+                                "sample": f"oracle/rp_oracle_nlmc.c, batch 128, {steps * 128} trees in {dtc:.1f} s on 1 host thread"}
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
     if args.no_extras:
@@ -520,6 +583,8 @@ def main():
         args.scaling = "strong" if world > 1 else "weak"
     if args.workload == "nlhe-synth":
         return nlhe_synth(args, rank, world, local_rank)
+    if args.workload == "nlhe":
+        return nlhe_real(args, local_rank)
 
     from robopoker_amd import Game
 

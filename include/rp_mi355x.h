@@ -567,6 +567,12 @@ RP_API int rp_artifact_write_metric(const char* path, int street, uint32_t K, co
  * descending, stable) as (prev i16, next i16, dx f32); counts/weight as rp_kmeans_centroids returns them */
 RP_API int rp_artifact_write_transitions(const char* path, int street, uint32_t K, uint32_t bins,
                                          const uint32_t* counts, const uint64_t* weight);
+/* NlheProfile::rows (nlhe/src/profile.rs:144-163) as the blueprint table's COPY file: columns (past BIGINT, present SMALLINT,
+ * choices BIGINT, edge BIGINT, weight REAL, regret REAL, payoff REAL, visits INTEGER) (profile.rs:20-31), one row per
+ * (infoset, edge of its choices); edge = From<Edge> for u64 (kicker/src/edge.rs:122-160).  Input: rp_nlhe_export's arrays.
+ * Read back with rp_pgcopy_read(path, "qhqqfffi", ...) and rp_nlhe_import (Hydrate, profile.rs:90-141). */
+RP_API int rp_artifact_write_blueprint(const char* path, uint64_t n_infosets, const uint64_t* past, const uint32_t* present,
+                                       const uint64_t* choices, const rp_encounter* enc, int only_visited, uint64_t* rows_written);
 
 /* =================================================================================================
  * The NLHE rules engine on the device (first device step).  The betting state machine of

@@ -251,6 +251,8 @@ _SIGNATURES = {
     "rp_pgcopy_read": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "rp_artifact_write_lookup": (C.c_int, [C.c_char_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rp_artifact_write_metric": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_void_p]),
+    "rp_artifact_write_blueprint": (C.c_int, [C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.POINTER(C.c_uint64)]),
     "rp_artifact_write_transitions": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
 }
 

@@ -208,4 +208,60 @@ int rp_artifact_write_transitions(const char* path, int street, uint32_t K, uint
     return RP_OK;
 }
 
+// From<Edge> for u64 (kicker/src/edge.rs:122-160): the `edge BIGINT` column.  `code` is the 5-bit edge code of a Path
+// (edge.rs:101-120): 1 Draw, 2 Fold, 3 Check, 4 Call, 5 Shove, 6..9 Open(2..5 bb), 10..19 Raise(odds) over the grid of
+// pokerkit/src/lib.rs:81-97.
+static uint64_t edge_code_to_u64(uint32_t code) {
+    static const uint64_t OPENS[4] = {2, 3, 4, 5};
+    static const uint64_t RAISES[10][2] = {{1, 4}, {1, 3}, {1, 2}, {2, 3}, {3, 4}, {1, 1}, {5, 4}, {3, 2}, {2, 1}, {3, 1}};
+    switch (code) {
+        case 1: return 0;
+        case 2: return 1;
+        case 3: return 2;
+        case 4: return 3;
+        case 5: return 5;
+    }
+    if (code >= 6 && code < 10) return 6ull | (OPENS[code - 6] << 3);
+    if (code >= 10 && code < 20) return 4ull | (RAISES[code - 10][0] << 3) | (RAISES[code - 10][1] << 11);
+    return ~0ull;
+}
+
+// NlheProfile::rows (nlhe/src/profile.rs:144-163) -> COPY blueprint (past, present, choices, edge, weight, regret, payoff,
+// visits) (profile.rs:20-31): one row per (infoset, edge of its choices).  Input = rp_nlhe_export's arrays (9 Encounters per
+// infoset, slot a = the a-th edge of `choices`).  only_visited != 0 skips infosets no update has touched (the reference's
+// map holds an infoset from its first update on).
+int rp_artifact_write_blueprint(const char* path, uint64_t n, const uint64_t* past, const uint32_t* present, const uint64_t* choices,
+                                const rp_encounter* enc, int only_visited, uint64_t* rows_written) {
+    if (!path || (n && (!past || !present || !choices || !enc))) return rp::fail(RP_ERR_INVALID, "null argument");
+    Writer w;
+    if (!w.open(path)) return rp::fail(RP_ERR_INVALID, "cannot create %s", path);
+    uint64_t rows = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const rp_encounter* e = enc + i * 9;
+        if (only_visited && e[0].visits == 0) continue;
+        const int64_t p = (int64_t)past[i], c = (int64_t)choices[i];
+        const int16_t b = (int16_t)present[i];
+        uint64_t path_bits = choices[i];
+        for (uint32_t a = 0; a < 9 && path_bits != 0 && (path_bits & 0x1f) != 0; ++a, path_bits >>= 5) {
+            const uint64_t ev = edge_code_to_u64((uint32_t)(path_bits & 0x1f));
+            if (ev == ~0ull) return rp::fail(RP_ERR_INVALID, "infoset %llu: choices hold an unknown edge code", (unsigned long long)i);
+            const int64_t edge = (int64_t)ev;
+            const int32_t visits = (int32_t)e[a].visits;
+            w.begin_row(8);
+            w.field(&p, 8);
+            w.field(&b, 2);
+            w.field(&c, 8);
+            w.field(&edge, 8);
+            w.field(&e[a].weight, 4);
+            w.field(&e[a].regret, 4);
+            w.field(&e[a].payoff, 4);
+            w.field(&visits, 4);
+            rows += 1;
+        }
+    }
+    if (!w.close()) return rp::fail(RP_ERR_INVALID, "short write to %s", path);
+    if (rows_written) *rows_written = rows;
+    return RP_OK;
+}
+
 }  // extern "C"

@@ -59,6 +59,56 @@ def write_transitions(path: str, street, counts, weight) -> None:
     _lib.check(_lib.load().rp_artifact_write_transitions(path.encode(), _street(street), K, bins, counts.ctypes.data, weight.ctypes.data))
 
 
+BLUEPRINT_TYPES = "qhqqfffi"  # past, present, choices, edge, weight, regret, payoff, visits (nlhe/src/profile.rs:20-31)
+_ENC = np.dtype([("weight", "<f4"), ("regret", "<f4"), ("payoff", "<f4"), ("visits", "<u4")])
+
+
+def write_blueprint(path: str, past, present, choices, enc, only_visited=True) -> int:
+    """NlheProfile::rows as a COPY file from ``NlheSolver.export()``'s arrays; returns the number of rows written."""
+    past, present, choices = (np.ascontiguousarray(past, np.uint64), np.ascontiguousarray(present, np.uint32),
+                              np.ascontiguousarray(choices, np.uint64))
+    enc = np.ascontiguousarray(enc, dtype=_ENC)
+    assert enc.shape == (past.size, 9)
+    n = C.c_uint64()
+    _lib.check(_lib.load().rp_artifact_write_blueprint(path.encode(), past.size, past.ctypes.data, present.ctypes.data, choices.ctypes.data,
+                                                       enc.ctypes.data, 1 if only_visited else 0, C.byref(n)))
+    return n.value
+
+
+def _edge_to_u64(code: int) -> int:
+    opens, raises = [2, 3, 4, 5], [(1, 4), (1, 3), (1, 2), (2, 3), (3, 4), (1, 1), (5, 4), (3, 2), (2, 1), (3, 1)]
+    if code < 6:
+        return {1: 0, 2: 1, 3: 2, 4: 3, 5: 5}[code]
+    if code < 10:
+        return 6 | (opens[code - 6] << 3)
+    return 4 | (raises[code - 10][0] << 3) | (raises[code - 10][1] << 11)
+
+
+def read_blueprint(path: str):
+    """the blueprint COPY file back into ``NlheSolver.load()``'s arrays (Hydrate, nlhe/src/profile.rs:90-141): rows grouped
+    by infoset, each row's slot = the position of its edge in the infoset's choices"""
+    past, present, choices, edge, weight, regret, payoff, visits = read_rows(path, BLUEPRINT_TYPES)
+    index, keys = {}, []
+    for p, b, c in zip(past.tolist(), present.tolist(), choices.tolist()):
+        k = (p, b, c)
+        if k not in index:
+            index[k] = len(keys)
+            keys.append(k)
+    enc = np.zeros((len(keys), 9), dtype=_ENC)
+    for r in range(past.size):
+        k = (int(past[r]), int(present[r]), int(choices[r]))
+        codes, bits = [], int(choices[r]) & ((1 << 64) - 1)
+        while bits & 0x1f:
+            codes.append(bits & 0x1f)
+            bits >>= 5
+        slot = [_edge_to_u64(c) for c in codes].index(int(edge[r]))
+        enc[index[k], slot] = (weight[r], regret[r], payoff[r], visits[r])
+    kp = np.array([k[0] for k in keys], dtype=np.int64).astype(np.uint64)
+    kb = np.array([k[1] for k in keys], dtype=np.int64).astype(np.uint32) & 0xffff
+    kc = np.array([k[2] for k in keys], dtype=np.int64).astype(np.uint64)
+    return kp, kb, kc, enc
+
+
 def save_artifacts(directory: str, art) -> dict:
     """Artifacts::stream (lloyd/src/artifacts.rs) to files: one lookup file per street plus metric / transitions where
     the street has them.  `art` is a robopoker_amd.pretraining.Artifacts.  Returns {kind: path}."""

@@ -105,3 +105,32 @@ def test_transition_rows(tmp_path):
     rows = [(1 << 8 | 0, 2 << 8 | 4, float(f(10) / f(20))), (1 << 8 | 0, 2 << 8 | 1, float(f(5) / f(20))),
             (1 << 8 | 0, 2 << 8 | 3, float(f(5) / f(20))), (1 << 8 | 1, 2 << 8 | 0, 1.0)]  # the empty centroid has no rows
     assert open(p, "rb").read() == pg_stream("hhf", rows)
+
+
+def test_blueprint_rows_roundtrip(tmp_path):
+    # NlheProfile::rows (nlhe/src/profile.rs:144-163): (past, present, choices, edge, weight, regret, payoff, visits) per
+    # (infoset, edge); checked against an independent `struct` reading of the PostgreSQL binary COPY stream
+    import oracle_nlmc as M
+
+    s = M.OracleNlhe(cap_log2=14, batch=24, seed=4)
+    s.step()
+    past, present, choices, enc = s.export()
+    path = str(tmp_path / "blueprint.pgcopy")
+    rows = formats.write_blueprint(path, past, present, choices, enc, only_visited=True)
+    visited = enc["visits"][:, 0] > 0
+    n_edges = lambda c: sum(1 for k in range(12) if (int(c) >> (5 * k)) & 0x1f)  # noqa: E731
+    assert rows == sum(n_edges(c) for c in choices[visited]) and rows > 0
+    raw = open(path, "rb").read()
+    assert raw[:11] == b"PGCOPY\n\xff\r\n\0" and raw[-2:] == b"\xff\xff"
+    off = 19
+    nf, l0 = struct.unpack(">hi", raw[off:off + 6])
+    assert nf == 8 and l0 == 8
+    first = struct.unpack(">q", raw[off + 6:off + 14])[0]
+    assert first == int(past[visited][0])
+    kp, kb, kc, kenc = formats.read_blueprint(path)
+    want = M.as_map(past[visited], present[visited], choices[visited], enc[visited])
+    got = M.as_map(kp, kb, kc, kenc)
+    assert got.keys() == want.keys()
+    for k in want:
+        n = n_edges(k[2])
+        assert got[k][:n].tobytes() == want[k][:n].tobytes()

@@ -74,3 +74,74 @@ def test_large_batch_runs_and_conserves_visits(gpu):
     past, present, choices, enc = dev.export()
     assert len(past) == keys and int(enc["visits"][:, 0].sum()) == infos
     assert 100 * 8192 * 2 < nodes < 1500 * 8192 * 2 and dev.epoch == 2
+
+
+def _hash_buckets(obs, street):
+    """oracle/rp_oracle_nlmc.c ora_nlmc_hash_bucket on a CUDA int64 tensor of canonical observations (two's complement
+    arithmetic wraps like u64; shifts made logical by masking)"""
+    import torch
+
+    def lsr(x, k):
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    def signed(c):
+        return c - (1 << 64) if c >= (1 << 63) else c
+
+    def mix64(z):
+        z = z ^ lsr(z, 30)
+        z = z * signed(0xbf58476d1ce4e5b9)
+        z = z ^ lsr(z, 27)
+        z = z * signed(0x94d049bb133111eb)
+        return z ^ lsr(z, 31)
+
+    nb = (169, 256, 256, 101)[street]
+    z = mix64(obs ^ signed((0x51ed270b5 * (street + 1)) & ((1 << 64) - 1)))
+    half = lsr(z, 1)  # floor(u / 2) of the unsigned value
+    return (((half % nb) * 2 + (z & 1)) % nb).to(torch.uint8)
+
+
+def test_table_encoder_equals_the_hash_encoder_on_hash_tables(gpu):
+    # NlheEncoder over the pipeline's Lookup tables (all four streets: 169 / 1 286 792 / 13 960 050 / 123 156 254
+    # isomorphisms): filled with the hash encoder's buckets, the table-driven traversal must produce the hash-driven one
+    import torch  # noqa: F401
+
+    from robopoker_amd import deuce
+
+    tables = []
+    for street, name in enumerate(("pref", "flop", "turn", "rive")):
+        obs = deuce.isomorphisms(name)
+        tables.append(deuce.Lookup(name, obs, _hash_buckets(obs, street)))
+        del obs
+    a = NlheSolver(cap_log2=18, batch=256, seed=9)
+    b = NlheSolver(cap_log2=18, batch=256, seed=9, tables=tables)
+    da, db = a.batch(), b.batch()
+    assert da["n"] == db["n"] > 0
+    for f in ("tree", "past", "present", "choices", "n_actions", "expanded"):
+        assert np.array_equal(da[f], db[f]), f
+    for f in ("regret", "policy", "payoff"):
+        assert np.array_equal(da[f].view(np.uint32), db[f].view(np.uint32)), f
+    a.close()
+    b.close()
+    for t in tables:
+        t.close()
+
+
+def test_blueprint_file_roundtrip_through_the_device(gpu, tmp_path):
+    # train a little, stream the profile in the reference's COPY row format, hydrate a fresh solver from the file: the next
+    # batch (which depends on every regret and weight through sampling and regret matching) must be identical
+    from robopoker_amd import formats
+
+    a = NlheSolver(cap_log2=18, batch=256, seed=4)
+    for _ in range(3):
+        a.step("ordered")
+    path = str(tmp_path / "blueprint.pgcopy")
+    rows = formats.write_blueprint(path, *a.export(), only_visited=False)
+    assert rows > 1000
+    b = NlheSolver(cap_log2=18, batch=256, seed=4)
+    b.load(*formats.read_blueprint(path), epoch=a.epoch)
+    da, db = a.batch(), b.batch()
+    assert da["n"] == db["n"]
+    for f in ("tree", "past", "present", "choices", "n_actions", "expanded"):
+        assert np.array_equal(da[f], db[f]), f
+    for f in ("regret", "policy", "payoff"):
+        assert np.array_equal(da[f].view(np.uint32), db[f].view(np.uint32)), f
