@@ -459,7 +459,7 @@ int rp_river_equity(int device, uint64_t n, const int64_t* obs_dev, float* equit
 
 int rp_lookup_create(int device, int street, uint64_t n, const int64_t* obs_dev, const uint8_t* abs_dev, rp_lookup** out) {
     if (!out || !obs_dev || !abs_dev || !n) return rp::fail(RP_ERR_INVALID, "null or empty argument");
-    if (street < 1 || street > 3) return rp::fail(RP_ERR_INVALID, "street %d: a lookup table is for the flop (1), turn (2) or river (3)", street);
+    if (street < 0 || street > 3) return rp::fail(RP_ERR_INVALID, "street %d: a lookup table is for the preflop (0), flop (1), turn (2) or river (3)", street);
     if (int rc = pick_device(device)) return rc;
     rp_lookup* h = new rp_lookup{device, street, n, nullptr, nullptr};
     Scratch bad;
