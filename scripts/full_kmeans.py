@@ -11,4 +11,6 @@ from robopoker_amd import lloyd  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "flop"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 n = int(sys.argv[3]) if len(sys.argv) > 3 else None
-print(json.dumps(lloyd.bench_full(which, iters, n, log=lambda m: print(m, file=sys.stderr, flush=True))), flush=True)
+out = lloyd.bench_full(which, iters, n, log=lambda m: print(m, file=sys.stderr, flush=True))
+out.pop("_centroids", None)
+print(json.dumps(out), flush=True)
