@@ -59,6 +59,7 @@ struct CentroidSet {
     float* lnd;        // [K][MAXB] ln(density) on the support
     float* dens;       // [bins][K] density, transposed (variation path)
     float* densR;      // [K][256] density by centroid, 0 off the support and past `bins` (the MFMA bound's mu operand)
+    float* mincT;      // [256][256] mincT[y][k] = min over x in supp(centroid k) of C(x, y): the column-marginal bound
     float* self;       // [K] OT(c,c)
 };
 
@@ -624,6 +625,12 @@ __global__ __launch_bounds__(64) void k_prepare_centroids(CentroidSet cs, uint32
         cs.dens[(size_t)b * K + k] = (float)cs.counts[(size_t)k * bins + b] / (float)wt;  // NaN for an empty cluster, as in the reference
     for (uint32_t b = lane_id(); b < bins; b += 64)
         cs.densR[(size_t)k * MAXB + b] = wt ? (float)cs.counts[(size_t)k * bins + b] / (float)wt : 0.0f;
+    if (kind == RP_METRIC_SINKHORN)
+        for (uint32_t y = lane_id(); y < bins; y += 64) {  // the column-marginal bound's table (sinkhorn_bound.hpp)
+            float mn = m ? rp_u2f(0x7f800000u) : 0.0f;
+            for (uint32_t i = 0; i < m; ++i) mn = fminf(mn, M.Cm[(size_t)w.supA[i] * bins + y]);
+            cs.mincT[(size_t)y * MAXB + k] = mn;
+        }
     if (lane_id() == 0) cs.n[k] = m;
     __syncthreads();
     float self = 0.0f;
@@ -753,7 +760,8 @@ __global__ __launch_bounds__(64) void k_neighbor(Points P, CentroidSet cs, uint3
 // loop's result bit for bit as long as every minimiser survives.  `audit_*`: RP_LLOYD_AUDIT compares with the unpruned
 // pass instead of writing.
 __global__ __launch_bounds__(64) void k_neighbor_masked(Points P, CentroidSet cs, uint32_t K, Metric M, const unsigned long long* mask,
-                                                        uint8_t* out_j, float* out_d, Bounds init) {
+                                                        uint8_t* out_j, float* out_d, Bounds init, const uint8_t* hint_j,
+                                                        const float* hint_d) {
     __shared__ WaveLds w;
     const uint64_t i = blockIdx.x;
     const uint32_t lane = lane_id();
@@ -768,8 +776,13 @@ __global__ __launch_bounds__(64) void k_neighbor_masked(Points P, CentroidSet cs
             const uint32_t k = q * 64 + (uint32_t)__builtin_ctzll(bits);
             bits &= bits - 1;
             if (k >= K) break;
-            const uint32_t m = wave_load_centroid(cs, k, w.supA, w.lnA);
-            const float d = wave_divergence(w, m, n, cs.self[k], sp, M);  // distance(centroid, point)
+            float d;
+            if (hint_j && hint_j[i] == k) {
+                d = hint_d[i];  // this very solve was done for the upper bound handed to the MFMA bound
+            } else {
+                const uint32_t m = wave_load_centroid(cs, k, w.supA, w.lnA);
+                d = wave_divergence(w, m, n, cs.self[k], sp, M);  // distance(centroid, point)
+            }
             if (first || d < bd) {
                 bj = k;
                 bd = d;
@@ -791,6 +804,20 @@ __global__ __launch_bounds__(64) void k_neighbor_masked(Points P, CentroidSet cs
         for (uint32_t k = lane; k < K; k += 64) init.lower[i * K + k] = 0.0f;
 }
 
+// upper bounds handed to the MFMA bound before it starts
+__global__ __launch_bounds__(256) void k_hint_masks(const uint8_t* j, uint64_t N, uint32_t K, unsigned long long* mask) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t k = min((uint32_t)j[i], K - 1);
+    for (uint32_t q = 0; q < 4; ++q) mask[i * 4 + q] = (k >> 6) == q ? 1ull << (k & 63u) : 0ull;
+}
+// k-means++ left potentials = min_k d(c_k, x)^2 (layer.rs:170-178, the same centroid-first distance): sqrt, two ulps up
+__global__ __launch_bounds__(256) void k_ub_from_pot(const float* pot, uint64_t N, float* ub) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float p = pot[i];
+    ub[i] = p >= 0.0f ? sqrtf(p) * 1.0000003f + 1e-30f : rp_u2f(0x7f800000u);
+}
 __global__ __launch_bounds__(256) void k_mask_all(const uint32_t* list, uint32_t n, unsigned long long* mask) {
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
@@ -1835,6 +1862,10 @@ struct rp_kmeans {
     uint8_t* audit_j = nullptr;
     float* audit_d = nullptr;
     float* sb_d = nullptr;
+    float* sb_ub0 = nullptr;      // [N] upper bound handed to the bound kernel
+    uint8_t* sb_hint_j = nullptr; // [N]
+    unsigned long long* sb_hint_mask = nullptr;  // [N][4]
+    bool pot_is_min_d2 = false;   // the k-means++ potentials describe the CURRENT centroids
     uint64_t sb_audited = 0;
     unsigned long long* bsum = nullptr;
     unsigned long long* scal = nullptr;  // [0] picked, [1] moved
@@ -1895,6 +1926,8 @@ int alloc_centroid_set(rp_kmeans* h, CentroidSet* cs) {
     if ((rc = dev_alloc(h, &cs->dens, (size_t)h->K * h->bins))) return rc;
     if ((rc = dev_alloc(h, &cs->densR, (size_t)h->K * MAXB))) return rc;
     HIP_TRY(hipMemset(cs->densR, 0, (size_t)h->K * MAXB * 4));
+    if ((rc = dev_alloc(h, &cs->mincT, (size_t)MAXB * MAXB))) return rc;
+    HIP_TRY(hipMemset(cs->mincT, 0, (size_t)MAXB * MAXB * 4));
     if ((rc = dev_alloc(h, &cs->self, h->K))) return rc;
     return RP_OK;
 }
@@ -2051,6 +2084,11 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         h->sb.dc_abs = envf("RP_SB_DC_ABS", 4e-6f);
         h->sb.dc_rel = envf("RP_SB_DC_REL", 4e-5f);
         h->sb.flat = envf("RP_SB_FLAT", 4.0f);
+        {
+            float cmax = 0.0f;
+            for (size_t t = 0; t < (size_t)bins * (bins - 1) / 2; ++t) cmax = std::max(cmax, tri_metric[t]);
+            h->sb.use_lb0 = (cmax / h->hp.temperature <= 64.0f && !getenv("RP_SB_NO_LB0")) ? 1 : 0;
+        }
         std::vector<uint32_t> cls[4], big;
         for (uint64_t i = 0; i < N; ++i) {
             // k_point_support saturates at 255 bins; 0 (an empty histogram) is left to the exact kernel as well
@@ -2072,6 +2110,9 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         KM_TRY(dev_alloc(h, &h->sb_bad, 1));
         KM_HIP(hipMemset(h->sb_bad, 0, 8));
         KM_TRY(dev_alloc(h, &h->sb_d, N));
+        KM_TRY(dev_alloc(h, &h->sb_ub0, N));
+        KM_TRY(dev_alloc(h, &h->sb_hint_j, N));
+        KM_TRY(dev_alloc(h, &h->sb_hint_mask, (size_t)N * 4));
         h->sb_audit = getenv("RP_LLOYD_AUDIT") != nullptr;
         if (h->sb_audit) {
             KM_TRY(dev_alloc(h, &h->audit_j, N));
@@ -2150,7 +2191,7 @@ int launch_neighbor_full(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init
 }
 
 // the MFMA bound over every point (one launch per support class), leaving the survivor masks in h->sb_mask
-int launch_bound(rp_kmeans* h, float* dbg_lo, float* dbg_hi) {
+int launch_bound(rp_kmeans* h, float* dbg_lo, float* dbg_hi, const float* ub0 = nullptr) {
     HIP_TRY(hipMemsetAsync(h->sb_cursor, 0, 16, h->stream));
     const CentroidSet& cs = h->cs[h->cur];
     int cus = 256;
@@ -2162,7 +2203,7 @@ int launch_bound(rp_kmeans* h, float* dbg_lo, float* dbg_hi) {
         const dim3 grid(std::min<uint32_t>(n, (uint32_t)cus)), block(SB_THREADS);
 #define SB_LAUNCH(NT)                                                                                                      \
     hipLaunchKernelGGL(k_sinkhorn_bound<NT>, grid, block, 0, h->stream, h->P, cs, h->K, h->bins, h->sb, h->sb_list[t], n, \
-                       h->sb_cursor + t, h->sb_mask, dbg_lo, dbg_hi, h->sb_stats)
+                       h->sb_cursor + t, h->sb_mask, dbg_lo, dbg_hi, h->sb_stats, ub0)
         if (t == 0) SB_LAUNCH(1);
         else if (t == 1) SB_LAUNCH(2);
         else if (t == 2) SB_LAUNCH(3);
@@ -2177,14 +2218,36 @@ int launch_bound(rp_kmeans* h, float* dbg_lo, float* dbg_hi) {
 
 // Elkan::neighbor for every point (init_bounds / Layer::lookup / step_naive).  Sinkhorn layers: the MFMA bound discards
 // the centroids that cannot be the argmin, the bit-faithful kernel runs on the survivors (same bits).
-int launch_neighbor(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init) {
+enum { NB_INIT_BOUNDS, NB_LOOKUP, NB_NAIVE };
+int launch_neighbor(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init, int pass = NB_NAIVE) {
     if (!h->sb_on) return launch_neighbor_full(h, out_j, out_d, init);
-    int rc = launch_bound(h, nullptr, nullptr);
+    const unsigned nblk = (unsigned)((h->N + 255) / 256);
+    const float* ub0 = nullptr;
+    const uint8_t* hint_j = nullptr;
+    if (h->sb.use_lb0 && !getenv("RP_SB_NO_HINT")) {
+        if (pass == NB_INIT_BOUNDS && h->pot_is_min_d2) {
+            // right after k-means++: potentials = min_k d(c_k, x)^2 for exactly these centroids
+            hipLaunchKernelGGL(k_ub_from_pot, dim3(nblk), dim3(256), 0, h->stream, h->pot, h->N, h->sb_ub0);
+            ub0 = h->sb_ub0;
+        } else if (pass == NB_LOOKUP && h->bounds_ready) {
+            // after the Elkan iterations: the exact distance to the point's assigned centroid (one solve per point, reused below)
+            HIP_TRY(hipMemcpyAsync(h->sb_hint_j, h->B.j, h->N, hipMemcpyDeviceToDevice, h->stream));
+            hipLaunchKernelGGL(k_hint_masks, dim3(nblk), dim3(256), 0, h->stream, h->sb_hint_j, h->N, h->K, h->sb_hint_mask);
+            ck_begin(h, CK_NEIGHBOR);
+            Bounds none{};
+            hipLaunchKernelGGL(k_neighbor_masked, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M,
+                               h->sb_hint_mask, (uint8_t*)nullptr, h->sb_ub0, none, (const uint8_t*)nullptr, (const float*)nullptr);
+            ck_end(h, CK_NEIGHBOR);
+            ub0 = h->sb_ub0;
+            hint_j = h->sb_hint_j;
+        }
+    }
+    int rc = launch_bound(h, nullptr, nullptr, ub0);
     if (rc) return rc;
     float* dd = out_d ? out_d : h->sb_d;
     ck_begin(h, CK_NEIGHBOR);
     hipLaunchKernelGGL(k_neighbor_masked, dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->sb_mask,
-                       out_j, dd, init);
+                       out_j, dd, init, hint_j, hint_j ? ub0 : (const float*)nullptr);
     ck_end(h, CK_NEIGHBOR);
     HIP_TRY(hipGetLastError());
     if (h->sb_audit && out_j) {  // RP_LLOYD_AUDIT: the unpruned pass next to it; disagreements are counted, never corrected
@@ -2255,6 +2318,7 @@ int step_back(rp_kmeans* h, float* drift, uint64_t* sizes, double* reassigned) {
     hipLaunchKernelGGL(k_tally, dim3(1024), dim3(256), 0, h->stream, h->B.j, h->prior, h->N, h->scal + 1);
     HIP_TRY(hipGetLastError());
     h->cur = nxt;  // Kmeans::next installs the new centroids (kmeans.rs:88)
+    h->pot_is_min_d2 = false;
     std::vector<unsigned long long> sz(h->K);
     unsigned long long moved = 0;
     if (drift) HIP_TRY(hipMemcpyAsync(drift, h->drift, h->K * 4, hipMemcpyDeviceToHost, h->stream));
@@ -2304,6 +2368,7 @@ int rp_kmeans_set_centroids(rp_kmeans* h, const uint64_t* point_index) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->centroids_ready = true;
     h->bounds_ready = false;
+    h->pot_is_min_d2 = false;
     return RP_OK;
 }
 
@@ -2319,6 +2384,7 @@ int rp_kmeans_kpp_begin(rp_kmeans* h) {
     HIP_TRY(hipGetLastError());
     h->centroids_ready = false;
     h->bounds_ready = false;
+    h->pot_is_min_d2 = false;
     return RP_OK;
 }
 
@@ -2400,6 +2466,7 @@ int rp_kmeans_kpp_update(rp_kmeans* h, uint32_t k) {
     if (k + 1 == h->K) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         h->centroids_ready = true;
+        h->pot_is_min_d2 = true;  // potentials = min_k d(c_k, x)^2 over the K centroids now installed
         ck_drain(h);
     }
     return RP_OK;
@@ -2424,6 +2491,7 @@ int rp_kmeans_set_centroid(rp_kmeans* h, uint32_t k, const uint32_t* counts) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));  // `counts` may be a temporary on the caller's side
     h->bounds_ready = false;
+    h->pot_is_min_d2 = false;
     return RP_OK;
 }
 
@@ -2460,7 +2528,7 @@ int rp_kmeans_init_bounds(rp_kmeans* h) {
     int rc = need_centroids(h, "rp_kmeans_init_bounds");
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
-    if ((rc = launch_neighbor(h, h->prior, nullptr, h->B))) return rc;  // Prior::from_bounds (prior.rs:23-32)
+    if ((rc = launch_neighbor(h, h->prior, nullptr, h->B, NB_INIT_BOUNDS))) return rc;  // Prior::from_bounds (prior.rs:23-32)
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->bounds_ready = true;
     ck_drain(h);
@@ -2541,6 +2609,7 @@ int rp_kmeans_step_naive(rp_kmeans* h) {
     if ((rc = prepare_centroids(h, nxt))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->cur = nxt;
+    h->pot_is_min_d2 = false;
     ck_drain(h);
     return RP_OK;
 }
@@ -2551,7 +2620,7 @@ int rp_kmeans_assign(rp_kmeans* h, uint8_t* bucket, float* distance) {
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
     Bounds none{};
-    if ((rc = launch_neighbor(h, h->tmp_j, h->pdist, none))) return rc;
+    if ((rc = launch_neighbor(h, h->tmp_j, h->pdist, none, NB_LOOKUP))) return rc;
     if (bucket) HIP_TRY(hipMemcpyAsync(bucket, h->tmp_j, h->N, hipMemcpyDeviceToHost, h->stream));
     if (distance) HIP_TRY(hipMemcpyAsync(distance, h->pdist, h->N * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));

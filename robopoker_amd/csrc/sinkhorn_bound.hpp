@@ -57,6 +57,7 @@ struct SbParams {
     float dc_abs;  // cost margin: dc_abs + dc_rel * cost
     float dc_rel;
     float flat;    // the scaling iterate counts as stationary when err <= flat * 2^-23 * (sum u + sum v), twice in a row
+    int use_lb0;   // the column-marginal bound is valid for this metric / temperature (max C / T <= 64): sort and drop by it
 };
 
 struct __attribute__((aligned(16))) SbLds {
@@ -66,10 +67,15 @@ struct __attribute__((aligned(16))) SbLds {
     float dlo[256];
     float dhi[256];
     float red[8];
+    float lb0[256];   // per centroid: the column-marginal lower bound of the divergence (0 when not in use)
+    uint32_t perm[256];  // column slot -> centroid, ascending lb0
+    uint32_t ub;      // bits of the smallest upper bound published so far (non-negative floats order as integers)
     uint32_t sup[SB_MAXROWS];
     uint32_t np;
     uint32_t item;
 };
+#define SB_LB_SAFETY 0.999f
+#define SB_LB_SLACK 1e-6f
 
 __device__ __forceinline__ f32x4 sb_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float sb_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -177,14 +183,20 @@ struct SbCol {  // per-column window state (replicated in the four lanes of the 
     float wmin, wmax, nb_prev;
     int flatc;
     bool opened, done;
+    bool complete;  // the stopping window was followed to its end (not dropped)
 };
+// Column order.  The rigorous bound  cost >= sum_y nu(y) min_{x in supp mu_j} C(x, y)  (the column sums of the coupling are nu
+// after every rhs update, at any iteration count) costs n reads per centroid and needs no iteration.  Columns are sorted by it
+// so that a 16-column block holds centroids of similar distance, wave w takes sorted blocks w and 15 - w (a near and a far
+// one), and a column whose bound exceeds an upper bound already published by a finished column is dropped at once — its
+// interval is [bound, inf), it cannot be the argmin.
 
 // pstats: [0] survivors, [1] points, [2] column-block iterations, [3] cost passes, [4] MFMA instructions   (striped like Metric::stats)
 template <int NT>
 __global__ __launch_bounds__(SB_THREADS, 2) void k_sinkhorn_bound(Points P, CentroidSet cs, uint32_t K, uint32_t bins, SbParams prm,
                                                                    const uint32_t* list, uint32_t count, unsigned int* cursor,
                                                                    unsigned long long* mask_out, float* dbg_lo, float* dbg_hi,
-                                                                   unsigned long long* pstats) {
+                                                                   unsigned long long* pstats, const float* ub0) {
     __shared__ SbLds L;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t c = lane & 15u, g = lane >> 4;
@@ -234,10 +246,41 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_sinkhorn_bound(Points P, Cent
             L.ksub[y * SB_KS + x] = k;
             L.ksubT[x * SB_KT + y] = k;
         }
+        const float sp = P.self[i];
+        if (tid < 256) {
+            float key = __builtin_inff();
+            if (tid < K) {
+                key = 0.0f;
+                if (prm.use_lb0) {
+                    float acc = 0.0f;
+                    for (uint32_t y = 0; y < np; ++y) acc += L.b[y] * cs.mincT[(size_t)L.sup[y] * 256u + tid];
+                    key = rp_maxf((acc * SB_LB_SAFETY - SB_LB_SLACK) - 0.5f * cs.self[tid] - 0.5f * sp, 0.0f);
+                    if (!(key == key)) key = 0.0f;
+                }
+            }
+            L.lb0[tid] = key;
+        }
+        // ub0: an upper bound of the point's smallest distance known before the pass (the exact distance to SOME centroid:
+        // the Elkan assignment for lookup, the k-means++ potential for init_bounds); columns whose bound exceeds it never start
+        if (tid == 0) {
+            const float u = ub0 ? ub0[i] : __builtin_inff();
+            L.ub = (u == u && u >= 0.0f) ? __float_as_uint(u) : 0x7f800000u;
+        }
         __syncthreads();
-        // ---- this wave's 2 x 16 centroid columns
+        if (tid < 256) {  // rank sort (256 keys, LDS broadcasts): ties keep centroid order
+            const float mine = L.lb0[tid];
+            uint32_t rank = 0;
+            for (uint32_t k = 0; k < 256; ++k) {
+                const float o = L.lb0[k];
+                rank += (o < mine || (o == mine && k < tid)) ? 1u : 0u;
+            }
+            L.perm[rank] = tid;
+        }
+        __syncthreads();
+        // ---- this wave's 2 x 16 centroid columns: sorted blocks `wave` and 15 - `wave`
         f32x4 uo0[16], uo1[16], v0[NT], v1[NT];
-        const uint32_t j0 = wave * 32 + c, j1 = j0 + 16;
+        const uint32_t j0 = L.perm[wave * 16 + c], j1 = L.perm[(15 - wave) * 16 + c];
+        const float dlb0_0 = L.lb0[j0], dlb0_1 = L.lb0[j1];
         const uint32_t jc0 = j0 < K ? j0 : K - 1, jc1 = j1 < K ? j1 : K - 1;
         const uint32_t mj0 = cs.n[jc0], mj1 = cs.n[jc1];
         const bool valid0 = j0 < K && mj0 > 0, valid1 = j1 < K && mj1 > 0;
@@ -272,9 +315,12 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_sinkhorn_bound(Points P, Cent
         st1.nb_prev = nb0 + SB_EPS23 * 0.37f * (float)mj1;
         st0.flatc = st1.flatc = 0;
         st0.opened = st1.opened = false;
-        st0.done = !valid0;
-        st1.done = !valid1;
-        auto advance = [&](f32x4 (&uo)[16], f32x4 (&v)[NT], const float* drow, SbCol& st, uint32_t mj, bool last) {
+        const float ub_start = __uint_as_float(L.ub);
+        st0.done = !valid0 || dlb0_0 > ub_start;
+        st1.done = !valid1 || dlb0_1 > ub_start;
+        st0.complete = st1.complete = false;
+        const float sc0 = cs.self[jc0], sc1 = cs.self[jc1];
+        auto advance = [&](f32x4 (&uo)[16], f32x4 (&v)[NT], const float* drow, SbCol& st, uint32_t mj, bool last, float dlb0, float sc) {
             float err, sumu, umax, sumv, vmax;
             sb_iterate<NT>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax);
             my_cb_iters += 1;
@@ -298,24 +344,32 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_sinkhorn_bound(Points P, Cent
                 }
             }
             st.flatc = flat ? st.flatc + 1 : 0;
-            if (certain || st.flatc >= 2) st.done = true;
+            if (!st.done && (certain || st.flatc >= 2)) {
+                st.done = true;
+                st.complete = true;
+                if (st.opened && g == 0) {  // publish this column's upper bound
+                    const float ch = st.wmax + (prm.dc_abs + prm.dc_rel * fabsf(st.wmax));
+                    const float hi = rp_maxf(ch - 0.5f * sc - 0.5f * sp, 0.0f);
+                    if (hi == hi && hi < __builtin_inff()) atomicMin(&L.ub, __float_as_uint(hi));
+                }
+            }
+            // a column whose rigorous lower bound exceeds a published upper bound cannot be the argmin: stop iterating it
+            if (!st.done && dlb0 > __uint_as_float(*(volatile uint32_t*)&L.ub)) st.done = true;
         };
         for (uint32_t t = 0; t < prm.iters; ++t) {
             const bool act0 = __ballot(!st0.done) != 0, act1 = __ballot(!st1.done) != 0;
             if (!act0 && !act1) break;
             const bool last = t + 1 == prm.iters;
-            if (act0) advance(uo0, v0, drow0, st0, mj0, last);
-            if (act1) advance(uo1, v1, drow1, st1, mj1, last);
+            if (act0) advance(uo0, v0, drow0, st0, mj0, last, dlb0_0, sc0);
+            if (act1) advance(uo1, v1, drow1, st1, mj1, last, dlb0_1, sc1);
         }
         // ---- intervals of the divergence (sinkhorn.rs:166-171): the same three f32 operations, monotone in the cost
-        const float sp = P.self[i];
-        auto finish = [&](const SbCol& st, bool valid, uint32_t j, uint32_t jc) {
-            float lo = 0.0f, hi = __builtin_inff();
-            if (valid && st.opened) {
+        auto finish = [&](const SbCol& st, bool valid, uint32_t j, float sc, float dlb0, bool complete) {
+            float lo = valid ? dlb0 : 0.0f, hi = __builtin_inff();
+            if (valid && st.opened && complete) {  // a column dropped inside its window keeps [dlb0, inf)
                 const float cl = st.wmin - (prm.dc_abs + prm.dc_rel * fabsf(st.wmin));
                 const float ch = st.wmax + (prm.dc_abs + prm.dc_rel * fabsf(st.wmax));
-                const float sc = cs.self[jc];
-                if (cl == cl && cl > -__builtin_inff()) lo = rp_maxf(cl - 0.5f * sc - 0.5f * sp, 0.0f);
+                if (cl == cl && cl > -__builtin_inff()) lo = fmaxf(lo, rp_maxf(cl - 0.5f * sc - 0.5f * sp, 0.0f));
                 if (ch == ch) hi = rp_maxf(ch - 0.5f * sc - 0.5f * sp, 0.0f);
             }
             if (g == 0 && j < 256) {
@@ -323,8 +377,8 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_sinkhorn_bound(Points P, Cent
                 L.dhi[j] = hi;
             }
         };
-        finish(st0, valid0, j0, jc0);
-        finish(st1, valid1, j1, jc1);
+        finish(st0, valid0, j0, sc0, dlb0_0, st0.complete);
+        finish(st1, valid1, j1, sc1, dlb0_1, st1.complete);
         __syncthreads();
         // ---- survivors: every centroid whose lower bound does not exceed the smallest upper bound
         if (tid < 256) {
