@@ -509,39 +509,72 @@ def convergence_times(args, g, local_rank):
     return out
 
 
-def nlhe_real(args, local_rank):
-    """BASELINE configs[3] on one GPU: Solver::step of the NLHE blueprint solver (trees generated, traversed and applied on
-    the device), infoset-updates (= Decisions, the reference's `infos` counter) per second; the reference's batch of 128
-    trees beside the GPU-sized one; the CPU oracle on one host thread as the baseline."""
-    import torch  # noqa: F401  (one HIP runtime per process)
+def nlhe_real(args, rank, world, local_rank):
+    """BASELINE configs[3]: Solver::step of the NLHE blueprint solver (trees generated, traversed and applied on the device),
+    infoset-updates (= Decisions, the reference's `infos` counter) per second; the reference's batch of 128 trees beside the
+    GPU-sized one; the CPU oracle on one host thread as the baseline.  On several GPUs the trees of an epoch are sharded by
+    rank and the per-infoset entries exchanged by key (robopoker_amd.parallel.ShardedNlhe), weak scaling."""
+    import torch
 
     from robopoker_amd.nlhe import NlheSolver
 
+    sharded = world > 1 or args.force_sharded
+    dist = None
+    if sharded:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        init_rccl(rank, world)
+
     def run(batch, steps, warmup):
         s = NlheSolver(cap_log2=args.nlhe_cap, regret="linear", weight="linear", batch=batch, seed=args.seed, device=local_rank)
+        if sharded:
+            from robopoker_amd.parallel import ShardedNlhe
+
+            sh = ShardedNlhe(s, device="cuda")
+            one = sh.step
+        else:
+            one = lambda: s.step(args.update)  # noqa: E731
         for _ in range(warmup):
-            s.step(args.update)
+            one()
         n0, i0, _ = s.counters()
+        if sharded:
+            torch.cuda.synchronize()
+            dist.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            s.step(args.update)
+            one()
         n1, i1, keys = s.counters()  # counters() synchronises the stream
         dt = time.perf_counter() - t0
+        infos, nodes = i1 - i0, n1 - n0
+        if sharded:
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0, 0.0, 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+            t[1], t[2] = float(infos), float(nodes)  # each rank counts the Decisions of its own trees
+            dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+            dt, infos, nodes = float(t[0]), int(t[1]), int(t[2])
         s.close()
-        return {"infos": i1 - i0, "nodes": n1 - n0, "dt": dt, "keys": keys}
+        return {"infos": infos, "nodes": nodes, "dt": dt, "keys": keys}
 
     big = run(args.nlhe_batch, args.steps, args.warmup)
     ref = run(128, max(args.steps, 20), 3)
+    if rank != 0:
+        dist.destroy_process_group()
+        return
+    trees = args.nlhe_batch * args.steps * world
     line = {
-        "metric": "mccfr_infoset_updates_per_sec", "value": big["infos"] / big["dt"], "unit": "infoset-updates/s", "n_gpus": 1,
+        "metric": "mccfr_infoset_updates_per_sec", "value": big["infos"] / big["dt"], "unit": "infoset-updates/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": big["dt"] / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "heads-up NLHE blueprint MCCFR (BASELINE configs[3] on one GPU): trees generated on the device, "
                                "hash encoder (no trained abstraction), external sampling, linear regret / linear weight",
-                   "batch_per_gpu": args.nlhe_batch, "table_rows": 1 << args.nlhe_cap, "max_actions": 9, "update": args.update,
-                   "infosets_in_table": big["keys"]},
-        "trees_per_s": args.nlhe_batch * args.steps / big["dt"], "nodes_per_s": big["nodes"] / big["dt"],
-        "nodes_per_tree": big["nodes"] / (args.nlhe_batch * args.steps), "infos_per_tree": big["infos"] / (args.nlhe_batch * args.steps),
+                   "batch_per_gpu": args.nlhe_batch, "global_batch": args.nlhe_batch * world, "table_rows": 1 << args.nlhe_cap,
+                   "max_actions": 9, "update": "composed, exchanged by infoset key" if sharded else args.update,
+                   "infosets_in_table": big["keys"], "parallelism": f"tree-sharded x{world}"},
+        "trees_per_s": trees / big["dt"], "nodes_per_s": big["nodes"] / big["dt"],
+        "nodes_per_tree": big["nodes"] / trees, "infos_per_tree": big["infos"] / trees,
         "reference_batch_128": {"value": ref["infos"] / ref["dt"], "unit": "infoset-updates/s",
                                 "ms_per_step": ref["dt"] / max(args.steps, 20) * 1e3,
                                 "note": "nlhe/src/solver.rs:11 batch_size = 128: two wavefronts of a lane-per-tree traversal"},
@@ -567,6 +600,8 @@ def nlhe_real(args, local_rank):
     else:
         line["cpu_baseline"] = None
     print(json.dumps(line), flush=True)
+    if sharded:
+        dist.destroy_process_group()
 
 
 def main():
@@ -584,7 +619,7 @@ def main():
     if args.workload == "nlhe-synth":
         return nlhe_synth(args, rank, world, local_rank)
     if args.workload == "nlhe":
-        return nlhe_real(args, local_rank)
+        return nlhe_real(args, rank, world, local_rank)
 
     from robopoker_amd import Game
 

@@ -359,6 +359,25 @@ RP_API int rp_nlhe_export(rp_nlhe* h, uint64_t cap, uint64_t* n, uint64_t* past,
 RP_API int rp_nlhe_import(rp_nlhe* h, uint64_t n, const uint64_t* past, const uint32_t* present, const uint64_t* choices,
                           const rp_encounter* enc, uint64_t epoch);
 
+/* Multi-GPU (BASELINE configs[3]): trees sharded by rank (rank r samples tree ids [r*B, (r+1)*B) of a world*B-tree epoch
+ * against a replicated table).  step_local: this rank's traversal reduced to one composed entry per infoset touched
+ * (rp_profile_summarize's records, entry_bytes each, at most max_entries) plus the infoset KEY of every entry — each
+ * rank's table assigns rows in its own insertion order, so the exchange is by key; the caller all-gathers entries and keys
+ * (rank-major, packed); step_apply maps the keys to this table's rows (inserting unseen infosets with their default
+ * regrets) and folds in rank order, epoch += 1.  Replicas stay identical as key -> Encounter maps.  Oracle:
+ * ora_nlmc_step_world. */
+RP_API int rp_nlhe_set_shard(rp_nlhe* h, uint32_t rank, uint32_t world);
+RP_API int rp_nlhe_entry_bytes(rp_nlhe* h, size_t* bytes, uint32_t* max_entries);
+RP_API int rp_nlhe_step_local(rp_nlhe* h, void* entries_dev, uint64_t* past_dev, uint32_t* present_dev, uint64_t* choices_dev,
+                              uint32_t* n_entries);
+RP_API int rp_nlhe_step_apply(rp_nlhe* h, void* entries_dev, const uint64_t* past_dev, const uint32_t* present_dev,
+                              const uint64_t* choices_dev, uint32_t n_entries);
+/* every rp_nlhe kernel runs on ONE stream (the profile's): hand it the stream the collectives run on and the exchange is
+ * ordered without host synchronisation (NULL = back to a stream of the library's own); rp_nlhe_sync waits for it.
+ * step_local returns with *n_entries valid and the key arrays QUEUED on that stream. */
+RP_API int rp_nlhe_set_stream(rp_nlhe* h, void* hip_stream);
+RP_API int rp_nlhe_sync(rp_nlhe* h);
+
 /* ===================================================================== lloyd ==
  * crates/elkan: Elkan<K,N> (elkan.rs:27-207), Bounds (bounds.rs:19-120), Prior::tally (prior.rs:35-47)
  * crates/lloyd: Layer (layer.rs:23-273), Kmeans (kmeans.rs:29-111), Sinkhorn (sinkhorn.rs:62-230),

@@ -69,6 +69,7 @@ typedef struct ora_nlmc {
     uint32_t batch;
     uint64_t nodes, infos;
     uint32_t max_tree, max_tree_decisions;
+    uint32_t rank, world; /* tree ids [rank * batch, (rank + 1) * batch) of a world * batch-tree epoch */
     const int64_t* tab_obs[4]; /* encoder table per street: sorted canonical observations */
     const uint16_t* tab_abs[4];
     uint64_t tab_n[4];
@@ -410,6 +411,7 @@ ORA_API ora_nlmc* ora_nlmc_create(uint32_t cap_log2, int R, int W, const rp_hype
     h->hp = *hp;
     h->seed = seed;
     h->batch = batch ? batch : 128; /* nlhe/src/solver.rs:11 */
+    h->world = 1;
     h->prof = ora_profile_create(1ull << cap_log2, NLMC_A, R, W, hp, NULL);
     h->keys = (nl_key*)calloc(1ull << cap_log2, sizeof(nl_key));
     h->used = (uint8_t*)calloc(1ull << cap_log2, 1);
@@ -436,7 +438,8 @@ static void run_batch(ora_nlmc* h) {
     const uint64_t epoch = ora_mccfr_epoch(h->prof);
     const int walker = (int)(epoch % 2); /* CfrSampling::walker (book.rs:142-144) */
     h->nd_dec = 0;
-    for (uint32_t t = 0; t < h->batch; ++t) {
+    for (uint32_t i = 0; i < h->batch; ++i) {
+        const uint64_t t = (uint64_t)h->rank * h->batch + i;
         build_tree(h, epoch, t, walker);
         h->nodes += h->n;
         if (h->n > h->max_tree) h->max_tree = h->n;
@@ -460,6 +463,85 @@ ORA_API uint64_t ora_nlmc_batch(ora_nlmc* h, const uint32_t** row, const uint8_t
     *row = h->d_row; *nact = h->d_nact; *expanded = h->d_exp; *regret = h->d_regret; *policy = h->d_policy; *payoff = h->d_payoff;
     *tree = h->d_tree;
     return h->nd_dec;
+}
+/* ---- the multi-GPU exchange (rp_nlhe_set_shard / step_local / step_apply): trees sharded by rank, each rank's Decisions
+ * reduced to per-infoset composed entries (rp_oracle_mccfr.c ora_profile_summarize), the entries exchanged BY KEY — every
+ * rank's table assigns rows in its own insertion order — and folded in rank order (ora_profile_fold). */
+int64_t ora_profile_summarize(ora_mccfr* h, uint64_t n, const uint32_t* row, const uint8_t* nact, const uint16_t* expanded,
+                              const float* regret, const float* policy, const float* payoff, void* blob);
+void ora_profile_fold(ora_mccfr* h, const void* blob, uint64_t n_entries);
+size_t ora_profile_entry_bytes(const ora_mccfr* h);
+ORA_API void ora_nlmc_set_shard(ora_nlmc* h, uint32_t rank, uint32_t world) {
+    h->rank = rank;
+    h->world = world ? world : 1;
+}
+ORA_API size_t ora_nlmc_entry_bytes(const ora_nlmc* h) { return ora_profile_entry_bytes(h->prof); }
+/* this rank's batch -> entries (sorted by its rows) with the infoset key of each; returns the count (-1: schedule unsupported) */
+ORA_API int64_t ora_nlmc_step_local(ora_nlmc* h, void* entries, uint64_t* past, uint32_t* present, uint64_t* choices) {
+    run_batch(h);
+    const int64_t ne = ora_profile_summarize(h->prof, h->nd_dec, h->d_row, h->d_nact, h->d_exp, h->d_regret, h->d_policy, h->d_payoff, entries);
+    const size_t eb = ora_profile_entry_bytes(h->prof);
+    for (int64_t i = 0; i < ne; ++i) {
+        uint32_t row;
+        memcpy(&row, (const unsigned char*)entries + (size_t)i * eb, 4);
+        past[i] = h->keys[row].past;
+        present[i] = h->keys[row].present;
+        choices[i] = h->keys[row].choices;
+    }
+    return ne;
+}
+/* all ranks' entries back to back (rank-major) with their keys: rows rewritten to THIS table's, then folded; epoch += 1 */
+ORA_API void ora_nlmc_step_apply(ora_nlmc* h, void* entries, const uint64_t* past, const uint32_t* present, const uint64_t* choices,
+                                 uint64_t n) {
+    const size_t eb = ora_profile_entry_bytes(h->prof);
+    for (uint64_t i = 0; i < n; ++i) {
+        nl_key k = {past[i], choices[i], present[i]};
+        uint8_t e[MAX_PATH_EDGES + 1];
+        const int m = ora_path_unpack(choices[i], e);
+        const uint32_t row = row_of(h, &k, e, m);
+        memcpy((unsigned char*)entries + (size_t)i * eb, &row, 4);
+    }
+    ora_profile_fold(h->prof, entries, n);
+}
+/* single-process model of a `world`-rank step: every rank traverses against the same start-of-epoch table */
+ORA_API int ora_nlmc_step_world(ora_nlmc* h, uint32_t world) {
+    const size_t eb = ora_profile_entry_bytes(h->prof);
+    size_t cap = 1 << 16, n = 0;
+    unsigned char* ent = (unsigned char*)malloc(cap * eb);
+    uint64_t* kp = (uint64_t*)malloc(cap * 8);
+    uint64_t* kc = (uint64_t*)malloc(cap * 8);
+    uint32_t* kb = (uint32_t*)malloc(cap * 4);
+    const uint32_t rank0 = h->rank, world0 = h->world;
+    int rc = 0;
+    for (uint32_t r = 0; r < world && !rc; ++r) {
+        ora_nlmc_set_shard(h, r, world);
+        run_batch(h);
+        while (n + h->nd_dec > cap) {
+            cap *= 2;
+            ent = (unsigned char*)realloc(ent, cap * eb);
+            kp = (uint64_t*)realloc(kp, cap * 8);
+            kc = (uint64_t*)realloc(kc, cap * 8);
+            kb = (uint32_t*)realloc(kb, cap * 4);
+        }
+        const int64_t ne = ora_profile_summarize(h->prof, h->nd_dec, h->d_row, h->d_nact, h->d_exp, h->d_regret, h->d_policy, h->d_payoff,
+                                                 ent + n * eb);
+        if (ne < 0) {
+            rc = -1;
+            break;
+        }
+        for (int64_t i = 0; i < ne; ++i) {
+            uint32_t row;
+            memcpy(&row, ent + (n + (size_t)i) * eb, 4);
+            kp[n + i] = h->keys[row].past;
+            kb[n + i] = h->keys[row].present;
+            kc[n + i] = h->keys[row].choices;
+        }
+        n += (size_t)ne;
+    }
+    if (!rc) ora_nlmc_step_apply(h, ent, kp, kb, kc, n);
+    ora_nlmc_set_shard(h, rank0, world0);
+    free(ent); free(kp); free(kc); free(kb);
+    return rc;
 }
 ORA_API uint64_t ora_nlmc_epoch(const ora_nlmc* h) { return ora_mccfr_epoch(h->prof); }
 ORA_API void ora_nlmc_counters(const ora_nlmc* h, uint64_t* nodes, uint64_t* infos, uint64_t* keys) {

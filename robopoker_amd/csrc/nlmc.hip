@@ -58,6 +58,7 @@ struct NlTable {  // NlheInfo -> row: open addressing, linear probing; slot inde
 struct NlParams {
     uint64_t seed, epoch;
     uint32_t batch, walker;
+    uint64_t tree_base;  // first tree id of this rank's shard (rank * batch)
     float temperature, smoothing, curiosity;
     int encoder;  // 0: hash of the canonical observation, 1: lookup tables
     const uint64_t* tkeys[4];
@@ -145,7 +146,7 @@ __device__ uint32_t nl_row_of(const NlTable& t, uint64_t past, uint64_t choices,
     return 0;
 }
 
-__device__ __forceinline__ uint64_t nl_draw(uint64_t deck, int k, const NlParams& p, uint64_t tree, uint64_t key) {
+__device__ __forceinline__ uint64_t nl_draw(uint64_t deck, int k, const NlParams& p, uint64_t tree, uint64_t key) {  // tree = its id in the epoch
     uint64_t out = 0;
     for (int c = 0; c < k; ++c) {
         const uint32_t pick = rp_pick_uniform(rp_node_hash(p.seed, p.epoch, tree, key + (uint64_t)c), (uint32_t)__popcll(deck));
@@ -173,8 +174,9 @@ __device__ __forceinline__ uint32_t nl_bucket(const NlParams& p, int street, uin
 #define NL_SENT 12u
 
 __global__ __launch_bounds__(64) void k_nlhe_traverse(NlParams p, NlTable t, NlScratch sc, unsigned long long* counters) {
-    const uint32_t tree = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t tree = blockIdx.x * 64u + threadIdx.x;  // slot of the tree in this rank's scratch
     if (tree >= p.batch) return;
+    const uint64_t tree_id = p.tree_base + tree;           // its id in the epoch: what the random draws are keyed by
     uint32_t err = 0;
     uint32_t* meta = sc.meta + (size_t)tree * p.ncap;
     float* fac = sc.fac + (size_t)tree * p.ncap;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(64) void k_nlhe_traverse(NlParams p, NlTable t, NlS
         g.state[i] = NL_BETTING;
         g.stack[i] = 200;
         g.stake[i] = g.spent[i] = 0;
-        g.cards[i] = nl_draw(deck, 2, p, tree, 0xD0C0000000000000ull + 8u * (uint64_t)i);
+        g.cards[i] = nl_draw(deck, 2, p, tree_id, 0xD0C0000000000000ull + 8u * (uint64_t)i);
         deck &= ~g.cards[i];
     }
     for (int b = 0; b < 2; ++b) g.force_act(NlAction{NA_BLIND, g.to_post(), 0});
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(64) void k_nlhe_traverse(NlParams p, NlTable t, NlS
                     total += rp_maxf(sw[a] / z, RP_EPSILON);
                     cum[a] = total;
                 }
-                const float u = rp_u01(rp_node_hash(p.seed, p.epoch, tree, nl_key_hash(cur_past, chpath, bucket))) * total;
+                const float u = rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, nl_key_hash(cur_past, chpath, bucket))) * total;
                 while (pick + 1 < nch && cum[pick] <= u) ++pick;
                 childfac_opp = sigma[pick] / (sw[pick] / z);
             }
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(64) void k_nlhe_traverse(NlParams p, NlTable t, NlS
             const uint64_t hk = rp_mix64(cur_hkey ^ ((uint64_t)(e + 1u) * 0x9fb21c651e98df25ull));
             G2 c = g;
             NlAction act;
-            if (e == NE_DRAW) act = NlAction{NA_DRAW, 0, nl_draw(g.deck(), g.street() == 0 ? 3 : 1, p, tree, hk)};
+            if (e == NE_DRAW) act = NlAction{NA_DRAW, 0, nl_draw(g.deck(), g.street() == 0 ? 3 : 1, p, tree_id, hk)};
             else act = g.snap(nl_actionize(g, e, 0));
             if (!c.allowed(act)) err |= NERR_ILLEGAL;
             c.force_act(act);
@@ -451,6 +453,28 @@ __global__ __launch_bounds__(256) void k_nlhe_pack(NlScratch sc, uint32_t batch,
         out.payoff[base + d] = sc.dpay[src];
         out.tree[base + d] = tree;
     }
+}
+
+// ---- the multi-GPU exchange by infoset key (every rank's table assigns rows in its own insertion order) ----
+// entries: rp_profile_summarize's records, [row u32][count u32][psum f32][n_actions u32][maps]; keys beside them
+__global__ __launch_bounds__(256) void k_nlhe_entry_keys(NlTable t, const unsigned char* entries, uint32_t eb, uint32_t n, uint64_t* past,
+                                                         uint32_t* present, uint64_t* choices) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t row = *reinterpret_cast<const uint32_t*>(entries + (size_t)i * eb);
+    past[i] = t.past[row];
+    present[i] = t.present[row];
+    choices[i] = t.choices[row];
+}
+__global__ __launch_bounds__(256) void k_nlhe_entry_remap(NlTable t, unsigned char* entries, uint32_t eb, uint32_t n, const uint64_t* past,
+                                                          const uint32_t* present, const uint64_t* choices, unsigned long long* counters) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t edges[12], nch = 0, err = 0;
+    for (uint64_t c = choices[i]; nch < 12u && (c & 0x1full) != 0; c >>= 5) edges[nch++] = (uint32_t)(c & 0x1full);
+    const uint32_t row = nl_row_of(t, past[i], choices[i], present[i], edges, nch, &err);
+    *reinterpret_cast<uint32_t*>(entries + (size_t)i * eb) = row;
+    if (err) atomicOr(counters + 2, (unsigned long long)err);
 }
 
 }  // namespace rp
@@ -751,6 +775,63 @@ int rp_nlhe_import(rp_nlhe* h, uint64_t n, const uint64_t* past, const uint32_t*
     HIP_TRY(hipMemcpy(h->tab.n_keys, &k, 4, hipMemcpyHostToDevice));
     if ((rc = rp_profile_set_rows(h->prof, n, rows.data(), enc))) return rc;
     return rp_profile_set_epoch(h->prof, epoch);
+}
+
+int rp_nlhe_set_shard(rp_nlhe* h, uint32_t rank, uint32_t world) {
+    if (!h || world == 0 || rank >= world) return rp::fail(RP_ERR_INVALID, "rp_nlhe_set_shard: bad rank/world");
+    h->prm.tree_base = (uint64_t)rank * h->batch;
+    return RP_OK;
+}
+
+int rp_nlhe_entry_bytes(rp_nlhe* h, size_t* bytes, uint32_t* max_entries) {
+    if (!h || !bytes) return rp::fail(RP_ERR_INVALID, "rp_nlhe_entry_bytes: NULL argument");
+    int rc = rp_profile_entry_bytes(h->prof, bytes);
+    if (max_entries) *max_entries = h->out_cap;
+    return rc;
+}
+
+int rp_nlhe_step_local(rp_nlhe* h, void* entries_dev, uint64_t* past_dev, uint32_t* present_dev, uint64_t* choices_dev, uint32_t* n_entries) {
+    if (!h || !entries_dev || !past_dev || !present_dev || !choices_dev || !n_entries)
+        return rp::fail(RP_ERR_INVALID, "rp_nlhe_step_local: NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = nl_traverse(h);
+    if (rc) return rc;
+    rp_decisions b{h->last_n, h->out.row, h->out.nact, h->out.expanded, h->out.regret, h->out.policy, h->out.payoff};
+    if ((rc = rp_profile_summarize(h->prof, &b, entries_dev, n_entries))) return rc;  // synchronises: *n_entries is valid
+    if (*n_entries) {
+        size_t eb = 0;
+        (void)rp_profile_entry_bytes(h->prof, &eb);
+        hipLaunchKernelGGL(k_nlhe_entry_keys, dim3((*n_entries + 255u) / 256u), dim3(256), 0, rp::profile_stream(h->prof), h->tab,
+                           reinterpret_cast<const unsigned char*>(entries_dev), (uint32_t)eb, *n_entries, past_dev, present_dev, choices_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    return RP_OK;
+}
+
+int rp_nlhe_step_apply(rp_nlhe* h, void* entries_dev, const uint64_t* past_dev, const uint32_t* present_dev, const uint64_t* choices_dev,
+                       uint32_t n_entries) {
+    if (!h || (n_entries && (!entries_dev || !past_dev || !present_dev || !choices_dev)))
+        return rp::fail(RP_ERR_INVALID, "rp_nlhe_step_apply: NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (n_entries) {
+        size_t eb = 0;
+        (void)rp_profile_entry_bytes(h->prof, &eb);
+        hipLaunchKernelGGL(k_nlhe_entry_remap, dim3((n_entries + 255u) / 256u), dim3(256), 0, rp::profile_stream(h->prof), h->tab,
+                           reinterpret_cast<unsigned char*>(entries_dev), (uint32_t)eb, n_entries, past_dev, present_dev, choices_dev,
+                           h->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    return rp_profile_fold(h->prof, entries_dev, n_entries);
+}
+
+int rp_nlhe_set_stream(rp_nlhe* h, void* hip_stream) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_nlhe_set_stream: null handle");
+    return rp_profile_set_stream(h->prof, hip_stream);
+}
+
+int rp_nlhe_sync(rp_nlhe* h) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_nlhe_sync: null handle");
+    return rp_profile_sync(h->prof);
 }
 
 }  // extern "C"

@@ -326,8 +326,6 @@ def bench_slice(n_points: int = 16384, K: int = 256, bins: int = 256, iters: int
         "kernels_ms": {"step": step_ms / max(step_n, 1), "pairwise": pw_ms / max(pw_n, 1),
                        "bounds": bd_ms / max(bd_n, 1), "drift": dr_ms / max(dr_n, 1)},
     }
-    if kind == "sinkhorn":
-        out["_centroids"] = layer.centroids()[0]  # for the CPU baseline's pairwise sample; removed before printing
     layer.close()
     return out
 
@@ -486,6 +484,7 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
                                     "survivors_per_point": st["survivors"] / max(st["points"], 1),
                                     "note": "scaling-domain Sinkhorn bound in front of init_bounds and lookup; flops = MFMA "
                                             "instructions issued x 2048"}
+        out["_centroids"] = layer.centroids()[0]  # for the CPU baseline's pairwise sample; callers pop it before printing
     layer.close()
     return out
 

@@ -60,6 +60,31 @@ class NlheSolver:
                                            _p(out["n_actions"]), _p(out["expanded"]), _p(out["regret"]), _p(out["policy"]), _p(out["payoff"])))
         return out
 
+    # ---- multi-GPU exchange by infoset key (include/rp_mi355x.h rp_nlhe_step_local / step_apply) ----
+    def set_shard(self, rank: int, world: int):
+        _lib.check(self._lib.rp_nlhe_set_shard(self._h, rank, world))
+
+    def entry_bytes(self):
+        b, m = C.c_size_t(), C.c_uint32()
+        _lib.check(self._lib.rp_nlhe_entry_bytes(self._h, C.byref(b), C.byref(m)))
+        return b.value, m.value
+
+    def step_local(self, entries_ptr: int, past_ptr: int, present_ptr: int, choices_ptr: int) -> int:
+        n = C.c_uint32()
+        _lib.check(self._lib.rp_nlhe_step_local(self._h, C.c_void_p(entries_ptr), C.c_void_p(past_ptr), C.c_void_p(present_ptr),
+                                                C.c_void_p(choices_ptr), C.byref(n)))
+        return n.value
+
+    def step_apply(self, entries_ptr: int, past_ptr: int, present_ptr: int, choices_ptr: int, n: int):
+        _lib.check(self._lib.rp_nlhe_step_apply(self._h, C.c_void_p(entries_ptr), C.c_void_p(past_ptr), C.c_void_p(present_ptr),
+                                                C.c_void_p(choices_ptr), n))
+
+    def set_stream(self, hip_stream_ptr):
+        _lib.check(self._lib.rp_nlhe_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def sync(self):
+        _lib.check(self._lib.rp_nlhe_sync(self._h))
+
     @property
     def epoch(self) -> int:
         e = C.c_uint64()

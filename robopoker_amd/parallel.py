@@ -295,3 +295,53 @@ class ShardedProfile:
             total = sum(counts)
             self.engine.fold(self.packed.data_ptr(), total)
             return total
+
+
+class ShardedNlhe:
+    """Tree-sharded NLHE blueprint MCCFR (BASELINE configs[3]): rank r traverses tree ids [r*B, (r+1)*B) of a world*B-tree
+    epoch against its replica of the table; the per-infoset composed entries are exchanged BY KEY (every rank's table assigns
+    rows in its own insertion order) — all-gathered padded to the longest list, packed rank-major on the device, mapped to the
+    local rows and folded in rank order.  Replicas stay identical as key -> Encounter maps.
+
+    ``engine``: ``set_shard / entry_bytes / step_local / step_apply`` (robopoker_amd.nlhe.NlheSolver on a GPU; the oracle in the
+    gloo tests)."""
+
+    def __init__(self, engine, device="cpu", group=None):
+        self.engine = engine
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = device
+        self.flat = _flat_all_gather_supported(group)
+        engine.set_shard(self.rank, self.world)
+        self.scope = _StreamScope(engine, device)
+        self.eb, cap = engine.entry_bytes()
+        self.cap = cap
+        mk = lambda n, dt: torch.zeros(n, dtype=dt, device=device)  # noqa: E731
+        self.mine = {"ent": mk(cap * self.eb, torch.uint8), "past": mk(cap, torch.int64), "present": mk(cap, torch.int32),
+                     "choices": mk(cap, torch.int64)}
+        self.all = {k: mk(v.numel() * self.world, v.dtype) for k, v in self.mine.items()}
+        self.packed = {k: mk(v.numel() * self.world, v.dtype) for k, v in self.mine.items()}
+
+    def step(self) -> int:
+        with self.scope:
+            return self._step()
+
+    def _step(self) -> int:
+        m = self.mine
+        n = self.engine.step_local(m["ent"].data_ptr(), m["past"].data_ptr(), m["present"].data_ptr(), m["choices"].data_ptr())
+        counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+        _all_gather_bytes(counts, torch.tensor([n], dtype=torch.int64, device=self.device), self.group, self.flat)
+        counts = [int(c) for c in counts.cpu().tolist()]
+        width, total = max(counts), sum(counts)
+        if width:
+            for k, unit in (("ent", self.eb), ("past", 1), ("present", 1), ("choices", 1)):
+                w = width * unit
+                _all_gather_bytes(self.all[k][: self.world * w], m[k][:w], self.group, self.flat)
+                off = 0
+                for r, c in enumerate(counts):  # rank-major packing, on the device
+                    self.packed[k][off: off + c * unit] = self.all[k][r * w: r * w + c * unit]
+                    off += c * unit
+        p = self.packed
+        self.engine.step_apply(p["ent"].data_ptr(), p["past"].data_ptr(), p["present"].data_ptr(), p["choices"].data_ptr(), total)
+        return total

@@ -36,6 +36,14 @@ def lib():
         o.ora_nlmc_export.restype = C.c_uint64
         o.ora_nlmc_export.argtypes = [vp, C.c_uint64, vp, vp, vp, vp]
         o.ora_nlmc_import.argtypes = [vp, C.c_uint64, vp, vp, vp, vp]
+        o.ora_nlmc_set_shard.argtypes = [vp, C.c_uint32, C.c_uint32]
+        o.ora_nlmc_entry_bytes.restype = C.c_size_t
+        o.ora_nlmc_entry_bytes.argtypes = [vp]
+        o.ora_nlmc_step_local.restype = C.c_int64
+        o.ora_nlmc_step_local.argtypes = [vp, vp, vp, vp, vp]
+        o.ora_nlmc_step_apply.argtypes = [vp, vp, vp, vp, vp, C.c_uint64]
+        o.ora_nlmc_step_world.restype = C.c_int
+        o.ora_nlmc_step_world.argtypes = [vp, C.c_uint32]
         o.ora_nlmc_hash_bucket.restype = C.c_uint32
         o.ora_nlmc_hash_bucket.argtypes = [C.c_int, C.c_int64]
         _o = o
@@ -60,6 +68,26 @@ class OracleNlhe:
 
     def step(self):
         self._o.ora_nlmc_step(self._h)
+
+    # ---- the sharded surface of the C-ABI (rp_nlhe_set_shard / step_local / step_apply), host pointers ----
+    def set_shard(self, rank: int, world: int):
+        self._o.ora_nlmc_set_shard(self._h, rank, world)
+
+    def entry_bytes(self):
+        return self._o.ora_nlmc_entry_bytes(self._h), self.batch_size * 600
+
+    def step_local(self, entries_ptr, past_ptr, present_ptr, choices_ptr) -> int:
+        n = self._o.ora_nlmc_step_local(self._h, C.c_void_p(entries_ptr), C.c_void_p(past_ptr), C.c_void_p(present_ptr), C.c_void_p(choices_ptr))
+        if n < 0:
+            raise RuntimeError("composed update unsupported for this schedule")
+        return n
+
+    def step_apply(self, entries_ptr, past_ptr, present_ptr, choices_ptr, n: int):
+        self._o.ora_nlmc_step_apply(self._h, C.c_void_p(entries_ptr), C.c_void_p(past_ptr), C.c_void_p(present_ptr), C.c_void_p(choices_ptr), n)
+
+    def step_world(self, world: int):
+        if self._o.ora_nlmc_step_world(self._h, world) != 0:
+            raise RuntimeError("composed update unsupported for this schedule")
 
     def batch(self):
         ptr = [C.c_void_p() for _ in range(7)]

@@ -174,6 +174,43 @@ def _profile_worker(rank, port, out):
     dist.destroy_process_group()
 
 
+def _nlhe_worker(rank, port, out):
+    # BASELINE configs[3]'s exchange: trees sharded by rank, composed entries exchanged by infoset key (robopoker_amd.parallel.
+    # ShardedNlhe) — against the single-process world model, bit for bit, and replica against replica
+    import oracle_nlmc as M
+    from robopoker_amd.parallel import ShardedNlhe
+
+    _init(rank, port)
+    eng = M.OracleNlhe(cap_log2=16, regret="linear", weight="linear", batch=24, seed=8)
+    sh = ShardedNlhe(eng, device="cpu")
+    for _ in range(3):
+        sh.step()
+    # infosets a rank merely READ during its own traversal sit in its table with their default row (the reference treats a
+    # missing Encounter the same way, book.rs:93-122): replicas agree on every infoset an update has touched
+    mine = {k: v for k, v in M.as_map(*eng.export()).items() if v["visits"][0] > 0}
+    keys = sorted(mine)
+    blob = np.concatenate([np.frombuffer(mine[k].tobytes(), dtype=np.uint8) for k in keys])
+    t = torch.from_numpy(blob.copy())
+    size = torch.tensor([t.numel()])
+    ref_size = size.clone()
+    dist.broadcast(ref_size, src=0)
+    same = int(size) == int(ref_size)
+    if same:
+        ref = t.clone()
+        dist.broadcast(ref, src=0)
+        same = bool(torch.equal(t, ref))
+    if rank == 0:
+        single = M.OracleNlhe(cap_log2=16, regret="linear", weight="linear", batch=24, seed=8)
+        for _ in range(3):
+            single.step_world(WORLD)
+        want = {k: v for k, v in M.as_map(*single.export()).items() if v["visits"][0] > 0}
+        ok = want.keys() == mine.keys() and all(want[k].tobytes() == mine[k].tobytes() for k in want)
+        out.put(("nlhe", same and ok and eng.epoch == 3 and eng.counters()[1] > 0))
+    else:
+        out.put(("nlhe-replica", same))
+    dist.destroy_process_group()
+
+
 def _pretraining_gather_worker(rank, port, out):
     # the list plumbing of the sharded abstraction pipeline (robopoker_amd/pretraining.py): contiguous equal-width
     # slices of an isomorphism list, the last one short; 1-byte results all-gathered back into list order
@@ -233,6 +270,11 @@ def test_sharded_kmeans_two_ranks_equals_single_process(kind):
 def test_sharded_sparse_profile_two_ranks_equals_world_model():
     res = _run(_profile_worker)
     assert res == {"profile": True, "profile-replica": True}
+
+
+def test_sharded_nlhe_two_ranks_exchange_by_key_equals_world_model():
+    res = _run(_nlhe_worker)
+    assert res == {"nlhe": True, "nlhe-replica": True}
 
 
 def test_sharded_pretraining_slices_and_gathers_two_ranks():

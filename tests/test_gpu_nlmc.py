@@ -145,3 +145,47 @@ def test_blueprint_file_roundtrip_through_the_device(gpu, tmp_path):
         assert np.array_equal(da[f], db[f]), f
     for f in ("regret", "policy", "payoff"):
         assert np.array_equal(da[f].view(np.uint32), db[f].view(np.uint32)), f
+
+
+@pytest.mark.parametrize("world,batch", [(2, 96), (4, 64)])
+def test_tree_shards_exchanged_by_key_match_the_world_model(gpu, world, batch):
+    # BASELINE configs[3] on several GPUs: rank r traverses trees [r*B, (r+1)*B) of a world*B-tree epoch, the per-infoset
+    # entries travel BY KEY (each table numbers its rows in its own insertion order) and every replica folds all of them in
+    # rank order.  `world` handles on one device, buffers concatenated by hand; against ora_nlmc_step_world.  Same tolerance
+    # and the same resynchronisation as the single-rank test above.
+    import torch
+
+    devs = [NlheSolver(cap_log2=18, batch=batch, seed=31) for _ in range(world)]
+    for r, d in enumerate(devs):
+        d.set_shard(r, world)
+    eb, cap = devs[0].entry_bytes()
+    ora = M.OracleNlhe(cap_log2=18, batch=batch, seed=31)
+    mk = lambda n, dt: torch.zeros(n, dtype=dt, device="cuda")  # noqa: E731
+    bufs = {"ent": mk(cap * eb * world, torch.uint8), "past": mk(cap * world, torch.int64),
+            "present": mk(cap * world, torch.int32), "choices": mk(cap * world, torch.int64)}
+    unit = {"ent": eb, "past": 8, "present": 4, "choices": 8}
+    for step in range(3):
+        off = 0
+        for d in devs:  # rank-major: rank r's entries right behind rank r-1's
+            n = d.step_local(*[bufs[k].data_ptr() + off * unit[k] for k in ("ent", "past", "present", "choices")])
+            off += n
+            d.sync()  # each handle runs on a stream of its own; in a real job the collective's stream orders the ranks
+        assert off > 0
+        for d in devs:  # step_apply rewrites the entries' row fields for ITS table, in place: one replica after the other
+            d.step_apply(*[bufs[k].data_ptr() for k in ("ent", "past", "present", "choices")], off)
+            d.sync()
+        ora.step_world(world)
+        om = {k: v for k, v in M.as_map(*ora.export()).items() if v["visits"][0] > 0}
+        for d in devs:
+            dm = {k: v for k, v in M.as_map(*d.export()).items() if v["visits"][0] > 0}
+            assert dm.keys() == om.keys()
+            for k in om:
+                assert np.array_equal(dm[k]["visits"], om[k]["visits"]), (step, k)
+                np.testing.assert_allclose(dm[k]["regret"], om[k]["regret"], rtol=2e-4, atol=5e-3)
+                np.testing.assert_allclose(dm[k]["weight"], om[k]["weight"], rtol=2e-4, atol=1e-5)
+                np.testing.assert_allclose(dm[k]["payoff"], om[k]["payoff"], rtol=2e-4, atol=5e-3)
+            assert d.epoch == ora.epoch == step + 1
+        for d in devs:
+            d.load(*ora.export(), epoch=ora.epoch)
+    for d in devs:
+        d.close()
