@@ -274,6 +274,10 @@ RP_API int rp_mccfr_step_comm(rp_mccfr* h, rp_comm* c, uint32_t steps, uint32_t 
 RP_API int rp_mccfr_profile(rp_mccfr* h, int enable);
 /* name in {"traverse","compact","update"}; total milliseconds and launch count since profiling was enabled */
 RP_API int rp_mccfr_kernel_time(rp_mccfr* h, const char* name, double* total_ms, uint64_t* launches);
+/* which Solver::batch kernel this handle launches under its current sampling scheme: 0 = per-tree scratch in HBM (any
+ * game), 1 = per-lane DFS with the tree in LDS (small games), 2 = instantiated over the game's compile-time action
+ * skeleton (Kuhn / Leduc shapes, external sampling; csrc/traverse_static.hpp).  All three produce identical Decisions. */
+RP_API int rp_mccfr_traversal_variant(rp_mccfr* h, int* out);
 
 /* ============================================================= sparse profile ==
  * The update half of Solver::step (solver/solver.rs:96-105,143-192: update_regret, update_weight, update_payoff,

@@ -686,6 +686,10 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
     count_metrics(p, nn, ndec, err);
 }
 
+}  // namespace rp
+#include "traverse_static.hpp"
+namespace rp {
+
 // ------------------------------------------------------------------------------------------------
 // schedules (regret/*.rs, policy/*.rs)
 // ------------------------------------------------------------------------------------------------
@@ -1554,6 +1558,7 @@ struct rp_mccfr {
     uint32_t maxdec = 1;
     rp_update_mode mode = RP_UPDATE_ORDERED;
     bool use_lds_traverse = false;
+    int static_skel = 0;  // 0: none (k_traverse_lds / k_traverse), 1: KuhnSkel, 2: LeducSkel (traverse_static.hpp)
     bool profiling = false;
     KernelClock clk_traverse, clk_compact, clk_update;
 };
@@ -1724,6 +1729,35 @@ void clock_drain(KernelClock& c) {
     c.pending.clear();
 }
 
+// Does the game's state table match skeleton G node for node, for EVERY chance outcome?  (traverse_static.hpp)  Also: an
+// infoset belongs to one skeleton node only, so a sampled tree meets each walker infoset at most once (a span of the
+// reference's Tree::partition has a single root) — the static kernel writes one Decisions per live walker node.
+template <class G>
+bool skel_matches(const rp_game_table* game, const std::vector<uint32_t>& children) {
+    constexpr Skeleton S = SkelOf<G>::S;
+    if (game->n_players != 2 || game->max_actions != 2) return false;
+    std::vector<std::vector<int>> kids(S.n);
+    for (int s = 1; s < S.n; ++s) kids[S.parent[s]].push_back(s);
+    std::vector<int> node_of_info(game->n_infos, -1);
+    std::function<bool(uint32_t, int)> match = [&](uint32_t sid, int s) -> bool {
+        const rp_state& st = game->states[sid];
+        if (S.kind[s] == SK_TERMINAL) return st.n_children == 0;
+        if (S.kind[s] == SK_CHANCE) {
+            if (st.turn != RP_TURN_CHANCE || st.n_children == 0 || kids[s].size() != 1) return false;
+            for (uint32_t k = 0; k < st.n_children; ++k)
+                if (!match(children[st.offset + k], kids[s][0])) return false;
+            return true;
+        }
+        if (st.turn != (uint8_t)(S.kind[s] - SK_P0) || st.n_children != 2 || kids[s].size() != 2 || st.info >= game->n_infos) return false;
+        if (node_of_info[st.info] >= 0 && node_of_info[st.info] != s) return false;
+        node_of_info[st.info] = s;
+        for (int c : kids[s])
+            if (S.edge[c] > 1 || !match(children[st.offset + (uint32_t)S.edge[c]], c)) return false;
+        return kids[s][0] != kids[s][1] && S.edge[kids[s][0]] != S.edge[kids[s][1]];
+    };
+    return match(game->train_root, 0);
+}
+
 // The per-infoset sigma / q tables can ride in LDS (a copy per wave) when they are small; measured on Leduc the L1 path
 // at 8 waves/CU beats the LDS copy at 7 (0.54 vs 0.57 ms per 2^20 trees), so LDS is opt-in (RP_TRAV_TAB_LDS=1).
 bool traverse_tables_in_lds(const rp_mccfr* h) {
@@ -1743,7 +1777,19 @@ bool traverse_fits_lds(const rp_mccfr* h) {
 int launch_traverse(rp_mccfr* h, const StepParams& p) {
     if (h->dc.slotmap) HIP_TRY(hipMemsetAsync(h->dc.slotmap, 0, (size_t)h->tbl.n_infos * h->dc.stride, h->stream));
     clock_begin(h, h->clk_traverse);
-    if (h->use_lds_traverse) {
+    if (h->static_skel && p.S == RP_SAMPLING_EXTERNAL) {
+        hipLaunchKernelGGL(k_prepare_infos, dim3((h->tbl.n_infos + 63) / 64), dim3(64), 0, h->stream, h->g, h->t, p, h->itab);
+        const dim3 grid((h->batch + 255) / 256), block(256);
+#define LAUNCH_STATIC(G, WK) hipLaunchKernelGGL((k_traverse_static<G, WK>), grid, block, 0, h->stream, h->g, h->itab, h->dc, p)
+        if (h->static_skel == 1) {
+            if (p.walker == 0) LAUNCH_STATIC(KuhnSkel, 0);
+            else LAUNCH_STATIC(KuhnSkel, 1);
+        } else {
+            if (p.walker == 0) LAUNCH_STATIC(LeducSkel, 0);
+            else LAUNCH_STATIC(LeducSkel, 1);
+        }
+#undef LAUNCH_STATIC
+    } else if (h->use_lds_traverse) {
         hipLaunchKernelGGL(k_prepare_infos, dim3((h->tbl.n_infos + 63) / 64), dim3(64), 0, h->stream, h->g, h->t, p, h->itab);
         const size_t lds = traverse_lds_bytes(h);
         const dim3 grid((h->batch + 63) / 64), block(64);
@@ -2010,7 +2056,7 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
     CREATE_TRY(hipMalloc(&h->d_counters, (size_t)METRIC_STRIPES * METRIC_STRIDE * sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(h->d_counters, 0, (size_t)METRIC_STRIPES * METRIC_STRIDE * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(&h->d_summary, summary_bytes_of(h)));
-    CREATE_TRY(hipMalloc(&h->d_itab, (5 * cells + 2 * (size_t)game->n_infos + 2) * 4));
+    CREATE_TRY(hipMalloc(&h->d_itab, (5 * cells + 2 * (size_t)game->n_infos + 4) * 4));
     {
         float* f = reinterpret_cast<float*>(h->d_itab);
         h->itab.sigma = f;
@@ -2019,7 +2065,7 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
         h->itab.total = f + 3 * cells;
         h->itab.keep = reinterpret_cast<uint32_t*>(f + 3 * cells + game->n_infos);
         const size_t used = 3 * cells + 2 * (size_t)game->n_infos;
-        h->itab.sq = reinterpret_cast<float2*>(f + ((used + 1) & ~(size_t)1));  // 8-byte aligned
+        h->itab.sq = reinterpret_cast<float2*>(f + ((used + 3) & ~(size_t)3));  // 16-byte aligned: a two-action row is one float4
     }
     uint32_t maxstack = 1;
     sampled_tree_bounds(h, &h->maxdec, &maxstack, &h->maxint);
@@ -2034,6 +2080,10 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
         return rp::fail(RP_ERR_CAPACITY, "rp_mccfr_create: chain tiles need %zu B of LDS", chain_lds_bytes(game->max_actions));
     }
     h->use_lds_traverse = traverse_fits_lds(h) && getenv("RP_MCCFR_HBM_SCRATCH") == nullptr;
+    if (h->use_lds_traverse && getenv("RP_TRAV_GENERIC") == nullptr) {
+        if (skel_matches<KuhnSkel>(game, h->children)) h->static_skel = 1;
+        else if (skel_matches<LeducSkel>(game, h->children)) h->static_skel = 2;
+    }
     rc = alloc_batch_buffers(h, batch_size);
     if (rc) {
         rp_mccfr_destroy(h);
@@ -2446,6 +2496,12 @@ int rp_mccfr_profile(rp_mccfr* h, int enable) {
     h->profiling = enable != 0;
     h->clk_traverse.total_ms = h->clk_compact.total_ms = h->clk_update.total_ms = 0.0;
     h->clk_traverse.launches = h->clk_compact.launches = h->clk_update.launches = 0;
+    return RP_OK;
+}
+
+int rp_mccfr_traversal_variant(rp_mccfr* h, int* out) {
+    if (!h || !out) return rp::fail(RP_ERR_INVALID, "rp_mccfr_traversal_variant: NULL argument");
+    *out = (h->static_skel && h->S == RP_SAMPLING_EXTERNAL) ? 2 : (h->use_lds_traverse ? 1 : 0);
     return RP_OK;
 }
 

@@ -1,0 +1,272 @@
+// traverse_static.hpp — Solver::batch (crates/mccfr/src/solver/solver.rs:225-250) for games whose ACTION tree does not
+// depend on the cards: the traversal instantiated per game, as the reference's Solver<G> is monomorphised per CfrGame.
+//
+// k_traverse_lds walks each sampled tree with a per-lane DFS: 64 lanes = 64 different node sequences, half of the lanes
+// idle on average (profiles/r01_mccfr_sq_counters.txt) and every step of a lane waits for the one before it.  In Kuhn and
+// Leduc the sampled tree of ANY deal is a sub-tree of one fixed skeleton (the public betting tree with its chance nodes
+// collapsed to the sampled outcome): what varies per tree is which skeleton nodes are live (the opponent's sampled
+// actions), their infoset ids and their payoffs.  So the skeleton is a compile-time constant, the node loop is unrolled
+// over it, every lane executes the same instruction stream (no divergence, no LDS, no stack), all per-node state sits in
+// registers with static indices, and the loads of independent sub-trees overlap.
+//
+// Same arithmetic as k_traverse_lds, operation for operation (TreeBuilder::build builder.rs:74-87,141-161 in pop-last
+// order = pre-order with children in DESCENDING edge order; CfrFlow::dfs / recursed_value / ancestor_reach
+// flow.rs:64-87,166-216): the Decisions are bit-identical (tests/test_gpu_mccfr.py::test_static_skeleton_equals_generic).
+// Used when the game's tables match the skeleton node for node (skel_matches, checked once at rp_mccfr_create), the scheme
+// is external sampling (the walker expands every action) and max_actions == 2; everything else takes k_traverse_lds.
+#pragma once
+
+#include <type_traits>
+
+namespace rp {
+
+enum : int { SK_CHANCE = 0, SK_P0 = 1, SK_P1 = 2, SK_TERMINAL = 3 };
+#define SK_MAXN 48
+
+struct Skeleton {
+    int n = 0;
+    int kind[SK_MAXN] = {};
+    int parent[SK_MAXN] = {};  // -1 at the root
+    int edge[SK_MAXN] = {};    // the action leading here; ignored below a chance node (the sampled outcome)
+    int end[SK_MAXN] = {};     // last node of the sub-tree (pre-order: the sub-tree of s is [s, end[s]])
+    constexpr int add(int k, int p, int e) {
+        const int i = n++;
+        kind[i] = k;
+        parent[i] = p;
+        edge[i] = e;
+        end[i] = i;
+        return i;
+    }
+    constexpr void close(int s) { end[s] = n - 1; }
+};
+
+// ---- Kuhn (crates/kuhn/src/game.rs:7-15,131-151): Start -> Dealt -> Open{Check{T, CheckBet{T,T}}, Bet{T,T}} ----
+struct KuhnSkel {
+    static constexpr Skeleton make() {
+        Skeleton b;
+        const int start = b.add(SK_CHANCE, -1, 0);
+        const int dealt = b.add(SK_CHANCE, start, 0);
+        const int open = b.add(SK_P0, dealt, 0);
+        {  // children in descending edge order (the last child pushed is the first popped)
+            const int bet = b.add(SK_P1, open, 1);
+            b.add(SK_TERMINAL, bet, 1);
+            b.add(SK_TERMINAL, bet, 0);
+            b.close(bet);
+            const int check = b.add(SK_P1, open, 0);
+            const int cb = b.add(SK_P0, check, 1);
+            b.add(SK_TERMINAL, cb, 1);
+            b.add(SK_TERMINAL, cb, 0);
+            b.close(cb);
+            b.add(SK_TERMINAL, check, 0);
+            b.close(check);
+        }
+        b.close(open);
+        b.close(dealt);
+        b.close(start);
+        return b;
+    }
+};
+
+// ---- Leduc (crates/leduc/src/game.rs:7-12,152-223): two betting rounds of the same shape, a Deal between them ----
+struct LeducSkel {
+    enum { OPEN, CHECKED, RAISED, CHECKRAISED };
+    // one betting round below `parent`; `next` = 1: a closed round continues with the Deal and round 2, 0: it ends
+    static constexpr void round(Skeleton& b, int parent, int edge, int spot, int next) {
+        const int actor = (spot == OPEN || spot == CHECKRAISED) ? SK_P0 : SK_P1;
+        const int s = b.add(actor, parent, edge);
+        auto closes = [&](int e) {  // the child that closes the round: Deal -> round 2, or the showdown
+            if (next) {
+                const int deal = b.add(SK_CHANCE, s, e);
+                round(b, deal, 0, OPEN, 0);
+                b.close(deal);
+            } else {
+                b.add(SK_TERMINAL, s, e);
+            }
+        };
+        switch (spot) {
+            case OPEN:  // [Check, Raise]
+                round(b, s, 1, RAISED, next);
+                round(b, s, 0, CHECKED, next);
+                break;
+            case CHECKED:  // [Check -> closes, Raise]
+                round(b, s, 1, CHECKRAISED, next);
+                closes(0);
+                break;
+            default:  // RAISED / CHECKRAISED: [Fold, Call -> closes]
+                closes(1);
+                b.add(SK_TERMINAL, s, 0);
+                break;
+        }
+        b.close(s);
+    }
+    static constexpr Skeleton make() {
+        Skeleton b;
+        const int start = b.add(SK_CHANCE, -1, 0);
+        const int dealt = b.add(SK_CHANCE, start, 0);
+        round(b, dealt, 0, OPEN, 1);
+        b.close(dealt);
+        b.close(start);
+        return b;
+    }
+};
+
+template <class G>
+struct SkelOf {
+    static constexpr Skeleton S = G::make();
+};
+
+// compile-time loops: f(std::integral_constant<int, I>) for I = LO .. HI-1, ascending / descending
+template <int I, int HI, class F>
+__device__ __forceinline__ void sk_for(F&& f) {
+    if constexpr (I < HI) {
+        f(std::integral_constant<int, I>{});
+        sk_for<I + 1, HI>(f);
+    }
+}
+template <int I, int LO, class F>
+__device__ __forceinline__ void sk_for_down(F&& f) {  // I = HI-1 down to LO
+    if constexpr (I >= LO) {
+        f(std::integral_constant<int, I>{});
+        sk_for_down<I - 1, LO>(f);
+    }
+}
+
+// W = the walker (epoch % 2).  One lane per tree, 256 trees per workgroup, no LDS.
+template <class G, int W>
+__global__ __launch_bounds__(256) void k_traverse_static(DevGame g, DevInfoTab it, DevDecisions dc, StepParams p) {
+    using SK = SkelOf<G>;
+    constexpr int N = SK::S.n;
+    constexpr int K_WALKER = W == 0 ? SK_P0 : SK_P1;
+    constexpr int K_OPP = W == 0 ? SK_P1 : SK_P0;
+    const uint32_t lane = blockIdx.x * 256u + threadIdx.x;
+    if (lane >= p.batch) return;
+    const uint64_t tree_id = p.tree_base + lane;
+
+    // ---- TreeBuilder::build over the skeleton ----------------------------------------------------------------------
+    uint32_t rx[N], ry[N], rz[N], rw[N];  // the node's record (DevGame::kids): turn | n_children << 8, info / payoff0, offset / payoff1, state
+    uint32_t pick[N];                     // chance: the sampled outcome; opponent: the sampled action
+    bool live[N];
+    float sg0[N], sg1[N], q0[N], q1[N];   // (sigma, q) of a player node's two edges
+    rx[0] = g.root_rec.x;
+    ry[0] = g.root_rec.y;
+    rz[0] = g.root_rec.z;
+    rw[0] = g.root_rec.w;
+    live[0] = true;
+    sk_for<0, N>([&](auto I) __attribute__((always_inline)) {
+        constexpr int s = I;
+        constexpr int par = SK::S.parent[s];
+        if constexpr (par >= 0) {
+            uint32_t k = (uint32_t)SK::S.edge[s];
+            if constexpr (SK::S.kind[par] == SK_CHANCE) k = pick[par];
+            const uint4 r = g.kids[rz[par] + k];
+            rx[s] = r.x;
+            ry[s] = r.y;
+            rz[s] = r.z;
+            rw[s] = r.w;
+            if constexpr (SK::S.kind[par] == K_OPP) live[s] = live[par] && pick[par] == (uint32_t)SK::S.edge[s];
+            else live[s] = live[par];
+        }
+        if constexpr (SK::S.kind[s] == SK_CHANCE) {  // SamplingScheme::sample at a chance node: uniform (external.rs:41-64)
+            pick[s] = rp_pick_uniform(rp_node_hash(p.seed, p.epoch, tree_id, 0x80000000ull | rw[s]), (rx[s] >> 8) & 0xffu);
+        } else if constexpr (SK::S.kind[s] == SK_P0 || SK::S.kind[s] == SK_P1) {
+            const uint32_t info = ry[s];
+            const float4 f = *reinterpret_cast<const float4*>(&it.sq[info * 2u]);
+            sg0[s] = f.x;
+            q0[s] = f.y;
+            sg1[s] = f.z;
+            q1[s] = f.w;
+            if constexpr (SK::S.kind[s] == K_OPP) {  // WeightedIndex over max(q, EPSILON): two actions = one threshold
+                const float x = rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info)) * it.total[info];
+                pick[s] = it.cum[info * 2u] <= x ? 1u : 0u;
+            }
+        }
+    });
+
+    // ---- Tree::partition + CfrFlow::dfs per walker decision node (tree.rs:88-98, flow.rs:64-87) ---------------------
+    uint32_t ndec = 0, nn = 0;
+    sk_for<0, N>([&](auto I) __attribute__((always_inline)) { nn += live[decltype(I)::value] ? 1u : 0u; });
+    const size_t D = dc.stride;
+    sk_for<0, N>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = J;
+        if constexpr (SK::S.kind[j] == K_WALKER) {
+            constexpr int E = SK::S.end[j];
+            float rel[N], smp[N], acc[N], tv[2] = {0.0f, 0.0f};
+            // top-down over the sub-tree: reach products from j's children (flow.rs:195-212); a leaf hands its value to its
+            // parent right here, an internal node starts its sum at 0 (the two-children argument of k_traverse_lds)
+            sk_for<j + 1, E + 1>([&](auto Nn) __attribute__((always_inline)) {
+                constexpr int n = Nn;
+                constexpr int par = SK::S.parent[n];
+                constexpr int e = SK::S.edge[n];
+                float r = 1.0f, sm = 1.0f;
+                if constexpr (par != j) {
+                    r = rel[par];
+                    sm = smp[par];
+                    if constexpr (SK::S.kind[par] == K_WALKER) r = r * (e ? sg1[par] : sg0[par]);
+                    if constexpr (SK::S.kind[par] == K_OPP) {
+                        r = r * (e ? sg1[par] : sg0[par]);
+                        sm = sm * (e ? q1[par] : q0[par]);
+                    }
+                }
+                if constexpr (SK::S.kind[n] == SK_TERMINAL) {
+                    const float v = r / sm * rp_u2f(W == 0 ? ry[n] : rz[n]);
+                    if constexpr (par == j) tv[e] = v;
+                    else acc[par] = live[n] ? acc[par] + v : acc[par];
+                } else {
+                    rel[n] = r;
+                    smp[n] = sm;
+                    acc[n] = 0.0f;
+                }
+            });
+            // bottom-up: the internal nodes' sums, descending node index (node.rs:103-107)
+            sk_for_down<E, j + 1>([&](auto Nn) __attribute__((always_inline)) {
+                constexpr int n = Nn;
+                constexpr int par = SK::S.parent[n];
+                if constexpr (SK::S.kind[n] != SK_TERMINAL) {
+                    if constexpr (par == j) tv[SK::S.edge[n]] = acc[n];
+                    else acc[par] = live[n] ? acc[par] + acc[n] : acc[par];
+                }
+            });
+            // ancestor_reach (flow.rs:166-174): the opponent's edges on the way up
+            float cf = 1.0f, sm_ = 1.0f;
+            sk_for<0, N>([&](auto Q) __attribute__((always_inline)) {
+                // ancestors of j in the order j, parent(j), ...: node index DESCENDS along the chain, so visit candidates from
+                // j downwards and keep those on the chain
+                constexpr int n = j - decltype(Q)::value;
+                if constexpr (n > 0) {
+                    // is n on the parent chain of j (n == j or an ancestor)?  pre-order: n <= j <= end[n]
+                    if constexpr (n <= j && j <= SK::S.end[n]) {
+                        constexpr int par = SK::S.parent[n];
+                        if constexpr (SK::S.kind[par] == K_OPP) {
+                            cf = cf * (SK::S.edge[n] ? sg1[par] : sg0[par]);
+                            sm_ = sm_ * (SK::S.edge[n] ? q1[par] : q0[par]);
+                        }
+                    }
+                }
+            });
+            const float reach = cf / sm_;
+            const float u0 = reach * tv[0], u1 = reach * tv[1];
+            float ev = 0.0f;
+            ev += sg0[j] * u0;
+            ev += sg1[j] * u1;
+            const float payoff = 0.0f + ev;
+            const float g0 = 0.0f + (u0 - ev), g1 = 0.0f + (u1 - ev);
+            if (live[j]) {
+                const uint32_t slot = ndec;
+                const uint32_t info = ry[j];
+                dc.regret[((size_t)slot * 2u + 0u) * D + lane] = g0;
+                dc.regret[((size_t)slot * 2u + 1u) * D + lane] = g1;
+                dc.policy[((size_t)slot * 2u + 0u) * D + lane] = sg0[j];
+                dc.policy[((size_t)slot * 2u + 1u) * D + lane] = sg1[j];
+                dc.info[(size_t)slot * D + lane] = info;
+                dc.mask[(size_t)slot * D + lane] = 3u;
+                dc.payoff[(size_t)slot * D + lane] = payoff;
+                if (dc.slotmap) dc.slotmap[(size_t)info * D + lane] = (uint8_t)(slot + 1u);
+                ndec += 1u;
+            }
+        }
+    });
+    dc.ndec[lane] = (uint8_t)ndec;
+    count_metrics(p, nn, ndec, 0u);
+}
+
+}  // namespace rp

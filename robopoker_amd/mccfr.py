@@ -180,6 +180,12 @@ class Solver:
     def profile(self, enable=True):
         _lib.check(self._lib.rp_mccfr_profile(self._h, 1 if enable else 0))
 
+    def kernel_variant(self) -> str:
+        """which Solver::batch kernel runs: "hbm" (any game), "lds" (small games), "static" (compile-time skeleton)"""
+        v = C.c_int()
+        _lib.check(self._lib.rp_mccfr_traversal_variant(self._h, C.byref(v)))
+        return ("hbm", "lds", "static")[v.value]
+
     def kernel_time(self, name: str):
         ms, n = C.c_double(), C.c_uint64()
         _lib.check(self._lib.rp_mccfr_kernel_time(self._h, name.encode(), C.byref(ms), C.byref(n)))

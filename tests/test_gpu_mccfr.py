@@ -96,6 +96,28 @@ def test_hbm_scratch_traversal_variant_is_identical(gpu, monkeypatch):
     assert a.counters() == b.counters() == ora.counters()
 
 
+@pytest.mark.parametrize("game,batch", [("leduc", 1500), ("kuhn", 700), ("leduc_wide", 900)])
+@pytest.mark.parametrize("regret,weight", [("linear", "linear"), ("floored", "quadratic")])
+def test_static_skeleton_traversal_equals_generic_and_oracle(gpu, monkeypatch, game, batch, regret, weight):
+    # csrc/traverse_static.hpp: Kuhn's and Leduc's traversal is instantiated over the game's compile-time action skeleton
+    # (external sampling); RP_TRAV_GENERIC=1 keeps the per-lane DFS kernel.  Both against the oracle, bit for bit, both
+    # walkers, long enough for the opponent's sampling weights to leave their defaults.
+    g = Game(game)
+    a = Solver(g, regret, weight, "external", batch=batch, seed=41)
+    monkeypatch.setenv("RP_TRAV_GENERIC", "1")
+    b = Solver(g, regret, weight, "external", batch=batch, seed=41)
+    monkeypatch.delenv("RP_TRAV_GENERIC")
+    ora = oracle.OracleSolver(g, regret, weight, "external", batch=batch, seed=41)
+    for _ in range(10):
+        a.step()
+        b.step()
+        ora.step()
+        assert_tables_equal(a.export(), ora.export())
+        assert_tables_equal(b.export(), ora.export())
+    assert a.counters() == b.counters() == ora.counters()
+    assert a.kernel_variant() == "static" and b.kernel_variant() != "static"
+
+
 @pytest.mark.parametrize("mode", ["ordered", "composed"])
 @pytest.mark.parametrize("overrides", [
     dict(temperature=0.5, smoothing=0.25, curiosity=0.2),         # sampling distribution far from the defaults
