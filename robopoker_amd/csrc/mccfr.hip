@@ -686,10 +686,6 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
     count_metrics(p, nn, ndec, err);
 }
 
-}  // namespace rp
-#include "traverse_static.hpp"
-namespace rp {
-
 // ------------------------------------------------------------------------------------------------
 // schedules (regret/*.rs, policy/*.rs)
 // ------------------------------------------------------------------------------------------------
@@ -1371,6 +1367,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_chunk_maps(DevGame g, DevDecisio
     }
 }
 
+}  // namespace rp
+#include "traverse_static.hpp"
+namespace rp {
+
 // One workgroup per infoset.  Two-level fold (include/rp_mi355x.h RP_FOLD_GROUP): thread (slot s, cell c) composes
 // the RP_FOLD_GROUP consecutive block maps of group g = g0 + s sequentially — 256 / 2A groups in parallel, loads
 // CB_PF ahead of the chain — then the 2A cell threads fold the group maps in group order.
@@ -1558,6 +1558,7 @@ struct rp_mccfr {
     uint32_t maxdec = 1;
     rp_update_mode mode = RP_UPDATE_ORDERED;
     bool use_lds_traverse = false;
+    bool fuse_maps = true;  // composed update: traversal + block maps in one kernel when the game allows (RP_TRAV_UNFUSED=1: never)
     int static_skel = 0;  // 0: none (k_traverse_lds / k_traverse), 1: KuhnSkel, 2: LeducSkel (traverse_static.hpp)
     bool profiling = false;
     KernelClock clk_traverse, clk_compact, clk_update;
@@ -1856,7 +1857,18 @@ size_t chunk_maps_lds_bytes(const rp_mccfr* h) {
 
 // Decisions of the batch -> one composed map per table cell (+ payoff sum and count per infoset) in `blob_dev`.
 // Small games compose straight from the traversal's output; large ones from the sorted segments (launch_sort first).
-int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev) {
+// the traversal and the block maps in one kernel (k_traverse_maps_static): composed update of a small game whose traversal is
+// instantiated over its skeleton, external sampling
+size_t traverse_maps_lds_bytes(const rp_mccfr* h) {
+    const size_t NI = h->tbl.n_infos;
+    return (NI * 8 + 2 * NI) * 4 + NI * 8 * 2 + (size_t)5 * h->maxdec * 256 * 4;
+}
+bool traverse_maps_fused(const rp_mccfr* h) {
+    return h->static_skel && h->S == RP_SAMPLING_EXTERNAL && !h->dc.slotmap && h->tbl.n_infos <= CH_THREADS &&
+           traverse_maps_lds_bytes(h) <= 64 * 1024 && h->fuse_maps;
+}
+
+int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev, bool fused = false) {
     unsigned char* blob = reinterpret_cast<unsigned char*>(blob_dev);
     Cell* cells = reinterpret_cast<Cell*>(blob);
     InfoSum* sums = reinterpret_cast<InfoSum*>(blob + (size_t)h->tbl.n_infos * h->tbl.max_actions * sizeof(Cell));
@@ -1867,8 +1879,25 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev) {
     float* bpsum = reinterpret_cast<float*>(bmaps + slots * 2 * A);
     uint32_t* bcnt = reinterpret_cast<uint32_t*>(bpsum + slots);
     const bool pruned = h->S != RP_SAMPLING_EXTERNAL;
+    if (fused) {
+        clock_begin(h, h->clk_traverse);
+        hipLaunchKernelGGL(k_prepare_infos, dim3((h->tbl.n_infos + 63) / 64), dim3(64), 0, h->stream, h->g, h->t, p, h->itab);
+        const size_t lds = traverse_maps_lds_bytes(h);
+#define LAUNCH_FUSED(G, WK) \
+    hipLaunchKernelGGL((k_traverse_maps_static<G, WK>), dim3(nblk), dim3(256), lds, h->stream, h->g, h->itab, p, bmaps, bpsum, bcnt, nblk_max, h->maxdec)
+        if (h->static_skel == 1) {
+            if (p.walker == 0) LAUNCH_FUSED(KuhnSkel, 0);
+            else LAUNCH_FUSED(KuhnSkel, 1);
+        } else {
+            if (p.walker == 0) LAUNCH_FUSED(LeducSkel, 0);
+            else LAUNCH_FUSED(LeducSkel, 1);
+        }
+#undef LAUNCH_FUSED
+        clock_end(h, h->clk_traverse);
+    }
     clock_begin(h, h->clk_update);
-    if (!h->dc.slotmap) {
+    if (fused) {
+    } else if (!h->dc.slotmap) {
         const size_t lds = chunk_maps_lds_bytes(h);
 #define LAUNCH_CHUNK_MAPS(PR, PS) \
     hipLaunchKernelGGL((k_chunk_maps<PR, PS>), dim3(nblk), dim3(CH_THREADS), lds, h->stream, h->g, h->dc, p, bmaps, bpsum, bcnt, nblk_max)
@@ -1889,17 +1918,26 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev) {
     return RP_OK;
 }
 
-int enqueue_step(rp_mccfr* h) {
-    const StepParams p = make_params(h);
+// Solver::batch + the composed maps of its Decisions -> one summary blob
+int launch_batch_summary(rp_mccfr* h, const StepParams& p, void* blob_dev) {
+    if (traverse_maps_fused(h)) return launch_summarize(h, p, blob_dev, true);
     int rc = launch_traverse(h, p);
     if (rc) return rc;
+    if (h->dc.slotmap && (rc = launch_sort(h, p))) return rc;
+    return launch_summarize(h, p, blob_dev);
+}
+
+int enqueue_step(rp_mccfr* h) {
+    const StepParams p = make_params(h);
+    int rc;
     // the ordered chains and the large-game composed path read the sorted segments; small games compose from the
     // traversal's output directly
-    if ((h->mode == RP_UPDATE_ORDERED || h->dc.slotmap) && (rc = launch_sort(h, p))) return rc;
     if (h->mode == RP_UPDATE_ORDERED) {
+        if ((rc = launch_traverse(h, p))) return rc;
+        if ((rc = launch_sort(h, p))) return rc;
         if ((rc = launch_chain(h, p))) return rc;
     } else {
-        if ((rc = launch_summarize(h, p, h->d_summary))) return rc;
+        if ((rc = launch_batch_summary(h, p, h->d_summary))) return rc;
         const uint32_t ncell = h->tbl.n_infos * h->tbl.max_actions;
         hipLaunchKernelGGL(k_fold, dim3((ncell + 255) / 256), dim3(256), 0, h->stream, h->g, h->t,
                            reinterpret_cast<const unsigned char*>(h->d_summary), summary_bytes_of(h), 1u);
@@ -2080,6 +2118,7 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
         return rp::fail(RP_ERR_CAPACITY, "rp_mccfr_create: chain tiles need %zu B of LDS", chain_lds_bytes(game->max_actions));
     }
     h->use_lds_traverse = traverse_fits_lds(h) && getenv("RP_MCCFR_HBM_SCRATCH") == nullptr;
+    h->fuse_maps = getenv("RP_TRAV_UNFUSED") == nullptr;
     if (h->use_lds_traverse && getenv("RP_TRAV_GENERIC") == nullptr) {
         if (skel_matches<KuhnSkel>(game, h->children)) h->static_skel = 1;
         else if (skel_matches<LeducSkel>(game, h->children)) h->static_skel = 2;
@@ -2405,9 +2444,7 @@ int rp_mccfr_step_local(rp_mccfr* h, void* summary_dev) {
     if (rc) return rc;
     if ((rc = composed_supported(h))) return rc;
     const StepParams p = make_params(h);
-    if ((rc = launch_traverse(h, p))) return rc;
-    if (h->dc.slotmap && (rc = launch_sort(h, p))) return rc;
-    return launch_summarize(h, p, summary_dev);
+    return launch_batch_summary(h, p, summary_dev);
 }
 
 int rp_mccfr_step_apply(rp_mccfr* h, const void* gathered_dev, uint32_t world) {
@@ -2433,9 +2470,7 @@ int rp_mccfr_window_local(rp_mccfr* h, void* window_dev, int first) {
     if (rc) return rc;
     if ((rc = composed_supported(h))) return rc;
     const StepParams p = make_params(h);
-    if ((rc = launch_traverse(h, p))) return rc;
-    if (h->dc.slotmap && (rc = launch_sort(h, p))) return rc;
-    if ((rc = launch_summarize(h, p, h->d_summary))) return rc;
+    if ((rc = launch_batch_summary(h, p, h->d_summary))) return rc;
     const uint32_t ncell = h->tbl.n_infos * h->tbl.max_actions;
     hipLaunchKernelGGL(k_accumulate, dim3((ncell + 255) / 256), dim3(256), 0, h->stream, h->g, reinterpret_cast<unsigned char*>(window_dev),
                        reinterpret_cast<const unsigned char*>(h->d_summary), first ? 1u : 0u);

@@ -131,16 +131,17 @@ __device__ __forceinline__ void sk_for_down(F&& f) {  // I = HI-1 down to LO
     }
 }
 
-// W = the walker (epoch % 2).  One lane per tree, 256 trees per workgroup, no LDS.
-template <class G, int W>
-__global__ __launch_bounds__(256) void k_traverse_static(DevGame g, DevInfoTab it, DevDecisions dc, StepParams p) {
+// The traversal of one tree by one lane.  W = the walker (epoch % 2).  `present` = this lane has a tree (the ragged last
+// workgroup).  on_built(info_of, live_of) runs once the tree is sampled — before any value is computed — with two callables
+// over the skeleton's node index; on_decision(j, info, regret0, regret1, sigma0, sigma1, payoff) once per LIVE walker node,
+// ascending node index (= the order of Tree::partition's spans).  Returns the number of nodes of the sampled tree.
+template <class G, int W, class OnBuilt, class OnDecision>
+__device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevInfoTab& it, const StepParams& p, uint64_t tree_id,
+                                                    bool present, OnBuilt&& on_built, OnDecision&& on_decision) {
     using SK = SkelOf<G>;
     constexpr int N = SK::S.n;
     constexpr int K_WALKER = W == 0 ? SK_P0 : SK_P1;
     constexpr int K_OPP = W == 0 ? SK_P1 : SK_P0;
-    const uint32_t lane = blockIdx.x * 256u + threadIdx.x;
-    if (lane >= p.batch) return;
-    const uint64_t tree_id = p.tree_base + lane;
 
     // ---- TreeBuilder::build over the skeleton ----------------------------------------------------------------------
     uint32_t rx[N], ry[N], rz[N], rw[N];  // the node's record (DevGame::kids): turn | n_children << 8, info / payoff0, offset / payoff1, state
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void k_traverse_static(DevGame g, DevInfoTab i
     ry[0] = g.root_rec.y;
     rz[0] = g.root_rec.z;
     rw[0] = g.root_rec.w;
-    live[0] = true;
+    live[0] = present;
     sk_for<0, N>([&](auto I) __attribute__((always_inline)) {
         constexpr int s = I;
         constexpr int par = SK::S.parent[s];
@@ -183,9 +184,10 @@ __global__ __launch_bounds__(256) void k_traverse_static(DevGame g, DevInfoTab i
     });
 
     // ---- Tree::partition + CfrFlow::dfs per walker decision node (tree.rs:88-98, flow.rs:64-87) ---------------------
-    uint32_t ndec = 0, nn = 0;
+    uint32_t nn = 0;
     sk_for<0, N>([&](auto I) __attribute__((always_inline)) { nn += live[decltype(I)::value] ? 1u : 0u; });
-    const size_t D = dc.stride;
+    on_built([&](auto I) __attribute__((always_inline)) { return ry[decltype(I)::value]; },
+             [&](auto I) __attribute__((always_inline)) { return live[decltype(I)::value]; });
     sk_for<0, N>([&](auto J) __attribute__((always_inline)) {
         constexpr int j = J;
         if constexpr (SK::S.kind[j] == K_WALKER) {
@@ -250,22 +252,124 @@ __global__ __launch_bounds__(256) void k_traverse_static(DevGame g, DevInfoTab i
             ev += sg1[j] * u1;
             const float payoff = 0.0f + ev;
             const float g0 = 0.0f + (u0 - ev), g1 = 0.0f + (u1 - ev);
-            if (live[j]) {
-                const uint32_t slot = ndec;
-                const uint32_t info = ry[j];
-                dc.regret[((size_t)slot * 2u + 0u) * D + lane] = g0;
-                dc.regret[((size_t)slot * 2u + 1u) * D + lane] = g1;
-                dc.policy[((size_t)slot * 2u + 0u) * D + lane] = sg0[j];
-                dc.policy[((size_t)slot * 2u + 1u) * D + lane] = sg1[j];
-                dc.info[(size_t)slot * D + lane] = info;
-                dc.mask[(size_t)slot * D + lane] = 3u;
-                dc.payoff[(size_t)slot * D + lane] = payoff;
-                if (dc.slotmap) dc.slotmap[(size_t)info * D + lane] = (uint8_t)(slot + 1u);
-                ndec += 1u;
-            }
+            if (live[j]) on_decision(J, ry[j], g0, g1, sg0[j], sg1[j], payoff);
         }
     });
+    return nn;
+}
+
+// Decisions to HBM (DevDecisions), for the ordered update, the sorted large-game path and the debugging views.
+// One lane per tree, 256 trees per workgroup, no LDS.
+template <class G, int W>
+__global__ __launch_bounds__(256) void k_traverse_static(DevGame g, DevInfoTab it, DevDecisions dc, StepParams p) {
+    const uint32_t lane = blockIdx.x * 256u + threadIdx.x;
+    if (lane >= p.batch) return;
+    const size_t D = dc.stride;
+    uint32_t ndec = 0;
+    const uint32_t nn = static_traverse<G, W>(
+        g, it, p, p.tree_base + lane, true, [](auto, auto) __attribute__((always_inline)) {},
+        [&](auto, uint32_t info, float g0, float g1, float s0, float s1, float payoff) __attribute__((always_inline)) {
+            const uint32_t slot = ndec;
+            dc.regret[((size_t)slot * 2u + 0u) * D + lane] = g0;
+            dc.regret[((size_t)slot * 2u + 1u) * D + lane] = g1;
+            dc.policy[((size_t)slot * 2u + 0u) * D + lane] = s0;
+            dc.policy[((size_t)slot * 2u + 1u) * D + lane] = s1;
+            dc.info[(size_t)slot * D + lane] = info;
+            dc.mask[(size_t)slot * D + lane] = 3u;
+            dc.payoff[(size_t)slot * D + lane] = payoff;
+            if (dc.slotmap) dc.slotmap[(size_t)info * D + lane] = (uint8_t)(slot + 1u);
+            ndec += 1u;
+        });
     dc.ndec[lane] = (uint8_t)ndec;
+    count_metrics(p, nn, ndec, 0u);
+}
+
+// Composed update, small games: the traversal AND the block maps of its 256-tree chunk in one kernel — the Decisions never
+// reach HBM.  What k_chunk_maps does with the Decisions it reads back (per-infoset, tree-ordered lists by LDS bitmap +
+// prefix popcount; one sequential composition per (infoset, cell) from the identity: include/rp_mi355x.h "Composed
+// update") happens here on the values as they are produced: the lists' places are known once the trees are sampled
+// (on_built), each Decisions drops its five values (two regret deltas, two weight deltas, the payoff) at its place in LDS,
+// and the chains of ALL cells run side by side, one thread per (infoset, cell).  Same lists, same order, same operations
+// as k_chunk_maps: bmaps / bpsum / bcnt are bit-identical (tests/test_gpu_mccfr.py).
+// LDS (dynamic): bits u32[NI][8] | lcount u32[NI] | lbase u32[NI] | pre u16[NI][8] | vals f32[5][maxdec * 256]
+template <class G, int W>
+__global__ __launch_bounds__(256) void k_traverse_maps_static(DevGame g, DevInfoTab it, StepParams p, Map* bmaps, float* bpsum,
+                                                              uint32_t* bcnt, uint32_t nblk_max, uint32_t maxdec) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t tm_lds[];
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t NI = g.n_infos, chunk = blockIdx.x, lt = threadIdx.x;
+    uint32_t* bits = tm_lds;
+    uint32_t* lcount = bits + NI * 8u;
+    uint32_t* lbase = lcount + NI;
+    uint16_t* pre = reinterpret_cast<uint16_t*>(lbase + NI);
+    float* vals = reinterpret_cast<float*>(pre + NI * 8u + ((NI * 8u) & 1u));
+    const uint32_t L = maxdec * 256u;  // places per cell
+    for (uint32_t e = lt; e < NI * 8u; e += 256u) bits[e] = 0;
+    __syncthreads();
+    const uint32_t lane = chunk * 256u + lt;
+    const float tf = (float)p.epoch;
+    uint32_t ndec = 0;
+    const uint32_t nn = static_traverse<G, W>(
+        g, it, p, p.tree_base + lane, lane < p.batch,
+        [&](auto info_of, auto live_of) __attribute__((always_inline)) {
+            sk_for<0, SkelOf<G>::S.n>([&](auto J) __attribute__((always_inline)) {
+                if constexpr (SkelOf<G>::S.kind[decltype(J)::value] == (W == 0 ? SK_P0 : SK_P1)) {
+                    if (live_of(J)) atomicOr(&bits[info_of(J) * 8u + (lt >> 5)], 1u << (lt & 31u));
+                }
+            });
+            __syncthreads();
+            for (uint32_t info = lt; info < NI; info += 256u) {
+                uint32_t run = 0;
+                for (uint32_t w = 0; w < 8u; ++w) {
+                    pre[info * 8u + w] = (uint16_t)run;
+                    run += __popc(bits[info * 8u + w]);
+                }
+                lcount[info] = run;
+            }
+            __syncthreads();
+            lds_exscan(lcount, lbase, NI, wave_tot);
+        },
+        [&](auto, uint32_t info, float g0, float g1, float s0, float s1, float payoff) __attribute__((always_inline)) {
+            const uint32_t pos = lbase[info] + pre[info * 8u + (lt >> 5)] + __popc(bits[info * 8u + (lt >> 5)] & ((1u << (lt & 31u)) - 1u));
+            vals[pos] = g0;
+            vals[L + pos] = g1;
+            vals[2u * L + pos] = p.W == RP_WEIGHT_LINEAR ? s0 * tf : (p.W == RP_WEIGHT_QUADRATIC ? s0 * tf * tf : s0);
+            vals[3u * L + pos] = p.W == RP_WEIGHT_LINEAR ? s1 * tf : (p.W == RP_WEIGHT_QUADRATIC ? s1 * tf * tf : s1);
+            vals[4u * L + pos] = payoff;
+            ndec += 1u;
+        });
+    __syncthreads();
+    // the chains: task = (cell c, infoset); cells 0,1 regret, 2,3 weight, 4 the payoff sum
+    const float NEG_INF = rp_u2f(0xff800000u);
+    for (uint32_t task = lt; task < 5u * NI; task += 256u) {
+        const uint32_t c = task / NI, info = task - c * NI;
+        if (g.info_player[info] != p.walker) continue;
+        const uint32_t n = lcount[info], base = lbase[info];
+        const size_t slot_out = (size_t)info * nblk_max + chunk;
+        const float* v = vals + (size_t)c * L + base;
+        if (c == 4u) {  // payoff sum of the block, left fold from 0.0f
+            float sum = 0.0f;
+            for (uint32_t e = 0; e < n; ++e) sum += v[e];
+            bpsum[slot_out] = sum;
+            bcnt[slot_out] = n;
+            continue;
+        }
+        const bool isreg = c < 2u;
+        const float fl = isreg ? regret_floor_of(p.R, p.regret_min) : RP_EPSILON;
+        const float d = isreg ? (p.R == RP_REGRET_LINEAR ? tf / (tf + 1.0f) : 1.0f) : (p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f);
+        float ma = 1.0f, mb = 0.0f, mm = NEG_INF;
+        for (uint32_t e = 0; e < n; ++e) {
+            const float delta = v[e];
+            // first touch of the block: (d, delta, floor); then a <- a d, b <- b d + delta, m <- max(m d + delta, floor)
+            const float na = e ? ma * d : d;
+            const float nb = e ? mb * d + delta : delta;
+            const float nm = e ? rp_maxf(mm * d + delta, fl) : fl;
+            ma = na;
+            mb = nb;
+            mm = nm;
+        }
+        bmaps[slot_out * 4u + c] = Map{ma, mb, mm, n};
+    }
     count_metrics(p, nn, ndec, 0u);
 }
 

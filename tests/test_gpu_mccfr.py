@@ -118,6 +118,33 @@ def test_static_skeleton_traversal_equals_generic_and_oracle(gpu, monkeypatch, g
     assert a.kernel_variant() == "static" and b.kernel_variant() != "static"
 
 
+@pytest.mark.parametrize("game,batch", [("leduc", 1500), ("kuhn", 300), ("leduc", 256), ("kuhn", 5000)])
+@pytest.mark.parametrize("regret,weight", [("linear", "linear"), ("floored", "quadratic"), ("summed", "exponential")])
+def test_fused_traversal_and_block_maps_equal_the_unfused_kernels_and_the_oracle(gpu, monkeypatch, game, batch, regret, weight):
+    # composed update: k_traverse_maps_static composes a chunk's block maps from the Decisions while they are still in
+    # registers / LDS (nothing goes through HBM); RP_TRAV_UNFUSED=1 keeps k_traverse_static + k_chunk_maps, RP_TRAV_GENERIC=1
+    # the per-lane DFS + k_chunk_maps.  All three against the oracle's blocked composition, bit for bit; ragged last chunk,
+    # a single full chunk, many chunks.
+    g = Game(game)
+    fused = Solver(g, regret, weight, "external", batch=batch, seed=17)
+    monkeypatch.setenv("RP_TRAV_UNFUSED", "1")
+    unfused = Solver(g, regret, weight, "external", batch=batch, seed=17)
+    monkeypatch.delenv("RP_TRAV_UNFUSED")
+    monkeypatch.setenv("RP_TRAV_GENERIC", "1")
+    generic = Solver(g, regret, weight, "external", batch=batch, seed=17)
+    monkeypatch.delenv("RP_TRAV_GENERIC")
+    ora = oracle.OracleSolver(g, regret, weight, "external", batch=batch, seed=17)
+    devs = (fused, unfused, generic)
+    for d in devs:
+        d.set_update_mode("composed")
+    for _ in range(8):
+        ora.step_world(1)
+        for d in devs:
+            d.step()
+            assert_tables_equal(d.export(), ora.export())
+    assert fused.counters() == unfused.counters() == generic.counters() == ora.counters()
+
+
 @pytest.mark.parametrize("mode", ["ordered", "composed"])
 @pytest.mark.parametrize("overrides", [
     dict(temperature=0.5, smoothing=0.25, curiosity=0.2),         # sampling distribution far from the defaults
