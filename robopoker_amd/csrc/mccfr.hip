@@ -1861,7 +1861,7 @@ size_t chunk_maps_lds_bytes(const rp_mccfr* h) {
 // instantiated over its skeleton, external sampling
 size_t traverse_maps_lds_bytes(const rp_mccfr* h) {
     const size_t NI = h->tbl.n_infos;
-    return (NI * 8 + 2 * NI) * 4 + NI * 8 * 2 + (size_t)5 * h->maxdec * 256 * 4;
+    return (NI * 8 + 2 * NI) * 4 + NI * 8 * 2 + (NI + (NI & 1)) * 2 + (size_t)5 * h->maxdec * 256 * 4;
 }
 bool traverse_maps_fused(const rp_mccfr* h) {
     return h->static_skel && h->S == RP_SAMPLING_EXTERNAL && !h->dc.slotmap && h->tbl.n_infos <= CH_THREADS &&

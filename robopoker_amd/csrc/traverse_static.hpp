@@ -291,20 +291,26 @@ __global__ __launch_bounds__(256) void k_traverse_static(DevGame g, DevInfoTab i
 // (on_built), each Decisions drops its five values (two regret deltas, two weight deltas, the payoff) at its place in LDS,
 // and the chains of ALL cells run side by side, one thread per (infoset, cell).  Same lists, same order, same operations
 // as k_chunk_maps: bmaps / bpsum / bcnt are bit-identical (tests/test_gpu_mccfr.py).
-// LDS (dynamic): bits u32[NI][8] | lcount u32[NI] | lbase u32[NI] | pre u16[NI][8] | vals f32[5][maxdec * 256]
+// A chain is sequential and as long as its list (a root infoset meets a third of the chunk's trees, a river infoset a few):
+// the (infoset, cell) tasks are handed out in descending order of list length (a counting sort by log2 class), so the 64
+// chains of a wave have similar lengths instead of every wave waiting for one long chain.
+// LDS (dynamic): bits u32[NI][8] | lcount u32[NI] | lbase u32[NI] | pre u16[NI][8] | order u16[NI + (NI & 1)] | vals f32[5][maxdec * 256]
 template <class G, int W>
-__global__ __launch_bounds__(256) void k_traverse_maps_static(DevGame g, DevInfoTab it, StepParams p, Map* bmaps, float* bpsum,
+__global__ __launch_bounds__(256, 4) void k_traverse_maps_static(DevGame g, DevInfoTab it, StepParams p, Map* bmaps, float* bpsum,
                                                               uint32_t* bcnt, uint32_t nblk_max, uint32_t maxdec) {
     extern __shared__ __attribute__((aligned(16))) uint32_t tm_lds[];
     __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t cls_n[16], cls_at[16];
     const uint32_t NI = g.n_infos, chunk = blockIdx.x, lt = threadIdx.x;
     uint32_t* bits = tm_lds;
     uint32_t* lcount = bits + NI * 8u;
     uint32_t* lbase = lcount + NI;
     uint16_t* pre = reinterpret_cast<uint16_t*>(lbase + NI);
-    float* vals = reinterpret_cast<float*>(pre + NI * 8u + ((NI * 8u) & 1u));
+    uint16_t* order = pre + NI * 8u;
+    float* vals = reinterpret_cast<float*>(order + NI + (NI & 1u));
     const uint32_t L = maxdec * 256u;  // places per cell
     for (uint32_t e = lt; e < NI * 8u; e += 256u) bits[e] = 0;
+    if (lt < 16u) cls_n[lt] = 0;
     __syncthreads();
     const uint32_t lane = chunk * 256u + lt;
     const float tf = (float)p.epoch;
@@ -325,9 +331,22 @@ __global__ __launch_bounds__(256) void k_traverse_maps_static(DevGame g, DevInfo
                     run += __popc(bits[info * 8u + w]);
                 }
                 lcount[info] = run;
+                atomicAdd(&cls_n[15u - (run ? 32u - (uint32_t)__builtin_clz(run) : 0u)], 1u);  // class 15 - bit length: long lists first
             }
             __syncthreads();
             lds_exscan(lcount, lbase, NI, wave_tot);
+            if (lt == 0) {
+                uint32_t at = 0;
+                for (uint32_t k = 0; k < 16u; ++k) {
+                    cls_at[k] = at;
+                    at += cls_n[k];
+                }
+            }
+            __syncthreads();
+            for (uint32_t info = lt; info < NI; info += 256u) {
+                const uint32_t run = lcount[info];
+                order[atomicAdd(&cls_at[15u - (run ? 32u - (uint32_t)__builtin_clz(run) : 0u)], 1u)] = (uint16_t)info;
+            }
         },
         [&](auto, uint32_t info, float g0, float g1, float s0, float s1, float payoff) __attribute__((always_inline)) {
             const uint32_t pos = lbase[info] + pre[info * 8u + (lt >> 5)] + __popc(bits[info * 8u + (lt >> 5)] & ((1u << (lt & 31u)) - 1u));
@@ -342,7 +361,7 @@ __global__ __launch_bounds__(256) void k_traverse_maps_static(DevGame g, DevInfo
     // the chains: task = (cell c, infoset); cells 0,1 regret, 2,3 weight, 4 the payoff sum
     const float NEG_INF = rp_u2f(0xff800000u);
     for (uint32_t task = lt; task < 5u * NI; task += 256u) {
-        const uint32_t c = task / NI, info = task - c * NI;
+        const uint32_t c = task % 5u, info = order[task / 5u];
         if (g.info_player[info] != p.walker) continue;
         const uint32_t n = lcount[info], base = lbase[info];
         const size_t slot_out = (size_t)info * nblk_max + chunk;
