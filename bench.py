@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--window", type=int, default=1,
                     help="N > 1: local steps per exchange (the composed maps of `window` consecutive steps are folded "
                          "locally and all-gathered once; 1 = exchange every step)")
+    ap.add_argument("--comm", default="native", choices=["native", "torch"],
+                    help="N > 1: the library's own RCCL communicator driven from C (rp_mccfr_step_comm), or torch.distributed "
+                         "collectives driven from Python")
     ap.add_argument("--force-sharded", action="store_true",
                     help="exercise the RCCL all-gather path even with one rank (plumbing check)")
     return ap.parse_args()
@@ -417,10 +420,34 @@ def timed_mccfr(args, g, batch, rank, world, local_rank, sharded_mode, torch, di
 
     solver = Solver(g, args.regret, args.weight, args.sampling, batch=batch, seed=args.seed, device=local_rank)
     solver.set_update_mode(args.update)
-    if sharded_mode:
+    comm = None
+    if sharded_mode and args.comm == "native":
+        from robopoker_amd.parallel import Comm
+
+        # tree ids [rank*B, (rank+1)*B); the library's own RCCL communicator (csrc/comm.cpp): the kernels of a window and its
+        # ncclAllGather of the per-cell composed maps are queued on the solver's stream by ONE C call, no host work between
+        comm = Comm.from_process_group(local_rank)
+        solver.set_shard(rank, world)
+        pending = [0]
+
+        def step():
+            pending[0] += 1
+            if pending[0] == max(args.window, 1) * 8:  # a few windows per call: the queue stays ahead of the GPU
+                solver.step_comm(comm, pending[0], args.window)
+                pending[0] = 0
+
+        def fence():
+            if pending[0]:
+                solver.step_comm(comm, pending[0], args.window)
+                pending[0] = 0
+            solver.sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+    elif sharded_mode:
         from robopoker_amd.parallel import ShardedSolver
 
-        # tree ids [rank*B, (rank+1)*B); one RCCL all-gather of the per-cell composed maps per exchange window
+        # the same exchange driven from Python over torch.distributed (one all_gather per window)
         sharded = ShardedSolver(solver, device="cuda", window=args.window)
 
         def step():
@@ -442,7 +469,6 @@ def timed_mccfr(args, g, batch, rank, world, local_rank, sharded_mode, torch, di
         step()
     fence()
     _, infos0 = solver.counters()
-    solver.profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -450,11 +476,19 @@ def timed_mccfr(args, g, batch, rank, world, local_rank, sharded_mode, torch, di
     dt = time.perf_counter() - t0
     _, infos1 = solver.counters()
     out = {"infos_local": infos1 - infos0, "infos": infos1 - infos0, "dt": dt, "batch": batch}
+    # per-kernel durations for the roofline: the same K steps again with a HIP event pair around every kernel group on the
+    # launch stream (the event packets cost a few microseconds per launch, so they stay out of the timed region above)
+    solver.profile(True)
+    for _ in range(args.steps):
+        step()
+    fence()
     for name in ("traverse", "update", "compact"):
         ms, n = solver.kernel_time(name)
         out[name + "_ms"] = ms / max(n, 1)
     solver.profile(False)
     solver.close()
+    if comm is not None:
+        comm.close()
     if sharded_mode:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -329,9 +329,8 @@ struct DevInfoTab {
     float2* sq;      // [n_infos][A] (sigma, q) side by side: one load per edge in the traversal's sweeps
 };
 
-__global__ void k_prepare_infos(DevGame g, DevTables t, StepParams p, DevInfoTab it) {
-    const uint32_t info = blockIdx.x * blockDim.x + threadIdx.x;
-    if (info >= g.n_infos) return;
+__device__ __forceinline__ void prepare_one(const DevGame& g, const DevTables& t, const StepParams& p, const DevInfoTab& it,
+                                            uint32_t info) {
     const uint32_t A = g.A, n = g.info_actions[info];
     const float rd = d_regret_denom(t, A, info, n);
     const float denom = d_weight_denom(t, A, info, n, p.smoothing);
@@ -349,6 +348,11 @@ __global__ void k_prepare_infos(DevGame g, DevTables t, StepParams p, DevInfoTab
     }
     it.total[info] = total;
     it.keep[info] = keep;
+}
+__global__ void k_prepare_infos(DevGame g, DevTables t, StepParams p, DevInfoTab it) {
+    const uint32_t info = blockIdx.x * blockDim.x + threadIdx.x;
+    if (info >= g.n_infos) return;
+    prepare_one(g, t, p, it, info);
 }
 
 // SamplingScheme::sample with the per-infoset tables
@@ -1189,7 +1193,7 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
 // ordered mode is replaced by a two-level composition of per-cell maps F(x) = max(a x + b, m).
 //   k_block_maps  one workgroup per (infoset, block of T consecutive Decisions): sequential composition inside the
 //                 block, all blocks of all infosets in parallel
-//   k_combine     one wave per infoset: the block maps composed in block order -> Cell / InfoSum blob
+//   k_combine2    (infoset, part) workgroups: block maps -> group maps -> Cell / InfoSum blob, or straight into the tables
 // ------------------------------------------------------------------------------------------------
 // Map / map_compose live in mccfr_kernels.hpp
 // block = the Decisions of infoset blockIdx.y produced by chunk blockIdx.x (RP_COMPOSE_CHUNK == CH_TREES trees):
@@ -1371,80 +1375,186 @@ __global__ __launch_bounds__(CH_THREADS) void k_chunk_maps(DevGame g, DevDecisio
 #include "traverse_static.hpp"
 namespace rp {
 
-// One workgroup per infoset.  Two-level fold (include/rp_mi355x.h RP_FOLD_GROUP): thread (slot s, cell c) composes
-// the RP_FOLD_GROUP consecutive block maps of group g = g0 + s sequentially — 256 / 2A groups in parallel, loads
-// CB_PF ahead of the chain — then the 2A cell threads fold the group maps in group order.
-#define CB_PF 8
-__global__ __launch_bounds__(256) void k_combine(DevGame g, StepParams p, const Map* bmaps, const float* bpsum, const uint32_t* bcnt,
-                                                 uint32_t nblk_max, Cell* cells, InfoSum* sums) {
-    __shared__ __attribute__((aligned(16))) Map sup[256];
-    __shared__ float supp[256];
-    __shared__ uint32_t supc[256];
-    const uint32_t info = blockIdx.x, tid = threadIdx.x;
-    const uint32_t A = g.A, W2 = 2 * A;
-    const float NEG_INF = rp_u2f(0xff800000u);
-    const bool walker = g.info_player[info] == p.walker;
-    const uint32_t nb = walker ? (p.batch + RP_COMPOSE_CHUNK - 1) / RP_COMPOSE_CHUNK : 0u;  // one block per chunk of trees
-    const uint32_t ngrp = (nb + RP_FOLD_GROUP - 1) / RP_FOLD_GROUP;
-    const uint32_t NS = 256u / W2, c = tid % W2, s = tid / W2;
-    const Map ident{1.0f, 0.0f, NEG_INF, 0u};
-    const Map* src = bmaps + (size_t)info * nblk_max * W2;
-    const float* psrc = bpsum + (size_t)info * nblk_max;
-    Map tot = ident;
-    float ps = 0.0f;
-    const uint32_t* csrc = bcnt + (size_t)info * nblk_max;
-    uint32_t len = 0;
-    for (uint32_t g0 = 0; g0 < ngrp; g0 += NS) {
-        const uint32_t grp = g0 + s;
-        if (s < NS && grp < ngrp) {
-            const uint32_t b_lo = grp * RP_FOLD_GROUP, b_hi = min(nb, b_lo + RP_FOLD_GROUP);
+// The two-level fold of the block maps (include/rp_mi355x.h RP_FOLD_GROUP: the block maps of a cell composed sequentially
+// inside groups of RP_FOLD_GROUP consecutive blocks, the group maps then in group order), spread over (infoset, part)
+// workgroups, and — APPLY — the rest of the step with it.
+//   stage 1  a part owns CB2_GPW(2A) consecutive groups: its block maps are one contiguous run of HBM, copied to LDS by all
+//            256 threads at once (one round trip instead of a chain of eight per thread), then thread (group, cell) composes
+//            its RP_FOLD_GROUP maps out of LDS in block order; the group maps go to HBM with agent-scope stores;
+//   stage 2  the LAST part of an infoset to finish (arrival counter; which one is timing, what it computes is not) folds the
+//            infoset's group maps in group order into the summary cell maps, payoff sum and count;
+//   APPLY    single-GPU step: that workgroup also applies the summary to the infoset's table row (k_fold with world = 1)
+//            and refreshes the row of the per-infoset tables the next traversal reads (k_prepare_infos): one launch
+//            instead of three.  Otherwise it writes the summary blob (rp_mccfr_step_local).
+// Cross-workgroup data is a few KB per infoset: agent-scope (sc1) stores + s_waitcnt before the arrival, agent-scope
+// loads after it.  (A release FENCE at agent scope writes back a whole XCD's L2: tried on the block maps, 4x slower.)
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* q, uint32_t v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ Map ld_map(const Map* m) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(m);
+    return Map{rp_u2f(ld_agent(w)), rp_u2f(ld_agent(w + 1)), rp_u2f(ld_agent(w + 2)), ld_agent(w + 3)};
+}
+__device__ __forceinline__ void st_map(Map* m, const Map& v) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(m);
+    st_agent(w, rp_f2u(v.a));
+    st_agent(w + 1, rp_f2u(v.b));
+    st_agent(w + 2, rp_f2u(v.m));
+    st_agent(w + 3, v.n);
+}
+__host__ __device__ inline uint32_t cb2_gpw(uint32_t W2) { return 32u / W2 ? 32u / W2 : 1u; }  // groups per part: a 32 KB tile
+struct FoldScratch {
+    Map* gmaps;      // [n_infos][ngrp_max][2A]
+    float* gpsum;    // [n_infos][ngrp_max]
+    uint32_t* gcnt;  // [n_infos][ngrp_max]
+    uint32_t* done;  // [n_infos] parts finished
+    uint32_t ngrp_max;
+};
+template <bool APPLY>
+__global__ __launch_bounds__(256) void k_combine2(DevGame g, DevTables t, DevInfoTab it, StepParams p, const Map* bmaps, const float* bpsum,
+                                                  const uint32_t* bcnt, uint32_t nblk_max, FoldScratch fs, Cell* cells, InfoSum* sums) {
+    extern __shared__ __attribute__((aligned(16))) uint4 cb_lds[];
+    __shared__ uint32_t role, sh_len;
+    __shared__ float sh_ps;
+    const uint32_t info = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+    const uint32_t A = g.A, W2 = 2 * A, GPW = cb2_gpw(W2);
+    const Map ident{1.0f, 0.0f, rp_u2f(0xff800000u), 0u};
+    if (g.info_player[info] != p.walker) {  // not this walker's infoset: nothing happened to it
+        if (!APPLY && part == 0) {
+            if (tid < W2) {
+                Cell* cl = &cells[(size_t)info * A + tid % A];
+                if (tid < A) { cl->ra = ident.a; cl->rb = ident.b; cl->rm = ident.m; cl->rn = 0u; }
+                else { cl->wa = ident.a; cl->wb = ident.b; cl->wm = ident.m; cl->wn = 0u; }
+            } else if (tid == W2) {
+                sums[info] = InfoSum{0u, 0.0f};
+            }
+        }
+        return;
+    }
+    const uint32_t nb = (p.batch + RP_COMPOSE_CHUNK - 1) / RP_COMPOSE_CHUNK;  // one block per chunk of trees
+    const uint32_t ngrp = (nb + RP_FOLD_GROUP - 1) / RP_FOLD_GROUP, nparts = (ngrp + GPW - 1) / GPW;
+    if (part >= nparts) return;
+    const uint32_t g0 = part * GPW, b_lo = g0 * RP_FOLD_GROUP, b_hi = min(nb, (g0 + GPW) * RP_FOLD_GROUP), count = b_hi - b_lo;
+    uint4* tile = cb_lds;                                                                // [GPW * 64][W2] block maps
+    float* ps_t = reinterpret_cast<float*>(tile + (size_t)GPW * RP_FOLD_GROUP * W2);     // [GPW * 64]
+    uint32_t* cn_t = reinterpret_cast<uint32_t*>(ps_t + GPW * RP_FOLD_GROUP);            // [GPW * 64]
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(bmaps + ((size_t)info * nblk_max + b_lo) * W2);
+        for (uint32_t e = tid; e < count * W2; e += 256u) tile[e] = src[e];
+        for (uint32_t e = tid; e < count; e += 256u) {
+            ps_t[e] = bpsum[(size_t)info * nblk_max + b_lo + e];
+            cn_t[e] = bcnt[(size_t)info * nblk_max + b_lo + e];
+        }
+    }
+    __syncthreads();
+    if (tid < GPW * W2) {
+        const uint32_t s = tid / W2, c = tid % W2, grp = g0 + s;
+        if (grp < ngrp) {
+            const uint32_t lo = s * RP_FOLD_GROUP, hi = min(count, lo + RP_FOLD_GROUP);
             Map m = ident;
+            for (uint32_t b0 = lo; b0 < hi; b0 += 8u) {  // eight LDS reads in flight ahead of the dependent chain
+                uint4 v[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q) v[q] = tile[min(b0 + q, hi - 1u) * W2 + c];
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q)
+                    if (b0 + q < hi) m = map_compose(m, Map{rp_u2f(v[q].x), rp_u2f(v[q].y), rp_u2f(v[q].z), v[q].w});
+            }
+            st_map(&fs.gmaps[((size_t)info * fs.ngrp_max + grp) * W2 + c], m);
+        }
+    } else if (tid < GPW * W2 + GPW) {
+        const uint32_t s = tid - GPW * W2, grp = g0 + s;
+        if (grp < ngrp) {
+            const uint32_t lo = s * RP_FOLD_GROUP, hi = min(count, lo + RP_FOLD_GROUP);
             float gp = 0.0f;
             uint32_t gc = 0;
-            for (uint32_t b0 = b_lo; b0 < b_hi; b0 += CB_PF) {
-                const uint32_t cnt = min((uint32_t)CB_PF, b_hi - b0);
-                Map mm[CB_PF];
-                float pp[CB_PF];
-                uint32_t cc[CB_PF];
-#pragma unroll
-                for (uint32_t q = 0; q < CB_PF; ++q) {
-                    mm[q] = q < cnt ? src[(size_t)(b0 + q) * W2 + c] : ident;
-                    pp[q] = (c == 0 && q < cnt) ? psrc[b0 + q] : 0.0f;
-                    cc[q] = (c == 0 && q < cnt) ? csrc[b0 + q] : 0u;
-                }
-#pragma unroll
-                for (uint32_t q = 0; q < CB_PF; ++q) {
-                    if (q >= cnt) break;
-                    m = map_compose(m, mm[q]);
-                    gp += pp[q];
-                    gc += cc[q];
-                }
+            for (uint32_t b = lo; b < hi; ++b) {
+                gp += ps_t[b];
+                gc += cn_t[b];
             }
-            sup[s * W2 + c] = m;
-            if (c == 0) {
-                supp[s] = gp;
-                supc[s] = gc;
-            }
+            st_agent(reinterpret_cast<uint32_t*>(fs.gpsum) + (size_t)info * fs.ngrp_max + grp, rp_f2u(gp));
+            st_agent(fs.gcnt + (size_t)info * fs.ngrp_max + grp, gc);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the group maps are in memory before this part counts itself in
+    __syncthreads();
+    if (tid == 0) role = atomicAdd(&fs.done[info], 1u) == nparts - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!role) return;
+    if (tid == 0) fs.done[info] = 0;  // for the next launch
+    // the infoset's group maps: into LDS by all threads at once (one round trip), then folded in group order
+    Map tot = ident;
+    float ps = 0.0f;
+    uint32_t len = 0;
+    const uint32_t TILE_G = GPW * RP_FOLD_GROUP;
+    const uint32_t* gm = reinterpret_cast<const uint32_t*>(fs.gmaps + (size_t)info * fs.ngrp_max * W2);
+    for (uint32_t k0 = 0; k0 < ngrp; k0 += TILE_G) {
+        const uint32_t n = min(TILE_G, ngrp - k0);
+        __syncthreads();
+        for (uint32_t e = tid; e < n * W2; e += 256u) {
+            const uint32_t* w = gm + ((size_t)k0 * W2 + e) * 4u;
+            tile[e] = make_uint4(ld_agent(w), ld_agent(w + 1), ld_agent(w + 2), ld_agent(w + 3));
+        }
+        for (uint32_t e = tid; e < n; e += 256u) {
+            ps_t[e] = rp_u2f(ld_agent(reinterpret_cast<const uint32_t*>(fs.gpsum) + (size_t)info * fs.ngrp_max + k0 + e));
+            cn_t[e] = ld_agent(fs.gcnt + (size_t)info * fs.ngrp_max + k0 + e);
         }
         __syncthreads();
-        const uint32_t have = min(NS, ngrp - g0);
         if (tid < W2) {
-            for (uint32_t k = 0; k < have; ++k) tot = map_compose(tot, sup[k * W2 + tid]);
+            for (uint32_t k0b = 0; k0b < n; k0b += 8u) {
+                uint4 v[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q) v[q] = tile[min(k0b + q, n - 1u) * W2 + tid];
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q)
+                    if (k0b + q < n) tot = map_compose(tot, Map{rp_u2f(v[q].x), rp_u2f(v[q].y), rp_u2f(v[q].z), v[q].w});
+            }
         } else if (tid == W2) {
-            for (uint32_t k = 0; k < have; ++k) {
-                ps += supp[k];
-                len += supc[k];
+            for (uint32_t k = 0; k < n; ++k) {
+                ps += ps_t[k];
+                len += cn_t[k];
             }
         }
+    }
+    if (tid == W2) {
+        sh_ps = ps;
+        sh_len = len;
+    }
+    if (!APPLY) {
+        if (tid < W2) {
+            Cell* cl = &cells[(size_t)info * A + tid % A];
+            if (tid < A) { cl->ra = tot.a; cl->rb = tot.b; cl->rm = tot.m; cl->rn = tot.n; }
+            else { cl->wa = tot.a; cl->wb = tot.b; cl->wm = tot.m; cl->wn = tot.n; }
+        }
         __syncthreads();
+        if (tid == 0) sums[info] = InfoSum{sh_len, sh_ps};
+        return;
     }
-    if (tid < W2) {
-        Cell* cl = &cells[(size_t)info * A + tid % A];
-        if (tid < A) { cl->ra = tot.a; cl->rb = tot.b; cl->rm = tot.m; cl->rn = tot.n; }
-        else { cl->wa = tot.a; cl->wb = tot.b; cl->wm = tot.m; cl->wn = tot.n; }
-    } else if (tid == W2) {
-        sums[info] = InfoSum{len, ps};
+    // k_fold, world = 1, for this infoset's row
+    __syncthreads();
+    const uint32_t nact = g.info_actions[info];
+    if (tid < W2 && tid % A < nact) {
+        const uint32_t cell = info * A + tid % A;
+        if (tid < A) {
+            float r = t.regret[cell];
+            if (tot.n) r = rp_maxf(tot.a * r + tot.b, tot.m);
+            t.regret[cell] = r;
+            float ev = t.payoff[cell];
+            uint32_t visits = t.visits[cell];
+            if (sh_len) {
+                const uint32_t n2 = visits + sh_len;
+                ev = ev + (sh_ps - (float)sh_len * ev) / (float)n2;
+                visits = n2;
+            }
+            t.payoff[cell] = ev;
+            t.visits[cell] = visits;
+        } else {
+            float w = t.weight[cell];
+            if (tot.n) w = rp_maxf(tot.a * w + tot.b, tot.m);
+            t.weight[cell] = w;
+        }
     }
+    __syncthreads();  // workgroup scope: the row just written is what prepare_one reads
+    if (tid == 0) prepare_one(g, t, p, it, info);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1558,6 +1668,8 @@ struct rp_mccfr {
     uint32_t maxdec = 1;
     rp_update_mode mode = RP_UPDATE_ORDERED;
     bool use_lds_traverse = false;
+    // the per-infoset tables of the traversal (DevInfoTab) are a function of the regret/strategy tables: refreshed when stale
+    uint64_t tables_version = 1, itab_version = 0;
     bool fuse_maps = true;  // composed update: traversal + block maps in one kernel when the game allows (RP_TRAV_UNFUSED=1: never)
     int static_skel = 0;  // 0: none (k_traverse_lds / k_traverse), 1: KuhnSkel, 2: LeducSkel (traverse_static.hpp)
     bool profiling = false;
@@ -1684,7 +1796,12 @@ int alloc_batch_buffers(rp_mccfr* h, uint32_t batch) {
     if (h->d_bmaps) HIP_TRY(hipFree(h->d_bmaps));
     h->d_bmaps = nullptr;
     const size_t nblk_max = (stride + RP_COMPOSE_CHUNK - 1) / RP_COMPOSE_CHUNK;
-    HIP_TRY(hipMalloc(&h->d_bmaps, (size_t)h->tbl.n_infos * nblk_max * (2 * A * sizeof(Map) + sizeof(float) + sizeof(uint32_t))));
+    // ... followed by the group maps and the arrival counters of k_combine2
+    const size_t ngrp_max = (nblk_max + RP_FOLD_GROUP - 1) / RP_FOLD_GROUP;
+    const size_t per_slot = 2 * A * sizeof(Map) + sizeof(float) + sizeof(uint32_t);
+    const size_t bytes = (size_t)h->tbl.n_infos * (nblk_max + ngrp_max) * per_slot + (size_t)h->tbl.n_infos * sizeof(uint32_t);
+    HIP_TRY(hipMalloc(&h->d_bmaps, bytes));
+    HIP_TRY(hipMemset(h->d_bmaps, 0, bytes));
     h->capacity = batch;
     return RP_OK;
 }
@@ -1775,11 +1892,19 @@ bool traverse_fits_lds(const rp_mccfr* h) {
            traverse_lds_bytes(h) <= 64 * 1024;
 }
 
+// k_prepare_infos, unless the tables have not changed since the per-infoset tables were last derived from them (an exchange
+// window traverses against a frozen table; k_combine2<APPLY> refreshes the rows it changes itself)
+void launch_prepare(rp_mccfr* h, const StepParams& p) {
+    if (h->itab_version == h->tables_version) return;
+    hipLaunchKernelGGL(k_prepare_infos, dim3((h->tbl.n_infos + 63) / 64), dim3(64), 0, h->stream, h->g, h->t, p, h->itab);
+    h->itab_version = h->tables_version;
+}
+
 int launch_traverse(rp_mccfr* h, const StepParams& p) {
     if (h->dc.slotmap) HIP_TRY(hipMemsetAsync(h->dc.slotmap, 0, (size_t)h->tbl.n_infos * h->dc.stride, h->stream));
     clock_begin(h, h->clk_traverse);
     if (h->static_skel && p.S == RP_SAMPLING_EXTERNAL) {
-        hipLaunchKernelGGL(k_prepare_infos, dim3((h->tbl.n_infos + 63) / 64), dim3(64), 0, h->stream, h->g, h->t, p, h->itab);
+        launch_prepare(h, p);
         const dim3 grid((h->batch + 255) / 256), block(256);
 #define LAUNCH_STATIC(G, WK) hipLaunchKernelGGL((k_traverse_static<G, WK>), grid, block, 0, h->stream, h->g, h->itab, h->dc, p)
         if (h->static_skel == 1) {
@@ -1791,7 +1916,7 @@ int launch_traverse(rp_mccfr* h, const StepParams& p) {
         }
 #undef LAUNCH_STATIC
     } else if (h->use_lds_traverse) {
-        hipLaunchKernelGGL(k_prepare_infos, dim3((h->tbl.n_infos + 63) / 64), dim3(64), 0, h->stream, h->g, h->t, p, h->itab);
+        launch_prepare(h, p);
         const size_t lds = traverse_lds_bytes(h);
         const dim3 grid((h->batch + 63) / 64), block(64);
         const bool tvreg = h->tbl.max_actions <= 4, tablds = traverse_tables_in_lds(h);
@@ -1868,7 +1993,8 @@ bool traverse_maps_fused(const rp_mccfr* h) {
            traverse_maps_lds_bytes(h) <= 64 * 1024 && h->fuse_maps;
 }
 
-int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev, bool fused = false) {
+// apply = true: the summary is applied to the tables by the fold itself (single-GPU step), `blob_dev` is not written
+int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev, bool fused = false, bool apply = false) {
     unsigned char* blob = reinterpret_cast<unsigned char*>(blob_dev);
     Cell* cells = reinterpret_cast<Cell*>(blob);
     InfoSum* sums = reinterpret_cast<InfoSum*>(blob + (size_t)h->tbl.n_infos * h->tbl.max_actions * sizeof(Cell));
@@ -1881,7 +2007,7 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev, bool fuse
     const bool pruned = h->S != RP_SAMPLING_EXTERNAL;
     if (fused) {
         clock_begin(h, h->clk_traverse);
-        hipLaunchKernelGGL(k_prepare_infos, dim3((h->tbl.n_infos + 63) / 64), dim3(64), 0, h->stream, h->g, h->t, p, h->itab);
+        launch_prepare(h, p);
         const size_t lds = traverse_maps_lds_bytes(h);
 #define LAUNCH_FUSED(G, WK) \
     hipLaunchKernelGGL((k_traverse_maps_static<G, WK>), dim3(nblk), dim3(256), lds, h->stream, h->g, h->itab, p, bmaps, bpsum, bcnt, nblk_max, h->maxdec)
@@ -1912,19 +2038,38 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev, bool fuse
     } else {
         hipLaunchKernelGGL((k_block_maps<false>), dim3(nblk, h->tbl.n_infos), dim3(128), 0, h->stream, h->g, h->so, p, bmaps, bpsum, bcnt, nblk_max);
     }
-    hipLaunchKernelGGL(k_combine, dim3(h->tbl.n_infos), dim3(256), 0, h->stream, h->g, p, bmaps, bpsum, bcnt, nblk_max, cells, sums);
+    {
+        const uint32_t W2 = 2 * A, GPW = cb2_gpw(W2);
+        const size_t ngrp_max = (nblk_max + RP_FOLD_GROUP - 1) / RP_FOLD_GROUP, gslots = (size_t)h->tbl.n_infos * ngrp_max;
+        FoldScratch fs;
+        fs.gmaps = reinterpret_cast<Map*>(bcnt + slots);
+        fs.gpsum = reinterpret_cast<float*>(fs.gmaps + gslots * W2);
+        fs.gcnt = reinterpret_cast<uint32_t*>(fs.gpsum + gslots);
+        fs.done = fs.gcnt + gslots;
+        fs.ngrp_max = (uint32_t)ngrp_max;
+        const uint32_t ngrp = (nblk + RP_FOLD_GROUP - 1) / RP_FOLD_GROUP, nparts = (ngrp + GPW - 1) / GPW;
+        const size_t lds = (size_t)GPW * RP_FOLD_GROUP * (W2 * 16 + 8);
+        const dim3 grid(h->tbl.n_infos, std::max(nparts, 1u));
+        if (apply) {
+            hipLaunchKernelGGL((k_combine2<true>), grid, dim3(256), lds, h->stream, h->g, h->t, h->itab, p, bmaps, bpsum, bcnt, nblk_max, fs, cells, sums);
+            h->tables_version += 1;  // the kernel refreshes the rows of the per-infoset tables it changes
+            if (h->itab_version + 1 == h->tables_version) h->itab_version = h->tables_version;
+        } else {
+            hipLaunchKernelGGL((k_combine2<false>), grid, dim3(256), lds, h->stream, h->g, h->t, h->itab, p, bmaps, bpsum, bcnt, nblk_max, fs, cells, sums);
+        }
+    }
     clock_end(h, h->clk_update);
     HIP_TRY(hipGetLastError());
     return RP_OK;
 }
 
 // Solver::batch + the composed maps of its Decisions -> one summary blob
-int launch_batch_summary(rp_mccfr* h, const StepParams& p, void* blob_dev) {
-    if (traverse_maps_fused(h)) return launch_summarize(h, p, blob_dev, true);
+int launch_batch_summary(rp_mccfr* h, const StepParams& p, void* blob_dev, bool apply = false) {
+    if (traverse_maps_fused(h)) return launch_summarize(h, p, blob_dev, true, apply);
     int rc = launch_traverse(h, p);
     if (rc) return rc;
     if (h->dc.slotmap && (rc = launch_sort(h, p))) return rc;
-    return launch_summarize(h, p, blob_dev);
+    return launch_summarize(h, p, blob_dev, false, apply);
 }
 
 int enqueue_step(rp_mccfr* h) {
@@ -1936,12 +2081,10 @@ int enqueue_step(rp_mccfr* h) {
         if ((rc = launch_traverse(h, p))) return rc;
         if ((rc = launch_sort(h, p))) return rc;
         if ((rc = launch_chain(h, p))) return rc;
+        h->tables_version += 1;
     } else {
-        if ((rc = launch_batch_summary(h, p, h->d_summary))) return rc;
-        const uint32_t ncell = h->tbl.n_infos * h->tbl.max_actions;
-        hipLaunchKernelGGL(k_fold, dim3((ncell + 255) / 256), dim3(256), 0, h->stream, h->g, h->t,
-                           reinterpret_cast<const unsigned char*>(h->d_summary), summary_bytes_of(h), 1u);
-        HIP_TRY(hipGetLastError());
+        // the fold applies the summary to the tables itself (k_combine2<APPLY>: fold + k_fold + k_prepare_infos in one launch)
+        if ((rc = launch_batch_summary(h, p, h->d_summary, true))) return rc;
     }
     h->epoch += 1;  // CfrSampling::increment via Solver::advance (solver.rs:103-104)
     return RP_OK;
@@ -2305,6 +2448,7 @@ int rp_mccfr_set(rp_mccfr* h, uint32_t info, uint32_t edge, const rp_encounter* 
     HIP_TRY(hipMemcpyAsync(h->t.payoff + c, &in->payoff, 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->t.visits + c, &in->visits, 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    h->tables_version += 1;
     return RP_OK;
 }
 
@@ -2337,6 +2481,7 @@ int rp_mccfr_import(rp_mccfr* h, const rp_encounter* rows, uint64_t n, uint64_t 
     HIP_TRY(hipMemcpy(h->t.weight, w.data(), cells * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->t.payoff, p.data(), cells * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->t.visits, v.data(), cells * 4, hipMemcpyHostToDevice));
+    h->tables_version += 1;
     h->epoch = epoch;
     return RP_OK;
 }
@@ -2455,6 +2600,7 @@ int rp_mccfr_step_apply(rp_mccfr* h, const void* gathered_dev, uint32_t world) {
     hipLaunchKernelGGL(k_fold, dim3((ncell + 255) / 256), dim3(256), 0, h->stream, h->g, h->t,
                        reinterpret_cast<const unsigned char*>(gathered_dev), summary_bytes_of(h), world);
     HIP_TRY(hipGetLastError());
+    h->tables_version += 1;
     h->epoch += 1;
     return RP_OK;
 }
@@ -2487,6 +2633,7 @@ int rp_mccfr_window_apply(rp_mccfr* h, const void* gathered_dev, uint32_t world)
     hipLaunchKernelGGL(k_fold, dim3((ncell + 255) / 256), dim3(256), 0, h->stream, h->g, h->t,
                        reinterpret_cast<const unsigned char*>(gathered_dev), summary_bytes_of(h), world);
     HIP_TRY(hipGetLastError());
+    h->tables_version += 1;
     return RP_OK;
 }
 
