@@ -44,8 +44,10 @@ def parse():
                     help="leduc: BASELINE configs[1] (default, the quoted metric); nlhe: the blueprint trainer's own step — "
                          "external-sampling MCCFR over heads-up NLHE generated on the device (rp_nlhe_*, BASELINE configs[3] on "
                          "one GPU); nlhe-synth: synthetic NLHE-scale infoset batches through the sparse profile (SURVEY §8d config 4)")
-    ap.add_argument("--nlhe-batch", type=int, default=16384, help="nlhe: trees per step (the reference's batch_size is 128)")
-    ap.add_argument("--nlhe-cap", type=int, default=24, help="nlhe: log2 of the infoset table's rows")
+    ap.add_argument("--nlhe-batch", type=int, default=262144,
+                    help="nlhe: trees per step per GPU (the reference's batch_size is 128; one lane per tree needs >= 131072 "
+                         "trees to put two wavefronts on every SIMD; 68 GB of per-tree scratch at the default)")
+    ap.add_argument("--nlhe-cap", type=int, default=27, help="nlhe: log2 of the infoset table's rows")
     ap.add_argument("--rows", type=int, default=1 << 27, help="nlhe-synth: table rows (infoset slots)")
     ap.add_argument("--decisions", type=int, default=128 * 1500, help="nlhe-synth: Decisions per step per GPU")
     ap.add_argument("--game", default="leduc", choices=["leduc", "kuhn", "rps", "leduc_wide"])
@@ -475,7 +477,8 @@ def timed_mccfr(args, g, batch, rank, world, local_rank, sharded_mode, torch, di
     fence()
     dt = time.perf_counter() - t0
     _, infos1 = solver.counters()
-    out = {"infos_local": infos1 - infos0, "infos": infos1 - infos0, "dt": dt, "batch": batch}
+    out = {"infos_local": infos1 - infos0, "infos": infos1 - infos0, "dt": dt, "batch": batch,
+           "variant": solver.kernel_variant() + ("+maps fused" if args.update == "composed" and solver.kernel_variant() == "static" else "")}
     # per-kernel durations for the roofline: the same K steps again with a HIP event pair around every kernel group on the
     # launch stream (the event packets cost a few microseconds per launch, so they stay out of the timed region above)
     solver.profile(True)
@@ -728,9 +731,13 @@ def main():
                 "bytes_per_update": bytes_per_update, "updates_per_launch": per_launch_updates,
                 "avg_launch_ms": dom_ms,
                 "kernels_ms": {"traverse": trav_avg_ms, "compact": m["compact_ms"], "update": upd_avg_ms},
-                "note": "Leduc's tables are 3.8 KB (L2/LDS resident): HBM is not the binding limit of this "
-                        "configuration (SURVEY §8d); traversal is latency/divergence bound, the ordered update "
-                        "by its serial per-cell chains",
+                "traversal_kernel": m.get("variant"),
+                "note": "achieved = SURVEY §8d's 24 + 32 A bytes per infoset-update x the updates of one launch / the "
+                        "dominant kernel's event-timed duration.  Leduc's tables are 3.8 KB (L2 resident) and in the "
+                        "composed mode the Decisions never reach HBM (traversal + block maps are one kernel: PMC traffic is "
+                        "far BELOW the algorithmic bytes), so HBM is not the binding limit of this configuration: the "
+                        "skeleton-instantiated traversal is bound by VALU issue (profiles/: SQ counters), the ordered "
+                        "update by its serial per-cell chains",
             },
             "other_update_mode": {"update": other, "value": other_rate, "unit": "infoset-updates/s"},
         }
