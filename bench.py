@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1 << 20, help="trees per step per GPU (Solver::batch_size)")
+    ap.add_argument("--batch", type=int, default=1 << 23,
+                    help="trees per step (Solver::batch_size): per GPU under weak scaling, in total under strong scaling")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
                     help="strong (default for N > 1): --batch trees per step in TOTAL, split across the GPUs (north_star's "
                          "strong-scaling figure); weak (N = 1, or on request): --batch trees per step on EVERY GPU.  With "
@@ -69,9 +70,10 @@ def parse():
                     help="k-means measurement in the `kmeans` object: the FULL flop-street configuration (default: BASELINE "
                          "configs[2], 1 286 792 x 32 Elkan iterations with k-means++, init_bounds and lookup, ~1.5 min), one "
                          "GPU's share of configs[4] (turn), or a bounded flop-layer slice (~10 s)")
-    ap.add_argument("--window", type=int, default=1,
+    ap.add_argument("--window", type=int, default=None,
                     help="N > 1: local steps per exchange (the composed maps of `window` consecutive steps are folded "
-                         "locally and all-gathered once; 1 = exchange every step)")
+                         "locally and all-gathered once; 1 = exchange every step).  Default: 4 on several GPUs (the periodic "
+                         "exchange of north_star), 1 otherwise")
     ap.add_argument("--comm", default="native", choices=["native", "torch"],
                     help="N > 1: the library's own RCCL communicator driven from C (rp_mccfr_step_comm), or torch.distributed "
                          "collectives driven from Python")
@@ -107,13 +109,29 @@ def cpu_baseline(args):
     }
 
 
+def host_cores():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU boxes show 256
+    logical CPUs under a 16-core quota; more threads than that only get throttled)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline_all_cores(args, seconds=4.0):
     """The CPU port in the reference's parallel structure: ONE process, tree-parallel batch() on every
-    physical core (rayon -> OpenMP: ora_mccfr_step_mt), then the sequential update on one thread; median of 3 runs."""
+    core the process may use (rayon -> OpenMP: ora_mccfr_step_mt; host_cores), then the sequential update on one thread; median of 3 runs."""
     import oracle
     from robopoker_amd import Game
 
-    threads = max(1, (os.cpu_count() or 2) // 2)
+    threads = host_cores()
     if threads < 2:
         return None
     g = Game(args.game)
@@ -156,11 +174,15 @@ def profiled_traffic(group, batch):
     doc = json.load(open(files[-1]))
     if doc.get("batch") != batch or doc.get("update", "ordered") != group[1]:
         return None, os.path.basename(files[-1])
-    total = 0.0
+    # a step launches ONE instantiation of a templated kernel (the walker alternates): average over the instances of a
+    # kernel name, add up the different kernels of the group
+    per_name = {}
     for name, v in doc["kernels"].items():
         if any(k in name for k in KERNEL_GROUPS[group[0]]):
-            total += v["hbm_bytes_per_launch"]
-    return total, os.path.basename(files[-1])
+            base = name.split("(")[0].split("<")[0].replace("void ", "")
+            per_name.setdefault(base, []).append(v["hbm_bytes_per_launch"])
+    total = sum(sum(v) / len(v) for v in per_name.values())
+    return (total if per_name else None), os.path.basename(files[-1])
 
 
 def side_rate(args, g, local_rank, mode, steps=10):
@@ -273,7 +295,7 @@ def kmeans_secondary(args):
         out["cpu_baseline"] = lloyd.cpu_baseline_slice(oracle, seconds=min(args.cpu_seconds, 8.0))
         if centroids is not None:
             try:
-                out["cpu_baseline_all_cores"] = lloyd.cpu_baseline_full(oracle, out, centroids)
+                out["cpu_baseline_all_cores"] = lloyd.cpu_baseline_full(oracle, out, centroids, threads=host_cores())
             except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
                 out["cpu_baseline_all_cores"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
@@ -653,6 +675,8 @@ def main():
     args.gpus = world
     if args.scaling is None:
         args.scaling = "strong" if world > 1 else "weak"
+    if args.window is None:
+        args.window = 4 if world > 1 else 1
     if args.workload == "nlhe-synth":
         return nlhe_synth(args, rank, world, local_rank)
     if args.workload == "nlhe":

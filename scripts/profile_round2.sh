@@ -7,6 +7,7 @@
 #   4 MFMA / issue counters of k_sinkhorn_bound on a slice                         -> r02_mfma_bound_counters.txt
 #   5 FETCH_SIZE / WRITE_SIZE of the Elkan bound update at full N                  -> r02_lloyd_bounds_hbm_traffic.txt
 #   6 kernel-trace stats of the NLHE traversal step                                -> r02_nlhe_kernel_stats.txt
+#   2b SQ issue / wait / lane counters of the MCCFR kernels                        -> r02_mccfr_sq_counters.txt
 set -u
 TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -21,7 +22,10 @@ grep -o '{"metric.*' $OUT/kt.log > $OUT/${TAG}_bench_line_under_rocprof.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o pmc -- $BENCH > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o pmc -- $BENCH > $OUT/write.log 2>&1
 python $REPO/scripts/pmc_traffic.py $OUT/fetch/pmc_counter_collection.csv $OUT/write/pmc_counter_collection.csv \
-    $OUT/${TAG}_mccfr_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of: $BENCH; FETCH_SIZE doubled (gfx950), KiB -> bytes" 1048576 composed > /dev/null
+    $OUT/${TAG}_mccfr_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of: $BENCH; FETCH_SIZE doubled (gfx950), KiB -> bytes" 8388608 composed > /dev/null
+# 2b: SQ issue / wait / lane counters of the same command (two more passes)      -> r02_mccfr_sq_counters.txt
+( cd $REPO && bash scripts/pmc_sq.sh ${TAG}mccfr $BENCH ) > $OUT/sq.log 2>&1
+{ echo "# scripts/pmc_sq.sh: rocprofv3 --pmc <two passes> --kernel-trace of: $BENCH  (sums over all dispatches of each kernel)"; grep -E "^(void )?rp::" $OUT/sq.log; } > $OUT/${TAG}_mccfr_sq_counters.txt
 # 3: the full flop configuration
 FK="python $REPO/scripts/full_kmeans.py flop 32"
 rocprofv3 --kernel-trace --stats -d $OUT/kl -o kl -- $FK > $OUT/${TAG}_full_flop_kmeans.json 2> $OUT/kl.log
@@ -71,7 +75,7 @@ for f, c, mul in (("$OUT/bf/pmc_counter_collection.csv", "FETCH_SIZE", 2.0), ("$
     for k in tot: print(c, k, len(n[k]), "launches", f"{tot[k] / len(n[k]) * 1024 * mul / 1e9:.3f} GB per launch")
 PY
 # 6: the NLHE traversal
-NL="python $REPO/bench.py --workload nlhe --steps 6 --warmup 1 --cpu-seconds 0"
+NL="python $REPO/bench.py --workload nlhe --steps 3 --warmup 1 --cpu-seconds 0"
 rocprofv3 --kernel-trace --stats -d $OUT/kn -o kn -- $NL > $OUT/kn.log 2>&1
 python $REPO/scripts/rocpd_summary.py $(ls $OUT/kn/*.db | head -1) $OUT/${TAG}_nlhe_kernel_stats.txt "$NL" > /dev/null
 grep -o '{"metric.*' $OUT/kn.log > $OUT/${TAG}_nlhe_bench_line.json
