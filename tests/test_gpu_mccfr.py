@@ -145,6 +145,22 @@ def test_fused_traversal_and_block_maps_equal_the_unfused_kernels_and_the_oracle
     assert fused.counters() == unfused.counters() == generic.counters() == ora.counters()
 
 
+def test_bench_sized_composed_step_equals_the_oracle(gpu):
+    # bench.py's default step (2^23 trees) and a little more: 36 865 chunks = 577 groups of RP_FOLD_GROUP block maps per
+    # infoset, i.e. 73 parts per infoset in k_combine2 and a final fold that runs through more than one LDS tile of group
+    # maps, a ragged last chunk.  Both walkers, bit for bit against the oracle's blocked composition.
+    g = Game("leduc")
+    batch = (1 << 23) + (1 << 20) + 77
+    dev = Solver(g, "floored", "linear", "external", batch=batch, seed=2026)
+    dev.set_update_mode("composed")
+    ora = oracle.OracleSolver(g, "floored", "linear", "external", batch=batch, seed=2026)
+    for _ in range(2):
+        dev.step()
+        ora.step_world(1)
+        assert_tables_equal(dev.export(), ora.export())
+    assert dev.counters() == ora.counters() and dev.kernel_variant() == "static"
+
+
 @pytest.mark.parametrize("mode", ["ordered", "composed"])
 @pytest.mark.parametrize("overrides", [
     dict(temperature=0.5, smoothing=0.25, curiosity=0.2),         # sampling distribution far from the defaults
