@@ -150,9 +150,24 @@ __device__ __forceinline__ uint64_t nl_draw(uint64_t deck, int k, const NlParams
     uint64_t out = 0;
     for (int c = 0; c < k; ++c) {
         const uint32_t pick = rp_pick_uniform(rp_node_hash(p.seed, p.epoch, tree, key + (uint64_t)c), (uint32_t)__popcll(deck));
-        uint64_t d = deck;
-        for (uint32_t s = 0; s < pick; ++s) d &= d - 1;
-        const uint64_t card = d & (~d + 1);
+        // the pick-th lowest card of the deck: a popcount search (a loop clearing `pick` bits runs up to 51 rounds at the few
+        // lanes of a wavefront that sit at a chance node)
+        uint32_t k = pick, w = (uint32_t)deck, base = 0;
+        const uint32_t plo = (uint32_t)__popc(w);
+        if (k >= plo) {
+            k -= plo;
+            w = (uint32_t)(deck >> 32);
+            base = 32;
+        }
+#pragma unroll
+        for (uint32_t half = 16; half >= 1; half >>= 1) {
+            const uint32_t c = (uint32_t)__popc(w & ((1u << half) - 1u));
+            const bool up = k >= c;
+            k -= up ? c : 0u;
+            w = up ? w >> half : w & ((1u << half) - 1u);
+            base += up ? half : 0u;
+        }
+        const uint64_t card = 1ull << base;
         out |= card;
         deck &= ~card;
     }
