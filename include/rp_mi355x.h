@@ -63,6 +63,12 @@ RP_API int rp_math_selftest(int device, uint64_t n, const float* x, const float*
  * contract's spec sequence (rp_expf_spec): mismatches[0] rp_expf, [1] rp_exp_floor vs max(spec, MIN_POSITIVE),
  * [2] rp_exp_floor2 (packed), [3] smallest mismatching bit pattern (~0 if none).  All counts must be 0. */
 RP_API int rp_math_exp_sweep(int device, uint64_t* mismatches);
+/* The device-wide primitives under the row-addressed profile and the isomorphism enumeration (csrc/sortscan.hpp: stable LSD
+ * radix sort of (key, index) pairs by the low `bits` bits of the key, run-length encoding of the sorted keys, exclusive
+ * scan), run on n host keys so a test can compare them with a host sort: sorted_keys / perm [n]; uniq / starts / counts
+ * [n] of which the first *n_runs are set; scan[i] = sum of keys[0..i) as u64. */
+RP_API int rp_sortscan_selftest(int device, uint32_t n, uint32_t bits, const uint32_t* keys, uint32_t* sorted_keys, uint32_t* perm,
+                                uint32_t* uniq, uint32_t* starts, uint32_t* counts, uint32_t* n_runs, uint64_t* scan);
 
 /* ======================================================================= mccfr ==
  * crates/mccfr: Solver (solver/solver.rs:38-351), RefProf/MutProf/CfrSampling

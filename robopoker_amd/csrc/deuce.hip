@@ -20,7 +20,7 @@
 //    in that order, so Lookup::lookup is a binary search over u64 and Lookup::projections is one wavefront per
 //    observation, one lane per revealed card.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include "sortscan.hpp"
 
 #include <vector>
 
@@ -415,10 +415,8 @@ int rp_isomorphisms(int device, int street, uint32_t pocket_lo, uint32_t pocket_
     hipLaunchKernelGGL((k_enumerate<false>), dim3((unsigned)blocks), dim3(EN_THREADS), 0, nullptr, a, dbn.as<Binom>(), counts.as<uint32_t>(),
                        (const uint64_t*)nullptr, (int64_t*)nullptr, (uint64_t)0);
     HIP_TRY(hipGetLastError());
-    size_t tb = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, counts.as<uint32_t>(), offs.as<uint64_t>(), (int)blocks, nullptr));
-    HIP_TRY(tmp.alloc(tb));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, counts.as<uint32_t>(), offs.as<uint64_t>(), (int)blocks, nullptr));
+    HIP_TRY(tmp.alloc(ss::scan_scratch_bytes(blocks)));
+    HIP_TRY(ss::exclusive_scan<uint64_t>(counts.as<uint32_t>(), offs.as<uint64_t>(), (uint32_t)blocks, tmp.p, nullptr));
     uint64_t last_off = 0;
     uint32_t last_cnt = 0;
     HIP_TRY(hipMemcpy(&last_off, offs.as<uint64_t>() + (blocks - 1), 8, hipMemcpyDeviceToHost));

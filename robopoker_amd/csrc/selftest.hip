@@ -1,8 +1,12 @@
 // selftest.hip — device-side evaluation of the arithmetic contract (include/rp_math.h) for parity tests.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "../../include/rp_math.h"
 #include "rp_internal.h"
+#include "sortscan.hpp"
 
 namespace rp {
 __global__ void k_math_selftest(uint64_t n, const float* x, const float* y, float* out) {
@@ -85,5 +89,63 @@ extern "C" int rp_math_exp_sweep(int device, uint64_t* mismatches) {
     ST_TRY(hipMemcpy(out, d, sizeof(out), hipMemcpyDeviceToHost));
     (void)hipFree(d);
     for (int i = 0; i < 4; ++i) mismatches[i] = out[i];
+    return RP_OK;
+}
+
+// the device-wide primitives of csrc/sortscan.hpp on host arrays: stable sort of (key, index) pairs by the low `bits` bits,
+// run-length encoding of the sorted keys, 64-bit exclusive scan of the keys
+extern "C" int rp_sortscan_selftest(int device, uint32_t n, uint32_t bits, const uint32_t* keys, uint32_t* sorted_keys, uint32_t* perm,
+                                    uint32_t* uniq, uint32_t* starts, uint32_t* counts, uint32_t* n_runs, uint64_t* scan) {
+    if (!keys || !sorted_keys || !perm || !uniq || !starts || !counts || !n_runs || !scan)
+        return rp::fail(RP_ERR_INVALID, "rp_sortscan_selftest: NULL argument");
+    if (rp_device_count() <= 0) return rp::fail(RP_ERR_NO_DEVICE, "rp_sortscan_selftest: no HIP device visible");
+#define SS_TRY(expr)                                                                                    \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            for (void* q : bufs) (void)hipFree(q);                                                      \
+            return rp::fail(RP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));                 \
+        }                                                                                               \
+    } while (0)
+    std::vector<void*> bufs;
+    SS_TRY(hipSetDevice(device));
+    const size_t m = std::max<uint32_t>(n, 1);
+    uint32_t *dk, *di, *dko, *dpo, *du, *ds, *dc, *dn, *dw;
+    uint64_t* dscan;
+    void *tmp, *stmp;
+    auto dalloc = [&](void** q, size_t bytes) {
+        hipError_t e = hipMalloc(q, bytes);
+        if (e == hipSuccess) bufs.push_back(*q);
+        return e;
+    };
+    SS_TRY(dalloc((void**)&dk, m * 4));
+    SS_TRY(dalloc((void**)&di, m * 4));
+    SS_TRY(dalloc((void**)&dko, m * 4));
+    SS_TRY(dalloc((void**)&dpo, m * 4));
+    SS_TRY(dalloc((void**)&du, m * 4));
+    SS_TRY(dalloc((void**)&ds, m * 4));
+    SS_TRY(dalloc((void**)&dc, m * 4));
+    SS_TRY(dalloc((void**)&dn, 4));
+    SS_TRY(dalloc((void**)&dw, m * 4));
+    SS_TRY(dalloc((void**)&dscan, m * 8));
+    SS_TRY(dalloc(&tmp, rp::ss::sort_scratch_bytes((uint32_t)m)));
+    SS_TRY(dalloc(&stmp, rp::ss::scan_scratch_bytes(m)));
+    std::vector<uint32_t> iota(m);
+    for (size_t i = 0; i < m; ++i) iota[i] = (uint32_t)i;
+    SS_TRY(hipMemcpy(dk, keys, (size_t)n * 4, hipMemcpyHostToDevice));
+    SS_TRY(hipMemcpy(di, iota.data(), m * 4, hipMemcpyHostToDevice));
+    SS_TRY(rp::ss::sort_pairs(dk, di, dko, dpo, n, bits, tmp, nullptr));
+    SS_TRY(rp::ss::run_length_encode(dko, n, du, ds, dc, dn, dw, stmp, nullptr));
+    SS_TRY(rp::ss::exclusive_scan<uint64_t>(dk, dscan, n, stmp, nullptr));
+    SS_TRY(hipDeviceSynchronize());
+    SS_TRY(hipMemcpy(sorted_keys, dko, (size_t)n * 4, hipMemcpyDeviceToHost));
+    SS_TRY(hipMemcpy(perm, dpo, (size_t)n * 4, hipMemcpyDeviceToHost));
+    SS_TRY(hipMemcpy(n_runs, dn, 4, hipMemcpyDeviceToHost));
+    SS_TRY(hipMemcpy(uniq, du, (size_t)n * 4, hipMemcpyDeviceToHost));
+    SS_TRY(hipMemcpy(starts, ds, (size_t)n * 4, hipMemcpyDeviceToHost));
+    SS_TRY(hipMemcpy(counts, dc, (size_t)n * 4, hipMemcpyDeviceToHost));
+    SS_TRY(hipMemcpy(scan, dscan, (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (void* q : bufs) (void)hipFree(q);
+#undef SS_TRY
     return RP_OK;
 }

@@ -10,11 +10,11 @@
 // encode; then a group of 16 lanes owns one row — lane a owns action a's four cells, so a row is loaded and stored
 // with coalesced dwords — and walks the row's touches in order.  Four rows per wavefront.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <string>
 #include <vector>
 
+#include "sortscan.hpp"
 #include "mccfr_kernels.hpp"
 
 namespace rp {
@@ -623,8 +623,8 @@ struct rp_profile {
     uint32_t* hot = nullptr;           // [HOT_CAP + 1] rows with more than RP_FOLD_GROUP blocks; last slot = counter
     float *srt_regret = nullptr, *srt_policy = nullptr, *srt_payoff = nullptr;  // the batch in sorted order (ordered mode)
     uint16_t* srt_expanded = nullptr;
-    void* cub_tmp = nullptr;
-    size_t cub_bytes = 0;
+    void* sort_tmp = nullptr;
+    size_t sort_bytes = 0;
     unsigned char* entries = nullptr;  // local composed apply
     bool profiling = false;
     SpClock clk_sort, clk_apply;
@@ -668,7 +668,7 @@ static void sp_drain(SpClock& c) {
 static void free_workspace(rp_profile* h) {
     for (void* p : {(void*)h->iota, (void*)h->keys_out, (void*)h->perm, (void*)h->seg_rows, (void*)h->seg_counts,
                     (void*)h->seg_offsets, (void*)h->ent_rows, (void*)h->nblk, (void*)h->boff, (void*)h->blocks, (void*)h->blkseg,
-                    h->cub_tmp,
+                    h->sort_tmp,
                     (void*)h->entries, (void*)h->srt_regret, (void*)h->srt_policy, (void*)h->srt_payoff,
                     (void*)h->srt_expanded})
         if (p) (void)hipFree(p);
@@ -677,7 +677,7 @@ static void free_workspace(rp_profile* h) {
     h->blkseg = nullptr;
     h->srt_regret = h->srt_policy = h->srt_payoff = nullptr;
     h->srt_expanded = nullptr;
-    h->cub_tmp = nullptr;
+    h->sort_tmp = nullptr;
     h->entries = nullptr;
     h->cap = 0;
 }
@@ -704,12 +704,9 @@ static int ensure_capacity(rp_profile* h, uint32_t n) {
     HIP_TRY(hipMalloc(&h->boff, (size_t)cap * 4));
     HIP_TRY(hipMalloc(&h->blocks, (size_t)max_blocks_of(cap) * entry_bytes_of(h)));
     HIP_TRY(hipMalloc(&h->blkseg, (size_t)max_blocks_of(cap) * 4));
-    size_t s1 = 0, s2 = 0, s3 = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, s1, h->iota, h->keys_out, h->iota, h->perm, (int)cap, 0, 32, h->stream));
-    HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, s2, h->keys_out, h->seg_rows, h->seg_counts, h->n_segs, (int)cap, h->stream));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, s3, h->seg_counts, h->seg_offsets, (int)cap, h->stream));
-    h->cub_bytes = std::max(s1, std::max(s2, s3));
-    HIP_TRY(hipMalloc(&h->cub_tmp, h->cub_bytes));
+    // scratch of the sort (histograms, their scan, one ping-pong pair) + the run-length encoding's n flag words
+    h->sort_bytes = ss::sort_scratch_bytes(cap) + ((ss::scan_scratch_bytes(cap) + 255) & ~(size_t)255) + (size_t)cap * 4 + 256;
+    HIP_TRY(hipMalloc(&h->sort_tmp, h->sort_bytes));
     hipLaunchKernelGGL(k_iota, dim3((cap + 255) / 256), dim3(256), 0, h->stream, h->iota, cap);
     HIP_TRY(hipGetLastError());
     h->cap = cap;
@@ -726,15 +723,14 @@ static uint32_t key_bits(uint64_t n_rows) {
 static int sort_and_segment(rp_profile* h, const uint32_t* rows, uint32_t n) {
     int rc = ensure_capacity(h, n);
     if (rc) return rc;
-    size_t tmp = h->cub_bytes;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, tmp, rows, h->keys_out, h->iota, h->perm, (int)n, 0,
-                                               (int)key_bits(h->n_rows), h->stream));
-    tmp = h->cub_bytes;
-    HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(h->cub_tmp, tmp, h->keys_out, h->seg_rows, h->seg_counts, h->n_segs, (int)n,
-                                                  h->stream));
-    tmp = h->cub_bytes;
-    // scanning all n slots is harmless (slots past n_segs are never read) and avoids a host round trip
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp, tmp, h->seg_counts, h->seg_offsets, (int)n, h->stream));
+    unsigned char* sp = reinterpret_cast<unsigned char*>(h->sort_tmp);
+    HIP_TRY(ss::sort_pairs(rows, h->iota, h->keys_out, h->perm, n, key_bits(h->n_rows), sp, h->stream));
+    sp += ss::sort_scratch_bytes(h->cap);
+    void* scan_tmp = sp;
+    sp += (ss::scan_scratch_bytes(h->cap) + 255) & ~(size_t)255;
+    // seg_offsets = the start of every run = the exclusive scan of the run lengths
+    HIP_TRY(ss::run_length_encode(h->keys_out, n, h->seg_rows, h->seg_offsets, h->seg_counts, h->n_segs, reinterpret_cast<uint32_t*>(sp),
+                                  scan_tmp, h->stream));
     return RP_OK;
 }
 
@@ -776,8 +772,8 @@ static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch
                             unsigned char* entries) {
     const uint32_t eb = (uint32_t)entry_bytes_of(h);
     hipLaunchKernelGGL(k_block_counts, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->seg_counts, h->n_segs, n, h->nblk);
-    size_t tmp = h->cub_bytes;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp, tmp, h->nblk, h->boff, (int)n, h->stream));
+    HIP_TRY(ss::exclusive_scan<uint32_t>(h->nblk, h->boff, n, reinterpret_cast<unsigned char*>(h->sort_tmp) + ss::sort_scratch_bytes(h->cap),
+                                         h->stream));
     const uint32_t mb = max_blocks_of(n);
     hipLaunchKernelGGL(k_block_index, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->nblk, h->boff, h->n_segs, h->blkseg);
     const SortedBatch sb{h->srt_regret, h->srt_policy, h->srt_payoff, h->srt_expanded};

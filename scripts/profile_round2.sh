@@ -7,6 +7,7 @@
 #   4 MFMA / issue counters of k_sinkhorn_bound on a slice                         -> r02_mfma_bound_counters.txt
 #   5 FETCH_SIZE / WRITE_SIZE of the Elkan bound update at full N                  -> r02_lloyd_bounds_hbm_traffic.txt
 #   6 kernel-trace stats of the NLHE traversal step                                -> r02_nlhe_kernel_stats.txt
+#   7 kernel-trace stats of the sparse profile step (nlhe-synth)                    -> r02_sparse_kernel_stats.txt
 #   2b SQ issue / wait / lane counters of the MCCFR kernels                        -> r02_mccfr_sq_counters.txt
 set -u
 TAG=${1:-r02}
@@ -79,6 +80,11 @@ NL="python $REPO/bench.py --workload nlhe --steps 3 --warmup 1 --cpu-seconds 0"
 rocprofv3 --kernel-trace --stats -d $OUT/kn -o kn -- $NL > $OUT/kn.log 2>&1
 python $REPO/scripts/rocpd_summary.py $(ls $OUT/kn/*.db | head -1) $OUT/${TAG}_nlhe_kernel_stats.txt "$NL" > /dev/null
 grep -o '{"metric.*' $OUT/kn.log > $OUT/${TAG}_nlhe_bench_line.json
+# 7: the row-addressed profile on synthetic NLHE-scale batches (own radix sort / scan / run lengths)
+SP="python $REPO/bench.py --workload nlhe-synth --steps 20 --warmup 3 --cpu-seconds 0"
+rocprofv3 --kernel-trace --stats -d $OUT/ks -o ks -- $SP > $OUT/ks.log 2>&1
+python $REPO/scripts/rocpd_summary.py $(ls $OUT/ks/*.db | head -1) $OUT/${TAG}_sparse_kernel_stats.txt "$SP" > /dev/null
+grep -o '{"metric.*' $OUT/ks.log > $OUT/${TAG}_sparse_bench_line.json
 ls -la $OUT | head -40
 cat $OUT/${TAG}_mfma_bound_counters.txt $OUT/${TAG}_lloyd_bounds_hbm_traffic.txt
 head -12 $OUT/${TAG}_lloyd_full_kernel_stats.txt $OUT/${TAG}_bench_kernel_stats.txt $OUT/${TAG}_nlhe_kernel_stats.txt

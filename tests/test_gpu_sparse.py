@@ -159,3 +159,37 @@ def test_full_size_table_properties(gpu):
         g.close()
     for f in ("regret", "weight", "payoff"):
         assert np.allclose(results["ordered"][f], results["composed"][f], rtol=2e-4, atol=1e-2), f
+
+
+@pytest.mark.parametrize("n,bits,kind", [(1, 27, "uniform"), (255, 8, "uniform"), (2049, 27, "uniform"), (70_001, 27, "hot"),
+                                         (200_000, 32, "uniform"), (1_500_000, 27, "hot"), (3_000_000, 13, "uniform"),
+                                         (50_000, 0, "zero")])
+def test_device_sort_scan_and_run_lengths_equal_numpy(gpu, n, bits, kind):
+    # csrc/sortscan.hpp (the library's own radix sort / scan / run-length encoding under rp_profile_* and the isomorphism
+    # enumeration): the sort must be STABLE (the ordered update applies a row's touches in batch order); sizes around the tile
+    # boundaries, past the single-workgroup scan, a multi-level scan (256 x 1465 tile histograms), hot rows (a third of the
+    # batch on three keys, like the root infosets of a batch of NLHE trees), bits = 0
+    import ctypes as C
+
+    from robopoker_amd import _lib
+
+    rng = np.random.default_rng(n + bits)
+    hi = (1 << bits) if bits else 1
+    keys = rng.integers(0, hi, size=n, dtype=np.uint64).astype(np.uint32)
+    if kind == "hot":
+        hot = rng.random(n) < 0.35
+        keys[hot] = rng.integers(0, 3, size=int(hot.sum()), dtype=np.uint64).astype(np.uint32) * 1000 + 5
+    out = {k: np.zeros(max(n, 1), np.uint32) for k in ("keys", "perm", "uniq", "starts", "counts")}
+    n_runs = C.c_uint32()
+    scan = np.zeros(max(n, 1), np.uint64)
+    p = lambda a: a.ctypes.data  # noqa: E731
+    _lib.check(_lib.load().rp_sortscan_selftest(0, n, bits, p(keys), p(out["keys"]), p(out["perm"]), p(out["uniq"]), p(out["starts"]),
+                                                p(out["counts"]), C.addressof(n_runs), p(scan)))
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(out["perm"][:n], order.astype(np.uint32)) and np.array_equal(out["keys"][:n], keys[order])
+    uniq, starts, counts = np.unique(keys[order], return_index=True, return_counts=True)
+    r = n_runs.value
+    assert r == len(uniq)
+    assert np.array_equal(out["uniq"][:r], uniq) and np.array_equal(out["starts"][:r], starts.astype(np.uint32))
+    assert np.array_equal(out["counts"][:r], counts.astype(np.uint32))
+    assert np.array_equal(scan[:n], np.concatenate([[0], np.cumsum(keys.astype(np.uint64))[:-1]]).astype(np.uint64))
