@@ -695,7 +695,25 @@ struct Bounds {
     float* u;        // [N]   Bounds::error
     uint8_t* stale;  // [N]
     float* lower;    // [N][K]
+    // the last EXACT distance(point, its centroid) and what it was measured against.  Bounds::refresh (bounds.rs:79-83)
+    // recomputes distance(point, centroid j) whenever the bound is stale; the distance is a pure function of the two
+    // histograms, so while centroid j has not changed (cver[j], bumped when its integer sums change) and the point still
+    // belongs to it the refresh would return memo_d bit for bit — the solve is skipped.  Late iterations move a few dozen
+    // points: most centroids, hence most refreshes, repeat.
+    float* memo_d;          // [N]
+    uint32_t* memo_ver;     // [N]  cver[memo_j] at the time; 0 = nothing remembered
+    uint8_t* memo_j;        // [N]
+    const uint32_t* cver;   // [K]  content version of the centroids in use (starts at 1)
 };
+__device__ __forceinline__ bool memo_valid(const Bounds& B, uint64_t i, uint32_t j) {
+    return B.memo_ver && B.memo_j[i] == (uint8_t)j && B.memo_ver[i] == B.cver[j];
+}
+__device__ __forceinline__ void memo_store(const Bounds& B, uint64_t i, uint32_t j, float d) {
+    if (!B.memo_ver) return;
+    B.memo_d[i] = d;
+    B.memo_j[i] = (uint8_t)j;
+    B.memo_ver[i] = B.cver[j];
+}
 
 __global__ __launch_bounds__(64) void k_neighbor(Points P, CentroidSet cs, uint32_t K, Metric M, int kind,
                                                  uint8_t* out_j, float* out_d, Bounds init, const uint32_t* only) {
@@ -994,9 +1012,20 @@ __global__ __launch_bounds__(256) void k_pairwise_var(CentroidSet cs, uint32_t K
 }
 
 // Elkan::pairwises (elkan.rs:80-93): both orders; one wave per ordered pair
-__global__ __launch_bounds__(64) void k_pairwise(CentroidSet cs, uint32_t K, Metric M, int kind, float* pairw) {
+// pver[2e], pver[2e+1]: the centroid versions pairw[e] was computed from (0 = never): an entry whose two centroids have not
+// changed keeps its value (distance(a, b) is a pure function of the two)
+__global__ __launch_bounds__(64) void k_pairwise(CentroidSet cs, uint32_t K, Metric M, int kind, float* pairw, const uint32_t* cver,
+                                                 uint32_t* pver) {
     __shared__ WaveLds w;
     const uint32_t a = blockIdx.x / K, b = blockIdx.x % K;
+    if (pver) {
+        const uint32_t va = cver[a], vb = cver[b];
+        if (pver[2 * blockIdx.x] == va && pver[2 * blockIdx.x + 1] == vb) return;
+        if (lane_id() == 0) {
+            pver[2 * blockIdx.x] = va;
+            pver[2 * blockIdx.x + 1] = vb;
+        }
+    }
     float d = 0.0f;
     if (a != b) {
         if (kind == RP_METRIC_SINKHORN) {
@@ -1076,10 +1105,12 @@ __global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uin
             else lw[3] = d;
         }
     };
+    bool exact = false;  // u is an exact distance to the CURRENT centroid j, measured in this call
     if (B.stale[i]) {
-        const float d = distance_to(j);
+        const float d = memo_valid(B, i, j) ? B.memo_d[i] : distance_to(j);
         set_lower(j, d);
         u = d;
+        exact = true;
     }
     uint32_t start = 0;
     for (;;) {
@@ -1097,6 +1128,7 @@ __global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uin
         if (d < u) {
             j = found;
             u = d;
+            exact = true;
         }
         start = found + 1;
     }
@@ -1109,6 +1141,7 @@ __global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uin
         B.j[i] = (uint8_t)j;
         B.u[i] = u;
         B.stale[i] = 0;
+        if (exact) memo_store(B, i, j, u);
     }
 }
 
@@ -1129,6 +1162,18 @@ struct Refresh {
 };
 __device__ __forceinline__ bool needs_refresh(const Bounds& B, const Refresh& R, const float* mid, uint64_t i) {
     return B.stale[i] && B.u[i] > mid[B.j[i]] && R.nsup[i] <= PAIR_ROWS;
+}
+// stale bounds whose refresh is remembered: Bounds::refresh without the solve
+__global__ __launch_bounds__(256) void k_refresh_memo(Bounds B, const float* mid, uint64_t N, uint32_t K) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t j = B.j[i];
+        if (B.stale[i] && B.u[i] > mid[j] && memo_valid(B, i, j)) {
+            const float d = B.memo_d[i];
+            B.u[i] = d;
+            B.lower[i * K + j] = d;
+            B.stale[i] = 0;
+        }
+    }
 }
 __global__ __launch_bounds__(256) void k_refresh_count(Bounds B, Refresh R, const float* mid, uint64_t N, uint32_t K) {
     __shared__ uint32_t c[MAXB];
@@ -1190,6 +1235,7 @@ __global__ __launch_bounds__(64) void k_refresh_pairs(Points P, CentroidSet cs, 
             B.u[i] = d;
             B.lower[(uint64_t)i * K + j] = d;
             B.stale[i] = 0;
+            memo_store(B, i, j, d);
             atomicAdd(STAT(M, 0), 1ull);
         }
     }
@@ -1832,6 +1878,11 @@ struct rp_kmeans {
     Bounds B{};
     uint8_t* prior = nullptr;
     float* pairw = nullptr;
+    uint32_t* cver = nullptr;   // [K] content versions of the centroids (Bounds::cver)
+    uint32_t* pver = nullptr;   // [K*K][2] versions pairw was computed from
+    uint32_t memo_epoch = 0;
+    bool memo_dirty = true;     // centroids were installed outside an Elkan step: forget everything at the next one
+    bool memo_on = true;        // RP_LLOYD_NO_MEMO=1 switches the remembered refreshes off
     float* mid = nullptr;
     float* drift = nullptr;
     float* pot = nullptr;
@@ -1932,7 +1983,29 @@ int alloc_centroid_set(rp_kmeans* h, CentroidSet* cs) {
     return RP_OK;
 }
 
-int prepare_centroids(rp_kmeans* h, int set) {
+__global__ void k_fill_u32(uint32_t* p, uint32_t n, uint32_t v) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// content versions of the centroids (Bounds::cver).  against = the set being replaced: centroid k keeps its version iff its
+// integer sums and weight are unchanged; against = none: every centroid gets a new version
+__global__ __launch_bounds__(64) void k_centroid_versions(CentroidSet now, CentroidSet was, bool compare, uint32_t bins, uint32_t* cver) {
+    const uint32_t k = blockIdx.x, lane = lane_id();
+    bool differs = !compare;
+    if (compare) {
+        for (uint32_t t = lane; t < bins; t += 64) differs |= now.counts[(size_t)k * bins + t] != was.counts[(size_t)k * bins + t];
+        differs |= now.weight[k] != was.weight[k];
+    }
+    if (__ballot(differs) && lane == 0) cver[k] += 1u;
+}
+
+int prepare_centroids(rp_kmeans* h, int set, bool replaces_other = false) {
+    // an Elkan step replaces the other set: compare contents.  Any other way of installing centroids (k-means++, set_*,
+    // step_naive) invalidates everything remembered, lazily at the next Elkan step (memo_reset).
+    if (h->cver && replaces_other)
+        hipLaunchKernelGGL(k_centroid_versions, dim3(h->K), dim3(64), 0, h->stream, h->cs[set], h->cs[set ^ 1], true, h->bins, h->cver);
+    else
+        h->memo_dirty = true;
     ck_begin(h, CK_SELF);
     hipLaunchKernelGGL(k_prepare_centroids, dim3(h->K), dim3(64), 0, h->stream, h->cs[set], h->K, h->M, h->kind, 0u);
     ck_end(h, CK_SELF);
@@ -2020,6 +2093,15 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
     KM_TRY(dev_alloc(h, &h->prior, N));
     KM_TRY(dev_alloc(h, &h->tmp_j, N));
     KM_TRY(dev_alloc(h, &h->pairw, (size_t)K * K));
+    h->memo_on = getenv("RP_LLOYD_NO_MEMO") == nullptr && kind == RP_METRIC_SINKHORN;
+    if (h->memo_on) {
+        KM_TRY(dev_alloc(h, &h->cver, (size_t)K));
+        KM_TRY(dev_alloc(h, &h->pver, (size_t)K * K * 2));
+        KM_TRY(dev_alloc(h, &h->B.memo_d, N));
+        KM_TRY(dev_alloc(h, &h->B.memo_ver, N));
+        KM_TRY(dev_alloc(h, &h->B.memo_j, N));
+        h->B.cver = h->cver;
+    }
     KM_TRY(dev_alloc(h, &h->mid, K));
     KM_TRY(dev_alloc(h, &h->drift, K));
     KM_TRY(dev_alloc(h, &h->pot, N));
@@ -2273,11 +2355,18 @@ int launch_recompute(rp_kmeans* h, const uint8_t* assign, int set) {
 // the part of step_elkan before the centroid exchange: pairwise, midpoints, bound refresh, partial sums
 int step_front(rp_kmeans* h) {
     const int cur = h->cur;
+    if (h->memo_on && h->memo_dirty) {  // centroids installed outside an Elkan step: nothing remembered is valid
+        h->memo_epoch += 1;
+        hipLaunchKernelGGL(k_fill_u32, dim3((h->K + 255) / 256), dim3(256), 0, h->stream, h->cver, h->K, h->memo_epoch << 16);
+        HIP_TRY(hipMemsetAsync(h->pver, 0, (size_t)h->K * h->K * 8, h->stream));
+        HIP_TRY(hipMemsetAsync(h->B.memo_ver, 0, (size_t)h->N * 4, h->stream));
+        h->memo_dirty = false;
+    }
     ck_begin(h, CK_PAIRWISE);
     if (h->kind == RP_METRIC_VARIATION)
         hipLaunchKernelGGL(k_pairwise_var, dim3((h->K * h->K + 255) / 256), dim3(256), 0, h->stream, h->cs[cur], h->K, h->M, h->pairw);
     else
-        hipLaunchKernelGGL(k_pairwise, dim3(h->K * h->K), dim3(64), 0, h->stream, h->cs[cur], h->K, h->M, h->kind, h->pairw);
+        hipLaunchKernelGGL(k_pairwise, dim3(h->K * h->K), dim3(64), 0, h->stream, h->cs[cur], h->K, h->M, h->kind, h->pairw, h->cver, h->pver);
     hipLaunchKernelGGL(k_midpoints, dim3((h->K + 63) / 64), dim3(64), 0, h->stream, h->pairw, h->K, h->mid);
     ck_end(h, CK_PAIRWISE);
     ck_begin(h, CK_STEP);
@@ -2289,6 +2378,7 @@ int step_front(rp_kmeans* h) {
             const size_t entries = (size_t)h->N + 2 * (size_t)h->K;
             HIP_TRY(hipMemsetAsync(h->refresh.count, 0, (size_t)h->K * 4, h->stream));
             HIP_TRY(hipMemsetAsync(h->refresh.list, 0xff, entries * 4, h->stream));
+            if (h->B.memo_ver) hipLaunchKernelGGL(k_refresh_memo, dim3(1024), dim3(256), 0, h->stream, h->B, h->mid, h->N, h->K);
             hipLaunchKernelGGL(k_refresh_count, dim3(1024), dim3(256), 0, h->stream, h->B, h->refresh, h->mid, h->N, h->K);
             hipLaunchKernelGGL(k_refresh_offsets, dim3(1), dim3(1), 0, h->stream, h->refresh, h->K);
             hipLaunchKernelGGL(k_refresh_fill, dim3(1024), dim3(256), 0, h->stream, h->B, h->refresh, h->mid, h->N);
@@ -2306,7 +2396,7 @@ int step_front(rp_kmeans* h) {
 // after the (optional) all-reduce of the integer sums in cs[cur^1]: drift, bounds update, install, tally
 int step_back(rp_kmeans* h, float* drift, uint64_t* sizes, double* reassigned) {
     const int cur = h->cur, nxt = cur ^ 1;
-    int rc = prepare_centroids(h, nxt);
+    int rc = prepare_centroids(h, nxt, true);
     if (rc) return rc;
     ck_begin(h, CK_DRIFT);
     hipLaunchKernelGGL(k_drift, dim3(h->K), dim3(64), 0, h->stream, h->cs[nxt], h->cs[cur], h->K, h->M, h->kind, h->drift);
@@ -2488,6 +2578,7 @@ int rp_kmeans_set_centroid(rp_kmeans* h, uint32_t k, const uint32_t* counts) {
     HIP_TRY(hipMemcpyAsync(h->hist_stage, counts, (size_t)h->bins * 4, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_centroid_from_hist, dim3(1), dim3(256), 0, h->stream, h->cs[h->cur], k, h->hist_stage, h->bins);
     hipLaunchKernelGGL(k_prepare_centroids, dim3(1), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, k);
+    h->memo_dirty = true;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));  // `counts` may be a temporary on the caller's side
     h->bounds_ready = false;
@@ -2513,6 +2604,7 @@ int rp_kmeans_init_centroids(rp_kmeans* h, uint64_t* chosen) {
         if (chosen) chosen[k] = pick;
         hipLaunchKernelGGL(k_centroid_from_point, dim3(1), dim3(256), 0, h->stream, h->cs[h->cur], k, h->P, pick, h->bins);
         hipLaunchKernelGGL(k_prepare_centroids, dim3(1), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, k);
+        h->memo_dirty = true;
         HIP_TRY(hipGetLastError());
         if ((rc = rp_kmeans_kpp_update(h, k))) return rc;
     }
@@ -2659,7 +2751,7 @@ int rp_kmeans_metric(rp_kmeans* h, float* tri) {
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
     ck_begin(h, CK_PAIRWISE);
-    hipLaunchKernelGGL(k_pairwise, dim3(h->K * h->K), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, h->pairw);
+    hipLaunchKernelGGL(k_pairwise, dim3(h->K * h->K), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, h->pairw, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     ck_end(h, CK_PAIRWISE);
     HIP_TRY(hipGetLastError());
     std::vector<float> pw((size_t)h->K * h->K);
