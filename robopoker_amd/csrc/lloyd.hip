@@ -42,7 +42,18 @@ struct Metric {
     unsigned long long* stats;  // [0] distances, [1] sinkhorn iterations, [2] exp evaluations of the softmin/cost loops
     uint32_t stat_stripes;      // the counters are striped over this many 128-byte lines (STAT): every wavefront adds to
                                 // them once per solve, and adds to ONE address serialise at its L2 channel (~9 ns each)
+    // k-means++ computes distance(centroid_k, point) — the very value Elkan::neighbor needs (elkan.rs:68-77: the same
+    // centroid-first call, first minimum wins).  Every solved distance is noted: nearest centroid so far and its distance.
+    // -1 = not known (the picked point, whose potential is set to 0 without a solve).  See k_init_from_kpp.
+    float* kpp_d;               // [N] or NULL
+    uint8_t* kpp_j;             // [N]
 };
+__device__ __forceinline__ void kpp_note(const Metric& M, uint64_t i, uint32_t k, float d) {
+    if (M.kpp_d && d < M.kpp_d[i]) {  // strict: the first minimum in centroid order stays (a NaN never enters, -1 never leaves)
+        M.kpp_d[i] = d;
+        M.kpp_j[i] = (uint8_t)k;
+    }
+}
 #define STAT_STRIDE 16u  // u64 per stripe
 #define KM_STAT_STRIPES 256u
 __device__ __forceinline__ unsigned long long* STAT(const Metric& M, uint32_t k) {
@@ -822,6 +833,31 @@ __global__ __launch_bounds__(64) void k_neighbor_masked(Points P, CentroidSet cs
         for (uint32_t k = lane; k < K; k += 64) init.lower[i * K + k] = 0.0f;
 }
 
+// init_bounds right after k-means++: Elkan::neighbor of a point = the nearest centroid k-means++ noted, when that is known to
+// be the minimum over ALL K centroids.  A pair k-means++ did not solve was skipped because its rigorous lower bound (with the
+// margins of k_kpp_filter) squared was >= the potential at that time, which is >= the final potential; so once the noted
+// distance is what the final potential stands for — d*d below the initial potential 1 — every unsolved pair is farther, and
+// among the solved ones the note is the first minimum.  Everything else (the K picked points, points that ended at
+// potential 1, NaNs) goes on `todo` for the exact search.
+__global__ __launch_bounds__(256) void k_init_from_kpp(Metric M, uint64_t N, uint32_t K, uint8_t* out_j, Bounds init, uint32_t* todo,
+                                                       unsigned int* n_todo) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float d = M.kpp_d[i];
+    if (d >= 0.0f && d * d < 1.0f) {
+        const uint8_t j = M.kpp_j[i];
+        if (out_j) out_j[i] = j;
+        init.j[i] = j;  // Bounds::from((j, upper)) (bounds.rs:111-120)
+        init.u[i] = d;
+        init.stale[i] = 0;
+    } else {
+        todo[atomicAdd(n_todo, 1u)] = (uint32_t)i;
+    }
+}
+__global__ __launch_bounds__(256) void k_zero_f32(float* p, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = 0.0f;
+}
+
 // upper bounds handed to the MFMA bound before it starts
 __global__ __launch_bounds__(256) void k_hint_masks(const uint8_t* j, uint64_t N, uint32_t K, unsigned long long* mask) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -988,6 +1024,7 @@ __global__ __launch_bounds__(64) void k_kpp_updateG(Points P, CentroidSet cs, ui
         const uint64_t i = pick<G>(ip, lane);
         const float d = rp_maxf(pick<G>(xy, lane) - 0.5f * cs.self[k] - 0.5f * P.self[i], 0.0f);
         pot[i] = rp_minf(d * d, pot[i]);
+        kpp_note(M, i, k, d);
     }
 }
 
@@ -1631,6 +1668,7 @@ __global__ __launch_bounds__(256) void k_kpp_update_var(Points P, CentroidSet cs
     if (i >= P.N) return;
     const float d = lane_variation(P, i, cs, K, k, M.bins);
     pot[i] = rp_minf(d * d, pot[i]);
+    kpp_note(M, i, k, d);
 }
 __global__ __launch_bounds__(256) void k_point_dist_var(Points P, CentroidSet cs, uint32_t K, Metric M, const uint8_t* j, float* out) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1671,7 +1709,7 @@ __global__ __launch_bounds__(1024) void k_kpp_total(const unsigned long long* bs
     }
 }
 // single block: winner = first i whose inclusive quantised prefix exceeds r (r < this shard's total)
-__global__ __launch_bounds__(1024) void k_kpp_pick(float* pot, uint64_t N, const unsigned long long* bsum, uint32_t nblocks,
+__global__ __launch_bounds__(1024) void k_kpp_pick(float* pot, float* kpp_d, uint64_t N, const unsigned long long* bsum, uint32_t nblocks,
                                                    unsigned long long r, unsigned long long* picked) {
     __shared__ unsigned long long strip[1024];
     __shared__ unsigned long long sh_before;
@@ -1705,6 +1743,7 @@ __global__ __launch_bounds__(1024) void k_kpp_pick(float* pot, uint64_t N, const
         const uint64_t win = (uint64_t)sh_block * KPP_BLOCK + t;
         picked[0] = win;
         pot[win] = 0.0f;  // potentials[i] = 0 (layer.rs:169)
+        if (kpp_d) kpp_d[win] = -1.0f;  // no solve stands behind that 0: its neighbor is found the long way
     }
 }
 // potentials <- min(potentials, d(new centroid, point)^2) (layer.rs:170-178): distance(&x, h), centroid first
@@ -1729,7 +1768,10 @@ __global__ __launch_bounds__(64) void k_kpp_update(Points P, CentroidSet cs, uin
         d = s / (float)M.bins;
         if (lane_id() == 0) atomicAdd(STAT(M, 0), 1ull);
     }
-    if (lane_id() == 0) pot[i] = rp_minf(d * d, pot[i]);
+    if (lane_id() == 0) {
+        pot[i] = rp_minf(d * d, pot[i]);
+        kpp_note(M, i, k, d);
+    }
 }
 __global__ void k_fill(float* p, uint64_t n, float v) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
@@ -1880,6 +1922,8 @@ struct rp_kmeans {
     float* pairw = nullptr;
     uint32_t* cver = nullptr;   // [K] content versions of the centroids (Bounds::cver)
     uint32_t* pver = nullptr;   // [K*K][2] versions pairw was computed from
+    uint32_t* kpp_todo = nullptr;      // init_bounds after k-means++: the points whose neighbor the notes do not settle
+    unsigned int* kpp_ntodo = nullptr;
     uint32_t memo_epoch = 0;
     bool memo_dirty = true;     // centroids were installed outside an Elkan step: forget everything at the next one
     bool memo_on = true;        // RP_LLOYD_NO_MEMO=1 switches the remembered refreshes off
@@ -2083,7 +2127,13 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
     }
     KM_TRY(dev_alloc(h, &h->stats, (size_t)KM_STAT_STRIPES * STAT_STRIDE));
     KM_HIP(hipMemset(h->stats, 0, (size_t)KM_STAT_STRIPES * STAT_STRIDE * 8));
-    h->M = Metric{d_C, d_R, bins, h->hp.iterations, h->hp.tolerance, h->stats, KM_STAT_STRIPES};
+    h->M = Metric{d_C, d_R, bins, h->hp.iterations, h->hp.tolerance, h->stats, KM_STAT_STRIPES, nullptr, nullptr};
+    if (getenv("RP_LLOYD_NO_KPP_MEMO") == nullptr) {
+        KM_TRY(dev_alloc(h, &h->M.kpp_d, N));
+        KM_TRY(dev_alloc(h, &h->M.kpp_j, N));
+        KM_TRY(dev_alloc(h, &h->kpp_todo, N));
+        KM_TRY(dev_alloc(h, &h->kpp_ntodo, 1));
+    }
     KM_TRY(alloc_centroid_set(h, &h->cs[0]));
     KM_TRY(alloc_centroid_set(h, &h->cs[1]));
     KM_TRY(dev_alloc(h, &h->B.j, N));
@@ -2471,6 +2521,7 @@ int rp_kmeans_kpp_begin(rp_kmeans* h) {
     HIP_TRY(hipMemsetAsync(cs.weight, 0, h->K * 4, h->stream));
     hipLaunchKernelGGL(k_prepare_centroids, dim3(h->K), dim3(64), 0, h->stream, cs, h->K, h->M, h->kind, 0u);
     hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, h->stream, h->pot, h->N, 1.0f);  // potentials = 1 (layer.rs:161)
+    if (h->M.kpp_d) hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, h->stream, h->M.kpp_d, h->N, rp_u2f(0x7f800000u));
     HIP_TRY(hipGetLastError());
     h->centroids_ready = false;
     h->bounds_ready = false;
@@ -2499,7 +2550,7 @@ int rp_kmeans_kpp_pick(rp_kmeans* h, uint64_t r, uint64_t* index) {
     if (!h || !index) return rp::fail(RP_ERR_INVALID, "rp_kmeans_kpp_pick: NULL argument");
     HIP_TRY(hipSetDevice(h->device));
     const uint32_t nblocks = (uint32_t)((h->N + KPP_BLOCK - 1) / KPP_BLOCK);
-    hipLaunchKernelGGL(k_kpp_pick, dim3(1), dim3(1024), 0, h->stream, h->pot, h->N, h->bsum, nblocks, (unsigned long long)r, h->scal);
+    hipLaunchKernelGGL(k_kpp_pick, dim3(1), dim3(1024), 0, h->stream, h->pot, h->M.kpp_d, h->N, h->bsum, nblocks, (unsigned long long)r, h->scal);
     HIP_TRY(hipGetLastError());
     unsigned long long p = 0;
     HIP_TRY(hipMemcpyAsync(&p, h->scal, 8, hipMemcpyDeviceToHost, h->stream));
@@ -2620,7 +2671,25 @@ int rp_kmeans_init_bounds(rp_kmeans* h) {
     int rc = need_centroids(h, "rp_kmeans_init_bounds");
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
-    if ((rc = launch_neighbor(h, h->prior, nullptr, h->B, NB_INIT_BOUNDS))) return rc;  // Prior::from_bounds (prior.rs:23-32)
+    if (h->M.kpp_d && h->pot_is_min_d2 && !h->sb_audit) {
+        // right after k-means++ on these very centroids: the nearest centroid of almost every point is already known
+        // (k_init_from_kpp); the exact search runs on the rest
+        unsigned int n_todo = 0;
+        HIP_TRY(hipMemsetAsync(h->kpp_ntodo, 0, 4, h->stream));
+        ck_begin(h, CK_NEIGHBOR);
+        hipLaunchKernelGGL(k_zero_f32, dim3(2048), dim3(256), 0, h->stream, h->B.lower, (uint64_t)h->N * h->K);
+        hipLaunchKernelGGL(k_init_from_kpp, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->M, h->N, h->K, h->prior, h->B,
+                           h->kpp_todo, h->kpp_ntodo);
+        HIP_TRY(hipMemcpyAsync(&n_todo, h->kpp_ntodo, 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (n_todo)
+            hipLaunchKernelGGL(k_neighbor, dim3(n_todo), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->kind, h->prior,
+                               (float*)nullptr, h->B, h->kpp_todo);
+        ck_end(h, CK_NEIGHBOR);
+        HIP_TRY(hipGetLastError());
+    } else if ((rc = launch_neighbor(h, h->prior, nullptr, h->B, NB_INIT_BOUNDS))) {  // Prior::from_bounds (prior.rs:23-32)
+        return rc;
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->bounds_ready = true;
     ck_drain(h);
