@@ -284,6 +284,9 @@ RP_API int rp_mccfr_kernel_time(rp_mccfr* h, const char* name, double* total_ms,
  * game), 1 = per-lane DFS with the tree in LDS (small games), 2 = instantiated over the game's compile-time action
  * skeleton (Kuhn / Leduc shapes, external sampling; csrc/traverse_static.hpp).  All three produce identical Decisions. */
 RP_API int rp_mccfr_traversal_variant(rp_mccfr* h, int* out);
+/* Which compile-time action skeleton a game table matches node for node, for every chance outcome (host only, no device
+ * needed): 0 none (the generic traversal kernels), 1 Kuhn's, 2 Leduc's (any number of ranks). */
+RP_API int rp_game_skeleton(const rp_game_table* game, int* out);
 
 /* ============================================================= sparse profile ==
  * The update half of Solver::step (solver/solver.rs:96-105,143-192: update_regret, update_weight, update_payoff,

@@ -150,6 +150,7 @@ _SIGNATURES = {
     "rp_mccfr_set_update_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "rp_mccfr_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_mccfr_traversal_variant": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "rp_game_skeleton": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "rp_mccfr_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "rp_mccfr_summary_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "rp_mccfr_step_local": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -2681,6 +2681,15 @@ int rp_mccfr_profile(rp_mccfr* h, int enable) {
     return RP_OK;
 }
 
+int rp_game_skeleton(const rp_game_table* game, int* out) {
+    if (!game || !out) return rp::fail(RP_ERR_INVALID, "rp_game_skeleton: NULL argument");
+    int rc = rp_game_table_check(game);
+    if (rc) return rc;
+    const std::vector<uint32_t> children(game->children, game->children + game->n_children);
+    *out = skel_matches<KuhnSkel>(game, children) ? 1 : (skel_matches<LeducSkel>(game, children) ? 2 : 0);
+    return RP_OK;
+}
+
 int rp_mccfr_traversal_variant(rp_mccfr* h, int* out) {
     if (!h || !out) return rp::fail(RP_ERR_INVALID, "rp_mccfr_traversal_variant: NULL argument");
     *out = (h->static_skel && h->S == RP_SAMPLING_EXTERNAL) ? 2 : (h->use_lds_traverse ? 1 : 0);

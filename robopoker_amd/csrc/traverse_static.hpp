@@ -115,6 +115,10 @@ struct SkelOf {
     static constexpr Skeleton S = G::make();
 };
 
+static_assert(SkelOf<KuhnSkel>::S.n == 11, "Kuhn: two deals, four decision nodes, five terminals");
+static_assert(SkelOf<LeducSkel>::S.n == 38, "Leduc: two deals, 4 + 3 x 4 decision nodes, three board draws, 2 + 3 x 5 terminals");
+static_assert(SkelOf<LeducSkel>::S.end[0] == 37 && SkelOf<LeducSkel>::S.kind[2] == SK_P0, "pre-order, the first decision is P0's");
+
 // compile-time loops: f(std::integral_constant<int, I>) for I = LO .. HI-1, ascending / descending
 template <int I, int HI, class F>
 __device__ __forceinline__ void sk_for(F&& f) {

@@ -31,6 +31,13 @@ class Game:
     def max_actions(self) -> int:
         return self.table.max_actions
 
+    def skeleton(self) -> str:
+        """the compile-time action skeleton this table matches (csrc/traverse_static.hpp): "kuhn", "leduc" or "" — decides
+        whether the solver's traversal is the instantiated kernel or the generic per-lane DFS; host-side check, no device"""
+        out = C.c_int()
+        _lib.check(_lib.load().rp_game_skeleton(C.byref(self.table), C.byref(out)))
+        return ("", "kuhn", "leduc")[out.value]
+
     def info_id(self, name: str) -> int:
         out = C.c_uint32()
         _lib.check(_lib.load().rp_game_info_id(self._h, name.encode(), C.byref(out)))

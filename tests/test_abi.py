@@ -97,3 +97,15 @@ def test_header_is_valid_c11_and_a_plain_c_host_links(tmp_path):
         # no device: the library must refuse (RP_ERR_NO_DEVICE -> exit code 2), never compute on the CPU
         assert r.returncode == 2, r.stdout + r.stderr
         assert "no HIP device" in r.stderr or "NO_DEVICE" in r.stderr or "device" in r.stderr
+
+
+def test_builtin_games_match_their_compile_time_skeletons():
+    # csrc/traverse_static.hpp: the traversal is instantiated over a game's action skeleton when the table matches it node for
+    # node for every chance outcome (checked on the host at solver creation).  Kuhn and both Leducs must take that path, a game
+    # with three actions (RPS) must not.
+    from robopoker_amd import Game
+
+    assert Game("kuhn").skeleton() == "kuhn"
+    assert Game("leduc").skeleton() == "leduc"
+    assert Game("leduc_wide").skeleton() == "leduc"
+    assert Game("rps").skeleton() == ""
