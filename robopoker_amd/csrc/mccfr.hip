@@ -1644,6 +1644,7 @@ struct rp_mccfr {
     void* d_states = nullptr;
     void* d_children = nullptr;
     void* d_kids = nullptr;
+    void* d_flat = nullptr;  // DevGame::flat
     void* d_payoffs = nullptr;
     void* d_info_actions = nullptr;
     void* d_info_player = nullptr;
@@ -1874,6 +1875,52 @@ bool skel_matches(const rp_game_table* game, const std::vector<uint32_t>& childr
         return kids[s][0] != kids[s][1] && S.edge[kids[s][0]] != S.edge[kids[s][1]];
     };
     return match(game->train_root, 0);
+}
+
+// DevGame::flat for a game that matches skeleton G: records re-indexed by (skeleton node, chance outcomes on its path).  Returns
+// false (no table) when two instances of a skeleton chance node differ in their number of outcomes.
+template <class G>
+bool build_flat(const rp_game_table* game, const std::vector<uint32_t>& children, const std::function<uint4(uint32_t)>& rec_of,
+                std::vector<uint4>& flat, uint32_t* base, uint32_t* fan) {
+    constexpr Skeleton S = SkelOf<G>::S;
+    std::vector<std::vector<int>> kids(S.n);
+    for (int s = 1; s < S.n; ++s) kids[S.parent[s]].push_back(s);
+    for (int s = 0; s < S.n; ++s) fan[s] = 0;
+    bool uniform = true;
+    std::function<void(uint32_t, int)> fans = [&](uint32_t sid, int s) {
+        const rp_state& st = game->states[sid];
+        if (S.kind[s] == SK_CHANCE) {
+            if (fan[s] == 0) fan[s] = st.n_children;
+            else if (fan[s] != st.n_children) uniform = false;
+            for (uint32_t k = 0; k < st.n_children; ++k) fans(children[st.offset + k], kids[s][0]);
+        } else if (S.kind[s] != SK_TERMINAL) {
+            for (int c : kids[s]) fans(children[st.offset + (uint32_t)S.edge[c]], c);
+        }
+    };
+    fans(game->train_root, 0);
+    if (!uniform) return false;
+    // entries of node s = product of the fans of its chance ancestors
+    std::vector<uint64_t> count(S.n, 1);
+    uint64_t total = 0;
+    for (int s = 0; s < S.n; ++s) {
+        for (int c = 0; c < s; ++c)
+            if (S.kind[c] == SK_CHANCE && s <= S.end[c]) count[s] *= fan[c];
+        base[s] = (uint32_t)total;
+        total += count[s];
+    }
+    if (total > (1ull << 26)) return false;
+    flat.assign(total, make_uint4(0, 0, 0, 0));
+    std::function<void(uint32_t, int, uint64_t)> fill = [&](uint32_t sid, int s, uint64_t idx) {
+        const rp_state& st = game->states[sid];
+        flat[base[s] + idx] = rec_of(sid);
+        if (S.kind[s] == SK_CHANCE) {
+            for (uint32_t k = 0; k < st.n_children; ++k) fill(children[st.offset + k], kids[s][0], idx * fan[s] + k);
+        } else if (S.kind[s] != SK_TERMINAL) {
+            for (int c : kids[s]) fill(children[st.offset + (uint32_t)S.edge[c]], c, idx);
+        }
+    };
+    fill(game->train_root, 0, 0);
+    return true;
 }
 
 // The per-infoset sigma / q tables can ride in LDS (a copy per wave) when they are small; measured on Leduc the L1 path
@@ -2266,6 +2313,26 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
         if (skel_matches<KuhnSkel>(game, h->children)) h->static_skel = 1;
         else if (skel_matches<LeducSkel>(game, h->children)) h->static_skel = 2;
     }
+    h->g.flat = nullptr;
+    if (h->static_skel && getenv("RP_TRAV_NO_FLAT") == nullptr) {
+        const std::function<uint4(uint32_t)> rec_of = [&](uint32_t sid) {
+            uint4 r = packed[sid];
+            r.w = sid;
+            if (game->states[sid].n_children == 0 && game->n_players == 2) {
+                r.y = rp_f2u(h->payoffs[(size_t)game->states[sid].offset * 2 + 0]);
+                r.z = rp_f2u(h->payoffs[(size_t)game->states[sid].offset * 2 + 1]);
+            }
+            return r;
+        };
+        std::vector<uint4> flat;
+        const bool ok = h->static_skel == 1 ? build_flat<KuhnSkel>(game, h->children, rec_of, flat, h->g.flat_base, h->g.flat_fan)
+                                            : build_flat<LeducSkel>(game, h->children, rec_of, flat, h->g.flat_base, h->g.flat_fan);
+        if (ok) {
+            CREATE_TRY(hipMalloc(&h->d_flat, flat.size() * sizeof(uint4)));
+            CREATE_TRY(hipMemcpy(h->d_flat, flat.data(), flat.size() * sizeof(uint4), hipMemcpyHostToDevice));
+            h->g.flat = reinterpret_cast<const uint4*>(h->d_flat);
+        }
+    }
     rc = alloc_batch_buffers(h, batch_size);
     if (rc) {
         rp_mccfr_destroy(h);
@@ -2283,7 +2350,7 @@ int rp_mccfr_destroy(rp_mccfr* h) {
     clock_drain(h->clk_traverse);
     clock_drain(h->clk_compact);
     clock_drain(h->clk_update);
-    void* ptrs[] = {h->d_states, h->d_children, h->d_kids, h->d_payoffs, h->d_info_actions, h->d_info_player, h->d_scratch,
+    void* ptrs[] = {h->d_flat, h->d_states, h->d_children, h->d_kids, h->d_payoffs, h->d_info_actions, h->d_info_player, h->d_scratch,
                     h->d_dec, h->d_sorted, h->d_bmaps, h->d_itab, h->d_summary, h->d_window, h->d_counters, h->t.regret, h->t.weight, h->t.payoff,
                     h->t.visits};
     for (void* p : ptrs)

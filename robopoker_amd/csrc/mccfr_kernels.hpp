@@ -23,6 +23,13 @@ struct DevGame {
     uint32_t A;                   // table row stride (max_actions)
     uint32_t root;                // train_root
     uint4 root_rec;               // states[root] with w = root
+    // games that match a compile-time skeleton (traverse_static.hpp), when every instance of a skeleton chance node has the
+    // same number of outcomes: the record of skeleton node s for the chance outcomes (o_1, o_2, ...) on its path, root first,
+    // sits at flat[flat_base[s] + ((o_1 * fan_2 + o_2) * fan_3 + ...)] — a node's record then depends on the sampled outcomes
+    // only, not on its parent's record (a chain of ten dependent loads becomes four)
+    const uint4* flat;            // NULL: follow the child records
+    uint32_t flat_base[48];
+    uint32_t flat_fan[48];        // outcomes of skeleton chance node s
 };
 
 // regret/strategy tables, SoA by field, row-major [info][A] (Encounter, solver/encounter.rs:22-27)

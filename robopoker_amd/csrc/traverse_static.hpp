@@ -161,9 +161,19 @@ __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevI
         constexpr int s = I;
         constexpr int par = SK::S.parent[s];
         if constexpr (par >= 0) {
-            uint32_t k = (uint32_t)SK::S.edge[s];
-            if constexpr (SK::S.kind[par] == SK_CHANCE) k = pick[par];
-            const uint4 r = g.kids[rz[par] + k];
+            uint4 r;
+            if (g.flat) {  // wave-uniform: the record by the chance outcomes on the path (DevGame::flat)
+                uint32_t idx = 0;
+                sk_for<0, s>([&](auto C) __attribute__((always_inline)) {
+                    constexpr int c = C;
+                    if constexpr (SK::S.kind[c] == SK_CHANCE && s <= SK::S.end[c]) idx = idx * g.flat_fan[c] + pick[c];
+                });
+                r = g.flat[g.flat_base[s] + idx];
+            } else {
+                uint32_t k = (uint32_t)SK::S.edge[s];
+                if constexpr (SK::S.kind[par] == SK_CHANCE) k = pick[par];
+                r = g.kids[rz[par] + k];
+            }
             rx[s] = r.x;
             ry[s] = r.y;
             rz[s] = r.z;
