@@ -65,6 +65,7 @@ struct NlParams {
     const uint8_t* tabs[4];
     uint64_t tn[4];
     uint32_t ncap, scap, wcap, dcap;  // per-tree capacities: nodes, stack entries, walker nodes, Decisions
+    uint32_t check_legal;             // evaluate Game::is_allowed on every applied action (RP_NLHE_CHECK_LEGAL=1)
 };
 
 // per-tree scratch, tree-major (a lane walks its own region sequentially)
@@ -185,6 +186,57 @@ __device__ __forceinline__ uint32_t nl_bucket(const NlParams& p, int street, uin
     return at < 0 ? 0xffffu : (((uint32_t)street << 8) | (uint32_t)p.tabs[street][at]);
 }
 
+// What NlheGame::apply needs from the state of a DECISION node, computed once per node: every child of the node is
+// game.apply(game.snap(game.actionize(edge))) on the SAME game (nlhe/src/game.rs:50-70), and actor / amounts / permissions
+// (kicker game.rs:513-576) do not depend on the edge.  nl_choices_v / nl_action_v are GameN::choices (game.rs:724-739) and
+// actionize + snap (:741-753, :835-854) over those cached values: the same decisions as the engine's own functions
+// (nlhe_engine.hpp), which recompute them from the seats at every call.
+struct NlView {
+    int to_call, to_shove, to_raise, pot, street;
+    bool may_fold, may_call, may_check, may_raise, may_shove, must_post;
+};
+__device__ __forceinline__ NlView nl_view(const G2& g) {  // g.turn() is a player
+    NlView v;
+    const int me = g.actor(), ms = g.max_stake();
+    v.to_call = ms - g.stake[me];
+    v.to_shove = g.stack[me];
+    v.to_raise = g.to_raise();
+    v.pot = g.pot;
+    v.street = g.street();
+    v.may_fold = v.to_call > 0;
+    v.may_call = v.may_fold && v.to_call < v.to_shove;
+    v.may_check = ms == g.stake[me];
+    v.may_raise = v.to_raise < v.to_shove;
+    v.may_shove = v.to_shove > 0;
+    v.must_post = g.must_post();
+    return v;
+}
+__device__ __forceinline__ int nl_choices_v(const NlView& v, int depth, uint32_t* out) {
+    int k = 0;
+    if (v.must_post) return 0;
+    if (v.may_raise) k += nl_raise_edges(v.street, depth, out + k);
+    if (v.may_shove) out[k++] = NE_SHOVE;
+    if (v.may_call) out[k++] = NE_CALL;
+    if (v.may_fold) out[k++] = NE_FOLD;
+    if (v.may_check) out[k++] = NE_CHECK;
+    return k;
+}
+__device__ __forceinline__ NlAction nl_action_v(const NlView& v, uint32_t e) {  // snap(actionize(e)), e is not a draw
+    const NlAction shove{NA_SHOVE, v.to_shove, 0}, calls{NA_CALL, v.to_call, 0};
+    const NlAction passive{v.may_check ? NA_CHECK : NA_FOLD, 0, 0};
+    if (e == NE_FOLD) return v.may_fold ? NlAction{NA_FOLD, 0, 0} : NlAction{NA_CHECK, 0, 0};
+    if (e == NE_CHECK) return v.may_check ? NlAction{NA_CHECK, 0, 0} : (v.may_call ? calls : NlAction{NA_FOLD, 0, 0});
+    if (e == NE_CALL) return v.may_call ? calls : (v.may_shove ? shove : passive);
+    bool is_shove = e == NE_SHOVE;
+    int chips = 0;
+    if (!is_shove) {  // a raise edge
+        chips = nl_edge_chips(e, v.pot);
+        if (chips >= v.to_shove || !v.may_raise) is_shove = true;  // Raise turns into Shove, which is snapped once more
+        else return NlAction{NA_RAISE, chips < v.to_raise ? v.to_raise : chips, 0};
+    }
+    return v.may_shove ? shove : (v.may_call ? calls : passive);
+}
+
 // stack entry: [0..4] packed game, [5] parent | slot << 13 | edge << 17 | depth << 22 | plen << 25, [6,7] past, [8,9] hkey, [10] fac
 #define NL_SENT 12u
 
@@ -238,6 +290,7 @@ __global__ __launch_bounds__(64) void k_nlhe_traverse(NlParams p, NlTable t, NlS
         float sigma[NLMC_A];
         float childfac_opp = 1.0f;
         uint32_t pick = 0;
+        NlView view{};
         if (turn == NT_TERMINAL) {
             kind = NK_TERMINAL;
             int reward[2];
@@ -248,7 +301,8 @@ __global__ __launch_bounds__(64) void k_nlhe_traverse(NlParams p, NlTable t, NlS
             nch = 1;
             edges[0] = NE_DRAW;
         } else {
-            nch = (uint32_t)nl_choices(g, (int)cur_depth, edges);
+            view = nl_view(g);
+            nch = (uint32_t)nl_choices_v(view, (int)cur_depth, edges);
             uint64_t chpath = 0;
             for (uint32_t a = 0; a < nch; ++a) chpath |= (uint64_t)edges[a] << (5u * a);
             const uint32_t bucket = nl_bucket(p, g.street(), turn == 0 ? hole0 : hole1, g.board);
@@ -309,8 +363,10 @@ __global__ __launch_bounds__(64) void k_nlhe_traverse(NlParams p, NlTable t, NlS
             G2 c = g;
             NlAction act;
             if (e == NE_DRAW) act = NlAction{NA_DRAW, 0, nl_draw(g.deck(), g.street() == 0 ? 3 : 1, p, tree_id, hk)};
-            else act = g.snap(nl_actionize(g, e, 0));
-            if (!c.allowed(act)) err |= NERR_ILLEGAL;
+            else act = nl_action_v(view, e);
+            // Game::apply panics on an illegal action (kicker game.rs:234-247).  snap()'s output is legal by construction, so
+            // the test can only catch an engine bug: it runs in the checking mode (RP_NLHE_CHECK_LEGAL=1, the tests), not per child
+            if (p.check_legal && !c.allowed(act)) err |= NERR_ILLEGAL;
             c.force_act(act);
             const Packed pk = pack_game(c);
             uint32_t* se = stack + (size_t)top * NL_SENT;
@@ -594,6 +650,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     h->prm.smoothing = hp->smoothing;
     h->prm.curiosity = hp->curiosity;
     h->prm.ncap = ncap; h->prm.scap = scap; h->prm.wcap = wcap; h->prm.dcap = dcap;
+    h->prm.check_legal = getenv("RP_NLHE_CHECK_LEGAL") ? 1u : 0u;
     h->prm.encoder = 0;
     if (tables) {
         for (int s = 0; s < 4; ++s) {

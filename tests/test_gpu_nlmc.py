@@ -43,6 +43,22 @@ def test_first_batch_equals_the_oracle(gpu, batch, seed):
     assert dev.counters()[2] == ora.counters()[2]
 
 
+def test_every_applied_action_is_legal_in_the_checking_mode(gpu, monkeypatch):
+    # Game::apply panics on an illegal action (kicker/src/game.rs:234-247).  The device evaluates is_allowed on every applied
+    # action only when RP_NLHE_CHECK_LEGAL=1 (it is a third of the traversal's time and can only fire on an engine bug): with
+    # the check on, two steps at a batch of a few thousand trees raise no error and produce the unchecked run's table
+    monkeypatch.setenv("RP_NLHE_CHECK_LEGAL", "1")
+    a = NlheSolver(cap_log2=20, batch=4096, seed=7)
+    monkeypatch.delenv("RP_NLHE_CHECK_LEGAL")
+    b = NlheSolver(cap_log2=20, batch=4096, seed=7)
+    for _ in range(2):
+        a.step("ordered")
+        b.step("ordered")
+    assert a.counters() == b.counters()
+    am, bm = M.as_map(*a.export()), M.as_map(*b.export())
+    assert am.keys() == bm.keys() and all(am[k].tobytes() == bm[k].tobytes() for k in am)
+
+
 def test_steps_with_resynchronisation_track_the_oracle(gpu):
     # four Solver::steps (both walkers twice).  After each: the same infosets, identical visits, regrets / weights / payoffs
     # within the stated tolerance; then the device table is overwritten with the oracle's so the NEXT step samples the same
