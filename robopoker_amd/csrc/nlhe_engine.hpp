@@ -27,10 +27,13 @@ struct NlAction {
     uint64_t cards;
 };
 // GameN<P> (game.rs:30-36) with the seats as parallel arrays
-template <int MAXP>
+// FIXN > 0: the number of seats is that compile-time constant (the heads-up MCCFR traversal: every seat loop unrolls, the
+// seat arrays stay in registers, `% n` is a mask); FIXN = 0: the run-time field `n` (the playout kernels, 2..MAXP seats)
+template <int MAXP, int FIXN = 0>
 struct NlGameT {
     static constexpr int CAP = MAXP;
     int n, dealer, ticker, pot;
+    __device__ __forceinline__ int N() const { return FIXN > 0 ? FIXN : n; }
     uint64_t board;
     int state[MAXP], stack[MAXP], stake[MAXP], spent[MAXP];
     uint64_t cards[MAXP];
@@ -39,28 +42,28 @@ struct NlGameT {
         const int c = __popcll(board);
         return c == 0 ? 0 : (c == 3 ? 1 : (c == 4 ? 2 : 3));
     }
-    __device__ int actor() const { return (dealer + ticker) % n; }  // game.rs:656-658
+    __device__ int actor() const { return (dealer + ticker) % N(); }  // game.rs:656-658
     __device__ int max_stake() const {                              // :693-695
         int m = stake[0];
-        for (int i = 1; i < n; ++i) m = max(m, stake[i]);
+        for (int i = 1; i < N(); ++i) m = max(m, stake[i]);
         return m;
     }
     // ---- the closing predicates (game.rs:463-511) ----
-    __device__ bool touched() const { return ticker > n + (street() == 0 ? (n == 2 ? 1 : 2) : 0); }
+    __device__ bool touched() const { return ticker > N() + (street() == 0 ? (N() == 2 ? 1 : 2) : 0); }
     __device__ bool matched() const {
         const int top = max_stake();
         bool ok = true;
-        for (int i = 0; i < n; ++i) ok = ok && !(state[i] == NL_BETTING && stake[i] != top);
+        for (int i = 0; i < N(); ++i) ok = ok && !(state[i] == NL_BETTING && stake[i] != top);
         return ok;
     }
     __device__ int alive() const {
         int a = 0;
-        for (int i = 0; i < n; ++i) a += state[i] != NL_FOLDING;
+        for (int i = 0; i < N(); ++i) a += state[i] != NL_FOLDING;
         return a;
     }
     __device__ bool all_shoving() const {
         bool ok = true;
-        for (int i = 0; i < n; ++i) ok = ok && (state[i] == NL_FOLDING || state[i] == NL_SHOVING);
+        for (int i = 0; i < N(); ++i) ok = ok && (state[i] == NL_FOLDING || state[i] == NL_SHOVING);
         return ok;
     }
     __device__ bool all_folding() const { return alive() == 1; }
@@ -75,7 +78,7 @@ struct NlGameT {
     __device__ int to_shove() const { return stack[actor()]; }
     __device__ int to_raise() const {
         int most = 0, next = 0;
-        for (int i = 0; i < n; ++i) {
+        for (int i = 0; i < N(); ++i) {
             if (state[i] == NL_FOLDING) continue;
             if (stake[i] > most) {
                 next = most;
@@ -95,7 +98,7 @@ struct NlGameT {
     __device__ bool may_shove() const { return choosing() && to_shove() > 0; }
     __device__ uint64_t deck() const {  // :644-650
         uint64_t gone = board;
-        for (int i = 0; i < n; ++i) gone |= cards[i];
+        for (int i = 0; i < N(); ++i) gone |= cards[i];
         return ~gone & HAND_MASK;
     }
     // ---- act (game.rs:395-460) ----
@@ -120,7 +123,7 @@ struct NlGameT {
         }
         next_player();
         if (a.kind == NA_DRAW)
-            for (int i = 0; i < n; ++i) stake[i] = 0;  // next_street
+            for (int i = 0; i < N(); ++i) stake[i] = 0;  // next_street
     }
     // is_allowed (game.rs:297-319) for the kinds a solver produces
     __device__ bool allowed(const NlAction& a) const {
@@ -211,7 +214,7 @@ __device__ NlAction nl_actionize(const G& g, uint32_t e, uint64_t draw) {  // ga
 template <class G>
 __device__ void nl_settle(const G& g, int* reward) {
     uint32_t strength[G::CAP];
-    for (int i = 0; i < g.n; ++i) {
+    for (int i = 0; i < g.N(); ++i) {
         reward[i] = 0;
         strength[i] = strength_key(sw_of_hand(g.cards[i] | g.board));
     }
@@ -220,7 +223,7 @@ __device__ void nl_settle(const G& g, int* reward) {
     for (;;) {
         bool found = false;
         uint32_t top = 0;
-        for (int i = 0; i < g.n; ++i)
+        for (int i = 0; i < g.N(); ++i)
             if (strength[i] < best && g.state[i] != NL_FOLDING && (!found || strength[i] > top)) {
                 found = true;
                 top = strength[i];
@@ -230,19 +233,19 @@ __device__ void nl_settle(const G& g, int* reward) {
         for (;;) {
             distributed = distributing;
             int amount = -1;
-            for (int i = 0; i < g.n; ++i)
+            for (int i = 0; i < g.N(); ++i)
                 if (strength[i] == best && g.spent[i] > distributed && g.state[i] != NL_FOLDING && (amount < 0 || g.spent[i] < amount))
                     amount = g.spent[i];
             if (amount < 0) break;
             distributing = amount;
             int chips = 0, nw = 0;
-            for (int i = 0; i < g.n; ++i) {
+            for (int i = 0; i < g.N(); ++i) {
                 chips += max(min(g.spent[i], distributing) - distributed, 0);
                 nw += g.state[i] != NL_FOLDING && strength[i] == best && g.spent[i] > distributed;
             }
             const int share = chips / nw, bonus = chips % nw;
             int w = 0, staked = 0, paid = 0;
-            for (int i = 0; i < g.n; ++i) {
+            for (int i = 0; i < g.N(); ++i) {
                 if (g.state[i] != NL_FOLDING && strength[i] == best && g.spent[i] > distributed) {
                     reward[i] += share + (w < bonus ? 1 : 0);
                     w += 1;

@@ -41,7 +41,7 @@ namespace rp {
     } while (0)
 
 #define NLMC_A 9u
-typedef NlGameT<2> G2;
+typedef NlGameT<2, 2> G2;  // heads-up: two seats at compile time
 enum : uint32_t { NK_TERMINAL = 0, NK_CHANCE = 1, NK_WALKER = 2, NK_OPP = 3 };
 enum : uint32_t { NERR_NODES = 1u, NERR_STACK = 2u, NERR_WALKERS = 4u, NERR_DECISIONS = 8u, NERR_ILLEGAL = 16u, NERR_TABLE_FULL = 32u };
 
@@ -121,9 +121,9 @@ __device__ __forceinline__ uint64_t nl_key_hash(uint64_t past, uint64_t choices,
 }
 // find or insert; every lane makes progress in every iteration (the winner of a slot writes it inside the same iteration),
 // so lanes of one wavefront that meet on a slot cannot deadlock
-__device__ uint32_t nl_row_of(const NlTable& t, uint64_t past, uint64_t choices, uint32_t present, const uint32_t* edges, uint32_t nch,
-                              uint32_t* err) {
-    uint32_t s = (uint32_t)nl_key_hash(past, choices, present) & t.mask;
+__device__ uint32_t nl_row_of(const NlTable& t, uint64_t past, uint64_t choices, uint32_t present, uint64_t key_hash, const uint32_t* edges,
+                              uint32_t nch, uint32_t* err) {
+    uint32_t s = (uint32_t)key_hash & t.mask;
     for (uint32_t probes = 0; probes <= t.mask; ) {
         const uint32_t st = atomicCAS(&t.state[s], 0u, 1u);
         if (st == 0u) {
@@ -306,7 +306,8 @@ __global__ __launch_bounds__(64) void k_nlhe_traverse(NlParams p, NlTable t, NlS
             uint64_t chpath = 0;
             for (uint32_t a = 0; a < nch; ++a) chpath |= (uint64_t)edges[a] << (5u * a);
             const uint32_t bucket = nl_bucket(p, g.street(), turn == 0 ? hole0 : hole1, g.board);
-            const uint32_t row = nl_row_of(t, cur_past, chpath, bucket, edges, nch, &err);
+            const uint64_t khash = nl_key_hash(cur_past, chpath, bucket);  // the table slot and, at an opponent node, the draw's key
+            const uint32_t row = nl_row_of(t, cur_past, chpath, bucket, khash, edges, nch, &err);
             const float* r = t.rows + (size_t)row * 4u * NLMC_A;
             float rd = 0.0f;
             for (uint32_t a = 0; a < nch; ++a) {
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(64) void k_nlhe_traverse(NlParams p, NlTable t, NlS
                     total += rp_maxf(sw[a] / z, RP_EPSILON);
                     cum[a] = total;
                 }
-                const float u = rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, nl_key_hash(cur_past, chpath, bucket))) * total;
+                const float u = rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, khash)) * total;
                 while (pick + 1 < nch && cum[pick] <= u) ++pick;
                 childfac_opp = sigma[pick] / (sw[pick] / z);
             }
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(256) void k_nlhe_entry_remap(NlTable t, unsigned ch
     if (i >= n) return;
     uint32_t edges[12], nch = 0, err = 0;
     for (uint64_t c = choices[i]; nch < 12u && (c & 0x1full) != 0; c >>= 5) edges[nch++] = (uint32_t)(c & 0x1full);
-    const uint32_t row = nl_row_of(t, past[i], choices[i], present[i], edges, nch, &err);
+    const uint32_t row = nl_row_of(t, past[i], choices[i], present[i], nl_key_hash(past[i], choices[i], present[i]), edges, nch, &err);
     *reinterpret_cast<uint32_t*>(entries + (size_t)i * eb) = row;
     if (err) atomicOr(counters + 2, (unsigned long long)err);
 }
