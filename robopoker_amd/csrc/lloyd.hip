@@ -2283,6 +2283,9 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
     }
 #undef KM_TRY
 #undef KM_HIP
+    // hipMemset on device memory returns before it has run, and a non-blocking stream does not wait for the null stream: the
+    // first launch on this handle's stream could otherwise overtake the initialisation above and be overwritten by it
+    (void)hipDeviceSynchronize();
     *out = h;
     return RP_OK;
 }

@@ -2339,6 +2339,9 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
         return rc;
     }
 #undef CREATE_TRY
+    // hipMemset on device memory returns before it has run, and a non-blocking stream does not wait for the null stream: the
+    // first launch on this handle's stream could otherwise overtake the initialisation above and be overwritten by it
+    (void)hipDeviceSynchronize();
     *out = h;
     return RP_OK;
 }

@@ -214,9 +214,12 @@ __device__ NlAction nl_actionize(const G& g, uint32_t e, uint64_t draw) {  // ga
 template <class G>
 __device__ void nl_settle(const G& g, int* reward) {
     uint32_t strength[G::CAP];
+    // a hand's strength only ranks the seats still in the pot against each other: when everybody else has folded there is
+    // nothing to rank (and most terminal nodes of a betting tree are folds), so the seven-card evaluation is skipped
+    const bool showdown = g.alive() > 1;
     for (int i = 0; i < g.N(); ++i) {
         reward[i] = 0;
-        strength[i] = strength_key(sw_of_hand(g.cards[i] | g.board));
+        strength[i] = showdown ? strength_key(sw_of_hand(g.cards[i] | g.board)) : 1u;
     }
     uint32_t best = 0xffffffffu;
     int distributing = 0, distributed = 0;

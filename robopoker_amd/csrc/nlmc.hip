@@ -692,6 +692,9 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     NL_TRY(nl_alloc(h, &h->d_total, 1));
     NL_TRY(nl_alloc(h, &h->d_counters, 4));
 #undef NL_TRY
+    // hipMemset on device memory returns before it has run, and a non-blocking stream does not wait for the null stream: the
+    // first launch on this handle's stream could otherwise overtake the initialisation above and be overwritten by it
+    (void)hipDeviceSynchronize();
     *out = h;
     return RP_OK;
 }

@@ -840,6 +840,9 @@ int rp_profile_create(int device, uint64_t n_rows, uint32_t max_actions, rp_regr
             return rc;
         }
     }
+    // hipMemset on device memory returns before it has run, and a non-blocking stream does not wait for the null stream: the
+    // first launch on this handle's stream could otherwise overtake the initialisation above and be overwritten by it
+    (void)hipDeviceSynchronize();
     *out = h;
     return RP_OK;
 }
