@@ -3073,6 +3073,7 @@ int rp_sinkhorn_flow(uint32_t bins, const uint32_t* mu, const uint32_t* nu, cons
     HIP_TRY(hipMalloc(&dstats, 32));
     HIP_TRY(hipMemset(dstats, 0, 32));
     HIP_TRY(hipMemset(buf + 2 * cells, 0, cells * 8));
+    HIP_TRY(hipDeviceSynchronize());  // null-stream memsets before launches on other streams
     HIP_TRY(hipMemcpy(buf, C.data(), cells * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(buf + cells, R.data(), cells * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(hist, mu, (size_t)bins * 4, hipMemcpyHostToDevice));

@@ -1803,6 +1803,7 @@ int alloc_batch_buffers(rp_mccfr* h, uint32_t batch) {
     const size_t bytes = (size_t)h->tbl.n_infos * (nblk_max + ngrp_max) * per_slot + (size_t)h->tbl.n_infos * sizeof(uint32_t);
     HIP_TRY(hipMalloc(&h->d_bmaps, bytes));
     HIP_TRY(hipMemset(h->d_bmaps, 0, bytes));
+    HIP_TRY(hipDeviceSynchronize());  // the memset runs on the null stream; the solver's stream is non-blocking (rp_mccfr_set_batch)
     h->capacity = batch;
     return RP_OK;
 }
