@@ -205,3 +205,25 @@ def test_tree_shards_exchanged_by_key_match_the_world_model(gpu, world, batch):
             d.load(*ora.export(), epoch=ora.epoch)
     for d in devs:
         d.close()
+
+
+def test_twin_solvers_at_a_gpu_sized_batch_are_identical(gpu):
+    # two solvers, same seed, 131 072 trees per step (34 GB of scratch each): which lane meets which table slot first is timing,
+    # the tables must not be — every infoset, visit, regret, weight and payoff bit for bit.  (This is the size at which a handle
+    # whose zero-initialisation was still running when its first step started lost infosets: the create functions now
+    # synchronise the device.)
+    res = []
+    for _ in range(2):
+        s = NlheSolver(cap_log2=24, batch=131072, seed=77)
+        for _ in range(2):
+            s.step("composed")
+        past, present, choices, enc = s.export()
+        order = np.lexsort((choices, present, past))
+        res.append((s.counters(), past[order], present[order], choices[order], enc[order]))
+        s.close()
+    a, b = res
+    assert a[0] == b[0] and a[0][1] > 131072 * 2 * 30
+    for i in (1, 2, 3):
+        assert np.array_equal(a[i], b[i])
+    for f in ("visits", "regret", "weight", "payoff"):
+        assert np.array_equal(a[4][f].view(np.uint32), b[4][f].view(np.uint32)), f
