@@ -179,8 +179,11 @@ __device__ __forceinline__ uint32_t nl_bucket(const NlParams& p, int street, uin
     uint64_t cp, cb;
     canonical(pocket, board, &cp, &cb);
     if (p.encoder == 0) {
-        const uint32_t nb = street == 0 ? 169u : (street == 3 ? 101u : 256u);
-        return ((uint32_t)street << 8) | (uint32_t)(rp_mix64((uint64_t)obs_encode(cp, cb) ^ (0x51ed270b5ull * (uint64_t)(street + 1))) % nb);
+        // z mod the street's bucket count (169 / 256 / 256 / 101), each with its own compile-time divisor: a 64-bit remainder by
+        // a run-time divisor is a software routine of a hundred instructions
+        const uint64_t z = rp_mix64((uint64_t)obs_encode(cp, cb) ^ (0x51ed270b5ull * (uint64_t)(street + 1)));
+        const uint32_t idx = street == 0 ? (uint32_t)(z % 169ull) : (street == 3 ? (uint32_t)(z % 101ull) : (uint32_t)(z & 255ull));
+        return ((uint32_t)street << 8) | idx;
     }
     const int64_t at = table_find(p.tkeys[street], p.tn[street], search_key(cp, cb));
     return at < 0 ? 0xffffu : (((uint32_t)street << 8) | (uint32_t)p.tabs[street][at]);
