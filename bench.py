@@ -448,9 +448,17 @@ def timed_mccfr(args, g, batch, rank, world, local_rank, sharded_mode, torch, di
     if sharded_mode and args.comm == "native":
         from robopoker_amd.parallel import Comm
 
+        try:
+            Comm.unique_id()  # opens librccl: fails on every rank alike, before any collective, if the library is not there
+        except Exception as exc:  # noqa: BLE001
+            if rank == 0:
+                print(f"bench: native RCCL communicator unavailable ({exc}); using --comm torch", file=sys.stderr, flush=True)
+            args.comm = "torch"
+    if sharded_mode and args.comm == "native":
+
         # tree ids [rank*B, (rank+1)*B); the library's own RCCL communicator (csrc/comm.cpp): the kernels of a window and its
         # ncclAllGather of the per-cell composed maps are queued on the solver's stream by ONE C call, no host work between
-        comm = Comm.from_process_group(local_rank)
+        comm = Comm.from_process_group(local_rank)  # collective; raises on every rank alike if librccl cannot be opened
         solver.set_shard(rank, world)
         pending = [0]
 
