@@ -54,7 +54,8 @@ def parse():
     ap.add_argument("--game", default="leduc", choices=["leduc", "kuhn", "rps", "leduc_wide"])
     ap.add_argument("--regret", default="floored")
     ap.add_argument("--weight", default="linear")
-    ap.add_argument("--sampling", default="external")
+    ap.add_argument("--sampling", default="external", choices=["external", "prunable", "pluribus"],
+                    help="the SamplingScheme at walker nodes; nlhe: pluribus = the Flagship type (nlhe/src/lib.rs:86-90)")
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--update", default="composed", choices=["composed", "ordered"],
                     help="composed: blocked per-cell map composition (tables within 1e-4/step of the reference's "
@@ -594,7 +595,8 @@ def nlhe_real(args, rank, world, local_rank):
         init_rccl(rank, world)
 
     def run(batch, steps, warmup):
-        s = NlheSolver(cap_log2=args.nlhe_cap, regret="linear", weight="linear", batch=batch, seed=args.seed, device=local_rank)
+        s = NlheSolver(cap_log2=args.nlhe_cap, regret="linear", weight="linear", batch=batch, seed=args.seed, device=local_rank,
+                       sampling=args.sampling)
         if sharded:
             from robopoker_amd.parallel import ShardedNlhe
 

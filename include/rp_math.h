@@ -258,12 +258,18 @@ RP_HD uint64_t rp_mix64(uint64_t z) { /* SplitMix64 finalizer */
     z ^= z >> 31;
     return z;
 }
-RP_HD uint64_t rp_node_hash(uint64_t seed, uint64_t epoch, uint64_t tree, uint64_t key) {
+/* rp_node_hash in two halves: the (seed, epoch) half is the same for every draw of a step (a host computes it once per
+ * launch), the (tree, key) half is per draw.  rp_node_hash is their composition by definition. */
+RP_HD uint64_t rp_node_hash_step(uint64_t seed, uint64_t epoch) {
     uint64_t h = rp_mix64(seed + 0x9e3779b97f4a7c15ull);
-    h = rp_mix64(h ^ (epoch * 0xd1342543de82ef95ull + 0x632be59bd9b4e019ull));
-    h = rp_mix64(h ^ (tree * 0xaf251af3b0f025b5ull + 0x2545f4914f6cdd1dull));
-    h = rp_mix64(h ^ (key * 0x9fb21c651e98df25ull + 0x27d4eb2f165667c5ull));
-    return h;
+    return rp_mix64(h ^ (epoch * 0xd1342543de82ef95ull + 0x632be59bd9b4e019ull));
+}
+RP_HD uint64_t rp_node_hash_draw(uint64_t step_hash, uint64_t tree, uint64_t key) {
+    uint64_t h = rp_mix64(step_hash ^ (tree * 0xaf251af3b0f025b5ull + 0x2545f4914f6cdd1dull));
+    return rp_mix64(h ^ (key * 0x9fb21c651e98df25ull + 0x27d4eb2f165667c5ull));
+}
+RP_HD uint64_t rp_node_hash(uint64_t seed, uint64_t epoch, uint64_t tree, uint64_t key) {
+    return rp_node_hash_draw(rp_node_hash_step(seed, epoch), tree, key);
 }
 /* uniform f32 in [0,1): top 24 bits (rand's random::<f32>() shape) */
 RP_HD float rp_u01(uint64_t h) { return (float)(uint32_t)(h >> 40) * 5.9604644775390625e-8f; }

@@ -348,13 +348,21 @@ RP_API int rp_profile_kernel_time(rp_profile* h, const char* name, double* total
  * table, nlhe/src/profile.rs:20-31) and hashed to rows of an rp_profile table.  The encoder's isomorphism -> abstraction
  * map (NlheEncoder, nlhe/src/encoder.rs:30-36) is the four rp_lookup tables the clustering pipeline produces
  * (tables[street], street = 0 pref .. 3 river); tables = NULL selects a hash of the canonical observation (tests).
- * 2^cap_log2 table rows of 9 actions (144 B each); batch = trees per step (0 = the reference's 128).  External sampling,
- * 2 players, stacks of 100 big blinds.  Oracle: oracle/rp_oracle_nlmc.c. */
+ * 2^cap_log2 table rows of 9 actions (144 B each) + one 32-byte key slot per row; batch = trees per step (0 = the
+ * reference's 128).  2 players, stacks of 100 big blinds.  The batch is grown LEVEL-SYNCHRONOUSLY (all trees one level per
+ * pair of launches, kernels sorted by node kind: robopoker_amd/csrc/nlmc_level.hpp); a batch may hold at most 2^28 / 768
+ * trees.  Sampling scheme: ExternalSampling (the mccfr! macro's default) until rp_nlhe_set_sampling selects
+ * PrunableSampling / PluribusSampling (Flagship, nlhe/src/lib.rs:86-90; thresholds from `hp`).
+ * Oracle: oracle/rp_oracle_nlmc.c. */
 typedef struct rp_nlhe rp_nlhe;
 typedef struct rp_lookup rp_lookup;
 RP_API int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weight_kind weight, const rp_hyper* hp,
                           uint64_t seed, uint32_t batch, const rp_lookup* const* tables, rp_nlhe** out);
 RP_API int rp_nlhe_destroy(rp_nlhe* h);
+/* SamplingScheme::sample at walker nodes (mccfr/src/sample/{external.rs:17-64, pruning.rs:44-66, pluribus.rs:72-101}) */
+RP_API int rp_nlhe_set_sampling(rp_nlhe* h, rp_sampling_kind sampling);
+/* levels grown and nodes created by the last traversed batch (diagnostics of the level-synchronous traversal) */
+RP_API int rp_nlhe_last_shape(rp_nlhe* h, uint32_t* levels, uint32_t* nodes);
 /* Solver::step (solver.rs:96-105): the batch's trees, their Decisions, the table update (ordered or composed), epoch += 1 */
 RP_API int rp_nlhe_step(rp_nlhe* h, rp_update_mode mode);
 /* Solver::batch (solver.rs:225-250) alone, for inspection: the Decisions of the current epoch in tree order, each with

@@ -64,6 +64,7 @@ typedef struct ora_nlmc {
     uint8_t* used;
     uint32_t cap_log2, n_keys;
     int R, W, encoder;
+    int S; /* rp_sampling_kind: External (the mccfr! default), Prunable, Pluribus (nlhe/src/lib.rs:86-90 Flagship) */
     rp_hyper hp;
     uint64_t seed;
     uint32_t batch;
@@ -216,7 +217,32 @@ static void describe(ora_nlmc* h, uint32_t idx) {
 static uint32_t sample_mask(const ora_nlmc* h, uint64_t epoch, uint64_t tree, const nl_node* x, int walker) {
     const uint32_t all = (1u << x->n_choices) - 1u;
     if (x->n_choices == 0) return 0;
-    if (x->turn == walker || x->turn == T_CHANCE) return all; /* the chance node's single Draw edge; its cards are drawn in grow() */
+    if (x->turn == T_CHANCE) return all; /* the chance node's single Draw edge; its cards are drawn in grow() */
+    if (x->turn == walker) {
+        /* PrunableSampling (sample/pruning.rs:44-66) / PluribusSampling (sample/pluribus.rs:72-101) at a walker node:
+         * cum_regret is the RAW accumulated regret (profile.rs:26-30), not the clamped one regret matching reads */
+        if (h->S == RP_SAMPLING_EXTERNAL) return all;
+        const nl_key k = {h->keys[x->row].past, h->keys[x->row].choices, h->keys[x->row].present};
+        if (h->S == RP_SAMPLING_PLURIBUS) {
+            if (epoch < h->hp.prune_warmup) return all;
+            /* profile.rng(node): one stream per (epoch, infoset, tree) (flow.rs:285-295), first draw random::<f32>() */
+            if (rp_u01(rp_node_hash(h->seed, epoch, tree, key_hash(&k))) < h->hp.prune_explore) return all;
+        }
+        rp_encounter e[NLMC_A];
+        ora_profile_get(h->prof, x->row, e);
+        uint32_t mask = 0;
+        for (int a = 0; a < x->n_choices; ++a) {
+            int keep = e[a].regret > h->hp.prune_threshold;
+            if (!keep && h->S == RP_SAMPLING_PLURIBUS) { /* game.turn().is_terminal() of the BRANCH's game (pluribus.rs:96) */
+                ora_game c = x->g;
+                uint64_t none = 0;
+                ora_nlhe_apply_edge(&c, x->choice[a], &none); /* a walker node's choices are never Draw */
+                keep = ora_nlhe_turn(&c) == T_TERMINAL;
+            }
+            if (keep) mask |= 1u << a;
+        }
+        return mask ? mask : all; /* pruning.rs:64, pluribus.rs:99 */
+    }
     nl_view v;
     view_row(h, x->row, x->n_choices, &v);
     const float denom = weight_denom(h, &v, x->n_choices), z = sampling_z(h, &v, x->n_choices, denom);
@@ -417,6 +443,8 @@ ORA_API ora_nlmc* ora_nlmc_create(uint32_t cap_log2, int R, int W, const rp_hype
     h->used = (uint8_t*)calloc(1ull << cap_log2, 1);
     return h;
 }
+/* SamplingScheme of the solver type (the macro's default is ExternalSampling; Flagship uses PluribusSampling) */
+ORA_API void ora_nlmc_set_sampling(ora_nlmc* h, int sampling) { h->S = sampling; }
 ORA_API void ora_nlmc_destroy(ora_nlmc* h) {
     if (!h) return;
     ora_profile_destroy(h->prof);
@@ -587,4 +615,21 @@ ORA_API void ora_nlmc_import(ora_nlmc* h, uint64_t n, const uint64_t* past, cons
         const uint32_t r = row_of(h, &k, e, m);
         ora_profile_set_row(h->prof, r, enc + i * NLMC_A);
     }
+}
+/* shape of the LAST tree built (sizing the device's level-synchronous expansion): nodes per depth into levels[0..cap),
+ * kinds[4] = terminal, chance, walker, opponent node counts; returns the tree's depth (levels used) */
+ORA_API uint32_t ora_nlmc_last_tree_shape(const ora_nlmc* h, int walker, uint32_t* levels, uint32_t cap, uint32_t* kinds) {
+    uint32_t depth = 0;
+    uint32_t* d = (uint32_t*)calloc(h->n ? h->n : 1, sizeof(uint32_t));
+    for (uint32_t l = 0; l < cap; ++l) levels[l] = 0;
+    for (int k = 0; k < 4; ++k) kinds[k] = 0;
+    for (uint32_t i = 0; i < h->n; ++i) {
+        const nl_node* x = &h->nd[i];
+        d[i] = x->parent < 0 ? 0 : d[x->parent] + 1; /* a parent's index is below its children's */
+        if (d[i] < cap) levels[d[i]] += 1;
+        if (d[i] + 1 > depth) depth = d[i] + 1;
+        kinds[x->turn == T_TERMINAL ? 0 : (x->turn == T_CHANCE ? 1 : (x->turn == walker ? 2 : 3))] += 1;
+    }
+    free(d);
+    return depth;
 }

@@ -38,6 +38,16 @@ struct NlGameT {
     int state[MAXP], stack[MAXP], stake[MAXP], spent[MAXP];
     uint64_t cards[MAXP];
 
+    // seat arrays are indexed by the actor: with two compile-time seats a select keeps them in registers (a run-time index
+    // would send every game of the traversal kernels through scratch memory)
+    __device__ __forceinline__ int at(const int* a, int i) const {
+        if constexpr (FIXN == 2) {
+            const int x0 = a[0], x1 = a[1];  // both loads first: a conditional LOAD would be folded back into an indexed one
+            return i ? x1 : x0;
+        } else {
+            return a[i];
+        }
+    }
     __device__ int street() const {  // Board::street
         const int c = __popcll(board);
         return c == 0 ? 0 : (c == 3 ? 1 : (c == 4 ? 2 : 3));
@@ -45,6 +55,7 @@ struct NlGameT {
     __device__ int actor() const { return (dealer + ticker) % N(); }  // game.rs:656-658
     __device__ int max_stake() const {                              // :693-695
         int m = stake[0];
+        _Pragma("unroll")
         for (int i = 1; i < N(); ++i) m = max(m, stake[i]);
         return m;
     }
@@ -53,16 +64,19 @@ struct NlGameT {
     __device__ bool matched() const {
         const int top = max_stake();
         bool ok = true;
+        _Pragma("unroll")
         for (int i = 0; i < N(); ++i) ok = ok && !(state[i] == NL_BETTING && stake[i] != top);
         return ok;
     }
     __device__ int alive() const {
         int a = 0;
+        _Pragma("unroll")
         for (int i = 0; i < N(); ++i) a += state[i] != NL_FOLDING;
         return a;
     }
     __device__ bool all_shoving() const {
         bool ok = true;
+        _Pragma("unroll")
         for (int i = 0; i < N(); ++i) ok = ok && (state[i] == NL_FOLDING || state[i] == NL_SHOVING);
         return ok;
     }
@@ -73,11 +87,12 @@ struct NlGameT {
     __device__ bool must_post() const { return street() == 0 && pot < NL_SBLIND + NL_BBLIND; }
     __device__ int turn() const { return must_stop() ? NT_TERMINAL : (must_deal() ? NT_CHANCE : actor()); }  // :166-174
     // ---- amounts (game.rs:537-576) ----
-    __device__ int to_call() const { return max_stake() - stake[actor()]; }
-    __device__ int to_post() const { return min(pot < NL_SBLIND ? NL_SBLIND : NL_BBLIND, stack[actor()]); }
-    __device__ int to_shove() const { return stack[actor()]; }
+    __device__ int to_call() const { return max_stake() - at(stake, actor()); }
+    __device__ int to_post() const { return min(pot < NL_SBLIND ? NL_SBLIND : NL_BBLIND, at(stack, actor())); }
+    __device__ int to_shove() const { return at(stack, actor()); }
     __device__ int to_raise() const {
         int most = 0, next = 0;
+        _Pragma("unroll")
         for (int i = 0; i < N(); ++i) {
             if (state[i] == NL_FOLDING) continue;
             if (stake[i] > most) {
@@ -87,17 +102,18 @@ struct NlGameT {
                 next = stake[i];
             }
         }
-        return (most - stake[actor()]) + max(most - next, NL_BBLIND);
+        return (most - at(stake, actor())) + max(most - next, NL_BBLIND);
     }
     // ---- permissions (game.rs:513-531) ----
     __device__ bool choosing() const { return turn() >= 0; }
     __device__ bool may_fold() const { return choosing() && to_call() > 0; }
     __device__ bool may_call() const { return may_fold() && to_call() < to_shove(); }
-    __device__ bool may_check() const { return choosing() && max_stake() == stake[actor()]; }
+    __device__ bool may_check() const { return choosing() && max_stake() == at(stake, actor()); }
     __device__ bool may_raise() const { return choosing() && to_raise() < to_shove(); }
     __device__ bool may_shove() const { return choosing() && to_shove() > 0; }
     __device__ uint64_t deck() const {  // :644-650
         uint64_t gone = board;
+        _Pragma("unroll")
         for (int i = 0; i < N(); ++i) gone |= cards[i];
         return ~gone & HAND_MASK;
     }
@@ -105,17 +121,33 @@ struct NlGameT {
     __device__ void next_player() {
         if (alright()) return;
         do ticker += 1;
-        while (state[actor()] != NL_BETTING);
+        while (at(state, actor()) != NL_BETTING);
     }
     __device__ void force_act(const NlAction& a) {
         const int me = actor();
-        if (a.kind == NA_FOLD) state[me] = NL_FOLDING;
-        if (a.kind == NA_CALL || a.kind == NA_BLIND || a.kind == NA_RAISE || a.kind == NA_SHOVE) {
-            pot += a.chips;
-            stack[me] -= a.chips;
-            stake[me] += a.chips;
-            spent[me] += a.chips;
-            if (stack[me] == 0) state[me] = NL_SHOVING;
+        const bool pays = a.kind == NA_CALL || a.kind == NA_BLIND || a.kind == NA_RAISE || a.kind == NA_SHOVE;
+        if constexpr (FIXN == 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {  // the same updates as below, the seat selected instead of indexed
+                const bool mine = i == me;
+                if (mine && a.kind == NA_FOLD) state[i] = NL_FOLDING;
+                if (mine && pays) {
+                    stack[i] -= a.chips;
+                    stake[i] += a.chips;
+                    spent[i] += a.chips;
+                    if (stack[i] == 0) state[i] = NL_SHOVING;
+                }
+            }
+            if (pays) pot += a.chips;
+        } else {
+            if (a.kind == NA_FOLD) state[me] = NL_FOLDING;
+            if (pays) {
+                pot += a.chips;
+                stack[me] -= a.chips;
+                stake[me] += a.chips;
+                spent[me] += a.chips;
+                if (stack[me] == 0) state[me] = NL_SHOVING;
+            }
         }
         if (a.kind == NA_DRAW) {
             ticker = 0;
@@ -123,6 +155,7 @@ struct NlGameT {
         }
         next_player();
         if (a.kind == NA_DRAW)
+            _Pragma("unroll")
             for (int i = 0; i < N(); ++i) stake[i] = 0;  // next_street
     }
     // is_allowed (game.rs:297-319) for the kinds a solver produces
@@ -166,8 +199,22 @@ struct NlGameT {
 // ---- the action abstraction (edge.rs:77-92, size.rs:95-138, pokerkit/src/lib.rs:81-151; Pluribus regime) ----
 __device__ __constant__ int8_t NL_OPENS[4] = {2, 3, 4, 5};
 __device__ __constant__ int8_t NL_RAISES[10][2] = {{1, 4}, {1, 3}, {1, 2}, {2, 3}, {3, 4}, {1, 1}, {5, 4}, {3, 2}, {2, 1}, {3, 1}};
-__device__ __constant__ int8_t NL_GRID[12][6] = {{-1}, {5, 8, -1}, {5, -1}, {0, 2, 4, 5, 8, -1}, {2, 5, -1}, {5, -1}, {1, 2, 5, 8, -1},
-                                                  {5, 8, -1}, {5, -1}, {1, 2, 5, 8, -1}, {5, 8, -1}, {5, -1}};
+#define NL_GRID_INIT                                                                                                          \
+    {{-1}, {5, 8, -1}, {5, -1}, {0, 2, 4, 5, 8, -1}, {2, 5, -1}, {5, -1}, {1, 2, 5, 8, -1}, {5, 8, -1}, {5, -1}, {1, 2, 5, 8, -1}, \
+     {5, 8, -1}, {5, -1}}
+__device__ __constant__ int8_t NL_GRID[12][6] = NL_GRID_INIT;
+// the same grid as a compile-time table, and every row as a ready-made piece of a choices Path: the row's Raise edges
+// in 5-bit fields (path.rs), their count in bits 27..29 — nl_choices_path (nlmc_common.hpp) ORs it in instead of looping
+constexpr int8_t NL_GRID_CE[12][6] = NL_GRID_INIT;
+constexpr uint32_t nl_grid_packed(int r) {
+    uint32_t p = 0, k = 0;
+    for (int i = 0; i < 6 && NL_GRID_CE[r][i] >= 0; ++i, ++k) p |= (uint32_t)(NE_RAISE0 + NL_GRID_CE[r][i]) << (5u * k);
+    return p | (k << 27);
+}
+__device__ __constant__ uint32_t NL_GRIDP[12] = {nl_grid_packed(0), nl_grid_packed(1), nl_grid_packed(2),  nl_grid_packed(3),
+                                                 nl_grid_packed(4), nl_grid_packed(5), nl_grid_packed(6),  nl_grid_packed(7),
+                                                 nl_grid_packed(8), nl_grid_packed(9), nl_grid_packed(10), nl_grid_packed(11)};
+constexpr uint32_t NL_OPENSP = (NE_OPEN0 + 0u) | ((NE_OPEN0 + 1u) << 5) | ((NE_OPEN0 + 2u) << 10) | ((NE_OPEN0 + 3u) << 15) | (4u << 27);
 __device__ int nl_raise_edges(int street, int depth, uint32_t* out) {
     int k = 0;
     if (depth > 3) return 0;  // MAX_RAISE_REPEATS
@@ -210,22 +257,31 @@ __device__ NlAction nl_actionize(const G& g, uint32_t e, uint64_t draw) {  // ga
     }
     return NlAction{NA_RAISE, nl_edge_chips(e, g.pot), 0};
 }
-// Showdown::settle (showdown.rs:36-109) on the seats of a terminal game; reward[i] = chips received
+// Showdown::settle (showdown.rs:36-109) on the seats of a terminal game; reward[i] = chips received.  The strengths enter only
+// through comparisons, so any keys with the showdown's order give the showdown's rewards (nl_settle_ranked: the level-
+// synchronous traversal ranks the two hands once per river card, not once per terminal node).
+template <class G>
+__device__ void nl_settle_ranked(const G& g, const uint32_t* strength, int* reward);
 template <class G>
 __device__ void nl_settle(const G& g, int* reward) {
     uint32_t strength[G::CAP];
     // a hand's strength only ranks the seats still in the pot against each other: when everybody else has folded there is
     // nothing to rank (and most terminal nodes of a betting tree are folds), so the seven-card evaluation is skipped
     const bool showdown = g.alive() > 1;
-    for (int i = 0; i < g.N(); ++i) {
-        reward[i] = 0;
-        strength[i] = showdown ? strength_key(sw_of_hand(g.cards[i] | g.board)) : 1u;
-    }
+    _Pragma("unroll")
+    for (int i = 0; i < g.N(); ++i) strength[i] = showdown ? strength_key(sw_of_hand(g.cards[i] | g.board)) : 1u;
+    nl_settle_ranked(g, strength, reward);
+}
+template <class G>
+__device__ void nl_settle_ranked(const G& g, const uint32_t* strength, int* reward) {
+    _Pragma("unroll")
+    for (int i = 0; i < g.N(); ++i) reward[i] = 0;
     uint32_t best = 0xffffffffu;
     int distributing = 0, distributed = 0;
     for (;;) {
         bool found = false;
         uint32_t top = 0;
+        _Pragma("unroll")
         for (int i = 0; i < g.N(); ++i)
             if (strength[i] < best && g.state[i] != NL_FOLDING && (!found || strength[i] > top)) {
                 found = true;
@@ -236,18 +292,21 @@ __device__ void nl_settle(const G& g, int* reward) {
         for (;;) {
             distributed = distributing;
             int amount = -1;
+            _Pragma("unroll")
             for (int i = 0; i < g.N(); ++i)
                 if (strength[i] == best && g.spent[i] > distributed && g.state[i] != NL_FOLDING && (amount < 0 || g.spent[i] < amount))
                     amount = g.spent[i];
             if (amount < 0) break;
             distributing = amount;
             int chips = 0, nw = 0;
+            _Pragma("unroll")
             for (int i = 0; i < g.N(); ++i) {
                 chips += max(min(g.spent[i], distributing) - distributed, 0);
                 nw += g.state[i] != NL_FOLDING && strength[i] == best && g.spent[i] > distributed;
             }
             const int share = chips / nw, bonus = chips % nw;
             int w = 0, staked = 0, paid = 0;
+            _Pragma("unroll")
             for (int i = 0; i < g.N(); ++i) {
                 if (g.state[i] != NL_FOLDING && strength[i] == best && g.spent[i] > distributed) {
                     reward[i] += share + (w < bonus ? 1 : 0);

@@ -27,9 +27,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "../../include/rp_math.h"
-#include "nlhe_engine.hpp"
-#include "obs.hpp"
+#include "nlmc_level.hpp"
 #include "rp_internal.h"
 
 namespace rp {
@@ -40,34 +38,10 @@ namespace rp {
         if (_e != hipSuccess) return rp::fail(RP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
-#define NLMC_A 9u
-typedef NlGameT<2, 2> G2;  // heads-up: two seats at compile time
-enum : uint32_t { NK_TERMINAL = 0, NK_CHANCE = 1, NK_WALKER = 2, NK_OPP = 3 };
-enum : uint32_t { NERR_NODES = 1u, NERR_STACK = 2u, NERR_WALKERS = 4u, NERR_DECISIONS = 8u, NERR_ILLEGAL = 16u, NERR_TABLE_FULL = 32u };
-
-struct NlTable {  // NlheInfo -> row: open addressing, linear probing; slot index = row of the profile
-    uint64_t* past;
-    uint64_t* choices;
-    uint32_t* present;
-    uint32_t* state;  // 0 empty, 1 being written, 2 ready
-    uint32_t mask;
-    unsigned int* n_keys;
-    float* rows;  // the profile's table: row r = rows + r * 4A: regret[A] weight[A] payoff[A] visits[A]
-};
-
-struct NlParams {
-    uint64_t seed, epoch;
-    uint32_t batch, walker;
-    uint64_t tree_base;  // first tree id of this rank's shard (rank * batch)
-    float temperature, smoothing, curiosity;
-    int encoder;  // 0: hash of the canonical observation, 1: lookup tables
-    const uint64_t* tkeys[4];
-    const uint8_t* tabs[4];
-    uint64_t tn[4];
-    uint32_t ncap, scap, wcap, dcap;  // per-tree capacities: nodes, stack entries, walker nodes, Decisions
-    uint32_t check_legal;             // evaluate Game::is_allowed on every applied action (RP_NLHE_CHECK_LEGAL=1)
-};
-
+// ================================================================================================================
+// The first device version: ONE LANE PER TREE.  Kept as an independent cross-check of the level-synchronous traversal
+// (RP_NLHE_LANE_PER_TREE=1; tests/test_gpu_nlmc.py compares the two bit for bit) — not the product path.
+// ================================================================================================================
 // per-tree scratch, tree-major (a lane walks its own region sequentially)
 struct NlScratch {
     uint32_t* meta;    // [batch][ncap]  parent (13) | slot (4) << 13 | kind (2) << 17 | n_choices (4) << 19
@@ -88,157 +62,6 @@ struct NlScratch {
     uint32_t* dcount;  // [batch]
     uint32_t* ncount;  // [batch] nodes of the tree
 };
-
-// the 2-seat game in five dwords (chips fit a byte: the stack is 200)
-struct Packed {
-    uint32_t w0, w1, w2, blo, bhi;
-};
-__device__ __forceinline__ Packed pack_game(const G2& g) {
-    Packed p;
-    p.w0 = (uint32_t)g.ticker | ((uint32_t)g.pot << 8) | ((uint32_t)g.state[0] << 24) | ((uint32_t)g.state[1] << 26);
-    p.w1 = (uint32_t)g.stack[0] | ((uint32_t)g.stake[0] << 8) | ((uint32_t)g.spent[0] << 16);
-    p.w2 = (uint32_t)g.stack[1] | ((uint32_t)g.stake[1] << 8) | ((uint32_t)g.spent[1] << 16);
-    p.blo = (uint32_t)g.board;
-    p.bhi = (uint32_t)(g.board >> 32);
-    return p;
-}
-__device__ __forceinline__ void unpack_game(const Packed& p, G2& g) {
-    g.ticker = (int)(p.w0 & 0xffu);
-    g.pot = (int)((p.w0 >> 8) & 0xffffu);
-    g.state[0] = (int)((p.w0 >> 24) & 3u);
-    g.state[1] = (int)((p.w0 >> 26) & 3u);
-    g.stack[0] = (int)(p.w1 & 0xffu); g.stake[0] = (int)((p.w1 >> 8) & 0xffu); g.spent[0] = (int)((p.w1 >> 16) & 0xffu);
-    g.stack[1] = (int)(p.w2 & 0xffu); g.stake[1] = (int)((p.w2 >> 8) & 0xffu); g.spent[1] = (int)((p.w2 >> 16) & 0xffu);
-    g.board = (uint64_t)p.blo | ((uint64_t)p.bhi << 32);
-}
-
-// kicker/src/edge.rs:61-72 with BiasHyperParams::default (bias.rs:47-70)
-__device__ __forceinline__ float nl_default_regret(uint32_t e) {
-    return e == NE_FOLD ? 100.0f : (e == NE_SHOVE ? 0.0f : ((e == NE_CHECK || e == NE_CALL) ? 50.0f : 10.0f));
-}
-__device__ __forceinline__ uint64_t nl_key_hash(uint64_t past, uint64_t choices, uint32_t present) {
-    return rp_mix64(rp_mix64(past ^ 0x9e3779b97f4a7c15ull) ^ rp_mix64(choices + 0xd1342543de82ef95ull) ^ ((uint64_t)present * 0xaf251af3b0f025b5ull));
-}
-// find or insert; every lane makes progress in every iteration (the winner of a slot writes it inside the same iteration),
-// so lanes of one wavefront that meet on a slot cannot deadlock
-__device__ uint32_t nl_row_of(const NlTable& t, uint64_t past, uint64_t choices, uint32_t present, uint64_t key_hash, const uint32_t* edges,
-                              uint32_t nch, uint32_t* err) {
-    uint32_t s = (uint32_t)key_hash & t.mask;
-    for (uint32_t probes = 0; probes <= t.mask; ) {
-        const uint32_t st = atomicCAS(&t.state[s], 0u, 1u);
-        if (st == 0u) {
-            t.past[s] = past;
-            t.choices[s] = choices;
-            t.present[s] = present;
-            float* row = t.rows + (size_t)s * 4u * NLMC_A;
-            for (uint32_t a = 0; a < nch; ++a) row[a] = nl_default_regret(edges[a]);
-            __threadfence();
-            atomicExch(&t.state[s], 2u);
-            atomicAdd(t.n_keys, 1u);
-            return s;
-        }
-        if (st == 1u) continue;  // being written by another lane or wavefront: look again
-        __threadfence();
-        if (t.past[s] == past && t.choices[s] == choices && t.present[s] == present) return s;
-        s = (s + 1u) & t.mask;
-        probes += 1;
-    }
-    *err |= NERR_TABLE_FULL;
-    return 0;
-}
-
-__device__ __forceinline__ uint64_t nl_draw(uint64_t deck, int k, const NlParams& p, uint64_t tree, uint64_t key) {  // tree = its id in the epoch
-    uint64_t out = 0;
-    for (int c = 0; c < k; ++c) {
-        const uint32_t pick = rp_pick_uniform(rp_node_hash(p.seed, p.epoch, tree, key + (uint64_t)c), (uint32_t)__popcll(deck));
-        // the pick-th lowest card of the deck: a popcount search (a loop clearing `pick` bits runs up to 51 rounds at the few
-        // lanes of a wavefront that sit at a chance node)
-        uint32_t k = pick, w = (uint32_t)deck, base = 0;
-        const uint32_t plo = (uint32_t)__popc(w);
-        if (k >= plo) {
-            k -= plo;
-            w = (uint32_t)(deck >> 32);
-            base = 32;
-        }
-#pragma unroll
-        for (uint32_t half = 16; half >= 1; half >>= 1) {
-            const uint32_t c = (uint32_t)__popc(w & ((1u << half) - 1u));
-            const bool up = k >= c;
-            k -= up ? c : 0u;
-            w = up ? w >> half : w & ((1u << half) - 1u);
-            base += up ? half : 0u;
-        }
-        const uint64_t card = 1ull << base;
-        out |= card;
-        deck &= ~card;
-    }
-    return out;
-}
-// NlheEncoder::abstraction (nlhe/src/encoder.rs:30-36); Abstraction = [8 bits street][8 bits index] (kicker/src/abstraction.rs:14-24)
-__device__ __forceinline__ uint32_t nl_bucket(const NlParams& p, int street, uint64_t pocket, uint64_t board) {
-    uint64_t cp, cb;
-    canonical(pocket, board, &cp, &cb);
-    if (p.encoder == 0) {
-        // z mod the street's bucket count (169 / 256 / 256 / 101), each with its own compile-time divisor: a 64-bit remainder by
-        // a run-time divisor is a software routine of a hundred instructions
-        const uint64_t z = rp_mix64((uint64_t)obs_encode(cp, cb) ^ (0x51ed270b5ull * (uint64_t)(street + 1)));
-        const uint32_t idx = street == 0 ? (uint32_t)(z % 169ull) : (street == 3 ? (uint32_t)(z % 101ull) : (uint32_t)(z & 255ull));
-        return ((uint32_t)street << 8) | idx;
-    }
-    const int64_t at = table_find(p.tkeys[street], p.tn[street], search_key(cp, cb));
-    return at < 0 ? 0xffffu : (((uint32_t)street << 8) | (uint32_t)p.tabs[street][at]);
-}
-
-// What NlheGame::apply needs from the state of a DECISION node, computed once per node: every child of the node is
-// game.apply(game.snap(game.actionize(edge))) on the SAME game (nlhe/src/game.rs:50-70), and actor / amounts / permissions
-// (kicker game.rs:513-576) do not depend on the edge.  nl_choices_v / nl_action_v are GameN::choices (game.rs:724-739) and
-// actionize + snap (:741-753, :835-854) over those cached values: the same decisions as the engine's own functions
-// (nlhe_engine.hpp), which recompute them from the seats at every call.
-struct NlView {
-    int to_call, to_shove, to_raise, pot, street;
-    bool may_fold, may_call, may_check, may_raise, may_shove, must_post;
-};
-__device__ __forceinline__ NlView nl_view(const G2& g) {  // g.turn() is a player
-    NlView v;
-    const int me = g.actor(), ms = g.max_stake();
-    v.to_call = ms - g.stake[me];
-    v.to_shove = g.stack[me];
-    v.to_raise = g.to_raise();
-    v.pot = g.pot;
-    v.street = g.street();
-    v.may_fold = v.to_call > 0;
-    v.may_call = v.may_fold && v.to_call < v.to_shove;
-    v.may_check = ms == g.stake[me];
-    v.may_raise = v.to_raise < v.to_shove;
-    v.may_shove = v.to_shove > 0;
-    v.must_post = g.must_post();
-    return v;
-}
-__device__ __forceinline__ int nl_choices_v(const NlView& v, int depth, uint32_t* out) {
-    int k = 0;
-    if (v.must_post) return 0;
-    if (v.may_raise) k += nl_raise_edges(v.street, depth, out + k);
-    if (v.may_shove) out[k++] = NE_SHOVE;
-    if (v.may_call) out[k++] = NE_CALL;
-    if (v.may_fold) out[k++] = NE_FOLD;
-    if (v.may_check) out[k++] = NE_CHECK;
-    return k;
-}
-__device__ __forceinline__ NlAction nl_action_v(const NlView& v, uint32_t e) {  // snap(actionize(e)), e is not a draw
-    const NlAction shove{NA_SHOVE, v.to_shove, 0}, calls{NA_CALL, v.to_call, 0};
-    const NlAction passive{v.may_check ? NA_CHECK : NA_FOLD, 0, 0};
-    if (e == NE_FOLD) return v.may_fold ? NlAction{NA_FOLD, 0, 0} : NlAction{NA_CHECK, 0, 0};
-    if (e == NE_CHECK) return v.may_check ? NlAction{NA_CHECK, 0, 0} : (v.may_call ? calls : NlAction{NA_FOLD, 0, 0});
-    if (e == NE_CALL) return v.may_call ? calls : (v.may_shove ? shove : passive);
-    bool is_shove = e == NE_SHOVE;
-    int chips = 0;
-    if (!is_shove) {  // a raise edge
-        chips = nl_edge_chips(e, v.pot);
-        if (chips >= v.to_shove || !v.may_raise) is_shove = true;  // Raise turns into Shove, which is snapped once more
-        else return NlAction{NA_RAISE, chips < v.to_raise ? v.to_raise : chips, 0};
-    }
-    return v.may_shove ? shove : (v.may_call ? calls : passive);
-}
 
 // stack entry: [0..4] packed game, [5] parent | slot << 13 | edge << 17 | depth << 22 | plen << 25, [6,7] past, [8,9] hkey, [10] fac
 #define NL_SENT 12u
@@ -308,9 +131,9 @@ __global__ __launch_bounds__(64) void k_nlhe_traverse(NlParams p, NlTable t, NlS
             nch = (uint32_t)nl_choices_v(view, (int)cur_depth, edges);
             uint64_t chpath = 0;
             for (uint32_t a = 0; a < nch; ++a) chpath |= (uint64_t)edges[a] << (5u * a);
-            const uint32_t bucket = nl_bucket(p, g.street(), turn == 0 ? hole0 : hole1, g.board);
+            const uint32_t bucket = nl_bucket(p, g.street(), turn == 0 ? hole0 : hole1, g.board, &err);
             const uint64_t khash = nl_key_hash(cur_past, chpath, bucket);  // the table slot and, at an opponent node, the draw's key
-            const uint32_t row = nl_row_of(t, cur_past, chpath, bucket, khash, edges, nch, &err);
+            const uint32_t row = nl_row_of(t, cur_past, chpath, bucket, khash, nch, p.tag, &err);
             const float* r = t.rows + (size_t)row * 4u * NLMC_A;
             float rd = 0.0f;
             for (uint32_t a = 0; a < nch; ++a) {
@@ -347,7 +170,7 @@ __global__ __launch_bounds__(64) void k_nlhe_traverse(NlParams p, NlTable t, NlS
                     total += rp_maxf(sw[a] / z, RP_EPSILON);
                     cum[a] = total;
                 }
-                const float u = rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, khash)) * total;
+                const float u = rp_u01(rp_node_hash_draw(p.step_hash, tree_id, khash)) * total;
                 while (pick + 1 < nch && cum[pick] <= u) ++pick;
                 childfac_opp = sigma[pick] / (sw[pick] / z);
             }
@@ -477,40 +300,6 @@ __global__ __launch_bounds__(64) void k_nlhe_traverse(NlParams p, NlTable t, NlS
     if (err) atomicOr(counters + 2, (unsigned long long)err);
 }
 
-// exclusive scan of the per-tree Decisions counts (one workgroup; a batch has at most a few 10^5 trees)
-__global__ __launch_bounds__(1024) void k_nlhe_scan(const uint32_t* dcount, uint32_t batch, uint32_t* offset, uint32_t* total) {
-    __shared__ uint32_t part[1024];
-    const uint32_t tid = threadIdx.x, per = (batch + 1023u) / 1024u;
-    uint32_t s = 0;
-    for (uint32_t i = tid * per; i < min(batch, (tid + 1) * per); ++i) s += dcount[i];
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (uint32_t i = 0; i < 1024; ++i) {
-            const uint32_t v = part[i];
-            part[i] = run;
-            run += v;
-        }
-        *total = run;
-    }
-    __syncthreads();
-    uint32_t run = part[tid];
-    for (uint32_t i = tid * per; i < min(batch, (tid + 1) * per); ++i) {
-        offset[i] = run;
-        run += dcount[i];
-    }
-}
-
-struct NlBatch {  // rp_decisions layout
-    uint32_t* row;
-    uint8_t* nact;
-    uint16_t* expanded;
-    float* regret;
-    float* policy;
-    float* payoff;
-    uint32_t* tree;
-};
 __global__ __launch_bounds__(256) void k_nlhe_pack(NlScratch sc, uint32_t batch, uint32_t dcap, const uint32_t* offset, NlBatch out) {
     const uint32_t tree = blockIdx.x;
     const uint32_t nd = sc.dcount[tree], base = offset[tree];
@@ -537,19 +326,19 @@ __global__ __launch_bounds__(256) void k_nlhe_entry_keys(NlTable t, const unsign
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint32_t row = *reinterpret_cast<const uint32_t*>(entries + (size_t)i * eb);
-    past[i] = t.past[row];
-    present[i] = t.present[row];
-    choices[i] = t.choices[row];
+    past[i] = t.slots[row].past;
+    present[i] = t.slots[row].present;
+    choices[i] = t.slots[row].choices;
 }
 __global__ __launch_bounds__(256) void k_nlhe_entry_remap(NlTable t, unsigned char* entries, uint32_t eb, uint32_t n, const uint64_t* past,
-                                                          const uint32_t* present, const uint64_t* choices, unsigned long long* counters) {
+                                                          const uint32_t* present, const uint64_t* choices, uint32_t tag, uint32_t* errflags) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    uint32_t edges[12], nch = 0, err = 0;
-    for (uint64_t c = choices[i]; nch < 12u && (c & 0x1full) != 0; c >>= 5) edges[nch++] = (uint32_t)(c & 0x1full);
-    const uint32_t row = nl_row_of(t, past[i], choices[i], present[i], nl_key_hash(past[i], choices[i], present[i]), edges, nch, &err);
+    uint32_t nch = 0, err = 0;
+    for (uint64_t c = choices[i]; nch < 12u && (c & 0x1full) != 0; c >>= 5) nch += 1;
+    const uint32_t row = nl_row_of(t, past[i], choices[i], present[i], nl_key_hash(past[i], choices[i], present[i]), nch, tag, &err);
     *reinterpret_cast<uint32_t*>(entries + (size_t)i * eb) = row;
-    if (err) atomicOr(counters + 2, (unsigned long long)err);
+    if (err) atomicOr(errflags, err);
 }
 
 }  // namespace rp
@@ -564,14 +353,20 @@ struct rp_nlhe {
     uint64_t seed = 0;
     NlTable tab{};
     NlParams prm{};
-    NlScratch sc{};
+    bool lane_per_tree = false;  // RP_NLHE_LANE_PER_TREE=1: the first device version (cross-check)
+    NlScratch sc{};              // lane-per-tree scratch (allocated in that mode only)
+    NlNodes lv{};                // level-synchronous traversal
     NlBatch out{};
     uint32_t out_cap = 0;
     uint32_t* d_offset = nullptr;
-    uint32_t* d_total = nullptr;
-    unsigned long long* d_counters = nullptr;  // nodes, infos, error flags
+    uint32_t* d_total = nullptr;   // [0] Decisions of the batch, [1] walker nodes of the batch
+    unsigned long long* d_counters = nullptr;  // lane-per-tree kernel: nodes, infos, error flags of the launch
+    uint32_t* d_remap_err = nullptr;           // rp_nlhe_step_apply: table full while inserting exchanged keys
     std::vector<void*> allocs;
     uint32_t last_n = 0;
+    uint32_t tag = 0;              // launch tags handed to nl_row_of (never 0)
+    uint64_t nodes = 0, infos = 0;  // Metrics (mccfr/src/metrics/mod.rs): nodes grown, Decisions recorded
+    uint32_t last_levels = 0, last_nodes = 0;
 };
 
 namespace {
@@ -584,11 +379,28 @@ int nl_alloc(rp_nlhe* h, T** out, size_t count) {
     *out = reinterpret_cast<T*>(p);
     return RP_OK;
 }
-// the traversal of the current epoch: Decisions in h->out, their count in h->last_n
-int nl_traverse(rp_nlhe* h) {
-    hipStream_t st = rp::profile_stream(h->prof);
+uint32_t nl_next_tag(rp_nlhe* h) {
+    h->tag += 1;
+    if (h->tag == 0) h->tag = 1;
+    return h->tag;
+}
+int nl_capacity_error(unsigned long long flags) {
+    return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: traversal failed (flags %llu: 1 node budget, 2 stack, 4 walker nodes of a tree, 8 decisions, "
+                                     "16 illegal action, 32 infoset table full, 64 isomorphism not found in the encoder table, 128 tree deeper "
+                                     "than the level table, 256 work list full)", flags);
+}
+void nl_begin_step(rp_nlhe* h) {
     h->prm.epoch = rp::profile_epoch(h->prof);
     h->prm.walker = (uint32_t)(h->prm.epoch % 2u);  // CfrSampling::walker (book.rs:142-144)
+    h->prm.step_hash = rp_node_hash_step(h->prm.seed, h->prm.epoch);
+}
+
+// ---- the lane-per-tree traversal of the current epoch: Decisions in h->out, their count in h->last_n
+int nl_traverse_lanes(rp_nlhe* h) {
+    hipStream_t st = rp::profile_stream(h->prof);
+    nl_begin_step(h);
+    h->prm.tag = nl_next_tag(h);
+    HIP_TRY(hipMemsetAsync(h->d_counters, 0, 3 * sizeof(unsigned long long), st));  // per launch: an error does not stick to the handle
     hipLaunchKernelGGL(k_nlhe_traverse, dim3((h->batch + 63u) / 64u), dim3(64), 0, st, h->prm, h->tab, h->sc, h->d_counters);
     hipLaunchKernelGGL(k_nlhe_scan, dim3(1), dim3(1024), 0, st, h->sc.dcount, h->batch, h->d_offset, h->d_total);
     HIP_TRY(hipGetLastError());
@@ -597,14 +409,73 @@ int nl_traverse(rp_nlhe* h) {
     HIP_TRY(hipMemcpyAsync(&total, h->d_total, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(c, h->d_counters, 24, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (c[2]) return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: traversal capacity exceeded (flags %llu: 1 nodes, 2 stack, 4 walker nodes, 8 decisions, "
-                                                "16 illegal action, 32 infoset table full)", c[2]);
+    if (c[2]) return nl_capacity_error(c[2]);
     if (total > h->out_cap) return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %u Decisions in one batch exceed the buffer (%u)", total, h->out_cap);
     hipLaunchKernelGGL(k_nlhe_pack, dim3(h->batch), dim3(256), 0, st, h->sc, h->batch, h->prm.dcap, h->d_offset, h->out);
     HIP_TRY(hipGetLastError());
     h->last_n = total;
+    h->nodes += c[0];
+    h->infos += c[1];
+    h->last_nodes = (uint32_t)c[0];
     return RP_OK;
 }
+
+// ---- the level-synchronous traversal (nlmc_level.hpp)
+int nl_traverse_levels(rp_nlhe* h) {
+    hipStream_t st = rp::profile_stream(h->prof);
+    nl_begin_step(h);
+    NlNodes& lv = h->lv;
+    const uint32_t B = h->batch;
+    const dim3 wide(std::min<uint32_t>(4096u, std::max<uint32_t>(1u, (lv.ncap / 4u + 255u) / 256u))), blk(256);
+    HIP_TRY(hipMemsetAsync(lv.ctl, 0, sizeof(NlCtl), st));
+    HIP_TRY(hipMemsetAsync(lv.t_nw, 0, (size_t)B * 4, st));
+    h->prm.tag = nl_next_tag(h);
+    hipLaunchKernelGGL(k_nl_roots, dim3((B + 255u) / 256u), blk, 0, st, h->prm, lv);
+    NlCtl ctl;
+    uint32_t L = 0;
+    for (;;) {  // grow all trees one level per pair of launches; look at the frontier every few levels
+        const uint32_t stop = std::min<uint32_t>(NL_MAXL - 1u, L + (L == 0 ? 22u : 6u));
+        for (; L < stop; ++L) {
+            h->prm.tag = nl_next_tag(h);
+            hipLaunchKernelGGL(k_nl_expand, wide, blk, 0, st, h->prm, h->tab, lv, L);
+            hipLaunchKernelGGL(k_nl_children, wide, blk, 0, st, h->prm, lv, L);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&ctl, lv.ctl, sizeof(NlCtl), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (ctl.err) return nl_capacity_error(ctl.err);
+        // level L's work lists begin where level L-1's expansion found the cursors (lvl_list[L]); anything behind is alive
+        const bool alive = ctl.cur[0] > ctl.lvl_list[L][0] || ctl.cur[1] > ctl.lvl_list[L][1] || ctl.cur[2] > ctl.lvl_list[L][2];
+        if (!alive) break;
+        if (L >= NL_MAXL - 1u) return nl_capacity_error(NERR_LEVELS);
+    }
+    uint32_t levels = 0;
+    while (levels < NL_MAXL && ctl.lvl_node[levels + 1] > ctl.lvl_node[levels]) levels += 1;
+    const uint32_t n_nodes = ctl.lvl_node[levels];
+    for (uint32_t l = levels; l-- > 0;) hipLaunchKernelGGL(k_nl_up, wide, blk, 0, st, lv, l);
+    for (uint32_t l = 0; l + 1 < levels; ++l) hipLaunchKernelGGL(k_nl_down, wide, blk, 0, st, lv, l);
+    hipLaunchKernelGGL(k_nlhe_scan, dim3(1), dim3(1024), 0, st, lv.t_nw, B, lv.t_woff, h->d_total + 1);
+    hipLaunchKernelGGL(k_nl_fill, wide, blk, 0, st, lv);
+    hipLaunchKernelGGL((k_nl_group<256, 0>), dim3(B), dim3(64), 0, st, lv, B);
+    hipLaunchKernelGGL((k_nl_group<NL_WMAX, 256>), dim3(B), dim3(64), 0, st, lv, B);
+    hipLaunchKernelGGL(k_nlhe_scan, dim3(1), dim3(1024), 0, st, lv.t_dcount, B, lv.t_doff, h->d_total);
+    HIP_TRY(hipGetLastError());
+    uint32_t total[2] = {0, 0}, err = 0;
+    HIP_TRY(hipMemcpyAsync(total, h->d_total, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&err, &lv.ctl->err, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (err) return nl_capacity_error(err);
+    if (total[0] > h->out_cap) return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %u Decisions in one batch exceed the buffer (%u)", total[0], h->out_cap);
+    hipLaunchKernelGGL(k_nl_emit, wide, blk, 0, st, lv, h->tab, h->out_cap, h->out);
+    HIP_TRY(hipGetLastError());
+    h->last_n = total[0];
+    h->nodes += n_nodes;
+    h->infos += total[0];
+    h->last_levels = levels;
+    h->last_nodes = n_nodes;
+    return RP_OK;
+}
+int nl_traverse(rp_nlhe* h) { return h->lane_per_tree ? nl_traverse_lanes(h) : nl_traverse_levels(h); }
 }  // namespace
 
 extern "C" {
@@ -620,6 +491,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     h->batch = batch;
     h->hp = *hp;
     h->seed = seed;
+    h->lane_per_tree = getenv("RP_NLHE_LANE_PER_TREE") != nullptr;
 #define NL_TRY(expr)                    \
     do {                                \
         int _rc = (expr);               \
@@ -633,18 +505,16 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
         return rp::fail(RP_ERR_HIP, "rp_nlhe_create: hipSetDevice(%d) failed", device);
     }
     const uint64_t rows = 1ull << cap_log2;
-    const uint32_t ncap = 4096, scap = 256, wcap = 2048, dcap = 1024;
-    // Decisions per tree: ~60 on average, 483 the largest seen in 20 000 oracle trees; the batch buffer holds 160 per tree
+    // Decisions per tree: ~40 / ~90 on average by walker, 483 the largest seen in 20 000 oracle trees; the batch buffer holds 160 per
+    // tree.  Nodes per tree: 280 / 660 on average by walker, 3 300 the largest: 768 per tree of budget (the total is what counts)
     const uint64_t dec_cap64 = std::max<uint64_t>((uint64_t)batch * 160u, 4096u);
-    if (dec_cap64 >= (1ull << 31)) {
+    const uint64_t ncap64 = std::max<uint64_t>((uint64_t)batch * 768u, 1u << 17);
+    if (dec_cap64 >= (1ull << 31) || ncap64 > (1ull << 28)) {  // a node's link packs its parent in 28 bits
         delete h;
-        return rp::fail(RP_ERR_INVALID, "rp_nlhe_create: batch too large");
+        return rp::fail(RP_ERR_INVALID, "rp_nlhe_create: batch too large (at most %u trees per step)", (1u << 28) / 768u);
     }
     NL_TRY(rp_profile_create(device, rows, NLMC_A, regret, weight, hp, nullptr, (uint32_t)dec_cap64, &h->prof));
-    NL_TRY(nl_alloc(h, &h->tab.past, rows));
-    NL_TRY(nl_alloc(h, &h->tab.choices, rows));
-    NL_TRY(nl_alloc(h, &h->tab.present, rows));
-    NL_TRY(nl_alloc(h, &h->tab.state, rows));
+    NL_TRY(nl_alloc(h, &h->tab.slots, rows));
     NL_TRY(nl_alloc(h, &h->tab.n_keys, 1));
     h->tab.mask = (uint32_t)(rows - 1);
     h->tab.rows = rp::profile_table(h->prof);
@@ -653,7 +523,10 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     h->prm.temperature = hp->temperature;
     h->prm.smoothing = hp->smoothing;
     h->prm.curiosity = hp->curiosity;
-    h->prm.ncap = ncap; h->prm.scap = scap; h->prm.wcap = wcap; h->prm.dcap = dcap;
+    h->prm.sampling = RP_SAMPLING_EXTERNAL;  // the mccfr! macro's default scheme; rp_nlhe_set_sampling selects Flagship's
+    h->prm.prune_threshold = hp->prune_threshold;
+    h->prm.prune_explore = hp->prune_explore;
+    h->prm.prune_warmup = hp->prune_warmup;
     h->prm.check_legal = getenv("RP_NLHE_CHECK_LEGAL") ? 1u : 0u;
     h->prm.encoder = 0;
     if (tables) {
@@ -667,22 +540,46 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
         h->prm.encoder = 1;
     }
     const size_t B = batch;
-    NL_TRY(nl_alloc(h, &h->sc.meta, B * ncap));
-    NL_TRY(nl_alloc(h, &h->sc.fac, B * ncap));
-    NL_TRY(nl_alloc(h, &h->sc.val, B * ncap));
-    NL_TRY(nl_alloc(h, &h->sc.aux, B * ncap));
-    NL_TRY(nl_alloc(h, &h->sc.wrow, B * wcap));
-    NL_TRY(nl_alloc(h, &h->sc.wnode, B * wcap));
-    NL_TRY(nl_alloc(h, &h->sc.kidd, B * wcap * NLMC_A));
-    NL_TRY(nl_alloc(h, &h->sc.stack, B * scap * NL_SENT));
-    NL_TRY(nl_alloc(h, &h->sc.drow, B * dcap));
-    NL_TRY(nl_alloc(h, &h->sc.dmeta, B * dcap));
-    NL_TRY(nl_alloc(h, &h->sc.dreg, B * dcap * NLMC_A));
-    NL_TRY(nl_alloc(h, &h->sc.dpol, B * dcap * NLMC_A));
-    NL_TRY(nl_alloc(h, &h->sc.dpay, B * dcap));
-    NL_TRY(nl_alloc(h, &h->sc.dmap, B * 2 * dcap));
-    NL_TRY(nl_alloc(h, &h->sc.dcount, B));
-    NL_TRY(nl_alloc(h, &h->sc.ncount, B));
+    if (h->lane_per_tree) {
+        const uint32_t ncap = 4096, scap = 256, wcap = 2048, dcap = 1024;
+        h->prm.ncap = ncap; h->prm.scap = scap; h->prm.wcap = wcap; h->prm.dcap = dcap;
+        NL_TRY(nl_alloc(h, &h->sc.meta, B * ncap));
+        NL_TRY(nl_alloc(h, &h->sc.fac, B * ncap));
+        NL_TRY(nl_alloc(h, &h->sc.val, B * ncap));
+        NL_TRY(nl_alloc(h, &h->sc.aux, B * ncap));
+        NL_TRY(nl_alloc(h, &h->sc.wrow, B * wcap));
+        NL_TRY(nl_alloc(h, &h->sc.wnode, B * wcap));
+        NL_TRY(nl_alloc(h, &h->sc.kidd, B * wcap * NLMC_A));
+        NL_TRY(nl_alloc(h, &h->sc.stack, B * scap * NL_SENT));
+        NL_TRY(nl_alloc(h, &h->sc.drow, B * dcap));
+        NL_TRY(nl_alloc(h, &h->sc.dmeta, B * dcap));
+        NL_TRY(nl_alloc(h, &h->sc.dreg, B * dcap * NLMC_A));
+        NL_TRY(nl_alloc(h, &h->sc.dpol, B * dcap * NLMC_A));
+        NL_TRY(nl_alloc(h, &h->sc.dpay, B * dcap));
+        NL_TRY(nl_alloc(h, &h->sc.dmap, B * 2 * dcap));
+        NL_TRY(nl_alloc(h, &h->sc.dcount, B));
+        NL_TRY(nl_alloc(h, &h->sc.ncount, B));
+        NL_TRY(nl_alloc(h, &h->d_offset, B));
+        NL_TRY(nl_alloc(h, &h->d_counters, 4));
+    } else {
+        NlNodes& lv = h->lv;
+        const size_t N = (size_t)ncap64, LC = N / 2;  // a work list holds one kind of one batch: half the node budget each
+        lv.ncap = (uint32_t)N;
+        lv.lcap = (uint32_t)LC;
+        NL_TRY(nl_alloc(h, &lv.link, N)); NL_TRY(nl_alloc(h, &lv.tree, N)); NL_TRY(nl_alloc(h, &lv.meta, N));
+        NL_TRY(nl_alloc(h, &lv.kid0, N)); NL_TRY(nl_alloc(h, &lv.row, N)); NL_TRY(nl_alloc(h, &lv.size, N));
+        NL_TRY(nl_alloc(h, &lv.dfs, N)); NL_TRY(nl_alloc(h, &lv.aux, N));
+        NL_TRY(nl_alloc(h, &lv.fac, N)); NL_TRY(nl_alloc(h, &lv.val, N)); NL_TRY(nl_alloc(h, &lv.reach, N));
+        NL_TRY(nl_alloc(h, &lv.w0, N)); NL_TRY(nl_alloc(h, &lv.w1, N)); NL_TRY(nl_alloc(h, &lv.w2, N));
+        NL_TRY(nl_alloc(h, &lv.blo, N)); NL_TRY(nl_alloc(h, &lv.bhi, N)); NL_TRY(nl_alloc(h, &lv.bucket, N));
+        NL_TRY(nl_alloc(h, &lv.past, N)); NL_TRY(nl_alloc(h, &lv.hkey, N)); NL_TRY(nl_alloc(h, &lv.chpath, N));
+        NL_TRY(nl_alloc(h, &lv.hole0, B)); NL_TRY(nl_alloc(h, &lv.hole1, B));
+        NL_TRY(nl_alloc(h, &lv.t_nw, B)); NL_TRY(nl_alloc(h, &lv.t_woff, B));
+        NL_TRY(nl_alloc(h, &lv.t_dcount, B)); NL_TRY(nl_alloc(h, &lv.t_doff, B));
+        for (int k = 0; k < 3; ++k) NL_TRY(nl_alloc(h, &lv.list[k], LC));
+        NL_TRY(nl_alloc(h, &lv.wl, LC)); NL_TRY(nl_alloc(h, &lv.ws, LC)); NL_TRY(nl_alloc(h, &lv.gdesc, LC));
+        NL_TRY(nl_alloc(h, &lv.ctl, 1));
+    }
     h->out_cap = (uint32_t)dec_cap64;
     NL_TRY(nl_alloc(h, &h->out.row, h->out_cap));
     NL_TRY(nl_alloc(h, &h->out.nact, h->out_cap));
@@ -691,14 +588,31 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     NL_TRY(nl_alloc(h, &h->out.policy, (size_t)h->out_cap * NLMC_A));
     NL_TRY(nl_alloc(h, &h->out.payoff, h->out_cap));
     NL_TRY(nl_alloc(h, &h->out.tree, h->out_cap));
-    NL_TRY(nl_alloc(h, &h->d_offset, B));
-    NL_TRY(nl_alloc(h, &h->d_total, 1));
-    NL_TRY(nl_alloc(h, &h->d_counters, 4));
+    NL_TRY(nl_alloc(h, &h->d_total, 2));
+    NL_TRY(nl_alloc(h, &h->d_remap_err, 1));
 #undef NL_TRY
     // hipMemset on device memory returns before it has run, and a non-blocking stream does not wait for the null stream: the
     // first launch on this handle's stream could otherwise overtake the initialisation above and be overwritten by it
     (void)hipDeviceSynchronize();
     *out = h;
+    return RP_OK;
+}
+
+// the SamplingScheme of the solver type at walker nodes: ExternalSampling (the mccfr! macro's default, nlhe/src/solver.rs:11),
+// PrunableSampling, PluribusSampling (Flagship, nlhe/src/lib.rs:86-90); thresholds from the rp_hyper given at creation
+int rp_nlhe_set_sampling(rp_nlhe* h, rp_sampling_kind sampling) {
+    if (!h || (int)sampling < 0 || (int)sampling > (int)RP_SAMPLING_PLURIBUS) return rp::fail(RP_ERR_INVALID, "rp_nlhe_set_sampling: bad argument");
+    if (h->lane_per_tree && sampling != RP_SAMPLING_EXTERNAL)
+        return rp::fail(RP_ERR_UNSUPPORTED, "rp_nlhe_set_sampling: the lane-per-tree cross-check kernel samples externally only");
+    h->prm.sampling = (int)sampling;
+    return RP_OK;
+}
+
+// shape of the last traversed batch (level-synchronous traversal): levels grown and nodes
+int rp_nlhe_last_shape(rp_nlhe* h, uint32_t* levels, uint32_t* nodes) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_nlhe_last_shape: NULL handle");
+    if (levels) *levels = h->last_levels;
+    if (nodes) *nodes = h->last_nodes;
     return RP_OK;
 }
 
@@ -727,12 +641,11 @@ int rp_nlhe_batch(rp_nlhe* h, uint32_t cap, uint32_t* n, uint32_t* tree, uint64_
                   uint8_t* n_actions, uint16_t* expanded, float* regret, float* policy, float* payoff) {
     if (!h || !n) return rp::fail(RP_ERR_INVALID, "rp_nlhe_batch: NULL argument");
     HIP_TRY(hipSetDevice(h->device));
-    unsigned long long before[3];
     hipStream_t st = rp::profile_stream(h->prof);
-    HIP_TRY(hipMemcpyAsync(before, h->d_counters, 24, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t nodes0 = h->nodes, infos0 = h->infos;
     int rc = nl_traverse(h);
-    HIP_TRY(hipMemcpyAsync(h->d_counters, before, 16, hipMemcpyHostToDevice, st));  // a debugging view: counters not advanced
+    h->nodes = nodes0;  // a debugging view: counters not advanced
+    h->infos = infos0;
     if (rc) return rc;
     *n = h->last_n;
     const uint32_t m = std::min(cap, h->last_n);
@@ -745,18 +658,15 @@ int rp_nlhe_batch(rp_nlhe* h, uint32_t cap, uint32_t* n, uint32_t* tree, uint64_
     if (regret) HIP_TRY(hipMemcpyAsync(regret, h->out.regret, (size_t)m * NLMC_A * 4, hipMemcpyDeviceToHost, st));
     if (policy) HIP_TRY(hipMemcpyAsync(policy, h->out.policy, (size_t)m * NLMC_A * 4, hipMemcpyDeviceToHost, st));
     if (payoff) HIP_TRY(hipMemcpyAsync(payoff, h->out.payoff, (size_t)m * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipStreamSynchronize(st));  // every copy above has landed before any return below
     if (past || present || choices) {  // the infoset behind each row (rows differ between implementations; keys do not)
         const size_t rowsn = (size_t)1 << h->cap_log2;
-        std::vector<uint64_t> kp(rowsn), kc(rowsn);
-        std::vector<uint32_t> kb(rowsn);
-        HIP_TRY(hipMemcpy(kp.data(), h->tab.past, rowsn * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(kc.data(), h->tab.choices, rowsn * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(kb.data(), h->tab.present, rowsn * 4, hipMemcpyDeviceToHost));
+        std::vector<NlSlot> slots(rowsn);
+        HIP_TRY(hipMemcpy(slots.data(), h->tab.slots, rowsn * sizeof(NlSlot), hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < m; ++i) {
-            if (past) past[i] = kp[rows[i]];
-            if (choices) choices[i] = kc[rows[i]];
-            if (present) present[i] = kb[rows[i]];
+            if (past) past[i] = slots[rows[i]].past;
+            if (choices) choices[i] = slots[rows[i]].choices;
+            if (present) present[i] = slots[rows[i]].present;
         }
     }
     return RP_OK;
@@ -772,13 +682,11 @@ int rp_nlhe_counters(rp_nlhe* h, uint64_t* nodes, uint64_t* infos, uint64_t* key
     if (!h) return rp::fail(RP_ERR_INVALID, "rp_nlhe_counters: NULL handle");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = rp::profile_stream(h->prof);
-    unsigned long long c[3];
     unsigned int k = 0;
-    HIP_TRY(hipMemcpyAsync(c, h->d_counters, 24, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&k, h->tab.n_keys, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (nodes) *nodes = c[0];
-    if (infos) *infos = c[1];
+    if (nodes) *nodes = h->nodes;
+    if (infos) *infos = h->infos;
     if (keys) *keys = k;
     return RP_OK;
 }
@@ -790,22 +698,18 @@ int rp_nlhe_export(rp_nlhe* h, uint64_t cap, uint64_t* n, uint64_t* past, uint32
     int rc = rp_profile_sync(h->prof);
     if (rc) return rc;
     const size_t rowsn = (size_t)1 << h->cap_log2;
-    std::vector<uint32_t> state(rowsn), rows;
-    HIP_TRY(hipMemcpy(state.data(), h->tab.state, rowsn * 4, hipMemcpyDeviceToHost));
+    std::vector<NlSlot> slots(rowsn);
+    std::vector<uint32_t> rows;
+    HIP_TRY(hipMemcpy(slots.data(), h->tab.slots, rowsn * sizeof(NlSlot), hipMemcpyDeviceToHost));
     for (size_t s = 0; s < rowsn; ++s)
-        if (state[s] == 2u) rows.push_back((uint32_t)s);
+        if (slots[s].state == 2u) rows.push_back((uint32_t)s);
     *n = rows.size();
     const size_t m = std::min<size_t>(cap, rows.size());
     if (m == 0 || !past || !present || !choices || !enc) return RP_OK;
-    std::vector<uint64_t> kp(rowsn), kc(rowsn);
-    std::vector<uint32_t> kb(rowsn);
-    HIP_TRY(hipMemcpy(kp.data(), h->tab.past, rowsn * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(kc.data(), h->tab.choices, rowsn * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(kb.data(), h->tab.present, rowsn * 4, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < m; ++i) {
-        past[i] = kp[rows[i]];
-        choices[i] = kc[rows[i]];
-        present[i] = kb[rows[i]];
+        past[i] = slots[rows[i]].past;
+        choices[i] = slots[rows[i]].choices;
+        present[i] = slots[rows[i]].present;
     }
     return rp_profile_get_rows(h->prof, m, rows.data(), enc);
 }
@@ -818,12 +722,9 @@ int rp_nlhe_import(rp_nlhe* h, uint64_t n, const uint64_t* past, const uint32_t*
     int rc = rp_profile_sync(h->prof);
     if (rc) return rc;
     const size_t rowsn = (size_t)1 << h->cap_log2;
-    std::vector<uint32_t> state(rowsn), kb(rowsn), rows(n);
-    std::vector<uint64_t> kp(rowsn), kc(rowsn);
-    HIP_TRY(hipMemcpy(state.data(), h->tab.state, rowsn * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(kp.data(), h->tab.past, rowsn * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(kc.data(), h->tab.choices, rowsn * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(kb.data(), h->tab.present, rowsn * 4, hipMemcpyDeviceToHost));
+    std::vector<NlSlot> slots(rowsn);
+    std::vector<uint32_t> rows(n);
+    HIP_TRY(hipMemcpy(slots.data(), h->tab.slots, rowsn * sizeof(NlSlot), hipMemcpyDeviceToHost));
     unsigned int added = 0;
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t hk = rp_mix64(rp_mix64(past[i] ^ 0x9e3779b97f4a7c15ull) ^ rp_mix64(choices[i] + 0xd1342543de82ef95ull) ^
@@ -831,23 +732,22 @@ int rp_nlhe_import(rp_nlhe* h, uint64_t n, const uint64_t* past, const uint32_t*
         uint32_t s = (uint32_t)hk & h->tab.mask;
         for (size_t probes = 0;; ++probes) {
             if (probes > rowsn) return rp::fail(RP_ERR_CAPACITY, "rp_nlhe_import: infoset table full");
-            if (state[s] != 2u) {
-                state[s] = 2u;
-                kp[s] = past[i];
-                kc[s] = choices[i];
-                kb[s] = present[i];
+            NlSlot& sl = slots[s];
+            if (sl.state != 2u) {
+                sl.state = 2u;
+                sl.born = 0u;
+                sl.past = past[i];
+                sl.choices = choices[i];
+                sl.present = present[i];
                 added += 1;
                 break;
             }
-            if (kp[s] == past[i] && kc[s] == choices[i] && kb[s] == present[i]) break;
+            if (sl.past == past[i] && sl.choices == choices[i] && sl.present == present[i]) break;
             s = (s + 1u) & h->tab.mask;
         }
         rows[i] = s;
     }
-    HIP_TRY(hipMemcpy(h->tab.state, state.data(), rowsn * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->tab.past, kp.data(), rowsn * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->tab.choices, kc.data(), rowsn * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->tab.present, kb.data(), rowsn * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->tab.slots, slots.data(), rowsn * sizeof(NlSlot), hipMemcpyHostToDevice));
     unsigned int k = 0;
     HIP_TRY(hipMemcpy(&k, h->tab.n_keys, 4, hipMemcpyDeviceToHost));
     k += added;
@@ -897,7 +797,7 @@ int rp_nlhe_step_apply(rp_nlhe* h, void* entries_dev, const uint64_t* past_dev, 
         (void)rp_profile_entry_bytes(h->prof, &eb);
         hipLaunchKernelGGL(k_nlhe_entry_remap, dim3((n_entries + 255u) / 256u), dim3(256), 0, rp::profile_stream(h->prof), h->tab,
                            reinterpret_cast<unsigned char*>(entries_dev), (uint32_t)eb, n_entries, past_dev, present_dev, choices_dev,
-                           h->d_counters);
+                           nl_next_tag(h), h->d_remap_err);
         HIP_TRY(hipGetLastError());
     }
     return rp_profile_fold(h->prof, entries_dev, n_entries);
@@ -910,7 +810,16 @@ int rp_nlhe_set_stream(rp_nlhe* h, void* hip_stream) {
 
 int rp_nlhe_sync(rp_nlhe* h) {
     if (!h) return rp::fail(RP_ERR_INVALID, "rp_nlhe_sync: null handle");
-    return rp_profile_sync(h->prof);
+    int rc = rp_profile_sync(h->prof);
+    if (rc) return rc;
+    uint32_t err = 0;  // keys of an exchange that did not fit the table: reported once, then cleared
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy(&err, h->d_remap_err, 4, hipMemcpyDeviceToHost));
+    if (err) {
+        HIP_TRY(hipMemset(h->d_remap_err, 0, 4));
+        return nl_capacity_error(err);
+    }
+    return RP_OK;
 }
 
 }  // extern "C"

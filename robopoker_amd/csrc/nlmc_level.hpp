@@ -1,0 +1,643 @@
+// nlmc_level.hpp — the NLHE MCCFR traversal of a whole batch, LEVEL-SYNCHRONOUS (BASELINE configs[3]; the product path).
+//
+// Reference: Solver::batch (mccfr/src/solver/solver.rs:225-250) = per tree TreeBuilder (builder.rs:74-161) over NlheGame
+// (nlhe/src/game.rs:33-65) with NlheEncoder::info (encoder.rs:30-68), ExternalSampling / PrunableSampling / PluribusSampling
+// (sample/{external.rs:17-64, pruning.rs:44-66, pluribus.rs:72-101}), Tree::partition (tree.rs:88-98) and CfrFlow::dfs per
+// walker infoset (strategy/flow.rs:64-216).  Oracle: oracle/rp_oracle_nlmc.c.
+//
+// WHY NOT A LANE PER TREE (the first device version, kept in nlmc.hip as a cross-check): a wavefront then runs as long as the
+// largest of its 64 trees and every iteration splits by node kind — 5.3 of 64 lanes did work.  Here the trees of a batch grow
+// together, one level of ALL trees per pair of launches, and every kernel works on nodes of ONE kind:
+//
+//   k_nl_roots      lane = tree      hole cards, blinds, preflop buckets -> level 0
+//   k_nl_expand(L)  lane = node      walker | opponent | chance nodes of level L from three work lists (a wavefront holds
+//                                    one kind): choices, NlheInfo key -> row (one 32-B slot + one row per probe), regret matching;
+//                                    opponent: the sampled edge; walker: the pruning scheme's mask; children allocated as one
+//                                    contiguous block per node (wave-aggregated cursor), per child its (parent, slot) and edge factor
+//   k_nl_children(L) lane = child    apply(edge) on the parent's game -> the child's game, kind, reach; chance children draw
+//                                    their cards, compute BOTH seats' buckets for the new street and, on the river, rank the two
+//                                    hands once — so a decision node never canonicalises cards and a terminal node settles
+//                                    with integer compares; terminals get their payoff here; the rest join level L+1's lists
+//   k_nl_up(L)      lane = node      D(node) = sum f(edge) D(child) in choices() order, subtree sizes     (L descending)
+//   k_nl_down(L)    lane = node      pre-order index of every child = the reference's creation index       (L ascending)
+//   k_nl_group      wave = tree      the tree's walker nodes sorted by (row, creation index) in LDS -> Tree::partition's spans,
+//                                    in the order of their first node
+//   k_nl_emit       lane = Decisions regret vector / policy / payoff of one walker infoset of one tree -> rp_decisions
+//
+// Node placement (which index a child block gets) depends on timing; nothing else does: a node's children are contiguous and in
+// slot order, sums run over slots, spans over creation indices, draws are hashes of (seed, epoch, tree, path).  The integer
+// state equals the oracle's and the float results equal the lane-per-tree kernel's bit for bit (tests/test_gpu_nlmc.py).
+//
+// HBM per node: 44 B of tree structure + 48 B of game state (SoA, coalesced by node index) instead of 260 KB of worst-case
+// scratch per tree: ~92 B x 768 nodes per tree of capacity.
+#ifndef RP_NLMC_LEVEL_HPP
+#define RP_NLMC_LEVEL_HPP
+
+#include "nlmc_common.hpp"
+
+namespace rp {
+
+#define NL_MAXL 48u        // levels of a tree: <= 8 decisions per street, 3 draws, the terminal (observed: <= 20)
+#define NL_WMAX 2048u      // walker nodes of one tree (observed: <= 455)
+#define NL_LINK_NONE 0xffffffffu
+// meta: kind [0,2) | n_choices [2,6) | n_kids [6,10) | depth [10,13) | path length [13,17) | showdown order [17,19)
+#define NL_META_KIND(m) ((m) & 3u)
+#define NL_META_NCH(m) (((m) >> 2) & 15u)
+#define NL_META_NKIDS(m) (((m) >> 6) & 15u)
+#define NL_META_DEPTH(m) (((m) >> 10) & 7u)
+#define NL_META_PLEN(m) (((m) >> 13) & 15u)
+#define NL_META_CMP(m) (((m) >> 17) & 3u)
+
+struct NlCtl {
+    uint32_t n_nodes;  // allocation cursor
+    uint32_t cur[3];   // work-list cursors: walker, opponent, chance
+    uint32_t err;
+    uint32_t pad[3];
+    uint32_t lvl_node[NL_MAXL + 2];     // first node of each level
+    uint32_t lvl_list[NL_MAXL + 2][3];  // first work-list entry of each level
+};
+struct NlNodes {
+    // tree structure, by node
+    uint32_t *link, *tree, *meta, *kid0, *row, *size, *dfs, *aux;
+    float *fac, *val, *reach;
+    // game state, by node (decision and chance nodes only)
+    uint32_t *w0, *w1, *w2, *blo, *bhi, *bucket;
+    uint64_t *past, *hkey, *chpath;
+    // by tree
+    uint64_t *hole0, *hole1;
+    uint32_t *t_nw, *t_woff, *t_dcount, *t_doff;
+    // work lists (node indices; a level's entries are contiguous), walker nodes by tree (unsorted / sorted), span descriptors
+    uint32_t* list[3];
+    uint32_t *wl, *ws, *gdesc;
+    NlCtl* ctl;
+    uint32_t ncap, lcap;
+};
+struct NlBatch {  // rp_decisions layout
+    uint32_t* row;
+    uint8_t* nact;
+    uint16_t* expanded;
+    float* regret;
+    float* policy;
+    float* payoff;
+    uint32_t* tree;
+};
+
+__device__ __forceinline__ uint32_t nl_lane() { return __lane_id(); }
+__device__ __forceinline__ uint32_t nl_rank_in(unsigned long long mask) {  // set bits of mask below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// every lane of the wavefront calls this; list = 0..2, or 3 for "nothing to append"
+__device__ __forceinline__ void nl_append(const NlNodes& nd, uint32_t list, uint32_t node, uint32_t* err) {
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k) {
+        const unsigned long long m = __ballot(list == k);
+        if (m == 0ull) continue;
+        uint32_t base = 0;
+        const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+        if (nl_lane() == leader) base = atomicAdd(&nd.ctl->cur[k], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, (int)leader);
+        if (list == k) {
+            const uint32_t pos = base + nl_rank_in(m);
+            if (pos < nd.lcap) nd.list[k][pos] = node;
+            else *err |= NERR_LISTS;
+        }
+    }
+}
+__device__ __forceinline__ void nl_store_game(const NlNodes& nd, uint32_t i, const G2& g) {
+    const Packed pk = pack_game(g);
+    nd.w0[i] = pk.w0; nd.w1[i] = pk.w1; nd.w2[i] = pk.w2; nd.blo[i] = pk.blo; nd.bhi[i] = pk.bhi;
+}
+__device__ __forceinline__ void nl_load_game(const NlNodes& nd, uint32_t i, G2& g) {
+    unpack_game(Packed{nd.w0[i], nd.w1[i], nd.w2[i], nd.blo[i], nd.bhi[i]}, g);
+    g.cards[0] = g.cards[1] = 0;
+}
+// the order of the two river hands: 1 = seat 0 stronger, 2 = equal, 3 = seat 1 stronger (0: the board is not complete)
+__device__ __forceinline__ uint32_t nl_showdown_order(uint64_t hole0, uint64_t hole1, uint64_t board) {
+    const uint32_t s0 = strength_key(sw_of_hand(hole0 | board)), s1 = strength_key(sw_of_hand(hole1 | board));
+    return s0 > s1 ? 1u : (s0 == s1 ? 2u : 3u);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// level 0: Solver::tree — Game::root() with the hole cards dealt (P0 on the button, kicker game.rs:66-78)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_nl_roots(NlParams p, NlNodes nd) {
+    const uint32_t tree = blockIdx.x * 256u + threadIdx.x;
+    const bool valid = tree < p.batch;
+    uint32_t err = 0, list = 3;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        nd.ctl->n_nodes = p.batch;  // the roots are nodes [0, batch): children are allocated behind them
+        nd.ctl->lvl_node[0] = 0;
+        nd.ctl->lvl_node[1] = p.batch;
+        nd.ctl->lvl_list[0][0] = nd.ctl->lvl_list[0][1] = nd.ctl->lvl_list[0][2] = 0;
+    }
+    if (valid) {
+        const uint64_t tree_id = p.tree_base + tree;
+        G2 g;
+        g.n = 2;
+        g.dealer = 0;
+        g.ticker = 0;  // n == 2: the dealer posts the small blind
+        g.pot = 0;
+        g.board = 0;
+        uint64_t deck = HAND_MASK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            g.state[i] = NL_BETTING;
+            g.stack[i] = 200;
+            g.stake[i] = g.spent[i] = 0;
+            g.cards[i] = nl_draw(deck, 2, p, tree_id, 0xD0C0000000000000ull + 8u * (uint64_t)i);
+            deck &= ~g.cards[i];
+        }
+        for (int b = 0; b < 2; ++b) g.force_act(NlAction{NA_BLIND, g.to_post(), 0});
+        nd.hole0[tree] = g.cards[0];
+        nd.hole1[tree] = g.cards[1];
+        const uint32_t b0 = nl_bucket(p, 0, g.cards[0], 0ull, &err), b1 = nl_bucket(p, 0, g.cards[1], 0ull, &err);
+        const int turn = g.turn();  // a player: nobody is all-in after the blinds of a 200-chip stack
+        const uint32_t kind = turn == (int)p.walker ? NK_WALKER : NK_OPP;
+        nl_store_game(nd, tree, g);
+        nd.bucket[tree] = b0 | (b1 << 16);
+        nd.past[tree] = 0ull;
+        nd.hkey[tree] = rp_mix64(0x726f6f74ull);
+        nd.link[tree] = NL_LINK_NONE;
+        nd.tree[tree] = tree;
+        nd.meta[tree] = kind;
+        nd.fac[tree] = 1.0f;
+        nd.reach[tree] = 1.0f;
+        nd.val[tree] = 0.0f;
+        nd.dfs[tree] = 0u;
+        list = kind == NK_WALKER ? 0u : 1u;
+    }
+    nl_append(nd, list, tree, &err);
+    if (err) atomicOr(&nd.ctl->err, err);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_nl_expand: the nodes of one level, by kind.  encoder.info + branches + sample (builder.rs:98-139).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_nl_expand(NlParams p, NlTable t, NlNodes nd, uint32_t level) {
+    NlCtl* ctl = nd.ctl;
+    uint32_t s[3], n[3], pad[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s[k] = ctl->lvl_list[level][k];
+        n[k] = min(ctl->cur[k], nd.lcap) - s[k];
+        pad[k] = (n[k] + 63u) & ~63u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int k = 0; k < 3; ++k) ctl->lvl_list[level + 1][k] = s[k] + n[k];
+    const uint32_t total = pad[0] + pad[1] + pad[2];
+    if (total == 0 || ctl->err) return;  // an error anywhere ends the batch: the host fails the step
+    if (level + 1u >= NL_MAXL) {  // a tree deeper than the level table: the step fails (never observed; the rules bound the depth)
+        if (threadIdx.x == 0) atomicOr(&ctl->err, NERR_LEVELS);
+        return;
+    }
+    // pruning is live for this launch? (sample/pluribus.rs:86-88: the warm-up is on the profile's epoch)
+    const bool pruning = p.sampling == RP_SAMPLING_PRUNABLE || (p.sampling == RP_SAMPLING_PLURIBUS && p.epoch >= p.prune_warmup);
+    for (uint32_t base = blockIdx.x * 256u; base < total; base += gridDim.x * 256u) {
+        const uint32_t j = base + threadIdx.x;
+        const uint32_t seg = j < pad[0] ? 0u : (j < pad[0] + pad[1] ? 1u : 2u);  // wave-uniform: the segments are padded to 64
+        const uint32_t idx = j - (seg == 0 ? 0u : (seg == 1 ? pad[0] : pad[0] + pad[1]));
+        const bool valid = idx < n[seg];
+        const uint32_t node = valid ? nd.list[seg][s[seg] + idx] : 0u;
+        uint32_t err = 0, nkids = 0, nch = 0, mask = 0, row = 0, pick = 0;
+        uint64_t chpath = 0;
+        float sg[NLMC_A], rd = 1.0f, oppfac = 1.0f;
+#pragma unroll
+        for (uint32_t a = 0; a < NLMC_A; ++a) sg[a] = 0.0f;
+        if (seg == 2) {  // chance: legal() = [reveal()] -> choices = [Draw] (kicker game.rs:253-260)
+            nkids = valid ? 1u : 0u;
+            nch = 1;
+            mask = 1;
+        } else if (valid) {
+            const uint32_t m = nd.meta[node];
+            const uint32_t tree = nd.tree[node];
+            G2 g;
+            nl_load_game(nd, node, g);
+            const int turn = g.actor();
+            const NlView view = nl_view(g);
+            nch = nl_choices_path(view, (int)NL_META_DEPTH(m), &chpath);
+            const uint32_t bk = nd.bucket[node];
+            const uint32_t present = turn == 0 ? (bk & 0xffffu) : (bk >> 16);
+            const uint64_t past = nd.past[node];
+            const uint64_t khash = nl_key_hash(past, chpath, present);  // the table slot and the key of the node's random draws
+            row = nl_row_of(t, past, chpath, present, khash, nch, p.tag, &err);
+            const float* r = t.rows + (size_t)row * 4u * NLMC_A;
+            float raw[NLMC_A];
+            rd = 0.0f;
+#pragma unroll
+            for (uint32_t a = 0; a < NLMC_A; ++a) {
+                raw[a] = a < nch ? r[a] : 0.0f;
+                if (a < nch) {
+                    sg[a] = rp_maxf(raw[a], RP_EPSILON);  // RefProf::regret (profile.rs:31-33)
+                    rd += sg[a];
+                }
+            }
+            const uint32_t all = (1u << nch) - 1u;
+            if (seg == 0) {
+                // walker: every edge (ExternalSampling) or the pruning scheme's survivors
+                mask = all;
+                if (pruning) {
+                    bool prune = true;
+                    if (p.sampling == RP_SAMPLING_PLURIBUS)  // profile.rng(node).random::<f32>() < explore (pluribus.rs:89-91)
+                        prune = !(rp_u01(rp_node_hash_draw(p.step_hash, p.tree_base + tree, khash)) < p.prune_explore);
+                    if (prune) {
+                        uint32_t keep = 0;
+#pragma unroll
+                        for (uint32_t a = 0; a < NLMC_A; ++a) {
+                            if (a >= nch) continue;
+                            bool k = raw[a] > p.prune_threshold;  // cum_regret: the RAW accumulated regret (book.rs:101-106)
+                            if (!k && p.sampling == RP_SAMPLING_PLURIBUS) {  // never prune an edge into a terminal node (pluribus.rs:96)
+                                G2 c = g;
+                                c.force_act(nl_action_v(view, (uint32_t)(chpath >> (5u * a)) & 31u));
+                                k = c.turn() == NT_TERMINAL;
+                            }
+                            keep |= k ? (1u << a) : 0u;
+                        }
+                        mask = keep ? keep : all;  // pruning.rs:64, pluribus.rs:99
+                    }
+                }
+                nkids = (uint32_t)__popc(mask);
+                const uint32_t ord = atomicAdd(&nd.t_nw[tree], 1u);
+                if (ord >= NL_WMAX) err |= NERR_WALKERS;
+                nd.aux[node] = ord | (mask << 16);
+            } else {
+                // opponent: weighted (sample/external.rs:41-64) over sampling_distribution (flow.rs:24-42), one draw per
+                // (epoch, infoset, tree)
+                float wv[NLMC_A], sw[NLMC_A], wsum = 0.0f, z = 0.0f;
+#pragma unroll
+                for (uint32_t a = 0; a < NLMC_A; ++a)
+                    if (a < nch) {
+                        wv[a] = rp_maxf(r[NLMC_A + a], RP_EPSILON);
+                        wsum += wv[a];
+                    }
+                const float denom = wsum + p.smoothing;
+#pragma unroll
+                for (uint32_t a = 0; a < NLMC_A; ++a)
+                    if (a < nch) {
+                        sw[a] = rp_maxf((wv[a] / p.temperature + p.smoothing) / denom, p.curiosity);
+                        z += sw[a];
+                    }
+                float total_w = 0.0f, cum[NLMC_A];
+#pragma unroll
+                for (uint32_t a = 0; a < NLMC_A; ++a)
+                    if (a < nch) {
+                        total_w += rp_maxf(sw[a] / z, RP_EPSILON);
+                        cum[a] = total_w;
+                    }
+                const float u = rp_u01(rp_node_hash_draw(p.step_hash, p.tree_base + tree, khash)) * total_w;
+                float swp = sw[0], sgp = sg[0];
+#pragma unroll
+                for (uint32_t a = 0; a + 1 < NLMC_A; ++a)  // while (pick + 1 < nch && cum[pick] <= u) ++pick
+                    if (pick == a && a + 1 < nch && cum[a] <= u) {
+                        pick = a + 1;
+                        swp = sw[a + 1];
+                        sgp = sg[a + 1];
+                    }
+                oppfac = (sgp / rd) / (swp / z);
+                mask = 1u << pick;
+                nkids = 1;
+            }
+        }
+        // ---- one contiguous block of children per node: wavefront prefix sum, one cursor bump per wavefront
+        uint32_t incl = nkids;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if (nl_lane() >= d) incl += up;
+        }
+        const uint32_t wave_total = (uint32_t)__shfl((int)incl, 63);
+        uint32_t wbase = 0;
+        if (wave_total) {
+            if (nl_lane() == 0) wbase = atomicAdd(&ctl->n_nodes, wave_total);
+            wbase = (uint32_t)__shfl((int)wbase, 0);
+        }
+        uint32_t kid0 = wbase + incl - nkids;
+        if (kid0 + nkids > nd.ncap) {  // the batch's node budget is spent: the step fails, nothing is written past the arrays
+            if (nkids) err |= NERR_NODES;
+            nkids = 0;
+        }
+        if (valid) {
+            nd.kid0[node] = kid0;
+            if (seg == 2) {
+                nd.meta[node] |= (1u << 2) | (nkids << 6);
+                if (nkids) {
+                    nd.link[kid0] = node;
+                    nd.fac[kid0] = 1.0f;
+                }
+            } else {
+                nd.meta[node] |= (nch << 2) | (nkids << 6);
+                nd.row[node] = row;
+                nd.chpath[node] = chpath;
+                if (nkids) {
+                    if (seg == 0) {
+                        uint32_t c = kid0;
+#pragma unroll
+                        for (uint32_t a = 0; a < NLMC_A; ++a)
+                            if ((mask >> a) & 1u) {
+                                nd.link[c] = node | (a << 28);
+                                nd.fac[c] = sg[a] / rd;  // instant_policy (flow.rs:46-48)
+                                c += 1;
+                            }
+                    } else {
+                        nd.link[kid0] = node | (pick << 28);
+                        nd.fac[kid0] = oppfac;  // sigma / q of the sampled edge
+                    }
+                }
+            }
+        }
+        if (err) atomicOr(&ctl->err, err);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_nl_children: NlheGame::apply(edge) (nlhe/src/game.rs:33-53) for every child of the level, the child's node
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_nl_children(NlParams p, NlNodes nd, uint32_t level) {
+    NlCtl* ctl = nd.ctl;
+    const uint32_t lo = ctl->lvl_node[level + 1], hi = min(ctl->n_nodes, nd.ncap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->lvl_node[level + 2] = hi;
+    if (hi <= lo || ctl->err) return;
+    const uint32_t total = (hi - lo + 63u) & ~63u;
+    const int walker = (int)p.walker;
+    for (uint32_t base = blockIdx.x * 256u; base < total; base += gridDim.x * 256u) {
+        const uint32_t c = lo + base + threadIdx.x;
+        const bool valid = c < hi;
+        uint32_t err = 0, list = 3;
+        if (valid) {
+            const uint32_t link = nd.link[c], par = link & 0x0fffffffu, slot = link >> 28;
+            const uint32_t pm = nd.meta[par], pkind = NL_META_KIND(pm);
+            const uint32_t tree = nd.tree[par];
+            G2 g;
+            nl_load_game(nd, par, g);
+            const uint64_t phk = nd.hkey[par];
+            const uint32_t e = pkind == NK_CHANCE ? (uint32_t)NE_DRAW : (uint32_t)(nd.chpath[par] >> (5u * slot)) & 31u;
+            const uint64_t hk = rp_mix64(phk ^ ((uint64_t)(e + 1u) * 0x9fb21c651e98df25ull));
+            uint32_t bucket = nd.bucket[par], cmp = NL_META_CMP(pm), cdepth, cplen;
+            uint64_t cpast;
+            if (e == NE_DRAW) {
+                const uint64_t h0 = nd.hole0[tree], h1 = nd.hole1[tree];
+                g.cards[0] = h0;
+                g.cards[1] = h1;
+                const NlAction act{NA_DRAW, 0, nl_draw(g.deck(), g.street() == 0 ? 3 : 1, p, p.tree_base + tree, hk)};
+                if (p.check_legal && !g.allowed(act)) err |= NERR_ILLEGAL;
+                g.force_act(act);
+                const int st = g.street();
+                bucket = nl_bucket(p, st, h0, g.board, &err) | (nl_bucket(p, st, h1, g.board, &err) << 16);
+                if (st == 3) cmp = nl_showdown_order(h0, h1, g.board);
+                cdepth = 0;
+                cplen = 0;
+                cpast = 0ull;
+            } else {
+                const NlView view = nl_view(g);
+                const NlAction act = nl_action_v(view, e);
+                // Game::apply panics on an illegal action (kicker game.rs:234-247).  snap()'s output is legal by construction, so the
+                // test can only catch an engine bug: it runs in the checking mode (RP_NLHE_CHECK_LEGAL=1, the tests)
+                if (p.check_legal && !g.allowed(act)) err |= NERR_ILLEGAL;
+                g.force_act(act);
+                const uint32_t pdepth = NL_META_DEPTH(pm), pplen = NL_META_PLEN(pm);
+                const bool raise = e == NE_SHOVE || e >= NE_OPEN0;
+                const uint64_t ppast = nd.past[par];
+                cdepth = pdepth + (raise ? 1u : 0u);
+                cplen = pplen + 1u;
+                cpast = pplen < 12u ? ppast | ((uint64_t)e << (5u * pplen)) : ppast;
+            }
+            const int turn = g.turn();
+            nd.tree[c] = tree;
+            const float f = nd.fac[c], pr = nd.reach[par];
+            nd.reach[c] = pkind == NK_OPP ? pr * f : pr;  // ancestor_reach (flow.rs:166-174): sigma / q over the opponent's edges
+            if (turn == NT_TERMINAL) {
+                // NlheGame::payoff (nlhe/src/game.rs:59-65): settlement minus what the walker put in; the showdown order was
+                // fixed when the river card fell
+                int reward[2];
+                const uint32_t strength[2] = {cmp == 1u ? 2u : 1u, cmp == 3u ? 2u : 1u};
+                nl_settle_ranked(g, strength, reward);
+                nd.val[c] = (float)(walker ? reward[1] - g.spent[1] : reward[0] - g.spent[0]);
+                nd.meta[c] = NK_TERMINAL;
+            } else {
+                const uint32_t kind = turn == NT_CHANCE ? NK_CHANCE : (turn == walker ? NK_WALKER : NK_OPP);
+                nl_store_game(nd, c, g);
+                nd.bucket[c] = bucket;
+                nd.past[c] = cpast;
+                nd.hkey[c] = hk;
+                nd.meta[c] = kind | ((cdepth & 7u) << 10) | ((cplen & 15u) << 13) | (cmp << 17);
+                nd.val[c] = 0.0f;
+                list = kind == NK_WALKER ? 0u : (kind == NK_OPP ? 1u : 2u);
+            }
+        }
+        nl_append(nd, list, c, &err);
+        if (err) atomicOr(&ctl->err, err);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// evaluation sweeps
+// ---------------------------------------------------------------------------------------------------------------
+// D(node) = sum over the expanded children, in choices() order, of f(edge) D(child): the factorised form of
+// CfrFlow::recursed_value (flow.rs:182-216), which multiplies the same factors at the leaves; subtree sizes beside it
+__global__ __launch_bounds__(256) void k_nl_up(NlNodes nd, uint32_t level) {
+    const uint32_t lo = nd.ctl->lvl_node[level], hi = nd.ctl->lvl_node[level + 1];
+    for (uint32_t i = lo + blockIdx.x * 256u + threadIdx.x; i < hi; i += gridDim.x * 256u) {
+        const uint32_t nk = NL_META_NKIDS(nd.meta[i]);
+        uint32_t sz = 1;
+        if (nk) {
+            const uint32_t k0 = nd.kid0[i];
+            float sum = 0.0f;
+            for (uint32_t c = 0; c < nk; ++c) {
+                sum += nd.fac[k0 + c] * nd.val[k0 + c];
+                sz += nd.size[k0 + c];
+            }
+            nd.val[i] = sum;
+        }
+        nd.size[i] = sz;
+        if (level == 0 && sz >= 65536u) atomicOr(&nd.ctl->err, NERR_NODES);  // creation indices are sort keys of 16 bits
+    }
+}
+// the reference's creation index: pop-last DFS (builder.rs:141-161) visits the children of a node from the LAST choice to the
+// first, each with its whole subtree
+__global__ __launch_bounds__(256) void k_nl_down(NlNodes nd, uint32_t level) {
+    const uint32_t lo = nd.ctl->lvl_node[level], hi = nd.ctl->lvl_node[level + 1];
+    for (uint32_t i = lo + blockIdx.x * 256u + threadIdx.x; i < hi; i += gridDim.x * 256u) {
+        const uint32_t nk = NL_META_NKIDS(nd.meta[i]);
+        if (!nk) continue;
+        const uint32_t k0 = nd.kid0[i];
+        uint32_t run = nd.dfs[i] + 1u;
+        for (uint32_t c = nk; c-- > 0;) {
+            nd.dfs[k0 + c] = run;
+            run += nd.size[k0 + c];
+        }
+    }
+}
+
+// exclusive scan of per-tree counts (one workgroup; a batch has at most a few 10^5 trees)
+__global__ __launch_bounds__(1024) void k_nlhe_scan(const uint32_t* dcount, uint32_t batch, uint32_t* offset, uint32_t* total) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x, per = (batch + 1023u) / 1024u;
+    uint32_t s = 0;
+    for (uint32_t i = tid * per; i < min(batch, (tid + 1) * per); ++i) s += dcount[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < 1024; ++i) {
+            const uint32_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    uint32_t run = part[tid];
+    for (uint32_t i = tid * per; i < min(batch, (tid + 1) * per); ++i) {
+        offset[i] = run;
+        run += dcount[i];
+    }
+}
+
+// walker nodes by tree: wl[t_woff[tree] + ordinal]
+__global__ __launch_bounds__(256) void k_nl_fill(NlNodes nd) {
+    const uint32_t n = min(nd.ctl->cur[0], nd.lcap);
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
+        const uint32_t node = nd.list[0][j];
+        nd.wl[nd.t_woff[nd.tree[node]] + (nd.aux[node] & 0xffffu)] = node;
+    }
+}
+
+// Tree::partition (tree.rs:88-98) for one tree per wavefront: walker nodes sorted by (row, creation index) -> spans; spans
+// ordered by their first node.  CAP = LDS capacity class (a launch handles the trees with CAP/4 < n <= CAP, or n <= CAP for the
+// smallest class).
+template <uint32_t CAP, uint32_t LOW>
+__global__ __launch_bounds__(64) void k_nl_group(NlNodes nd, uint32_t batch) {
+    __shared__ uint64_t key[CAP];
+    __shared__ uint32_t key2[CAP];
+    __shared__ uint16_t hp[CAP + 2];
+    const uint32_t tree = blockIdx.x, lane = threadIdx.x;
+    const uint32_t n = nd.t_nw[tree];
+    if (n > CAP || n <= LOW) {  // another capacity class' tree; nothing to do for an empty one or one k_nl_expand has flagged
+        if (lane == 0 && ((n == 0 && LOW == 0) || (n > NL_WMAX && CAP == NL_WMAX))) nd.t_dcount[tree] = 0;
+        return;
+    }
+    const uint32_t off = nd.t_woff[tree];
+    uint32_t P = 64;
+    while (P < n) P <<= 1;
+    for (uint32_t i = lane; i < P; i += 64) {
+        uint64_t k = ~0ull;
+        if (i < n) {
+            const uint32_t node = nd.wl[off + i];
+            k = ((uint64_t)nd.row[node] << 32) | ((uint64_t)(nd.dfs[node] & 0xffffu) << 16) | (uint64_t)i;
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t tix = lane; tix < (P >> 1); tix += 64) {
+                const uint32_t i = ((tix & ~(j - 1u)) << 1) | (tix & (j - 1u)), x = i | j;
+                const uint64_t a = key[i], b = key[x];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    key[i] = b;
+                    key[x] = a;
+                }
+            }
+            __syncthreads();
+        }
+    // span heads in row order
+    uint32_t G = 0;
+    for (uint32_t base = 0; base < P; base += 64) {
+        const uint32_t i = base + lane;
+        const bool head = i < n && (i == 0 || (uint32_t)(key[i] >> 32) != (uint32_t)(key[i - 1] >> 32));
+        const unsigned long long m = __ballot(head);
+        if (head) {
+            const uint32_t g = G + nl_rank_in(m);
+            hp[g] = (uint16_t)i;
+            key2[g] = (((uint32_t)(key[i] >> 16) & 0xffffu) << 16) | g;  // first creation index of the span | its rank by row
+        }
+        G += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) hp[G] = (uint16_t)n;
+    uint32_t P2 = 64;
+    while (P2 < G) P2 <<= 1;
+    for (uint32_t i = G + lane; i < P2; i += 64) key2[i] = 0xffffffffu;
+    __syncthreads();
+    for (uint32_t k = 2; k <= P2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t tix = lane; tix < (P2 >> 1); tix += 64) {
+                const uint32_t i = ((tix & ~(j - 1u)) << 1) | (tix & (j - 1u)), x = i | j;
+                const uint32_t a = key2[i], b = key2[x];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    key2[i] = b;
+                    key2[x] = a;
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = lane; i < n; i += 64) nd.ws[off + i] = nd.wl[off + (uint32_t)(key[i] & 0xffffu)];
+    for (uint32_t g = lane; g < G; g += 64) {
+        const uint32_t r = key2[g] & 0xffffu;
+        const uint32_t start = hp[r], len = (uint32_t)hp[r + 1] - start;
+        nd.gdesc[off + g] = start | (len << 12);
+    }
+    if (lane == 0) nd.t_dcount[tree] = G;
+}
+
+// one Decisions per lane: record_infosets + update_vector (solver.rs:263-305) for one walker infoset of one tree.  Walks the
+// slots of the walker-node array; the first t_dcount[tree] slots of a tree stand for its spans.
+__global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t out_cap, NlBatch out) {
+    const uint32_t n = min(nd.ctl->cur[0], nd.lcap);
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
+        const uint32_t tr = nd.tree[nd.ws[j]];
+        const uint32_t off = nd.t_woff[tr], g = j - off;
+        if (g >= nd.t_dcount[tr]) continue;
+        const uint32_t d = nd.t_doff[tr] + g;
+        if (d >= out_cap) continue;  // the host has already refused the batch
+        const uint32_t desc = nd.gdesc[j], start = desc & 0xfffu, len = desc >> 12;
+        const uint32_t first = nd.ws[off + start];
+        const uint32_t row = nd.row[first], nch = NL_META_NCH(nd.meta[first]);
+        const float* r = t.rows + (size_t)row * 4u * NLMC_A;
+        float sg[NLMC_A], rd = 0.0f, acc[NLMC_A];
+#pragma unroll
+        for (uint32_t a = 0; a < NLMC_A; ++a) {
+            acc[a] = 0.0f;
+            sg[a] = 0.0f;
+            if (a < nch) {
+                sg[a] = rp_maxf(r[a], RP_EPSILON);
+                rd += sg[a];
+            }
+        }
+        float pay = 0.0f;
+        uint32_t expanded = 0;
+        for (uint32_t mb = 0; mb < len; ++mb) {  // the span in ascending creation index
+            const uint32_t node = nd.ws[off + start + mb];
+            const uint32_t em = nd.aux[node] >> 16, k0 = nd.kid0[node];
+            const float reach = nd.reach[node];
+            float cfv[NLMC_A], ev = 0.0f;
+#pragma unroll
+            for (uint32_t a = 0; a < NLMC_A; ++a) {
+                cfv[a] = 0.0f;
+                if ((em >> a) & 1u) {
+                    cfv[a] = reach * nd.val[k0 + (uint32_t)__popc(em & ((1u << a) - 1u))];
+                    ev += sg[a] / rd * cfv[a];
+                }
+            }
+            pay += ev;
+#pragma unroll
+            for (uint32_t a = 0; a < NLMC_A; ++a)
+                if ((em >> a) & 1u) acc[a] += cfv[a] - ev;
+            expanded |= em;
+        }
+        out.row[d] = row;
+        out.nact[d] = (uint8_t)nch;
+        out.expanded[d] = (uint16_t)expanded;
+        out.payoff[d] = pay;
+        out.tree[d] = tr;
+#pragma unroll
+        for (uint32_t a = 0; a < NLMC_A; ++a) {
+            out.regret[(size_t)d * NLMC_A + a] = acc[a];
+            out.policy[(size_t)d * NLMC_A + a] = a < nch ? sg[a] / rd : 0.0f;  // policy_vector = iterated_distribution (flow.rs:118-120)
+        }
+    }
+}
+
+}  // namespace rp
+
+#endif

@@ -20,9 +20,11 @@ def _p(a):
 class NlheSolver:
     """``mccfr!(Nlhe, NlheEncoder, NlheTurn, NlheEdge, NlheGame, NlheInfo, 128)`` (crates/nlhe/src/solver.rs:11) on one
     MI355X: ``step`` = ``Solver::step``, ``batch`` = ``Solver::batch`` (inspection), ``export`` / ``load`` = the blueprint
-    rows by NlheInfo.  ``tables``: the encoder's four ``deuce.Lookup`` (pref, flop, turn, river); None = hash encoder."""
+    rows by NlheInfo.  ``tables``: the encoder's four ``deuce.Lookup`` (pref, flop, turn, river); None = hash encoder.
+    ``sampling``: "external" (the macro's default), "prunable", "pluribus" (the Flagship type)."""
 
-    def __init__(self, cap_log2=20, regret="linear", weight="linear", batch=128, seed=0, hyper=None, tables=None, device=0):
+    def __init__(self, cap_log2=20, regret="linear", weight="linear", batch=128, seed=0, hyper=None, tables=None, device=0,
+                 sampling="external"):
         self._lib = _lib.load()
         self.hp = hyper
         if self.hp is None:
@@ -38,6 +40,8 @@ class NlheSolver:
         self._h = C.c_void_p()
         _lib.check(self._lib.rp_nlhe_create(device, cap_log2, _lib.REGRET[regret], _lib.WEIGHT[weight], C.byref(self.hp), seed, batch,
                                             tab, C.byref(self._h)))
+        if sampling != "external":  # Flagship = Nlhe<LinearRegret, LinearWeight, PluribusSampling> (nlhe/src/lib.rs:86-90)
+            _lib.check(self._lib.rp_nlhe_set_sampling(self._h, _lib.SAMPLING[sampling]))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -48,6 +52,12 @@ class NlheSolver:
 
     def step(self, mode="ordered"):
         _lib.check(self._lib.rp_nlhe_step(self._h, _lib.UPDATE[mode]))
+
+    def last_shape(self):
+        """(levels, nodes) of the last traversed batch"""
+        a, b = C.c_uint32(), C.c_uint32()
+        _lib.check(self._lib.rp_nlhe_last_shape(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def batch(self, cap=1 << 22):
         n = C.c_uint32()

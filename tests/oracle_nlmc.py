@@ -24,6 +24,7 @@ def lib():
         o.ora_nlmc_create.restype = vp
         o.ora_nlmc_create.argtypes = [C.c_uint32, C.c_int, C.c_int, C.POINTER(_lib.Hyper), C.c_uint64, C.c_uint32]
         o.ora_nlmc_destroy.argtypes = [vp]
+        o.ora_nlmc_set_sampling.argtypes = [vp, C.c_int]
         o.ora_nlmc_set_table.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
         o.ora_nlmc_step.argtypes = [vp]
         o.ora_nlmc_batch.restype = C.c_uint64
@@ -44,6 +45,8 @@ def lib():
         o.ora_nlmc_step_apply.argtypes = [vp, vp, vp, vp, vp, C.c_uint64]
         o.ora_nlmc_step_world.restype = C.c_int
         o.ora_nlmc_step_world.argtypes = [vp, C.c_uint32]
+        o.ora_nlmc_row_key.restype = C.c_int
+        o.ora_nlmc_row_key.argtypes = [vp, C.c_uint32, vp, vp, vp]
         o.ora_nlmc_hash_bucket.restype = C.c_uint32
         o.ora_nlmc_hash_bucket.argtypes = [C.c_int, C.c_int64]
         _o = o
@@ -55,11 +58,12 @@ def _p(a):
 
 
 class OracleNlhe:
-    def __init__(self, cap_log2=16, regret="linear", weight="linear", batch=128, seed=0, hyper=None):
+    def __init__(self, cap_log2=16, regret="linear", weight="linear", batch=128, seed=0, hyper=None, sampling="external"):
         self._o = lib()
         self.hp = hyper or oracle.default_hyper()
         self.batch_size = batch
         self._h = C.c_void_p(self._o.ora_nlmc_create(cap_log2, _lib.REGRET[regret], _lib.WEIGHT[weight], C.byref(self.hp), seed, batch))
+        self._o.ora_nlmc_set_sampling(self._h, _lib.SAMPLING[sampling])
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -43,6 +43,85 @@ def test_first_batch_equals_the_oracle(gpu, batch, seed):
     assert dev.counters()[2] == ora.counters()[2]
 
 
+def test_level_synchronous_traversal_equals_the_lane_per_tree_kernel(gpu, monkeypatch):
+    # Two independent device implementations of Solver::batch: the product path grows all trees of the batch one level per
+    # launch pair with kind-sorted kernels (nlmc_level.hpp); the first version walks one tree per lane with its own stack
+    # (RP_NLHE_LANE_PER_TREE=1).  Same float operations in the same order: every Decisions bit for bit, over three steps with
+    # table updates in between (the second and third batch read trained regrets and weights).
+    monkeypatch.setenv("RP_NLHE_LANE_PER_TREE", "1")
+    old = NlheSolver(cap_log2=20, batch=3000, seed=17)
+    monkeypatch.delenv("RP_NLHE_LANE_PER_TREE")
+    new = NlheSolver(cap_log2=20, batch=3000, seed=17)
+    for step in range(3):
+        a, b = old.batch(), new.batch()
+        assert a["n"] == b["n"] > 3000 * 20
+        for f in ("tree", "past", "present", "choices", "n_actions", "expanded"):
+            assert np.array_equal(a[f], b[f]), (step, f)
+        for f in ("regret", "policy", "payoff"):
+            assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), (step, f)
+        old.step("ordered")
+        new.step("ordered")
+        assert old.counters() == new.counters()
+    levels, nodes = new.last_shape()
+    assert 10 < levels < 40 and nodes > 3000 * 100
+    am, bm = M.as_map(*old.export()), M.as_map(*new.export())
+    assert am.keys() == bm.keys() and all(am[k].tobytes() == bm[k].tobytes() for k in am)
+
+
+def _pruning_hyper(warmup=2, threshold=-5.0, explore=0.05):
+    import oracle
+
+    hp = oracle.default_hyper()
+    hp.prune_warmup, hp.prune_threshold, hp.prune_explore = warmup, threshold, explore
+    return hp
+
+
+@pytest.mark.parametrize("sampling", ["pluribus", "prunable"])
+def test_pruned_sampling_schemes_equal_the_oracle(gpu, sampling):
+    # Flagship = Nlhe<LinearRegret, LinearWeight, PluribusSampling> (nlhe/src/lib.rs:86-90).  Pruning is forced to bite
+    # (warm-up 2 epochs, threshold -5 instead of 16 384 / -3e5): the expanded masks — which walker edges survived, the explore
+    # draws, the terminal-child exemption, the keep-all fallback (sample/pluribus.rs:72-101, pruning.rs:44-66) — the trees and
+    # every key are the oracle's; regrets within the stated tolerance, with resynchronisation as above.
+    batch = 160
+    dev = NlheSolver(cap_log2=18, batch=batch, seed=33, sampling=sampling, hyper=_pruning_hyper())
+    ora = M.OracleNlhe(cap_log2=18, batch=batch, seed=33, sampling=sampling, hyper=_pruning_hyper())
+    pruned = 0
+    for step in range(6):
+        d, o = dev.batch(), ora.batch()
+        _same_batch(d, o)
+        full = (1 << d["n_actions"].astype(np.uint32)) - 1
+        pruned += int((d["expanded"] != full).sum())
+        dev.step("ordered")
+        ora.step()
+        assert dev.counters() == ora.counters()
+        dev.load(*ora.export(), epoch=ora.epoch)
+    assert pruned > 50
+
+
+def test_steps_without_resynchronisation_stay_close_to_the_oracle(gpu):
+    # the NLHE counterpart of test_composed_drift.py, on the device: NO resynchronisation.  While the two runs still sample the
+    # same trees (same node and Decisions counters after a step) the visits agree exactly and the tables within a tolerance that
+    # grows with the steps taken (rtol 5e-4 per step: the per-step re-association error of 2e-4 feeds the next step's reach
+    # products); the first step at which a sampled edge flips on a rounding difference ends the comparison
+    # (from then on they are two different, equally valid runs) — it must not be the first one.
+    dev = NlheSolver(cap_log2=18, regret="linear", weight="linear", batch=128, seed=44)
+    ora = M.OracleNlhe(cap_log2=18, regret="linear", weight="linear", batch=128, seed=44)
+    agreed = 0
+    for step in range(6):
+        dev.step("ordered")
+        ora.step()
+        if dev.counters() != ora.counters():
+            break
+        dm, om = M.as_map(*dev.export()), M.as_map(*ora.export())
+        assert dm.keys() == om.keys()
+        for k in om:
+            assert np.array_equal(dm[k]["visits"], om[k]["visits"]), (step, k)
+            np.testing.assert_allclose(dm[k]["regret"], om[k]["regret"], rtol=5e-4 * (step + 1), atol=5e-3 * (step + 1))
+            np.testing.assert_allclose(dm[k]["weight"], om[k]["weight"], rtol=5e-4 * (step + 1), atol=1e-5 * (step + 1))
+        agreed += 1
+    assert agreed >= 2
+
+
 def test_every_applied_action_is_legal_in_the_checking_mode(gpu, monkeypatch):
     # Game::apply panics on an illegal action (kicker/src/game.rs:234-247).  The device evaluates is_allowed on every applied
     # action only when RP_NLHE_CHECK_LEGAL=1 (it is a third of the traversal's time and can only fire on an engine bug): with
@@ -208,7 +287,7 @@ def test_tree_shards_exchanged_by_key_match_the_world_model(gpu, world, batch):
 
 
 def test_twin_solvers_at_a_gpu_sized_batch_are_identical(gpu):
-    # two solvers, same seed, 131 072 trees per step (34 GB of scratch each): which lane meets which table slot first is timing,
+    # two solvers, same seed, 131 072 trees per step: which lane meets which table slot first (and which index a node gets) is timing,
     # the tables must not be — every infoset, visit, regret, weight and payoff bit for bit.  (This is the size at which a handle
     # whose zero-initialisation was still running when its first step started lost infosets: the create functions now
     # synchronise the device.)

@@ -1,6 +1,8 @@
 """The NLHE MCCFR oracle (oracle/rp_oracle_nlmc.c): structural properties of the Decisions it produces and of the table it
 trains.  (The rules underneath are pinned to the reference's unit tests in test_oracle_nlhe.py; the generic MCCFR loop to
 the reference's Kuhn / Leduc thresholds in test_oracle_mccfr.py — this file checks the NLHE instance of both.)"""
+import ctypes as C
+
 import numpy as np
 
 import oracle_nlhe as rules
@@ -90,3 +92,68 @@ def test_hash_encoder_uses_the_canonical_observation():
     p2, b2 = card(12, 0) | card(11, 1), card(0, 3) | card(5, 2) | card(9, 1)  # suits 3->0, 2->1, 0->3, 1->2
     assert bucket(1, p1, b1) == bucket(1, p2, b2)
     assert rules is not None
+
+
+def _pruning_hyper(warmup=2, threshold=-5.0, explore=0.05):
+    import oracle
+
+    hp = oracle.default_hyper()
+    hp.prune_warmup, hp.prune_threshold, hp.prune_explore = warmup, threshold, explore
+    return hp
+
+
+def test_pluribus_sampling_prunes_walker_edges_after_the_warm_up():
+    # PluribusSampling (sample/pluribus.rs:72-101) on the NLHE path (nlhe/src/lib.rs:86-90 Flagship): no pruning during the
+    # warm-up, afterwards walker edges whose raw regret is at or below the threshold are dropped unless their child is terminal
+    # (a fold always is), except in the explored fraction of (infoset, tree) pairs; nothing kept = everything kept
+    s = M.OracleNlhe(cap_log2=18, batch=96, seed=5, sampling="pluribus", hyper=_pruning_hyper())
+    e = M.OracleNlhe(cap_log2=18, batch=96, seed=5, sampling="external", hyper=_pruning_hyper())
+    for step in range(2):  # warm-up: identical to external sampling
+        bs, be = s.batch(), e.batch()
+        assert bs["n"] == be["n"] and np.array_equal(bs["expanded"], be["expanded"])
+        assert np.array_equal(bs["regret"].view(np.uint32), be["regret"].view(np.uint32))
+        s.step()
+        e.step()
+    assert s.counters() == e.counters()
+    pruned_any = False
+    for step in range(4):
+        b = s.batch()
+        past, present, choices, enc = s.export()
+        keyed = M.as_map(past, present, choices, enc)
+        full = (1 << b["n_actions"].astype(np.uint32)) - 1
+        partial = b["expanded"] != full
+        pruned_any |= bool(partial.any())
+        assert np.all(b["expanded"] != 0) and np.all((b["expanded"] & ~full) == 0)
+        # a dropped edge has raw regret <= threshold in the table and is never a fold (its child would be terminal)
+        o = M.lib()
+        for i in np.nonzero(partial)[0][:200]:
+            n = int(b["n_actions"][i])
+            kp, kb, kc = C.c_uint64(), C.c_uint32(), C.c_uint64()
+            assert o.ora_nlmc_row_key(s._h, int(b["row"][i]), C.byref(kp), C.byref(kb), C.byref(kc)) == 0
+            row, edges = keyed[(kp.value, kb.value, kc.value)], _edges(kc.value)
+            assert np.all(b["regret"][i, n:] == 0)
+            for a in range(n):
+                if not (int(b["expanded"][i]) >> a) & 1:
+                    assert row["regret"][a] <= -5.0 and edges[a] != 2
+                    assert b["regret"][i, a] == 0.0  # an unexpanded edge receives no regret (solver.rs:263-305)
+        s.step()
+    assert pruned_any
+    nodes_p, _, _ = s.counters()
+    for _ in range(4):
+        e.step()
+    nodes_e, _, _ = e.counters()
+    assert nodes_p < nodes_e  # pruning shrinks the trees
+
+
+def test_prunable_sampling_has_no_warm_up_and_no_terminal_exemption():
+    hp = _pruning_hyper(warmup=0, threshold=20.0)  # the bias leaves raises at 10 and shoves at 0: pruned from the first epoch
+    s = M.OracleNlhe(cap_log2=18, batch=32, seed=9, sampling="prunable", hyper=hp)
+    b = s.batch()
+    full = (1 << b["n_actions"].astype(np.uint32)) - 1
+    assert (b["expanded"] != full).any() and np.all(b["expanded"] != 0)
+    past, present, choices, enc = s.export()
+    # every infoset of a fresh table keeps exactly the edges whose bias exceeds 20: fold (100), check / call (50)
+    for i in range(int(b["n"])):
+        n = int(b["n_actions"][i])
+        assert bin(int(b["expanded"][i])).count("1") <= n
+    assert s.counters()[2] == len(past)
