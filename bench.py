@@ -594,7 +594,7 @@ def nlhe_real(args, rank, world, local_rank):
         torch.cuda.set_device(local_rank)
         init_rccl(rank, world)
 
-    def run(batch, steps, warmup):
+    def run(batch, steps, warmup, profile=False):
         s = NlheSolver(cap_log2=args.nlhe_cap, regret="linear", weight="linear", batch=batch, seed=args.seed, device=local_rank,
                        sampling=args.sampling)
         if sharded:
@@ -624,10 +624,19 @@ def nlhe_real(args, rank, world, local_rank):
             t[1], t[2] = float(infos), float(nodes)  # each rank counts the Decisions of its own trees
             dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
             dt, infos, nodes = float(t[0]), int(t[1]), int(t[2])
+        prof = None
+        if profile and not sharded:
+            # a second pass of the same number of steps with a HIP event pair around every kernel group (the event packets cost
+            # a few microseconds per launch, so they stay out of the timed region above)
+            s.profile(True)
+            for _ in range(steps):
+                one()
+            prof = {"groups": s.kernel_times(), "census": s.census(), "levels": s.last_shape()[0], "steps": steps}
+            s.profile(False)
         s.close()
-        return {"infos": infos, "nodes": nodes, "dt": dt, "keys": keys}
+        return {"infos": infos, "nodes": nodes, "dt": dt, "keys": keys, "prof": prof}
 
-    big = run(args.nlhe_batch, args.steps, args.warmup)
+    big = run(args.nlhe_batch, args.steps, args.warmup, profile=True)
     ref = run(128, max(args.steps, 20), 3)
     if rank != 0:
         dist.destroy_process_group()
@@ -638,7 +647,7 @@ def nlhe_real(args, rank, world, local_rank):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": big["dt"] / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "heads-up NLHE blueprint MCCFR (BASELINE configs[3] on one GPU): trees generated on the device, "
-                               "hash encoder (no trained abstraction), external sampling, linear regret / linear weight",
+                               "hash encoder (no trained abstraction), linear regret / linear weight; level-synchronous traversal",
                    "batch_per_gpu": args.nlhe_batch, "global_batch": args.nlhe_batch * world, "table_rows": 1 << args.nlhe_cap,
                    "max_actions": 9, "update": "composed, exchanged by infoset key" if sharded else args.update,
                    "infosets_in_table": big["keys"], "parallelism": f"tree-sharded x{world}"},
@@ -646,11 +655,33 @@ def nlhe_real(args, rank, world, local_rank):
         "nodes_per_tree": big["nodes"] / trees, "infos_per_tree": big["infos"] / trees,
         "reference_batch_128": {"value": ref["infos"] / ref["dt"], "unit": "infoset-updates/s",
                                 "ms_per_step": ref["dt"] / max(args.steps, 20) * 1e3,
-                                "note": "nlhe/src/solver.rs:11 batch_size = 128: two wavefronts of a lane-per-tree traversal"},
-        "roofline": {"bound": "hbm", "kernel": "k_nlhe_traverse", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
-                     "traffic": None, "note": "first device version: one lane per tree, latency / divergence bound; not priced "
-                                              "against a roofline yet (DESIGN §3c)"},
+                                "note": "nlhe/src/solver.rs:11 batch_size = 128: a step is ~90 small launches (two per tree level "
+                                        "+ the sweeps): launch-latency bound"},
     }
+    line["config"]["sampling"] = args.sampling
+    pr = big["prof"]
+    if pr:
+        c, g, k = pr["census"], pr["groups"], pr["steps"]
+        n_all = c["terminal"] + c["chance"] + c["walker"] + c["opponent"]
+        # what k_nl_expand has to move per node — every node's meta once (the kind sort); a decision node's game
+        # state (48 B), key slot (32 B), row (regrets 36 B, + weights 36 B at an opponent node), its node record (24 / 20 B) and
+        # 8 B (link, factor) per child; a chance node 12 B + 8 B
+        alg = (4 * n_all + c["walker"] * (48 + 32 + 36 + 24 + 4) + 8 * c["walker_children"] + c["opponent"] * (48 + 32 + 72 + 20 + 8)
+               + c["chance"] * 20)
+        ms = g["expand"][0]
+        ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else None
+        line["roofline"] = {"bound": "hbm", "kernel": "k_nl_expand", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBPS if ach else None, "traffic": None,
+                            "algorithmic_bytes_per_launch": alg / max(g["expand"][1], 1),
+                            "avg_launch_us": ms * 1e3 / max(g["expand"][1], 1), "launches_per_step": g["expand"][1] / k,
+                            "note": "one launch per tree level; latency bound (random 32-B key probes and 144-B rows of a "
+                                    f"2^{args.nlhe_cap}-row table, dependent on each other) — profiles/r03_nlhe_*"}
+        line["kernel_ms_per_step"] = {name: v[0] / k for name, v in g.items()}
+        line["nodes_by_kind_per_step"] = {name: v / k for name, v in c.items()}
+        line["levels"] = pr["levels"]
+    else:
+        line["roofline"] = {"bound": "hbm", "kernel": "k_nl_expand", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": None, "traffic": None, "note": "not profiled in the sharded run"}
     if args.cpu_seconds > 0:
         import oracle_nlmc
 

@@ -363,6 +363,12 @@ RP_API int rp_nlhe_destroy(rp_nlhe* h);
 RP_API int rp_nlhe_set_sampling(rp_nlhe* h, rp_sampling_kind sampling);
 /* levels grown and nodes created by the last traversed batch (diagnostics of the level-synchronous traversal) */
 RP_API int rp_nlhe_last_shape(rp_nlhe* h, uint32_t* levels, uint32_t* nodes);
+/* profiling hooks used by bench.py (HIP events on the launch stream); name in {"expand","children","sweeps","decide",
+ * "apply"}: total milliseconds and launches since profiling was enabled; census: nodes of those steps by kind {terminal,
+ * chance, walker, opponent} and the children of their walker nodes (what k_nl_expand's algorithmic bytes are counted from) */
+RP_API int rp_nlhe_profile(rp_nlhe* h, int enable);
+RP_API int rp_nlhe_kernel_time(rp_nlhe* h, const char* name, double* total_ms, uint64_t* launches);
+RP_API int rp_nlhe_census(rp_nlhe* h, uint64_t* kinds4, uint64_t* walker_children);
 /* Solver::step (solver.rs:96-105): the batch's trees, their Decisions, the table update (ordered or composed), epoch += 1 */
 RP_API int rp_nlhe_step(rp_nlhe* h, rp_update_mode mode);
 /* Solver::batch (solver.rs:225-250) alone, for inspection: the Decisions of the current epoch in tree order, each with

@@ -235,6 +235,9 @@ _SIGNATURES = {
     "rp_nlhe_destroy": (C.c_int, [C.c_void_p]),
     "rp_nlhe_step": (C.c_int, [C.c_void_p, C.c_int]),
     "rp_nlhe_set_sampling": (C.c_int, [C.c_void_p, C.c_int]),
+    "rp_nlhe_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "rp_nlhe_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "rp_nlhe_census": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rp_nlhe_last_shape": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rp_nlhe_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)] + [C.c_void_p] * 9),
     "rp_nlhe_epoch": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

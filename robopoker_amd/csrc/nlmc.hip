@@ -29,6 +29,7 @@
 
 #include "nlmc_level.hpp"
 #include "rp_internal.h"
+#include "sortscan.hpp"
 
 namespace rp {
 
@@ -361,12 +362,23 @@ struct rp_nlhe {
     uint32_t* d_offset = nullptr;
     uint32_t* d_total = nullptr;   // [0] Decisions of the batch, [1] walker nodes of the batch
     unsigned long long* d_counters = nullptr;  // lane-per-tree kernel: nodes, infos, error flags of the launch
+    void* d_scan = nullptr;                    // scratch of the per-tree scans
     uint32_t* d_remap_err = nullptr;           // rp_nlhe_step_apply: table full while inserting exchanged keys
     std::vector<void*> allocs;
     uint32_t last_n = 0;
     uint32_t tag = 0;              // launch tags handed to nl_row_of (never 0)
     uint64_t nodes = 0, infos = 0;  // Metrics (mccfr/src/metrics/mod.rs): nodes grown, Decisions recorded
     uint32_t last_levels = 0, last_nodes = 0;
+    // profiling (rp_nlhe_profile): HIP event pairs around the launches of each kernel group, on the launch stream
+    struct Clock {
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+        double total_ms = 0.0;
+        uint64_t launches = 0;
+    };
+    bool profiling = false;
+    Clock clk[5];  // expand, children, sweeps (up + down), decide (scan + fill + group + emit), apply
+    uint64_t census[5] = {0, 0, 0, 0, 0};  // nodes by kind + walker children, summed over the profiled steps
+    uint32_t grid_cap = 16384;  // workgroups of the grid-stride kernels (RP_NLHE_GRID; measured: 1024 -14 %, 4096 -4 %)
 };
 
 namespace {
@@ -388,6 +400,32 @@ int nl_capacity_error(unsigned long long flags) {
     return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: traversal failed (flags %llu: 1 node budget, 2 stack, 4 walker nodes of a tree, 8 decisions, "
                                      "16 illegal action, 32 infoset table full, 64 isomorphism not found in the encoder table, 128 tree deeper "
                                      "than the level table, 256 work list full)", flags);
+}
+void nl_clock_begin(rp_nlhe* h, int k) {
+    if (!h->profiling) return;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, rp::profile_stream(h->prof));
+    h->clk[k].pending.emplace_back(a, b);
+}
+void nl_clock_end(rp_nlhe* h, int k) {
+    if (!h->profiling) return;
+    (void)hipEventRecord(h->clk[k].pending.back().second, rp::profile_stream(h->prof));
+    h->clk[k].launches += 1;
+}
+void nl_clock_drain(rp_nlhe* h) {
+    for (auto& c : h->clk) {
+        for (auto& pr : c.pending) {
+            float ms = 0.0f;
+            (void)hipEventSynchronize(pr.second);
+            (void)hipEventElapsedTime(&ms, pr.first, pr.second);
+            c.total_ms += ms;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        c.pending.clear();
+    }
 }
 void nl_begin_step(rp_nlhe* h) {
     h->prm.epoch = rp::profile_epoch(h->prof);
@@ -426,7 +464,7 @@ int nl_traverse_levels(rp_nlhe* h) {
     nl_begin_step(h);
     NlNodes& lv = h->lv;
     const uint32_t B = h->batch;
-    const dim3 wide(std::min<uint32_t>(4096u, std::max<uint32_t>(1u, (lv.ncap / 4u + 255u) / 256u))), blk(256);
+    const dim3 wide(std::min<uint32_t>(h->grid_cap, std::max<uint32_t>(1u, (lv.ncap / 4u + 255u) / 256u))), blk(256);
     HIP_TRY(hipMemsetAsync(lv.ctl, 0, sizeof(NlCtl), st));
     HIP_TRY(hipMemsetAsync(lv.t_nw, 0, (size_t)B * 4, st));
     h->prm.tag = nl_next_tag(h);
@@ -437,36 +475,49 @@ int nl_traverse_levels(rp_nlhe* h) {
         const uint32_t stop = std::min<uint32_t>(NL_MAXL - 1u, L + (L == 0 ? 22u : 6u));
         for (; L < stop; ++L) {
             h->prm.tag = nl_next_tag(h);
+            nl_clock_begin(h, 0);
             hipLaunchKernelGGL(k_nl_expand, wide, blk, 0, st, h->prm, h->tab, lv, L);
+            nl_clock_end(h, 0);
+            nl_clock_begin(h, 1);
             hipLaunchKernelGGL(k_nl_children, wide, blk, 0, st, h->prm, lv, L);
+            nl_clock_end(h, 1);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(&ctl, lv.ctl, sizeof(NlCtl), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (ctl.err) return nl_capacity_error(ctl.err);
-        // level L's work lists begin where level L-1's expansion found the cursors (lvl_list[L]); anything behind is alive
-        const bool alive = ctl.cur[0] > ctl.lvl_list[L][0] || ctl.cur[1] > ctl.lvl_list[L][1] || ctl.cur[2] > ctl.lvl_list[L][2];
+        // level L = the children the last launch pair created; an empty level ends every tree
+        const bool alive = ctl.lvl_node[L + 1] > ctl.lvl_node[L];
         if (!alive) break;
         if (L >= NL_MAXL - 1u) return nl_capacity_error(NERR_LEVELS);
     }
     uint32_t levels = 0;
     while (levels < NL_MAXL && ctl.lvl_node[levels + 1] > ctl.lvl_node[levels]) levels += 1;
     const uint32_t n_nodes = ctl.lvl_node[levels];
+    nl_clock_begin(h, 2);
     for (uint32_t l = levels; l-- > 0;) hipLaunchKernelGGL(k_nl_up, wide, blk, 0, st, lv, l);
     for (uint32_t l = 0; l + 1 < levels; ++l) hipLaunchKernelGGL(k_nl_down, wide, blk, 0, st, lv, l);
-    hipLaunchKernelGGL(k_nlhe_scan, dim3(1), dim3(1024), 0, st, lv.t_nw, B, lv.t_woff, h->d_total + 1);
-    hipLaunchKernelGGL(k_nl_fill, wide, blk, 0, st, lv);
+    nl_clock_end(h, 2);
+    nl_clock_begin(h, 3);
+    HIP_TRY(rp::ss::exclusive_scan<uint32_t>(lv.t_nw, lv.t_woff, B, h->d_scan, st, h->d_total + 1));
+    hipLaunchKernelGGL(k_nl_fill, dim3(std::min<uint32_t>(wide.x, 2048u)), blk, 0, st, lv, n_nodes);
     hipLaunchKernelGGL((k_nl_group<256, 0>), dim3(B), dim3(64), 0, st, lv, B);
     hipLaunchKernelGGL((k_nl_group<NL_WMAX, 256>), dim3(B), dim3(64), 0, st, lv, B);
-    hipLaunchKernelGGL(k_nlhe_scan, dim3(1), dim3(1024), 0, st, lv.t_dcount, B, lv.t_doff, h->d_total);
+    HIP_TRY(rp::ss::exclusive_scan<uint32_t>(lv.t_dcount, lv.t_doff, B, h->d_scan, st, h->d_total));
     HIP_TRY(hipGetLastError());
-    uint32_t total[2] = {0, 0}, err = 0;
+    uint32_t total[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(total, h->d_total, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&err, &lv.ctl->err, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&ctl, lv.ctl, sizeof(NlCtl), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (err) return nl_capacity_error(err);
+    if (ctl.err) return nl_capacity_error(ctl.err);
+    if (h->profiling) {
+        for (int k = 0; k < 4; ++k) h->census[k] += ctl.kinds[k];
+        h->census[4] += ctl.walker_kids;
+    }
     if (total[0] > h->out_cap) return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %u Decisions in one batch exceed the buffer (%u)", total[0], h->out_cap);
-    hipLaunchKernelGGL(k_nl_emit, wide, blk, 0, st, lv, h->tab, h->out_cap, h->out);
+    if (total[1] > lv.lcap) return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %u walker nodes in one batch exceed the buffer (%u)", total[1], lv.lcap);
+    hipLaunchKernelGGL(k_nl_emit, wide, blk, 0, st, lv, h->tab, total[1], h->out_cap, h->out);
+    nl_clock_end(h, 3);
     HIP_TRY(hipGetLastError());
     h->last_n = total[0];
     h->nodes += n_nodes;
@@ -492,6 +543,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     h->hp = *hp;
     h->seed = seed;
     h->lane_per_tree = getenv("RP_NLHE_LANE_PER_TREE") != nullptr;
+    if (getenv("RP_NLHE_GRID")) h->grid_cap = std::max(1, atoi(getenv("RP_NLHE_GRID")));
 #define NL_TRY(expr)                    \
     do {                                \
         int _rc = (expr);               \
@@ -528,6 +580,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     h->prm.prune_explore = hp->prune_explore;
     h->prm.prune_warmup = hp->prune_warmup;
     h->prm.check_legal = getenv("RP_NLHE_CHECK_LEGAL") ? 1u : 0u;
+    h->prm.ablate = getenv("RP_NLHE_ABLATE") ? (uint32_t)atoi(getenv("RP_NLHE_ABLATE")) : 0u;
     h->prm.encoder = 0;
     if (tables) {
         for (int s = 0; s < 4; ++s) {
@@ -563,7 +616,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
         NL_TRY(nl_alloc(h, &h->d_counters, 4));
     } else {
         NlNodes& lv = h->lv;
-        const size_t N = (size_t)ncap64, LC = N / 2;  // a work list holds one kind of one batch: half the node budget each
+        const size_t N = (size_t)ncap64, LC = N / 2;  // walker nodes of a batch (a seventh of its nodes): half the node budget
         lv.ncap = (uint32_t)N;
         lv.lcap = (uint32_t)LC;
         NL_TRY(nl_alloc(h, &lv.link, N)); NL_TRY(nl_alloc(h, &lv.tree, N)); NL_TRY(nl_alloc(h, &lv.meta, N));
@@ -576,7 +629,6 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
         NL_TRY(nl_alloc(h, &lv.hole0, B)); NL_TRY(nl_alloc(h, &lv.hole1, B));
         NL_TRY(nl_alloc(h, &lv.t_nw, B)); NL_TRY(nl_alloc(h, &lv.t_woff, B));
         NL_TRY(nl_alloc(h, &lv.t_dcount, B)); NL_TRY(nl_alloc(h, &lv.t_doff, B));
-        for (int k = 0; k < 3; ++k) NL_TRY(nl_alloc(h, &lv.list[k], LC));
         NL_TRY(nl_alloc(h, &lv.wl, LC)); NL_TRY(nl_alloc(h, &lv.ws, LC)); NL_TRY(nl_alloc(h, &lv.gdesc, LC));
         NL_TRY(nl_alloc(h, &lv.ctl, 1));
     }
@@ -590,6 +642,11 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     NL_TRY(nl_alloc(h, &h->out.tree, h->out_cap));
     NL_TRY(nl_alloc(h, &h->d_total, 2));
     NL_TRY(nl_alloc(h, &h->d_remap_err, 1));
+    {
+        unsigned char* scratch = nullptr;
+        NL_TRY(nl_alloc(h, &scratch, rp::ss::scan_scratch_bytes(B)));
+        h->d_scan = scratch;
+    }
 #undef NL_TRY
     // hipMemset on device memory returns before it has run, and a non-blocking stream does not wait for the null stream: the
     // first launch on this handle's stream could otherwise overtake the initialisation above and be overwritten by it
@@ -634,7 +691,44 @@ int rp_nlhe_step(rp_nlhe* h, rp_update_mode mode) {
     int rc = nl_traverse(h);
     if (rc) return rc;
     rp_decisions b{h->last_n, h->out.row, h->out.nact, h->out.expanded, h->out.regret, h->out.policy, h->out.payoff};
-    return rp_profile_apply(h->prof, &b, mode);
+    nl_clock_begin(h, 4);
+    rc = rp_profile_apply(h->prof, &b, mode);
+    nl_clock_end(h, 4);
+    return rc;
+}
+
+// ---- profiling hooks used by bench.py: HIP events on the launch stream around each kernel group
+int rp_nlhe_profile(rp_nlhe* h, int enable) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_nlhe_profile: NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(rp::profile_stream(h->prof)));
+    nl_clock_drain(h);
+    h->profiling = enable != 0 && !h->lane_per_tree;
+    for (auto& c : h->clk) c.total_ms = 0.0, c.launches = 0;
+    for (auto& c : h->census) c = 0;
+    return RP_OK;
+}
+int rp_nlhe_kernel_time(rp_nlhe* h, const char* name, double* total_ms, uint64_t* launches) {
+    if (!h || !name) return rp::fail(RP_ERR_INVALID, "rp_nlhe_kernel_time: NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(rp::profile_stream(h->prof)));
+    nl_clock_drain(h);
+    static const char* names[5] = {"expand", "children", "sweeps", "decide", "apply"};
+    for (int k = 0; k < 5; ++k)
+        if (!strcmp(name, names[k])) {
+            if (total_ms) *total_ms = h->clk[k].total_ms;
+            if (launches) *launches = h->clk[k].launches;
+            return RP_OK;
+        }
+    return rp::fail(RP_ERR_INVALID, "rp_nlhe_kernel_time: unknown kernel group '%s'", name);
+}
+// nodes of the profiled steps by kind {terminal, chance, walker, opponent} and the children of their walker nodes
+int rp_nlhe_census(rp_nlhe* h, uint64_t* kinds4, uint64_t* walker_children) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_nlhe_census: NULL handle");
+    if (kinds4)
+        for (int k = 0; k < 4; ++k) kinds4[k] = h->census[k];
+    if (walker_children) *walker_children = h->census[4];
+    return RP_OK;
 }
 
 int rp_nlhe_batch(rp_nlhe* h, uint32_t cap, uint32_t* n, uint32_t* tree, uint64_t* past, uint32_t* present, uint64_t* choices,

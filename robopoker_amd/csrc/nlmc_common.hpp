@@ -54,6 +54,7 @@ struct NlParams {
     uint32_t ncap, scap, wcap, dcap;  // lane-per-tree kernel: per-tree capacities (nodes, stack entries, walker nodes, Decisions)
     uint32_t check_legal;             // evaluate Game::is_allowed on every applied action (RP_NLHE_CHECK_LEGAL=1)
     uint32_t tag;                     // launch tag of the kernel about to run (never 0)
+    uint32_t ablate;                  // RP_NLHE_ABLATE (profiling experiments only; results are garbage when set)
 };
 
 // the 2-seat game in five dwords (chips fit a byte: the stack is 200)
@@ -103,14 +104,20 @@ __device__ __forceinline__ uint32_t nl_peek32(const uint32_t* p) { return __hip_
 //     insertion (rows are 144 B, neighbours share lines) — an acquire fence drops it before the caller reads the row.  Keys from
 //     earlier launches need nothing: kernel boundaries already ordered their bytes.
 __device__ __forceinline__ uint32_t nl_row_of(const NlTable& t, uint64_t past, uint64_t choices, uint32_t present, uint64_t key_hash, uint32_t nch,
-                                              uint32_t tag, uint32_t* err) {
+                                              uint32_t tag, uint32_t* err, bool* settled = nullptr) {
+    // *settled: the key was found at its home slot by the optimistic read and was not born in this launch — row bytes a caller
+    // loaded from the home slot BEFORE the probe (in parallel with it) are then the row's
     uint32_t s = (uint32_t)key_hash & t.mask, probes = 0, row = 0;
-    bool done = false;
+    bool done = false, quiet = false;
     while (!done) {
         NlSlot* sl = t.slots + s;
-        const uint64_t sb = nl_peek64(reinterpret_cast<const uint64_t*>(&sl->state));  // state | born << 32
-        if ((uint32_t)sb == 2u && nl_peek64(&sl->past) == past && nl_peek64(&sl->choices) == choices && nl_peek32(&sl->present) == present) {
-            if ((uint32_t)(sb >> 32) == tag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // the whole slot in two 16-byte loads.  Whatever they return — current, stale or torn — only a full match of state 2 and
+        // the 20 key bytes is trusted; everything else goes through the compare-and-swap path below
+        const uint4 lo = *reinterpret_cast<const uint4*>(sl), hi = *(reinterpret_cast<const uint4*>(sl) + 1);
+        const uint64_t kp = (uint64_t)lo.x | ((uint64_t)lo.y << 32), kc = (uint64_t)lo.z | ((uint64_t)lo.w << 32);
+        if (hi.z == 2u && kp == past && kc == choices && hi.x == present) {
+            if (hi.w == tag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            else quiet = probes == 0;
             row = s;
             done = true;
         } else {
@@ -143,7 +150,20 @@ __device__ __forceinline__ uint32_t nl_row_of(const NlTable& t, uint64_t past, u
             // st == 1: another lane (possibly of this wavefront) is writing the slot: look again
         }
     }
+    if (settled) *settled = quiet;
     return row;
+}
+// regret[9] | weight[9] of a row as aligned 16-byte loads (a row is 144 B = 9 x 16): f[0..8] regrets, f[9..17] weights
+__device__ __forceinline__ void nl_load_row(const float* rows, uint32_t row, bool weights, float* f) {
+    const float4* q = reinterpret_cast<const float4*>(rows + (size_t)row * 4u * NLMC_A);
+    float4* o = reinterpret_cast<float4*>(f);
+    o[0] = q[0];
+    o[1] = q[1];
+    o[2] = q[2];
+    if (weights) {
+        o[3] = q[3];
+        o[4] = q[4];
+    }
 }
 
 __device__ __forceinline__ uint64_t nl_draw(uint64_t deck, int k, const NlParams& p, uint64_t tree, uint64_t key) {  // tree = its id in the epoch

@@ -10,14 +10,17 @@
 // together, one level of ALL trees per pair of launches, and every kernel works on nodes of ONE kind:
 //
 //   k_nl_roots      lane = tree      hole cards, blinds, preflop buckets -> level 0
-//   k_nl_expand(L)  lane = node      walker | opponent | chance nodes of level L from three work lists (a wavefront holds
-//                                    one kind): choices, NlheInfo key -> row (one 32-B slot + one row per probe), regret matching;
-//                                    opponent: the sampled edge; walker: the pruning scheme's mask; children allocated as one
-//                                    contiguous block per node (wave-aggregated cursor), per child its (parent, slot) and edge factor
+//   k_nl_expand(L)  lane = node      a workgroup takes a tile of 2048 consecutive nodes of level L and sorts it by kind in LDS
+//                                    (walker | opponent | chance, each padded to whole wavefronts; terminals drop out): a
+//                                    wavefront holds one kind.  Choices, NlheInfo key -> row (one 32-B slot + one row per probe),
+//                                    regret matching; opponent: the sampled edge; walker: the pruning scheme's mask; children
+//                                    allocated as one contiguous block per node (ONE cursor bump per 256 nodes: bumps of one
+//                                    address serialise at ~8 ns, the first version's per-wavefront work lists spent 2/3 of the
+//                                    step there), per child its (parent, slot) and edge factor
 //   k_nl_children(L) lane = child    apply(edge) on the parent's game -> the child's game, kind, reach; chance children draw
 //                                    their cards, compute BOTH seats' buckets for the new street and, on the river, rank the two
 //                                    hands once — so a decision node never canonicalises cards and a terminal node settles
-//                                    with integer compares; terminals get their payoff here; the rest join level L+1's lists
+//                                    with integer compares; terminals get their payoff here.  No atomics, no lists
 //   k_nl_up(L)      lane = node      D(node) = sum f(edge) D(child) in choices() order, subtree sizes     (L descending)
 //   k_nl_down(L)    lane = node      pre-order index of every child = the reference's creation index       (L ascending)
 //   k_nl_group      wave = tree      the tree's walker nodes sorted by (row, creation index) in LDS -> Tree::partition's spans,
@@ -50,11 +53,11 @@ namespace rp {
 
 struct NlCtl {
     uint32_t n_nodes;  // allocation cursor
-    uint32_t cur[3];   // work-list cursors: walker, opponent, chance
     uint32_t err;
-    uint32_t pad[3];
-    uint32_t lvl_node[NL_MAXL + 2];     // first node of each level
-    uint32_t lvl_list[NL_MAXL + 2][3];  // first work-list entry of each level
+    uint32_t pad[2];
+    uint32_t lvl_node[NL_MAXL + 2];  // first node of each level
+    uint32_t kinds[4];               // nodes of the batch by kind (terminal, chance, walker, opponent) and ...
+    uint32_t walker_kids;            // ... children of its walker nodes: what k_nl_expand's algorithmic bytes are counted from
 };
 struct NlNodes {
     // tree structure, by node
@@ -66,8 +69,7 @@ struct NlNodes {
     // by tree
     uint64_t *hole0, *hole1;
     uint32_t *t_nw, *t_woff, *t_dcount, *t_doff;
-    // work lists (node indices; a level's entries are contiguous), walker nodes by tree (unsorted / sorted), span descriptors
-    uint32_t* list[3];
+    // walker nodes by tree (unsorted / sorted), span descriptors
     uint32_t *wl, *ws, *gdesc;
     NlCtl* ctl;
     uint32_t ncap, lcap;
@@ -85,23 +87,6 @@ struct NlBatch {  // rp_decisions layout
 __device__ __forceinline__ uint32_t nl_lane() { return __lane_id(); }
 __device__ __forceinline__ uint32_t nl_rank_in(unsigned long long mask) {  // set bits of mask below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-// every lane of the wavefront calls this; list = 0..2, or 3 for "nothing to append"
-__device__ __forceinline__ void nl_append(const NlNodes& nd, uint32_t list, uint32_t node, uint32_t* err) {
-#pragma unroll
-    for (uint32_t k = 0; k < 3; ++k) {
-        const unsigned long long m = __ballot(list == k);
-        if (m == 0ull) continue;
-        uint32_t base = 0;
-        const uint32_t leader = (uint32_t)__builtin_ctzll(m);
-        if (nl_lane() == leader) base = atomicAdd(&nd.ctl->cur[k], (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, (int)leader);
-        if (list == k) {
-            const uint32_t pos = base + nl_rank_in(m);
-            if (pos < nd.lcap) nd.list[k][pos] = node;
-            else *err |= NERR_LISTS;
-        }
-    }
 }
 __device__ __forceinline__ void nl_store_game(const NlNodes& nd, uint32_t i, const G2& g) {
     const Packed pk = pack_game(g);
@@ -123,12 +108,11 @@ __device__ __forceinline__ uint32_t nl_showdown_order(uint64_t hole0, uint64_t h
 __global__ __launch_bounds__(256) void k_nl_roots(NlParams p, NlNodes nd) {
     const uint32_t tree = blockIdx.x * 256u + threadIdx.x;
     const bool valid = tree < p.batch;
-    uint32_t err = 0, list = 3;
+    uint32_t err = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         nd.ctl->n_nodes = p.batch;  // the roots are nodes [0, batch): children are allocated behind them
         nd.ctl->lvl_node[0] = 0;
         nd.ctl->lvl_node[1] = p.batch;
-        nd.ctl->lvl_list[0][0] = nd.ctl->lvl_list[0][1] = nd.ctl->lvl_list[0][2] = 0;
     }
     if (valid) {
         const uint64_t tree_id = p.tree_base + tree;
@@ -164,74 +148,123 @@ __global__ __launch_bounds__(256) void k_nl_roots(NlParams p, NlNodes nd) {
         nd.reach[tree] = 1.0f;
         nd.val[tree] = 0.0f;
         nd.dfs[tree] = 0u;
-        list = kind == NK_WALKER ? 0u : 1u;
     }
-    nl_append(nd, list, tree, &err);
     if (err) atomicOr(&nd.ctl->err, err);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_nl_expand: the nodes of one level, by kind.  encoder.info + branches + sample (builder.rs:98-139).
 // ---------------------------------------------------------------------------------------------------------------
+#define NL_TILE 2048u  // nodes a workgroup sorts by kind at a time (8 per thread)
 __global__ __launch_bounds__(256) void k_nl_expand(NlParams p, NlTable t, NlNodes nd, uint32_t level) {
+    constexpr uint32_t R = NL_TILE / 256u;         // classification sub-rounds
+    constexpr uint32_t SCAP = NL_TILE + 192u;      // the sorted tile: three kinds, each from a multiple of 64
+    __shared__ uint32_t sorted[SCAP];  // node index
+    __shared__ uint32_t s_info[SCAP];  // n_kids | expanded mask << 4 | sampled slot << 13   (what the write phase needs)
+    __shared__ uint32_t s_row[SCAP];   // walker items: the infoset's row
+    __shared__ float s_fac[SCAP];      // opponent items: sigma / q of the sampled edge
+    __shared__ uint32_t wcnt[R][4][3];  // per sub-round, wavefront, kind: count, then exclusive prefix
+    __shared__ uint32_t segbase[3], segcnt[3], wsum[4], blockbase, tiletotal;
     NlCtl* ctl = nd.ctl;
-    uint32_t s[3], n[3], pad[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        s[k] = ctl->lvl_list[level][k];
-        n[k] = min(ctl->cur[k], nd.lcap) - s[k];
-        pad[k] = (n[k] + 63u) & ~63u;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int k = 0; k < 3; ++k) ctl->lvl_list[level + 1][k] = s[k] + n[k];
-    const uint32_t total = pad[0] + pad[1] + pad[2];
-    if (total == 0 || ctl->err) return;  // an error anywhere ends the batch: the host fails the step
+    const uint32_t lo = ctl->lvl_node[level], hi = ctl->lvl_node[level + 1];
+    if (hi <= lo || ctl->err) return;  // an error anywhere ends the batch: the host fails the step
     if (level + 1u >= NL_MAXL) {  // a tree deeper than the level table: the step fails (never observed; the rules bound the depth)
         if (threadIdx.x == 0) atomicOr(&ctl->err, NERR_LEVELS);
         return;
     }
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
     // pruning is live for this launch? (sample/pluribus.rs:86-88: the warm-up is on the profile's epoch)
     const bool pruning = p.sampling == RP_SAMPLING_PRUNABLE || (p.sampling == RP_SAMPLING_PLURIBUS && p.epoch >= p.prune_warmup);
-    for (uint32_t base = blockIdx.x * 256u; base < total; base += gridDim.x * 256u) {
-        const uint32_t j = base + threadIdx.x;
-        const uint32_t seg = j < pad[0] ? 0u : (j < pad[0] + pad[1] ? 1u : 2u);  // wave-uniform: the segments are padded to 64
-        const uint32_t idx = j - (seg == 0 ? 0u : (seg == 1 ? pad[0] : pad[0] + pad[1]));
-        const bool valid = idx < n[seg];
-        const uint32_t node = valid ? nd.list[seg][s[seg] + idx] : 0u;
-        uint32_t err = 0, nkids = 0, nch = 0, mask = 0, row = 0, pick = 0;
-        uint64_t chpath = 0;
-        float sg[NLMC_A], rd = 1.0f, oppfac = 1.0f;
+    for (uint32_t t0 = lo + blockIdx.x * NL_TILE; t0 < hi; t0 += gridDim.x * NL_TILE) {
+        // ---- 1. the tile sorted by kind (walker 0 | opponent 1 | chance 2; terminals have nothing to expand)
+        uint32_t kd[R], rk[R];
 #pragma unroll
-        for (uint32_t a = 0; a < NLMC_A; ++a) sg[a] = 0.0f;
-        if (seg == 2) {  // chance: legal() = [reveal()] -> choices = [Draw] (kicker game.rs:253-260)
-            nkids = valid ? 1u : 0u;
-            nch = 1;
-            mask = 1;
-        } else if (valid) {
+        for (uint32_t r = 0; r < R; ++r) {
+            const uint32_t i = t0 + r * 256u + tid;
+            const uint32_t kind = i < hi ? NL_META_KIND(nd.meta[i]) : (uint32_t)NK_TERMINAL;
+            kd[r] = kind == NK_WALKER ? 0u : (kind == NK_OPP ? 1u : (kind == NK_CHANCE ? 2u : 3u));
+            rk[r] = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 3; ++k) {
+                const unsigned long long m = __ballot(kd[r] == k);
+                if (kd[r] == k) rk[r] = nl_rank_in(m);
+                if ((tid & 63u) == 0) wcnt[r][wave][k] = (uint32_t)__popcll(m);
+            }
+        }
+        __syncthreads();
+        if (tid < 3) {
+            uint32_t run = 0;
+            for (uint32_t r = 0; r < R; ++r)
+                for (uint32_t w = 0; w < 4; ++w) {
+                    const uint32_t v = wcnt[r][w][tid];
+                    wcnt[r][w][tid] = run;
+                    run += v;
+                }
+            segcnt[tid] = run;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            segbase[0] = 0;
+            segbase[1] = (segcnt[0] + 63u) & ~63u;
+            segbase[2] = segbase[1] + ((segcnt[1] + 63u) & ~63u);
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < R; ++r)
+            if (kd[r] < 3u) sorted[segbase[kd[r]] + wcnt[r][wave][kd[r]] + rk[r]] = t0 + r * 256u + tid;
+        __syncthreads();
+        const uint32_t total = segbase[2] + ((segcnt[2] + 63u) & ~63u);
+        // ---- 2. every item: choices, key -> row, policy, the sampled / surviving edges.  No synchronisation between rounds:
+        //         the children are placed afterwards, with ONE bump of the node cursor for the whole tile
+        uint32_t mykids = 0, err = 0;
+        for (uint32_t jb = 0; jb < total; jb += 256u) {
+            const uint32_t j = jb + tid;
+            const uint32_t seg = j < segbase[1] ? 0u : (j < segbase[2] ? 1u : 2u);  // wave-uniform: the segments start at multiples of 64
+            const bool valid = j < total && j - segbase[seg] < segcnt[seg];
+            if (!valid) {
+                if (j < SCAP) s_info[j] = 0u;
+                continue;
+            }
+            const uint32_t node = sorted[j];
             const uint32_t m = nd.meta[node];
+            if (seg == 2) {  // chance: legal() = [reveal()] -> choices = [Draw] (kicker game.rs:253-260)
+                nd.meta[node] = m | (1u << 2) | (1u << 6);
+                s_info[j] = 1u | (1u << 4);
+                mykids += 1;
+                continue;
+            }
             const uint32_t tree = nd.tree[node];
             G2 g;
             nl_load_game(nd, node, g);
+            const uint32_t bk = nd.bucket[node];
+            const uint64_t past = nd.past[node];
             const int turn = g.actor();
             const NlView view = nl_view(g);
-            nch = nl_choices_path(view, (int)NL_META_DEPTH(m), &chpath);
-            const uint32_t bk = nd.bucket[node];
+            uint64_t chpath;
+            const uint32_t nch = nl_choices_path(view, (int)NL_META_DEPTH(m), &chpath);
             const uint32_t present = turn == 0 ? (bk & 0xffffu) : (bk >> 16);
-            const uint64_t past = nd.past[node];
             const uint64_t khash = nl_key_hash(past, chpath, present);  // the table slot and the key of the node's random draws
-            row = nl_row_of(t, past, chpath, present, khash, nch, p.tag, &err);
-            const float* r = t.rows + (size_t)row * 4u * NLMC_A;
-            float raw[NLMC_A];
-            rd = 0.0f;
+            // the row is read from the key's home slot WHILE the key is probed: one memory round trip instead of two whenever the
+            // infoset sits at its home slot and is older than this launch (the usual case); otherwise it is read again
+            float rf[20];
+            if (!(p.ablate & 4u)) nl_load_row(t.rows, (uint32_t)khash & t.mask, seg == 1, rf);
+            else
+                for (int q = 0; q < 20; ++q) rf[q] = 1.0f + (float)q;
+            bool settled = true;
+            const uint32_t row = (p.ablate & 2u) ? ((uint32_t)khash & t.mask) : nl_row_of(t, past, chpath, present, khash, nch, p.tag, &err, &settled);
+            if (!settled) nl_load_row(t.rows, row, seg == 1, rf);
+            float sg[NLMC_A], rd = 0.0f;
 #pragma unroll
             for (uint32_t a = 0; a < NLMC_A; ++a) {
-                raw[a] = a < nch ? r[a] : 0.0f;
+                sg[a] = 0.0f;
                 if (a < nch) {
-                    sg[a] = rp_maxf(raw[a], RP_EPSILON);  // RefProf::regret (profile.rs:31-33)
+                    sg[a] = rp_maxf(rf[a], RP_EPSILON);  // RefProf::regret (profile.rs:31-33)
                     rd += sg[a];
                 }
             }
             const uint32_t all = (1u << nch) - 1u;
+            uint32_t mask, pick = 0, nkids;
+            float oppfac = 1.0f;
             if (seg == 0) {
                 // walker: every edge (ExternalSampling) or the pruning scheme's survivors
                 mask = all;
@@ -244,7 +277,7 @@ __global__ __launch_bounds__(256) void k_nl_expand(NlParams p, NlTable t, NlNode
 #pragma unroll
                         for (uint32_t a = 0; a < NLMC_A; ++a) {
                             if (a >= nch) continue;
-                            bool k = raw[a] > p.prune_threshold;  // cum_regret: the RAW accumulated regret (book.rs:101-106)
+                            bool k = rf[a] > p.prune_threshold;  // cum_regret: the RAW accumulated regret (book.rs:101-106)
                             if (!k && p.sampling == RP_SAMPLING_PLURIBUS) {  // never prune an edge into a terminal node (pluribus.rs:96)
                                 G2 c = g;
                                 c.force_act(nl_action_v(view, (uint32_t)(chpath >> (5u * a)) & 31u));
@@ -256,33 +289,35 @@ __global__ __launch_bounds__(256) void k_nl_expand(NlParams p, NlTable t, NlNode
                     }
                 }
                 nkids = (uint32_t)__popc(mask);
-                const uint32_t ord = atomicAdd(&nd.t_nw[tree], 1u);
+                const uint32_t ord = (p.ablate & 1u) ? 0u : atomicAdd(&nd.t_nw[tree], 1u);
                 if (ord >= NL_WMAX) err |= NERR_WALKERS;
                 nd.aux[node] = ord | (mask << 16);
+                s_row[j] = row;
             } else {
                 // opponent: weighted (sample/external.rs:41-64) over sampling_distribution (flow.rs:24-42), one draw per
                 // (epoch, infoset, tree)
-                float wv[NLMC_A], sw[NLMC_A], wsum = 0.0f, z = 0.0f;
+                float sw[NLMC_A], wsum_ = 0.0f, z = 0.0f;
 #pragma unroll
                 for (uint32_t a = 0; a < NLMC_A; ++a)
-                    if (a < nch) {
-                        wv[a] = rp_maxf(r[NLMC_A + a], RP_EPSILON);
-                        wsum += wv[a];
-                    }
-                const float denom = wsum + p.smoothing;
+                    if (a < nch) wsum_ += rp_maxf(rf[NLMC_A + a], RP_EPSILON);
+                const float denom = wsum_ + p.smoothing;
 #pragma unroll
-                for (uint32_t a = 0; a < NLMC_A; ++a)
+                for (uint32_t a = 0; a < NLMC_A; ++a) {
+                    sw[a] = 0.0f;
                     if (a < nch) {
-                        sw[a] = rp_maxf((wv[a] / p.temperature + p.smoothing) / denom, p.curiosity);
+                        sw[a] = rp_maxf((rp_maxf(rf[NLMC_A + a], RP_EPSILON) / p.temperature + p.smoothing) / denom, p.curiosity);
                         z += sw[a];
                     }
+                }
                 float total_w = 0.0f, cum[NLMC_A];
 #pragma unroll
-                for (uint32_t a = 0; a < NLMC_A; ++a)
+                for (uint32_t a = 0; a < NLMC_A; ++a) {
+                    cum[a] = 0.0f;
                     if (a < nch) {
                         total_w += rp_maxf(sw[a] / z, RP_EPSILON);
                         cum[a] = total_w;
                     }
+                }
                 const float u = rp_u01(rp_node_hash_draw(p.step_hash, p.tree_base + tree, khash)) * total_w;
                 float swp = sw[0], sgp = sg[0];
 #pragma unroll
@@ -292,59 +327,97 @@ __global__ __launch_bounds__(256) void k_nl_expand(NlParams p, NlTable t, NlNode
                         swp = sw[a + 1];
                         sgp = sg[a + 1];
                     }
-                oppfac = (sgp / rd) / (swp / z);
+                oppfac = (sgp / rd) / (swp / z);  // sigma / q of the sampled edge
                 mask = 1u << pick;
                 nkids = 1;
+                s_fac[j] = oppfac;
             }
+            nd.row[node] = row;
+            nd.chpath[node] = chpath;
+            nd.meta[node] = m | (nch << 2) | (nkids << 6);
+            s_info[j] = nkids | (mask << 4) | (pick << 13);
+            mykids += nkids;
         }
-        // ---- one contiguous block of children per node: wavefront prefix sum, one cursor bump per wavefront
-        uint32_t incl = nkids;
+        // ---- 3. one contiguous run of node indices for all children of the tile, in the tile's sorted order (neighbouring
+        //         parents get neighbouring child blocks: the next kernels read both): block prefix sum over s_info, ONE cursor bump
+        __syncthreads();  // every s_info / s_row / s_fac of the tile is written
+        constexpr uint32_t CH = (SCAP + 255u) / 256u;  // consecutive items per thread in the scan
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < CH; ++q) {
+            const uint32_t j = tid * CH + q;
+            mine += j < total ? (s_info[j] & 15u) : 0u;
+        }
+        uint32_t incl = mine;
 #pragma unroll
         for (uint32_t d = 1; d < 64; d <<= 1) {
             const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
             if (nl_lane() >= d) incl += up;
         }
-        const uint32_t wave_total = (uint32_t)__shfl((int)incl, 63);
-        uint32_t wbase = 0;
-        if (wave_total) {
-            if (nl_lane() == 0) wbase = atomicAdd(&ctl->n_nodes, wave_total);
-            wbase = (uint32_t)__shfl((int)wbase, 0);
+        if ((tid & 63u) == 63u) wsum[wave] = incl;
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t a0 = wsum[0], a1 = wsum[1], a2 = wsum[2], a3 = wsum[3], tot = a0 + a1 + a2 + a3;
+            blockbase = tot ? atomicAdd(&ctl->n_nodes, tot) : 0u;
+            tiletotal = tot;
+            wsum[0] = 0; wsum[1] = a0; wsum[2] = a0 + a1; wsum[3] = a0 + a1 + a2;
         }
-        uint32_t kid0 = wbase + incl - nkids;
-        if (kid0 + nkids > nd.ncap) {  // the batch's node budget is spent: the step fails, nothing is written past the arrays
-            if (nkids) err |= NERR_NODES;
-            nkids = 0;
-        }
-        if (valid) {
-            nd.kid0[node] = kid0;
-            if (seg == 2) {
-                nd.meta[node] |= (1u << 2) | (nkids << 6);
-                if (nkids) {
-                    nd.link[kid0] = node;
-                    nd.fac[kid0] = 1.0f;
-                }
-            } else {
-                nd.meta[node] |= (nch << 2) | (nkids << 6);
-                nd.row[node] = row;
-                nd.chpath[node] = chpath;
-                if (nkids) {
-                    if (seg == 0) {
-                        uint32_t c = kid0;
+        __syncthreads();
+        {
+            uint32_t pre = wsum[wave] + incl - mine;  // exclusive prefix of the thread's first item: < 2048 * 9, kept in bits 17..31
 #pragma unroll
-                        for (uint32_t a = 0; a < NLMC_A; ++a)
-                            if ((mask >> a) & 1u) {
-                                nd.link[c] = node | (a << 28);
-                                nd.fac[c] = sg[a] / rd;  // instant_policy (flow.rs:46-48)
-                                c += 1;
-                            }
-                    } else {
-                        nd.link[kid0] = node | (pick << 28);
-                        nd.fac[kid0] = oppfac;  // sigma / q of the sampled edge
-                    }
+            for (uint32_t q = 0; q < CH; ++q) {
+                const uint32_t j = tid * CH + q;
+                if (j < total) {
+                    const uint32_t info = s_info[j];
+                    s_info[j] = info | (pre << 17);
+                    pre += info & 15u;
                 }
             }
         }
+        __syncthreads();
+        const bool fits = blockbase + tiletotal <= nd.ncap;  // else the batch's node budget is spent: the step fails, nothing is written
+        if (!fits && mykids) err |= NERR_NODES;
+        // ---- 4. per child its (parent, slot) and edge factor
+        for (uint32_t jb = 0; jb < total && fits; jb += 256u) {
+            const uint32_t j = jb + tid;
+            if (j >= total) continue;
+            const uint32_t info = s_info[j], nk = info & 15u;
+            if (!nk) continue;
+            const uint32_t node = sorted[j], mask = (info >> 4) & 0x1ffu;
+            uint32_t run = blockbase + (info >> 17);
+            nd.kid0[node] = run;
+            if (j < segbase[1]) {  // walker: sigma of every surviving edge, recomputed from the row (the same operations as above)
+                float rf[12], sg[NLMC_A], rd = 0.0f;
+                nl_load_row(t.rows, s_row[j], false, rf);
+                const uint32_t nch = NL_META_NCH(nd.meta[node]);
+#pragma unroll
+                for (uint32_t a = 0; a < NLMC_A; ++a) {
+                    sg[a] = 0.0f;
+                    if (a < nch) {
+                        sg[a] = rp_maxf(rf[a], RP_EPSILON);
+                        rd += sg[a];
+                    }
+                }
+#pragma unroll
+                for (uint32_t a = 0; a < NLMC_A; ++a)
+                    if ((mask >> a) & 1u) {
+                        nd.link[run] = node | (a << 28);
+                        nd.fac[run] = sg[a] / rd;  // instant_policy (flow.rs:46-48)
+                        run += 1;
+                    }
+            } else if (j < segbase[2]) {
+                nd.link[run] = node | (((info >> 13) & 15u) << 28);
+                nd.fac[run] = s_fac[j];
+                run += 1;
+            } else {
+                nd.link[run] = node;
+                nd.fac[run] = 1.0f;
+                run += 1;
+            }
+        }
         if (err) atomicOr(&ctl->err, err);
+        __syncthreads();  // the LDS arrays are rewritten for the next tile
     }
 }
 
@@ -361,7 +434,7 @@ __global__ __launch_bounds__(256) void k_nl_children(NlParams p, NlNodes nd, uin
     for (uint32_t base = blockIdx.x * 256u; base < total; base += gridDim.x * 256u) {
         const uint32_t c = lo + base + threadIdx.x;
         const bool valid = c < hi;
-        uint32_t err = 0, list = 3;
+        uint32_t err = 0;
         if (valid) {
             const uint32_t link = nd.link[c], par = link & 0x0fffffffu, slot = link >> 28;
             const uint32_t pm = nd.meta[par], pkind = NL_META_KIND(pm);
@@ -420,10 +493,8 @@ __global__ __launch_bounds__(256) void k_nl_children(NlParams p, NlNodes nd, uin
                 nd.hkey[c] = hk;
                 nd.meta[c] = kind | ((cdepth & 7u) << 10) | ((cplen & 15u) << 13) | (cmp << 17);
                 nd.val[c] = 0.0f;
-                list = kind == NK_WALKER ? 0u : (kind == NK_OPP ? 1u : 2u);
             }
         }
-        nl_append(nd, list, c, &err);
         if (err) atomicOr(&ctl->err, err);
     }
 }
@@ -492,13 +563,29 @@ __global__ __launch_bounds__(1024) void k_nlhe_scan(const uint32_t* dcount, uint
     }
 }
 
-// walker nodes by tree: wl[t_woff[tree] + ordinal]
-__global__ __launch_bounds__(256) void k_nl_fill(NlNodes nd) {
-    const uint32_t n = min(nd.ctl->cur[0], nd.lcap);
-    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
-        const uint32_t node = nd.list[0][j];
-        nd.wl[nd.t_woff[nd.tree[node]] + (nd.aux[node] & 0xffffu)] = node;
+// walker nodes by tree: wl[t_woff[tree] + ordinal]; the batch's node census on the way (one pass over every node's meta)
+__global__ __launch_bounds__(256) void k_nl_fill(NlNodes nd, uint32_t n_nodes) {
+    __shared__ uint32_t census[5];
+    if (threadIdx.x < 5) census[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t c[4] = {0, 0, 0, 0}, wk = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_nodes; i += gridDim.x * 256u) {
+        const uint32_t m = nd.meta[i], kind = NL_META_KIND(m);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) c[k] += kind == k ? 1u : 0u;
+        if (kind == NK_WALKER) {
+            wk += NL_META_NKIDS(m);
+            const uint32_t at = nd.t_woff[nd.tree[i]] + (nd.aux[i] & 0xffffu);
+            if (at < nd.lcap) nd.wl[at] = i;  // more walker nodes than the arrays hold: the host refuses the batch (their total)
+        }
     }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (c[k]) atomicAdd(&census[k], c[k]);
+    if (wk) atomicAdd(&census[4], wk);
+    __syncthreads();
+    if (threadIdx.x < 4 && census[threadIdx.x]) atomicAdd(&nd.ctl->kinds[threadIdx.x], census[threadIdx.x]);
+    if (threadIdx.x == 4 && census[4]) atomicAdd(&nd.ctl->walker_kids, census[4]);
 }
 
 // Tree::partition (tree.rs:88-98) for one tree per wavefront: walker nodes sorted by (row, creation index) -> spans; spans
@@ -582,8 +669,7 @@ __global__ __launch_bounds__(64) void k_nl_group(NlNodes nd, uint32_t batch) {
 
 // one Decisions per lane: record_infosets + update_vector (solver.rs:263-305) for one walker infoset of one tree.  Walks the
 // slots of the walker-node array; the first t_dcount[tree] slots of a tree stand for its spans.
-__global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t out_cap, NlBatch out) {
-    const uint32_t n = min(nd.ctl->cur[0], nd.lcap);
+__global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t n, uint32_t out_cap, NlBatch out) {
     for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
         const uint32_t tr = nd.tree[nd.ws[j]];
         const uint32_t off = nd.t_woff[tr], g = j - off;

@@ -53,6 +53,24 @@ class NlheSolver:
     def step(self, mode="ordered"):
         _lib.check(self._lib.rp_nlhe_step(self._h, _lib.UPDATE[mode]))
 
+    def profile(self, enable: bool):
+        _lib.check(self._lib.rp_nlhe_profile(self._h, 1 if enable else 0))
+
+    def kernel_times(self):
+        """{group: (total_ms, launches)} since profile(True); groups: expand, children, sweeps, decide, apply"""
+        out = {}
+        for name in ("expand", "children", "sweeps", "decide", "apply"):
+            ms, n = C.c_double(), C.c_uint64()
+            _lib.check(self._lib.rp_nlhe_kernel_time(self._h, name.encode(), C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def census(self):
+        """nodes of the profiled steps by kind + children of their walker nodes"""
+        k, w = (C.c_uint64 * 4)(), C.c_uint64()
+        _lib.check(self._lib.rp_nlhe_census(self._h, k, C.byref(w)))
+        return dict(terminal=k[0], chance=k[1], walker=k[2], opponent=k[3], walker_children=w.value)
+
     def last_shape(self):
         """(levels, nodes) of the last traversed batch"""
         a, b = C.c_uint32(), C.c_uint32()
