@@ -45,7 +45,8 @@ typedef enum rp_status {
     RP_ERR_NO_DEVICE = 2,   /* no HIP device (the product path has no CPU mode) */
     RP_ERR_HIP = 3,         /* a HIP runtime call failed (see rp_last_error)    */
     RP_ERR_UNSUPPORTED = 4, /* combination not implemented on the device path   */
-    RP_ERR_CAPACITY = 5     /* game exceeds the compiled per-tree limits        */
+    RP_ERR_CAPACITY = 5,    /* game exceeds the compiled per-tree limits        */
+    RP_ERR_INTERNAL = 6     /* a self-check of the library failed (rp_last_error) */
 } rp_status;
 
 /* human-readable text of the last failure on the calling thread */
@@ -502,6 +503,8 @@ typedef struct rp_prune_stats {
     uint64_t mfma_instructions;/* v_mfma_f32_16x16x4_f32 issued per wavefront, summed (2048 flop each) */
     uint64_t audited_points;   /* RP_LLOYD_AUDIT: points compared with the unpruned pass */
     uint64_t audit_mismatches; /* ... and how many differed in bucket or distance bits */
+    uint64_t sampled_points;   /* the production self-check: every 521st point is searched again WITHOUT the prune after every */
+    uint64_t sample_mismatches;/* pruned pass; a mismatch fails the next call that hands results out (RP_ERR_INTERNAL) */
 } rp_prune_stats;
 RP_API int rp_kmeans_prune_stats(rp_kmeans* h, rp_prune_stats* out);
 /* the divergence intervals of the bound against the current centroids: lo[N*K], hi[N*K] (tests / diagnostics) */

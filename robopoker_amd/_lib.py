@@ -109,7 +109,8 @@ class PruneStats(C.Structure):
     """rp_prune_stats (include/rp_mi355x.h): what the MFMA Sinkhorn bound discarded and what it cost"""
     _fields_ = [("enabled", C.c_uint32), ("reserved", C.c_uint32), ("points", C.c_uint64), ("candidates", C.c_uint64),
                 ("survivors", C.c_uint64), ("block_iterations", C.c_uint64), ("cost_passes", C.c_uint64),
-                ("mfma_instructions", C.c_uint64), ("audited_points", C.c_uint64), ("audit_mismatches", C.c_uint64)]
+                ("mfma_instructions", C.c_uint64), ("audited_points", C.c_uint64), ("audit_mismatches", C.c_uint64),
+                ("sampled_points", C.c_uint64), ("sample_mismatches", C.c_uint64)]
 
 
 _SIGNATURES = {
@@ -283,6 +284,13 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C robopoker_amd/csrc).  The MI355X path has no CPU fallback."
         )
+    # One HIP runtime per process: PyTorch ships its own libamdhip64, and whichever copy initialises the device first owns it —
+    # a torch imported AFTER the library's first HIP call finds "No HIP GPUs".  Tests, bench.py and the multi-GPU harness all use
+    # torch tensors for device buffers, so when torch is installed it is imported first, whatever order the callers import in.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

@@ -799,8 +799,18 @@ __global__ __launch_bounds__(64) void k_neighbor_masked(Points P, CentroidSet cs
     uint32_t bj = 0;
     float bd = 0.0f;
     bool first = true;
+    // Two guards so that a bound that missed can cost time, never a bucket: the centroid whose exact distance seeded the bound
+    // (the hint) is always a candidate, and a mask without any centroid below K means "search them all".
+    unsigned long long mq[4];
+    bool any = false;
     for (uint32_t q = 0; q < 4; ++q) {
-        unsigned long long bits = mask[i * 4 + q];
+        mq[q] = mask[i * 4 + q];
+        if (hint_j && (hint_j[i] >> 6) == q) mq[q] |= 1ull << (hint_j[i] & 63u);
+        const uint32_t below = K > q * 64u ? min(K - q * 64u, 64u) : 0u;
+        any = any || (mq[q] & (below == 64u ? ~0ull : ((1ull << below) - 1ull))) != 0ull;
+    }
+    for (uint32_t q = 0; q < 4; ++q) {
+        unsigned long long bits = any ? mq[q] : ~0ull;
         while (bits) {
             const uint32_t k = q * 64 + (uint32_t)__builtin_ctzll(bits);
             bits &= bits - 1;
@@ -878,6 +888,14 @@ __global__ __launch_bounds__(256) void k_mask_all(const uint32_t* list, uint32_t
     for (int q = 0; q < 4; ++q) mask[(size_t)list[e] * 4 + q] = ~0ull;
 }
 
+// the production sample check: the same comparison over a list of points
+__global__ __launch_bounds__(256) void k_audit_compare_list(const uint8_t* ja, const float* da, const uint8_t* jb, const float* db,
+                                                            const uint32_t* list, uint32_t n, unsigned long long* bad) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t i = list[e];
+    if (ja[i] != jb[i] || __float_as_uint(da[i]) != __float_as_uint(db[i])) atomicAdd(bad, 1ull);
+}
 // RP_LLOYD_AUDIT: count the points on which two neighbor passes disagree (bucket or distance bits)
 __global__ __launch_bounds__(256) void k_audit_compare(const uint8_t* ja, const float* da, const uint8_t* jb, const float* db, uint64_t N,
                                                        unsigned long long* bad) {
@@ -1902,6 +1920,7 @@ const char* const CLOCK_NAMES[] = {"pairwise", "step", "recompute", "bounds", "n
 enum { CK_PAIRWISE, CK_STEP, CK_RECOMPUTE, CK_BOUNDS, CK_NEIGHBOR, CK_SELF, CK_KPP, CK_DRIFT, CK_BOUND, CK_COUNT };
 }  // namespace
 
+#define SB_SAMPLE_STRIDE 521u  // the production self-check of the MFMA prune looks at every 521st point (0.2 % more exact solves)
 struct rp_kmeans {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1953,7 +1972,11 @@ struct rp_kmeans {
     unsigned int* sb_cursor = nullptr;      // [4]
     unsigned long long* sb_mask = nullptr;  // [N][4]
     unsigned long long* sb_stats = nullptr; // striped: survivors, points, column-block iterations, cost passes
-    unsigned long long* sb_bad = nullptr;   // [1] audit disagreements
+    unsigned long long* sb_bad = nullptr;   // [0] audit disagreements, [1] disagreements of the production sample check
+    uint32_t* sb_sample = nullptr;          // the sampled points (every SB_SAMPLE_STRIDE-th)
+    uint32_t sb_nsample = 0;
+    uint64_t sb_sampled = 0;
+    bool sb_check_pending = false;
     uint8_t* audit_j = nullptr;
     float* audit_d = nullptr;
     float* sb_d = nullptr;
@@ -2211,11 +2234,13 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         h->sb.neg_t_ln2 = -h->hp.temperature * 0.6931472f;
         h->sb.tol = h->hp.tolerance;
         h->sb.iters = h->hp.iterations;
-        h->sb.kappa = envf("RP_SB_KAPPA", 2.0f);
-        h->sb.rho = envf("RP_SB_RHO", 1.25f);
-        h->sb.dc_abs = envf("RP_SB_DC_ABS", 4e-6f);
-        h->sb.dc_rel = envf("RP_SB_DC_REL", 4e-5f);
-        h->sb.flat = envf("RP_SB_FLAT", 4.0f);
+        // the margins can be WIDENED through the environment (more survivors, same results); values on the unsafe side of the
+        // validated defaults (profiles/r03_mfma_audit.json) are clamped back to them
+        h->sb.kappa = std::max(envf("RP_SB_KAPPA", 2.0f), 2.0f);
+        h->sb.rho = std::max(envf("RP_SB_RHO", 1.25f), 1.25f);
+        h->sb.dc_abs = std::max(envf("RP_SB_DC_ABS", 4e-6f), 4e-6f);
+        h->sb.dc_rel = std::max(envf("RP_SB_DC_REL", 4e-5f), 4e-5f);
+        h->sb.flat = std::min(envf("RP_SB_FLAT", 4.0f), 4.0f);
         {
             float cmax = 0.0f;
             for (size_t t = 0; t < (size_t)bins * (bins - 1) / 2; ++t) cmax = std::max(cmax, tri_metric[t]);
@@ -2239,14 +2264,22 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         KM_TRY(dev_alloc(h, &h->sb_mask, (size_t)N * 4));
         KM_TRY(dev_alloc(h, &h->sb_stats, (size_t)KM_STAT_STRIPES * STAT_STRIDE));
         KM_HIP(hipMemset(h->sb_stats, 0, (size_t)KM_STAT_STRIPES * STAT_STRIDE * 8));
-        KM_TRY(dev_alloc(h, &h->sb_bad, 1));
-        KM_HIP(hipMemset(h->sb_bad, 0, 8));
+        KM_TRY(dev_alloc(h, &h->sb_bad, 2));
+        KM_HIP(hipMemset(h->sb_bad, 0, 16));
         KM_TRY(dev_alloc(h, &h->sb_d, N));
         KM_TRY(dev_alloc(h, &h->sb_ub0, N));
         KM_TRY(dev_alloc(h, &h->sb_hint_j, N));
         KM_TRY(dev_alloc(h, &h->sb_hint_mask, (size_t)N * 4));
         h->sb_audit = getenv("RP_LLOYD_AUDIT") != nullptr;
-        if (h->sb_audit) {
+        {
+            // production self-check: every SB_SAMPLE_STRIDE-th point goes through the unpruned search after every pruned pass;
+            // a disagreement fails the next call that hands results out (never a silently different bucket)
+            std::vector<uint32_t> smp;
+            if (!getenv("RP_LLOYD_NO_SAMPLE_CHECK"))
+                for (uint64_t i = 0; i < N; i += SB_SAMPLE_STRIDE) smp.push_back((uint32_t)i);
+            h->sb_nsample = (uint32_t)smp.size();
+            KM_TRY(dev_alloc(h, &h->sb_sample, smp.size()));
+            if (!smp.empty()) KM_HIP(hipMemcpy(h->sb_sample, smp.data(), smp.size() * 4, hipMemcpyHostToDevice));
             KM_TRY(dev_alloc(h, &h->audit_j, N));
             KM_TRY(dev_alloc(h, &h->audit_d, N));
         }
@@ -2302,6 +2335,19 @@ int need_bounds(const rp_kmeans* h, const char* who) {
 }
 
 // every (point, centroid) distance through the bit-faithful kernels: the reference's loop as it stands
+// the production self-check of the pruned passes (launch_neighbor, the init_bounds shortcut): a sampled point whose pruned result
+// differs from the unpruned search is a library bug that would silently move a bucket — the call fails instead
+int prune_check(rp_kmeans* h, const char* who) {
+    if (!h->sb_on || !h->sb_check_pending) return RP_OK;
+    unsigned long long bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, h->sb_bad + 1, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->sb_check_pending = false;
+    if (bad)
+        return rp::fail(RP_ERR_INTERNAL, "%s: the pruned nearest-centroid search disagrees with the unpruned one on %llu of the sampled points "
+                                         "(set RP_LLOYD_NO_MFMA_BOUND=1 and report)", who, bad);
+    return RP_OK;
+}
 int launch_neighbor_full(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init) {
     ck_begin(h, CK_NEIGHBOR);
     if (h->kind == RP_METRIC_VARIATION && h->bins == 101)  // turn layer: register-resident centroid CDFs
@@ -2385,6 +2431,18 @@ int launch_neighbor(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init, int
                        out_j, dd, init, hint_j, hint_j ? ub0 : (const float*)nullptr);
     ck_end(h, CK_NEIGHBOR);
     HIP_TRY(hipGetLastError());
+    if (!h->sb_audit && out_j && h->sb_nsample) {  // the sampled points once more, unpruned (k_neighbor takes a point list)
+        Bounds none{};
+        ck_begin(h, CK_NEIGHBOR);
+        hipLaunchKernelGGL(k_neighbor, dim3(h->sb_nsample), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->kind, h->audit_j,
+                           h->audit_d, none, (const uint32_t*)h->sb_sample);
+        ck_end(h, CK_NEIGHBOR);
+        hipLaunchKernelGGL(k_audit_compare_list, dim3((h->sb_nsample + 255) / 256), dim3(256), 0, h->stream, out_j, dd, h->audit_j,
+                           h->audit_d, h->sb_sample, h->sb_nsample, h->sb_bad + 1);
+        HIP_TRY(hipGetLastError());
+        h->sb_sampled += h->sb_nsample;
+        h->sb_check_pending = true;
+    }
     if (h->sb_audit && out_j) {  // RP_LLOYD_AUDIT: the unpruned pass next to it; disagreements are counted, never corrected
         Bounds none{};
         if ((rc = launch_neighbor_full(h, h->audit_j, h->audit_d, none))) return rc;
@@ -2674,7 +2732,7 @@ int rp_kmeans_init_bounds(rp_kmeans* h) {
     int rc = need_centroids(h, "rp_kmeans_init_bounds");
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
-    if (h->M.kpp_d && h->pot_is_min_d2 && !h->sb_audit) {
+    if (h->M.kpp_d && h->pot_is_min_d2) {
         // right after k-means++ on these very centroids: the nearest centroid of almost every point is already known
         // (k_init_from_kpp); the exact search runs on the rest
         unsigned int n_todo = 0;
@@ -2690,13 +2748,32 @@ int rp_kmeans_init_bounds(rp_kmeans* h) {
                                (float*)nullptr, h->B, h->kpp_todo);
         ck_end(h, CK_NEIGHBOR);
         HIP_TRY(hipGetLastError());
+        // the shortcut trusts the k-means++ column-marginal filter: checked like the MFMA prune — on the sample in production,
+        // on every point under RP_LLOYD_AUDIT — against the unpruned search (bucket and upper bound, bit for bit)
+        if (h->sb_on && (h->sb_audit || h->sb_nsample)) {
+            Bounds none{};
+            if (h->sb_audit) {
+                if ((rc = launch_neighbor_full(h, h->audit_j, h->audit_d, none))) return rc;
+                hipLaunchKernelGGL(k_audit_compare, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, h->B.j, h->B.u, h->audit_j,
+                                   h->audit_d, h->N, h->sb_bad);
+                h->sb_audited += h->N;
+            } else {
+                hipLaunchKernelGGL(k_neighbor, dim3(h->sb_nsample), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->kind,
+                                   h->audit_j, h->audit_d, none, (const uint32_t*)h->sb_sample);
+                hipLaunchKernelGGL(k_audit_compare_list, dim3((h->sb_nsample + 255) / 256), dim3(256), 0, h->stream, h->B.j, h->B.u,
+                                   h->audit_j, h->audit_d, h->sb_sample, h->sb_nsample, h->sb_bad + 1);
+                h->sb_sampled += h->sb_nsample;
+                h->sb_check_pending = true;
+            }
+            HIP_TRY(hipGetLastError());
+        }
     } else if ((rc = launch_neighbor(h, h->prior, nullptr, h->B, NB_INIT_BOUNDS))) {  // Prior::from_bounds (prior.rs:23-32)
         return rc;
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->bounds_ready = true;
     ck_drain(h);
-    return RP_OK;
+    return prune_check(h, "rp_kmeans_init_bounds");
 }
 
 int rp_kmeans_step(rp_kmeans* h, float* drift, uint64_t* sizes, double* reassigned) {
@@ -2775,7 +2852,7 @@ int rp_kmeans_step_naive(rp_kmeans* h) {
     h->cur = nxt;
     h->pot_is_min_d2 = false;
     ck_drain(h);
-    return RP_OK;
+    return prune_check(h, "rp_kmeans_step_naive");
 }
 
 int rp_kmeans_assign(rp_kmeans* h, uint8_t* bucket, float* distance) {
@@ -2789,7 +2866,7 @@ int rp_kmeans_assign(rp_kmeans* h, uint8_t* bucket, float* distance) {
     if (distance) HIP_TRY(hipMemcpyAsync(distance, h->pdist, h->N * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     ck_drain(h);
-    return RP_OK;
+    return prune_check(h, "rp_kmeans_assign");
 }
 
 int rp_kmeans_bounds(rp_kmeans* h, uint8_t* j, float* upper, float* lower) {
@@ -2902,9 +2979,9 @@ int rp_kmeans_prune_stats(rp_kmeans* h, rp_prune_stats* out) {
     if (!h->sb_on) return RP_OK;
     HIP_TRY(hipSetDevice(h->device));
     std::vector<unsigned long long> all((size_t)KM_STAT_STRIPES * STAT_STRIDE);
-    unsigned long long bad = 0;
+    unsigned long long bad[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(all.data(), h->sb_stats, all.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(&bad, h->sb_bad, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(bad, h->sb_bad, 16, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     unsigned long long s[5] = {0, 0, 0, 0, 0};
     for (uint32_t q = 0; q < KM_STAT_STRIPES; ++q)
@@ -2916,7 +2993,9 @@ int rp_kmeans_prune_stats(rp_kmeans* h, rp_prune_stats* out) {
     out->cost_passes = s[3];
     out->mfma_instructions = s[4];
     out->audited_points = h->sb_audited;
-    out->audit_mismatches = bad;
+    out->audit_mismatches = bad[0];
+    out->sampled_points = h->sb_sampled;
+    out->sample_mismatches = bad[1];
     return RP_OK;
 }
 

@@ -378,6 +378,7 @@ struct rp_nlhe {
     bool profiling = false;
     Clock clk[5];  // expand, children, sweeps (up + down), decide (scan + fill + group + emit), apply
     uint64_t census[5] = {0, 0, 0, 0, 0};  // nodes by kind + walker children, summed over the profiled steps
+    int expand_waves = 4;  // RP_NLHE_EXPAND_WAVES: 4 (128 VGPRs) or 5 (96 VGPRs, some spilled)
     uint32_t grid_cap = 16384;  // workgroups of the grid-stride kernels (RP_NLHE_GRID; measured: 1024 -14 %, 4096 -4 %)
 };
 
@@ -476,7 +477,8 @@ int nl_traverse_levels(rp_nlhe* h) {
         for (; L < stop; ++L) {
             h->prm.tag = nl_next_tag(h);
             nl_clock_begin(h, 0);
-            hipLaunchKernelGGL(k_nl_expand, wide, blk, 0, st, h->prm, h->tab, lv, L);
+            if (h->expand_waves == 5) hipLaunchKernelGGL(k_nl_expand<5>, wide, blk, 0, st, h->prm, h->tab, lv, L);
+            else hipLaunchKernelGGL(k_nl_expand<4>, wide, blk, 0, st, h->prm, h->tab, lv, L);
             nl_clock_end(h, 0);
             nl_clock_begin(h, 1);
             hipLaunchKernelGGL(k_nl_children, wide, blk, 0, st, h->prm, lv, L);
@@ -544,6 +546,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     h->seed = seed;
     h->lane_per_tree = getenv("RP_NLHE_LANE_PER_TREE") != nullptr;
     if (getenv("RP_NLHE_GRID")) h->grid_cap = std::max(1, atoi(getenv("RP_NLHE_GRID")));
+    if (getenv("RP_NLHE_EXPAND_WAVES")) h->expand_waves = atoi(getenv("RP_NLHE_EXPAND_WAVES"));
 #define NL_TRY(expr)                    \
     do {                                \
         int _rc = (expr);               \

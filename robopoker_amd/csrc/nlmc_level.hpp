@@ -156,13 +156,13 @@ __global__ __launch_bounds__(256) void k_nl_roots(NlParams p, NlNodes nd) {
 // k_nl_expand: the nodes of one level, by kind.  encoder.info + branches + sample (builder.rs:98-139).
 // ---------------------------------------------------------------------------------------------------------------
 #define NL_TILE 2048u  // nodes a workgroup sorts by kind at a time (8 per thread)
-__global__ __launch_bounds__(256) void k_nl_expand(NlParams p, NlTable t, NlNodes nd, uint32_t level) {
+template <int MINW>  // minimum wavefronts per SIMD the register allocation aims for
+__global__ __launch_bounds__(256, MINW) void k_nl_expand(NlParams p, NlTable t, NlNodes nd, uint32_t level) {
     constexpr uint32_t R = NL_TILE / 256u;         // classification sub-rounds
     constexpr uint32_t SCAP = NL_TILE + 192u;      // the sorted tile: three kinds, each from a multiple of 64
     __shared__ uint32_t sorted[SCAP];  // node index
     __shared__ uint32_t s_info[SCAP];  // n_kids | expanded mask << 4 | sampled slot << 13   (what the write phase needs)
-    __shared__ uint32_t s_row[SCAP];   // walker items: the infoset's row
-    __shared__ float s_fac[SCAP];      // opponent items: sigma / q of the sampled edge
+    __shared__ uint32_t s_aux[SCAP];   // walker items: the infoset's row; opponent items: the bits of sigma / q of the sampled edge
     __shared__ uint32_t wcnt[R][4][3];  // per sub-round, wavefront, kind: count, then exclusive prefix
     __shared__ uint32_t segbase[3], segcnt[3], wsum[4], blockbase, tiletotal;
     NlCtl* ctl = nd.ctl;
@@ -253,15 +253,6 @@ __global__ __launch_bounds__(256) void k_nl_expand(NlParams p, NlTable t, NlNode
             bool settled = true;
             const uint32_t row = (p.ablate & 2u) ? ((uint32_t)khash & t.mask) : nl_row_of(t, past, chpath, present, khash, nch, p.tag, &err, &settled);
             if (!settled) nl_load_row(t.rows, row, seg == 1, rf);
-            float sg[NLMC_A], rd = 0.0f;
-#pragma unroll
-            for (uint32_t a = 0; a < NLMC_A; ++a) {
-                sg[a] = 0.0f;
-                if (a < nch) {
-                    sg[a] = rp_maxf(rf[a], RP_EPSILON);  // RefProf::regret (profile.rs:31-33)
-                    rd += sg[a];
-                }
-            }
             const uint32_t all = (1u << nch) - 1u;
             uint32_t mask, pick = 0, nkids;
             float oppfac = 1.0f;
@@ -292,14 +283,19 @@ __global__ __launch_bounds__(256) void k_nl_expand(NlParams p, NlTable t, NlNode
                 const uint32_t ord = (p.ablate & 1u) ? 0u : atomicAdd(&nd.t_nw[tree], 1u);
                 if (ord >= NL_WMAX) err |= NERR_WALKERS;
                 nd.aux[node] = ord | (mask << 16);
-                s_row[j] = row;
+                s_aux[j] = row;
             } else {
                 // opponent: weighted (sample/external.rs:41-64) over sampling_distribution (flow.rs:24-42), one draw per
                 // (epoch, infoset, tree)
-                float sw[NLMC_A], wsum_ = 0.0f, z = 0.0f;
+                // (registers are what limits this kernel's occupancy: the policy sigma is needed for the sampled edge only, the
+                // cumulative weights are a running sum — no arrays beyond the row itself and the sampling weights)
+                float sw[NLMC_A], rd = 0.0f, wsum_ = 0.0f, z = 0.0f;
 #pragma unroll
                 for (uint32_t a = 0; a < NLMC_A; ++a)
-                    if (a < nch) wsum_ += rp_maxf(rf[NLMC_A + a], RP_EPSILON);
+                    if (a < nch) {
+                        rd += rp_maxf(rf[a], RP_EPSILON);  // RefProf::regret (profile.rs:31-33), summed in choices() order
+                        wsum_ += rp_maxf(rf[NLMC_A + a], RP_EPSILON);
+                    }
                 const float denom = wsum_ + p.smoothing;
 #pragma unroll
                 for (uint32_t a = 0; a < NLMC_A; ++a) {
@@ -309,28 +305,25 @@ __global__ __launch_bounds__(256) void k_nl_expand(NlParams p, NlTable t, NlNode
                         z += sw[a];
                     }
                 }
-                float total_w = 0.0f, cum[NLMC_A];
+                float total_w = 0.0f;
 #pragma unroll
-                for (uint32_t a = 0; a < NLMC_A; ++a) {
-                    cum[a] = 0.0f;
-                    if (a < nch) {
-                        total_w += rp_maxf(sw[a] / z, RP_EPSILON);
-                        cum[a] = total_w;
-                    }
-                }
+                for (uint32_t a = 0; a < NLMC_A; ++a)
+                    if (a < nch) total_w += rp_maxf(sw[a] / z, RP_EPSILON);
                 const float u = rp_u01(rp_node_hash_draw(p.step_hash, p.tree_base + tree, khash)) * total_w;
-                float swp = sw[0], sgp = sg[0];
+                float swp = sw[0], rgp = rf[0], cum = 0.0f;
 #pragma unroll
-                for (uint32_t a = 0; a + 1 < NLMC_A; ++a)  // while (pick + 1 < nch && cum[pick] <= u) ++pick
-                    if (pick == a && a + 1 < nch && cum[a] <= u) {
+                for (uint32_t a = 0; a + 1 < NLMC_A; ++a) {  // while (pick + 1 < nch && cum[pick] <= u) ++pick
+                    if (a < nch) cum += rp_maxf(sw[a] / z, RP_EPSILON);  // cum[a]: the same running sum as total_w
+                    if (pick == a && a + 1 < nch && cum <= u) {
                         pick = a + 1;
                         swp = sw[a + 1];
-                        sgp = sg[a + 1];
+                        rgp = rf[a + 1];
                     }
-                oppfac = (sgp / rd) / (swp / z);  // sigma / q of the sampled edge
+                }
+                oppfac = (rp_maxf(rgp, RP_EPSILON) / rd) / (swp / z);  // sigma / q of the sampled edge
                 mask = 1u << pick;
                 nkids = 1;
-                s_fac[j] = oppfac;
+                s_aux[j] = __float_as_uint(oppfac);
             }
             nd.row[node] = row;
             nd.chpath[node] = chpath;
@@ -340,7 +333,7 @@ __global__ __launch_bounds__(256) void k_nl_expand(NlParams p, NlTable t, NlNode
         }
         // ---- 3. one contiguous run of node indices for all children of the tile, in the tile's sorted order (neighbouring
         //         parents get neighbouring child blocks: the next kernels read both): block prefix sum over s_info, ONE cursor bump
-        __syncthreads();  // every s_info / s_row / s_fac of the tile is written
+        __syncthreads();  // every s_info / s_aux of the tile is written
         constexpr uint32_t CH = (SCAP + 255u) / 256u;  // consecutive items per thread in the scan
         uint32_t mine = 0;
 #pragma unroll
@@ -389,7 +382,7 @@ __global__ __launch_bounds__(256) void k_nl_expand(NlParams p, NlTable t, NlNode
             nd.kid0[node] = run;
             if (j < segbase[1]) {  // walker: sigma of every surviving edge, recomputed from the row (the same operations as above)
                 float rf[12], sg[NLMC_A], rd = 0.0f;
-                nl_load_row(t.rows, s_row[j], false, rf);
+                nl_load_row(t.rows, s_aux[j], false, rf);
                 const uint32_t nch = NL_META_NCH(nd.meta[node]);
 #pragma unroll
                 for (uint32_t a = 0; a < NLMC_A; ++a) {
@@ -408,7 +401,7 @@ __global__ __launch_bounds__(256) void k_nl_expand(NlParams p, NlTable t, NlNode
                     }
             } else if (j < segbase[2]) {
                 nd.link[run] = node | (((info >> 13) & 15u) << 28);
-                nd.fac[run] = s_fac[j];
+                nd.fac[run] = __uint_as_float(s_aux[j]);
                 run += 1;
             } else {
                 nd.link[run] = node;
@@ -668,58 +661,87 @@ __global__ __launch_bounds__(64) void k_nl_group(NlNodes nd, uint32_t batch) {
 }
 
 // one Decisions per lane: record_infosets + update_vector (solver.rs:263-305) for one walker infoset of one tree.  Walks the
-// slots of the walker-node array; the first t_dcount[tree] slots of a tree stand for its spans.
+// slots of the walker-node array; the first t_dcount[tree] slots of a tree stand for its spans.  Slots and Decisions are both
+// numbered tree-major, so the active lanes of a wavefront own a CONTIGUOUS run of Decisions: the [n][9] regret / policy rows are
+// staged in LDS by active rank and stored as whole 64-lane lines instead of 18 stores of stride 36 B.
 __global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t n, uint32_t out_cap, NlBatch out) {
-    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
-        const uint32_t tr = nd.tree[nd.ws[j]];
-        const uint32_t off = nd.t_woff[tr], g = j - off;
-        if (g >= nd.t_dcount[tr]) continue;
-        const uint32_t d = nd.t_doff[tr] + g;
-        if (d >= out_cap) continue;  // the host has already refused the batch
-        const uint32_t desc = nd.gdesc[j], start = desc & 0xfffu, len = desc >> 12;
-        const uint32_t first = nd.ws[off + start];
-        const uint32_t row = nd.row[first], nch = NL_META_NCH(nd.meta[first]);
-        const float* r = t.rows + (size_t)row * 4u * NLMC_A;
-        float sg[NLMC_A], rd = 0.0f, acc[NLMC_A];
-#pragma unroll
-        for (uint32_t a = 0; a < NLMC_A; ++a) {
-            acc[a] = 0.0f;
-            sg[a] = 0.0f;
-            if (a < nch) {
-                sg[a] = rp_maxf(r[a], RP_EPSILON);
-                rd += sg[a];
+    __shared__ float tile[4][2][64 * NLMC_A];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t padded = (n + 255u) & ~255u;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < padded; j += gridDim.x * 256u) {
+        bool active = false;
+        uint32_t d = 0, tr = 0, off = 0, g = 0;
+        if (j < n) {
+            tr = nd.tree[nd.ws[j]];
+            off = nd.t_woff[tr];
+            g = j - off;
+            if (g < nd.t_dcount[tr]) {
+                d = nd.t_doff[tr] + g;
+                active = d < out_cap;  // beyond: the host has already refused the batch
             }
         }
-        float pay = 0.0f;
-        uint32_t expanded = 0;
-        for (uint32_t mb = 0; mb < len; ++mb) {  // the span in ascending creation index
-            const uint32_t node = nd.ws[off + start + mb];
-            const uint32_t em = nd.aux[node] >> 16, k0 = nd.kid0[node];
-            const float reach = nd.reach[node];
-            float cfv[NLMC_A], ev = 0.0f;
+        float acc[NLMC_A], pol[NLMC_A];
+        if (active) {
+            const uint32_t desc = nd.gdesc[j], start = desc & 0xfffu, len = desc >> 12;
+            const uint32_t first = nd.ws[off + start];
+            const uint32_t row = nd.row[first], nch = NL_META_NCH(nd.meta[first]);
+            float rf[12], sg[NLMC_A], rd = 0.0f;
+            nl_load_row(t.rows, row, false, rf);
 #pragma unroll
             for (uint32_t a = 0; a < NLMC_A; ++a) {
-                cfv[a] = 0.0f;
-                if ((em >> a) & 1u) {
-                    cfv[a] = reach * nd.val[k0 + (uint32_t)__popc(em & ((1u << a) - 1u))];
-                    ev += sg[a] / rd * cfv[a];
+                acc[a] = 0.0f;
+                sg[a] = 0.0f;
+                if (a < nch) {
+                    sg[a] = rp_maxf(rf[a], RP_EPSILON);
+                    rd += sg[a];
                 }
             }
-            pay += ev;
+            float pay = 0.0f;
+            uint32_t expanded = 0;
+            for (uint32_t mb = 0; mb < len; ++mb) {  // the span in ascending creation index
+                const uint32_t node = nd.ws[off + start + mb];
+                const uint32_t em = nd.aux[node] >> 16, k0 = nd.kid0[node];
+                const float reach = nd.reach[node];
+                float cfv[NLMC_A], ev = 0.0f;
 #pragma unroll
-            for (uint32_t a = 0; a < NLMC_A; ++a)
-                if ((em >> a) & 1u) acc[a] += cfv[a] - ev;
-            expanded |= em;
+                for (uint32_t a = 0; a < NLMC_A; ++a) {
+                    cfv[a] = 0.0f;
+                    if ((em >> a) & 1u) {
+                        cfv[a] = reach * nd.val[k0 + (uint32_t)__popc(em & ((1u << a) - 1u))];
+                        ev += sg[a] / rd * cfv[a];
+                    }
+                }
+                pay += ev;
+#pragma unroll
+                for (uint32_t a = 0; a < NLMC_A; ++a)
+                    if ((em >> a) & 1u) acc[a] += cfv[a] - ev;
+                expanded |= em;
+            }
+#pragma unroll
+            for (uint32_t a = 0; a < NLMC_A; ++a) pol[a] = a < nch ? sg[a] / rd : 0.0f;  // policy_vector = iterated_distribution (flow.rs:118-120)
+            out.row[d] = row;
+            out.nact[d] = (uint8_t)nch;
+            out.expanded[d] = (uint16_t)expanded;
+            out.payoff[d] = pay;
+            out.tree[d] = tr;
         }
-        out.row[d] = row;
-        out.nact[d] = (uint8_t)nch;
-        out.expanded[d] = (uint16_t)expanded;
-        out.payoff[d] = pay;
-        out.tree[d] = tr;
+        const unsigned long long am = __ballot(active);
+        if (am) {
+            const uint32_t nact = (uint32_t)__popcll(am), rank = nl_rank_in(am);
+            const uint32_t d0 = (uint32_t)__shfl((int)d, __builtin_ctzll(am));  // Decisions d0 .. d0 + nact - 1, in lane order
+            if (active) {
 #pragma unroll
-        for (uint32_t a = 0; a < NLMC_A; ++a) {
-            out.regret[(size_t)d * NLMC_A + a] = acc[a];
-            out.policy[(size_t)d * NLMC_A + a] = a < nch ? sg[a] / rd : 0.0f;  // policy_vector = iterated_distribution (flow.rs:118-120)
+                for (uint32_t a = 0; a < NLMC_A; ++a) {
+                    tile[wave][0][rank * NLMC_A + a] = acc[a];
+                    tile[wave][1][rank * NLMC_A + a] = pol[a];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t e = lane; e < nact * NLMC_A; e += 64u) {
+                out.regret[(size_t)d0 * NLMC_A + e] = tile[wave][0][e];
+                out.policy[(size_t)d0 * NLMC_A + e] = tile[wave][1][e];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }

@@ -194,6 +194,38 @@ class Layer:
         return ms.value, n.value
 
 
+def margin_audit(points, centroids, tri, hp=None, device=0, chunk=64) -> dict:
+    """How much room the MFMA bound's intervals (csrc/sinkhorn_bound.hpp) leave around the exact divergence: for every
+    (point, centroid) pair of ``points`` (S, bins) x ``centroids`` (K, bins) the interval [lo, hi] of the bound and the
+    bit-faithful ``distance(centroid, point)``.  slack = min(exact - lo, hi - exact) >= 0 or the interval missed; reported
+    absolute and relative to the cost margin the kernel applies (dc_abs + dc_rel * d)."""
+    points = np.ascontiguousarray(points, dtype=np.uint8)
+    centroids = np.ascontiguousarray(centroids, dtype=np.uint32)
+    S, K = points.shape[0], centroids.shape[0]
+    sub = Layer(K, points, "sinkhorn", tri, hp=hp, seed=1, device=device)
+    sub.set_centroids(np.arange(K, dtype=np.uint64) % S)
+    for k in range(K):
+        sub.set_centroid(k, centroids[k])
+    lo, hi = sub.bound_intervals()
+    sub.close()
+    exact = np.zeros((S, K), dtype=np.float32)
+    for a in range(0, S, chunk):
+        b = min(S, a + chunk)
+        mu = np.repeat(centroids[None, :, :], b - a, axis=0).reshape(-1, centroids.shape[1])
+        nu = np.repeat(points[a:b].astype(np.uint32), K, axis=0)
+        exact[a:b] = sinkhorn_divergence(mu, nu, tri, hp, device).reshape(b - a, K)
+    finite = np.isfinite(hi)
+    miss = (exact < lo) | (exact > hi)
+    slack = np.minimum(exact - lo, np.where(finite, hi - exact, np.inf))
+    margin = 4e-6 + 4e-5 * exact
+    nearest = exact.argmin(axis=1)
+    return {"pairs": int(S * K), "closed_intervals": int(finite.sum()), "missed": int(miss.sum()),
+            "min_slack": float(slack.min()), "min_slack_over_margin": float((slack / margin).min()),
+            "median_slack_over_margin": float(np.median((slack / margin)[finite])),
+            "nearest_always_closed": bool(finite[np.arange(S), nearest].all()),
+            "survivors_per_point": float((lo <= hi.min(axis=1, keepdims=True)).sum(axis=1).mean())}
+
+
 def sinkhorn_divergence(mu, nu, tri, hp=None, device=0) -> np.ndarray:
     """``Sinkhorn::divergence`` (sinkhorn.rs:166-171) for P pairs: mu, nu are (P, bins) u32 counts."""
     mu = np.ascontiguousarray(np.atleast_2d(mu), dtype=np.uint32)

@@ -143,6 +143,16 @@ def cluster_layer(street: str, below: Artifacts, tri=None, K=None, iterations=No
     future, weight = layer.centroids()
     tm["rms"] = layer.rms()
     tm["distances"], tm["sinkhorn_iterations"] = layer.stats()
+    if kind == "sinkhorn":
+        import os
+
+        tm["prune"] = layer.prune_stats()
+        n_margin = int(os.environ.get("RP_LLOYD_MARGIN_SAMPLE", "0"))
+        if n_margin:  # scripts/mfma_audit.py: the bound's room around the exact divergence on a sample of THESE points
+            from .lloyd import margin_audit
+
+            idx = torch.linspace(0, points.shape[0] - 1, n_margin, device=points.device).long()
+            tm["margins"] = margin_audit(points[idx].cpu().numpy(), future, tri, device=dev.index or 0)
     layer.close()
     del points
     return Artifacts(street, obs, torch.from_numpy(bucket).to(dev), metric, future, weight, tm)

@@ -27,3 +27,13 @@ with open(out, "w") as f:
     for k in sorted(tot, key=lambda k: -tot[k]):
         f.write(f"{cnt[k] / nsteps:14.1f} {tot[k] / nsteps:12.1f} {tot[k] / cnt[k]:10.2f} {100 * tot[k] / busy:6.2f}  {k[:100]}\n")
 print(open(out).read())
+
+# per-launch durations of the level kernels of ONE steady step (the last one inside the window)
+if len(sys.argv) > 6:
+    last = roots[skip + nsteps - 1]
+    nxt = t1
+    print("# per level (us): expand | children")
+    ex = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if last <= int(r["Start_Timestamp"]) < nxt and "k_nl_expand" in r["Kernel_Name"]]
+    ch = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if last <= int(r["Start_Timestamp"]) < nxt and "k_nl_children" in r["Kernel_Name"]]
+    for l, (a, b) in enumerate(zip(ex, ch)):
+        print(f"{l:3d} {a:9.1f} {b:9.1f}")
