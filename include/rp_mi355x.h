@@ -178,6 +178,12 @@ typedef enum rp_update_mode {
     RP_UPDATE_ORDERED = 0, /* per-key sequential application in tree-id order: solver.rs:96-105 exactly */
     RP_UPDATE_COMPOSED = 1 /* per-key composed (a,b,floor) maps; used for the multi-GPU exchange         */
 } rp_update_mode;
+/* WHICH MODE TO USE.  ORDERED is the reference's arithmetic bit for bit and the default of rp_mccfr_create (a drop-in caller
+ * gets the reference's numbers); it is a serial chain per table cell: 0.35 G infoset-updates/s on Leduc.  COMPOSED re-associates
+ * the same touches (tables within rtol 1e-4 per step of ORDERED, the "stated fp32 tolerance" of the build's north star), runs
+ * 100x faster (36 G/s) and is the only mode that shards across GPUs — it is the mode bench.py's headline `value` is measured in
+ * (`other_update_mode` in the same line quotes ORDERED).  Select it at creation with rp_mccfr_create_mode, or later with
+ * rp_mccfr_set_update_mode.  Discounted / Asymmetric regret (sign-dependent discount) exist in ORDERED only. */
 
 /* Composed update: a BLOCK is the set of Decisions of one infoset produced by one chunk of RP_COMPOSE_CHUNK
  * consecutive trees (of this rank); it is composed sequentially, in tree-id order, from the identity into a map
@@ -194,6 +200,9 @@ typedef enum rp_update_mode {
  * `batch_size` = Solver::batch_size() (trees per step). */
 RP_API int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind w, rp_sampling_kind s,
                            uint32_t batch_size, const rp_hyper* hp, uint64_t seed, int device, rp_mccfr** out);
+RP_API int rp_mccfr_create_mode(const rp_game_table* game, rp_regret_kind r, rp_weight_kind w, rp_sampling_kind s,
+                                uint32_t batch_size, const rp_hyper* hp, uint64_t seed, int device, rp_update_mode mode,
+                                rp_mccfr** out);
 RP_API int rp_mccfr_destroy(rp_mccfr* h);
 /* Solver::step (solver.rs:96-105): batch() then update_{regret,weight,payoff,visits} then epoch += 1 */
 RP_API int rp_mccfr_step(rp_mccfr* h);
@@ -351,8 +360,8 @@ RP_API int rp_profile_kernel_time(rp_profile* h, const char* name, double* total
  * (tables[street], street = 0 pref .. 3 river); tables = NULL selects a hash of the canonical observation (tests).
  * 2^cap_log2 table rows of 9 actions (144 B each) + one 32-byte key slot per row; batch = trees per step (0 = the
  * reference's 128).  2 players, stacks of 100 big blinds.  The batch is grown LEVEL-SYNCHRONOUSLY (all trees one level per
- * pair of launches, kernels sorted by node kind: robopoker_amd/csrc/nlmc_level.hpp); a batch may hold at most 2^28 / 768
- * trees.  Sampling scheme: ExternalSampling (the mccfr! macro's default) until rp_nlhe_set_sampling selects
+ * pair of launches, kernels sorted by node kind: robopoker_amd/csrc/nlmc_level.hpp) in 1 536 nodes of budget per tree
+ * (92 B each; RP_ERR_CAPACITY when a batch needs more).  Sampling scheme: ExternalSampling (the mccfr! macro's default) until rp_nlhe_set_sampling selects
  * PrunableSampling / PluribusSampling (Flagship, nlhe/src/lib.rs:86-90; thresholds from `hp`).
  * Oracle: oracle/rp_oracle_nlmc.c. */
 typedef struct rp_nlhe rp_nlhe;

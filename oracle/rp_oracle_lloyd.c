@@ -108,7 +108,7 @@ static float sinkhorn_cost_traced(uint32_t bins, const ora_hist* mu, const ora_h
     for (uint32_t i = 0; i < m; ++i) lhs[i] = lu;
     for (uint32_t j = 0; j < n; ++j) rhs[j] = ru;
     float T = hp->temperature;
-    uint32_t t, stop_t = 0;
+    uint32_t t, stop_t = 0, done_iters = 0;
     int stopped = 0;
     float stop_cost = 0.0f;
     for (t = 0; t < hp->iterations; ++t) {
@@ -136,8 +136,7 @@ static float sinkhorn_cost_traced(uint32_t bins, const ora_hist* mu, const ora_h
         }
         for (uint32_t j = 0; j < n; ++j) rhs_err += rp_absf(rp_expf(nxt[j]) - rp_expf(rhs[j]));
         for (uint32_t j = 0; j < n; ++j) rhs[j] = nxt[j];
-#pragma omp atomic
-        g_sinkhorn_iters += 1;
+        done_iters += 1; /* counted per solve and added once at the end: no shared counter inside the threaded hot loop */
         if (trace_err) {
             trace_err[t] = lhs_err + rhs_err;
             trace_cost[t] = coupling_cost(tri, sx, m, sy, n, lhs, rhs, T);
@@ -150,6 +149,8 @@ static float sinkhorn_cost_traced(uint32_t bins, const ora_hist* mu, const ora_h
         }
         if (lhs_err + rhs_err < hp->tolerance) { t += 1; break; }
     }
+#pragma omp atomic
+    g_sinkhorn_iters += done_iters;
     if (trace_err && stopped) {
         if (iters_out) *iters_out = stop_t;
         return stop_cost;

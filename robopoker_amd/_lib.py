@@ -132,6 +132,11 @@ _SIGNATURES = {
         [C.POINTER(GameTable), C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(Hyper), C.c_uint64, C.c_int,
          C.POINTER(C.c_void_p)],
     ),
+    "rp_mccfr_create_mode": (
+        C.c_int,
+        [C.POINTER(GameTable), C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(Hyper), C.c_uint64, C.c_int, C.c_int,
+         C.POINTER(C.c_void_p)],
+    ),
     "rp_mccfr_destroy": (C.c_int, [C.c_void_p]),
     "rp_mccfr_step": (C.c_int, [C.c_void_p]),
     "rp_mccfr_solve": (C.c_int, [C.c_void_p, C.c_uint64]),

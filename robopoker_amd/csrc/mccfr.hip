@@ -2616,6 +2616,22 @@ int rp_mccfr_set_batch(rp_mccfr* h, uint32_t batch_size) {
     return RP_OK;
 }
 
+// rp_mccfr_create with the update mode chosen up front (a caller that wants the fast, shardable composed update does not have to
+// know about a second call; schedules the composed mode cannot express are refused here, not at the first step)
+int rp_mccfr_create_mode(const rp_game_table* game, rp_regret_kind r, rp_weight_kind w, rp_sampling_kind s, uint32_t batch_size,
+                         const rp_hyper* hp, uint64_t seed, int device, rp_update_mode mode, rp_mccfr** out) {
+    if (mode != RP_UPDATE_ORDERED && mode != RP_UPDATE_COMPOSED) return rp::fail(RP_ERR_INVALID, "rp_mccfr_create_mode: unknown update mode");
+    int rc = rp_mccfr_create(game, r, w, s, batch_size, hp, seed, device, out);
+    if (rc) return rc;
+    (*out)->mode = mode;
+    if (mode == RP_UPDATE_COMPOSED && (rc = composed_supported(*out))) {
+        rp_mccfr_destroy(*out);
+        *out = nullptr;
+        return rc;
+    }
+    return RP_OK;
+}
+
 int rp_mccfr_set_update_mode(rp_mccfr* h, rp_update_mode mode) {
     if (!h) return rp::fail(RP_ERR_INVALID, "rp_mccfr_set_update_mode: NULL handle");
     if (mode != RP_UPDATE_ORDERED && mode != RP_UPDATE_COMPOSED) return rp::fail(RP_ERR_INVALID, "unknown update mode");

@@ -561,12 +561,14 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     }
     const uint64_t rows = 1ull << cap_log2;
     // Decisions per tree: ~40 / ~90 on average by walker, 483 the largest seen in 20 000 oracle trees; the batch buffer holds 160 per
-    // tree.  Nodes per tree: 280 / 660 on average by walker, 3 300 the largest: 768 per tree of budget (the total is what counts)
+    // tree.  Nodes per tree: 280 / 660 on average by walker on a fresh table, 3 300 the largest — and they GROW with training (the
+    // opponent's average strategy calls and raises more than the warm-start bias: 760 per tree after a few steps on the trained
+    // abstraction): 1 536 per tree of budget, 92 B each (the batch's total is what counts)
     const uint64_t dec_cap64 = std::max<uint64_t>((uint64_t)batch * 160u, 4096u);
-    const uint64_t ncap64 = std::max<uint64_t>((uint64_t)batch * 768u, 1u << 17);
-    if (dec_cap64 >= (1ull << 31) || ncap64 > (1ull << 28)) {  // a node's link packs its parent in 28 bits
+    const uint64_t ncap64 = std::max<uint64_t>((uint64_t)batch * 1536u, 1u << 17);
+    if (dec_cap64 >= (1ull << 31) || ncap64 >= (1ull << 32)) {
         delete h;
-        return rp::fail(RP_ERR_INVALID, "rp_nlhe_create: batch too large (at most %u trees per step)", (1u << 28) / 768u);
+        return rp::fail(RP_ERR_INVALID, "rp_nlhe_create: batch too large (at most %u trees per step)", (uint32_t)((1ull << 32) / 1536u));
     }
     NL_TRY(rp_profile_create(device, rows, NLMC_A, regret, weight, hp, nullptr, (uint32_t)dec_cap64, &h->prof));
     NL_TRY(nl_alloc(h, &h->tab.slots, rows));
@@ -619,7 +621,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
         NL_TRY(nl_alloc(h, &h->d_counters, 4));
     } else {
         NlNodes& lv = h->lv;
-        const size_t N = (size_t)ncap64, LC = N / 2;  // walker nodes of a batch (a seventh of its nodes): half the node budget
+        const size_t N = (size_t)ncap64, LC = N / 4;  // walker nodes of a batch (a seventh of its nodes): a quarter of the node budget
         lv.ncap = (uint32_t)N;
         lv.lcap = (uint32_t)LC;
         NL_TRY(nl_alloc(h, &lv.link, N)); NL_TRY(nl_alloc(h, &lv.tree, N)); NL_TRY(nl_alloc(h, &lv.meta, N));

@@ -43,6 +43,7 @@ namespace rp {
 #define NL_MAXL 48u        // levels of a tree: <= 8 decisions per street, 3 draws, the terminal (observed: <= 20)
 #define NL_WMAX 2048u      // walker nodes of one tree (observed: <= 455)
 #define NL_LINK_NONE 0xffffffffu
+// link[c] = the parent's node index (the root: NL_LINK_NONE)
 // meta: kind [0,2) | n_choices [2,6) | n_kids [6,10) | depth [10,13) | path length [13,17) | showdown order [17,19)
 #define NL_META_KIND(m) ((m) & 3u)
 #define NL_META_NCH(m) (((m) >> 2) & 15u)
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(256, MINW) void k_nl_expand(NlParams p, NlTable t, 
                 oppfac = (rp_maxf(rgp, RP_EPSILON) / rd) / (swp / z);  // sigma / q of the sampled edge
                 mask = 1u << pick;
                 nkids = 1;
+                nd.aux[node] = mask << 16;  // k_nl_children reads the child's slot from it, as at a walker node
                 s_aux[j] = __float_as_uint(oppfac);
             }
             nd.row[node] = row;
@@ -395,12 +397,12 @@ __global__ __launch_bounds__(256, MINW) void k_nl_expand(NlParams p, NlTable t, 
 #pragma unroll
                 for (uint32_t a = 0; a < NLMC_A; ++a)
                     if ((mask >> a) & 1u) {
-                        nd.link[run] = node | (a << 28);
+                        nd.link[run] = node;
                         nd.fac[run] = sg[a] / rd;  // instant_policy (flow.rs:46-48)
                         run += 1;
                     }
             } else if (j < segbase[2]) {
-                nd.link[run] = node | (((info >> 13) & 15u) << 28);
+                nd.link[run] = node;
                 nd.fac[run] = __uint_as_float(s_aux[j]);
                 run += 1;
             } else {
@@ -429,8 +431,16 @@ __global__ __launch_bounds__(256) void k_nl_children(NlParams p, NlNodes nd, uin
         const bool valid = c < hi;
         uint32_t err = 0;
         if (valid) {
-            const uint32_t link = nd.link[c], par = link & 0x0fffffffu, slot = link >> 28;
+            const uint32_t par = nd.link[c];
             const uint32_t pm = nd.meta[par], pkind = NL_META_KIND(pm);
+            // the child's slot among the parent's choices: children are stored in slot order, so it is the (c - kid0)-th expanded
+            // edge of the parent's mask
+            uint32_t slot = 0;
+            if (pkind != NK_CHANCE) {
+                uint32_t mbits = nd.aux[par] >> 16;
+                for (uint32_t r = c - nd.kid0[par]; r > 0; --r) mbits &= mbits - 1u;
+                slot = (uint32_t)__builtin_ctz(mbits);
+            }
             const uint32_t tree = nd.tree[par];
             G2 g;
             nl_load_game(nd, par, g);

@@ -86,27 +86,37 @@ def _edge_to_u64(code: int) -> int:
 
 def read_blueprint(path: str):
     """the blueprint COPY file back into ``NlheSolver.load()``'s arrays (Hydrate, nlhe/src/profile.rs:90-141): rows grouped
-    by infoset, each row's slot = the position of its edge in the infoset's choices"""
+    by infoset (in the order of their first row), each row's slot = the position of its edge in the infoset's choices.
+    Vectorised: a blueprint of a few million infosets has tens of millions of rows."""
     past, present, choices, edge, weight, regret, payoff, visits = read_rows(path, BLUEPRINT_TYPES)
-    index, keys = {}, []
-    for p, b, c in zip(past.tolist(), present.tolist(), choices.tolist()):
-        k = (p, b, c)
-        if k not in index:
-            index[k] = len(keys)
-            keys.append(k)
-    enc = np.zeros((len(keys), 9), dtype=_ENC)
-    for r in range(past.size):
-        k = (int(past[r]), int(present[r]), int(choices[r]))
-        codes, bits = [], int(choices[r]) & ((1 << 64) - 1)
-        while bits & 0x1f:
-            codes.append(bits & 0x1f)
-            bits >>= 5
-        slot = [_edge_to_u64(c) for c in codes].index(int(edge[r]))
-        enc[index[k], slot] = (weight[r], regret[r], payoff[r], visits[r])
-    kp = np.array([k[0] for k in keys], dtype=np.int64).astype(np.uint64)
-    kb = np.array([k[1] for k in keys], dtype=np.int64).astype(np.uint32) & 0xffff
-    kc = np.array([k[2] for k in keys], dtype=np.int64).astype(np.uint64)
-    return kp, kb, kc, enc
+    past, choices = np.asarray(past).astype(np.int64).view(np.uint64), np.asarray(choices).astype(np.int64).view(np.uint64)
+    present = (np.asarray(present).astype(np.int64) & 0xffff).astype(np.uint32)
+    key = np.zeros(past.size, dtype=[("p", "<u8"), ("b", "<u4"), ("c", "<u8")])
+    key["p"], key["b"], key["c"] = past, present, choices
+    _, first, inverse = np.unique(key, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")  # infosets in the order of their first row
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    group = rank[inverse]
+    # the row's slot: the a with Edge::into_u64(choices[a]) == edge
+    table = np.zeros(32, dtype=np.uint64)
+    for code in range(1, 20):
+        table[code] = _edge_to_u64(code)
+    slot = np.full(past.size, -1, dtype=np.int64)
+    e64 = np.asarray(edge).astype(np.int64).view(np.uint64)
+    for a in range(9):
+        code = (choices >> np.uint64(5 * a)) & np.uint64(0x1f)
+        hit = (slot < 0) & (code != 0) & (table[code.astype(np.int64)] == e64)
+        slot[hit] = a
+    if (slot < 0).any():
+        raise ValueError("read_blueprint: a row's edge is not among its infoset's choices")
+    enc = np.zeros((order.size, 9), dtype=_ENC)
+    enc["weight"][group, slot] = weight
+    enc["regret"][group, slot] = regret
+    enc["payoff"][group, slot] = payoff
+    enc["visits"][group, slot] = np.asarray(visits).astype(np.uint32)
+    f = first[order]
+    return past[f], present[f], choices[f], enc
 
 
 def save_artifacts(directory: str, art) -> dict:

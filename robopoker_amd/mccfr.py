@@ -31,14 +31,19 @@ class Solver:
     """
 
     def __init__(self, game: Game, regret="floored", weight="linear", sampling="external", batch=1, seed=0,
-                 hyper=None, device=0):
+                 hyper=None, device=0, mode=None):
         self._lib = _lib.load()
         self.game = game
         self.hp = hyper if hyper is not None else default_hyper()
         self._h = C.c_void_p()
-        _lib.check(self._lib.rp_mccfr_create(C.byref(game.table), _lib.REGRET[regret], _lib.WEIGHT[weight],
-                                             _lib.SAMPLING[sampling], batch, C.byref(self.hp), seed, device,
-                                             C.byref(self._h)))
+        if mode is None:  # the reference's exact order (rp_mccfr_create's default)
+            _lib.check(self._lib.rp_mccfr_create(C.byref(game.table), _lib.REGRET[regret], _lib.WEIGHT[weight],
+                                                 _lib.SAMPLING[sampling], batch, C.byref(self.hp), seed, device,
+                                                 C.byref(self._h)))
+        else:
+            _lib.check(self._lib.rp_mccfr_create_mode(C.byref(game.table), _lib.REGRET[regret], _lib.WEIGHT[weight],
+                                                      _lib.SAMPLING[sampling], batch, C.byref(self.hp), seed, device,
+                                                      _lib.UPDATE[mode], C.byref(self._h)))
         self.batch = batch
         self.cells = game.table.n_infos * game.table.max_actions
 

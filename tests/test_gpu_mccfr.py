@@ -417,3 +417,22 @@ def test_trainer_loop_checkpoints_and_summary(gpu):
     stop = ctypes.c_int(1)
     a.train(interrupt=stop)
     assert a.epoch == 13
+
+
+def test_update_mode_chosen_at_creation(gpu):
+    # rp_mccfr_create_mode: a caller that wants the fast, shardable composed update says so once; the result is the solver that
+    # rp_mccfr_create + rp_mccfr_set_update_mode builds, and a schedule the composed mode cannot express is refused at creation
+    g = Game("leduc")
+    a = Solver(g, "linear", "linear", "external", batch=4096, seed=3, mode="composed")
+    b = Solver(g, "linear", "linear", "external", batch=4096, seed=3)
+    b.set_update_mode("composed")
+    for _ in range(3):
+        a.step()
+        b.step()
+    ea, eb = a.export(), b.export()
+    for f in ("visits", "regret", "weight", "payoff"):
+        assert np.array_equal(ea[f].view(np.uint32), eb[f].view(np.uint32)), f
+    with pytest.raises(_lib.RpError):
+        Solver(g, "discounted", "linear", "external", batch=64, seed=3, mode="composed")
+    c = Solver(g, "discounted", "linear", "external", batch=64, seed=3, mode="ordered")
+    c.step()
