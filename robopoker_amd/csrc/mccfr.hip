@@ -1673,6 +1673,8 @@ struct rp_mccfr {
     uint64_t tables_version = 1, itab_version = 0;
     bool fuse_maps = true;  // composed update: traversal + block maps in one kernel when the game allows (RP_TRAV_UNFUSED=1: never)
     int static_skel = 0;  // 0: none (k_traverse_lds / k_traverse), 1: KuhnSkel, 2: LeducSkel (traverse_static.hpp)
+    bool static_pruned = true;  // RP_TRAV_STATIC_EXTERNAL_ONLY=1: the pruned schemes keep k_traverse_lds (cross-check)
+    bool no_static_pruned_ok(int S) const { return S != RP_SAMPLING_EXTERNAL && !static_pruned; }
     bool profiling = false;
     KernelClock clk_traverse, clk_compact, clk_update;
 };
@@ -1951,10 +1953,15 @@ void launch_prepare(rp_mccfr* h, const StepParams& p) {
 int launch_traverse(rp_mccfr* h, const StepParams& p) {
     if (h->dc.slotmap) HIP_TRY(hipMemsetAsync(h->dc.slotmap, 0, (size_t)h->tbl.n_infos * h->dc.stride, h->stream));
     clock_begin(h, h->clk_traverse);
-    if (h->static_skel && p.S == RP_SAMPLING_EXTERNAL) {
+    if (h->static_skel && !h->no_static_pruned_ok(p.S)) {
         launch_prepare(h, p);
         const dim3 grid((h->batch + 255) / 256), block(256);
-#define LAUNCH_STATIC(G, WK) hipLaunchKernelGGL((k_traverse_static<G, WK>), grid, block, 0, h->stream, h->g, h->itab, h->dc, p)
+        const bool pr = p.S != RP_SAMPLING_EXTERNAL;
+#define LAUNCH_STATIC(G, WK)                                                                                                   \
+    do {                                                                                                                       \
+        if (pr) hipLaunchKernelGGL((k_traverse_static<G, WK, true>), grid, block, 0, h->stream, h->g, h->itab, h->dc, p);     \
+        else hipLaunchKernelGGL((k_traverse_static<G, WK, false>), grid, block, 0, h->stream, h->g, h->itab, h->dc, p);        \
+    } while (0)
         if (h->static_skel == 1) {
             if (p.walker == 0) LAUNCH_STATIC(KuhnSkel, 0);
             else LAUNCH_STATIC(KuhnSkel, 1);
@@ -2034,10 +2041,11 @@ size_t chunk_maps_lds_bytes(const rp_mccfr* h) {
 // instantiated over its skeleton, external sampling
 size_t traverse_maps_lds_bytes(const rp_mccfr* h) {
     const size_t NI = h->tbl.n_infos;
-    return (NI * 8 + 2 * NI) * 4 + NI * 8 * 2 + (NI + (NI & 1)) * 2 + (size_t)5 * h->maxdec * 256 * 4;
+    const size_t masks = h->S != RP_SAMPLING_EXTERNAL ? (size_t)h->maxdec * 256 * 4 : 0;  // the expanded edges of every list entry
+    return (NI * 8 + 2 * NI) * 4 + NI * 8 * 2 + (NI + (NI & 1)) * 2 + (size_t)5 * h->maxdec * 256 * 4 + masks;
 }
 bool traverse_maps_fused(const rp_mccfr* h) {
-    return h->static_skel && h->S == RP_SAMPLING_EXTERNAL && !h->dc.slotmap && h->tbl.n_infos <= CH_THREADS &&
+    return h->static_skel && !h->no_static_pruned_ok(h->S) && !h->dc.slotmap && h->tbl.n_infos <= CH_THREADS &&
            traverse_maps_lds_bytes(h) <= 64 * 1024 && h->fuse_maps;
 }
 
@@ -2057,8 +2065,15 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev, bool fuse
         clock_begin(h, h->clk_traverse);
         launch_prepare(h, p);
         const size_t lds = traverse_maps_lds_bytes(h);
-#define LAUNCH_FUSED(G, WK) \
-    hipLaunchKernelGGL((k_traverse_maps_static<G, WK>), dim3(nblk), dim3(256), lds, h->stream, h->g, h->itab, p, bmaps, bpsum, bcnt, nblk_max, h->maxdec)
+#define LAUNCH_FUSED(G, WK)                                                                                                            \
+    do {                                                                                                                               \
+        if (pruned)                                                                                                                    \
+            hipLaunchKernelGGL((k_traverse_maps_static<G, WK, true>), dim3(nblk), dim3(256), lds, h->stream, h->g, h->itab, p, bmaps, \
+                               bpsum, bcnt, nblk_max, h->maxdec);                                                                      \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((k_traverse_maps_static<G, WK, false>), dim3(nblk), dim3(256), lds, h->stream, h->g, h->itab, p, bmaps, \
+                               bpsum, bcnt, nblk_max, h->maxdec);                                                                      \
+    } while (0)
         if (h->static_skel == 1) {
             if (p.walker == 0) LAUNCH_FUSED(KuhnSkel, 0);
             else LAUNCH_FUSED(KuhnSkel, 1);
@@ -2310,6 +2325,7 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
     }
     h->use_lds_traverse = traverse_fits_lds(h) && getenv("RP_MCCFR_HBM_SCRATCH") == nullptr;
     h->fuse_maps = getenv("RP_TRAV_UNFUSED") == nullptr;
+    h->static_pruned = getenv("RP_TRAV_STATIC_EXTERNAL_ONLY") == nullptr;
     if (h->use_lds_traverse && getenv("RP_TRAV_GENERIC") == nullptr) {
         if (skel_matches<KuhnSkel>(game, h->children)) h->static_skel = 1;
         else if (skel_matches<LeducSkel>(game, h->children)) h->static_skel = 2;
@@ -2779,7 +2795,7 @@ int rp_game_skeleton(const rp_game_table* game, int* out) {
 
 int rp_mccfr_traversal_variant(rp_mccfr* h, int* out) {
     if (!h || !out) return rp::fail(RP_ERR_INVALID, "rp_mccfr_traversal_variant: NULL argument");
-    *out = (h->static_skel && h->S == RP_SAMPLING_EXTERNAL) ? 2 : (h->use_lds_traverse ? 1 : 0);
+    *out = (h->static_skel && !h->no_static_pruned_ok(h->S)) ? 2 : (h->use_lds_traverse ? 1 : 0);
     return RP_OK;
 }
 

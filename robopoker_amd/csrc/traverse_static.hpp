@@ -12,8 +12,12 @@
 // Same arithmetic as k_traverse_lds, operation for operation (TreeBuilder::build builder.rs:74-87,141-161 in pop-last
 // order = pre-order with children in DESCENDING edge order; CfrFlow::dfs / recursed_value / ancestor_reach
 // flow.rs:64-87,166-216): the Decisions are bit-identical (tests/test_gpu_mccfr.py::test_static_skeleton_equals_generic).
-// Used when the game's tables match the skeleton node for node (skel_matches, checked once at rp_mccfr_create), the scheme
-// is external sampling (the walker expands every action) and max_actions == 2; everything else takes k_traverse_lds.
+// Used when the game's tables match the skeleton node for node (skel_matches, checked once at rp_mccfr_create) and
+// max_actions == 2; everything else takes k_traverse_lds.  PRUNED = false: external sampling (the walker expands every action).
+// PRUNED = true: PrunableSampling / PluribusSampling (sample/pruning.rs:44-66, pluribus.rs:72-101) — a walker node's surviving
+// edges come from the per-infoset keep masks (k_prepare_infos), the explore draw of (epoch, infoset, tree) and, for Pluribus,
+// the edges whose child is a terminal node of the SKELETON (a compile-time fact); a pruned child is a dead skeleton node,
+// exactly like an opponent action that was not sampled, and its edge takes no part in the node's value, regret or mask.
 #pragma once
 
 #include <type_traits>
@@ -115,6 +119,14 @@ struct SkelOf {
     static constexpr Skeleton S = G::make();
 };
 
+// the skeleton child of node s along edge e is a terminal node?  (walker nodes: the Pluribus exemption, pluribus.rs:96)
+template <class G>
+constexpr bool sk_child_terminal(int s, int e) {
+    for (int c = 0; c < SkelOf<G>::S.n; ++c)
+        if (SkelOf<G>::S.parent[c] == s && SkelOf<G>::S.edge[c] == e) return SkelOf<G>::S.kind[c] == SK_TERMINAL;
+    return false;
+}
+
 static_assert(SkelOf<KuhnSkel>::S.n == 11, "Kuhn: two deals, four decision nodes, five terminals");
 static_assert(SkelOf<LeducSkel>::S.n == 38, "Leduc: two deals, 4 + 3 x 4 decision nodes, three board draws, 2 + 3 x 5 terminals");
 static_assert(SkelOf<LeducSkel>::S.end[0] == 37 && SkelOf<LeducSkel>::S.kind[2] == SK_P0, "pre-order, the first decision is P0's");
@@ -139,7 +151,8 @@ __device__ __forceinline__ void sk_for_down(F&& f) {  // I = HI-1 down to LO
 // workgroup).  on_built(info_of, live_of) runs once the tree is sampled — before any value is computed — with two callables
 // over the skeleton's node index; on_decision(j, info, regret0, regret1, sigma0, sigma1, payoff) once per LIVE walker node,
 // ascending node index (= the order of Tree::partition's spans).  Returns the number of nodes of the sampled tree.
-template <class G, int W, class OnBuilt, class OnDecision>
+// on_decision's `mask`: the expanded edges (3 under external sampling).
+template <class G, int W, bool PRUNED, class OnBuilt, class OnDecision>
 __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevInfoTab& it, const StepParams& p, uint64_t tree_id,
                                                     bool present, OnBuilt&& on_built, OnDecision&& on_decision) {
     using SK = SkelOf<G>;
@@ -149,7 +162,7 @@ __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevI
 
     // ---- TreeBuilder::build over the skeleton ----------------------------------------------------------------------
     uint32_t rx[N], ry[N], rz[N], rw[N];  // the node's record (DevGame::kids): turn | n_children << 8, info / payoff0, offset / payoff1, state
-    uint32_t pick[N];                     // chance: the sampled outcome; opponent: the sampled action
+    uint32_t pick[N];                     // chance: the sampled outcome; opponent: the sampled action; walker (PRUNED): the surviving edges
     bool live[N];
     float sg0[N], sg1[N], q0[N], q1[N];   // (sigma, q) of a player node's two edges
     rx[0] = g.root_rec.x;
@@ -179,6 +192,7 @@ __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevI
             rz[s] = r.z;
             rw[s] = r.w;
             if constexpr (SK::S.kind[par] == K_OPP) live[s] = live[par] && pick[par] == (uint32_t)SK::S.edge[s];
+            else if constexpr (PRUNED && SK::S.kind[par] == K_WALKER) live[s] = live[par] && ((pick[par] >> SK::S.edge[s]) & 1u);
             else live[s] = live[par];
         }
         if constexpr (SK::S.kind[s] == SK_CHANCE) {  // SamplingScheme::sample at a chance node: uniform (external.rs:41-64)
@@ -193,6 +207,18 @@ __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevI
             if constexpr (SK::S.kind[s] == K_OPP) {  // WeightedIndex over max(q, EPSILON): two actions = one threshold
                 const float x = rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info)) * it.total[info];
                 pick[s] = it.cum[info * 2u] <= x ? 1u : 0u;
+            } else if constexpr (PRUNED) {  // SamplingScheme::sample at a walker node (d_sample_mask_tab, the same draw and masks)
+                uint32_t mask = 3u;
+                bool prune = true;
+                if (p.S == RP_SAMPLING_PLURIBUS)
+                    prune = p.epoch >= p.prune_warmup && !(rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info)) < p.prune_explore);
+                if (prune) {
+                    mask = it.keep[info] & 3u;
+                    if (p.S == RP_SAMPLING_PLURIBUS)
+                        mask |= (sk_child_terminal<G>(s, 0) ? 1u : 0u) | (sk_child_terminal<G>(s, 1) ? 2u : 0u);
+                    mask = mask ? mask : 3u;  // pruning.rs:64, pluribus.rs:99
+                }
+                pick[s] = mask;
             }
         }
     });
@@ -261,12 +287,22 @@ __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevI
             });
             const float reach = cf / sm_;
             const float u0 = reach * tv[0], u1 = reach * tv[1];
-            float ev = 0.0f;
-            ev += sg0[j] * u0;
-            ev += sg1[j] * u1;
-            const float payoff = 0.0f + ev;
-            const float g0 = 0.0f + (u0 - ev), g1 = 0.0f + (u1 - ev);
-            if (live[j]) on_decision(J, ry[j], g0, g1, sg0[j], sg1[j], payoff);
+            if constexpr (!PRUNED) {
+                float ev = 0.0f;
+                ev += sg0[j] * u0;
+                ev += sg1[j] * u1;
+                const float payoff = 0.0f + ev;
+                const float g0 = 0.0f + (u0 - ev), g1 = 0.0f + (u1 - ev);
+                if (live[j]) on_decision(J, ry[j], g0, g1, sg0[j], sg1[j], payoff, 3u);
+            } else {  // only the expanded edges enter the node's value and receive a regret (k_traverse_lds, the same order)
+                const uint32_t mask = pick[j];
+                float ev = 0.0f;
+                if (mask & 1u) ev += sg0[j] * u0;
+                if (mask & 2u) ev += sg1[j] * u1;
+                const float payoff = 0.0f + ev;
+                const float g0 = (mask & 1u) ? 0.0f + (u0 - ev) : 0.0f, g1 = (mask & 2u) ? 0.0f + (u1 - ev) : 0.0f;
+                if (live[j]) on_decision(J, ry[j], g0, g1, sg0[j], sg1[j], payoff, mask);
+            }
         }
     });
     return nn;
@@ -274,22 +310,22 @@ __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevI
 
 // Decisions to HBM (DevDecisions), for the ordered update, the sorted large-game path and the debugging views.
 // One lane per tree, 256 trees per workgroup, no LDS.
-template <class G, int W>
+template <class G, int W, bool PRUNED>
 __global__ __launch_bounds__(256) void k_traverse_static(DevGame g, DevInfoTab it, DevDecisions dc, StepParams p) {
     const uint32_t lane = blockIdx.x * 256u + threadIdx.x;
     if (lane >= p.batch) return;
     const size_t D = dc.stride;
     uint32_t ndec = 0;
-    const uint32_t nn = static_traverse<G, W>(
+    const uint32_t nn = static_traverse<G, W, PRUNED>(
         g, it, p, p.tree_base + lane, true, [](auto, auto) __attribute__((always_inline)) {},
-        [&](auto, uint32_t info, float g0, float g1, float s0, float s1, float payoff) __attribute__((always_inline)) {
+        [&](auto, uint32_t info, float g0, float g1, float s0, float s1, float payoff, uint32_t mask) __attribute__((always_inline)) {
             const uint32_t slot = ndec;
             dc.regret[((size_t)slot * 2u + 0u) * D + lane] = g0;
             dc.regret[((size_t)slot * 2u + 1u) * D + lane] = g1;
             dc.policy[((size_t)slot * 2u + 0u) * D + lane] = s0;
             dc.policy[((size_t)slot * 2u + 1u) * D + lane] = s1;
             dc.info[(size_t)slot * D + lane] = info;
-            dc.mask[(size_t)slot * D + lane] = 3u;
+            dc.mask[(size_t)slot * D + lane] = mask;
             dc.payoff[(size_t)slot * D + lane] = payoff;
             if (dc.slotmap) dc.slotmap[(size_t)info * D + lane] = (uint8_t)(slot + 1u);
             ndec += 1u;
@@ -309,7 +345,9 @@ __global__ __launch_bounds__(256) void k_traverse_static(DevGame g, DevInfoTab i
 // the (infoset, cell) tasks are handed out in descending order of list length (a counting sort by log2 class), so the 64
 // chains of a wave have similar lengths instead of every wave waiting for one long chain.
 // LDS (dynamic): bits u32[NI][8] | lcount u32[NI] | lbase u32[NI] | pre u16[NI][8] | order u16[NI + (NI & 1)] | vals f32[5][maxdec * 256]
-template <class G, int W>
+//                | (PRUNED) lmask u32[maxdec * 256]: the expanded edges of every list entry — a regret cell skips the entries
+//                  whose edge was pruned (no touch at all: a touch would apply the discount), as k_chunk_maps<true> does
+template <class G, int W, bool PRUNED>
 __global__ __launch_bounds__(256, 4) void k_traverse_maps_static(DevGame g, DevInfoTab it, StepParams p, Map* bmaps, float* bpsum,
                                                               uint32_t* bcnt, uint32_t nblk_max, uint32_t maxdec) {
     extern __shared__ __attribute__((aligned(16))) uint32_t tm_lds[];
@@ -323,13 +361,14 @@ __global__ __launch_bounds__(256, 4) void k_traverse_maps_static(DevGame g, DevI
     uint16_t* order = pre + NI * 8u;
     float* vals = reinterpret_cast<float*>(order + NI + (NI & 1u));
     const uint32_t L = maxdec * 256u;  // places per cell
+    uint32_t* lmask = reinterpret_cast<uint32_t*>(vals + 5u * L);
     for (uint32_t e = lt; e < NI * 8u; e += 256u) bits[e] = 0;
     if (lt < 16u) cls_n[lt] = 0;
     __syncthreads();
     const uint32_t lane = chunk * 256u + lt;
     const float tf = (float)p.epoch;
     uint32_t ndec = 0;
-    const uint32_t nn = static_traverse<G, W>(
+    const uint32_t nn = static_traverse<G, W, PRUNED>(
         g, it, p, p.tree_base + lane, lane < p.batch,
         [&](auto info_of, auto live_of) __attribute__((always_inline)) {
             sk_for<0, SkelOf<G>::S.n>([&](auto J) __attribute__((always_inline)) {
@@ -362,8 +401,9 @@ __global__ __launch_bounds__(256, 4) void k_traverse_maps_static(DevGame g, DevI
                 order[atomicAdd(&cls_at[15u - (run ? 32u - (uint32_t)__builtin_clz(run) : 0u)], 1u)] = (uint16_t)info;
             }
         },
-        [&](auto, uint32_t info, float g0, float g1, float s0, float s1, float payoff) __attribute__((always_inline)) {
+        [&](auto, uint32_t info, float g0, float g1, float s0, float s1, float payoff, uint32_t mask) __attribute__((always_inline)) {
             const uint32_t pos = lbase[info] + pre[info * 8u + (lt >> 5)] + __popc(bits[info * 8u + (lt >> 5)] & ((1u << (lt & 31u)) - 1u));
+            if constexpr (PRUNED) lmask[pos] = mask;
             vals[pos] = g0;
             vals[L + pos] = g1;
             vals[2u * L + pos] = p.W == RP_WEIGHT_LINEAR ? s0 * tf : (p.W == RP_WEIGHT_QUADRATIC ? s0 * tf * tf : s0);
@@ -391,17 +431,20 @@ __global__ __launch_bounds__(256, 4) void k_traverse_maps_static(DevGame g, DevI
         const float fl = isreg ? regret_floor_of(p.R, p.regret_min) : RP_EPSILON;
         const float d = isreg ? (p.R == RP_REGRET_LINEAR ? tf / (tf + 1.0f) : 1.0f) : (p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f);
         float ma = 1.0f, mb = 0.0f, mm = NEG_INF;
+        uint32_t cnt = 0;
         for (uint32_t e = 0; e < n; ++e) {
             const float delta = v[e];
+            const bool skip = PRUNED && isreg && !((lmask[base + e] >> c) & 1u);
             // first touch of the block: (d, delta, floor); then a <- a d, b <- b d + delta, m <- max(m d + delta, floor)
-            const float na = e ? ma * d : d;
-            const float nb = e ? mb * d + delta : delta;
-            const float nm = e ? rp_maxf(mm * d + delta, fl) : fl;
-            ma = na;
-            mb = nb;
-            mm = nm;
+            const float na = cnt ? ma * d : d;
+            const float nb = cnt ? mb * d + delta : delta;
+            const float nm = cnt ? rp_maxf(mm * d + delta, fl) : fl;
+            ma = skip ? ma : na;
+            mb = skip ? mb : nb;
+            mm = skip ? mm : nm;
+            cnt += skip ? 0u : 1u;
         }
-        bmaps[slot_out * 4u + c] = Map{ma, mb, mm, n};
+        bmaps[slot_out * 4u + c] = Map{ma, mb, mm, cnt};
     }
     count_metrics(p, nn, ndec, 0u);
 }

@@ -436,3 +436,39 @@ def test_update_mode_chosen_at_creation(gpu):
         Solver(g, "discounted", "linear", "external", batch=64, seed=3, mode="composed")
     c = Solver(g, "discounted", "linear", "external", batch=64, seed=3, mode="ordered")
     c.step()
+
+
+@pytest.mark.parametrize("mode", ["ordered", "composed"])
+@pytest.mark.parametrize("game,sampling,batch", [("leduc", "pluribus", 1500), ("leduc", "prunable", 700), ("kuhn", "pluribus", 900)])
+def test_static_skeleton_traversal_of_the_pruned_schemes(gpu, monkeypatch, mode, game, sampling, batch):
+    # PrunableSampling / PluribusSampling on the compile-time skeleton (traverse_static.hpp, PRUNED = true): a pruned walker edge
+    # is a dead skeleton node.  Pruning is forced to bite (warm-up 2, threshold just below zero).  Against the per-lane DFS
+    # kernel (RP_TRAV_STATIC_EXTERNAL_ONLY=1) and the oracle, bit for bit, in both update modes (the fused traversal + block maps
+    # kernel skips the list entries of pruned edges like k_chunk_maps<true>).
+    g = Game(game)
+    hp = oracle.default_hyper()
+    hp.prune_warmup, hp.prune_threshold, hp.prune_explore = 2, -0.05, 0.1
+    a = Solver(g, "linear", "linear", sampling, batch=batch, seed=23, hyper=hp)
+    monkeypatch.setenv("RP_TRAV_STATIC_EXTERNAL_ONLY", "1")
+    b = Solver(g, "linear", "linear", sampling, batch=batch, seed=23, hyper=hp)
+    monkeypatch.delenv("RP_TRAV_STATIC_EXTERNAL_ONLY")
+    ora = oracle.OracleSolver(g, "linear", "linear", sampling, batch=batch, seed=23, hyper=hp)
+    assert a.kernel_variant() == "static" and b.kernel_variant() != "static"
+    if mode == "composed":
+        a.set_update_mode("composed")
+        b.set_update_mode("composed")
+    for _ in range(12):
+        a.step()
+        b.step()
+        if mode == "composed":
+            ora.step_world(1)
+        else:
+            ora.step()
+        assert_tables_equal(a.export(), ora.export())
+        assert_tables_equal(b.export(), ora.export())
+    assert a.counters() == b.counters() == ora.counters()
+    # pruning did bite: fewer nodes than external sampling grows from the same seed
+    e = Solver(g, "linear", "linear", "external", batch=batch, seed=23, hyper=hp)
+    for _ in range(12):
+        e.step()
+    assert a.counters()[0] < e.counters()[0]
