@@ -264,9 +264,15 @@ RP_HD uint64_t rp_node_hash_step(uint64_t seed, uint64_t epoch) {
     uint64_t h = rp_mix64(seed + 0x9e3779b97f4a7c15ull);
     return rp_mix64(h ^ (epoch * 0xd1342543de82ef95ull + 0x632be59bd9b4e019ull));
 }
+/* ... and the per-draw half in two again: a kernel that draws several times for one tree hashes the tree once */
+RP_HD uint64_t rp_node_hash_tree(uint64_t step_hash, uint64_t tree) {
+    return rp_mix64(step_hash ^ (tree * 0xaf251af3b0f025b5ull + 0x2545f4914f6cdd1dull));
+}
+RP_HD uint64_t rp_node_hash_key(uint64_t tree_hash, uint64_t key) {
+    return rp_mix64(tree_hash ^ (key * 0x9fb21c651e98df25ull + 0x27d4eb2f165667c5ull));
+}
 RP_HD uint64_t rp_node_hash_draw(uint64_t step_hash, uint64_t tree, uint64_t key) {
-    uint64_t h = rp_mix64(step_hash ^ (tree * 0xaf251af3b0f025b5ull + 0x2545f4914f6cdd1dull));
-    return rp_mix64(h ^ (key * 0x9fb21c651e98df25ull + 0x27d4eb2f165667c5ull));
+    return rp_node_hash_key(rp_node_hash_tree(step_hash, tree), key);
 }
 RP_HD uint64_t rp_node_hash(uint64_t seed, uint64_t epoch, uint64_t tree, uint64_t key) {
     return rp_node_hash_draw(rp_node_hash_step(seed, epoch), tree, key);

@@ -165,6 +165,8 @@ __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevI
     uint32_t pick[N];                     // chance: the sampled outcome; opponent: the sampled action; walker (PRUNED): the surviving edges
     bool live[N];
     float sg0[N], sg1[N], q0[N], q1[N];   // (sigma, q) of a player node's two edges
+    // every draw of this tree: rp_node_hash(seed, epoch, tree, key) with the (seed, epoch, tree) part hashed once
+    const uint64_t th = rp_node_hash_tree(rp_node_hash_step(p.seed, p.epoch), tree_id);
     rx[0] = g.root_rec.x;
     ry[0] = g.root_rec.y;
     rz[0] = g.root_rec.z;
@@ -196,7 +198,7 @@ __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevI
             else live[s] = live[par];
         }
         if constexpr (SK::S.kind[s] == SK_CHANCE) {  // SamplingScheme::sample at a chance node: uniform (external.rs:41-64)
-            pick[s] = rp_pick_uniform(rp_node_hash(p.seed, p.epoch, tree_id, 0x80000000ull | rw[s]), (rx[s] >> 8) & 0xffu);
+            pick[s] = rp_pick_uniform(rp_node_hash_key(th, 0x80000000ull | rw[s]), (rx[s] >> 8) & 0xffu);
         } else if constexpr (SK::S.kind[s] == SK_P0 || SK::S.kind[s] == SK_P1) {
             const uint32_t info = ry[s];
             const float4 f = *reinterpret_cast<const float4*>(&it.sq[info * 2u]);
@@ -205,13 +207,13 @@ __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevI
             sg1[s] = f.z;
             q1[s] = f.w;
             if constexpr (SK::S.kind[s] == K_OPP) {  // WeightedIndex over max(q, EPSILON): two actions = one threshold
-                const float x = rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info)) * it.total[info];
+                const float x = rp_u01(rp_node_hash_key(th, info)) * it.total[info];
                 pick[s] = it.cum[info * 2u] <= x ? 1u : 0u;
             } else if constexpr (PRUNED) {  // SamplingScheme::sample at a walker node (d_sample_mask_tab, the same draw and masks)
                 uint32_t mask = 3u;
                 bool prune = true;
                 if (p.S == RP_SAMPLING_PLURIBUS)
-                    prune = p.epoch >= p.prune_warmup && !(rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info)) < p.prune_explore);
+                    prune = p.epoch >= p.prune_warmup && !(rp_u01(rp_node_hash_key(th, info)) < p.prune_explore);
                 if (prune) {
                     mask = it.keep[info] & 3u;
                     if (p.S == RP_SAMPLING_PLURIBUS)
