@@ -409,6 +409,10 @@ RP_API int rp_nlhe_step_local(rp_nlhe* h, void* entries_dev, uint64_t* past_dev,
                               uint32_t* n_entries);
 RP_API int rp_nlhe_step_apply(rp_nlhe* h, void* entries_dev, const uint64_t* past_dev, const uint32_t* present_dev,
                               const uint64_t* choices_dev, uint32_t n_entries);
+/* the whole sharded step over the library's own RCCL communicator (rp_comm, below): step_local, the ranks' entry counts
+ * (the one host read of a step: ncclAllGather takes host-known sizes), entries + keys gathered padded to the longest list,
+ * packed rank-major on the device, step_apply; `steps` times.  Sets the shard from the communicator's rank / world. */
+RP_API int rp_nlhe_step_comm(rp_nlhe* h, rp_comm* c, uint32_t steps);
 /* every rp_nlhe kernel runs on ONE stream (the profile's): hand it the stream the collectives run on and the exchange is
  * ordered without host synchronisation (NULL = back to a stream of the library's own); rp_nlhe_sync waits for it.
  * step_local returns with *n_entries valid and the key arrays QUEUED on that stream. */

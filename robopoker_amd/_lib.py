@@ -254,6 +254,7 @@ _SIGNATURES = {
     "rp_nlhe_entry_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
     "rp_nlhe_step_local": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "rp_nlhe_step_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "rp_nlhe_step_comm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "rp_nlhe_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_nlhe_sync": (C.c_int, [C.c_void_p]),
     "rp_profile_set_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),

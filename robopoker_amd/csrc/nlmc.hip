@@ -363,6 +363,8 @@ struct rp_nlhe {
     uint32_t* d_total = nullptr;   // [0] Decisions of the batch, [1] walker nodes of the batch
     unsigned long long* d_counters = nullptr;  // lane-per-tree kernel: nodes, infos, error flags of the launch
     void* d_scan = nullptr;                    // scratch of the per-tree scans
+    void *x_keys = nullptr, *x_counts = nullptr, *x_all = nullptr, *x_packed = nullptr;  // rp_nlhe_step_comm: grow-only exchange buffers
+    size_t x_keys_bytes = 0, x_counts_bytes = 0, x_all_bytes = 0, x_packed_bytes = 0;
     uint32_t* d_remap_err = nullptr;           // rp_nlhe_step_apply: table full while inserting exchanged keys
     std::vector<void*> allocs;
     uint32_t last_n = 0;
@@ -686,6 +688,8 @@ int rp_nlhe_destroy(rp_nlhe* h) {
         (void)rp_profile_destroy(h->prof);
     }
     for (void* p : h->allocs) (void)hipFree(p);
+    for (void* p : {h->x_keys, h->x_counts, h->x_all, h->x_packed})
+        if (p) (void)hipFree(p);
     delete h;
     return RP_OK;
 }
@@ -900,6 +904,84 @@ int rp_nlhe_step_apply(rp_nlhe* h, void* entries_dev, const uint64_t* past_dev, 
         HIP_TRY(hipGetLastError());
     }
     return rp_profile_fold(h->prof, entries_dev, n_entries);
+}
+
+// Solver::step across the ranks of an rp_comm (the library's own RCCL communicator; hosts without torch.distributed): step_local,
+// the entry counts of all ranks (4 bytes each — ncclAllGather takes host-known sizes, so this is the one host read of a step),
+// entries and keys all-gathered padded to the longest list, packed rank-major on the device, step_apply.  `steps` steps.
+int rp_nlhe_step_comm(rp_nlhe* h, rp_comm* c, uint32_t steps) {
+    if (!h || !c) return rp::fail(RP_ERR_INVALID, "rp_nlhe_step_comm: NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const uint32_t world = (uint32_t)rp::comm_world(c), rank = (uint32_t)rp::comm_rank(c);
+    int rc = rp_nlhe_set_shard(h, rank, world);
+    if (rc) return rc;
+    size_t eb = 0;
+    (void)rp_profile_entry_bytes(h->prof, &eb);
+    hipStream_t st = rp::profile_stream(h->prof);
+    unsigned char* mine_ent = rp::profile_entries(h->prof);
+    if (!mine_ent) return rp::fail(RP_ERR_INVALID, "rp_nlhe_step_comm: the profile has no summary buffer");
+    auto grow = [&](void** p, size_t* have, size_t need) -> int {
+        if (*have >= need) return RP_OK;
+        HIP_TRY(hipStreamSynchronize(st));
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+        *have = 0;
+        HIP_TRY(hipMalloc(p, need + need / 4));
+        *have = need + need / 4;
+        return RP_OK;
+    };
+    for (uint32_t s = 0; s < steps; ++s) {
+        if ((rc = nl_traverse(h))) return rc;
+        rp_decisions b{h->last_n, h->out.row, h->out.nact, h->out.expanded, h->out.regret, h->out.policy, h->out.payoff};
+        uint32_t n_mine = 0;
+        if ((rc = rp_profile_summarize(h->prof, &b, mine_ent, &n_mine))) return rc;  // synchronises: n_mine is valid
+        // every rank's count
+        if ((rc = grow(&h->x_counts, &h->x_counts_bytes, (size_t)(world + 1) * 4u))) return rc;
+        uint32_t* d_counts = reinterpret_cast<uint32_t*>(h->x_counts);
+        HIP_TRY(hipMemcpyAsync(d_counts + world, &n_mine, 4, hipMemcpyHostToDevice, st));
+        if ((rc = rp::comm_all_gather(c, d_counts + world, d_counts, 4, st))) return rc;
+        std::vector<uint32_t> counts(world);
+        HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, (size_t)world * 4u, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        uint32_t width = 0, total = 0;
+        for (uint32_t r = 0; r < world; ++r) width = std::max(width, counts[r]), total += counts[r];
+        // keys of my entries: [past u64][choices u64][present u32] planes of `width` items (the gather sends `width` of each)
+        if ((rc = grow(&h->x_keys, &h->x_keys_bytes, (size_t)std::max<uint32_t>(width, 1u) * 20u))) return rc;
+        uint64_t* kp = reinterpret_cast<uint64_t*>(h->x_keys);
+        uint64_t* kc = kp + width;
+        uint32_t* kb = reinterpret_cast<uint32_t*>(kc + width);
+        if (n_mine)
+            hipLaunchKernelGGL(k_nlhe_entry_keys, dim3((n_mine + 255u) / 256u), dim3(256), 0, st, h->tab, mine_ent, (uint32_t)eb, n_mine, kp, kb, kc);
+        // padded gathers: four planes (entries, past, choices, present), each world x width items
+        const size_t unit[4] = {eb, 8, 8, 4};
+        size_t all_bytes = 0, pk_bytes = 0;
+        for (int q = 0; q < 4; ++q) all_bytes += (size_t)world * width * unit[q], pk_bytes += (size_t)std::max(total, 1u) * unit[q];
+        if ((rc = grow(&h->x_all, &h->x_all_bytes, std::max<size_t>(all_bytes, 64)))) return rc;
+        if ((rc = grow(&h->x_packed, &h->x_packed_bytes, std::max<size_t>(pk_bytes, 64)))) return rc;
+        unsigned char* all = reinterpret_cast<unsigned char*>(h->x_all);
+        unsigned char* pk = reinterpret_cast<unsigned char*>(h->x_packed);
+        const void* src[4] = {mine_ent, kp, kc, kb};
+        unsigned char* pk_plane[4];
+        size_t all_off = 0, pk_off = 0;
+        for (int q = 0; q < 4 && width; ++q) {
+            unsigned char* plane = all + all_off;
+            if ((rc = rp::comm_all_gather(c, src[q], plane, (size_t)width * unit[q], st))) return rc;  // reads `width` items of mine: within its buffers
+            pk_plane[q] = pk + pk_off;
+            size_t at = 0;
+            for (uint32_t r = 0; r < world; ++r) {  // rank-major packing
+                if (counts[r])
+                    HIP_TRY(hipMemcpyAsync(pk_plane[q] + at, plane + (size_t)r * width * unit[q], (size_t)counts[r] * unit[q], hipMemcpyDeviceToDevice, st));
+                at += (size_t)counts[r] * unit[q];
+            }
+            all_off += (size_t)world * width * unit[q];
+            pk_off += (size_t)total * unit[q];
+        }
+        if (!width) pk_plane[0] = pk_plane[1] = pk_plane[2] = pk_plane[3] = pk;
+        if ((rc = rp_nlhe_step_apply(h, pk_plane[0], reinterpret_cast<const uint64_t*>(pk_plane[1]), reinterpret_cast<const uint32_t*>(pk_plane[3]),
+                                     reinterpret_cast<const uint64_t*>(pk_plane[2]), total)))
+            return rc;
+    }
+    return RP_OK;
 }
 
 int rp_nlhe_set_stream(rp_nlhe* h, void* hip_stream) {

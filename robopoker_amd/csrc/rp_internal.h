@@ -29,6 +29,7 @@ namespace rp {
 float* profile_table(rp_profile* h);
 ihipStream_t* profile_stream(rp_profile* h);
 uint64_t profile_epoch(const rp_profile* h);
+unsigned char* profile_entries(rp_profile* h);
 int lookup_view(const rp_lookup* t, const uint64_t** keys, const uint8_t** abs_, uint64_t* n, int* street);
 }  // namespace rp
 

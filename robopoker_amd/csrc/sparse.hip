@@ -636,6 +636,7 @@ namespace rp {
 float* profile_table(rp_profile* h) { return h->tab; }
 hipStream_t profile_stream(rp_profile* h) { return h->stream; }
 uint64_t profile_epoch(const rp_profile* h) { return h->epoch; }
+unsigned char* profile_entries(rp_profile* h) { return h->entries; }  // the local summary buffer: max_batch entries
 
 static size_t entry_bytes_of(const rp_profile* h) { return 16 + (size_t)2 * h->A * sizeof(Map); }
 // sum over rows of ceil(count / RP_SPARSE_BLOCK) <= rows + n / RP_SPARSE_BLOCK <= n + n / RP_SPARSE_BLOCK

@@ -107,6 +107,10 @@ class NlheSolver:
         _lib.check(self._lib.rp_nlhe_step_apply(self._h, C.c_void_p(entries_ptr), C.c_void_p(past_ptr), C.c_void_p(present_ptr),
                                                 C.c_void_p(choices_ptr), n))
 
+    def step_comm(self, comm, steps: int = 1):
+        """`steps` sharded steps over the library's own RCCL communicator (robopoker_amd.mccfr.Comm)"""
+        _lib.check(self._lib.rp_nlhe_step_comm(self._h, comm.handle, steps))
+
     def set_stream(self, hip_stream_ptr):
         _lib.check(self._lib.rp_nlhe_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
 

@@ -317,11 +317,20 @@ class ShardedNlhe:
         self.scope = _StreamScope(engine, device)
         self.eb, cap = engine.entry_bytes()
         self.cap = cap
-        mk = lambda n, dt: torch.zeros(n, dtype=dt, device=device)  # noqa: E731
+        self._mk = lambda n, dt: torch.zeros(n, dtype=dt, device=device)  # noqa: E731
+        mk = self._mk
+        # step_local writes one entry per infoset the rank touched into `mine` (capacity: the batch's Decisions, the C contract);
+        # the gathered and packed lists are sized by what the ranks actually send (grow-only): a few 10^5 entries, not the 4 x 10^7
+        # of the worst case
         self.mine = {"ent": mk(cap * self.eb, torch.uint8), "past": mk(cap, torch.int64), "present": mk(cap, torch.int32),
                      "choices": mk(cap, torch.int64)}
-        self.all = {k: mk(v.numel() * self.world, v.dtype) for k, v in self.mine.items()}
-        self.packed = {k: mk(v.numel() * self.world, v.dtype) for k, v in self.mine.items()}
+        self.all = {k: mk(0, v.dtype) for k, v in self.mine.items()}
+        self.packed = {k: mk(0, v.dtype) for k, v in self.mine.items()}
+
+    def _room(self, bufs, k, n):
+        if bufs[k].numel() < n:
+            bufs[k] = self._mk(n + n // 4, bufs[k].dtype)
+        return bufs[k]
 
     def step(self) -> int:
         with self.scope:
@@ -334,14 +343,16 @@ class ShardedNlhe:
         _all_gather_bytes(counts, torch.tensor([n], dtype=torch.int64, device=self.device), self.group, self.flat)
         counts = [int(c) for c in counts.cpu().tolist()]
         width, total = max(counts), sum(counts)
-        if width:
-            for k, unit in (("ent", self.eb), ("past", 1), ("present", 1), ("choices", 1)):
-                w = width * unit
-                _all_gather_bytes(self.all[k][: self.world * w], m[k][:w], self.group, self.flat)
-                off = 0
-                for r, c in enumerate(counts):  # rank-major packing, on the device
-                    self.packed[k][off: off + c * unit] = self.all[k][r * w: r * w + c * unit]
-                    off += c * unit
+        for k, unit in (("ent", self.eb), ("past", 1), ("present", 1), ("choices", 1)):
+            w = width * unit
+            allk, pk = self._room(self.all, k, max(self.world * w, 1)), self._room(self.packed, k, max(total * unit, 1))
+            if not width:
+                continue
+            _all_gather_bytes(allk[: self.world * w], m[k][:w], self.group, self.flat)
+            off = 0
+            for r, c in enumerate(counts):  # rank-major packing, on the device
+                pk[off: off + c * unit] = allk[r * w: r * w + c * unit]
+                off += c * unit
         p = self.packed
         self.engine.step_apply(p["ent"].data_ptr(), p["past"].data_ptr(), p["present"].data_ptr(), p["choices"].data_ptr(), total)
         return total

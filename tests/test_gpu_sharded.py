@@ -164,4 +164,25 @@ def test_native_rccl_comm_world_of_one(gpu):
         d1, s1, m1 = a.step_comm(comm)
         d2, s2, m2 = b.step()
         assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32)) and np.array_equal(s1, s2) and m1 == m2
+    # NLHE: rp_nlhe_step_comm (step_local, the count + padded entry / key gathers, rank-major packing, step_apply inside one C
+    # call) == the Python ShardedNlhe exchange == the oracle's world model, for a world of one: composed entries folded by key
+    import oracle_nlmc as M
+    from robopoker_amd.nlhe import NlheSolver
+
+    n1 = NlheSolver(cap_log2=18, batch=96, seed=31)
+    o1 = M.OracleNlhe(cap_log2=18, batch=96, seed=31)
+    for step in range(3):
+        n1.step_comm(comm, 1)
+        n1.sync()
+        o1.step_world(1)
+        dm = {k: v for k, v in M.as_map(*n1.export()).items() if v["visits"][0] > 0}
+        om = {k: v for k, v in M.as_map(*o1.export()).items() if v["visits"][0] > 0}
+        assert dm.keys() == om.keys()
+        for k in om:
+            assert np.array_equal(dm[k]["visits"], om[k]["visits"]), (step, k)
+            np.testing.assert_allclose(dm[k]["regret"], om[k]["regret"], rtol=2e-4, atol=5e-3)
+            np.testing.assert_allclose(dm[k]["weight"], om[k]["weight"], rtol=2e-4, atol=1e-5)
+        assert n1.epoch == o1.epoch == step + 1
+        n1.load(*o1.export(), epoch=o1.epoch)
+    n1.close()
     comm.close()
