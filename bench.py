@@ -26,6 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("RP_ORACLE_NATIVE", "1")  # the cpu_baseline legs time the oracle built -O3 -march=native on this machine
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -107,6 +108,7 @@ def cpu_baseline(args):
         "kind": "port",
         "sample": f"oracle/rp_oracle_mccfr.c, {args.game} {args.regret}/{args.weight}/{args.sampling}, "
                   f"batch {B}, {steps * B} trees in {dt:.1f} s on 1 host thread",
+        "build": oracle.ORACLE_BUILD,
     }
 
 
@@ -577,6 +579,67 @@ def convergence_times(args, g, local_rank):
     return out
 
 
+def nlhe_extra(args, local_rank):
+    """BASELINE configs[3] on this GPU, as an extra of the default line: the Flagship solver type's step (level-synchronous traversal
+    + composed table update) at a GPU-sized batch and at the reference's 128, with the dominant kernel's roofline; CPU oracle beside."""
+    from robopoker_amd.nlhe import NlheSolver
+
+    def run(batch, steps, warmup, profile):
+        s = NlheSolver(cap_log2=args.nlhe_cap, regret="linear", weight="linear", batch=batch, seed=args.seed, device=local_rank,
+                       sampling="pluribus")
+        for _ in range(warmup):
+            s.step("composed")
+        n0, i0, _ = s.counters()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s.step("composed")
+        n1, i1, keys = s.counters()  # synchronises
+        dt = time.perf_counter() - t0
+        out = {"value": (i1 - i0) / dt, "unit": "infoset-updates/s", "ms_per_step": dt / steps * 1e3, "trees_per_step": batch,
+               "nodes_per_s": (n1 - n0) / dt, "infosets_in_table": keys}
+        if profile:
+            s.profile(True)
+            for _ in range(steps):
+                s.step("composed")
+            g, c = s.kernel_times(), s.census()
+            s.profile(False)
+            n_all = c["terminal"] + c["chance"] + c["walker"] + c["opponent"]
+            alg = (4 * n_all + c["walker"] * (48 + 32 + 36 + 24 + 4) + 8 * c["walker_children"] + c["opponent"] * (48 + 32 + 72 + 20 + 8)
+                   + c["chance"] * 20)
+            ms = g["expand"][0]
+            ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else None
+            out["kernel_ms_per_step"] = {k: v[0] / steps for k, v in g.items()}
+            out["roofline"] = {"bound": "hbm", "kernel": "k_nl_expand", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBPS if ach else None, "traffic": None,
+                               "algorithmic_bytes_per_launch": alg / max(g["expand"][1], 1),
+                               "avg_launch_us": ms * 1e3 / max(g["expand"][1], 1),
+                               "note": "one launch per tree level; DESIGN 3c: bytes = 4 N + 144 walker + 8 walker-children + 180 opponent + 20 chance"}
+        s.close()
+        return out
+
+    big = run(args.nlhe_batch, 6, 3, True)
+    big["workload"] = ("heads-up NLHE blueprint MCCFR, Nlhe<LinearRegret, LinearWeight, PluribusSampling> (BASELINE configs[3] on one GPU): "
+                       "trees generated on the device, hash encoder, 2^%d-row table" % args.nlhe_cap)
+    ref = run(128, 20, 3, False)
+    big["reference_batch_128"] = {"value": ref["value"], "unit": "infoset-updates/s", "ms_per_step": ref["ms_per_step"]}
+    if args.cpu_seconds > 0:
+        import oracle_nlmc
+
+        o = oracle_nlmc.OracleNlhe(cap_log2=20, regret="linear", weight="linear", batch=128, seed=args.seed, sampling="pluribus")
+        o.step()
+        _, i0, _ = o.counters()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < min(5.0, args.cpu_seconds):
+            o.step()
+            n += 1
+        dtc = time.perf_counter() - t0
+        _, i1, _ = o.counters()
+        big["cpu_baseline"] = {"value": (i1 - i0) / dtc, "unit": "infoset-updates/s", "cores": 1, "kind": "port",
+                               "sample": f"oracle/rp_oracle_nlmc.c, batch 128, {n * 128} trees in {dtc:.1f} s on 1 host thread"}
+    return big
+
+
 def nlhe_real(args, rank, world, local_rank):
     """BASELINE configs[3]: Solver::step of the NLHE blueprint solver (trees generated, traversed and applied on the device),
     infoset-updates (= Decisions, the reference's `infos` counter) per second; the reference's batch of 128 trees beside the
@@ -827,6 +890,10 @@ def main():
             if km is not None:
                 line["kmeans"] = km
         if world == 1 and not args.force_sharded and not args.no_extras:
+            try:
+                line["nlhe"] = nlhe_extra(args, local_rank)
+            except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
+                line["nlhe"] = {"error": f"{type(exc).__name__}: {exc}"}
             try:
                 line["abstraction_inputs"] = abstraction_inputs(args, local_rank)
             except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)

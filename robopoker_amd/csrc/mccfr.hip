@@ -1388,6 +1388,12 @@ namespace rp {
 //            instead of three.  Otherwise it writes the summary blob (rp_mccfr_step_local).
 // Cross-workgroup data is a few KB per infoset: agent-scope (sc1) stores + s_waitcnt before the arrival, agent-scope
 // loads after it.  (A release FENCE at agent scope writes back a whole XCD's L2: tried on the block maps, 4x slower.)
+// This hand-over is written against the gfx942 / gfx950 memory system, not against the portable memory model: relaxed agent-scope
+// stores are sc1 write-through stores that `s_waitcnt vmcnt(0)` waits for (no separate store counter), relaxed agent-scope loads
+// bypass the XCD's non-coherent lines.  On any other target the arrival counter would need release / acquire semantics:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "k_combine2's cross-workgroup hand-over relies on gfx942/gfx950 store counting and sc1 semantics: use an acq_rel arrival counter on other targets"
+#endif
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(uint32_t* q, uint32_t v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ Map ld_map(const Map* m) {

@@ -14,6 +14,7 @@ from robopoker_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_PATH = os.path.join(ROOT, "oracle", "_build", "librp_oracle.so")
+ORACLE_BUILD = "-O3 (portable)"
 MAXA = 16
 
 
@@ -38,7 +39,20 @@ def load() -> C.CDLL:
         return _ora
     if not os.path.exists(ORACLE_PATH):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
-    o = C.CDLL(ORACLE_PATH)
+    path = ORACLE_PATH
+    if os.environ.get("RP_ORACLE_NATIVE"):
+        # bench.py's cpu_baseline legs: the same sources compiled -O3 -march=native ON THIS MACHINE; the parity tests
+        # use the portable build, which travels between machines.  No compiler here = the portable build, said in the sample text
+        native = os.path.join(ROOT, "oracle", "_build", "librp_oracle_native.so")
+        try:
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "native"], stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.DEVNULL)
+            path = native
+        except (OSError, subprocess.CalledProcessError):
+            pass
+    global ORACLE_BUILD
+    ORACLE_BUILD = "-O3 -march=native" if path != ORACLE_PATH else "-O3 (portable)"
+    o = C.CDLL(path)
     vp = C.c_void_p
     o.ora_mccfr_create.restype = vp
     o.ora_mccfr_create.argtypes = [C.POINTER(_lib.GameTable), C.c_int, C.c_int, C.c_int, C.c_uint32,
