@@ -381,6 +381,7 @@ struct rp_nlhe {
     Clock clk[5];  // expand, children, sweeps (up + down), decide (scan + fill + group + emit), apply
     uint64_t census[5] = {0, 0, 0, 0, 0};  // nodes by kind + walker children, summed over the profiled steps
     int expand_waves = 4;  // RP_NLHE_EXPAND_WAVES: 4 (128 VGPRs) or 5 (96 VGPRs, some spilled)
+    int expand_threads = 256;  // RP_NLHE_EXPAND_THREADS: workgroup size of k_nl_expand (64 / 128 / 256)
     uint32_t grid_cap = 16384;  // workgroups of the grid-stride kernels (RP_NLHE_GRID; measured: 1024 -14 %, 4096 -4 %)
 };
 
@@ -468,6 +469,7 @@ int nl_traverse_levels(rp_nlhe* h) {
     NlNodes& lv = h->lv;
     const uint32_t B = h->batch;
     const dim3 wide(std::min<uint32_t>(h->grid_cap, std::max<uint32_t>(1u, (lv.ncap / 4u + 255u) / 256u))), blk(256);
+    const dim3 wide_x(std::min<uint32_t>(h->grid_cap * 2u, std::max<uint32_t>(1u, (lv.ncap / 4u + NL_TILE - 1u) / NL_TILE)));  // one tile per workgroup
     HIP_TRY(hipMemsetAsync(lv.ctl, 0, sizeof(NlCtl), st));
     HIP_TRY(hipMemsetAsync(lv.t_nw, 0, (size_t)B * 4, st));
     h->prm.tag = nl_next_tag(h);
@@ -479,8 +481,10 @@ int nl_traverse_levels(rp_nlhe* h) {
         for (; L < stop; ++L) {
             h->prm.tag = nl_next_tag(h);
             nl_clock_begin(h, 0);
-            if (h->expand_waves == 5) hipLaunchKernelGGL(k_nl_expand<5>, wide, blk, 0, st, h->prm, h->tab, lv, L);
-            else hipLaunchKernelGGL(k_nl_expand<4>, wide, blk, 0, st, h->prm, h->tab, lv, L);
+            if (h->expand_threads == 64) hipLaunchKernelGGL((k_nl_expand<4, 64>), wide_x, dim3(64), 0, st, h->prm, h->tab, lv, L);
+            else if (h->expand_threads == 128) hipLaunchKernelGGL((k_nl_expand<4, 128>), wide_x, dim3(128), 0, st, h->prm, h->tab, lv, L);
+            else if (h->expand_waves == 5) hipLaunchKernelGGL((k_nl_expand<5, 256>), wide_x, blk, 0, st, h->prm, h->tab, lv, L);
+            else hipLaunchKernelGGL((k_nl_expand<4, 256>), wide_x, blk, 0, st, h->prm, h->tab, lv, L);
             nl_clock_end(h, 0);
             nl_clock_begin(h, 1);
             hipLaunchKernelGGL(k_nl_children, wide, blk, 0, st, h->prm, lv, L);
@@ -549,6 +553,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     h->lane_per_tree = getenv("RP_NLHE_LANE_PER_TREE") != nullptr;
     if (getenv("RP_NLHE_GRID")) h->grid_cap = std::max(1, atoi(getenv("RP_NLHE_GRID")));
     if (getenv("RP_NLHE_EXPAND_WAVES")) h->expand_waves = atoi(getenv("RP_NLHE_EXPAND_WAVES"));
+    if (getenv("RP_NLHE_EXPAND_THREADS")) h->expand_threads = atoi(getenv("RP_NLHE_EXPAND_THREADS"));
 #define NL_TRY(expr)                    \
     do {                                \
         int _rc = (expr);               \

@@ -10,11 +10,11 @@
 // together, one level of ALL trees per pair of launches, and every kernel works on nodes of ONE kind:
 //
 //   k_nl_roots      lane = tree      hole cards, blinds, preflop buckets -> level 0
-//   k_nl_expand(L)  lane = node      a workgroup takes a tile of 2048 consecutive nodes of level L and sorts it by kind in LDS
+//   k_nl_expand(L)  lane = node      a workgroup takes a tile of 512 consecutive nodes of level L and sorts it by kind in LDS
 //                                    (walker | opponent | chance, each padded to whole wavefronts; terminals drop out): a
 //                                    wavefront holds one kind.  Choices, NlheInfo key -> row (one 32-B slot + one row per probe),
 //                                    regret matching; opponent: the sampled edge; walker: the pruning scheme's mask; children
-//                                    allocated as one contiguous block per node (ONE cursor bump per 256 nodes: bumps of one
+//                                    allocated as one contiguous block per node (ONE cursor bump per tile: bumps of one
 //                                    address serialise at ~8 ns, the first version's per-wavefront work lists spent 2/3 of the
 //                                    step there), per child its (parent, slot) and edge factor
 //   k_nl_children(L) lane = child    apply(edge) on the parent's game -> the child's game, kind, reach; chance children draw
@@ -156,16 +156,18 @@ __global__ __launch_bounds__(256) void k_nl_roots(NlParams p, NlNodes nd) {
 // ---------------------------------------------------------------------------------------------------------------
 // k_nl_expand: the nodes of one level, by kind.  encoder.info + branches + sample (builder.rs:98-139).
 // ---------------------------------------------------------------------------------------------------------------
-#define NL_TILE 2048u  // nodes a workgroup sorts by kind at a time (8 per thread)
-template <int MINW>  // minimum wavefronts per SIMD the register allocation aims for
-__global__ __launch_bounds__(256, MINW) void k_nl_expand(NlParams p, NlTable t, NlNodes nd, uint32_t level) {
-    constexpr uint32_t R = NL_TILE / 256u;         // classification sub-rounds
+#define NL_TILE 512u  // nodes a workgroup sorts by kind at a time (measured: 512 and 1024 equal at 262 144 trees, 2048 -7 %, 4096 -13 % in
+                      // k_nl_expand; at 128 trees per step 8.0 / 7.8 / 6.6 / 5.3 M updates per second: a tile is a serial chain of phases)
+template <int MINW, uint32_t BT>  // minimum wavefronts per SIMD the register allocation aims for; threads per workgroup
+__global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, NlNodes nd, uint32_t level) {
+    constexpr uint32_t R = NL_TILE / BT;           // classification sub-rounds
+    constexpr uint32_t NW = BT / 64u;              // wavefronts of the workgroup
     constexpr uint32_t SCAP = NL_TILE + 192u;      // the sorted tile: three kinds, each from a multiple of 64
     __shared__ uint32_t sorted[SCAP];  // node index
     __shared__ uint32_t s_info[SCAP];  // n_kids | expanded mask << 4 | sampled slot << 13   (what the write phase needs)
     __shared__ uint32_t s_aux[SCAP];   // walker items: the infoset's row; opponent items: the bits of sigma / q of the sampled edge
-    __shared__ uint32_t wcnt[R][4][3];  // per sub-round, wavefront, kind: count, then exclusive prefix
-    __shared__ uint32_t segbase[3], segcnt[3], wsum[4], blockbase, tiletotal;
+    __shared__ uint32_t wcnt[R][NW][3];  // per sub-round, wavefront, kind: count, then exclusive prefix
+    __shared__ uint32_t segbase[3], segcnt[3], wsum[NW], blockbase, tiletotal;
     NlCtl* ctl = nd.ctl;
     const uint32_t lo = ctl->lvl_node[level], hi = ctl->lvl_node[level + 1];
     if (hi <= lo || ctl->err) return;  // an error anywhere ends the batch: the host fails the step
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256, MINW) void k_nl_expand(NlParams p, NlTable t, 
         uint32_t kd[R], rk[R];
 #pragma unroll
         for (uint32_t r = 0; r < R; ++r) {
-            const uint32_t i = t0 + r * 256u + tid;
+            const uint32_t i = t0 + r * BT + tid;
             const uint32_t kind = i < hi ? NL_META_KIND(nd.meta[i]) : (uint32_t)NK_TERMINAL;
             kd[r] = kind == NK_WALKER ? 0u : (kind == NK_OPP ? 1u : (kind == NK_CHANCE ? 2u : 3u));
             rk[r] = 0;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256, MINW) void k_nl_expand(NlParams p, NlTable t, 
         if (tid < 3) {
             uint32_t run = 0;
             for (uint32_t r = 0; r < R; ++r)
-                for (uint32_t w = 0; w < 4; ++w) {
+                for (uint32_t w = 0; w < NW; ++w) {
                     const uint32_t v = wcnt[r][w][tid];
                     wcnt[r][w][tid] = run;
                     run += v;
@@ -212,13 +214,13 @@ __global__ __launch_bounds__(256, MINW) void k_nl_expand(NlParams p, NlTable t, 
         __syncthreads();
 #pragma unroll
         for (uint32_t r = 0; r < R; ++r)
-            if (kd[r] < 3u) sorted[segbase[kd[r]] + wcnt[r][wave][kd[r]] + rk[r]] = t0 + r * 256u + tid;
+            if (kd[r] < 3u) sorted[segbase[kd[r]] + wcnt[r][wave][kd[r]] + rk[r]] = t0 + r * BT + tid;
         __syncthreads();
         const uint32_t total = segbase[2] + ((segcnt[2] + 63u) & ~63u);
         // ---- 2. every item: choices, key -> row, policy, the sampled / surviving edges.  No synchronisation between rounds:
         //         the children are placed afterwards, with ONE bump of the node cursor for the whole tile
         uint32_t mykids = 0, err = 0;
-        for (uint32_t jb = 0; jb < total; jb += 256u) {
+        for (uint32_t jb = 0; jb < total; jb += BT) {
             const uint32_t j = jb + tid;
             const uint32_t seg = j < segbase[1] ? 0u : (j < segbase[2] ? 1u : 2u);  // wave-uniform: the segments start at multiples of 64
             const bool valid = j < total && j - segbase[seg] < segcnt[seg];
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256, MINW) void k_nl_expand(NlParams p, NlTable t, 
         // ---- 3. one contiguous run of node indices for all children of the tile, in the tile's sorted order (neighbouring
         //         parents get neighbouring child blocks: the next kernels read both): block prefix sum over s_info, ONE cursor bump
         __syncthreads();  // every s_info / s_aux of the tile is written
-        constexpr uint32_t CH = (SCAP + 255u) / 256u;  // consecutive items per thread in the scan
+        constexpr uint32_t CH = (SCAP + BT - 1u) / BT;  // consecutive items per thread in the scan
         uint32_t mine = 0;
 #pragma unroll
         for (uint32_t q = 0; q < CH; ++q) {
@@ -352,10 +354,14 @@ __global__ __launch_bounds__(256, MINW) void k_nl_expand(NlParams p, NlTable t, 
         if ((tid & 63u) == 63u) wsum[wave] = incl;
         __syncthreads();
         if (tid == 0) {
-            const uint32_t a0 = wsum[0], a1 = wsum[1], a2 = wsum[2], a3 = wsum[3], tot = a0 + a1 + a2 + a3;
+            uint32_t tot = 0;
+            for (uint32_t w = 0; w < NW; ++w) {  // exclusive prefix over the wavefronts
+                const uint32_t v = wsum[w];
+                wsum[w] = tot;
+                tot += v;
+            }
             blockbase = tot ? atomicAdd(&ctl->n_nodes, tot) : 0u;
             tiletotal = tot;
-            wsum[0] = 0; wsum[1] = a0; wsum[2] = a0 + a1; wsum[3] = a0 + a1 + a2;
         }
         __syncthreads();
         {
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256, MINW) void k_nl_expand(NlParams p, NlTable t, 
         const bool fits = blockbase + tiletotal <= nd.ncap;  // else the batch's node budget is spent: the step fails, nothing is written
         if (!fits && mykids) err |= NERR_NODES;
         // ---- 4. per child its (parent, slot) and edge factor
-        for (uint32_t jb = 0; jb < total && fits; jb += 256u) {
+        for (uint32_t jb = 0; jb < total && fits; jb += BT) {
             const uint32_t j = jb + tid;
             if (j >= total) continue;
             const uint32_t info = s_info[j], nk = info & 15u;
