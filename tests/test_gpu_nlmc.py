@@ -328,3 +328,35 @@ def test_twin_solvers_at_a_gpu_sized_batch_are_identical(gpu):
         assert np.array_equal(a[i], b[i])
     for f in ("visits", "regret", "weight", "payoff"):
         assert np.array_equal(a[4][f].view(np.uint32), b[4][f].view(np.uint32)), f
+
+
+@pytest.mark.parametrize("batch,seed", [(1, 2), (65, 3), (257, 4)])
+def test_ragged_batches_equal_the_oracle(gpu, batch, seed):
+    # one tree (a single lane of a single tile per level), one tree past a wavefront, one past a workgroup: two steps each,
+    # both walkers, with resynchronisation — the level-synchronous kernels' ragged edges
+    dev = NlheSolver(cap_log2=16, batch=batch, seed=seed)
+    ora = M.OracleNlhe(cap_log2=16, batch=batch, seed=seed)
+    for _ in range(2):
+        _same_batch(dev.batch(), ora.batch())
+        dev.step("ordered")
+        ora.step()
+        assert dev.counters() == ora.counters()
+        dev.load(*ora.export(), epoch=ora.epoch)
+
+
+def test_a_full_infoset_table_fails_the_step_and_the_error_does_not_stick(gpu):
+    # 256 rows cannot hold the infosets of 200 trees: the step reports RP_ERR_CAPACITY (flag 32) instead of hanging in the probe
+    # loop or corrupting rows; the error belongs to that launch — a solver with room, created afterwards in the same process,
+    # and the failed handle's own counters are unaffected
+    from robopoker_amd import _lib
+
+    small = NlheSolver(cap_log2=8, batch=200, seed=1)
+    with pytest.raises(_lib.RpError) as e:
+        small.step("ordered")
+    assert e.value.code == 5 and "32" in str(e.value)
+    assert small.counters()[:2] == (0, 0)
+    ok = NlheSolver(cap_log2=18, batch=200, seed=1)
+    ok.step("ordered")
+    assert ok.counters()[1] > 200 * 20
+    small.close()
+    ok.close()
