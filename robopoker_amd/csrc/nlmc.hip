@@ -509,8 +509,8 @@ int nl_traverse_levels(rp_nlhe* h) {
     nl_clock_begin(h, 3);
     HIP_TRY(rp::ss::exclusive_scan<uint32_t>(lv.t_nw, lv.t_woff, B, h->d_scan, st, h->d_total + 1));
     hipLaunchKernelGGL(k_nl_fill, dim3(std::min<uint32_t>(wide.x, 2048u)), blk, 0, st, lv, n_nodes);
-    hipLaunchKernelGGL((k_nl_group<256, 0>), dim3(B), dim3(64), 0, st, lv, B);
-    hipLaunchKernelGGL((k_nl_group<NL_WMAX, 256>), dim3(B), dim3(64), 0, st, lv, B);
+    hipLaunchKernelGGL((k_nl_group<256>), dim3(B), dim3(64), 0, st, lv, B);
+    hipLaunchKernelGGL(k_nl_group_big, dim3(std::min<uint32_t>(B, 1280u)), dim3(64), 0, st, lv);
     HIP_TRY(rp::ss::exclusive_scan<uint32_t>(lv.t_dcount, lv.t_doff, B, h->d_scan, st, h->d_total));
     HIP_TRY(hipGetLastError());
     uint32_t total[2] = {0, 0};
@@ -642,6 +642,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
         NL_TRY(nl_alloc(h, &lv.t_nw, B)); NL_TRY(nl_alloc(h, &lv.t_woff, B));
         NL_TRY(nl_alloc(h, &lv.t_dcount, B)); NL_TRY(nl_alloc(h, &lv.t_doff, B));
         NL_TRY(nl_alloc(h, &lv.wl, LC)); NL_TRY(nl_alloc(h, &lv.ws, LC)); NL_TRY(nl_alloc(h, &lv.gdesc, LC));
+        NL_TRY(nl_alloc(h, &lv.big, B));
         NL_TRY(nl_alloc(h, &lv.ctl, 1));
     }
     h->out_cap = (uint32_t)dec_cap64;

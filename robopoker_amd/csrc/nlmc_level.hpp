@@ -59,6 +59,7 @@ struct NlCtl {
     uint32_t lvl_node[NL_MAXL + 2];  // first node of each level
     uint32_t kinds[4];               // nodes of the batch by kind (terminal, chance, walker, opponent) and ...
     uint32_t walker_kids;            // ... children of its walker nodes: what k_nl_expand's algorithmic bytes are counted from
+    uint32_t n_big;                  // trees with more than 256 walker nodes (k_nl_group -> k_nl_group_big)
 };
 struct NlNodes {
     // tree structure, by node
@@ -72,6 +73,7 @@ struct NlNodes {
     uint32_t *t_nw, *t_woff, *t_dcount, *t_doff;
     // walker nodes by tree (unsorted / sorted), span descriptors
     uint32_t *wl, *ws, *gdesc;
+    uint32_t* big;  // [batch] trees for k_nl_group_big
     NlCtl* ctl;
     uint32_t ncap, lcap;
 };
@@ -598,19 +600,11 @@ __global__ __launch_bounds__(256) void k_nl_fill(NlNodes nd, uint32_t n_nodes) {
 }
 
 // Tree::partition (tree.rs:88-98) for one tree per wavefront: walker nodes sorted by (row, creation index) -> spans; spans
-// ordered by their first node.  CAP = LDS capacity class (a launch handles the trees with CAP/4 < n <= CAP, or n <= CAP for the
-// smallest class).
-template <uint32_t CAP, uint32_t LOW>
-__global__ __launch_bounds__(64) void k_nl_group(NlNodes nd, uint32_t batch) {
-    __shared__ uint64_t key[CAP];
-    __shared__ uint32_t key2[CAP];
-    __shared__ uint16_t hp[CAP + 2];
-    const uint32_t tree = blockIdx.x, lane = threadIdx.x;
-    const uint32_t n = nd.t_nw[tree];
-    if (n > CAP || n <= LOW) {  // another capacity class' tree; nothing to do for an empty one or one k_nl_expand has flagged
-        if (lane == 0 && ((n == 0 && LOW == 0) || (n > NL_WMAX && CAP == NL_WMAX))) nd.t_dcount[tree] = 0;
-        return;
-    }
+// ordered by their first node.
+// the partition of one tree by one wavefront (LDS arrays of capacity CAP >= n)
+template <uint32_t CAP>
+__device__ __forceinline__ void nl_group_tree(const NlNodes& nd, uint32_t tree, uint32_t n, uint32_t lane, uint64_t* key, uint32_t* key2,
+                                              uint16_t* hp) {
     const uint32_t off = nd.t_woff[tree];
     uint32_t P = 64;
     while (P < n) P <<= 1;
@@ -674,6 +668,36 @@ __global__ __launch_bounds__(64) void k_nl_group(NlNodes nd, uint32_t batch) {
         nd.gdesc[off + g] = start | (len << 12);
     }
     if (lane == 0) nd.t_dcount[tree] = G;
+}
+// every tree of the batch, one per workgroup of one wavefront: trees with at most CAP walker nodes are partitioned here (the
+// usual case: 40 to 110 per tree), the larger ones are put on a list for k_nl_group_big (whose 28 KB of LDS per workgroup would
+// otherwise gate the launch of 262 144 mostly idle workgroups: 0.67 ms per step)
+template <uint32_t CAP>
+__global__ __launch_bounds__(64) void k_nl_group(NlNodes nd, uint32_t batch) {
+    __shared__ uint64_t key[CAP];
+    __shared__ uint32_t key2[CAP];
+    __shared__ uint16_t hp[CAP + 2];
+    const uint32_t tree = blockIdx.x, lane = threadIdx.x;
+    const uint32_t n = nd.t_nw[tree];
+    if (n == 0 || n > CAP) {
+        if (lane == 0) {
+            if (n == 0 || n > NL_WMAX) nd.t_dcount[tree] = 0;  // nothing to do for an empty tree or one k_nl_expand has flagged
+            else nd.big[atomicAdd(&nd.ctl->n_big, 1u)] = tree;
+        }
+        return;
+    }
+    nl_group_tree<CAP>(nd, tree, n, lane, key, key2, hp);
+}
+__global__ __launch_bounds__(64) void k_nl_group_big(NlNodes nd) {
+    __shared__ uint64_t key[NL_WMAX];
+    __shared__ uint32_t key2[NL_WMAX];
+    __shared__ uint16_t hp[NL_WMAX + 2];
+    const uint32_t n_big = nd.ctl->n_big;
+    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const uint32_t tree = nd.big[b];
+        nl_group_tree<NL_WMAX>(nd, tree, nd.t_nw[tree], threadIdx.x, key, key2, hp);
+        __syncthreads();
+    }
 }
 
 // one Decisions per lane: record_infosets + update_vector (solver.rs:263-305) for one walker infoset of one tree.  Walks the
