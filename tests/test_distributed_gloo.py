@@ -174,14 +174,20 @@ def _profile_worker(rank, port, out):
     dist.destroy_process_group()
 
 
-def _nlhe_worker(rank, port, out):
+def _nlhe_worker(rank, port, out, sampling="external"):
     # BASELINE configs[3]'s exchange: trees sharded by rank, composed entries exchanged by infoset key (robopoker_amd.parallel.
     # ShardedNlhe) — against the single-process world model, bit for bit, and replica against replica
     import oracle_nlmc as M
     from robopoker_amd.parallel import ShardedNlhe
 
     _init(rank, port)
-    eng = M.OracleNlhe(cap_log2=16, regret="linear", weight="linear", batch=24, seed=8)
+
+    def make():
+        hp = oracle.default_hyper()
+        hp.prune_warmup, hp.prune_threshold, hp.prune_explore = 1, -2.0, 0.1  # pruning live from the second step on
+        return M.OracleNlhe(cap_log2=16, regret="linear", weight="linear", batch=24, seed=8, sampling=sampling, hyper=hp)
+
+    eng = make()
     sh = ShardedNlhe(eng, device="cpu")
     for _ in range(3):
         sh.step()
@@ -200,7 +206,7 @@ def _nlhe_worker(rank, port, out):
         dist.broadcast(ref, src=0)
         same = bool(torch.equal(t, ref))
     if rank == 0:
-        single = M.OracleNlhe(cap_log2=16, regret="linear", weight="linear", batch=24, seed=8)
+        single = make()
         for _ in range(3):
             single.step_world(WORLD)
         want = {k: v for k, v in M.as_map(*single.export()).items() if v["visits"][0] > 0}
@@ -272,8 +278,10 @@ def test_sharded_sparse_profile_two_ranks_equals_world_model():
     assert res == {"profile": True, "profile-replica": True}
 
 
-def test_sharded_nlhe_two_ranks_exchange_by_key_equals_world_model():
-    res = _run(_nlhe_worker)
+@pytest.mark.parametrize("sampling", ["external", "pluribus"])
+def test_sharded_nlhe_two_ranks_exchange_by_key_equals_world_model(sampling):
+    # pluribus: the Flagship type (nlhe/src/lib.rs:86-90) with pruning forced live — a rank's pruned trees still exchange by key
+    res = _run(_nlhe_worker, sampling)
     assert res == {"nlhe": True, "nlhe-replica": True}
 
 
