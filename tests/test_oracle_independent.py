@@ -181,3 +181,72 @@ def test_first_epoch_decisions_are_hand_traceable(game):
     for d in decs:
         want[d["info"], :d["n"]] += d["regret"]
     assert np.allclose(rows["regret"], want, rtol=1e-5, atol=1e-5)
+
+
+# ---- the pruning schemes' masks, from the table alone (sample/pruning.rs:44-66, pluribus.rs:72-101) -----------------------
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    z ^= z >> 30
+    z = (z * 0xbf58476d1ce4e5b9) & _M64
+    z ^= z >> 27
+    z = (z * 0x94d049bb133111eb) & _M64
+    return z ^ (z >> 31)
+
+
+def _node_hash(seed, epoch, tree, key):  # include/rp_math.h rp_node_hash, restated on Python integers
+    h = _mix64((seed + 0x9e3779b97f4a7c15) & _M64)
+    h = _mix64(h ^ ((epoch * 0xd1342543de82ef95 + 0x632be59bd9b4e019) & _M64))
+    h = _mix64(h ^ ((tree * 0xaf251af3b0f025b5 + 0x2545f4914f6cdd1d) & _M64))
+    return _mix64(h ^ ((key * 0x9fb21c651e98df25 + 0x27d4eb2f165667c5) & _M64))
+
+
+def _u01(h):  # rp_u01: the top 24 bits as a float in [0, 1)
+    return np.float32(h >> 40) * np.float32(5.9604644775390625e-8)
+
+
+@pytest.mark.parametrize("sampling", ["pluribus", "prunable"])
+def test_pruned_masks_follow_from_the_table(sampling):
+    # Which walker edges a Decisions expanded is a pure function of (the infoset's accumulated regrets, the scheme's constants,
+    # the epoch, one hashed draw per (epoch, infoset, tree), which children are terminal): recomputed here from the exported table
+    # and the game table, in Python, for every Decisions of six Leduc batches with pruning forced to bite.
+    g = Game("leduc")
+    t = g.table
+    hp = oracle.default_hyper()
+    hp.prune_warmup, hp.prune_threshold, hp.prune_explore = 2, -0.05, 0.3
+    seed = 77
+    s = oracle.OracleSolver(g, "linear", "linear", sampling, batch=300, seed=seed, hyper=hp)
+    # terminal children per infoset (the same for every state of an infoset: the actions of a betting state are public)
+    term = {}
+    for st_i in range(t.n_states):
+        st = t.states[st_i]
+        if st.turn >= t.n_players:
+            continue
+        bits = 0
+        for a in range(st.n_children):
+            child = t.states[t.children[st.offset + a]]
+            bits |= (1 << a) if child.turn == 255 else 0
+        assert term.setdefault(st.info, bits) == bits
+    pruned = explored = 0
+    for step in range(6):
+        rows = s.export().reshape(g.n_infos, g.max_actions)
+        epoch = s.epoch
+        for d in s.batch():
+            n, info = d["n"], d["info"]
+            full = (1 << n) - 1
+            want = full
+            live = sampling == "prunable" or epoch >= hp.prune_warmup
+            if live and sampling == "pluribus" and _u01(_node_hash(seed, epoch, d["tree"], info)) < np.float32(hp.prune_explore):
+                live = False
+                explored += 1
+            if live:
+                keep = 0
+                for a in range(n):
+                    if rows["regret"][info, a] > np.float32(hp.prune_threshold) or (sampling == "pluribus" and (term[info] >> a) & 1):
+                        keep |= 1 << a
+                want = keep or full
+            assert d["expanded"] == want, (step, d, want)
+            pruned += want != full
+        s.step()
+    assert pruned > 20 and (sampling == "prunable" or explored > 20)

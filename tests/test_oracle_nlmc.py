@@ -157,3 +157,25 @@ def test_prunable_sampling_has_no_warm_up_and_no_terminal_exemption():
         n = int(b["n_actions"][i])
         assert bin(int(b["expanded"][i])).count("1") <= n
     assert s.counters()[2] == len(past)
+
+
+def test_prunable_masks_follow_from_the_table():
+    # PrunableSampling (sample/pruning.rs:44-66) has no warm-up, no explore draw and no terminal exemption: which edges a
+    # Decisions expanded is a pure function of its infoset's accumulated regrets — recomputed here from the exported table
+    hp = _pruning_hyper(warmup=0, threshold=-2.0)
+    s = M.OracleNlhe(cap_log2=18, batch=64, seed=13, sampling="prunable", hyper=hp)
+    o = M.lib()
+    partial = 0
+    for step in range(5):
+        b = s.batch()
+        keyed = M.as_map(*s.export())
+        for i in range(int(b["n"])):
+            kp, kb, kc = C.c_uint64(), C.c_uint32(), C.c_uint64()
+            assert o.ora_nlmc_row_key(s._h, int(b["row"][i]), C.byref(kp), C.byref(kb), C.byref(kc)) == 0
+            row, n = keyed[(kp.value, kb.value, kc.value)], int(b["n_actions"][i])
+            keep = sum(1 << a for a in range(n) if row["regret"][a] > np.float32(-2.0))
+            want = keep or (1 << n) - 1
+            assert int(b["expanded"][i]) == want, (step, i)
+            partial += want != (1 << n) - 1
+        s.step()
+    assert partial > 20
