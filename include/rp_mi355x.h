@@ -21,6 +21,9 @@
  *            <= 8191 infosets (Kuhn, Leduc, RPS, the wide Leduc) take the LDS-resident traversal; larger ones its HBM-scratch
  *            variant.  NLHE-sized trees (10^3-10^4 nodes) are NOT reachable through rp_game_table: see rp_nlhe_* below.
  *   profile  (rp_profile_*) max_actions <= 16, rows < 2^32, Decisions per batch < 2^31.
+ *   nlhe     (rp_nlhe_*) 2 players, stacks of 200 chips; at most 9 choices per infoset; a batch's trees together may hold
+ *            1 536 nodes per tree on average (92 B each) and 160 Decisions per tree on average, one tree at most 48 levels,
+ *            65 535 nodes and 2 048 walker nodes; the infoset table holds 2^cap_log2 rows (a full table fails the step).
  *   lloyd    K <= 256 and bins <= 256 (an Abstraction index is 8 bits, kicker/src/abstraction.rs:22-23), counts are u8
  *            (a point's mass per bin <= 255; the flop / turn layers have mass 47 / 46), N < 2^32.  The MFMA bound prunes
  *            points with 1..64 support bins; others go through the unpruned kernels.

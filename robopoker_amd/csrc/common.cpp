@@ -31,7 +31,7 @@ int rp_device_count(void) {
     return n;
 }
 
-const char* rp_version(void) { return "rp_mi355x 0.1.0 gfx950 hip " RP_STR(HIP_VERSION_MAJOR) "." RP_STR(HIP_VERSION_MINOR); }
+const char* rp_version(void) { return "rp_mi355x 0.3.0 gfx950 hip " RP_STR(HIP_VERSION_MAJOR) "." RP_STR(HIP_VERSION_MINOR); }
 
 void rp_hyper_default(rp_hyper* out) {
     if (!out) return;
