@@ -384,6 +384,11 @@ RP_API int rp_nlhe_kernel_time(rp_nlhe* h, const char* name, double* total_ms, u
 RP_API int rp_nlhe_census(rp_nlhe* h, uint64_t* kinds4, uint64_t* walker_children);
 /* Solver::step (solver.rs:96-105): the batch's trees, their Decisions, the table update (ordered or composed), epoch += 1 */
 RP_API int rp_nlhe_step(rp_nlhe* h, rp_update_mode mode);
+/* Trainer::train (crates/forge/src/trainer.rs:18-66) over this solver — the loop forge runs on the Flagship type; the contract of
+ * rp_mccfr_train (checkpoint / flush events, Checkpoint's display line, interrupt flag, Progress::summary) */
+RP_API int rp_nlhe_train(rp_nlhe* h, rp_update_mode mode, uint64_t max_steps, double max_seconds, double log_interval,
+                         double flush_interval, rp_train_event_fn on_event, void* user, const volatile int* interrupt,
+                         char* summary, size_t summary_cap);
 /* Solver::batch (solver.rs:225-250) alone, for inspection: the Decisions of the current epoch in tree order, each with
  * the infoset behind its row; *n = their number, at most `cap` are copied out; any output may be NULL.
  * regret / policy: [n][9]. */

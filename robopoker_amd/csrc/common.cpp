@@ -16,6 +16,16 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// Checkpoint's Display / Progress::format (metrics/checkpoint.rs:39-50, progress.rs:8-18): four 20-column fields
+void format_progress(char* buf, size_t cap, uint64_t epoch, uint64_t nodes, uint64_t infos, double rate) {
+    char f[4][48];
+    snprintf(f[0], sizeof f[0], "batch %llu", (unsigned long long)epoch);
+    snprintf(f[1], sizeof f[1], "nodes %llu", (unsigned long long)nodes);
+    snprintf(f[2], sizeof f[2], "infos %llu", (unsigned long long)infos);
+    snprintf(f[3], sizeof f[3], "I/sec %.1f", rate);
+    snprintf(buf, cap, "%-20s%-20s%-20s%-20s", f[0], f[1], f[2], f[3]);
+}
+
 }  // namespace rp
 
 extern "C" {

@@ -2443,15 +2443,8 @@ int rp_mccfr_spend(rp_mccfr* h, double seconds, uint64_t* iterations, double* el
     return RP_OK;
 }
 
-// Checkpoint's Display / Progress::format (metrics/checkpoint.rs:39-50, progress.rs:8-18): four 20-column fields
-static void format_progress(char* buf, size_t cap, uint64_t epoch, uint64_t nodes, uint64_t infos, double rate) {
-    char f[4][48];
-    snprintf(f[0], sizeof f[0], "batch %llu", (unsigned long long)epoch);
-    snprintf(f[1], sizeof f[1], "nodes %llu", (unsigned long long)nodes);
-    snprintf(f[2], sizeof f[2], "infos %llu", (unsigned long long)infos);
-    snprintf(f[3], sizeof f[3], "I/sec %.1f", rate);
-    snprintf(buf, cap, "%-20s%-20s%-20s%-20s", f[0], f[1], f[2], f[3]);
-}
+// Checkpoint's Display / Progress::format: rp::format_progress (common.cpp), shared with rp_nlhe_train
+using rp::format_progress;
 
 int rp_mccfr_train(rp_mccfr* h, uint64_t max_steps, double max_seconds, double log_interval, double flush_interval,
                    rp_train_event_fn on_event, void* user, const volatile int* interrupt, char* summary, size_t summary_cap) {

@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cmath>
 #include <vector>
 
 #include "nlmc_level.hpp"
@@ -710,6 +712,53 @@ int rp_nlhe_step(rp_nlhe* h, rp_update_mode mode) {
     rc = rp_profile_apply(h->prof, &b, mode);
     nl_clock_end(h, 4);
     return rc;
+}
+
+// Trainer::train (crates/forge/src/trainer.rs:18-66) over the NLHE solver — what forge runs on the Flagship type: loop { step;
+// checkpoint; flush; interrupt? } with Metrics::checkpoint's rate (mccfr/src/metrics/mod.rs:67-80), Checkpoint's display line
+// (metrics/checkpoint.rs:39-50) and Progress::summary (progress.rs:24-26); the same contract as rp_mccfr_train.  The counters
+// live on the host (the step synchronises once anyway), so a checkpoint costs nothing.
+int rp_nlhe_train(rp_nlhe* h, rp_update_mode mode, uint64_t max_steps, double max_seconds, double log_interval, double flush_interval,
+                  rp_train_event_fn on_event, void* user, const volatile int* interrupt, char* summary, size_t summary_cap) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_nlhe_train: NULL handle");
+    using clock = std::chrono::steady_clock;
+    const auto start = clock::now();
+    auto prior = start, flushed = start;
+    uint64_t prior_infos = 0, steps = 0;
+    auto secs_since = [](clock::time_point t) { return std::chrono::duration<double>(clock::now() - t).count(); };
+    for (;;) {
+        int rc = rp_nlhe_step(h, mode);
+        if (rc) return rc;
+        steps += 1;
+        const uint64_t epoch = rp::profile_epoch(h->prof);
+        if (secs_since(prior) >= log_interval) {
+            const double secs = std::max(1.0, std::floor(secs_since(prior)));  // elapsed().as_secs().max(1)
+            rp_checkpoint cp{epoch, h->nodes, h->infos, (double)(h->infos - prior_infos) / secs};
+            prior = clock::now();
+            prior_infos = h->infos;
+            if (on_event) {
+                char line[96];
+                rp::format_progress(line, sizeof line, cp.epoch, cp.nodes, cp.infos, cp.rate);
+                on_event(RP_TRAIN_CHECKPOINT, &cp, line, user);
+            }
+        }
+        if (secs_since(flushed) >= flush_interval) {  // FastSession::flush cadence (forge/src/fast.rs:97-125)
+            flushed = clock::now();
+            if (on_event) {
+                rp_checkpoint cp{epoch, h->nodes, h->infos, 0.0};
+                on_event(RP_TRAIN_FLUSH, &cp, "", user);
+            }
+        }
+        const bool stop = (interrupt && *interrupt) || (max_steps && steps >= max_steps) || (max_seconds > 0.0 && secs_since(start) >= max_seconds);
+        if (stop) break;
+    }
+    if (summary && summary_cap) {
+        char line[96];
+        const double secs = std::max(1.0, std::floor(secs_since(start)));
+        rp::format_progress(line, sizeof line, rp::profile_epoch(h->prof), h->nodes, h->infos, (double)h->infos / secs);
+        snprintf(summary, summary_cap, "training stopped\n%s", line);
+    }
+    return RP_OK;
 }
 
 // ---- profiling hooks used by bench.py: HIP events on the launch stream around each kernel group

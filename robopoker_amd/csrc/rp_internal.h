@@ -19,6 +19,8 @@ namespace rp {
 
 // records the message for rp_last_error() and returns the code
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// Checkpoint's display line / Progress::format (metrics/checkpoint.rs:39-50, progress.rs:8-18)
+void format_progress(char* buf, size_t cap, uint64_t epoch, uint64_t nodes, uint64_t infos, double rate);
 
 }  // namespace rp
 

@@ -53,6 +53,29 @@ class NlheSolver:
     def step(self, mode="ordered"):
         _lib.check(self._lib.rp_nlhe_step(self._h, _lib.UPDATE[mode]))
 
+    def train(self, mode="composed", max_steps=0, max_seconds=0.0, log_interval=60.0, flush_interval=1800.0, on_checkpoint=None,
+              on_flush=None, interrupt=None):
+        """``Trainer::train`` (crates/forge/src/trainer.rs:18-66) over this solver; returns Progress::summary"""
+        EVENT = C.CFUNCTYPE(None, C.c_int, C.c_void_p, C.c_char_p, C.c_void_p)
+
+        class Checkpoint(C.Structure):
+            _fields_ = [("epoch", C.c_uint64), ("nodes", C.c_uint64), ("infos", C.c_uint64), ("rate", C.c_double)]
+
+        def cb(event, cp, line, _user):
+            c = C.cast(cp, C.POINTER(Checkpoint)).contents
+            d = {"epoch": c.epoch, "nodes": c.nodes, "infos": c.infos, "rate": c.rate}
+            if event == 0 and on_checkpoint:
+                on_checkpoint(d, line.decode())
+            if event == 1 and on_flush:
+                on_flush(d)
+
+        fn = EVENT(cb)
+        buf = C.create_string_buffer(256)
+        _lib.check(self._lib.rp_nlhe_train(self._h, _lib.UPDATE[mode], int(max_steps), float(max_seconds), float(log_interval),
+                                           float(flush_interval), C.cast(fn, C.c_void_p), None,
+                                           C.byref(interrupt) if interrupt is not None else None, buf, len(buf)))
+        return buf.value.decode()
+
     def profile(self, enable: bool):
         _lib.check(self._lib.rp_nlhe_profile(self._h, 1 if enable else 0))
 

@@ -360,3 +360,32 @@ def test_a_full_infoset_table_fails_the_step_and_the_error_does_not_stick(gpu):
     assert ok.counters()[1] > 200 * 20
     small.close()
     ok.close()
+
+
+def test_trainer_loop_over_the_nlhe_solver(gpu):
+    # Trainer::train (forge/src/trainer.rs:18-66) over the Flagship solver type: a checkpoint every step (log interval 0),
+    # Checkpoint's display line (metrics/checkpoint.rs:39-50), rate = new infos / max(1, whole seconds), Progress::summary; the
+    # table is the one plain step() calls produce; the interrupt flag stops the loop after the step in flight
+    import ctypes
+
+    a = NlheSolver(cap_log2=18, batch=128, seed=6, sampling="pluribus")
+    b = NlheSolver(cap_log2=18, batch=128, seed=6, sampling="pluribus")
+    seen, flushes = [], []
+    summary = a.train("composed", max_steps=5, log_interval=0.0, flush_interval=0.0,
+                      on_checkpoint=lambda cp, line: seen.append((cp, line)), on_flush=lambda cp: flushes.append(cp))
+    for _ in range(5):
+        b.step("composed")
+    assert a.counters() == b.counters() and a.epoch == b.epoch == 5
+    am, bm = M.as_map(*a.export()), M.as_map(*b.export())
+    assert am.keys() == bm.keys() and all(am[k].tobytes() == bm[k].tobytes() for k in am)
+    assert len(seen) == 5 and len(flushes) == 5 and [cp["epoch"] for cp, _ in seen] == [1, 2, 3, 4, 5]
+    prev = 0
+    for cp, line in seen:
+        assert cp["rate"] == float(cp["infos"] - prev)
+        prev = cp["infos"]
+        assert line == "".join(f"{x:<20}" for x in (f"batch {cp['epoch']}", f"nodes {cp['nodes']}", f"infos {cp['infos']}", f"I/sec {cp['rate']:.1f}"))
+    nodes, infos, _ = a.counters()
+    assert summary == "training stopped\n" + "".join(f"{x:<20}" for x in ("batch 5", f"nodes {nodes}", f"infos {infos}", f"I/sec {float(infos):.1f}"))
+    stop = ctypes.c_int(1)
+    a.train("composed", interrupt=stop)
+    assert a.epoch == 6
