@@ -22,7 +22,8 @@
  *            variant.  NLHE-sized trees (10^3-10^4 nodes) are NOT reachable through rp_game_table: see rp_nlhe_* below.
  *   profile  (rp_profile_*) max_actions <= 16, rows < 2^32, Decisions per batch < 2^31.
  *   nlhe     (rp_nlhe_*) 2 players, stacks of 200 chips; at most 9 choices per infoset; a batch's trees together may hold
- *            1 536 nodes per tree on average (92 B each) and 160 Decisions per tree on average, one tree at most 48 levels,
+ *            1 536 nodes per tree on average (92 B each) per PASS (a batch that needs more is split into passes automatically)
+ *            and 160 Decisions per tree on average, one tree at most 48 levels,
  *            65 535 nodes and 2 048 walker nodes; the infoset table holds 2^cap_log2 rows (a full table fails the step).
  *   lloyd    K <= 256 and bins <= 256 (an Abstraction index is 8 bits, kicker/src/abstraction.rs:22-23), counts are u8
  *            (a point's mass per bin <= 255; the flop / turn layers have mass 47 / 46), N < 2^32.  The MFMA bound prunes
@@ -364,7 +365,7 @@ RP_API int rp_profile_kernel_time(rp_profile* h, const char* name, double* total
  * 2^cap_log2 table rows of 9 actions (144 B each) + one 32-byte key slot per row; batch = trees per step (0 = the
  * reference's 128).  2 players, stacks of 100 big blinds.  The batch is grown LEVEL-SYNCHRONOUSLY (all trees one level per
  * pair of launches, kernels sorted by node kind: robopoker_amd/csrc/nlmc_level.hpp) in 1 536 nodes of budget per tree
- * (92 B each; RP_ERR_CAPACITY when a batch needs more).  Sampling scheme: ExternalSampling (the mccfr! macro's default) until rp_nlhe_set_sampling selects
+ * (92 B each); a batch that needs more is traversed in several passes over contiguous ranges of its trees (same Decisions).  Sampling scheme: ExternalSampling (the mccfr! macro's default) until rp_nlhe_set_sampling selects
  * PrunableSampling / PluribusSampling (Flagship, nlhe/src/lib.rs:86-90; thresholds from `hp`).
  * Oracle: oracle/rp_oracle_nlmc.c. */
 typedef struct rp_nlhe rp_nlhe;

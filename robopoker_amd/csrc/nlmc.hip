@@ -384,6 +384,7 @@ struct rp_nlhe {
     uint64_t census[5] = {0, 0, 0, 0, 0};  // nodes by kind + walker children, summed over the profiled steps
     int expand_waves = 4;  // RP_NLHE_EXPAND_WAVES: 4 (128 VGPRs) or 5 (96 VGPRs, some spilled)
     int expand_threads = 256;  // RP_NLHE_EXPAND_THREADS: workgroup size of k_nl_expand (64 / 128 / 256)
+    uint32_t chunks = 1;  // passes per batch (RP_NLHE_CHUNKS; doubled when a pass runs out of nodes)
     uint32_t grid_cap = 16384;  // workgroups of the grid-stride kernels (RP_NLHE_GRID; measured: 1024 -14 %, 4096 -4 %)
 };
 
@@ -465,37 +466,44 @@ int nl_traverse_lanes(rp_nlhe* h) {
 }
 
 // ---- the level-synchronous traversal (nlmc_level.hpp)
-int nl_traverse_levels(rp_nlhe* h) {
+// the trees [lo, lo + B) of the batch, grown and evaluated together; their Decisions go behind the `d_base` already emitted.
+// *flags: the traversal's error flags when the return code is RP_ERR_CAPACITY (the caller retries a spent node budget in chunks)
+int nl_traverse_chunk(rp_nlhe* h, uint32_t lo, uint32_t B, uint32_t d_base, uint32_t* n_dec, uint32_t* n_nod, uint32_t* n_lev, uint32_t* flags) {
     hipStream_t st = rp::profile_stream(h->prof);
-    nl_begin_step(h);
     NlNodes& lv = h->lv;
-    const uint32_t B = h->batch;
+    NlParams prm = h->prm;
+    prm.batch = B;
+    prm.tree_base = h->prm.tree_base + lo;
+    *flags = 0;
     const dim3 wide(std::min<uint32_t>(h->grid_cap, std::max<uint32_t>(1u, (lv.ncap / 4u + 255u) / 256u))), blk(256);
     const dim3 wide_x(std::min<uint32_t>(h->grid_cap * 2u, std::max<uint32_t>(1u, (lv.ncap / 4u + NL_TILE - 1u) / NL_TILE)));  // one tile per workgroup
     HIP_TRY(hipMemsetAsync(lv.ctl, 0, sizeof(NlCtl), st));
     HIP_TRY(hipMemsetAsync(lv.t_nw, 0, (size_t)B * 4, st));
-    h->prm.tag = nl_next_tag(h);
-    hipLaunchKernelGGL(k_nl_roots, dim3((B + 255u) / 256u), blk, 0, st, h->prm, lv);
+    prm.tag = nl_next_tag(h);
+    hipLaunchKernelGGL(k_nl_roots, dim3((B + 255u) / 256u), blk, 0, st, prm, lv);
     NlCtl ctl;
     uint32_t L = 0;
     for (;;) {  // grow all trees one level per pair of launches; look at the frontier every few levels
         const uint32_t stop = std::min<uint32_t>(NL_MAXL - 1u, L + (L == 0 ? 22u : 6u));
         for (; L < stop; ++L) {
-            h->prm.tag = nl_next_tag(h);
+            prm.tag = nl_next_tag(h);
             nl_clock_begin(h, 0);
-            if (h->expand_threads == 64) hipLaunchKernelGGL((k_nl_expand<4, 64>), wide_x, dim3(64), 0, st, h->prm, h->tab, lv, L);
-            else if (h->expand_threads == 128) hipLaunchKernelGGL((k_nl_expand<4, 128>), wide_x, dim3(128), 0, st, h->prm, h->tab, lv, L);
-            else if (h->expand_waves == 5) hipLaunchKernelGGL((k_nl_expand<5, 256>), wide_x, blk, 0, st, h->prm, h->tab, lv, L);
-            else hipLaunchKernelGGL((k_nl_expand<4, 256>), wide_x, blk, 0, st, h->prm, h->tab, lv, L);
+            if (h->expand_threads == 64) hipLaunchKernelGGL((k_nl_expand<4, 64>), wide_x, dim3(64), 0, st, prm, h->tab, lv, L);
+            else if (h->expand_threads == 128) hipLaunchKernelGGL((k_nl_expand<4, 128>), wide_x, dim3(128), 0, st, prm, h->tab, lv, L);
+            else if (h->expand_waves == 5) hipLaunchKernelGGL((k_nl_expand<5, 256>), wide_x, blk, 0, st, prm, h->tab, lv, L);
+            else hipLaunchKernelGGL((k_nl_expand<4, 256>), wide_x, blk, 0, st, prm, h->tab, lv, L);
             nl_clock_end(h, 0);
             nl_clock_begin(h, 1);
-            hipLaunchKernelGGL(k_nl_children, wide, blk, 0, st, h->prm, lv, L);
+            hipLaunchKernelGGL(k_nl_children, wide, blk, 0, st, prm, lv, L);
             nl_clock_end(h, 1);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(&ctl, lv.ctl, sizeof(NlCtl), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (ctl.err) return nl_capacity_error(ctl.err);
+        if (ctl.err) {
+            *flags = ctl.err;
+            return nl_capacity_error(ctl.err);
+        }
         // level L = the children the last launch pair created; an empty level ends every tree
         const bool alive = ctl.lvl_node[L + 1] > ctl.lvl_node[L];
         if (!alive) break;
@@ -519,22 +527,63 @@ int nl_traverse_levels(rp_nlhe* h) {
     HIP_TRY(hipMemcpyAsync(total, h->d_total, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&ctl, lv.ctl, sizeof(NlCtl), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (ctl.err) return nl_capacity_error(ctl.err);
+    if (ctl.err) {
+        *flags = ctl.err;
+        return nl_capacity_error(ctl.err);
+    }
     if (h->profiling) {
         for (int k = 0; k < 4; ++k) h->census[k] += ctl.kinds[k];
         h->census[4] += ctl.walker_kids;
     }
-    if (total[0] > h->out_cap) return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %u Decisions in one batch exceed the buffer (%u)", total[0], h->out_cap);
-    if (total[1] > lv.lcap) return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %u walker nodes in one batch exceed the buffer (%u)", total[1], lv.lcap);
-    hipLaunchKernelGGL(k_nl_emit, wide, blk, 0, st, lv, h->tab, total[1], h->out_cap, h->out);
+    if ((uint64_t)d_base + total[0] > h->out_cap)
+        return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %llu Decisions in one batch exceed the buffer (%u)", (unsigned long long)d_base + total[0], h->out_cap);
+    if (total[1] > lv.lcap) {  // as many walker nodes as this is a spent node budget too
+        *flags = NERR_NODES;
+        return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %u walker nodes in one pass exceed the buffer (%u)", total[1], lv.lcap);
+    }
+    hipLaunchKernelGGL(k_nl_emit, wide, blk, 0, st, lv, h->tab, total[1], d_base, lo, h->out_cap, h->out);
     nl_clock_end(h, 3);
     HIP_TRY(hipGetLastError());
-    h->last_n = total[0];
-    h->nodes += n_nodes;
-    h->infos += total[0];
-    h->last_levels = levels;
-    h->last_nodes = n_nodes;
+    *n_dec = total[0];
+    *n_nod = n_nodes;
+    *n_lev = levels;
     return RP_OK;
+}
+// Solver::batch for the whole batch.  The node arrays hold 1 536 nodes per tree of the batch; trees grow with training, and when a
+// pass runs out of nodes the batch is traversed in twice as many passes from then on (same trees, same Decisions in the same
+// order: a pass is a contiguous range of tree ids) instead of failing the step.
+int nl_traverse_levels(rp_nlhe* h) {
+    nl_begin_step(h);
+    const uint32_t B = h->batch;
+    for (;;) {
+        const uint32_t K = std::min<uint32_t>(h->chunks, B);
+        uint32_t dec = 0, nodes = 0, levels = 0;
+        bool again = false;
+        for (uint32_t c = 0; c < K; ++c) {
+            const uint32_t lo = (uint32_t)((uint64_t)B * c / K), hi = (uint32_t)((uint64_t)B * (c + 1) / K);
+            if (hi == lo) continue;
+            uint32_t d = 0, nn = 0, nl = 0, flags = 0;
+            const int rc = nl_traverse_chunk(h, lo, hi - lo, dec, &d, &nn, &nl, &flags);
+            if (rc) {
+                if (flags == NERR_NODES && K < B && K < 4096u) {  // only the node budget: more, smaller passes
+                    h->chunks = K * 2u;
+                    again = true;
+                    break;
+                }
+                return rc;
+            }
+            dec += d;
+            nodes += nn;
+            levels = std::max(levels, nl);
+        }
+        if (again) continue;
+        h->last_n = dec;
+        h->nodes += nodes;
+        h->infos += dec;
+        h->last_levels = levels;
+        h->last_nodes = nodes;
+        return RP_OK;
+    }
 }
 int nl_traverse(rp_nlhe* h) { return h->lane_per_tree ? nl_traverse_lanes(h) : nl_traverse_levels(h); }
 }  // namespace
@@ -556,6 +605,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     if (getenv("RP_NLHE_GRID")) h->grid_cap = std::max(1, atoi(getenv("RP_NLHE_GRID")));
     if (getenv("RP_NLHE_EXPAND_WAVES")) h->expand_waves = atoi(getenv("RP_NLHE_EXPAND_WAVES"));
     if (getenv("RP_NLHE_EXPAND_THREADS")) h->expand_threads = atoi(getenv("RP_NLHE_EXPAND_THREADS"));
+    if (getenv("RP_NLHE_CHUNKS")) h->chunks = (uint32_t)std::max(1, atoi(getenv("RP_NLHE_CHUNKS")));
 #define NL_TRY(expr)                    \
     do {                                \
         int _rc = (expr);               \
@@ -574,7 +624,9 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     // opponent's average strategy calls and raises more than the warm-start bias: 760 per tree after a few steps on the trained
     // abstraction): 1 536 per tree of budget, 92 B each (the batch's total is what counts)
     const uint64_t dec_cap64 = std::max<uint64_t>((uint64_t)batch * 160u, 4096u);
-    const uint64_t ncap64 = std::max<uint64_t>((uint64_t)batch * 1536u, 1u << 17);
+    // RP_NLHE_NODE_BUDGET: nodes per tree of budget (tests of the chunked retry)
+    const uint64_t per_tree = getenv("RP_NLHE_NODE_BUDGET") ? (uint64_t)std::max(64, atoi(getenv("RP_NLHE_NODE_BUDGET"))) : 1536u;
+    const uint64_t ncap64 = getenv("RP_NLHE_NODE_BUDGET") ? (uint64_t)batch * per_tree : std::max<uint64_t>((uint64_t)batch * per_tree, 1u << 17);
     if (dec_cap64 >= (1ull << 31) || ncap64 >= (1ull << 32)) {
         delete h;
         return rp::fail(RP_ERR_INVALID, "rp_nlhe_create: batch too large (at most %u trees per step)", (uint32_t)((1ull << 32) / 1536u));

@@ -704,7 +704,8 @@ __global__ __launch_bounds__(64) void k_nl_group_big(NlNodes nd) {
 // slots of the walker-node array; the first t_dcount[tree] slots of a tree stand for its spans.  Slots and Decisions are both
 // numbered tree-major, so the active lanes of a wavefront own a CONTIGUOUS run of Decisions: the [n][9] regret / policy rows are
 // staged in LDS by active rank and stored as whole 64-lane lines instead of 18 stores of stride 36 B.
-__global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t n, uint32_t out_cap, NlBatch out) {
+__global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t n, uint32_t d_base, uint32_t tree_off, uint32_t out_cap,
+                                                 NlBatch out) {  // d_base / tree_off: this pass' first Decisions slot and first tree of the batch
     __shared__ float tile[4][2][64 * NLMC_A];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t padded = (n + 255u) & ~255u;
@@ -716,7 +717,7 @@ __global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t
             off = nd.t_woff[tr];
             g = j - off;
             if (g < nd.t_dcount[tr]) {
-                d = nd.t_doff[tr] + g;
+                d = d_base + nd.t_doff[tr] + g;
                 active = d < out_cap;  // beyond: the host has already refused the batch
             }
         }
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t
             out.nact[d] = (uint8_t)nch;
             out.expanded[d] = (uint16_t)expanded;
             out.payoff[d] = pay;
-            out.tree[d] = tr;
+            out.tree[d] = tr + tree_off;
         }
         const unsigned long long am = __ballot(active);
         if (am) {

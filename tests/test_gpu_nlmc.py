@@ -389,3 +389,34 @@ def test_trainer_loop_over_the_nlhe_solver(gpu):
     stop = ctypes.c_int(1)
     a.train("composed", interrupt=stop)
     assert a.epoch == 6
+
+
+def test_a_batch_traversed_in_several_passes_is_the_same_batch(gpu, monkeypatch):
+    # The node arrays hold 1 536 nodes per tree of the batch.  Trees grow with training; a pass that runs out of nodes makes the
+    # library traverse the batch in twice as many passes from then on (a pass = a contiguous range of tree ids) instead of failing
+    # the step.  Forced here two ways — RP_NLHE_CHUNKS=3 from the start, and a budget of 200 nodes per tree (below the average
+    # tree: the first step overflows and retries) — against a solver with room: every Decisions, in order, bit for bit; the
+    # counters; the tables after three steps.
+    room = NlheSolver(cap_log2=18, batch=300, seed=19)
+    monkeypatch.setenv("RP_NLHE_CHUNKS", "3")
+    three = NlheSolver(cap_log2=18, batch=300, seed=19)
+    monkeypatch.delenv("RP_NLHE_CHUNKS")
+    monkeypatch.setenv("RP_NLHE_NODE_BUDGET", "200")
+    tight = NlheSolver(cap_log2=18, batch=300, seed=19)
+    monkeypatch.delenv("RP_NLHE_NODE_BUDGET")
+    for step in range(3):
+        a = room.batch()
+        for other in (three, tight):
+            b = other.batch()
+            assert a["n"] == b["n"]
+            for f in ("tree", "past", "present", "choices", "n_actions", "expanded"):
+                assert np.array_equal(a[f], b[f]), (step, f)
+            for f in ("regret", "policy", "payoff"):
+                assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), (step, f)
+        for s in (room, three, tight):
+            s.step("ordered")
+        assert room.counters() == three.counters() == tight.counters()
+    am = M.as_map(*room.export())
+    for other in (three, tight):
+        bm = M.as_map(*other.export())
+        assert am.keys() == bm.keys() and all(am[k].tobytes() == bm[k].tobytes() for k in am)
