@@ -23,8 +23,9 @@
 //                                    with integer compares; terminals get their payoff here.  No atomics, no lists
 //   k_nl_up(L)      lane = node      D(node) = sum f(edge) D(child) in choices() order, subtree sizes     (L descending)
 //   k_nl_down(L)    lane = node      pre-order index of every child = the reference's creation index       (L ascending)
-//   k_nl_group      wave = tree      the tree's walker nodes sorted by (row, creation index) in LDS -> Tree::partition's spans,
-//                                    in the order of their first node
+//   k_nl_fill       lane = node      walker nodes bucketed by tree; the batch's node census
+//   k_nl_group(_big) wave = tree     the tree's walker nodes sorted by (row, creation index) in LDS -> Tree::partition's spans,
+//                                    in the order of their first node (trees with more than 256 walker nodes: a listed launch)
 //   k_nl_emit       lane = Decisions regret vector / policy / payoff of one walker infoset of one tree -> rp_decisions
 //
 // Node placement (which index a child block gets) depends on timing; nothing else does: a node's children are contiguous and in
@@ -32,7 +33,8 @@
 // state equals the oracle's and the float results equal the lane-per-tree kernel's bit for bit (tests/test_gpu_nlmc.py).
 //
 // HBM per node: 44 B of tree structure + 48 B of game state (SoA, coalesced by node index) instead of 260 KB of worst-case
-// scratch per tree: ~92 B x 768 nodes per tree of capacity.
+// scratch per tree: ~92 B x 1 536 nodes per tree of capacity (a batch whose trees outgrow it is traversed in several passes:
+// nlmc.hip nl_traverse_levels).
 #ifndef RP_NLMC_LEVEL_HPP
 #define RP_NLMC_LEVEL_HPP
 
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
         }
         __syncthreads();
         {
-            uint32_t pre = wsum[wave] + incl - mine;  // exclusive prefix of the thread's first item: < 2048 * 9, kept in bits 17..31
+            uint32_t pre = wsum[wave] + incl - mine;  // exclusive prefix of the thread's first item: < (NL_TILE + 192) * 9 < 2^15, kept in bits 17..31
 #pragma unroll
             for (uint32_t q = 0; q < CH; ++q) {
                 const uint32_t j = tid * CH + q;
