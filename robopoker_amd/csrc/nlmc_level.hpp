@@ -167,6 +167,8 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
     constexpr uint32_t R = NL_TILE / BT;           // classification sub-rounds
     constexpr uint32_t NW = BT / 64u;              // wavefronts of the workgroup
     constexpr uint32_t SCAP = NL_TILE + 192u;      // the sorted tile: three kinds, each from a multiple of 64
+    static_assert(SCAP * NLMC_A < (1u << 15), "a tile's children must fit the 15-bit prefix kept in s_info");
+    static_assert(NL_TILE % BT == 0 && BT % 64u == 0, "whole sub-rounds of whole wavefronts");
     __shared__ uint32_t sorted[SCAP];  // node index
     __shared__ uint32_t s_info[SCAP];  // n_kids | expanded mask << 4 | sampled slot << 13   (what the write phase needs)
     __shared__ uint32_t s_aux[SCAP];   // walker items: the infoset's row; opponent items: the bits of sigma / q of the sampled edge
