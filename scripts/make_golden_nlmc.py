@@ -16,12 +16,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_nlmc as M  # noqa: E402
 
 
-def case(batch, seed):
-    o = M.OracleNlhe(cap_log2=16, batch=batch, seed=seed)
+def case(batch, seed, sampling="external", hyper=None):
+    import oracle
+
+    hp = oracle.default_hyper()
+    for k, v in (hyper or {}).items():
+        setattr(hp, k, v)
+    o = M.OracleNlhe(cap_log2=16, batch=batch, seed=seed, sampling=sampling, hyper=hp)
     b = o.batch()
     n = b["n"]
     past, present, choices, _ = o.export()
-    out = dict(batch=batch, seed=seed, n=int(n), tree=b["tree"][:n].astype(np.uint32).tolist(),
+    out = dict(batch=batch, seed=seed, sampling=sampling, hyper=hyper or {}, n=int(n), tree=b["tree"][:n].astype(np.uint32).tolist(),
                n_actions=b["n_actions"][:n].astype(np.uint32).tolist(), expanded=b["expanded"][:n].astype(np.uint32).tolist(),
                policy_crc=zlib.crc32(np.ascontiguousarray(b["policy"][:n]).view(np.uint32).tobytes()),
                keys_after_batch=int(len(past)),
@@ -39,7 +44,12 @@ def case(batch, seed):
 
 
 if __name__ == "__main__":
-    doc = {"note": __doc__.split("\n")[0], "cases": [case(64, 5), case(150, 12)]}
+    # the pruned schemes bite on a FRESH table when the threshold sits above the warm-start bias of raises (10) and shoves (0):
+    # PrunableSampling drops them everywhere, PluribusSampling keeps those whose child is terminal and explores 30 % of the
+    # (infoset, tree) pairs — masks, tree shapes and keys from the very first batch (sample/pruning.rs:44-66, pluribus.rs:72-101)
+    bite = {"prune_warmup": 0, "prune_threshold": 20.0, "prune_explore": 0.3}
+    doc = {"note": __doc__.split("\n")[0],
+           "cases": [case(64, 5), case(150, 12), case(96, 7, "prunable", bite), case(96, 7, "pluribus", bite)]}
     path = os.path.join(ROOT, "tests", "golden", "nlmc.json")
     json.dump(doc, open(path, "w"))
     print(path, os.path.getsize(path), "bytes")

@@ -277,11 +277,20 @@ def _nlmc_table(eng):
 NLMC = json.load(open(os.path.join(GOLD, "nlmc.json")))["cases"] if os.path.exists(os.path.join(GOLD, "nlmc.json")) else []
 
 
-@pytest.mark.parametrize("case", NLMC, ids=lambda c: f"b{c['batch']}s{c['seed']}")
+def _nlmc_hyper(case):
+    import oracle
+
+    hp = oracle.default_hyper()
+    for k, v in case.get("hyper", {}).items():
+        setattr(hp, k, v)
+    return hp
+
+
+@pytest.mark.parametrize("case", NLMC, ids=lambda c: f"b{c['batch']}s{c['seed']}{c.get('sampling', '')}")
 def test_oracle_reproduces_nlmc_golden(case):
     import oracle_nlmc as M
 
-    o = M.OracleNlhe(cap_log2=16, batch=case["batch"], seed=case["seed"])
+    o = M.OracleNlhe(cap_log2=16, batch=case["batch"], seed=case["seed"], sampling=case.get("sampling", "external"), hyper=_nlmc_hyper(case))
     for k, v in _nlmc_summary(o, M).items():
         assert case[k] == v, k
     for _ in range(2):
@@ -292,7 +301,7 @@ def test_oracle_reproduces_nlmc_golden(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", NLMC[:1], ids=lambda c: f"b{c['batch']}s{c['seed']}")
+@pytest.mark.parametrize("case", NLMC[:1] + NLMC[2:], ids=lambda c: f"b{c['batch']}s{c['seed']}{c.get('sampling', '')}")
 def test_device_reproduces_nlmc_golden(gpu, case):
     # the first batch of the device equals the fixture in every integer and in the policy bits (the regret vectors carry the
     # stated tolerance and are not in the fixture; the steps after it depend on them through sampling, see test_gpu_nlmc.py)
@@ -300,7 +309,7 @@ def test_device_reproduces_nlmc_golden(gpu, case):
 
     from robopoker_amd.nlhe import NlheSolver
 
-    d = NlheSolver(cap_log2=16, batch=case["batch"], seed=case["seed"])
+    d = NlheSolver(cap_log2=16, batch=case["batch"], seed=case["seed"], sampling=case.get("sampling", "external"), hyper=_nlmc_hyper(case))
     for k, v in _nlmc_summary(d, M).items():
         assert case[k] == v, k
     d.close()
