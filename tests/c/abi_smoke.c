@@ -42,5 +42,22 @@ int main(void) {
     CHECK(rp_mccfr_destroy(solver));
     CHECK(rp_game_destroy(game));
     /* Kuhn's Nash has exploitability 0; the reference asserts < 0.005 after 2^18 epochs (kuhn/src/solver.rs tests) */
-    return expl < 0.02f && epoch == 256 ? 0 : 1;
+    if (!(expl < 0.02f && epoch == 256)) return 1;
+
+    /* the blueprint trainer: Flagship = Nlhe<LinearRegret, LinearWeight, PluribusSampling> (nlhe/src/lib.rs:86-90) driven by
+     * Trainer::train (forge/src/trainer.rs:18-66) for six steps of the reference's batch of 128 (nlhe/src/solver.rs:11) */
+    rp_nlhe* nl = NULL;
+    CHECK(rp_nlhe_create(0, 18, RP_REGRET_LINEAR, RP_WEIGHT_LINEAR, &hp, 11, 128, NULL, &nl));
+    CHECK(rp_nlhe_set_sampling(nl, RP_SAMPLING_PLURIBUS));
+    char summary[256];
+    CHECK(rp_nlhe_train(nl, RP_UPDATE_COMPOSED, 6, 0.0, 1e9, 1e9, NULL, NULL, NULL, summary, sizeof summary));
+    uint64_t nl_epoch = 0, nl_nodes = 0, nl_infos = 0, nl_keys = 0, n_rows = 0;
+    CHECK(rp_nlhe_epoch(nl, &nl_epoch));
+    CHECK(rp_nlhe_counters(nl, &nl_nodes, &nl_infos, &nl_keys));
+    CHECK(rp_nlhe_export(nl, 0, &n_rows, NULL, NULL, NULL, NULL)); /* how many infosets the blueprint holds */
+    printf("nlhe: epoch=%llu nodes=%llu infos=%llu infosets=%llu\n%s\n", (unsigned long long)nl_epoch, (unsigned long long)nl_nodes,
+           (unsigned long long)nl_infos, (unsigned long long)n_rows, summary);
+    CHECK(rp_nlhe_destroy(nl));
+    /* 6 x 128 trees of a few hundred nodes and a few dozen walker infosets each; every infoset of the table was inserted once */
+    return nl_epoch == 6 && nl_nodes > 6u * 128u * 100u && nl_infos > 6u * 128u * 10u && n_rows == nl_keys && n_rows > 1000 ? 0 : 1;
 }
