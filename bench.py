@@ -700,7 +700,8 @@ def nlhe_real(args, rank, world, local_rank):
         return {"infos": infos, "nodes": nodes, "dt": dt, "keys": keys, "prof": prof}
 
     big = run(args.nlhe_batch, args.steps, args.warmup, profile=True)
-    ref = run(128, max(args.steps, 20), 3)
+    # RP_BENCH_NO_REF=1 (profiling runs: scripts/r3_nlhe_traffic.sh): every dispatch of the process belongs to the big batch
+    ref = run(128, max(args.steps, 20), 3) if not os.environ.get("RP_BENCH_NO_REF") else {"infos": 0, "dt": 1.0}
     if rank != 0:
         dist.destroy_process_group()
         return
