@@ -27,6 +27,28 @@ def _build_once():
 _build_once()
 
 
+def _load_emulated():
+    """RP_EMUL=1 (a developer switch, tests only): the `-m gpu` tests call the kernels' SOURCES compiled against the wave64
+    execution model of tests/emul/ instead of the device library — a logic check for a machine without a GPU.  It replaces
+    the handle the ctypes binding hands out, for this pytest process only; the product never does this."""
+    import ctypes as C
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emul"))
+    import build as emul_build
+    from robopoker_amd import _lib
+
+    lib = C.CDLL(emul_build.build())
+    for name, (res, args) in _lib._SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib._lib = lib
+
+
+if os.environ.get("RP_EMUL") == "1":
+    _load_emulated()
+
+
 def has_gpu() -> bool:
     from robopoker_amd import _lib
 
