@@ -176,7 +176,13 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
     __shared__ uint32_t segbase[3], segcnt[3], wsum[NW], blockbase, tiletotal;
     NlCtl* ctl = nd.ctl;
     const uint32_t lo = ctl->lvl_node[level], hi = ctl->lvl_node[level + 1];
-    if (hi <= lo || ctl->err) return;  // an error anywhere ends the batch: the host fails the step
+    // An error anywhere ends the batch (the host fails the step).  The word can be raised by another workgroup of THIS launch
+    // (the node budget): ONE work-item reads it for the whole workgroup — were every work-item to look for itself, part of a
+    // workgroup could leave before the barriers below and the rest would sort a tile with holes (found by tests/emul)
+    __shared__ uint32_t s_stop;
+    if (threadIdx.x == 0) s_stop = ctl->err;
+    __syncthreads();
+    if (hi <= lo || s_stop) return;
     if (level + 1u >= NL_MAXL) {  // a tree deeper than the level table: the step fails (never observed; the rules bound the depth)
         if (threadIdx.x == 0) atomicOr(&ctl->err, NERR_LEVELS);
         return;

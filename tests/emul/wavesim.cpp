@@ -420,7 +420,34 @@ struct ihipStream_t {
 };
 
 extern "C" {
+// RP_EMUL_GUARD=1: every device allocation ends at an inaccessible page (and starts after one), so that a kernel reading or
+// writing past its buffer faults at the access — on the device such an access usually lands in a neighbouring allocation unseen
+namespace {
+struct Mapping {
+    void* base;
+    size_t len;
+};
+std::mutex g_map_mu;
+std::vector<std::pair<void*, Mapping>> g_maps;
+bool guard_mode() {
+    static const bool on = getenv("RP_EMUL_GUARD") != nullptr;
+    return on;
+}
+}  // namespace
 hipError_t emu_hipMalloc(void** p, size_t bytes) {
+    if (guard_mode()) {
+        const size_t page = 4096, body = (std::max<size_t>(bytes, 1) + 15) & ~(size_t)15, span = (body + page - 1) & ~(page - 1);
+        char* m = static_cast<char*>(mmap(nullptr, span + 2 * page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0));
+        if (m == MAP_FAILED) return hipErrorOutOfMemory;
+        mprotect(m, page, PROT_NONE);
+        mprotect(m + page + span, page, PROT_NONE);
+        char* q = m + page + (span - body);
+        if (body <= (size_t)1 << 30) memset(q, 0xA5, body);
+        std::lock_guard<std::mutex> lk(g_map_mu);
+        g_maps.push_back({q, Mapping{m, span + 2 * page}});
+        *p = q;
+        return hipSuccess;
+    }
     void* q = nullptr;
     const size_t n = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
     if (posix_memalign(&q, 256, n) != 0) return hipErrorOutOfMemory;
@@ -429,6 +456,18 @@ hipError_t emu_hipMalloc(void** p, size_t bytes) {
     return hipSuccess;
 }
 hipError_t hipFree(void* p) {
+    if (!p) return hipSuccess;
+    if (guard_mode()) {
+        std::lock_guard<std::mutex> lk(g_map_mu);
+        for (size_t i = 0; i < g_maps.size(); ++i)
+            if (g_maps[i].first == p) {
+                munmap(g_maps[i].second.base, g_maps[i].second.len);
+                g_maps[i] = g_maps.back();
+                g_maps.pop_back();
+                return hipSuccess;
+            }
+        return hipErrorInvalidValue;
+    }
     free(p);
     return hipSuccess;
 }
