@@ -1075,7 +1075,9 @@ __global__ __launch_bounds__(64) void k_pairwise(CentroidSet cs, uint32_t K, Met
     const uint32_t a = blockIdx.x / K, b = blockIdx.x % K;
     if (pver) {
         const uint32_t va = cver[a], vb = cver[b];
-        if (pver[2 * blockIdx.x] == va && pver[2 * blockIdx.x + 1] == vb) return;
+        // one decision for the wavefront, taken before lane 0 overwrites what it was taken from
+        const bool same = pver[2 * blockIdx.x] == va && pver[2 * blockIdx.x + 1] == vb;
+        if (__builtin_amdgcn_readfirstlane((uint32_t)same)) return;
         if (lane_id() == 0) {
             pver[2 * blockIdx.x] = va;
             pver[2 * blockIdx.x + 1] = vb;

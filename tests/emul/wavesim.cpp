@@ -66,6 +66,7 @@ struct Fiber {
 struct Worker {
     char* stacks = nullptr;  // MAX_THREADS stacks, mapped once per host thread
     Fiber fib[MAX_THREADS];
+    uint16_t order[MAX_THREADS];
     void* sched_sp = nullptr;
     Fiber* cur = nullptr;
     body_fn fn = nullptr;
@@ -176,10 +177,29 @@ void run_block(Worker& w, unsigned nthreads) {
         f.sp = sp;
     }
     const unsigned nwaves = (nthreads + 63) / 64;
+    // The order in which parked work-items are resumed.  The hardware interleaves the wavefronts of a workgroup freely; a fixed
+    // 0..n-1 order would hide a missing barrier (the producer always ran first).  RP_EMUL_ORDER=reverse | random (RP_EMUL_SEED)
+    {
+        static const int mode = [] {
+            const char* e = getenv("RP_EMUL_ORDER");
+            return !e ? 0 : (!strcmp(e, "reverse") ? 1 : (!strcmp(e, "random") ? 2 : 0));
+        }();
+        for (unsigned t = 0; t < nthreads; ++t) w.order[t] = (uint16_t)(mode == 1 ? nthreads - 1 - t : t);
+        if (mode == 2) {
+            static const uint64_t seed = getenv("RP_EMUL_SEED") ? strtoull(getenv("RP_EMUL_SEED"), nullptr, 10) : 1;
+            uint64_t x = seed * 0x9e3779b97f4a7c15ull + blockIdx.x * 0xbf58476d1ce4e5b9ull + blockIdx.y * 0x94d049bb133111ebull + 1;
+            for (unsigned t = nthreads; t > 1; --t) {
+                x ^= x << 13;
+                x ^= x >> 7;
+                x ^= x << 17;
+                std::swap(w.order[t - 1], w.order[x % t]);
+            }
+        }
+    }
     for (;;) {
         bool ran = false;
-        for (unsigned t = 0; t < nthreads; ++t) {
-            Fiber& f = w.fib[t];
+        for (unsigned o = 0; o < nthreads; ++o) {
+            Fiber& f = w.fib[w.order[o]];
             if (f.state != RUNNABLE) continue;
             ran = true;
             w.cur = &f;
@@ -429,6 +449,10 @@ struct Mapping {
 };
 std::mutex g_map_mu;
 std::vector<std::pair<void*, Mapping>> g_maps;
+int fill_byte() {  // RP_EMUL_FILL=0: fresh allocations read as zero (to tell a forgotten initialisation from another fault)
+    static const int v = getenv("RP_EMUL_FILL") ? atoi(getenv("RP_EMUL_FILL")) : 0xA5;
+    return v;
+}
 bool guard_mode() {
     static const bool on = getenv("RP_EMUL_GUARD") != nullptr;
     return on;
@@ -442,7 +466,7 @@ hipError_t emu_hipMalloc(void** p, size_t bytes) {
         mprotect(m, page, PROT_NONE);
         mprotect(m + page + span, page, PROT_NONE);
         char* q = m + page + (span - body);
-        if (body <= (size_t)1 << 30) memset(q, 0xA5, body);
+        if (body <= (size_t)1 << 30) memset(q, fill_byte(), body);
         std::lock_guard<std::mutex> lk(g_map_mu);
         g_maps.push_back({q, Mapping{m, span + 2 * page}});
         *p = q;
@@ -451,7 +475,7 @@ hipError_t emu_hipMalloc(void** p, size_t bytes) {
     void* q = nullptr;
     const size_t n = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
     if (posix_memalign(&q, 256, n) != 0) return hipErrorOutOfMemory;
-    if (n <= (size_t)1 << 30) memset(q, 0xA5, n);  // fresh device memory is not zero: make forgotten initialisation visible
+    if (n <= (size_t)1 << 30) memset(q, fill_byte(), n);  // fresh device memory is not zero: make forgotten initialisation visible
     *p = q;
     return hipSuccess;
 }

@@ -1,0 +1,61 @@
+"""The kernels' logic on a machine without a GPU: a short selection of the `-m gpu` parity tests, run through the wave64
+execution model of tests/emul/ (DESIGN.md §2b).  Test infrastructure checking test subjects — the product library is not
+involved, and nothing here is a measurement.
+
+The selection runs in a child pytest (RP_EMUL=1 swaps the handle of the ctypes binding for that process only): a few bit-exact
+comparisons with the oracle per kernel family, chosen to finish in about a minute after the ~40 s build."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = os.environ.get("RP_EMUL_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+
+SELECTION = [
+    # Path A, dense solver: ordered update, composed update, the skeleton-instantiated traversal, pruned sampling
+    ("tests/test_gpu_mccfr.py", "(test_tables_bit_exact_vs_oracle and (kuhn or rps)) or (composed_mode_matches_oracle_world_semantics and 777)"
+                                " or test_static_skeleton_traversal_equals_generic_and_oracle or test_hyper_parameter_corners_bit_exact"),
+    # the sparse profile: own radix sort / scan / run lengths, ordered and composed application
+    ("tests/test_gpu_sparse.py", "test_ordered_apply_bit_exact or test_composed_apply"),
+    # NLHE traversal: level-synchronous expansion against the oracle, pruned schemes, ragged batches, the chunked retry
+    ("tests/test_gpu_nlmc.py", "(test_first_batch_equals_the_oracle and 64) or test_pruned_sampling_schemes_equal_the_oracle"
+                               " or test_ragged_batches_equal_the_oracle or test_a_batch_traversed_in_several_passes"
+                               " or test_a_full_infoset_table_fails"),
+    # Path B: wave-cooperative Sinkhorn, Elkan iterations with remembered pairwise entries
+    ("tests/test_gpu_lloyd.py", "(test_sinkhorn_random_pairs_bit_exact and 32-5-9) or test_sinkhorn_fixture_bit_exact"
+                                " or (test_elkan_iterations_bit_exact and sinkhorn-5-150) or test_equity_variation_bit_exact"),
+]
+
+
+@pytest.fixture(scope="module")
+def emulated_library():
+    if not os.path.exists(CLANG):
+        pytest.skip(f"{CLANG} (host compiler of the execution model) is not installed")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emul"))
+    import build as emul_build
+
+    return emul_build.build(jobs=os.cpu_count() or 4)
+
+
+@pytest.mark.parametrize("module,expr", SELECTION, ids=[m.split("/")[-1][9:-3] for m, _ in SELECTION])
+def test_kernel_sources_under_the_wave64_model(emulated_library, module, expr):
+    env = dict(os.environ, RP_EMUL="1", RP_EMUL_GUARD="1", RP_EMUL_TRAP="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", module, "-m", "gpu", "-q", "-x", "-k", expr, "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and " failed" not in r.stdout, tail
+
+
+def test_the_emulated_library_exports_the_whole_abi(emulated_library):
+    import ctypes as C
+
+    from robopoker_amd import _lib
+
+    lib = C.CDLL(emulated_library)
+    missing = [n for n in _lib.declared_symbols() if not hasattr(lib, n)]
+    assert not missing
