@@ -7,6 +7,7 @@ there is no GPU; robopoker_amd/ never loads it.
 Two spellings of the sources are rewritten on the way in (the product sources are not touched):
   extern __shared__ ... T name[];   ->  T* name = the workgroup's dynamic LDS
   asm volatile("s_waitcnt ...")     ->  a host fence
+  comm.cpp's dlopen("librccl.so.1")  ->  tests/emul/fake_rccl.cpp's library
 """
 from __future__ import annotations
 
@@ -31,7 +32,12 @@ EXTERN_SHARED = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(
 ASM_WAIT = re.compile(r'asm\s+volatile\("s_waitcnt[^"]*"[^;]*;')
 
 
-def rewrite(text: str) -> str:
+def rewrite(text: str, name: str = "") -> str:
+    if name == "comm.cpp":  # the library's dlopen of RCCL: the stand-in of tests/emul/fake_rccl.cpp, by absolute path (torch has the
+        # real librccl.so.1 mapped already, and dlopen by soname would hand that one back)
+        names = '"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"'
+        assert names in text
+        text = text.replace(names, '"' + os.path.join(OUT, "rccl", "librp_emul_rccl.so") + '"')
     text = EXTERN_SHARED.sub(lambda m: f"{m.group(1)}* {m.group(2)} = reinterpret_cast<{m.group(1)}*>(::emu::dyn_smem());", text)
     text = ASM_WAIT.sub("__atomic_thread_fence(__ATOMIC_SEQ_CST);", text)
     return text
@@ -48,7 +54,7 @@ def stage_sources() -> list[str]:
         path = os.path.join(CSRC, name)
         if not os.path.isfile(path) or not name.endswith((".hip", ".hpp", ".cpp", ".h")):
             continue
-        new = rewrite(open(path).read())
+        new = rewrite(open(path).read(), name)
         dst = os.path.join(src_dir, name)
         if not os.path.exists(dst) or open(dst).read() != new:
             open(dst, "w").write(new)
@@ -102,7 +108,29 @@ def build(jobs: int = 8, only=None) -> str:
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-20000:])
         raise SystemExit("emul link failed")
+    build_fake_rccl()
     return LIB
+
+
+RCCL_DIR = os.path.join(OUT, "rccl")
+
+
+def build_fake_rccl() -> str:
+    """tests/emul/fake_rccl.cpp -> _build/rccl/librp_emul_rccl.so (ranks = processes of this host); the staged comm.cpp opens it"""
+    os.makedirs(RCCL_DIR, exist_ok=True)
+    src = os.path.join(HERE, "fake_rccl.cpp")
+    lib = os.path.join(RCCL_DIR, "librp_emul_rccl.so")
+    stamp = lib + ".sig"
+    sig = digest([src])
+    if os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read() == sig:
+        return lib
+    r = subprocess.run([CLANG, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-fvisibility=hidden", "-pthread", src, "-o", lib, "-lrt"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr[-8000:])
+        raise SystemExit("emul build failed: fake_rccl.cpp")
+    open(stamp, "w").write(sig)
+    return lib
 
 
 if __name__ == "__main__":
