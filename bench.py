@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--comm", default="native", choices=["native", "torch"],
                     help="N > 1: the library's own RCCL communicator driven from C (rp_mccfr_step_comm), or torch.distributed "
                          "collectives driven from Python")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the rank bookkeeping (unique-id broadcast, max-over-ranks time); nccl = RCCL "
+                         "on the GPUs; gloo only for tests/test_emul_bench.py, where the ranks have no GPU")
     ap.add_argument("--force-sharded", action="store_true",
                     help="exercise the RCCL all-gather path even with one rank (plumbing check)")
     return ap.parse_args()
@@ -206,7 +209,7 @@ def side_rate(args, g, local_rank, mode, steps=10):
     return (i1 - i0) / dt
 
 
-def init_rccl(rank, world):
+def init_rccl(rank, world, backend="nccl"):
     """init_process_group + communicator creation with fd 1 pointed at stderr: RCCL prints a version banner to stdout
     when the communicator is created, and stdout must carry exactly one JSON line."""
     import torch
@@ -218,7 +221,7 @@ def init_rccl(rank, world):
     saved = os.dup(1)
     os.dup2(2, 1)
     try:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
         warm = torch.zeros(1, device="cuda")
         dist.all_reduce(warm)
         torch.cuda.synchronize()
@@ -345,7 +348,7 @@ def nlhe_synth(args, rank, world, local_rank):
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.force_sharded
     if sharded:
-        init_rccl(rank, world)
+        init_rccl(rank, world, args.dist_backend)
     A = 9
     prof = SparseProfile(args.rows, A, "linear", "linear", max_batch=args.decisions * (world if sharded else 1), device=local_rank)
     host = [synthetic_batch(args.decisions, args.rows, A, seed=args.seed + 17 * rank + k) for k in range(4)]
@@ -655,7 +658,7 @@ def nlhe_real(args, rank, world, local_rank):
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        init_rccl(rank, world)
+        init_rccl(rank, world, args.dist_backend)
 
     def run(batch, steps, warmup, profile=False):
         s = NlheSolver(cap_log2=args.nlhe_cap, regret="linear", weight="linear", batch=batch, seed=args.seed, device=local_rank,
@@ -799,7 +802,7 @@ def main():
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        init_rccl(rank, world)
+        init_rccl(rank, world, args.dist_backend)
 
     g = Game(args.game)
     A = g.max_actions

@@ -71,3 +71,18 @@ def _cuda_means_host():
     torch.cuda.is_available = lambda: True
     torch.cuda.current_device = lambda: 0
     torch.cuda.device_count = lambda: 1
+
+    class _HostStream:  # torch.cuda.Stream(): the emulated library's streams are all the same synchronous one
+        cuda_stream = 0
+
+        def synchronize(self):
+            pass
+
+        def wait_stream(self, other):
+            pass
+
+    import contextlib
+
+    torch.cuda.Stream = _HostStream
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+    torch.cuda.current_stream = lambda *a, **k: _HostStream()

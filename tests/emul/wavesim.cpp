@@ -511,13 +511,13 @@ hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t) {
     if (n) memset(dst, v, n);
     return hipSuccess;
 }
-hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipSetDevice(int d) { return d >= 0 && d < 8 ? hipSuccess : hipErrorInvalidValue; }  // eight names for the same host memory
 hipError_t hipGetDevice(int* d) {
     *d = 0;
     return hipSuccess;
 }
 hipError_t hipGetDeviceCount(int* n) {
-    *n = 1;
+    *n = 8;
     return hipSuccess;
 }
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
