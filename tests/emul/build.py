@@ -102,12 +102,19 @@ def build(jobs: int = 8, only=None) -> str:
     objs = [os.path.join(OUT, os.path.basename(u) + ".o") for u in units]
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         list(ex.map(lambda so: compile_one(so[0], so[1], deps_sig), zip(units, objs)))
-    # plain __device__ functions defined in headers: one copy per device image in the product, identical copies here
-    cmd = [CLANG, "-shared", "-o", LIB, *objs, "-pthread", "-ldl", "-Wl,--allow-multiple-definition"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stderr[-20000:])
-        raise SystemExit("emul link failed")
+    link_sig = digest(objs)
+    link_stamp = LIB + ".sig"
+    if not (os.path.exists(LIB) and os.path.exists(link_stamp) and open(link_stamp).read() == link_sig) and not only:
+        # plain __device__ functions defined in headers: one copy per device image in the product, identical copies here.
+        # Linked under another name and renamed: a process that is loading the library never sees a half-written file.
+        tmp = LIB + f".{os.getpid()}.tmp"
+        cmd = [CLANG, "-shared", "-o", tmp, *objs, "-pthread", "-ldl", "-Wl,--allow-multiple-definition"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr[-20000:])
+            raise SystemExit("emul link failed")
+        os.replace(tmp, LIB)
+        open(link_stamp, "w").write(link_sig)
     build_fake_rccl()
     return LIB
 

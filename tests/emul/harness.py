@@ -12,11 +12,12 @@ if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
 
-def load_emulated(cuda_means_host: bool = True) -> str:
+def load_emulated(cuda_means_host: bool = True, build: bool = True) -> str:
+    """build=False: the library was built by the parent of this (rank) process; several ranks must not rebuild it at once"""
     import build as emul_build
     from robopoker_amd import _lib
 
-    path = emul_build.build(jobs=os.cpu_count() or 4)
+    path = emul_build.build(jobs=os.cpu_count() or 4) if build else emul_build.LIB
     lib = C.CDLL(path)
     for name, (res, args) in _lib._SIGNATURES.items():
         fn = getattr(lib, name)

@@ -22,7 +22,7 @@ RANK_MAIN = """
 import sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, {emul!r})
 import harness
-harness.load_emulated()
+harness.load_emulated(build=False)
 import bench
 sys.argv = ["bench.py"] + {argv!r}
 bench.main()

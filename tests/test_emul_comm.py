@@ -29,7 +29,7 @@ def _free_port():
     return p
 
 
-def _enter(rank, port):
+def _enter(rank, port, world=WORLD):
     """in a rank process: gloo (carries the communicator's id and the comparisons), then the emulated library"""
     for p in (ROOT, os.path.join(ROOT, "tests"), EMUL):
         if p not in sys.path:
@@ -38,10 +38,10 @@ def _enter(rank, port):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     import harness
 
-    harness.load_emulated()
+    harness.load_emulated(build=False)
     return dist
 
 
@@ -59,8 +59,8 @@ def _same_everywhere(dist, arr) -> bool:
     return bool(torch.equal(t, ref))
 
 
-def _mccfr_native(rank, port, out, window):
-    dist = _enter(rank, port)
+def _mccfr_native(rank, port, out, window, world):
+    dist = _enter(rank, port, world)
     import oracle
     from robopoker_amd import Game
     from robopoker_amd.mccfr import Solver
@@ -71,7 +71,7 @@ def _mccfr_native(rank, port, out, window):
     s = Solver(g, "linear", "linear", "external", batch=B, seed=33, device=0)
     s.set_update_mode("composed")
     comm = Comm.from_process_group(0)
-    s.set_shard(rank, WORLD)
+    s.set_shard(rank, world)
     s.step_comm(comm, steps, window)
     s.sync()
     rows = s.export()
@@ -82,7 +82,7 @@ def _mccfr_native(rank, port, out, window):
         left = steps
         while left:
             w = min(window, left)
-            single.window_world(WORLD, w)
+            single.window_world(world, w)
             left -= w
         exp = single.export()
         ok = all(np.array_equal(rows[f].view(np.uint32), exp[f].view(np.uint32)) for f in ("regret", "weight", "payoff", "visits"))
@@ -212,14 +212,14 @@ def rccl_dir():
     return emul_build.RCCL_DIR
 
 
-def _run(rccl_dir, fn, *args):
+def _run(rccl_dir, fn, *args, world=WORLD):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     saved = {k: os.environ.get(k) for k in ("RP_EMUL_THREADS",)}
-    os.environ["RP_EMUL_THREADS"] = "4"  # two ranks share the host's cores
+    os.environ["RP_EMUL_THREADS"] = str(max(1, 8 // world))  # the ranks share the host's cores
     try:
-        procs = [ctx.Process(target=_guarded, args=(fn, r, port, q) + args) for r in range(WORLD)]
+        procs = [ctx.Process(target=_guarded, args=(fn, r, port, q) + args) for r in range(world)]
         for p in procs:
             p.start()
     finally:
@@ -228,7 +228,7 @@ def _run(rccl_dir, fn, *args):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    results = dict(q.get(timeout=600) for _ in range(WORLD))
+    results = dict(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
     assert not [k for k in results if k.startswith("error")], results
@@ -236,9 +236,10 @@ def _run(rccl_dir, fn, *args):
     return results
 
 
-@pytest.mark.parametrize("window", [1, 3])
-def test_native_sharded_mccfr_two_ranks_equals_the_world_model(rccl_dir, window):
-    assert _run(rccl_dir, _mccfr_native, window) == {"mccfr-0": True, "mccfr-1": True}
+@pytest.mark.parametrize("world,window", [(2, 1), (2, 3), (8, 1), (8, 3)])
+def test_native_sharded_mccfr_equals_the_world_model(rccl_dir, world, window):
+    # eight ranks: the node the scaling run uses
+    assert _run(rccl_dir, _mccfr_native, window, world, world=world) == {f"mccfr-{r}": True for r in range(world)}
 
 
 @pytest.mark.parametrize("sampling", ["external", "pluribus"])
