@@ -46,8 +46,9 @@ RP_HD uint32_t rp_f2u(float f) {
     memcpy(&u, &f, 4);
     return u;
 }
-/* f32::max / f32::min for non-NaN inputs (NaN never occurs on the hot path: the reference
- * debug_asserts it, flow.rs:81-82), specified as IEEE 754-2019 maximum / minimum: +0 is greater
+/* f32::max / f32::min: a NaN operand yields the other operand (NaN never occurs on the hot path: the reference
+ * debug_asserts it, flow.rs:81-82; it does in a degenerate layer whose empty clusters have 0/0 densities); otherwise
+ * IEEE 754-2019 maximum / minimum: +0 is greater
  * than -0.  On gfx950 this is exactly one v_max_f32 / v_min_f32 (CDNA ISA: max(+0,-0) = +0,
  * min(+0,-0) = -0); the host spells the same function with compares. */
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -55,10 +56,14 @@ RP_HD float rp_maxf(float a, float b) { return __builtin_fmaxf(a, b); }
 RP_HD float rp_minf(float a, float b) { return __builtin_fminf(a, b); }
 #else
 RP_HD float rp_maxf(float a, float b) {
+    if (a != a) return b; /* f32::max / v_max_f32: a NaN operand yields the other one (a degenerate layer's empty cluster) */
+    if (b != b) return a;
     if (a == b) return (rp_f2u(a) & 0x80000000u) ? b : a; /* equal: prefer the one without a sign bit */
     return a > b ? a : b;
 }
 RP_HD float rp_minf(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
     if (a == b) return (rp_f2u(a) & 0x80000000u) ? a : b; /* equal: prefer the one with a sign bit */
     return a < b ? a : b;
 }

@@ -116,6 +116,28 @@ def test_elkan_iterations_bit_exact(gpu, kind, K, N, bins, mass):
     assert bits(dev.rms()) == bits(ora.rms())
 
 
+@pytest.mark.parametrize("kind,K,N,bins,mass", [("sinkhorn", 1, 5, 2, 3), ("sinkhorn", 2, 2, 5, 4), ("sinkhorn", 65, 130, 33, 7),
+                                                ("sinkhorn", 2, 1000, 64, 47), ("variation", 1, 5, 7, 3), ("variation", 64, 64, 7, 3),
+                                                ("variation", 65, 130, 2, 5), ("variation", 2, 2, 101, 46)])
+def test_layer_shape_corners_bit_exact(gpu, kind, K, N, bins, mass):
+    # one cluster, as many clusters as points, more clusters than DISTINCT points (empty clusters: 0/0 densities, NaN distances
+    # that f32::max skips when the metric is normalised, metric.rs:127-141), two bins, a bin count that is no multiple of four,
+    # 65 clusters (one past a wavefront of lower bounds): picks, bounds, drift, sizes, lookup and metric against the oracle
+    dev, ora = _pair(kind, K, N, bins, mass, seed=K + N, iters=10)
+    assert np.array_equal(dev.init_centroids(), ora.init_centroids())
+    dev.init_bounds()
+    ora.init_bounds()
+    for _ in range(2):
+        d1, s1, m1 = dev.step()
+        d2, s2, m2 = ora.step()
+        assert np.array_equal(bits(d1), bits(d2)) and np.array_equal(s1, s2) and m1 == m2
+        _check_state(dev, ora)
+    b1, dd1 = dev.lookup()
+    b2, dd2 = ora.assign()
+    assert np.array_equal(b1, b2) and np.array_equal(bits(dd1), bits(dd2))
+    assert np.array_equal(bits(dev.metric()), bits(ora.metric()))
+
+
 def test_elkan_equals_naive_on_device(gpu):
     # crates/lloyd/src/tests.rs:148-161 (variation layer, K=8, N=2048, 8 iterations) on the GPU
     pts = turn_like_points(2048, bins=101, mass=46, seed=1)

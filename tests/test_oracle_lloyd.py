@@ -252,3 +252,26 @@ def test_point_parallel_kmeans_equals_the_sequential_oracle():
     assert all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(b1, b2))
     assert all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(d1, d2))
     assert np.array_equal(a1[0], a2[0]) and np.array_equal(a1[1].view(np.uint32), a2[1].view(np.uint32))
+
+
+def test_metric_of_a_degenerate_layer_normalises_like_f32_max():
+    # Metric::from(BTreeMap) folds the maximum with f32::max (metric.rs:127-141), which returns the other operand when one is
+    # NaN.  A layer with more clusters than distinct points has empty clusters whose densities are 0/0: every distance to
+    # them is NaN, the others must still come out normalised by the largest finite one (found by the edge sweep under
+    # tests/emul: the restatement's maximum used to let a NaN through and turned the whole metric into NaN)
+    K, N, bins, mass, seed = 64, 64, 7, 3, 134
+    pts = turn_like_points(N, bins=bins, mass=mass, seed=seed)
+    km = oracle.OracleKmeans(K, pts, "variation", None, seed=seed)
+    km.init_centroids()
+    km.init_bounds()
+    km.step()
+    _, weight = km.centroids()
+    empty = np.asarray(weight) == 0
+    assert empty.any() and not empty.all()
+    tri = np.asarray(km.metric())
+    pairs = [(i, j) for i in range(K) for j in range(i)]  # Pair order: (hi, lo), index hi(hi-1)/2 + lo
+    idx = {p: p[0] * (p[0] - 1) // 2 + p[1] for p in pairs}
+    for (i, j), t in idx.items():
+        assert np.isnan(tri[t]) == bool(empty[i] or empty[j]), (i, j)
+    finite = tri[~np.isnan(tri)]
+    assert finite.size and finite.max() == 1.0 and finite.min() >= 0.0
