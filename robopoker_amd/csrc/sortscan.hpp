@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 namespace rp {
 namespace ss {
@@ -335,16 +336,96 @@ static __global__ __launch_bounds__(256) void k_rle_counts(const uint32_t* start
     const uint32_t g = blockIdx.x * 256u + threadIdx.x, runs = *n_runs;
     if (g < runs) counts[g] = (g + 1u < runs ? starts[g + 1u] : n) - starts[g];
 }
-// sorted keys -> uniq[r], starts[r] (= the exclusive scan of counts), counts[r] for r < *n_runs; work = n words of scratch
+// ---- the same, with the head flags inside the scan (no flag array, no separate heads / write launches) ----------------
+// a thread's four consecutive keys and which of them start a run
+__device__ __forceinline__ uint32_t rle_heads4(const uint32_t* keys, uint32_t n, uint32_t base, uint32_t (&key)[4], bool (&head)[4]) {
+    uint32_t prev = base > 0u && base - 1u < n ? keys[base - 1u] : 0u, heads = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t i = base + k;
+        key[k] = i < n ? keys[i] : 0u;
+        head[k] = i < n && (i == 0u || key[k] != prev);
+        heads += head[k] ? 1u : 0u;
+        prev = key[k];
+    }
+    return heads;
+}
+static __global__ __launch_bounds__(256) void k_rle_sums(const uint32_t* keys, uint32_t n, uint64_t* sums) {
+    __shared__ uint64_t wt[4];
+    uint32_t key[4];
+    bool head[4];
+    const uint64_t s = rle_heads4(keys, n, blockIdx.x * SCAN_TILE + threadIdx.x * 4u, key, head);
+    uint64_t tot;
+    (void)block_exscan64(s, wt, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+// bases = the exclusive scan of the tile sums; a head writes its key and its start at its rank
+static __global__ __launch_bounds__(256) void k_rle_tiles(const uint32_t* keys, uint32_t n, const uint64_t* bases, uint32_t* uniq, uint32_t* starts,
+                                                          uint32_t* n_runs) {
+    __shared__ uint64_t wt[4];
+    uint32_t key[4];
+    bool head[4];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 4u;
+    const uint64_t s = rle_heads4(keys, n, base, key, head);
+    uint64_t tot;
+    uint32_t run = (uint32_t)(bases[blockIdx.x] + block_exscan64(s, wt, &tot));
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k)
+        if (head[k]) {
+            uniq[run] = key[k];
+            starts[run] = base + k;
+            run += 1u;
+        }
+    if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 255u) *n_runs = run;  // the last thread ends at the number of runs
+}
+// at most SCAN_ONE keys: one workgroup does all of it, counts included, in one launch
+static __global__ __launch_bounds__(256) void k_rle_one(const uint32_t* keys, uint32_t n, uint32_t* uniq, uint32_t* starts, uint32_t* counts,
+                                                        uint32_t* n_runs) {
+    __shared__ uint64_t wt[4];
+    const uint32_t per = (n + 255u) / 256u, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    uint64_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += (i == 0u || keys[i] != keys[i - 1u]) ? 1u : 0u;
+    uint64_t tot;
+    uint32_t run = (uint32_t)block_exscan64(s, wt, &tot);
+    for (uint32_t i = lo; i < hi; ++i)
+        if (i == 0u || keys[i] != keys[i - 1u]) {
+            uniq[run] = keys[i];
+            starts[run] = i;
+            run += 1u;
+        }
+    if (threadIdx.x == 0) *n_runs = (uint32_t)tot;
+    if (!counts) return;
+    __syncthreads();  // every start of the workgroup is written
+    const uint32_t runs = (uint32_t)tot;
+    for (uint32_t g = threadIdx.x; g < runs; g += 256u) counts[g] = (g + 1u < runs ? starts[g + 1u] : n) - starts[g];
+}
+
+// sorted keys -> uniq[r], starts[r] (= the exclusive scan of counts), counts[r] for r < *n_runs; work = n words of scratch.
+// counts may be NULL (a caller that derives them itself).  Three launches (one for at most SCAN_ONE keys) + one for the counts;
+// RP_SS_RLE_V1=1 keeps the first version (flag array: heads, scan, write, counts).
 inline hipError_t run_length_encode(const uint32_t* keys, uint32_t n, uint32_t* uniq, uint32_t* starts, uint32_t* counts, uint32_t* n_runs,
                                     uint32_t* work, void* scan_tmp, hipStream_t st) {
     if (n == 0) return hipMemsetAsync(n_runs, 0, 4, st);
     const dim3 grid((n + 255u) / 256u), block(256);
+    static const bool v1 = getenv("RP_SS_RLE_V1") != nullptr;
+    const uint32_t tiles = (n + SCAN_TILE - 1u) / SCAN_TILE;
+    if (!v1 && n <= SCAN_ONE) {
+        hipLaunchKernelGGL(k_rle_one, dim3(1), block, 0, st, keys, n, uniq, starts, counts, n_runs);
+        return hipGetLastError();
+    }
+    if (!v1 && tiles <= SCAN_ONE) {
+        uint64_t* sums = reinterpret_cast<uint64_t*>(scan_tmp);  // scan_scratch_bytes(n) holds the tile sums
+        hipLaunchKernelGGL(k_rle_sums, dim3(tiles), block, 0, st, keys, n, sums);
+        hipLaunchKernelGGL(k_scan_one64, dim3(1), block, 0, st, sums, tiles);
+        hipLaunchKernelGGL(k_rle_tiles, dim3(tiles), block, 0, st, keys, n, sums, uniq, starts, n_runs);
+        if (counts) hipLaunchKernelGGL(k_rle_counts, grid, block, 0, st, starts, n_runs, n, counts);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_rle_heads, grid, block, 0, st, keys, n, work);
     hipError_t e = exclusive_scan<uint32_t>(work, work, n, scan_tmp, st, n_runs);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_rle_write, grid, block, 0, st, keys, work, n, uniq, starts);
-    hipLaunchKernelGGL(k_rle_counts, grid, block, 0, st, starts, n_runs, n, counts);
+    if (counts) hipLaunchKernelGGL(k_rle_counts, grid, block, 0, st, starts, n_runs, n, counts);
     return hipGetLastError();
 }
 

@@ -352,6 +352,80 @@ __global__ void k_block_index(const uint32_t* nblk, const uint32_t* boff, const 
     for (uint32_t k = 0; k < nb; ++k) blkseg[base + k] = g;
 }
 
+// The same three steps (touches per row -> blocks per row -> first block of every row -> block -> row index) inside ONE tiled scan:
+// its tile-sum kernel derives the counts from the run starts and zeroes the hot-row counter on the way, its tile kernel writes the
+// index.  Three launches instead of six (the counts of the run-length encoding, block counts, a three-launch scan, the index, the
+// counter's memset); one launch and one workgroup when the batch has at most ss::SCAN_ONE Decisions.
+__device__ __forceinline__ uint32_t blk_of_row(const uint32_t* starts, uint32_t runs, uint32_t n, uint32_t g, uint32_t* count) {
+    const uint32_t cnt = g < runs ? (g + 1u < runs ? starts[g + 1u] : n) - starts[g] : 0u;
+    *count = cnt;
+    return (cnt + RP_SPARSE_BLOCK - 1u) / RP_SPARSE_BLOCK;
+}
+__global__ __launch_bounds__(256) void k_blk_sums(const uint32_t* starts, const uint32_t* n_segs, uint32_t n, uint32_t* counts, uint32_t* nblk,
+                                                  uint64_t* sums, uint32_t* hot_counter) {
+    __shared__ uint64_t wt[4];
+    const uint32_t runs = *n_segs, base = blockIdx.x * ss::SCAN_TILE + threadIdx.x * 4u;
+    uint64_t s = 0;
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t g = base + k;
+        if (g >= n) break;
+        uint32_t cnt;
+        const uint32_t nb = blk_of_row(starts, runs, n, g, &cnt);
+        if (g < runs) counts[g] = cnt;
+        nblk[g] = nb;
+        s += nb;
+    }
+    uint64_t tot;
+    (void)ss::block_exscan64(s, wt, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *hot_counter = 0;
+}
+__global__ __launch_bounds__(256) void k_blk_tiles(const uint32_t* nblk, const uint32_t* n_segs, uint32_t n, const uint64_t* bases, uint32_t* boff,
+                                                   uint32_t* blkseg) {
+    __shared__ uint64_t wt[4];
+    const uint32_t runs = *n_segs, base = blockIdx.x * ss::SCAN_TILE + threadIdx.x * 4u;
+    uint32_t v[4];
+    uint64_t s = 0;
+    for (uint32_t k = 0; k < 4u; ++k) {
+        v[k] = base + k < n ? nblk[base + k] : 0u;
+        s += v[k];
+    }
+    uint64_t tot;
+    uint32_t run = (uint32_t)(bases[blockIdx.x] + ss::block_exscan64(s, wt, &tot));
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t g = base + k;
+        if (g >= n) break;
+        boff[g] = run;
+        if (g < runs)
+            for (uint32_t b = 0; b < v[k]; ++b) blkseg[run + b] = g;
+        run += v[k];
+    }
+}
+__global__ __launch_bounds__(256) void k_blk_one(const uint32_t* starts, const uint32_t* n_segs, uint32_t n, uint32_t* counts, uint32_t* nblk,
+                                                 uint32_t* boff, uint32_t* blkseg, uint32_t* hot_counter) {
+    __shared__ uint64_t wt[4];
+    const uint32_t runs = *n_segs, per = (n + 255u) / 256u, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    uint64_t s = 0;
+    for (uint32_t g = lo; g < hi; ++g) {
+        uint32_t cnt;
+        const uint32_t nb = blk_of_row(starts, runs, n, g, &cnt);
+        if (g < runs) counts[g] = cnt;
+        nblk[g] = nb;
+        s += nb;
+    }
+    uint64_t tot;
+    uint32_t run = (uint32_t)ss::block_exscan64(s, wt, &tot);
+    for (uint32_t g = lo; g < hi; ++g) {
+        uint32_t cnt;
+        const uint32_t nb = blk_of_row(starts, runs, n, g, &cnt);
+        boff[g] = run;
+        if (g < runs)
+            for (uint32_t b = 0; b < nb; ++b) blkseg[run + b] = g;
+        run += nb;
+    }
+    if (threadIdx.x == 0) *hot_counter = 0;
+}
+
 template <bool GATHER>  // true: the touches are read from the unsorted batch through sg.perm (no sorted copy exists)
 __global__ __launch_bounds__(256) void k_block_maps_sparse(SparseParams p, DevBatch b, Segments sg, const uint32_t* nblk,
                                                            const uint32_t* boff, const uint32_t* blkseg, SortedBatch sb,
@@ -634,6 +708,7 @@ struct rp_profile {
     uint32_t max_batch = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
+    bool fused_blocks = true;  // rows -> blocks inside one tiled scan (RP_SPARSE_V1=1: block counts, scan, index and memset as separate launches)
     bool gather_maps = true;  // composed update: block maps read the touches through the sort permutation (RP_SPARSE_PERMUTE=1: via a sorted copy)
     float* tab = nullptr;
     // sort / segment workspace (capacity `cap` items)
@@ -743,7 +818,7 @@ static uint32_t key_bits(uint64_t n_rows) {
 }
 
 // rows[n] (device) -> perm (stable by row), distinct rows, counts, offsets, n_segs
-static int sort_and_segment(rp_profile* h, const uint32_t* rows, uint32_t n) {
+static int sort_and_segment(rp_profile* h, const uint32_t* rows, uint32_t n, bool counts_later = false) {
     int rc = ensure_capacity(h, n);
     if (rc) return rc;
     unsigned char* sp = reinterpret_cast<unsigned char*>(h->sort_tmp);
@@ -752,8 +827,9 @@ static int sort_and_segment(rp_profile* h, const uint32_t* rows, uint32_t n) {
     void* scan_tmp = sp;
     sp += (ss::scan_scratch_bytes(h->cap) + 255) & ~(size_t)255;
     // seg_offsets = the start of every run = the exclusive scan of the run lengths
-    HIP_TRY(ss::run_length_encode(h->keys_out, n, h->seg_rows, h->seg_offsets, h->seg_counts, h->n_segs, reinterpret_cast<uint32_t*>(sp),
-                                  scan_tmp, h->stream));
+    // counts_later: the caller is launch_summarize, whose block scan derives the counts from the starts on its way
+    HIP_TRY(ss::run_length_encode(h->keys_out, n, h->seg_rows, h->seg_offsets, counts_later && h->fused_blocks ? nullptr : h->seg_counts, h->n_segs,
+                                  reinterpret_cast<uint32_t*>(sp), scan_tmp, h->stream));
     return RP_OK;
 }
 
@@ -794,11 +870,24 @@ static uint32_t group_blocks(uint32_t n) { return std::max(1u, std::min((n * GRO
 static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch& b, const Segments& sg, uint32_t n,
                             unsigned char* entries) {
     const uint32_t eb = (uint32_t)entry_bytes_of(h);
-    hipLaunchKernelGGL(k_block_counts, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->seg_counts, h->n_segs, n, h->nblk);
-    HIP_TRY(ss::exclusive_scan<uint32_t>(h->nblk, h->boff, n, reinterpret_cast<unsigned char*>(h->sort_tmp) + ss::sort_scratch_bytes(h->cap),
-                                         h->stream));
     const uint32_t mb = max_blocks_of(n);
-    hipLaunchKernelGGL(k_block_index, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->nblk, h->boff, h->n_segs, h->blkseg);
+    void* scan_tmp = reinterpret_cast<unsigned char*>(h->sort_tmp) + ss::sort_scratch_bytes(h->cap);
+    const uint32_t tiles = (n + ss::SCAN_TILE - 1u) / ss::SCAN_TILE;
+    if (h->fused_blocks && n <= ss::SCAN_ONE) {
+        hipLaunchKernelGGL(k_blk_one, dim3(1), dim3(256), 0, h->stream, h->seg_offsets, h->n_segs, n, h->seg_counts, h->nblk, h->boff, h->blkseg,
+                           h->hot + HOT_CAP);
+    } else if (h->fused_blocks && tiles <= ss::SCAN_ONE) {
+        uint64_t* sums = reinterpret_cast<uint64_t*>(scan_tmp);
+        hipLaunchKernelGGL(k_blk_sums, dim3(tiles), dim3(256), 0, h->stream, h->seg_offsets, h->n_segs, n, h->seg_counts, h->nblk, sums,
+                           h->hot + HOT_CAP);
+        hipLaunchKernelGGL(ss::k_scan_one64, dim3(1), dim3(256), 0, h->stream, sums, tiles);
+        hipLaunchKernelGGL(k_blk_tiles, dim3(tiles), dim3(256), 0, h->stream, h->nblk, h->n_segs, n, sums, h->boff, h->blkseg);
+    } else {
+        hipLaunchKernelGGL(k_block_counts, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->seg_counts, h->n_segs, n, h->nblk);
+        HIP_TRY(ss::exclusive_scan<uint32_t>(h->nblk, h->boff, n, scan_tmp, h->stream));
+        hipLaunchKernelGGL(k_block_index, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->nblk, h->boff, h->n_segs, h->blkseg);
+        HIP_TRY(hipMemsetAsync(h->hot + HOT_CAP, 0, 4, h->stream));
+    }
     const SortedBatch sb{h->srt_regret, h->srt_policy, h->srt_payoff, h->srt_expanded};
     if (h->gather_maps) {
         hipLaunchKernelGGL(k_block_maps_sparse<true>, dim3(group_blocks(mb)), dim3(256), 0, h->stream, p, b, sg, h->nblk, h->boff, h->blkseg,
@@ -808,7 +897,6 @@ static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch
         hipLaunchKernelGGL(k_block_maps_sparse<false>, dim3(group_blocks(mb)), dim3(256), 0, h->stream, p, b, sg, h->nblk, h->boff, h->blkseg,
                            sb, entries, h->blocks, eb, mb);
     }
-    HIP_TRY(hipMemsetAsync(h->hot + HOT_CAP, 0, 4, h->stream));
     hipLaunchKernelGGL(k_seg_fold, dim3(group_blocks(n)), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb,
                        h->hot, h->hot + HOT_CAP, (uint32_t)HOT_CAP);
     hipLaunchKernelGGL(k_hot_fold, dim3(64), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb, h->hot,
@@ -839,6 +927,7 @@ int rp_profile_create(int device, uint64_t n_rows, uint32_t max_actions, rp_regr
     if (hp) h->hp = *hp; else rp_hyper_default(&h->hp);
     h->max_batch = max_batch;
     h->gather_maps = getenv("RP_SPARSE_PERMUTE") == nullptr;
+    h->fused_blocks = getenv("RP_SPARSE_V1") == nullptr;
 #define PF_TRY(expr)                                                                              \
     do {                                                                                          \
         hipError_t _e = (expr);                                                                   \
@@ -900,7 +989,7 @@ int rp_profile_apply(rp_profile* h, const rp_decisions* batch, rp_update_mode mo
     if (batch->n) {
         const DevBatch b{batch->row, batch->n_actions, batch->expanded, batch->regret, batch->policy, batch->payoff};
         sp_begin(h, h->clk_sort);
-        if ((rc = sort_and_segment(h, batch->row, batch->n))) return rc;
+        if ((rc = sort_and_segment(h, batch->row, batch->n, mode == RP_UPDATE_COMPOSED))) return rc;
         sp_end(h, h->clk_sort);
         const Segments sg{h->seg_rows, h->seg_counts, h->seg_offsets, h->n_segs, h->perm};
         sp_begin(h, h->clk_apply);
@@ -1021,7 +1110,7 @@ int rp_profile_summarize(rp_profile* h, const rp_decisions* batch, void* entries
     if (batch->n == 0) return RP_OK;
     const DevBatch b{batch->row, batch->n_actions, batch->expanded, batch->regret, batch->policy, batch->payoff};
     sp_begin(h, h->clk_sort);
-    if ((rc = sort_and_segment(h, batch->row, batch->n))) return rc;
+    if ((rc = sort_and_segment(h, batch->row, batch->n, true))) return rc;
     sp_end(h, h->clk_sort);
     const Segments sg{h->seg_rows, h->seg_counts, h->seg_offsets, h->n_segs, h->perm};
     sp_begin(h, h->clk_apply);
