@@ -828,7 +828,8 @@ static int sort_and_segment(rp_profile* h, const uint32_t* rows, uint32_t n, boo
     sp += (ss::scan_scratch_bytes(h->cap) + 255) & ~(size_t)255;
     // seg_offsets = the start of every run = the exclusive scan of the run lengths
     // counts_later: the caller is launch_summarize, whose block scan derives the counts from the starts on its way
-    HIP_TRY(ss::run_length_encode(h->keys_out, n, h->seg_rows, h->seg_offsets, counts_later && h->fused_blocks ? nullptr : h->seg_counts, h->n_segs,
+    const bool derived = counts_later && h->fused_blocks && (n + ss::SCAN_TILE - 1u) / ss::SCAN_TILE <= ss::SCAN_ONE;  // launch_summarize's condition
+    HIP_TRY(ss::run_length_encode(h->keys_out, n, h->seg_rows, h->seg_offsets, derived ? nullptr : h->seg_counts, h->n_segs,
                                   reinterpret_cast<uint32_t*>(sp), scan_tmp, h->stream));
     return RP_OK;
 }
