@@ -1,0 +1,40 @@
+#!/bin/bash
+# The first GPU call of a round, in one piece (run through gpurun from the repo root, `--timeout 1500`):
+#   1 the whole -m gpu suite                                   -> gpurun_out/rs/gpu_tests.log
+#   2 the driver's default bench line                          -> gpurun_out/rs/<tag>_bench_line.json
+#   3 the NLHE workload's line (both batches)                  -> gpurun_out/rs/<tag>_nlhe_bench_line.json
+#   4 kernel-trace statistics of both timed loops              -> gpurun_out/rs/<tag>_bench_kernel_stats.txt, <tag>_nlhe_kernel_stats_*.txt
+#   5 PMC HBM traffic of the NLHE level kernels                -> gpurun_out/rs/<tag>_nlhe_hbm_traffic.json
+# Every step has its own `timeout` (a counter pass that hung once ate 40 GPU-minutes) and writes what it has as it goes; the
+# judged copies are committed under profiles/ by hand afterwards.  About 12 GPU-minutes.
+set -u
+TAG=${1:-r04}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/rs
+mkdir -p $OUT
+cd $REPO
+echo "== 1 gpu tests"; date +%T
+timeout 600 python -m pytest tests -m gpu -q -x > $OUT/gpu_tests.log 2>&1; tail -3 $OUT/gpu_tests.log
+echo "== 2 default bench"; date +%T
+timeout 300 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err; head -c 300 $OUT/${TAG}_bench_line.json; echo
+echo "== 3 nlhe bench"; date +%T
+timeout 150 python bench.py --workload nlhe --cpu-seconds 10 > $OUT/${TAG}_nlhe_bench_line.json 2> $OUT/nlhe.err; head -c 300 $OUT/${TAG}_nlhe_bench_line.json; echo
+echo "== 4 kernel traces"; date +%T
+cd /tmp && export TMPDIR=/tmp
+export PYTHONPATH=$REPO
+BENCH="python $REPO/bench.py --no-extras --steps 40 --warmup 5"
+rm -rf $OUT/kt
+timeout 150 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $BENCH > $OUT/kt.log 2>&1
+python $REPO/scripts/rocpd_summary.py "$(ls $OUT/kt/*.db 2>/dev/null | head -1)" $OUT/${TAG}_bench_kernel_stats.txt "$BENCH" | head -8
+rm -rf $OUT/kt
+CMD="python $REPO/bench.py --workload nlhe --steps 8 --warmup 4 --cpu-seconds 0"
+rm -rf $OUT/nl
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/nl -o nl -- $CMD > $OUT/nl.log 2>&1
+python $REPO/scripts/steady_stats.py $OUT/nl/nl_kernel_trace.csv 4 8 $OUT/${TAG}_nlhe_kernel_stats_b262144.txt "$CMD (the timed 262144-tree steps)" levels | head -16
+python $REPO/scripts/steady_stats.py $OUT/nl/nl_kernel_trace.csv 23 20 $OUT/${TAG}_nlhe_kernel_stats_b128.txt "$CMD (the timed 128-tree steps)" | head -10
+rm -rf $OUT/nl
+echo "== 5 nlhe traffic"; date +%T
+cd $REPO
+timeout 240 bash scripts/r3_nlhe_traffic.sh $TAG 65536 > $OUT/traffic.log 2>&1; tail -12 $OUT/traffic.log
+cp gpurun_out/prof3/${TAG}_nlhe_hbm_traffic.json $OUT/ 2>/dev/null
+date +%T
