@@ -426,6 +426,39 @@ __global__ __launch_bounds__(256) void k_blk_one(const uint32_t* starts, const u
     if (threadIdx.x == 0) *hot_counter = 0;
 }
 
+// the same in ONE launch: the scan is single-pass with decoupled look-back (sortscan.hpp; opt-in with RP_SS_ONEPASS=1)
+__global__ __launch_bounds__(256) void k_blk_onepass(const uint32_t* starts, const uint32_t* n_segs, uint32_t n, uint32_t* counts, uint32_t* nblk,
+                                                     uint32_t* boff, uint32_t* blkseg, uint32_t* hot_counter, ss::OnePass op) {
+    __shared__ uint64_t wt[4];
+    __shared__ uint32_t slot;
+    const uint32_t tile = ss::onepass_tile(op, &slot);
+    const uint32_t runs = *n_segs, base = tile * ss::SCAN_TILE + threadIdx.x * 4u;
+    uint32_t v[4];
+    uint64_t s = 0;
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t g = base + k;
+        v[k] = 0;
+        if (g >= n) continue;
+        uint32_t cnt;
+        v[k] = blk_of_row(starts, runs, n, g, &cnt);
+        if (g < runs) counts[g] = cnt;
+        nblk[g] = v[k];
+        s += v[k];
+    }
+    uint64_t tot;
+    const uint32_t local = (uint32_t)ss::block_exscan64(s, wt, &tot);
+    uint32_t run = ss::onepass_base(op, tile, (uint32_t)tot, &slot) + local;
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t g = base + k;
+        if (g >= n) break;
+        boff[g] = run;
+        if (g < runs)
+            for (uint32_t b = 0; b < v[k]; ++b) blkseg[run + b] = g;
+        run += v[k];
+    }
+    if (tile == 0 && threadIdx.x == 0) *hot_counter = 0;
+}
+
 template <bool GATHER>  // true: the touches are read from the unsorted batch through sg.perm (no sorted copy exists)
 __global__ __launch_bounds__(256) void k_block_maps_sparse(SparseParams p, DevBatch b, Segments sg, const uint32_t* nblk,
                                                            const uint32_t* boff, const uint32_t* blkseg, SortedBatch sb,
@@ -708,6 +741,7 @@ struct rp_profile {
     uint32_t max_batch = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
+    ss::OnePassState onepass;  // descriptors + ticket of the single-pass scans (RP_SS_ONEPASS=1)
     bool fused_blocks = true;  // rows -> blocks inside one tiled scan (RP_SPARSE_V1=1: block counts, scan, index and memset as separate launches)
     bool gather_maps = true;  // composed update: block maps read the touches through the sort permutation (RP_SPARSE_PERMUTE=1: via a sorted copy)
     float* tab = nullptr;
@@ -770,6 +804,9 @@ static void free_workspace(rp_profile* h) {
                     (void*)h->entries, (void*)h->srt_regret, (void*)h->srt_policy, (void*)h->srt_payoff,
                     (void*)h->srt_expanded})
         if (p) (void)hipFree(p);
+    if (h->onepass.desc) (void)hipFree(h->onepass.desc);
+    if (h->onepass.ticket) (void)hipFree(h->onepass.ticket);
+    h->onepass = ss::OnePassState{};
     h->iota = h->keys_out = h->perm = h->seg_rows = h->seg_counts = h->seg_offsets = h->ent_rows = h->nblk = h->boff = nullptr;
     h->blocks = nullptr;
     h->blkseg = nullptr;
@@ -802,6 +839,12 @@ static int ensure_capacity(rp_profile* h, uint32_t n) {
     HIP_TRY(hipMalloc(&h->boff, (size_t)cap * 4));
     HIP_TRY(hipMalloc(&h->blocks, (size_t)max_blocks_of(cap) * entry_bytes_of(h)));
     HIP_TRY(hipMalloc(&h->blkseg, (size_t)max_blocks_of(cap) * 4));
+    h->onepass = ss::OnePassState{};
+    h->onepass.tiles_cap = (cap + ss::SCAN_TILE - 1u) / ss::SCAN_TILE + 1u;
+    HIP_TRY(hipMalloc(&h->onepass.desc, (size_t)h->onepass.tiles_cap * 8));
+    HIP_TRY(hipMalloc(&h->onepass.ticket, 4));
+    HIP_TRY(hipMemsetAsync(h->onepass.desc, 0, (size_t)h->onepass.tiles_cap * 8, h->stream));
+    HIP_TRY(hipMemsetAsync(h->onepass.ticket, 0, 4, h->stream));
     // scratch of the sort (histograms, their scan, one ping-pong pair) + the run-length encoding's n flag words
     h->sort_bytes = ss::sort_scratch_bytes(cap) + ((ss::scan_scratch_bytes(cap) + 255) & ~(size_t)255) + (size_t)cap * 4 + 256;
     HIP_TRY(hipMalloc(&h->sort_tmp, h->sort_bytes));
@@ -830,7 +873,7 @@ static int sort_and_segment(rp_profile* h, const uint32_t* rows, uint32_t n, boo
     // counts_later: the caller is launch_summarize, whose block scan derives the counts from the starts on its way
     const bool derived = counts_later && h->fused_blocks && (n + ss::SCAN_TILE - 1u) / ss::SCAN_TILE <= ss::SCAN_ONE;  // launch_summarize's condition
     HIP_TRY(ss::run_length_encode(h->keys_out, n, h->seg_rows, h->seg_offsets, derived ? nullptr : h->seg_counts, h->n_segs,
-                                  reinterpret_cast<uint32_t*>(sp), scan_tmp, h->stream));
+                                  reinterpret_cast<uint32_t*>(sp), scan_tmp, h->stream, &h->onepass));
     return RP_OK;
 }
 
@@ -874,7 +917,12 @@ static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch
     const uint32_t mb = max_blocks_of(n);
     void* scan_tmp = reinterpret_cast<unsigned char*>(h->sort_tmp) + ss::sort_scratch_bytes(h->cap);
     const uint32_t tiles = (n + ss::SCAN_TILE - 1u) / ss::SCAN_TILE;
-    if (h->fused_blocks && n <= ss::SCAN_ONE) {
+    if (h->fused_blocks && n > ss::SCAN_ONE && h->onepass.desc && tiles <= h->onepass.tiles_cap && ss::onepass_wanted()) {
+        ss::OnePass op;
+        HIP_TRY(ss::onepass_begin(h->onepass, tiles, h->stream, &op));
+        hipLaunchKernelGGL(k_blk_onepass, dim3(tiles), dim3(256), 0, h->stream, h->seg_offsets, h->n_segs, n, h->seg_counts, h->nblk, h->boff,
+                           h->blkseg, h->hot + HOT_CAP, op);
+    } else if (h->fused_blocks && n <= ss::SCAN_ONE) {
         hipLaunchKernelGGL(k_blk_one, dim3(1), dim3(256), 0, h->stream, h->seg_offsets, h->n_segs, n, h->seg_counts, h->nblk, h->boff, h->blkseg,
                            h->hot + HOT_CAP);
     } else if (h->fused_blocks && tiles <= ss::SCAN_ONE) {

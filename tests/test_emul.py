@@ -20,11 +20,14 @@ SELECTION = [
     ("tests/test_gpu_mccfr.py", "(test_tables_bit_exact_vs_oracle and (kuhn or rps)) or (composed_mode_matches_oracle_world_semantics and 777)"
                                 " or test_static_skeleton_traversal_equals_generic_and_oracle or test_hyper_parameter_corners_bit_exact"),
     # the sparse profile: own radix sort / scan / run lengths, ordered and composed application
-    ("tests/test_gpu_sparse.py", "test_ordered_apply_bit_exact or test_composed_apply"),
+    ("tests/test_gpu_sparse.py", "test_ordered_apply_bit_exact or test_composed_apply or (test_batches_just_past_one_scan_tile_set_bit_exact and 66000)"),
     # NLHE traversal: level-synchronous expansion against the oracle, pruned schemes, ragged batches, the chunked retry
     ("tests/test_gpu_nlmc.py", "(test_first_batch_equals_the_oracle and 64) or test_pruned_sampling_schemes_equal_the_oracle"
                                " or test_ragged_batches_equal_the_oracle or test_a_batch_traversed_in_several_passes"
                                " or test_a_full_infoset_table_fails"),
+    # the opt-in single-pass scans (decoupled look-back, sortscan.hpp): not yet run on hardware, so this is their only check —
+    # eight host threads make the look-back wait on tiles that are really in flight
+    ("tests/test_gpu_sparse.py", "test_batches_just_past_one_scan_tile_set_bit_exact", {"RP_SS_ONEPASS": "1"}),
     # Path B: wave-cooperative Sinkhorn, Elkan iterations with remembered pairwise entries
     ("tests/test_gpu_lloyd.py", "(test_sinkhorn_random_pairs_bit_exact and 32-5-9) or test_sinkhorn_fixture_bit_exact"
                                 " or (test_elkan_iterations_bit_exact and sinkhorn-5-150) or test_equity_variation_bit_exact"),
@@ -41,9 +44,12 @@ def emulated_library():
     return emul_build.build(jobs=os.cpu_count() or 4)
 
 
-@pytest.mark.parametrize("module,expr", SELECTION, ids=[m.split("/")[-1][9:-3] for m, _ in SELECTION])
-def test_kernel_sources_under_the_wave64_model(emulated_library, module, expr):
-    env = dict(os.environ, RP_EMUL="1", RP_EMUL_GUARD="1", RP_EMUL_TRAP="1")
+CASES = [(c[0], c[1], c[2] if len(c) > 2 else {}) for c in SELECTION]
+
+
+@pytest.mark.parametrize("module,expr,extra", CASES, ids=[c[0].split("/")[-1][9:-3] + ("-onepass" if c[2] else "") for c in CASES])
+def test_kernel_sources_under_the_wave64_model(emulated_library, module, expr, extra):
+    env = dict(os.environ, RP_EMUL="1", RP_EMUL_GUARD="1", RP_EMUL_TRAP="1", **extra)
     r = subprocess.run([sys.executable, "-m", "pytest", module, "-m", "gpu", "-q", "-x", "-k", expr, "-p", "no:cacheprovider"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]

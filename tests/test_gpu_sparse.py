@@ -54,6 +54,26 @@ def test_composed_apply_and_entries_bit_exact(gpu, regret, weight, A):
     same(g.rows(np.arange(n_rows)), o.rows(np.arange(n_rows)))
 
 
+@pytest.mark.parametrize("n_rows,A,n", [(50000, 9, 70000), (300, 9, 66000), (1 << 16, 16, 131073)])
+def test_batches_just_past_one_scan_tile_set_bit_exact(gpu, n_rows, A, n):
+    # more than ss::SCAN_ONE = 65 536 Decisions: the run lengths and the rows -> blocks index come from the TILED scans (tile sums,
+    # scan of the sums, tiles — or, with RP_SS_ONEPASS=1, the single-pass scan), few rows / many rows / the widest rows
+    g = SparseProfile(n_rows, A, "linear", "linear")
+    o = oracle.OracleProfile(n_rows, A, "linear", "linear")
+    for e in range(2):
+        batch = synthetic_batch(n, n_rows, A, seed=n + e)
+        db = DeviceBatch(*batch)
+        buf = torch.zeros(db.n * g.entry_bytes(), dtype=torch.uint8, device="cuda")
+        k = g.summarize(db, buf.data_ptr())
+        exp = o.summarize(batch)
+        assert k * g.entry_bytes() == exp.size and np.array_equal(buf[: exp.size].cpu().numpy(), exp), "summary entries differ"
+        g.apply(db, "composed")
+        o.fold(exp)
+    g.sync()
+    rows = np.unique(batch[0])[:5000]
+    same(g.rows(rows), o.rows(rows))
+
+
 def test_hot_rows_fold_their_block_groups_in_parallel_bit_exact(gpu):
     # 40 rows, 60 000 touches: the popular rows collect > RP_FOLD_GROUP * RP_SPARSE_BLOCK touches (k_hot_fold)
     n_rows, A = 40, 9
