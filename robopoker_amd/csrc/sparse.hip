@@ -352,6 +352,26 @@ __global__ void k_block_index(const uint32_t* nblk, const uint32_t* boff, const 
     for (uint32_t k = 0; k < nb; ++k) blkseg[base + k] = g;
 }
 
+// k_fold's arithmetic for ONE entry of a row and one of its cells (a single rank's entry is applied where it is produced when
+// RP_SPARSE_APPLY_FUSED=1: the step's last launch goes away).  The same operations in the same order as k_fold.
+__device__ __forceinline__ void apply_cell(const SparseParams& p, uint32_t rowid, uint32_t A, uint32_t a, const Map& mr, const Map& mw, uint32_t c,
+                                           float psum) {
+    float* row = p.tab + (size_t)rowid * 4u * A;
+    float r = row[a], w = row[A + a], ev = row[2 * A + a];
+    uint32_t v = reinterpret_cast<const uint32_t*>(row)[3 * A + a];
+    if (mr.n) r = rp_maxf(mr.a * r + mr.b, mr.m);
+    if (mw.n) w = rp_maxf(mw.a * w + mw.b, mw.m);
+    if (c) {
+        const uint32_t n2 = v + c;
+        ev = ev + (psum - (float)c * ev) / (float)n2;
+        v = n2;
+    }
+    row[a] = r;
+    row[A + a] = w;
+    row[2 * A + a] = ev;
+    reinterpret_cast<uint32_t*>(row)[3 * A + a] = v;
+}
+
 // The same three steps (touches per row -> blocks per row -> first block of every row -> block -> row index) inside ONE tiled scan:
 // its tile-sum kernel derives the counts from the run starts and zeroes the hot-row counter on the way, its tile kernel writes the
 // index.  Three launches instead of six (the counts of the run-length encoding, block counts, a three-launch scan, the index, the
@@ -459,7 +479,8 @@ __global__ __launch_bounds__(256) void k_blk_onepass(const uint32_t* starts, con
     if (tile == 0 && threadIdx.x == 0) *hot_counter = 0;
 }
 
-template <bool GATHER>  // true: the touches are read from the unsorted batch through sg.perm (no sorted copy exists)
+template <bool GATHER, bool APPLY>  // GATHER: the touches are read from the unsorted batch through sg.perm (no sorted copy exists);
+                                    // APPLY: a one-block row's entry goes straight into the table (single rank)
 __global__ __launch_bounds__(256) void k_block_maps_sparse(SparseParams p, DevBatch b, Segments sg, const uint32_t* nblk,
                                                            const uint32_t* boff, const uint32_t* blkseg, SortedBatch sb,
                                                            unsigned char* entries, unsigned char* blocks, uint32_t entry_bytes,
@@ -517,10 +538,12 @@ __global__ __launch_bounds__(256) void k_block_maps_sparse(SparseParams p, DevBa
             mr[a] = mine ? br : ident;
             mr[A + a] = mine ? bw : ident;
         }
+        if (APPLY && single && mine) apply_cell(p, sg.rows[g], A, a, br, bw, cnt, 0.0f + (0.0f + bp));
     }
 }
 
 // rows with several blocks: fold the block records in block order into the entry
+template <bool APPLY>
 __global__ __launch_bounds__(256) void k_seg_fold(SparseParams p, Segments sg, const uint32_t* nblk, const uint32_t* boff,
                                                   unsigned char* entries, const unsigned char* blocks, uint32_t entry_bytes,
                                                   uint32_t* hot, uint32_t* n_hot, uint32_t hot_cap) {
@@ -588,11 +611,13 @@ __global__ __launch_bounds__(256) void k_seg_fold(SparseParams p, Segments sg, c
             mr[a] = tr;
             mr[A + a] = tw;
         }
+        if (APPLY && a < nact) apply_cell(p, sg.rows[g], A, a, tr, tw, sg.counts[g], tp);
     }
 }
 
 // hot rows (more than RP_FOLD_GROUP blocks): one workgroup per row, the groups of the two-level fold in parallel —
 // thread (slot s, cell c) folds the records of group g0 + s, then the cell threads fold the group maps in order
+template <bool APPLY>
 __global__ __launch_bounds__(256) void k_hot_fold(SparseParams p, Segments sg, const uint32_t* nblk, const uint32_t* boff,
                                                   unsigned char* entries, const unsigned char* blocks, uint32_t entry_bytes,
                                                   const uint32_t* hot, const uint32_t* n_hot, uint32_t hot_cap) {
@@ -654,6 +679,13 @@ __global__ __launch_bounds__(256) void k_hot_fold(SparseParams p, Segments sg, c
             hdr[3] = nact;
         }
         if (tid < W2) reinterpret_cast<Map*>(ent + 16)[tid] = tot;
+        if (APPLY) {  // the entry is read back by the cell lanes once the whole workgroup has written it
+            __syncthreads();
+            if (tid < nact) {
+                const Map mr = reinterpret_cast<const Map*>(ent + 16)[tid], mw = reinterpret_cast<const Map*>(ent + 16)[A + tid];
+                apply_cell(p, sg.rows[g], A, tid, mr, mw, sg.counts[g], rp_u2f(reinterpret_cast<const uint32_t*>(ent)[2]));
+            }
+        }
     }
 }
 
@@ -742,6 +774,7 @@ struct rp_profile {
     hipStream_t stream = nullptr;
     bool own_stream = true;
     ss::OnePassState onepass;  // descriptors + ticket of the single-pass scans (RP_SS_ONEPASS=1)
+    bool apply_fused = false;  // RP_SPARSE_APPLY_FUSED=1: a single rank's entries are applied where they are produced (no k_fold launch)
     bool fused_blocks = true;  // rows -> blocks inside one tiled scan (RP_SPARSE_V1=1: block counts, scan, index and memset as separate launches)
     bool gather_maps = true;  // composed update: block maps read the touches through the sort permutation (RP_SPARSE_PERMUTE=1: via a sorted copy)
     float* tab = nullptr;
@@ -912,7 +945,7 @@ static uint32_t group_blocks(uint32_t n) { return std::max(1u, std::min((n * GRO
 
 // segments (already built for this batch) -> entries[g] for g < n_segs
 static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch& b, const Segments& sg, uint32_t n,
-                            unsigned char* entries) {
+                            unsigned char* entries, bool apply_local = false) {
     const uint32_t eb = (uint32_t)entry_bytes_of(h);
     const uint32_t mb = max_blocks_of(n);
     void* scan_tmp = reinterpret_cast<unsigned char*>(h->sort_tmp) + ss::sort_scratch_bytes(h->cap);
@@ -938,18 +971,29 @@ static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch
         HIP_TRY(hipMemsetAsync(h->hot + HOT_CAP, 0, 4, h->stream));
     }
     const SortedBatch sb{h->srt_regret, h->srt_policy, h->srt_payoff, h->srt_expanded};
+#define RP_MAPS(G, AP)                                                                                                                  \
+    hipLaunchKernelGGL((k_block_maps_sparse<G, AP>), dim3(group_blocks(mb)), dim3(256), 0, h->stream, p, b, sg, h->nblk, h->boff, h->blkseg, \
+                       sb, entries, h->blocks, eb, mb)
     if (h->gather_maps) {
-        hipLaunchKernelGGL(k_block_maps_sparse<true>, dim3(group_blocks(mb)), dim3(256), 0, h->stream, p, b, sg, h->nblk, h->boff, h->blkseg,
-                           sb, entries, h->blocks, eb, mb);
+        if (apply_local) RP_MAPS(true, true);
+        else RP_MAPS(true, false);
     } else {  // RP_SPARSE_PERMUTE=1: a sorted copy first (the ordered update's layout), then contiguous reads
         hipLaunchKernelGGL(k_permute, dim3((unsigned)(((uint64_t)n * h->A + 255) / 256)), dim3(256), 0, h->stream, b, h->perm, n, h->A, sb);
-        hipLaunchKernelGGL(k_block_maps_sparse<false>, dim3(group_blocks(mb)), dim3(256), 0, h->stream, p, b, sg, h->nblk, h->boff, h->blkseg,
-                           sb, entries, h->blocks, eb, mb);
+        if (apply_local) RP_MAPS(false, true);
+        else RP_MAPS(false, false);
     }
-    hipLaunchKernelGGL(k_seg_fold, dim3(group_blocks(n)), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb,
-                       h->hot, h->hot + HOT_CAP, (uint32_t)HOT_CAP);
-    hipLaunchKernelGGL(k_hot_fold, dim3(64), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb, h->hot,
-                       h->hot + HOT_CAP, (uint32_t)HOT_CAP);
+#undef RP_MAPS
+    if (apply_local) {
+        hipLaunchKernelGGL(k_seg_fold<true>, dim3(group_blocks(n)), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb,
+                           h->hot, h->hot + HOT_CAP, (uint32_t)HOT_CAP);
+        hipLaunchKernelGGL(k_hot_fold<true>, dim3(64), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb, h->hot,
+                           h->hot + HOT_CAP, (uint32_t)HOT_CAP);
+    } else {
+        hipLaunchKernelGGL(k_seg_fold<false>, dim3(group_blocks(n)), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb,
+                           h->hot, h->hot + HOT_CAP, (uint32_t)HOT_CAP);
+        hipLaunchKernelGGL(k_hot_fold<false>, dim3(64), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb, h->hot,
+                           h->hot + HOT_CAP, (uint32_t)HOT_CAP);
+    }
     HIP_TRY(hipGetLastError());
     return RP_OK;
 }
@@ -977,6 +1021,7 @@ int rp_profile_create(int device, uint64_t n_rows, uint32_t max_actions, rp_regr
     h->max_batch = max_batch;
     h->gather_maps = getenv("RP_SPARSE_PERMUTE") == nullptr;
     h->fused_blocks = getenv("RP_SPARSE_V1") == nullptr;
+    h->apply_fused = getenv("RP_SPARSE_APPLY_FUSED") != nullptr;
 #define PF_TRY(expr)                                                                              \
     do {                                                                                          \
         hipError_t _e = (expr);                                                                   \
@@ -1057,10 +1102,11 @@ int rp_profile_apply(rp_profile* h, const rp_decisions* batch, rp_update_mode mo
                                    (uint32_t)HOT_CAP);
         } else {
             const uint32_t eb = (uint32_t)entry_bytes_of(h);
-            if ((rc = launch_summarize(h, p, b, sg, batch->n, h->entries))) return rc;
+            if ((rc = launch_summarize(h, p, b, sg, batch->n, h->entries, h->apply_fused))) return rc;
             // a single rank's entries have distinct rows: entry g is its own segment, the count comes from n_segs
-            hipLaunchKernelGGL(k_fold, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, h->entries, eb,
-                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, h->n_segs);
+            if (!h->apply_fused)
+                hipLaunchKernelGGL(k_fold, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, h->entries, eb,
+                                   (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, h->n_segs);
         }
         sp_end(h, h->clk_apply);
         HIP_TRY(hipGetLastError());
