@@ -37,4 +37,19 @@ echo "== 5 nlhe traffic"; date +%T
 cd $REPO
 timeout 240 bash scripts/r3_nlhe_traffic.sh $TAG 65536 > $OUT/traffic.log 2>&1; tail -12 $OUT/traffic.log
 cp gpurun_out/prof3/${TAG}_nlhe_hbm_traffic.json $OUT/ 2>/dev/null
+echo "== 6 opt-in sparse paths (never run on a GPU before round 4): tests first, under a short timeout, then the A/B"; date +%T
+RP_SS_ONEPASS=1 RP_SPARSE_APPLY_FUSED=1 timeout 60 python -m pytest tests/test_gpu_sparse.py -m gpu -q -x > $OUT/sparse_optin_tests.log 2>&1; tail -2 $OUT/sparse_optin_tests.log
+if grep -q " passed" $OUT/sparse_optin_tests.log && ! grep -q "failed\|error" $OUT/sparse_optin_tests.log; then
+  timeout 30 python bench.py --workload nlhe-synth --steps 60 --warmup 5 --cpu-seconds 0 > $OUT/${TAG}_sparse_default.json 2>/dev/null
+  RP_SS_ONEPASS=1 timeout 30 python bench.py --workload nlhe-synth --steps 60 --warmup 5 --cpu-seconds 0 > $OUT/${TAG}_sparse_onepass.json 2>/dev/null
+  RP_SS_ONEPASS=1 RP_SPARSE_APPLY_FUSED=1 timeout 30 python bench.py --workload nlhe-synth --steps 60 --warmup 5 --cpu-seconds 0 > $OUT/${TAG}_sparse_onepass_applyfused.json 2>/dev/null
+  python - <<PY
+import json
+for f in ("default", "onepass", "onepass_applyfused"):
+    try:
+        d = json.load(open("$OUT/${TAG}_sparse_%s.json" % f)); print(f, round(d["value"] / 1e6), "M/s", round(d["ms_per_step"], 4), "ms", d["roofline"]["kernels_ms"])
+    except Exception as e:
+        print(f, "no line:", e)
+PY
+fi
 date +%T
