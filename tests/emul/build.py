@@ -68,6 +68,15 @@ def stage_sources() -> list[str]:
     return units
 
 
+def stage_selfcheck() -> str:
+    """tests/emul/selfcheck.cpp goes through the same two rewrites as the product sources (it uses dynamic LDS)"""
+    dst = os.path.join(OUT, "src", "selfcheck.cpp")
+    new = rewrite(open(os.path.join(HERE, "selfcheck.cpp")).read())
+    if not os.path.exists(dst) or open(dst).read() != new:
+        open(dst, "w").write(new)
+    return dst
+
+
 def digest(paths) -> str:
     h = hashlib.sha256()
     for p in sorted(paths):
@@ -99,6 +108,8 @@ def build(jobs: int = 8, only=None) -> str:
     headers += [os.path.join(HERE, "hip", "hip_runtime.h")]
     deps_sig = digest(headers) + " ".join(FLAGS)
     units.append(os.path.join(HERE, "wavesim.cpp"))
+    if not only:
+        units.append(stage_selfcheck())
     objs = [os.path.join(OUT, os.path.basename(u) + ".o") for u in units]
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         list(ex.map(lambda so: compile_one(so[0], so[1], deps_sig), zip(units, objs)))

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <climits>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -52,6 +53,7 @@ constexpr size_t STACK_BYTES = 256 * 1024;
 constexpr unsigned MAX_THREADS = 1024;
 
 enum State : int { RUNNABLE = 0, AT_WAVE = 1, AT_BARRIER = 2, DONE = 3 };
+std::atomic<uint64_t> g_split_rounds{0};  // rounds in which the lanes of a wavefront were parked at more than one collective
 
 struct Fiber {
     void* sp;
@@ -213,15 +215,23 @@ void run_block(Worker& w, unsigned nthreads) {
             uint64_t waiting = 0;
             for (unsigned l = 0; l < n; ++l)
                 if (w.fib[base + l].state == AT_WAVE) waiting |= 1ull << l;
-            while (waiting) {
-                Fiber& h = w.fib[base + (unsigned)__builtin_ctzll(waiting)];
+            if (waiting) {
+                // Lanes parked at DIFFERENT collectives: the hardware runs a divergent region to its end before the code after
+                // it, so the lanes at the later collective wait for the others to arrive there (a lane that skipped a branch
+                // waits for those inside it; a lane that left a loop waits for those still iterating).  "Later" is read off the
+                // source line; only the earliest collective is settled in this round.
+                int first = INT32_MAX;
+                for (uint64_t r = waiting; r; r &= r - 1) first = std::min(first, w.fib[base + (unsigned)__builtin_ctzll(r)].site);
                 uint64_t members = 0;
+                int op = 0;
                 for (uint64_t r = waiting; r; r &= r - 1) {
                     const unsigned l = (unsigned)__builtin_ctzll(r);
-                    if (w.fib[base + l].site == h.site && w.fib[base + l].op == h.op) members |= 1ull << l;
+                    if (w.fib[base + l].site != first) continue;
+                    if (!members) op = w.fib[base + l].op;
+                    if (w.fib[base + l].op == op) members |= 1ull << l;
                 }
+                if (members != waiting) g_split_rounds.fetch_add(1, std::memory_order_relaxed);
                 resolve_group(w, base, members);
-                waiting &= ~members;
                 resolved = true;
             }
         }
@@ -567,4 +577,5 @@ __attribute__((visibility("default"))) void emu_stats(uint64_t* launches, uint64
     *launches = emu::g_stats.launches;
     *blocks = emu::g_stats.blocks;
 }
+__attribute__((visibility("default"))) uint64_t emu_split_rounds(void) { return emu::g_split_rounds.load(); }
 }

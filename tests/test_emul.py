@@ -66,3 +66,14 @@ def test_the_emulated_library_exports_the_whole_abi(emulated_library):
     lib = C.CDLL(emulated_library)
     missing = [n for n in _lib.declared_symbols() if not hasattr(lib, n)]
     assert not missing
+
+
+@pytest.mark.parametrize("order", ["forward", "reverse", "random"])
+def test_the_execution_model_keeps_its_own_rules(emulated_library, order):
+    # tests/emul/selfcheck.cpp: ballots in a loop with per-lane trip counts, a shuffle after a divergent shuffle (the lanes that
+    # skipped the branch wait for the others), sources outside EXEC, segment widths, a barrier after a wavefront has left,
+    # readfirstlane under a partial mask, the 16x16x4 MFMA layout against a host matmul, 500 workgroups on one counter with
+    # their own LDS — under every resume order
+    code = "import ctypes as C; raise SystemExit(C.CDLL(%r).emu_selfcheck())" % emulated_library
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RP_EMUL_ORDER=order), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
