@@ -9,9 +9,11 @@
 //
 // Model: a workgroup = fibers (one per work-item) on one host thread; a fiber runs until it reaches a wavefront
 // collective (ballot, shuffle, readfirstlane, mfma, wave_barrier) or __syncthreads, or returns.  When every lane of
-// a wavefront is parked, the lanes parked at the SAME source line and operation form the collective's EXEC mask —
-// which is what structured divergence / reconvergence gives on the hardware.  Workgroups run one after another
-// (optionally on several host threads: RP_EMUL_THREADS).
+// a wavefront is parked, the lanes parked at the SAME source line and operation form the collective's EXEC mask; when
+// they are parked at different collectives only the earliest in the source is settled (a divergent region runs to its
+// end before the code after it: lanes that skipped a branch or left a loop wait for the others) — which is what
+// structured divergence / reconvergence gives on the hardware.  The workgroups of a launch are spread over host threads
+// (RP_EMUL_THREADS), so races between workgroups are real.
 #ifndef RP_EMUL_HIP_RUNTIME_H
 #define RP_EMUL_HIP_RUNTIME_H
 
