@@ -24,7 +24,7 @@ CSRC = os.path.join(ROOT, "robopoker_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "librp_emul.so")
 CLANG = os.environ.get("RP_EMUL_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-FLAGS = ["-x", "c++", "-std=c++17", os.environ.get("RP_EMUL_OPT", "-O1"), "-g", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-strict-aliasing",
+FLAGS = ["-x", "c++", "-std=c++17", os.environ.get("RP_EMUL_OPT", "-O1"), *(["-g"] if os.environ.get("RP_EMUL_DEBUG") else ["-gline-tables-only"]), "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-strict-aliasing",
          "-fvisibility=hidden", "-pthread", "-Wno-unknown-pragmas", "-Wno-unused-function", "-Wno-pass-failed",
          "-Wno-unknown-attributes", "-Wno-unused-value", "-Wno-c++20-extensions"]
 
