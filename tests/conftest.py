@@ -41,6 +41,20 @@ if os.environ.get("RP_EMUL") == "1":
     _load_emulated()
 
 
+def pytest_terminal_summary(terminalreporter):
+    """under RP_EMUL: how often the lanes of a wavefront were parked at more than one collective (the only situation in which the
+    execution model has to decide an order)"""
+    if os.environ.get("RP_EMUL") != "1":
+        return
+    import ctypes as C
+
+    from robopoker_amd import _lib
+
+    fn = _lib._lib.emu_split_rounds
+    fn.restype = C.c_uint64
+    terminalreporter.write_line(f"tests/emul: {fn()} rounds with lanes of one wavefront parked at different collectives")
+
+
 def has_gpu() -> bool:
     from robopoker_amd import _lib
 
