@@ -384,6 +384,7 @@ struct rp_nlhe {
     uint64_t census[5] = {0, 0, 0, 0, 0};  // nodes by kind + walker children, summed over the profiled steps
     int expand_waves = 4;  // RP_NLHE_EXPAND_WAVES: 4 (128 VGPRs) or 5 (96 VGPRs, some spilled)
     int expand_threads = 256;  // RP_NLHE_EXPAND_THREADS: workgroup size of k_nl_expand (64 / 128 / 256)
+    bool fused_levels = false;  // RP_NLHE_FUSED_LEVELS=1: one launch per tree level (k_nl_expand<4, 256, true> makes the nodes it expands)
     uint32_t chunks = 1;  // passes per batch (RP_NLHE_CHUNKS; doubled when a pass runs out of nodes)
     uint32_t grid_cap = 16384;  // workgroups of the grid-stride kernels (RP_NLHE_GRID; measured: 1024 -14 %, 4096 -4 %)
 };
@@ -488,11 +489,13 @@ int nl_traverse_chunk(rp_nlhe* h, uint32_t lo, uint32_t B, uint32_t d_base, uint
         for (; L < stop; ++L) {
             prm.tag = nl_next_tag(h);
             nl_clock_begin(h, 0);
-            if (h->expand_threads == 64) hipLaunchKernelGGL((k_nl_expand<4, 64>), wide_x, dim3(64), 0, st, prm, h->tab, lv, L);
+            if (h->fused_levels) hipLaunchKernelGGL((k_nl_expand<4, 256, true>), wide_x, blk, 0, st, prm, h->tab, lv, L);
+            else if (h->expand_threads == 64) hipLaunchKernelGGL((k_nl_expand<4, 64>), wide_x, dim3(64), 0, st, prm, h->tab, lv, L);
             else if (h->expand_threads == 128) hipLaunchKernelGGL((k_nl_expand<4, 128>), wide_x, dim3(128), 0, st, prm, h->tab, lv, L);
             else if (h->expand_waves == 5) hipLaunchKernelGGL((k_nl_expand<5, 256>), wide_x, blk, 0, st, prm, h->tab, lv, L);
             else hipLaunchKernelGGL((k_nl_expand<4, 256>), wide_x, blk, 0, st, prm, h->tab, lv, L);
             nl_clock_end(h, 0);
+            if (h->fused_levels) continue;  // the nodes of level L + 1 are made by the launch that expands them
             nl_clock_begin(h, 1);
             hipLaunchKernelGGL(k_nl_children, wide, blk, 0, st, prm, lv, L);
             nl_clock_end(h, 1);
@@ -605,6 +608,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     if (getenv("RP_NLHE_GRID")) h->grid_cap = std::max(1, atoi(getenv("RP_NLHE_GRID")));
     if (getenv("RP_NLHE_EXPAND_WAVES")) h->expand_waves = atoi(getenv("RP_NLHE_EXPAND_WAVES"));
     if (getenv("RP_NLHE_EXPAND_THREADS")) h->expand_threads = atoi(getenv("RP_NLHE_EXPAND_THREADS"));
+    h->fused_levels = getenv("RP_NLHE_FUSED_LEVELS") != nullptr;
     if (getenv("RP_NLHE_CHUNKS")) h->chunks = (uint32_t)std::max(1, atoi(getenv("RP_NLHE_CHUNKS")));
 #define NL_TRY(expr)                    \
     do {                                \

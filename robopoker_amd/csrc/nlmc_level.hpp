@@ -57,7 +57,7 @@ namespace rp {
 struct NlCtl {
     uint32_t n_nodes;  // allocation cursor
     uint32_t err;
-    uint32_t pad[2];
+    uint32_t pad[2];  // pad[0]: workgroups of the running FUSED level launch that have finished
     uint32_t lvl_node[NL_MAXL + 2];  // first node of each level
     uint32_t kinds[4];               // nodes of the batch by kind (terminal, chance, walker, opponent) and ...
     uint32_t walker_kids;            // ... children of its walker nodes: what k_nl_expand's algorithmic bytes are counted from
@@ -162,7 +162,19 @@ __global__ __launch_bounds__(256) void k_nl_roots(NlParams p, NlNodes nd) {
 // ---------------------------------------------------------------------------------------------------------------
 #define NL_TILE 512u  // nodes a workgroup sorts by kind at a time (measured: 512 and 1024 equal at 262 144 trees, 2048 -7 %, 4096 -13 % in
                       // k_nl_expand; at 128 trees per step 8.0 / 7.8 / 6.6 / 5.3 M updates per second: a tile is a serial chain of phases)
-template <int MINW, uint32_t BT>  // minimum wavefronts per SIMD the register allocation aims for; threads per workgroup
+__device__ __forceinline__ uint32_t nl_make_child(const NlParams& p, const NlNodes& nd, uint32_t c, int walker);  // below, with k_nl_children
+// FUSED (RP_NLHE_FUSED_LEVELS=1, one launch per tree level instead of two; not yet run on a GPU): a tile's nodes are first MADE —
+// nl_make_child, what k_nl_children does for the whole level — by the workgroup that then expands them, and the level's end for the
+// next launch (the node cursor moves while this launch runs) is written by the workgroup that finishes last.
+__device__ __forceinline__ void nl_level_done(NlCtl* ctl, const NlNodes& nd, uint32_t level) {
+    if (threadIdx.x != 0) return;
+    __threadfence();
+    if (atomicAdd(&ctl->pad[0], 1u) + 1u == gridDim.x) {  // every workgroup of the launch has bumped the cursor for the last time
+        ctl->pad[0] = 0u;
+        ctl->lvl_node[level + 2] = min(atomicAdd(&ctl->n_nodes, 0u), nd.ncap);
+    }
+}
+template <int MINW, uint32_t BT, bool FUSED = false>  // minimum wavefronts per SIMD the register allocation aims for; threads per workgroup
 __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, NlNodes nd, uint32_t level) {
     constexpr uint32_t R = NL_TILE / BT;           // classification sub-rounds
     constexpr uint32_t NW = BT / 64u;              // wavefronts of the workgroup
@@ -182,15 +194,28 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
     __shared__ uint32_t s_stop;
     if (threadIdx.x == 0) s_stop = ctl->err;
     __syncthreads();
-    if (hi <= lo || s_stop) return;
     if (level + 1u >= NL_MAXL) {  // a tree deeper than the level table: the step fails (never observed; the rules bound the depth)
-        if (threadIdx.x == 0) atomicOr(&ctl->err, NERR_LEVELS);
+        if (threadIdx.x == 0 && hi > lo && !s_stop) atomicOr(&ctl->err, NERR_LEVELS);
+        return;
+    }
+    if (hi <= lo || s_stop) {
+        if (FUSED) nl_level_done(ctl, nd, level);
         return;
     }
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     // pruning is live for this launch? (sample/pluribus.rs:86-88: the warm-up is on the profile's epoch)
     const bool pruning = p.sampling == RP_SAMPLING_PRUNABLE || (p.sampling == RP_SAMPLING_PLURIBUS && p.epoch >= p.prune_warmup);
     for (uint32_t t0 = lo + blockIdx.x * NL_TILE; t0 < hi; t0 += gridDim.x * NL_TILE) {
+        if (FUSED && level > 0u) {  // ---- 0. the tile's nodes themselves (level 0 = the roots, made by k_nl_roots)
+            uint32_t cerr = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < R; ++r) {
+                const uint32_t i = t0 + r * BT + tid;
+                if (i < hi) cerr |= nl_make_child(p, nd, i, (int)p.walker);
+            }
+            if (cerr) atomicOr(&ctl->err, cerr);
+            __syncthreads();  // the node records are read back below by other work-items of this workgroup
+        }
         // ---- 1. the tile sorted by kind (walker 0 | opponent 1 | chance 2; terminals have nothing to expand)
         uint32_t kd[R], rk[R];
 #pragma unroll
@@ -432,11 +457,83 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
         if (err) atomicOr(&ctl->err, err);
         __syncthreads();  // the LDS arrays are rewritten for the next tile
     }
+    if (FUSED) nl_level_done(ctl, nd, level);  // after the loop's last barrier: every cursor bump of this workgroup is behind it
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_nl_children: NlheGame::apply(edge) (nlhe/src/game.rs:33-53) for every child of the level, the child's node
 // ---------------------------------------------------------------------------------------------------------------
+// one child: NlheGame::apply(edge) on its parent's state, the child's node record.  Returns error bits.
+__device__ __forceinline__ uint32_t nl_make_child(const NlParams& p, const NlNodes& nd, uint32_t c, int walker) {
+    uint32_t err = 0;
+    const uint32_t par = nd.link[c];
+    const uint32_t pm = nd.meta[par], pkind = NL_META_KIND(pm);
+    // the child's slot among the parent's choices: children are stored in slot order, so it is the (c - kid0)-th expanded
+    // edge of the parent's mask
+    uint32_t slot = 0;
+    if (pkind != NK_CHANCE) {
+        uint32_t mbits = nd.aux[par] >> 16;
+        for (uint32_t r = c - nd.kid0[par]; r > 0; --r) mbits &= mbits - 1u;
+        slot = (uint32_t)__builtin_ctz(mbits);
+    }
+    const uint32_t tree = nd.tree[par];
+    G2 g;
+    nl_load_game(nd, par, g);
+    const uint64_t phk = nd.hkey[par];
+    const uint32_t e = pkind == NK_CHANCE ? (uint32_t)NE_DRAW : (uint32_t)(nd.chpath[par] >> (5u * slot)) & 31u;
+    const uint64_t hk = rp_mix64(phk ^ ((uint64_t)(e + 1u) * 0x9fb21c651e98df25ull));
+    uint32_t bucket = nd.bucket[par], cmp = NL_META_CMP(pm), cdepth, cplen;
+    uint64_t cpast;
+    if (e == NE_DRAW) {
+        const uint64_t h0 = nd.hole0[tree], h1 = nd.hole1[tree];
+        g.cards[0] = h0;
+        g.cards[1] = h1;
+        const NlAction act{NA_DRAW, 0, nl_draw(g.deck(), g.street() == 0 ? 3 : 1, p, p.tree_base + tree, hk)};
+        if (p.check_legal && !g.allowed(act)) err |= NERR_ILLEGAL;
+        g.force_act(act);
+        const int st = g.street();
+        bucket = nl_bucket(p, st, h0, g.board, &err) | (nl_bucket(p, st, h1, g.board, &err) << 16);
+        if (st == 3) cmp = nl_showdown_order(h0, h1, g.board);
+        cdepth = 0;
+        cplen = 0;
+        cpast = 0ull;
+    } else {
+        const NlView view = nl_view(g);
+        const NlAction act = nl_action_v(view, e);
+        // Game::apply panics on an illegal action (kicker game.rs:234-247).  snap()'s output is legal by construction, so the
+        // test can only catch an engine bug: it runs in the checking mode (RP_NLHE_CHECK_LEGAL=1, the tests)
+        if (p.check_legal && !g.allowed(act)) err |= NERR_ILLEGAL;
+        g.force_act(act);
+        const uint32_t pdepth = NL_META_DEPTH(pm), pplen = NL_META_PLEN(pm);
+        const bool raise = e == NE_SHOVE || e >= NE_OPEN0;
+        const uint64_t ppast = nd.past[par];
+        cdepth = pdepth + (raise ? 1u : 0u);
+        cplen = pplen + 1u;
+        cpast = pplen < 12u ? ppast | ((uint64_t)e << (5u * pplen)) : ppast;
+    }
+    const int turn = g.turn();
+    nd.tree[c] = tree;
+    const float f = nd.fac[c], pr = nd.reach[par];
+    nd.reach[c] = pkind == NK_OPP ? pr * f : pr;  // ancestor_reach (flow.rs:166-174): sigma / q over the opponent's edges
+    if (turn == NT_TERMINAL) {
+        // NlheGame::payoff (nlhe/src/game.rs:59-65): settlement minus what the walker put in; the showdown order was
+        // fixed when the river card fell
+        int reward[2];
+        const uint32_t strength[2] = {cmp == 1u ? 2u : 1u, cmp == 3u ? 2u : 1u};
+        nl_settle_ranked(g, strength, reward);
+        nd.val[c] = (float)(walker ? reward[1] - g.spent[1] : reward[0] - g.spent[0]);
+        nd.meta[c] = NK_TERMINAL;
+    } else {
+        const uint32_t kind = turn == NT_CHANCE ? NK_CHANCE : (turn == walker ? NK_WALKER : NK_OPP);
+        nl_store_game(nd, c, g);
+        nd.bucket[c] = bucket;
+        nd.past[c] = cpast;
+        nd.hkey[c] = hk;
+        nd.meta[c] = kind | ((cdepth & 7u) << 10) | ((cplen & 15u) << 13) | (cmp << 17);
+        nd.val[c] = 0.0f;
+    }
+    return err;
+}
 __global__ __launch_bounds__(256) void k_nl_children(NlParams p, NlNodes nd, uint32_t level) {
     NlCtl* ctl = nd.ctl;
     const uint32_t lo = ctl->lvl_node[level + 1], hi = min(ctl->n_nodes, nd.ncap);
@@ -446,76 +543,7 @@ __global__ __launch_bounds__(256) void k_nl_children(NlParams p, NlNodes nd, uin
     const int walker = (int)p.walker;
     for (uint32_t base = blockIdx.x * 256u; base < total; base += gridDim.x * 256u) {
         const uint32_t c = lo + base + threadIdx.x;
-        const bool valid = c < hi;
-        uint32_t err = 0;
-        if (valid) {
-            const uint32_t par = nd.link[c];
-            const uint32_t pm = nd.meta[par], pkind = NL_META_KIND(pm);
-            // the child's slot among the parent's choices: children are stored in slot order, so it is the (c - kid0)-th expanded
-            // edge of the parent's mask
-            uint32_t slot = 0;
-            if (pkind != NK_CHANCE) {
-                uint32_t mbits = nd.aux[par] >> 16;
-                for (uint32_t r = c - nd.kid0[par]; r > 0; --r) mbits &= mbits - 1u;
-                slot = (uint32_t)__builtin_ctz(mbits);
-            }
-            const uint32_t tree = nd.tree[par];
-            G2 g;
-            nl_load_game(nd, par, g);
-            const uint64_t phk = nd.hkey[par];
-            const uint32_t e = pkind == NK_CHANCE ? (uint32_t)NE_DRAW : (uint32_t)(nd.chpath[par] >> (5u * slot)) & 31u;
-            const uint64_t hk = rp_mix64(phk ^ ((uint64_t)(e + 1u) * 0x9fb21c651e98df25ull));
-            uint32_t bucket = nd.bucket[par], cmp = NL_META_CMP(pm), cdepth, cplen;
-            uint64_t cpast;
-            if (e == NE_DRAW) {
-                const uint64_t h0 = nd.hole0[tree], h1 = nd.hole1[tree];
-                g.cards[0] = h0;
-                g.cards[1] = h1;
-                const NlAction act{NA_DRAW, 0, nl_draw(g.deck(), g.street() == 0 ? 3 : 1, p, p.tree_base + tree, hk)};
-                if (p.check_legal && !g.allowed(act)) err |= NERR_ILLEGAL;
-                g.force_act(act);
-                const int st = g.street();
-                bucket = nl_bucket(p, st, h0, g.board, &err) | (nl_bucket(p, st, h1, g.board, &err) << 16);
-                if (st == 3) cmp = nl_showdown_order(h0, h1, g.board);
-                cdepth = 0;
-                cplen = 0;
-                cpast = 0ull;
-            } else {
-                const NlView view = nl_view(g);
-                const NlAction act = nl_action_v(view, e);
-                // Game::apply panics on an illegal action (kicker game.rs:234-247).  snap()'s output is legal by construction, so the
-                // test can only catch an engine bug: it runs in the checking mode (RP_NLHE_CHECK_LEGAL=1, the tests)
-                if (p.check_legal && !g.allowed(act)) err |= NERR_ILLEGAL;
-                g.force_act(act);
-                const uint32_t pdepth = NL_META_DEPTH(pm), pplen = NL_META_PLEN(pm);
-                const bool raise = e == NE_SHOVE || e >= NE_OPEN0;
-                const uint64_t ppast = nd.past[par];
-                cdepth = pdepth + (raise ? 1u : 0u);
-                cplen = pplen + 1u;
-                cpast = pplen < 12u ? ppast | ((uint64_t)e << (5u * pplen)) : ppast;
-            }
-            const int turn = g.turn();
-            nd.tree[c] = tree;
-            const float f = nd.fac[c], pr = nd.reach[par];
-            nd.reach[c] = pkind == NK_OPP ? pr * f : pr;  // ancestor_reach (flow.rs:166-174): sigma / q over the opponent's edges
-            if (turn == NT_TERMINAL) {
-                // NlheGame::payoff (nlhe/src/game.rs:59-65): settlement minus what the walker put in; the showdown order was
-                // fixed when the river card fell
-                int reward[2];
-                const uint32_t strength[2] = {cmp == 1u ? 2u : 1u, cmp == 3u ? 2u : 1u};
-                nl_settle_ranked(g, strength, reward);
-                nd.val[c] = (float)(walker ? reward[1] - g.spent[1] : reward[0] - g.spent[0]);
-                nd.meta[c] = NK_TERMINAL;
-            } else {
-                const uint32_t kind = turn == NT_CHANCE ? NK_CHANCE : (turn == walker ? NK_WALKER : NK_OPP);
-                nl_store_game(nd, c, g);
-                nd.bucket[c] = bucket;
-                nd.past[c] = cpast;
-                nd.hkey[c] = hk;
-                nd.meta[c] = kind | ((cdepth & 7u) << 10) | ((cplen & 15u) << 13) | (cmp << 17);
-                nd.val[c] = 0.0f;
-            }
-        }
+        const uint32_t err = c < hi ? nl_make_child(p, nd, c, walker) : 0u;
         if (err) atomicOr(&ctl->err, err);
     }
 }

@@ -52,4 +52,18 @@ for f in ("default", "onepass", "onepass_applyfused"):
         print(f, "no line:", e)
 PY
 fi
+echo "== 7 opt-in one launch per NLHE tree level: tests under a short timeout, then the A/B at both batch sizes"; date +%T
+RP_NLHE_FUSED_LEVELS=1 timeout 90 python -m pytest tests/test_gpu_nlmc.py -m gpu -q -x -k "not twin and not large_batch" > $OUT/nlhe_fused_tests.log 2>&1; tail -2 $OUT/nlhe_fused_tests.log
+if grep -q " passed" $OUT/nlhe_fused_tests.log && ! grep -q "failed\|error" $OUT/nlhe_fused_tests.log; then
+  timeout 60 python bench.py --workload nlhe --steps 5 --warmup 3 --cpu-seconds 0 > $OUT/${TAG}_nlhe_two_launches.json 2>/dev/null
+  RP_NLHE_FUSED_LEVELS=1 timeout 60 python bench.py --workload nlhe --steps 5 --warmup 3 --cpu-seconds 0 > $OUT/${TAG}_nlhe_fused_levels.json 2>/dev/null
+  python - <<PY
+import json
+for f in ("two_launches", "fused_levels"):
+    try:
+        d = json.load(open("$OUT/${TAG}_nlhe_%s.json" % f)); print(f, round(d["value"] / 1e6), "M/s", d.get("kernel_ms_per_step"), "batch 128:", d.get("reference_batch_128"))
+    except Exception as e:
+        print(f, "no line:", e)
+PY
+fi
 date +%T
