@@ -1677,6 +1677,7 @@ struct rp_mccfr {
     bool use_lds_traverse = false;
     // the per-infoset tables of the traversal (DevInfoTab) are a function of the regret/strategy tables: refreshed when stale
     uint64_t tables_version = 1, itab_version = 0;
+    uint32_t cell_pad = 0;  // RP_TRAV_CELL_PAD (0..31): words between the cells' value arrays in k_traverse_maps_static's LDS (bank spread)
     bool fuse_maps = true;  // composed update: traversal + block maps in one kernel when the game allows (RP_TRAV_UNFUSED=1: never)
     int static_skel = 0;  // 0: none (k_traverse_lds / k_traverse), 1: KuhnSkel, 2: LeducSkel (traverse_static.hpp)
     bool static_pruned = true;  // RP_TRAV_STATIC_EXTERNAL_ONLY=1: the pruned schemes keep k_traverse_lds (cross-check)
@@ -2048,7 +2049,7 @@ size_t chunk_maps_lds_bytes(const rp_mccfr* h) {
 size_t traverse_maps_lds_bytes(const rp_mccfr* h) {
     const size_t NI = h->tbl.n_infos;
     const size_t masks = h->S != RP_SAMPLING_EXTERNAL ? (size_t)h->maxdec * 256 * 4 : 0;  // the expanded edges of every list entry
-    return (NI * 8 + 2 * NI) * 4 + NI * 8 * 2 + (NI + (NI & 1)) * 2 + (size_t)5 * h->maxdec * 256 * 4 + masks;
+    return (NI * 8 + 2 * NI) * 4 + NI * 8 * 2 + (NI + (NI & 1)) * 2 + (size_t)5 * (h->maxdec * 256 + h->cell_pad) * 4 + masks;
 }
 bool traverse_maps_fused(const rp_mccfr* h) {
     return h->static_skel && !h->no_static_pruned_ok(h->S) && !h->dc.slotmap && h->tbl.n_infos <= CH_THREADS &&
@@ -2075,10 +2076,10 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev, bool fuse
     do {                                                                                                                               \
         if (pruned)                                                                                                                    \
             hipLaunchKernelGGL((k_traverse_maps_static<G, WK, true>), dim3(nblk), dim3(256), lds, h->stream, h->g, h->itab, p, bmaps, \
-                               bpsum, bcnt, nblk_max, h->maxdec);                                                                      \
+                               bpsum, bcnt, nblk_max, h->maxdec, h->cell_pad);                                                         \
         else                                                                                                                           \
             hipLaunchKernelGGL((k_traverse_maps_static<G, WK, false>), dim3(nblk), dim3(256), lds, h->stream, h->g, h->itab, p, bmaps, \
-                               bpsum, bcnt, nblk_max, h->maxdec);                                                                      \
+                               bpsum, bcnt, nblk_max, h->maxdec, h->cell_pad);                                                         \
     } while (0)
         if (h->static_skel == 1) {
             if (p.walker == 0) LAUNCH_FUSED(KuhnSkel, 0);
@@ -2331,6 +2332,7 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
     }
     h->use_lds_traverse = traverse_fits_lds(h) && getenv("RP_MCCFR_HBM_SCRATCH") == nullptr;
     h->fuse_maps = getenv("RP_TRAV_UNFUSED") == nullptr;
+    if (getenv("RP_TRAV_CELL_PAD")) h->cell_pad = (uint32_t)std::min(31, std::max(0, atoi(getenv("RP_TRAV_CELL_PAD"))));
     h->static_pruned = getenv("RP_TRAV_STATIC_EXTERNAL_ONLY") == nullptr;
     if (h->use_lds_traverse && getenv("RP_TRAV_GENERIC") == nullptr) {
         if (skel_matches<KuhnSkel>(game, h->children)) h->static_skel = 1;

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void k_traverse_static(DevGame g, DevInfoTab i
 //                  whose edge was pruned (no touch at all: a touch would apply the discount), as k_chunk_maps<true> does
 template <class G, int W, bool PRUNED>
 __global__ __launch_bounds__(256, 4) void k_traverse_maps_static(DevGame g, DevInfoTab it, StepParams p, Map* bmaps, float* bpsum,
-                                                              uint32_t* bcnt, uint32_t nblk_max, uint32_t maxdec) {
+                                                              uint32_t* bcnt, uint32_t nblk_max, uint32_t maxdec, uint32_t lpad) {
     extern __shared__ __attribute__((aligned(16))) uint32_t tm_lds[];
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t cls_n[16], cls_at[16];
@@ -362,7 +362,9 @@ __global__ __launch_bounds__(256, 4) void k_traverse_maps_static(DevGame g, DevI
     uint16_t* pre = reinterpret_cast<uint16_t*>(lbase + NI);
     uint16_t* order = pre + NI * 8u;
     float* vals = reinterpret_cast<float*>(order + NI + (NI & 1u));
-    const uint32_t L = maxdec * 256u;  // places per cell
+    // places per cell.  The five chains of an infoset read vals[c L + base + e] in the same instruction: with L a multiple of 32 they
+    // share a bank (a 5-way conflict at every step); lpad (RP_TRAV_CELL_PAD, 0 by default until measured) moves the cells apart
+    const uint32_t L = maxdec * 256u + lpad;
     uint32_t* lmask = reinterpret_cast<uint32_t*>(vals + 5u * L);
     for (uint32_t e = lt; e < NI * 8u; e += 256u) bits[e] = 0;
     if (lt < 16u) cls_n[lt] = 0;

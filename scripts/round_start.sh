@@ -66,4 +66,16 @@ for f in ("two_launches", "fused_levels"):
         print(f, "no line:", e)
 PY
 fi
+echo "== 8 the headline kernel with its cells' LDS arrays moved apart (RP_TRAV_CELL_PAD)"; date +%T
+for pad in 0 7 13; do
+  RP_TRAV_CELL_PAD=$pad timeout 60 python bench.py --no-extras --steps 40 --warmup 5 > $OUT/${TAG}_bench_cellpad_$pad.json 2>/dev/null
+  python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/${TAG}_bench_cellpad_$pad.json")); print("pad $pad:", round(d["value"] / 1e9, 2), "G/s", d["roofline"]["kernels_ms"])
+except Exception as e:
+    print("pad $pad: no line:", e)
+PY
+done
+RP_TRAV_CELL_PAD=7 timeout 120 python -m pytest tests/test_gpu_mccfr.py -m gpu -q -x -k "composed or static or bench_sized" 2>&1 | tail -2
 date +%T
