@@ -67,7 +67,7 @@ for f in ("two_launches", "fused_levels"):
 PY
 fi
 echo "== 8 the headline kernel with its cells' LDS arrays moved apart (RP_TRAV_CELL_PAD)"; date +%T
-for pad in 0 7 13; do
+for pad in 0 3 7 13; do
   RP_TRAV_CELL_PAD=$pad timeout 60 python bench.py --no-extras --steps 40 --warmup 5 > $OUT/${TAG}_bench_cellpad_$pad.json 2>/dev/null
   python - <<PY
 import json
