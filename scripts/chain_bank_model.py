@@ -1,4 +1,7 @@
-"""LDS bank model of k_traverse_maps_static's chain loop: the lists of real Leduc chunks (the oracle's Decisions), 32-lane groups of\n(cell, infoset) tasks in the kernel's order, one ds_read_b32 per step — cycles = the fullest bank of each group — for every padding of\nthe cells' value arrays (RP_TRAV_CELL_PAD).  A prediction to be checked against SQ_LDS_BANK_CONFLICT, not a measurement."""
+"""LDS bank model of k_traverse_maps_static's chain loop: the lists of real Leduc chunks (the oracle's Decisions), 32-lane
+groups of (cell, infoset) tasks in the kernel's order, one ds_read_b32 per step — cycles = the fullest bank of each group — for
+every padding of the cells' value arrays (RP_TRAV_CELL_PAD).  A prediction to be checked against SQ_LDS_BANK_CONFLICT, not a
+measurement."""
 import sys
 import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R, os.path.join(R, 'tests')]
 import numpy as np, oracle
