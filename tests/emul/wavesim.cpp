@@ -74,6 +74,9 @@ struct Worker {
     body_fn fn = nullptr;
     void* ctx = nullptr;
     std::vector<unsigned char> dyn;
+    char* strict_map = nullptr;  // RP_EMUL_LDS_STRICT
+    size_t strict_len = 0;
+    char* strict_dyn = nullptr;
     const char* kernel = "";
     ~Worker() {
         if (stacks) munmap(stacks, STACK_BYTES * MAX_THREADS);
@@ -297,6 +300,23 @@ struct Job {
         // the LDS aperture: a read past the workgroup's allocation returns junk on the device, it does not fault (the
         // traversal's software pipeline reads a few slots past its arrays by design) — keep a wide margin mapped
         if (w.dyn.size() < ((size_t)1 << 20) + shmem) w.dyn.assign(((size_t)1 << 20) + shmem, 0xA5);
+        // RP_EMUL_LDS_STRICT=1: the dynamic LDS ends at an inaccessible page instead (a kernel that indexes past what the host asked
+        // for faults; k_traverse_lds' look-ahead reads do so by design — leave it out of such a run)
+        static const bool strict = getenv("RP_EMUL_LDS_STRICT") != nullptr;
+        if (strict) {
+            const size_t page = 4096, body = (shmem + 15) & ~(size_t)15, span = ((body + page - 1) & ~(page - 1)) + page;
+            if (w.strict_len < span + page) {
+                if (w.strict_map) munmap(w.strict_map, w.strict_len);
+                w.strict_len = span + page;
+                w.strict_map = static_cast<char*>(mmap(nullptr, w.strict_len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+            } else {
+                mprotect(w.strict_map, w.strict_len, PROT_READ | PROT_WRITE);
+            }
+            mprotect(w.strict_map + span - page, w.strict_len - (span - page), PROT_NONE);
+            w.strict_dyn = w.strict_map + (span - page) - body;
+        } else {
+            w.strict_dyn = nullptr;
+        }
         blockDim = block;
         gridDim = grid;
         for (;;) {
@@ -408,7 +428,7 @@ void syncthreads() {
 
 unsigned lane() { return tl_worker->cur->lin & 63u; }
 
-void* dyn_smem() { return tl_worker->dyn.data(); }
+void* dyn_smem() { return tl_worker->strict_dyn ? static_cast<void*>(tl_worker->strict_dyn) : static_cast<void*>(tl_worker->dyn.data()); }
 
 void launch(dim3 grid, dim3 block, size_t shmem, const char* name, body_fn fn, void* ctx) {
     const uint64_t nblocks = (uint64_t)grid.x * grid.y * grid.z;
