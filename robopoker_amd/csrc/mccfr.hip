@@ -1677,7 +1677,7 @@ struct rp_mccfr {
     bool use_lds_traverse = false;
     // the per-infoset tables of the traversal (DevInfoTab) are a function of the regret/strategy tables: refreshed when stale
     uint64_t tables_version = 1, itab_version = 0;
-    uint32_t cell_pad = 0;  // RP_TRAV_CELL_PAD (0..31): words between the cells' value arrays in k_traverse_maps_static's LDS (bank spread)
+    uint32_t cell_pad = 7;  // RP_TRAV_CELL_PAD (0..31): words between the cells' value arrays in k_traverse_maps_static's LDS (bank spread)
     bool fuse_maps = true;  // composed update: traversal + block maps in one kernel when the game allows (RP_TRAV_UNFUSED=1: never)
     int static_skel = 0;  // 0: none (k_traverse_lds / k_traverse), 1: KuhnSkel, 2: LeducSkel (traverse_static.hpp)
     bool static_pruned = true;  // RP_TRAV_STATIC_EXTERNAL_ONLY=1: the pruned schemes keep k_traverse_lds (cross-check)

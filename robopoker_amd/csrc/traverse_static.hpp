@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 4) void k_traverse_maps_static(DevGame g, DevI
     uint16_t* order = pre + NI * 8u;
     float* vals = reinterpret_cast<float*>(order + NI + (NI & 1u));
     // places per cell.  The five chains of an infoset read vals[c L + base + e] in the same instruction: with L a multiple of 32 they
-    // share a bank (a 5-way conflict at every step); lpad (RP_TRAV_CELL_PAD, 0 by default until measured) moves the cells apart
+    // share a bank (a 5-way conflict at every step); lpad (RP_TRAV_CELL_PAD, 7 words by default) moves the cells apart
     const uint32_t L = maxdec * 256u + lpad;
     uint32_t* lmask = reinterpret_cast<uint32_t*>(vals + 5u * L);
     for (uint32_t e = lt; e < NI * 8u; e += 256u) bits[e] = 0;
