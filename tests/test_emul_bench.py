@@ -89,3 +89,37 @@ def test_bench_nlhe_two_ranks_prints_one_contract_line(built):
     assert len(lines) == 1, res[0][1][-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["workload"]
+
+
+KMEANS_MAIN = """
+import os, sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, {emul!r})
+import harness
+harness.load_emulated(build=False)
+import bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+bench.init_rccl(rank, world, "gloo")
+out = bench.kmeans_sharded(rank, world, 0, n_points=96, K=6, bins=32, iters=2)
+if rank == 0:
+    print(json.dumps(out))
+import torch.distributed as dist
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_bench_kmeans_exchange_two_ranks(built):
+    # what the driver's N > 1 launch runs after the contract line (stderr, under a watchdog): k-means++ across the ranks, two Elkan
+    # iterations with the integer all-reduce — here at a size the execution model finishes in seconds
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RP_EMUL_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, "-c", KMEANS_MAIN.format(root=ROOT, emul=EMUL)], cwd=ROOT, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    line = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
