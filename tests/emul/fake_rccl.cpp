@@ -19,7 +19,7 @@
 
 namespace {
 constexpr int MAX_WORLD = 16;
-constexpr size_t SLOT_BYTES = (size_t)1 << 30;  // per rank, sparse: only what a collective touches is ever committed
+constexpr size_t SLOT_BYTES = (size_t)64 << 20;  // per rank, sparse: only what a collective touches is ever committed (a larger one fails)
 
 struct Header {
     std::atomic<uint32_t> arrived;
