@@ -1677,6 +1677,7 @@ struct rp_mccfr {
     bool use_lds_traverse = false;
     // the per-infoset tables of the traversal (DevInfoTab) are a function of the regret/strategy tables: refreshed when stale
     uint64_t tables_version = 1, itab_version = 0;
+    bool split_payoff = false;  // RP_TRAV_SPLIT_PAYOFF=1: k_traverse_maps_static hands the payoff sums out after the map chains
     uint32_t cell_pad = 7;  // RP_TRAV_CELL_PAD (0..31): words between the cells' value arrays in k_traverse_maps_static's LDS (bank spread)
     bool fuse_maps = true;  // composed update: traversal + block maps in one kernel when the game allows (RP_TRAV_UNFUSED=1: never)
     int static_skel = 0;  // 0: none (k_traverse_lds / k_traverse), 1: KuhnSkel, 2: LeducSkel (traverse_static.hpp)
@@ -2076,10 +2077,10 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev, bool fuse
     do {                                                                                                                               \
         if (pruned)                                                                                                                    \
             hipLaunchKernelGGL((k_traverse_maps_static<G, WK, true>), dim3(nblk), dim3(256), lds, h->stream, h->g, h->itab, p, bmaps, \
-                               bpsum, bcnt, nblk_max, h->maxdec, h->cell_pad);                                                         \
+                               bpsum, bcnt, nblk_max, h->maxdec, h->cell_pad | (h->split_payoff ? 256u : 0u));                         \
         else                                                                                                                           \
             hipLaunchKernelGGL((k_traverse_maps_static<G, WK, false>), dim3(nblk), dim3(256), lds, h->stream, h->g, h->itab, p, bmaps, \
-                               bpsum, bcnt, nblk_max, h->maxdec, h->cell_pad);                                                         \
+                               bpsum, bcnt, nblk_max, h->maxdec, h->cell_pad | (h->split_payoff ? 256u : 0u));                         \
     } while (0)
         if (h->static_skel == 1) {
             if (p.walker == 0) LAUNCH_FUSED(KuhnSkel, 0);
@@ -2332,6 +2333,7 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
     }
     h->use_lds_traverse = traverse_fits_lds(h) && getenv("RP_MCCFR_HBM_SCRATCH") == nullptr;
     h->fuse_maps = getenv("RP_TRAV_UNFUSED") == nullptr;
+    h->split_payoff = getenv("RP_TRAV_SPLIT_PAYOFF") != nullptr;
     if (getenv("RP_TRAV_CELL_PAD")) h->cell_pad = (uint32_t)std::min(31, std::max(0, atoi(getenv("RP_TRAV_CELL_PAD"))));
     h->static_pruned = getenv("RP_TRAV_STATIC_EXTERNAL_ONLY") == nullptr;
     if (h->use_lds_traverse && getenv("RP_TRAV_GENERIC") == nullptr) {

@@ -77,5 +77,7 @@ except Exception as e:
     print("pad $pad: no line:", e)
 PY
 done
-RP_TRAV_CELL_PAD=7 timeout 120 python -m pytest tests/test_gpu_mccfr.py -m gpu -q -x -k "composed or static or bench_sized" 2>&1 | tail -2
+RP_TRAV_SPLIT_PAYOFF=1 timeout 60 python bench.py --no-extras --steps 40 --warmup 5 > $OUT/${TAG}_bench_split_payoff.json 2>/dev/null
+python -c "import json; d=json.load(open('$OUT/${TAG}_bench_split_payoff.json')); print('split payoff:', round(d['value']/1e9,2), 'G/s', d['roofline']['kernels_ms'])" 2>/dev/null
+RP_TRAV_SPLIT_PAYOFF=1 timeout 120 python -m pytest tests/test_gpu_mccfr.py -m gpu -q -x -k "composed or static or bench_sized" 2>&1 | tail -2
 date +%T
