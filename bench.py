@@ -209,6 +209,38 @@ def side_rate(args, g, local_rank, mode, steps=10):
     return (i1 - i0) / dt
 
 
+def strong_scaling_projection(args, local_rank, ms_single, ranks=8, window=4, timeout=120):
+    """A PROJECTION, labelled as such: what the timed step would take spread over `ranks` GPUs.  Measured, on this one GPU: a rank's
+    share of the step (batch / ranks trees) through the sharded code path — exchange windows, the library's own communicator and a
+    real all-gather, with a world of one (`bench.py --force-sharded` in a child process under a timeout: a collective that hung
+    must not take the contract line with it).  Assumed: the wire.  An exchange moves ranks x the per-rank summary (8.6 KB for
+    Leduc) once per window; at that size an xGMI all-gather is latency, taken as 20 us per exchange."""
+    import subprocess
+
+    share = max(64, args.batch // ranks)
+    cmd = [sys.executable, os.path.abspath(__file__), "--force-sharded", "--no-extras", "--batch", str(share), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--window", str(window), "--game", args.game, "--regret", args.regret, "--weight", args.weight,
+           "--sampling", args.sampling, "--update", "composed", "--seed", str(args.seed), "--dist-backend", args.dist_backend]
+    import socket
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, LOCAL_RANK=str(local_rank), RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"child exited {r.returncode}: {r.stderr[-300:]}")
+    child = json.loads(lines[-1])
+    share_ms = child["ms_per_step"]
+    wire_ms = 0.020 / window
+    return {"kind": "projection (one GPU measured, the wire assumed)", "ranks": ranks, "scaling": "strong",
+            "batch_per_rank": share, "measured_ms_per_step_of_a_rank_share": share_ms, "exchange_window": window,
+            "assumed_exchange_ms_per_step": wire_ms, "single_gpu_ms_per_step": ms_single,
+            "projected_speedup": ms_single / (share_ms + wire_ms)}
+
+
 def init_rccl(rank, world, backend="nccl"):
     """init_process_group + communicator creation with fd 1 pointed at stderr: RCCL prints a version banner to stdout
     when the communicator is created, and stdout must carry exactly one JSON line."""
@@ -877,6 +909,10 @@ def main():
             line["other_scaling"] = other_scaling
         if world == 1 and not args.force_sharded and args.game == "leduc" and not args.no_extras:
             line["convergence"] = convergence(args, g, local_rank)
+            try:
+                line["strong_scaling_projection"] = strong_scaling_projection(args, local_rank, dt / args.steps * 1e3)
+            except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
+                line["strong_scaling_projection"] = {"error": f"{type(exc).__name__}: {exc}"}
             try:
                 line["time_to_exploitability"] = convergence_times(args, g, local_rank)
             except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)

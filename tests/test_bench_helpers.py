@@ -34,3 +34,38 @@ def test_profiled_traffic_averages_template_instances_and_sums_kernels():
     assert abs(total - (sum(inst) / len(inst) + sum(prep))) < 1.0
     none, _ = b.profiled_traffic(("traverse", doc["update"]), doc["batch"] + 1)
     assert none is None
+
+
+def test_strong_scaling_projection_runs_a_child_and_labels_its_result(monkeypatch):
+    # the 8-GPU figure of the default line is a projection: one rank's share measured by a child `bench.py --force-sharded` (so that
+    # a hung collective cannot take the contract line along), the wire assumed and said so
+    import argparse
+    import subprocess
+
+    b = _bench()
+    seen = {}
+
+    def fake_run(cmd, env=None, capture_output=None, text=None, timeout=None):
+        seen["cmd"], seen["env"], seen["timeout"] = cmd, env, timeout
+        out = "banner\n" + json.dumps({"metric": "mccfr_infoset_updates_per_sec", "ms_per_step": 0.125, "n_gpus": 1}) + "\n"
+        return subprocess.CompletedProcess(cmd, 0, stdout=out, stderr="")
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    args = argparse.Namespace(batch=1 << 23, steps=20, warmup=5, game="leduc", regret="linear", weight="linear", sampling="external",
+                              seed=7, dist_backend="nccl")
+    p = b.strong_scaling_projection(args, 0, ms_single=0.75)
+    assert "projection" in p["kind"] and p["ranks"] == 8 and p["batch_per_rank"] == 1 << 20
+    assert abs(p["projected_speedup"] - 0.75 / (0.125 + 0.020 / 4)) < 1e-12
+    cmd = seen["cmd"]
+    assert "--force-sharded" in cmd and "--no-extras" in cmd and cmd[cmd.index("--batch") + 1] == str(1 << 20)
+    assert seen["env"]["WORLD_SIZE"] == "1" and seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["timeout"]
+
+    def failing_run(cmd, **kw):
+        return subprocess.CompletedProcess(cmd, 3, stdout="", stderr="no device")
+
+    monkeypatch.setattr(subprocess, "run", failing_run)
+    try:
+        b.strong_scaling_projection(args, 0, ms_single=0.75)
+        raise AssertionError("a failed child must raise (the caller records the error in the line)")
+    except RuntimeError as exc:
+        assert "child exited 3" in str(exc)
