@@ -896,6 +896,7 @@ def main():
                 "avg_launch_ms": dom_ms,
                 "kernels_ms": {"traverse": trav_avg_ms, "compact": m["compact_ms"], "update": upd_avg_ms},
                 "traversal_kernel": m.get("variant"),
+                "lds_cell_pad": int(os.environ.get("RP_TRAV_CELL_PAD", "7")),  # words between the chain phase's per-cell arrays
                 "note": "achieved = SURVEY §8d's 24 + 32 A bytes per infoset-update x the updates of one launch / the "
                         "dominant kernel's event-timed duration.  Leduc's tables are 3.8 KB (L2 resident) and in the "
                         "composed mode the Decisions never reach HBM (traversal + block maps are one kernel: PMC traffic is "
