@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
+
+extern "C" unsigned emu_host_threads(void);
 
 namespace {
 
@@ -65,6 +68,29 @@ __global__ void k_blocks(uint32_t* counter, uint32_t* per_block /* [grid] */) {
     __syncthreads();
     if (threadIdx.x == 0) per_block[blockIdx.x] = local + dyn[blockDim.x - 1u];
     atomicAdd(counter, 1u);
+}
+
+// wave-synchronous exchange through LDS: legal only with a wave_barrier between the store and the load
+__global__ void k_wave_barrier(uint32_t* out /* [128] */) {
+    __shared__ uint32_t box[128];
+    const uint32_t tid = threadIdx.x;
+    box[tid] = tid + 1000u;
+    __builtin_amdgcn_wave_barrier();
+    out[tid] = box[tid ^ 63u];  // the mirror lane of the own wavefront
+}
+// __any / __all under a partial mask; a workgroup waiting for another one's flag (workgroups run side by side)
+__global__ void k_votes_and_flags(uint32_t* out /* [64] */, uint32_t* flag, uint32_t* order /* [2] */) {
+    const uint32_t lane = threadIdx.x;
+    if (blockIdx.x == 0) {
+        if (lane < 40u) out[lane] = (__any(lane == 39u) ? 1u : 0u) | (__all(lane < 40u) ? 2u : 0u) | (__all(lane < 39u) ? 4u : 0u);
+        else out[lane] = 8u;
+        if (lane == 0) {
+            while (atomicAdd(flag, 0u) == 0u) {}  // set by workgroup 1
+            order[0] = atomicAdd(flag, 1u);
+        }
+    } else if (lane == 0) {
+        order[1] = atomicAdd(flag, 1u);
+    }
 }
 
 template <class T>
@@ -145,6 +171,22 @@ extern "C" __attribute__((visibility("default"))) int emu_selfcheck(void) {
         for (uint32_t b = 0; b < grid; ++b) CHECK("per-workgroup LDS", b, per[b], block * (block - 1u) / 2u + b);
         (void)hipFree(counter);
         (void)hipFree(per);
+    }
+    {
+        uint32_t* out = dev<uint32_t>(128);
+        hipLaunchKernelGGL(k_wave_barrier, dim3(1), dim3(128), 0, nullptr, out);
+        for (uint32_t t = 0; t < 128; ++t) CHECK("wave_barrier exchange", t, out[t], (t ^ 63u) + 1000u);
+        (void)hipFree(out);
+    }
+    if (emu_host_threads() > 1) {  // the flag test needs two workgroups in flight
+        uint32_t *out = dev<uint32_t>(64), *flag = dev<uint32_t>(1), *order = dev<uint32_t>(2);
+        hipLaunchKernelGGL(k_votes_and_flags, dim3(2), dim3(64), 0, nullptr, out, flag, order);
+        for (uint32_t l = 0; l < 64; ++l) CHECK("any / all under a partial mask", l, out[l], (l < 40u ? 3u : 8u));
+        CHECK("flag order", 0, order[1], 0u);
+        CHECK("flag order", 1, order[0], 1u);
+        (void)hipFree(out);
+        (void)hipFree(flag);
+        (void)hipFree(order);
     }
     return bad;
 }

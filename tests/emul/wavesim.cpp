@@ -598,4 +598,5 @@ __attribute__((visibility("default"))) void emu_stats(uint64_t* launches, uint64
     *blocks = emu::g_stats.blocks;
 }
 __attribute__((visibility("default"))) uint64_t emu_split_rounds(void) { return emu::g_split_rounds.load(); }
+__attribute__((visibility("default"))) unsigned emu_host_threads(void) { return emu::host_threads(); }
 }
