@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "nlmc_level.hpp"
@@ -628,9 +629,13 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     // opponent's average strategy calls and raises more than the warm-start bias: 760 per tree after a few steps on the trained
     // abstraction): 1 536 per tree of budget, 92 B each (the batch's total is what counts)
     const uint64_t dec_cap64 = std::max<uint64_t>((uint64_t)batch * 160u, 4096u);
-    // RP_NLHE_NODE_BUDGET: nodes per tree of budget (tests of the chunked retry)
-    const uint64_t per_tree = getenv("RP_NLHE_NODE_BUDGET") ? (uint64_t)std::max(64, atoi(getenv("RP_NLHE_NODE_BUDGET"))) : 1536u;
-    const uint64_t ncap64 = getenv("RP_NLHE_NODE_BUDGET") ? (uint64_t)batch * per_tree : std::max<uint64_t>((uint64_t)batch * per_tree, 1u << 17);
+    // RP_NLHE_NODE_BUDGET = "<nodes per tree>[,<walker divisor>]" (tests of the chunked retry): the node budget per tree, and the
+    // share of it the walker-node arrays hold (a quarter by default: ",16" makes a pass overflow THOSE arrays with nodes to spare)
+    const char* budget_env = getenv("RP_NLHE_NODE_BUDGET");
+    const uint64_t per_tree = budget_env ? (uint64_t)std::max(64, atoi(budget_env)) : 1536u;
+    uint64_t walker_div = 4;
+    if (budget_env && strchr(budget_env, ',')) walker_div = (uint64_t)std::min(4096, std::max(1, atoi(strchr(budget_env, ',') + 1)));
+    const uint64_t ncap64 = budget_env ? (uint64_t)batch * per_tree : std::max<uint64_t>((uint64_t)batch * per_tree, 1u << 17);
     if (dec_cap64 >= (1ull << 31) || ncap64 >= (1ull << 32)) {
         delete h;
         return rp::fail(RP_ERR_INVALID, "rp_nlhe_create: batch too large (at most %u trees per step)", (uint32_t)((1ull << 32) / 1536u));
@@ -686,7 +691,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
         NL_TRY(nl_alloc(h, &h->d_counters, 4));
     } else {
         NlNodes& lv = h->lv;
-        const size_t N = (size_t)ncap64, LC = N / 4;  // walker nodes of a batch (a seventh of its nodes): a quarter of the node budget
+        const size_t N = (size_t)ncap64, LC = std::max<size_t>(N / walker_div, 64);  // walker nodes of a batch (a seventh of its nodes): a quarter of the node budget
         lv.ncap = (uint32_t)N;
         lv.lcap = (uint32_t)LC;
         NL_TRY(nl_alloc(h, &lv.link, N)); NL_TRY(nl_alloc(h, &lv.tree, N)); NL_TRY(nl_alloc(h, &lv.meta, N));

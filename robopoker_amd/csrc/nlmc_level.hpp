@@ -644,6 +644,15 @@ template <uint32_t CAP>
 __device__ __forceinline__ void nl_group_tree(const NlNodes& nd, uint32_t tree, uint32_t n, uint32_t lane, uint64_t* key, uint32_t* key2,
                                               uint16_t* hp) {
     const uint32_t off = nd.t_woff[tree];
+    // wl / ws / gdesc hold lcap entries: a pass with more walker nodes than that is a spent node budget (the host retries it in
+    // more, smaller passes); the whole wavefront leaves together, before the first barrier, and nothing past the arrays is touched
+    if (off + n > nd.lcap) {
+        if (lane == 0) {
+            nd.t_dcount[tree] = 0;
+            atomicOr(&nd.ctl->err, NERR_NODES);
+        }
+        return;
+    }
     uint32_t P = 64;
     while (P < n) P <<= 1;
     for (uint32_t i = lane; i < P; i += 64) {

@@ -81,3 +81,17 @@ RP_TRAV_SPLIT_PAYOFF=1 timeout 60 python bench.py --no-extras --steps 40 --warmu
 python -c "import json; d=json.load(open('$OUT/${TAG}_bench_split_payoff.json')); print('split payoff:', round(d['value']/1e9,2), 'G/s', d['roofline']['kernels_ms'])" 2>/dev/null
 RP_TRAV_SPLIT_PAYOFF=1 timeout 120 python -m pytest tests/test_gpu_mccfr.py -m gpu -q -x -k "composed or static or bench_sized" 2>&1 | tail -2
 date +%T
+echo "== 9 the shipped Leduc loop's PMC passes (FETCH / WRITE / two SQ groups), each its own run under its own timeout"; date +%T
+cd /tmp && export TMPDIR=/tmp
+rm -rf $OUT/fetch $OUT/write $OUT/sq1 $OUT/sq2
+timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o pmc -- $BENCH > $OUT/fetch.log 2>&1
+timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o pmc -- $BENCH > $OUT/write.log 2>&1
+python $REPO/scripts/pmc_traffic.py $OUT/fetch/pmc_counter_collection.csv $OUT/write/pmc_counter_collection.csv \
+    $OUT/${TAG}_mccfr_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of: $BENCH; FETCH_SIZE doubled (gfx950), KiB -> bytes" 8388608 composed
+timeout 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY \
+  --kernel-trace --output-format csv -d $OUT/sq1 -o pmc -- $BENCH > $OUT/sq1.log 2>&1
+timeout 120 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA \
+  --kernel-trace --output-format csv -d $OUT/sq2 -o pmc -- $BENCH > $OUT/sq2.log 2>&1
+python $REPO/scripts/sq_reduce.py $OUT/${TAG}_mccfr_sq_counters.json "$BENCH" $OUT/sq1/pmc_counter_collection.csv $OUT/sq2/pmc_counter_collection.csv
+rm -rf $OUT/fetch $OUT/write $OUT/sq1 $OUT/sq2
+date +%T
