@@ -191,6 +191,27 @@ def profiled_traffic(group, batch):
     return (total if per_name else None), os.path.basename(files[-1])
 
 
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2.0  # 4 SIMD-32 per CU, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
+
+
+def profiled_valu(group):
+    """Wave-level VALU instructions per launch of a kernel group from the newest committed SQ counter reduction
+    (scripts/round_start.sh step 9: rocprofv3 --pmc SQ_INSTS_VALU ... of this same command), or None."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mccfr_sq_counters.json")))
+    if not files:
+        return None, None
+    doc = json.load(open(files[-1]))
+    per_name = {}
+    for name, v in doc["kernels"].items():
+        if any(k in name for k in KERNEL_GROUPS[group]) and v.get("dispatches"):
+            base = name.split("(")[0].split("<")[0].replace("void ", "")
+            per_name.setdefault(base, []).append(v["counters"].get("SQ_INSTS_VALU", 0.0) / v["dispatches"])
+    total = sum(sum(v) / len(v) for v in per_name.values())
+    return (total if per_name else None), os.path.basename(files[-1])
+
+
 def side_rate(args, g, local_rank, mode, steps=10):
     """The other update mode's rate on the same workload, reported beside `value` for transparency."""
     from robopoker_amd.mccfr import Solver
@@ -864,6 +885,37 @@ def main():
         other = "ordered" if args.update == "composed" else "composed"
         args.batch = batch
         other_rate = side_rate(args, g, local_rank, other) if world == 1 and not args.force_sharded and not args.no_extras else None
+        valu_instr, valu_src = profiled_valu(dom)
+        hbm_alg = {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                   "bytes_per_update": bytes_per_update,
+                   "note": "SURVEY §8d's 24 + 32 A algorithmic bytes per infoset-update x the updates of one launch / the "
+                           "dominant kernel's event-timed duration: a nominal figure — these bytes never reach HBM here "
+                           "(see hbm_frac_measured)"}
+        hbm_measured = traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if traffic and dom_ms > 0 else None
+        composed_small = args.update == "composed" and dom == "traverse"
+        if composed_small and valu_instr:
+            # Leduc's tables are 3.8 KB (L2 resident) and in the composed mode the Decisions never reach HBM (traversal + block
+            # maps are one kernel): the kernel is priced against what binds it, VALU issue
+            rate = valu_instr / (dom_ms * 1e-3)
+            roofline_obj = {"bound": "valu", "kernel": dom, "achieved": rate, "peak": VALU_PEAK_WAVE_INSTR,
+                            "unit": "wave-instructions/s", "frac": rate / VALU_PEAK_WAVE_INSTR,
+                            "valu_instructions_per_launch": valu_instr, "valu_source": valu_src,
+                            "valu_note": "SQ_INSTS_VALU per launch from the committed rocprofv3 --pmc reduction named in "
+                                         "valu_source (a separate profiling run of this command at this batch) / this run's "
+                                         "event-timed launch duration; peak = 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 "
+                                         "instruction",
+                            "lane_instructions_per_update": valu_instr * 64.0 / per_launch_updates if per_launch_updates else None}
+        else:
+            roofline_obj = {"bound": "hbm", "kernel": dom, **{k: hbm_alg[k] for k in ("achieved", "peak", "unit", "frac")}}
+        roofline_obj.update({
+            "traffic": traffic, "traffic_source": traffic_src, "hbm_frac_measured": hbm_measured,
+            "traffic_note": "PMC bytes per launch read from the committed rocprofv3 --pmc reduction named in "
+                            "traffic_source (a separate profiling run at this batch), not measured in this run; "
+                            "hbm_frac_measured = traffic / avg_launch_ms / 8 TB/s",
+            "hbm_algorithmic": hbm_alg, "updates_per_launch": per_launch_updates, "avg_launch_ms": dom_ms,
+            "kernels_ms": {"traverse": trav_avg_ms, "compact": m["compact_ms"], "update": upd_avg_ms},
+            "traversal_kernel": m.get("variant"),
+        })
         line = {
             "metric": "mccfr_infoset_updates_per_sec",
             "value": infos / dt,
@@ -887,23 +939,7 @@ def main():
                                     "order (tests/test_gpu_mccfr.py), visits exact; ordered: bit-exact",
                 "parallelism": f"tree-sharded x{world}",
             },
-            "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                "traffic_note": "PMC bytes per launch read from the committed rocprofv3 --pmc reduction named in "
-                                "traffic_source (a separate profiling run at this batch), not measured in this run",
-                "bytes_per_update": bytes_per_update, "updates_per_launch": per_launch_updates,
-                "avg_launch_ms": dom_ms,
-                "kernels_ms": {"traverse": trav_avg_ms, "compact": m["compact_ms"], "update": upd_avg_ms},
-                "traversal_kernel": m.get("variant"),
-                "lds_cell_pad": int(os.environ.get("RP_TRAV_CELL_PAD", "7")),  # words between the chain phase's per-cell arrays
-                "note": "achieved = SURVEY §8d's 24 + 32 A bytes per infoset-update x the updates of one launch / the "
-                        "dominant kernel's event-timed duration.  Leduc's tables are 3.8 KB (L2 resident) and in the "
-                        "composed mode the Decisions never reach HBM (traversal + block maps are one kernel: PMC traffic is "
-                        "far BELOW the algorithmic bytes), so HBM is not the binding limit of this configuration: the "
-                        "skeleton-instantiated traversal is bound by VALU issue (profiles/: SQ counters), the ordered "
-                        "update by its serial per-cell chains",
-            },
+            "roofline": roofline_obj,
             "other_update_mode": {"update": other, "value": other_rate, "unit": "infoset-updates/s"},
         }
         if other_scaling is not None:

@@ -1,0 +1,67 @@
+/* rp_oracle_refrng.c — TEST INFRASTRUCTURE: exports of include/rp_refrng.h's pieces (SipHash-c-d, SplitMix64, xoshiro256++,
+ * rand 0.9.2's three draws) so that tests/test_refrng.py can check each against its published vectors and an independent
+ * Python restatement.  The reference call sites they stand for: crates/mccfr/src/strategy/flow.rs:285-295,
+ * sample/external.rs:41-64, sample/mod.rs:68-82, sample/pluribus.rs:91, crates/lloyd/src/layer.rs:155-178. */
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../include/rp_refrng.h"
+
+#define ORA_API __attribute__((visibility("default")))
+
+ORA_API uint64_t ora_siphash(uint64_t k0, uint64_t k1, const uint8_t* msg, uint32_t n, int c, int d) {
+    rp_sip s;
+    rp_sip_init(&s, k0, k1);
+    rp_sip_write(&s, msg, n, c);
+    return rp_sip_finish(&s, c, d);
+}
+/* DefaultHasher over a sequence of integer writes: widths[i] in {1, 2, 8} bytes */
+ORA_API uint64_t ora_defaulthasher_ints(const uint64_t* vals, const uint8_t* widths, uint32_t n) {
+    rp_sip s;
+    rp_defaulthasher_new(&s);
+    for (uint32_t i = 0; i < n; ++i) rp_sip_write_le(&s, vals[i], widths[i], 1);
+    return rp_defaulthasher_finish(&s);
+}
+ORA_API void ora_splitmix64(uint64_t seed, uint64_t* out, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i) out[i] = rp_splitmix64_next(&seed);
+}
+ORA_API void ora_xoshiro256pp(const uint64_t* state, uint64_t* out, uint32_t n) {
+    rp_smallrng r;
+    for (int i = 0; i < 4; ++i) r.s[i] = state[i];
+    for (uint32_t i = 0; i < n; ++i) out[i] = rp_smallrng_next_u64(&r);
+}
+ORA_API void ora_smallrng_seeded(uint64_t seed, uint64_t* out, uint32_t n) {
+    rp_smallrng r;
+    rp_smallrng_seed(&r, seed);
+    for (uint32_t i = 0; i < n; ++i) out[i] = rp_smallrng_next_u64(&r);
+}
+ORA_API float ora_ref_draw_f32(uint64_t seed) { return rp_ref_draw_f32(seed); }
+ORA_API uint32_t ora_ref_draw_range(uint64_t seed, uint32_t n) { return rp_ref_draw_range(seed, n); }
+ORA_API float ora_ref_draw_weight(uint64_t seed, float total) { return rp_ref_draw_weight(seed, total); }
+ORA_API float ora_uniform_f32_scale(float total) { return rp_uniform_f32_scale(total); }
+/* a generator that keeps going (k-means++ takes K draws from one): state in/out */
+ORA_API uint32_t ora_smallrng_range(uint64_t* state, uint32_t n) {
+    rp_smallrng r;
+    for (int i = 0; i < 4; ++i) r.s[i] = state[i];
+    const uint32_t v = rp_rand_range_u32(&r, n);
+    for (int i = 0; i < 4; ++i) state[i] = r.s[i];
+    return v;
+}
+ORA_API uint64_t ora_ref_node_seed(uint64_t t, const uint8_t* info_bytes, uint32_t n, uint64_t tree_id) {
+    return rp_ref_node_seed(t, info_bytes, n, tree_id);
+}
+/* WeightedIndex::<f32>::new(weights).sample(rng) with a fresh SmallRng::seed_from_u64(seed); cum is scratch of n floats */
+ORA_API uint32_t ora_ref_weighted_index(uint64_t seed, const float* w, uint32_t n) {
+    float total = w[0];
+    uint32_t idx = 0;
+    /* first pass: total; second: partition_point over the n - 1 cumulative sums */
+    for (uint32_t i = 1; i < n; ++i) total += w[i];
+    const float x = rp_ref_draw_weight(seed, total);
+    float run = w[0];
+    for (uint32_t i = 0; i + 1 < n; ++i) {
+        if (run <= x) idx = i + 1;
+        else break;
+        run += w[i + 1];
+    }
+    return idx;
+}
