@@ -137,7 +137,9 @@ typedef struct rp_encounter {
 typedef struct rp_state {
     uint8_t turn;       /* acting player 0..n_players-1, RP_TURN_CHANCE or RP_TURN_TERMINAL */
     uint8_t n_children; /* branching factor (0 for terminals)                                */
-    uint16_t reserved;
+    uint16_t chance_info; /* chance states, reference-seed mode only: 1 + index of the node's info among rp_hash_streams.chance;
+                             0 = this chance state has no counterpart in the reference's trees (the root deal, which the
+                             reference takes from the thread RNG, kuhn/src/game.rs:115-123) and keeps the counter hash   */
     uint32_t info;      /* infoset id at player states, RP_NO_INFO otherwise                  */
     uint32_t offset;    /* player/chance: first child in children[]; terminal: row in payoffs */
 } rp_state;
@@ -177,6 +179,33 @@ RP_API int rp_game_info_name(const rp_game* g, uint32_t info, char* buf, size_t 
 RP_API int rp_game_table_check(const rp_game_table* t);
 
 typedef struct rp_mccfr rp_mccfr;
+
+/* ---- which generator draws the sampled branches ------------------------------------------------------------------------------
+ * RP_RNG_COUNTER (default): one 64-bit counter hash per (seed, epoch, tree, infoset), include/rp_math.h rp_node_hash — the
+ *   build's own definition, cheap on the device.
+ * RP_RNG_REFERENCE ("reference-seed" mode): the reference's own chain, restated from the published algorithms in
+ *   include/rp_refrng.h: DefaultHasher (SipHash-1-3, zero key) over t.hash(), info.hash(), node.seed().hash()
+ *   (crates/mccfr/src/strategy/flow.rs:285-295) -> SmallRng::seed_from_u64 (xoshiro256++) -> one draw: WeightedIndex<f32> at an
+ *   opponent node (sample/external.rs:41-64), random_range(0..n) at a chance node (sample/mod.rs:68-82), random::<f32>() for
+ *   Pluribus' exploration coin (sample/pluribus.rs:91).  `t` = the epoch, node.seed() = the tree's index in the batch
+ *   (solver.rs: the par_iter index), info.hash() = the byte stream the caller's `impl Hash for I` writes, handed over once as
+ *   rp_hash_streams (INTEGRATION.md shows the ten-line recording Hasher that produces it from any CfrInfo).  The library's
+ *   `seed` then only enters the root deal, which the reference leaves to the unseeded thread RNG. */
+typedef enum rp_rng_kind { RP_RNG_COUNTER = 0, RP_RNG_REFERENCE = 1 } rp_rng_kind;
+#define RP_HASH_STREAM_MAX 55u
+typedef struct rp_hash_stream {
+    uint8_t len;                       /* bytes written by I::hash                          */
+    uint8_t bytes[RP_HASH_STREAM_MAX]; /* in write order                                    */
+} rp_hash_stream;
+typedef struct rp_hash_streams {
+    uint32_t n_infos;              /* = rp_game_table.n_infos                                     */
+    uint32_t n_chance;             /* distinct infos of in-tree chance nodes                      */
+    const rp_hash_stream* infos;   /* [n_infos]                                                   */
+    const rp_hash_stream* chance;  /* [n_chance], indexed by rp_state.chance_info - 1             */
+} rp_hash_streams;
+/* the streams of a built-in game (kuhn/src/info.rs:20-24,71; leduc/src/info.rs:11-17,85; roshambo/src/turn.rs:10-18) */
+RP_API int rp_game_hash_streams(const rp_game* g, rp_hash_streams* out); /* pointers valid until destroy */
+RP_API int rp_mccfr_set_rng(rp_mccfr* h, rp_rng_kind kind, const rp_hash_streams* streams /* NULL for RP_RNG_COUNTER */);
 
 typedef enum rp_update_mode {
     RP_UPDATE_ORDERED = 0, /* per-key sequential application in tree-id order: solver.rs:96-105 exactly */

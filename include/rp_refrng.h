@@ -196,13 +196,6 @@ RP_HD float rp_ref_draw_weight(uint64_t seed, float total) {
 }
 
 /* ------------------------------------------------------------------------------------------ the node's seed ---------------- */
-/* Hash::hash byte stream of an infoset, as the caller's `impl Hash` writes it (INTEGRATION.md shows the recording Hasher) */
-#define RP_HASH_STREAM_MAX 55u
-typedef struct rp_hash_stream {
-    uint8_t len;
-    uint8_t bytes[RP_HASH_STREAM_MAX];
-} rp_hash_stream;
-
 /* DefaultHasher after t.hash() and info.hash(): every node of the step that shares the infoset continues from here */
 typedef struct rp_sip_mid {
     uint64_t v0, v1, v2, v3;

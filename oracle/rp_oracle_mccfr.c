@@ -30,6 +30,7 @@
 
 #include "../include/rp_math.h"
 #include "../include/rp_mi355x.h"
+#include "../include/rp_refrng.h"
 
 #define ORA_MAXA 16
 
@@ -67,6 +68,10 @@ typedef struct ora_mccfr {
     int R, W, S;
     rp_hyper hp;
     uint64_t seed;
+    int rng;                       /* rp_rng_kind */
+    rp_hash_stream* info_streams;  /* RP_RNG_REFERENCE: I::hash byte stream per infoset / per in-tree chance info */
+    rp_hash_stream* chance_streams;
+    uint32_t n_chance_streams;
     uint32_t batch;
     uint64_t epoch;
     uint64_t nodes, infos;
@@ -151,6 +156,30 @@ static uint64_t node_hash(const ora_mccfr* h, uint64_t tree_id, const rp_state* 
     uint64_t key = st->turn == RP_TURN_CHANCE ? (0x80000000ull | state) : (uint64_t)st->info;
     return rp_node_hash(h->seed, h->epoch, tree_id, key);
 }
+/* reference-seed mode: does this node draw from the reference's own chain?  (a chance state without a chance_info is the root
+ * deal, which the reference takes from the thread RNG — kuhn/src/game.rs:115-123 — and keeps the counter hash) */
+static int node_is_ref(const ora_mccfr* h, const rp_state* st) {
+    if (h->rng != RP_RNG_REFERENCE) return 0;
+    return st->turn == RP_TURN_CHANCE ? st->chance_info != 0 : 1;
+}
+/* flow.rs:285-295: DefaultHasher over t, info, node.seed() -> the u64 SmallRng::seed_from_u64 takes */
+static uint64_t node_seed_ref(const ora_mccfr* h, uint64_t tree_id, const rp_state* st) {
+    const rp_hash_stream* hs = st->turn == RP_TURN_CHANCE ? &h->chance_streams[st->chance_info - 1] : &h->info_streams[st->info];
+    return rp_ref_node_seed(h->epoch, hs->bytes, hs->len, tree_id);
+}
+/* the three draws of SamplingScheme::sample, in either mode */
+static uint32_t draw_range(const ora_mccfr* h, uint64_t tree_id, const rp_state* st, uint32_t state, uint32_t n) {
+    if (node_is_ref(h, st)) return rp_ref_draw_range(node_seed_ref(h, tree_id, st), n); /* rng.random_range(0..n) */
+    return rp_pick_uniform(node_hash(h, tree_id, st, state), n);
+}
+static float draw_weight(const ora_mccfr* h, uint64_t tree_id, const rp_state* st, uint32_t state, float total) {
+    if (node_is_ref(h, st)) return rp_ref_draw_weight(node_seed_ref(h, tree_id, st), total); /* Uniform::new(0, total).sample */
+    return rp_u01(node_hash(h, tree_id, st, state)) * total;
+}
+static float draw_f32(const ora_mccfr* h, uint64_t tree_id, const rp_state* st, uint32_t state) {
+    if (node_is_ref(h, st)) return rp_ref_draw_f32(node_seed_ref(h, tree_id, st)); /* rng.random::<f32>() */
+    return rp_u01(node_hash(h, tree_id, st, state));
+}
 
 /* SamplingScheme::sample: returns a bitmask over child slots to expand.
  * vanilla != 0 -> VanillaSampling (sample/vanilla.rs), used only by exploitability. */
@@ -162,7 +191,7 @@ static uint32_t sample_mask(const ora_mccfr* h, uint64_t tree_id, uint32_t state
     if (vanilla) return all;
     if (st->turn == RP_TURN_CHANCE) {
         /* randomly (sample/mod.rs:68-82) */
-        return 1u << rp_pick_uniform(node_hash(h, tree_id, st, state), n);
+        return 1u << draw_range(h, tree_id, st, state, n);
     }
     if (st->turn != walker) {
         /* weighted (sample/external.rs:41-64): WeightedIndex over sampling_distribution.max(EPSILON) */
@@ -180,7 +209,7 @@ static uint32_t sample_mask(const ora_mccfr* h, uint64_t tree_id, uint32_t state
             total += rp_maxf(raw[a] / z, RP_EPSILON);
             cum[a] = total;
         }
-        float x = rp_u01(node_hash(h, tree_id, st, state)) * total;
+        float x = draw_weight(h, tree_id, st, state, total);
         uint32_t idx = 0;
         while (idx + 1 < n && cum[idx] <= x) ++idx;
         return 1u << idx;
@@ -191,7 +220,7 @@ static uint32_t sample_mask(const ora_mccfr* h, uint64_t tree_id, uint32_t state
     if (h->S == RP_SAMPLING_PLURIBUS) {
         /* sample/pluribus.rs:72-101 */
         if (h->epoch < h->hp.prune_warmup) return all;
-        if (rp_u01(node_hash(h, tree_id, st, state)) < h->hp.prune_explore) return all;
+        if (draw_f32(h, tree_id, st, state) < h->hp.prune_explore) return all;
     }
     uint32_t mask = 0;
     for (uint32_t a = 0; a < n; ++a) {
@@ -456,8 +485,30 @@ ORA_API ora_mccfr* ora_mccfr_create(const rp_game_table* g, int R, int W, int S,
     return h;
 }
 
+/* rp_mccfr_set_rng: which generator draws the sampled branches (include/rp_mi355x.h rp_rng_kind) */
+ORA_API int ora_mccfr_set_rng(ora_mccfr* h, int kind, const rp_hash_streams* st) {
+    if (!h) return -1;
+    if (kind == RP_RNG_COUNTER) {
+        h->rng = RP_RNG_COUNTER;
+        return 0;
+    }
+    if (kind != RP_RNG_REFERENCE || !st || st->n_infos != h->g.n_infos || !st->infos) return -1;
+    for (uint32_t s = 0; s < h->g.n_states; ++s)
+        if (h->states[s].turn == RP_TURN_CHANCE && h->states[s].chance_info > st->n_chance) return -1;
+    free(h->info_streams);
+    free(h->chance_streams);
+    h->info_streams = (rp_hash_stream*)malloc(sizeof(rp_hash_stream) * (st->n_infos ? st->n_infos : 1));
+    memcpy(h->info_streams, st->infos, sizeof(rp_hash_stream) * st->n_infos);
+    h->chance_streams = (rp_hash_stream*)malloc(sizeof(rp_hash_stream) * (st->n_chance ? st->n_chance : 1));
+    if (st->n_chance) memcpy(h->chance_streams, st->chance, sizeof(rp_hash_stream) * st->n_chance);
+    h->n_chance_streams = st->n_chance;
+    h->rng = RP_RNG_REFERENCE;
+    return 0;
+}
+
 ORA_API void ora_mccfr_destroy(ora_mccfr* h) {
     if (!h) return;
+    free(h->info_streams); free(h->chance_streams);
     free(h->states); free(h->children); free(h->payoffs); free(h->info_actions); free(h->info_player);
     free(h->default_regret); free(h->regret); free(h->weight); free(h->payoff); free(h->visits);
     free(h->tree.nodes); free(h->dec);

@@ -54,10 +54,23 @@ class State(C.Structure):
     _fields_ = [
         ("turn", C.c_uint8),
         ("n_children", C.c_uint8),
-        ("reserved", C.c_uint16),
+        ("chance_info", C.c_uint16),
         ("info", C.c_uint32),
         ("offset", C.c_uint32),
     ]
+
+
+class HashStream(C.Structure):
+    """rp_hash_stream: what `impl Hash for I` writes for one infoset (reference-seed mode)"""
+    _fields_ = [("len", C.c_uint8), ("bytes", C.c_uint8 * 55)]
+
+
+class HashStreams(C.Structure):
+    _fields_ = [("n_infos", C.c_uint32), ("n_chance", C.c_uint32), ("infos", C.POINTER(HashStream)),
+                ("chance", C.POINTER(HashStream))]
+
+
+RNG = {"counter": 0, "reference": 1}
 
 
 class GameTable(C.Structure):
@@ -154,6 +167,8 @@ _SIGNATURES = {
     "rp_mccfr_sum_regret": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rp_mccfr_set_batch": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rp_mccfr_set_update_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "rp_mccfr_set_rng": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(HashStreams)]),
+    "rp_game_hash_streams": (C.c_int, [C.c_void_p, C.POINTER(HashStreams)]),
     "rp_mccfr_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_mccfr_traversal_variant": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "rp_game_skeleton": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),

@@ -26,9 +26,12 @@ struct Builder {
     std::vector<uint8_t> info_actions, info_player;
     std::vector<std::string> info_names;
     std::map<std::string, uint32_t> info_by_name;
+    // reference-seed mode (rp_rng_kind): what `impl Hash for I` writes for each infoset / in-tree chance node's info
+    std::vector<rp_hash_stream> info_streams, chance_streams;
+    std::map<std::string, uint16_t> chance_by_bytes;
     uint32_t n_players = 2;
 
-    uint32_t info(const std::string& name, uint8_t actions, uint8_t player) {
+    uint32_t info(const std::string& name, uint8_t actions, uint8_t player, const rp_hash_stream& stream) {
         auto it = info_by_name.find(name);
         if (it != info_by_name.end()) return it->second;
         uint32_t id = (uint32_t)info_names.size();
@@ -36,7 +39,16 @@ struct Builder {
         info_names.push_back(name);
         info_actions.push_back(actions);
         info_player.push_back(player);
+        info_streams.push_back(stream);
         return id;
+    }
+    // 1 + index of a chance node's info among the distinct ones (rp_state.chance_info)
+    uint16_t chance_info(const rp_hash_stream& stream) {
+        const std::string key((const char*)stream.bytes, stream.len);
+        auto it = chance_by_bytes.find(key);
+        if (it != chance_by_bytes.end()) return it->second;
+        chance_streams.push_back(stream);
+        return chance_by_bytes[key] = (uint16_t)chance_streams.size();
     }
     uint32_t terminal(float p0, float p1) {
         rp_state s{};
@@ -63,6 +75,22 @@ struct Builder {
     void set_child(uint32_t parent, uint32_t k, uint32_t child) { children[states[parent].offset + k] = child; }
 };
 
+// #[derive(Hash)] streams (include/rp_refrng.h): bool = one byte; an enum's discriminant = isize, 8 bytes little-endian, before
+// the variant's fields; Option<T> = discriminant 0 / 1 then T
+struct HashWriter {
+    rp_hash_stream s{};
+    HashWriter& u8(uint8_t v) {
+        s.bytes[s.len++] = v;
+        return *this;
+    }
+    HashWriter& isize(uint64_t v) {
+        for (int i = 0; i < 8; ++i) s.bytes[s.len++] = (uint8_t)(v >> (8 * i));
+        return *this;
+    }
+    HashWriter& some(uint64_t v) { return isize(1).isize(v); }
+    HashWriter& none() { return isize(0); }
+};
+
 // Card::ALL = J0 J1 Q0 Q1 K0 K1 (card.rs): two suits per rank.  The reference games have three ranks; the synthetic
 // "wide" Leduc (RP_GAME_LEDUC_WIDE, same rules) has seven, which pushes the infoset count past 256.
 thread_local int g_cards = 6;
@@ -87,7 +115,9 @@ uint32_t kuhn_node(Builder& b, int c0, int c1, KuhnNode node) {
     int actor = (node == K_OPEN || node == K_CHECKBET) ? 0 : 1;
     int rank = rank_of(actor == 0 ? c0 : c1);
     std::string name = std::string(1, RANKS[rank]) + "|" + HIST[node];
-    uint32_t id = b.info(name, 2, (uint8_t)actor);
+    // KuhnInfo = Composite { public: KuhnPublic { acting: bool, node: History }, secret: Rank } (kuhn/src/info.rs:20-24,71;
+    // mccfr/src/state/composite.rs:19-22); History::{Open, Check, Bet, CheckBet} = 0..3 (info.rs:7-12)
+    uint32_t id = b.info(name, 2, (uint8_t)actor, HashWriter().u8(1).isize((uint64_t)node).isize((uint64_t)rank).s);
     uint32_t s = b.inner((uint8_t)actor, 2, id);
     switch (node) {
         case K_OPEN:  // [Check, Bet]
@@ -176,7 +206,10 @@ uint32_t leduc_r2(Builder& b, int c0, int c1, int board, Spot r1, Spot r2) {
     int rank = rank_of(actor == 0 ? c0 : c1);
     std::string name = std::string(1, RANKS[rank]) + "|" + std::string(1, RANKS[rank_of(board)]) + "|" +
                        leduc_hist(r1, true, (int)r2);
-    uint32_t id = b.info(name, 2, (uint8_t)actor);
+    // LeducInfo = Composite { public: LeducPublic { acting: bool, board: Option<Rank>, r1: Spot, r2: Option<Spot> }, secret: Rank }
+    // (leduc/src/info.rs:11-17,85; encoder.rs:21-32)
+    uint32_t id = b.info(name, 2, (uint8_t)actor,
+                         HashWriter().u8(1).some((uint64_t)rank_of(board)).isize((uint64_t)r1).some((uint64_t)r2).isize((uint64_t)rank).s);
     uint32_t s = b.inner((uint8_t)actor, 2, id);
     float pay[2];
     switch (r2) {
@@ -207,6 +240,8 @@ uint32_t leduc_r2(Builder& b, int c0, int c1, int board, Spot r1, Spot r2) {
 // Node::Deal(spot): chance over the 4 undealt cards in Card::ALL order (game.rs:152-161)
 uint32_t leduc_deal(Builder& b, int c0, int c1, Spot r1) {
     uint32_t s = b.inner(RP_TURN_CHANCE, (uint8_t)(g_cards - 2), RP_NO_INFO);
+    // the chance node's info (encoder.rs:21-32): acting = false, actor 0's rank, no board yet, spots() = (r1, Some(Open)) (game.rs:118)
+    b.states[s].chance_info = b.chance_info(HashWriter().u8(0).none().isize((uint64_t)r1).some(0).isize((uint64_t)rank_of(c0)).s);
     uint32_t k = 0;
     for (int c = 0; c < g_cards; ++c) {
         if (c == c0 || c == c1) continue;
@@ -218,7 +253,7 @@ uint32_t leduc_r1(Builder& b, int c0, int c1, Spot spot) {
     int actor = spot_actor(spot);
     int rank = rank_of(actor == 0 ? c0 : c1);
     std::string name = std::string(1, RANKS[rank]) + "|" + leduc_hist(spot, false, -1);
-    uint32_t id = b.info(name, 2, (uint8_t)actor);
+    uint32_t id = b.info(name, 2, (uint8_t)actor, HashWriter().u8(1).none().isize((uint64_t)spot).none().isize((uint64_t)rank).s);
     uint32_t s = b.inner((uint8_t)actor, 2, id);
     float pay[2];
     switch (spot) {
@@ -247,7 +282,8 @@ uint32_t leduc_r1(Builder& b, int c0, int c1, Spot spot) {
 // ------------------------------------------------------------------ RPS
 // roshambo/src/game.rs:7-78: P1 then P2 (P2 does not observe), info = turn; scissors wins count x2
 uint32_t rps_build(Builder& b) {
-    uint32_t i1 = b.info("P1", 3, 0), i2 = b.info("P2", 3, 1);
+    // the info IS the turn: RpsTurn::{P1, P2, Terminal} (roshambo/src/turn.rs:10-18, encoder.rs:15-24)
+    uint32_t i1 = b.info("P1", 3, 0, HashWriter().isize(0).s), i2 = b.info("P2", 3, 1, HashWriter().isize(1).s);
     uint32_t root = b.inner(0, 3, i1);
     const float S_WIN = 2.0f, P_WIN = 1.0f;
     // payoff to P1 for (a1, a2), R=0 P=1 S=2  (game.rs:63-73)
@@ -358,6 +394,15 @@ int rp_game_create(rp_game_kind kind, rp_game** out) {
 int rp_game_view(const rp_game* g, rp_game_table* out) {
     if (!g || !out) return rp::fail(RP_ERR_INVALID, "rp_game_view: NULL argument");
     *out = g->view;
+    return RP_OK;
+}
+
+int rp_game_hash_streams(const rp_game* g, rp_hash_streams* out) {
+    if (!g || !out) return rp::fail(RP_ERR_INVALID, "rp_game_hash_streams: NULL argument");
+    out->n_infos = (uint32_t)g->b.info_streams.size();
+    out->n_chance = (uint32_t)g->b.chance_streams.size();
+    out->infos = g->b.info_streams.data();
+    out->chance = g->b.chance_streams.data();
     return RP_OK;
 }
 

@@ -67,13 +67,11 @@ __device__ __forceinline__ float d_sampling_z(const DevTables& t, uint32_t A, ui
 
 // SamplingScheme::sample as a bitmask over child slots (sample/{mod,external,pruning,pluribus}.rs)
 __device__ uint32_t d_sample_mask(const DevGame& g, const DevTables& t, const StepParams& p, uint64_t tree_id,
-                                  uint32_t state, uint32_t turn, uint32_t n, uint32_t info, uint32_t off) {
+                                  uint32_t state, uint32_t turn, uint32_t n, uint32_t info, uint32_t off, uint32_t rec_x) {
     const uint32_t all = (1u << n) - 1u;
+    const bool ref = p.ref_info != nullptr;
     if (n == 0) return 0;
-    if (turn == RP_TURN_CHANCE) {
-        uint64_t h = rp_node_hash(p.seed, p.epoch, tree_id, 0x80000000ull | state);
-        return 1u << rp_pick_uniform(h, n);
-    }
+    if (turn == RP_TURN_CHANCE) return 1u << d_draw_chance(p, ref, tree_id, state, rec_x);
     if (turn != p.walker) {
         // weighted (external.rs:41-64): WeightedIndex over sampling_distribution().max(EPSILON)
         const float denom = d_weight_denom(t, g.A, info, n, p.smoothing);
@@ -81,7 +79,7 @@ __device__ uint32_t d_sample_mask(const DevGame& g, const DevTables& t, const St
         float total = 0.0f;
         for (uint32_t a = 0; a < n; ++a)
             total += rp_maxf(d_sampling_weight(t, g.A, info, a, denom, p) / z, RP_EPSILON);
-        const float x = rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info)) * total;
+        const float x = d_draw_weight(p, ref, tree_id, info, total);
         float cum = 0.0f;
         uint32_t idx = 0;
         bool open = true;
@@ -95,7 +93,7 @@ __device__ uint32_t d_sample_mask(const DevGame& g, const DevTables& t, const St
     if (p.S == RP_SAMPLING_EXTERNAL) return all;
     if (p.S == RP_SAMPLING_PLURIBUS) {
         if (p.epoch < p.prune_warmup) return all;
-        if (rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info)) < p.prune_explore) return all;
+        if (d_draw_coin(p, ref, tree_id, info) < p.prune_explore) return all;
     }
     uint32_t mask = 0;
     for (uint32_t a = 0; a < n; ++a) {
@@ -177,7 +175,7 @@ __global__ __launch_bounds__(256) void k_traverse(DevGame g, DevTables t, DevScr
         if (nch == 0) sc.n_pay[me * S + lane] = g.payoffs[off * g.n_players + p.walker];
         nn += 1;
         if (nch > 0) {
-            const uint32_t mask = d_sample_mask(g, t, p, tree_id, cur_state, turn, nch, info, off);
+            const uint32_t mask = d_sample_mask(g, t, p, tree_id, cur_state, turn, nch, info, off, st.x);
             const bool chance = turn == RP_TURN_CHANCE;
             const uint32_t ptype = chance ? PT_CHANCE : (is_walker ? PT_WALKER : PT_OPP);
             float rd = 0.0f, denom = 0.0f, z = 0.0f;
@@ -355,14 +353,24 @@ __global__ void k_prepare_infos(DevGame g, DevTables t, StepParams p, DevInfoTab
     prepare_one(g, t, p, it, info);
 }
 
+// reference-seed mode: DefaultHasher after t.hash() and info.hash() for every infoset and every in-tree chance info
+// (flow.rs:290-293); a node continues with node.seed().hash() and finish() (rp_ref_seed_finish).  Depends on the epoch: every step.
+__global__ void k_prepare_ref(const rp_hash_stream* infos, uint32_t n_infos, const rp_hash_stream* chance, uint32_t n_chance,
+                              uint64_t epoch, rp_sip_mid* info_mid, rp_sip_mid* chance_mid) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_infos) rp_ref_seed_prefix(&info_mid[i], epoch, infos[i].bytes, infos[i].len);
+    else if (i < n_infos + n_chance) rp_ref_seed_prefix(&chance_mid[i - n_infos], epoch, chance[i - n_infos].bytes, chance[i - n_infos].len);
+}
+
 // SamplingScheme::sample with the per-infoset tables
 __device__ __forceinline__ uint32_t d_sample_mask_tab(const DevGame& g, const DevInfoTab& it, const StepParams& p,
                                                       uint64_t tree_id, uint32_t state, uint32_t turn, uint32_t n,
-                                                      uint32_t info, uint32_t off) {
+                                                      uint32_t info, uint32_t off, uint32_t rec_x) {
     const uint32_t all = (1u << n) - 1u;
-    if (turn == RP_TURN_CHANCE) return 1u << rp_pick_uniform(rp_node_hash(p.seed, p.epoch, tree_id, 0x80000000ull | state), n);
+    const bool ref = p.ref_info != nullptr;
+    if (turn == RP_TURN_CHANCE) return 1u << d_draw_chance(p, ref, tree_id, state, rec_x);
     if (turn != p.walker) {
-        const float x = rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info)) * it.total[info];
+        const float x = d_draw_weight(p, ref, tree_id, info, it.total[info]);
         uint32_t idx = 0;
         bool open = true;
         for (uint32_t a = 0; a + 1 < n; ++a) {
@@ -374,7 +382,7 @@ __device__ __forceinline__ uint32_t d_sample_mask_tab(const DevGame& g, const De
     if (p.S == RP_SAMPLING_EXTERNAL) return all;
     if (p.S == RP_SAMPLING_PLURIBUS) {
         if (p.epoch < p.prune_warmup) return all;
-        if (rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info)) < p.prune_explore) return all;
+        if (d_draw_coin(p, ref, tree_id, info) < p.prune_explore) return all;
     }
     uint32_t mask = it.keep[info] & all;
     if (p.S == RP_SAMPLING_PLURIBUS) {
@@ -508,7 +516,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
         if (nch > 0) {
             n_int += 1;
             if (is_walker) wmask |= 1ull << me;
-            uint32_t mask = d_sample_mask_tab(g, it, p, tree_id, rec.w, turn, nch, info, off);
+            uint32_t mask = d_sample_mask_tab(g, it, p, tree_id, rec.w, turn, nch, info, off, rec.x);
             const bool chance = turn == RP_TURN_CHANCE;
             const uint32_t ptype = chance ? PT_CHANCE : (is_walker ? PT_WALKER : PT_OPP);
             const uint32_t last = 31u - (uint32_t)__builtin_clz(mask);
@@ -1669,6 +1677,13 @@ struct rp_mccfr {
     int R = 0, W = 0, S = 0;
     rp_hyper hp{};
     uint64_t seed = 0;
+    // rp_mccfr_set_rng: RP_RNG_REFERENCE draws from the reference's own chain (include/rp_refrng.h)
+    rp_rng_kind rng = RP_RNG_COUNTER;
+    uint32_t n_chance_infos = 0;
+    void* d_info_streams = nullptr;    // rp_hash_stream[n_infos]
+    void* d_chance_streams = nullptr;  // rp_hash_stream[n_chance_infos]
+    void* d_ref_mid = nullptr;         // rp_sip_mid[n_infos + n_chance_infos], of epoch ref_mid_epoch
+    uint64_t ref_mid_epoch = ~0ull;
     uint32_t batch = 1, capacity = 0;
     uint64_t epoch = 0;
     uint32_t rank = 0, world = 1;
@@ -1831,6 +1846,10 @@ StepParams make_params(const rp_mccfr* h) {
     p.prune_warmup = h->hp.prune_warmup;
     p.regret_min = h->hp.regret_min;
     p.counters = h->d_counters;
+    if (h->rng == RP_RNG_REFERENCE) {
+        p.ref_info = reinterpret_cast<const rp_sip_mid*>(h->d_ref_mid);
+        p.ref_chance = p.ref_info + h->tbl.n_infos;
+    }
     return p;
 }
 
@@ -1952,7 +1971,18 @@ bool traverse_fits_lds(const rp_mccfr* h) {
 
 // k_prepare_infos, unless the tables have not changed since the per-infoset tables were last derived from them (an exchange
 // window traverses against a frozen table; k_combine2<APPLY> refreshes the rows it changes itself)
+void launch_prepare_ref(rp_mccfr* h, const StepParams& p) {
+    if (h->rng == RP_RNG_REFERENCE && h->ref_mid_epoch != p.epoch) {
+        const uint32_t n = h->tbl.n_infos + h->n_chance_infos;
+        rp_sip_mid* mid = reinterpret_cast<rp_sip_mid*>(h->d_ref_mid);
+        hipLaunchKernelGGL(k_prepare_ref, dim3((n + 63) / 64), dim3(64), 0, h->stream, reinterpret_cast<const rp_hash_stream*>(h->d_info_streams),
+                           h->tbl.n_infos, reinterpret_cast<const rp_hash_stream*>(h->d_chance_streams), h->n_chance_infos, p.epoch, mid,
+                           mid + h->tbl.n_infos);
+        h->ref_mid_epoch = p.epoch;
+    }
+}
 void launch_prepare(rp_mccfr* h, const StepParams& p) {
+    launch_prepare_ref(h, p);
     if (h->itab_version == h->tables_version) return;
     hipLaunchKernelGGL(k_prepare_infos, dim3((h->tbl.n_infos + 63) / 64), dim3(64), 0, h->stream, h->g, h->t, p, h->itab);
     h->itab_version = h->tables_version;
@@ -1964,11 +1994,13 @@ int launch_traverse(rp_mccfr* h, const StepParams& p) {
     if (h->static_skel && !h->no_static_pruned_ok(p.S)) {
         launch_prepare(h, p);
         const dim3 grid((h->batch + 255) / 256), block(256);
-        const bool pr = p.S != RP_SAMPLING_EXTERNAL;
+        const bool pr = p.S != RP_SAMPLING_EXTERNAL, rf = p.ref_info != nullptr;
 #define LAUNCH_STATIC(G, WK)                                                                                                   \
     do {                                                                                                                       \
-        if (pr) hipLaunchKernelGGL((k_traverse_static<G, WK, true>), grid, block, 0, h->stream, h->g, h->itab, h->dc, p);     \
-        else hipLaunchKernelGGL((k_traverse_static<G, WK, false>), grid, block, 0, h->stream, h->g, h->itab, h->dc, p);        \
+        if (pr && rf) hipLaunchKernelGGL((k_traverse_static<G, WK, true, true>), grid, block, 0, h->stream, h->g, h->itab, h->dc, p);    \
+        else if (pr) hipLaunchKernelGGL((k_traverse_static<G, WK, true, false>), grid, block, 0, h->stream, h->g, h->itab, h->dc, p);   \
+        else if (rf) hipLaunchKernelGGL((k_traverse_static<G, WK, false, true>), grid, block, 0, h->stream, h->g, h->itab, h->dc, p);   \
+        else hipLaunchKernelGGL((k_traverse_static<G, WK, false, false>), grid, block, 0, h->stream, h->g, h->itab, h->dc, p);          \
     } while (0)
         if (h->static_skel == 1) {
             if (p.walker == 0) LAUNCH_STATIC(KuhnSkel, 0);
@@ -1991,6 +2023,7 @@ int launch_traverse(rp_mccfr* h, const StepParams& p) {
         else LAUNCH_TRAVERSE(false, false);
 #undef LAUNCH_TRAVERSE
     } else {
+        launch_prepare_ref(h, p);
         const uint32_t threads = 256, blocks = (h->batch + threads - 1) / threads;
         hipLaunchKernelGGL(k_traverse, dim3(blocks), dim3(threads), 0, h->stream, h->g, h->t, h->sc, h->dc, p);
     }
@@ -2073,14 +2106,16 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev, bool fuse
         clock_begin(h, h->clk_traverse);
         launch_prepare(h, p);
         const size_t lds = traverse_maps_lds_bytes(h);
-#define LAUNCH_FUSED(G, WK)                                                                                                            \
-    do {                                                                                                                               \
-        if (pruned)                                                                                                                    \
-            hipLaunchKernelGGL((k_traverse_maps_static<G, WK, true>), dim3(nblk), dim3(256), lds, h->stream, h->g, h->itab, p, bmaps, \
-                               bpsum, bcnt, nblk_max, h->maxdec, h->cell_pad | (h->split_payoff ? 256u : 0u));                         \
-        else                                                                                                                           \
-            hipLaunchKernelGGL((k_traverse_maps_static<G, WK, false>), dim3(nblk), dim3(256), lds, h->stream, h->g, h->itab, p, bmaps, \
-                               bpsum, bcnt, nblk_max, h->maxdec, h->cell_pad | (h->split_payoff ? 256u : 0u));                         \
+#define LAUNCH_FUSED_AS(G, WK, PR, RF)                                                                                                  \
+    hipLaunchKernelGGL((k_traverse_maps_static<G, WK, PR, RF>), dim3(nblk), dim3(256), lds, h->stream, h->g, h->itab, p, bmaps, bpsum, \
+                       bcnt, nblk_max, h->maxdec, h->cell_pad | (h->split_payoff ? 256u : 0u))
+#define LAUNCH_FUSED(G, WK)                                    \
+    do {                                                       \
+        const bool rf = p.ref_info != nullptr;                 \
+        if (pruned && rf) LAUNCH_FUSED_AS(G, WK, true, true);  \
+        else if (pruned) LAUNCH_FUSED_AS(G, WK, true, false);  \
+        else if (rf) LAUNCH_FUSED_AS(G, WK, false, true);      \
+        else LAUNCH_FUSED_AS(G, WK, false, false);             \
     } while (0)
         if (h->static_skel == 1) {
             if (p.walker == 0) LAUNCH_FUSED(KuhnSkel, 0);
@@ -2090,6 +2125,7 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev, bool fuse
             else LAUNCH_FUSED(LeducSkel, 1);
         }
 #undef LAUNCH_FUSED
+#undef LAUNCH_FUSED_AS
         clock_end(h, h->clk_traverse);
     }
     clock_begin(h, h->clk_update);
@@ -2258,7 +2294,7 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
     std::vector<uint4> packed(game->n_states);
     for (uint32_t i = 0; i < game->n_states; ++i) {
         const rp_state& st = game->states[i];
-        packed[i] = make_uint4((uint32_t)st.turn | ((uint32_t)st.n_children << 8), st.info, st.offset, 0u);
+        packed[i] = make_uint4((uint32_t)st.turn | ((uint32_t)st.n_children << 8) | ((uint32_t)st.chance_info << 16), st.info, st.offset, 0u);
     }
     CREATE_TRY(hipMalloc(&h->d_states, packed.size() * sizeof(uint4)));
     CREATE_TRY(hipMemcpy(h->d_states, packed.data(), packed.size() * sizeof(uint4), hipMemcpyHostToDevice));
@@ -2380,13 +2416,47 @@ int rp_mccfr_destroy(rp_mccfr* h) {
     clock_drain(h->clk_traverse);
     clock_drain(h->clk_compact);
     clock_drain(h->clk_update);
-    void* ptrs[] = {h->d_flat, h->d_states, h->d_children, h->d_kids, h->d_payoffs, h->d_info_actions, h->d_info_player, h->d_scratch,
+    void* ptrs[] = {h->d_info_streams, h->d_chance_streams, h->d_ref_mid, h->d_flat, h->d_states, h->d_children, h->d_kids, h->d_payoffs, h->d_info_actions, h->d_info_player, h->d_scratch,
                     h->d_dec, h->d_sorted, h->d_bmaps, h->d_itab, h->d_summary, h->d_window, h->d_counters, h->t.regret, h->t.weight, h->t.payoff,
                     h->t.visits};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+    return RP_OK;
+}
+
+int rp_mccfr_set_rng(rp_mccfr* h, rp_rng_kind kind, const rp_hash_streams* st) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_mccfr_set_rng: NULL handle");
+    int rc = set_device(h);
+    if (rc) return rc;
+    if (kind == RP_RNG_COUNTER) {
+        h->rng = RP_RNG_COUNTER;
+        return RP_OK;
+    }
+    if (kind != RP_RNG_REFERENCE) return rp::fail(RP_ERR_INVALID, "rp_mccfr_set_rng: unknown rp_rng_kind");
+    if (!st || !st->infos || st->n_infos != h->tbl.n_infos || (st->n_chance && !st->chance))
+        return rp::fail(RP_ERR_INVALID, "rp_mccfr_set_rng: RP_RNG_REFERENCE needs the hash stream of each of the game's %u infosets", h->tbl.n_infos);
+    for (uint32_t i = 0; i < st->n_infos; ++i)
+        if (st->infos[i].len > RP_HASH_STREAM_MAX) return rp::fail(RP_ERR_INVALID, "rp_mccfr_set_rng: stream %u is longer than %u bytes", i, RP_HASH_STREAM_MAX);
+    for (uint32_t i = 0; i < st->n_chance; ++i)
+        if (st->chance[i].len > RP_HASH_STREAM_MAX) return rp::fail(RP_ERR_INVALID, "rp_mccfr_set_rng: chance stream %u is longer than %u bytes", i, RP_HASH_STREAM_MAX);
+    for (const rp_state& s : h->states)
+        if (s.turn == RP_TURN_CHANCE && s.chance_info > st->n_chance)
+            return rp::fail(RP_ERR_INVALID, "rp_mccfr_set_rng: a chance state names chance info %u of %u", s.chance_info, st->n_chance);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (void** q : {&h->d_info_streams, &h->d_chance_streams, &h->d_ref_mid}) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    HIP_TRY(hipMalloc(&h->d_info_streams, sizeof(rp_hash_stream) * std::max<size_t>(1, st->n_infos)));
+    HIP_TRY(hipMalloc(&h->d_chance_streams, sizeof(rp_hash_stream) * std::max<size_t>(1, st->n_chance)));
+    HIP_TRY(hipMalloc(&h->d_ref_mid, sizeof(rp_sip_mid) * ((size_t)st->n_infos + st->n_chance + 1)));
+    HIP_TRY(hipMemcpy(h->d_info_streams, st->infos, sizeof(rp_hash_stream) * st->n_infos, hipMemcpyHostToDevice));
+    if (st->n_chance) HIP_TRY(hipMemcpy(h->d_chance_streams, st->chance, sizeof(rp_hash_stream) * st->n_chance, hipMemcpyHostToDevice));
+    h->n_chance_infos = st->n_chance;
+    h->ref_mid_epoch = ~0ull;
+    h->rng = RP_RNG_REFERENCE;
     return RP_OK;
 }
 

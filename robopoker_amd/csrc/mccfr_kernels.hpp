@@ -5,11 +5,12 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/rp_math.h"
+#include "../../include/rp_refrng.h"
 #include "rp_internal.h"
 
 namespace rp {
 
-// rp_state repacked to one 16-byte load: x = turn | n_children << 8, y = info, z = offset
+// rp_state repacked to one 16-byte load: x = turn | n_children << 8 | chance_info << 16, y = info, z = offset
 struct DevGame {
     const uint4* states;
     const uint32_t* children;
@@ -86,7 +87,30 @@ struct StepParams {
     uint64_t prune_warmup;
     float regret_min;
     unsigned long long* counters;  // [0] nodes, [1] infos, [2] error flags
+    // reference-seed mode (rp_rng_kind RP_RNG_REFERENCE), NULL otherwise: DefaultHasher after t.hash() and info.hash()
+    // (flow.rs:290-293) per infoset / per in-tree chance info, refreshed by k_prepare_ref every step
+    const rp_sip_mid* ref_info;
+    const rp_sip_mid* ref_chance;
 };
+
+// ------------------------------------------------------------------------------------------------
+// the three draws of SamplingScheme::sample (sample/{mod,external,pluribus}.rs) in either rp_rng_kind.  `rec_x` = the state
+// record's x (chance nodes: chance_info in bits 16..31; 0 = the root deal, which keeps the counter hash in both modes).
+// REF is a compile-time switch in the skeleton kernels and p.ref_info != NULL elsewhere.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t d_draw_chance(const StepParams& p, bool ref, uint64_t tree_id, uint32_t state, uint32_t rec_x) {
+    const uint32_t n = (rec_x >> 8) & 0xffu, ci = rec_x >> 16;
+    if (ref && ci) return rp_ref_draw_range(rp_ref_seed_finish(&p.ref_chance[ci - 1u], tree_id), n);  // rng.random_range(0..n)
+    return rp_pick_uniform(rp_node_hash(p.seed, p.epoch, tree_id, 0x80000000ull | state), n);
+}
+__device__ __forceinline__ float d_draw_weight(const StepParams& p, bool ref, uint64_t tree_id, uint32_t info, float total) {
+    if (ref) return rp_ref_draw_weight(rp_ref_seed_finish(&p.ref_info[info], tree_id), total);  // Uniform::new(0, total).sample(rng)
+    return rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info)) * total;
+}
+__device__ __forceinline__ float d_draw_coin(const StepParams& p, bool ref, uint64_t tree_id, uint32_t info) {
+    if (ref) return rp_ref_draw_f32(rp_ref_seed_finish(&p.ref_info[info], tree_id));  // rng.random::<f32>()
+    return rp_u01(rp_node_hash(p.seed, p.epoch, tree_id, info));
+}
 
 // per-cell composed map of the multi-GPU exchange (rp_mccfr_step_local / step_apply)
 struct Cell {

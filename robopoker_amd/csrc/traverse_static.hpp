@@ -152,7 +152,8 @@ __device__ __forceinline__ void sk_for_down(F&& f) {  // I = HI-1 down to LO
 // over the skeleton's node index; on_decision(j, info, regret0, regret1, sigma0, sigma1, payoff) once per LIVE walker node,
 // ascending node index (= the order of Tree::partition's spans).  Returns the number of nodes of the sampled tree.
 // on_decision's `mask`: the expanded edges (3 under external sampling).
-template <class G, int W, bool PRUNED, class OnBuilt, class OnDecision>
+// REF: the draws come from the reference's own chain (rp_rng_kind RP_RNG_REFERENCE, mccfr_kernels.hpp d_draw_*).
+template <class G, int W, bool PRUNED, bool REF, class OnBuilt, class OnDecision>
 __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevInfoTab& it, const StepParams& p, uint64_t tree_id,
                                                     bool present, OnBuilt&& on_built, OnDecision&& on_decision) {
     using SK = SkelOf<G>;
@@ -198,7 +199,9 @@ __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevI
             else live[s] = live[par];
         }
         if constexpr (SK::S.kind[s] == SK_CHANCE) {  // SamplingScheme::sample at a chance node: uniform (external.rs:41-64)
-            pick[s] = rp_pick_uniform(rp_node_hash_key(th, 0x80000000ull | rw[s]), (rx[s] >> 8) & 0xffu);
+            const uint32_t nout = (rx[s] >> 8) & 0xffu, ci = rx[s] >> 16;  // ci = 0: the root deal (thread RNG in the reference)
+            if (REF && ci) pick[s] = rp_ref_draw_range(rp_ref_seed_finish(&p.ref_chance[ci - 1u], tree_id), nout);
+            else pick[s] = rp_pick_uniform(rp_node_hash_key(th, 0x80000000ull | rw[s]), nout);
         } else if constexpr (SK::S.kind[s] == SK_P0 || SK::S.kind[s] == SK_P1) {
             const uint32_t info = ry[s];
             const float4 f = *reinterpret_cast<const float4*>(&it.sq[info * 2u]);
@@ -207,13 +210,16 @@ __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevI
             sg1[s] = f.z;
             q1[s] = f.w;
             if constexpr (SK::S.kind[s] == K_OPP) {  // WeightedIndex over max(q, EPSILON): two actions = one threshold
-                const float x = rp_u01(rp_node_hash_key(th, info)) * it.total[info];
+                const float x = REF ? rp_ref_draw_weight(rp_ref_seed_finish(&p.ref_info[info], tree_id), it.total[info])
+                                    : rp_u01(rp_node_hash_key(th, info)) * it.total[info];
                 pick[s] = it.cum[info * 2u] <= x ? 1u : 0u;
             } else if constexpr (PRUNED) {  // SamplingScheme::sample at a walker node (d_sample_mask_tab, the same draw and masks)
                 uint32_t mask = 3u;
                 bool prune = true;
                 if (p.S == RP_SAMPLING_PLURIBUS)
-                    prune = p.epoch >= p.prune_warmup && !(rp_u01(rp_node_hash_key(th, info)) < p.prune_explore);
+                    prune = p.epoch >= p.prune_warmup &&
+                            !((REF ? rp_ref_draw_f32(rp_ref_seed_finish(&p.ref_info[info], tree_id)) : rp_u01(rp_node_hash_key(th, info))) <
+                              p.prune_explore);
                 if (prune) {
                     mask = it.keep[info] & 3u;
                     if (p.S == RP_SAMPLING_PLURIBUS)
@@ -312,13 +318,13 @@ __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevI
 
 // Decisions to HBM (DevDecisions), for the ordered update, the sorted large-game path and the debugging views.
 // One lane per tree, 256 trees per workgroup, no LDS.
-template <class G, int W, bool PRUNED>
+template <class G, int W, bool PRUNED, bool REF>
 __global__ __launch_bounds__(256) void k_traverse_static(DevGame g, DevInfoTab it, DevDecisions dc, StepParams p) {
     const uint32_t lane = blockIdx.x * 256u + threadIdx.x;
     if (lane >= p.batch) return;
     const size_t D = dc.stride;
     uint32_t ndec = 0;
-    const uint32_t nn = static_traverse<G, W, PRUNED>(
+    const uint32_t nn = static_traverse<G, W, PRUNED, REF>(
         g, it, p, p.tree_base + lane, true, [](auto, auto) __attribute__((always_inline)) {},
         [&](auto, uint32_t info, float g0, float g1, float s0, float s1, float payoff, uint32_t mask) __attribute__((always_inline)) {
             const uint32_t slot = ndec;
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(256) void k_traverse_static(DevGame g, DevInfoTab i
 // LDS (dynamic): bits u32[NI][8] | lcount u32[NI] | lbase u32[NI] | pre u16[NI][8] | order u16[NI + (NI & 1)] | vals f32[5][maxdec * 256]
 //                | (PRUNED) lmask u32[maxdec * 256]: the expanded edges of every list entry — a regret cell skips the entries
 //                  whose edge was pruned (no touch at all: a touch would apply the discount), as k_chunk_maps<true> does
-template <class G, int W, bool PRUNED>
+template <class G, int W, bool PRUNED, bool REF>
 __global__ __launch_bounds__(256, 4) void k_traverse_maps_static(DevGame g, DevInfoTab it, StepParams p, Map* bmaps, float* bpsum,
                                                               uint32_t* bcnt, uint32_t nblk_max, uint32_t maxdec, uint32_t lpad) {
     extern __shared__ __attribute__((aligned(16))) uint32_t tm_lds[];
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(256, 4) void k_traverse_maps_static(DevGame g, DevI
     const uint32_t lane = chunk * 256u + lt;
     const float tf = (float)p.epoch;
     uint32_t ndec = 0;
-    const uint32_t nn = static_traverse<G, W, PRUNED>(
+    const uint32_t nn = static_traverse<G, W, PRUNED, REF>(
         g, it, p, p.tree_base + lane, lane < p.batch,
         [&](auto info_of, auto live_of) __attribute__((always_inline)) {
             sk_for<0, SkelOf<G>::S.n>([&](auto J) __attribute__((always_inline)) {

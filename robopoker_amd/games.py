@@ -31,6 +31,12 @@ class Game:
     def max_actions(self) -> int:
         return self.table.max_actions
 
+    def hash_streams(self) -> _lib.HashStreams:
+        """the `Hash::hash` byte stream of every infoset and in-tree chance info (reference-seed mode, Solver.set_rng)"""
+        out = _lib.HashStreams()
+        _lib.check(_lib.load().rp_game_hash_streams(self._h, C.byref(out)))
+        return out
+
     def skeleton(self) -> str:
         """the compile-time action skeleton this table matches (csrc/traverse_static.hpp): "kuhn", "leduc" or "" — decides
         whether the solver's traversal is the instantiated kernel or the generic per-lane DFS; host-side check, no device"""

@@ -152,6 +152,13 @@ class Solver:
     def set_update_mode(self, mode: str):
         _lib.check(self._lib.rp_mccfr_set_update_mode(self._h, _lib.UPDATE[mode]))
 
+    def set_rng(self, kind: str, streams: "_lib.HashStreams | None" = None):
+        """"counter" (default: the build's own hash) or "reference" (the reference's DefaultHasher -> SmallRng chain,
+        include/rp_refrng.h); `streams` defaults to the built-in game's (Game.hash_streams)"""
+        if kind == "reference" and streams is None:
+            streams = self.game.hash_streams()
+        _lib.check(self._lib.rp_mccfr_set_rng(self._h, _lib.RNG[kind], C.byref(streams) if streams is not None else None))
+
     def set_stream(self, hip_stream_ptr):
         _lib.check(self._lib.rp_mccfr_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
 

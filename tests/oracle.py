@@ -171,6 +171,15 @@ class OracleSolver:
         self._o.ora_mccfr_step_mt(self._h, threads)
 
     # ---- the sharded surface of the C-ABI (rp_mccfr_set_shard / step_local / step_apply), host pointers ----
+    def set_rng(self, kind: str, streams=None):
+        """rp_rng_kind: "counter" or "reference" (include/rp_refrng.h); streams default to the built-in game's"""
+        o = load()
+        o.ora_mccfr_set_rng.argtypes = [C.c_void_p, C.c_int, C.POINTER(_lib.HashStreams)]
+        if kind == "reference" and streams is None:
+            streams = self.game.hash_streams()
+        rc = o.ora_mccfr_set_rng(self._h, _lib.RNG[kind], C.byref(streams) if streams is not None else None)
+        assert rc == 0, "ora_mccfr_set_rng refused the streams"
+
     def set_shard(self, rank: int, world: int):
         self._rank, self._world = rank, world
 

@@ -472,3 +472,81 @@ def test_static_skeleton_traversal_of_the_pruned_schemes(gpu, monkeypatch, mode,
     for _ in range(12):
         e.step()
     assert a.counters()[0] < e.counters()[0]
+
+
+# ---- reference-seed mode (rp_rng_kind RP_RNG_REFERENCE): the reference's DefaultHasher -> SmallRng chain draws the branches
+# (flow.rs:285-295; include/rp_refrng.h; the CPU side of it in tests/test_reference_seed.py) -----------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", ["kuhn", "leduc", "rps", "leduc_wide"])
+@pytest.mark.parametrize("regret,weight,sampling", [
+    ("linear", "linear", "external"), ("linear", "linear", "pluribus"), ("discounted", "quadratic", "prunable")])
+def test_reference_seed_tables_bit_exact_vs_oracle(gpu, game, regret, weight, sampling):
+    g = Game(game)
+    hp = oracle.default_hyper()
+    hp.prune_warmup = 3
+    hp.prune_threshold = -2.0
+    hp.prune_explore = 0.3
+    B, steps = 333, 10
+    dev = Solver(g, regret, weight, sampling, batch=B, seed=42, hyper=hp)
+    ora = oracle.OracleSolver(g, regret, weight, sampling, batch=B, seed=42, hyper=hp)
+    dev.set_rng("reference")
+    ora.set_rng("reference")
+    for s in range(steps):
+        dev.step()
+        ora.step()
+        assert_tables_equal(dev.export(), ora.export())
+    assert dev.counters() == ora.counters()
+    assert dev.exploitability() == ora.exploitability()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["RP_TRAV_GENERIC", "RP_MCCFR_HBM_SCRATCH"])
+def test_reference_seed_in_the_generic_traversals(gpu, monkeypatch, variant):
+    g = Game("leduc")
+    hp = oracle.default_hyper()
+    hp.prune_warmup = 2
+    hp.prune_threshold = -2.0
+    monkeypatch.setenv(variant, "1")
+    dev = Solver(g, "linear", "linear", "pluribus", batch=700, seed=9, hyper=hp)
+    monkeypatch.delenv(variant)
+    ora = oracle.OracleSolver(g, "linear", "linear", "pluribus", batch=700, seed=9, hyper=hp)
+    dev.set_rng("reference")
+    ora.set_rng("reference")
+    for _ in range(6):
+        dev.step()
+        ora.step()
+        assert_tables_equal(dev.export(), ora.export())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampling", ["external", "pluribus"])
+def test_reference_seed_composed_step_equals_the_oracle(gpu, sampling):
+    # the headline path (k_traverse_maps_static + k_combine2) with the reference chain drawing the branches
+    g = Game("leduc")
+    hp = oracle.default_hyper()
+    hp.prune_warmup = 2
+    hp.prune_threshold = -2.0
+    B = 4096 + 77
+    dev = Solver(g, "linear", "linear", sampling, batch=B, seed=3, hyper=hp)
+    ora = oracle.OracleSolver(g, "linear", "linear", sampling, batch=B, seed=3, hyper=hp)
+    dev.set_update_mode("composed")
+    dev.set_rng("reference")
+    ora.set_rng("reference")
+    for _ in range(6):
+        dev.step()
+        ora.step_world(1)
+        assert_tables_equal(dev.export(), ora.export())
+    assert dev.counters() == ora.counters()
+
+
+@pytest.mark.gpu
+def test_reference_seed_rejects_missing_streams(gpu):
+    g = Game("kuhn")
+    dev = Solver(g, "linear", "linear", "external", batch=8, seed=1)
+    lib = _lib.load()
+    assert lib.rp_mccfr_set_rng(dev._h, 1, None) != 0
+    bad = g.hash_streams()
+    bad.n_infos = 5
+    assert lib.rp_mccfr_set_rng(dev._h, 1, C.byref(bad)) != 0
+    dev.set_rng("counter")
+    dev.step()

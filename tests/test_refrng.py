@@ -11,7 +11,7 @@ import struct
 import numpy as np
 import pytest
 
-from tests import oracle
+import oracle
 
 M64 = (1 << 64) - 1
 
