@@ -404,6 +404,12 @@ RP_API int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, 
 RP_API int rp_nlhe_destroy(rp_nlhe* h);
 /* SamplingScheme::sample at walker nodes (mccfr/src/sample/{external.rs:17-64, pruning.rs:44-66, pluribus.rs:72-101}) */
 RP_API int rp_nlhe_set_sampling(rp_nlhe* h, rp_sampling_kind sampling);
+/* rp_rng_kind for the NLHE trainer.  RP_RNG_REFERENCE: the opponent's WeightedIndex draw (sample/external.rs:41-64) and Pluribus'
+ * exploration coin (sample/pluribus.rs:91) come from DefaultHasher(t, NlheInfo, tree id) -> SmallRng (flow.rs:285-295), NlheInfo's
+ * Hash stream being subgame: Path(u64), choices: Path(u64), Abstraction(u16) (nlhe/src/{info.rs:41-42, public.rs:19-23,
+ * secret.rs:10-11}) — the three fields of the infoset key this library already carries.  Hole cards and board cards stay on the
+ * library's counter hash in both modes: the reference deals them from the unseeded thread RNG (kicker game.rs). */
+RP_API int rp_nlhe_set_rng(rp_nlhe* h, rp_rng_kind kind);
 /* levels grown and nodes created by the last traversed batch (diagnostics of the level-synchronous traversal) */
 RP_API int rp_nlhe_last_shape(rp_nlhe* h, uint32_t* levels, uint32_t* nodes);
 /* profiling hooks used by bench.py (HIP events on the launch stream); name in {"expand","children","sweeps","decide",
@@ -498,6 +504,13 @@ RP_API int rp_kmeans_create_device(uint32_t K, uint64_t N, uint32_t bins, const 
 RP_API int rp_kmeans_destroy(rp_kmeans* h);
 /* Elkan::init_centroids = k-means++ (layer.rs:140-181); chosen[] receives the K point indices (may be NULL) */
 RP_API int rp_kmeans_init_centroids(rp_kmeans* h, uint64_t* chosen);
+/* rp_rng_kind of rp_kmeans_init_centroids.  RP_RNG_REFERENCE = Layer::init_centroids' own chain (crates/lloyd/src/layer.rs:155-178):
+ * DefaultHasher over the Street (`street` = its discriminant: 0 Pref, 1 Flop, 2 Turn, 3 Rive; deuce/src/street.rs:21-27) ->
+ * SmallRng::seed_from_u64, ONE generator for the K picks, each pick WeightedIndex::<f32>::new(potentials).sample(rng): f32
+ * running sums in index order (sequential by definition: one wavefront, ~4 ns per point), x = Uniform::new(0, total).sample,
+ * partition_point (include/rp_refrng.h).  Single GPU: the running sums span all N points in order, so the sharded k-means++
+ * (rp_kmeans_kpp_* composed across ranks) keeps the fixed-point draw.  `seed` is not used in this mode. */
+RP_API int rp_kmeans_set_rng(rp_kmeans* h, rp_rng_kind kind, int street);
 /* install centroids = copies of the given points (TestLayer-style explicit seeding, tests.rs:100-102) */
 RP_API int rp_kmeans_set_centroids(rp_kmeans* h, const uint64_t* point_index);
 /* install / read one centroid as an integer histogram (counts[bins] u32): resume, and the multi-GPU

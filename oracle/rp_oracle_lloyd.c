@@ -31,6 +31,7 @@
 
 #include "../include/rp_math.h"
 #include "../include/rp_mi355x.h"
+#include "../include/rp_refrng.h"
 
 #define ORA_API __attribute__((visibility("default")))
 #define ORA_MAXBINS 256
@@ -283,6 +284,8 @@ typedef struct ora_kmeans {
     float* tri;
     rp_sinkhorn_hp hp;
     uint64_t seed;
+    int rng;    /* rp_rng_kind: RP_RNG_REFERENCE = layer.rs:155-166's own generator and WeightedIndex<f32> */
+    int street; /* Street discriminant hashed into the generator's seed (layer.rs:156-158; deuce/src/street.rs:21-27) */
     ora_hist* points;
     float* self_p; /* OT(p,p) per point */
     ora_hist* cent;
@@ -381,19 +384,59 @@ ORA_API void ora_kmeans_kpp_update(ora_kmeans* h, uint32_t k) {
         h->pot[i] = rp_minf(d * d, h->pot[i]);
     }
 }
+ORA_API void ora_kmeans_set_rng(ora_kmeans* h, int kind, int street) {
+    h->rng = kind;
+    h->street = street;
+}
+/* WeightedIndex::new(potentials.iter()).sample(rng) (layer.rs:164-166; rand 0.9.2 weighted_index.rs): f32 running sums in index
+ * order, x = Uniform::new(0, total).sample(rng), partition_point(cum <= x) over the sums of all but the last weight.
+ * Returns N when the weights are invalid (total == 0: the reference panics on "valid weights array"). */
+static uint64_t weighted_index_f32(const float* w, uint64_t n, rp_smallrng* rng, float* cum) {
+    float total = w[0];
+    for (uint64_t i = 0; i + 1 < n; ++i) {
+        cum[i] = total;
+        total += w[i + 1];
+    }
+    if (!(total > 0.0f)) return n;
+    const float x = rp_rand_uniform_f32(rng, rp_uniform_f32_scale(total));
+    uint64_t lo = 0, hi = n - 1; /* partition_point over cum[0 .. n-1) */
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (cum[mid] <= x) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
 ORA_API void ora_kmeans_init_centroids(ora_kmeans* h, uint64_t* chosen) {
     uint32_t* hist = (uint32_t*)malloc(4 * ORA_MAXBINS);
     ora_kmeans_kpp_begin(h);
+    rp_smallrng rng;
+    float* cum = NULL;
+    if (h->rng == RP_RNG_REFERENCE) { /* DefaultHasher::default(); self.street().hash(hasher); SmallRng::seed_from_u64(finish()) */
+        rp_sip s;
+        rp_defaulthasher_new(&s);
+        rp_defaulthasher_write_u64(&s, (uint64_t)(int64_t)h->street); /* derive(Hash) on a fieldless enum: the discriminant as isize */
+        rp_smallrng_seed(&rng, rp_defaulthasher_finish(&s));
+        cum = (float*)malloc(4 * h->N);
+    }
     for (uint32_t k = 0; k < h->K; ++k) {
+        uint64_t pick;
+        if (h->rng == RP_RNG_REFERENCE) {
+            pick = weighted_index_f32(h->pot, h->N, &rng, cum);
+            if (pick >= h->N) pick = h->N - 1; /* all potentials zero: the reference panics; a defined answer here */
+            h->pot[pick] = 0.0f;
+        } else {
         uint64_t total = ora_kmeans_kpp_total(h);
         uint64_t hsh = rp_stream(h->seed, k);
-        uint64_t pick = total ? ora_kmeans_kpp_pick(h, rp_mulhi64(hsh, total)) : rp_mulhi64(hsh, h->N);
+        pick = total ? ora_kmeans_kpp_pick(h, rp_mulhi64(hsh, total)) : rp_mulhi64(hsh, h->N);
+        }
         if (chosen) chosen[k] = pick;
         ora_kmeans_get_point(h, pick, hist);
         ora_kmeans_set_centroid(h, k, hist);
         ora_kmeans_kpp_update(h, k);
     }
     free(hist);
+    free(cum);
 }
 
 /* Elkan::neighbor (elkan.rs:68-77): distance(centroid, point), first minimum wins */

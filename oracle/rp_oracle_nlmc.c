@@ -25,6 +25,7 @@
 
 #include "../include/rp_math.h"
 #include "../include/rp_mi355x.h"
+#include "../include/rp_refrng.h"
 #include "rp_oracle_nlhe.h"
 
 #define NLMC_A 9u /* widest infoset: 5 raise sizes + shove + call + fold (pokerkit/src/lib.rs:130-133: A <= 9) */
@@ -64,6 +65,7 @@ typedef struct ora_nlmc {
     uint8_t* used;
     uint32_t cap_log2, n_keys;
     int R, W, encoder;
+    int rng; /* rp_rng_kind: which generator draws the opponent's edge and Pluribus' coin */
     int S; /* rp_sampling_kind: External (the mccfr! default), Prunable, Pluribus (nlhe/src/lib.rs:86-90 Flagship) */
     rp_hyper hp;
     uint64_t seed;
@@ -213,6 +215,26 @@ static void describe(ora_nlmc* h, uint32_t idx) {
     nl_key k = {x->past, ch, abstraction(h, &x->g, x->turn)};
     x->row = row_of(h, &k, x->choice, x->n_choices);
 }
+/* CfrFlow::rng (flow.rs:285-295) in reference-seed mode: DefaultHasher over t, NlheInfo { subgame: Path(u64), choices: Path(u64),
+ * Abstraction(u16) } (nlhe/src/{info.rs:41-42, public.rs:19-23, secret.rs:10-11}), the tree's index */
+static uint64_t ref_seed(uint64_t epoch, uint64_t tree, const nl_key* k) {
+    rp_sip s;
+    rp_defaulthasher_new(&s);
+    rp_defaulthasher_write_u64(&s, epoch);
+    rp_defaulthasher_write_u64(&s, k->past);
+    rp_defaulthasher_write_u64(&s, k->choices);
+    rp_defaulthasher_write_u16(&s, (uint16_t)k->present);
+    rp_defaulthasher_write_u64(&s, tree);
+    return rp_defaulthasher_finish(&s);
+}
+static float draw_coin(const ora_nlmc* h, uint64_t epoch, uint64_t tree, const nl_key* k) {
+    if (h->rng == RP_RNG_REFERENCE) return rp_ref_draw_f32(ref_seed(epoch, tree, k)); /* rng.random::<f32>() */
+    return rp_u01(rp_node_hash(h->seed, epoch, tree, key_hash(k)));
+}
+static float draw_weight(const ora_nlmc* h, uint64_t epoch, uint64_t tree, const nl_key* k, float total) {
+    if (h->rng == RP_RNG_REFERENCE) return rp_ref_draw_weight(ref_seed(epoch, tree, k), total); /* WeightedIndex's Uniform(0, total) */
+    return rp_u01(rp_node_hash(h->seed, epoch, tree, key_hash(k))) * total;
+}
 /* ExternalSampling::sample (sample/external.rs:17-64): the choice slots to expand */
 static uint32_t sample_mask(const ora_nlmc* h, uint64_t epoch, uint64_t tree, const nl_node* x, int walker) {
     const uint32_t all = (1u << x->n_choices) - 1u;
@@ -226,7 +248,7 @@ static uint32_t sample_mask(const ora_nlmc* h, uint64_t epoch, uint64_t tree, co
         if (h->S == RP_SAMPLING_PLURIBUS) {
             if (epoch < h->hp.prune_warmup) return all;
             /* profile.rng(node): one stream per (epoch, infoset, tree) (flow.rs:285-295), first draw random::<f32>() */
-            if (rp_u01(rp_node_hash(h->seed, epoch, tree, key_hash(&k))) < h->hp.prune_explore) return all;
+            if (draw_coin(h, epoch, tree, &k) < h->hp.prune_explore) return all;
         }
         rp_encounter e[NLMC_A];
         ora_profile_get(h->prof, x->row, e);
@@ -252,7 +274,7 @@ static uint32_t sample_mask(const ora_nlmc* h, uint64_t epoch, uint64_t tree, co
         cum[a] = total;
     }
     const nl_key k = {h->keys[x->row].past, h->keys[x->row].choices, h->keys[x->row].present};
-    const float u = rp_u01(rp_node_hash(h->seed, epoch, tree, key_hash(&k))) * total;
+    const float u = draw_weight(h, epoch, tree, &k, total);
     uint32_t idx = 0;
     while (idx + 1 < x->n_choices && cum[idx] <= u) ++idx;
     return 1u << idx;
@@ -445,6 +467,7 @@ ORA_API ora_nlmc* ora_nlmc_create(uint32_t cap_log2, int R, int W, const rp_hype
 }
 /* SamplingScheme of the solver type (the macro's default is ExternalSampling; Flagship uses PluribusSampling) */
 ORA_API void ora_nlmc_set_sampling(ora_nlmc* h, int sampling) { h->S = sampling; }
+ORA_API void ora_nlmc_set_rng(ora_nlmc* h, int kind) { h->rng = kind; }
 ORA_API void ora_nlmc_destroy(ora_nlmc* h) {
     if (!h) return;
     ora_profile_destroy(h->prof);

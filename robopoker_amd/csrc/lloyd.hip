@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/rp_math.h"
+#include "../../include/rp_refrng.h"
 #include "rp_internal.h"
 
 namespace rp {
@@ -1766,6 +1767,59 @@ __global__ __launch_bounds__(1024) void k_kpp_pick(float* pot, float* kpp_d, uin
         if (kpp_d) kpp_d[win] = -1.0f;  // no solve stands behind that 0: its neighbor is found the long way
     }
 }
+// reference-seed mode (rp_kmeans_set_rng RP_RNG_REFERENCE): WeightedIndex::<f32>::new(potentials).sample(rng) (layer.rs:164-166;
+// rand 0.9.2 weighted_index.rs).  Its cumulative weights are f32 running sums in index order — f32 addition does not re-associate,
+// so the chain is sequential by definition: ONE wavefront walks it, 1024 potentials at a time through LDS; every lane runs the
+// same chain off broadcast LDS reads and keeps the sums of its own positions, so loads and stores stay coalesced.  ~4 ns per point:
+// 5 ms per pick at the flop layer's 1.3 M points, a few per cent of the round's Sinkhorn solves.
+// v01 = the generator's draw as UniformFloat<f32> maps it to [0, 1) (the host owns the SmallRng: one next_u32 per pick).
+#define KR_CHUNK 1024u
+__global__ __launch_bounds__(64) void k_kpp_ref_pick(float* pot, float* kpp_d, uint64_t N, float* cum, float v01, unsigned long long* picked) {
+    __shared__ float buf[KR_CHUNK];
+    const uint32_t ln = threadIdx.x;
+    float run = 0.0f;  // total_weight (0 + w0 = w0 exactly)
+    for (uint64_t base = 0; base < N; base += KR_CHUNK) {
+#pragma unroll
+        for (uint32_t q = 0; q < KR_CHUNK / 64u; ++q) {
+            const uint64_t i = base + q * 64u + ln;
+            buf[q * 64u + ln] = i < N ? pot[i] : 0.0f;  // + 0 past the end leaves the sum as it is
+        }
+        __syncthreads();
+        float mine[KR_CHUNK / 64u];
+#pragma unroll
+        for (uint32_t q = 0; q < KR_CHUNK / 64u; ++q) {
+#pragma unroll
+            for (uint32_t j = 0; j < 64u; ++j) {
+                run += buf[q * 64u + j];
+                mine[q] = j == ln ? run : mine[q];
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < KR_CHUNK / 64u; ++q) {
+            const uint64_t i = base + q * 64u + ln;
+            if (i < N) cum[i] = mine[q];  // cum[i] = w_0 + ... + w_i; WeightedIndex keeps i < N - 1, the last one is the total
+        }
+        __syncthreads();
+    }
+    __threadfence();
+    __syncthreads();
+    if (ln != 0) return;
+    const float total = run;
+    uint64_t win = N;  // invalid weights (total == 0): the reference panics ("valid weights array"); the host falls back
+    if (total > 0.0f) {
+        const float x = v01 * rp_uniform_f32_scale(total) + 0.0f;  // UniformFloat::sample: value0_1 * scale + low
+        uint64_t lo = 0, hi = N - 1;                               // partition_point(|w| w <= x) over cum[0 .. N-1)
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            if (__hip_atomic_load(&cum[mid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= x) lo = mid + 1;
+            else hi = mid;
+        }
+        win = lo;
+        pot[win] = 0.0f;                // potentials[i] = 0 (layer.rs:168)
+        if (kpp_d) kpp_d[win] = -1.0f;  // no solve stands behind that 0
+    }
+    picked[0] = win;
+}
 // potentials <- min(potentials, d(new centroid, point)^2) (layer.rs:170-178): distance(&x, h), centroid first
 __global__ __launch_bounds__(64) void k_kpp_update(Points P, CentroidSet cs, uint32_t k, uint32_t K, Metric M, int kind,
                                                    float* pot, const uint32_t* only, const unsigned int* count) {
@@ -1932,6 +1986,9 @@ struct rp_kmeans {
     int kind = 0;
     rp_sinkhorn_hp hp{};
     uint64_t seed = 0;
+    rp_rng_kind rng = RP_RNG_COUNTER;  // rp_kmeans_set_rng: RP_RNG_REFERENCE = the reference's generator and WeightedIndex<f32>
+    int street = 0;                    // Street discriminant hashed into that generator's seed (layer.rs:156-158)
+    float* kpp_cum = nullptr;          // [N] running sums of the potentials (reference-seed mode)
     std::vector<void*> allocs;
     bool owns_counts = true;
     Points P{};
@@ -2153,7 +2210,7 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
     KM_TRY(dev_alloc(h, &h->stats, (size_t)KM_STAT_STRIPES * STAT_STRIDE));
     KM_HIP(hipMemset(h->stats, 0, (size_t)KM_STAT_STRIPES * STAT_STRIDE * 8));
     h->M = Metric{d_C, d_R, bins, h->hp.iterations, h->hp.tolerance, h->stats, KM_STAT_STRIPES, nullptr, nullptr};
-    if (getenv("RP_LLOYD_NO_KPP_MEMO") == nullptr) {
+    {
         KM_TRY(dev_alloc(h, &h->M.kpp_d, N));
         KM_TRY(dev_alloc(h, &h->M.kpp_j, N));
         KM_TRY(dev_alloc(h, &h->kpp_todo, N));
@@ -2168,7 +2225,7 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
     KM_TRY(dev_alloc(h, &h->prior, N));
     KM_TRY(dev_alloc(h, &h->tmp_j, N));
     KM_TRY(dev_alloc(h, &h->pairw, (size_t)K * K));
-    h->memo_on = getenv("RP_LLOYD_NO_MEMO") == nullptr && kind == RP_METRIC_SINKHORN;
+    h->memo_on = kind == RP_METRIC_SINKHORN;
     if (h->memo_on) {
         KM_TRY(dev_alloc(h, &h->cver, (size_t)K));
         KM_TRY(dev_alloc(h, &h->pver, (size_t)K * K * 2));
@@ -2277,8 +2334,7 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
             // production self-check: every SB_SAMPLE_STRIDE-th point goes through the unpruned search after every pruned pass;
             // a disagreement fails the next call that hands results out (never a silently different bucket)
             std::vector<uint32_t> smp;
-            if (!getenv("RP_LLOYD_NO_SAMPLE_CHECK"))
-                for (uint64_t i = 0; i < N; i += SB_SAMPLE_STRIDE) smp.push_back((uint32_t)i);
+            for (uint64_t i = 0; i < N; i += SB_SAMPLE_STRIDE) smp.push_back((uint32_t)i);
             h->sb_nsample = (uint32_t)smp.size();
             KM_TRY(dev_alloc(h, &h->sb_sample, smp.size()));
             if (!smp.empty()) KM_HIP(hipMemcpy(h->sb_sample, smp.data(), smp.size() * 4, hipMemcpyHostToDevice));
@@ -2287,11 +2343,14 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         }
         h->sb_on = true;
     }
-    if (kind == RP_METRIC_SINKHORN && !getenv("RP_LLOYD_NO_PAIRS")) {
+    // RP_LLOYD_GROUPING (tests): "none" = one point per wavefront everywhere, "pairs" = no groups of four, "norefresh" = no regrouped
+    // refresh pass; every grouping performs the same float operations per solve (tests/test_gpu_lloyd.py)
+    const std::string grouping = getenv("RP_LLOYD_GROUPING") ? getenv("RP_LLOYD_GROUPING") : "";
+    if (kind == RP_METRIC_SINKHORN && grouping != "none") {
         // grouping lists: <= QUAD_ROWS bins -> four per wavefront, <= PAIR_ROWS -> two, the others one
         std::vector<uint32_t> tiny, small, rest;
-        const bool no_quads = getenv("RP_LLOYD_NO_QUADS") != nullptr;
-        if (!getenv("RP_LLOYD_NO_REFRESH_PASS")) {
+        const bool no_quads = grouping == "pairs";
+        if (grouping != "norefresh") {
             h->refresh.nsup = d_ns;
             KM_TRY(dev_alloc(h, &h->refresh.count, (size_t)K));
             KM_TRY(dev_alloc(h, &h->refresh.offset, (size_t)K + 1));
@@ -2407,7 +2466,7 @@ int launch_neighbor(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init, int
     const unsigned nblk = (unsigned)((h->N + 255) / 256);
     const float* ub0 = nullptr;
     const uint8_t* hint_j = nullptr;
-    if (h->sb.use_lb0 && !getenv("RP_SB_NO_HINT")) {
+    if (h->sb.use_lb0) {
         if (pass == NB_INIT_BOUNDS && h->pot_is_min_d2) {
             // right after k-means++: potentials = min_k d(c_k, x)^2 for exactly these centroids
             hipLaunchKernelGGL(k_ub_from_pot, dim3(nblk), dim3(256), 0, h->stream, h->pot, h->N, h->sb_ub0);
@@ -2575,6 +2634,14 @@ int rp_kmeans_set_centroids(rp_kmeans* h, const uint64_t* point_index) {
     return RP_OK;
 }
 
+int rp_kmeans_set_rng(rp_kmeans* h, rp_rng_kind kind, int street) {
+    if (!h || (kind != RP_RNG_COUNTER && kind != RP_RNG_REFERENCE) || street < 0 || street > 3)
+        return rp::fail(RP_ERR_INVALID, "rp_kmeans_set_rng: bad argument");
+    h->rng = kind;
+    h->street = street;
+    return RP_OK;
+}
+
 int rp_kmeans_kpp_begin(rp_kmeans* h) {
     if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_kpp_begin: NULL handle");
     HIP_TRY(hipSetDevice(h->device));
@@ -2706,14 +2773,35 @@ int rp_kmeans_init_centroids(rp_kmeans* h, uint64_t* chosen) {
     int rc = rp_kmeans_kpp_begin(h);
     if (rc) return rc;
     std::vector<uint32_t> hist(h->bins);
+    rp_smallrng rng;
+    if (h->rng == RP_RNG_REFERENCE) {  // DefaultHasher::default(); self.street().hash(hasher); SmallRng::seed_from_u64(hasher.finish())
+        rp_sip sh;
+        rp_defaulthasher_new(&sh);
+        rp_defaulthasher_write_u64(&sh, (uint64_t)(int64_t)h->street);  // a fieldless enum hashes its discriminant as isize
+        rp_smallrng_seed(&rng, rp_defaulthasher_finish(&sh));
+        if (!h->kpp_cum && (rc = dev_alloc(h, &h->kpp_cum, h->N))) return rc;
+    }
     for (uint32_t k = 0; k < h->K; ++k) {
         uint64_t total = 0, pick = 0;
+        if (h->rng == RP_RNG_REFERENCE) {
+            const float v01 = rp_u2f((rp_smallrng_next_u32(&rng) >> 9) | 0x3f800000u) - 1.0f;  // UniformFloat<f32>: [1, 2) - 1
+            ck_begin(h, CK_KPP);
+            hipLaunchKernelGGL(k_kpp_ref_pick, dim3(1), dim3(64), 0, h->stream, h->pot, h->M.kpp_d, h->N, h->kpp_cum, v01, h->scal);
+            ck_end(h, CK_KPP);
+            HIP_TRY(hipGetLastError());
+            unsigned long long pk = 0;
+            HIP_TRY(hipMemcpyAsync(&pk, h->scal, 8, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (pk >= h->N) return rp::fail(RP_ERR_INVALID, "rp_kmeans_init_centroids: every potential is zero after %u picks (fewer distinct points than K; the reference panics here)", k);
+            pick = pk;
+        } else {
         if ((rc = rp_kmeans_kpp_total(h, &total))) return rc;
         const uint64_t hsh = rp_stream(h->seed, k);
         if (total == 0) {
             pick = rp_mulhi64(hsh, h->N);
         } else if ((rc = rp_kmeans_kpp_pick(h, rp_mulhi64(hsh, total), &pick))) {
             return rc;
+        }
         }
         if (chosen) chosen[k] = pick;
         hipLaunchKernelGGL(k_centroid_from_point, dim3(1), dim3(256), 0, h->stream, h->cs[h->cur], k, h->P, pick, h->bins);

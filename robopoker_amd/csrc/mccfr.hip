@@ -413,10 +413,10 @@ __device__ __forceinline__ uint32_t d_sample_mask_tab(const DevGame& g, const De
 #define LM_NO_PARENT 63u
 
 // TVREG:  at most 4 actions, the per-action values of a root live in registers, not LDS.
-// TABLDS: the per-infoset sigma / q tables fit in LDS (a copy per wave); otherwise they are read through L1.
+// The per-infoset sigma / q tables are read through L1 (a per-wave LDS copy measured slower on Leduc: 0.57 vs 0.54 ms per 2^20 trees).
 // A node is TWO dwords (meta, value): the reach factor of its incoming edge is not stored but looked up as
 // table[infoset(parent)][edge] whenever a sweep needs it.  Leduc: 78 dwords per lane = 8 waves/CU.
-template <bool TVREG, bool TABLDS>
+template <bool TVREG>
 __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, DevDecisions dc, StepParams p, uint32_t maxn,
                                                      uint32_t maxs, uint32_t maxi) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -449,17 +449,8 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
     // register mask)
     float* xr = reinterpret_cast<float*>(ss);                        // [maxi][64] relative reach root's child -> node
     float* xs = xr + (size_t)maxi * 64;                              // [maxi][64] sampling reach root's child -> node
-    const uint32_t shared_rows = max(2u * maxi, 4u * maxs);
-    float* tab = reinterpret_cast<float*>(ss) + (size_t)shared_rows * 64;  // [2][n_infos * A] sigma, q (TABLDS)
     const uint32_t cells = g.n_infos * g.A;
-    if (TABLDS) {
-        for (uint32_t e = ln; e < cells; e += 64) {
-            tab[e] = it.sigma[e];
-            tab[cells + e] = it.q[e];
-        }
-        __syncthreads();
-    }
-    auto SIG = [&](uint32_t e) -> float { return TABLDS ? tab[e] : it.sigma[e]; };
+    auto SIG = [&](uint32_t e) -> float { return it.sigma[e]; };
     if (lane >= p.batch) return;
     const uint64_t tree_id = p.tree_base + lane;
     uint32_t err = 0;
@@ -472,7 +463,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
         const uint32_t pt = LM_PTYPE(mn);
         if (pt != PT_WALKER && pt != PT_OPP) return make_float2(1.0f, 1.0f);
         const uint32_t e = LM_INFO(mp) * g.A + LM_EDGE(mn);
-        float2 f = TABLDS ? make_float2(tab[e], tab[cells + e]) : it.sq[e];
+        float2 f = it.sq[e];
         if (pt != PT_OPP) f.y = 1.0f;
         return f;
     };
@@ -482,7 +473,6 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     auto f_issue = [&](uint32_t mn, uint32_t mp) -> float2 {
         const uint32_t e = LM_INFO(mp) * g.A + LM_EDGE(mn);
-        if (TABLDS) return make_float2(tab[e < cells ? e : 0u], tab[cells + (e < cells ? e : 0u)]);
         const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(sq_rsrc, (int)(e * 8u), 0, 0);
         return make_float2(rp_u2f(raw.x), rp_u2f(raw.y));
     };
@@ -1692,12 +1682,9 @@ struct rp_mccfr {
     bool use_lds_traverse = false;
     // the per-infoset tables of the traversal (DevInfoTab) are a function of the regret/strategy tables: refreshed when stale
     uint64_t tables_version = 1, itab_version = 0;
-    bool split_payoff = false;  // RP_TRAV_SPLIT_PAYOFF=1: k_traverse_maps_static hands the payoff sums out after the map chains
-    uint32_t cell_pad = 7;  // RP_TRAV_CELL_PAD (0..31): words between the cells' value arrays in k_traverse_maps_static's LDS (bank spread)
+    static constexpr uint32_t cell_pad = 7;  // words between the cells' value arrays in k_traverse_maps_static's LDS (bank spread)
     bool fuse_maps = true;  // composed update: traversal + block maps in one kernel when the game allows (RP_TRAV_UNFUSED=1: never)
     int static_skel = 0;  // 0: none (k_traverse_lds / k_traverse), 1: KuhnSkel, 2: LeducSkel (traverse_static.hpp)
-    bool static_pruned = true;  // RP_TRAV_STATIC_EXTERNAL_ONLY=1: the pruned schemes keep k_traverse_lds (cross-check)
-    bool no_static_pruned_ok(int S) const { return S != RP_SAMPLING_EXTERNAL && !static_pruned; }
     bool profiling = false;
     KernelClock clk_traverse, clk_compact, clk_update;
 };
@@ -1953,18 +1940,11 @@ bool build_flat(const rp_game_table* game, const std::vector<uint32_t>& children
     return true;
 }
 
-// The per-infoset sigma / q tables can ride in LDS (a copy per wave) when they are small; measured on Leduc the L1 path
-// at 8 waves/CU beats the LDS copy at 7 (0.54 vs 0.57 ms per 2^20 trees), so LDS is opt-in (RP_TRAV_TAB_LDS=1).
-bool traverse_tables_in_lds(const rp_mccfr* h) {
-    return (size_t)2 * h->tbl.n_infos * h->tbl.max_actions * 4 <= 4096 && getenv("RP_TRAV_TAB_LDS");
-}
 size_t traverse_lds_bytes(const rp_mccfr* h) {
     const size_t shared = std::max<size_t>(2 * (size_t)h->maxint, 4 * (size_t)h->sc.maxs);  // stack, then reach prefixes
-    return ((size_t)2 * h->sc.maxn + shared + (h->tbl.max_actions <= 4 ? 0 : h->tbl.max_actions)) * 64 * 4 +
-           (traverse_tables_in_lds(h) ? (size_t)2 * h->tbl.n_infos * h->tbl.max_actions * 4 : 0);
+    return ((size_t)2 * h->sc.maxn + shared + (h->tbl.max_actions <= 4 ? 0 : h->tbl.max_actions)) * 64 * 4;
 }
 bool traverse_fits_lds(const rp_mccfr* h) {
-    if (getenv("RP_DEBUG")) fprintf(stderr, "traverse: maxn=%u maxs=%u maxint=%u lds=%zu B/wave\n", h->sc.maxn, h->sc.maxs, h->maxint, traverse_lds_bytes(h));
     return h->sc.maxn <= 62 && h->maxint <= 32 && h->tbl.max_depth <= 10 && h->tbl.n_infos <= 8191 && h->tbl.max_actions <= 16 &&
            traverse_lds_bytes(h) <= 64 * 1024;
 }
@@ -1991,7 +1971,7 @@ void launch_prepare(rp_mccfr* h, const StepParams& p) {
 int launch_traverse(rp_mccfr* h, const StepParams& p) {
     if (h->dc.slotmap) HIP_TRY(hipMemsetAsync(h->dc.slotmap, 0, (size_t)h->tbl.n_infos * h->dc.stride, h->stream));
     clock_begin(h, h->clk_traverse);
-    if (h->static_skel && !h->no_static_pruned_ok(p.S)) {
+    if (h->static_skel) {
         launch_prepare(h, p);
         const dim3 grid((h->batch + 255) / 256), block(256);
         const bool pr = p.S != RP_SAMPLING_EXTERNAL, rf = p.ref_info != nullptr;
@@ -2014,13 +1994,10 @@ int launch_traverse(rp_mccfr* h, const StepParams& p) {
         launch_prepare(h, p);
         const size_t lds = traverse_lds_bytes(h);
         const dim3 grid((h->batch + 63) / 64), block(64);
-        const bool tvreg = h->tbl.max_actions <= 4, tablds = traverse_tables_in_lds(h);
-#define LAUNCH_TRAVERSE(TV, TB) \
-    hipLaunchKernelGGL((k_traverse_lds<TV, TB>), grid, block, lds, h->stream, h->g, h->itab, h->dc, p, h->sc.maxn, h->sc.maxs, h->maxint)
-        if (tvreg && tablds) LAUNCH_TRAVERSE(true, true);
-        else if (tvreg) LAUNCH_TRAVERSE(true, false);
-        else if (tablds) LAUNCH_TRAVERSE(false, true);
-        else LAUNCH_TRAVERSE(false, false);
+#define LAUNCH_TRAVERSE(TV) \
+    hipLaunchKernelGGL((k_traverse_lds<TV>), grid, block, lds, h->stream, h->g, h->itab, h->dc, p, h->sc.maxn, h->sc.maxs, h->maxint)
+        if (h->tbl.max_actions <= 4) LAUNCH_TRAVERSE(true);
+        else LAUNCH_TRAVERSE(false);
 #undef LAUNCH_TRAVERSE
     } else {
         launch_prepare_ref(h, p);
@@ -2086,7 +2063,7 @@ size_t traverse_maps_lds_bytes(const rp_mccfr* h) {
     return (NI * 8 + 2 * NI) * 4 + NI * 8 * 2 + (NI + (NI & 1)) * 2 + (size_t)5 * (h->maxdec * 256 + h->cell_pad) * 4 + masks;
 }
 bool traverse_maps_fused(const rp_mccfr* h) {
-    return h->static_skel && !h->no_static_pruned_ok(h->S) && !h->dc.slotmap && h->tbl.n_infos <= CH_THREADS &&
+    return h->static_skel && !h->dc.slotmap && h->tbl.n_infos <= CH_THREADS &&
            traverse_maps_lds_bytes(h) <= 64 * 1024 && h->fuse_maps;
 }
 
@@ -2108,7 +2085,7 @@ int launch_summarize(rp_mccfr* h, const StepParams& p, void* blob_dev, bool fuse
         const size_t lds = traverse_maps_lds_bytes(h);
 #define LAUNCH_FUSED_AS(G, WK, PR, RF)                                                                                                  \
     hipLaunchKernelGGL((k_traverse_maps_static<G, WK, PR, RF>), dim3(nblk), dim3(256), lds, h->stream, h->g, h->itab, p, bmaps, bpsum, \
-                       bcnt, nblk_max, h->maxdec, h->cell_pad | (h->split_payoff ? 256u : 0u))
+                       bcnt, nblk_max, h->maxdec, h->cell_pad)
 #define LAUNCH_FUSED(G, WK)                                    \
     do {                                                       \
         const bool rf = p.ref_info != nullptr;                 \
@@ -2369,15 +2346,12 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
     }
     h->use_lds_traverse = traverse_fits_lds(h) && getenv("RP_MCCFR_HBM_SCRATCH") == nullptr;
     h->fuse_maps = getenv("RP_TRAV_UNFUSED") == nullptr;
-    h->split_payoff = getenv("RP_TRAV_SPLIT_PAYOFF") != nullptr;
-    if (getenv("RP_TRAV_CELL_PAD")) h->cell_pad = (uint32_t)std::min(31, std::max(0, atoi(getenv("RP_TRAV_CELL_PAD"))));
-    h->static_pruned = getenv("RP_TRAV_STATIC_EXTERNAL_ONLY") == nullptr;
     if (h->use_lds_traverse && getenv("RP_TRAV_GENERIC") == nullptr) {
         if (skel_matches<KuhnSkel>(game, h->children)) h->static_skel = 1;
         else if (skel_matches<LeducSkel>(game, h->children)) h->static_skel = 2;
     }
     h->g.flat = nullptr;
-    if (h->static_skel && getenv("RP_TRAV_NO_FLAT") == nullptr) {
+    if (h->static_skel) {
         const std::function<uint4(uint32_t)> rec_of = [&](uint32_t sid) {
             uint4 r = packed[sid];
             r.w = sid;
@@ -2868,7 +2842,7 @@ int rp_game_skeleton(const rp_game_table* game, int* out) {
 
 int rp_mccfr_traversal_variant(rp_mccfr* h, int* out) {
     if (!h || !out) return rp::fail(RP_ERR_INVALID, "rp_mccfr_traversal_variant: NULL argument");
-    *out = (h->static_skel && !h->no_static_pruned_ok(h->S)) ? 2 : (h->use_lds_traverse ? 1 : 0);
+    *out = h->static_skel ? 2 : (h->use_lds_traverse ? 1 : 0);
     return RP_OK;
 }
 

@@ -42,287 +42,6 @@ namespace rp {
         if (_e != hipSuccess) return rp::fail(RP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
-// ================================================================================================================
-// The first device version: ONE LANE PER TREE.  Kept as an independent cross-check of the level-synchronous traversal
-// (RP_NLHE_LANE_PER_TREE=1; tests/test_gpu_nlmc.py compares the two bit for bit) — not the product path.
-// ================================================================================================================
-// per-tree scratch, tree-major (a lane walks its own region sequentially)
-struct NlScratch {
-    uint32_t* meta;    // [batch][ncap]  parent (13) | slot (4) << 13 | kind (2) << 17 | n_choices (4) << 19
-    float* fac;        // [batch][ncap]  factor of the edge into the node
-    float* val;        // [batch][ncap]  D(node), later reach(node)
-    uint32_t* aux;     // [batch][ncap]  walker nodes: ordinal among the tree's walker nodes
-    uint32_t* wrow;    // [batch][wcap]
-    uint32_t* wnode;   // [batch][wcap]
-    float* kidd;       // [batch][wcap][A]  D of the walker node's children by choice slot
-    uint32_t* stack;   // [batch][scap][12]
-    // per-tree Decisions
-    uint32_t* drow;    // [batch][dcap]
-    uint32_t* dmeta;   // [batch][dcap]  n_actions | expanded << 8
-    float* dreg;       // [batch][dcap][A]
-    float* dpol;       // [batch][dcap][A]
-    float* dpay;       // [batch][dcap]
-    uint32_t* dmap;    // [batch][2 * dcap]  row -> decision index + 1
-    uint32_t* dcount;  // [batch]
-    uint32_t* ncount;  // [batch] nodes of the tree
-};
-
-// stack entry: [0..4] packed game, [5] parent | slot << 13 | edge << 17 | depth << 22 | plen << 25, [6,7] past, [8,9] hkey, [10] fac
-#define NL_SENT 12u
-
-__global__ __launch_bounds__(64) void k_nlhe_traverse(NlParams p, NlTable t, NlScratch sc, unsigned long long* counters) {
-    const uint32_t tree = blockIdx.x * 64u + threadIdx.x;  // slot of the tree in this rank's scratch
-    if (tree >= p.batch) return;
-    const uint64_t tree_id = p.tree_base + tree;           // its id in the epoch: what the random draws are keyed by
-    uint32_t err = 0;
-    uint32_t* meta = sc.meta + (size_t)tree * p.ncap;
-    float* fac = sc.fac + (size_t)tree * p.ncap;
-    float* val = sc.val + (size_t)tree * p.ncap;
-    uint32_t* aux = sc.aux + (size_t)tree * p.ncap;
-    uint32_t* wrow = sc.wrow + (size_t)tree * p.wcap;
-    uint32_t* wnode = sc.wnode + (size_t)tree * p.wcap;
-    float* kidd = sc.kidd + (size_t)tree * p.wcap * NLMC_A;
-    uint32_t* stack = sc.stack + (size_t)tree * p.scap * NL_SENT;
-    const int walker = (int)p.walker;
-    // ---- Solver::tree: Game::root() with the hole cards dealt (P0 on the button, game.rs:66-78)
-    G2 g;
-    g.n = 2;
-    g.dealer = 0;
-    g.ticker = 0;  // n == 2: the dealer posts the small blind
-    g.pot = 0;
-    g.board = 0;
-    uint64_t deck = HAND_MASK;
-    for (int i = 0; i < 2; ++i) {
-        g.state[i] = NL_BETTING;
-        g.stack[i] = 200;
-        g.stake[i] = g.spent[i] = 0;
-        g.cards[i] = nl_draw(deck, 2, p, tree_id, 0xD0C0000000000000ull + 8u * (uint64_t)i);
-        deck &= ~g.cards[i];
-    }
-    for (int b = 0; b < 2; ++b) g.force_act(NlAction{NA_BLIND, g.to_post(), 0});
-    const uint64_t hole0 = g.cards[0], hole1 = g.cards[1];
-    uint32_t n = 0, top = 0, nw = 0;
-    // the node being grown
-    uint32_t cur_parent = 0, cur_slot = 0, cur_depth = 0, cur_plen = 0;
-    uint64_t cur_past = 0, cur_hkey = rp_mix64(0x726f6f74ull);
-    float cur_fac = 1.0f;
-    for (;;) {
-        // ---- grow: node n = (g, info)
-        if (n >= p.ncap) {
-            err |= NERR_NODES;
-            break;
-        }
-        const uint32_t me = n++;
-        const int turn = g.turn();
-        uint32_t kind, nch = 0;
-        uint32_t edges[12];
-        float nodeval = 0.0f;
-        float sigma[NLMC_A];
-        float childfac_opp = 1.0f;
-        uint32_t pick = 0;
-        NlView view{};
-        if (turn == NT_TERMINAL) {
-            kind = NK_TERMINAL;
-            int reward[2];
-            nl_settle(g, reward);
-            nodeval = (float)(reward[walker] - g.spent[walker]);  // NlheGame::payoff (nlhe/src/game.rs:59-65)
-        } else if (turn == NT_CHANCE) {
-            kind = NK_CHANCE;
-            nch = 1;
-            edges[0] = NE_DRAW;
-        } else {
-            view = nl_view(g);
-            nch = (uint32_t)nl_choices_v(view, (int)cur_depth, edges);
-            uint64_t chpath = 0;
-            for (uint32_t a = 0; a < nch; ++a) chpath |= (uint64_t)edges[a] << (5u * a);
-            const uint32_t bucket = nl_bucket(p, g.street(), turn == 0 ? hole0 : hole1, g.board, &err);
-            const uint64_t khash = nl_key_hash(cur_past, chpath, bucket);  // the table slot and, at an opponent node, the draw's key
-            const uint32_t row = nl_row_of(t, cur_past, chpath, bucket, khash, nch, p.tag, &err);
-            const float* r = t.rows + (size_t)row * 4u * NLMC_A;
-            float rd = 0.0f;
-            for (uint32_t a = 0; a < nch; ++a) {
-                sigma[a] = rp_maxf(r[a], RP_EPSILON);  // RefProf::regret (profile.rs:31-33)
-                rd += sigma[a];
-            }
-            for (uint32_t a = 0; a < nch; ++a) sigma[a] = sigma[a] / rd;  // instant_policy (flow.rs:46-48)
-            if (turn == walker) {
-                kind = NK_WALKER;
-                if (nw >= p.wcap) {
-                    err |= NERR_WALKERS;
-                    break;
-                }
-                aux[me] = nw;
-                wrow[nw] = row;
-                wnode[nw] = me;
-                nw += 1;
-            } else {
-                // weighted (sample/external.rs:41-64) over sampling_distribution (flow.rs:24-42), one draw per (epoch, infoset, tree)
-                kind = NK_OPP;
-                float wsum = 0.0f, wv[NLMC_A];
-                for (uint32_t a = 0; a < nch; ++a) {
-                    wv[a] = rp_maxf(r[NLMC_A + a], RP_EPSILON);
-                    wsum += wv[a];
-                }
-                const float denom = wsum + p.smoothing;
-                float z = 0.0f, sw[NLMC_A];
-                for (uint32_t a = 0; a < nch; ++a) {
-                    sw[a] = rp_maxf((wv[a] / p.temperature + p.smoothing) / denom, p.curiosity);
-                    z += sw[a];
-                }
-                float cum[NLMC_A], total = 0.0f;
-                for (uint32_t a = 0; a < nch; ++a) {
-                    total += rp_maxf(sw[a] / z, RP_EPSILON);
-                    cum[a] = total;
-                }
-                const float u = rp_u01(rp_node_hash_draw(p.step_hash, tree_id, khash)) * total;
-                while (pick + 1 < nch && cum[pick] <= u) ++pick;
-                childfac_opp = sigma[pick] / (sw[pick] / z);
-            }
-        }
-        meta[me] = cur_parent | (cur_slot << 13) | (kind << 17) | (nch << 19);
-        fac[me] = cur_fac;
-        val[me] = nodeval;
-        // ---- branches + sample: push the children to expand, ascending choice slot (popped last-first)
-        for (uint32_t a = 0; a < nch; ++a) {
-            if (kind == NK_OPP && a != pick) continue;
-            if (top >= p.scap) {
-                err |= NERR_STACK;
-                break;
-            }
-            const uint32_t e = edges[a];
-            const uint64_t hk = rp_mix64(cur_hkey ^ ((uint64_t)(e + 1u) * 0x9fb21c651e98df25ull));
-            G2 c = g;
-            NlAction act;
-            if (e == NE_DRAW) act = NlAction{NA_DRAW, 0, nl_draw(g.deck(), g.street() == 0 ? 3 : 1, p, tree_id, hk)};
-            else act = nl_action_v(view, e);
-            // Game::apply panics on an illegal action (kicker game.rs:234-247).  snap()'s output is legal by construction, so
-            // the test can only catch an engine bug: it runs in the checking mode (RP_NLHE_CHECK_LEGAL=1, the tests), not per child
-            if (p.check_legal && !c.allowed(act)) err |= NERR_ILLEGAL;
-            c.force_act(act);
-            const Packed pk = pack_game(c);
-            uint32_t* se = stack + (size_t)top * NL_SENT;
-            const bool raise = e == NE_SHOVE || e >= NE_OPEN0;
-            const uint32_t cdepth = e == NE_DRAW ? 0u : cur_depth + (raise ? 1u : 0u);
-            const uint32_t cplen = e == NE_DRAW ? 0u : cur_plen + 1u;
-            const uint64_t cpast = e == NE_DRAW ? 0ull : (cur_plen < 12u ? cur_past | ((uint64_t)e << (5u * cur_plen)) : cur_past);
-            se[0] = pk.w0; se[1] = pk.w1; se[2] = pk.w2; se[3] = pk.blo; se[4] = pk.bhi;
-            se[5] = me | (a << 13) | (cdepth << 22) | (cplen << 25);
-            se[6] = (uint32_t)cpast; se[7] = (uint32_t)(cpast >> 32);
-            se[8] = (uint32_t)hk; se[9] = (uint32_t)(hk >> 32);
-            const float f = kind == NK_WALKER ? sigma[a] : (kind == NK_OPP ? childfac_opp : 1.0f);
-            se[10] = __float_as_uint(f);
-            top += 1;
-        }
-        if (err & (NERR_STACK | NERR_NODES | NERR_WALKERS)) break;
-        if (top == 0) break;
-        // ---- pop-last (builder.rs:143)
-        top -= 1;
-        const uint32_t* se = stack + (size_t)top * NL_SENT;
-        unpack_game(Packed{se[0], se[1], se[2], se[3], se[4]}, g);
-        cur_parent = se[5] & 0x1fffu;
-        cur_slot = (se[5] >> 13) & 15u;
-        cur_depth = (se[5] >> 22) & 7u;
-        cur_plen = (se[5] >> 25) & 15u;
-        cur_past = (uint64_t)se[6] | ((uint64_t)se[7] << 32);
-        cur_hkey = (uint64_t)se[8] | ((uint64_t)se[9] << 32);
-        cur_fac = __uint_as_float(se[10]);
-    }
-    sc.ncount[tree] = n;
-    uint32_t nd = 0;
-    if (!err) {
-        // ---- D(node): descending index adds a node's children in choices() order (the reference's newest-edge-first walk)
-        for (uint32_t w = 0; w < nw * NLMC_A; ++w) kidd[w] = 0.0f;
-        for (uint32_t i = n - 1; i >= 1; --i) {
-            const uint32_t m = meta[i], par = m & 0x1fffu;
-            const float d = val[i];
-            val[par] += fac[i] * d;
-            if (((meta[par] >> 17) & 3u) == NK_WALKER) kidd[(size_t)aux[par] * NLMC_A + ((m >> 13) & 15u)] = d;
-        }
-        // ---- reach(node): sigma / q over the opponent ancestors (ancestor_reach, flow.rs:166-174); chance and walker edges carry 1
-        val[0] = 1.0f;
-        for (uint32_t i = 1; i < n; ++i) {
-            const uint32_t par = meta[i] & 0x1fffu;
-            val[i] = ((meta[par] >> 17) & 3u) == NK_OPP ? val[par] * fac[i] : val[par];
-        }
-        // ---- Decisions: infosets in the order of their first walker node, span in ascending node index (tree.rs:88-98)
-        uint32_t* drow = sc.drow + (size_t)tree * p.dcap;
-        uint32_t* dmeta = sc.dmeta + (size_t)tree * p.dcap;
-        float* dreg = sc.dreg + (size_t)tree * p.dcap * NLMC_A;
-        float* dpol = sc.dpol + (size_t)tree * p.dcap * NLMC_A;
-        float* dpay = sc.dpay + (size_t)tree * p.dcap;
-        uint32_t* dmap = sc.dmap + (size_t)tree * 2u * p.dcap;
-        const uint32_t dmask = 2u * p.dcap - 1u;
-        for (uint32_t q = 0; q <= dmask; ++q) dmap[q] = 0u;
-        for (uint32_t w = 0; w < nw; ++w) {
-            const uint32_t node = wnode[w], row = wrow[w];
-            const uint32_t nch = (meta[node] >> 19) & 15u;
-            if (nch == 0) continue;
-            uint32_t s = (row * 2654435761u) & dmask, d = 0;
-            for (;;) {
-                if (dmap[s] == 0u) {
-                    if (nd >= p.dcap) {
-                        err |= NERR_DECISIONS;
-                        break;
-                    }
-                    d = nd++;
-                    dmap[s] = d + 1u;
-                    drow[d] = row;
-                    dmeta[d] = nch;
-                    dpay[d] = 0.0f;
-                    for (uint32_t a = 0; a < NLMC_A; ++a) dreg[(size_t)d * NLMC_A + a] = 0.0f, dpol[(size_t)d * NLMC_A + a] = 0.0f;
-                    break;
-                }
-                if (drow[dmap[s] - 1u] == row) {
-                    d = dmap[s] - 1u;
-                    break;
-                }
-                s = (s + 1u) & dmask;
-            }
-            if (err) break;
-            const float* r = t.rows + (size_t)row * 4u * NLMC_A;
-            float sg[NLMC_A], rd = 0.0f;
-            for (uint32_t a = 0; a < nch; ++a) {
-                sg[a] = rp_maxf(r[a], RP_EPSILON);
-                rd += sg[a];
-            }
-            const float reach = val[node];
-            float cfv[NLMC_A], ev = 0.0f;
-            for (uint32_t a = 0; a < nch; ++a) cfv[a] = reach * kidd[(size_t)w * NLMC_A + a];
-            for (uint32_t a = 0; a < nch; ++a) ev += sg[a] / rd * cfv[a];
-            dpay[d] += ev;
-            for (uint32_t a = 0; a < nch; ++a) {
-                dreg[(size_t)d * NLMC_A + a] += cfv[a] - ev;
-                dpol[(size_t)d * NLMC_A + a] = sg[a] / rd;  // policy_vector = iterated_distribution (flow.rs:118-120)
-            }
-            dmeta[d] = nch | (((1u << nch) - 1u) << 8);  // external sampling expands every walker edge
-        }
-    }
-    sc.dcount[tree] = err ? 0u : nd;
-    // metrics: nodes, infos; error flags
-    atomicAdd(counters + 0, (unsigned long long)n);
-    atomicAdd(counters + 1, (unsigned long long)(err ? 0u : nd));
-    if (err) atomicOr(counters + 2, (unsigned long long)err);
-}
-
-__global__ __launch_bounds__(256) void k_nlhe_pack(NlScratch sc, uint32_t batch, uint32_t dcap, const uint32_t* offset, NlBatch out) {
-    const uint32_t tree = blockIdx.x;
-    const uint32_t nd = sc.dcount[tree], base = offset[tree];
-    for (uint32_t e = threadIdx.x; e < nd * NLMC_A; e += 256) {
-        const uint32_t d = e / NLMC_A, a = e % NLMC_A;
-        const size_t src = ((size_t)tree * dcap + d) * NLMC_A + a, dst = (size_t)(base + d) * NLMC_A + a;
-        out.regret[dst] = sc.dreg[src];
-        out.policy[dst] = sc.dpol[src];
-    }
-    for (uint32_t d = threadIdx.x; d < nd; d += 256) {
-        const size_t src = (size_t)tree * dcap + d;
-        out.row[base + d] = sc.drow[src];
-        out.nact[base + d] = (uint8_t)(sc.dmeta[src] & 0xffu);
-        out.expanded[base + d] = (uint16_t)(sc.dmeta[src] >> 8);
-        out.payoff[base + d] = sc.dpay[src];
-        out.tree[base + d] = tree;
-    }
-}
-
 // ---- the multi-GPU exchange by infoset key (every rank's table assigns rows in its own insertion order) ----
 // entries: rp_profile_summarize's records, [row u32][count u32][psum f32][n_actions u32][maps]; keys beside them
 __global__ __launch_bounds__(256) void k_nlhe_entry_keys(NlTable t, const unsigned char* entries, uint32_t eb, uint32_t n, uint64_t* past,
@@ -357,14 +76,11 @@ struct rp_nlhe {
     uint64_t seed = 0;
     NlTable tab{};
     NlParams prm{};
-    bool lane_per_tree = false;  // RP_NLHE_LANE_PER_TREE=1: the first device version (cross-check)
-    NlScratch sc{};              // lane-per-tree scratch (allocated in that mode only)
     NlNodes lv{};                // level-synchronous traversal
     NlBatch out{};
     uint32_t out_cap = 0;
     uint32_t* d_offset = nullptr;
     uint32_t* d_total = nullptr;   // [0] Decisions of the batch, [1] walker nodes of the batch
-    unsigned long long* d_counters = nullptr;  // lane-per-tree kernel: nodes, infos, error flags of the launch
     void* d_scan = nullptr;                    // scratch of the per-tree scans
     void *x_keys = nullptr, *x_counts = nullptr, *x_all = nullptr, *x_packed = nullptr;  // rp_nlhe_step_comm: grow-only exchange buffers
     size_t x_keys_bytes = 0, x_counts_bytes = 0, x_all_bytes = 0, x_packed_bytes = 0;
@@ -383,11 +99,8 @@ struct rp_nlhe {
     bool profiling = false;
     Clock clk[5];  // expand, children, sweeps (up + down), decide (scan + fill + group + emit), apply
     uint64_t census[5] = {0, 0, 0, 0, 0};  // nodes by kind + walker children, summed over the profiled steps
-    int expand_waves = 4;  // RP_NLHE_EXPAND_WAVES: 4 (128 VGPRs) or 5 (96 VGPRs, some spilled)
-    int expand_threads = 256;  // RP_NLHE_EXPAND_THREADS: workgroup size of k_nl_expand (64 / 128 / 256)
-    bool fused_levels = false;  // RP_NLHE_FUSED_LEVELS=1: one launch per tree level (k_nl_expand<4, 256, true> makes the nodes it expands)
     uint32_t chunks = 1;  // passes per batch (RP_NLHE_CHUNKS; doubled when a pass runs out of nodes)
-    uint32_t grid_cap = 16384;  // workgroups of the grid-stride kernels (RP_NLHE_GRID; measured: 1024 -14 %, 4096 -4 %)
+    uint32_t grid_cap = 16384;  // workgroups of the grid-stride kernels (measured: 1024 -14 %, 4096 -4 %)
 };
 
 namespace {
@@ -440,31 +153,12 @@ void nl_begin_step(rp_nlhe* h) {
     h->prm.epoch = rp::profile_epoch(h->prof);
     h->prm.walker = (uint32_t)(h->prm.epoch % 2u);  // CfrSampling::walker (book.rs:142-144)
     h->prm.step_hash = rp_node_hash_step(h->prm.seed, h->prm.epoch);
-}
-
-// ---- the lane-per-tree traversal of the current epoch: Decisions in h->out, their count in h->last_n
-int nl_traverse_lanes(rp_nlhe* h) {
-    hipStream_t st = rp::profile_stream(h->prof);
-    nl_begin_step(h);
-    h->prm.tag = nl_next_tag(h);
-    HIP_TRY(hipMemsetAsync(h->d_counters, 0, 3 * sizeof(unsigned long long), st));  // per launch: an error does not stick to the handle
-    hipLaunchKernelGGL(k_nlhe_traverse, dim3((h->batch + 63u) / 64u), dim3(64), 0, st, h->prm, h->tab, h->sc, h->d_counters);
-    hipLaunchKernelGGL(k_nlhe_scan, dim3(1), dim3(1024), 0, st, h->sc.dcount, h->batch, h->d_offset, h->d_total);
-    HIP_TRY(hipGetLastError());
-    uint32_t total = 0;
-    unsigned long long c[3] = {0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(&total, h->d_total, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(c, h->d_counters, 24, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (c[2]) return nl_capacity_error(c[2]);
-    if (total > h->out_cap) return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %u Decisions in one batch exceed the buffer (%u)", total, h->out_cap);
-    hipLaunchKernelGGL(k_nlhe_pack, dim3(h->batch), dim3(256), 0, st, h->sc, h->batch, h->prm.dcap, h->d_offset, h->out);
-    HIP_TRY(hipGetLastError());
-    h->last_n = total;
-    h->nodes += c[0];
-    h->infos += c[1];
-    h->last_nodes = (uint32_t)c[0];
-    return RP_OK;
+    if (h->prm.ref_rng) {  // DefaultHasher::new(); self.t().hash(hasher)  (flow.rs:289-291)
+        rp_sip s;
+        rp_defaulthasher_new(&s);
+        rp_defaulthasher_write_u64(&s, h->prm.epoch);
+        h->prm.ref_v[0] = s.v0; h->prm.ref_v[1] = s.v1; h->prm.ref_v[2] = s.v2; h->prm.ref_v[3] = s.v3;
+    }
 }
 
 // ---- the level-synchronous traversal (nlmc_level.hpp)
@@ -490,13 +184,8 @@ int nl_traverse_chunk(rp_nlhe* h, uint32_t lo, uint32_t B, uint32_t d_base, uint
         for (; L < stop; ++L) {
             prm.tag = nl_next_tag(h);
             nl_clock_begin(h, 0);
-            if (h->fused_levels) hipLaunchKernelGGL((k_nl_expand<4, 256, true>), wide_x, blk, 0, st, prm, h->tab, lv, L);
-            else if (h->expand_threads == 64) hipLaunchKernelGGL((k_nl_expand<4, 64>), wide_x, dim3(64), 0, st, prm, h->tab, lv, L);
-            else if (h->expand_threads == 128) hipLaunchKernelGGL((k_nl_expand<4, 128>), wide_x, dim3(128), 0, st, prm, h->tab, lv, L);
-            else if (h->expand_waves == 5) hipLaunchKernelGGL((k_nl_expand<5, 256>), wide_x, blk, 0, st, prm, h->tab, lv, L);
-            else hipLaunchKernelGGL((k_nl_expand<4, 256>), wide_x, blk, 0, st, prm, h->tab, lv, L);
+            hipLaunchKernelGGL((k_nl_expand<4, 256>), wide_x, blk, 0, st, prm, h->tab, lv, L);
             nl_clock_end(h, 0);
-            if (h->fused_levels) continue;  // the nodes of level L + 1 are made by the launch that expands them
             nl_clock_begin(h, 1);
             hipLaunchKernelGGL(k_nl_children, wide, blk, 0, st, prm, lv, L);
             nl_clock_end(h, 1);
@@ -589,7 +278,7 @@ int nl_traverse_levels(rp_nlhe* h) {
         return RP_OK;
     }
 }
-int nl_traverse(rp_nlhe* h) { return h->lane_per_tree ? nl_traverse_lanes(h) : nl_traverse_levels(h); }
+int nl_traverse(rp_nlhe* h) { return nl_traverse_levels(h); }
 }  // namespace
 
 extern "C" {
@@ -605,11 +294,6 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     h->batch = batch;
     h->hp = *hp;
     h->seed = seed;
-    h->lane_per_tree = getenv("RP_NLHE_LANE_PER_TREE") != nullptr;
-    if (getenv("RP_NLHE_GRID")) h->grid_cap = std::max(1, atoi(getenv("RP_NLHE_GRID")));
-    if (getenv("RP_NLHE_EXPAND_WAVES")) h->expand_waves = atoi(getenv("RP_NLHE_EXPAND_WAVES"));
-    if (getenv("RP_NLHE_EXPAND_THREADS")) h->expand_threads = atoi(getenv("RP_NLHE_EXPAND_THREADS"));
-    h->fused_levels = getenv("RP_NLHE_FUSED_LEVELS") != nullptr;
     if (getenv("RP_NLHE_CHUNKS")) h->chunks = (uint32_t)std::max(1, atoi(getenv("RP_NLHE_CHUNKS")));
 #define NL_TRY(expr)                    \
     do {                                \
@@ -655,7 +339,6 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     h->prm.prune_explore = hp->prune_explore;
     h->prm.prune_warmup = hp->prune_warmup;
     h->prm.check_legal = getenv("RP_NLHE_CHECK_LEGAL") ? 1u : 0u;
-    h->prm.ablate = getenv("RP_NLHE_ABLATE") ? (uint32_t)atoi(getenv("RP_NLHE_ABLATE")) : 0u;
     h->prm.encoder = 0;
     if (tables) {
         for (int s = 0; s < 4; ++s) {
@@ -668,28 +351,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
         h->prm.encoder = 1;
     }
     const size_t B = batch;
-    if (h->lane_per_tree) {
-        const uint32_t ncap = 4096, scap = 256, wcap = 2048, dcap = 1024;
-        h->prm.ncap = ncap; h->prm.scap = scap; h->prm.wcap = wcap; h->prm.dcap = dcap;
-        NL_TRY(nl_alloc(h, &h->sc.meta, B * ncap));
-        NL_TRY(nl_alloc(h, &h->sc.fac, B * ncap));
-        NL_TRY(nl_alloc(h, &h->sc.val, B * ncap));
-        NL_TRY(nl_alloc(h, &h->sc.aux, B * ncap));
-        NL_TRY(nl_alloc(h, &h->sc.wrow, B * wcap));
-        NL_TRY(nl_alloc(h, &h->sc.wnode, B * wcap));
-        NL_TRY(nl_alloc(h, &h->sc.kidd, B * wcap * NLMC_A));
-        NL_TRY(nl_alloc(h, &h->sc.stack, B * scap * NL_SENT));
-        NL_TRY(nl_alloc(h, &h->sc.drow, B * dcap));
-        NL_TRY(nl_alloc(h, &h->sc.dmeta, B * dcap));
-        NL_TRY(nl_alloc(h, &h->sc.dreg, B * dcap * NLMC_A));
-        NL_TRY(nl_alloc(h, &h->sc.dpol, B * dcap * NLMC_A));
-        NL_TRY(nl_alloc(h, &h->sc.dpay, B * dcap));
-        NL_TRY(nl_alloc(h, &h->sc.dmap, B * 2 * dcap));
-        NL_TRY(nl_alloc(h, &h->sc.dcount, B));
-        NL_TRY(nl_alloc(h, &h->sc.ncount, B));
-        NL_TRY(nl_alloc(h, &h->d_offset, B));
-        NL_TRY(nl_alloc(h, &h->d_counters, 4));
-    } else {
+    {
         NlNodes& lv = h->lv;
         const size_t N = (size_t)ncap64, LC = std::max<size_t>(N / walker_div, 64);  // walker nodes of a batch (a seventh of its nodes): a quarter of the node budget
         lv.ncap = (uint32_t)N;
@@ -735,13 +397,16 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
 // PrunableSampling, PluribusSampling (Flagship, nlhe/src/lib.rs:86-90); thresholds from the rp_hyper given at creation
 int rp_nlhe_set_sampling(rp_nlhe* h, rp_sampling_kind sampling) {
     if (!h || (int)sampling < 0 || (int)sampling > (int)RP_SAMPLING_PLURIBUS) return rp::fail(RP_ERR_INVALID, "rp_nlhe_set_sampling: bad argument");
-    if (h->lane_per_tree && sampling != RP_SAMPLING_EXTERNAL)
-        return rp::fail(RP_ERR_UNSUPPORTED, "rp_nlhe_set_sampling: the lane-per-tree cross-check kernel samples externally only");
     h->prm.sampling = (int)sampling;
     return RP_OK;
 }
 
 // shape of the last traversed batch (level-synchronous traversal): levels grown and nodes
+int rp_nlhe_set_rng(rp_nlhe* h, rp_rng_kind kind) {
+    if (!h || (kind != RP_RNG_COUNTER && kind != RP_RNG_REFERENCE)) return rp::fail(RP_ERR_INVALID, "rp_nlhe_set_rng: bad argument");
+    h->prm.ref_rng = kind == RP_RNG_REFERENCE ? 1u : 0u;
+    return RP_OK;
+}
 int rp_nlhe_last_shape(rp_nlhe* h, uint32_t* levels, uint32_t* nodes) {
     if (!h) return rp::fail(RP_ERR_INVALID, "rp_nlhe_last_shape: NULL handle");
     if (levels) *levels = h->last_levels;
@@ -828,7 +493,7 @@ int rp_nlhe_profile(rp_nlhe* h, int enable) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(rp::profile_stream(h->prof)));
     nl_clock_drain(h);
-    h->profiling = enable != 0 && !h->lane_per_tree;
+    h->profiling = enable != 0;
     for (auto& c : h->clk) c.total_ms = 0.0, c.launches = 0;
     for (auto& c : h->census) c = 0;
     return RP_OK;

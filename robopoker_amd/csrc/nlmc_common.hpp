@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/rp_math.h"
+#include "../../include/rp_refrng.h"
 #include "../../include/rp_mi355x.h"
 #include "nlhe_engine.hpp"
 #include "obs.hpp"
@@ -51,10 +52,13 @@ struct NlParams {
     const uint64_t* tkeys[4];
     const uint8_t* tabs[4];
     uint64_t tn[4];
-    uint32_t ncap, scap, wcap, dcap;  // lane-per-tree kernel: per-tree capacities (nodes, stack entries, walker nodes, Decisions)
+    // reference-seed mode (rp_nlhe_set_rng RP_RNG_REFERENCE, include/rp_refrng.h): DefaultHasher after t.hash() (flow.rs:290-291);
+    // a sampled node continues with NlheInfo's stream — subgame: Path(u64), choices: Path(u64), Abstraction(u16)
+    // (nlhe/src/info.rs:41-42, public.rs:19-23, secret.rs:10-11, kicker/src/{path.rs:21-22, abstraction.rs:19-20}) — and the tree id
+    uint32_t ref_rng;
+    uint64_t ref_v[4];
     uint32_t check_legal;             // evaluate Game::is_allowed on every applied action (RP_NLHE_CHECK_LEGAL=1)
     uint32_t tag;                     // launch tag of the kernel about to run (never 0)
-    uint32_t ablate;                  // RP_NLHE_ABLATE (profiling experiments only; results are garbage when set)
 };
 
 // the 2-seat game in five dwords (chips fit a byte: the stack is 200)
@@ -85,6 +89,27 @@ __device__ __forceinline__ void unpack_game(const Packed& p, G2& g) {
 // kicker/src/edge.rs:61-72 with BiasHyperParams::default (bias.rs:47-70)
 __device__ __forceinline__ float nl_default_regret(uint32_t e) {
     return e == NE_FOLD ? 100.0f : (e == NE_SHOVE ? 0.0f : ((e == NE_CHECK || e == NE_CALL) ? 50.0f : 10.0f));
+}
+// the u64 a sampled node's SmallRng is seeded with, reference-seed mode (flow.rs:285-295)
+__device__ __forceinline__ uint64_t nl_ref_seed(const NlParams& p, uint64_t past, uint64_t choices, uint32_t present, uint64_t tree_id) {
+    rp_sip s;
+    s.v0 = p.ref_v[0]; s.v1 = p.ref_v[1]; s.v2 = p.ref_v[2]; s.v3 = p.ref_v[3];
+    s.tail = 0; s.ntail = 0; s.len = 8;
+    rp_defaulthasher_write_u64(&s, past);
+    rp_defaulthasher_write_u64(&s, choices);
+    rp_defaulthasher_write_u16(&s, (uint16_t)present);
+    rp_defaulthasher_write_u64(&s, tree_id);
+    return rp_defaulthasher_finish(&s);
+}
+// the two draws of a sampled NLHE node in either rp_rng_kind: Pluribus' coin (walker) and WeightedIndex's x (opponent)
+__device__ __forceinline__ float nl_draw_coin(const NlParams& p, uint64_t tree_id, uint64_t khash, uint64_t past, uint64_t choices, uint32_t present) {
+    if (p.ref_rng) return rp_ref_draw_f32(nl_ref_seed(p, past, choices, present, tree_id));
+    return rp_u01(rp_node_hash_draw(p.step_hash, tree_id, khash));
+}
+__device__ __forceinline__ float nl_draw_weight(const NlParams& p, uint64_t tree_id, uint64_t khash, uint64_t past, uint64_t choices, uint32_t present,
+                                                float total) {
+    if (p.ref_rng) return rp_ref_draw_weight(nl_ref_seed(p, past, choices, present, tree_id), total);
+    return rp_u01(rp_node_hash_draw(p.step_hash, tree_id, khash)) * total;
 }
 __device__ __forceinline__ uint64_t nl_key_hash(uint64_t past, uint64_t choices, uint32_t present) {
     return rp_mix64(rp_mix64(past ^ 0x9e3779b97f4a7c15ull) ^ rp_mix64(choices + 0xd1342543de82ef95ull) ^ ((uint64_t)present * 0xaf251af3b0f025b5ull));

@@ -57,7 +57,7 @@ namespace rp {
 struct NlCtl {
     uint32_t n_nodes;  // allocation cursor
     uint32_t err;
-    uint32_t pad[2];  // pad[0]: workgroups of the running FUSED level launch that have finished
+    uint32_t pad[2];
     uint32_t lvl_node[NL_MAXL + 2];  // first node of each level
     uint32_t kinds[4];               // nodes of the batch by kind (terminal, chance, walker, opponent) and ...
     uint32_t walker_kids;            // ... children of its walker nodes: what k_nl_expand's algorithmic bytes are counted from
@@ -162,19 +162,7 @@ __global__ __launch_bounds__(256) void k_nl_roots(NlParams p, NlNodes nd) {
 // ---------------------------------------------------------------------------------------------------------------
 #define NL_TILE 512u  // nodes a workgroup sorts by kind at a time (measured: 512 and 1024 equal at 262 144 trees, 2048 -7 %, 4096 -13 % in
                       // k_nl_expand; at 128 trees per step 8.0 / 7.8 / 6.6 / 5.3 M updates per second: a tile is a serial chain of phases)
-__device__ __forceinline__ uint32_t nl_make_child(const NlParams& p, const NlNodes& nd, uint32_t c, int walker);  // below, with k_nl_children
-// FUSED (RP_NLHE_FUSED_LEVELS=1, one launch per tree level instead of two; not yet run on a GPU): a tile's nodes are first MADE —
-// nl_make_child, what k_nl_children does for the whole level — by the workgroup that then expands them, and the level's end for the
-// next launch (the node cursor moves while this launch runs) is written by the workgroup that finishes last.
-__device__ __forceinline__ void nl_level_done(NlCtl* ctl, const NlNodes& nd, uint32_t level) {
-    if (threadIdx.x != 0) return;
-    __threadfence();
-    if (atomicAdd(&ctl->pad[0], 1u) + 1u == gridDim.x) {  // every workgroup of the launch has bumped the cursor for the last time
-        ctl->pad[0] = 0u;
-        ctl->lvl_node[level + 2] = min(atomicAdd(&ctl->n_nodes, 0u), nd.ncap);
-    }
-}
-template <int MINW, uint32_t BT, bool FUSED = false>  // minimum wavefronts per SIMD the register allocation aims for; threads per workgroup
+template <int MINW, uint32_t BT>  // minimum wavefronts per SIMD the register allocation aims for; threads per workgroup
 __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, NlNodes nd, uint32_t level) {
     constexpr uint32_t R = NL_TILE / BT;           // classification sub-rounds
     constexpr uint32_t NW = BT / 64u;              // wavefronts of the workgroup
@@ -198,24 +186,11 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
         if (threadIdx.x == 0 && hi > lo && !s_stop) atomicOr(&ctl->err, NERR_LEVELS);
         return;
     }
-    if (hi <= lo || s_stop) {
-        if (FUSED) nl_level_done(ctl, nd, level);
-        return;
-    }
+    if (hi <= lo || s_stop) return;
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     // pruning is live for this launch? (sample/pluribus.rs:86-88: the warm-up is on the profile's epoch)
     const bool pruning = p.sampling == RP_SAMPLING_PRUNABLE || (p.sampling == RP_SAMPLING_PLURIBUS && p.epoch >= p.prune_warmup);
     for (uint32_t t0 = lo + blockIdx.x * NL_TILE; t0 < hi; t0 += gridDim.x * NL_TILE) {
-        if (FUSED && level > 0u) {  // ---- 0. the tile's nodes themselves (level 0 = the roots, made by k_nl_roots)
-            uint32_t cerr = 0;
-#pragma unroll
-            for (uint32_t r = 0; r < R; ++r) {
-                const uint32_t i = t0 + r * BT + tid;
-                if (i < hi) cerr |= nl_make_child(p, nd, i, (int)p.walker);
-            }
-            if (cerr) atomicOr(&ctl->err, cerr);
-            __syncthreads();  // the node records are read back below by other work-items of this workgroup
-        }
         // ---- 1. the tile sorted by kind (walker 0 | opponent 1 | chance 2; terminals have nothing to expand)
         uint32_t kd[R], rk[R];
 #pragma unroll
@@ -287,11 +262,9 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
             // the row is read from the key's home slot WHILE the key is probed: one memory round trip instead of two whenever the
             // infoset sits at its home slot and is older than this launch (the usual case); otherwise it is read again
             float rf[20];
-            if (!(p.ablate & 4u)) nl_load_row(t.rows, (uint32_t)khash & t.mask, seg == 1, rf);
-            else
-                for (int q = 0; q < 20; ++q) rf[q] = 1.0f + (float)q;
+            nl_load_row(t.rows, (uint32_t)khash & t.mask, seg == 1, rf);
             bool settled = true;
-            const uint32_t row = (p.ablate & 2u) ? ((uint32_t)khash & t.mask) : nl_row_of(t, past, chpath, present, khash, nch, p.tag, &err, &settled);
+            const uint32_t row = nl_row_of(t, past, chpath, present, khash, nch, p.tag, &err, &settled);
             if (!settled) nl_load_row(t.rows, row, seg == 1, rf);
             const uint32_t all = (1u << nch) - 1u;
             uint32_t mask, pick = 0, nkids;
@@ -302,7 +275,7 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
                 if (pruning) {
                     bool prune = true;
                     if (p.sampling == RP_SAMPLING_PLURIBUS)  // profile.rng(node).random::<f32>() < explore (pluribus.rs:89-91)
-                        prune = !(rp_u01(rp_node_hash_draw(p.step_hash, p.tree_base + tree, khash)) < p.prune_explore);
+                        prune = !(nl_draw_coin(p, p.tree_base + tree, khash, past, chpath, present) < p.prune_explore);
                     if (prune) {
                         uint32_t keep = 0;
 #pragma unroll
@@ -320,7 +293,7 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
                     }
                 }
                 nkids = (uint32_t)__popc(mask);
-                const uint32_t ord = (p.ablate & 1u) ? 0u : atomicAdd(&nd.t_nw[tree], 1u);
+                const uint32_t ord = atomicAdd(&nd.t_nw[tree], 1u);
                 if (ord >= NL_WMAX) err |= NERR_WALKERS;
                 nd.aux[node] = ord | (mask << 16);
                 s_aux[j] = row;
@@ -349,7 +322,7 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
 #pragma unroll
                 for (uint32_t a = 0; a < NLMC_A; ++a)
                     if (a < nch) total_w += rp_maxf(sw[a] / z, RP_EPSILON);
-                const float u = rp_u01(rp_node_hash_draw(p.step_hash, p.tree_base + tree, khash)) * total_w;
+                const float u = nl_draw_weight(p, p.tree_base + tree, khash, past, chpath, present, total_w);
                 float swp = sw[0], rgp = rf[0], cum = 0.0f;
 #pragma unroll
                 for (uint32_t a = 0; a + 1 < NLMC_A; ++a) {  // while (pick + 1 < nch && cum[pick] <= u) ++pick
@@ -457,7 +430,6 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
         if (err) atomicOr(&ctl->err, err);
         __syncthreads();  // the LDS arrays are rewritten for the next tile
     }
-    if (FUSED) nl_level_done(ctl, nd, level);  // after the loop's last barrier: every cursor bump of this workgroup is behind it
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -400,118 +400,19 @@ static __global__ __launch_bounds__(256) void k_rle_one(const uint32_t* keys, ui
     for (uint32_t g = threadIdx.x; g < runs; g += 256u) counts[g] = (g + 1u < runs ? starts[g + 1u] : n) - starts[g];
 }
 
-// ---- single-pass scan with decoupled look-back (OPT-IN: RP_SS_ONEPASS=1; not yet run on hardware) -------------------------
-// One launch instead of (tile sums, scan of the sums, tiles).  A workgroup takes its tile from a ticket counter — so every tile it
-// may have to wait for belongs to a workgroup that is already running —, publishes the tile's total, looks back over its
-// predecessors' descriptors until it meets an inclusive prefix, and publishes its own.  A descriptor is ONE 64-bit word
-// [generation:30][state:2][value:32] moved by agent-scope atomic loads and stores: state and value cannot be seen apart, no fence
-// is involved, and a word of an earlier launch (another generation) reads as "nothing yet", so nothing is cleared between launches.
-struct OnePass {
-    unsigned long long* desc;  // [tiles] of the caller, zeroed once
-    uint32_t* ticket;          // zeroed once; only ever grows
-    uint32_t ticket_base;      // the counter's value before this launch (the host adds the tiles of every launch)
-    uint32_t gen;              // 1 .. 2^30 - 1, one per launch
-};
-struct OnePassState {  // host side, one per owner of a (desc, ticket) pair
-    unsigned long long* desc = nullptr;
-    uint32_t* ticket = nullptr;
-    uint32_t tiles_cap = 0, next_ticket = 0, gen = 0;
-};
-// the descriptor of this launch; clears the descriptors when the generation wraps
-inline hipError_t onepass_begin(OnePassState& st, uint32_t tiles, hipStream_t stream, OnePass* out) {
-    if (st.gen >= (1u << 30) - 1u) {
-        const hipError_t e = hipMemsetAsync(st.desc, 0, (size_t)st.tiles_cap * 8, stream);
-        if (e != hipSuccess) return e;
-        st.gen = 0;
-    }
-    st.gen += 1;
-    *out = OnePass{st.desc, st.ticket, st.next_ticket, st.gen};
-    st.next_ticket += tiles;  // modulo 2^32, like the counter
-    return hipSuccess;
-}
-constexpr int OP_NONE = 0, OP_AGGREGATE = 1, OP_PREFIX = 2;
-__device__ __forceinline__ unsigned long long op_word(uint32_t gen, int state, uint32_t value) {
-    return ((unsigned long long)gen << 34) | ((unsigned long long)state << 32) | value;
-}
-// the workgroup's tile (every work-item gets the same answer); *slot: one LDS word
-__device__ __forceinline__ uint32_t onepass_tile(const OnePass& op, uint32_t* slot) {
-    if (threadIdx.x == 0) *slot = atomicAdd(op.ticket, 1u) - op.ticket_base;
-    __syncthreads();
-    const uint32_t t = *slot;
-    __syncthreads();
-    return t;
-}
-// called by the whole workgroup with its tile's total: the sum of all earlier tiles
-__device__ __forceinline__ uint32_t onepass_base(const OnePass& op, uint32_t tile, uint32_t total, uint32_t* slot) {
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        if (tile > 0) {
-            __hip_atomic_store(&op.desc[tile], op_word(op.gen, OP_AGGREGATE, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (uint32_t t = tile; t-- > 0;) {
-                unsigned long long d;
-                do {
-                    d = __hip_atomic_load(&op.desc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } while ((uint32_t)(d >> 34) != op.gen || ((d >> 32) & 3u) == (unsigned)OP_NONE);
-                run += (uint32_t)d;
-                if (((d >> 32) & 3u) == (unsigned)OP_PREFIX) break;  // tile 0 always publishes a prefix: the walk ends there at the latest
-            }
-        }
-        __hip_atomic_store(&op.desc[tile], op_word(op.gen, OP_PREFIX, run + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *slot = run;
-    }
-    __syncthreads();
-    const uint32_t base = *slot;
-    __syncthreads();
-    return base;
-}
-static __global__ __launch_bounds__(256) void k_rle_onepass(const uint32_t* keys, uint32_t n, uint32_t* uniq, uint32_t* starts, uint32_t* n_runs,
-                                                            OnePass op) {
-    __shared__ uint64_t wt[4];
-    __shared__ uint32_t slot;
-    const uint32_t tile = onepass_tile(op, &slot), tiles = gridDim.x;
-    uint32_t key[4];
-    bool head[4];
-    const uint32_t base = tile * SCAN_TILE + threadIdx.x * 4u;
-    const uint64_t s = rle_heads4(keys, n, base, key, head);
-    uint64_t tot;
-    const uint32_t local = (uint32_t)block_exscan64(s, wt, &tot);
-    uint32_t run = onepass_base(op, tile, (uint32_t)tot, &slot) + local;
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; ++k)
-        if (head[k]) {
-            uniq[run] = key[k];
-            starts[run] = base + k;
-            run += 1u;
-        }
-    if (tile == tiles - 1u && threadIdx.x == 255u) *n_runs = run;
-}
-
 // sorted keys -> uniq[r], starts[r] (= the exclusive scan of counts), counts[r] for r < *n_runs; work = n words of scratch.
 // counts may be NULL (a caller that derives them itself).  Three launches (one for at most SCAN_ONE keys) + one for the counts;
-// RP_SS_RLE_V1=1 keeps the first version (flag array: heads, scan, write, counts).
-inline bool onepass_wanted() {
-    static const bool on = getenv("RP_SS_ONEPASS") != nullptr;
-    return on;
-}
+// more than SCAN_ONE tiles: the general form (flag array: heads, scan, write, counts).
 inline hipError_t run_length_encode(const uint32_t* keys, uint32_t n, uint32_t* uniq, uint32_t* starts, uint32_t* counts, uint32_t* n_runs,
-                                    uint32_t* work, void* scan_tmp, hipStream_t st, OnePassState* onepass = nullptr) {
+                                    uint32_t* work, void* scan_tmp, hipStream_t st) {
     if (n == 0) return hipMemsetAsync(n_runs, 0, 4, st);
     const dim3 grid((n + 255u) / 256u), block(256);
-    static const bool v1 = getenv("RP_SS_RLE_V1") != nullptr;
     const uint32_t tiles = (n + SCAN_TILE - 1u) / SCAN_TILE;
-    if (!v1 && n > SCAN_ONE && onepass && onepass->desc && tiles <= onepass->tiles_cap && onepass_wanted()) {
-        OnePass op;
-        const hipError_t e = onepass_begin(*onepass, tiles, st, &op);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_rle_onepass, dim3(tiles), block, 0, st, keys, n, uniq, starts, n_runs, op);
-        if (counts) hipLaunchKernelGGL(k_rle_counts, grid, block, 0, st, starts, n_runs, n, counts);
-        return hipGetLastError();
-    }
-    if (!v1 && n <= SCAN_ONE) {
+    if (n <= SCAN_ONE) {
         hipLaunchKernelGGL(k_rle_one, dim3(1), block, 0, st, keys, n, uniq, starts, counts, n_runs);
         return hipGetLastError();
     }
-    if (!v1 && tiles <= SCAN_ONE) {
+    if (tiles <= SCAN_ONE) {
         uint64_t* sums = reinterpret_cast<uint64_t*>(scan_tmp);  // scan_scratch_bytes(n) holds the tile sums
         hipLaunchKernelGGL(k_rle_sums, dim3(tiles), block, 0, st, keys, n, sums);
         hipLaunchKernelGGL(k_scan_one64, dim3(1), block, 0, st, sums, tiles);

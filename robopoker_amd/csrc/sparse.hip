@@ -352,8 +352,8 @@ __global__ void k_block_index(const uint32_t* nblk, const uint32_t* boff, const 
     for (uint32_t k = 0; k < nb; ++k) blkseg[base + k] = g;
 }
 
-// k_fold's arithmetic for ONE entry of a row and one of its cells (a single rank's entry is applied where it is produced when
-// RP_SPARSE_APPLY_FUSED=1: the step's last launch goes away).  The same operations in the same order as k_fold.
+// k_fold's arithmetic for ONE entry of a row and one of its cells (a single rank's entry is applied where it is produced: the
+// step's last launch goes away).  The same operations in the same order as k_fold.
 __device__ __forceinline__ void apply_cell(const SparseParams& p, uint32_t rowid, uint32_t A, uint32_t a, const Map& mr, const Map& mw, uint32_t c,
                                            float psum) {
     float* row = p.tab + (size_t)rowid * 4u * A;
@@ -444,39 +444,6 @@ __global__ __launch_bounds__(256) void k_blk_one(const uint32_t* starts, const u
         run += nb;
     }
     if (threadIdx.x == 0) *hot_counter = 0;
-}
-
-// the same in ONE launch: the scan is single-pass with decoupled look-back (sortscan.hpp; opt-in with RP_SS_ONEPASS=1)
-__global__ __launch_bounds__(256) void k_blk_onepass(const uint32_t* starts, const uint32_t* n_segs, uint32_t n, uint32_t* counts, uint32_t* nblk,
-                                                     uint32_t* boff, uint32_t* blkseg, uint32_t* hot_counter, ss::OnePass op) {
-    __shared__ uint64_t wt[4];
-    __shared__ uint32_t slot;
-    const uint32_t tile = ss::onepass_tile(op, &slot);
-    const uint32_t runs = *n_segs, base = tile * ss::SCAN_TILE + threadIdx.x * 4u;
-    uint32_t v[4];
-    uint64_t s = 0;
-    for (uint32_t k = 0; k < 4u; ++k) {
-        const uint32_t g = base + k;
-        v[k] = 0;
-        if (g >= n) continue;
-        uint32_t cnt;
-        v[k] = blk_of_row(starts, runs, n, g, &cnt);
-        if (g < runs) counts[g] = cnt;
-        nblk[g] = v[k];
-        s += v[k];
-    }
-    uint64_t tot;
-    const uint32_t local = (uint32_t)ss::block_exscan64(s, wt, &tot);
-    uint32_t run = ss::onepass_base(op, tile, (uint32_t)tot, &slot) + local;
-    for (uint32_t k = 0; k < 4u; ++k) {
-        const uint32_t g = base + k;
-        if (g >= n) break;
-        boff[g] = run;
-        if (g < runs)
-            for (uint32_t b = 0; b < v[k]; ++b) blkseg[run + b] = g;
-        run += v[k];
-    }
-    if (tile == 0 && threadIdx.x == 0) *hot_counter = 0;
 }
 
 template <bool GATHER, bool APPLY>  // GATHER: the touches are read from the unsorted batch through sg.perm (no sorted copy exists);
@@ -773,10 +740,6 @@ struct rp_profile {
     uint32_t max_batch = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
-    ss::OnePassState onepass;  // descriptors + ticket of the single-pass scans (RP_SS_ONEPASS=1)
-    bool apply_fused = false;  // RP_SPARSE_APPLY_FUSED=1: a single rank's entries are applied where they are produced (no k_fold launch)
-    bool fused_blocks = true;  // rows -> blocks inside one tiled scan (RP_SPARSE_V1=1: block counts, scan, index and memset as separate launches)
-    bool gather_maps = true;  // composed update: block maps read the touches through the sort permutation (RP_SPARSE_PERMUTE=1: via a sorted copy)
     float* tab = nullptr;
     // sort / segment workspace (capacity `cap` items)
     uint32_t cap = 0;
@@ -837,9 +800,6 @@ static void free_workspace(rp_profile* h) {
                     (void*)h->entries, (void*)h->srt_regret, (void*)h->srt_policy, (void*)h->srt_payoff,
                     (void*)h->srt_expanded})
         if (p) (void)hipFree(p);
-    if (h->onepass.desc) (void)hipFree(h->onepass.desc);
-    if (h->onepass.ticket) (void)hipFree(h->onepass.ticket);
-    h->onepass = ss::OnePassState{};
     h->iota = h->keys_out = h->perm = h->seg_rows = h->seg_counts = h->seg_offsets = h->ent_rows = h->nblk = h->boff = nullptr;
     h->blocks = nullptr;
     h->blkseg = nullptr;
@@ -872,12 +832,6 @@ static int ensure_capacity(rp_profile* h, uint32_t n) {
     HIP_TRY(hipMalloc(&h->boff, (size_t)cap * 4));
     HIP_TRY(hipMalloc(&h->blocks, (size_t)max_blocks_of(cap) * entry_bytes_of(h)));
     HIP_TRY(hipMalloc(&h->blkseg, (size_t)max_blocks_of(cap) * 4));
-    h->onepass = ss::OnePassState{};
-    h->onepass.tiles_cap = (cap + ss::SCAN_TILE - 1u) / ss::SCAN_TILE + 1u;
-    HIP_TRY(hipMalloc(&h->onepass.desc, (size_t)h->onepass.tiles_cap * 8));
-    HIP_TRY(hipMalloc(&h->onepass.ticket, 4));
-    HIP_TRY(hipMemsetAsync(h->onepass.desc, 0, (size_t)h->onepass.tiles_cap * 8, h->stream));
-    HIP_TRY(hipMemsetAsync(h->onepass.ticket, 0, 4, h->stream));
     // scratch of the sort (histograms, their scan, one ping-pong pair) + the run-length encoding's n flag words
     h->sort_bytes = ss::sort_scratch_bytes(cap) + ((ss::scan_scratch_bytes(cap) + 255) & ~(size_t)255) + (size_t)cap * 4 + 256;
     HIP_TRY(hipMalloc(&h->sort_tmp, h->sort_bytes));
@@ -904,9 +858,9 @@ static int sort_and_segment(rp_profile* h, const uint32_t* rows, uint32_t n, boo
     sp += (ss::scan_scratch_bytes(h->cap) + 255) & ~(size_t)255;
     // seg_offsets = the start of every run = the exclusive scan of the run lengths
     // counts_later: the caller is launch_summarize, whose block scan derives the counts from the starts on its way
-    const bool derived = counts_later && h->fused_blocks && (n + ss::SCAN_TILE - 1u) / ss::SCAN_TILE <= ss::SCAN_ONE;  // launch_summarize's condition
+    const bool derived = counts_later && (n + ss::SCAN_TILE - 1u) / ss::SCAN_TILE <= ss::SCAN_ONE;  // launch_summarize's condition
     HIP_TRY(ss::run_length_encode(h->keys_out, n, h->seg_rows, h->seg_offsets, derived ? nullptr : h->seg_counts, h->n_segs,
-                                  reinterpret_cast<uint32_t*>(sp), scan_tmp, h->stream, &h->onepass));
+                                  reinterpret_cast<uint32_t*>(sp), scan_tmp, h->stream));
     return RP_OK;
 }
 
@@ -950,15 +904,10 @@ static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch
     const uint32_t mb = max_blocks_of(n);
     void* scan_tmp = reinterpret_cast<unsigned char*>(h->sort_tmp) + ss::sort_scratch_bytes(h->cap);
     const uint32_t tiles = (n + ss::SCAN_TILE - 1u) / ss::SCAN_TILE;
-    if (h->fused_blocks && n > ss::SCAN_ONE && h->onepass.desc && tiles <= h->onepass.tiles_cap && ss::onepass_wanted()) {
-        ss::OnePass op;
-        HIP_TRY(ss::onepass_begin(h->onepass, tiles, h->stream, &op));
-        hipLaunchKernelGGL(k_blk_onepass, dim3(tiles), dim3(256), 0, h->stream, h->seg_offsets, h->n_segs, n, h->seg_counts, h->nblk, h->boff,
-                           h->blkseg, h->hot + HOT_CAP, op);
-    } else if (h->fused_blocks && n <= ss::SCAN_ONE) {
+    if (n <= ss::SCAN_ONE) {
         hipLaunchKernelGGL(k_blk_one, dim3(1), dim3(256), 0, h->stream, h->seg_offsets, h->n_segs, n, h->seg_counts, h->nblk, h->boff, h->blkseg,
                            h->hot + HOT_CAP);
-    } else if (h->fused_blocks && tiles <= ss::SCAN_ONE) {
+    } else if (tiles <= ss::SCAN_ONE) {
         uint64_t* sums = reinterpret_cast<uint64_t*>(scan_tmp);
         hipLaunchKernelGGL(k_blk_sums, dim3(tiles), dim3(256), 0, h->stream, h->seg_offsets, h->n_segs, n, h->seg_counts, h->nblk, sums,
                            h->hot + HOT_CAP);
@@ -974,14 +923,8 @@ static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch
 #define RP_MAPS(G, AP)                                                                                                                  \
     hipLaunchKernelGGL((k_block_maps_sparse<G, AP>), dim3(group_blocks(mb)), dim3(256), 0, h->stream, p, b, sg, h->nblk, h->boff, h->blkseg, \
                        sb, entries, h->blocks, eb, mb)
-    if (h->gather_maps) {
-        if (apply_local) RP_MAPS(true, true);
-        else RP_MAPS(true, false);
-    } else {  // RP_SPARSE_PERMUTE=1: a sorted copy first (the ordered update's layout), then contiguous reads
-        hipLaunchKernelGGL(k_permute, dim3((unsigned)(((uint64_t)n * h->A + 255) / 256)), dim3(256), 0, h->stream, b, h->perm, n, h->A, sb);
-        if (apply_local) RP_MAPS(false, true);
-        else RP_MAPS(false, false);
-    }
+    if (apply_local) RP_MAPS(true, true);  // the block maps read the touches through the sort permutation
+    else RP_MAPS(true, false);
 #undef RP_MAPS
     if (apply_local) {
         hipLaunchKernelGGL(k_seg_fold<true>, dim3(group_blocks(n)), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb,
@@ -1019,9 +962,6 @@ int rp_profile_create(int device, uint64_t n_rows, uint32_t max_actions, rp_regr
     h->W = weight;
     if (hp) h->hp = *hp; else rp_hyper_default(&h->hp);
     h->max_batch = max_batch;
-    h->gather_maps = getenv("RP_SPARSE_PERMUTE") == nullptr;
-    h->fused_blocks = getenv("RP_SPARSE_V1") == nullptr;
-    h->apply_fused = getenv("RP_SPARSE_APPLY_FUSED") != nullptr;
 #define PF_TRY(expr)                                                                              \
     do {                                                                                          \
         hipError_t _e = (expr);                                                                   \
@@ -1101,12 +1041,9 @@ int rp_profile_apply(rp_profile* h, const rp_decisions* batch, rp_update_mode mo
                 hipLaunchKernelGGL(k_apply_hot<false>, dim3(256), dim3(128), 0, h->stream, p, b, sg, sb, h->hot, h->hot + HOT_CAP,
                                    (uint32_t)HOT_CAP);
         } else {
-            const uint32_t eb = (uint32_t)entry_bytes_of(h);
-            if ((rc = launch_summarize(h, p, b, sg, batch->n, h->entries, h->apply_fused))) return rc;
-            // a single rank's entries have distinct rows: entry g is its own segment, the count comes from n_segs
-            if (!h->apply_fused)
-                hipLaunchKernelGGL(k_fold, dim3(group_blocks(batch->n)), dim3(256), 0, h->stream, p, h->entries, eb,
-                                   (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, h->n_segs);
+            // a single rank's entries have distinct rows and are applied where they are produced (k_fold's arithmetic, apply_cell):
+            // no k_fold launch (measured round 4: apply 0.118 -> 0.113 ms at 2^17 Decisions, profiles/r04_optin_ab.json)
+            if ((rc = launch_summarize(h, p, b, sg, batch->n, h->entries, true))) return rc;
         }
         sp_end(h, h->clk_apply);
         HIP_TRY(hipGetLastError());

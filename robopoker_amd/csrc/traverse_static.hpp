@@ -369,11 +369,9 @@ __global__ __launch_bounds__(256, 4) void k_traverse_maps_static(DevGame g, DevI
     uint16_t* order = pre + NI * 8u;
     float* vals = reinterpret_cast<float*>(order + NI + (NI & 1u));
     // places per cell.  The five chains of an infoset read vals[c L + base + e] in the same instruction: with L a multiple of 32 they
-    // share a bank (a 5-way conflict at every step); lpad (RP_TRAV_CELL_PAD, 7 words by default) moves the cells apart
-    const uint32_t L = maxdec * 256u + (lpad & 31u);
-    // bit 8 of lpad (RP_TRAV_SPLIT_PAYOFF=1, not yet timed): the payoff sums are handed out after all the map chains, so that no
-    // wavefront mixes the two loops (today every wavefront runs the payoff loop for the one lane in five that has one)
-    const bool split_payoff = (lpad >> 8) & 1u;
+    // share a bank (a 5-way conflict at every step); lpad = 7 words moves the cells apart (measured round 4, profiles/r04_optin_ab.json:
+    // pads 0 / 3 / 7 / 13 within 1 % of each other — the conflicts were not the limiter)
+    const uint32_t L = maxdec * 256u + lpad;
     uint32_t* lmask = reinterpret_cast<uint32_t*>(vals + 5u * L);
     for (uint32_t e = lt; e < NI * 8u; e += 256u) bits[e] = 0;
     if (lt < 16u) cls_n[lt] = 0;
@@ -425,11 +423,12 @@ __global__ __launch_bounds__(256, 4) void k_traverse_maps_static(DevGame g, DevI
             ndec += 1u;
         });
     __syncthreads();
-    // the chains: task = (cell c, infoset); cells 0,1 regret, 2,3 weight, 4 the payoff sum
+    // the chains: task = (cell c, infoset); cells 0,1 regret, 2,3 weight, 4 the payoff sum.  The payoff sums are handed out after all
+    // the map chains, so that no wavefront mixes the two loops (measured round 4: 0.582 -> 0.562 ms per launch against task % 5)
     const float NEG_INF = rp_u2f(0xff800000u);
     for (uint32_t task = lt; task < 5u * NI; task += 256u) {
-        const uint32_t c = split_payoff ? (task < 4u * NI ? task & 3u : 4u) : task % 5u;
-        const uint32_t info = order[split_payoff ? (task < 4u * NI ? task >> 2 : task - 4u * NI) : task / 5u];
+        const uint32_t c = task < 4u * NI ? task & 3u : 4u;
+        const uint32_t info = order[task < 4u * NI ? task >> 2 : task - 4u * NI];
         if (g.info_player[info] != p.walker) continue;
         const uint32_t n = lcount[info], base = lbase[info];
         const size_t slot_out = (size_t)info * nblk_max + chunk;

@@ -54,6 +54,11 @@ class Layer:
     __del__ = close
 
     # ---- Elkan / Layer --------------------------------------------------------------------------
+    def set_rng(self, kind: str, street: int = 1):
+        """"counter" (default: the fixed-point draw) or "reference": Layer::init_centroids' own SmallRng + WeightedIndex<f32>
+        (layer.rs:155-178); street = the Street discriminant hashed into the seed (1 = Flop)"""
+        _lib.check(self._lib.rp_kmeans_set_rng(self._h, _lib.RNG[kind], street))
+
     def init_centroids(self) -> np.ndarray:
         chosen = np.zeros(self.K, dtype=np.uint64)
         _lib.check(self._lib.rp_kmeans_init_centroids(self._h, _p(chosen)))

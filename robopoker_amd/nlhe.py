@@ -43,6 +43,10 @@ class NlheSolver:
         if sampling != "external":  # Flagship = Nlhe<LinearRegret, LinearWeight, PluribusSampling> (nlhe/src/lib.rs:86-90)
             _lib.check(self._lib.rp_nlhe_set_sampling(self._h, _lib.SAMPLING[sampling]))
 
+    def set_rng(self, kind: str):
+        """"counter" (default) or "reference": opponent draws and Pluribus' coin from the reference's DefaultHasher -> SmallRng chain"""
+        _lib.check(self._lib.rp_nlhe_set_rng(self._h, _lib.RNG[kind]))
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.rp_nlhe_destroy(self._h)

@@ -415,6 +415,11 @@ class OracleKmeans:
             self._o.ora_kmeans_destroy(self._h)
             self._h = None
 
+    def set_rng(self, kind: str, street: int = 1):
+        o = load()
+        o.ora_kmeans_set_rng.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        o.ora_kmeans_set_rng(self._h, _lib.RNG[kind], street)
+
     def init_centroids(self):
         chosen = np.zeros(self.K, dtype=np.uint64)
         self._o.ora_kmeans_init_centroids(self._h, _p(chosen))

@@ -25,6 +25,7 @@ def lib():
         o.ora_nlmc_create.argtypes = [C.c_uint32, C.c_int, C.c_int, C.POINTER(_lib.Hyper), C.c_uint64, C.c_uint32]
         o.ora_nlmc_destroy.argtypes = [vp]
         o.ora_nlmc_set_sampling.argtypes = [vp, C.c_int]
+        o.ora_nlmc_set_rng.argtypes = [vp, C.c_int]
         o.ora_nlmc_set_table.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
         o.ora_nlmc_step.argtypes = [vp]
         o.ora_nlmc_batch.restype = C.c_uint64
@@ -64,6 +65,9 @@ class OracleNlhe:
         self.batch_size = batch
         self._h = C.c_void_p(self._o.ora_nlmc_create(cap_log2, _lib.REGRET[regret], _lib.WEIGHT[weight], C.byref(self.hp), seed, batch))
         self._o.ora_nlmc_set_sampling(self._h, _lib.SAMPLING[sampling])
+
+    def set_rng(self, kind: str):
+        self._o.ora_nlmc_set_rng(self._h, _lib.RNG[kind])
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -25,14 +25,6 @@ SELECTION = [
     ("tests/test_gpu_nlmc.py", "(test_first_batch_equals_the_oracle and 64) or test_pruned_sampling_schemes_equal_the_oracle"
                                " or test_ragged_batches_equal_the_oracle or test_a_batch_traversed_in_several_passes"
                                " or test_a_full_infoset_table_fails"),
-    # the opt-in one-launch-per-level traversal (k_nl_expand<4, 256, true>): not yet run on hardware either
-    ("tests/test_gpu_nlmc.py", "(test_first_batch_equals_the_oracle and 64) or test_level_synchronous_traversal_equals_the_lane_per_tree_kernel"
-                               " or test_a_batch_traversed_in_several_passes or (test_ragged_batches_equal_the_oracle and 65)",
-     {"RP_NLHE_FUSED_LEVELS": "1"}),
-    # the opt-in single-pass scans (decoupled look-back, sortscan.hpp) and entries applied where they are produced: not yet run
-    # on hardware, so this is their only check — eight host threads make the look-back wait on tiles that are really in flight
-    ("tests/test_gpu_sparse.py", "test_batches_just_past_one_scan_tile_set_bit_exact or test_composed_apply or test_hot_rows",
-     {"RP_SS_ONEPASS": "1", "RP_SPARSE_APPLY_FUSED": "1"}),
     # Path B: wave-cooperative Sinkhorn, Elkan iterations with remembered pairwise entries
     ("tests/test_gpu_lloyd.py", "(test_sinkhorn_random_pairs_bit_exact and 32-5-9) or test_sinkhorn_fixture_bit_exact"
                                 " or (test_elkan_iterations_bit_exact and sinkhorn-5-150) or test_equity_variation_bit_exact"),

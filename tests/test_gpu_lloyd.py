@@ -94,6 +94,23 @@ def _check_state(dev, ora):
     assert np.array_equal(c1, c2) and np.array_equal(w1, w2), "centroids differ"
 
 
+@pytest.mark.parametrize("kind,K,N,bins,mass,street", [("sinkhorn", 24, 5000, 32, 20, 1), ("variation", 40, 70001, 101, 46, 2),
+                                                       ("variation", 7, 1024, 64, 30, 2), ("variation", 3, 5, 64, 30, 1)])
+def test_reference_seed_kmeanspp_picks_equal_the_oracle(gpu, kind, K, N, bins, mass, street):
+    # rp_kmeans_set_rng(RP_RNG_REFERENCE): Layer::init_centroids' own chain (layer.rs:155-178) — DefaultHasher(street) ->
+    # SmallRng, one generator for the K picks, WeightedIndex<f32> over f32 running sums in index order (k_kpp_ref_pick: one
+    # wavefront, 1024 potentials per LDS chunk; N = 70001 and 1024 sit on the chunk edges) — picks, then the state after a step
+    dev, ora = _pair(kind, K, N, bins, mass, seed=21)
+    dev.set_rng("reference", street)
+    ora.set_rng("reference", street)
+    assert np.array_equal(dev.init_centroids(), ora.init_centroids()), "k-means++ picks differ"
+    dev.init_bounds()
+    ora.init_bounds()
+    dev.step()
+    ora.step()
+    _check_state(dev, ora)
+
+
 @pytest.mark.parametrize("kind,K,N,bins,mass", [("sinkhorn", 5, 150, 32, 20), ("sinkhorn", 70, 200, 48, 24),
                                                 ("variation", 8, 2048, 101, 46), ("variation", 130, 700, 101, 46),
                                                 ("variation", 20, 500, 64, 30)])
@@ -222,8 +239,8 @@ def test_flop_config_slice_properties(gpu):
 @pytest.mark.parametrize("small_supports", [False, True])
 def test_points_per_wavefront_groupings_agree(gpu, monkeypatch, small_supports):
     # Points with <= 16 support bins are solved four per wavefront against a shared centroid, those with <= 32 two per
-    # wavefront (k_neighborG / k_kpp_updateG, k_refresh_pairs), the rest one; RP_LLOYD_NO_QUADS=1 / RP_LLOYD_NO_PAIRS=1 /
-    # RP_LLOYD_NO_REFRESH_PASS=1 switch the groupings off.  Every grouping performs the same float operations per solve: identical picks, buckets and
+    # wavefront (k_neighborG / k_kpp_updateG, k_refresh_pairs), the rest one; RP_LLOYD_GROUPING=pairs / none /
+    # norefresh switch the groupings off.  Every grouping performs the same float operations per solve: identical picks, buckets and
     # distances.  Large enough that the lists are built while the GPU is busy (a missing stream sync once
     # mis-classified late points).  small_supports: like the real flop points (<= 27 bins, ~11 on average), so
     # that most points take the four-per-wavefront path and centroids the shared centroid-row pass.
@@ -243,10 +260,10 @@ def test_points_per_wavefront_groupings_agree(gpu, monkeypatch, small_supports):
     tri = smooth_metric(bins, 1)
 
     def run(env):
-        for v in ("RP_LLOYD_NO_PAIRS", "RP_LLOYD_NO_QUADS", "RP_LLOYD_NO_REFRESH_PASS", "RP_LLOYD_NO_KPP_BOUND", "RP_LLOYD_NO_MFMA_BOUND"):
+        for v in ("RP_LLOYD_GROUPING", "RP_LLOYD_NO_KPP_BOUND", "RP_LLOYD_NO_MFMA_BOUND"):
             monkeypatch.delenv(v, raising=False)
         if env:
-            monkeypatch.setenv(env, "1")
+            monkeypatch.setenv(*env)
         layer = lloyd.Layer(K, pts, "sinkhorn", tri, seed=11)
         chosen = np.asarray(layer.init_centroids())
         layer.init_bounds()
@@ -255,9 +272,10 @@ def test_points_per_wavefront_groupings_agree(gpu, monkeypatch, small_supports):
         bucket, dist = layer.lookup()
         return chosen, np.asarray(bucket), np.asarray(dist)
 
-    c1, b1, d1 = run("RP_LLOYD_NO_PAIRS")
+    c1, b1, d1 = run(("RP_LLOYD_GROUPING", "none"))
     # ... and the two prunes (k-means++ column-marginal bound, MFMA bound of the neighbor passes) against their absence
-    for env in (None, "RP_LLOYD_NO_QUADS", "RP_LLOYD_NO_REFRESH_PASS", "RP_LLOYD_NO_KPP_BOUND", "RP_LLOYD_NO_MFMA_BOUND"):
+    for env in (None, ("RP_LLOYD_GROUPING", "pairs"), ("RP_LLOYD_GROUPING", "norefresh"), ("RP_LLOYD_NO_KPP_BOUND", "1"),
+                ("RP_LLOYD_NO_MFMA_BOUND", "1")):
         c2, b2, d2 = run(env)
         assert np.array_equal(c1, c2), "k-means++ picks differ"
         assert np.array_equal(b1, b2)

@@ -443,15 +443,15 @@ def test_update_mode_chosen_at_creation(gpu):
 def test_static_skeleton_traversal_of_the_pruned_schemes(gpu, monkeypatch, mode, game, sampling, batch):
     # PrunableSampling / PluribusSampling on the compile-time skeleton (traverse_static.hpp, PRUNED = true): a pruned walker edge
     # is a dead skeleton node.  Pruning is forced to bite (warm-up 2, threshold just below zero).  Against the per-lane DFS
-    # kernel (RP_TRAV_STATIC_EXTERNAL_ONLY=1) and the oracle, bit for bit, in both update modes (the fused traversal + block maps
+    # kernel (RP_TRAV_GENERIC=1) and the oracle, bit for bit, in both update modes (the fused traversal + block maps
     # kernel skips the list entries of pruned edges like k_chunk_maps<true>).
     g = Game(game)
     hp = oracle.default_hyper()
     hp.prune_warmup, hp.prune_threshold, hp.prune_explore = 2, -0.05, 0.1
     a = Solver(g, "linear", "linear", sampling, batch=batch, seed=23, hyper=hp)
-    monkeypatch.setenv("RP_TRAV_STATIC_EXTERNAL_ONLY", "1")
+    monkeypatch.setenv("RP_TRAV_GENERIC", "1")
     b = Solver(g, "linear", "linear", sampling, batch=batch, seed=23, hyper=hp)
-    monkeypatch.delenv("RP_TRAV_STATIC_EXTERNAL_ONLY")
+    monkeypatch.delenv("RP_TRAV_GENERIC")
     ora = oracle.OracleSolver(g, "linear", "linear", sampling, batch=batch, seed=23, hyper=hp)
     assert a.kernel_variant() == "static" and b.kernel_variant() != "static"
     if mode == "composed":

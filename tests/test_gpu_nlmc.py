@@ -43,31 +43,6 @@ def test_first_batch_equals_the_oracle(gpu, batch, seed):
     assert dev.counters()[2] == ora.counters()[2]
 
 
-def test_level_synchronous_traversal_equals_the_lane_per_tree_kernel(gpu, monkeypatch):
-    # Two independent device implementations of Solver::batch: the product path grows all trees of the batch one level per
-    # launch pair with kind-sorted kernels (nlmc_level.hpp); the first version walks one tree per lane with its own stack
-    # (RP_NLHE_LANE_PER_TREE=1).  Same float operations in the same order: every Decisions bit for bit, over three steps with
-    # table updates in between (the second and third batch read trained regrets and weights).
-    monkeypatch.setenv("RP_NLHE_LANE_PER_TREE", "1")
-    old = NlheSolver(cap_log2=20, batch=3000, seed=17)
-    monkeypatch.delenv("RP_NLHE_LANE_PER_TREE")
-    new = NlheSolver(cap_log2=20, batch=3000, seed=17)
-    for step in range(3):
-        a, b = old.batch(), new.batch()
-        assert a["n"] == b["n"] > 3000 * 20
-        for f in ("tree", "past", "present", "choices", "n_actions", "expanded"):
-            assert np.array_equal(a[f], b[f]), (step, f)
-        for f in ("regret", "policy", "payoff"):
-            assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), (step, f)
-        old.step("ordered")
-        new.step("ordered")
-        assert old.counters() == new.counters()
-    levels, nodes = new.last_shape()
-    assert 10 < levels < 40 and nodes > 3000 * 100
-    am, bm = M.as_map(*old.export()), M.as_map(*new.export())
-    assert am.keys() == bm.keys() and all(am[k].tobytes() == bm[k].tobytes() for k in am)
-
-
 def _pruning_hyper(warmup=2, threshold=-5.0, explore=0.05):
     import oracle
 
@@ -96,6 +71,30 @@ def test_pruned_sampling_schemes_equal_the_oracle(gpu, sampling):
         assert dev.counters() == ora.counters()
         dev.load(*ora.export(), epoch=ora.epoch)
     assert pruned > 50
+
+
+@pytest.mark.parametrize("sampling", ["external", "pluribus"])
+def test_reference_seed_mode_equals_the_oracle(gpu, sampling):
+    # rp_nlhe_set_rng(RP_RNG_REFERENCE): the opponent's WeightedIndex draw and Pluribus' coin come from DefaultHasher(t, NlheInfo,
+    # tree id) -> SmallRng (flow.rs:285-295; include/rp_refrng.h) on both sides: trees, keys, masks as the oracle's
+    batch = 160
+    dev = NlheSolver(cap_log2=18, batch=batch, seed=35, sampling=sampling, hyper=_pruning_hyper())
+    ora = M.OracleNlhe(cap_log2=18, batch=batch, seed=35, sampling=sampling, hyper=_pruning_hyper())
+    cnt = NlheSolver(cap_log2=18, batch=batch, seed=35, sampling=sampling, hyper=_pruning_hyper())
+    dev.set_rng("reference")
+    ora.set_rng("reference")
+    differs = False
+    for step in range(4):
+        d, o, c = dev.batch(), ora.batch(), cnt.batch()
+        _same_batch(d, o)
+        differs = differs or len(c["row"]) != len(d["row"]) or not np.array_equal(c["expanded"], d["expanded"])
+        dev.step("ordered")
+        ora.step()
+        cnt.step("ordered")
+        assert dev.counters() == ora.counters()
+        dev.load(*ora.export(), epoch=ora.epoch)
+        cnt.load(*ora.export(), epoch=ora.epoch)
+    assert differs  # and it is not the counter hash that drew them
 
 
 def test_steps_without_resynchronisation_stay_close_to_the_oracle(gpu):

@@ -57,7 +57,7 @@ def test_composed_apply_and_entries_bit_exact(gpu, regret, weight, A):
 @pytest.mark.parametrize("n_rows,A,n", [(50000, 9, 70000), (300, 9, 66000), (1 << 16, 16, 131073)])
 def test_batches_just_past_one_scan_tile_set_bit_exact(gpu, n_rows, A, n):
     # more than ss::SCAN_ONE = 65 536 Decisions: the run lengths and the rows -> blocks index come from the TILED scans (tile sums,
-    # scan of the sums, tiles — or, with RP_SS_ONEPASS=1, the single-pass scan), few rows / many rows / the widest rows
+    # scan of the sums, tiles), few rows / many rows / the widest rows
     g = SparseProfile(n_rows, A, "linear", "linear")
     o = oracle.OracleProfile(n_rows, A, "linear", "linear")
     for e in range(2):

@@ -231,3 +231,37 @@ def test_pluribus_coin_is_random_f32():
         assert d["expanded"] == (3 if explore else 1), (name, d)
         seen[explore] += 1
     assert seen[True] > 20 and seen[False] > 20
+
+
+# -- k-means++ (crates/lloyd/src/layer.rs:155-178): one SmallRng seeded from DefaultHasher(street), WeightedIndex<f32> per pick ----
+def test_kmeanspp_picks_follow_weighted_index_f32():
+    from lloyd_fixtures import turn_like_points
+    from test_refrng import PyXoshiro
+
+    N, K = 3000, 12
+    pts = turn_like_points(N, bins=101, mass=46, seed=4)
+    km = oracle.OracleKmeans(K, pts, "variation", seed=99)
+    km.set_rng("reference", street=2)
+    chosen = km.init_centroids()
+    # independent restatement: potentials start at 1, f32 running sums, x = value0_1 * scale, partition_point; the potentials of
+    # later rounds are min(d^2, old) with d = equity variation — recomputed here from the oracle's own distance entry point
+    rng = PyXoshiro.seed_from_u64(py_siphash(0, 0, isz(2), 1, 3))
+    pot = np.ones(N, dtype=np.float32)
+    for k in range(K):
+        cum = np.add.accumulate(pot, dtype=np.float32)  # sequential f32 running sums
+        total = cum[-1]
+        scale = total
+        while np.float32(np.float32(scale * np.float32(1 - 2.0 ** -23)) + np.float32(0)) >= total:
+            scale = np.nextafter(scale, np.float32(0), dtype=np.float32)
+        v12 = np.frombuffer(np.uint32((rng.next_u32() >> 9) | 0x3F800000).tobytes(), np.float32)[0]
+        x = np.float32(np.float32(v12 - np.float32(1)) * scale)
+        pick = int(np.searchsorted(cum[:-1], x, side="right"))  # partition_point(w <= x)
+        assert pick == int(chosen[k]), (k, pick, int(chosen[k]))
+        pot[pick] = 0
+        d = np.array([oracle.equity_variation(pts[pick], pts[i]) for i in range(N)], dtype=np.float32)
+        pot = np.minimum(d * d, pot).astype(np.float32)
+    assert len(set(int(c) for c in chosen)) == K
+    # another street, another stream; the counter mode is something else again
+    km2 = oracle.OracleKmeans(K, pts, "variation", seed=99)
+    km2.set_rng("reference", street=1)
+    assert not np.array_equal(km2.init_centroids(), chosen)
