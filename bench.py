@@ -82,6 +82,12 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the rank bookkeeping (unique-id broadcast, max-over-ranks time); nccl = RCCL "
                          "on the GPUs; gloo only for tests/test_emul_bench.py, where the ranks have no GPU")
+    ap.add_argument("--prune-warmup", type=int, default=0, help="nlhe: warm-up epochs of the pruned-regime leg")
+    ap.add_argument("--prune-threshold", type=float, default=30.0, help="nlhe: regret threshold of the pruned-regime leg")
+    ap.add_argument("--prune-explore", type=float, default=0.05, help="nlhe: exploration probability of the pruned-regime leg")
+    ap.add_argument("--projection", action="store_true",
+                    help="add an 8-GPU strong-scaling PROJECTION (one rank's share timed by a child run, an assumed wire time) "
+                         "under the key `unmeasured`; never part of the default line")
     ap.add_argument("--force-sharded", action="store_true",
                     help="exercise the RCCL all-gather path even with one rank (plumbing check)")
     return ap.parse_args()
@@ -262,6 +268,9 @@ def strong_scaling_projection(args, local_rank, ms_single, ranks=8, window=4, ti
             "projected_speedup": ms_single / (share_ms + wire_ms)}
 
 
+RCCL_NRANKS = None  # the communicator's own count of ranks (an all-reduce of ones), set by init_rccl
+
+
 def init_rccl(rank, world, backend="nccl"):
     """init_process_group + communicator creation with fd 1 pointed at stderr: RCCL prints a version banner to stdout
     when the communicator is created, and stdout must carry exactly one JSON line."""
@@ -275,9 +284,14 @@ def init_rccl(rank, world, backend="nccl"):
     os.dup2(2, 1)
     try:
         dist.init_process_group(backend, rank=rank, world_size=world)
-        warm = torch.zeros(1, device="cuda")
-        dist.all_reduce(warm)
-        torch.cuda.synchronize()
+        warm = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(warm)  # sums one per rank: what the communicator itself says its size is
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        global RCCL_NRANKS
+        got = RCCL_NRANKS = int(warm.item())
+        if got != world or dist.get_world_size() != world:
+            raise SystemExit(f"bench.py --gpus {world}: the communicator reports {got} ranks (get_world_size {dist.get_world_size()})")
     finally:
         import ctypes
 
@@ -693,7 +707,45 @@ def nlhe_extra(args, local_rank):
         _, i1, _ = o.counters()
         big["cpu_baseline"] = {"value": (i1 - i0) / dtc, "unit": "infoset-updates/s", "cores": 1, "kind": "port",
                                "sample": f"oracle/rp_oracle_nlmc.c, batch 128, {n * 128} trees in {dtc:.1f} s on 1 host thread"}
+        try:
+            big["cpu_baseline_all_cores"] = nlhe_cpu_all_cores(args.seed, min(4.0, args.cpu_seconds), sampling="pluribus")
+        except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
+            big["cpu_baseline_all_cores"] = {"error": f"{type(exc).__name__}: {exc}"}
     return big
+
+
+def nlhe_cpu_all_cores(seed, seconds, sampling="external", cap_log2=20):
+    """The NLHE CPU baseline on every host core: one oracle solver per thread (private table, batch 128, ctypes releases the GIL),
+    all stepping for `seconds`; the sum of their infoset-updates.  Independent instances share no table, so this is an UPPER
+    bound on what the reference's rayon batch over one shared profile can reach on these cores."""
+    import threading
+
+    import oracle_nlmc
+
+    T = host_cores()
+    sols = [oracle_nlmc.OracleNlhe(cap_log2=cap_log2, regret="linear", weight="linear", batch=128, seed=seed + 7919 * t, sampling=sampling)
+            for t in range(T)]
+    for o in sols:
+        o.step()
+    base = [o.counters()[1] for o in sols]
+    steps = [0] * T
+    t0 = time.perf_counter()
+
+    def work(t):
+        while time.perf_counter() - t0 < seconds:
+            sols[t].step()
+            steps[t] += 1
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    done = sum(o.counters()[1] - b for o, b in zip(sols, base))
+    return {"value": done / dt, "unit": "infoset-updates/s", "cores": T, "kind": "port",
+            "sample": f"oracle/rp_oracle_nlmc.c, {T} independent solvers (one per host thread, private tables, batch 128), "
+                      f"{sum(steps) * 128} trees in {dt:.1f} s; an upper bound for one shared-profile solver on these cores"}
 
 
 def nlhe_real(args, rank, world, local_rank):
@@ -713,9 +765,9 @@ def nlhe_real(args, rank, world, local_rank):
         torch.cuda.set_device(local_rank)
         init_rccl(rank, world, args.dist_backend)
 
-    def run(batch, steps, warmup, profile=False):
+    def run(batch, steps, warmup, profile=False, sampling=None, hyper=None):
         s = NlheSolver(cap_log2=args.nlhe_cap, regret="linear", weight="linear", batch=batch, seed=args.seed, device=local_rank,
-                       sampling=args.sampling)
+                       sampling=sampling or args.sampling, hyper=hyper)
         if sharded:
             from robopoker_amd.parallel import ShardedNlhe
 
@@ -779,6 +831,26 @@ def nlhe_real(args, rank, world, local_rank):
                                         "+ the sweeps): launch-latency bound"},
     }
     line["config"]["sampling"] = args.sampling
+    if not sharded and not os.environ.get("RP_BENCH_NO_REF"):
+        # the regime a training run spends all but its first minutes in: PluribusSampling past its warm-up (sample/pluribus.rs:72-101,
+        # hyperparams/pruning.rs:45-51: 16 384 epochs, threshold -3e5, explore 0.05).  A fresh table has no regret below the
+        # reference's threshold, so the leg sets the warm-up to 0 and a threshold that bites on the default regrets (fold 100,
+        # check/call 50, raise 10, shove 0 — kicker/src/edge.rs:61-72): what is timed is the pruned traversal's machinery (coin,
+        # masks, the terminal-child exemption, smaller trees), not a trained blueprint's pruning rate
+        import ctypes
+
+        from robopoker_amd import _lib as rp_lib
+
+        hp = rp_lib.Hyper()
+        rp_lib.load().rp_hyper_default(ctypes.byref(hp))
+        hp.prune_warmup, hp.prune_threshold, hp.prune_explore = args.prune_warmup, args.prune_threshold, args.prune_explore
+        pr_run = run(args.nlhe_batch, args.steps, args.warmup, sampling="pluribus", hyper=hp)
+        line["pruned_regime"] = {
+            "value": pr_run["infos"] / pr_run["dt"], "unit": "infoset-updates/s", "ms_per_step": pr_run["dt"] / args.steps * 1e3,
+            "sampling": "pluribus", "prune_warmup": args.prune_warmup, "prune_threshold": args.prune_threshold,
+            "prune_explore": args.prune_explore, "nodes_per_tree": pr_run["nodes"] / trees, "infos_per_tree": pr_run["infos"] / trees,
+            "trees_per_s": trees / pr_run["dt"],
+            "note": "same batch, PluribusSampling past its warm-up with a threshold that bites on a fresh table's default regrets"}
     pr = big["prof"]
     if pr:
         c, g, k = pr["census"], pr["groups"], pr["steps"]
@@ -817,8 +889,11 @@ def nlhe_real(args, rank, world, local_rank):
         _, i1, _ = o.counters()
         line["cpu_baseline"] = {"value": (i1 - i0) / dtc, "unit": "infoset-updates/s", "cores": 1, "kind": "port",
                                 "sample": f"oracle/rp_oracle_nlmc.c, batch 128, {steps * 128} trees in {dtc:.1f} s on 1 host thread"}
+        line["cpu_baseline_all_cores"] = nlhe_cpu_all_cores(args.seed, min(5.0, args.cpu_seconds))
     else:
         line["cpu_baseline"] = None
+    if sharded:
+        line["rccl_nranks"] = RCCL_NRANKS
     print(json.dumps(line), flush=True)
     if sharded:
         dist.destroy_process_group()
@@ -946,10 +1021,11 @@ def main():
             line["other_scaling"] = other_scaling
         if world == 1 and not args.force_sharded and args.game == "leduc" and not args.no_extras:
             line["convergence"] = convergence(args, g, local_rank)
-            try:
-                line["strong_scaling_projection"] = strong_scaling_projection(args, local_rank, dt / args.steps * 1e3)
-            except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
-                line["strong_scaling_projection"] = {"error": f"{type(exc).__name__}: {exc}"}
+            if args.projection:  # opt-in, under a key that cannot be mistaken for a multi-GPU result
+                try:
+                    line["unmeasured"] = {"strong_scaling_projection": strong_scaling_projection(args, local_rank, dt / args.steps * 1e3)}
+                except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
+                    line["unmeasured"] = {"strong_scaling_projection": {"error": f"{type(exc).__name__}: {exc}"}}
             try:
                 line["time_to_exploitability"] = convergence_times(args, g, local_rank)
             except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
@@ -975,6 +1051,8 @@ def main():
                 line["abstraction_inputs"] = abstraction_inputs(args, local_rank)
             except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
                 line["abstraction_inputs"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if sharded_mode:
+            line["rccl_nranks"] = RCCL_NRANKS
         print(json.dumps(line), flush=True)
 
     if sharded_mode and not args.no_kmeans:

@@ -15,7 +15,8 @@
  *     random_range / random::<f32>() from rand 0.9.2
  *     (crates/mccfr/src/strategy/flow.rs:285-295, sample/external.rs:57-63,
  *      sample/mod.rs:76-81, sample/pluribus.rs:91, crates/lloyd/src/layer.rs:155-165)
- *                                                               -> rp_node_hash / rp_u01 / rp_pick_*
+ *                                                               -> rp_node_hash / rp_u01 / rp_pick_* (the default,
+ *     cheap on the device) or, in reference-seed mode, include/rp_refrng.h's restatement of those published algorithms
  * Only IEEE-754 correctly rounded primitives are used: + - * / sqrt, fma,
  * int<->float conversion and integer bit operations.
  */

@@ -571,6 +571,9 @@ typedef struct rp_prune_stats {
     uint64_t sample_mismatches;/* pruned pass; a mismatch fails the next call that hands results out (RP_ERR_INTERNAL) */
 } rp_prune_stats;
 RP_API int rp_kmeans_prune_stats(rp_kmeans* h, rp_prune_stats* out);
+/* the same with the size of the CALLER's struct: a host compiled against an older (shorter) rp_prune_stats passes its own sizeof
+ * and gets the fields it knows; bytes beyond this library's struct are zeroed.  Prefer this one from plain-C hosts. */
+RP_API int rp_kmeans_prune_stats_sized(rp_kmeans* h, void* out, size_t out_bytes);
 /* the divergence intervals of the bound against the current centroids: lo[N*K], hi[N*K] (tests / diagnostics) */
 RP_API int rp_kmeans_bound_intervals(rp_kmeans* h, float* lo, float* hi);
 RP_API int rp_kmeans_set_stream(rp_kmeans* h, void* hip_stream);

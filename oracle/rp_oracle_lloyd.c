@@ -15,8 +15,9 @@
  * self-divergence < 1e-4 and symmetry < 1e-3 on the closed-form fixture (sinkhorn.rs:240-293),
  * OT(mu,mu) <= 0.01 / positivity / triangle (emd.rs:105-131), variation symmetric/zero/positive
  * (emd.rs:72-97), Elkan == naive (tests.rs:148-161), Pair bijection (pair.rs:171-189).
- * exp/ln are include/rp_math.h's rp_expf/rp_logf (<= 1 ulp from libm); the k-means++ draw is the
- * documented fixed-point scheme of rp_math.h ("parity unpinned" at the rand/SipHash boundary).
+ * exp/ln are include/rp_math.h's rp_expf/rp_logf (<= 1 ulp from libm: PARITY UNPINNED there, no published definition of the
+ * platform's libm exists); the k-means++ draw is rp_math.h's order-independent fixed-point scheme by default and, under
+ * ora_kmeans_set_rng(RP_RNG_REFERENCE), layer.rs:155-178's own SmallRng + WeightedIndex<f32> (include/rp_refrng.h).
  *
  * f32 operation order follows the reference: supports ascend by bin index (phi.rs:51-57), every softmin
  * term is clamped at MIN_POSITIVE before the left-fold sum (sinkhorn.rs:119-128), the cost is summed

@@ -15,9 +15,12 @@
  * not bit-reproducible against itself (thread RNG root deals, RandomState HashMaps).
  * The oracle is therefore pinned against every known-answer test the reference holds for this path —
  * Kuhn analytic Nash (kuhn/src/solver.rs:176-203), the 44 Kuhn / 3 Leduc exploitability thresholds,
- * RPS equilibrium, sampling-distribution normalisation — see tests/test_oracle_mccfr.py.  RNG, hashing
- * and libm boundaries are "parity unpinned" by construction; they are replaced by the documented
- * definitions of include/rp_math.h (same structure: one hash per (epoch, info, tree)).
+ * RPS equilibrium, sampling-distribution normalisation — see tests/test_oracle_mccfr.py.  The seed -> sample chain
+ * (DefaultHasher / SmallRng / WeightedIndex / random_range / random::<f32>(), flow.rs:285-295) is third-party but published:
+ * include/rp_refrng.h restates it and pins it to the published vectors (tests/test_refrng.py); ora_mccfr_set_rng(RP_RNG_REFERENCE)
+ * draws every sampled branch through it ("reference-seed" mode; the default keeps include/rp_math.h's counter hash, same
+ * structure: one hash per (epoch, info, tree)).  PARITY UNPINNED at one boundary: libm's powf in DiscountedRegret
+ * (discounted.rs:33,37), restated as t * sqrt(t) / sqrt(t).
  *
  * f32 operation order follows the reference expression by expression (sums fold left from 0 in
  * `choices()` order; petgraph's newest-edge-first adjacency over children pushed in reverse pop order

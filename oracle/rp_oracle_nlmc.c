@@ -13,10 +13,11 @@
  * The rules (GameN, action abstraction, showdown) are rp_oracle_nlhe.c's, pinned to the reference's own unit tests; the
  * table update is rp_oracle_mccfr.c's row-addressed profile (ora_profile_apply = Solver::step's update loop).
  *
- * PARITY STATUS: unpinned at the same third-party boundaries as the rest: the reference draws hole cards,
- * boards and sampled edges from rand / SipHash; here every draw is rp_node_hash of (seed, epoch, tree, key) — hole cards and
- * boards keyed by the node's path from the root, a sampled opponent edge keyed by the infoset (the reference's rng(node)
- * hashes (epoch, info, tree id): the same infoset samples the same edge within a tree, flow.rs:285-295).
+ * PARITY STATUS: the reference deals hole cards and boards from the unseeded thread RNG (not reproducible in the reference
+ * itself): here they are rp_node_hash of (seed, epoch, tree, path).  The sampled opponent edge and Pluribus' coin come from
+ * rng(node) = DefaultHasher(epoch, info, tree id) -> SmallRng (flow.rs:285-295): ora_nlmc_set_rng(RP_RNG_REFERENCE) draws them
+ * through include/rp_refrng.h's restatement of that chain (pinned to the published vectors, tests/test_refrng.py); the default
+ * keys the counter hash by the infoset the same way (the same infoset samples the same edge within a tree).
  * The encoder's isomorphism -> abstraction map is an input: a table (sorted canonical observations + buckets, the
  * artifact of the clustering pipeline) or, for tests, a hash of the canonical observation.
  */

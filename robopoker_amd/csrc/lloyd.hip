@@ -3062,7 +3062,20 @@ int rp_kmeans_exp_evals(rp_kmeans* h, uint64_t* evals) {
     return RP_OK;
 }
 
-int rp_kmeans_prune_stats(rp_kmeans* h, rp_prune_stats* out) {
+static int prune_stats_full(rp_kmeans* h, rp_prune_stats* out);
+// the caller says how large ITS rp_prune_stats is: the struct grew in 0.3 (sampled_points, sample_mismatches) and may grow again;
+// a host compiled against an older header gets the fields it knows, never a write past its struct
+int rp_kmeans_prune_stats_sized(rp_kmeans* h, void* out, size_t out_bytes) {
+    if (!h || !out || out_bytes < 8) return rp::fail(RP_ERR_INVALID, "rp_kmeans_prune_stats_sized: bad argument");
+    rp_prune_stats full;
+    const int rc = prune_stats_full(h, &full);
+    if (rc) return rc;
+    memcpy(out, &full, std::min(out_bytes, sizeof(full)));
+    if (out_bytes > sizeof(full)) memset(reinterpret_cast<unsigned char*>(out) + sizeof(full), 0, out_bytes - sizeof(full));
+    return RP_OK;
+}
+int rp_kmeans_prune_stats(rp_kmeans* h, rp_prune_stats* out) { return rp_kmeans_prune_stats_sized(h, out, sizeof(rp_prune_stats)); }
+static int prune_stats_full(rp_kmeans* h, rp_prune_stats* out) {
     if (!h || !out) return rp::fail(RP_ERR_INVALID, "rp_kmeans_prune_stats: NULL argument");
     memset(out, 0, sizeof(*out));
     out->enabled = h->sb_on ? 1u : 0u;

@@ -67,11 +67,11 @@ __device__ __forceinline__ float d_sampling_z(const DevTables& t, uint32_t A, ui
 
 // SamplingScheme::sample as a bitmask over child slots (sample/{mod,external,pruning,pluribus}.rs)
 __device__ uint32_t d_sample_mask(const DevGame& g, const DevTables& t, const StepParams& p, uint64_t tree_id,
-                                  uint32_t state, uint32_t turn, uint32_t n, uint32_t info, uint32_t off, uint32_t rec_x) {
+                                  uint32_t state, uint32_t turn, uint32_t n, uint32_t info, uint32_t off) {
     const uint32_t all = (1u << n) - 1u;
     const bool ref = p.ref_info != nullptr;
     if (n == 0) return 0;
-    if (turn == RP_TURN_CHANCE) return 1u << d_draw_chance(p, ref, tree_id, state, rec_x);
+    if (turn == RP_TURN_CHANCE) return 1u << d_draw_chance(p, ref, tree_id, state, n, info);  // a chance record carries chance_info in y
     if (turn != p.walker) {
         // weighted (external.rs:41-64): WeightedIndex over sampling_distribution().max(EPSILON)
         const float denom = d_weight_denom(t, g.A, info, n, p.smoothing);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_traverse(DevGame g, DevTables t, DevScr
         if (nch == 0) sc.n_pay[me * S + lane] = g.payoffs[off * g.n_players + p.walker];
         nn += 1;
         if (nch > 0) {
-            const uint32_t mask = d_sample_mask(g, t, p, tree_id, cur_state, turn, nch, info, off, st.x);
+            const uint32_t mask = d_sample_mask(g, t, p, tree_id, cur_state, turn, nch, info, off);
             const bool chance = turn == RP_TURN_CHANCE;
             const uint32_t ptype = chance ? PT_CHANCE : (is_walker ? PT_WALKER : PT_OPP);
             float rd = 0.0f, denom = 0.0f, z = 0.0f;
@@ -365,10 +365,10 @@ __global__ void k_prepare_ref(const rp_hash_stream* infos, uint32_t n_infos, con
 // SamplingScheme::sample with the per-infoset tables
 __device__ __forceinline__ uint32_t d_sample_mask_tab(const DevGame& g, const DevInfoTab& it, const StepParams& p,
                                                       uint64_t tree_id, uint32_t state, uint32_t turn, uint32_t n,
-                                                      uint32_t info, uint32_t off, uint32_t rec_x) {
+                                                      uint32_t info, uint32_t off) {
     const uint32_t all = (1u << n) - 1u;
     const bool ref = p.ref_info != nullptr;
-    if (turn == RP_TURN_CHANCE) return 1u << d_draw_chance(p, ref, tree_id, state, rec_x);
+    if (turn == RP_TURN_CHANCE) return 1u << d_draw_chance(p, ref, tree_id, state, n, info);  // a chance record carries chance_info in y
     if (turn != p.walker) {
         const float x = d_draw_weight(p, ref, tree_id, info, it.total[info]);
         uint32_t idx = 0;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64) void k_traverse_lds(DevGame g, DevInfoTab it, D
         if (nch > 0) {
             n_int += 1;
             if (is_walker) wmask |= 1ull << me;
-            uint32_t mask = d_sample_mask_tab(g, it, p, tree_id, rec.w, turn, nch, info, off, rec.x);
+            uint32_t mask = d_sample_mask_tab(g, it, p, tree_id, rec.w, turn, nch, info, off);
             const bool chance = turn == RP_TURN_CHANCE;
             const uint32_t ptype = chance ? PT_CHANCE : (is_walker ? PT_WALKER : PT_OPP);
             const uint32_t last = 31u - (uint32_t)__builtin_clz(mask);
@@ -2271,7 +2271,7 @@ int rp_mccfr_create(const rp_game_table* game, rp_regret_kind r, rp_weight_kind 
     std::vector<uint4> packed(game->n_states);
     for (uint32_t i = 0; i < game->n_states; ++i) {
         const rp_state& st = game->states[i];
-        packed[i] = make_uint4((uint32_t)st.turn | ((uint32_t)st.n_children << 8) | ((uint32_t)st.chance_info << 16), st.info, st.offset, 0u);
+        packed[i] = make_uint4((uint32_t)st.turn | ((uint32_t)st.n_children << 8), st.turn == RP_TURN_CHANCE ? (uint32_t)st.chance_info : st.info, st.offset, 0u);
     }
     CREATE_TRY(hipMalloc(&h->d_states, packed.size() * sizeof(uint4)));
     CREATE_TRY(hipMemcpy(h->d_states, packed.data(), packed.size() * sizeof(uint4), hipMemcpyHostToDevice));

@@ -10,7 +10,7 @@
 
 namespace rp {
 
-// rp_state repacked to one 16-byte load: x = turn | n_children << 8 | chance_info << 16, y = info, z = offset
+// rp_state repacked to one 16-byte load: x = turn | n_children << 8, y = info (chance states: rp_state.chance_info), z = offset
 struct DevGame {
     const uint4* states;
     const uint32_t* children;
@@ -94,12 +94,11 @@ struct StepParams {
 };
 
 // ------------------------------------------------------------------------------------------------
-// the three draws of SamplingScheme::sample (sample/{mod,external,pluribus}.rs) in either rp_rng_kind.  `rec_x` = the state
-// record's x (chance nodes: chance_info in bits 16..31; 0 = the root deal, which keeps the counter hash in both modes).
+// the three draws of SamplingScheme::sample (sample/{mod,external,pluribus}.rs) in either rp_rng_kind.  `ci` = a chance state's
+// chance_info (the record's y; 0 = the root deal, which keeps the counter hash in both modes), n its number of outcomes.
 // REF is a compile-time switch in the skeleton kernels and p.ref_info != NULL elsewhere.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t d_draw_chance(const StepParams& p, bool ref, uint64_t tree_id, uint32_t state, uint32_t rec_x) {
-    const uint32_t n = (rec_x >> 8) & 0xffu, ci = rec_x >> 16;
+__device__ __forceinline__ uint32_t d_draw_chance(const StepParams& p, bool ref, uint64_t tree_id, uint32_t state, uint32_t n, uint32_t ci) {
     if (ref && ci) return rp_ref_draw_range(rp_ref_seed_finish(&p.ref_chance[ci - 1u], tree_id), n);  // rng.random_range(0..n)
     return rp_pick_uniform(rp_node_hash(p.seed, p.epoch, tree_id, 0x80000000ull | state), n);
 }

@@ -28,6 +28,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "nlmc_level.hpp"
@@ -712,10 +713,18 @@ int rp_nlhe_step_comm(rp_nlhe* h, rp_comm* c, uint32_t steps) {
         return RP_OK;
     };
     for (uint32_t s = 0; s < steps; ++s) {
-        if ((rc = nl_traverse(h))) return rc;
-        rp_decisions b{h->last_n, h->out.row, h->out.nact, h->out.expanded, h->out.regret, h->out.policy, h->out.payoff};
+        // A rank that fails here (a full table, the Decisions buffer, the node budget after its retries) must not leave the others
+        // waiting in the gather: its failure travels in the count exchange (NL_RANK_FAILED) and every rank leaves the step with an
+        // error together.
+        constexpr uint32_t NL_RANK_FAILED = 0xffffffffu;
         uint32_t n_mine = 0;
-        if ((rc = rp_profile_summarize(h->prof, &b, mine_ent, &n_mine))) return rc;  // synchronises: n_mine is valid
+        int local_rc = nl_traverse(h);
+        if (!local_rc) {
+            rp_decisions b{h->last_n, h->out.row, h->out.nact, h->out.expanded, h->out.regret, h->out.policy, h->out.payoff};
+            local_rc = rp_profile_summarize(h->prof, &b, mine_ent, &n_mine);  // synchronises: n_mine is valid
+        }
+        const std::string local_msg = local_rc ? rp_last_error() : "";
+        if (local_rc) n_mine = NL_RANK_FAILED;
         // every rank's count
         if ((rc = grow(&h->x_counts, &h->x_counts_bytes, (size_t)(world + 1) * 4u))) return rc;
         uint32_t* d_counts = reinterpret_cast<uint32_t*>(h->x_counts);
@@ -724,6 +733,9 @@ int rp_nlhe_step_comm(rp_nlhe* h, rp_comm* c, uint32_t steps) {
         std::vector<uint32_t> counts(world);
         HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, (size_t)world * 4u, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (local_rc) return rp::fail(local_rc, "%s", local_msg.c_str());
+        for (uint32_t r = 0; r < world; ++r)
+            if (counts[r] == NL_RANK_FAILED) return rp::fail(RP_ERR_CAPACITY, "rp_nlhe_step_comm: rank %u failed its part of the step", r);
         uint32_t width = 0, total = 0;
         for (uint32_t r = 0; r < world; ++r) width = std::max(width, counts[r]), total += counts[r];
         // keys of my entries: [past u64][choices u64][present u32] planes of `width` items (the gather sends `width` of each)

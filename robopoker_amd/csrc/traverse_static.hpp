@@ -199,7 +199,7 @@ __device__ __forceinline__ uint32_t static_traverse(const DevGame& g, const DevI
             else live[s] = live[par];
         }
         if constexpr (SK::S.kind[s] == SK_CHANCE) {  // SamplingScheme::sample at a chance node: uniform (external.rs:41-64)
-            const uint32_t nout = (rx[s] >> 8) & 0xffu, ci = rx[s] >> 16;  // ci = 0: the root deal (thread RNG in the reference)
+            const uint32_t nout = (rx[s] >> 8) & 0xffu, ci = ry[s];  // a chance record's y = chance_info; 0: the root deal (thread RNG in the reference)
             if (REF && ci) pick[s] = rp_ref_draw_range(rp_ref_seed_finish(&p.ref_chance[ci - 1u], tree_id), nout);
             else pick[s] = rp_pick_uniform(rp_node_hash_key(th, 0x80000000ull | rw[s]), nout);
         } else if constexpr (SK::S.kind[s] == SK_P0 || SK::S.kind[s] == SK_P1) {

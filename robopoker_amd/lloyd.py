@@ -410,6 +410,7 @@ def cpu_baseline_full(oracle, gpu_out, centroids, threads=None):
     d_iter = float(np.median([it["distances"] for it in per_iter[len(per_iter) // 2:]])) - K * (K - 1) - K if per_iter else 0.0
     t_iter = t_pw + max(d_iter, 0.0) / rate
     return {"value": gpu_out["N"] / t_iter if t_iter > 0 else 0.0, "unit": "points/s", "cores": threads, "kind": "port",
+            "estimate": True,  # composed from a measured solve rate and the GPU run's distance counts; no full-size CPU run stands behind it
             "distances_per_s": rate, "pairwise_s_at_K256": t_pw, "iteration_s_at_full_size": t_iter,
             "sample": f"oracle/rp_oracle_lloyd.c, OpenMP x{threads}: init_bounds of {Ns} points x {Ks} converged centroids "
                       f"({Ns * Ks} solves in {t_ib:.1f} s) and one Elkan step ({pair_solves} centroid-pair solves, {t_step:.1f} s); "

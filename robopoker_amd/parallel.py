@@ -338,10 +338,20 @@ class ShardedNlhe:
 
     def _step(self) -> int:
         m = self.mine
-        n = self.engine.step_local(m["ent"].data_ptr(), m["past"].data_ptr(), m["present"].data_ptr(), m["choices"].data_ptr())
+        # a rank whose part fails (full table, node budget) says so in the count exchange: every rank leaves the step together
+        # instead of the others waiting in the gather (as rp_nlhe_step_comm does)
+        failure = None
+        try:
+            n = self.engine.step_local(m["ent"].data_ptr(), m["past"].data_ptr(), m["present"].data_ptr(), m["choices"].data_ptr())
+        except Exception as exc:  # noqa: BLE001
+            failure, n = exc, -1
         counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
         _all_gather_bytes(counts, torch.tensor([n], dtype=torch.int64, device=self.device), self.group, self.flat)
         counts = [int(c) for c in counts.cpu().tolist()]
+        if failure is not None:
+            raise failure
+        if min(counts) < 0:
+            raise RuntimeError(f"ShardedNlhe.step: rank {counts.index(min(counts))} failed its part of the step")
         width, total = max(counts), sum(counts)
         for k, unit in (("ent", self.eb), ("past", 1), ("present", 1), ("choices", 1)):
             w = width * unit

@@ -10,8 +10,8 @@
 
 Everything between the streets stays in HBM: the projection writes the points in the layout
 ``rp_kmeans_create_device`` reads.  ``Artifacts`` mirrors lloyd/src/artifacts.rs:11-18 {lookup, metric, future}.
-Seeds are this build's own (the reference seeds its k-means++ from SipHash(street), layer.rs:156-158; SURVEY §8c:
-RNG parity with the Rust crates is unpinned) — parity is GPU <-> oracle on the same inputs.
+Seeds are this build's own by default; ``Layer.set_rng("reference", street)`` seeds k-means++ the reference's way
+(SipHash(street) -> SmallRng -> WeightedIndex<f32>, layer.rs:156-166; include/rp_refrng.h).
 """
 from __future__ import annotations
 

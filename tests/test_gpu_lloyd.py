@@ -94,7 +94,7 @@ def _check_state(dev, ora):
     assert np.array_equal(c1, c2) and np.array_equal(w1, w2), "centroids differ"
 
 
-@pytest.mark.parametrize("kind,K,N,bins,mass,street", [("sinkhorn", 24, 5000, 32, 20, 1), ("variation", 40, 70001, 101, 46, 2),
+@pytest.mark.parametrize("kind,K,N,bins,mass,street", [("sinkhorn", 12, 1500, 32, 20, 1), ("variation", 40, 70001, 101, 46, 2),
                                                        ("variation", 7, 1024, 64, 30, 2), ("variation", 3, 5, 64, 30, 1)])
 def test_reference_seed_kmeanspp_picks_equal_the_oracle(gpu, kind, K, N, bins, mass, street):
     # rp_kmeans_set_rng(RP_RNG_REFERENCE): Layer::init_centroids' own chain (layer.rs:155-178) — DefaultHasher(street) ->
