@@ -274,8 +274,25 @@ RP_HD uint64_t rp_node_hash_step(uint64_t seed, uint64_t epoch) {
 RP_HD uint64_t rp_node_hash_tree(uint64_t step_hash, uint64_t tree) {
     return rp_mix64(step_hash ^ (tree * 0xaf251af3b0f025b5ull + 0x2545f4914f6cdd1dull));
 }
+/* the per-DRAW half is 32-bit arithmetic (round 4): a draw reads only the top 32 bits of its hash (rp_u01: 24, rp_pick_uniform:
+ * 32), and on gfx950 an integer multiply issues at a quarter of the VALU rate — the 64-bit mixer's eight multiplies per draw were a
+ * fifth of the headline traversal's issue time.  Murmur3's 32-bit finaliser (full avalanche, a bijection: distinct keys of one tree
+ * never collide) over the tree hash's low word and the folded key, the high word multiplied in afterwards: three multiplies. */
+RP_HD uint32_t rp_fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
 RP_HD uint64_t rp_node_hash_key(uint64_t tree_hash, uint64_t key) {
-    return rp_mix64(tree_hash ^ (key * 0x9fb21c651e98df25ull + 0x27d4eb2f165667c5ull));
+    const uint32_t lo = (uint32_t)tree_hash, hi = (uint32_t)(tree_hash >> 32);
+    const uint32_t k = (uint32_t)key ^ (uint32_t)(key >> 32);
+    uint32_t x = rp_fmix32(lo ^ k);
+    x = (x ^ hi) * 0x9e3779b1u;
+    x ^= x >> 15;
+    return (uint64_t)x << 32;
 }
 RP_HD uint64_t rp_node_hash_draw(uint64_t step_hash, uint64_t tree, uint64_t key) {
     return rp_node_hash_key(rp_node_hash_tree(step_hash, tree), key);

@@ -1811,7 +1811,8 @@ __global__ __launch_bounds__(64) void k_kpp_ref_pick(float* pot, float* kpp_d, u
         uint64_t lo = 0, hi = N - 1;                               // partition_point(|w| w <= x) over cum[0 .. N-1)
         while (lo < hi) {
             const uint64_t mid = lo + (hi - lo) / 2;
-            if (__hip_atomic_load(&cum[mid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= x) lo = mid + 1;
+            // (an agent-scope load: the sums were written by the other lanes of this wavefront a moment ago)
+            if (rp_u2f(__hip_atomic_load(reinterpret_cast<const uint32_t*>(cum) + mid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= x) lo = mid + 1;
             else hi = mid;
         }
         win = lo;

@@ -199,7 +199,17 @@ def _node_hash(seed, epoch, tree, key):  # include/rp_math.h rp_node_hash, resta
     h = _mix64((seed + 0x9e3779b97f4a7c15) & _M64)
     h = _mix64(h ^ ((epoch * 0xd1342543de82ef95 + 0x632be59bd9b4e019) & _M64))
     h = _mix64(h ^ ((tree * 0xaf251af3b0f025b5 + 0x2545f4914f6cdd1d) & _M64))
-    return _mix64(h ^ ((key * 0x9fb21c651e98df25 + 0x27d4eb2f165667c5) & _M64))
+    # the per-draw half: Murmur3's 32-bit finaliser over the low word and the folded key, the high word multiplied in
+    lo, hi, k = h & 0xffffffff, h >> 32, (key ^ (key >> 32)) & 0xffffffff
+    x = lo ^ k
+    x ^= x >> 16
+    x = (x * 0x85ebca6b) & 0xffffffff
+    x ^= x >> 13
+    x = (x * 0xc2b2ae35) & 0xffffffff
+    x ^= x >> 16
+    x = ((x ^ hi) * 0x9e3779b1) & 0xffffffff
+    x ^= x >> 15
+    return x << 32
 
 
 def _u01(h):  # rp_u01: the top 24 bits as a float in [0, 1)
