@@ -100,6 +100,10 @@ struct rp_nlhe {
     bool profiling = false;
     Clock clk[5];  // expand, children, sweeps (up + down), decide (scan + fill + group + emit), apply
     uint64_t census[5] = {0, 0, 0, 0, 0};  // nodes by kind + walker children, summed over the profiled steps
+    // small batches (the reference's 128): one tree per workgroup, the whole traversal in one launch (k_nl_tree); tree_cap = nodes of a
+    // tree's region (0: the node arrays were not sized for it), level_ncap = the batch-wide path's own node budget (its launch sizes)
+    uint32_t tree_cap = 0, level_ncap = 0;
+    bool tree_mode_off = false;  // a tree outgrew its region once: the handle stays on the batch-wide path
     uint32_t chunks = 1;  // passes per batch (RP_NLHE_CHUNKS; doubled when a pass runs out of nodes)
     uint32_t grid_cap = 16384;  // workgroups of the grid-stride kernels (measured: 1024 -14 %, 4096 -4 %)
 };
@@ -172,8 +176,50 @@ int nl_traverse_chunk(rp_nlhe* h, uint32_t lo, uint32_t B, uint32_t d_base, uint
     prm.batch = B;
     prm.tree_base = h->prm.tree_base + lo;
     *flags = 0;
-    const dim3 wide(std::min<uint32_t>(h->grid_cap, std::max<uint32_t>(1u, (lv.ncap / 4u + 255u) / 256u))), blk(256);
-    const dim3 wide_x(std::min<uint32_t>(h->grid_cap * 2u, std::max<uint32_t>(1u, (lv.ncap / 4u + NL_TILE - 1u) / NL_TILE)));  // one tile per workgroup
+    const dim3 wide(std::min<uint32_t>(h->grid_cap, std::max<uint32_t>(1u, (h->level_ncap / 4u + 255u) / 256u))), blk(256);
+    const dim3 wide_x(std::min<uint32_t>(h->grid_cap * 2u, std::max<uint32_t>(1u, (h->level_ncap / 4u + NL_TILE - 1u) / NL_TILE)));  // one tile per workgroup
+    if (h->tree_cap && !h->tree_mode_off && lo == 0 && B == h->batch) {
+        // ---- a small batch: one tree per workgroup, one launch (k_nl_tree), then the partition and the Decisions as below
+        const uint32_t WC = NL_WMAX;
+        HIP_TRY(hipMemsetAsync(lv.ctl, 0, sizeof(NlCtl), st));
+        prm.tag = nl_next_tag(h);
+        nl_clock_begin(h, 0);
+        hipLaunchKernelGGL(k_nl_tree, dim3(B), blk, 0, st, prm, h->tab, lv, h->tree_cap, WC);
+        nl_clock_end(h, 0);
+        nl_clock_begin(h, 3);
+        hipLaunchKernelGGL((k_nl_group<256>), dim3(B), dim3(64), 0, st, lv, B);
+        hipLaunchKernelGGL(k_nl_group_big, dim3(std::min<uint32_t>(B, 1280u)), dim3(64), 0, st, lv);
+        HIP_TRY(rp::ss::exclusive_scan<uint32_t>(lv.t_dcount, lv.t_doff, B, h->d_scan, st, h->d_total));
+        HIP_TRY(hipGetLastError());
+        uint32_t total0 = 0;
+        NlCtl ctl;
+        HIP_TRY(hipMemcpyAsync(&total0, h->d_total, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&ctl, lv.ctl, sizeof(NlCtl), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (ctl.err & (NERR_NODES | NERR_WALKERS)) {
+            h->tree_mode_off = true;  // a tree outgrew its region: this step and the following ones on the batch-wide path
+            nl_clock_end(h, 3);
+        } else {
+            if (ctl.err) {
+                *flags = ctl.err;
+                return nl_capacity_error(ctl.err);
+            }
+            if (h->profiling) {
+                for (int k = 0; k < 4; ++k) h->census[k] += ctl.kinds[k];
+                h->census[4] += ctl.walker_kids;
+            }
+            if ((uint64_t)d_base + total0 > h->out_cap)
+                return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %llu Decisions in one batch exceed the buffer (%u)", (unsigned long long)d_base + total0, h->out_cap);
+            hipLaunchKernelGGL(k_nl_emit, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(h->grid_cap, B * WC / 256u))), blk, 0, st, lv, h->tab, B * WC, d_base, lo,
+                               h->out_cap, h->out, WC);
+            nl_clock_end(h, 3);
+            HIP_TRY(hipGetLastError());
+            *n_dec = total0;
+            *n_nod = ctl.n_nodes;
+            *n_lev = ctl.pad[0];
+            return RP_OK;
+        }
+    }
     HIP_TRY(hipMemsetAsync(lv.ctl, 0, sizeof(NlCtl), st));
     HIP_TRY(hipMemsetAsync(lv.t_nw, 0, (size_t)B * 4, st));
     prm.tag = nl_next_tag(h);
@@ -235,7 +281,7 @@ int nl_traverse_chunk(rp_nlhe* h, uint32_t lo, uint32_t B, uint32_t d_base, uint
         *flags = NERR_NODES;
         return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %u walker nodes in one pass exceed the buffer (%u)", total[1], lv.lcap);
     }
-    hipLaunchKernelGGL(k_nl_emit, wide, blk, 0, st, lv, h->tab, total[1], d_base, lo, h->out_cap, h->out);
+    hipLaunchKernelGGL(k_nl_emit, wide, blk, 0, st, lv, h->tab, total[1], d_base, lo, h->out_cap, h->out, 0u);
     nl_clock_end(h, 3);
     HIP_TRY(hipGetLastError());
     *n_dec = total[0];
@@ -354,7 +400,12 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     const size_t B = batch;
     {
         NlNodes& lv = h->lv;
-        const size_t N = (size_t)ncap64, LC = std::max<size_t>(N / walker_div, 64);  // walker nodes of a batch (a seventh of its nodes): a quarter of the node budget
+        // a batch of at most NL_TREE_BATCH trees also gets a region of NL_TREE_CAP nodes and NL_WMAX walker slots per tree (k_nl_tree)
+        const bool tree_mode = !budget_env && batch <= NL_TREE_BATCH;
+        h->level_ncap = (uint32_t)ncap64;
+        h->tree_cap = tree_mode ? NL_TREE_CAP : 0u;
+        const size_t N = std::max<size_t>((size_t)ncap64, tree_mode ? (size_t)batch * NL_TREE_CAP : 0);
+        const size_t LC = std::max<size_t>(std::max<size_t>((size_t)ncap64 / walker_div, 64), tree_mode ? (size_t)batch * NL_WMAX : 0);  // walker nodes of a batch (a seventh of its nodes): a quarter of the node budget
         lv.ncap = (uint32_t)N;
         lv.lcap = (uint32_t)LC;
         NL_TRY(nl_alloc(h, &lv.link, N)); NL_TRY(nl_alloc(h, &lv.tree, N)); NL_TRY(nl_alloc(h, &lv.meta, N));

@@ -110,50 +110,52 @@ __device__ __forceinline__ uint32_t nl_showdown_order(uint64_t hole0, uint64_t h
 // ---------------------------------------------------------------------------------------------------------------
 // level 0: Solver::tree — Game::root() with the hole cards dealt (P0 on the button, kicker game.rs:66-78)
 // ---------------------------------------------------------------------------------------------------------------
+// the root of one tree at node index `node`: hole cards, blinds, preflop buckets
+__device__ __forceinline__ uint32_t nl_make_root(const NlParams& p, const NlNodes& nd, uint32_t tree, uint32_t node) {
+    uint32_t err = 0;
+    const uint64_t tree_id = p.tree_base + tree;
+    G2 g;
+    g.n = 2;
+    g.dealer = 0;
+    g.ticker = 0;  // n == 2: the dealer posts the small blind
+    g.pot = 0;
+    g.board = 0;
+    uint64_t deck = HAND_MASK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        g.state[i] = NL_BETTING;
+        g.stack[i] = 200;
+        g.stake[i] = g.spent[i] = 0;
+        g.cards[i] = nl_draw(deck, 2, p, tree_id, 0xD0C0000000000000ull + 8u * (uint64_t)i);
+        deck &= ~g.cards[i];
+    }
+    for (int b = 0; b < 2; ++b) g.force_act(NlAction{NA_BLIND, g.to_post(), 0});
+    nd.hole0[tree] = g.cards[0];
+    nd.hole1[tree] = g.cards[1];
+    const uint32_t b0 = nl_bucket(p, 0, g.cards[0], 0ull, &err), b1 = nl_bucket(p, 0, g.cards[1], 0ull, &err);
+    const int turn = g.turn();  // a player: nobody is all-in after the blinds of a 200-chip stack
+    const uint32_t kind = turn == (int)p.walker ? NK_WALKER : NK_OPP;
+    nl_store_game(nd, node, g);
+    nd.bucket[node] = b0 | (b1 << 16);
+    nd.past[node] = 0ull;
+    nd.hkey[node] = rp_mix64(0x726f6f74ull);
+    nd.link[node] = NL_LINK_NONE;
+    nd.tree[node] = tree;
+    nd.meta[node] = kind;
+    nd.fac[node] = 1.0f;
+    nd.reach[node] = 1.0f;
+    nd.val[node] = 0.0f;
+    nd.dfs[node] = 0u;
+    return err;
+}
 __global__ __launch_bounds__(256) void k_nl_roots(NlParams p, NlNodes nd) {
     const uint32_t tree = blockIdx.x * 256u + threadIdx.x;
-    const bool valid = tree < p.batch;
-    uint32_t err = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         nd.ctl->n_nodes = p.batch;  // the roots are nodes [0, batch): children are allocated behind them
         nd.ctl->lvl_node[0] = 0;
         nd.ctl->lvl_node[1] = p.batch;
     }
-    if (valid) {
-        const uint64_t tree_id = p.tree_base + tree;
-        G2 g;
-        g.n = 2;
-        g.dealer = 0;
-        g.ticker = 0;  // n == 2: the dealer posts the small blind
-        g.pot = 0;
-        g.board = 0;
-        uint64_t deck = HAND_MASK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            g.state[i] = NL_BETTING;
-            g.stack[i] = 200;
-            g.stake[i] = g.spent[i] = 0;
-            g.cards[i] = nl_draw(deck, 2, p, tree_id, 0xD0C0000000000000ull + 8u * (uint64_t)i);
-            deck &= ~g.cards[i];
-        }
-        for (int b = 0; b < 2; ++b) g.force_act(NlAction{NA_BLIND, g.to_post(), 0});
-        nd.hole0[tree] = g.cards[0];
-        nd.hole1[tree] = g.cards[1];
-        const uint32_t b0 = nl_bucket(p, 0, g.cards[0], 0ull, &err), b1 = nl_bucket(p, 0, g.cards[1], 0ull, &err);
-        const int turn = g.turn();  // a player: nobody is all-in after the blinds of a 200-chip stack
-        const uint32_t kind = turn == (int)p.walker ? NK_WALKER : NK_OPP;
-        nl_store_game(nd, tree, g);
-        nd.bucket[tree] = b0 | (b1 << 16);
-        nd.past[tree] = 0ull;
-        nd.hkey[tree] = rp_mix64(0x726f6f74ull);
-        nd.link[tree] = NL_LINK_NONE;
-        nd.tree[tree] = tree;
-        nd.meta[tree] = kind;
-        nd.fac[tree] = 1.0f;
-        nd.reach[tree] = 1.0f;
-        nd.val[tree] = 0.0f;
-        nd.dfs[tree] = 0u;
-    }
+    const uint32_t err = tree < p.batch ? nl_make_root(p, nd, tree, tree) : 0u;
     if (err) atomicOr(&nd.ctl->err, err);
 }
 
@@ -162,6 +164,144 @@ __global__ __launch_bounds__(256) void k_nl_roots(NlParams p, NlNodes nd) {
 // ---------------------------------------------------------------------------------------------------------------
 #define NL_TILE 512u  // nodes a workgroup sorts by kind at a time (measured: 512 and 1024 equal at 262 144 trees, 2048 -7 %, 4096 -13 % in
                       // k_nl_expand; at 128 trees per step 8.0 / 7.8 / 6.6 / 5.3 M updates per second: a tile is a serial chain of phases)
+// One decision or chance node of a level (what a lane of k_nl_expand / k_nl_tree does for its node): choices, NlheInfo key -> row,
+// regret matching, the opponent's sampled edge or the walker's surviving edges (builder.rs:98-139).  seg: 0 walker, 1 opponent,
+// 2 chance.  walker_count: the tree's counter of walker nodes.  Returns n_kids | expanded mask << 4 | sampled slot << 13; aux = the
+// infoset's row (walker) or the bits of sigma / q of the sampled edge (opponent).
+__device__ __forceinline__ uint32_t nl_expand_item(const NlParams& p, const NlTable& t, const NlNodes& nd, uint32_t node, uint32_t seg,
+                                                   bool pruning, uint32_t* walker_count, uint32_t& err, uint32_t& aux) {
+    const uint32_t m = nd.meta[node];
+    if (seg == 2) {  // chance: legal() = [reveal()] -> choices = [Draw] (kicker game.rs:253-260)
+        nd.meta[node] = m | (1u << 2) | (1u << 6);
+        return 1u | (1u << 4);
+    }
+    const uint32_t tree = nd.tree[node];
+    G2 g;
+    nl_load_game(nd, node, g);
+    const uint32_t bk = nd.bucket[node];
+    const uint64_t past = nd.past[node];
+    const int turn = g.actor();
+    const NlView view = nl_view(g);
+    uint64_t chpath;
+    const uint32_t nch = nl_choices_path(view, (int)NL_META_DEPTH(m), &chpath);
+    const uint32_t present = turn == 0 ? (bk & 0xffffu) : (bk >> 16);
+    const uint64_t khash = nl_key_hash(past, chpath, present);  // the table slot and the key of the node's random draws
+    // the row is read from the key's home slot WHILE the key is probed: one memory round trip instead of two whenever the
+    // infoset sits at its home slot and is older than this launch (the usual case); otherwise it is read again
+    float rf[20];
+    nl_load_row(t.rows, (uint32_t)khash & t.mask, seg == 1, rf);
+    bool settled = true;
+    const uint32_t row = nl_row_of(t, past, chpath, present, khash, nch, p.tag, &err, &settled);
+    if (!settled) nl_load_row(t.rows, row, seg == 1, rf);
+    const uint32_t all = (1u << nch) - 1u;
+    uint32_t mask, pick = 0, nkids;
+    float oppfac = 1.0f;
+    if (seg == 0) {
+        // walker: every edge (ExternalSampling) or the pruning scheme's survivors
+        mask = all;
+        if (pruning) {
+            bool prune = true;
+            if (p.sampling == RP_SAMPLING_PLURIBUS)  // profile.rng(node).random::<f32>() < explore (pluribus.rs:89-91)
+                prune = !(nl_draw_coin(p, p.tree_base + tree, khash, past, chpath, present) < p.prune_explore);
+            if (prune) {
+                uint32_t keep = 0;
+#pragma unroll
+                for (uint32_t a = 0; a < NLMC_A; ++a) {
+                    if (a >= nch) continue;
+                    bool k = rf[a] > p.prune_threshold;  // cum_regret: the RAW accumulated regret (book.rs:101-106)
+                    if (!k && p.sampling == RP_SAMPLING_PLURIBUS) {  // never prune an edge into a terminal node (pluribus.rs:96)
+                        G2 c = g;
+                        c.force_act(nl_action_v(view, (uint32_t)(chpath >> (5u * a)) & 31u));
+                        k = c.turn() == NT_TERMINAL;
+                    }
+                    keep |= k ? (1u << a) : 0u;
+                }
+                mask = keep ? keep : all;  // pruning.rs:64, pluribus.rs:99
+            }
+        }
+        nkids = (uint32_t)__popc(mask);
+        const uint32_t ord = atomicAdd(walker_count, 1u);
+        if (ord >= NL_WMAX) err |= NERR_WALKERS;
+        nd.aux[node] = ord | (mask << 16);
+        aux = row;
+    } else {
+        // opponent: weighted (sample/external.rs:41-64) over sampling_distribution (flow.rs:24-42), one draw per
+        // (epoch, infoset, tree)
+        // (registers are what limits this kernel's occupancy: the policy sigma is needed for the sampled edge only, the
+        // cumulative weights are a running sum — no arrays beyond the row itself and the sampling weights)
+        float sw[NLMC_A], rd = 0.0f, wsum_ = 0.0f, z = 0.0f;
+#pragma unroll
+        for (uint32_t a = 0; a < NLMC_A; ++a)
+            if (a < nch) {
+                rd += rp_maxf(rf[a], RP_EPSILON);  // RefProf::regret (profile.rs:31-33), summed in choices() order
+                wsum_ += rp_maxf(rf[NLMC_A + a], RP_EPSILON);
+            }
+        const float denom = wsum_ + p.smoothing;
+#pragma unroll
+        for (uint32_t a = 0; a < NLMC_A; ++a) {
+            sw[a] = 0.0f;
+            if (a < nch) {
+                sw[a] = rp_maxf((rp_maxf(rf[NLMC_A + a], RP_EPSILON) / p.temperature + p.smoothing) / denom, p.curiosity);
+                z += sw[a];
+            }
+        }
+        float total_w = 0.0f;
+#pragma unroll
+        for (uint32_t a = 0; a < NLMC_A; ++a)
+            if (a < nch) total_w += rp_maxf(sw[a] / z, RP_EPSILON);
+        const float u = nl_draw_weight(p, p.tree_base + tree, khash, past, chpath, present, total_w);
+        float swp = sw[0], rgp = rf[0], cum = 0.0f;
+#pragma unroll
+        for (uint32_t a = 0; a + 1 < NLMC_A; ++a) {  // while (pick + 1 < nch && cum[pick] <= u) ++pick
+            if (a < nch) cum += rp_maxf(sw[a] / z, RP_EPSILON);  // cum[a]: the same running sum as total_w
+            if (pick == a && a + 1 < nch && cum <= u) {
+                pick = a + 1;
+                swp = sw[a + 1];
+                rgp = rf[a + 1];
+            }
+        }
+        oppfac = (rp_maxf(rgp, RP_EPSILON) / rd) / (swp / z);  // sigma / q of the sampled edge
+        mask = 1u << pick;
+        nkids = 1;
+        nd.aux[node] = mask << 16;  // k_nl_children reads the child's slot from it, as at a walker node
+        aux = __float_as_uint(oppfac);
+    }
+    nd.row[node] = row;
+    nd.chpath[node] = chpath;
+    nd.meta[node] = m | (nch << 2) | (nkids << 6);
+    return nkids | (mask << 4) | (pick << 13);
+}
+// the children of one expanded node: a contiguous block of node indices from `run`, in slot order; per child its parent and the
+// factor of its edge (walker: sigma of every surviving edge, recomputed from the row with the operations of nl_expand_item;
+// opponent: sigma / q of the sampled edge; chance: 1).  info / aux: what nl_expand_item returned.
+__device__ __forceinline__ void nl_place_children(const NlTable& t, const NlNodes& nd, uint32_t node, uint32_t seg, uint32_t info, uint32_t run,
+                                                  uint32_t aux) {
+    const uint32_t mask = (info >> 4) & 0x1ffu;
+    nd.kid0[node] = run;
+    if (seg == 0) {
+        float rf[12], sg[NLMC_A], rd = 0.0f;
+        nl_load_row(t.rows, aux, false, rf);
+        const uint32_t nch = NL_META_NCH(nd.meta[node]);
+#pragma unroll
+        for (uint32_t a = 0; a < NLMC_A; ++a) {
+            sg[a] = 0.0f;
+            if (a < nch) {
+                sg[a] = rp_maxf(rf[a], RP_EPSILON);
+                rd += sg[a];
+            }
+        }
+#pragma unroll
+        for (uint32_t a = 0; a < NLMC_A; ++a)
+            if ((mask >> a) & 1u) {
+                nd.link[run] = node;
+                nd.fac[run] = sg[a] / rd;  // instant_policy (flow.rs:46-48)
+                run += 1;
+            }
+    } else {
+        nd.link[run] = node;
+        nd.fac[run] = seg == 1 ? __uint_as_float(aux) : 1.0f;
+    }
+}
 template <int MINW, uint32_t BT>  // minimum wavefronts per SIMD the register allocation aims for; threads per workgroup
 __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, NlNodes nd, uint32_t level) {
     constexpr uint32_t R = NL_TILE / BT;           // classification sub-rounds
@@ -241,109 +381,11 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
                 continue;
             }
             const uint32_t node = sorted[j];
-            const uint32_t m = nd.meta[node];
-            if (seg == 2) {  // chance: legal() = [reveal()] -> choices = [Draw] (kicker game.rs:253-260)
-                nd.meta[node] = m | (1u << 2) | (1u << 6);
-                s_info[j] = 1u | (1u << 4);
-                mykids += 1;
-                continue;
-            }
-            const uint32_t tree = nd.tree[node];
-            G2 g;
-            nl_load_game(nd, node, g);
-            const uint32_t bk = nd.bucket[node];
-            const uint64_t past = nd.past[node];
-            const int turn = g.actor();
-            const NlView view = nl_view(g);
-            uint64_t chpath;
-            const uint32_t nch = nl_choices_path(view, (int)NL_META_DEPTH(m), &chpath);
-            const uint32_t present = turn == 0 ? (bk & 0xffffu) : (bk >> 16);
-            const uint64_t khash = nl_key_hash(past, chpath, present);  // the table slot and the key of the node's random draws
-            // the row is read from the key's home slot WHILE the key is probed: one memory round trip instead of two whenever the
-            // infoset sits at its home slot and is older than this launch (the usual case); otherwise it is read again
-            float rf[20];
-            nl_load_row(t.rows, (uint32_t)khash & t.mask, seg == 1, rf);
-            bool settled = true;
-            const uint32_t row = nl_row_of(t, past, chpath, present, khash, nch, p.tag, &err, &settled);
-            if (!settled) nl_load_row(t.rows, row, seg == 1, rf);
-            const uint32_t all = (1u << nch) - 1u;
-            uint32_t mask, pick = 0, nkids;
-            float oppfac = 1.0f;
-            if (seg == 0) {
-                // walker: every edge (ExternalSampling) or the pruning scheme's survivors
-                mask = all;
-                if (pruning) {
-                    bool prune = true;
-                    if (p.sampling == RP_SAMPLING_PLURIBUS)  // profile.rng(node).random::<f32>() < explore (pluribus.rs:89-91)
-                        prune = !(nl_draw_coin(p, p.tree_base + tree, khash, past, chpath, present) < p.prune_explore);
-                    if (prune) {
-                        uint32_t keep = 0;
-#pragma unroll
-                        for (uint32_t a = 0; a < NLMC_A; ++a) {
-                            if (a >= nch) continue;
-                            bool k = rf[a] > p.prune_threshold;  // cum_regret: the RAW accumulated regret (book.rs:101-106)
-                            if (!k && p.sampling == RP_SAMPLING_PLURIBUS) {  // never prune an edge into a terminal node (pluribus.rs:96)
-                                G2 c = g;
-                                c.force_act(nl_action_v(view, (uint32_t)(chpath >> (5u * a)) & 31u));
-                                k = c.turn() == NT_TERMINAL;
-                            }
-                            keep |= k ? (1u << a) : 0u;
-                        }
-                        mask = keep ? keep : all;  // pruning.rs:64, pluribus.rs:99
-                    }
-                }
-                nkids = (uint32_t)__popc(mask);
-                const uint32_t ord = atomicAdd(&nd.t_nw[tree], 1u);
-                if (ord >= NL_WMAX) err |= NERR_WALKERS;
-                nd.aux[node] = ord | (mask << 16);
-                s_aux[j] = row;
-            } else {
-                // opponent: weighted (sample/external.rs:41-64) over sampling_distribution (flow.rs:24-42), one draw per
-                // (epoch, infoset, tree)
-                // (registers are what limits this kernel's occupancy: the policy sigma is needed for the sampled edge only, the
-                // cumulative weights are a running sum — no arrays beyond the row itself and the sampling weights)
-                float sw[NLMC_A], rd = 0.0f, wsum_ = 0.0f, z = 0.0f;
-#pragma unroll
-                for (uint32_t a = 0; a < NLMC_A; ++a)
-                    if (a < nch) {
-                        rd += rp_maxf(rf[a], RP_EPSILON);  // RefProf::regret (profile.rs:31-33), summed in choices() order
-                        wsum_ += rp_maxf(rf[NLMC_A + a], RP_EPSILON);
-                    }
-                const float denom = wsum_ + p.smoothing;
-#pragma unroll
-                for (uint32_t a = 0; a < NLMC_A; ++a) {
-                    sw[a] = 0.0f;
-                    if (a < nch) {
-                        sw[a] = rp_maxf((rp_maxf(rf[NLMC_A + a], RP_EPSILON) / p.temperature + p.smoothing) / denom, p.curiosity);
-                        z += sw[a];
-                    }
-                }
-                float total_w = 0.0f;
-#pragma unroll
-                for (uint32_t a = 0; a < NLMC_A; ++a)
-                    if (a < nch) total_w += rp_maxf(sw[a] / z, RP_EPSILON);
-                const float u = nl_draw_weight(p, p.tree_base + tree, khash, past, chpath, present, total_w);
-                float swp = sw[0], rgp = rf[0], cum = 0.0f;
-#pragma unroll
-                for (uint32_t a = 0; a + 1 < NLMC_A; ++a) {  // while (pick + 1 < nch && cum[pick] <= u) ++pick
-                    if (a < nch) cum += rp_maxf(sw[a] / z, RP_EPSILON);  // cum[a]: the same running sum as total_w
-                    if (pick == a && a + 1 < nch && cum <= u) {
-                        pick = a + 1;
-                        swp = sw[a + 1];
-                        rgp = rf[a + 1];
-                    }
-                }
-                oppfac = (rp_maxf(rgp, RP_EPSILON) / rd) / (swp / z);  // sigma / q of the sampled edge
-                mask = 1u << pick;
-                nkids = 1;
-                nd.aux[node] = mask << 16;  // k_nl_children reads the child's slot from it, as at a walker node
-                s_aux[j] = __float_as_uint(oppfac);
-            }
-            nd.row[node] = row;
-            nd.chpath[node] = chpath;
-            nd.meta[node] = m | (nch << 2) | (nkids << 6);
-            s_info[j] = nkids | (mask << 4) | (pick << 13);
-            mykids += nkids;
+            uint32_t aux = 0;
+            const uint32_t info = nl_expand_item(p, t, nd, node, seg, pruning, &nd.t_nw[nd.tree[node]], err, aux);
+            s_info[j] = info;
+            if (seg != 2) s_aux[j] = aux;
+            mykids += info & 15u;
         }
         // ---- 3. one contiguous run of node indices for all children of the tile, in the tile's sorted order (neighbouring
         //         parents get neighbouring child blocks: the next kernels read both): block prefix sum over s_info, ONE cursor bump
@@ -395,37 +437,7 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
             if (j >= total) continue;
             const uint32_t info = s_info[j], nk = info & 15u;
             if (!nk) continue;
-            const uint32_t node = sorted[j], mask = (info >> 4) & 0x1ffu;
-            uint32_t run = blockbase + (info >> 17);
-            nd.kid0[node] = run;
-            if (j < segbase[1]) {  // walker: sigma of every surviving edge, recomputed from the row (the same operations as above)
-                float rf[12], sg[NLMC_A], rd = 0.0f;
-                nl_load_row(t.rows, s_aux[j], false, rf);
-                const uint32_t nch = NL_META_NCH(nd.meta[node]);
-#pragma unroll
-                for (uint32_t a = 0; a < NLMC_A; ++a) {
-                    sg[a] = 0.0f;
-                    if (a < nch) {
-                        sg[a] = rp_maxf(rf[a], RP_EPSILON);
-                        rd += sg[a];
-                    }
-                }
-#pragma unroll
-                for (uint32_t a = 0; a < NLMC_A; ++a)
-                    if ((mask >> a) & 1u) {
-                        nd.link[run] = node;
-                        nd.fac[run] = sg[a] / rd;  // instant_policy (flow.rs:46-48)
-                        run += 1;
-                    }
-            } else if (j < segbase[2]) {
-                nd.link[run] = node;
-                nd.fac[run] = __uint_as_float(s_aux[j]);
-                run += 1;
-            } else {
-                nd.link[run] = node;
-                nd.fac[run] = 1.0f;
-                run += 1;
-            }
+            nl_place_children(t, nd, sorted[j], j < segbase[1] ? 0u : (j < segbase[2] ? 1u : 2u), info, blockbase + (info >> 17), s_aux[j]);
         }
         if (err) atomicOr(&ctl->err, err);
         __syncthreads();  // the LDS arrays are rewritten for the next tile
@@ -525,37 +537,176 @@ __global__ __launch_bounds__(256) void k_nl_children(NlParams p, NlNodes nd, uin
 // ---------------------------------------------------------------------------------------------------------------
 // D(node) = sum over the expanded children, in choices() order, of f(edge) D(child): the factorised form of
 // CfrFlow::recursed_value (flow.rs:182-216), which multiplies the same factors at the leaves; subtree sizes beside it
+__device__ __forceinline__ uint32_t nl_up_node(const NlNodes& nd, uint32_t i) {  // returns the node's subtree size
+    const uint32_t nk = NL_META_NKIDS(nd.meta[i]);
+    uint32_t sz = 1;
+    if (nk) {
+        const uint32_t k0 = nd.kid0[i];
+        float sum = 0.0f;
+        for (uint32_t c = 0; c < nk; ++c) {
+            sum += nd.fac[k0 + c] * nd.val[k0 + c];
+            sz += nd.size[k0 + c];
+        }
+        nd.val[i] = sum;
+    }
+    nd.size[i] = sz;
+    return sz;
+}
 __global__ __launch_bounds__(256) void k_nl_up(NlNodes nd, uint32_t level) {
     const uint32_t lo = nd.ctl->lvl_node[level], hi = nd.ctl->lvl_node[level + 1];
     for (uint32_t i = lo + blockIdx.x * 256u + threadIdx.x; i < hi; i += gridDim.x * 256u) {
-        const uint32_t nk = NL_META_NKIDS(nd.meta[i]);
-        uint32_t sz = 1;
-        if (nk) {
-            const uint32_t k0 = nd.kid0[i];
-            float sum = 0.0f;
-            for (uint32_t c = 0; c < nk; ++c) {
-                sum += nd.fac[k0 + c] * nd.val[k0 + c];
-                sz += nd.size[k0 + c];
-            }
-            nd.val[i] = sum;
-        }
-        nd.size[i] = sz;
+        const uint32_t sz = nl_up_node(nd, i);
         if (level == 0 && sz >= 65536u) atomicOr(&nd.ctl->err, NERR_NODES);  // creation indices are sort keys of 16 bits
     }
 }
 // the reference's creation index: pop-last DFS (builder.rs:141-161) visits the children of a node from the LAST choice to the
 // first, each with its whole subtree
+__device__ __forceinline__ void nl_down_node(const NlNodes& nd, uint32_t i) {
+    const uint32_t nk = NL_META_NKIDS(nd.meta[i]);
+    if (!nk) return;
+    const uint32_t k0 = nd.kid0[i];
+    uint32_t run = nd.dfs[i] + 1u;
+    for (uint32_t c = nk; c-- > 0;) {
+        nd.dfs[k0 + c] = run;
+        run += nd.size[k0 + c];
+    }
+}
 __global__ __launch_bounds__(256) void k_nl_down(NlNodes nd, uint32_t level) {
     const uint32_t lo = nd.ctl->lvl_node[level], hi = nd.ctl->lvl_node[level + 1];
-    for (uint32_t i = lo + blockIdx.x * 256u + threadIdx.x; i < hi; i += gridDim.x * 256u) {
-        const uint32_t nk = NL_META_NKIDS(nd.meta[i]);
-        if (!nk) continue;
-        const uint32_t k0 = nd.kid0[i];
-        uint32_t run = nd.dfs[i] + 1u;
-        for (uint32_t c = nk; c-- > 0;) {
-            nd.dfs[k0 + c] = run;
-            run += nd.size[k0 + c];
+    for (uint32_t i = lo + blockIdx.x * 256u + threadIdx.x; i < hi; i += gridDim.x * 256u) nl_down_node(nd, i);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_nl_tree: ONE TREE PER WORKGROUP — the traversal of a SMALL batch (the reference's own: 128 trees per step,
+// nlhe/src/solver.rs:11) in one launch.  The level-synchronous kernels above pay two launches per tree level and one per sweep
+// level whatever the batch: ~85 launches of 3 - 14 us each for a step whose levels hold a few thousand nodes.  Here a workgroup
+// grows its tree in its own region of the node arrays [tree * C, (tree + 1) * C), level by level, with workgroup barriers where the
+// batch-wide path has kernel boundaries: the same per-node functions (nl_make_root, nl_expand_item, nl_place_children,
+// nl_make_child, nl_up_node, nl_down_node), children of a level allocated in node order from the region's cursor; then both sweeps
+// and the tree's walker list (a fixed region of WC slots per tree: no scan across trees).  Placement differs from the batch-wide
+// path, nothing else does (children contiguous and in slot order, sums over slots, spans over creation indices), so the Decisions
+// are the same bit for bit.  A tree that outgrows its region raises NERR_NODES / NERR_WALKERS and the host repeats the step on the
+// batch-wide path.  ctl: err, n_nodes (sum over trees), pad[0] (deepest tree), the census.
+// ---------------------------------------------------------------------------------------------------------------
+#define NL_TREE_BATCH 2048u  // batches up to this many trees take k_nl_tree
+#define NL_TREE_CAP 8192u  // nodes of a tree's region (observed: <= 2 900 on fresh tables; a blueprint's trees are pruned smaller)
+__global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes nd, uint32_t C, uint32_t WC) {
+    __shared__ uint32_t lvl[NL_MAXL + 2];
+    __shared__ uint32_t s_cursor, s_err, s_nw, s_wsum[4], s_census[5];
+    const uint32_t tree = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t base = tree * C;
+    if (tid == 0) {
+        s_err = nl_make_root(p, nd, tree, base);
+        s_cursor = base + 1u;
+        s_nw = 0;
+        lvl[0] = base;
+        lvl[1] = base + 1u;
+    }
+    if (tid < 5) s_census[tid] = 0;
+    __syncthreads();
+    const bool pruning = p.sampling == RP_SAMPLING_PRUNABLE || (p.sampling == RP_SAMPLING_PLURIBUS && p.epoch >= p.prune_warmup);
+    uint32_t levels = 0, err = 0;
+    for (uint32_t L = 0;; ++L) {
+        const uint32_t lo = lvl[L], hi = lvl[L + 1];
+        if (hi == lo) break;  // an empty level ends the tree
+        levels = L + 1u;
+        if (L + 2u >= NL_MAXL) {  // deeper than the level table (never observed: the rules bound the depth)
+            err |= NERR_LEVELS;
+            break;
         }
+        // ---- encoder.info + branches + sample for the level's nodes, 256 at a time; children in node order from the cursor
+        for (uint32_t c0 = lo; c0 < hi; c0 += 256u) {
+            const uint32_t i = c0 + tid;
+            uint32_t info = 0, aux = 0, seg = 3;
+            if (i < hi) {
+                const uint32_t kind = NL_META_KIND(nd.meta[i]);
+                seg = kind == NK_WALKER ? 0u : (kind == NK_OPP ? 1u : (kind == NK_CHANCE ? 2u : 3u));
+                if (seg < 3u) info = nl_expand_item(p, t, nd, i, seg, pruning, &s_nw, err, aux);
+            }
+            const uint32_t nk = info & 15u;
+            uint32_t incl = nk;
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                if (nl_lane() >= d) incl += up;
+            }
+            if ((tid & 63u) == 63u) s_wsum[wave] = incl;
+            __syncthreads();
+            const uint32_t cur = s_cursor;
+            uint32_t wpre = 0, tot = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; ++w) {
+                const uint32_t v = s_wsum[w];
+                wpre += w < wave ? v : 0u;
+                tot += v;
+            }
+            const bool fits = cur + tot <= base + C;  // workgroup uniform
+            if (!fits) err |= NERR_NODES;
+            if (nk && fits) nl_place_children(t, nd, i, seg, info, cur + wpre + incl - nk, aux);
+            __syncthreads();  // every work-item has read the cursor and the wavefront sums
+            if (tid == 0 && fits) s_cursor = cur + tot;
+            if (!fits) break;
+        }
+        if (err) atomicOr(&s_err, err);
+        __syncthreads();  // the cursor, the children's (parent, factor), the error word
+        if (s_err) break;
+        // ---- NlheGame::apply(edge) for the level's children: the next level's nodes
+        const uint32_t chi = s_cursor;
+        if (tid == 0) lvl[L + 2] = chi;
+        for (uint32_t c = hi + tid; c < chi; c += 256u) err |= nl_make_child(p, nd, c, (int)p.walker);
+        if (err) atomicOr(&s_err, err);
+        __syncthreads();  // the node records and the level table are read by other work-items from here on
+        if (s_err) break;
+    }
+    if (err) atomicOr(&s_err, err);
+    __syncthreads();
+    if (s_err) {
+        if (tid == 0) {
+            atomicOr(&nd.ctl->err, s_err);
+            nd.t_nw[tree] = 0;
+            nd.t_woff[tree] = tree * WC;
+            nd.t_dcount[tree] = 0;
+        }
+        return;
+    }
+    // ---- the sweeps: D(node) and subtree sizes bottom-up, creation indices top-down
+    for (uint32_t l = levels; l-- > 0;) {
+        for (uint32_t i = lvl[l] + tid; i < lvl[l + 1]; i += 256u) {
+            const uint32_t sz = nl_up_node(nd, i);
+            if (l == 0 && sz >= 65536u) atomicOr(&nd.ctl->err, NERR_NODES);
+        }
+        __syncthreads();
+    }
+    for (uint32_t l = 0; l + 1 < levels; ++l) {
+        for (uint32_t i = lvl[l] + tid; i < lvl[l + 1]; i += 256u) nl_down_node(nd, i);
+        __syncthreads();
+    }
+    // ---- the tree's walker nodes by ordinal (k_nl_fill's part), the census
+    const uint32_t end = s_cursor, woff = tree * WC;
+    uint32_t c4[4] = {0, 0, 0, 0}, wk = 0;
+    for (uint32_t i = base + tid; i < end; i += 256u) {
+        const uint32_t m = nd.meta[i], kind = NL_META_KIND(m);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) c4[k] += kind == k ? 1u : 0u;
+        if (kind == NK_WALKER) {
+            wk += NL_META_NKIDS(m);
+            const uint32_t ord = nd.aux[i] & 0xffffu;
+            if (ord < WC) nd.wl[woff + ord] = i;
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (c4[k]) atomicAdd(&s_census[k], c4[k]);
+    if (wk) atomicAdd(&s_census[4], wk);
+    __syncthreads();
+    if (tid < 4 && s_census[tid]) atomicAdd(&nd.ctl->kinds[tid], s_census[tid]);
+    if (tid == 4 && s_census[4]) atomicAdd(&nd.ctl->walker_kids, s_census[4]);
+    if (tid == 0) {
+        nd.t_nw[tree] = s_nw;
+        nd.t_woff[tree] = woff;
+        atomicAdd(&nd.ctl->n_nodes, end - base);
+        atomicMax(&nd.ctl->pad[0], levels);
+        if (s_nw > WC) atomicOr(&nd.ctl->err, NERR_WALKERS);
     }
 }
 
@@ -724,7 +875,8 @@ __global__ __launch_bounds__(64) void k_nl_group_big(NlNodes nd) {
 // numbered tree-major, so the active lanes of a wavefront own a CONTIGUOUS run of Decisions: the [n][9] regret / policy rows are
 // staged in LDS by active rank and stored as whole 64-lane lines instead of 18 stores of stride 36 B.
 __global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t n, uint32_t d_base, uint32_t tree_off, uint32_t out_cap,
-                                                 NlBatch out) {  // d_base / tree_off: this pass' first Decisions slot and first tree of the batch
+                                                 NlBatch out, uint32_t wc) {  // d_base / tree_off: this pass' first Decisions slot and first tree of the batch
+                                                                                // wc != 0: every tree owns wc walker slots (k_nl_tree); unused ones hold nothing
     __shared__ float tile[4][2][64 * NLMC_A];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t padded = (n + 255u) & ~255u;
@@ -732,7 +884,7 @@ __global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t
         bool active = false;
         uint32_t d = 0, tr = 0, off = 0, g = 0;
         if (j < n) {
-            tr = nd.tree[nd.ws[j]];
+            tr = wc ? j / wc : nd.tree[nd.ws[j]];
             off = nd.t_woff[tr];
             g = j - off;
             if (g < nd.t_dcount[tr]) {

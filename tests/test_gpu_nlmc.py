@@ -73,6 +73,32 @@ def test_pruned_sampling_schemes_equal_the_oracle(gpu, sampling):
     assert pruned > 50
 
 
+@pytest.mark.parametrize("sampling,batch", [("external", 128), ("pluribus", 300), ("external", 1)])
+def test_tree_per_workgroup_traversal_equals_the_level_synchronous_one(gpu, monkeypatch, sampling, batch):
+    # a batch of at most 2 048 trees is traversed by k_nl_tree (one tree per workgroup, one launch: the reference's batch of 128);
+    # RP_NLHE_NODE_BUDGET keeps a handle on the level-synchronous kernels.  Node placement differs, nothing else may: every
+    # Decisions field bit for bit over four steps, the counters, the tables
+    a = NlheSolver(cap_log2=18, batch=batch, seed=61, sampling=sampling, hyper=_pruning_hyper())
+    monkeypatch.setenv("RP_NLHE_NODE_BUDGET", "4096")
+    b = NlheSolver(cap_log2=18, batch=batch, seed=61, sampling=sampling, hyper=_pruning_hyper())
+    monkeypatch.delenv("RP_NLHE_NODE_BUDGET")
+    for step in range(4):
+        x, y = a.batch(), b.batch()
+        assert x["n"] == y["n"] and x["n"] > 0
+        for k in ("tree", "past", "present", "choices", "n_actions", "expanded"):
+            assert np.array_equal(x[k], y[k]), k
+        for k in ("regret", "policy", "payoff"):
+            assert np.array_equal(x[k].view(np.uint32), y[k].view(np.uint32)), k
+        a.step("ordered")
+        b.step("ordered")
+        assert a.counters() == b.counters()
+        assert a.last_shape() == b.last_shape()
+    pa, pb = a.export(), b.export()
+    ka = sorted(zip(pa[0].tolist(), pa[1].tolist(), pa[2].tolist()))
+    kb = sorted(zip(pb[0].tolist(), pb[1].tolist(), pb[2].tolist()))
+    assert ka == kb
+
+
 @pytest.mark.parametrize("sampling", ["external", "pluribus"])
 def test_reference_seed_mode_equals_the_oracle(gpu, sampling):
     # rp_nlhe_set_rng(RP_RNG_REFERENCE): the opponent's WeightedIndex draw and Pluribus' coin come from DefaultHasher(t, NlheInfo,
