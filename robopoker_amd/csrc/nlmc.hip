@@ -187,8 +187,6 @@ int nl_traverse_chunk(rp_nlhe* h, uint32_t lo, uint32_t B, uint32_t d_base, uint
         hipLaunchKernelGGL(k_nl_tree, dim3(B), blk, 0, st, prm, h->tab, lv, h->tree_cap, WC);
         nl_clock_end(h, 0);
         nl_clock_begin(h, 3);
-        hipLaunchKernelGGL((k_nl_group<256>), dim3(B), dim3(64), 0, st, lv, B);
-        hipLaunchKernelGGL(k_nl_group_big, dim3(std::min<uint32_t>(B, 1280u)), dim3(64), 0, st, lv);
         HIP_TRY(rp::ss::exclusive_scan<uint32_t>(lv.t_dcount, lv.t_doff, B, h->d_scan, st, h->d_total));
         HIP_TRY(hipGetLastError());
         uint32_t total0 = 0;

@@ -576,6 +576,265 @@ __global__ __launch_bounds__(256) void k_nl_down(NlNodes nd, uint32_t level) {
     for (uint32_t i = lo + blockIdx.x * 256u + threadIdx.x; i < hi; i += gridDim.x * 256u) nl_down_node(nd, i);
 }
 
+
+// exclusive scan of per-tree counts (one workgroup; a batch has at most a few 10^5 trees)
+__global__ __launch_bounds__(1024) void k_nlhe_scan(const uint32_t* dcount, uint32_t batch, uint32_t* offset, uint32_t* total) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x, per = (batch + 1023u) / 1024u;
+    uint32_t s = 0;
+    for (uint32_t i = tid * per; i < min(batch, (tid + 1) * per); ++i) s += dcount[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < 1024; ++i) {
+            const uint32_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    uint32_t run = part[tid];
+    for (uint32_t i = tid * per; i < min(batch, (tid + 1) * per); ++i) {
+        offset[i] = run;
+        run += dcount[i];
+    }
+}
+
+// walker nodes by tree: wl[t_woff[tree] + ordinal]; the batch's node census on the way (one pass over every node's meta)
+__global__ __launch_bounds__(256) void k_nl_fill(NlNodes nd, uint32_t n_nodes) {
+    __shared__ uint32_t census[5];
+    if (threadIdx.x < 5) census[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t c[4] = {0, 0, 0, 0}, wk = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_nodes; i += gridDim.x * 256u) {
+        const uint32_t m = nd.meta[i], kind = NL_META_KIND(m);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) c[k] += kind == k ? 1u : 0u;
+        if (kind == NK_WALKER) {
+            wk += NL_META_NKIDS(m);
+            const uint32_t at = nd.t_woff[nd.tree[i]] + (nd.aux[i] & 0xffffu);
+            if (at < nd.lcap) nd.wl[at] = i;  // more walker nodes than the arrays hold: the host refuses the batch (their total)
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (c[k]) atomicAdd(&census[k], c[k]);
+    if (wk) atomicAdd(&census[4], wk);
+    __syncthreads();
+    if (threadIdx.x < 4 && census[threadIdx.x]) atomicAdd(&nd.ctl->kinds[threadIdx.x], census[threadIdx.x]);
+    if (threadIdx.x == 4 && census[4]) atomicAdd(&nd.ctl->walker_kids, census[4]);
+}
+
+// Tree::partition (tree.rs:88-98) for one tree per wavefront: walker nodes sorted by (row, creation index) -> spans; spans
+// ordered by their first node.
+// the partition of one tree by one wavefront (LDS arrays of capacity CAP >= n)
+// NT work-items (one wavefront in k_nl_group / k_nl_group_big, the whole workgroup of k_nl_tree) — `t` = the work-item's index
+template <uint32_t CAP, uint32_t NT>
+__device__ __forceinline__ void nl_group_tree(const NlNodes& nd, uint32_t tree, uint32_t n, uint32_t t, uint64_t* key, uint32_t* key2,
+                                              uint16_t* hp, uint32_t* sG) {
+    const uint32_t off = nd.t_woff[tree];
+    // wl / ws / gdesc hold lcap entries: a pass with more walker nodes than that is a spent node budget (the host retries it in
+    // more, smaller passes); the whole workgroup leaves together, before the first barrier, and nothing past the arrays is touched
+    if (off + n > nd.lcap) {
+        if (t == 0) {
+            nd.t_dcount[tree] = 0;
+            atomicOr(&nd.ctl->err, NERR_NODES);
+        }
+        return;
+    }
+    uint32_t P = 64;
+    while (P < n) P <<= 1;
+    for (uint32_t i = t; i < P; i += NT) {
+        uint64_t k = ~0ull;
+        if (i < n) {
+            const uint32_t node = nd.wl[off + i];
+            k = ((uint64_t)nd.row[node] << 32) | ((uint64_t)(nd.dfs[node] & 0xffffu) << 16) | (uint64_t)i;
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t tix = t; tix < (P >> 1); tix += NT) {
+                const uint32_t i = ((tix & ~(j - 1u)) << 1) | (tix & (j - 1u)), x = i | j;
+                const uint64_t a = key[i], b = key[x];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    key[i] = b;
+                    key[x] = a;
+                }
+            }
+            __syncthreads();
+        }
+    // span heads in row order (the first wavefront: the running count is a wavefront ballot)
+    if (t < 64u) {
+        uint32_t G = 0;
+        for (uint32_t base = 0; base < P; base += 64) {
+            const uint32_t i = base + t;
+            const bool head = i < n && (i == 0 || (uint32_t)(key[i] >> 32) != (uint32_t)(key[i - 1] >> 32));
+            const unsigned long long m = __ballot(head);
+            if (head) {
+                const uint32_t g = G + nl_rank_in(m);
+                hp[g] = (uint16_t)i;
+                key2[g] = (((uint32_t)(key[i] >> 16) & 0xffffu) << 16) | g;  // first creation index of the span | its rank by row
+            }
+            G += (uint32_t)__popcll(m);
+        }
+        if (t == 0) {
+            hp[G] = (uint16_t)n;
+            *sG = G;
+        }
+    }
+    __syncthreads();
+    const uint32_t G = *sG;
+    uint32_t P2 = 64;
+    while (P2 < G) P2 <<= 1;
+    for (uint32_t i = G + t; i < P2; i += NT) key2[i] = 0xffffffffu;
+    __syncthreads();
+    for (uint32_t k = 2; k <= P2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t tix = t; tix < (P2 >> 1); tix += NT) {
+                const uint32_t i = ((tix & ~(j - 1u)) << 1) | (tix & (j - 1u)), x = i | j;
+                const uint32_t a = key2[i], b = key2[x];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    key2[i] = b;
+                    key2[x] = a;
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = t; i < n; i += NT) nd.ws[off + i] = nd.wl[off + (uint32_t)(key[i] & 0xffffu)];
+    for (uint32_t g = t; g < G; g += NT) {
+        const uint32_t r = key2[g] & 0xffffu;
+        const uint32_t start = hp[r], len = (uint32_t)hp[r + 1] - start;
+        nd.gdesc[off + g] = start | (len << 12);
+    }
+    if (t == 0) nd.t_dcount[tree] = G;
+}
+// every tree of the batch, one per workgroup of one wavefront: trees with at most CAP walker nodes are partitioned here (the
+// usual case: 40 to 110 per tree), the larger ones are put on a list for k_nl_group_big (whose 28 KB of LDS per workgroup would
+// otherwise gate the launch of 262 144 mostly idle workgroups: 0.67 ms per step)
+template <uint32_t CAP>
+__global__ __launch_bounds__(64) void k_nl_group(NlNodes nd, uint32_t batch) {
+    __shared__ uint64_t key[CAP];
+    __shared__ uint32_t key2[CAP];
+    __shared__ uint16_t hp[CAP + 2];
+    __shared__ uint32_t sG;
+    const uint32_t tree = blockIdx.x, lane = threadIdx.x;
+    const uint32_t n = nd.t_nw[tree];
+    if (n == 0 || n > CAP) {
+        if (lane == 0) {
+            if (n == 0 || n > NL_WMAX) nd.t_dcount[tree] = 0;  // nothing to do for an empty tree or one k_nl_expand has flagged
+            else nd.big[atomicAdd(&nd.ctl->n_big, 1u)] = tree;
+        }
+        return;
+    }
+    nl_group_tree<CAP, 64>(nd, tree, n, lane, key, key2, hp, &sG);
+}
+__global__ __launch_bounds__(64) void k_nl_group_big(NlNodes nd) {
+    __shared__ uint64_t key[NL_WMAX];
+    __shared__ uint32_t key2[NL_WMAX];
+    __shared__ uint16_t hp[NL_WMAX + 2];
+    __shared__ uint32_t sG;
+    const uint32_t n_big = nd.ctl->n_big;
+    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const uint32_t tree = nd.big[b];
+        nl_group_tree<NL_WMAX, 64>(nd, tree, nd.t_nw[tree], threadIdx.x, key, key2, hp, &sG);
+        __syncthreads();
+    }
+}
+
+// one Decisions per lane: record_infosets + update_vector (solver.rs:263-305) for one walker infoset of one tree.  Walks the
+// slots of the walker-node array; the first t_dcount[tree] slots of a tree stand for its spans.  Slots and Decisions are both
+// numbered tree-major, so the active lanes of a wavefront own a CONTIGUOUS run of Decisions: the [n][9] regret / policy rows are
+// staged in LDS by active rank and stored as whole 64-lane lines instead of 18 stores of stride 36 B.
+__global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t n, uint32_t d_base, uint32_t tree_off, uint32_t out_cap,
+                                                 NlBatch out, uint32_t wc) {  // d_base / tree_off: this pass' first Decisions slot and first tree of the batch
+                                                                                // wc != 0: every tree owns wc walker slots (k_nl_tree); unused ones hold nothing
+    __shared__ float tile[4][2][64 * NLMC_A];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t padded = (n + 255u) & ~255u;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < padded; j += gridDim.x * 256u) {
+        bool active = false;
+        uint32_t d = 0, tr = 0, off = 0, g = 0;
+        if (j < n) {
+            tr = wc ? j / wc : nd.tree[nd.ws[j]];
+            off = nd.t_woff[tr];
+            g = j - off;
+            if (g < nd.t_dcount[tr]) {
+                d = d_base + nd.t_doff[tr] + g;
+                active = d < out_cap;  // beyond: the host has already refused the batch
+            }
+        }
+        float acc[NLMC_A], pol[NLMC_A];
+        if (active) {
+            const uint32_t desc = nd.gdesc[j], start = desc & 0xfffu, len = desc >> 12;
+            const uint32_t first = nd.ws[off + start];
+            const uint32_t row = nd.row[first], nch = NL_META_NCH(nd.meta[first]);
+            float rf[12], sg[NLMC_A], rd = 0.0f;
+            nl_load_row(t.rows, row, false, rf);
+#pragma unroll
+            for (uint32_t a = 0; a < NLMC_A; ++a) {
+                acc[a] = 0.0f;
+                sg[a] = 0.0f;
+                if (a < nch) {
+                    sg[a] = rp_maxf(rf[a], RP_EPSILON);
+                    rd += sg[a];
+                }
+            }
+            float pay = 0.0f;
+            uint32_t expanded = 0;
+            for (uint32_t mb = 0; mb < len; ++mb) {  // the span in ascending creation index
+                const uint32_t node = nd.ws[off + start + mb];
+                const uint32_t em = nd.aux[node] >> 16, k0 = nd.kid0[node];
+                const float reach = nd.reach[node];
+                float cfv[NLMC_A], ev = 0.0f;
+#pragma unroll
+                for (uint32_t a = 0; a < NLMC_A; ++a) {
+                    cfv[a] = 0.0f;
+                    if ((em >> a) & 1u) {
+                        cfv[a] = reach * nd.val[k0 + (uint32_t)__popc(em & ((1u << a) - 1u))];
+                        ev += sg[a] / rd * cfv[a];
+                    }
+                }
+                pay += ev;
+#pragma unroll
+                for (uint32_t a = 0; a < NLMC_A; ++a)
+                    if ((em >> a) & 1u) acc[a] += cfv[a] - ev;
+                expanded |= em;
+            }
+#pragma unroll
+            for (uint32_t a = 0; a < NLMC_A; ++a) pol[a] = a < nch ? sg[a] / rd : 0.0f;  // policy_vector = iterated_distribution (flow.rs:118-120)
+            out.row[d] = row;
+            out.nact[d] = (uint8_t)nch;
+            out.expanded[d] = (uint16_t)expanded;
+            out.payoff[d] = pay;
+            out.tree[d] = tr + tree_off;
+        }
+        const unsigned long long am = __ballot(active);
+        if (am) {
+            const uint32_t nact = (uint32_t)__popcll(am), rank = nl_rank_in(am);
+            const uint32_t d0 = (uint32_t)__shfl((int)d, __builtin_ctzll(am));  // Decisions d0 .. d0 + nact - 1, in lane order
+            if (active) {
+#pragma unroll
+                for (uint32_t a = 0; a < NLMC_A; ++a) {
+                    tile[wave][0][rank * NLMC_A + a] = acc[a];
+                    tile[wave][1][rank * NLMC_A + a] = pol[a];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t e = lane; e < nact * NLMC_A; e += 64u) {
+                out.regret[(size_t)d0 * NLMC_A + e] = tile[wave][0][e];
+                out.policy[(size_t)d0 * NLMC_A + e] = tile[wave][1][e];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // k_nl_tree: ONE TREE PER WORKGROUP — the traversal of a SMALL batch (the reference's own: 128 trees per step,
 // nlhe/src/solver.rs:11) in one launch.  The level-synchronous kernels above pay two launches per tree level and one per sweep
@@ -708,254 +967,18 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
         atomicMax(&nd.ctl->pad[0], levels);
         if (s_nw > WC) atomicOr(&nd.ctl->err, NERR_WALKERS);
     }
-}
-
-// exclusive scan of per-tree counts (one workgroup; a batch has at most a few 10^5 trees)
-__global__ __launch_bounds__(1024) void k_nlhe_scan(const uint32_t* dcount, uint32_t batch, uint32_t* offset, uint32_t* total) {
-    __shared__ uint32_t part[1024];
-    const uint32_t tid = threadIdx.x, per = (batch + 1023u) / 1024u;
-    uint32_t s = 0;
-    for (uint32_t i = tid * per; i < min(batch, (tid + 1) * per); ++i) s += dcount[i];
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (uint32_t i = 0; i < 1024; ++i) {
-            const uint32_t v = part[i];
-            part[i] = run;
-            run += v;
-        }
-        *total = run;
-    }
-    __syncthreads();
-    uint32_t run = part[tid];
-    for (uint32_t i = tid * per; i < min(batch, (tid + 1) * per); ++i) {
-        offset[i] = run;
-        run += dcount[i];
-    }
-}
-
-// walker nodes by tree: wl[t_woff[tree] + ordinal]; the batch's node census on the way (one pass over every node's meta)
-__global__ __launch_bounds__(256) void k_nl_fill(NlNodes nd, uint32_t n_nodes) {
-    __shared__ uint32_t census[5];
-    if (threadIdx.x < 5) census[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t c[4] = {0, 0, 0, 0}, wk = 0;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_nodes; i += gridDim.x * 256u) {
-        const uint32_t m = nd.meta[i], kind = NL_META_KIND(m);
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) c[k] += kind == k ? 1u : 0u;
-        if (kind == NK_WALKER) {
-            wk += NL_META_NKIDS(m);
-            const uint32_t at = nd.t_woff[nd.tree[i]] + (nd.aux[i] & 0xffffu);
-            if (at < nd.lcap) nd.wl[at] = i;  // more walker nodes than the arrays hold: the host refuses the batch (their total)
-        }
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < 4; ++k)
-        if (c[k]) atomicAdd(&census[k], c[k]);
-    if (wk) atomicAdd(&census[4], wk);
-    __syncthreads();
-    if (threadIdx.x < 4 && census[threadIdx.x]) atomicAdd(&nd.ctl->kinds[threadIdx.x], census[threadIdx.x]);
-    if (threadIdx.x == 4 && census[4]) atomicAdd(&nd.ctl->walker_kids, census[4]);
-}
-
-// Tree::partition (tree.rs:88-98) for one tree per wavefront: walker nodes sorted by (row, creation index) -> spans; spans
-// ordered by their first node.
-// the partition of one tree by one wavefront (LDS arrays of capacity CAP >= n)
-template <uint32_t CAP>
-__device__ __forceinline__ void nl_group_tree(const NlNodes& nd, uint32_t tree, uint32_t n, uint32_t lane, uint64_t* key, uint32_t* key2,
-                                              uint16_t* hp) {
-    const uint32_t off = nd.t_woff[tree];
-    // wl / ws / gdesc hold lcap entries: a pass with more walker nodes than that is a spent node budget (the host retries it in
-    // more, smaller passes); the whole wavefront leaves together, before the first barrier, and nothing past the arrays is touched
-    if (off + n > nd.lcap) {
-        if (lane == 0) {
-            nd.t_dcount[tree] = 0;
-            atomicOr(&nd.ctl->err, NERR_NODES);
-        }
+    // ---- Tree::partition for this tree (k_nl_group's part; the key arrays overlay nothing: 28 KB of LDS for NL_WMAX walker nodes)
+    __shared__ uint64_t g_key[NL_WMAX];
+    __shared__ uint32_t g_key2[NL_WMAX];
+    __shared__ uint16_t g_hp[NL_WMAX + 2];
+    __shared__ uint32_t g_count;
+    const uint32_t nw = s_nw;  // workgroup uniform (the barrier above)
+    if (nw == 0 || nw > WC) {
+        if (tid == 0) nd.t_dcount[tree] = 0;
         return;
     }
-    uint32_t P = 64;
-    while (P < n) P <<= 1;
-    for (uint32_t i = lane; i < P; i += 64) {
-        uint64_t k = ~0ull;
-        if (i < n) {
-            const uint32_t node = nd.wl[off + i];
-            k = ((uint64_t)nd.row[node] << 32) | ((uint64_t)(nd.dfs[node] & 0xffffu) << 16) | (uint64_t)i;
-        }
-        key[i] = k;
-    }
-    __syncthreads();
-    for (uint32_t k = 2; k <= P; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t tix = lane; tix < (P >> 1); tix += 64) {
-                const uint32_t i = ((tix & ~(j - 1u)) << 1) | (tix & (j - 1u)), x = i | j;
-                const uint64_t a = key[i], b = key[x];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) {
-                    key[i] = b;
-                    key[x] = a;
-                }
-            }
-            __syncthreads();
-        }
-    // span heads in row order
-    uint32_t G = 0;
-    for (uint32_t base = 0; base < P; base += 64) {
-        const uint32_t i = base + lane;
-        const bool head = i < n && (i == 0 || (uint32_t)(key[i] >> 32) != (uint32_t)(key[i - 1] >> 32));
-        const unsigned long long m = __ballot(head);
-        if (head) {
-            const uint32_t g = G + nl_rank_in(m);
-            hp[g] = (uint16_t)i;
-            key2[g] = (((uint32_t)(key[i] >> 16) & 0xffffu) << 16) | g;  // first creation index of the span | its rank by row
-        }
-        G += (uint32_t)__popcll(m);
-    }
-    if (lane == 0) hp[G] = (uint16_t)n;
-    uint32_t P2 = 64;
-    while (P2 < G) P2 <<= 1;
-    for (uint32_t i = G + lane; i < P2; i += 64) key2[i] = 0xffffffffu;
-    __syncthreads();
-    for (uint32_t k = 2; k <= P2; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t tix = lane; tix < (P2 >> 1); tix += 64) {
-                const uint32_t i = ((tix & ~(j - 1u)) << 1) | (tix & (j - 1u)), x = i | j;
-                const uint32_t a = key2[i], b = key2[x];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) {
-                    key2[i] = b;
-                    key2[x] = a;
-                }
-            }
-            __syncthreads();
-        }
-    for (uint32_t i = lane; i < n; i += 64) nd.ws[off + i] = nd.wl[off + (uint32_t)(key[i] & 0xffffu)];
-    for (uint32_t g = lane; g < G; g += 64) {
-        const uint32_t r = key2[g] & 0xffffu;
-        const uint32_t start = hp[r], len = (uint32_t)hp[r + 1] - start;
-        nd.gdesc[off + g] = start | (len << 12);
-    }
-    if (lane == 0) nd.t_dcount[tree] = G;
-}
-// every tree of the batch, one per workgroup of one wavefront: trees with at most CAP walker nodes are partitioned here (the
-// usual case: 40 to 110 per tree), the larger ones are put on a list for k_nl_group_big (whose 28 KB of LDS per workgroup would
-// otherwise gate the launch of 262 144 mostly idle workgroups: 0.67 ms per step)
-template <uint32_t CAP>
-__global__ __launch_bounds__(64) void k_nl_group(NlNodes nd, uint32_t batch) {
-    __shared__ uint64_t key[CAP];
-    __shared__ uint32_t key2[CAP];
-    __shared__ uint16_t hp[CAP + 2];
-    const uint32_t tree = blockIdx.x, lane = threadIdx.x;
-    const uint32_t n = nd.t_nw[tree];
-    if (n == 0 || n > CAP) {
-        if (lane == 0) {
-            if (n == 0 || n > NL_WMAX) nd.t_dcount[tree] = 0;  // nothing to do for an empty tree or one k_nl_expand has flagged
-            else nd.big[atomicAdd(&nd.ctl->n_big, 1u)] = tree;
-        }
-        return;
-    }
-    nl_group_tree<CAP>(nd, tree, n, lane, key, key2, hp);
-}
-__global__ __launch_bounds__(64) void k_nl_group_big(NlNodes nd) {
-    __shared__ uint64_t key[NL_WMAX];
-    __shared__ uint32_t key2[NL_WMAX];
-    __shared__ uint16_t hp[NL_WMAX + 2];
-    const uint32_t n_big = nd.ctl->n_big;
-    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
-        const uint32_t tree = nd.big[b];
-        nl_group_tree<NL_WMAX>(nd, tree, nd.t_nw[tree], threadIdx.x, key, key2, hp);
-        __syncthreads();
-    }
-}
-
-// one Decisions per lane: record_infosets + update_vector (solver.rs:263-305) for one walker infoset of one tree.  Walks the
-// slots of the walker-node array; the first t_dcount[tree] slots of a tree stand for its spans.  Slots and Decisions are both
-// numbered tree-major, so the active lanes of a wavefront own a CONTIGUOUS run of Decisions: the [n][9] regret / policy rows are
-// staged in LDS by active rank and stored as whole 64-lane lines instead of 18 stores of stride 36 B.
-__global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t n, uint32_t d_base, uint32_t tree_off, uint32_t out_cap,
-                                                 NlBatch out, uint32_t wc) {  // d_base / tree_off: this pass' first Decisions slot and first tree of the batch
-                                                                                // wc != 0: every tree owns wc walker slots (k_nl_tree); unused ones hold nothing
-    __shared__ float tile[4][2][64 * NLMC_A];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t padded = (n + 255u) & ~255u;
-    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < padded; j += gridDim.x * 256u) {
-        bool active = false;
-        uint32_t d = 0, tr = 0, off = 0, g = 0;
-        if (j < n) {
-            tr = wc ? j / wc : nd.tree[nd.ws[j]];
-            off = nd.t_woff[tr];
-            g = j - off;
-            if (g < nd.t_dcount[tr]) {
-                d = d_base + nd.t_doff[tr] + g;
-                active = d < out_cap;  // beyond: the host has already refused the batch
-            }
-        }
-        float acc[NLMC_A], pol[NLMC_A];
-        if (active) {
-            const uint32_t desc = nd.gdesc[j], start = desc & 0xfffu, len = desc >> 12;
-            const uint32_t first = nd.ws[off + start];
-            const uint32_t row = nd.row[first], nch = NL_META_NCH(nd.meta[first]);
-            float rf[12], sg[NLMC_A], rd = 0.0f;
-            nl_load_row(t.rows, row, false, rf);
-#pragma unroll
-            for (uint32_t a = 0; a < NLMC_A; ++a) {
-                acc[a] = 0.0f;
-                sg[a] = 0.0f;
-                if (a < nch) {
-                    sg[a] = rp_maxf(rf[a], RP_EPSILON);
-                    rd += sg[a];
-                }
-            }
-            float pay = 0.0f;
-            uint32_t expanded = 0;
-            for (uint32_t mb = 0; mb < len; ++mb) {  // the span in ascending creation index
-                const uint32_t node = nd.ws[off + start + mb];
-                const uint32_t em = nd.aux[node] >> 16, k0 = nd.kid0[node];
-                const float reach = nd.reach[node];
-                float cfv[NLMC_A], ev = 0.0f;
-#pragma unroll
-                for (uint32_t a = 0; a < NLMC_A; ++a) {
-                    cfv[a] = 0.0f;
-                    if ((em >> a) & 1u) {
-                        cfv[a] = reach * nd.val[k0 + (uint32_t)__popc(em & ((1u << a) - 1u))];
-                        ev += sg[a] / rd * cfv[a];
-                    }
-                }
-                pay += ev;
-#pragma unroll
-                for (uint32_t a = 0; a < NLMC_A; ++a)
-                    if ((em >> a) & 1u) acc[a] += cfv[a] - ev;
-                expanded |= em;
-            }
-#pragma unroll
-            for (uint32_t a = 0; a < NLMC_A; ++a) pol[a] = a < nch ? sg[a] / rd : 0.0f;  // policy_vector = iterated_distribution (flow.rs:118-120)
-            out.row[d] = row;
-            out.nact[d] = (uint8_t)nch;
-            out.expanded[d] = (uint16_t)expanded;
-            out.payoff[d] = pay;
-            out.tree[d] = tr + tree_off;
-        }
-        const unsigned long long am = __ballot(active);
-        if (am) {
-            const uint32_t nact = (uint32_t)__popcll(am), rank = nl_rank_in(am);
-            const uint32_t d0 = (uint32_t)__shfl((int)d, __builtin_ctzll(am));  // Decisions d0 .. d0 + nact - 1, in lane order
-            if (active) {
-#pragma unroll
-                for (uint32_t a = 0; a < NLMC_A; ++a) {
-                    tile[wave][0][rank * NLMC_A + a] = acc[a];
-                    tile[wave][1][rank * NLMC_A + a] = pol[a];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t e = lane; e < nact * NLMC_A; e += 64u) {
-                out.regret[(size_t)d0 * NLMC_A + e] = tile[wave][0][e];
-                out.policy[(size_t)d0 * NLMC_A + e] = tile[wave][1][e];
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
+    __syncthreads();  // t_woff[tree] and the walker list are read by other work-items below
+    nl_group_tree<NL_WMAX, 256>(nd, tree, nw, tid, g_key, g_key2, g_hp, &g_count);
 }
 
 }  // namespace rp

@@ -25,10 +25,12 @@ namespace ss {
 
 constexpr uint32_t SCAN_TILE = 1024;        // elements per workgroup (256 threads x 4)
 constexpr uint32_t SCAN_ONE = 64 * 1024;    // at most this many elements: one workgroup, one launch
+constexpr uint32_t ONE_THREADS = 1024;      // ... of this many threads (a thread walks n / 1024 consecutive elements: 15 -> 5 us at 10^4)
 constexpr uint32_t RS_TILE = 2048;          // keys per workgroup and pass
 constexpr uint32_t RS_ROUNDS = RS_TILE / 256;
 
-// exclusive scan of v over the 256 threads of the workgroup, thread order; *total = the sum
+// exclusive scan of v over the threads of the workgroup (whole wavefronts, at most 16: wave_tot holds blockDim.x / 64 words), thread
+// order; *total = the sum
 __device__ __forceinline__ uint64_t block_exscan64(uint64_t v, uint64_t* wave_tot, uint64_t* total) {
     const uint32_t tid = threadIdx.x, ln = tid & 63u;
     uint64_t incl = v;
@@ -39,7 +41,8 @@ __device__ __forceinline__ uint64_t block_exscan64(uint64_t v, uint64_t* wave_to
     if (ln == 63u) wave_tot[tid >> 6] = incl;
     __syncthreads();
     uint64_t base = 0, tot = 0;
-    for (uint32_t w = 0; w < 4u; ++w) {
+    const uint32_t nw = blockDim.x >> 6;
+    for (uint32_t w = 0; w < nw; ++w) {
         const uint64_t c = wave_tot[w];
         if (w < (tid >> 6)) base += c;
         tot += c;
@@ -52,9 +55,9 @@ __device__ __forceinline__ uint64_t block_exscan64(uint64_t v, uint64_t* wave_to
 // ---- scan ----------------------------------------------------------------------------------------------------------
 // one workgroup scans everything: thread t owns the contiguous slice [t * per, (t + 1) * per)
 template <class OUT>
-static __global__ __launch_bounds__(256) void k_scan_one(const uint32_t* in, OUT* out, uint32_t n, OUT* total_out) {
-    __shared__ uint64_t wt[4];
-    const uint32_t per = (n + 255u) / 256u, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+static __global__ __launch_bounds__(1024) void k_scan_one(const uint32_t* in, OUT* out, uint32_t n, OUT* total_out) {
+    __shared__ uint64_t wt[16];
+    const uint32_t per = (n + blockDim.x - 1u) / blockDim.x, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
     uint64_t s = 0;
     for (uint32_t i = lo; i < hi; ++i) s += in[i];
     uint64_t tot;
@@ -146,7 +149,7 @@ template <class OUT>
 inline hipError_t exclusive_scan(const uint32_t* in, OUT* out, uint32_t n, void* scratch, hipStream_t st, OUT* total = nullptr) {
     if (n == 0) return hipSuccess;
     if (n <= SCAN_ONE) {
-        hipLaunchKernelGGL((k_scan_one<OUT>), dim3(1), dim3(256), 0, st, in, out, n, total);
+        hipLaunchKernelGGL((k_scan_one<OUT>), dim3(1), dim3(ONE_THREADS), 0, st, in, out, n, total);
         return hipGetLastError();
     }
     // level 0 tile sums, then the sums are scanned in place (recursively), then the tiles
@@ -379,10 +382,10 @@ static __global__ __launch_bounds__(256) void k_rle_tiles(const uint32_t* keys, 
     if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 255u) *n_runs = run;  // the last thread ends at the number of runs
 }
 // at most SCAN_ONE keys: one workgroup does all of it, counts included, in one launch
-static __global__ __launch_bounds__(256) void k_rle_one(const uint32_t* keys, uint32_t n, uint32_t* uniq, uint32_t* starts, uint32_t* counts,
-                                                        uint32_t* n_runs) {
-    __shared__ uint64_t wt[4];
-    const uint32_t per = (n + 255u) / 256u, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+static __global__ __launch_bounds__(1024) void k_rle_one(const uint32_t* keys, uint32_t n, uint32_t* uniq, uint32_t* starts, uint32_t* counts,
+                                                         uint32_t* n_runs) {
+    __shared__ uint64_t wt[16];
+    const uint32_t per = (n + blockDim.x - 1u) / blockDim.x, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
     uint64_t s = 0;
     for (uint32_t i = lo; i < hi; ++i) s += (i == 0u || keys[i] != keys[i - 1u]) ? 1u : 0u;
     uint64_t tot;
@@ -397,7 +400,7 @@ static __global__ __launch_bounds__(256) void k_rle_one(const uint32_t* keys, ui
     if (!counts) return;
     __syncthreads();  // every start of the workgroup is written
     const uint32_t runs = (uint32_t)tot;
-    for (uint32_t g = threadIdx.x; g < runs; g += 256u) counts[g] = (g + 1u < runs ? starts[g + 1u] : n) - starts[g];
+    for (uint32_t g = threadIdx.x; g < runs; g += blockDim.x) counts[g] = (g + 1u < runs ? starts[g + 1u] : n) - starts[g];
 }
 
 // sorted keys -> uniq[r], starts[r] (= the exclusive scan of counts), counts[r] for r < *n_runs; work = n words of scratch.
@@ -409,7 +412,7 @@ inline hipError_t run_length_encode(const uint32_t* keys, uint32_t n, uint32_t* 
     const dim3 grid((n + 255u) / 256u), block(256);
     const uint32_t tiles = (n + SCAN_TILE - 1u) / SCAN_TILE;
     if (n <= SCAN_ONE) {
-        hipLaunchKernelGGL(k_rle_one, dim3(1), block, 0, st, keys, n, uniq, starts, counts, n_runs);
+        hipLaunchKernelGGL(k_rle_one, dim3(1), dim3(ONE_THREADS), 0, st, keys, n, uniq, starts, counts, n_runs);
         return hipGetLastError();
     }
     if (tiles <= SCAN_ONE) {

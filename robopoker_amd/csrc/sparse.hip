@@ -421,10 +421,10 @@ __global__ __launch_bounds__(256) void k_blk_tiles(const uint32_t* nblk, const u
         run += v[k];
     }
 }
-__global__ __launch_bounds__(256) void k_blk_one(const uint32_t* starts, const uint32_t* n_segs, uint32_t n, uint32_t* counts, uint32_t* nblk,
-                                                 uint32_t* boff, uint32_t* blkseg, uint32_t* hot_counter) {
-    __shared__ uint64_t wt[4];
-    const uint32_t runs = *n_segs, per = (n + 255u) / 256u, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+__global__ __launch_bounds__(1024) void k_blk_one(const uint32_t* starts, const uint32_t* n_segs, uint32_t n, uint32_t* counts, uint32_t* nblk,
+                                                  uint32_t* boff, uint32_t* blkseg, uint32_t* hot_counter) {
+    __shared__ uint64_t wt[16];
+    const uint32_t runs = *n_segs, per = (n + blockDim.x - 1u) / blockDim.x, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
     uint64_t s = 0;
     for (uint32_t g = lo; g < hi; ++g) {
         uint32_t cnt;
@@ -905,7 +905,7 @@ static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch
     void* scan_tmp = reinterpret_cast<unsigned char*>(h->sort_tmp) + ss::sort_scratch_bytes(h->cap);
     const uint32_t tiles = (n + ss::SCAN_TILE - 1u) / ss::SCAN_TILE;
     if (n <= ss::SCAN_ONE) {
-        hipLaunchKernelGGL(k_blk_one, dim3(1), dim3(256), 0, h->stream, h->seg_offsets, h->n_segs, n, h->seg_counts, h->nblk, h->boff, h->blkseg,
+        hipLaunchKernelGGL(k_blk_one, dim3(1), dim3(ss::ONE_THREADS), 0, h->stream, h->seg_offsets, h->n_segs, n, h->seg_counts, h->nblk, h->boff, h->blkseg,
                            h->hot + HOT_CAP);
     } else if (tiles <= ss::SCAN_ONE) {
         uint64_t* sums = reinterpret_cast<uint64_t*>(scan_tmp);

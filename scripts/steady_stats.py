@@ -9,7 +9,7 @@ from collections import defaultdict
 path, skip, nsteps, out, title = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-roots = [int(r["Start_Timestamp"]) for r in rows if "k_nl_roots" in r["Kernel_Name"]]
+roots = [int(r["Start_Timestamp"]) for r in rows if "k_nl_roots" in r["Kernel_Name"] or "k_nl_tree" in r["Kernel_Name"]]  # the first launch of a step
 t0, t1 = roots[skip], roots[skip + nsteps] if len(roots) > skip + nsteps else int(rows[-1]["End_Timestamp"]) + 1
 tot, cnt = defaultdict(float), defaultdict(int)
 for r in rows:
