@@ -55,25 +55,12 @@ typedef enum rp_status {
 
 /* human-readable text of the last failure on the calling thread */
 RP_API const char* rp_last_error(void);
+/* Diagnostics — device self tests, HIP-event kernel clocks, traversal shape and census, the MFMA bound's intervals — are declared in
+ * rp_mi355x_diag.h (same library, same conventions): what tests and bench.py call, nothing a drop-in caller needs. */
 /* number of visible HIP devices (0 when there is none); never fails */
 RP_API int rp_device_count(void);
 /* library build info: "rp_mi355x <version> gfx950 hip <ver>" */
 RP_API const char* rp_version(void);
-/* Arithmetic-contract self test: evaluates rp_math.h's primitives ON THE DEVICE for n input pairs so a
- * caller can compare them bit for bit with a host evaluation of the same header.
- * out[0*n..] = rp_expf(x), [1*n..] = rp_logf(|x|), [2*n..] = x / y, [3*n..] = sqrtf(|x|),
- * [4*n..] = fmaf(x, y, x), [5*n..] = (float)(uint32)|x| as u32->f32 conversion of y's bits. */
-RP_API int rp_math_selftest(int device, uint64_t n, const float* x, const float* y, float* out);
-/* Sweeps ALL 2^32 f32 bit patterns on the device and counts where the gfx950 spellings of exp differ from the
- * contract's spec sequence (rp_expf_spec): mismatches[0] rp_expf, [1] rp_exp_floor vs max(spec, MIN_POSITIVE),
- * [2] rp_exp_floor2 (packed), [3] smallest mismatching bit pattern (~0 if none).  All counts must be 0. */
-RP_API int rp_math_exp_sweep(int device, uint64_t* mismatches);
-/* The device-wide primitives under the row-addressed profile and the isomorphism enumeration (csrc/sortscan.hpp: stable LSD
- * radix sort of (key, index) pairs by the low `bits` bits of the key, run-length encoding of the sorted keys, exclusive
- * scan), run on n host keys so a test can compare them with a host sort: sorted_keys / perm [n]; uniq / starts / counts
- * [n] of which the first *n_runs are set; scan[i] = sum of keys[0..i) as u64. */
-RP_API int rp_sortscan_selftest(int device, uint32_t n, uint32_t bits, const uint32_t* keys, uint32_t* sorted_keys, uint32_t* perm,
-                                uint32_t* uniq, uint32_t* starts, uint32_t* counts, uint32_t* n_runs, uint64_t* scan);
 
 /* ======================================================================= mccfr ==
  * crates/mccfr: Solver (solver/solver.rs:38-351), RefProf/MutProf/CfrSampling
@@ -319,10 +306,6 @@ RP_API int rp_comm_destroy(rp_comm* c);
  * rp_mccfr_set_shard(rank, world) itself.  Every rank must pass the same steps / window. */
 RP_API int rp_mccfr_step_comm(rp_mccfr* h, rp_comm* c, uint32_t steps, uint32_t window);
 
-/* ---- profiling hooks used by bench.py (HIP events on the launch stream) ------------------------- */
-RP_API int rp_mccfr_profile(rp_mccfr* h, int enable);
-/* name in {"traverse","compact","update"}; total milliseconds and launch count since profiling was enabled */
-RP_API int rp_mccfr_kernel_time(rp_mccfr* h, const char* name, double* total_ms, uint64_t* launches);
 /* which Solver::batch kernel this handle launches under its current sampling scheme: 0 = per-tree scratch in HBM (any
  * game), 1 = per-lane DFS with the tree in LDS (small games), 2 = instantiated over the game's compile-time action
  * skeleton (Kuhn / Leduc shapes, external sampling; csrc/traverse_static.hpp).  All three produce identical Decisions. */
@@ -379,9 +362,6 @@ RP_API int rp_profile_set_stream(rp_profile* h, void* hip_stream);
 RP_API int rp_profile_entry_bytes(const rp_profile* h, size_t* bytes);
 RP_API int rp_profile_summarize(rp_profile* h, const rp_decisions* batch, void* entries_dev, uint32_t* n_entries);
 RP_API int rp_profile_fold(rp_profile* h, const void* entries_dev, uint32_t n_entries);
-/* name in {"sort","apply"}: HIP-event milliseconds since rp_profile_profile(h, 1) */
-RP_API int rp_profile_profile(rp_profile* h, int enable);
-RP_API int rp_profile_kernel_time(rp_profile* h, const char* name, double* total_ms, uint64_t* launches);
 
 /* ===================================================================== nlhe ==
  * The blueprint trainer's solver: mccfr!(Nlhe, NlheEncoder, NlheTurn, NlheEdge, NlheGame, NlheInfo, 128)
@@ -410,14 +390,6 @@ RP_API int rp_nlhe_set_sampling(rp_nlhe* h, rp_sampling_kind sampling);
  * secret.rs:10-11}) — the three fields of the infoset key this library already carries.  Hole cards and board cards stay on the
  * library's counter hash in both modes: the reference deals them from the unseeded thread RNG (kicker game.rs). */
 RP_API int rp_nlhe_set_rng(rp_nlhe* h, rp_rng_kind kind);
-/* levels grown and nodes created by the last traversed batch (diagnostics of the level-synchronous traversal) */
-RP_API int rp_nlhe_last_shape(rp_nlhe* h, uint32_t* levels, uint32_t* nodes);
-/* profiling hooks used by bench.py (HIP events on the launch stream); name in {"expand","children","sweeps","decide",
- * "apply"}: total milliseconds and launches since profiling was enabled; census: nodes of those steps by kind {terminal,
- * chance, walker, opponent} and the children of their walker nodes (what k_nl_expand's algorithmic bytes are counted from) */
-RP_API int rp_nlhe_profile(rp_nlhe* h, int enable);
-RP_API int rp_nlhe_kernel_time(rp_nlhe* h, const char* name, double* total_ms, uint64_t* launches);
-RP_API int rp_nlhe_census(rp_nlhe* h, uint64_t* kinds4, uint64_t* walker_children);
 /* Solver::step (solver.rs:96-105): the batch's trees, their Decisions, the table update (ordered or composed), epoch += 1 */
 RP_API int rp_nlhe_step(rp_nlhe* h, rp_update_mode mode);
 /* Trainer::train (crates/forge/src/trainer.rs:18-66) over this solver — the loop forge runs on the Flagship type; the contract of
@@ -574,12 +546,7 @@ RP_API int rp_kmeans_prune_stats(rp_kmeans* h, rp_prune_stats* out);
 /* the same with the size of the CALLER's struct: a host compiled against an older (shorter) rp_prune_stats passes its own sizeof
  * and gets the fields it knows; bytes beyond this library's struct are zeroed.  Prefer this one from plain-C hosts. */
 RP_API int rp_kmeans_prune_stats_sized(rp_kmeans* h, void* out, size_t out_bytes);
-/* the divergence intervals of the bound against the current centroids: lo[N*K], hi[N*K] (tests / diagnostics) */
-RP_API int rp_kmeans_bound_intervals(rp_kmeans* h, float* lo, float* hi);
 RP_API int rp_kmeans_set_stream(rp_kmeans* h, void* hip_stream);
-RP_API int rp_kmeans_profile(rp_kmeans* h, int enable);
-/* name in {"pairwise","step","recompute","bounds","neighbor","selfcost","kpp","drift","mfma_bound"} */
-RP_API int rp_kmeans_kernel_time(rp_kmeans* h, const char* name, double* total_ms, uint64_t* launches);
 
 /* ---- multi-GPU: points sharded by rank, integer centroid sums all-reduced ----------
  * step_local(): pairwise + bound refresh on this rank's points, then partial centroid sums into

@@ -1,0 +1,58 @@
+/* rp_mi355x_diag.h — diagnostics of librp_mi355x.so: device self tests of the arithmetic contract and of the sort / scan primitives,
+ * HIP-event kernel clocks, the NLHE traversal's shape and node census, the MFMA Sinkhorn bound's intervals.  Tests and bench.py call
+ * these; a drop-in caller of the hot paths (include/rp_mi355x.h) needs none of them.  Same conventions: int status, rp_last_error(). */
+#ifndef RP_MI355X_DIAG_H
+#define RP_MI355X_DIAG_H
+
+#include "rp_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Arithmetic-contract self test: evaluates rp_math.h's primitives ON THE DEVICE for n input pairs so a
+ * caller can compare them bit for bit with a host evaluation of the same header.
+ * out[0*n..] = rp_expf(x), [1*n..] = rp_logf(|x|), [2*n..] = x / y, [3*n..] = sqrtf(|x|),
+ * [4*n..] = fmaf(x, y, x), [5*n..] = (float)(uint32)|x| as u32->f32 conversion of y's bits. */
+RP_API int rp_math_selftest(int device, uint64_t n, const float* x, const float* y, float* out);
+/* Sweeps ALL 2^32 f32 bit patterns on the device and counts where the gfx950 spellings of exp differ from the
+ * contract's spec sequence (rp_expf_spec): mismatches[0] rp_expf, [1] rp_exp_floor vs max(spec, MIN_POSITIVE),
+ * [2] rp_exp_floor2 (packed), [3] smallest mismatching bit pattern (~0 if none).  All counts must be 0. */
+RP_API int rp_math_exp_sweep(int device, uint64_t* mismatches);
+/* The device-wide primitives under the row-addressed profile and the isomorphism enumeration (csrc/sortscan.hpp: stable LSD
+ * radix sort of (key, index) pairs by the low `bits` bits of the key, run-length encoding of the sorted keys, exclusive
+ * scan), run on n host keys so a test can compare them with a host sort: sorted_keys / perm [n]; uniq / starts / counts
+ * [n] of which the first *n_runs are set; scan[i] = sum of keys[0..i) as u64. */
+RP_API int rp_sortscan_selftest(int device, uint32_t n, uint32_t bits, const uint32_t* keys, uint32_t* sorted_keys, uint32_t* perm,
+                                uint32_t* uniq, uint32_t* starts, uint32_t* counts, uint32_t* n_runs, uint64_t* scan);
+
+/* ---- profiling hooks used by bench.py (HIP events on the launch stream) ------------------------- */
+RP_API int rp_mccfr_profile(rp_mccfr* h, int enable);
+/* name in {"traverse","compact","update"}; total milliseconds and launch count since profiling was enabled */
+RP_API int rp_mccfr_kernel_time(rp_mccfr* h, const char* name, double* total_ms, uint64_t* launches);
+
+/* name in {"sort","apply"}: HIP-event milliseconds since rp_profile_profile(h, 1) */
+RP_API int rp_profile_profile(rp_profile* h, int enable);
+RP_API int rp_profile_kernel_time(rp_profile* h, const char* name, double* total_ms, uint64_t* launches);
+
+/* levels grown and nodes created by the last traversed batch (diagnostics of the level-synchronous traversal) */
+RP_API int rp_nlhe_last_shape(rp_nlhe* h, uint32_t* levels, uint32_t* nodes);
+/* profiling hooks used by bench.py (HIP events on the launch stream); name in {"expand","children","sweeps","decide",
+ * "apply"}: total milliseconds and launches since profiling was enabled; census: nodes of those steps by kind {terminal,
+ * chance, walker, opponent} and the children of their walker nodes (what k_nl_expand's algorithmic bytes are counted from) */
+RP_API int rp_nlhe_profile(rp_nlhe* h, int enable);
+RP_API int rp_nlhe_kernel_time(rp_nlhe* h, const char* name, double* total_ms, uint64_t* launches);
+RP_API int rp_nlhe_census(rp_nlhe* h, uint64_t* kinds4, uint64_t* walker_children);
+
+/* the divergence intervals of the bound against the current centroids: lo[N*K], hi[N*K] (tests / diagnostics) */
+RP_API int rp_kmeans_bound_intervals(rp_kmeans* h, float* lo, float* hi);
+
+RP_API int rp_kmeans_profile(rp_kmeans* h, int enable);
+/* name in {"pairwise","step","recompute","bounds","neighbor","selfcost","kpp","drift","mfma_bound"} */
+RP_API int rp_kmeans_kernel_time(rp_kmeans* h, const char* name, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RP_MI355X_DIAG_H */

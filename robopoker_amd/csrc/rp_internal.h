@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "../../include/rp_mi355x.h"
+#include "../../include/rp_mi355x_diag.h"
 
 #define RP_MAX_ACTIONS 16u   // widest infoset row the device kernels are compiled for (NLHE needs 9..14)
 #define RP_MAX_PLAYERS 8u

@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_in_header():
-    text = open(os.path.join(ROOT, "include", "rp_mi355x.h")).read()
+    # the C ABI and its diagnostics header (self tests, kernel clocks, traversal census): one library
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("rp_mi355x.h", "rp_mi355x_diag.h"))
     return sorted(set(re.findall(r"RP_API\s+[\w\s\*]+?\b(rp_\w+)\s*\(", text)))
 
 
