@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel trace of the reference-batch NLHE step (128 trees): per-step kernel times
+# kernel trace of a small-batch NLHE step (default 128 trees, the reference's batch): per-step kernel times -> gpurun_out/b128/
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/b128
