@@ -461,6 +461,7 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
     t0 = time.perf_counter()
     layer.init_centroids()
     out["kmeanspp_s"] = time.perf_counter() - t0
+    e_kpp = layer.exp_evals() - e0
     d0, _ = layer.stats()
     t0 = time.perf_counter()
     layer.init_bounds()
@@ -512,6 +513,16 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
                                     "note": "bit-reproducible software exp: 106 VALU instructions per 8 softmin terms per lane; achieved = "
                                             "terms / 64 / 8 x 106 / kernel time, i.e. counts only lanes that carry a term (a point fills "
                                             "<= 47 of 64 lanes); peak = one wave64 instruction per 2 cycles per SIMD"}
+        kpp_ms, kpp_n = ms["kpp"]
+        if kpp_ms > 0:  # k-means++ on its own: K rounds of (column-marginal filter, Sinkhorn solves of the survivors against ONE new centroid)
+            ki = e_kpp / 64.0 / 8.0 * SOFTMIN_INSTR_PER_8_TERMS
+            out["roofline_kmeanspp"] = {"bound": "valu", "kernel": "k_kpp_filter + k_kpp_update* (softmin)", "achieved": ki / (kpp_ms * 1e-3),
+                                        "peak": VALU_PEAK_WAVE_INSTR, "unit": "wave-instructions/s",
+                                        "frac": ki / (kpp_ms * 1e-3) / VALU_PEAK_WAVE_INSTR, "exp_terms": e_kpp, "launches": kpp_n,
+                                        "kernel_s": kpp_ms * 1e-3, "wall_s": out["kmeanspp_s"],
+                                        "note": "the same accounting as roofline_sinkhorn, for the k-means++ rounds alone: softmin terms of "
+                                                "the solves the column-marginal bound let through, against the kernels' event time (filter "
+                                                "launches included); K sequential rounds, each against one new sparse centroid"}
         st = layer.prune_stats()
         out["mfma_bound"] = st
         mb_ms, mb_n = ms["mfma_bound"]
