@@ -83,7 +83,7 @@ def parse():
                     help="torch.distributed backend of the rank bookkeeping (unique-id broadcast, max-over-ranks time); nccl = RCCL "
                          "on the GPUs; gloo only for tests/test_emul_bench.py, where the ranks have no GPU")
     ap.add_argument("--prune-warmup", type=int, default=0, help="nlhe: warm-up epochs of the pruned-regime leg")
-    ap.add_argument("--prune-threshold", type=float, default=5.0, help="nlhe: regret threshold of the pruned-regime leg")
+    ap.add_argument("--prune-threshold", type=float, default=-100.0, help="nlhe: regret threshold of the pruned-regime leg")
     ap.add_argument("--prune-explore", type=float, default=0.05, help="nlhe: exploration probability of the pruned-regime leg")
     ap.add_argument("--projection", action="store_true",
                     help="add an 8-GPU strong-scaling PROJECTION (one rank's share timed by a child run, an assumed wire time) "
