@@ -1788,6 +1788,7 @@ __global__ __launch_bounds__(64) void k_kpp_ref_pick(float* pot, float* kpp_d, u
         float mine[KR_CHUNK / 64u];
 #pragma unroll
         for (uint32_t q = 0; q < KR_CHUNK / 64u; ++q) {
+            mine[q] = 0.0f;
 #pragma unroll
             for (uint32_t j = 0; j < 64u; ++j) {
                 run += buf[q * 64u + j];
