@@ -209,7 +209,7 @@ int nl_traverse_chunk(rp_nlhe* h, uint32_t lo, uint32_t B, uint32_t d_base, uint
             if ((uint64_t)d_base + total0 > h->out_cap)
                 return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %llu Decisions in one batch exceed the buffer (%u)", (unsigned long long)d_base + total0, h->out_cap);
             hipLaunchKernelGGL(k_nl_emit, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(h->grid_cap, B * WC / 256u))), blk, 0, st, lv, h->tab, B * WC, d_base, lo,
-                               h->out_cap, h->out, WC);
+                               h->out_cap, h->out, WC, (const float*)lv.wval);
             nl_clock_end(h, 3);
             HIP_TRY(hipGetLastError());
             *n_dec = total0;
@@ -279,7 +279,7 @@ int nl_traverse_chunk(rp_nlhe* h, uint32_t lo, uint32_t B, uint32_t d_base, uint
         *flags = NERR_NODES;
         return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %u walker nodes in one pass exceed the buffer (%u)", total[1], lv.lcap);
     }
-    hipLaunchKernelGGL(k_nl_emit, wide, blk, 0, st, lv, h->tab, total[1], d_base, lo, h->out_cap, h->out, 0u);
+    hipLaunchKernelGGL(k_nl_emit, wide, blk, 0, st, lv, h->tab, total[1], d_base, lo, h->out_cap, h->out, 0u, (const float*)nullptr);
     nl_clock_end(h, 3);
     HIP_TRY(hipGetLastError());
     *n_dec = total[0];
@@ -419,6 +419,11 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
         NL_TRY(nl_alloc(h, &lv.wl, LC)); NL_TRY(nl_alloc(h, &lv.ws, LC)); NL_TRY(nl_alloc(h, &lv.gdesc, LC));
         NL_TRY(nl_alloc(h, &lv.big, B));
         NL_TRY(nl_alloc(h, &lv.ctl, 1));
+        if (tree_mode) {  // k_nl_tree's evaluation in the reference's own order (nlmc_level.hpp)
+            NL_TRY(nl_alloc(h, &lv.fsig, N)); NL_TRY(nl_alloc(h, &lv.fq, N)); NL_TRY(nl_alloc(h, &lv.ex_k, N));
+            NL_TRY(nl_alloc(h, &lv.ex_r, N * NL_EX_K)); NL_TRY(nl_alloc(h, &lv.ex_s, N * NL_EX_K)); NL_TRY(nl_alloc(h, &lv.ex_v, N * NL_EX_K));
+            NL_TRY(nl_alloc(h, &lv.wval, (size_t)batch * NL_WMAX * NLMC_A));
+        }
     }
     h->out_cap = (uint32_t)dec_cap64;
     NL_TRY(nl_alloc(h, &h->out.row, h->out_cap));

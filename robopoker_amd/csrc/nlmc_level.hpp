@@ -46,13 +46,14 @@ namespace rp {
 #define NL_WMAX 2048u      // walker nodes of one tree (observed: <= 455)
 #define NL_LINK_NONE 0xffffffffu
 // link[c] = the parent's node index (the root: NL_LINK_NONE)
-// meta: kind [0,2) | n_choices [2,6) | n_kids [6,10) | depth [10,13) | path length [13,17) | showdown order [17,19)
+// meta: kind [0,2) | n_choices [2,6) | n_kids [6,10) | depth [10,13) | path length [13,17) | showdown order [17,19) | parent kind [19,21)
 #define NL_META_KIND(m) ((m) & 3u)
 #define NL_META_NCH(m) (((m) >> 2) & 15u)
 #define NL_META_NKIDS(m) (((m) >> 6) & 15u)
 #define NL_META_DEPTH(m) (((m) >> 10) & 7u)
 #define NL_META_PLEN(m) (((m) >> 13) & 15u)
 #define NL_META_CMP(m) (((m) >> 17) & 3u)
+#define NL_META_PKIND(m) (((m) >> 19) & 3u)  // the PARENT's kind (the root: 0), so that a walk towards the root needs one load round per step
 
 struct NlCtl {
     uint32_t n_nodes;  // allocation cursor
@@ -78,7 +79,13 @@ struct NlNodes {
     uint32_t* big;  // [batch] trees for k_nl_group_big
     NlCtl* ctl;
     uint32_t ncap, lcap;
+    // k_nl_tree's evaluation in the REFERENCE'S OWN ORDER (NULL on the batch-wide path): per child sigma and q of its edge apart
+    // (fsig, fq); per node and walker ancestor ("chain") the reach products from that ancestor's child down and the value summed
+    // back up (ex_r, ex_s, ex_v: [node][NL_EX_K]; ex_k: chains at the node); per walker node the nine action values (wval)
+    float *fsig, *fq, *ex_r, *ex_s, *ex_v, *wval;
+    uint32_t* ex_k;
 };
+#define NL_EX_K 16u  // walker decision nodes on one root-to-leaf path (observed: <= 9)
 struct NlBatch {  // rp_decisions layout
     uint32_t* row;
     uint8_t* nact;
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256) void k_nl_roots(NlParams p, NlNodes nd) {
 // 2 chance.  walker_count: the tree's counter of walker nodes.  Returns n_kids | expanded mask << 4 | sampled slot << 13; aux = the
 // infoset's row (walker) or the bits of sigma / q of the sampled edge (opponent).
 __device__ __forceinline__ uint32_t nl_expand_item(const NlParams& p, const NlTable& t, const NlNodes& nd, uint32_t node, uint32_t seg,
-                                                   bool pruning, uint32_t* walker_count, uint32_t& err, uint32_t& aux) {
+                                                   bool pruning, uint32_t* walker_count, uint32_t& err, uint32_t& aux, float& osig, float& oq) {
     const uint32_t m = nd.meta[node];
     if (seg == 2) {  // chance: legal() = [reveal()] -> choices = [Draw] (kicker game.rs:253-260)
         nd.meta[node] = m | (1u << 2) | (1u << 6);
@@ -260,7 +267,9 @@ __device__ __forceinline__ uint32_t nl_expand_item(const NlParams& p, const NlTa
                 rgp = rf[a + 1];
             }
         }
-        oppfac = (rp_maxf(rgp, RP_EPSILON) / rd) / (swp / z);  // sigma / q of the sampled edge
+        osig = rp_maxf(rgp, RP_EPSILON) / rd;  // instant_policy of the sampled edge (flow.rs:46-48)
+        oq = swp / z;                          // its sampling probability (flow.rs:33-42)
+        oppfac = osig / oq;                    // sigma / q of the sampled edge
         mask = 1u << pick;
         nkids = 1;
         nd.aux[node] = mask << 16;  // k_nl_children reads the child's slot from it, as at a walker node
@@ -275,7 +284,7 @@ __device__ __forceinline__ uint32_t nl_expand_item(const NlParams& p, const NlTa
 // factor of its edge (walker: sigma of every surviving edge, recomputed from the row with the operations of nl_expand_item;
 // opponent: sigma / q of the sampled edge; chance: 1).  info / aux: what nl_expand_item returned.
 __device__ __forceinline__ void nl_place_children(const NlTable& t, const NlNodes& nd, uint32_t node, uint32_t seg, uint32_t info, uint32_t run,
-                                                  uint32_t aux) {
+                                                  uint32_t aux, float osig = 1.0f, float oq = 1.0f) {
     const uint32_t mask = (info >> 4) & 0x1ffu;
     nd.kid0[node] = run;
     if (seg == 0) {
@@ -295,11 +304,19 @@ __device__ __forceinline__ void nl_place_children(const NlTable& t, const NlNode
             if ((mask >> a) & 1u) {
                 nd.link[run] = node;
                 nd.fac[run] = sg[a] / rd;  // instant_policy (flow.rs:46-48)
+                if (nd.fsig) {
+                    nd.fsig[run] = sg[a] / rd;
+                    nd.fq[run] = 1.0f;
+                }
                 run += 1;
             }
     } else {
         nd.link[run] = node;
         nd.fac[run] = seg == 1 ? __uint_as_float(aux) : 1.0f;
+        if (nd.fsig) {
+            nd.fsig[run] = seg == 1 ? osig : 1.0f;
+            nd.fq[run] = seg == 1 ? oq : 1.0f;
+        }
     }
 }
 template <int MINW, uint32_t BT>  // minimum wavefronts per SIMD the register allocation aims for; threads per workgroup
@@ -382,7 +399,8 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
             }
             const uint32_t node = sorted[j];
             uint32_t aux = 0;
-            const uint32_t info = nl_expand_item(p, t, nd, node, seg, pruning, &nd.t_nw[nd.tree[node]], err, aux);
+            float osig = 1.0f, oq = 1.0f;
+            const uint32_t info = nl_expand_item(p, t, nd, node, seg, pruning, &nd.t_nw[nd.tree[node]], err, aux, osig, oq);
             s_info[j] = info;
             if (seg != 2) s_aux[j] = aux;
             mykids += info & 15u;
@@ -506,14 +524,14 @@ __device__ __forceinline__ uint32_t nl_make_child(const NlParams& p, const NlNod
         const uint32_t strength[2] = {cmp == 1u ? 2u : 1u, cmp == 3u ? 2u : 1u};
         nl_settle_ranked(g, strength, reward);
         nd.val[c] = (float)(walker ? reward[1] - g.spent[1] : reward[0] - g.spent[0]);
-        nd.meta[c] = NK_TERMINAL;
+        nd.meta[c] = NK_TERMINAL | (pkind << 19);
     } else {
         const uint32_t kind = turn == NT_CHANCE ? NK_CHANCE : (turn == walker ? NK_WALKER : NK_OPP);
         nl_store_game(nd, c, g);
         nd.bucket[c] = bucket;
         nd.past[c] = cpast;
         nd.hkey[c] = hk;
-        nd.meta[c] = kind | ((cdepth & 7u) << 10) | ((cplen & 15u) << 13) | (cmp << 17);
+        nd.meta[c] = kind | ((cdepth & 7u) << 10) | ((cplen & 15u) << 13) | (cmp << 17) | (pkind << 19);
         nd.val[c] = 0.0f;
     }
     return err;
@@ -752,7 +770,7 @@ __global__ __launch_bounds__(64) void k_nl_group_big(NlNodes nd) {
 // numbered tree-major, so the active lanes of a wavefront own a CONTIGUOUS run of Decisions: the [n][9] regret / policy rows are
 // staged in LDS by active rank and stored as whole 64-lane lines instead of 18 stores of stride 36 B.
 __global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t n, uint32_t d_base, uint32_t tree_off, uint32_t out_cap,
-                                                 NlBatch out, uint32_t wc) {  // d_base / tree_off: this pass' first Decisions slot and first tree of the batch
+                                                 NlBatch out, uint32_t wc, const float* wval) {  // d_base / tree_off: this pass' first Decisions slot and first tree of the batch
                                                                                 // wc != 0: every tree owns wc walker slots (k_nl_tree); unused ones hold nothing
     __shared__ float tile[4][2][64 * NLMC_A];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -791,12 +809,13 @@ __global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t
                 const uint32_t node = nd.ws[off + start + mb];
                 const uint32_t em = nd.aux[node] >> 16, k0 = nd.kid0[node];
                 const float reach = nd.reach[node];
+                const float* wv = wval ? wval + ((size_t)off + (nd.aux[node] & 0xffffu)) * NLMC_A : nullptr;  // k_nl_tree: reach * recursed_value
                 float cfv[NLMC_A], ev = 0.0f;
 #pragma unroll
                 for (uint32_t a = 0; a < NLMC_A; ++a) {
                     cfv[a] = 0.0f;
                     if ((em >> a) & 1u) {
-                        cfv[a] = reach * nd.val[k0 + (uint32_t)__popc(em & ((1u << a) - 1u))];
+                        cfv[a] = wv ? wv[a] : reach * nd.val[k0 + (uint32_t)__popc(em & ((1u << a) - 1u))];
                         ev += sg[a] / rd * cfv[a];
                     }
                 }
@@ -835,6 +854,108 @@ __global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t
     }
 }
 
+// ---- the values in the REFERENCE'S OWN ORDER (CfrFlow::recursed_value / ancestor_reach, flow.rs:166-216), for k_nl_tree: for every
+// walker decision node j and expanded edge a, reach(j) * recursed_value(kid_a, 1, 1), where recursed_value carries the products
+// rel = ((1 * sigma_1) * sigma_2) ... and smp = ((1 * q_1) * q_2) ... from j's child DOWN to each leaf, values a leaf at
+// rel / smp * payoff and sums children in choices() order.  nl_up_node multiplies the same factors bottom-up (the batch-wide path's
+// form: within 2e-4).  Here every node carries one (rel, smp) pair per walker ancestor ("chain") — extended when the node is made,
+// nl_ex_child — and one value per chain on the way back up, nl_ex_up: the reference's float operations in the reference's order, so
+// the Decisions equal the oracle's bit for bit.
+// (a node's NL_EX_K slots are one 64-byte row: moved as four float4 whatever the number of live chains — the loads of a row are
+// independent of each other, so a node costs one memory round trip, not one per chain; slots past ex_k hold junk nobody reads)
+__device__ __forceinline__ void nl_ex_child(const NlNodes& nd, uint32_t i) {
+    const uint32_t m = nd.meta[i], par = nd.link[i], pk = NL_META_PKIND(m);
+    const float4* pr = reinterpret_cast<const float4*>(nd.ex_r + (size_t)par * NL_EX_K);
+    const float4* ps = reinterpret_cast<const float4*>(nd.ex_s + (size_t)par * NL_EX_K);
+    const uint32_t kp = nd.ex_k[par];
+    const float sg = nd.fsig[i], q = nd.fq[i];  // chance: (1, 1); walker: (sigma, 1); opponent: (sigma, q)
+    float r[NL_EX_K], sm[NL_EX_K];
+#pragma unroll
+    for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) {
+        const float4 a = pr[v], b = ps[v];
+        r[4 * v + 0] = a.x * sg; r[4 * v + 1] = a.y * sg; r[4 * v + 2] = a.z * sg; r[4 * v + 3] = a.w * sg;
+        sm[4 * v + 0] = b.x * q; sm[4 * v + 1] = b.y * q; sm[4 * v + 2] = b.z * q; sm[4 * v + 3] = b.w * q;
+    }
+    uint32_t k = kp;
+    if (pk == NK_WALKER) {  // recursed_value(kid, 1.0, 1.0): the chain of this walker node starts at its children
+        if (kp < NL_EX_K) {
+#pragma unroll
+            for (uint32_t c = 0; c < NL_EX_K; ++c)
+                if (c == kp) {
+                    r[c] = 1.0f;
+                    sm[c] = 1.0f;
+                }
+            k = kp + 1u;
+        } else {
+            atomicOr(&nd.ctl->err, NERR_NODES);  // more walker decisions on one path than chains: the batch-wide path takes the step
+        }
+    }
+    nd.ex_k[i] = k;
+    float4* wr = reinterpret_cast<float4*>(nd.ex_r + (size_t)i * NL_EX_K);
+    float4* ws = reinterpret_cast<float4*>(nd.ex_s + (size_t)i * NL_EX_K);
+    const bool leaf = NL_META_KIND(m) == NK_TERMINAL;
+    if (!leaf) {
+#pragma unroll
+        for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) {
+            wr[v] = make_float4(r[4 * v], r[4 * v + 1], r[4 * v + 2], r[4 * v + 3]);
+            ws[v] = make_float4(sm[4 * v], sm[4 * v + 1], sm[4 * v + 2], sm[4 * v + 3]);
+        }
+    } else {  // terminal_value: rel / smp * payoff per chain
+        const float pay = nd.val[i];
+        float4* wv = reinterpret_cast<float4*>(nd.ex_v + (size_t)i * NL_EX_K);
+#pragma unroll
+        for (uint32_t v = 0; v < NL_EX_K / 4u; ++v)
+            wv[v] = make_float4(r[4 * v] / sm[4 * v] * pay, r[4 * v + 1] / sm[4 * v + 1] * pay, r[4 * v + 2] / sm[4 * v + 2] * pay,
+                                r[4 * v + 3] / sm[4 * v + 3] * pay);
+    }
+}
+__device__ __forceinline__ void nl_ex_up(const NlNodes& nd, uint32_t i) {
+    const uint32_t nk = NL_META_NKIDS(nd.meta[i]);
+    if (!nk) return;
+    const uint32_t k0 = nd.kid0[i];
+    float sum[NL_EX_K];
+#pragma unroll
+    for (uint32_t c = 0; c < NL_EX_K; ++c) sum[c] = 0.0f;
+    for (uint32_t ch = 0; ch < nk; ++ch) {  // children in choices() order; every chain's sum in that order
+        const float4* cv = reinterpret_cast<const float4*>(nd.ex_v + (size_t)(k0 + ch) * NL_EX_K);
+#pragma unroll
+        for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) {
+            const float4 a = cv[v];
+            sum[4 * v] += a.x; sum[4 * v + 1] += a.y; sum[4 * v + 2] += a.z; sum[4 * v + 3] += a.w;
+        }
+    }
+    float4* wv = reinterpret_cast<float4*>(nd.ex_v + (size_t)i * NL_EX_K);
+#pragma unroll
+    for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) wv[v] = make_float4(sum[4 * v], sum[4 * v + 1], sum[4 * v + 2], sum[4 * v + 3]);
+}
+// the nine action values of walker node i: ancestor_reach upward over the opponent's decisions, nearest first, times the chain
+// this node's children start
+__device__ __forceinline__ void nl_ex_walker(const NlNodes& nd, uint32_t i, uint32_t slot0 /* the tree's first walker slot */, uint32_t WC) {
+    float cf = 1.0f, sm = 1.0f;
+    for (uint32_t x = i;;) {
+        const uint32_t par = nd.link[x], mx = nd.meta[x];
+        const float sg = nd.fsig[x], q = nd.fq[x];  // all four loads depend on x only: one round trip per step
+        if (par == NL_LINK_NONE) break;
+        if (NL_META_PKIND(mx) == NK_OPP) {
+            cf = cf * sg;
+            sm = sm * q;
+        }
+        x = par;
+    }
+    const float reach = cf / sm;
+    const uint32_t ord = nd.aux[i] & 0xffffu, em = nd.aux[i] >> 16, k0 = nd.kid0[i], kc = nd.ex_k[i];
+    if (ord >= WC || kc >= NL_EX_K) return;
+    uint32_t rank = 0;
+    for (uint32_t a = 0; a < NLMC_A; ++a) {
+        float v = 0.0f;
+        if ((em >> a) & 1u) {
+            v = reach * nd.ex_v[(size_t)(k0 + rank) * NL_EX_K + kc];
+            rank += 1;
+        }
+        nd.wval[((size_t)slot0 + ord) * NLMC_A + a] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // k_nl_tree: ONE TREE PER WORKGROUP — the traversal of a SMALL batch (the reference's own: 128 trees per step,
 // nlhe/src/solver.rs:11) in one launch.  The level-synchronous kernels above pay two launches per tree level and one per sweep
@@ -856,6 +977,7 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
     const uint32_t base = tree * C;
     if (tid == 0) {
         s_err = nl_make_root(p, nd, tree, base);
+        if (nd.ex_k) nd.ex_k[base] = 0u;
         s_cursor = base + 1u;
         s_nw = 0;
         lvl[0] = base;
@@ -877,10 +999,11 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
         for (uint32_t c0 = lo; c0 < hi; c0 += 256u) {
             const uint32_t i = c0 + tid;
             uint32_t info = 0, aux = 0, seg = 3;
+            float osig = 1.0f, oq = 1.0f;
             if (i < hi) {
                 const uint32_t kind = NL_META_KIND(nd.meta[i]);
                 seg = kind == NK_WALKER ? 0u : (kind == NK_OPP ? 1u : (kind == NK_CHANCE ? 2u : 3u));
-                if (seg < 3u) info = nl_expand_item(p, t, nd, i, seg, pruning, &s_nw, err, aux);
+                if (seg < 3u) info = nl_expand_item(p, t, nd, i, seg, pruning, &s_nw, err, aux, osig, oq);
             }
             const uint32_t nk = info & 15u;
             uint32_t incl = nk;
@@ -901,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
             }
             const bool fits = cur + tot <= base + C;  // workgroup uniform
             if (!fits) err |= NERR_NODES;
-            if (nk && fits) nl_place_children(t, nd, i, seg, info, cur + wpre + incl - nk, aux);
+            if (nk && fits) nl_place_children(t, nd, i, seg, info, cur + wpre + incl - nk, aux, osig, oq);
             __syncthreads();  // every work-item has read the cursor and the wavefront sums
             if (tid == 0 && fits) s_cursor = cur + tot;
             if (!fits) break;
@@ -912,7 +1035,10 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
         // ---- NlheGame::apply(edge) for the level's children: the next level's nodes
         const uint32_t chi = s_cursor;
         if (tid == 0) lvl[L + 2] = chi;
-        for (uint32_t c = hi + tid; c < chi; c += 256u) err |= nl_make_child(p, nd, c, (int)p.walker);
+        for (uint32_t c = hi + tid; c < chi; c += 256u) {
+            err |= nl_make_child(p, nd, c, (int)p.walker);
+            if (nd.ex_k) nl_ex_child(nd, c);  // the parent's chains are a level old: no barrier between the two
+        }
         if (err) atomicOr(&s_err, err);
         __syncthreads();  // the node records and the level table are read by other work-items from here on
         if (s_err) break;
@@ -932,10 +1058,16 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
     for (uint32_t l = levels; l-- > 0;) {
         for (uint32_t i = lvl[l] + tid; i < lvl[l + 1]; i += 256u) {
             const uint32_t sz = nl_up_node(nd, i);
+            if (nd.ex_k) nl_ex_up(nd, i);
             if (l == 0 && sz >= 65536u) atomicOr(&nd.ctl->err, NERR_NODES);
         }
         __syncthreads();
     }
+    if (nd.ex_k)  // every chain value is in place: the walker nodes' action values (read by k_nl_emit, the next launch)
+        for (uint32_t i = base + tid; i < s_cursor; i += 256u) {
+            const uint32_t m = nd.meta[i];
+            if (NL_META_KIND(m) == NK_WALKER && NL_META_NKIDS(m) != 0u) nl_ex_walker(nd, i, tree * WC, WC);
+        }
     for (uint32_t l = 0; l + 1 < levels; ++l) {
         for (uint32_t i = lvl[l] + tid; i < lvl[l + 1]; i += 256u) nl_down_node(nd, i);
         __syncthreads();
