@@ -828,8 +828,9 @@ def nlhe_real(args, rank, world, local_rank):
         "reference_batch_128": {"value": ref["infos"] / ref["dt"], "unit": "infoset-updates/s",
                                 "ms_per_step": ref["dt"] / max(args.steps, 20) * 1e3,
                                 "note": "nlhe/src/solver.rs:11 batch_size = 128: one tree per workgroup, the traversal in one launch "
-                                        "(k_nl_tree, ~0.3 ms: twenty tree levels of dependent work per step) + the sparse table "
-                                        "update's dozen launches; latency bound by construction — a step depends on the previous one"},
+                                        "(k_nl_tree, ~0.4 ms: twenty tree levels of dependent work per step, values in the reference's "
+                                        "own order = bit-exact Decisions) + the sparse table update's dozen launches; latency bound by "
+                                        "construction — a step depends on the previous one"},
     }
     line["config"]["sampling"] = args.sampling
     if not sharded and not os.environ.get("RP_BENCH_NO_REF"):
