@@ -765,9 +765,11 @@ def nlhe_real(args, rank, world, local_rank):
         torch.cuda.set_device(local_rank)
         init_rccl(rank, world, args.dist_backend)
 
-    def run(batch, steps, warmup, profile=False, sampling=None, hyper=None):
+    def run(batch, steps, warmup, profile=False, sampling=None, hyper=None, exact=False):
         s = NlheSolver(cap_log2=args.nlhe_cap, regret="linear", weight="linear", batch=batch, seed=args.seed, device=local_rank,
                        sampling=sampling or args.sampling, hyper=hyper)
+        if exact:
+            s.set_exact(True)
         if sharded:
             from robopoker_amd.parallel import ShardedNlhe
 
@@ -853,6 +855,12 @@ def nlhe_real(args, rank, world, local_rank):
             "prune_explore": args.prune_explore, "nodes_per_tree": pr_run["nodes"] / trees, "infos_per_tree": pr_run["infos"] / trees,
             "trees_per_s": trees / pr_run["dt"],
             "note": "same batch, PluribusSampling past its warm-up with a threshold that bites on a fresh table's default regrets"}
+    if not sharded and not os.environ.get("RP_BENCH_NO_REF") and args.nlhe_batch > 2048:
+        # the same batch with the regret vectors in the reference's own float order on the batch-wide kernels (rp_nlhe_set_exact: bit-exact
+        # Decisions; 192 more bytes per node for the per-ancestor reach rows).  Batches up to 2 048 trees are always evaluated that way
+        ex = run(args.nlhe_batch, max(2, args.steps // 2), 2, exact=True)
+        line["exact_order"] = {"value": ex["infos"] / ex["dt"], "unit": "infoset-updates/s", "ms_per_step": ex["dt"] / max(2, args.steps // 2) * 1e3,
+                               "note": "rp_nlhe_set_exact(1): recursed_value / ancestor_reach in the reference's order (flow.rs:166-216) at this batch"}
     pr = big["prof"]
     if pr:
         c, g, k = pr["census"], pr["groups"], pr["steps"]

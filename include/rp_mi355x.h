@@ -390,6 +390,13 @@ RP_API int rp_nlhe_set_sampling(rp_nlhe* h, rp_sampling_kind sampling);
  * secret.rs:10-11}) — the three fields of the infoset key this library already carries.  Hole cards and board cards stay on the
  * library's counter hash in both modes: the reference deals them from the unseeded thread RNG (kicker game.rs). */
 RP_API int rp_nlhe_set_rng(rp_nlhe* h, rp_rng_kind kind);
+/* The regret vectors' float order.  The reference values a leaf at rel / smp * payoff with the two reach products multiplied from the
+ * walker node's CHILD down, and sums children in choices() order (CfrFlow::recursed_value / ancestor_reach, flow.rs:166-216).  A batch of
+ * at most 2 048 trees (the reference's is 128) is ALWAYS evaluated that way (one tree per workgroup): Decisions and tables equal the
+ * reference's arithmetic bit for bit.  Larger batches default to the factorised form D(node) = sum f(edge) D(child) (the same real
+ * number; regret vectors within rtol 2e-4 / atol 2e-3); rp_nlhe_set_exact(h, 1) makes them carry the per-ancestor reach rows too
+ * (192 B per node on top of 92: 77 GB at 262 144 trees) and equal the reference's order bit for bit as well. */
+RP_API int rp_nlhe_set_exact(rp_nlhe* h, int on);
 /* Solver::step (solver.rs:96-105): the batch's trees, their Decisions, the table update (ordered or composed), epoch += 1 */
 RP_API int rp_nlhe_step(rp_nlhe* h, rp_update_mode mode);
 /* Trainer::train (crates/forge/src/trainer.rs:18-66) over this solver — the loop forge runs on the Flagship type; the contract of

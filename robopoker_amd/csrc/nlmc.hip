@@ -118,6 +118,19 @@ int nl_alloc(rp_nlhe* h, T** out, size_t count) {
     *out = reinterpret_cast<T*>(p);
     return RP_OK;
 }
+// the arrays of the evaluation in the reference's own order (nlmc_level.hpp nl_ex_*): per node sigma and q of its edge, a 64-byte row of
+// chains for each of rel / smp / value, per walker slot its nine action values.  192 B per node on top of the 92.
+int nl_alloc_exact(rp_nlhe* h) {
+    NlNodes& lv = h->lv;
+    if (lv.ex_k) return RP_OK;
+    const size_t N = lv.ncap;
+    int rc;
+    if ((rc = nl_alloc(h, &lv.fsig, N)) || (rc = nl_alloc(h, &lv.fq, N)) || (rc = nl_alloc(h, &lv.ex_r, N * NL_EX_K)) ||
+        (rc = nl_alloc(h, &lv.ex_s, N * NL_EX_K)) || (rc = nl_alloc(h, &lv.ex_v, N * NL_EX_K)) ||
+        (rc = nl_alloc(h, &lv.wval, (size_t)lv.lcap * NLMC_A)))
+        return rc;
+    return nl_alloc(h, &lv.ex_k, N);  // last: the kernels take a non-NULL ex_k as "all of them are there"
+}
 uint32_t nl_next_tag(rp_nlhe* h) {
     h->tag += 1;
     if (h->tag == 0) h->tag = 1;
@@ -279,7 +292,7 @@ int nl_traverse_chunk(rp_nlhe* h, uint32_t lo, uint32_t B, uint32_t d_base, uint
         *flags = NERR_NODES;
         return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %u walker nodes in one pass exceed the buffer (%u)", total[1], lv.lcap);
     }
-    hipLaunchKernelGGL(k_nl_emit, wide, blk, 0, st, lv, h->tab, total[1], d_base, lo, h->out_cap, h->out, 0u, (const float*)nullptr);
+    hipLaunchKernelGGL(k_nl_emit, wide, blk, 0, st, lv, h->tab, total[1], d_base, lo, h->out_cap, h->out, 0u, (const float*)(lv.ex_k ? lv.wval : nullptr));
     nl_clock_end(h, 3);
     HIP_TRY(hipGetLastError());
     *n_dec = total[0];
@@ -419,11 +432,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
         NL_TRY(nl_alloc(h, &lv.wl, LC)); NL_TRY(nl_alloc(h, &lv.ws, LC)); NL_TRY(nl_alloc(h, &lv.gdesc, LC));
         NL_TRY(nl_alloc(h, &lv.big, B));
         NL_TRY(nl_alloc(h, &lv.ctl, 1));
-        if (tree_mode) {  // k_nl_tree's evaluation in the reference's own order (nlmc_level.hpp)
-            NL_TRY(nl_alloc(h, &lv.fsig, N)); NL_TRY(nl_alloc(h, &lv.fq, N)); NL_TRY(nl_alloc(h, &lv.ex_k, N));
-            NL_TRY(nl_alloc(h, &lv.ex_r, N * NL_EX_K)); NL_TRY(nl_alloc(h, &lv.ex_s, N * NL_EX_K)); NL_TRY(nl_alloc(h, &lv.ex_v, N * NL_EX_K));
-            NL_TRY(nl_alloc(h, &lv.wval, (size_t)batch * NL_WMAX * NLMC_A));
-        }
+        if (tree_mode) NL_TRY(nl_alloc_exact(h));  // a small batch is always evaluated in the reference's own order (k_nl_tree)
     }
     h->out_cap = (uint32_t)dec_cap64;
     NL_TRY(nl_alloc(h, &h->out.row, h->out_cap));
@@ -461,6 +470,24 @@ int rp_nlhe_set_rng(rp_nlhe* h, rp_rng_kind kind) {
     if (!h || (kind != RP_RNG_COUNTER && kind != RP_RNG_REFERENCE)) return rp::fail(RP_ERR_INVALID, "rp_nlhe_set_rng: bad argument");
     h->prm.ref_rng = kind == RP_RNG_REFERENCE ? 1u : 0u;
     return RP_OK;
+}
+int rp_nlhe_set_exact(rp_nlhe* h, int on) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_nlhe_set_exact: NULL handle");
+    if (!on) {
+        if (h->tree_cap) return rp::fail(RP_ERR_UNSUPPORTED, "rp_nlhe_set_exact: a batch of at most %u trees is always evaluated in the reference's order", NL_TREE_BATCH);
+        h->lv.ex_k = nullptr;  // the arrays stay allocated (freed with the handle); the kernels look at ex_k only
+        return RP_OK;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(rp::profile_stream(h->prof)));
+    if (h->lv.fsig && !h->lv.ex_k) {  // switched off before: the arrays are still there
+        uint32_t* p = nullptr;
+        int rc = nl_alloc(h, &p, h->lv.ncap);
+        if (rc) return rc;
+        h->lv.ex_k = p;
+        return RP_OK;
+    }
+    return nl_alloc_exact(h);
 }
 int rp_nlhe_last_shape(rp_nlhe* h, uint32_t* levels, uint32_t* nodes) {
     if (!h) return rp::fail(RP_ERR_INVALID, "rp_nlhe_last_shape: NULL handle");

@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void k_nl_roots(NlParams p, NlNodes nd) {
         nd.ctl->lvl_node[1] = p.batch;
     }
     const uint32_t err = tree < p.batch ? nl_make_root(p, nd, tree, tree) : 0u;
+    if (tree < p.batch && nd.ex_k) nd.ex_k[tree] = 0u;
     if (err) atomicOr(&nd.ctl->err, err);
 }
 
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
     __shared__ uint32_t sorted[SCAP];  // node index
     __shared__ uint32_t s_info[SCAP];  // n_kids | expanded mask << 4 | sampled slot << 13   (what the write phase needs)
     __shared__ uint32_t s_aux[SCAP];   // walker items: the infoset's row; opponent items: the bits of sigma / q of the sampled edge
+    __shared__ float s_sig[SCAP], s_q[SCAP];  // opponent items: sigma and q apart (read only when the handle evaluates in the reference's order)
     __shared__ uint32_t wcnt[R][NW][3];  // per sub-round, wavefront, kind: count, then exclusive prefix
     __shared__ uint32_t segbase[3], segcnt[3], wsum[NW], blockbase, tiletotal;
     NlCtl* ctl = nd.ctl;
@@ -403,6 +405,10 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
             const uint32_t info = nl_expand_item(p, t, nd, node, seg, pruning, &nd.t_nw[nd.tree[node]], err, aux, osig, oq);
             s_info[j] = info;
             if (seg != 2) s_aux[j] = aux;
+            if (seg == 1) {
+                s_sig[j] = osig;
+                s_q[j] = oq;
+            }
             mykids += info & 15u;
         }
         // ---- 3. one contiguous run of node indices for all children of the tile, in the tile's sorted order (neighbouring
@@ -455,10 +461,114 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
             if (j >= total) continue;
             const uint32_t info = s_info[j], nk = info & 15u;
             if (!nk) continue;
-            nl_place_children(t, nd, sorted[j], j < segbase[1] ? 0u : (j < segbase[2] ? 1u : 2u), info, blockbase + (info >> 17), s_aux[j]);
+            const uint32_t sg_ = j < segbase[1] ? 0u : (j < segbase[2] ? 1u : 2u);
+            nl_place_children(t, nd, sorted[j], sg_, info, blockbase + (info >> 17), s_aux[j], sg_ == 1u ? s_sig[j] : 1.0f, sg_ == 1u ? s_q[j] : 1.0f);
         }
         if (err) atomicOr(&ctl->err, err);
         __syncthreads();  // the LDS arrays are rewritten for the next tile
+    }
+}
+
+// ---- the values in the REFERENCE'S OWN ORDER (CfrFlow::recursed_value / ancestor_reach, flow.rs:166-216) — k_nl_tree always, the level kernels when
+// the handle asked for it (rp_nlhe_set_exact: the chain rows are 192 B per node on top of the 92) —: for every
+// walker decision node j and expanded edge a, reach(j) * recursed_value(kid_a, 1, 1), where recursed_value carries the products
+// rel = ((1 * sigma_1) * sigma_2) ... and smp = ((1 * q_1) * q_2) ... from j's child DOWN to each leaf, values a leaf at
+// rel / smp * payoff and sums children in choices() order.  nl_up_node multiplies the same factors bottom-up (the batch-wide path's
+// form: within 2e-4).  Here every node carries one (rel, smp) pair per walker ancestor ("chain") — extended when the node is made,
+// nl_ex_child — and one value per chain on the way back up, nl_ex_up: the reference's float operations in the reference's order, so
+// the Decisions equal the oracle's bit for bit.
+// (a node's NL_EX_K slots are one 64-byte row: moved as four float4 whatever the number of live chains — the loads of a row are
+// independent of each other, so a node costs one memory round trip, not one per chain; slots past ex_k hold junk nobody reads)
+__device__ __forceinline__ void nl_ex_child(const NlNodes& nd, uint32_t i) {
+    const uint32_t m = nd.meta[i], par = nd.link[i], pk = NL_META_PKIND(m);
+    const float4* pr = reinterpret_cast<const float4*>(nd.ex_r + (size_t)par * NL_EX_K);
+    const float4* ps = reinterpret_cast<const float4*>(nd.ex_s + (size_t)par * NL_EX_K);
+    const uint32_t kp = nd.ex_k[par];
+    const float sg = nd.fsig[i], q = nd.fq[i];  // chance: (1, 1); walker: (sigma, 1); opponent: (sigma, q)
+    float r[NL_EX_K], sm[NL_EX_K];
+#pragma unroll
+    for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) {
+        const float4 a = pr[v], b = ps[v];
+        r[4 * v + 0] = a.x * sg; r[4 * v + 1] = a.y * sg; r[4 * v + 2] = a.z * sg; r[4 * v + 3] = a.w * sg;
+        sm[4 * v + 0] = b.x * q; sm[4 * v + 1] = b.y * q; sm[4 * v + 2] = b.z * q; sm[4 * v + 3] = b.w * q;
+    }
+    uint32_t k = kp;
+    if (pk == NK_WALKER) {  // recursed_value(kid, 1.0, 1.0): the chain of this walker node starts at its children
+        if (kp < NL_EX_K) {
+#pragma unroll
+            for (uint32_t c = 0; c < NL_EX_K; ++c)
+                if (c == kp) {
+                    r[c] = 1.0f;
+                    sm[c] = 1.0f;
+                }
+            k = kp + 1u;
+        } else {
+            atomicOr(&nd.ctl->err, NERR_NODES);  // more walker decisions on one path than chains: the batch-wide path takes the step
+        }
+    }
+    nd.ex_k[i] = k;
+    float4* wr = reinterpret_cast<float4*>(nd.ex_r + (size_t)i * NL_EX_K);
+    float4* ws = reinterpret_cast<float4*>(nd.ex_s + (size_t)i * NL_EX_K);
+    const bool leaf = NL_META_KIND(m) == NK_TERMINAL;
+    if (!leaf) {
+#pragma unroll
+        for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) {
+            wr[v] = make_float4(r[4 * v], r[4 * v + 1], r[4 * v + 2], r[4 * v + 3]);
+            ws[v] = make_float4(sm[4 * v], sm[4 * v + 1], sm[4 * v + 2], sm[4 * v + 3]);
+        }
+    } else {  // terminal_value: rel / smp * payoff per chain
+        const float pay = nd.val[i];
+        float4* wv = reinterpret_cast<float4*>(nd.ex_v + (size_t)i * NL_EX_K);
+#pragma unroll
+        for (uint32_t v = 0; v < NL_EX_K / 4u; ++v)
+            wv[v] = make_float4(r[4 * v] / sm[4 * v] * pay, r[4 * v + 1] / sm[4 * v + 1] * pay, r[4 * v + 2] / sm[4 * v + 2] * pay,
+                                r[4 * v + 3] / sm[4 * v + 3] * pay);
+    }
+}
+__device__ __forceinline__ void nl_ex_up(const NlNodes& nd, uint32_t i) {
+    const uint32_t nk = NL_META_NKIDS(nd.meta[i]);
+    if (!nk) return;
+    const uint32_t k0 = nd.kid0[i];
+    float sum[NL_EX_K];
+#pragma unroll
+    for (uint32_t c = 0; c < NL_EX_K; ++c) sum[c] = 0.0f;
+    for (uint32_t ch = 0; ch < nk; ++ch) {  // children in choices() order; every chain's sum in that order
+        const float4* cv = reinterpret_cast<const float4*>(nd.ex_v + (size_t)(k0 + ch) * NL_EX_K);
+#pragma unroll
+        for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) {
+            const float4 a = cv[v];
+            sum[4 * v] += a.x; sum[4 * v + 1] += a.y; sum[4 * v + 2] += a.z; sum[4 * v + 3] += a.w;
+        }
+    }
+    float4* wv = reinterpret_cast<float4*>(nd.ex_v + (size_t)i * NL_EX_K);
+#pragma unroll
+    for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) wv[v] = make_float4(sum[4 * v], sum[4 * v + 1], sum[4 * v + 2], sum[4 * v + 3]);
+}
+// the nine action values of walker node i: ancestor_reach upward over the opponent's decisions, nearest first, times the chain
+// this node's children start
+__device__ __forceinline__ void nl_ex_walker(const NlNodes& nd, uint32_t i, uint32_t slot0 /* the tree's first walker slot */, uint32_t WC) {
+    float cf = 1.0f, sm = 1.0f;
+    for (uint32_t x = i;;) {
+        const uint32_t par = nd.link[x], mx = nd.meta[x];
+        const float sg = nd.fsig[x], q = nd.fq[x];  // all four loads depend on x only: one round trip per step
+        if (par == NL_LINK_NONE) break;
+        if (NL_META_PKIND(mx) == NK_OPP) {
+            cf = cf * sg;
+            sm = sm * q;
+        }
+        x = par;
+    }
+    const float reach = cf / sm;
+    const uint32_t ord = nd.aux[i] & 0xffffu, em = nd.aux[i] >> 16, k0 = nd.kid0[i], kc = nd.ex_k[i];
+    if (ord >= WC || kc >= NL_EX_K) return;
+    uint32_t rank = 0;
+    for (uint32_t a = 0; a < NLMC_A; ++a) {
+        float v = 0.0f;
+        if ((em >> a) & 1u) {
+            v = reach * nd.ex_v[(size_t)(k0 + rank) * NL_EX_K + kc];
+            rank += 1;
+        }
+        nd.wval[((size_t)slot0 + ord) * NLMC_A + a] = v;
     }
 }
 
@@ -546,6 +656,7 @@ __global__ __launch_bounds__(256) void k_nl_children(NlParams p, NlNodes nd, uin
     for (uint32_t base = blockIdx.x * 256u; base < total; base += gridDim.x * 256u) {
         const uint32_t c = lo + base + threadIdx.x;
         const uint32_t err = c < hi ? nl_make_child(p, nd, c, walker) : 0u;
+        if (c < hi && nd.ex_k) nl_ex_child(nd, c);  // the parent's chains are a launch old
         if (err) atomicOr(&ctl->err, err);
     }
 }
@@ -574,6 +685,7 @@ __global__ __launch_bounds__(256) void k_nl_up(NlNodes nd, uint32_t level) {
     const uint32_t lo = nd.ctl->lvl_node[level], hi = nd.ctl->lvl_node[level + 1];
     for (uint32_t i = lo + blockIdx.x * 256u + threadIdx.x; i < hi; i += gridDim.x * 256u) {
         const uint32_t sz = nl_up_node(nd, i);
+        if (nd.ex_k) nl_ex_up(nd, i);
         if (level == 0 && sz >= 65536u) atomicOr(&nd.ctl->err, NERR_NODES);  // creation indices are sort keys of 16 bits
     }
 }
@@ -632,8 +744,9 @@ __global__ __launch_bounds__(256) void k_nl_fill(NlNodes nd, uint32_t n_nodes) {
         for (uint32_t k = 0; k < 4; ++k) c[k] += kind == k ? 1u : 0u;
         if (kind == NK_WALKER) {
             wk += NL_META_NKIDS(m);
-            const uint32_t at = nd.t_woff[nd.tree[i]] + (nd.aux[i] & 0xffffu);
+            const uint32_t woff = nd.t_woff[nd.tree[i]], at = woff + (nd.aux[i] & 0xffffu);
             if (at < nd.lcap) nd.wl[at] = i;  // more walker nodes than the arrays hold: the host refuses the batch (their total)
+            if (nd.ex_k && NL_META_NKIDS(m) != 0u && woff < nd.lcap) nl_ex_walker(nd, i, woff, nd.lcap - woff);  // every chain value is in place
         }
     }
 #pragma unroll
@@ -851,108 +964,6 @@ __global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t
             }
             __builtin_amdgcn_wave_barrier();
         }
-    }
-}
-
-// ---- the values in the REFERENCE'S OWN ORDER (CfrFlow::recursed_value / ancestor_reach, flow.rs:166-216), for k_nl_tree: for every
-// walker decision node j and expanded edge a, reach(j) * recursed_value(kid_a, 1, 1), where recursed_value carries the products
-// rel = ((1 * sigma_1) * sigma_2) ... and smp = ((1 * q_1) * q_2) ... from j's child DOWN to each leaf, values a leaf at
-// rel / smp * payoff and sums children in choices() order.  nl_up_node multiplies the same factors bottom-up (the batch-wide path's
-// form: within 2e-4).  Here every node carries one (rel, smp) pair per walker ancestor ("chain") — extended when the node is made,
-// nl_ex_child — and one value per chain on the way back up, nl_ex_up: the reference's float operations in the reference's order, so
-// the Decisions equal the oracle's bit for bit.
-// (a node's NL_EX_K slots are one 64-byte row: moved as four float4 whatever the number of live chains — the loads of a row are
-// independent of each other, so a node costs one memory round trip, not one per chain; slots past ex_k hold junk nobody reads)
-__device__ __forceinline__ void nl_ex_child(const NlNodes& nd, uint32_t i) {
-    const uint32_t m = nd.meta[i], par = nd.link[i], pk = NL_META_PKIND(m);
-    const float4* pr = reinterpret_cast<const float4*>(nd.ex_r + (size_t)par * NL_EX_K);
-    const float4* ps = reinterpret_cast<const float4*>(nd.ex_s + (size_t)par * NL_EX_K);
-    const uint32_t kp = nd.ex_k[par];
-    const float sg = nd.fsig[i], q = nd.fq[i];  // chance: (1, 1); walker: (sigma, 1); opponent: (sigma, q)
-    float r[NL_EX_K], sm[NL_EX_K];
-#pragma unroll
-    for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) {
-        const float4 a = pr[v], b = ps[v];
-        r[4 * v + 0] = a.x * sg; r[4 * v + 1] = a.y * sg; r[4 * v + 2] = a.z * sg; r[4 * v + 3] = a.w * sg;
-        sm[4 * v + 0] = b.x * q; sm[4 * v + 1] = b.y * q; sm[4 * v + 2] = b.z * q; sm[4 * v + 3] = b.w * q;
-    }
-    uint32_t k = kp;
-    if (pk == NK_WALKER) {  // recursed_value(kid, 1.0, 1.0): the chain of this walker node starts at its children
-        if (kp < NL_EX_K) {
-#pragma unroll
-            for (uint32_t c = 0; c < NL_EX_K; ++c)
-                if (c == kp) {
-                    r[c] = 1.0f;
-                    sm[c] = 1.0f;
-                }
-            k = kp + 1u;
-        } else {
-            atomicOr(&nd.ctl->err, NERR_NODES);  // more walker decisions on one path than chains: the batch-wide path takes the step
-        }
-    }
-    nd.ex_k[i] = k;
-    float4* wr = reinterpret_cast<float4*>(nd.ex_r + (size_t)i * NL_EX_K);
-    float4* ws = reinterpret_cast<float4*>(nd.ex_s + (size_t)i * NL_EX_K);
-    const bool leaf = NL_META_KIND(m) == NK_TERMINAL;
-    if (!leaf) {
-#pragma unroll
-        for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) {
-            wr[v] = make_float4(r[4 * v], r[4 * v + 1], r[4 * v + 2], r[4 * v + 3]);
-            ws[v] = make_float4(sm[4 * v], sm[4 * v + 1], sm[4 * v + 2], sm[4 * v + 3]);
-        }
-    } else {  // terminal_value: rel / smp * payoff per chain
-        const float pay = nd.val[i];
-        float4* wv = reinterpret_cast<float4*>(nd.ex_v + (size_t)i * NL_EX_K);
-#pragma unroll
-        for (uint32_t v = 0; v < NL_EX_K / 4u; ++v)
-            wv[v] = make_float4(r[4 * v] / sm[4 * v] * pay, r[4 * v + 1] / sm[4 * v + 1] * pay, r[4 * v + 2] / sm[4 * v + 2] * pay,
-                                r[4 * v + 3] / sm[4 * v + 3] * pay);
-    }
-}
-__device__ __forceinline__ void nl_ex_up(const NlNodes& nd, uint32_t i) {
-    const uint32_t nk = NL_META_NKIDS(nd.meta[i]);
-    if (!nk) return;
-    const uint32_t k0 = nd.kid0[i];
-    float sum[NL_EX_K];
-#pragma unroll
-    for (uint32_t c = 0; c < NL_EX_K; ++c) sum[c] = 0.0f;
-    for (uint32_t ch = 0; ch < nk; ++ch) {  // children in choices() order; every chain's sum in that order
-        const float4* cv = reinterpret_cast<const float4*>(nd.ex_v + (size_t)(k0 + ch) * NL_EX_K);
-#pragma unroll
-        for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) {
-            const float4 a = cv[v];
-            sum[4 * v] += a.x; sum[4 * v + 1] += a.y; sum[4 * v + 2] += a.z; sum[4 * v + 3] += a.w;
-        }
-    }
-    float4* wv = reinterpret_cast<float4*>(nd.ex_v + (size_t)i * NL_EX_K);
-#pragma unroll
-    for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) wv[v] = make_float4(sum[4 * v], sum[4 * v + 1], sum[4 * v + 2], sum[4 * v + 3]);
-}
-// the nine action values of walker node i: ancestor_reach upward over the opponent's decisions, nearest first, times the chain
-// this node's children start
-__device__ __forceinline__ void nl_ex_walker(const NlNodes& nd, uint32_t i, uint32_t slot0 /* the tree's first walker slot */, uint32_t WC) {
-    float cf = 1.0f, sm = 1.0f;
-    for (uint32_t x = i;;) {
-        const uint32_t par = nd.link[x], mx = nd.meta[x];
-        const float sg = nd.fsig[x], q = nd.fq[x];  // all four loads depend on x only: one round trip per step
-        if (par == NL_LINK_NONE) break;
-        if (NL_META_PKIND(mx) == NK_OPP) {
-            cf = cf * sg;
-            sm = sm * q;
-        }
-        x = par;
-    }
-    const float reach = cf / sm;
-    const uint32_t ord = nd.aux[i] & 0xffffu, em = nd.aux[i] >> 16, k0 = nd.kid0[i], kc = nd.ex_k[i];
-    if (ord >= WC || kc >= NL_EX_K) return;
-    uint32_t rank = 0;
-    for (uint32_t a = 0; a < NLMC_A; ++a) {
-        float v = 0.0f;
-        if ((em >> a) & 1u) {
-            v = reach * nd.ex_v[(size_t)(k0 + rank) * NL_EX_K + kc];
-            rank += 1;
-        }
-        nd.wval[((size_t)slot0 + ord) * NLMC_A + a] = v;
     }
 }
 

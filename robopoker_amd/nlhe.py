@@ -47,6 +47,10 @@ class NlheSolver:
         """"counter" (default) or "reference": opponent draws and Pluribus' coin from the reference's DefaultHasher -> SmallRng chain"""
         _lib.check(self._lib.rp_nlhe_set_rng(self._h, _lib.RNG[kind]))
 
+    def set_exact(self, on: bool = True):
+        """regret vectors in the reference's own float order on the batch-wide kernels too (always so up to 2 048 trees per step)"""
+        _lib.check(self._lib.rp_nlhe_set_exact(self._h, 1 if on else 0))
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.rp_nlhe_destroy(self._h)

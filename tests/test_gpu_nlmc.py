@@ -136,6 +136,29 @@ def test_small_batch_decisions_are_bit_exact(gpu, sampling, batch, rng):
         assert de[i][:nact].tobytes() == oe[j][:nact].tobytes(), key
 
 
+@pytest.mark.parametrize("sampling,batch,budget", [("external", 300, "4096"), ("pluribus", 160, "4096"), ("external", 2500, None)])
+def test_exact_order_on_the_level_synchronous_kernels(gpu, monkeypatch, sampling, batch, budget):
+    # rp_nlhe_set_exact(1): the batch-wide kernels carry the per-ancestor reach rows too (nl_ex_child in k_nl_children, nl_ex_up in
+    # k_nl_up, nl_ex_walker in k_nl_fill) and their Decisions equal the oracle's bit for bit as well — forced onto those kernels by a
+    # node budget at small batches, taken by size at 2 500 trees
+    if budget:
+        monkeypatch.setenv("RP_NLHE_NODE_BUDGET", budget)
+    dev = NlheSolver(cap_log2=20, batch=batch, seed=83, sampling=sampling, hyper=_pruning_hyper())
+    if budget:
+        monkeypatch.delenv("RP_NLHE_NODE_BUDGET")
+    dev.set_exact(True)
+    ora = M.OracleNlhe(cap_log2=20, batch=batch, seed=83, sampling=sampling, hyper=_pruning_hyper())
+    for step in range(3 if batch > 1000 else 5):
+        d, o = dev.batch(), ora.batch()
+        assert d["n"] == o["n"] and d["n"] > 0
+        assert np.array_equal(d["n_actions"], o["n_actions"]) and np.array_equal(d["expanded"], o["expanded"])
+        for k in ("policy", "regret", "payoff"):
+            assert np.array_equal(d[k].view(np.uint32), o[k].view(np.uint32)), (step, k)
+        dev.step("ordered")
+        ora.step()
+        assert dev.counters() == ora.counters()
+
+
 @pytest.mark.parametrize("sampling", ["external", "pluribus"])
 def test_reference_seed_mode_equals_the_oracle(gpu, sampling):
     # rp_nlhe_set_rng(RP_RNG_REFERENCE): the opponent's WeightedIndex draw and Pluribus' coin come from DefaultHasher(t, NlheInfo,
@@ -461,7 +484,6 @@ def test_a_batch_traversed_in_several_passes_is_the_same_batch(gpu, monkeypatch)
     # counters; the tables after three steps.
     monkeypatch.setenv("RP_NLHE_NODE_BUDGET", "4096")  # room to spare, on the level-synchronous kernels like the other three (a
     room = NlheSolver(cap_log2=18, batch=300, seed=19)  # default handle of this size would take k_nl_tree, whose values are exact)
-    monkeypatch.delenv("RP_NLHE_NODE_BUDGET")
     monkeypatch.setenv("RP_NLHE_CHUNKS", "3")
     three = NlheSolver(cap_log2=18, batch=300, seed=19)
     monkeypatch.delenv("RP_NLHE_CHUNKS")
