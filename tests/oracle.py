@@ -7,6 +7,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import time
 
 import numpy as np
 
@@ -45,8 +46,17 @@ def load() -> C.CDLL:
         # use the portable build, which travels between machines.  No compiler here = the portable build, said in the sample text
         native = os.path.join(ROOT, "oracle", "_build", "librp_oracle_native.so")
         try:
-            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "native"], stdout=subprocess.DEVNULL,
-                                  stderr=subprocess.DEVNULL)
+            # several rank processes may get here together: each builds into a file of its own and renames it into place (a new inode:
+            # a process that has the previous file mapped keeps it), under a lock so that the builds do not compete for the cores
+            import fcntl
+
+            os.makedirs(os.path.dirname(native), exist_ok=True)
+            mine = f"_build/librp_oracle_native.{os.getpid()}.so"
+            with open(native + ".lock", "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "native", f"NATIVE={mine}"],
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                os.replace(os.path.join(ROOT, "oracle", mine), native)
             path = native
         except (OSError, subprocess.CalledProcessError):
             pass
