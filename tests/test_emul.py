@@ -25,6 +25,13 @@ SELECTION = [
     ("tests/test_gpu_nlmc.py", "(test_first_batch_equals_the_oracle and 64) or test_pruned_sampling_schemes_equal_the_oracle"
                                " or test_ragged_batches_equal_the_oracle or test_a_batch_traversed_in_several_passes"
                                " or test_a_full_infoset_table_fails"),
+    # round 4: reference-seed mode (DefaultHasher -> SmallRng draws in the skeleton and the generic kernels, k-means++'s sequential f32
+    # running sums), the one-tree-per-workgroup NLHE traversal with the values in the reference's order, the same order on the level kernels
+    ("tests/test_gpu_mccfr.py", "(test_reference_seed_tables_bit_exact_vs_oracle and (kuhn or rps)) or test_reference_seed_in_the_generic_traversals"),
+    ("tests/test_gpu_nlmc.py", "(test_small_batch_decisions_are_bit_exact and 33) or (test_exact_order_on_the_level_synchronous_kernels and 160)"
+                               " or (test_tree_per_workgroup_traversal_equals_the_level_synchronous_one and external-1)"
+                               " or (test_reference_seed_mode_equals_the_oracle and external)"),
+    ("tests/test_gpu_lloyd.py", "test_reference_seed_kmeanspp_picks_equal_the_oracle and (1024 or variation-3-5)"),
     # Path B: wave-cooperative Sinkhorn, Elkan iterations with remembered pairwise entries
     ("tests/test_gpu_lloyd.py", "(test_sinkhorn_random_pairs_bit_exact and 32-5-9) or test_sinkhorn_fixture_bit_exact"
                                 " or (test_elkan_iterations_bit_exact and sinkhorn-5-150) or test_equity_variation_bit_exact"),
