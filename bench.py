@@ -47,8 +47,8 @@ def parse():
                          "external-sampling MCCFR over heads-up NLHE generated on the device (rp_nlhe_*, BASELINE configs[3] on "
                          "one GPU); nlhe-synth: synthetic NLHE-scale infoset batches through the sparse profile (SURVEY §8d config 4)")
     ap.add_argument("--nlhe-batch", type=int, default=262144,
-                    help="nlhe: trees per step per GPU (the reference's batch_size is 128; one lane per tree needs >= 131072 "
-                         "trees to put two wavefronts on every SIMD; 68 GB of per-tree scratch at the default)")
+                    help="nlhe: trees per step per GPU (the reference's batch_size is 128: timed beside it; up to 2 048 trees take the "
+                         "one-tree-per-workgroup kernel, larger batches the level-synchronous ones: 37 GB of node arrays at the default)")
     ap.add_argument("--nlhe-cap", type=int, default=27, help="nlhe: log2 of the infoset table's rows")
     ap.add_argument("--rows", type=int, default=1 << 27, help="nlhe-synth: table rows (infoset slots)")
     ap.add_argument("--decisions", type=int, default=128 * 1500, help="nlhe-synth: Decisions per step per GPU")

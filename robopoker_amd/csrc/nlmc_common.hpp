@@ -1,5 +1,5 @@
-// nlmc_common.hpp — what both NLHE traversals (nlmc_level.hpp: level-synchronous, the product path; nlmc.hip's lane-per-tree
-// kernel: the cross-check) share: the NlheInfo -> row table, the draw / bucket / choices helpers, the per-step parameters.
+// nlmc_common.hpp — what the NLHE traversal kernels (nlmc_level.hpp: level-synchronous for large batches, one tree per workgroup for
+// small ones) share: the NlheInfo -> row table, the draw / bucket / choices helpers, the per-step parameters.
 //
 // Reference: nlhe/src/encoder.rs:30-68 (NlheEncoder::info), nlhe/src/info.rs:145-160 (the key), kicker/src/edge.rs:61-72 +
 // bias.rs:47-70 (default regrets), kicker/src/game.rs:513-576,724-753,835-854 (permissions, choices, actionize, snap).

@@ -5,7 +5,7 @@
 // (sample/{external.rs:17-64, pruning.rs:44-66, pluribus.rs:72-101}), Tree::partition (tree.rs:88-98) and CfrFlow::dfs per
 // walker infoset (strategy/flow.rs:64-216).  Oracle: oracle/rp_oracle_nlmc.c.
 //
-// WHY NOT A LANE PER TREE (the first device version, kept in nlmc.hip as a cross-check): a wavefront then runs as long as the
+// WHY NOT A LANE PER TREE (the first device version, round 2; deleted in round 4): a wavefront then runs as long as the
 // largest of its 64 trees and every iteration splits by node kind — 5.3 of 64 lanes did work.  Here the trees of a batch grow
 // together, one level of ALL trees per pair of launches, and every kernel works on nodes of ONE kind:
 //
@@ -30,7 +30,8 @@
 //
 // Node placement (which index a child block gets) depends on timing; nothing else does: a node's children are contiguous and in
 // slot order, sums run over slots, spans over creation indices, draws are hashes of (seed, epoch, tree, path).  The integer
-// state equals the oracle's and the float results equal the lane-per-tree kernel's bit for bit (tests/test_gpu_nlmc.py).
+// state equals the oracle's (tests/test_gpu_nlmc.py); the float results are the factorised evaluation's (within rtol 2e-4 of the
+// oracle) or, with the chain rows (rp_nlhe_set_exact; always in k_nl_tree below), the reference's own order: bit for bit.
 //
 // HBM per node: 44 B of tree structure + 48 B of game state (SoA, coalesced by node index) instead of 260 KB of worst-case
 // scratch per tree: ~92 B x 1 536 nodes per tree of capacity (a batch whose trees outgrow it is traversed in several passes:
