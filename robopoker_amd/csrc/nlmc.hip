@@ -139,7 +139,7 @@ uint32_t nl_next_tag(rp_nlhe* h) {
 int nl_capacity_error(unsigned long long flags) {
     return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: traversal failed (flags %llu: 1 node budget, 2 stack, 4 walker nodes of a tree, 8 decisions, "
                                      "16 illegal action, 32 infoset table full, 64 isomorphism not found in the encoder table, 128 tree deeper "
-                                     "than the level table, 256 work list full)", flags);
+                                     "than the level table, 256 work list full, 512 more than 16 walker decisions on one path with the exact evaluation on)", flags);
 }
 void nl_clock_begin(rp_nlhe* h, int k) {
     if (!h->profiling) return;

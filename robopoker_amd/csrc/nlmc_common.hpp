@@ -21,7 +21,7 @@ typedef NlGameT<2, 2> G2;  // heads-up: two seats at compile time
 enum : uint32_t { NK_TERMINAL = 0, NK_CHANCE = 1, NK_WALKER = 2, NK_OPP = 3 };
 enum : uint32_t {
     NERR_NODES = 1u, NERR_STACK = 2u, NERR_WALKERS = 4u, NERR_DECISIONS = 8u, NERR_ILLEGAL = 16u, NERR_TABLE_FULL = 32u,
-    NERR_LOOKUP = 64u, NERR_LEVELS = 128u, NERR_LISTS = 256u
+    NERR_LOOKUP = 64u, NERR_LEVELS = 128u, NERR_LISTS = 256u, NERR_CHAINS = 512u
 };
 
 // One infoset = one 32-byte slot (a single HBM sector per probe) + one profile row.  `state`: 0 empty, 1 being written,

@@ -86,7 +86,7 @@ struct NlNodes {
     float *fsig, *fq, *ex_r, *ex_s, *ex_v, *wval;
     uint32_t* ex_k;
 };
-#define NL_EX_K 16u  // walker decision nodes on one root-to-leaf path (observed: <= 9)
+#define NL_EX_K 16u  // walker decision nodes on one root-to-leaf path (observed: <= 9; MAX_RAISE_REPEATS = 3 allows about four per street)
 struct NlBatch {  // rp_decisions layout
     uint32_t* row;
     uint8_t* nact;
@@ -504,7 +504,7 @@ __device__ __forceinline__ void nl_ex_child(const NlNodes& nd, uint32_t i) {
                 }
             k = kp + 1u;
         } else {
-            atomicOr(&nd.ctl->err, NERR_NODES);  // more walker decisions on one path than chains: the batch-wide path takes the step
+            atomicOr(&nd.ctl->err, NERR_CHAINS);  // a 17th walker decision on one path (the rules allow ~4 per street): the step fails loudly
         }
     }
     nd.ex_k[i] = k;
