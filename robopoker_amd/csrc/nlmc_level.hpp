@@ -476,12 +476,12 @@ __global__ __launch_bounds__(BT, MINW) void k_nl_expand(NlParams p, NlTable t, N
 // rel = ((1 * sigma_1) * sigma_2) ... and smp = ((1 * q_1) * q_2) ... from j's child DOWN to each leaf, values a leaf at
 // rel / smp * payoff and sums children in choices() order.  nl_up_node multiplies the same factors bottom-up (the batch-wide path's
 // form: within 2e-4).  Here every node carries one (rel, smp) pair per walker ancestor ("chain") — extended when the node is made,
-// nl_ex_child — and one value per chain on the way back up, nl_ex_up: the reference's float operations in the reference's order, so
+// nl_ex_child — and one value per chain on the way back up, nl_ex_up_kids: the reference's float operations in the reference's order, so
 // the Decisions equal the oracle's bit for bit.
 // (a node's NL_EX_K slots are one 64-byte row: moved as four float4 whatever the number of live chains — the loads of a row are
 // independent of each other, so a node costs one memory round trip, not one per chain; slots past ex_k hold junk nobody reads)
-__device__ __forceinline__ void nl_ex_child(const NlNodes& nd, uint32_t i) {
-    const uint32_t m = nd.meta[i], par = nd.link[i], pk = NL_META_PKIND(m);
+// (called by nl_make_child with what it already holds: the parent, its kind, whether the child is a leaf and its payoff)
+__device__ __forceinline__ void nl_ex_child(const NlNodes& nd, uint32_t i, uint32_t par, uint32_t pk, bool leaf, float pay) {
     const float4* pr = reinterpret_cast<const float4*>(nd.ex_r + (size_t)par * NL_EX_K);
     const float4* ps = reinterpret_cast<const float4*>(nd.ex_s + (size_t)par * NL_EX_K);
     const uint32_t kp = nd.ex_k[par];
@@ -510,7 +510,6 @@ __device__ __forceinline__ void nl_ex_child(const NlNodes& nd, uint32_t i) {
     nd.ex_k[i] = k;
     float4* wr = reinterpret_cast<float4*>(nd.ex_r + (size_t)i * NL_EX_K);
     float4* ws = reinterpret_cast<float4*>(nd.ex_s + (size_t)i * NL_EX_K);
-    const bool leaf = NL_META_KIND(m) == NK_TERMINAL;
     if (!leaf) {
 #pragma unroll
         for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) {
@@ -518,7 +517,6 @@ __device__ __forceinline__ void nl_ex_child(const NlNodes& nd, uint32_t i) {
             ws[v] = make_float4(sm[4 * v], sm[4 * v + 1], sm[4 * v + 2], sm[4 * v + 3]);
         }
     } else {  // terminal_value: rel / smp * payoff per chain
-        const float pay = nd.val[i];
         float4* wv = reinterpret_cast<float4*>(nd.ex_v + (size_t)i * NL_EX_K);
 #pragma unroll
         for (uint32_t v = 0; v < NL_EX_K / 4u; ++v)
@@ -526,20 +524,29 @@ __device__ __forceinline__ void nl_ex_child(const NlNodes& nd, uint32_t i) {
                                 r[4 * v + 3] / sm[4 * v + 3] * pay);
     }
 }
-__device__ __forceinline__ void nl_ex_up(const NlNodes& nd, uint32_t i) {
-    const uint32_t nk = NL_META_NKIDS(nd.meta[i]);
-    if (!nk) return;
-    const uint32_t k0 = nd.kid0[i];
+__device__ __forceinline__ void nl_ex_up_kids(const NlNodes& nd, uint32_t i, uint32_t nk, uint32_t k0) {
     float sum[NL_EX_K];
 #pragma unroll
     for (uint32_t c = 0; c < NL_EX_K; ++c) sum[c] = 0.0f;
-    for (uint32_t ch = 0; ch < nk; ++ch) {  // children in choices() order; every chain's sum in that order
-        const float4* cv = reinterpret_cast<const float4*>(nd.ex_v + (size_t)(k0 + ch) * NL_EX_K);
+    // children in choices() order, every chain's sum in that order; three children's rows are in flight at a time (a loop that waits
+    // for each child's row in turn costs a memory round trip per child: up to nine per level)
+    for (uint32_t ch0 = 0; ch0 < nk; ch0 += 3u) {
+        float4 a[3][NL_EX_K / 4u];
 #pragma unroll
-        for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) {
-            const float4 a = cv[v];
-            sum[4 * v] += a.x; sum[4 * v + 1] += a.y; sum[4 * v + 2] += a.z; sum[4 * v + 3] += a.w;
-        }
+        for (uint32_t u = 0; u < 3u; ++u)
+            if (ch0 + u < nk) {
+                const float4* cv = reinterpret_cast<const float4*>(nd.ex_v + (size_t)(k0 + ch0 + u) * NL_EX_K);
+#pragma unroll
+                for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) a[u][v] = cv[v];
+            }
+#pragma unroll
+        for (uint32_t u = 0; u < 3u; ++u)
+            if (ch0 + u < nk) {
+#pragma unroll
+                for (uint32_t v = 0; v < NL_EX_K / 4u; ++v) {
+                    sum[4 * v] += a[u][v].x; sum[4 * v + 1] += a[u][v].y; sum[4 * v + 2] += a[u][v].z; sum[4 * v + 3] += a[u][v].w;
+                }
+            }
     }
     float4* wv = reinterpret_cast<float4*>(nd.ex_v + (size_t)i * NL_EX_K);
 #pragma unroll
@@ -634,8 +641,10 @@ __device__ __forceinline__ uint32_t nl_make_child(const NlParams& p, const NlNod
         int reward[2];
         const uint32_t strength[2] = {cmp == 1u ? 2u : 1u, cmp == 3u ? 2u : 1u};
         nl_settle_ranked(g, strength, reward);
-        nd.val[c] = (float)(walker ? reward[1] - g.spent[1] : reward[0] - g.spent[0]);
+        const float pay = (float)(walker ? reward[1] - g.spent[1] : reward[0] - g.spent[0]);
+        nd.val[c] = pay;
         nd.meta[c] = NK_TERMINAL | (pkind << 19);
+        if (nd.ex_k) nl_ex_child(nd, c, par, pkind, true, pay);
     } else {
         const uint32_t kind = turn == NT_CHANCE ? NK_CHANCE : (turn == walker ? NK_WALKER : NK_OPP);
         nl_store_game(nd, c, g);
@@ -644,6 +653,7 @@ __device__ __forceinline__ uint32_t nl_make_child(const NlParams& p, const NlNod
         nd.hkey[c] = hk;
         nd.meta[c] = kind | ((cdepth & 7u) << 10) | ((cplen & 15u) << 13) | (cmp << 17) | (pkind << 19);
         nd.val[c] = 0.0f;
+        if (nd.ex_k) nl_ex_child(nd, c, par, pkind, false, 0.0f);  // the parent's chains are a launch (a level) old
     }
     return err;
 }
@@ -657,7 +667,6 @@ __global__ __launch_bounds__(256) void k_nl_children(NlParams p, NlNodes nd, uin
     for (uint32_t base = blockIdx.x * 256u; base < total; base += gridDim.x * 256u) {
         const uint32_t c = lo + base + threadIdx.x;
         const uint32_t err = c < hi ? nl_make_child(p, nd, c, walker) : 0u;
-        if (c < hi && nd.ex_k) nl_ex_child(nd, c);  // the parent's chains are a launch old
         if (err) atomicOr(&ctl->err, err);
     }
 }
@@ -667,6 +676,7 @@ __global__ __launch_bounds__(256) void k_nl_children(NlParams p, NlNodes nd, uin
 // ---------------------------------------------------------------------------------------------------------------
 // D(node) = sum over the expanded children, in choices() order, of f(edge) D(child): the factorised form of
 // CfrFlow::recursed_value (flow.rs:182-216), which multiplies the same factors at the leaves; subtree sizes beside it
+__device__ __forceinline__ void nl_ex_up_kids(const NlNodes& nd, uint32_t i, uint32_t nk, uint32_t k0);
 __device__ __forceinline__ uint32_t nl_up_node(const NlNodes& nd, uint32_t i) {  // returns the node's subtree size
     const uint32_t nk = NL_META_NKIDS(nd.meta[i]);
     uint32_t sz = 1;
@@ -677,6 +687,7 @@ __device__ __forceinline__ uint32_t nl_up_node(const NlNodes& nd, uint32_t i) { 
             sum += nd.fac[k0 + c] * nd.val[k0 + c];
             sz += nd.size[k0 + c];
         }
+        if (nd.ex_k) nl_ex_up_kids(nd, i, nk, k0);  // the chains' sums beside it (the reference's order), before any store of this node
         nd.val[i] = sum;
     }
     nd.size[i] = sz;
@@ -686,7 +697,6 @@ __global__ __launch_bounds__(256) void k_nl_up(NlNodes nd, uint32_t level) {
     const uint32_t lo = nd.ctl->lvl_node[level], hi = nd.ctl->lvl_node[level + 1];
     for (uint32_t i = lo + blockIdx.x * 256u + threadIdx.x; i < hi; i += gridDim.x * 256u) {
         const uint32_t sz = nl_up_node(nd, i);
-        if (nd.ex_k) nl_ex_up(nd, i);
         if (level == 0 && sz >= 65536u) atomicOr(&nd.ctl->err, NERR_NODES);  // creation indices are sort keys of 16 bits
     }
 }
@@ -1047,10 +1057,7 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
         // ---- NlheGame::apply(edge) for the level's children: the next level's nodes
         const uint32_t chi = s_cursor;
         if (tid == 0) lvl[L + 2] = chi;
-        for (uint32_t c = hi + tid; c < chi; c += 256u) {
-            err |= nl_make_child(p, nd, c, (int)p.walker);
-            if (nd.ex_k) nl_ex_child(nd, c);  // the parent's chains are a level old: no barrier between the two
-        }
+        for (uint32_t c = hi + tid; c < chi; c += 256u) err |= nl_make_child(p, nd, c, (int)p.walker);
         if (err) atomicOr(&s_err, err);
         __syncthreads();  // the node records and the level table are read by other work-items from here on
         if (s_err) break;
@@ -1070,7 +1077,6 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
     for (uint32_t l = levels; l-- > 0;) {
         for (uint32_t i = lvl[l] + tid; i < lvl[l + 1]; i += 256u) {
             const uint32_t sz = nl_up_node(nd, i);
-            if (nd.ex_k) nl_ex_up(nd, i);
             if (l == 0 && sz >= 65536u) atomicOr(&nd.ctl->err, NERR_NODES);
         }
         __syncthreads();

@@ -138,7 +138,7 @@ def test_small_batch_decisions_are_bit_exact(gpu, sampling, batch, rng):
 
 @pytest.mark.parametrize("sampling,batch,budget", [("external", 300, "4096"), ("pluribus", 160, "4096"), ("external", 2500, None)])
 def test_exact_order_on_the_level_synchronous_kernels(gpu, monkeypatch, sampling, batch, budget):
-    # rp_nlhe_set_exact(1): the batch-wide kernels carry the per-ancestor reach rows too (nl_ex_child in k_nl_children, nl_ex_up in
+    # rp_nlhe_set_exact(1): the batch-wide kernels carry the per-ancestor reach rows too (nl_ex_child in k_nl_children, nl_ex_up_kids in
     # k_nl_up, nl_ex_walker in k_nl_fill) and their Decisions equal the oracle's bit for bit as well — forced onto those kernels by a
     # node budget at small batches, taken by size at 2 500 trees
     if budget:
