@@ -46,17 +46,31 @@ def load() -> C.CDLL:
         # use the portable build, which travels between machines.  No compiler here = the portable build, said in the sample text
         native = os.path.join(ROOT, "oracle", "_build", "librp_oracle_native.so")
         try:
-            # several rank processes may get here together: each builds into a file of its own and renames it into place (a new inode:
-            # a process that has the previous file mapped keeps it), under a lock so that the builds do not compete for the cores
+            # several rank processes may get here together: one of them builds (under a lock, into a file of its own that is renamed
+            # into place: a process that has the previous file mapped keeps it), the others find its stamp — this machine's boot id
+            # and the sources' newest mtime — and load what it built.  A library that travelled here from another machine has
+            # another boot id in its stamp and is rebuilt (-march=native is this machine's).
             import fcntl
+            import glob
 
             os.makedirs(os.path.dirname(native), exist_ok=True)
+            try:
+                boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+            except OSError:
+                boot = "unknown"
+            srcs = glob.glob(os.path.join(ROOT, "oracle", "*.[ch]")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+            want = f"{boot} {max(os.path.getmtime(f) for f in srcs):.3f}"
+            stamp = native + ".stamp"
             mine = f"_build/librp_oracle_native.{os.getpid()}.so"
             with open(native + ".lock", "w") as lock:
                 fcntl.flock(lock, fcntl.LOCK_EX)
-                subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "native", f"NATIVE={mine}"],
-                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                os.replace(os.path.join(ROOT, "oracle", mine), native)
+                have = open(stamp).read() if os.path.exists(stamp) and os.path.exists(native) else ""
+                if have != want or boot == "unknown":
+                    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "native", f"NATIVE={mine}"],
+                                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    os.replace(os.path.join(ROOT, "oracle", mine), native)
+                    with open(stamp, "w") as f:
+                        f.write(want)
             path = native
         except (OSError, subprocess.CalledProcessError):
             pass
