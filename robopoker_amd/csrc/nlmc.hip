@@ -104,6 +104,7 @@ struct rp_nlhe {
     // tree's region (0: the node arrays were not sized for it), level_ncap = the batch-wide path's own node budget (its launch sizes)
     uint32_t tree_cap = 0, level_ncap = 0;
     bool tree_mode_off = false;  // a tree outgrew its region once: the handle stays on the batch-wide path
+    uint32_t* ex_k_parked = nullptr;  // rp_nlhe_set_exact(h, 0) on a large-batch handle: lv.ex_k while the exact evaluation is off
     uint32_t chunks = 1;  // passes per batch (RP_NLHE_CHUNKS; doubled when a pass runs out of nodes)
     uint32_t grid_cap = 16384;  // workgroups of the grid-stride kernels (measured: 1024 -14 %, 4096 -4 %)
 };
@@ -473,18 +474,16 @@ int rp_nlhe_set_rng(rp_nlhe* h, rp_rng_kind kind) {
 }
 int rp_nlhe_set_exact(rp_nlhe* h, int on) {
     if (!h) return rp::fail(RP_ERR_INVALID, "rp_nlhe_set_exact: NULL handle");
-    if (!on) {
-        if (h->tree_cap) return rp::fail(RP_ERR_UNSUPPORTED, "rp_nlhe_set_exact: a batch of at most %u trees is always evaluated in the reference's order", NL_TREE_BATCH);
-        h->lv.ex_k = nullptr;  // the arrays stay allocated (freed with the handle); the kernels look at ex_k only
-        return RP_OK;
-    }
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(rp::profile_stream(h->prof)));
-    if (h->lv.fsig && !h->lv.ex_k) {  // switched off before: the arrays are still there
-        uint32_t* p = nullptr;
-        int rc = nl_alloc(h, &p, h->lv.ncap);
-        if (rc) return rc;
-        h->lv.ex_k = p;
+    if (!on) {
+        if (h->tree_cap) return rp::fail(RP_ERR_UNSUPPORTED, "rp_nlhe_set_exact: a batch of at most %u trees is always evaluated in the reference's order", NL_TREE_BATCH);
+        if (h->lv.ex_k) h->ex_k_parked = h->lv.ex_k;
+        h->lv.ex_k = nullptr;  // the kernels look at ex_k only; the arrays stay with the handle
+        return RP_OK;
+    }
+    if (!h->lv.ex_k && h->ex_k_parked) {
+        h->lv.ex_k = h->ex_k_parked;
         return RP_OK;
     }
     return nl_alloc_exact(h);
