@@ -10,7 +10,7 @@
  * Why it exists (reference boundaries that are NOT reproducible):
  *   - f32::exp / f32::ln / f32::powf are platform libm in the reference
  *     (crates/lloyd/src/sinkhorn.rs:115,120-127,136; phi.rs:36;
- *      crates/mccfr/src/regret/discounted.rs:33,37)           -> rp_expf/rp_logf/rp_pow15/rp_pow05
+ *      crates/mccfr/src/regret/discounted.rs:33,37)           -> rp_expf/rp_logf here; powf: rp_libm_glibc.h
  *   - DefaultHasher(SipHash-1-3) + SmallRng::seed_from_u64 + WeightedIndex /
  *     random_range / random::<f32>() from rand 0.9.2
  *     (crates/mccfr/src/strategy/flow.rs:285-295, sample/external.rs:57-63,
@@ -246,10 +246,9 @@ RP_HD float rp_div_by_recip1(float a, float b, float r, int* proven) {
 RP_HD float rp_div_by_recip64(float a, double rd) { return (float)((double)a * rd); }
 RP_HD int rp_div_by_recip_ok(float a) { return a == 0.0f || rp_absf(a) >= 8.6736174e-19f; /* 2^-60 */ }
 
-/* powf(x, 1.5) and powf(x, 0.5) for DiscountedRegret's ALPHA/BETA constants
- * (crates/mccfr/src/regret/discounted.rs:12-13,33,37), via correctly rounded sqrt. */
-RP_HD float rp_pow15(float x) { return x * sqrtf(x); }
-RP_HD float rp_pow05(float x) { return sqrtf(x); }
+/* powf(t, 1.5) and powf(t, 0.5) of DiscountedRegret's ALPHA / BETA (crates/mccfr/src/regret/discounted.rs:12-13,33,37) are
+ * per-epoch scalars: the HOST computes them with glibc's powf restated (include/rp_libm_glibc.h: rp_pow15 / rp_pow05) and hands
+ * them to the kernels as parameters; there is no device powf. */
 
 /* ---------------------------------------------------------------- RNG ----
  * The reference builds a fresh SmallRng per sampled node from

@@ -567,6 +567,14 @@ RP_API int rp_kmeans_step_local(rp_kmeans* h, void* partial_dev);
 RP_API int rp_kmeans_step_finish(rp_kmeans* h, const void* reduced_dev, float* drift, uint64_t* sizes,
                                  double* reassigned);
 
+/* Which exp / ln the three stand-alone operators below compute with (process-wide, default RP_LIBM_CONTRACT).
+ *   RP_LIBM_CONTRACT  include/rp_math.h's rp_expf / rp_logf: f32 only, what the clustering kernels use, <= 1 ulp from libm.
+ *   RP_LIBM_GLIBC     glibc's expf / logf as a Rust build on Linux calls them (f32::exp / f32::ln, sinkhorn.rs:115,120-127,136;
+ *                     phi.rs:36), restated in include/rp_libm_glibc.h (equal to glibc 2.35's on all 2^32 inputs) and evaluated in
+ *                     double on the device: a solve is the reference's, bit for bit, at a few times the cost.
+ * The k-means handle has no such mode: what the <= 1 ulp is worth there is measured (no pick, no bucket moves). */
+typedef enum rp_libm_kind { RP_LIBM_CONTRACT = 0, RP_LIBM_GLIBC = 1 } rp_libm_kind;
+RP_API int rp_sinkhorn_set_libm(rp_libm_kind kind);
 /* Sinkhorn::divergence (sinkhorn.rs:166-171) / Metric::emd for P independent pairs:
  * mu[P*bins], nu[P*bins] u32 counts (host), out[P].  One wavefront per pair. */
 RP_API int rp_sinkhorn_divergence(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_t* nu,

@@ -15,8 +15,9 @@
  * self-divergence < 1e-4 and symmetry < 1e-3 on the closed-form fixture (sinkhorn.rs:240-293),
  * OT(mu,mu) <= 0.01 / positivity / triangle (emd.rs:105-131), variation symmetric/zero/positive
  * (emd.rs:72-97), Elkan == naive (tests.rs:148-161), Pair bijection (pair.rs:171-189).
- * exp/ln are include/rp_math.h's rp_expf/rp_logf (<= 1 ulp from libm: PARITY UNPINNED there, no published definition of the
- * platform's libm exists); the k-means++ draw is rp_math.h's order-independent fixed-point scheme by default and, under
+ * exp/ln are by default include/rp_math.h's rp_expf/rp_logf (the clustering kernels' f32 contract, <= 1 ulp from glibc's) and, under
+ * ora_lloyd_set_libm, the platform's own functions (1) or glibc's restated (2: include/rp_libm_glibc.h, equal to glibc 2.35's on all
+ * 2^32 inputs — the boundary is pinned for glibc hosts, tests/test_libm_glibc.py); the k-means++ draw is rp_math.h's order-independent fixed-point scheme by default and, under
  * ora_kmeans_set_rng(RP_RNG_REFERENCE), layer.rs:155-178's own SmallRng + WeightedIndex<f32> (include/rp_refrng.h).
  *
  * f32 operation order follows the reference: supports ascend by bin index (phi.rs:51-57), every softmin
@@ -33,17 +34,20 @@
 #include "../include/rp_math.h"
 #include "../include/rp_mi355x.h"
 #include "../include/rp_refrng.h"
+#include "../include/rp_libm_glibc.h"
 
-/* THE ONE UNPINNED BOUNDARY, made measurable.  The reference calls the platform's libm (f32::exp / f32::ln; sinkhorn.rs:115,120-127,136,
- * phi.rs:36); this build's contract is rp_expf / rp_logf (include/rp_math.h: <= 1 ulp from libm, host == device).  ora_lloyd_set_libm(1)
+/* THE LIBM BOUNDARY, made measurable.  The reference calls the platform's libm (f32::exp / f32::ln; sinkhorn.rs:115,120-127,136,
+ * phi.rs:36); the clustering kernels' contract is rp_expf / rp_logf (include/rp_math.h: <= 1 ulp from glibc's, host == device).  ora_lloyd_set_libm(1)
  * makes THIS oracle call the platform's expf / logf instead — the reference's arithmetic on this machine — so that tests can state what
  * the boundary is worth: how many Sinkhorn costs change and by how much, whether any k-means++ pick or bucket moves
- * (tests/test_oracle_lloyd.py::test_platform_libm_*).  The device has no such mode: its results are the contract's. */
+ * (tests/test_oracle_lloyd.py::test_platform_libm_*).  Mode 2 = glibc's functions restated: what the device's stand-alone Sinkhorn
+ * operators compute under rp_sinkhorn_set_libm(RP_LIBM_GLIBC), checked against this oracle in that mode. */
 #define ORA_API __attribute__((visibility("default")))
 static int g_libm = 0;
 ORA_API void ora_lloyd_set_libm(int on) { g_libm = on; }
-static inline float ora_expf(float x) { return g_libm ? expf(x) : rp_expf(x); }
-static inline float ora_logf(float x) { return g_libm ? logf(x) : rp_logf(x); }
+/* 0: the contract (rp_math.h); 1: this machine's libm; 2: glibc's algorithms restated (include/rp_libm_glibc.h: = 1 on glibc / x86-64) */
+static inline float ora_expf(float x) { return g_libm == 1 ? expf(x) : (g_libm == 2 ? rp_glibc_expf(x) : rp_expf(x)); }
+static inline float ora_logf(float x) { return g_libm == 1 ? logf(x) : (g_libm == 2 ? rp_glibc_logf(x) : rp_logf(x)); }
 
 #define ORA_MAXBINS 256
 

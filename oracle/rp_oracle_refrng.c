@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "../include/rp_refrng.h"
+#include "../include/rp_libm_glibc.h"
 
 #define ORA_API __attribute__((visibility("default")))
 
@@ -65,3 +66,54 @@ ORA_API uint32_t ora_ref_weighted_index(uint64_t seed, const float* w, uint32_t 
     }
     return idx;
 }
+
+/* include/rp_libm_glibc.h against THIS machine's libm over every float bit pattern in [lo, hi): mismatches of expf and logf (both NaN
+ * counts as equal); first[0..1] = the first mismatching bit pattern of each (~0 if none).  OpenMP: the whole 2^32 range takes ~10 s on
+ * eight cores. */
+ORA_API void ora_libm_glibc_sweep(uint64_t lo, uint64_t hi, uint64_t* bad_exp, uint64_t* bad_log, uint32_t* first) {
+    uint64_t be = 0, bl = 0;
+    uint32_t fe = 0xffffffffu, fl = 0xffffffffu;
+#pragma omp parallel for reduction(+ : be, bl) reduction(min : fe, fl) schedule(static)
+    for (long long b = (long long)lo; b < (long long)hi; ++b) {
+        const float x = rp_u2f((uint32_t)b);
+        const float a = rp_glibc_expf(x), c = expf(x);
+        if (rp_f2u(a) != rp_f2u(c) && !(a != a && c != c)) {
+            be += 1;
+            if ((uint32_t)b < fe) fe = (uint32_t)b;
+        }
+        const float d = rp_glibc_logf(x), e = logf(x);
+        if (rp_f2u(d) != rp_f2u(e) && !(d != d && e != e)) {
+            bl += 1;
+            if ((uint32_t)b < fl) fl = (uint32_t)b;
+        }
+    }
+    *bad_exp = be;
+    *bad_log = bl;
+    first[0] = fe;
+    first[1] = fl;
+}
+ORA_API float ora_glibc_expf(float x) { return rp_glibc_expf(x); }
+ORA_API float ora_glibc_logf(float x) { return rp_glibc_logf(x); }
+ORA_API void ora_glibc_vec(uint64_t n, const float* x, float* e, float* l) {
+    for (uint64_t i = 0; i < n; ++i) {
+        e[i] = rp_glibc_expf(x[i]);
+        l[i] = rp_glibc_logf(x[i] < 0 ? -x[i] : x[i]);
+    }
+}
+/* rp_glibc_powf(x, y) against this machine's powf for every positive finite float x in bit range [lo, hi) */
+ORA_API uint64_t ora_libm_glibc_pow_sweep(uint64_t lo, uint64_t hi, float y, uint32_t* first) {
+    uint64_t bad = 0;
+    uint32_t fb = 0xffffffffu;
+#pragma omp parallel for reduction(+ : bad) reduction(min : fb) schedule(static)
+    for (long long b = (long long)lo; b < (long long)hi; ++b) {
+        const float x = rp_u2f((uint32_t)b);
+        const float a = rp_glibc_powf(x, y), c = powf(x, y);
+        if (rp_f2u(a) != rp_f2u(c)) {
+            bad += 1;
+            if ((uint32_t)b < fb) fb = (uint32_t)b;
+        }
+    }
+    *first = fb;
+    return bad;
+}
+ORA_API float ora_glibc_powf(float x, float y) { return rp_glibc_powf(x, y); }

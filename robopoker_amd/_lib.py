@@ -238,6 +238,7 @@ _SIGNATURES = {
     "rp_kmeans_partial_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "rp_kmeans_step_local": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_kmeans_step_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "rp_sinkhorn_set_libm": (C.c_int, [C.c_int]),
     "rp_sinkhorn_divergence": (
         C.c_int,
         [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SinkhornHP), C.c_int, C.c_void_p],

@@ -15,6 +15,7 @@
 // Everything f32 is spelled with the primitives of include/rp_math.h and compiled -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <string>
@@ -22,6 +23,7 @@
 
 #include "../../include/rp_math.h"
 #include "../../include/rp_refrng.h"
+#include "../../include/rp_libm_glibc.h"
 #include "rp_internal.h"
 
 namespace rp {
@@ -98,7 +100,7 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 #include "sinkhorn_bound.hpp"
 
 // Bins::support + Bins::density (bins.rs:58-60,84-88) of a dense histogram into LDS; returns the support size
-template <typename CT>
+template <typename CT, int LIBM = 0>  // LIBM 1: ln as glibc computes it (rp_sinkhorn_set_libm; the stand-alone operators only)
 __device__ uint32_t wave_load_hist(const CT* counts, uint32_t weight, uint32_t bins, uint16_t* sup, float* lnd) {
     const uint32_t lane = lane_id();
     const float fw = (float)weight;
@@ -111,7 +113,8 @@ __device__ uint32_t wave_load_hist(const CT* counts, uint32_t weight, uint32_t b
         if (has) {
             const uint32_t r = base + __popcll(mask & ((1ull << lane) - 1ull));
             sup[r] = (uint16_t)b;
-            lnd[r] = rp_logf((float)c / fw);
+            if constexpr (LIBM) lnd[r] = rp_glibc_logf((float)c / fw);
+            else lnd[r] = rp_logf((float)c / fw);
         }
         base += __popcll(mask);
     }
@@ -359,6 +362,72 @@ __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint
         __syncthreads();
     }
     return cost;
+}
+
+// The same solve in the REFERENCE'S OWN libm arithmetic on a glibc host (rp_sinkhorn_set_libm(RP_LIBM_GLIBC)): f32::exp / f32::ln =
+// glibc's expf / logf, which compute in double around small tables (include/rp_libm_glibc.h, equal to the platform's functions on all
+// 2^32 inputs).  Same loops, same order, one term at a time: lane i owns row i and folds the other support ascending.  This is the
+// stand-alone operators' path (rp_sinkhorn_cost / _divergence / _flow), where "identical to a Rust build" can be asked of one
+// solve; the clustering keeps the f32 contract (rp_expf / rp_logf, <= 1 ulp away, packed and pipelined above).
+__device__ float wave_sinkhorn_cost_glibc(WaveLds& w, uint32_t m, uint32_t n, const Metric& M) {
+    const uint32_t lane = lane_id();
+    if (m == 0 || n == 0) return 0.0f;
+    const uint32_t bins = M.bins;
+    const float lu = rp_glibc_logf(1.0f / (float)m), ru = rp_glibc_logf(1.0f / (float)n);
+    for (uint32_t i = lane; i < m; i += 64) w.f[i] = lu;
+    for (uint32_t j = lane; j < n; j += 64) w.g[j] = ru;
+    __syncthreads();
+    uint32_t t = 0;
+    for (; t < M.iters; ++t) {
+        for (uint32_t i = lane; i < m; i += 64) {
+            const uint32_t x = w.supA[i];
+            float s = 0.0f;
+            for (uint32_t j = 0; j < n; ++j) s += rp_maxf(rp_glibc_expf(w.g[j] - M.Rt[x * bins + w.supB[j]]), RP_EPSILON);
+            const float nf = w.lnA[i] - rp_glibc_logf(s);
+            w.tmp[i] = rp_absf(rp_glibc_expf(nf) - rp_glibc_expf(w.f[i]));
+            w.f[i] = nf;
+        }
+        __syncthreads();
+        const float lhs_err = lds_sum_in_order(w.tmp, m);
+        __syncthreads();
+        for (uint32_t j = lane; j < n; j += 64) {
+            const uint32_t y = w.supB[j];
+            float s = 0.0f;
+            for (uint32_t i = 0; i < m; ++i) s += rp_maxf(rp_glibc_expf(w.f[i] - M.Rt[y * bins + w.supA[i]]), RP_EPSILON);
+            const float ng = w.lnB[j] - rp_glibc_logf(s);
+            w.tmp[j] = rp_absf(rp_glibc_expf(ng) - rp_glibc_expf(w.g[j]));
+            w.g[j] = ng;
+        }
+        __syncthreads();
+        const float rhs_err = lds_sum_in_order(w.tmp, n);
+        __syncthreads();
+        if (lhs_err + rhs_err < M.tol) {
+            t += 1;
+            break;
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(STAT(M, 1), (unsigned long long)t);
+        atomicAdd(STAT(M, 2), (unsigned long long)(2 * t + 1) * m * n);
+    }
+    float cost = 0.0f;
+    for (uint32_t i = 0; i < m; ++i) {
+        const uint32_t x = w.supA[i];
+        const float fi = w.f[i];
+        for (uint32_t j = lane; j < n; j += 64) {
+            const uint32_t y = w.supB[j];
+            w.tmp[j] = rp_glibc_expf(fi + w.g[j] - M.Rt[x * bins + y]) * M.Cm[x * bins + y];
+        }
+        __syncthreads();
+        for (uint32_t j = 0; j < n; ++j) cost += w.tmp[j];
+        __syncthreads();
+    }
+    return cost;
+}
+template <int LIBM>
+__device__ __forceinline__ float pair_cost(WaveLds& w, uint32_t m, uint32_t n, const Metric& M) {
+    if constexpr (LIBM) return wave_sinkhorn_cost_glibc(w, m, n, M);
+    else return wave_sinkhorn_cost(w, m, n, M);
 }
 
 // Sinkhorn::divergence (sinkhorn.rs:166-171) with memoised self terms
@@ -1856,6 +1925,7 @@ __global__ void k_fill(float* p, uint64_t n, float v) {
 // ------------------------------------------------------------------------------------------------
 // stand-alone batched entry points: one wave per pair of u32 histograms
 // ------------------------------------------------------------------------------------------------
+template <int LIBM>
 __global__ __launch_bounds__(64) void k_pair_sinkhorn(const uint32_t* mu, const uint32_t* nu, Metric M, int divergence,
                                                       float* out, uint32_t* iters_out) {
     __shared__ WaveLds w;
@@ -1872,22 +1942,22 @@ __global__ __launch_bounds__(64) void k_pair_sinkhorn(const uint32_t* mu, const 
     }
     float xx = 0.0f, yy = 0.0f;
     if (divergence) {
-        uint32_t m = wave_load_hist(mu + p * bins, wa, bins, w.supA, w.lnA);
+        uint32_t m = wave_load_hist<uint32_t, LIBM>(mu + p * bins, wa, bins, w.supA, w.lnA);
         for (uint32_t k = lane; k < m; k += 64) { w.supB[k] = w.supA[k]; w.lnB[k] = w.lnA[k]; }
         __syncthreads();
-        xx = wave_sinkhorn_cost(w, m, m, M);
+        xx = pair_cost<LIBM>(w, m, m, M);
         __syncthreads();
-        m = wave_load_hist(nu + p * bins, wb, bins, w.supA, w.lnA);
+        m = wave_load_hist<uint32_t, LIBM>(nu + p * bins, wb, bins, w.supA, w.lnA);
         for (uint32_t k = lane; k < m; k += 64) { w.supB[k] = w.supA[k]; w.lnB[k] = w.lnA[k]; }
         __syncthreads();
-        yy = wave_sinkhorn_cost(w, m, m, M);
+        yy = pair_cost<LIBM>(w, m, m, M);
         __syncthreads();
     }
-    const uint32_t m = wave_load_hist(mu + p * bins, wa, bins, w.supA, w.lnA);
-    const uint32_t n = wave_load_hist(nu + p * bins, wb, bins, w.supB, w.lnB);
+    const uint32_t m = wave_load_hist<uint32_t, LIBM>(mu + p * bins, wa, bins, w.supA, w.lnA);
+    const uint32_t n = wave_load_hist<uint32_t, LIBM>(nu + p * bins, wb, bins, w.supB, w.lnB);
     unsigned long long before = 0;
     if (iters_out && lane == 0) before = M.stats[1];
-    const float xy = wave_sinkhorn_cost(w, m, n, M);
+    const float xy = pair_cost<LIBM>(w, m, n, M);
     float r = xy;
     if (divergence) r = rp_maxf(xy - 0.5f * xx - 0.5f * yy, 0.0f);
     if (lane == 0) out[p] = r;
@@ -1895,6 +1965,7 @@ __global__ __launch_bounds__(64) void k_pair_sinkhorn(const uint32_t* mu, const 
 }
 // Coupling::flow (monge/src/coupling.rs:23-51 as Sinkhorn implements it, sinkhorn.rs:114-116,202-204) of ONE minimised pair:
 // coupling(x, y) = exp(lhs(x) + rhs(y) - C/T) and flow = coupling * C on supp(mu) x supp(nu), 0 elsewhere
+template <int LIBM>
 __global__ __launch_bounds__(64) void k_pair_flow(const uint32_t* mu, const uint32_t* nu, Metric M, float* flow, float* coupling) {
     __shared__ WaveLds w;
     const uint32_t bins = M.bins, lane = lane_id();
@@ -1907,20 +1978,24 @@ __global__ __launch_bounds__(64) void k_pair_flow(const uint32_t* mu, const uint
         wa += __shfl_xor(wa, d, 64);
         wb += __shfl_xor(wb, d, 64);
     }
-    const uint32_t m = wave_load_hist(mu, wa, bins, w.supA, w.lnA);
-    const uint32_t n = wave_load_hist(nu, wb, bins, w.supB, w.lnB);
-    (void)wave_sinkhorn_cost(w, m, n, M);  // leaves the minimised potentials in w.f / w.g
+    const uint32_t m = wave_load_hist<uint32_t, LIBM>(mu, wa, bins, w.supA, w.lnA);
+    const uint32_t n = wave_load_hist<uint32_t, LIBM>(nu, wb, bins, w.supB, w.lnB);
+    (void)pair_cost<LIBM>(w, m, n, M);  // leaves the minimised potentials in w.f / w.g
     for (uint32_t i = 0; i < m; ++i) {
         const uint32_t x = w.supA[i];
         for (uint32_t j = lane; j < n; j += 64) {
             const uint32_t y = w.supB[j];
-            const float pi = rp_expf(w.f[i] + w.g[j] - M.Rt[x * bins + y]);
+            const float e = w.f[i] + w.g[j] - M.Rt[x * bins + y];
+            float pi;
+            if constexpr (LIBM) pi = rp_glibc_expf(e);
+            else pi = rp_expf(e);
             if (coupling) coupling[x * bins + y] = pi;
             flow[x * bins + y] = pi * M.Cm[x * bins + y];
         }
     }
 }
 // iteration counts need a private counter per pair: a second tiny variant keeps the hot kernel lean
+template <int LIBM>
 __global__ __launch_bounds__(64) void k_pair_iters(const uint32_t* mu, const uint32_t* nu, Metric M, unsigned long long* scratch,
                                                    uint32_t* iters_out) {
     __shared__ WaveLds w;
@@ -1937,9 +2012,9 @@ __global__ __launch_bounds__(64) void k_pair_iters(const uint32_t* mu, const uin
     }
     Metric mine = M;
     mine.stats = scratch + 4 * p;
-    const uint32_t m = wave_load_hist(mu + p * bins, wa, bins, w.supA, w.lnA);
-    const uint32_t n = wave_load_hist(nu + p * bins, wb, bins, w.supB, w.lnB);
-    (void)wave_sinkhorn_cost(w, m, n, mine);
+    const uint32_t m = wave_load_hist<uint32_t, LIBM>(mu + p * bins, wa, bins, w.supA, w.lnA);
+    const uint32_t n = wave_load_hist<uint32_t, LIBM>(nu + p * bins, wb, bins, w.supB, w.lnB);
+    (void)pair_cost<LIBM>(w, m, n, mine);
     __syncthreads();
     if (lane == 0) iters_out[p] = (uint32_t)scratch[4 * p + 1];
 }
@@ -3177,6 +3252,7 @@ int rp_kmeans_kernel_time(rp_kmeans* h, const char* name, double* total_ms, uint
 
 // ---- stand-alone batched distances -------------------------------------------------------------------
 namespace {
+std::atomic<int> g_pair_libm{RP_LIBM_CONTRACT};
 int pair_common(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_t* nu, const float* tri, const rp_sinkhorn_hp* hp,
                 int device, float* out, uint32_t* iterations, int divergence) {
     if (!mu || !nu || !out || pairs == 0 || bins == 0 || bins > MAXB || (!tri && bins > 1))
@@ -3208,14 +3284,17 @@ int pair_common(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_
     HIP_TRY(hipMemcpy(dmu, mu, hb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dnu, nu, hb, hipMemcpyHostToDevice));
     Metric M{dC, dR, bins, hh.iterations, hh.tolerance, dstats, 1u};
-    hipLaunchKernelGGL(k_pair_sinkhorn, dim3((unsigned)pairs), dim3(64), 0, 0, dmu, dnu, M, divergence, dout, (uint32_t*)nullptr);
+    const bool glibc = g_pair_libm.load() == RP_LIBM_GLIBC;
+    if (glibc) hipLaunchKernelGGL((k_pair_sinkhorn<1>), dim3((unsigned)pairs), dim3(64), 0, 0, dmu, dnu, M, divergence, dout, (uint32_t*)nullptr);
+    else hipLaunchKernelGGL((k_pair_sinkhorn<0>), dim3((unsigned)pairs), dim3(64), 0, 0, dmu, dnu, M, divergence, dout, (uint32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, dout, pairs * 4, hipMemcpyDeviceToHost));
     if (iterations) {
         HIP_TRY(hipMalloc(&dit, pairs * 4));
         HIP_TRY(hipMalloc(&dscr, pairs * 32));
         HIP_TRY(hipMemset(dscr, 0, pairs * 32));
-        hipLaunchKernelGGL(k_pair_iters, dim3((unsigned)pairs), dim3(64), 0, 0, dmu, dnu, M, dscr, dit);
+        if (glibc) hipLaunchKernelGGL((k_pair_iters<1>), dim3((unsigned)pairs), dim3(64), 0, 0, dmu, dnu, M, dscr, dit);
+        else hipLaunchKernelGGL((k_pair_iters<0>), dim3((unsigned)pairs), dim3(64), 0, 0, dmu, dnu, M, dscr, dit);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(iterations, dit, pairs * 4, hipMemcpyDeviceToHost));
         (void)hipFree(dit);
@@ -3226,6 +3305,11 @@ int pair_common(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_
 }
 }  // namespace
 
+int rp_sinkhorn_set_libm(rp_libm_kind kind) {
+    if (kind != RP_LIBM_CONTRACT && kind != RP_LIBM_GLIBC) return rp::fail(RP_ERR_INVALID, "rp_sinkhorn_set_libm: unknown kind %d", (int)kind);
+    g_pair_libm.store(kind);
+    return RP_OK;
+}
 int rp_sinkhorn_divergence(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_t* nu, const float* tri_metric,
                            const rp_sinkhorn_hp* hp, int device, float* out) {
     return pair_common(bins, pairs, mu, nu, tri_metric, hp, device, out, nullptr, 1);
@@ -3263,7 +3347,9 @@ int rp_sinkhorn_flow(uint32_t bins, const uint32_t* mu, const uint32_t* nu, cons
     HIP_TRY(hipMemcpy(hist, mu, (size_t)bins * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(hist + bins, nu, (size_t)bins * 4, hipMemcpyHostToDevice));
     Metric M{buf, buf + cells, bins, hh.iterations, hh.tolerance, dstats, 1u};
-    hipLaunchKernelGGL(k_pair_flow, dim3(1), dim3(64), 0, 0, hist, hist + bins, M, buf + 2 * cells, buf + 3 * cells);
+    if (g_pair_libm.load() == RP_LIBM_GLIBC)
+        hipLaunchKernelGGL((k_pair_flow<1>), dim3(1), dim3(64), 0, 0, hist, hist + bins, M, buf + 2 * cells, buf + 3 * cells);
+    else hipLaunchKernelGGL((k_pair_flow<0>), dim3(1), dim3(64), 0, 0, hist, hist + bins, M, buf + 2 * cells, buf + 3 * cells);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(flow, buf + 2 * cells, cells * 4, hipMemcpyDeviceToHost));
     if (coupling) HIP_TRY(hipMemcpy(coupling, buf + 3 * cells, cells * 4, hipMemcpyDeviceToHost));

@@ -927,13 +927,13 @@ __global__ __launch_bounds__(CH_THREADS) void k_compact_small(DevGame g, DevDeci
 struct Discount {
     float pos, neg, zero;
 };
-__device__ __forceinline__ Discount regret_discount(int R, float t) {
+__device__ __forceinline__ Discount regret_discount(int R, float t, float pow15, float pow05) {
     Discount d{1.0f, 1.0f, 1.0f};
     const float lin = t / (t + 1.0f);
     if (R == RP_REGRET_LINEAR) d = Discount{lin, lin, lin};
     else if (R == RP_REGRET_ASYMMETRIC) d = Discount{1.0f, lin, lin};
     else if (R == RP_REGRET_DISCOUNTED) {
-        const float xp = rp_pow15(t / 1.0f), xn = rp_pow05(t / 1.0f), xz = t / 1.0f;
+        const float xp = pow15, xn = pow05, xz = t / 1.0f;
         d = Discount{xp / (xp + 1.0f), xn / (xn + 1.0f), xz / (xz + 1.0f)};
     }
     return d;
@@ -986,7 +986,7 @@ __global__ __launch_bounds__(128) void k_chain(DevGame g, DevTables t, DevSorted
             if (isreg) {
                 acc = t.regret[cell];
                 fl = regret_floor_of(p.R, p.regret_min);
-                d = regret_discount(p.R, tf);
+                d = regret_discount(p.R, tf, p.pow15, p.pow05);
             } else {
                 acc = t.weight[cell];
                 const float dw = p.W == RP_WEIGHT_EXPONENTIAL ? 0.9999f : 1.0f;
@@ -1832,6 +1832,10 @@ StepParams make_params(const rp_mccfr* h) {
     p.prune_threshold = h->hp.prune_threshold; p.prune_explore = h->hp.prune_explore;
     p.prune_warmup = h->hp.prune_warmup;
     p.regret_min = h->hp.regret_min;
+    if (h->R == RP_REGRET_DISCOUNTED) {  // (t / PERIOD).powf(ALPHA | BETA), PERIOD = 1 (discounted.rs:23,33,37)
+        p.pow15 = rp_pow15((float)h->epoch);
+        p.pow05 = rp_pow05((float)h->epoch);
+    }
     p.counters = h->d_counters;
     if (h->rng == RP_RNG_REFERENCE) {
         p.ref_info = reinterpret_cast<const rp_sip_mid*>(h->d_ref_mid);

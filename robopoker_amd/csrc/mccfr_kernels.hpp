@@ -6,6 +6,7 @@
 
 #include "../../include/rp_math.h"
 #include "../../include/rp_refrng.h"
+#include "../../include/rp_libm_glibc.h"
 #include "rp_internal.h"
 
 namespace rp {
@@ -86,6 +87,7 @@ struct StepParams {
     float prune_threshold, prune_explore;
     uint64_t prune_warmup;
     float regret_min;
+    float pow15, pow05;  // powf(t, 1.5), powf(t, 0.5) of t = (float)epoch: DiscountedRegret (host: rp_libm_glibc.h)
     unsigned long long* counters;  // [0] nodes, [1] infos, [2] error flags
     // reference-seed mode (rp_rng_kind RP_RNG_REFERENCE), NULL otherwise: DefaultHasher after t.hash() and info.hash()
     // (flow.rs:290-293) per infoset / per in-tree chance info, refreshed by k_prepare_ref every step
@@ -128,7 +130,7 @@ enum : uint32_t { ERR_NODE_CAPACITY = 1u, ERR_STACK_CAPACITY = 2u, ERR_DEC_CAPAC
 // ------------------------------------------------------------------------------------------------
 // schedules (regret/*.rs, policy/*.rs) and the per-cell map algebra of the composed update
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float d_regret_gain(int kind, float acc, float imm, float t, float floor_r) {
+__device__ __forceinline__ float d_regret_gain(int kind, float acc, float imm, float t, float pow15, float pow05, float floor_r) {
     float v;
     switch (kind) {
         case RP_REGRET_LINEAR: {
@@ -137,8 +139,8 @@ __device__ __forceinline__ float d_regret_gain(int kind, float acc, float imm, f
         } break;
         case RP_REGRET_DISCOUNTED: {
             float x;
-            if (acc > 0.0f) x = rp_pow15(t / 1.0f);
-            else if (acc < 0.0f) x = rp_pow05(t / 1.0f);
+            if (acc > 0.0f) x = pow15;
+            else if (acc < 0.0f) x = pow05;
             else x = t / 1.0f;
             const float discount = x / (x + 1.0f);
             v = acc * discount + imm;

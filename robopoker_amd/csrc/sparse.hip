@@ -35,6 +35,7 @@ struct SparseParams {
     uint32_t A;
     int R, W;
     float tf;             // (float)epoch
+    float pow15, pow05;   // powf(tf, 1.5), powf(tf, 0.5): DiscountedRegret (host: rp_libm_glibc.h)
     float floor_r;
     float dr, dw;         // composed discounts
 };
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void k_apply_ordered(SparseParams p, DevBatch 
 #pragma unroll
                 for (uint32_t u = 0; u < PF; ++u) {
                     if (u >= m) break;
-                    if ((cur.ev_mask >> u) & 1u) r = d_regret_gain(p.R, r, cur.dv[u], p.tf, p.floor_r);
+                    if ((cur.ev_mask >> u) & 1u) r = d_regret_gain(p.R, r, cur.dv[u], p.tf, p.pow15, p.pow05, p.floor_r);
                     w = d_weight_learn(p.W, w, cur.sv[u], p.tf);
                     ev += (cur.pv[u] - ev) / (float)(v + 1u);
                     v += 1u;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(128) void k_apply_hot(SparseParams p, DevBatch b, S
     if (p.R == RP_REGRET_LINEAR) dpos = dneg = dzero = lin;
     else if (p.R == RP_REGRET_ASYMMETRIC) dneg = dzero = lin;
     else if (p.R == RP_REGRET_DISCOUNTED) {
-        const float xp = rp_pow15(p.tf / 1.0f), xn = rp_pow05(p.tf / 1.0f), xz = p.tf / 1.0f;
+        const float xp = p.pow15, xn = p.pow05, xz = p.tf / 1.0f;
         dpos = xp / (xp + 1.0f);
         dneg = xn / (xn + 1.0f);
         dzero = xz / (xz + 1.0f);
@@ -884,6 +885,10 @@ static SparseParams make_params(const rp_profile* h) {
     p.R = h->R;
     p.W = h->W;
     p.tf = (float)h->epoch;
+    if (h->R == RP_REGRET_DISCOUNTED) {
+        p.pow15 = rp_pow15(p.tf);
+        p.pow05 = rp_pow05(p.tf);
+    }
     p.floor_r = regret_floor_of(h->R, h->hp.regret_min);
     p.dr = p.dw = 1.0f;
     return p;

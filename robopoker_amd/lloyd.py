@@ -231,6 +231,16 @@ def margin_audit(points, centroids, tri, hp=None, device=0, chunk=64) -> dict:
             "survivors_per_point": float((lo <= hi.min(axis=1, keepdims=True)).sum(axis=1).mean())}
 
 
+LIBM = {"contract": 0, "glibc": 1}
+
+
+def sinkhorn_set_libm(kind: str = "contract") -> None:
+    """Which exp / ln ``sinkhorn_cost`` / ``sinkhorn_divergence`` / ``sinkhorn_flow`` compute with (``rp_sinkhorn_set_libm``):
+    ``"contract"`` = the build's f32 functions (what the clustering uses), ``"glibc"`` = glibc's ``expf`` / ``logf`` restated
+    (include/rp_libm_glibc.h): one solve as a Rust build on Linux computes it, bit for bit."""
+    _lib.check(_lib.load().rp_sinkhorn_set_libm(LIBM[kind]))
+
+
 def sinkhorn_divergence(mu, nu, tri, hp=None, device=0) -> np.ndarray:
     """``Sinkhorn::divergence`` (sinkhorn.rs:166-171) for P pairs: mu, nu are (P, bins) u32 counts."""
     mu = np.ascontiguousarray(np.atleast_2d(mu), dtype=np.uint32)

@@ -1,0 +1,161 @@
+"""include/rp_libm_glibc.h: glibc's expf / logf (Arm Optimized Routines) restated, against THIS machine's libm over every float.
+
+The reference's Sinkhorn calls f32::exp / f32::ln (crates/lloyd/src/sinkhorn.rs:115,120-127,136; phi.rs:36) = the platform's libm.
+The restatement pins that boundary to the published algorithm the way tests/test_refrng.py pins the hash and the generator; the
+oracle's mode 2 (ora_lloyd_set_libm) runs the Sinkhorn on it."""
+import ctypes as C
+import platform
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _glibc_x86_fma() -> bool:
+    if platform.machine() != "x86_64" or platform.libc_ver()[0] != "glibc":
+        return False
+    try:
+        flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags"))
+    except (OSError, StopIteration):
+        return False
+    return " fma " in flags + " "
+
+
+needs_glibc = pytest.mark.skipif(not _glibc_x86_fma(), reason="the restatement is of glibc's x86-64 FMA variant")
+
+
+def _ulps(a, b):
+    return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+
+def _sweep(lo, hi):
+    o = oracle.load()
+    f = o.ora_libm_glibc_sweep
+    f.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    f.restype = None
+    be, bl, first = C.c_uint64(), C.c_uint64(), (C.c_uint32 * 2)()
+    f(lo, hi, be, bl, first)
+    return be.value, bl.value, first[0], first[1]
+
+
+@needs_glibc
+def test_every_float_bit_pattern_equals_the_platform_libm():
+    # all 2^32 inputs of both functions, NaNs, infinities, subnormals and the overflow / underflow edges included (~13 s on 8 cores)
+    be, bl, fe, fl = _sweep(0, 1 << 32)
+    assert (be, bl) == (0, 0), (be, bl, hex(fe), hex(fl))
+
+
+@needs_glibc
+@pytest.mark.parametrize("y", [1.5, 0.5])
+def test_powf_of_every_positive_float_equals_the_platform_libm(y):
+    # DiscountedRegret's two exponents (crates/mccfr/src/regret/discounted.rs:12-13,33,37) over EVERY positive finite x, subnormals
+    # and the overflow range included: the whole domain the reference can reach (t = epoch as f32), ~8 s each
+    o = oracle.load()
+    f = o.ora_libm_glibc_pow_sweep
+    f.argtypes, f.restype = [C.c_uint64, C.c_uint64, C.c_float, C.POINTER(C.c_uint32)], C.c_uint64
+    first = C.c_uint32()
+    assert f(1, 0x7F800000, y, first) == 0, hex(first.value)
+
+
+@needs_glibc
+def test_powf_on_other_exponents_over_a_stride_of_the_floats():
+    o = oracle.load()
+    f = o.ora_glibc_powf
+    f.argtypes, f.restype = [C.c_float, C.c_float], C.c_float
+    libm = C.CDLL("libm.so.6")
+    libm.powf.argtypes, libm.powf.restype = [C.c_float, C.c_float], C.c_float
+    rng = np.random.default_rng(3)
+    xs = rng.integers(1, 0x7F800000, 20000, dtype=np.uint32).view(np.float32)
+    ys = rng.uniform(-12, 12, 20000).astype(np.float32)
+    for x, y in zip(xs, ys):
+        a, b = np.float32(f(float(x), float(y))), np.float32(libm.powf(float(x), float(y)))
+        assert a.tobytes() == b.tobytes(), (float(x), float(y))
+
+
+def test_the_old_contract_differed_from_powf_on_a_quarter_of_the_epochs():
+    # why the powers moved from t * sqrt(t) to glibc's powf (round 4): over t = 1 .. 2^20 the two differ in the last bit for ~24 %
+    # of the epochs at 1.5 (two roundings against one) and for a few at 0.5 — a Rust build on glibc follows powf
+    o = oracle.load()
+    f = o.ora_glibc_powf
+    f.argtypes, f.restype = [C.c_float, C.c_float], C.c_float
+    t = np.arange(1, 1 << 16, dtype=np.float32)
+    a = np.array([f(float(x), 1.5) for x in t], np.float32)
+    b = t * np.sqrt(t)
+    frac = float((a != b).mean())
+    assert 0.1 < frac < 0.4, frac
+    assert _ulps(a, b).max() <= 1
+    # exact squares: t^1.5 is an integer and both agree with it while it fits 24 bits
+    for q in (2, 3, 10, 100, 255):
+        assert f(float(q * q), 1.5) == float(q**3) and f(float(q * q), 0.5) == float(q)
+
+
+def test_known_values_and_edges():
+    o = oracle.load()
+    for f in (o.ora_glibc_expf, o.ora_glibc_logf):
+        f.argtypes, f.restype = [C.c_float], C.c_float
+    e, l = o.ora_glibc_expf, o.ora_glibc_logf
+    assert e(0.0) == 1.0 and l(1.0) == 0.0
+    assert e(float("-inf")) == 0.0 and e(float("inf")) == float("inf") and np.isnan(e(float("nan")))
+    assert e(89.0) == float("inf") and e(-104.0) == 0.0
+    assert l(0.0) == float("-inf") and l(float("inf")) == float("inf") and np.isnan(l(-1.0)) and np.isnan(l(float("nan")))
+    # correctly rounded values computed in double (both functions are within 0.51 ulp by their error analysis; these are not ties)
+    for x in (1.0, -1.0, 0.5, 10.0, -20.0, 1e-3, 87.0):
+        assert abs(np.float32(e(x)) - np.float32(np.exp(np.float64(x)))) <= np.spacing(np.float32(np.exp(np.float64(x))))
+    for x in (2.0, 0.5, 1e-30, 3e38, 1.0000001, 1e-40):
+        assert abs(np.float32(l(x)) - np.float32(np.log(np.float64(np.float32(x))))) <= np.spacing(abs(np.float32(np.log(np.float64(np.float32(x))))))
+
+
+def _both(xs):
+    o = oracle.load()
+    n = len(xs)
+    fp = C.POINTER(C.c_float)
+    xs = np.ascontiguousarray(xs, np.float32)
+    e, l, sel = np.empty(n, np.float32), np.empty(n, np.float32), np.empty((6, n), np.float32)
+    o.ora_glibc_vec.argtypes = [C.c_uint64, fp, fp, fp]
+    o.ora_glibc_vec(n, xs.ctypes.data_as(fp), e.ctypes.data_as(fp), l.ctypes.data_as(fp))
+    o.ora_math_selftest.argtypes = [C.c_uint64, fp, fp, fp]
+    o.ora_math_selftest(n, xs.ctypes.data_as(fp), xs.ctypes.data_as(fp), sel.ctypes.data_as(fp))
+    return e, l, sel[0], sel[1]  # glibc exp, glibc ln|x|, contract exp, contract ln|x|
+
+
+def test_the_contract_functions_stay_within_one_ulp_of_the_restatement_where_sinkhorn_uses_them():
+    # rp_expf / rp_logf (the build's contract, include/rp_math.h) against the restated glibc functions on the Sinkhorn's domain:
+    # exp of [-40, 0] (kernel entries, potentials), ln of (1e-30, 4]
+    rng = np.random.default_rng(5)
+    ge, _, ce, _ = _both((-40.0 * rng.random(200000)).astype(np.float32))
+    assert _ulps(ge, ce).max() <= 1
+    xs = np.exp(rng.uniform(np.log(1e-30), np.log(4.0), 200000)).astype(np.float32)
+    _, gl, _, cl = _both(xs)
+    near_one = np.abs(xs - 1.0) < 0.05  # results near 0: an ulp of the result is far below what the input's own rounding is worth
+    assert _ulps(gl, cl)[~near_one].max() <= 1
+    assert np.abs(gl - cl)[near_one].max() <= 2.0**-23
+
+
+@needs_glibc
+def test_oracle_on_the_restatement_equals_the_oracle_on_the_platform_libm():
+    from lloyd_fixtures import flop_like_points, smooth_metric
+
+    o = oracle.load()
+    o.ora_lloyd_set_libm.argtypes = [C.c_int]
+    bins, n = 64, 60
+    tri = smooth_metric(bins, 3)
+    pts = flop_like_points(2 * n, bins=bins, mass=30, seed=11).astype(np.uint32)
+    try:
+        o.ora_lloyd_set_libm(1)
+        a = [oracle.sinkhorn_trace(x, y, tri, bins=bins)[:2] for x, y in zip(pts[:n], pts[n:])]
+        o.ora_lloyd_set_libm(2)
+        b = [oracle.sinkhorn_trace(x, y, tri, bins=bins)[:2] for x, y in zip(pts[:n], pts[n:])]
+    finally:
+        o.ora_lloyd_set_libm(0)
+    assert [(np.float32(c).tobytes(), i) for c, i in a] == [(np.float32(c).tobytes(), i) for c, i in b]
+
+
+def test_tables_recompute():
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "glibc_tables.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
