@@ -20,9 +20,11 @@
  *   powf   IS the build's contract: t^1.5 and t^0.5 are per-epoch scalars, computed on the host with rp_glibc_powf and handed to the
  *          kernels as parameters (rp_pow15 / rp_pow05 below) — DCFR's discounts are those of a Rust build on glibc, bit for bit
  *          (the earlier t * sqrt(t) differed from powf in the last bit on 24 % of the epochs).
- *   exp/ln the device contract stays include/rp_math.h's rp_expf / rp_logf (f32 only, <= 1 ulp from these: tests/test_libm_glibc.py;
- *          cheaper in the softmin loops); the oracle can run on the restated functions instead (ora_lloyd_set_libm(2), equal to
- *          the platform's libm = mode 1) to state what the difference is worth.
+ *   exp/ln the DEFAULT device arithmetic stays include/rp_math.h's rp_expf / rp_logf (f32 only, <= 1 ulp from these:
+ *          tests/test_libm_glibc.py; cheaper in the softmin loops); every lloyd kernel is also compiled on THESE functions
+ *          (csrc/lloyd_kernels.hpp, namespace lm_glibc; rp_kmeans_set_libm / rp_sinkhorn_set_libm), and the oracle runs on them under
+ *          ora_lloyd_set_libm(2) (equal to the platform's libm = mode 1): the checker of that pass, and the measure of what the
+ *          default's <= 1 ulp is worth.
  */
 #ifndef RP_LIBM_GLIBC_H
 #define RP_LIBM_GLIBC_H

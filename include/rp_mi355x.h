@@ -490,6 +490,20 @@ RP_API int rp_kmeans_init_centroids(rp_kmeans* h, uint64_t* chosen);
  * partition_point (include/rp_refrng.h).  Single GPU: the running sums span all N points in order, so the sharded k-means++
  * (rp_kmeans_kpp_* composed across ranks) keeps the fixed-point draw.  `seed` is not used in this mode. */
 RP_API int rp_kmeans_set_rng(rp_kmeans* h, rp_rng_kind kind, int street);
+/* Which exp / ln the Sinkhorn distances compute with.
+ *   RP_LIBM_CONTRACT  (default) include/rp_math.h's rp_expf / rp_logf: f32 only, packed and pipelined in the softmin loops,
+ *                     <= 1 ulp from glibc's on the Sinkhorn's domain.
+ *   RP_LIBM_GLIBC     glibc's expf / logf as a Rust build on Linux calls them (f32::exp / f32::ln, sinkhorn.rs:115,120-127,136;
+ *                     phi.rs:36), restated in include/rp_libm_glibc.h (equal to glibc 2.35's on all 2^32 inputs) and evaluated in
+ *                     double on the device: every distance, bound, drift and bucket is the reference's, bit for bit, at a few
+ *                     times the cost (every kernel that evaluates exp / ln exists in both arithmetics: csrc/lloyd_kernels.hpp).
+ * What the default's <= 1 ulp is worth is measured (costs within 7 ulps, no k-means++ pick and no bucket moves). */
+typedef enum rp_libm_kind { RP_LIBM_CONTRACT = 0, RP_LIBM_GLIBC = 1 } rp_libm_kind;
+/* a layer: call before the first centroid exists (recomputes the points' self costs; the k-means++ column bound and the MFMA
+ * bound, whose margins are validated for the contract's arithmetic, are switched off: the layer runs unpruned).  One way only. */
+RP_API int rp_kmeans_set_libm(rp_kmeans* h, rp_libm_kind kind);
+/* the three stand-alone operators (rp_sinkhorn_divergence / _cost / _flow): process-wide */
+RP_API int rp_sinkhorn_set_libm(rp_libm_kind kind);
 /* install centroids = copies of the given points (TestLayer-style explicit seeding, tests.rs:100-102) */
 RP_API int rp_kmeans_set_centroids(rp_kmeans* h, const uint64_t* point_index);
 /* install / read one centroid as an integer histogram (counts[bins] u32): resume, and the multi-GPU
@@ -567,14 +581,6 @@ RP_API int rp_kmeans_step_local(rp_kmeans* h, void* partial_dev);
 RP_API int rp_kmeans_step_finish(rp_kmeans* h, const void* reduced_dev, float* drift, uint64_t* sizes,
                                  double* reassigned);
 
-/* Which exp / ln the three stand-alone operators below compute with (process-wide, default RP_LIBM_CONTRACT).
- *   RP_LIBM_CONTRACT  include/rp_math.h's rp_expf / rp_logf: f32 only, what the clustering kernels use, <= 1 ulp from libm.
- *   RP_LIBM_GLIBC     glibc's expf / logf as a Rust build on Linux calls them (f32::exp / f32::ln, sinkhorn.rs:115,120-127,136;
- *                     phi.rs:36), restated in include/rp_libm_glibc.h (equal to glibc 2.35's on all 2^32 inputs) and evaluated in
- *                     double on the device: a solve is the reference's, bit for bit, at a few times the cost.
- * The k-means handle has no such mode: what the <= 1 ulp is worth there is measured (no pick, no bucket moves). */
-typedef enum rp_libm_kind { RP_LIBM_CONTRACT = 0, RP_LIBM_GLIBC = 1 } rp_libm_kind;
-RP_API int rp_sinkhorn_set_libm(rp_libm_kind kind);
 /* Sinkhorn::divergence (sinkhorn.rs:166-171) / Metric::emd for P independent pairs:
  * mu[P*bins], nu[P*bins] u32 counts (host), out[P].  One wavefront per pair. */
 RP_API int rp_sinkhorn_divergence(uint32_t bins, uint64_t pairs, const uint32_t* mu, const uint32_t* nu,

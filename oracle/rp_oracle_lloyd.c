@@ -40,8 +40,8 @@
  * phi.rs:36); the clustering kernels' contract is rp_expf / rp_logf (include/rp_math.h: <= 1 ulp from glibc's, host == device).  ora_lloyd_set_libm(1)
  * makes THIS oracle call the platform's expf / logf instead — the reference's arithmetic on this machine — so that tests can state what
  * the boundary is worth: how many Sinkhorn costs change and by how much, whether any k-means++ pick or bucket moves
- * (tests/test_oracle_lloyd.py::test_platform_libm_*).  Mode 2 = glibc's functions restated: what the device's stand-alone Sinkhorn
- * operators compute under rp_sinkhorn_set_libm(RP_LIBM_GLIBC), checked against this oracle in that mode. */
+ * (tests/test_oracle_lloyd.py::test_platform_libm_*).  Mode 2 = glibc's functions restated: what the device's lm_glibc pass computes
+ * (rp_kmeans_set_libm / rp_sinkhorn_set_libm with RP_LIBM_GLIBC), checked against this oracle in that mode. */
 #define ORA_API __attribute__((visibility("default")))
 static int g_libm = 0;
 ORA_API void ora_lloyd_set_libm(int on) { g_libm = on; }

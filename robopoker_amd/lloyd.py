@@ -59,6 +59,12 @@ class Layer:
         (layer.rs:155-178); street = the Street discriminant hashed into the seed (1 = Flop)"""
         _lib.check(self._lib.rp_kmeans_set_rng(self._h, _lib.RNG[kind], street))
 
+    def set_libm(self, kind: str):
+        """``"glibc"``: every exp / ln of the layer's Sinkhorn distances is glibc's ``expf`` / ``logf`` (what ``f32::exp`` / ``f32::ln``
+        are in a Rust build on Linux), evaluated in double on the device: distances, bounds, drift and buckets are the reference's
+        bit for bit.  Before the first centroid; unpruned and a few times slower than the default f32 contract."""
+        _lib.check(self._lib.rp_kmeans_set_libm(self._h, LIBM[kind]))
+
     def init_centroids(self) -> np.ndarray:
         chosen = np.zeros(self.K, dtype=np.uint64)
         _lib.check(self._lib.rp_kmeans_init_centroids(self._h, _p(chosen)))

@@ -197,8 +197,8 @@ static inline u32x2_t buf_load64(rsrc r, int voff, int soff) {
 
 #define EMU_SITE (__LINE__)
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...)                                                   \
-    ::emu::launch_lambda(dim3(grid), dim3(block), (size_t)(shmem), #kern, [emu_args = std::make_tuple(__VA_ARGS__)]() { \
-        std::apply([](auto... emu_a) { kern(emu_a...); }, emu_args);                                               \
+    ::emu::launch_lambda(dim3(grid), dim3(block), (size_t)(shmem), #kern, [=, emu_args = std::make_tuple(__VA_ARGS__)]() { \
+        std::apply([&](auto... emu_a) { kern(emu_a...); }, emu_args);                                               \
     })
 
 #define __syncthreads() ::emu::syncthreads()

@@ -1,9 +1,11 @@
-"""GPU parity of the glibc-arithmetic mode of the stand-alone Sinkhorn operators (rp_sinkhorn_set_libm(RP_LIBM_GLIBC)).
+"""GPU parity of the glibc-arithmetic pass of the lloyd kernels: a whole layer (rp_kmeans_set_libm(RP_LIBM_GLIBC)) and the stand-alone
+Sinkhorn operators (rp_sinkhorn_set_libm(RP_LIBM_GLIBC)).
 
 In this mode exp / ln are glibc's expf / logf (include/rp_libm_glibc.h, equal to glibc 2.35's on all 2^32 inputs:
 tests/test_libm_glibc.py), i.e. what f32::exp / f32::ln are in a Rust build on Linux (sinkhorn.rs:115,120-127,136; phi.rs:36).
 The checker is the oracle on the same restated functions (ora_lloyd_set_libm(2)), which on a glibc host IS the oracle on the
-platform's libm (mode 1).  Bit-exact: costs, iteration counts, divergences, the flow matrix.
+platform's libm (mode 1).  Bit-exact: k-means++ picks, bounds, drift, sizes, buckets, lookup distances and the layer's metric;
+costs, iteration counts, divergences and the flow matrix of single solves.
 
 Added after round 4's GPU minutes were spent: run on the wave64 execution model (tests/test_emul.py) before its first hardware
 run, and kept in a file of its own, collected last, so a surprise here cannot hide the tests that have run on hardware."""
@@ -104,3 +106,76 @@ def test_the_mode_differs_from_the_contract_by_ulps_and_switches_back(gpu):
     with pytest.raises(Exception):
         from robopoker_amd import _lib
         _lib.check(_lib.load().rp_sinkhorn_set_libm(7))
+
+
+def _layer_pair(K, N, bins, mass, seed, iters):
+    pts = flop_like_points(N, bins=bins, mass=mass, seed=seed)
+    tri = smooth_metric(bins, seed)
+    hp = oracle.default_sinkhorn()
+    hp.iterations = iters
+    dev = lloyd.Layer(K, pts, "sinkhorn", tri, hp=hp, seed=seed)
+    dev.set_libm("glibc")
+    return dev, oracle.OracleKmeans(K, pts, "sinkhorn", tri, hp=hp, seed=seed)
+
+
+def _check_state(dev, ora):
+    j1, u1, l1 = dev.bounds()
+    j2, u2, l2 = ora.bounds()
+    assert np.array_equal(j1, j2), "assignments differ"
+    assert np.array_equal(bits(u1), bits(u2)), "upper bounds differ"
+    assert np.array_equal(bits(l1), bits(l2)), "lower bounds differ"
+    c1, w1 = dev.centroids()
+    c2, w2 = ora.centroids()
+    assert np.array_equal(c1, c2) and np.array_equal(w1, w2), "centroids differ"
+
+
+@pytest.fixture()
+def oracle_on_glibc(gpu):
+    o = oracle.load()
+    o.ora_lloyd_set_libm.argtypes = [C.c_int]
+    o.ora_lloyd_set_libm(2)
+    yield
+    o.ora_lloyd_set_libm(0)
+
+
+@pytest.mark.parametrize("K,N,bins,mass,rng", [(5, 150, 32, 20, "counter"), (70, 200, 48, 24, "counter"), (12, 300, 32, 20, "reference")])
+def test_a_layer_clustered_in_glibc_arithmetic_equals_the_oracle(oracle_on_glibc, K, N, bins, mass, rng):
+    # Layer::cluster (layer.rs:200-240) with every exp / ln glibc's: k-means++ (counter draw, or layer.rs:155-178's own SmallRng +
+    # WeightedIndex), init_bounds, four Elkan iterations, lookup, metric, rms — the grouped (four / two points per wavefront)
+    # kernels included, the two bound filters off
+    dev, ora = _layer_pair(K, N, bins, mass, seed=K + N, iters=16)
+    if rng == "reference":
+        dev.set_rng("reference", 1)
+        ora.set_rng("reference", 1)
+    assert np.array_equal(dev.init_centroids(), ora.init_centroids()), "k-means++ picks differ"
+    dev.init_bounds()
+    ora.init_bounds()
+    _check_state(dev, ora)
+    for _ in range(4):
+        d1, s1, m1 = dev.step()
+        d2, s2, m2 = ora.step()
+        assert np.array_equal(bits(d1), bits(d2)), "drift differs"
+        assert np.array_equal(s1, s2) and m1 == m2
+        _check_state(dev, ora)
+    b1, dd1 = dev.lookup()
+    b2, dd2 = ora.assign()
+    assert np.array_equal(b1, b2) and np.array_equal(bits(dd1), bits(dd2))
+    assert np.array_equal(bits(dev.metric()), bits(ora.metric()))
+    assert bits(dev.rms()) == bits(ora.rms())
+
+
+def test_the_layer_mode_is_set_before_the_first_centroid_and_stays(gpu):
+    pts = flop_like_points(64, bins=32, mass=20, seed=4)
+    tri = smooth_metric(32, 4)
+    dev = lloyd.Layer(4, pts, "sinkhorn", tri, seed=4)
+    dev.init_centroids()
+    with pytest.raises(Exception):
+        dev.set_libm("glibc")  # centroids exist: their tables are in the other arithmetic
+    dev = lloyd.Layer(4, pts, "sinkhorn", tri, seed=4)
+    dev.set_libm("glibc")
+    dev.set_libm("glibc")      # idempotent
+    with pytest.raises(Exception):
+        dev.set_libm("contract")
+    var = lloyd.Layer(4, pts, "variation", seed=4)
+    var.set_libm("glibc")      # no exp / ln on the variation path: accepted, nothing changes
+    var.init_centroids()
