@@ -72,6 +72,9 @@ def parse():
                     help="k-means measurement in the `kmeans` object: the FULL flop-street configuration (default: BASELINE "
                          "configs[2], 1 286 792 x 32 Elkan iterations with k-means++, init_bounds and lookup, ~1.5 min), one "
                          "GPU's share of configs[4] (turn), or a bounded flop-layer slice (~10 s)")
+    ap.add_argument("--kmeans-libm", default="contract", choices=["contract", "glibc"],
+                    help="glibc: additionally time the k-means slice in the lm_glibc pass of the kernels (rp_kmeans_set_libm: the "
+                         "reference's own libm arithmetic, unpruned) and report it beside the contract pass; opt-in")
     ap.add_argument("--window", type=int, default=None,
                     help="N > 1: local steps per exchange (the composed maps of `window` consecutive steps are folded "
                          "locally and all-gathered once; 1 = exchange every step).  Default: 4 on several GPUs (the periodic "
@@ -364,6 +367,17 @@ def kmeans_secondary(args):
 
     out = lloyd.bench_slice() if args.kmeans == "slice" else lloyd.bench_full(args.kmeans)
     centroids = out.pop("_centroids", None)
+    if args.kmeans_libm == "glibc":
+        try:
+            small = lloyd.bench_slice(n_points=4096, iters=1)
+            gl = lloyd.bench_slice(n_points=4096, iters=1, libm="glibc")
+            out["glibc_pass"] = {"points_per_sec": gl["value"], "contract_points_per_sec": small["value"], "unit": "points/s",
+                                 "init_bounds_points_per_sec": gl["init_bounds_points_per_sec"],
+                                 "contract_init_bounds_points_per_sec": small["init_bounds_points_per_sec"],
+                                 "workload": "flop-layer slice N=4096, K=256, bins=256: one Elkan iteration after init_bounds, the contract pass "
+                                             "(pruned) beside the lm_glibc pass (unpruned)"}
+        except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
+            out["glibc_pass"] = {"error": f"{type(exc).__name__}: {exc}"}
     if args.cpu_seconds > 0:
         out["cpu_baseline"] = lloyd.cpu_baseline_slice(oracle, seconds=min(args.cpu_seconds, 8.0))
         if centroids is not None:

@@ -17,9 +17,10 @@
  *
  * What this is for: it pins the last third-party boundary (exp / ln of the lloyd path, powf of DiscountedRegret) to a published
  * algorithm, like include/rp_refrng.h does for the hash and the generator.
- *   powf   IS the build's contract: t^1.5 and t^0.5 are per-epoch scalars, computed on the host with rp_glibc_powf and handed to the
- *          kernels as parameters (rp_pow15 / rp_pow05 below) — DCFR's discounts are those of a Rust build on glibc, bit for bit
- *          (the earlier t * sqrt(t) differed from powf in the last bit on 24 % of the epochs).
+ *   powf   IS the build's contract: t^1.5 and t^0.5 are per-epoch scalars, computed on the host (rp_pow15 = rp_glibc_powf(t, 1.5),
+ *          rp_pow05 = sqrtf(t): what LLVM makes of the two calls, see below) and handed to the kernels as parameters — DCFR's
+ *          discounts are those of a Rust build on glibc, bit for bit (the earlier t * sqrt(t) differed from powf(t, 1.5) in the last
+ *          bit on 24 % of the epochs).
  *   exp/ln the DEFAULT device arithmetic stays include/rp_math.h's rp_expf / rp_logf (f32 only, <= 1 ulp from these:
  *          tests/test_libm_glibc.py; cheaper in the softmin loops); every lloyd kernel is also compiled on THESE functions
  *          (csrc/lloyd_kernels.hpp, namespace lm_glibc; rp_kmeans_set_libm / rp_sinkhorn_set_libm), and the oracle runs on them under
@@ -172,8 +173,14 @@ RP_HD float rp_glibc_powf(float x, float y) {
     return (float)e;
 }
 
-/* DiscountedRegret's two powers (discounted.rs:33,37) of t = epoch as f32, t >= 1 */
+/* DiscountedRegret's two powers (discounted.rs:33,37) of t = epoch as f32, t >= 1, as a build of the reference computes them.  Rust's
+ * f32::powf is the llvm.pow.f32 intrinsic, and the exponents are associated consts (discounted.rs:12-13), so at the workspace's
+ * opt-level = 3 (Cargo.toml: dev AND release) LLVM's libcall simplifier sees pow(x, 0.5) and pow(x, 1.5):
+ *   pow(x, 0.5) -> fabs(sqrt(x)), with -inf -> +inf   (replacePowWithSqrt: no fast-math flag needed on the errno-free intrinsic;
+ *                                                      checked with this image's LLVM: `sqrtss`, no call)  = sqrtf(t) for t >= 1
+ *   pow(x, 1.5) -> stays a call to libm's powf        (the n + 0.5 expansion needs `afn`)                   = glibc's powf
+ * glibc's powf(t, 0.5) would differ from sqrtf(t) in the last bit on 11 294 of the first 2^24 epochs. */
 RP_HD float rp_pow15(float t) { return rp_glibc_powf(t, 1.5f); }
-RP_HD float rp_pow05(float t) { return rp_glibc_powf(t, 0.5f); }
+RP_HD float rp_pow05(float t) { return sqrtf(t); }
 
 #endif /* RP_LIBM_GLIBC_H */

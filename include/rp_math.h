@@ -247,8 +247,9 @@ RP_HD float rp_div_by_recip64(float a, double rd) { return (float)((double)a * r
 RP_HD int rp_div_by_recip_ok(float a) { return a == 0.0f || rp_absf(a) >= 8.6736174e-19f; /* 2^-60 */ }
 
 /* powf(t, 1.5) and powf(t, 0.5) of DiscountedRegret's ALPHA / BETA (crates/mccfr/src/regret/discounted.rs:12-13,33,37) are
- * per-epoch scalars: the HOST computes them with glibc's powf restated (include/rp_libm_glibc.h: rp_pow15 / rp_pow05) and hands
- * them to the kernels as parameters; there is no device powf. */
+ * per-epoch scalars: the HOST computes them as a build of the reference does (include/rp_libm_glibc.h: rp_pow15 = glibc's powf
+ * restated, rp_pow05 = sqrtf, which is what LLVM makes of pow(x, 0.5)) and hands them to the kernels as parameters; there is no
+ * device powf. */
 
 /* ---------------------------------------------------------------- RNG ----
  * The reference builds a fresh SmallRng per sampled node from

@@ -19,8 +19,9 @@
  * (DefaultHasher / SmallRng / WeightedIndex / random_range / random::<f32>(), flow.rs:285-295) is third-party but published:
  * include/rp_refrng.h restates it and pins it to the published vectors (tests/test_refrng.py); ora_mccfr_set_rng(RP_RNG_REFERENCE)
  * draws every sampled branch through it ("reference-seed" mode; the default keeps include/rp_math.h's counter hash, same
- * structure: one hash per (epoch, info, tree)).  DiscountedRegret's powf (discounted.rs:33,37) is glibc's, restated in
- * include/rp_libm_glibc.h and equal to this machine's powf on every positive float for both exponents (tests/test_libm_glibc.py).
+ * structure: one hash per (epoch, info, tree)).  DiscountedRegret's powers (discounted.rs:33,37) are what a build of the reference
+ * computes: powf(t, 1.5) = glibc's powf, restated in include/rp_libm_glibc.h and equal to this machine's on every positive float
+ * (tests/test_libm_glibc.py); powf(t, 0.5) = sqrt(t), LLVM's fold of pow(x, 0.5) at the workspace's opt-level 3.
  *
  * f32 operation order follows the reference expression by expression (sums fold left from 0 in
  * `choices()` order; petgraph's newest-edge-first adjacency over children pushed in reverse pop order
@@ -398,8 +399,8 @@ static float regret_accumulate(int kind, float acc, float imm, uint64_t epoch) {
         case RP_REGRET_DISCOUNTED: {
             float p = 1.0f;
             float x;
-            if (acc > 0.0f) x = rp_glibc_powf(t / p, 1.5f); /* (t / p).powf(ALPHA): glibc's powf restated (rp_libm_glibc.h) */
-            else if (acc < 0.0f) x = rp_glibc_powf(t / p, 0.5f);
+            if (acc > 0.0f) x = rp_pow15(t / p);      /* (t / p).powf(ALPHA): a call to libm's powf = glibc's, restated (rp_libm_glibc.h) */
+            else if (acc < 0.0f) x = rp_pow05(t / p); /* (t / p).powf(BETA): LLVM folds pow(x, 0.5) into sqrt(x) at opt-level 3 */
             else x = t / p;
             float discount = x / (x + 1.0f);
             return acc * discount + imm;

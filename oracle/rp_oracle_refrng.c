@@ -117,3 +117,5 @@ ORA_API uint64_t ora_libm_glibc_pow_sweep(uint64_t lo, uint64_t hi, float y, uin
     return bad;
 }
 ORA_API float ora_glibc_powf(float x, float y) { return rp_glibc_powf(x, y); }
+ORA_API float ora_pow15(float t) { return rp_pow15(t); }
+ORA_API float ora_pow05(float t) { return rp_pow05(t); }

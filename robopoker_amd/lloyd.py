@@ -318,7 +318,7 @@ def smoke(oracle) -> None:
     dev.close()
 
 
-def bench_slice(n_points: int = 16384, K: int = 256, bins: int = 256, iters: int = 2, seed: int = 0xF10F):
+def bench_slice(n_points: int = 16384, K: int = 256, bins: int = 256, iters: int = 2, seed: int = 0xF10F, libm: str = "contract"):
     """points/sec of Elkan iterations on a bounded slice of the flop-street configuration (BASELINE configs[2]):
     K = 256 centroids, 256-bin histograms of mass 47, Sinkhorn T=0.025 / <=128 iterations / tol 5e-4.
 
@@ -329,6 +329,8 @@ def bench_slice(n_points: int = 16384, K: int = 256, bins: int = 256, iters: int
     pts = flop_like_points(n_points, bins=bins, mass=47, seed=seed)
     tri = smooth_metric(bins, 1)
     layer = Layer(K, pts, "sinkhorn", tri, seed=seed)
+    if libm != "contract":
+        layer.set_libm(libm)  # the lm_glibc pass of the kernels, unpruned (the rooflines below are the contract pass's)
     rng = np.random.default_rng(seed)
     layer.set_centroids(rng.choice(n_points, size=K, replace=False).astype(np.uint64))
     t0 = time.perf_counter()

@@ -78,9 +78,37 @@ def test_powf_on_other_exponents_over_a_stride_of_the_floats():
         assert a.tobytes() == b.tobytes(), (float(x), float(y))
 
 
+def test_llvm_folds_pow_half_into_sqrt_and_leaves_pow_three_halves_a_libm_call():
+    # f32::powf is the llvm.pow.f32 intrinsic (no errno); BETA = 0.5 and ALPHA = 1.5 are consts (discounted.rs:12-13) and the
+    # workspace builds at opt-level 3 in dev and release: LLVM's libcall simplifier rewrites pow(x, 0.5) as fabs(sqrt(x)) (with
+    # -inf -> +inf) WITHOUT any fast-math flag, and leaves pow(x, 1.5) to libm.  Checked with this image's LLVM on the same IR shape.
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    import os
+    if not os.path.exists(clang):
+        pytest.skip("no clang in this image")
+    src = "float p05(float x){ return __builtin_powf(x, 0.5f); }\nfloat p15(float x){ return __builtin_powf(x, 1.5f); }\n"
+    r = subprocess.run([clang, "--target=x86_64-unknown-linux-gnu", "-O2", "-fno-math-errno", "-S", "-x", "c", "-", "-o", "-"],
+                       input=src, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    asm = r.stdout
+    p05 = asm[asm.index("p05:") : asm.index("p15:")]
+    p15 = asm[asm.index("p15:") :]
+    assert "sqrtss" in p05 and "powf" not in p05
+    assert "powf" in p15
+    # ... and that is how the oracle and the library compute the two powers (include/rp_libm_glibc.h: rp_pow05 / rp_pow15)
+    o = oracle.load()
+    for f in (o.ora_pow05, o.ora_pow15, o.ora_glibc_powf):
+        f.restype = C.c_float
+    o.ora_pow05.argtypes = o.ora_pow15.argtypes = [C.c_float]
+    o.ora_glibc_powf.argtypes = [C.c_float, C.c_float]
+    t = np.arange(1, 1 << 14, dtype=np.float32)
+    assert all(np.float32(o.ora_pow05(float(x))) == np.sqrt(x) for x in t)
+    assert all(o.ora_pow15(float(x)) == o.ora_glibc_powf(float(x), 1.5) for x in t[::7])
+
+
 def test_the_old_contract_differed_from_powf_on_a_quarter_of_the_epochs():
-    # why the powers moved from t * sqrt(t) to glibc's powf (round 4): over t = 1 .. 2^20 the two differ in the last bit for ~24 %
-    # of the epochs at 1.5 (two roundings against one) and for a few at 0.5 — a Rust build on glibc follows powf
+    # why t^1.5 moved from t * sqrt(t) to glibc's powf (round 4): over t = 1 .. 2^16 the two differ in the last bit for ~24 %
+    # of the epochs (two roundings against one) — a Rust build on glibc follows powf there
     o = oracle.load()
     f = o.ora_glibc_powf
     f.argtypes, f.restype = [C.c_float, C.c_float], C.c_float
