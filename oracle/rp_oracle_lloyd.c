@@ -97,7 +97,7 @@ static float sinkhorn_cost(uint32_t bins, const ora_hist* mu, const ora_hist* nu
 /* x-major sum of coupling * distance (sinkhorn.rs:206-217) for the potentials (lhs, rhs) */
 static float coupling_cost(const float* tri, const uint32_t* sx, uint32_t m, const uint32_t* sy, uint32_t n,
                            const float* lhs, const float* rhs, float T) {
-    float cost = 0.0f;
+    float cost = -0.0f; /* Iterator::sum::<f32>() folds from -0.0 (libcore iter/traits/accum.rs since Rust 1.83; the workspace asks for 1.90) */
     for (uint32_t i = 0; i < m; ++i)
         for (uint32_t j = 0; j < n; ++j) {
             float c = raw_distance(tri, sx[i], sy[j]);
@@ -117,7 +117,7 @@ static float sinkhorn_cost_traced(uint32_t bins, const ora_hist* mu, const ora_h
         if (nu->counts[i] > 0) sy[n++] = i;
     }
     if (iters_out) *iters_out = 0;
-    if (m == 0 || n == 0) return 0.0f; /* empty support: the cost sum is empty */
+    if (m == 0 || n == 0) return -0.0f; /* empty support: the cost sum is empty, and an empty f32 sum is -0.0 */
     float lhs[ORA_MAXBINS], rhs[ORA_MAXBINS], nxt[ORA_MAXBINS];
     /* Potential::uniform (phi.rs:34-39): ln(1 / n()) on the support */
     float lu = ora_logf(1.0f / (float)m), ru = ora_logf(1.0f / (float)n);

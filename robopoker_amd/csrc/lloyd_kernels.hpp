@@ -252,7 +252,7 @@ __device__ __forceinline__ float softmin_sum(const uint16_t* sup, const float* p
 
 __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint32_t n, const Metric& M) {
     const uint32_t lane = lane_id();
-    if (m == 0 || n == 0) return 0.0f;  // empty support: the cost sum is empty
+    if (m == 0 || n == 0) return -0.0f;  // empty support: the cost sum is empty, and f32's Sum folds from -0.0 (libcore since 1.83)
     const uint32_t bins = M.bins;
     const __amdgpu_buffer_rsrc_t rt = rt_resource(M);
     const float lu = LM_LOGF(1.0f / (float)m), ru = LM_LOGF(1.0f / (float)n);  // Potential::uniform (phi.rs:34-39)
@@ -301,7 +301,7 @@ __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint
         atomicAdd(STAT(M, 2), (unsigned long long)(2 * t + 1) * m * n);
     }
     // cost(): x-major left fold of coupling * distance (sinkhorn.rs:206-217)
-    float cost = 0.0f;
+    float cost = -0.0f;  // .sum::<Energy>() folds from -0.0 (sinkhorn.rs:216; same result unless the sum is empty)
     for (uint32_t i = 0; i < m; ++i) {
         const uint32_t x = w.supA[i];
         const float fi = w.f[i];
@@ -366,7 +366,7 @@ __device__ __forceinline__ void wave_sinkhorn_costG(GroupLds<G>& w, uint32_t m, 
     const uint32_t bins = M.bins;
     const __amdgpu_buffer_rsrc_t rt = rt_resource(M);
 #pragma unroll
-    for (uint32_t h = 0; h < G; ++h) cost_out[h] = 0.0f;
+    for (uint32_t h = 0; h < G; ++h) cost_out[h] = -0.0f;
     if (m == 0) return;
     bool active[G];
     uint32_t iters_done[G];
@@ -479,7 +479,7 @@ __device__ __forceinline__ void wave_sinkhorn_costG(GroupLds<G>& w, uint32_t m, 
         atomicAdd(STAT(M, 2), exps);
     }
     // cost(): A-major left fold of coupling * distance (sinkhorn.rs:206-217), one solve per lane group
-    float cost = 0.0f;
+    float cost = -0.0f;  // .sum::<Energy>() folds from -0.0 (sinkhorn.rs:216; same result unless the sum is empty)
     if (centroid_is_A) {
         for (uint32_t i = 0; i < m; ++i) {
             const uint32_t x = w.supC[i];

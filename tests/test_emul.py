@@ -37,7 +37,8 @@ SELECTION = [
                                        " or (test_a_layer_clustered_in_glibc_arithmetic and (5-150 or reference)) or test_the_layer_mode_is_set"),
     # Path B: wave-cooperative Sinkhorn, Elkan iterations with remembered pairwise entries
     ("tests/test_gpu_lloyd.py", "(test_sinkhorn_random_pairs_bit_exact and 32-5-9) or test_sinkhorn_fixture_bit_exact"
-                                " or (test_elkan_iterations_bit_exact and sinkhorn-5-150) or test_equity_variation_bit_exact"),
+                                " or (test_elkan_iterations_bit_exact and sinkhorn-5-150) or test_equity_variation_bit_exact"
+                                " or test_empty_histogram_costs_zero or (test_layer_shape_corners_bit_exact and sinkhorn-65-130)"),
 ]
 
 

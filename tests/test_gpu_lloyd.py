@@ -58,6 +58,14 @@ def test_empty_histogram_costs_zero(gpu):
     tri = flop_metric()
     d = lloyd.sinkhorn_divergence(flop_hist([]), flop_hist([(2, 2), (8, 5)]), tri)
     assert d[0] == 0.0
+    # the raw cost of an empty support is an EMPTY f32 sum (sinkhorn.rs:211-216), which libcore folds from -0.0 since Rust 1.83
+    # (the workspace asks for 1.90): sign bit set; the divergence's x - 0.5 xx - 0.5 yy and .max(0.0) bring +0.0 back
+    empty, some = flop_hist([]), flop_hist([(2, 2), (8, 5)])
+    c, it = lloyd.sinkhorn_cost(np.stack([empty, some, empty]), np.stack([some, empty, empty]), tri)
+    assert [int(x) for x in bits(c)] == [0x80000000] * 3
+    assert bits(c[0]) == bits(oracle.sinkhorn_cost(empty, some, tri)[0])
+    d = lloyd.sinkhorn_divergence(np.stack([empty, empty]), np.stack([some, empty]), tri)
+    assert [int(x) for x in bits(d)] == [0, 0]
 
 
 def test_equity_variation_bit_exact(gpu):
