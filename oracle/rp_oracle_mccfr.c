@@ -413,6 +413,10 @@ static float regret_accumulate(int kind, float acc, float imm, uint64_t epoch) {
     }
     return acc + imm;
 }
+/* RegretSchedule::accumulate as a pure function (known answers for the reference: scripts/make_reference_kat.py) */
+__attribute__((visibility("default"))) float ora_regret_accumulate(int kind, float acc, float imm, uint64_t epoch) {
+    return regret_accumulate(kind, acc, imm, epoch);
+}
 static float regret_floor(const ora_mccfr* h) {
     if (h->R == RP_REGRET_FLOORED) return 0.0f;
     if (h->R == RP_REGRET_SUMMED) return rp_u2f(0xff800000u);
