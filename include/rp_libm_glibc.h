@@ -115,10 +115,18 @@ RP_HD float rp_glibc_logf(float x) {
     return (float)y;
 }
 
-/* powf(x, y) for 0 < x < inf and finite y != 0 — the domain DiscountedRegret uses (t^1.5, t^0.5 with t = epoch as f32;
- * crates/mccfr/src/regret/discounted.rs:33,37).  e_powf.c: log2(x) in double from a 16-entry table (the same 1/c as logf's, with
- * log2 c = RN(-log2(1/c)): recomputed by scripts/glibc_tables.py) and a quartic, times y, then 2^(.) through expf's table.
- * Negative x, zeros, infinities and NaNs take e_powf.c's special-case ladder, which is not restated: NaN is returned for them. */
+/* powf(x, y), all of e_powf.c: log2(x) in double from a 16-entry table (the same 1/c as logf's, with log2 c = RN(-log2(1/c)): recomputed
+ * by scripts/glibc_tables.py) and a quartic, times y, then 2^(.) through expf's table; in front of it the special-case ladder (zeros,
+ * infinities, NaNs, negative bases with integer exponents).  DiscountedRegret uses t^1.5 with t = epoch as f32 (discounted.rs:33) —
+ * epoch 0 included: powf(+0, 1.5) = +0, a discount of 0. */
+RP_HD int rp_glibc_checkint(uint32_t iy) { /* 0: not an integer, 1: odd, 2: even */
+    const int e = (int)((iy >> 23) & 0xffu);
+    if (e < 0x7f) return 0;
+    if (e > 0x7f + 23) return 2;
+    if (iy & ((1u << (0x7f + 23 - e)) - 1u)) return 0;
+    if (iy & (1u << (0x7f + 23 - e))) return 1;
+    return 2;
+}
 RP_HD float rp_glibc_powf(float x, float y) {
     const double LT[16][2] = {
         {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2}, {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},
@@ -131,10 +139,33 @@ RP_HD float rp_glibc_powf(float x, float y) {
     const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1, SHIFT = 0x1.8p+52 / 32.0;
     uint32_t ix = rp_f2u(x);
     const uint32_t iy = rp_f2u(y);
-    if (ix == 0u || ix >= 0x7f800000u || (iy << 1) == 0u || (iy << 1) >= 0xff000000u) return rp_u2f(0x7fc00000u);
-    if (ix < 0x00800000u) { /* subnormal x: normalise so that the exponent goes negative */
-        ix = rp_f2u(x * 0x1p23f);
-        ix -= 23u << 23;
+    uint64_t sign_bias = 0;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || 2u * iy - 1u >= 2u * 0x7f800000u - 1u) {
+        /* x < 0x1p-126, inf or NaN; or y is 0, inf or NaN */
+        if (2u * iy - 1u >= 2u * 0x7f800000u - 1u) {
+            if (2u * iy == 0u) return 2u * (ix ^ 0x00400000u) > 2u * 0x7fc00000u ? x + y : 1.0f; /* x^0 = 1 unless x is a signalling NaN */
+            if (ix == 0x3f800000u) return 2u * (iy ^ 0x00400000u) > 2u * 0x7fc00000u ? x + y : 1.0f; /* 1^y = 1, likewise */
+            if (2u * ix > 2u * 0x7f800000u || 2u * iy > 2u * 0x7f800000u) return x + y; /* NaN in, NaN out */
+            if (2u * ix == 2u * 0x3f800000u) return 1.0f;                               /* (-1)^(+-inf) */
+            if ((2u * ix < 2u * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;       /* |x| < 1, y = inf or |x| > 1, y = -inf */
+            return y * y;
+        }
+        if (2u * ix - 1u >= 2u * 0x7f800000u - 1u) { /* x is 0, inf or NaN */
+            float x2 = x * x;
+            if ((ix & 0x80000000u) && rp_glibc_checkint(iy) == 1) x2 = -x2;
+            return (iy & 0x80000000u) ? 1.0f / x2 : x2;
+        }
+        if (ix & 0x80000000u) { /* finite x < 0 */
+            const int yint = rp_glibc_checkint(iy);
+            if (yint == 0) return rp_u2f(0x7fc00000u) /* invalid */;
+            if (yint == 1) sign_bias = 1ull << (5 + 11);
+            ix &= 0x7fffffffu;
+        }
+        if (ix < 0x00800000u) { /* subnormal x: normalise so that the exponent goes negative */
+            ix = rp_f2u(rp_u2f(ix) * 0x1p23f);
+            ix &= 0x7fffffffu;
+            ix -= 23u << 23;
+        }
     }
     /* log2(x) = log1p(z / c - 1) / ln2 + log2(c) + k */
     const uint32_t tmp = ix - 0x3f330000u;
@@ -154,8 +185,8 @@ RP_HD float rp_glibc_powf(float x, float y) {
     yy = fma(yy, r4, q);
     const double ylogx = (double)y * yy; /* cannot overflow: y is single precision */
     if (((rp_d2u(ylogx) >> 47) & 0xffffu) >= (rp_d2u(126.0) >> 47)) { /* |y log2 x| >= 126 */
-        if (ylogx > 0x1.fffffffd1d571p+6) return rp_u2f(0x7f800000u); /* overflow */
-        if (ylogx <= -150.0) return 0.0f;                              /* underflow */
+        if (ylogx > 0x1.fffffffd1d571p+6) return rp_u2f(sign_bias ? 0xff800000u : 0x7f800000u); /* overflow */
+        if (ylogx <= -150.0) return rp_u2f(sign_bias ? 0x80000000u : 0u);                          /* underflow */
     }
     /* 2^(y log2 x): x = k/N + r, |r| <= 1/(2N) */
     double kd = ylogx + SHIFT;
@@ -163,7 +194,7 @@ RP_HD float rp_glibc_powf(float x, float y) {
     kd -= SHIFT;
     const double rr = ylogx - kd;
     uint64_t t = rp_glibc_exp2f_tab((uint32_t)ki);
-    t += ki << (52 - 5);
+    t += (ki + sign_bias) << (52 - 5);
     const double s = rp_u2d(t);
     const double zz = fma(C0, rr, C1);
     const double rr2 = rr * rr;

@@ -100,7 +100,7 @@ ORA_API void ora_glibc_vec(uint64_t n, const float* x, float* e, float* l) {
         l[i] = rp_glibc_logf(x[i] < 0 ? -x[i] : x[i]);
     }
 }
-/* rp_glibc_powf(x, y) against this machine's powf for every positive finite float x in bit range [lo, hi) */
+/* rp_glibc_powf(x, y) against this machine's powf for every float x in bit range [lo, hi) (both NaN counts as equal) */
 ORA_API uint64_t ora_libm_glibc_pow_sweep(uint64_t lo, uint64_t hi, float y, uint32_t* first) {
     uint64_t bad = 0;
     uint32_t fb = 0xffffffffu;
@@ -108,7 +108,7 @@ ORA_API uint64_t ora_libm_glibc_pow_sweep(uint64_t lo, uint64_t hi, float y, uin
     for (long long b = (long long)lo; b < (long long)hi; ++b) {
         const float x = rp_u2f((uint32_t)b);
         const float a = rp_glibc_powf(x, y), c = powf(x, y);
-        if (rp_f2u(a) != rp_f2u(c)) {
+        if (rp_f2u(a) != rp_f2u(c) && !(a != a && c != c)) {
             bad += 1;
             if ((uint32_t)b < fb) fb = (uint32_t)b;
         }

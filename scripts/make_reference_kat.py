@@ -58,7 +58,7 @@ def dcfr_cases(o):
     g = o.ora_glibc_powf
     g.argtypes, g.restype = [C.c_float, C.c_float], C.c_float
     DISCOUNTED = 2
-    epochs = [1, 2, 3, 5, 7, 10, 100, 1000, 12345, 1 << 20]
+    epochs = [0, 1, 2, 3, 5, 7, 10, 100, 1000, 12345, 1 << 20]  # 0: the first step (powf(+0, 1.5) = +0: the discount is 0)
     # the first epochs where the three candidate arithmetics part: powf(t, 1.5) != t * sqrt(t), and glibc powf(t, 0.5) != sqrt(t)
     t, found15, found05 = 2, [], []
     while (len(found15) < 3 or len(found05) < 3) and t < 1 << 22:

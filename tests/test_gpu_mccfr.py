@@ -19,6 +19,8 @@ pytestmark = pytest.mark.gpu
 
 def assert_tables_equal(a: np.ndarray, b: np.ndarray):
     for f in ("visits", "regret", "weight", "payoff"):
+        if a[f].dtype.kind == "f":  # equal bits would also be equal NaNs: a table never holds one
+            assert not np.isnan(a[f]).any(), f"NaN in {f}"
         assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), f"{f} differs bitwise"
 
 

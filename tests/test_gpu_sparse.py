@@ -13,6 +13,8 @@ FIELDS = ("weight", "regret", "payoff", "visits")
 
 def same(a, b):
     for f in FIELDS:
+        if a[f].dtype.kind == "f":  # equal bits would also be equal NaNs: a table never holds one
+            assert not np.isnan(a[f]).any(), f"{f}: NaN in the table"
         assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), f"{f}: {np.count_nonzero(a[f].view(np.uint32) != b[f].view(np.uint32))} cells differ"
 
 
