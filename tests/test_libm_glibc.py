@@ -203,3 +203,33 @@ def test_oracle_on_the_restatement_equals_the_oracle_on_the_platform_libm():
 def test_tables_recompute():
     r = subprocess.run([sys.executable, str(ROOT / "scripts" / "glibc_tables.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_regret_schedules_against_a_float64_restatement():
+    # RegretSchedule::accumulate (regret/{summed,linear,discounted,floored,asymmetric}.rs) written again in float64 from the Rust
+    # sources, epochs 0 .. 2000 and the three signs of the accumulated regret: the oracle (f32, glibc's powf / sqrt) within 2e-6
+    # relative — an error of kind (a NaN clamped to the floor, a wrong branch) would be orders of magnitude away
+    o = oracle.load()
+    f = o.ora_regret_accumulate
+    f.argtypes, f.restype = [C.c_int, C.c_float, C.c_float, C.c_uint64], C.c_float
+    SUMMED, LINEAR, DISCOUNTED, FLOORED, ASYMMETRIC = 0, 1, 2, 3, 4
+    from robopoker_amd import _lib
+    assert (_lib.REGRET["summed"], _lib.REGRET["linear"], _lib.REGRET["discounted"], _lib.REGRET["floored"], _lib.REGRET["asymmetric"]) == (
+        SUMMED, LINEAR, DISCOUNTED, FLOORED, ASYMMETRIC)
+
+    def ref(kind, acc, imm, t):
+        t = float(t)
+        if kind in (SUMMED, FLOORED):
+            return acc + imm
+        if kind == LINEAR:
+            return acc * (t / (t + 1.0)) + imm
+        if kind == ASYMMETRIC:
+            return acc + imm if acc > 0 else acc * (t / (t + 1.0)) + imm
+        x = t**1.5 if acc > 0 else (t**0.5 if acc < 0 else t)
+        return acc * (x / (x + 1.0)) + imm
+
+    for kind in (SUMMED, LINEAR, DISCOUNTED, FLOORED, ASYMMETRIC):
+        for t in list(range(0, 40)) + [100, 999, 2000, 1 << 20]:
+            for acc in (0.0, 1.0, -1.0, 250.0, -3.75e5):
+                got, want = f(kind, acc, 0.625, t), ref(kind, acc, 0.625, t)
+                assert np.isfinite(got) and abs(got - want) <= 2e-6 * max(1.0, abs(want)), (kind, t, acc, got, want)
