@@ -13,14 +13,8 @@ echo "== 2 default bench"; date +%T
 timeout 330 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err; head -c 400 $OUT/${TAG}_bench_line.json; echo
 echo "== 3 nlhe bench"; date +%T
 timeout 200 python bench.py --workload nlhe --cpu-seconds 8 --steps 8 --warmup 4 > $OUT/${TAG}_nlhe_bench_line.json 2> $OUT/nlhe.err; head -c 300 $OUT/${TAG}_nlhe_bench_line.json; echo
-echo "== 3b k-means slice in both arithmetic passes (lm_contract beside lm_glibc)"; date +%T
-timeout 240 python bench.py --steps 2 --warmup 1 --cpu-seconds 0 --kmeans slice --kmeans-libm glibc > $OUT/${TAG}_glibc_pass_line.json 2> $OUT/glibc.err; python - <<PY
-import json
-try:
-    print(json.dumps(json.load(open("$OUT/${TAG}_glibc_pass_line.json")).get("kmeans", {}).get("glibc_pass"), indent=1))
-except Exception as e:
-    print("glibc pass line unreadable:", e)
-PY
+echo "== 3b the lloyd kernels' two arithmetic passes (lm_contract beside lm_glibc), same unpruned solves"; date +%T
+timeout 120 python scripts/glibc_pass_timing.py 16384 > $OUT/${TAG}_glibc_pass_timing.json 2> $OUT/glibc.err; cat $OUT/${TAG}_glibc_pass_timing.json
 echo "== 4 kernel trace + PMC of the Leduc loop"; date +%T
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$REPO
