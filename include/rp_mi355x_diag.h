@@ -19,6 +19,11 @@ RP_API int rp_math_selftest(int device, uint64_t n, const float* x, const float*
  * contract's spec sequence (rp_expf_spec): mismatches[0] rp_expf, [1] rp_exp_floor vs max(spec, MIN_POSITIVE),
  * [2] rp_exp_floor2 (packed), [3] smallest mismatching bit pattern (~0 if none).  All counts must be 0. */
 RP_API int rp_math_exp_sweep(int device, uint64_t* mismatches);
+/* include/rp_libm_glibc.h's expf / logf evaluated ON THE DEVICE over the f32 bit patterns [lo, hi) (a multiple of 65536 of them; the
+ * whole range is [0, 2^32)): sums[0] = sum of expf's result bits, [1] = sum of result bits x (2 u + 1) for input pattern u, [2], [3]
+ * the same for logf; wrapping u64 arithmetic, NaN results counted as 0x7fc00000.  A host evaluation of the same header gives the
+ * same four numbers iff the two agree on every input (tests/test_gpu_z_glibc_mode.py). */
+RP_API int rp_libm_glibc_sweep(int device, uint64_t lo, uint64_t hi, uint64_t* sums);
 /* The device-wide primitives under the row-addressed profile and the isomorphism enumeration (csrc/sortscan.hpp: stable LSD
  * radix sort of (key, index) pairs by the low `bits` bits of the key, run-length encoding of the sorted keys, exclusive
  * scan), run on n host keys so a test can compare them with a host sort: sorted_keys / perm [n]; uniq / starts / counts

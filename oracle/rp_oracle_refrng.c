@@ -119,3 +119,23 @@ ORA_API uint64_t ora_libm_glibc_pow_sweep(uint64_t lo, uint64_t hi, float y, uin
 ORA_API float ora_glibc_powf(float x, float y) { return rp_glibc_powf(x, y); }
 ORA_API float ora_pow15(float t) { return rp_pow15(t); }
 ORA_API float ora_pow05(float t) { return rp_pow05(t); }
+/* the four checksums of rp_libm_glibc_sweep (include/rp_mi355x_diag.h), computed on the host */
+ORA_API void ora_libm_glibc_checksums(uint64_t lo, uint64_t hi, uint64_t* sums) {
+    uint64_t se = 0, we = 0, sl = 0, wl = 0;
+#pragma omp parallel for reduction(+ : se, we, sl, wl) schedule(static)
+    for (long long b = (long long)lo; b < (long long)hi; ++b) {
+        const uint32_t u = (uint32_t)b;
+        const float x = rp_u2f(u);
+        const float e = rp_glibc_expf(x), l = rp_glibc_logf(x);
+        const uint64_t be = e != e ? 0x7fc00000u : rp_f2u(e), bl = l != l ? 0x7fc00000u : rp_f2u(l);
+        const uint64_t odd = 2ull * u + 1ull;
+        se += be;
+        we += be * odd;
+        sl += bl;
+        wl += bl * odd;
+    }
+    sums[0] = se;
+    sums[1] = we;
+    sums[2] = sl;
+    sums[3] = wl;
+}

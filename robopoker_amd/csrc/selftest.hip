@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../../include/rp_math.h"
+#include "../../include/rp_libm_glibc.h"
 #include "rp_internal.h"
 #include "sortscan.hpp"
 
@@ -49,7 +50,51 @@ __global__ void k_exp_sweep(unsigned long long* bad) {
     if (b2) atomicAdd(&bad[2], b2);
     if (first != 0xffffffffu) atomicMin(&bad[3], (unsigned long long)first);
 }
+
+// include/rp_libm_glibc.h on the device: order-independent checksums of expf and logf over the bit patterns [lo, lo + 256 * threads)
+// (thread t takes lo + 256 t .. + 255): sums of the result bits and of the result bits times the odd number 2 u + 1 of the input,
+// NaN results canonicalised (which payload an x + x keeps is the hardware's business).  The host computes the same four numbers.
+__global__ void k_glibc_sweep(uint64_t lo, unsigned long long* acc) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long se = 0, we = 0, sl = 0, wl = 0;
+    for (uint32_t k = 0; k < 256; ++k) {
+        const uint32_t u = (uint32_t)(lo + t * 256u + k);
+        const float x = rp_u2f(u);
+        const float e = rp_glibc_expf(x), l = rp_glibc_logf(x);
+        const uint64_t be = e != e ? 0x7fc00000u : rp_f2u(e), bl = l != l ? 0x7fc00000u : rp_f2u(l);
+        const uint64_t odd = 2ull * u + 1ull;
+        se += be;
+        we += be * odd;
+        sl += bl;
+        wl += bl * odd;
+    }
+    atomicAdd(&acc[0], se);
+    atomicAdd(&acc[1], we);
+    atomicAdd(&acc[2], sl);
+    atomicAdd(&acc[3], wl);
+}
 }  // namespace rp
+
+extern "C" int rp_libm_glibc_sweep(int device, uint64_t lo, uint64_t hi, uint64_t* sums) {
+    if (!sums || hi <= lo || hi > (1ull << 32) || ((hi - lo) & 0xffffull)) return rp::fail(RP_ERR_INVALID, "rp_libm_glibc_sweep: the range must be a multiple of 65536 bit patterns inside [0, 2^32]");
+    if (rp_device_count() <= 0) return rp::fail(RP_ERR_NO_DEVICE, "rp_libm_glibc_sweep: no HIP device");
+#define GL_TRY(e)                                                                                   \
+    do {                                                                                            \
+        hipError_t _e = (e);                                                                        \
+        if (_e != hipSuccess) return rp::fail(RP_ERR_HIP, "%s failed: %s", #e, hipGetErrorString(_e)); \
+    } while (0)
+    GL_TRY(hipSetDevice(device));
+    unsigned long long* d = nullptr;
+    GL_TRY(hipMalloc(&d, 32));
+    GL_TRY(hipMemset(d, 0, 32));
+    hipLaunchKernelGGL(rp::k_glibc_sweep, dim3((unsigned)((hi - lo) >> 16)), dim3(256), 0, 0, lo, d);
+    GL_TRY(hipGetLastError());
+    unsigned long long out[4];
+    GL_TRY(hipMemcpy(out, d, 32, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    for (int i = 0; i < 4; ++i) sums[i] = out[i];
+    return RP_OK;
+}
 
 extern "C" int rp_math_selftest(int device, uint64_t n, const float* x, const float* y, float* out) {
     if (!x || !y || !out || n == 0) return rp::fail(RP_ERR_INVALID, "rp_math_selftest: bad argument");
