@@ -233,3 +233,15 @@ def test_regret_schedules_against_a_float64_restatement():
             for acc in (0.0, 1.0, -1.0, 250.0, -3.75e5):
                 got, want = f(kind, acc, 0.625, t), ref(kind, acc, 0.625, t)
                 assert np.isfinite(got) and abs(got - want) <= 2e-6 * max(1.0, abs(want)), (kind, t, acc, got, want)
+
+
+def test_the_committed_checksums_are_the_hosts():
+    # tests/golden/glibc_checksums.json is what the GPU's evaluation of the header is compared with (tests/test_gpu_z_glibc_mode.py)
+    import json
+
+    o = oracle.load()
+    o.ora_libm_glibc_checksums.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    want = json.load(open(ROOT / "tests" / "golden" / "glibc_checksums.json"))
+    host = (C.c_uint64 * 4)()
+    o.ora_libm_glibc_checksums(want["range"][0], want["range"][1], host)
+    assert [hex(x) for x in host] == want["sums"]
