@@ -8,7 +8,8 @@ platform's libm (mode 1).  Bit-exact: k-means++ picks, bounds, drift, sizes, buc
 costs, iteration counts, divergences and the flow matrix of single solves.
 
 Written against the wave64 execution model (tests/test_emul.py) when round 4's GPU minutes were all but spent; first hardware run
-with the last of them: 12 passed (this file + tests/test_reference_kat.py, profiles/r04_glibc_pass_first_hw_run.log), and the pass
+with the last of them: all passed (this file + tests/test_reference_kat.py, profiles/r04_glibc_pass_first_hw_run.log; the 2^32 sweep
+in profiles/r04_glibc_device_sweep.txt), and the pass
 costs 2.3 x the contract's on the same unpruned solves (profiles/r04_glibc_pass_timing.json)."""
 import ctypes as C
 
