@@ -26,6 +26,8 @@ if which == "synthetic":
     N, K, bins = int(os.environ.get("RP_AUDIT_N", "1286792")), 256, 256
     pts, tri = flop_like_points(N, bins=bins, mass=47, seed=0xF10F), smooth_metric(256, 1)
     layer = lloyd.Layer(K, pts, "sinkhorn", tri, seed=1)
+    if os.environ.get("RP_AUDIT_LIBM") == "glibc":  # the audit of the bounds in the glibc-arithmetic pass (with RP_LLOYD_GLIBC_PRUNE=1)
+        layer.set_libm("glibc")
     layer.init_centroids()
     layer.init_bounds()
     for it in range(32):

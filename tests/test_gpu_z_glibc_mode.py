@@ -207,3 +207,25 @@ def test_glibc_expf_and_logf_on_the_device_equal_the_host_on_every_float(gpu):
         host = (C.c_uint64 * 4)()
         o.ora_libm_glibc_checksums(lo, hi, host)
         assert list(dev) == list(host), (hex(lo), hex(hi))
+
+
+def test_the_pruned_glibc_pass_equals_the_oracle(oracle_on_glibc, monkeypatch):
+    # RP_LLOYD_GLIBC_PRUNE=1 (a developer switch): the glibc pass keeps the k-means++ column bound and the MFMA bound.  Exactness does
+    # not depend on them as long as every minimiser survives: picks, bounds, an iteration and the lookup against the unpruned oracle,
+    # and the on-device audit (RP_LLOYD_AUDIT: the unpruned search behind every pruned pass) counts no disagreement
+    monkeypatch.setenv("RP_LLOYD_GLIBC_PRUNE", "1")
+    monkeypatch.setenv("RP_LLOYD_AUDIT", "1")
+    dev, ora = _layer_pair(24, 400, 64, 30, seed=31, iters=24)
+    assert np.array_equal(dev.init_centroids(), ora.init_centroids())
+    dev.init_bounds()
+    ora.init_bounds()
+    _check_state(dev, ora)
+    dev.step()
+    ora.step()
+    _check_state(dev, ora)
+    b1, dd1 = dev.lookup()
+    b2, dd2 = ora.assign()
+    assert np.array_equal(b1, b2) and np.array_equal(bits(dd1), bits(dd2))
+    st = dev.prune_stats()
+    assert st["enabled"] == 1 and st["audited_points"] > 0 and st["audit_mismatches"] == 0
+    assert st["survivors"] < st["candidates"]  # it did prune
