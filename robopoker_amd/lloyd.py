@@ -444,7 +444,7 @@ VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2.0
 SOFTMIN_INSTR_PER_8_TERMS = 106  # VALU instructions per 8 softmin terms per lane in the shipped ISA
 
 
-def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None, seed: int = 1, log=None):
+def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None, seed: int = 1, log=None, libm: str = "contract"):
     """A full-size k-means configuration of BASELINE.json on one GPU:
 
     flop (configs[2]): N = 1 286 792 histograms, K = 256, bins = 256, mass 47, Sinkhorn EMD, k-means++,
@@ -473,6 +473,8 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
            "N": N, "K": K, "bins": bins, "distance": kind, "iterations": iters}
     t0 = time.perf_counter()
     layer = Layer(K, pts, kind, tri, seed=seed)
+    if libm != "contract":
+        layer.set_libm(libm)  # the kernels' lm_glibc pass (unpruned unless RP_LLOYD_GLIBC_PRUNE is set)
     out["create_s"] = time.perf_counter() - t0  # upload + point masses + memoised OT(p,p)
     layer.profile(True)
     e0 = layer.exp_evals()
