@@ -13,7 +13,8 @@
  * spelled fma() here, so the functions do not depend on the compiler's contraction.  tests/test_libm_glibc.py sweeps ALL 2^32 float
  * bit patterns of expf and logf against the machine's own libm, and powf over every positive float for DiscountedRegret's two
  * exponents: zero mismatches on glibc 2.35 / x86-64 with FMA (the one fusion that matters is r = x N / ln2 - k in expf: unfused, two
- * of the 2^32 inputs differ in the last bit; logf matches either way).
+ * of the 2^32 inputs differ in the last bit — x = 0x1.04845ep+5 and x = -0x1.f8cbb2p+5, which is what a pre-FMA x86 host would return
+ * there; logf matches either way).
  *
  * What this is for: it pins the last third-party boundary (exp / ln of the lloyd path, powf of DiscountedRegret) to a published
  * algorithm, like include/rp_refrng.h does for the hash and the generator.
