@@ -562,6 +562,11 @@ typedef struct rp_prune_stats {
     uint64_t audit_mismatches; /* ... and how many differed in bucket or distance bits */
     uint64_t sampled_points;   /* the production self-check: every 521st point is searched again WITHOUT the prune after every */
     uint64_t sample_mismatches;/* pruned pass; a mismatch fails the next call that hands results out (RP_ERR_INTERNAL) */
+    /* the second k-means++ filter (csrc/kpp_bound.hpp; layer.rs:170-178 needs d(c_k, x) only where d^2 < potential): */
+    uint64_t kpp_bound_pairs;      /* (new centroid, point) pairs the column-marginal bound let through and the interval examined */
+    uint64_t kpp_bound_kept;       /* ... of which the bit-faithful solve was still run */
+    uint64_t kpp_bound_iterations; /* scaling-domain iterations over all examined pairs */
+    uint64_t kpp_bound_cost_passes;/* cost evaluations inside the stopping windows */
 } rp_prune_stats;
 RP_API int rp_kmeans_prune_stats(rp_kmeans* h, rp_prune_stats* out);
 /* the same with the size of the CALLER's struct: a host compiled against an older (shorter) rp_prune_stats passes its own sizeof

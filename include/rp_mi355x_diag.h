@@ -51,6 +51,10 @@ RP_API int rp_nlhe_census(rp_nlhe* h, uint64_t* kinds4, uint64_t* walker_childre
 
 /* the divergence intervals of the bound against the current centroids: lo[N*K], hi[N*K] (tests / diagnostics) */
 RP_API int rp_kmeans_bound_intervals(rp_kmeans* h, float* lo, float* hi);
+/* the second k-means++ filter (csrc/kpp_bound.hpp): lo[N] = its lower bound of distance(centroid k, point i) (Elkan::neighbor's
+ * centroid-first call, elkan.rs:68-77) for every point, each stopping window followed to its end; 0 where the pair does not fit the
+ * register tile (either support above 48 bins) or no bound was obtained.  Tests compare it with the bit-faithful distances. */
+RP_API int rp_kmeans_kpp_bound_probe(rp_kmeans* h, uint32_t k, float* lo);
 
 RP_API int rp_kmeans_profile(rp_kmeans* h, int enable);
 /* name in {"pairwise","step","recompute","bounds","neighbor","selfcost","kpp","drift","mfma_bound"} */

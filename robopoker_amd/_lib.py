@@ -123,7 +123,8 @@ class PruneStats(C.Structure):
     _fields_ = [("enabled", C.c_uint32), ("reserved", C.c_uint32), ("points", C.c_uint64), ("candidates", C.c_uint64),
                 ("survivors", C.c_uint64), ("block_iterations", C.c_uint64), ("cost_passes", C.c_uint64),
                 ("mfma_instructions", C.c_uint64), ("audited_points", C.c_uint64), ("audit_mismatches", C.c_uint64),
-                ("sampled_points", C.c_uint64), ("sample_mismatches", C.c_uint64)]
+                ("sampled_points", C.c_uint64), ("sample_mismatches", C.c_uint64), ("kpp_bound_pairs", C.c_uint64),
+                ("kpp_bound_kept", C.c_uint64), ("kpp_bound_iterations", C.c_uint64), ("kpp_bound_cost_passes", C.c_uint64)]
 
 
 _SIGNATURES = {
@@ -233,6 +234,7 @@ _SIGNATURES = {
     "rp_kmeans_exp_evals": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rp_kmeans_prune_stats": (C.c_int, [C.c_void_p, C.POINTER(PruneStats)]),
     "rp_kmeans_bound_intervals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rp_kmeans_kpp_bound_probe": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "rp_kmeans_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_kmeans_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "rp_kmeans_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -113,6 +113,13 @@ struct rp_kmeans {
     float* minc = nullptr;        // [bins]
     KppLists kpp{};
     uint64_t kpp_cap[3] = {0, 0, 0};  // points per support class (<= QUAD_ROWS, <= PAIR_ROWS, more): grid bounds
+    // the second k-means++ filter (kpp_bound.hpp): a scaling-domain interval per (new centroid, point) pair the column bound let through
+    bool kb_on = false;
+    KppLists kpp2{};                        // the pairs the solve is still needed for, per support class
+    unsigned int* kb_cursor = nullptr;      // [3] work cursors of the three launches of a round
+    unsigned long long* kb_stats = nullptr; // striped: pairs examined, kept, pair-iterations, cost passes
+    std::vector<uint8_t> ns_host;           // support size of every point (saturated at 255)
+    std::vector<uint32_t> cent_m;           // [K] support size of the centroids installed one at a time (0 = not known on the host)
     // the MFMA bound in front of the neighbor passes (sinkhorn_bound.hpp)
     bool sb_on = false, sb_audit = false;
     SbParams sb{};
@@ -435,7 +442,17 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
             KM_TRY(dev_alloc(h, &h->audit_d, N));
         }
         h->sb_on = true;
+        if (h->kpp_lb && !getenv("RP_LLOYD_NO_KPP_BOUND2")) {  // the second k-means++ filter shares K = exp(-C/T) and the margins
+            for (int c = 0; c < 3; ++c) KM_TRY(dev_alloc(h, &h->kpp2.list[c], (size_t)N + 4));
+            KM_TRY(dev_alloc(h, &h->kpp2.count, 4));
+            KM_TRY(dev_alloc(h, &h->kb_cursor, 4));
+            KM_TRY(dev_alloc(h, &h->kb_stats, (size_t)KM_STAT_STRIPES * STAT_STRIDE));
+            KM_HIP(hipMemset(h->kb_stats, 0, (size_t)KM_STAT_STRIPES * STAT_STRIDE * 8));
+            h->kb_on = true;
+        }
     }
+    h->ns_host = ns;
+    h->cent_m.assign(K, 0u);
     // RP_LLOYD_GROUPING (tests): "none" = one point per wavefront everywhere, "pairs" = no groups of four, "norefresh" = no regrouped
     // refresh pass; every grouping performs the same float operations per solve (tests/test_gpu_lloyd.py)
     const std::string grouping = getenv("RP_LLOYD_GROUPING") ? getenv("RP_LLOYD_GROUPING") : "";
@@ -752,6 +769,7 @@ int rp_kmeans_set_libm(rp_kmeans* h, rp_libm_kind kind) {
     // it like in the contract pass).
     if (!getenv("RP_LLOYD_GLIBC_PRUNE")) {
         h->kpp_lb = false;
+        h->kb_on = false;
         h->sb_on = false;
     }
     if (h->kind == RP_METRIC_SINKHORN) {  // OT(p, p) of every point (sinkhorn.rs:175-191) in the new arithmetic
@@ -776,6 +794,7 @@ int rp_kmeans_kpp_begin(rp_kmeans* h) {
     h->centroids_ready = false;
     h->bounds_ready = false;
     h->pot_is_min_d2 = false;
+    std::fill(h->cent_m.begin(), h->cent_m.end(), 0u);
     return RP_OK;
 }
 
@@ -827,15 +846,46 @@ int rp_kmeans_kpp_update(rp_kmeans* h, uint32_t k) {
         // grids sized for the worst case (every eligible point active); surplus wavefronts leave at once
         const uint64_t cap4 = qrows ? h->kpp_cap[0] : 0, cap2 = prows ? h->kpp_cap[1] + (qrows ? 0 : h->kpp_cap[0]) : 0,
                        cap1 = h->N - cap4 - cap2;
+        const KppLists* todo = &h->kpp;
+        if (h->kb_on) {
+            // the second filter: a scaling-domain interval of each remaining pair (kpp_bound.hpp); the solve runs where the interval's
+            // lower end, squared, is still below the potential.  Two pairs per wavefront while both supports fit 32 lanes.
+            uint32_t m = h->cent_m[k];
+            if (!m) {  // a centroid installed by other means: ask the device
+                HIP_TRY(hipMemcpyAsync(&m, h->cs[h->cur].n + k, 4, hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(hipStreamSynchronize(h->stream));
+            }
+            if (m && m <= 48u) {
+                HIP_TRY(hipMemsetAsync(h->kpp2.count, 0, 16, h->stream));
+                HIP_TRY(hipMemsetAsync(h->kb_cursor, 0, 16, h->stream));
+                int cus = 256;
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+                const uint64_t caps[3] = {cap4, cap2, cap1};
+                for (int c = 0; c < 3; ++c) {
+                    if (!caps[c]) continue;
+                    const bool two = m <= 32u && c < 2;  // classes 0 / 1 hold points with <= 32 bins
+                    const unsigned grid = (unsigned)std::min<uint64_t>((caps[c] + (two ? 1 : 0)) / (two ? 2 : 1), (uint64_t)cus * 16u);
+                    if (two)
+                        hipLaunchKernelGGL((k_kpp_bound<32, 32>), dim3(grid), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
+                                           (const float*)h->pot, (const uint32_t*)h->kpp.list[c], (const unsigned int*)(h->kpp.count + c),
+                                           h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr);
+                    else
+                        hipLaunchKernelGGL((k_kpp_bound<64, 48>), dim3(grid), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
+                                           (const float*)h->pot, (const uint32_t*)h->kpp.list[c], (const unsigned int*)(h->kpp.count + c),
+                                           h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr);
+                }
+                todo = &h->kpp2;
+            }
+        }
         if (cap4)
             hipLaunchKernelGGL(KSEL(h, k_kpp_updateG<4>), dim3((unsigned)((cap4 + 3) / 4)), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->M,
-                               h->kpp.list[0], h->kpp.count + 0, h->pot);
+                               todo->list[0], todo->count + 0, h->pot);
         if (cap2)
             hipLaunchKernelGGL(KSEL(h, k_kpp_updateG<2>), dim3((unsigned)((cap2 + 1) / 2)), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->M,
-                               h->kpp.list[1], h->kpp.count + 1, h->pot);
+                               todo->list[1], todo->count + 1, h->pot);
         if (cap1)
             hipLaunchKernelGGL(KSEL(h, k_kpp_update), dim3((unsigned)cap1), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->K, h->M, h->kind,
-                               h->pot, h->kpp.list[2], h->kpp.count + 2);
+                               h->pot, todo->list[2], todo->count + 2);
     } else {
         if (h->n_pairs || h->n_quads) {
             if (h->n_quads)
@@ -877,6 +927,11 @@ int rp_kmeans_set_centroid(rp_kmeans* h, uint32_t k, const uint32_t* counts) {
     if (!h || !counts || k >= h->K) return rp::fail(RP_ERR_INVALID, "rp_kmeans_set_centroid: bad argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpyAsync(h->hist_stage, counts, (size_t)h->bins * 4, hipMemcpyHostToDevice, h->stream));
+    {
+        uint32_t m = 0;
+        for (uint32_t b = 0; b < h->bins; ++b) m += counts[b] > 0;
+        h->cent_m[k] = m;
+    }
     hipLaunchKernelGGL(k_centroid_from_hist, dim3(1), dim3(256), 0, h->stream, h->cs[h->cur], k, h->hist_stage, h->bins);
     hipLaunchKernelGGL(KSEL(h, k_prepare_centroids), dim3(1), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, k);
     h->memo_dirty = true;
@@ -924,6 +979,7 @@ int rp_kmeans_init_centroids(rp_kmeans* h, uint64_t* chosen) {
         }
         }
         if (chosen) chosen[k] = pick;
+        if (!h->ns_host.empty()) h->cent_m[k] = h->ns_host[pick];
         hipLaunchKernelGGL(k_centroid_from_point, dim3(1), dim3(256), 0, h->stream, h->cs[h->cur], k, h->P, pick, h->bins);
         hipLaunchKernelGGL(KSEL(h, k_prepare_centroids), dim3(1), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, k);
         h->memo_dirty = true;
@@ -1219,6 +1275,51 @@ static int prune_stats_full(rp_kmeans* h, rp_prune_stats* out) {
     out->audit_mismatches = bad[0];
     out->sampled_points = h->sb_sampled;
     out->sample_mismatches = bad[1];
+    if (h->kb_stats) {
+        HIP_TRY(hipMemcpyAsync(all.data(), h->kb_stats, all.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        unsigned long long q4[4] = {0, 0, 0, 0};
+        for (uint32_t q = 0; q < KM_STAT_STRIPES; ++q)
+            for (uint32_t k = 0; k < 4; ++k) q4[k] += all[(size_t)q * STAT_STRIDE + k];
+        out->kpp_bound_pairs = q4[0];
+        out->kpp_bound_kept = q4[1];
+        out->kpp_bound_iterations = q4[2];
+        out->kpp_bound_cost_passes = q4[3];
+    }
+    return RP_OK;
+}
+
+// diagnostics (rp_mi355x_diag.h): the second k-means++ filter's lower bound of distance(centroid k, point i) for EVERY point,
+// against an infinite potential (no early exit); 0 where the pair is outside the register tile or its window did not close
+int rp_kmeans_kpp_bound_probe(rp_kmeans* h, uint32_t k, float* lo) {
+    if (!h || !lo || k >= h->K) return rp::fail(RP_ERR_INVALID, "rp_kmeans_kpp_bound_probe: bad argument");
+    if (!h->kb_on) return rp::fail(RP_ERR_UNSUPPORTED, "rp_kmeans_kpp_bound_probe: the layer has no k-means++ interval filter");
+    HIP_TRY(hipSetDevice(h->device));
+    float *d_lo = nullptr, *d_pot = nullptr;
+    uint32_t* d_list = nullptr;
+    unsigned int* d_ctl = nullptr;
+    const size_t N = (size_t)h->N;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_lo), N * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_pot), N * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_list), (N + 4) * 4 * 2));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ctl), 16));
+    std::vector<uint32_t> ids(N);
+    for (size_t i = 0; i < N; ++i) ids[i] = (uint32_t)i;
+    const unsigned int ctl[4] = {(unsigned int)N, 0u, 0u, 0u};  // [0] count in, [1] cursor, [2] count out
+    HIP_TRY(hipMemcpyAsync(d_list, ids.data(), N * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_ctl, ctl, 16, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(d_lo, 0, N * 4, h->stream));
+    hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, h->stream, d_pot, h->N, -1.0f);  // lo^2 >= -1 always: every window runs to its end
+    hipLaunchKernelGGL((k_kpp_bound<64, 48>), dim3(2048), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
+                       (const float*)d_pot, (const uint32_t*)d_list, (const unsigned int*)d_ctl, d_ctl + 1, d_list + N + 4, d_ctl + 2,
+                       h->kb_stats, d_lo);
+    (void)hipMemcpyAsync(lo, d_lo, N * 4, hipMemcpyDeviceToHost, h->stream);
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_lo);
+    (void)hipFree(d_pot);
+    (void)hipFree(d_list);
+    (void)hipFree(d_ctl);
+    if (e != hipSuccess) return rp::fail(RP_ERR_HIP, "rp_kmeans_kpp_bound_probe: %s", hipGetErrorString(e));
     return RP_OK;
 }
 

@@ -51,6 +51,7 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
 #if !LM_GLIBC  // the MFMA bound and its margins are validated for the contract arithmetic only: the glibc pass runs unpruned
 #include "sinkhorn_bound.hpp"
+#include "kpp_bound.hpp"
 #endif
 
 // Bins::support + Bins::density (bins.rs:58-60,84-88) of a dense histogram into LDS; returns the support size

@@ -62,7 +62,16 @@ def turn_like_points(n: int, bins: int = 101, mass: int = 46, seed: int = 0, spr
 
 
 def flop_like_points(n: int, bins: int = 256, mass: int = 47, seed: int = 0xF10F) -> np.ndarray:
-    """n histograms of `mass` draws over a neighbourhood of s ~ U{8..47} of the `bins` turn buckets."""
+    """n histograms of `mass` draws over a neighbourhood of s ~ U{8..47} of the `bins` turn buckets.
+
+    RP_FIXTURE_CACHE=<dir>: the array is kept there as .npy (the full flop layer takes 30 s of host time to draw; scripts that
+    start several processes on it in one GPU call set this)."""
+    import os
+
+    cache = os.environ.get("RP_FIXTURE_CACHE")
+    path = os.path.join(cache, f"flop_like_{n}_{bins}_{mass}_{seed}.npy") if cache else None
+    if path and os.path.exists(path):
+        return np.load(path)
     rng = np.random.default_rng(seed)
     out = np.zeros((n, bins), dtype=np.uint8)
     centers = rng.integers(0, bins, size=n)
@@ -72,4 +81,8 @@ def flop_like_points(n: int, bins: int = 256, mass: int = 47, seed: int = 0xF10F
         support = (centers[i] + rng.choice(min(bins, 3 * s), size=min(s, bins), replace=False)) % bins
         draws = rng.choice(support, size=mass)
         np.add.at(out[i], draws, 1)
+    if path:
+        tmp = path + f".{os.getpid()}.tmp.npy"
+        np.save(tmp, out)
+        os.replace(tmp, path)
     return out

@@ -167,6 +167,12 @@ class Layer:
         _lib.check(self._lib.rp_kmeans_bound_intervals(self._h, _p(lo), _p(hi)))
         return lo, hi
 
+    def kpp_bound_probe(self, k: int) -> np.ndarray:
+        """lo[N]: the second k-means++ filter's lower bound of distance(centroid k, point i) (rp_mi355x_diag.h)"""
+        lo = np.zeros(self.N, dtype=np.float32)
+        _lib.check(self._lib.rp_kmeans_kpp_bound_probe(self._h, C.c_uint32(k), _p(lo)))
+        return lo
+
     # ---- multi-GPU exchange (SURVEY §8e) --------------------------------------------------------
     def partial_bytes(self) -> int:
         n = C.c_size_t()

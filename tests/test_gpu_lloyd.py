@@ -376,6 +376,59 @@ def test_mfma_bound_intervals_contain_the_oracle(gpu, monkeypatch, N, K, bins, m
     assert st["enabled"] == 1 and st["survivors"] < st["candidates"] // 4
 
 
+@pytest.mark.parametrize("N,K,bins,mass,iters", [(300, 6, 256, 47, None), (200, 5, 64, 20, None), (160, 4, 101, 30, 12)])
+def test_kmeanspp_interval_filter_lower_bounds_hold(gpu, N, K, bins, mass, iters):
+    # the second k-means++ filter (kpp_bound.hpp): for every (point-like centroid, point) pair its lower bound must not exceed the
+    # distance the bit-faithful solve returns (oracle: Sinkhorn::divergence, centroid first as in layer.rs:170-178), and it must be
+    # tight enough to be worth running: within the margin for most pairs
+    pts = flop_like_points(N, bins=bins, mass=mass, seed=N + bins)
+    tri = smooth_metric(bins, K)
+    hp = oracle.default_sinkhorn()
+    if iters:
+        hp.iterations = iters
+    dev = lloyd.Layer(K, pts, "sinkhorn", tri, hp=hp, seed=3)
+    start = np.random.default_rng(N).choice(N, size=K, replace=False).astype(np.uint64)
+    dev.set_centroids(start)
+    tight = []
+    for k in range(K):
+        lo = dev.kpp_bound_probe(k)
+        assert lo.shape == (N,) and np.all(lo >= 0) and np.all(np.isfinite(lo))
+        c = pts[start[k]].astype(np.uint32)
+        exact = np.array([oracle.sinkhorn_divergence(c, pts[i].astype(np.uint32), tri, hp, bins) for i in range(N)], dtype=np.float32)
+        bad = np.flatnonzero(lo > exact)
+        assert bad.size == 0, f"centroid {k}: {bad.size} lower bounds above the exact distance, first {[(lo[i], exact[i]) for i in bad[:3]]}"
+        got = lo > 0
+        tight.append(np.mean((exact[got] - lo[got]) <= 1e-4 + 1e-3 * exact[got]) if got.any() else 0.0)
+        assert got.mean() > 0.5  # a bound for most pairs (0 = no bound: outside the tile, or a window that did not close)
+    assert np.mean(tight) > 0.8, tight
+
+
+def test_kmeanspp_interval_filter_keeps_the_picks(gpu, monkeypatch):
+    # k-means++ with and without the interval filter: identical picks, potentials' consequences (init_bounds from the notes) and buckets;
+    # the filter must actually discard most of what the column bound lets through
+    N, K, bins = 6000, 24, 256
+    pts = flop_like_points(N, bins=bins, mass=47, seed=21)
+    tri = smooth_metric(bins, 1)
+
+    def run(off):
+        monkeypatch.delenv("RP_LLOYD_NO_KPP_BOUND2", raising=False)
+        if off:
+            monkeypatch.setenv("RP_LLOYD_NO_KPP_BOUND2", "1")
+        layer = lloyd.Layer(K, pts, "sinkhorn", tri, seed=4)
+        chosen = np.asarray(layer.init_centroids())
+        layer.init_bounds()
+        j, u, _ = layer.bounds()
+        return chosen, np.asarray(j), np.asarray(u), layer.prune_stats(), layer.stats()[0]
+
+    c0, j0, u0, st0, d0 = run(True)
+    c1, j1, u1, st1, d1 = run(False)
+    assert np.array_equal(c0, c1), "k-means++ picks differ"
+    assert np.array_equal(j0, j1) and np.array_equal(bits(u0), bits(u1))
+    assert st0["kpp_bound_pairs"] == 0 and st1["kpp_bound_pairs"] > 0
+    assert st1["kpp_bound_kept"] < st1["kpp_bound_pairs"] // 2, st1
+    assert d1 < d0  # fewer bit-faithful solves
+
+
 def test_mfma_bound_audit_against_the_unpruned_pass(gpu, monkeypatch):
     # RP_LLOYD_AUDIT=1: every pruned neighbor pass is followed by the unpruned one and compared point by point on the
     # device (the "debug build" of the prune); k-means++ picks, init_bounds, two Elkan iterations, lookup at the
