@@ -567,6 +567,7 @@ typedef struct rp_prune_stats {
     uint64_t kpp_bound_kept;       /* ... of which the bit-faithful solve was still run */
     uint64_t kpp_bound_iterations; /* scaling-domain iterations over all examined pairs */
     uint64_t kpp_bound_cost_passes;/* cost evaluations inside the stopping windows */
+    uint64_t column_iterations;    /* MFMA bound: iterations summed over single centroid columns (a block of 16 runs until its slowest) */
 } rp_prune_stats;
 RP_API int rp_kmeans_prune_stats(rp_kmeans* h, rp_prune_stats* out);
 /* the same with the size of the CALLER's struct: a host compiled against an older (shorter) rp_prune_stats passes its own sizeof

@@ -124,7 +124,8 @@ class PruneStats(C.Structure):
                 ("survivors", C.c_uint64), ("block_iterations", C.c_uint64), ("cost_passes", C.c_uint64),
                 ("mfma_instructions", C.c_uint64), ("audited_points", C.c_uint64), ("audit_mismatches", C.c_uint64),
                 ("sampled_points", C.c_uint64), ("sample_mismatches", C.c_uint64), ("kpp_bound_pairs", C.c_uint64),
-                ("kpp_bound_kept", C.c_uint64), ("kpp_bound_iterations", C.c_uint64), ("kpp_bound_cost_passes", C.c_uint64)]
+                ("kpp_bound_kept", C.c_uint64), ("kpp_bound_iterations", C.c_uint64), ("kpp_bound_cost_passes", C.c_uint64),
+                ("column_iterations", C.c_uint64)]
 
 
 _SIGNATURES = {

@@ -138,6 +138,9 @@ struct rp_kmeans {
     uint8_t* audit_j = nullptr;
     float* audit_d = nullptr;
     float* sb_d = nullptr;
+    uint8_t* sb_crank = nullptr;  // [256] rank of every centroid in the similarity order (centroid_order)
+    bool sb_crank_set = false;
+    bool pairw_seen = false;      // an Elkan step has filled pairw for (nearly) the current centroids
     float* sb_ub0 = nullptr;      // [N] upper bound handed to the bound kernel
     uint8_t* sb_hint_j = nullptr; // [N]
     unsigned long long* sb_hint_mask = nullptr;  // [N][4]
@@ -231,7 +234,7 @@ int prepare_centroids(rp_kmeans* h, int set, bool replaces_other = false) {
     if (h->cver && replaces_other)
         hipLaunchKernelGGL(k_centroid_versions, dim3(h->K), dim3(64), 0, h->stream, h->cs[set], h->cs[set ^ 1], true, h->bins, h->cver);
     else
-        h->memo_dirty = true;
+        h->memo_dirty = true, h->pairw_seen = false;
     ck_begin(h, CK_SELF);
     hipLaunchKernelGGL(KSEL(h, k_prepare_centroids), dim3(h->K), dim3(64), 0, h->stream, h->cs[set], h->K, h->M, h->kind, 0u);
     ck_end(h, CK_SELF);
@@ -427,6 +430,7 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         KM_HIP(hipMemset(h->sb_bad, 0, 16));
         KM_TRY(dev_alloc(h, &h->sb_d, N));
         KM_TRY(dev_alloc(h, &h->sb_ub0, N));
+        KM_TRY(dev_alloc(h, &h->sb_crank, MAXB));
         KM_TRY(dev_alloc(h, &h->sb_hint_j, N));
         KM_TRY(dev_alloc(h, &h->sb_hint_mask, (size_t)N * 4));
         h->sb_audit = getenv("RP_LLOYD_AUDIT") != nullptr;
@@ -542,6 +546,41 @@ int launch_neighbor_full(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init
     return RP_OK;
 }
 
+// An order of the centroids in which neighbours are similar (a nearest-neighbour chain over the last Elkan step's pairwise
+// distances, started at the centroid farthest from centroid 0).  Only the GROUPING of the bound kernel's columns follows it — a block of
+// sixteen columns runs until its slowest one is done, and against one point similar centroids need similar numbers of iterations —
+// never a result.  Without pairwise distances (no Elkan step yet) the centroids keep their index order.
+int centroid_order(rp_kmeans* h) {
+    h->sb_crank_set = false;
+    if (!h->pairw_seen || !h->sb_crank) return RP_OK;
+    const uint32_t K = h->K;
+    std::vector<float> pw((size_t)K * K);
+    HIP_TRY(hipMemcpyAsync(pw.data(), h->pairw, pw.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    auto dist = [&](uint32_t a, uint32_t b) {
+        const float d = pw[(size_t)a * K + b];
+        return d == d ? d : INFINITY;
+    };
+    std::vector<uint8_t> rank(MAXB), used(K, 0);
+    for (uint32_t k = 0; k < MAXB; ++k) rank[k] = (uint8_t)k;
+    uint32_t at = 0;
+    for (uint32_t k = 1; k < K; ++k)
+        if (std::isfinite(dist(0, k)) && (at == 0 || dist(0, k) > dist(0, at))) at = k;
+    for (uint32_t pos = 0; pos < K; ++pos) {
+        used[at] = 1;
+        rank[at] = (uint8_t)pos;
+        uint32_t best = K;
+        for (uint32_t k = 0; k < K; ++k)
+            if (!used[k] && (best == K || dist(at, k) < dist(at, best))) best = k;
+        if (best == K) break;
+        at = best;
+    }
+    HIP_TRY(hipMemcpyAsync(h->sb_crank, rank.data(), MAXB, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));  // `rank` is a local
+    h->sb_crank_set = true;
+    return RP_OK;
+}
+
 // the MFMA bound over every point (one launch per support class), leaving the survivor masks in h->sb_mask
 int launch_bound(rp_kmeans* h, float* dbg_lo, float* dbg_hi, const float* ub0 = nullptr) {
     HIP_TRY(hipMemsetAsync(h->sb_cursor, 0, 16, h->stream));
@@ -552,10 +591,12 @@ int launch_bound(rp_kmeans* h, float* dbg_lo, float* dbg_hi, const float* ub0 = 
     for (int t = 3; t >= 0; --t) {  // the longest-running class first
         const uint32_t n = h->sb_count[t];
         if (!n) continue;
-        const dim3 grid(std::min<uint32_t>(n, (uint32_t)cus)), block(SB_THREADS);
+        const uint32_t per_cu = 1u;  // workgroups a CU holds (registers: 8 wavefronts of up to 256)
+        const dim3 grid(std::min<uint32_t>(n, (uint32_t)cus * per_cu)), block(SB_THREADS);
 #define SB_LAUNCH(NT)                                                                                                      \
     hipLaunchKernelGGL(k_sinkhorn_bound<NT>, grid, block, 0, h->stream, h->P, cs, h->K, h->bins, h->sb, h->sb_list[t], n, \
-                       h->sb_cursor + t, h->sb_mask, dbg_lo, dbg_hi, h->sb_stats, ub0)
+                       h->sb_cursor + t, h->sb_mask, dbg_lo, dbg_hi, h->sb_stats, ub0,                                   \
+                       (const uint8_t*)(h->sb_crank_set ? h->sb_crank : nullptr))
         if (t == 0) SB_LAUNCH(1);
         else if (t == 1) SB_LAUNCH(2);
         else if (t == 2) SB_LAUNCH(3);
@@ -594,8 +635,8 @@ int launch_neighbor(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init, int
             hint_j = h->sb_hint_j;
         }
     }
-    int rc = launch_bound(h, nullptr, nullptr, ub0);
-    if (rc) return rc;
+    int rc = centroid_order(h);
+    if (rc || (rc = launch_bound(h, nullptr, nullptr, ub0))) return rc;
     float* dd = out_d ? out_d : h->sb_d;
     ck_begin(h, CK_NEIGHBOR);
     hipLaunchKernelGGL(KSEL(h, k_neighbor_masked), dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->sb_mask,
@@ -651,6 +692,7 @@ int step_front(rp_kmeans* h) {
         hipLaunchKernelGGL(KSEL(h, k_pairwise), dim3(h->K * h->K), dim3(64), 0, h->stream, h->cs[cur], h->K, h->M, h->kind, h->pairw, h->cver, h->pver);
     hipLaunchKernelGGL(k_midpoints, dim3((h->K + 63) / 64), dim3(64), 0, h->stream, h->pairw, h->K, h->mid);
     ck_end(h, CK_PAIRWISE);
+    h->pairw_seen = true;
     ck_begin(h, CK_STEP);
     if (h->kind == RP_METRIC_VARIATION && h->bins == 101)
         hipLaunchKernelGGL(k_elkan_step_var<101>, dim3((unsigned)((h->N + VB - 1) / VB)), dim3(256), 0, h->stream, h->P, h->cs[cur],
@@ -934,7 +976,7 @@ int rp_kmeans_set_centroid(rp_kmeans* h, uint32_t k, const uint32_t* counts) {
     }
     hipLaunchKernelGGL(k_centroid_from_hist, dim3(1), dim3(256), 0, h->stream, h->cs[h->cur], k, h->hist_stage, h->bins);
     hipLaunchKernelGGL(KSEL(h, k_prepare_centroids), dim3(1), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, k);
-    h->memo_dirty = true;
+    h->memo_dirty = true, h->pairw_seen = false;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));  // `counts` may be a temporary on the caller's side
     h->bounds_ready = false;
@@ -982,7 +1024,7 @@ int rp_kmeans_init_centroids(rp_kmeans* h, uint64_t* chosen) {
         if (!h->ns_host.empty()) h->cent_m[k] = h->ns_host[pick];
         hipLaunchKernelGGL(k_centroid_from_point, dim3(1), dim3(256), 0, h->stream, h->cs[h->cur], k, h->P, pick, h->bins);
         hipLaunchKernelGGL(KSEL(h, k_prepare_centroids), dim3(1), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, k);
-        h->memo_dirty = true;
+        h->memo_dirty = true, h->pairw_seen = false;
         HIP_TRY(hipGetLastError());
         if ((rc = rp_kmeans_kpp_update(h, k))) return rc;
     }
@@ -1262,9 +1304,10 @@ static int prune_stats_full(rp_kmeans* h, rp_prune_stats* out) {
     HIP_TRY(hipMemcpyAsync(all.data(), h->sb_stats, all.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(bad, h->sb_bad, 16, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    unsigned long long s[5] = {0, 0, 0, 0, 0};
+    unsigned long long s[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t q = 0; q < KM_STAT_STRIPES; ++q)
-        for (uint32_t k = 0; k < 5; ++k) s[k] += all[(size_t)q * STAT_STRIDE + k];
+        for (uint32_t k = 0; k < 6; ++k) s[k] += all[(size_t)q * STAT_STRIDE + k];
+    out->column_iterations = s[5];
     out->survivors = s[0];
     out->points = s[1];
     out->candidates = s[1] * h->K;

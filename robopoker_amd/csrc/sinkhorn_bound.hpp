@@ -43,7 +43,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define SB_THREADS 512
 #define SB_KS 264       // ksub  row stride in floats: 264 mod 64 = 8  -> the 16 lanes of a ds_read_b128 group hit 64 banks once
-#define SB_KT 72        // ksubT row stride in floats:  72 mod 64 = 8
 #define SB_MAXROWS 64   // a point with more support bins than this is not pruned (all its centroids go to the exact kernel)
 #define SB_EPS23 1.1920929e-7f
 
@@ -60,10 +59,14 @@ struct SbParams {
     int use_lb0;   // the column-marginal bound is valid for this metric / temperature (max C / T <= 64): sort and drop by it
 };
 
+// LDS per workgroup, sized by the point's support class: NT = 1 / 2 leave room for three / two workgroups per CU (46 / 78 KB of 160),
+// whose wavefronts cover each other's tails; the transposed rows are NT*16 + 8 floats long (== 8 mod 16)
+template <int NT>
 struct __attribute__((aligned(16))) SbLds {
-    float ksub[SB_MAXROWS * SB_KS];  // [y][x] = K[sup_y][x]
-    float ksubT[256 * SB_KT];        // [x][y]
-    float b[SB_MAXROWS];             // nu(sup_y), 0 on the padding rows
+    static constexpr int KT = NT * 16 + 8;
+    float ksub[NT * 16 * SB_KS];  // [y][x] = K[sup_y][x]
+    float ksubT[256 * KT];        // [x][y]
+    float b[SB_MAXROWS];          // nu(sup_y), 0 on the padding rows
     float dlo[256];
     float dhi[256];
     float red[8];
@@ -73,6 +76,8 @@ struct __attribute__((aligned(16))) SbLds {
     uint32_t sup[SB_MAXROWS];
     uint32_t np;
     uint32_t item;
+    uint32_t next;    // the point's next column block (16 of them, taken by whichever wavefront is free)
+    uint8_t crank[256];  // the centroids' place in an order that keeps similar centroids together (ties of lb0 follow it)
 };
 #define SB_LB_SAFETY 0.999f
 #define SB_LB_SLACK 1e-6f
@@ -94,30 +99,54 @@ __device__ __forceinline__ float sb_max4(float x) {
 // One Gauss-Seidel iteration for a block of 16 centroid columns: U <- mu ./ (K V), then V <- nu ./ (K^T U).
 // uo: U of the previous iteration in C/D layout (lane (c, g), register r of tile xt = U[16 xt + 4g + r][column c]);
 // v likewise over the point's rows.  drow = this lane's centroid density row (256 floats, zero off the support).
-template <int NT>
-__device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], const float* __restrict__ drow, const SbLds& L, uint32_t c,
-                                           uint32_t g, float& err, float& sumu, float& umax, float& sumv, float& vmax) {
-    f32x4 racc[NT];
+// The A operands of tile xt + 1 (two ds_read_b128 per y tile) and its densities are requested before tile xt's MFMAs: with two
+// wavefronts per SIMD the LDS round trip is otherwise exposed twice per tile.  The K V chain of a tile is split over two
+// accumulators (its eight MFMAs depend on each other otherwise).  COST: the K .* C contraction of the cost (sb_cost) rides on
+// the second contraction's operands — the same K tile, the same fresh U — and returns the cost of the iterate this call produces.
+template <int NT, bool COST>
+__device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], const float* __restrict__ drow, const SbLds<NT>& L, uint32_t c,
+                                           uint32_t g, float& err, float& sumu, float& umax, float& sumv, float& vmax, float neg_t_ln2,
+                                           float& cost) {
+    f32x4 racc[NT], w[NT];
 #pragma unroll
-    for (int yt = 0; yt < NT; ++yt) racc[yt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int yt = 0; yt < NT; ++yt) {
+        racc[yt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        w[yt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
     float eu = 0.0f, su = 0.0f, mu_ = 0.0f;
+    constexpr int SB_KT = SbLds<NT>::KT;
     const float* kt = &L.ksubT[c * SB_KT + 4 * g];
     const float* ks = &L.ksub[c * SB_KS + 4 * g];
-    f32x4 mnext = *reinterpret_cast<const f32x4*>(drow + 4 * g);
+    f32x4 aS[NT], aR[NT];
+    f32x4 mcur = *reinterpret_cast<const f32x4*>(drow + 4 * g);
+#pragma unroll
+    for (int yt = 0; yt < NT; ++yt) {
+        aS[yt] = *reinterpret_cast<const f32x4*>(kt + yt * 16);
+        aR[yt] = *reinterpret_cast<const f32x4*>(ks + yt * 16 * SB_KS);
+    }
 #pragma unroll
     for (int xt = 0; xt < 16; ++xt) {
-        const f32x4 m0 = mnext;
-        if (xt + 1 < 16) mnext = *reinterpret_cast<const f32x4*>(drow + (xt + 1) * 16 + 4 * g);  // one tile ahead (L2 latency)
-        f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 nS[NT], nR[NT], mnext = mcur;
+        if (xt + 1 < 16) {  // one tile ahead
+            mnext = *reinterpret_cast<const f32x4*>(drow + (xt + 1) * 16 + 4 * g);
+#pragma unroll
+            for (int yt = 0; yt < NT; ++yt) {
+                nS[yt] = *reinterpret_cast<const f32x4*>(kt + (xt + 1) * 16 * SB_KT + yt * 16);
+                nR[yt] = *reinterpret_cast<const f32x4*>(ks + yt * 16 * SB_KS + (xt + 1) * 16);
+            }
+        }
+        f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int yt = 0; yt < NT; ++yt) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(kt + xt * 16 * SB_KT + yt * 16);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s0 = sb_mfma(a0[r], v[yt][r], s0);
+            for (int r = 0; r < 4; ++r) {
+                if ((yt * 4 + r) & 1) s1 = sb_mfma(aS[yt][r], v[yt][r], s1);
+                else s0 = sb_mfma(aS[yt][r], v[yt][r], s0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float u0 = m0[r] * sb_rcp(fmaxf(s0[r], 1e-37f));
+            const float u0 = mcur[r] * sb_rcp(fmaxf(s0[r] + s1[r], 1e-37f));
             eu += fabsf(u0 - uo[xt][r]);
             su += u0;
             mu_ = fmaxf(mu_, u0);
@@ -125,13 +154,26 @@ __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], cons
         }
 #pragma unroll
         for (int yt = 0; yt < NT; ++yt) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ks + yt * 16 * SB_KS + xt * 16);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) racc[yt] = sb_mfma(a0[r], uo[xt][r], racc[yt]);
+            for (int r = 0; r < 4; ++r) {
+                racc[yt] = sb_mfma(aR[yt][r], uo[xt][r], racc[yt]);
+                if (COST) {
+                    const float kc = aR[yt][r] * (neg_t_ln2 * __builtin_amdgcn_logf(aR[yt][r]));
+                    w[yt] = sb_mfma(kc, uo[xt][r], w[yt]);
+                }
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep the tiles apart: hoisting the next tiles' operands costs more registers than the wave has
+        __builtin_amdgcn_sched_barrier(0);  // keep the tiles apart: hoisting further tiles' operands costs more registers than the wave has
+        if (xt + 1 < 16) {
+            mcur = mnext;
+#pragma unroll
+            for (int yt = 0; yt < NT; ++yt) {
+                aS[yt] = nS[yt];
+                aR[yt] = nR[yt];
+            }
+        }
     }
-    float ev = 0.0f, sv = 0.0f, mv = 0.0f;
+    float ev = 0.0f, sv = 0.0f, mv = 0.0f, part = 0.0f;
 #pragma unroll
     for (int yt = 0; yt < NT; ++yt) {
         const f32x4 bq = *reinterpret_cast<const f32x4*>(&L.b[yt * 16 + 4 * g]);
@@ -142,6 +184,7 @@ __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], cons
             sv += vn;
             mv = fmaxf(mv, vn);
             v[yt][r] = vn;
+            if (COST) part += vn * w[yt][r];
         }
     }
     err = sb_sum4(eu) + sb_sum4(ev);
@@ -149,11 +192,12 @@ __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], cons
     sumv = sb_sum4(sv);
     umax = sb_max4(mu_);
     vmax = sb_max4(mv);
+    cost = COST ? sb_sum4(part) : 0.0f;
 }
 
 // cost of the current iterate: sum_y v_y sum_x K[y][x] C[y][x] u_x, with C recovered from K (C = -T ln K)
 template <int NT>
-__device__ __forceinline__ float sb_cost(const f32x4 (&uo)[16], const f32x4 (&v)[NT], const SbLds& L, uint32_t c, uint32_t g,
+__device__ __forceinline__ float sb_cost(const f32x4 (&uo)[16], const f32x4 (&v)[NT], const SbLds<NT>& L, uint32_t c, uint32_t g,
                                          float neg_t_ln2) {
     f32x4 w[NT];
 #pragma unroll
@@ -170,6 +214,7 @@ __device__ __forceinline__ float sb_cost(const f32x4 (&uo)[16], const f32x4 (&v)
                 w[yt] = sb_mfma(kc, uo[xt][r], w[yt]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);  // as in sb_iterate: the tiles' operands are not hoisted over each other
     }
     float part = 0.0f;
 #pragma unroll
@@ -192,18 +237,26 @@ struct SbCol {  // per-column window state (replicated in the four lanes of the 
 // interval is [bound, inf), it cannot be the argmin.
 
 // pstats: [0] survivors, [1] points, [2] column-block iterations, [3] cost passes, [4] MFMA instructions   (striped like Metric::stats)
+// A wavefront runs ONE column block at a time (64 + 12 NT accumulator registers: four wavefronts per SIMD for NT <= 2) and takes the
+// point's next block from an LDS counter when it is done: the sixteen blocks of a point differ in length by a factor of six, and with
+// two or three workgroups on a CU another point's wavefronts fill what a straggler leaves idle.
 template <int NT>
 __global__ __launch_bounds__(SB_THREADS, 2) void k_sinkhorn_bound(Points P, CentroidSet cs, uint32_t K, uint32_t bins, SbParams prm,
                                                                    const uint32_t* list, uint32_t count, unsigned int* cursor,
                                                                    unsigned long long* mask_out, float* dbg_lo, float* dbg_hi,
-                                                                   unsigned long long* pstats, const float* ub0) {
-    __shared__ SbLds L;
+                                                                   unsigned long long* pstats, const float* ub0, const uint8_t* crank) {
+    __shared__ SbLds<NT> L;
+    if (threadIdx.x < 256) L.crank[threadIdx.x] = crank ? crank[threadIdx.x] : (uint8_t)threadIdx.x;
+    constexpr int SB_KT = SbLds<NT>::KT;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t c = lane & 15u, g = lane >> 4;
-    unsigned long long my_cb_iters = 0, my_cost_passes = 0;
+    unsigned long long my_cb_iters = 0, my_cost_passes = 0, my_col_iters = 0;
     for (;;) {
         __syncthreads();  // the previous point's LDS is no longer read
-        if (tid == 0) L.item = atomicAdd(cursor, 1u);
+        if (tid == 0) {
+            L.item = atomicAdd(cursor, 1u);
+            L.next = 0;
+        }
         __syncthreads();
         const uint32_t item = L.item;
         if (item >= count) break;
@@ -267,118 +320,112 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_sinkhorn_bound(Points P, Cent
             L.ub = (u == u && u >= 0.0f) ? __float_as_uint(u) : 0x7f800000u;
         }
         __syncthreads();
-        if (tid < 256) {  // rank sort (256 keys, LDS broadcasts): ties keep centroid order
+        if (tid < 256) {  // rank sort (256 keys, LDS broadcasts): ties follow the similarity order of the centroids — a block of 16
+            // columns iterates until its slowest one is done, and similar centroids take similar numbers of iterations against a point
             const float mine = L.lb0[tid];
+            const uint32_t myr = L.crank[tid];
             uint32_t rank = 0;
             for (uint32_t k = 0; k < 256; ++k) {
                 const float o = L.lb0[k];
-                rank += (o < mine || (o == mine && k < tid)) ? 1u : 0u;
+                rank += (o < mine || (o == mine && (uint32_t)L.crank[k] < myr)) ? 1u : 0u;
             }
             L.perm[rank] = tid;
         }
         __syncthreads();
-        // ---- this wave's 2 x 16 centroid columns: sorted blocks `wave` and 15 - `wave`
-        f32x4 uo0[16], uo1[16], v0[NT], v1[NT];
-        const uint32_t j0 = L.perm[wave * 16 + c], j1 = L.perm[(15 - wave) * 16 + c];
-        const float dlb0_0 = L.lb0[j0], dlb0_1 = L.lb0[j1];
-        const uint32_t jc0 = j0 < K ? j0 : K - 1, jc1 = j1 < K ? j1 : K - 1;
-        const uint32_t mj0 = cs.n[jc0], mj1 = cs.n[jc1];
-        const bool valid0 = j0 < K && mj0 > 0, valid1 = j1 < K && mj1 > 0;
-        const float* drow0 = cs.densR + (size_t)jc0 * 256;
-        const float* drow1 = cs.densR + (size_t)jc1 * 256;
-        {   // Potential::uniform (phi.rs:34-39): exp(lhs) = 1/|supp mu| on the support, exp(rhs) = 1/|supp nu|
-            const float iu0 = 1.0f / (float)(mj0 ? mj0 : 1u), iu1 = 1.0f / (float)(mj1 ? mj1 : 1u), iv = 1.0f / (float)np;
+        // ---- column blocks in ascending bound (the near ones first: their upper bounds are published while the far ones wait)
+        for (;;) {
+            uint32_t blk = 0;
+            if (lane == 0) blk = atomicAdd(&L.next, 1u);
+            blk = __builtin_amdgcn_readfirstlane(blk);
+            if (blk >= 16u) break;
+            f32x4 uo[16], v[NT];
+            const uint32_t j0 = L.perm[blk * 16 + c];
+            const float dlb0 = L.lb0[j0];
+            const uint32_t jc = j0 < K ? j0 : K - 1;
+            const uint32_t mj = cs.n[jc];
+            const bool valid = j0 < K && mj > 0;
+            const float* drow = cs.densR + (size_t)jc * 256;
+            {   // Potential::uniform (phi.rs:34-39): exp(lhs) = 1/|supp mu| on the support, exp(rhs) = 1/|supp nu|
+                const float iu = 1.0f / (float)(mj ? mj : 1u), iv = 1.0f / (float)np;
 #pragma unroll
-            for (int xt = 0; xt < 16; ++xt) {
-                const f32x4 d0 = *reinterpret_cast<const f32x4*>(drow0 + xt * 16 + 4 * g);
-                const f32x4 d1 = *reinterpret_cast<const f32x4*>(drow1 + xt * 16 + 4 * g);
+                for (int xt = 0; xt < 16; ++xt) {
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(drow + xt * 16 + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    uo0[xt][r] = d0[r] > 0.0f ? iu0 : 0.0f;
-                    uo1[xt][r] = d1[r] > 0.0f ? iu1 : 0.0f;
+                    for (int r = 0; r < 4; ++r) uo[xt][r] = d0[r] > 0.0f ? iu : 0.0f;
+                    if (xt & 1) __builtin_amdgcn_sched_barrier(0);
                 }
+#pragma unroll
+                for (int yt = 0; yt < NT; ++yt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[yt][r] = (uint32_t)(yt * 16 + 4 * g + r) < np ? iv : 0.0f;
             }
-#pragma unroll
-            for (int yt = 0; yt < NT; ++yt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float vi = (uint32_t)(yt * 16 + 4 * g + r) < np ? iv : 0.0f;
-                    v0[yt][r] = vi;
-                    v1[yt][r] = vi;
+            SbCol st;
+            uint32_t t_done = 0;  // the iteration count at which this lane's column left the loop (statistics)
+            st.wmin = __builtin_inff();
+            st.wmax = -__builtin_inff();
+            st.nb_prev = SB_EPS23 * (8.0f + 0.37f * (float)np) + SB_EPS23 * 0.37f * (float)mj;
+            st.flatc = 0;
+            st.opened = false;
+            st.done = !valid || dlb0 > __uint_as_float(*(volatile uint32_t*)&L.ub);
+            st.complete = false;
+            const float sc = cs.self[jc];
+            for (uint32_t t = 0; t < prm.iters; ++t) {
+                if (__ballot(!st.done) == 0) break;
+                const bool last = t + 1 == prm.iters;
+                float err, sumu, umax, sumv, vmax, fused = 0.0f;
+                // once a column of the block is inside its stopping window every further iterate's cost is wanted: the cost contraction
+                // then rides on the iteration itself; the first iterate of a window (not known in advance) takes the separate pass below
+                const bool with_cost = __ballot(st.opened && !st.done) != 0;
+                if (with_cost) sb_iterate<NT, true>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused);
+                else sb_iterate<NT, false>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused);
+                my_cb_iters += 1;
+                const float ln2 = 0.6931472f;
+                const float lu = fmaxf(__builtin_amdgcn_logf(umax) * ln2, 0.0f), lv = fmaxf(__builtin_amdgcn_logf(vmax) * ln2, 0.0f);
+                const float nb = SB_EPS23 * (sumu * (lu + 4.0f) + 0.37f * (float)mj + sumv * (lv + 4.0f) + 0.37f * (float)np);
+                const float noise = prm.kappa * (nb + st.nb_prev);
+                st.nb_prev = nb;
+                const bool possible = last || (err - noise < prm.tol * prm.rho);
+                const bool certain = last || ((err + noise) * prm.rho < prm.tol);
+                const bool flat = err <= prm.flat * SB_EPS23 * (sumu + sumv);
+                const bool want = !st.done && (possible || flat);
+                if (__ballot(want)) {  // wave uniform: one more contraction with K .* C for the cost of this iterate
+                    const float cost = with_cost ? fused : sb_cost<NT>(uo, v, L, c, g, prm.neg_t_ln2);
+                    my_cost_passes += 1;
+                    if (want) {
+                        // a non-finite cost (under/overflow of the scaling form) poisons the window: the column survives
+                        st.wmin = cost == cost ? fminf(st.wmin, cost) : -__builtin_inff();
+                        st.wmax = cost == cost ? fmaxf(st.wmax, cost) : __builtin_inff();
+                        st.opened = true;
+                    }
                 }
-        }
-        SbCol st0, st1;
-        const float nb0 = SB_EPS23 * (8.0f + 0.37f * (float)np);
-        st0.wmin = st1.wmin = __builtin_inff();
-        st0.wmax = st1.wmax = -__builtin_inff();
-        st0.nb_prev = nb0 + SB_EPS23 * 0.37f * (float)mj0;
-        st1.nb_prev = nb0 + SB_EPS23 * 0.37f * (float)mj1;
-        st0.flatc = st1.flatc = 0;
-        st0.opened = st1.opened = false;
-        const float ub_start = __uint_as_float(L.ub);
-        st0.done = !valid0 || dlb0_0 > ub_start;
-        st1.done = !valid1 || dlb0_1 > ub_start;
-        st0.complete = st1.complete = false;
-        const float sc0 = cs.self[jc0], sc1 = cs.self[jc1];
-        auto advance = [&](f32x4 (&uo)[16], f32x4 (&v)[NT], const float* drow, SbCol& st, uint32_t mj, bool last, float dlb0, float sc) {
-            float err, sumu, umax, sumv, vmax;
-            sb_iterate<NT>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax);
-            my_cb_iters += 1;
-            const float ln2 = 0.6931472f;
-            const float lu = fmaxf(__builtin_amdgcn_logf(umax) * ln2, 0.0f), lv = fmaxf(__builtin_amdgcn_logf(vmax) * ln2, 0.0f);
-            const float nb = SB_EPS23 * (sumu * (lu + 4.0f) + 0.37f * (float)mj + sumv * (lv + 4.0f) + 0.37f * (float)np);
-            const float noise = prm.kappa * (nb + st.nb_prev);
-            st.nb_prev = nb;
-            const bool possible = last || (err - noise < prm.tol * prm.rho);
-            const bool certain = last || ((err + noise) * prm.rho < prm.tol);
-            const bool flat = err <= prm.flat * SB_EPS23 * (sumu + sumv);
-            const bool want = !st.done && (possible || flat);
-            if (__ballot(want)) {  // wave uniform: one more contraction with K .* C for the cost of this iterate
-                const float cost = sb_cost<NT>(uo, v, L, c, g, prm.neg_t_ln2);
-                my_cost_passes += 1;
-                if (want) {
-                    // a non-finite cost (under/overflow of the scaling form) poisons the window: the column survives
-                    st.wmin = cost == cost ? fminf(st.wmin, cost) : -__builtin_inff();
-                    st.wmax = cost == cost ? fmaxf(st.wmax, cost) : __builtin_inff();
-                    st.opened = true;
+                st.flatc = flat ? st.flatc + 1 : 0;
+                if (!st.done && (certain || st.flatc >= 2)) {
+                    st.done = true;
+                    st.complete = true;
+                    if (st.opened && g == 0) {  // publish this column's upper bound
+                        const float ch = st.wmax + (prm.dc_abs + prm.dc_rel * fabsf(st.wmax));
+                        const float hi = rp_maxf(ch - 0.5f * sc - 0.5f * sp, 0.0f);
+                        if (hi == hi && hi < __builtin_inff()) atomicMin(&L.ub, __float_as_uint(hi));
+                    }
                 }
+                // a column whose rigorous lower bound exceeds a published upper bound cannot be the argmin: stop iterating it
+                if (!st.done && dlb0 > __uint_as_float(*(volatile uint32_t*)&L.ub)) st.done = true;
+                if (!st.done) t_done = t + 1;
             }
-            st.flatc = flat ? st.flatc + 1 : 0;
-            if (!st.done && (certain || st.flatc >= 2)) {
-                st.done = true;
-                st.complete = true;
-                if (st.opened && g == 0) {  // publish this column's upper bound
-                    const float ch = st.wmax + (prm.dc_abs + prm.dc_rel * fabsf(st.wmax));
-                    const float hi = rp_maxf(ch - 0.5f * sc - 0.5f * sp, 0.0f);
-                    if (hi == hi && hi < __builtin_inff()) atomicMin(&L.ub, __float_as_uint(hi));
-                }
-            }
-            // a column whose rigorous lower bound exceeds a published upper bound cannot be the argmin: stop iterating it
-            if (!st.done && dlb0 > __uint_as_float(*(volatile uint32_t*)&L.ub)) st.done = true;
-        };
-        for (uint32_t t = 0; t < prm.iters; ++t) {
-            const bool act0 = __ballot(!st0.done) != 0, act1 = __ballot(!st1.done) != 0;
-            if (!act0 && !act1) break;
-            const bool last = t + 1 == prm.iters;
-            if (act0) advance(uo0, v0, drow0, st0, mj0, last, dlb0_0, sc0);
-            if (act1) advance(uo1, v1, drow1, st1, mj1, last, dlb0_1, sc1);
-        }
-        // ---- intervals of the divergence (sinkhorn.rs:166-171): the same three f32 operations, monotone in the cost
-        auto finish = [&](const SbCol& st, bool valid, uint32_t j, float sc, float dlb0, bool complete) {
+            if (g == 0) my_col_iters += t_done;
+            // ---- interval of the divergence (sinkhorn.rs:166-171): the same three f32 operations, monotone in the cost
             float lo = valid ? dlb0 : 0.0f, hi = __builtin_inff();
-            if (valid && st.opened && complete) {  // a column dropped inside its window keeps [dlb0, inf)
+            if (valid && st.opened && st.complete) {  // a column dropped inside its window keeps [dlb0, inf)
                 const float cl = st.wmin - (prm.dc_abs + prm.dc_rel * fabsf(st.wmin));
                 const float ch = st.wmax + (prm.dc_abs + prm.dc_rel * fabsf(st.wmax));
                 if (cl == cl && cl > -__builtin_inff()) lo = fmaxf(lo, rp_maxf(cl - 0.5f * sc - 0.5f * sp, 0.0f));
                 if (ch == ch) hi = rp_maxf(ch - 0.5f * sc - 0.5f * sp, 0.0f);
             }
-            if (g == 0 && j < 256) {
-                L.dlo[j] = j < K ? lo : __builtin_inff();
-                L.dhi[j] = hi;
+            if (g == 0 && j0 < 256) {
+                L.dlo[j0] = j0 < K ? lo : __builtin_inff();
+                L.dhi[j0] = hi;
             }
-        };
-        finish(st0, valid0, j0, sc0, dlb0_0, st0.complete);
-        finish(st1, valid1, j1, sc1, dlb0_1, st1.complete);
+        }
         __syncthreads();
         // ---- survivors: every centroid whose lower bound does not exceed the smallest upper bound
         if (tid < 256) {
@@ -402,7 +449,9 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_sinkhorn_bound(Points P, Cent
         }
         if (tid == 0) atomicAdd(pstats + (size_t)(blockIdx.x % KM_STAT_STRIPES) * STAT_STRIDE + 1, 1ull);
     }
+    for (int o = 8; o > 0; o >>= 1) my_col_iters += __shfl_xor(my_col_iters, o, 64);  // the 16 columns of lanes g == 0
     if (lane == 0) {
+        atomicAdd(pstats + (size_t)(blockIdx.x % KM_STAT_STRIPES) * STAT_STRIDE + 5, my_col_iters);
         atomicAdd(pstats + (size_t)(blockIdx.x % KM_STAT_STRIPES) * STAT_STRIDE + 2, my_cb_iters);
         atomicAdd(pstats + (size_t)(blockIdx.x % KM_STAT_STRIPES) * STAT_STRIDE + 3, my_cost_passes);
         // per block iteration 16 x-tiles x NT y-tiles x 4 k-steps in each of the two contractions; a cost pass is one more
