@@ -64,6 +64,8 @@ def parse():
                          "ordered: the reference's sequential tree-id order exactly (N=1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-oracle baseline sample length (0 = skip)")
     ap.add_argument("--no-kmeans", action="store_true", help="skip the secondary k-means measurement")
+    ap.add_argument("--no-kmeans-reference", action="store_true",
+                    help="skip the flop layer in the reference's own arithmetic and draw (two more full-size passes, ~70 s)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed MCCFR loop (no other-mode rate, convergence run, k-means or CPU baselines): the "
                          "command profiled by scripts/profile_round.sh, so that rocprof's per-kernel averages are those of "
@@ -365,8 +367,43 @@ def kmeans_secondary(args):
         return None
     import oracle
 
-    out = lloyd.bench_slice() if args.kmeans == "slice" else lloyd.bench_full(args.kmeans)
+    pts, keep = None, {}
+    if args.kmeans == "flop" and not args.no_kmeans_reference:
+        from robopoker_amd.fixtures import flop_like_points
+
+        pts = flop_like_points(1286792, bins=256, mass=47, seed=0xF10F)  # drawn once, shared by the three flop passes below
+    out = lloyd.bench_slice() if args.kmeans == "slice" else lloyd.bench_full(args.kmeans, pts=pts)
     centroids = out.pop("_centroids", None)
+    if args.kmeans == "flop":
+        # configs[4]'s share of one GPU rides along (under a second of device time)
+        try:
+            turn = lloyd.bench_full("turn")
+            turn.pop("_centroids", None)
+            out["kmeans_turn"] = turn
+        except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
+            out["kmeans_turn"] = {"error": f"{type(exc).__name__}: {exc}"}
+    if pts is not None:
+        # north_star's "bit-exact bucket assignments" at configs[2]: the whole layer in the reference's own arithmetic (glibc's expf /
+        # logf) with the reference's own k-means++ draw (SmallRng + WeightedIndex<f32>), filters kept — and, for the comparison, the
+        # contract's arithmetic on the same draw: how many of the 1 286 792 buckets (and of the 256 picks) differ between the two
+        try:
+            ref = lloyd.bench_full("flop", pts=pts, libm="glibc", rng="reference", keep=keep)
+            ref.pop("_centroids", None)
+            same = {}
+            con = lloyd.bench_full("flop", pts=pts, libm="contract", rng="reference", keep=same)
+            slim = {k: ref[k] for k in ("libm", "rng", "create_s", "kmeanspp_s", "init_bounds_s", "elkan_total_s", "lookup_s", "end_to_end_s",
+                                        "points_per_s", "distances_total", "sinkhorn_iterations_total", "rms", "kernels_ms")}
+            slim["prune"] = {k: ref["mfma_bound"][k] for k in ("survivors", "candidates", "sampled_points", "sample_mismatches",
+                                                              "kpp_bound_pairs", "kpp_bound_kept")}
+            slim["contract_pass_same_draw"] = {k: con[k] for k in ("kmeanspp_s", "elkan_total_s", "lookup_s", "end_to_end_s", "rms")}
+            slim["picks_differing_from_contract_pass"] = int((keep["picks"] != same["picks"]).sum())
+            slim["buckets_differing_from_contract_pass"] = int((keep["buckets"] != same["buckets"]).sum())
+            slim["note"] = ("rp_kmeans_set_libm(RP_LIBM_GLIBC) + rp_kmeans_set_rng(RP_RNG_REFERENCE, Flop): what a Linux build of the reference "
+                            "computes for this layer, bit for bit (tests/test_gpu_z_glibc_mode.py, tests/test_reference_seed.py); the count "
+                            "compares its Layer::lookup buckets with the default f32 contract's on the same draw")
+            out["reference_arithmetic"] = slim
+        except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
+            out["reference_arithmetic"] = {"error": f"{type(exc).__name__}: {exc}"}
     if args.kmeans_libm == "glibc":
         try:
             small = lloyd.bench_slice(n_points=4096, iters=1)
@@ -663,6 +700,22 @@ def convergence_times(args, g, local_rank):
     return out
 
 
+def nlhe_profiled_traffic(kernel, batch):
+    """HBM bytes per launch of an NLHE kernel from the newest committed PMC reduction taken at THIS batch (profiles/r*_nlhe_hbm_traffic*.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH prescribes); (None, file) otherwise."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_nlhe_hbm_traffic*.json")))
+    for f in reversed(files):
+        doc = json.load(open(f))
+        if doc.get("batch") != batch:
+            continue
+        vals = [v["hbm_bytes_per_launch"] for name, v in doc["kernels"].items() if kernel in name]
+        if vals:
+            return sum(vals) / len(vals), os.path.basename(f)
+    return None, (os.path.basename(files[-1]) + " (another batch)" if files else None)
+
+
 def nlhe_extra(args, local_rank):
     """BASELINE configs[3] on this GPU, as an extra of the default line: the Flagship solver type's step (level-synchronous traversal
     + composed table update) at a GPU-sized batch and at the reference's 128, with the dominant kernel's roofline; CPU oracle beside."""
@@ -693,8 +746,10 @@ def nlhe_extra(args, local_rank):
             ms = g["expand"][0]
             ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else None
             out["kernel_ms_per_step"] = {k: v[0] / steps for k, v in g.items()}
+            traffic, traffic_src = nlhe_profiled_traffic("k_nl_expand", batch)
             out["roofline"] = {"bound": "hbm", "kernel": "k_nl_expand", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBPS if ach else None, "traffic": None,
+                               "frac": ach / HBM_PEAK_GBPS if ach else None, "traffic": traffic, "traffic_source": traffic_src,
+                               "hbm_frac_measured": (traffic / (ms * 1e-3 / max(g["expand"][1], 1)) / 1e9 / HBM_PEAK_GBPS) if traffic and ms > 0 else None,
                                "algorithmic_bytes_per_launch": alg / max(g["expand"][1], 1),
                                "avg_launch_us": ms * 1e3 / max(g["expand"][1], 1),
                                "note": "one launch per tree level; DESIGN 3c: bytes = 4 N + 144 walker + 8 walker-children + 180 opponent + 20 chance"}

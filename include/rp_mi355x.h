@@ -499,9 +499,16 @@ RP_API int rp_kmeans_set_rng(rp_kmeans* h, rp_rng_kind kind, int street);
  *                     times the cost (every kernel that evaluates exp / ln exists in both arithmetics: csrc/lloyd_kernels.hpp).
  * What the default's <= 1 ulp is worth is measured (costs within 7 ulps, no k-means++ pick and no bucket moves). */
 typedef enum rp_libm_kind { RP_LIBM_CONTRACT = 0, RP_LIBM_GLIBC = 1 } rp_libm_kind;
-/* a layer: call before the first centroid exists (recomputes the points' self costs; the k-means++ column bound and the MFMA
- * bound, whose margins are validated for the contract's arithmetic, are switched off: the layer runs unpruned).  One way only. */
+/* a layer: call before the first centroid exists (recomputes the points' self costs).  One way only.  The three filters in front of
+ * the bit-faithful solves — the k-means++ column bound, the k-means++ interval filter, the MFMA bound of the neighbor passes — stay
+ * in place: their margins (4e-5 relative, 4e-6 absolute) sit three orders above the <= 7 ulps between the two arithmetics, and the
+ * full flop layer has been audited in both (profiles/r05_glibc_audit.json, profiles/r03_mfma_audit.json: 0 of 1 286 792 points differ
+ * from the unpruned search).  rp_kmeans_set_prune(h, 0) runs every distance through the bit-faithful kernel instead. */
 RP_API int rp_kmeans_set_libm(rp_kmeans* h, rp_libm_kind kind);
+/* enable = 0: no filter in front of the exact solves (Elkan::neighbor / Layer::init_centroids as the reference loops them, every
+ * (point, centroid) pair solved): the yardstick the filtered passes are audited against.  Before the first centroid; a layer that
+ * gave its filters up does not get them back (enable = 1 on such a layer: RP_ERR_UNSUPPORTED). */
+RP_API int rp_kmeans_set_prune(rp_kmeans* h, int enable);
 /* the three stand-alone operators (rp_sinkhorn_divergence / _cost / _flow): process-wide */
 RP_API int rp_sinkhorn_set_libm(rp_libm_kind kind);
 /* install centroids = copies of the given points (TestLayer-style explicit seeding, tests.rs:100-102) */

@@ -57,7 +57,7 @@ RP_API int rp_kmeans_bound_intervals(rp_kmeans* h, float* lo, float* hi);
 RP_API int rp_kmeans_kpp_bound_probe(rp_kmeans* h, uint32_t k, float* lo);
 
 RP_API int rp_kmeans_profile(rp_kmeans* h, int enable);
-/* name in {"pairwise","step","recompute","bounds","neighbor","selfcost","kpp","drift","mfma_bound"} */
+/* name in {"pairwise","step","recompute","bounds","neighbor","selfcost","kpp","drift","mfma_bound","kpp_bound"} */
 RP_API int rp_kmeans_kernel_time(rp_kmeans* h, const char* name, double* total_ms, uint64_t* launches);
 
 #ifdef __cplusplus

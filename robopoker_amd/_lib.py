@@ -265,6 +265,7 @@ _SIGNATURES = {
     "rp_nlhe_set_exact": (C.c_int, [C.c_void_p, C.c_int]),
     "rp_kmeans_set_rng": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rp_kmeans_set_libm": (C.c_int, [C.c_void_p, C.c_int]),
+    "rp_kmeans_set_prune": (C.c_int, [C.c_void_p, C.c_int]),
     "rp_kmeans_prune_stats_sized": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rp_nlhe_train": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_char_p, C.c_size_t]),

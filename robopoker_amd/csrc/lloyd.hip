@@ -64,8 +64,8 @@ struct Clock {
     double total_ms = 0.0;
     uint64_t launches = 0;
 };
-const char* const CLOCK_NAMES[] = {"pairwise", "step", "recompute", "bounds", "neighbor", "selfcost", "kpp", "drift", "mfma_bound"};
-enum { CK_PAIRWISE, CK_STEP, CK_RECOMPUTE, CK_BOUNDS, CK_NEIGHBOR, CK_SELF, CK_KPP, CK_DRIFT, CK_BOUND, CK_COUNT };
+const char* const CLOCK_NAMES[] = {"pairwise", "step", "recompute", "bounds", "neighbor", "selfcost", "kpp", "drift", "mfma_bound", "kpp_bound"};
+enum { CK_PAIRWISE, CK_STEP, CK_RECOMPUTE, CK_BOUNDS, CK_NEIGHBOR, CK_SELF, CK_KPP, CK_DRIFT, CK_BOUND, CK_KPP_BOUND, CK_COUNT };
 }  // namespace
 
 #define SB_SAMPLE_STRIDE 521u  // the production self-check of the MFMA prune looks at every 521st point (0.2 % more exact solves)
@@ -138,6 +138,8 @@ struct rp_kmeans {
     uint8_t* audit_j = nullptr;
     float* audit_d = nullptr;
     float* sb_d = nullptr;
+    uint8_t* nb_tmp_j = nullptr;  // [NB_LIST_MAX][NB_CHUNKS] partial nearest centroids of launch_neighbor_list
+    float* nb_tmp_d = nullptr;
     uint8_t* sb_crank = nullptr;  // [256] rank of every centroid in the similarity order (centroid_order)
     bool sb_crank_set = false;
     bool pairw_seen = false;      // an Elkan step has filled pairw for (nearly) the current centroids
@@ -523,6 +525,24 @@ int prune_check(rp_kmeans* h, const char* who) {
                                          "(set RP_LLOYD_NO_MFMA_BOUND=1 and report)", who, bad);
     return RP_OK;
 }
+// Elkan::neighbor for the points of a (short) device list: K centroids per point split over NB_CHUNKS wavefronts, merged in order
+#define NB_LIST_MAX 65536u
+int launch_neighbor_list(rp_kmeans* h, const uint32_t* list, uint32_t n, uint8_t* out_j, float* out_d, Bounds init) {
+    if (!n) return RP_OK;
+    if (h->kind != RP_METRIC_SINKHORN || n > NB_LIST_MAX) {  // enough wavefronts as it is (or the variation metric's own kernel)
+        hipLaunchKernelGGL(KSEL(h, k_neighbor), dim3(n), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->kind, out_j, out_d, init, list);
+        return RP_OK;
+    }
+    int rc;
+    if (!h->nb_tmp_j && ((rc = dev_alloc(h, &h->nb_tmp_j, (size_t)NB_LIST_MAX * NB_CHUNKS)) || (rc = dev_alloc(h, &h->nb_tmp_d, (size_t)NB_LIST_MAX * NB_CHUNKS))))
+        return rc;
+    hipLaunchKernelGGL(KSEL(h, k_neighbor_chunk), dim3(n * NB_CHUNKS), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, list, h->nb_tmp_j,
+                       h->nb_tmp_d);
+    hipLaunchKernelGGL(k_neighbor_merge, dim3((n + 255u) / 256u), dim3(256), 0, h->stream, list, n, h->K, (const uint8_t*)h->nb_tmp_j,
+                       (const float*)h->nb_tmp_d, out_j, out_d, init);
+    return RP_OK;
+}
+
 int launch_neighbor_full(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init) {
     ck_begin(h, CK_NEIGHBOR);
     if (h->kind == RP_METRIC_VARIATION && h->bins == 101)  // turn layer: register-resident centroid CDFs
@@ -646,8 +666,7 @@ int launch_neighbor(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init, int
     if (!h->sb_audit && out_j && h->sb_nsample) {  // the sampled points once more, unpruned (k_neighbor takes a point list)
         Bounds none{};
         ck_begin(h, CK_NEIGHBOR);
-        hipLaunchKernelGGL(KSEL(h, k_neighbor), dim3(h->sb_nsample), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->kind, h->audit_j,
-                           h->audit_d, none, (const uint32_t*)h->sb_sample);
+        if ((rc = launch_neighbor_list(h, h->sb_sample, h->sb_nsample, h->audit_j, h->audit_d, none))) return rc;
         ck_end(h, CK_NEIGHBOR);
         hipLaunchKernelGGL(k_audit_compare_list, dim3((h->sb_nsample + 255) / 256), dim3(256), 0, h->stream, out_j, dd, h->audit_j,
                            h->audit_d, h->sb_sample, h->sb_nsample, h->sb_bad + 1);
@@ -795,30 +814,35 @@ int rp_kmeans_set_rng(rp_kmeans* h, rp_rng_kind kind, int street) {
 }
 
 // Which exp / ln the layer's Sinkhorn distances compute with.  RP_LIBM_GLIBC: the lm_glibc pass of every kernel that evaluates them
-// (KSEL), point self costs recomputed in it, and the two margin filters off (the k-means++ column bound and the MFMA bound carry
-// margins validated for the contract's arithmetic; unpruned is exact by definition).  To be called before the first centroid exists.
+// (KSEL), point self costs recomputed in it; the filters in front of the exact solves stay (audited in both arithmetics).  To be
+// called before the first centroid exists.
 int rp_kmeans_set_libm(rp_kmeans* h, rp_libm_kind kind) {
     if (!h || (kind != RP_LIBM_CONTRACT && kind != RP_LIBM_GLIBC)) return rp::fail(RP_ERR_INVALID, "rp_kmeans_set_libm: bad argument");
     if (h->centroids_ready || h->bounds_ready) return rp::fail(RP_ERR_INVALID, "rp_kmeans_set_libm: the layer already has centroids; set the mode first");
     if (kind == h->libm) return RP_OK;
-    if (kind == RP_LIBM_CONTRACT) return rp::fail(RP_ERR_UNSUPPORTED, "rp_kmeans_set_libm: a layer switched to glibc's arithmetic stays there (its bound filters are gone)");
+    if (kind == RP_LIBM_CONTRACT) return rp::fail(RP_ERR_UNSUPPORTED, "rp_kmeans_set_libm: a layer switched to glibc's arithmetic stays there");
     HIP_TRY(hipSetDevice(h->device));
     h->libm = kind;
-    // The k-means++ column bound and the MFMA bound compute in their own f32 arithmetic and carry margins (4e-5 relative, 4e-6 absolute:
-    // sinkhorn_bound.hpp) validated at full size against the CONTRACT's distances (profiles/r03_mfma_audit.json).  glibc's distances
-    // sit <= 7 ulps from those, three orders inside the margins, but the full-size audit in this arithmetic has not been run: the pass
-    // is unpruned unless RP_LLOYD_GLIBC_PRUNE is set (a developer switch for that audit; the sample check of every pruned pass guards
-    // it like in the contract pass).
-    if (!getenv("RP_LLOYD_GLIBC_PRUNE")) {
-        h->kpp_lb = false;
-        h->kb_on = false;
-        h->sb_on = false;
-    }
+    // The k-means++ column bound, its interval filter and the MFMA bound compute in their own f32 arithmetic and carry margins (4e-5
+    // relative, 4e-6 absolute: sinkhorn_bound.hpp).  glibc's distances sit <= 7 ulps from the contract's, three orders inside the
+    // margins, and the full-size audit has been run in this arithmetic too (profiles/r05_glibc_audit.json): the filters stay; the
+    // sample check of every pruned pass guards them as in the contract pass.  rp_kmeans_set_prune(h, 0) drops them.
     if (h->kind == RP_METRIC_SINKHORN) {  // OT(p, p) of every point (sinkhorn.rs:175-191) in the new arithmetic
         hipLaunchKernelGGL(KSEL(h, k_point_self), dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->M, const_cast<float*>(h->P.self));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
+    return RP_OK;
+}
+
+int rp_kmeans_set_prune(rp_kmeans* h, int enable) {
+    if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_set_prune: NULL handle");
+    if (h->centroids_ready || h->bounds_ready) return rp::fail(RP_ERR_INVALID, "rp_kmeans_set_prune: the layer already has centroids; set the mode first");
+    const bool has = h->kpp_lb || h->kb_on || h->sb_on;
+    if (enable) return has ? RP_OK : rp::fail(RP_ERR_UNSUPPORTED, "rp_kmeans_set_prune: this layer has no filters (variation metric, switched off at creation, or given up)");
+    h->kpp_lb = false;
+    h->kb_on = false;
+    h->sb_on = false;
     return RP_OK;
 }
 
@@ -898,6 +922,8 @@ int rp_kmeans_kpp_update(rp_kmeans* h, uint32_t k) {
                 HIP_TRY(hipStreamSynchronize(h->stream));
             }
             if (m && m <= 48u) {
+                ck_end(h, CK_KPP);  // the interval filter has its own clock ("kpp_bound"): it is not a softmin kernel
+                ck_begin(h, CK_KPP_BOUND);
                 HIP_TRY(hipMemsetAsync(h->kpp2.count, 0, 16, h->stream));
                 HIP_TRY(hipMemsetAsync(h->kb_cursor, 0, 16, h->stream));
                 int cus = 256;
@@ -917,6 +943,8 @@ int rp_kmeans_kpp_update(rp_kmeans* h, uint32_t k) {
                                            h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr);
                 }
                 todo = &h->kpp2;
+                ck_end(h, CK_KPP_BOUND);
+                ck_begin(h, CK_KPP);
             }
         }
         if (cap4)
@@ -1051,9 +1079,11 @@ int rp_kmeans_init_bounds(rp_kmeans* h) {
                            h->kpp_todo, h->kpp_ntodo);
         HIP_TRY(hipMemcpyAsync(&n_todo, h->kpp_ntodo, 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        if (n_todo)
-            hipLaunchKernelGGL(KSEL(h, k_neighbor), dim3(n_todo), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->kind, h->prior,
-                               (float*)nullptr, h->B, h->kpp_todo);
+        if (n_todo) {
+            Bounds into = h->B;
+            into.lower = nullptr;  // zeroed above
+            if ((rc = launch_neighbor_list(h, h->kpp_todo, n_todo, h->prior, nullptr, into))) return rc;
+        }
         ck_end(h, CK_NEIGHBOR);
         HIP_TRY(hipGetLastError());
         // the shortcut trusts the k-means++ column-marginal filter: checked like the MFMA prune — on the sample in production,
@@ -1066,8 +1096,7 @@ int rp_kmeans_init_bounds(rp_kmeans* h) {
                                    h->audit_d, h->N, h->sb_bad);
                 h->sb_audited += h->N;
             } else {
-                hipLaunchKernelGGL(KSEL(h, k_neighbor), dim3(h->sb_nsample), dim3(64), 0, h->stream, h->P, h->cs[h->cur], h->K, h->M, h->kind,
-                                   h->audit_j, h->audit_d, none, (const uint32_t*)h->sb_sample);
+                if ((rc = launch_neighbor_list(h, h->sb_sample, h->sb_nsample, h->audit_j, h->audit_d, none))) return rc;
                 hipLaunchKernelGGL(k_audit_compare_list, dim3((h->sb_nsample + 255) / 256), dim3(256), 0, h->stream, h->B.j, h->B.u,
                                    h->audit_j, h->audit_d, h->sb_sample, h->sb_nsample, h->sb_bad + 1);
                 h->sb_sampled += h->sb_nsample;

@@ -725,6 +725,61 @@ __global__ __launch_bounds__(64) void k_neighbor(Points P, CentroidSet cs, uint3
         for (uint32_t k = lane; k < K; k += 64) init.lower[i * K + k] = 0.0f;
 }
 
+// Elkan::neighbor for a SHORT list of points (the sampled self-check of the pruned passes, the points k-means++ leaves to init_bounds):
+// a few thousand wavefronts that each walk all K centroids leave most of the chip idle, so the K centroids of a point are split over
+// NB_CHUNKS wavefronts; k_neighbor_merge takes the first minimum over the chunks in ascending order (strict <), which is the first
+// minimum over all K (elkan.rs:68-77: min_by keeps the first).  Sinkhorn only.
+#define NB_CHUNKS 8u
+__global__ __launch_bounds__(64) void k_neighbor_chunk(Points P, CentroidSet cs, uint32_t K, Metric M, const uint32_t* list, uint8_t* tmp_j,
+                                                       float* tmp_d) {
+    __shared__ WaveLds w;
+    const uint32_t e = blockIdx.x / NB_CHUNKS, q = blockIdx.x % NB_CHUNKS;
+    const uint64_t i = list[e];
+    const uint32_t per = (K + NB_CHUNKS - 1u) / NB_CHUNKS, k0 = q * per, k1 = min(K, k0 + per);
+    const uint32_t n = wave_load_hist(P.counts + i * P.stride, P.weight[i], M.bins, w.supB, w.lnB);
+    const float sp = P.self[i];
+    uint32_t bj = 0xffu;
+    float bd = 0.0f;
+    for (uint32_t k = k0; k < k1; ++k) {
+        const uint32_t m = wave_load_centroid(cs, k, w.supA, w.lnA);
+        const float d = wave_divergence(w, m, n, cs.self[k], sp, M);  // distance(centroid, point)
+        if (k == k0 || d < bd) {
+            bj = k;
+            bd = d;
+        }
+        __syncthreads();
+    }
+    if (lane_id() == 0) {
+        tmp_j[(size_t)e * NB_CHUNKS + q] = (uint8_t)bj;
+        tmp_d[(size_t)e * NB_CHUNKS + q] = bd;
+    }
+}
+__global__ __launch_bounds__(256) void k_neighbor_merge(const uint32_t* list, uint32_t n, uint32_t K, const uint8_t* tmp_j, const float* tmp_d,
+                                                        uint8_t* out_j, float* out_d, Bounds init) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t per = (K + NB_CHUNKS - 1u) / NB_CHUNKS;
+    uint32_t bj = tmp_j[(size_t)e * NB_CHUNKS];
+    float bd = tmp_d[(size_t)e * NB_CHUNKS];
+    for (uint32_t q = 1; q < NB_CHUNKS && q * per < K; ++q) {
+        const float d = tmp_d[(size_t)e * NB_CHUNKS + q];
+        if (d < bd) {
+            bd = d;
+            bj = tmp_j[(size_t)e * NB_CHUNKS + q];
+        }
+    }
+    const uint64_t i = list[e];
+    if (out_j) out_j[i] = (uint8_t)bj;
+    if (out_d) out_d[i] = bd;
+    if (init.j) {  // Bounds::from((j, upper)) (bounds.rs:111-120)
+        init.j[i] = (uint8_t)bj;
+        init.u[i] = bd;
+        init.stale[i] = 0;
+    }
+    if (init.lower)
+        for (uint32_t k = 0; k < K; ++k) init.lower[i * K + k] = 0.0f;
+}
+
 // Elkan::neighbor over the survivors of the MFMA bound (sinkhorn_bound.hpp): the centroids whose bit is set in the
 // point's 256-bit mask, in ascending index, first minimum wins (elkan.rs:68-77: min_by keeps the first) — the unpruned
 // loop's result bit for bit as long as every minimiser survives.  `audit_*`: RP_LLOYD_AUDIT compares with the unpruned

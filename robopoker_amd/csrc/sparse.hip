@@ -6,7 +6,7 @@
 // MI355X mapping.  A table row is 16*A contiguous bytes {regret[A], weight[A], payoff[A], visits[A]}: the touches of
 // a row read and write one contiguous span, so the HBM traffic of a batch is (rows touched) x 32*A bytes plus the
 // Decisions themselves, independent of the table size.  A batch is brought into per-row, batch-ordered segments by a
-// stable radix sort of (row, position) pairs (rocPRIM through hipCUB: a plain library sort) and a run-length
+// stable radix sort of (row, position) pairs (the library's own LSD radix sort and scans: csrc/sortscan.hpp) and a run-length
 // encode; then a group of 16 lanes owns one row — lane a owns action a's four cells, so a row is loaded and stored
 // with coalesced dwords — and walks the row's touches in order.  Four rows per wavefront.
 #include <hip/hip_runtime.h>

@@ -8,6 +8,7 @@ HIP kernels; there is no CPU path here.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -62,8 +63,14 @@ class Layer:
     def set_libm(self, kind: str):
         """``"glibc"``: every exp / ln of the layer's Sinkhorn distances is glibc's ``expf`` / ``logf`` (what ``f32::exp`` / ``f32::ln``
         are in a Rust build on Linux), evaluated in double on the device: distances, bounds, drift and buckets are the reference's
-        bit for bit.  Before the first centroid; unpruned and a few times slower than the default f32 contract."""
+        bit for bit.  Before the first centroid; the exact solves cost 2.3 x the default f32 contract's, the filters in front of them
+        (audited in both arithmetics) stay."""
         _lib.check(self._lib.rp_kmeans_set_libm(self._h, LIBM[kind]))
+
+    def set_prune(self, enable: bool):
+        """``False``: no filter in front of the exact solves — every (point, centroid) distance through the bit-faithful kernel, as
+        the reference loops them (the yardstick of the audits).  Before the first centroid."""
+        _lib.check(self._lib.rp_kmeans_set_prune(self._h, 1 if enable else 0))
 
     def init_centroids(self) -> np.ndarray:
         chosen = np.zeros(self.K, dtype=np.uint64)
@@ -448,9 +455,11 @@ HBM_PEAK_GBPS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2.0
 SOFTMIN_INSTR_PER_8_TERMS = 106  # VALU instructions per 8 softmin terms per lane in the shipped ISA
+VALU_SUSTAINED_PLAIN = 8.2e11    # plain (unpacked) wave64 VALU instructions/s the chip sustains (profiles/r01_valu_issue_rates.txt)
 
 
-def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None, seed: int = 1, log=None, libm: str = "contract"):
+def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None, seed: int = 1, log=None, libm: str = "contract",
+               rng: str = "counter", pts=None, keep: dict | None = None):
     """A full-size k-means configuration of BASELINE.json on one GPU:
 
     flop (configs[2]): N = 1 286 792 histograms, K = 256, bins = 256, mass 47, Sinkhorn EMD, k-means++,
@@ -458,14 +467,16 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
     turn (configs[4], one GPU's 1/8 share): N = 1 745 006, K = 256, bins = 101, mass 46, Equity::variation.
     Returns per-phase wall times, rates and the rooflines of the three kernel families (a dict): the bit-faithful
     Sinkhorn solves against the VALU issue peak, the MFMA bound against the f32 MFMA peak, the Elkan bound update
-    against the HBM peak — all from HIP events recorded by the library on its launch stream over the whole run."""
+    against the HBM peak — all from HIP events recorded by the library on its launch stream over the whole run.
+    libm / rng: the layer's arithmetic ("glibc": the reference's own exp / ln) and k-means++ draw ("reference": Layer::init_centroids'
+    SmallRng + WeightedIndex<f32>); pts: the points, when the caller already holds them; keep: receives the picks and the buckets."""
     from .fixtures import flop_like_points, smooth_metric, turn_like_points
 
     K = 256
     if which == "flop":
         N = n_points or 1286792
         bins, kind, tri, bytes_per_point = 256, "sinkhorn", smooth_metric(256, 1), 2320
-        pts = flop_like_points(N, bins=bins, mass=47, seed=0xF10F)
+        pts = flop_like_points(N, bins=bins, mass=47, seed=0xF10F) if pts is None else pts
     elif which == "turn":
         N = n_points or 1745006
         bins, kind, tri, bytes_per_point = 101, "variation", None, 2165
@@ -480,12 +491,17 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
     t0 = time.perf_counter()
     layer = Layer(K, pts, kind, tri, seed=seed)
     if libm != "contract":
-        layer.set_libm(libm)  # the kernels' lm_glibc pass (unpruned unless RP_LLOYD_GLIBC_PRUNE is set)
+        layer.set_libm(libm)  # the kernels' lm_glibc pass (filters kept; RP_FULL_NO_PRUNE=1: rp_kmeans_set_prune(h, 0))
+        if os.environ.get("RP_FULL_NO_PRUNE"):
+            layer.set_prune(False)
+    if rng != "counter":
+        layer.set_rng(rng, 1)  # Street::Flop
+    out["libm"], out["rng"] = libm, rng
     out["create_s"] = time.perf_counter() - t0  # upload + point masses + memoised OT(p,p)
     layer.profile(True)
     e0 = layer.exp_evals()
     t0 = time.perf_counter()
-    layer.init_centroids()
+    chosen = layer.init_centroids()
     out["kmeanspp_s"] = time.perf_counter() - t0
     e_kpp = layer.exp_evals() - e0
     d0, _ = layer.stats()
@@ -512,15 +528,17 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
     out["hbm_frac"] = out["algorithmic_GBps"] / HBM_PEAK_GBPS
     out["per_iteration"] = per_iter
     t0 = time.perf_counter()
-    layer.lookup()
+    buckets, _ = layer.lookup()
     out["lookup_s"] = time.perf_counter() - t0
+    if keep is not None:
+        keep["picks"], keep["buckets"] = np.asarray(chosen).copy(), np.asarray(buckets).copy()
     out["end_to_end_s"] = out["create_s"] + out["kmeanspp_s"] + out["init_bounds_s"] + total + out["lookup_s"]
     out["rms"] = layer.rms()
     d2, i2 = layer.stats()
     out["distances_total"] = d2
     out["sinkhorn_iterations_total"] = i2
     ms = {name: layer.kernel_time(name) for name in ("pairwise", "step", "recompute", "bounds", "neighbor", "selfcost", "kpp",
-                                                     "drift", "mfma_bound")}
+                                                     "drift", "mfma_bound", "kpp_bound")}
     out["kernels_ms"] = {k: {"total_ms": round(v[0], 3), "launches": v[1]} for k, v in ms.items()}
     bd_ms, bd_n = ms["bounds"]
     if bd_n:
@@ -538,7 +556,18 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
                                     "frac": instr / valu_s / VALU_PEAK_WAVE_INSTR if valu_s else 0.0, "exp_terms": exps,
                                     "note": "bit-reproducible software exp: 106 VALU instructions per 8 softmin terms per lane; achieved = "
                                             "terms / 64 / 8 x 106 / kernel time, i.e. counts only lanes that carry a term (a point fills "
-                                            "<= 47 of 64 lanes); peak = one wave64 instruction per 2 cycles per SIMD"}
+                                            "<= 47 of 64 lanes); peak = one wave64 instruction per 2 cycles per SIMD",
+                                    # what the counters say binds these kernels (profiles/r05_lloyd_sq_counters_before.json, reduced in
+                                    # profiles/r05_lloyd_valu_ceiling.json): 44 of the 106 instructions are packed f32 and cost two issue
+                                    # slots each (profiles/r01_valu_issue_rates.txt: no throughput gain from packing on gfx950), so a term
+                                    # is 155 / 8 plain-equivalent instructions against the chip's sustained 8.2e11 plain wave64 VALU/s
+                                    "issue": {"plain_equivalent_per_8_terms": 155,
+                                              "achieved": exps / 64.0 / 8.0 * 155 / valu_s if valu_s else 0.0,
+                                              "peak": VALU_SUSTAINED_PLAIN, "unit": "plain-equivalent wave-instructions/s",
+                                              "frac": exps / 64.0 / 8.0 * 155 / valu_s / VALU_SUSTAINED_PLAIN if valu_s else 0.0,
+                                              "counters": "profiles/r05_lloyd_valu_ceiling.json: SQ_INSTS_VALU x 1.46 / kernel time = 80 - 97 % "
+                                                          "of the sustained issue rate in k_refresh_pairs, k_pairwise, k_neighbor_masked, "
+                                                          "k_point_dist; the rest of the gap to this figure is lanes that carry no term"}}
         kpp_ms, kpp_n = ms["kpp"]
         if kpp_ms > 0:  # k-means++ on its own: K rounds of (column-marginal filter, Sinkhorn solves of the survivors against ONE new centroid)
             ki = e_kpp / 64.0 / 8.0 * SOFTMIN_INSTR_PER_8_TERMS
@@ -550,6 +579,14 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
                                                 "the solves the column-marginal bound let through, against the kernels' event time (filter "
                                                 "launches included); K sequential rounds, each against one new sparse centroid"}
         st = layer.prune_stats()
+        kb_ms, kb_n = ms["kpp_bound"]
+        if kb_ms > 0:  # the k-means++ interval filter (csrc/kpp_bound.hpp): FMA-bound scaling-domain iterations, registers only
+            out["kmeanspp_interval_filter"] = {"pairs": st["kpp_bound_pairs"], "kept": st["kpp_bound_kept"],
+                                               "pair_iterations": st["kpp_bound_iterations"], "cost_passes": st["kpp_bound_cost_passes"],
+                                               "kernel_s": kb_ms * 1e-3, "launches": kb_n,
+                                               "pair_iterations_per_s": st["kpp_bound_iterations"] / (kb_ms * 1e-3),
+                                               "note": "the (new centroid, point) pairs the column-marginal bound let through, examined by a "
+                                                       "scaling-domain interval; `kept` went on to the bit-faithful solve"}
         out["mfma_bound"] = st
         mb_ms, mb_n = ms["mfma_bound"]
         if st["enabled"] and mb_ms > 0:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The k-means++ interval filter (csrc/kpp_bound.hpp) audited at FULL size: Layer::init_centroids + init_bounds of the flop layer with
 the filter and without it (RP_LLOYD_NO_KPP_BOUND2=1) — the picks, the buckets and the upper-bound bits must be identical.
-    python scripts/kpp_audit.py [N]      -> one JSON object on stdout"""
+    python scripts/kpp_audit.py [N [contract|glibc]]      -> one JSON object on stdout"""
 import json
 import os
 import sys
@@ -15,14 +15,17 @@ from robopoker_amd import lloyd  # noqa: E402
 from robopoker_amd.fixtures import flop_like_points, smooth_metric  # noqa: E402
 
 N, K, bins = int(sys.argv[1]) if len(sys.argv) > 1 else 1286792, 256, 256
+libm = sys.argv[2] if len(sys.argv) > 2 else "contract"
 pts, tri = flop_like_points(N, bins=bins, mass=47, seed=0xF10F), smooth_metric(256, 1)
-out = {"N": N, "K": K, "bins": bins}
+out = {"N": N, "K": K, "bins": bins, "libm": libm}
 res = {}
 for name, off in (("filtered", False), ("unfiltered", True)):
     os.environ.pop("RP_LLOYD_NO_KPP_BOUND2", None)
     if off:
         os.environ["RP_LLOYD_NO_KPP_BOUND2"] = "1"
     layer = lloyd.Layer(K, pts, "sinkhorn", tri, seed=1)
+    if libm != "contract":
+        layer.set_libm(libm)
     t0 = time.perf_counter()
     chosen = np.asarray(layer.init_centroids())
     t1 = time.perf_counter()

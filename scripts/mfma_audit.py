@@ -15,7 +15,6 @@ which = sys.argv[1] if len(sys.argv) > 1 else "synthetic"
 sample = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 say = lambda m: print(m, file=sys.stderr, flush=True)  # noqa: E731
 import numpy as np  # noqa: E402
-import torch  # noqa: E402,F401
 
 from robopoker_amd import lloyd  # noqa: E402
 
@@ -26,7 +25,7 @@ if which == "synthetic":
     N, K, bins = int(os.environ.get("RP_AUDIT_N", "1286792")), 256, 256
     pts, tri = flop_like_points(N, bins=bins, mass=47, seed=0xF10F), smooth_metric(256, 1)
     layer = lloyd.Layer(K, pts, "sinkhorn", tri, seed=1)
-    if os.environ.get("RP_AUDIT_LIBM") == "glibc":  # the audit of the bounds in the glibc-arithmetic pass (with RP_LLOYD_GLIBC_PRUNE=1)
+    if os.environ.get("RP_AUDIT_LIBM") == "glibc":  # the audit of the bounds in the glibc-arithmetic pass (rp_kmeans_set_libm keeps them)
         layer.set_libm("glibc")
     layer.init_centroids()
     layer.init_bounds()
@@ -39,7 +38,8 @@ if which == "synthetic":
     layer.close()
     idx = np.linspace(0, N - 1, sample).astype(np.int64)
     margins = lloyd.margin_audit(pts[idx], cents, tri)
-    out = {"points": "synthetic flop-like histograms (fixtures.flop_like_points, seed 0xF10F)", "N": N, "K": K, "bins": bins}
+    out = {"points": "synthetic flop-like histograms (fixtures.flop_like_points, seed 0xF10F)", "N": N, "K": K, "bins": bins,
+           "libm": os.environ.get("RP_AUDIT_LIBM", "contract")}
 else:
     os.environ["RP_LLOYD_MARGIN_SAMPLE"] = str(sample)
     from robopoker_amd import pretraining

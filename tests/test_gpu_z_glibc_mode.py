@@ -18,7 +18,7 @@ import pytest
 
 import oracle
 from lloyd_fixtures import flop_hist, flop_like_points, flop_metric, random_metric, smooth_metric
-from robopoker_amd import lloyd
+from robopoker_amd import _lib, lloyd
 
 pytestmark = pytest.mark.gpu
 
@@ -210,10 +210,9 @@ def test_glibc_expf_and_logf_on_the_device_equal_the_host_on_every_float(gpu):
 
 
 def test_the_pruned_glibc_pass_equals_the_oracle(oracle_on_glibc, monkeypatch):
-    # RP_LLOYD_GLIBC_PRUNE=1 (a developer switch): the glibc pass keeps the k-means++ column bound and the MFMA bound.  Exactness does
+    # the glibc pass keeps the k-means++ column bound, its interval filter and the MFMA bound (rp_kmeans_set_libm).  Exactness does
     # not depend on them as long as every minimiser survives: picks, bounds, an iteration and the lookup against the unpruned oracle,
     # and the on-device audit (RP_LLOYD_AUDIT: the unpruned search behind every pruned pass) counts no disagreement
-    monkeypatch.setenv("RP_LLOYD_GLIBC_PRUNE", "1")
     monkeypatch.setenv("RP_LLOYD_AUDIT", "1")
     dev, ora = _layer_pair(24, 400, 64, 30, seed=31, iters=24)
     assert np.array_equal(dev.init_centroids(), ora.init_centroids())
@@ -229,3 +228,36 @@ def test_the_pruned_glibc_pass_equals_the_oracle(oracle_on_glibc, monkeypatch):
     st = dev.prune_stats()
     assert st["enabled"] == 1 and st["audited_points"] > 0 and st["audit_mismatches"] == 0
     assert st["survivors"] < st["candidates"]  # it did prune
+    assert st["kpp_bound_pairs"] > 0 and st["kpp_bound_kept"] < st["kpp_bound_pairs"]  # ... in the k-means++ rounds too
+
+
+def test_set_prune_off_runs_every_distance_and_changes_nothing(gpu):
+    # rp_kmeans_set_prune(h, 0): Elkan::neighbor / Layer::init_centroids as the reference loops them — K exact solves per point — in
+    # either arithmetic; same picks, bounds and buckets as the filtered passes, and the mode is refused once centroids exist
+    N, K, bins = 500, 12, 64
+    pts = flop_like_points(N, bins=bins, mass=30, seed=77)
+    tri = smooth_metric(bins, 2)
+    got = {}
+    for libm in ("contract", "glibc"):
+        for prune in (True, False):
+            layer = lloyd.Layer(K, pts, "sinkhorn", tri, seed=9)
+            if libm == "glibc":
+                layer.set_libm("glibc")
+            if not prune:
+                layer.set_prune(False)
+            chosen = np.asarray(layer.init_centroids())
+            layer.init_bounds()
+            d_init = layer.stats()[0]
+            layer.step()
+            b, d = layer.lookup()
+            st = layer.prune_stats()
+            got[(libm, prune)] = (chosen, np.asarray(b), bits(d))
+            if prune:
+                assert st["enabled"] == 1 and st["kpp_bound_pairs"] > 0
+            else:
+                assert st["enabled"] == 0 and st["kpp_bound_pairs"] == 0
+                assert d_init >= N * K  # k-means++ and init_bounds solved every pair
+                with pytest.raises(_lib.RpError):
+                    layer.set_prune(False)  # too late: the layer has centroids
+        a, c = got[(libm, True)], got[(libm, False)]
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
