@@ -253,12 +253,15 @@ struct SbCol {  // per-column window state (replicated in the four lanes of the 
 // A wavefront runs ONE column block at a time (64 + 12 NT accumulator registers: four wavefronts per SIMD for NT <= 2) and takes the
 // point's next block from an LDS counter when it is done: the sixteen blocks of a point differ in length by a factor of six, and with
 // two or three workgroups on a CU another point's wavefronts fill what a straggler leaves idle.
+// NT <= 2: four wavefronts per point and two points per CU (2 x 78 KB of LDS): a point's sixteen blocks spread evenly over four
+// wavefronts, and one point's gather / tail is covered by the other's iterations.  NT >= 3 (110 / 146 KB): eight wavefronts, one point.
 template <int NT>
-__global__ __launch_bounds__(SB_THREADS, 2) void k_sinkhorn_bound(Points P, CentroidSet cs, uint32_t K, uint32_t bins, SbParams prm,
+__global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Points P, CentroidSet cs, uint32_t K, uint32_t bins, SbParams prm,
                                                                    const uint32_t* list, uint32_t count, unsigned int* cursor,
                                                                    unsigned long long* mask_out, float* dbg_lo, float* dbg_hi,
                                                                    unsigned long long* pstats, const float* ub0, const uint8_t* crank) {
     __shared__ SbLds<NT> L;
+    constexpr uint32_t THREADS = NT <= 2 ? 256u : 512u;
     if (threadIdx.x < 256) L.crank[threadIdx.x] = crank ? crank[threadIdx.x] : (uint8_t)threadIdx.x;
     constexpr int SB_KT = SbLds<NT>::KT;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void k_sinkhorn_bound(Points P, Cent
             L.b[tid] = 0.0f;
         }
         __syncthreads();
-        for (uint32_t e = tid; e < NT * 16 * 256; e += SB_THREADS) {
+        for (uint32_t e = tid; e < NT * 16 * 256; e += THREADS) {
             const uint32_t y = e >> 8, x = e & 255u;
             const float k = prm.Kmat[L.sup[y] * 256u + x];
             L.ksub[y * SB_KS + x] = k;
