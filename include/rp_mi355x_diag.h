@@ -55,6 +55,12 @@ RP_API int rp_kmeans_bound_intervals(rp_kmeans* h, float* lo, float* hi);
  * centroid-first call, elkan.rs:68-77) for every point, each stopping window followed to its end; 0 where the pair does not fit the
  * register tile (either support above 48 bins) or no bound was obtained.  Tests compare it with the bit-faithful distances. */
 RP_API int rp_kmeans_kpp_bound_probe(rp_kmeans* h, uint32_t k, float* lo);
+/* the layer's raw counters, out[5]: [0] distances evaluated (rp_kmeans_stats), [1] Sinkhorn iterations, [2] softmin + cost terms,
+ * [3] distances the reference evaluates at that point of Elkan::step_elkan (elkan.rs:153-168) and this library remembers instead of
+ * solving again (same centroid content, same point: the value is a pure function of the two), [4] variation distances computed
+ * beyond the ones Elkan's rule evaluates (the turn kernels compute whole 64-centroid tiles).  Over Elkan steps [0] + [3] is the
+ * reference's own distance count (tests/test_gpu_lloyd.py::test_elkan_iterations_bit_exact). */
+RP_API int rp_kmeans_stats_ex(rp_kmeans* h, uint64_t* out5);
 
 RP_API int rp_kmeans_profile(rp_kmeans* h, int enable);
 /* name in {"pairwise","step","recompute","bounds","neighbor","selfcost","kpp","drift","mfma_bound","kpp_bound"} */

@@ -236,6 +236,7 @@ _SIGNATURES = {
     "rp_kmeans_prune_stats": (C.c_int, [C.c_void_p, C.POINTER(PruneStats)]),
     "rp_kmeans_bound_intervals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rp_kmeans_kpp_bound_probe": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rp_kmeans_stats_ex": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_kmeans_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_kmeans_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "rp_kmeans_kernel_time": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

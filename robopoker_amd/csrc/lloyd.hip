@@ -721,7 +721,7 @@ int step_front(rp_kmeans* h) {
             const size_t entries = (size_t)h->N + 2 * (size_t)h->K;
             HIP_TRY(hipMemsetAsync(h->refresh.count, 0, (size_t)h->K * 4, h->stream));
             HIP_TRY(hipMemsetAsync(h->refresh.list, 0xff, entries * 4, h->stream));
-            if (h->B.memo_ver) hipLaunchKernelGGL(k_refresh_memo, dim3(1024), dim3(256), 0, h->stream, h->B, h->mid, h->N, h->K);
+            if (h->B.memo_ver) hipLaunchKernelGGL(k_refresh_memo, dim3(1024), dim3(256), 0, h->stream, h->B, h->mid, h->N, h->K, h->M);
             hipLaunchKernelGGL(k_refresh_count, dim3(1024), dim3(256), 0, h->stream, h->B, h->refresh, h->mid, h->N, h->K);
             hipLaunchKernelGGL(k_refresh_offsets, dim3(1), dim3(1), 0, h->stream, h->refresh, h->K);
             hipLaunchKernelGGL(k_refresh_fill, dim3(1024), dim3(256), 0, h->stream, h->B, h->refresh, h->mid, h->N);
@@ -1296,6 +1296,23 @@ int rp_kmeans_stats(rp_kmeans* h, uint64_t* distances, uint64_t* sinkhorn_iterat
     if (rc) return rc;
     if (distances) *distances = s[0];
     if (sinkhorn_iterations) *sinkhorn_iterations = s[1];
+    return RP_OK;
+}
+
+// diagnostics: the raw counters.  out[0] distances evaluated by a solve (or, variation metric, taken from the computed tile by Elkan's
+// rule), [1] Sinkhorn iterations, [2] softmin / cost terms, [3] distances the reference evaluates at that point of its loop and this
+// library REMEMBERS (Bounds::memo_*, the pairwise versions): [0] + [3] over the Elkan steps is the reference's own distance count,
+// [4] variation distances computed beyond the ones the rule evaluates (whole 64-centroid tiles)
+int rp_kmeans_stats_ex(rp_kmeans* h, uint64_t* out5) {
+    if (!h || !out5) return rp::fail(RP_ERR_INVALID, "rp_kmeans_stats_ex: NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<unsigned long long> all((size_t)KM_STAT_STRIPES * STAT_STRIDE);
+    HIP_TRY(hipMemcpyAsync(all.data(), h->stats, all.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (uint32_t k = 0; k < 5; ++k) {
+        out5[k] = 0;
+        for (uint32_t q = 0; q < KM_STAT_STRIPES; ++q) out5[k] += all[(size_t)q * STAT_STRIDE + k];
+    }
     return RP_OK;
 }
 

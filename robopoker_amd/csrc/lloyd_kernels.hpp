@@ -635,7 +635,7 @@ __device__ void wave_point_density(const Points& P, uint64_t i, uint32_t bins, f
 }
 // d[q] = variation(point, centroid q*64+lane) for q < 4
 __device__ void wave_variation_all(const float* pd, const CentroidSet& cs, uint32_t K, uint32_t bins, float d[4],
-                                   const Metric& M) {
+                                   const Metric& M, bool evaluated_all = true) {
     const uint32_t lane = lane_id();
 #pragma unroll
     for (uint32_t q = 0; q < 4; ++q) {
@@ -651,7 +651,8 @@ __device__ void wave_variation_all(const float* pd, const CentroidSet& cs, uint3
         }
         d[q] = s;
     }
-    if (lane == 0) atomicAdd(STAT(M, 0), (unsigned long long)K);
+    // Elkan::neighbor evaluates all K; k_elkan_step computes all K and counts the ones its rule evaluates itself (STAT 4: computed)
+    if (lane == 0) atomicAdd(STAT(M, evaluated_all ? 0 : 4), (unsigned long long)K);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1069,7 +1070,10 @@ __global__ __launch_bounds__(64) void k_pairwise(CentroidSet cs, uint32_t K, Met
         const uint32_t va = cver[a], vb = cver[b];
         // one decision for the wavefront, taken before lane 0 overwrites what it was taken from
         const bool same = pver[2 * blockIdx.x] == va && pver[2 * blockIdx.x + 1] == vb;
-        if (__builtin_amdgcn_readfirstlane((uint32_t)same)) return;
+        if (__builtin_amdgcn_readfirstlane((uint32_t)same)) {
+            if (a != b && lane_id() == 0) atomicAdd(STAT(M, 3), 1ull);  // remembered
+            return;
+        }
         if (lane_id() == 0) {
             pver[2 * blockIdx.x] = va;
             pver[2 * blockIdx.x + 1] = vb;
@@ -1125,8 +1129,8 @@ __global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uin
         sp = P.self[i];
     } else {
         wave_point_density(P, i, M.bins, w.f);
-        wave_variation_all(w.f, cs, K, M.bins, dv, M);  // distances to every centroid; the replay below uses only
-                                                        // the ones the sequential rule would have evaluated
+        wave_variation_all(w.f, cs, K, M.bins, dv, M, false);  // distances to every centroid; the replay below uses (and
+                                                               // counts) only the ones the sequential rule evaluates
     }
     auto distance_to = [&](uint32_t k) -> float {  // distance(point, centroid k)
         if (kind == RP_METRIC_SINKHORN) {
@@ -1137,6 +1141,7 @@ __global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uin
         }
         const uint32_t q = k >> 6, src = k & 63u;
         float mine = q == 0 ? dv[0] : (q == 1 ? dv[1] : (q == 2 ? dv[2] : dv[3]));
+        if (lane == 0) atomicAdd(STAT(M, 0), 1ull);
         return __shfl(mine, (int)src, 64);
     };
     float lw[4];
@@ -1156,7 +1161,9 @@ __global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uin
     };
     bool exact = false;  // u is an exact distance to the CURRENT centroid j, measured in this call
     if (B.stale[i]) {
-        const float d = memo_valid(B, i, j) ? B.memo_d[i] : distance_to(j);
+        const bool remembered = memo_valid(B, i, j);
+        if (remembered && lane == 0) atomicAdd(STAT(M, 3), 1ull);  // a distance the reference evaluates here and this pass remembers
+        const float d = remembered ? B.memo_d[i] : distance_to(j);
         set_lower(j, d);
         u = d;
         exact = true;
@@ -1207,7 +1214,8 @@ __device__ __forceinline__ bool needs_refresh(const Bounds& B, const Refresh& R,
     return B.stale[i] && B.u[i] > mid[B.j[i]] && R.nsup[i] <= PAIR_ROWS;
 }
 // stale bounds whose refresh is remembered: Bounds::refresh without the solve
-__global__ __launch_bounds__(256) void k_refresh_memo(Bounds B, const float* mid, uint64_t N, uint32_t K) {
+__global__ __launch_bounds__(256) void k_refresh_memo(Bounds B, const float* mid, uint64_t N, uint32_t K, Metric M) {
+    unsigned long long hits = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (uint64_t)gridDim.x * 256) {
         const uint32_t j = B.j[i];
         if (B.stale[i] && B.u[i] > mid[j] && memo_valid(B, i, j)) {
@@ -1215,8 +1223,11 @@ __global__ __launch_bounds__(256) void k_refresh_memo(Bounds B, const float* mid
             B.u[i] = d;
             B.lower[i * K + j] = d;
             B.stale[i] = 0;
+            hits += 1;
         }
     }
+    for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o, 64);
+    if ((threadIdx.x & 63u) == 0 && hits) atomicAdd(STAT(M, 3), hits);  // distances the reference evaluates and this pass remembers
 }
 __global__ __launch_bounds__(256) void k_refresh_count(Bounds B, Refresh R, const float* mid, uint64_t N, uint32_t K) {
     __shared__ uint32_t c[MAXB];
@@ -1433,7 +1444,9 @@ __global__ __launch_bounds__(256) void k_elkan_step_var(Points P, CentroidSet cs
     __syncthreads();
     // (skipping a wave's 64 centroids when none of them can become a candidate was measured: candidates are spread
     // over all four waves, the test costs more than it saves)
-    if (tid == 0) atomicAdd(STAT(M, 0), (unsigned long long)K * na);
+    // STAT 0 counts the distances Elkan's rule EVALUATES (the reference's count: the replay below), STAT 4 the ones computed to feed it
+    if (tid == 0) atomicAdd(STAT(M, 4), (unsigned long long)K * na);
+    unsigned long long evaluated = 0;
     for (uint32_t a = q; a < na; a += 4) {  // one wave per point, as k_elkan_step
         const uint64_t i = i0 + L.active[a];
         uint32_t j = B.j[i];
@@ -1457,6 +1470,7 @@ __global__ __launch_bounds__(256) void k_elkan_step_var(Points P, CentroidSet cs
             const float d = dist[a][j];
             set_lower(j, d);
             u = d;
+            evaluated += 1;
         }
         uint32_t start = 0;
         for (;;) {
@@ -1469,6 +1483,7 @@ __global__ __launch_bounds__(256) void k_elkan_step_var(Points P, CentroidSet cs
                 if (mask && found == K) found = qq * 64 + (uint32_t)__ffsll((long long)mask) - 1u;
             }
             if (found == K) break;
+            evaluated += 1;
             const float d = dist[a][found];
             set_lower(found, d);
             if (d < u) {
@@ -1488,6 +1503,7 @@ __global__ __launch_bounds__(256) void k_elkan_step_var(Points P, CentroidSet cs
             B.stale[i] = 0;
         }
     }
+    if (lane == 0 && evaluated) atomicAdd(STAT(M, 0), evaluated);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -156,6 +156,13 @@ class Layer:
         _lib.check(self._lib.rp_kmeans_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def stats_ex(self) -> dict:
+        """raw counters (rp_mi355x_diag.h): evaluated + remembered over Elkan steps is the reference's own distance count"""
+        a = np.zeros(5, dtype=np.uint64)
+        _lib.check(self._lib.rp_kmeans_stats_ex(self._h, _p(a)))
+        return {"evaluated": int(a[0]), "sinkhorn_iterations": int(a[1]), "terms": int(a[2]), "remembered": int(a[3]),
+                "computed_beyond": int(a[4])}
+
     def exp_evals(self) -> int:
         v = C.c_uint64()
         _lib.check(self._lib.rp_kmeans_exp_evals(self._h, C.byref(v)))
@@ -535,7 +542,9 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
     out["end_to_end_s"] = out["create_s"] + out["kmeanspp_s"] + out["init_bounds_s"] + total + out["lookup_s"]
     out["rms"] = layer.rms()
     d2, i2 = layer.stats()
+    ex = layer.stats_ex()
     out["distances_total"] = d2
+    out["distances_remembered"] = ex["remembered"]  # evaluated by the reference at that point, reused here (same centroid content)
     out["sinkhorn_iterations_total"] = i2
     ms = {name: layer.kernel_time(name) for name in ("pairwise", "step", "recompute", "bounds", "neighbor", "selfcost", "kpp",
                                                      "drift", "mfma_bound", "kpp_bound")}
@@ -547,6 +556,20 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
                                   "frac": gbps / HBM_PEAK_GBPS, "bytes_per_launch": N * K * 8, "avg_launch_ms": bd_ms / bd_n,
                                   "note": f"lower bounds f32[N][K] read + written once per Elkan iteration: {N * K * 8 / 1e9:.2f} GB per launch"
                                           " (past the 256 MiB Infinity Cache at full size)"}
+    if kind == "variation":
+        # the turn kernels (k_elkan_step_var / k_neighbor_var) keep 64 centroid CDFs per wavefront in registers and compute whole
+        # (point, 64 centroids) tiles — 2 VALU instructions per bin per tile — then replay Elkan's rule on the tile: what the rule
+        # EVALUATES is `distances_total` (the reference's count, tests/test_gpu_lloyd.py::test_elkan_iterations_bit_exact), what was
+        # computed beyond it is counted here
+        st_ms = ms["step"][0] + ms["neighbor"][0]
+        tiles = (ex["computed_beyond"] + N * K * 2) / 64.0  # init_bounds and lookup evaluate all K for every point
+        winstr = tiles * bins * 2.0
+        out["distances_computed_beyond_rule"] = ex["computed_beyond"]
+        out["roofline_variation"] = {"bound": "valu", "kernel": "k_elkan_step_var + k_neighbor_var", "achieved": winstr / (st_ms * 1e-3) if st_ms else 0.0,
+                                     "peak": VALU_PEAK_WAVE_INSTR, "unit": "wave-instructions/s",
+                                     "frac": winstr / (st_ms * 1e-3) / VALU_PEAK_WAVE_INSTR if st_ms else 0.0,
+                                     "note": "(point, 64-centroid) tiles x bins x 2 VALU instructions (t = cx - CY, s += |t|: equity.rs:41-53) over "
+                                             "the event-timed step and neighbor kernels; the CDF build and the rule's replay are not counted"}
     if kind == "sinkhorn":
         exps = layer.exp_evals() - e0
         valu_s = (ms["pairwise"][0] + ms["step"][0] + ms["neighbor"][0] + ms["selfcost"][0] + ms["kpp"][0] + ms["drift"][0]) * 1e-3

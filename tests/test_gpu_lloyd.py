@@ -129,11 +129,16 @@ def test_elkan_iterations_bit_exact(gpu, kind, K, N, bins, mass):
     ora.init_bounds()
     _check_state(dev, ora)
     for _ in range(4):
+        e0, o0 = dev.stats_ex(), oracle.lloyd_stats()[0]
         d1, s1, m1 = dev.step()
         d2, s2, m2 = ora.step()
         assert np.array_equal(bits(d1), bits(d2)), "drift differs"
         assert np.array_equal(s1, s2) and m1 == m2
         _check_state(dev, ora)
+        # the distances Elkan's rule evaluates in this step (has_shifted BEFORE the distance, bounds.rs:57-61): the reference's count —
+        # solved here, or remembered from an earlier step (same centroid content); the turn kernels compute whole tiles on top
+        e1, o1 = dev.stats_ex(), oracle.lloyd_stats()[0]
+        assert (e1["evaluated"] - e0["evaluated"]) + (e1["remembered"] - e0["remembered"]) == o1 - o0, (kind, e0, e1, o0, o1)
     b1, dd1 = dev.lookup()
     b2, dd2 = ora.assign()
     assert np.array_equal(b1, b2) and np.array_equal(bits(dd1), bits(dd2))
