@@ -48,6 +48,9 @@ struct __attribute__((aligned(16))) WaveLds {
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+#ifndef SPLIT_ROWS
+#define SPLIT_ROWS 1  // 0: every softmin row on one lane (the shape the split is checked against)
+#endif
 
 #if !LM_GLIBC  // the MFMA bound and its margins are validated for the contract arithmetic only: the glibc pass runs unpruned
 #include "sinkhorn_bound.hpp"
@@ -217,22 +220,21 @@ __device__ __forceinline__ float softmin_sum_lane(const uint16_t* sup, const flo
     }
     return s;
 }
+// the fold continues from (s, j): j a multiple of 8, s the left fold of the terms before j
 template <bool PIPE = true>
-__device__ __forceinline__ float softmin_sum(const uint16_t* sup, const float* pot, uint32_t cnt,
-                                              __amdgpu_buffer_rsrc_t rt, uint32_t bins, uint32_t xi) {
+__device__ __forceinline__ float softmin_sum_from(float s, uint32_t j, const uint16_t* sup, const float* pot, uint32_t cnt,
+                                                   __amdgpu_buffer_rsrc_t rt, uint32_t bins, uint32_t xi) {
     const uint32_t rowb = bins * 4u, xoff = xi * 4u;
-    float s = 0.0f;
-    uint32_t j = 0;
     if (!PIPE) {  // one group in flight: 16 fewer VGPRs (the two-point kernels keep 7 waves per SIMD with it)
         for (; j + 8 <= cnt; j += 8) {
             SoftminGroup cur;
             softmin_fetch(cur, sup, pot, j, rt, rowb, xoff);
             s = softmin_fold(s, cur);
         }
-    } else if (cnt >= 8) {  // software pipeline: the loads of group j+8 are in flight while group j is exponentiated
+    } else if (j + 8 <= cnt) {  // software pipeline: the loads of group j+8 are in flight while group j is exponentiated
         SoftminGroup cur, nxt;
-        softmin_fetch(cur, sup, pot, 0, rt, rowb, xoff);
-        for (j = 8; j + 8 <= cnt; j += 8) {
+        softmin_fetch(cur, sup, pot, j, rt, rowb, xoff);
+        for (j += 8; j + 8 <= cnt; j += 8) {
             softmin_fetch(nxt, sup, pot, j, rt, rowb, xoff);
             s = softmin_fold(s, cur);
             cur = nxt;
@@ -250,6 +252,66 @@ __device__ __forceinline__ float softmin_sum(const uint16_t* sup, const float* p
     }
     return s;
 }
+template <bool PIPE = true>
+__device__ __forceinline__ float softmin_sum(const uint16_t* sup, const float* pot, uint32_t cnt,
+                                              __amdgpu_buffer_rsrc_t rt, uint32_t bins, uint32_t xi) {
+    return softmin_sum_from<PIPE>(0.0f, 0u, sup, pot, cnt, rt, bins, xi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// A support with <= 32 rows leaves half the wavefront without a row while it walks the other support (the point side of a
+// point-against-centroid solve: up to 256 columns).  Lanes l and l ^ 32 then take the SAME row and alternate over the column groups:
+// of every 16 columns the lower half exponentiates the first 8, the upper half the next 8 — the exponentials are the cost of a
+// term — and the left fold stays the reference's: the running sum visits the lower half's eight terms, crosses to the upper half
+// (v_permlane32_swap), visits its eight, and crosses back.  Same terms, same order, same additions as softmin_sum.
+// ------------------------------------------------------------------------------------------------
+template <uint32_t SRC>
+__device__ __forceinline__ float half_take(float x) {  // the value lane (l & 31) + 32 SRC holds, in every lane l
+#if defined(RP_EMUL)
+    return __shfl(x, (int)((lane_id() & 31u) + 32u * SRC), 64);
+#else
+    const uint32_t w = __builtin_bit_cast(uint32_t, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(w, w, false, false);  // r[0]: the lower half's values in all lanes, r[1]: the upper's
+    const uint32_t lo = r[0], hi = r[1];
+    return __builtin_bit_cast(float, SRC ? hi : lo);
+#endif
+}
+__device__ __forceinline__ float softmin_sum_split(const uint16_t* sup, const float* pot, uint32_t cnt, __amdgpu_buffer_rsrc_t rt,
+                                                   uint32_t bins, uint32_t xi) {
+    const uint32_t rowb = bins * 4u, xoff = xi * 4u, up = lane_id() >> 5;
+    float s = 0.0f;
+    uint32_t j = 0;
+    for (; j + 16 <= cnt; j += 16) {
+        const uint32_t jj = j + 8u * up;
+        const uint4 sp = *reinterpret_cast<const uint4*>(sup + jj);
+        const float4 p0 = *reinterpret_cast<const float4*>(pot + jj), p1 = *reinterpret_cast<const float4*>(pot + jj + 4);
+        float r[8];
+        r[0] = rt_load(rt, (sp.x & 0xffffu) * rowb + xoff, 0);
+        r[1] = rt_load(rt, (sp.x >> 16) * rowb + xoff, 0);
+        r[2] = rt_load(rt, (sp.y & 0xffffu) * rowb + xoff, 0);
+        r[3] = rt_load(rt, (sp.y >> 16) * rowb + xoff, 0);
+        r[4] = rt_load(rt, (sp.z & 0xffffu) * rowb + xoff, 0);
+        r[5] = rt_load(rt, (sp.z >> 16) * rowb + xoff, 0);
+        r[6] = rt_load(rt, (sp.w & 0xffffu) * rowb + xoff, 0);
+        r[7] = rt_load(rt, (sp.w >> 16) * rowb + xoff, 0);
+        rp_f2 e0, e1, e2, e3;
+        e0.x = p0.x - r[0]; e0.y = p0.y - r[1];
+        e1.x = p0.z - r[2]; e1.y = p0.w - r[3];
+        e2.x = p1.x - r[4]; e2.y = p1.y - r[5];
+        e3.x = p1.z - r[6]; e3.y = p1.w - r[7];
+        e0 = LM_EXP_FLOOR2(e0);
+        e1 = LM_EXP_FLOOR2(e1);
+        e2 = LM_EXP_FLOOR2(e2);
+        e3 = LM_EXP_FLOOR2(e3);
+        float a = s;  // meaningful in the lower half: the fold over columns j .. j+7
+        a += e0.x; a += e0.y; a += e1.x; a += e1.y; a += e2.x; a += e2.y; a += e3.x; a += e3.y;
+        float b = half_take<0>(a);  // meaningful in the upper half: it goes on over columns j+8 .. j+15
+        b += e0.x; b += e0.y; b += e1.x; b += e1.y; b += e2.x; b += e2.y; b += e3.x; b += e3.y;
+        s = half_take<1>(b);
+    }
+    // fewer than 16 columns left: both halves fold them alike
+    return softmin_sum_from<false>(s, j, sup, pot, cnt, rt, bins, xi);
+}
 
 __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint32_t n, const Metric& M) {
     const uint32_t lane = lane_id();
@@ -260,9 +322,22 @@ __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint
     for (uint32_t i = lane; i < m; i += 64) w.f[i] = lu;
     for (uint32_t j = lane; j < n; j += 64) w.g[j] = ru;
     __syncthreads();
+    // a side with <= 32 rows against >= 32 columns: two lanes per row (softmin_sum_split)
+    const bool split_a = SPLIT_ROWS && m <= 32u && n >= 32u, split_b = SPLIT_ROWS && n <= 32u && m >= 32u;
     uint32_t t = 0;
     for (; t < M.iters; ++t) {
         // lhs(): f(x) <- ln mu(x) - ln sum_y max(exp(g(y) - C(x,y)/T), MIN_POSITIVE)   (sinkhorn.rs:94-102,119-128)
+        if (split_a) {
+            const uint32_t i = lane & 31u;
+            const bool act = i < m;
+            const uint32_t x = act ? w.supA[i] : w.supA[0];
+            const float s = softmin_sum_split(w.supB, w.g, n, rt, bins, x);
+            if (act && lane < 32u) {
+                const float nf = w.lnA[i] - LM_LOGF(s);
+                w.tmp[i] = rp_absf(LM_EXPF(nf) - LM_EXPF(w.f[i]));  // delta term (sinkhorn.rs:134-139)
+                w.f[i] = nf;
+            }
+        } else
         for (uint32_t i0 = 0; i0 < m; i0 += 64) {
             const uint32_t i = i0 + lane;
             const bool act = i < m;
@@ -278,6 +353,17 @@ __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint
         const float lhs_err = lds_sum_in_order(w.tmp, m);
         __syncthreads();
         // rhs(): sees the fresh lhs (Gauss-Seidel, sinkhorn.rs:80-87)
+        if (split_b) {
+            const uint32_t j = lane & 31u;
+            const bool act = j < n;
+            const uint32_t y = act ? w.supB[j] : w.supB[0];
+            const float s = softmin_sum_split(w.supA, w.f, m, rt, bins, y);
+            if (act && lane < 32u) {
+                const float ng = w.lnB[j] - LM_LOGF(s);
+                w.tmp[j] = rp_absf(LM_EXPF(ng) - LM_EXPF(w.g[j]));
+                w.g[j] = ng;
+            }
+        } else
         for (uint32_t j0 = 0; j0 < n; j0 += 64) {
             const uint32_t j = j0 + lane;
             const bool act = j < n;

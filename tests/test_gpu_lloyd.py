@@ -34,7 +34,10 @@ def test_sinkhorn_fixture_bit_exact_and_properties(gpu):
         assert bits(c[k]) == bits(ec) and it[k] == eit
 
 
-@pytest.mark.parametrize("bins,nnz_a,nnz_b", [(32, 5, 9), (101, 30, 60), (256, 47, 256), (256, 256, 47), (64, 1, 64)])
+# the last four: a side with <= 32 rows against >= 32 columns takes two lanes per row (softmin_sum_split): either side, column counts
+# with every remainder class of 16 and of 8
+@pytest.mark.parametrize("bins,nnz_a,nnz_b", [(32, 5, 9), (101, 30, 60), (256, 47, 256), (256, 256, 47), (64, 1, 64),
+                                              (256, 256, 20), (256, 17, 250), (128, 32, 33), (256, 201, 32)])
 def test_sinkhorn_random_pairs_bit_exact(gpu, bins, nnz_a, nnz_b):
     rng = np.random.default_rng(bins * 1000 + nnz_a)
     tri = random_metric(bins, rng)
