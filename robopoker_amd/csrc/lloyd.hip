@@ -238,7 +238,12 @@ int prepare_centroids(rp_kmeans* h, int set, bool replaces_other = false) {
     else
         h->memo_dirty = true, h->pairw_seen = false;
     ck_begin(h, CK_SELF);
-    hipLaunchKernelGGL(KSEL(h, k_prepare_centroids), dim3(h->K), dim3(64), 0, h->stream, h->cs[set], h->K, h->M, h->kind, 0u);
+    if (h->kind == RP_METRIC_SINKHORN) {  // the tables by one wavefront per centroid, OT(c, c) by four (K solves of up to 256 x 256 bins)
+        hipLaunchKernelGGL(KSEL(h, k_prepare_centroids), dim3(h->K), dim3(64), 0, h->stream, h->cs[set], h->K, h->M, h->kind, 0u,
+                           (const float*)h->cs[set].self);
+        hipLaunchKernelGGL(KSEL(h, k_self_block), dim3(h->K), dim3(256), 0, h->stream, h->cs[set], h->K, h->M);
+    } else
+        hipLaunchKernelGGL(KSEL(h, k_prepare_centroids), dim3(h->K), dim3(64), 0, h->stream, h->cs[set], h->K, h->M, h->kind, 0u, (const float*)nullptr);
     ck_end(h, CK_SELF);
     HIP_TRY(hipGetLastError());
     return RP_OK;
@@ -742,7 +747,10 @@ int step_back(rp_kmeans* h, float* drift, uint64_t* sizes, double* reassigned) {
     int rc = prepare_centroids(h, nxt, true);
     if (rc) return rc;
     ck_begin(h, CK_DRIFT);
-    hipLaunchKernelGGL(KSEL(h, k_drift), dim3(h->K), dim3(64), 0, h->stream, h->cs[nxt], h->cs[cur], h->K, h->M, h->kind, h->drift);
+    if (h->kind == RP_METRIC_SINKHORN)
+        hipLaunchKernelGGL(KSEL(h, k_drift_block), dim3(h->K), dim3(256), 0, h->stream, h->cs[nxt], h->cs[cur], h->K, h->M, h->drift);
+    else
+        hipLaunchKernelGGL(KSEL(h, k_drift), dim3(h->K), dim3(64), 0, h->stream, h->cs[nxt], h->cs[cur], h->K, h->M, h->kind, h->drift);
     ck_end(h, CK_DRIFT);
     ck_begin(h, CK_BOUNDS);
     hipLaunchKernelGGL(k_bounds_update, dim3(2048), dim3(256), 0, h->stream, h->B, h->N, h->K, h->drift);
@@ -853,7 +861,7 @@ int rp_kmeans_kpp_begin(rp_kmeans* h) {
     // all centroids start empty so every derived table is well defined for the not-yet-chosen ones
     HIP_TRY(hipMemsetAsync(cs.counts, 0, (size_t)h->K * h->bins * 4, h->stream));
     HIP_TRY(hipMemsetAsync(cs.weight, 0, h->K * 4, h->stream));
-    hipLaunchKernelGGL(KSEL(h, k_prepare_centroids), dim3(h->K), dim3(64), 0, h->stream, cs, h->K, h->M, h->kind, 0u);
+    hipLaunchKernelGGL(KSEL(h, k_prepare_centroids), dim3(h->K), dim3(64), 0, h->stream, cs, h->K, h->M, h->kind, 0u, (const float*)nullptr);
     hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, h->stream, h->pot, h->N, 1.0f);  // potentials = 1 (layer.rs:161)
     if (h->M.kpp_d) hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, h->stream, h->M.kpp_d, h->N, rp_u2f(0x7f800000u));
     HIP_TRY(hipGetLastError());
@@ -1003,7 +1011,7 @@ int rp_kmeans_set_centroid(rp_kmeans* h, uint32_t k, const uint32_t* counts) {
         h->cent_m[k] = m;
     }
     hipLaunchKernelGGL(k_centroid_from_hist, dim3(1), dim3(256), 0, h->stream, h->cs[h->cur], k, h->hist_stage, h->bins);
-    hipLaunchKernelGGL(KSEL(h, k_prepare_centroids), dim3(1), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, k);
+    hipLaunchKernelGGL(KSEL(h, k_prepare_centroids), dim3(1), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, k, (const float*)nullptr);
     h->memo_dirty = true, h->pairw_seen = false;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));  // `counts` may be a temporary on the caller's side
@@ -1051,7 +1059,8 @@ int rp_kmeans_init_centroids(rp_kmeans* h, uint64_t* chosen) {
         if (chosen) chosen[k] = pick;
         if (!h->ns_host.empty()) h->cent_m[k] = h->ns_host[pick];
         hipLaunchKernelGGL(k_centroid_from_point, dim3(1), dim3(256), 0, h->stream, h->cs[h->cur], k, h->P, pick, h->bins);
-        hipLaunchKernelGGL(KSEL(h, k_prepare_centroids), dim3(1), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, k);
+        hipLaunchKernelGGL(KSEL(h, k_prepare_centroids), dim3(1), dim3(64), 0, h->stream, h->cs[h->cur], h->K, h->M, h->kind, k,
+                           h->kind == RP_METRIC_SINKHORN ? h->P.self + pick : (const float*)nullptr);  // OT(c, c) = the point's memoised OT(p, p)
         h->memo_dirty = true, h->pairw_seen = false;
         HIP_TRY(hipGetLastError());
         if ((rc = rp_kmeans_kpp_update(h, k))) return rc;

@@ -313,17 +313,22 @@ __device__ __forceinline__ float softmin_sum_split(const uint16_t* sup, const fl
     return softmin_sum_from<false>(s, j, sup, pot, cnt, rt, bins, xi);
 }
 
+// NTHR = 64: one wavefront per solve.  NTHR = 256: the rows of every half-iteration spread over the four wavefronts of a workgroup (the K
+// centroid-against-centroid solves of Elkan::drift and the centroids' self costs: 256 solves of 256 x 256 supports, one wavefront each
+// would leave three quarters of the chip idle and every one of them latency bound) — the same operations on the same rows, the folds
+// (error sums, cost) evaluated by every work-item from LDS as before.
+template <uint32_t NTHR = 64u>
 __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint32_t n, const Metric& M) {
-    const uint32_t lane = lane_id();
+    const uint32_t lane = NTHR == 64u ? lane_id() : threadIdx.x;
     if (m == 0 || n == 0) return -0.0f;  // empty support: the cost sum is empty, and f32's Sum folds from -0.0 (libcore since 1.83)
     const uint32_t bins = M.bins;
     const __amdgpu_buffer_rsrc_t rt = rt_resource(M);
     const float lu = LM_LOGF(1.0f / (float)m), ru = LM_LOGF(1.0f / (float)n);  // Potential::uniform (phi.rs:34-39)
-    for (uint32_t i = lane; i < m; i += 64) w.f[i] = lu;
-    for (uint32_t j = lane; j < n; j += 64) w.g[j] = ru;
+    for (uint32_t i = lane; i < m; i += NTHR) w.f[i] = lu;
+    for (uint32_t j = lane; j < n; j += NTHR) w.g[j] = ru;
     __syncthreads();
     // a side with <= 32 rows against >= 32 columns: two lanes per row (softmin_sum_split)
-    const bool split_a = SPLIT_ROWS && m <= 32u && n >= 32u, split_b = SPLIT_ROWS && n <= 32u && m >= 32u;
+    const bool split_a = SPLIT_ROWS && NTHR == 64u && m <= 32u && n >= 32u, split_b = SPLIT_ROWS && NTHR == 64u && n <= 32u && m >= 32u;
     uint32_t t = 0;
     for (; t < M.iters; ++t) {
         // lhs(): f(x) <- ln mu(x) - ln sum_y max(exp(g(y) - C(x,y)/T), MIN_POSITIVE)   (sinkhorn.rs:94-102,119-128)
@@ -338,7 +343,8 @@ __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint
                 w.f[i] = nf;
             }
         } else
-        for (uint32_t i0 = 0; i0 < m; i0 += 64) {
+        for (uint32_t i0 = 0; i0 < m; i0 += NTHR) {
+            if (NTHR > 64u && i0 + (lane & ~63u) >= m) break;  // this wavefront has no row in the pass (wave uniform)
             const uint32_t i = i0 + lane;
             const bool act = i < m;
             const uint32_t x = act ? w.supA[i] : w.supA[0];
@@ -364,7 +370,8 @@ __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint
                 w.g[j] = ng;
             }
         } else
-        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+        for (uint32_t j0 = 0; j0 < n; j0 += NTHR) {
+            if (NTHR > 64u && j0 + (lane & ~63u) >= n) break;
             const uint32_t j = j0 + lane;
             const bool act = j < n;
             const uint32_t y = act ? w.supB[j] : w.supB[0];
@@ -392,7 +399,7 @@ __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint
     for (uint32_t i = 0; i < m; ++i) {
         const uint32_t x = w.supA[i];
         const float fi = w.f[i];
-        for (uint32_t j = lane; j < n; j += 64) {
+        for (uint32_t j = lane; j < n; j += NTHR) {
             const uint32_t y = w.supB[j];
             const float c = M.Cm[x * bins + y];
             w.tmp[j] = LM_EXPF(fi + w.g[j] - M.Rt[x * bins + y]) * c;
@@ -405,10 +412,11 @@ __device__ __forceinline__ float wave_sinkhorn_cost(WaveLds& w, uint32_t m, uint
 }
 
 // Sinkhorn::divergence (sinkhorn.rs:166-171) with memoised self terms
+template <uint32_t NTHR = 64u>
 __device__ __forceinline__ float wave_divergence(WaveLds& w, uint32_t m, uint32_t n, float selfA, float selfB,
                                                  const Metric& M) {
-    const float xy = wave_sinkhorn_cost(w, m, n, M);
-    if (lane_id() == 0) atomicAdd(STAT(M, 0), 1ull);
+    const float xy = wave_sinkhorn_cost<NTHR>(w, m, n, M);
+    if ((NTHR == 64u ? lane_id() : threadIdx.x) == 0) atomicAdd(STAT(M, 0), 1ull);
     return rp_maxf(xy - 0.5f * selfA - 0.5f * selfB, 0.0f);
 }
 
@@ -662,7 +670,9 @@ __global__ __launch_bounds__(64) void k_point_self(Points P, Metric M, float* se
 }
 
 // derive support / ln-density / transposed density tables of a centroid set, and OT(c,c) for Sinkhorn layers
-__global__ __launch_bounds__(64) void k_prepare_centroids(CentroidSet cs, uint32_t K, Metric M, int kind, uint32_t k0) {
+// self_from: OT(c, c) is already known (the centroid is a copy of a point whose memoised OT(p, p) this is: the same histogram, the same
+// solve, the same bits) — the k-means++ rounds install one such centroid each and would otherwise wait for a one-wavefront solve
+__global__ __launch_bounds__(64) void k_prepare_centroids(CentroidSet cs, uint32_t K, Metric M, int kind, uint32_t k0, const float* self_from) {
     __shared__ WaveLds w;
     const uint32_t k = k0 + blockIdx.x;
     const uint32_t bins = M.bins;
@@ -687,7 +697,8 @@ __global__ __launch_bounds__(64) void k_prepare_centroids(CentroidSet cs, uint32
     if (lane_id() == 0) cs.n[k] = m;
     __syncthreads();
     float self = 0.0f;
-    if (kind == RP_METRIC_SINKHORN) self = wave_sinkhorn_cost(w, m, m, M);
+    if (kind == RP_METRIC_SINKHORN && self_from == cs.self) return;  // the caller runs k_self_block on the prepared tables next
+    if (kind == RP_METRIC_SINKHORN) self = self_from ? *self_from : wave_sinkhorn_cost(w, m, m, M);
     if (lane_id() == 0) cs.self[k] = self;
 }
 
@@ -1696,6 +1707,24 @@ __global__ __launch_bounds__(64) void k_drift(CentroidSet nw, CentroidSet old, u
         if (lane_id() == 0) atomicAdd(STAT(M, 0), 1ull);
     }
     if (lane_id() == 0) drift[k] = d;
+}
+
+// Elkan::drift and the centroids' OT(c, c) with four wavefronts per solve (wave_sinkhorn_cost<256>): Sinkhorn layers
+__global__ __launch_bounds__(256) void k_drift_block(CentroidSet nw, CentroidSet old, uint32_t K, Metric M, float* drift) {
+    __shared__ WaveLds w;
+    const uint32_t k = blockIdx.x;
+    const uint32_t m = wave_load_centroid(nw, k, w.supA, w.lnA);  // every wavefront stores the same values
+    const uint32_t n = wave_load_centroid(old, k, w.supB, w.lnB);
+    const float d = wave_divergence<256u>(w, m, n, nw.self[k], old.self[k], M);
+    if (threadIdx.x == 0) drift[k] = d;
+}
+__global__ __launch_bounds__(256) void k_self_block(CentroidSet cs, uint32_t K, Metric M) {
+    __shared__ WaveLds w;
+    const uint32_t k = blockIdx.x;
+    const uint32_t m = wave_load_centroid(cs, k, w.supA, w.lnA);
+    (void)wave_load_centroid(cs, k, w.supB, w.lnB);
+    const float c = wave_sinkhorn_cost<256u>(w, m, m, M);
+    if (threadIdx.x == 0) cs.self[k] = c;
 }
 
 // Bounds::update (bounds.rs:69-77): the HBM-streaming part of an iteration (N*K lower bounds read + written)
