@@ -126,7 +126,9 @@ typedef struct rp_state {
     uint8_t n_children; /* branching factor (0 for terminals)                                */
     uint16_t chance_info; /* chance states, reference-seed mode only: 1 + index of the node's info among rp_hash_streams.chance;
                              0 = this chance state has no counterpart in the reference's trees (the root deal, which the
-                             reference takes from the thread RNG, kuhn/src/game.rs:115-123) and keeps the counter hash   */
+                             reference takes from the thread RNG, kuhn/src/game.rs:115-123) and keeps the counter hash.
+                             Was `reserved` before 0.4: a caller that builds its own rp_game_table MUST zero it unless it hands
+                             hash streams to rp_mccfr_set_rng (a stray value in range selects the wrong chance stream)       */
     uint32_t info;      /* infoset id at player states, RP_NO_INFO otherwise                  */
     uint32_t offset;    /* player/chance: first child in children[]; terminal: row in payoffs */
 } rp_state;
@@ -503,7 +505,9 @@ typedef enum rp_libm_kind { RP_LIBM_CONTRACT = 0, RP_LIBM_GLIBC = 1 } rp_libm_ki
  * the bit-faithful solves — the k-means++ column bound, the k-means++ interval filter, the MFMA bound of the neighbor passes — stay
  * in place: their margins (4e-5 relative, 4e-6 absolute) sit three orders above the <= 7 ulps between the two arithmetics, and the
  * full flop layer has been audited in both (profiles/r05_glibc_audit.json, profiles/r03_mfma_audit.json: 0 of 1 286 792 points differ
- * from the unpruned search).  rp_kmeans_set_prune(h, 0) runs every distance through the bit-faithful kernel instead. */
+ * from the unpruned search).  rp_kmeans_set_prune(h, 0) runs every distance through the bit-faithful kernel instead.
+ * Host assumption of RP_LIBM_GLIBC ("bit for bit with a Rust build"): x86-64 glibc whose expf is the FMA variant (the ifunc every
+ * AVX2 machine selects); rp_libm_glibc.h restates that one, and tests/test_libm_glibc.py compares it with the platform's libm. */
 RP_API int rp_kmeans_set_libm(rp_kmeans* h, rp_libm_kind kind);
 /* enable = 0: no filter in front of the exact solves (Elkan::neighbor / Layer::init_centroids as the reference loops them, every
  * (point, centroid) pair solved): the yardstick the filtered passes are audited against.  Before the first centroid; a layer that

@@ -371,7 +371,8 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     // tree.  Nodes per tree: 280 / 660 on average by walker on a fresh table, 3 300 the largest — and they GROW with training (the
     // opponent's average strategy calls and raises more than the warm-start bias: 760 per tree after a few steps on the trained
     // abstraction): 1 536 per tree of budget, 92 B each (the batch's total is what counts)
-    const uint64_t dec_cap64 = std::max<uint64_t>((uint64_t)batch * 160u, 4096u);
+    // (round 5: 224 — after a few steps of external sampling in the reference's float order a 262 144-tree batch emitted 175 per tree)
+    const uint64_t dec_cap64 = std::max<uint64_t>((uint64_t)batch * 224u, 4096u);
     // RP_NLHE_NODE_BUDGET = "<nodes per tree>[,<walker divisor>]" (tests of the chunked retry): the node budget per tree, and the
     // share of it the walker-node arrays hold (a quarter by default: ",16" makes a pass overflow THOSE arrays with nodes to spare)
     const char* budget_env = getenv("RP_NLHE_NODE_BUDGET");
