@@ -1882,57 +1882,66 @@ __global__ __launch_bounds__(1024) void k_kpp_pick(float* pot, float* kpp_d, uin
 }
 // reference-seed mode (rp_kmeans_set_rng RP_RNG_REFERENCE): WeightedIndex::<f32>::new(potentials).sample(rng) (layer.rs:164-166;
 // rand 0.9.2 weighted_index.rs).  Its cumulative weights are f32 running sums in index order — f32 addition does not re-associate,
-// so the chain is sequential by definition: ONE wavefront walks it, 1024 potentials at a time through LDS; every lane runs the
-// same chain off broadcast LDS reads and keeps the sums of its own positions, so loads and stores stay coalesced.  ~4 ns per point:
-// 5 ms per pick at the flop layer's 1.3 M points, a few per cent of the round's Sinkhorn solves.
+// so the chain is sequential by definition: ONE wavefront walks it, 1024 potentials at a time through LDS (coalesced loads, broadcast
+// ds_read_b128), every lane running the same chain of dependent adds: one add per term is all the chain costs (~3 ms per pick at the
+// flop layer's 1.3 M points).  Only the running sum at the END of every 1024-chunk is kept (`cum`, N / 1024 floats): the sums are
+// non-decreasing (potentials >= 0), so the sample's partition point lies in the first chunk whose end exceeds the draw, and that one
+// chunk is walked again.
 // v01 = the generator's draw as UniformFloat<f32> maps it to [0, 1) (the host owns the SmallRng: one next_u32 per pick).
 __global__ __launch_bounds__(64) void k_kpp_ref_pick(float* pot, float* kpp_d, uint64_t N, float* cum, float v01, unsigned long long* picked) {
-    __shared__ float buf[KR_CHUNK];
+    __shared__ __attribute__((aligned(16))) float buf[KR_CHUNK];
     const uint32_t ln = threadIdx.x;
-    float run = 0.0f;  // total_weight (0 + w0 = w0 exactly)
-    for (uint64_t base = 0; base < N; base += KR_CHUNK) {
+    const uint64_t nchunks = (N + KR_CHUNK - 1) / KR_CHUNK;
+    auto load_chunk = [&](uint64_t base) {
 #pragma unroll
         for (uint32_t q = 0; q < KR_CHUNK / 64u; ++q) {
             const uint64_t i = base + q * 64u + ln;
             buf[q * 64u + ln] = i < N ? pot[i] : 0.0f;  // + 0 past the end leaves the sum as it is
         }
+    };
+    float run = 0.0f;  // total_weight (0 + w0 = w0 exactly)
+    for (uint64_t c = 0; c < nchunks; ++c) {
+        load_chunk(c * KR_CHUNK);
         __syncthreads();
-        float mine[KR_CHUNK / 64u];
-#pragma unroll
-        for (uint32_t q = 0; q < KR_CHUNK / 64u; ++q) {
-            mine[q] = 0.0f;
-#pragma unroll
-            for (uint32_t j = 0; j < 64u; ++j) {
-                run += buf[q * 64u + j];
-                mine[q] = j == ln ? run : mine[q];
-            }
+#pragma unroll 8
+        for (uint32_t j = 0; j < KR_CHUNK; j += 4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(buf + j);
+            run += w4.x; run += w4.y; run += w4.z; run += w4.w;
         }
-#pragma unroll
-        for (uint32_t q = 0; q < KR_CHUNK / 64u; ++q) {
-            const uint64_t i = base + q * 64u + ln;
-            if (i < N) cum[i] = mine[q];  // cum[i] = w_0 + ... + w_i; WeightedIndex keeps i < N - 1, the last one is the total
-        }
+        if (ln == 0) cum[c] = run;  // w_0 + ... + w_(1024 c + 1023)
         __syncthreads();
     }
-    __threadfence();
-    __syncthreads();
-    if (ln != 0) return;
     const float total = run;
     uint64_t win = N;  // invalid weights (total == 0): the reference panics ("valid weights array"); the host falls back
-    if (total > 0.0f) {
+    if (total > 0.0f) {  // wave uniform
         const float x = v01 * rp_uniform_f32_scale(total) + 0.0f;  // UniformFloat::sample: value0_1 * scale + low
-        uint64_t lo = 0, hi = N - 1;                               // partition_point(|w| w <= x) over cum[0 .. N-1)
+        // partition_point(|w| w <= x) over cum[0 .. N-1): the first index whose running sum exceeds x, N - 1 if none does
+        __threadfence();
+        uint64_t lo = 0, hi = nchunks;  // first chunk whose END sum exceeds x
         while (lo < hi) {
             const uint64_t mid = lo + (hi - lo) / 2;
-            // (an agent-scope load: the sums were written by the other lanes of this wavefront a moment ago)
+            // (an agent-scope load: the sums were written by lane 0 of this wavefront a moment ago)
             if (rp_u2f(__hip_atomic_load(reinterpret_cast<const uint32_t*>(cum) + mid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= x) lo = mid + 1;
             else hi = mid;
         }
-        win = lo;
-        pot[win] = 0.0f;                // potentials[i] = 0 (layer.rs:168)
-        if (kpp_d) kpp_d[win] = -1.0f;  // no solve stands behind that 0
+        win = N - 1;
+        if (lo < nchunks) {
+            float r2 = lo ? rp_u2f(__hip_atomic_load(reinterpret_cast<const uint32_t*>(cum) + lo - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0f;
+            load_chunk(lo * KR_CHUNK);
+            __syncthreads();
+            uint32_t at = KR_CHUNK;
+            for (uint32_t j = 0; j < KR_CHUNK; ++j) {  // the same adds as above, from the same start: the same sums
+                r2 += buf[j];
+                if (at == KR_CHUNK && r2 > x) at = j;
+            }
+            if (at < KR_CHUNK) win = min(lo * KR_CHUNK + at, N - 1);
+        }
+        if (ln == 0) {
+            pot[win] = 0.0f;                // potentials[i] = 0 (layer.rs:168)
+            if (kpp_d) kpp_d[win] = -1.0f;  // no solve stands behind that 0
+        }
     }
-    picked[0] = win;
+    if (ln == 0) picked[0] = win;
 }
 // potentials <- min(potentials, d(new centroid, point)^2) (layer.rs:170-178): distance(&x, h), centroid first
 __global__ __launch_bounds__(64) void k_kpp_update(Points P, CentroidSet cs, uint32_t k, uint32_t K, Metric M, int kind,
