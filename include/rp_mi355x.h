@@ -378,6 +378,10 @@ RP_API int rp_profile_fold(rp_profile* h, const void* entries_dev, uint32_t n_en
  * pair of launches, kernels sorted by node kind: robopoker_amd/csrc/nlmc_level.hpp) in 1 536 nodes of budget per tree
  * (92 B each); a batch that needs more is traversed in several passes over contiguous ranges of its trees (same Decisions).  Sampling scheme: ExternalSampling (the mccfr! macro's default) until rp_nlhe_set_sampling selects
  * PrunableSampling / PluribusSampling (Flagship, nlhe/src/lib.rs:86-90; thresholds from `hp`).
+ * Device memory beside the table: 224 Decisions of buffer per tree (~120 B each) and the node arrays.  A batch of at most 2 048
+ * trees (the reference runs 128) takes the one-tree-per-workgroup kernel and reserves a region of 8 192 nodes (92 + 192 B each: the
+ * reference-order evaluation arrays are always allocated there) and 9 floats per walker slot PER TREE: 0.3 GB at 128 trees, 4.8 GB at
+ * 2 048; the region is not released when a tree outgrows it and the handle falls back to the level-synchronous kernels.
  * Oracle: oracle/rp_oracle_nlmc.c. */
 typedef struct rp_nlhe rp_nlhe;
 typedef struct rp_lookup rp_lookup;
