@@ -1393,30 +1393,31 @@ int rp_kmeans_kpp_bound_probe(rp_kmeans* h, uint32_t k, float* lo) {
     if (!h || !lo || k >= h->K) return rp::fail(RP_ERR_INVALID, "rp_kmeans_kpp_bound_probe: bad argument");
     if (!h->kb_on) return rp::fail(RP_ERR_UNSUPPORTED, "rp_kmeans_kpp_bound_probe: the layer has no k-means++ interval filter");
     HIP_TRY(hipSetDevice(h->device));
-    float *d_lo = nullptr, *d_pot = nullptr;
-    uint32_t* d_list = nullptr;
-    unsigned int* d_ctl = nullptr;
+    // one scratch allocation (diagnostics: freed on every path): lo[N], pot[N], list in[N + 4], list out[N + 4], ctl[4]
     const size_t N = (size_t)h->N;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_lo), N * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_pot), N * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_list), (N + 4) * 4 * 2));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ctl), 16));
+    unsigned char* scratch = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), (4 * N + 8 + 4) * 4));
+    float* d_lo = reinterpret_cast<float*>(scratch);
+    float* d_pot = d_lo + N;
+    uint32_t* d_list = reinterpret_cast<uint32_t*>(d_pot + N);
+    unsigned int* d_ctl = reinterpret_cast<unsigned int*>(d_list + 2 * (N + 4));
     std::vector<uint32_t> ids(N);
     for (size_t i = 0; i < N; ++i) ids[i] = (uint32_t)i;
     const unsigned int ctl[4] = {(unsigned int)N, 0u, 0u, 0u};  // [0] count in, [1] cursor, [2] count out
-    HIP_TRY(hipMemcpyAsync(d_list, ids.data(), N * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(d_ctl, ctl, 16, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemsetAsync(d_lo, 0, N * 4, h->stream));
-    hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, h->stream, d_pot, h->N, -1.0f);  // lo^2 >= -1 always: every window runs to its end
-    hipLaunchKernelGGL((k_kpp_bound<64, 48>), dim3(2048), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
-                       (const float*)d_pot, (const uint32_t*)d_list, (const unsigned int*)d_ctl, d_ctl + 1, d_list + N + 4, d_ctl + 2,
-                       h->kb_stats, d_lo);
-    (void)hipMemcpyAsync(lo, d_lo, N * 4, hipMemcpyDeviceToHost, h->stream);
-    const hipError_t e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d_lo);
-    (void)hipFree(d_pot);
-    (void)hipFree(d_list);
-    (void)hipFree(d_ctl);
+    hipError_t e = hipMemcpyAsync(d_list, ids.data(), N * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ctl, ctl, 16, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_lo, 0, N * 4, h->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, h->stream, d_pot, h->N, -1.0f);  // lo^2 >= -1 always: every window runs to its end
+        hipLaunchKernelGGL((k_kpp_bound<64, 48>), dim3(2048), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
+                           (const float*)d_pot, (const uint32_t*)d_list, (const unsigned int*)d_ctl, d_ctl + 1, d_list + N + 4, d_ctl + 2,
+                           h->kb_stats, d_lo);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(lo, d_lo, N * 4, hipMemcpyDeviceToHost, h->stream);
+    const hipError_t e2 = hipStreamSynchronize(h->stream);  // `ids` and `ctl` are locals
+    (void)hipFree(scratch);
+    if (e == hipSuccess) e = e2;
     if (e != hipSuccess) return rp::fail(RP_ERR_HIP, "rp_kmeans_kpp_bound_probe: %s", hipGetErrorString(e));
     return RP_OK;
 }
