@@ -47,15 +47,17 @@ RP_HD double rp_u2d(uint64_t u) {
     return d;
 }
 
-/* T[i] = bits(RN(2^(i/32))) - (i << 47): the exponent field is added back from k (e_exp2f_data.c) */
+/* T[i] = bits(RN(2^(i/32))) - (i << 47): the exponent field is added back from k (e_exp2f_data.c).  The initialiser is a macro so that
+ * the device kernels can keep the same 32 numbers in LDS (robopoker_amd/csrc/lm_glibc_dev.hpp). */
+#define RP_GLIBC_EXP2F_TAB_INIT                                                                                                              \
+    {0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, \
+     0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull, \
+     0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, \
+     0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, \
+     0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, \
+     0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull}
 RP_HD uint64_t rp_glibc_exp2f_tab(uint32_t i) {
-    const uint64_t T[32] = {
-        0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
-        0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
-        0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
-        0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
-        0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
-        0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+    const uint64_t T[32] = RP_GLIBC_EXP2F_TAB_INIT;
     return T[i & 31u];
 }
 RP_HD float rp_glibc_expf(float x) {
@@ -84,14 +86,16 @@ RP_HD float rp_glibc_expf(float x) {
     y = y * s;
     return (float)y;
 }
+/* logf's table: sixteen (1/c, log c) pairs (e_logf_data.c) */
+#define RP_GLIBC_LOGF_TAB_INIT                                                                                                                \
+    {{0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2}, {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2}, \
+     {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3}, {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},   \
+     {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4}, {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, \
+     {0x1p+0, 0x0p+0},                              {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},   \
+     {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},   {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  \
+     {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}}
 RP_HD float rp_glibc_logf(float x) {
-    const double LT[16][2] = {
-        {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2}, {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},
-        {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3}, {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
-        {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4}, {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5},
-        {0x1p+0, 0x0p+0},                              {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
-        {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},   {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},
-        {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+    const double LT[16][2] = RP_GLIBC_LOGF_TAB_INIT;
     const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2, Ln2 = 0x1.62e42fefa39efp-1;
     uint32_t ix = rp_f2u(x);
     if (ix == 0x3f800000u) return 0.0f;
@@ -102,6 +106,76 @@ RP_HD float rp_glibc_logf(float x) {
         ix = rp_f2u(x * 0x1p23f); /* subnormal: normalise */
         ix -= 23u << 23;
     }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const uint32_t i = (tmp >> (23 - 4)) & 15u;
+    const int32_t k = (int32_t)tmp >> 23;
+    const uint32_t iz = ix - (tmp & 0xff800000u);
+    const double invc = LT[i][0], logc = LT[i][1], z = (double)rp_u2f(iz);
+    const double r = fma(z, invc, -1.0);
+    const double y0 = fma((double)k, Ln2, logc);
+    const double r2 = r * r;
+    double y = fma(A1, r, A2);
+    y = fma(A0, r2, y);
+    y = fma(y, r2, y0 + r);
+    return (float)y;
+}
+
+/* ---- The same two functions shaped for a wavefront (round 6).
+ * rp_glibc_expf above is glibc's control flow: a ladder of special cases in front of the arithmetic, which a GPU compiles into ~25
+ * exec-mask instructions per call, and a table the compiler leaves in global memory.  The functions below return THE SAME BITS for
+ * every input (swept over all 2^32 patterns against the ones above: tests/test_libm_glibc.py on the host, rp_libm_glibc_sweep on the
+ * device) without a branch: the argument is clamped to a range on which the arithmetic alone gives the ladder's answers —
+ *   x >= 89.5 and +inf  : y = e^89.5 > 2^128, and the double -> float conversion overflows to +inf like the ladder's `return inf`
+ *   x <= -104 and -inf  : y < 2^-150, the conversion rounds to +0 like `return 0`
+ *   NaN                 : fmaxf drops it (-104); the one compare + select at the end puts x + x back
+ * and the table pointer is a parameter, so that a kernel can hand in a copy it keeps in LDS (csrc/lm_glibc_dev.hpp).
+ * kd = rint(z) is (z + 0x1.8p52) - 0x1.8p52 for |z| < 2^51 (here |z| < 4200) and k its integer value, so ki's low 17 bits are k's.
+ * The _floor form is max(expf(x), f32::MIN_POSITIVE) (sinkhorn.rs:119-128): below -88 expf is under MIN_POSITIVE whatever its bits,
+ * and a NaN term yields MIN_POSITIVE (f32::max), which is what the clamp to -88 gives. */
+RP_HD double rp_glibc_exp_core(float xc, const uint64_t* T) { /* xc in [-104, 89.5] */
+    const double N = 32.0, InvLn2N = 0x1.71547652b82fep+0 * N;
+    const double C0 = 0x1.c6af84b912394p-5 / N / N / N, C1 = 0x1.ebfce50fac4f3p-3 / N / N, C2 = 0x1.62e42ff0c52d6p-1 / N;
+    const double xd = (double)xc;
+    const double z = InvLn2N * xd;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double kd = __builtin_rint(z); /* v_rndne_f64 */
+#else
+    const double kd = rint(z);
+#endif
+    const int32_t k = (int32_t)kd;
+    const double r = fma(InvLn2N, xd, -kd);
+    const uint64_t t0 = T[(uint32_t)k & 31u];
+    const uint32_t hi = (uint32_t)(t0 >> 32) + ((uint32_t)k << 15); /* t += ki << 47: only the high word moves */
+    const double s = rp_u2d(((uint64_t)hi << 32) | (uint32_t)t0);
+    const double p = fma(C0, r, C1);
+    const double r2 = r * r;
+    double y = fma(C2, r, 1.0);
+    y = fma(p, r2, y);
+    return y * s;
+}
+RP_HD float rp_glibc_expf_tab(float x, const uint64_t* T) { /* == rp_glibc_expf(x) */
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float xc = __builtin_fminf(__builtin_fmaxf(x, -104.0f), 89.5f);
+#else
+    const float xc = x != x ? -104.0f : (x < -104.0f ? -104.0f : (x > 89.5f ? 89.5f : x));
+#endif
+    const float y = (float)rp_glibc_exp_core(xc, T);
+    return x != x ? x + x : y;
+}
+RP_HD float rp_glibc_exp_floor_tab(float x, const uint64_t* T) { /* == rp_maxf(rp_glibc_expf(x), RP_EPSILON) */
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float xc = __builtin_fminf(__builtin_fmaxf(x, -88.0f), 89.5f);
+#else
+    const float xc = x != x ? -88.0f : (x < -88.0f ? -88.0f : (x > 89.5f ? 89.5f : x));
+#endif
+    return rp_maxf((float)rp_glibc_exp_core(xc, T), RP_EPSILON);
+}
+/* logf: one test in front (zero, subnormal, negative, inf, NaN: never on the Sinkhorn's path, whose arguments are sums of terms
+ * >= MIN_POSITIVE) instead of the ladder; log(1) = +0 comes out of the arithmetic (r = 0, k = 0, log c = 0). */
+RP_HD float rp_glibc_logf_tab(float x, const double (*LT)[2]) { /* == rp_glibc_logf(x) */
+    const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2, Ln2 = 0x1.62e42fefa39efp-1;
+    const uint32_t ix = rp_f2u(x);
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) return rp_glibc_logf(x);
     const uint32_t tmp = ix - 0x3f330000u;
     const uint32_t i = (tmp >> (23 - 4)) & 15u;
     const int32_t k = (int32_t)tmp >> 23;

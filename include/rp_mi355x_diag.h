@@ -24,6 +24,11 @@ RP_API int rp_math_exp_sweep(int device, uint64_t* mismatches);
  * the same for logf; wrapping u64 arithmetic, NaN results counted as 0x7fc00000.  A host evaluation of the same header gives the
  * same four numbers iff the two agree on every input (tests/test_gpu_z_glibc_mode.py). */
 RP_API int rp_libm_glibc_sweep(int device, uint64_t lo, uint64_t hi, uint64_t* sums);
+/* The forms of the same two functions that the lloyd kernels' glibc pass evaluates (branch-free, tables in LDS:
+ * csrc/lm_glibc_dev.hpp, include/rp_libm_glibc.h's rp_glibc_expf_tab / rp_glibc_exp_floor_tab / rp_glibc_logf_tab) against the ladder
+ * forms the sweep above pins to the host, on the device, over the same kind of range: mismatches[0] expf, [1] max(expf, MIN_POSITIVE),
+ * [2] logf, [3] the smallest mismatching bit pattern (~0 if none).  All counts must be 0. */
+RP_API int rp_libm_glibc_tab_sweep(int device, uint64_t lo, uint64_t hi, uint64_t* mismatches);
 /* The device-wide primitives under the row-addressed profile and the isomorphism enumeration (csrc/sortscan.hpp: stable LSD
  * radix sort of (key, index) pairs by the low `bits` bits of the key, run-length encoding of the sorted keys, exclusive
  * scan), run on n host keys so a test can compare them with a host sort: sorted_keys / perm [n]; uniq / starts / counts

@@ -92,6 +92,37 @@ ORA_API void ora_libm_glibc_sweep(uint64_t lo, uint64_t hi, uint64_t* bad_exp, u
     first[0] = fe;
     first[1] = fl;
 }
+/* the branch-free, table-parameterised forms the device kernels evaluate (rp_glibc_expf_tab, rp_glibc_exp_floor_tab,
+ * rp_glibc_logf_tab) against the forms above over every float bit pattern in [lo, hi): bad[0..2] mismatches (both NaN counts as
+ * equal), first[0..2] the first mismatching pattern of each (~0 if none) */
+ORA_API void ora_libm_glibc_tab_sweep(uint64_t lo, uint64_t hi, uint64_t* bad, uint32_t* first) {
+    static const uint64_t T[32] = RP_GLIBC_EXP2F_TAB_INIT;
+    static const double LT[16][2] = RP_GLIBC_LOGF_TAB_INIT;
+    uint64_t b0 = 0, b1 = 0, b2 = 0;
+    uint32_t f0 = 0xffffffffu, f1 = 0xffffffffu, f2 = 0xffffffffu;
+#pragma omp parallel for reduction(+ : b0, b1, b2) reduction(min : f0, f1, f2) schedule(static)
+    for (long long b = (long long)lo; b < (long long)hi; ++b) {
+        const float x = rp_u2f((uint32_t)b);
+        const float e = rp_glibc_expf(x);
+        const float a = rp_glibc_expf_tab(x, T);
+        if (rp_f2u(a) != rp_f2u(e) && !(a != a && e != e)) {
+            b0 += 1;
+            if ((uint32_t)b < f0) f0 = (uint32_t)b;
+        }
+        const float c = rp_glibc_exp_floor_tab(x, T), d = rp_maxf(e, RP_EPSILON);
+        if (rp_f2u(c) != rp_f2u(d)) {
+            b1 += 1;
+            if ((uint32_t)b < f1) f1 = (uint32_t)b;
+        }
+        const float g = rp_glibc_logf_tab(x, LT), h = rp_glibc_logf(x);
+        if (rp_f2u(g) != rp_f2u(h) && !(g != g && h != h)) {
+            b2 += 1;
+            if ((uint32_t)b < f2) f2 = (uint32_t)b;
+        }
+    }
+    bad[0] = b0, bad[1] = b1, bad[2] = b2;
+    first[0] = f0, first[1] = f1, first[2] = f2;
+}
 ORA_API float ora_glibc_expf(float x) { return rp_glibc_expf(x); }
 ORA_API float ora_glibc_logf(float x) { return rp_glibc_logf(x); }
 ORA_API void ora_glibc_vec(uint64_t n, const float* x, float* e, float* l) {

@@ -134,6 +134,7 @@ _SIGNATURES = {
     "rp_version": (C.c_char_p, []),
     "rp_math_selftest": (C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rp_libm_glibc_sweep": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "rp_libm_glibc_tab_sweep": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
     "rp_math_exp_sweep": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     "rp_sortscan_selftest": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32] + [C.c_void_p] * 8),
     "rp_hyper_default": (None, [C.POINTER(Hyper)]),

@@ -27,6 +27,7 @@
 #include "rp_internal.h"
 
 #include "lloyd_shared.hpp"
+#include "lm_glibc_dev.hpp"
 
 namespace rp {
 

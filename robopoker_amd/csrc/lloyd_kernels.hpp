@@ -3,22 +3,26 @@
 //   namespace rp::lm_glibc     (LM_GLIBC 1)  exp / ln = glibc's expf / logf evaluated in double (include/rp_libm_glibc.h, equal to glibc
 //                                            2.35's on all 2^32 inputs): f32::exp / f32::ln of a Rust build on Linux, so a layer clustered
 //                                            in this pass is the reference's bit for bit (rp_kmeans_set_libm / rp_sinkhorn_set_libm)
-// The two passes are the same source, term for term and in the same order; only the three spellings below differ.
+// The two passes are the same source, term for term and in the same order; only the spellings below differ.  The glibc pass evaluates
+// the header's branch-free forms on tables it keeps in LDS (lm_glibc_dev.hpp): every kernel that reaches an exponential or a logarithm
+// starts with LM_TABLES().
 #if LM_GLIBC
-#define LM_EXPF(x) rp_glibc_expf(x)
-#define LM_LOGF(x) rp_glibc_logf(x)
+#define LM_EXPF(x) rp_glibc_expf_tab(x, lmg::lds_exp)
+#define LM_LOGF(x) rp_glibc_logf_tab(x, lmg::lds_log)
 #define LM_EXP_FLOOR2(v) lm_exp_floor2_glibc(v)
+#define LM_TABLES() lmg::tables_init()
 // max(exp(x), MIN_POSITIVE) of two terms (sinkhorn.rs:119-128), as the oracle spells it on glibc's expf
 __device__ __forceinline__ rp_f2 lm_exp_floor2_glibc(rp_f2 x) {
     rp_f2 r;
-    r.x = rp_maxf(rp_glibc_expf(x.x), RP_EPSILON);
-    r.y = rp_maxf(rp_glibc_expf(x.y), RP_EPSILON);
+    r.x = rp_glibc_exp_floor_tab(x.x, lmg::lds_exp);
+    r.y = rp_glibc_exp_floor_tab(x.y, lmg::lds_exp);
     return r;
 }
 #else
 #define LM_EXPF(x) rp_expf(x)
 #define LM_LOGF(x) rp_logf(x)
 #define LM_EXP_FLOOR2(v) rp_exp_floor2(v)
+#define LM_TABLES() ((void)0)
 #endif
 
 
@@ -52,7 +56,8 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 #define SPLIT_ROWS 1  // 0: every softmin row on one lane (the shape the split is checked against)
 #endif
 
-#if !LM_GLIBC  // the MFMA bound and its margins are validated for the contract arithmetic only: the glibc pass runs unpruned
+#if !LM_GLIBC  // the scaling-domain filters have no exponential of their own: one copy (the contract namespace) serves both passes,
+               // their margins audited at full size in both arithmetics (profiles/r05_glibc_audit.json, rp_kmeans_set_prune)
 #include "sinkhorn_bound.hpp"
 #include "kpp_bound.hpp"
 #endif
@@ -657,6 +662,7 @@ __global__ __launch_bounds__(64) void k_point_weights(const uint8_t* counts, uin
 }
 
 __global__ __launch_bounds__(64) void k_point_self(Points P, Metric M, float* self_out) {
+    LM_TABLES();
     __shared__ WaveLds w;
     const uint64_t i = blockIdx.x;
     const uint32_t m = wave_load_hist(P.counts + i * P.stride, P.weight[i], M.bins, w.supA, w.lnA);
@@ -673,6 +679,7 @@ __global__ __launch_bounds__(64) void k_point_self(Points P, Metric M, float* se
 // self_from: OT(c, c) is already known (the centroid is a copy of a point whose memoised OT(p, p) this is: the same histogram, the same
 // solve, the same bits) — the k-means++ rounds install one such centroid each and would otherwise wait for a one-wavefront solve
 __global__ __launch_bounds__(64) void k_prepare_centroids(CentroidSet cs, uint32_t K, Metric M, int kind, uint32_t k0, const float* self_from) {
+    LM_TABLES();
     __shared__ WaveLds w;
     const uint32_t k = k0 + blockIdx.x;
     const uint32_t bins = M.bins;
@@ -767,6 +774,7 @@ __device__ __forceinline__ void memo_store(const Bounds& B, uint64_t i, uint32_t
 
 __global__ __launch_bounds__(64) void k_neighbor(Points P, CentroidSet cs, uint32_t K, Metric M, int kind,
                                                  uint8_t* out_j, float* out_d, Bounds init, const uint32_t* only) {
+    LM_TABLES();
     __shared__ WaveLds w;
     const uint64_t i = only ? only[blockIdx.x] : blockIdx.x;  // `only`: the points the grouped kernels do not take
     const uint32_t lane = lane_id();
@@ -830,6 +838,7 @@ __global__ __launch_bounds__(64) void k_neighbor(Points P, CentroidSet cs, uint3
 #define NB_CHUNKS 8u
 __global__ __launch_bounds__(64) void k_neighbor_chunk(Points P, CentroidSet cs, uint32_t K, Metric M, const uint32_t* list, uint8_t* tmp_j,
                                                        float* tmp_d) {
+    LM_TABLES();
     __shared__ WaveLds w;
     const uint32_t e = blockIdx.x / NB_CHUNKS, q = blockIdx.x % NB_CHUNKS;
     const uint64_t i = list[e];
@@ -885,6 +894,7 @@ __global__ __launch_bounds__(256) void k_neighbor_merge(const uint32_t* list, ui
 __global__ __launch_bounds__(64) void k_neighbor_masked(Points P, CentroidSet cs, uint32_t K, Metric M, const unsigned long long* mask,
                                                         uint8_t* out_j, float* out_d, Bounds init, const uint8_t* hint_j,
                                                         const float* hint_d) {
+    LM_TABLES();
     __shared__ WaveLds w;
     const uint64_t i = blockIdx.x;
     const uint32_t lane = lane_id();
@@ -1002,6 +1012,7 @@ __global__ __launch_bounds__(256) void k_audit_compare(const uint8_t* ja, const 
 template <uint32_t G>
 __global__ __launch_bounds__(64) void k_neighborG(Points P, CentroidSet cs, uint32_t K, Metric M, const uint32_t* groups,
                                                   uint8_t* out_j, float* out_d, Bounds init) {
+    LM_TABLES();
     __shared__ GroupLds<G> w;
     const uint32_t lane = lane_id();
     uint64_t ip[G];
@@ -1107,6 +1118,7 @@ __global__ __launch_bounds__(1024) void k_kpp_filter(Points P, CentroidSet cs, u
 template <uint32_t G>
 __global__ __launch_bounds__(64) void k_kpp_updateG(Points P, CentroidSet cs, uint32_t k, Metric M, const uint32_t* groups,
                                                     const unsigned int* count, float* pot) {
+    LM_TABLES();
     __shared__ GroupLds<G> w;
     const uint32_t have = count ? *count : 0xffffffffu;
     if (G * blockIdx.x >= have) return;
@@ -1161,6 +1173,7 @@ __global__ __launch_bounds__(256) void k_pairwise_var(CentroidSet cs, uint32_t K
 // changed keeps its value (distance(a, b) is a pure function of the two)
 __global__ __launch_bounds__(64) void k_pairwise(CentroidSet cs, uint32_t K, Metric M, int kind, float* pairw, const uint32_t* cver,
                                                  uint32_t* pver) {
+    LM_TABLES();
     __shared__ WaveLds w;
     const uint32_t a = blockIdx.x / K, b = blockIdx.x % K;
     if (pver) {
@@ -1212,6 +1225,7 @@ __global__ void k_midpoints(const float* pairw, uint32_t K, float* mid) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uint32_t K, Metric M, int kind, Bounds B,
                                                    const float* pairw, const float* mid) {
+    LM_TABLES();
     __shared__ WaveLds w;
     const uint64_t i = blockIdx.x;
     const uint32_t lane = lane_id();
@@ -1353,6 +1367,7 @@ __global__ __launch_bounds__(256) void k_refresh_fill(Bounds B, Refresh R, const
         }
 }
 __global__ __launch_bounds__(64) void k_refresh_pairs(Points P, CentroidSet cs, uint32_t K, Metric M, Bounds B, Refresh R) {
+    LM_TABLES();
     __shared__ GroupLds<2> w;
     const uint32_t e0 = 2u * blockIdx.x;
     if (e0 >= R.offset[K]) return;
@@ -1689,6 +1704,7 @@ __global__ __launch_bounds__(256) void k_recompute(Points P, const uint8_t* assi
 
 // Elkan::drift (elkan.rs:108-110): distance(new_k, old_k)
 __global__ __launch_bounds__(64) void k_drift(CentroidSet nw, CentroidSet old, uint32_t K, Metric M, int kind, float* drift) {
+    LM_TABLES();
     __shared__ WaveLds w;
     const uint32_t k = blockIdx.x;
     float d;
@@ -1711,6 +1727,7 @@ __global__ __launch_bounds__(64) void k_drift(CentroidSet nw, CentroidSet old, u
 
 // Elkan::drift and the centroids' OT(c, c) with four wavefronts per solve (wave_sinkhorn_cost<256>): Sinkhorn layers
 __global__ __launch_bounds__(256) void k_drift_block(CentroidSet nw, CentroidSet old, uint32_t K, Metric M, float* drift) {
+    LM_TABLES();
     __shared__ WaveLds w;
     const uint32_t k = blockIdx.x;
     const uint32_t m = wave_load_centroid(nw, k, w.supA, w.lnA);  // every wavefront stores the same values
@@ -1719,6 +1736,7 @@ __global__ __launch_bounds__(256) void k_drift_block(CentroidSet nw, CentroidSet
     if (threadIdx.x == 0) drift[k] = d;
 }
 __global__ __launch_bounds__(256) void k_self_block(CentroidSet cs, uint32_t K, Metric M) {
+    LM_TABLES();
     __shared__ WaveLds w;
     const uint32_t k = blockIdx.x;
     const uint32_t m = wave_load_centroid(cs, k, w.supA, w.lnA);
@@ -1759,6 +1777,7 @@ __global__ void k_tally(const uint8_t* j, uint8_t* prior, uint64_t N, unsigned l
 // distance(point, centroid[j]) for Elkan::rms_with (elkan.rs:191-200)
 __global__ __launch_bounds__(64) void k_point_dist(Points P, CentroidSet cs, uint32_t K, Metric M, int kind, const uint8_t* j,
                                                    float* out) {
+    LM_TABLES();
     __shared__ WaveLds w;
     const uint64_t i = blockIdx.x;
     const uint32_t k = j[i];
@@ -1946,6 +1965,7 @@ __global__ __launch_bounds__(64) void k_kpp_ref_pick(float* pot, float* kpp_d, u
 // potentials <- min(potentials, d(new centroid, point)^2) (layer.rs:170-178): distance(&x, h), centroid first
 __global__ __launch_bounds__(64) void k_kpp_update(Points P, CentroidSet cs, uint32_t k, uint32_t K, Metric M, int kind,
                                                    float* pot, const uint32_t* only, const unsigned int* count) {
+    LM_TABLES();
     __shared__ WaveLds w;
     if (count && blockIdx.x >= *count) return;
     const uint64_t i = only ? only[blockIdx.x] : blockIdx.x;
@@ -1979,6 +1999,7 @@ __global__ void k_fill(float* p, uint64_t n, float v) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_pair_sinkhorn(const uint32_t* mu, const uint32_t* nu, Metric M, int divergence,
                                                       float* out, uint32_t* iters_out) {
+    LM_TABLES();
     __shared__ WaveLds w;
     const uint64_t p = blockIdx.x;
     const uint32_t bins = M.bins, lane = lane_id();
@@ -2017,6 +2038,7 @@ __global__ __launch_bounds__(64) void k_pair_sinkhorn(const uint32_t* mu, const 
 // Coupling::flow (monge/src/coupling.rs:23-51 as Sinkhorn implements it, sinkhorn.rs:114-116,202-204) of ONE minimised pair:
 // coupling(x, y) = exp(lhs(x) + rhs(y) - C/T) and flow = coupling * C on supp(mu) x supp(nu), 0 elsewhere
 __global__ __launch_bounds__(64) void k_pair_flow(const uint32_t* mu, const uint32_t* nu, Metric M, float* flow, float* coupling) {
+    LM_TABLES();
     __shared__ WaveLds w;
     const uint32_t bins = M.bins, lane = lane_id();
     uint32_t wa = 0, wb = 0;
@@ -2044,6 +2066,7 @@ __global__ __launch_bounds__(64) void k_pair_flow(const uint32_t* mu, const uint
 // iteration counts need a private counter per pair: a second tiny variant keeps the hot kernel lean
 __global__ __launch_bounds__(64) void k_pair_iters(const uint32_t* mu, const uint32_t* nu, Metric M, unsigned long long* scratch,
                                                    uint32_t* iters_out) {
+    LM_TABLES();
     __shared__ WaveLds w;
     const uint64_t p = blockIdx.x;
     const uint32_t bins = M.bins, lane = lane_id();
@@ -2085,3 +2108,4 @@ __global__ void k_pair_variation(const uint32_t* x, const uint32_t* y, uint32_t 
 #undef LM_EXPF
 #undef LM_LOGF
 #undef LM_EXP_FLOOR2
+#undef LM_TABLES

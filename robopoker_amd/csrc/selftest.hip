@@ -6,6 +6,7 @@
 
 #include "../../include/rp_math.h"
 #include "../../include/rp_libm_glibc.h"
+#include "lm_glibc_dev.hpp"
 #include "rp_internal.h"
 #include "sortscan.hpp"
 
@@ -73,6 +74,34 @@ __global__ void k_glibc_sweep(uint64_t lo, unsigned long long* acc) {
     atomicAdd(&acc[2], sl);
     atomicAdd(&acc[3], wl);
 }
+// the forms the lloyd kernels evaluate (branch-free, tables in LDS: lm_glibc_dev.hpp) against the header's ladder forms above, on the
+// device, over [lo, lo + 256 * threads): bad[0] expf, [1] max(expf, MIN_POSITIVE), [2] logf (both NaN counts as equal), [3] the
+// smallest mismatching pattern
+__global__ void k_glibc_tab_sweep(uint64_t lo, unsigned long long* bad) {
+    lmg::tables_init();
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long b0 = 0, b1 = 0, b2 = 0;
+    uint32_t first = 0xffffffffu;
+    for (uint32_t k = 0; k < 256; ++k) {
+        const uint32_t u = (uint32_t)(lo + t * 256u + k);
+        const float x = rp_u2f(u);
+        const float e = rp_glibc_expf(x), l = rp_glibc_logf(x);
+        const float a = rp_glibc_expf_tab(x, lmg::lds_exp);
+        const float c = rp_glibc_exp_floor_tab(x, lmg::lds_exp);
+        const float g = rp_glibc_logf_tab(x, lmg::lds_log);
+        const bool m0 = rp_f2u(a) != rp_f2u(e) && !(a != a && e != e);
+        const bool m1 = rp_f2u(c) != rp_f2u(rp_maxf(e, RP_EPSILON));
+        const bool m2 = rp_f2u(g) != rp_f2u(l) && !(g != g && l != l);
+        b0 += m0;
+        b1 += m1;
+        b2 += m2;
+        if (m0 || m1 || m2) first = min(first, u);
+    }
+    if (b0) atomicAdd(&bad[0], b0);
+    if (b1) atomicAdd(&bad[1], b1);
+    if (b2) atomicAdd(&bad[2], b2);
+    if (first != 0xffffffffu) atomicMin(&bad[3], (unsigned long long)first);
+}
 }  // namespace rp
 
 extern "C" int rp_libm_glibc_sweep(int device, uint64_t lo, uint64_t hi, uint64_t* sums) {
@@ -93,6 +122,23 @@ extern "C" int rp_libm_glibc_sweep(int device, uint64_t lo, uint64_t hi, uint64_
     GL_TRY(hipMemcpy(out, d, 32, hipMemcpyDeviceToHost));
     (void)hipFree(d);
     for (int i = 0; i < 4; ++i) sums[i] = out[i];
+    return RP_OK;
+}
+
+extern "C" int rp_libm_glibc_tab_sweep(int device, uint64_t lo, uint64_t hi, uint64_t* mismatches) {
+    if (!mismatches || hi <= lo || hi > (1ull << 32) || ((hi - lo) & 0xffffull)) return rp::fail(RP_ERR_INVALID, "rp_libm_glibc_tab_sweep: the range must be a multiple of 65536 bit patterns inside [0, 2^32]");
+    if (rp_device_count() <= 0) return rp::fail(RP_ERR_NO_DEVICE, "rp_libm_glibc_tab_sweep: no HIP device");
+    GL_TRY(hipSetDevice(device));
+    unsigned long long* d = nullptr;
+    const unsigned long long init[4] = {0, 0, 0, ~0ull};
+    GL_TRY(hipMalloc(&d, sizeof(init)));
+    GL_TRY(hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rp::k_glibc_tab_sweep, dim3((unsigned)((hi - lo) >> 16)), dim3(256), 0, 0, lo, d);
+    GL_TRY(hipGetLastError());
+    unsigned long long out[4];
+    GL_TRY(hipMemcpy(out, d, sizeof(out), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    for (int i = 0; i < 4; ++i) mismatches[i] = out[i];
     return RP_OK;
 }
 

@@ -15,7 +15,9 @@ __global__ __launch_bounds__(256) void k(float* out, float a, float b) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 y[UNROLL];
     unsigned u[UNROLL];
+    double d[UNROLL];
     for (int i = 0; i < UNROLL; ++i) {
+        d[i] = threadIdx.x * 1e-3 + i;
         x[i] = threadIdx.x * 1e-3f + i;
         y[i] = f2{x[i], x[i] + 1.0f};
         u[i] = threadIdx.x * 2654435761u + i;
@@ -33,10 +35,24 @@ __global__ __launch_bounds__(256) void k(float* out, float a, float b) {
             if (KIND == 7) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(*reinterpret_cast<unsigned long long*>(&y[i])));
             if (KIND == 8) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
             if (KIND == 9) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(y[i]) : "v"(f2{a, a}));
+            // round 6: the f64 instructions of glibc's expf evaluated in double (include/rp_libm_glibc.h)
+            if (KIND == 10) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[i]) : "v"((double)a), "v"((double)b));
+            if (KIND == 11) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i]) : "v"((double)a));
+            if (KIND == 12) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i]) : "v"((double)b));
+            if (KIND == 13) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[i]) : "v"(x[i]));
+            if (KIND == 14) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x[i]) : "v"(d[i]));
+            if (KIND == 15) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+            if (KIND == 16) asm volatile("v_lshl_add_u32 %0, %0, 15, %1" : "+v"(u[i]) : "v"(u[(i + 1) % UNROLL]));
+            if (KIND == 17) asm volatile("ds_read_b64 %0, %1" : "=v"(d[i]) : "v"((u[i] & 31u) << 3));
+            if (KIND == 18) asm volatile("v_rndne_f64 %0, %0" : "+v"(d[i]));
+            if (KIND == 19) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(u[i]) : "v"(d[i]));
+            if (KIND == 20) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(d[i]) : "v"(u[i]));
+            if (KIND == 21) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
         }
     }
+    if (KIND == 17) asm volatile("s_waitcnt lgkmcnt(0)");
     float s = 0;
-    for (int i = 0; i < UNROLL; ++i) s += x[i] + y[i].x + y[i].y + (float)u[i];
+    for (int i = 0; i < UNROLL; ++i) s += x[i] + y[i].x + y[i].y + (float)u[i] + (float)d[i];
     if (s == 12345.678f) out[0] = s;
 }
 
@@ -74,5 +90,17 @@ int main() {
     run<4>("v_ffbh_u32");
     run<7>("v_lshlrev_b64");
     run<5>("v_exp_f32");
+    run<10>("v_fma_f64");
+    run<11>("v_mul_f64");
+    run<12>("v_add_f64");
+    run<13>("v_cvt_f64_f32");
+    run<14>("v_cvt_f32_f64");
+    run<15>("v_med3_f32");
+    run<16>("v_lshl_add_u32");
+    run<17>("ds_read_b64");
+    run<18>("v_rndne_f64");
+    run<19>("v_cvt_i32_f64");
+    run<20>("v_ldexp_f64");
+    run<21>("v_max_f32");
     return 0;
 }

@@ -35,7 +35,7 @@ SELECTION = [
     # the stand-alone Sinkhorn operators in glibc's arithmetic (expf / logf evaluated in double: include/rp_libm_glibc.h)
     ("tests/test_gpu_z_glibc_mode.py", "test_closed_form_fixture or (test_random_pairs and 32-5-9) or test_converging_solves or test_the_mode_differs"
                                        " or (test_a_layer_clustered_in_glibc_arithmetic and (5-150 or reference)) or test_the_layer_mode_is_set"
-                                       " or test_glibc_expf_and_logf_on_the_device or test_the_pruned_glibc_pass"),
+                                       " or test_glibc_expf_and_logf_on_the_device or test_the_pruned_glibc_pass or test_the_kernels_branch_free_glibc_forms"),
     # Path B: wave-cooperative Sinkhorn, Elkan iterations with remembered pairwise entries
     ("tests/test_gpu_lloyd.py", "(test_sinkhorn_random_pairs_bit_exact and 32-5-9) or test_sinkhorn_fixture_bit_exact"
                                 " or (test_elkan_iterations_bit_exact and sinkhorn-5-150) or test_equity_variation_bit_exact"

@@ -209,6 +209,22 @@ def test_glibc_expf_and_logf_on_the_device_equal_the_host_on_every_float(gpu):
         assert list(dev) == list(host), (hex(lo), hex(hi))
 
 
+def test_the_kernels_branch_free_glibc_forms_equal_the_ladder_forms_on_every_float(gpu):
+    # what the lm_glibc kernels evaluate since round 6 — rp_glibc_expf_tab / rp_glibc_exp_floor_tab / rp_glibc_logf_tab on the tables
+    # in LDS (csrc/lm_glibc_dev.hpp) — against the header's ladder forms (pinned to the host by the test above), on the device, over
+    # ALL 2^32 bit patterns.  Under the execution model: the same four windows as above.
+    import os
+
+    from robopoker_amd import _lib
+
+    ranges = [(0, 1 << 32)] if os.environ.get("RP_EMUL") != "1" else [(0x3F7F0000, 0x3F810000), (0xC2AF0000, 0xC2B10000), (0x00000000, 0x00020000),
+                                                                      (0x7F7F0000, 0x7F810000), (0x42B00000, 0x42B40000), (0xFF7F0000, 0xFF810000)]
+    for lo, hi in ranges:
+        bad = (C.c_uint64 * 4)()
+        _lib.check(_lib.load().rp_libm_glibc_tab_sweep(0, lo, hi, bad))
+        assert list(bad)[:3] == [0, 0, 0], (hex(lo), hex(hi), list(bad)[:3], hex(bad[3] & 0xFFFFFFFF))
+
+
 def test_the_pruned_glibc_pass_equals_the_oracle(oracle_on_glibc, monkeypatch):
     # the glibc pass keeps the k-means++ column bound, its interval filter and the MFMA bound (rp_kmeans_set_libm).  Exactness does
     # not depend on them as long as every minimiser survives: picks, bounds, an iteration and the lookup against the unpruned oracle,

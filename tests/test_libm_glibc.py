@@ -51,6 +51,17 @@ def test_every_float_bit_pattern_equals_the_platform_libm():
     assert (be, bl) == (0, 0), (be, bl, hex(fe), hex(fl))
 
 
+def test_the_branch_free_forms_equal_the_ladder_forms_on_every_float():
+    # rp_glibc_expf_tab / rp_glibc_exp_floor_tab / rp_glibc_logf_tab (what the device kernels evaluate, tables handed in) against
+    # rp_glibc_expf / max(rp_glibc_expf, MIN_POSITIVE) / rp_glibc_logf over all 2^32 inputs (~40 s on 8 cores)
+    o = oracle.load()
+    f = o.ora_libm_glibc_tab_sweep
+    f.argtypes, f.restype = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)], None
+    bad, first = (C.c_uint64 * 3)(), (C.c_uint32 * 3)()
+    f(0, 1 << 32, bad, first)
+    assert list(bad) == [0, 0, 0], (list(bad), [hex(x) for x in first])
+
+
 @needs_glibc
 @pytest.mark.parametrize("y", [1.5, 0.5])
 def test_powf_of_every_float_equals_the_platform_libm(y):
