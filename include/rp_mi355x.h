@@ -583,6 +583,9 @@ typedef struct rp_prune_stats {
     uint64_t kpp_bound_iterations; /* scaling-domain iterations over all examined pairs */
     uint64_t kpp_bound_cost_passes;/* cost evaluations inside the stopping windows */
     uint64_t column_iterations;    /* MFMA bound: iterations summed over single centroid columns (a block of 16 runs until its slowest) */
+    /* the reference-seed k-means++ draw (csrc/kpp_refpick.hpp; WeightedIndex<f32>'s sequential running sums, layer.rs:160-166): */
+    uint64_t ref_pick_chunks;      /* 256-term chunks over the layer's K draws */
+    uint64_t ref_pick_walked;      /* ... of which were walked term by term (first chunk, binade crossings, ties); the others are one exact add */
 } rp_prune_stats;
 RP_API int rp_kmeans_prune_stats(rp_kmeans* h, rp_prune_stats* out);
 /* the same with the size of the CALLER's struct: a host compiled against an older (shorter) rp_prune_stats passes its own sizeof

@@ -60,6 +60,12 @@ RP_API int rp_kmeans_bound_intervals(rp_kmeans* h, float* lo, float* hi);
  * centroid-first call, elkan.rs:68-77) for every point, each stopping window followed to its end; 0 where the pair does not fit the
  * register tile (either support above 48 bins) or no bound was obtained.  Tests compare it with the bit-faithful distances. */
 RP_API int rp_kmeans_kpp_bound_probe(rp_kmeans* h, uint32_t k, float* lo);
+/* rand 0.9.2's WeightedIndex::new(weights).sample() on n host weights for a given value0_1 (the UniformFloat draw in [0, 1)): the
+ * reference-seed k-means++ draw (crates/lloyd/src/layer.rs:160-166) in isolation.  mode 0: one wavefront walks the n dependent f32
+ * additions (round 5's kernel, kept as the checker); mode 1: the chunked walk the layer uses (csrc/kpp_refpick.hpp), exact by
+ * construction.  out[0] = the index (n if the total is 0), out[1] = the bits of the total weight, out[2] = chunks of 256 terms that
+ * mode 1 walked term by term (ties, binade crossings, mispredictions).  Both modes must agree with a host loop on every input. */
+RP_API int rp_weighted_index_probe(int device, uint64_t n, const float* weights, float v01, int mode, uint64_t* out);
 /* the layer's raw counters, out[5]: [0] distances evaluated (rp_kmeans_stats), [1] Sinkhorn iterations, [2] softmin + cost terms,
  * [3] distances the reference evaluates at that point of Elkan::step_elkan (elkan.rs:153-168) and this library remembers instead of
  * solving again (same centroid content, same point: the value is a pure function of the two), [4] variation distances computed

@@ -125,7 +125,7 @@ class PruneStats(C.Structure):
                 ("mfma_instructions", C.c_uint64), ("audited_points", C.c_uint64), ("audit_mismatches", C.c_uint64),
                 ("sampled_points", C.c_uint64), ("sample_mismatches", C.c_uint64), ("kpp_bound_pairs", C.c_uint64),
                 ("kpp_bound_kept", C.c_uint64), ("kpp_bound_iterations", C.c_uint64), ("kpp_bound_cost_passes", C.c_uint64),
-                ("column_iterations", C.c_uint64)]
+                ("column_iterations", C.c_uint64), ("ref_pick_chunks", C.c_uint64), ("ref_pick_walked", C.c_uint64)]
 
 
 _SIGNATURES = {
@@ -237,6 +237,7 @@ _SIGNATURES = {
     "rp_kmeans_prune_stats": (C.c_int, [C.c_void_p, C.POINTER(PruneStats)]),
     "rp_kmeans_bound_intervals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rp_kmeans_kpp_bound_probe": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rp_weighted_index_probe": (C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     "rp_kmeans_stats_ex": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_kmeans_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_kmeans_profile": (C.c_int, [C.c_void_p, C.c_int]),

@@ -69,6 +69,22 @@ const char* const CLOCK_NAMES[] = {"pairwise", "step", "recompute", "bounds", "n
 enum { CK_PAIRWISE, CK_STEP, CK_RECOMPUTE, CK_BOUNDS, CK_NEIGHBOR, CK_SELF, CK_KPP, CK_DRIFT, CK_BOUND, CK_KPP_BOUND, CK_COUNT };
 }  // namespace
 
+// the reference-seed k-means++ draw (kpp_refpick.hpp): four launches on `stream`; out = [picked index, total bits, chunks walked]
+namespace {
+uint32_t ref_pick_chunks(uint64_t N) { return (uint32_t)((N + KR_ELEMS - 1) / KR_ELEMS); }
+size_t ref_pick_work_floats(uint64_t N) { return (size_t)5 * ref_pick_chunks(N) + 64; }
+void ref_pick_launch(hipStream_t stream, float* pot, float* kpp_d, uint64_t N, float* work, float v01, unsigned long long* out) {
+    const uint32_t nc = ref_pick_chunks(N);
+    float *cum = work, *csum = work + nc;
+    uint32_t* expo = reinterpret_cast<uint32_t*>(work + 2 * (size_t)nc);
+    uint2* meta = reinterpret_cast<uint2*>(work + 3 * (size_t)nc + (nc & 1u));  // 8-byte aligned
+    hipLaunchKernelGGL(k_kr_sums, dim3((nc + 3) / 4), dim3(256), 0, stream, pot, N, nc, csum);
+    hipLaunchKernelGGL(k_kr_scan, dim3(1), dim3(1024), 0, stream, csum, nc, expo);
+    hipLaunchKernelGGL(k_kr_chunks, dim3((nc + 3) / 4), dim3(256), 0, stream, pot, N, nc, expo, meta);
+    hipLaunchKernelGGL(k_kr_pick, dim3(1), dim3(64), 0, stream, pot, kpp_d, N, nc, meta, cum, v01, out);
+}
+}  // namespace
+
 #define SB_SAMPLE_STRIDE 521u  // the production self-check of the MFMA prune looks at every 521st point (0.2 % more exact solves)
 struct rp_kmeans {
     int device = 0;
@@ -81,7 +97,9 @@ struct rp_kmeans {
     uint64_t seed = 0;
     rp_rng_kind rng = RP_RNG_COUNTER;  // rp_kmeans_set_rng: RP_RNG_REFERENCE = the reference's generator and WeightedIndex<f32>
     int street = 0;                    // Street discriminant hashed into that generator's seed (layer.rs:156-158)
-    float* kpp_cum = nullptr;          // [N] running sums of the potentials (reference-seed mode)
+    float* kpp_cum = nullptr;          // reference-seed draw (kpp_refpick.hpp): [5 x chunks] chunk-end sums, approximate sums, exponents, summaries
+    unsigned long long* kr_out = nullptr;  // [4] picked index, total bits, chunks walked term by term
+    uint64_t kr_walked = 0, kr_chunks = 0;  // over the layer's picks
     std::vector<void*> allocs;
     bool owns_counts = true;
     Points P{};
@@ -1033,19 +1051,23 @@ int rp_kmeans_init_centroids(rp_kmeans* h, uint64_t* chosen) {
         rp_defaulthasher_new(&sh);
         rp_defaulthasher_write_u64(&sh, (uint64_t)(int64_t)h->street);  // a fieldless enum hashes its discriminant as isize
         rp_smallrng_seed(&rng, rp_defaulthasher_finish(&sh));
-        if (!h->kpp_cum && (rc = dev_alloc(h, &h->kpp_cum, h->N))) return rc;
+        if (!h->kpp_cum && (rc = dev_alloc(h, &h->kpp_cum, ref_pick_work_floats(h->N)))) return rc;
+        if (!h->kr_out && (rc = dev_alloc(h, &h->kr_out, 4))) return rc;
+        h->kr_walked = h->kr_chunks = 0;
     }
     for (uint32_t k = 0; k < h->K; ++k) {
         uint64_t total = 0, pick = 0;
         if (h->rng == RP_RNG_REFERENCE) {
             const float v01 = rp_u2f((rp_smallrng_next_u32(&rng) >> 9) | 0x3f800000u) - 1.0f;  // UniformFloat<f32>: [1, 2) - 1
             ck_begin(h, CK_KPP);
-            hipLaunchKernelGGL(k_kpp_ref_pick, dim3(1), dim3(64), 0, h->stream, h->pot, h->M.kpp_d, h->N, h->kpp_cum, v01, h->scal);
+            ref_pick_launch(h->stream, h->pot, h->M.kpp_d, h->N, h->kpp_cum, v01, h->kr_out);
             ck_end(h, CK_KPP);
             HIP_TRY(hipGetLastError());
-            unsigned long long pk = 0;
-            HIP_TRY(hipMemcpyAsync(&pk, h->scal, 8, hipMemcpyDeviceToHost, h->stream));
+            unsigned long long out[3] = {0, 0, 0};
+            HIP_TRY(hipMemcpyAsync(out, h->kr_out, 24, hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
+            const unsigned long long pk = out[0];
+            h->kr_walked += out[2], h->kr_chunks += ref_pick_chunks(h->N);
             if (pk >= h->N) return rp::fail(RP_ERR_INVALID, "rp_kmeans_init_centroids: every potential is zero after %u picks (fewer distinct points than K; the reference panics here)", k);
             pick = pk;
         } else {
@@ -1353,6 +1375,8 @@ static int prune_stats_full(rp_kmeans* h, rp_prune_stats* out) {
     if (!h || !out) return rp::fail(RP_ERR_INVALID, "rp_kmeans_prune_stats: NULL argument");
     memset(out, 0, sizeof(*out));
     out->enabled = h->sb_on ? 1u : 0u;
+    out->ref_pick_chunks = h->kr_chunks;
+    out->ref_pick_walked = h->kr_walked;
     if (!h->sb_on) return RP_OK;
     HIP_TRY(hipSetDevice(h->device));
     std::vector<unsigned long long> all((size_t)KM_STAT_STRIPES * STAT_STRIDE);
@@ -1420,6 +1444,33 @@ int rp_kmeans_kpp_bound_probe(rp_kmeans* h, uint32_t k, float* lo) {
     (void)hipFree(scratch);
     if (e == hipSuccess) e = e2;
     if (e != hipSuccess) return rp::fail(RP_ERR_HIP, "rp_kmeans_kpp_bound_probe: %s", hipGetErrorString(e));
+    return RP_OK;
+}
+
+// diagnostics (rp_mi355x_diag.h): WeightedIndex::new(weights).sample() for a drawn value0_1 on n host weights, by the term-by-term
+// kernel of round 5 (mode 0: one wavefront, n dependent additions) or by the chunked walk the layer uses (mode 1: kpp_refpick.hpp);
+// out = [picked index (n if the total is 0), bits of the total, chunks walked term by term (mode 1)]
+int rp_weighted_index_probe(int device, uint64_t n, const float* weights, float v01, int mode, uint64_t* out) {
+    if (!weights || !out || n == 0 || (mode != 0 && mode != 1)) return rp::fail(RP_ERR_INVALID, "rp_weighted_index_probe: bad argument");
+    if (rp_device_count() <= 0) return rp::fail(RP_ERR_NO_DEVICE, "rp_weighted_index_probe: no HIP device");
+    HIP_TRY(hipSetDevice(device));
+    float* d = nullptr;
+    const size_t work = mode ? ref_pick_work_floats(n) : (size_t)((n + KR_CHUNK - 1) / KR_CHUNK);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), (n + work + 8) * 4));
+    float* d_work = d + n;
+    unsigned long long* d_out = reinterpret_cast<unsigned long long*>(d_work + work + ((n + work) & 1u));
+    hipError_t e = hipMemcpy(d, weights, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_out, 0, 24);
+    if (e == hipSuccess) {
+        if (mode) ref_pick_launch(nullptr, d, nullptr, n, d_work, v01, d_out);
+        else hipLaunchKernelGGL(k_kpp_ref_pick, dim3(1), dim3(64), 0, nullptr, d, (float*)nullptr, n, d_work, v01, d_out, d_out + 1);
+        e = hipGetLastError();
+    }
+    unsigned long long got[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(got, d_out, 24, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return rp::fail(RP_ERR_HIP, "rp_weighted_index_probe: %s", hipGetErrorString(e));
+    for (int i = 0; i < 3; ++i) out[i] = got[i];
     return RP_OK;
 }
 

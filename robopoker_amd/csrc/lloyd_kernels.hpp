@@ -60,6 +60,7 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
                // their margins audited at full size in both arithmetics (profiles/r05_glibc_audit.json, rp_kmeans_set_prune)
 #include "sinkhorn_bound.hpp"
 #include "kpp_bound.hpp"
+#include "kpp_refpick.hpp"
 #endif
 
 // Bins::support + Bins::density (bins.rs:58-60,84-88) of a dense histogram into LDS; returns the support size
@@ -1907,7 +1908,8 @@ __global__ __launch_bounds__(1024) void k_kpp_pick(float* pot, float* kpp_d, uin
 // non-decreasing (potentials >= 0), so the sample's partition point lies in the first chunk whose end exceeds the draw, and that one
 // chunk is walked again.
 // v01 = the generator's draw as UniformFloat<f32> maps it to [0, 1) (the host owns the SmallRng: one next_u32 per pick).
-__global__ __launch_bounds__(64) void k_kpp_ref_pick(float* pot, float* kpp_d, uint64_t N, float* cum, float v01, unsigned long long* picked) {
+__global__ __launch_bounds__(64) void k_kpp_ref_pick(float* pot, float* kpp_d, uint64_t N, float* cum, float v01, unsigned long long* picked,
+                                                    unsigned long long* picked_total) {
     __shared__ __attribute__((aligned(16))) float buf[KR_CHUNK];
     const uint32_t ln = threadIdx.x;
     const uint64_t nchunks = (N + KR_CHUNK - 1) / KR_CHUNK;
@@ -1961,6 +1963,7 @@ __global__ __launch_bounds__(64) void k_kpp_ref_pick(float* pot, float* kpp_d, u
         }
     }
     if (ln == 0) picked[0] = win;
+    if (ln == 0 && picked_total) *picked_total = rp_f2u(total);  // the probe compares the totals (rp_weighted_index_probe)
 }
 // potentials <- min(potentials, d(new centroid, point)^2) (layer.rs:170-178): distance(&x, h), centroid first
 __global__ __launch_bounds__(64) void k_kpp_update(Points P, CentroidSet cs, uint32_t k, uint32_t K, Metric M, int kind,

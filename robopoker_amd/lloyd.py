@@ -502,7 +502,7 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
         if os.environ.get("RP_FULL_NO_PRUNE"):
             layer.set_prune(False)
     if rng != "counter":
-        layer.set_rng(rng, 1)  # Street::Flop
+        layer.set_rng(rng, 1 if which == "flop" else 2)  # Street::Flop / Street::Turn: the seed of init_centroids' SmallRng (layer.rs:155-157)
     out["libm"], out["rng"] = libm, rng
     out["create_s"] = time.perf_counter() - t0  # upload + point masses + memoised OT(p,p)
     layer.profile(True)
@@ -610,6 +610,10 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
                                                "pair_iterations_per_s": st["kpp_bound_iterations"] / (kb_ms * 1e-3),
                                                "note": "the (new centroid, point) pairs the column-marginal bound let through, examined by a "
                                                        "scaling-domain interval; `kept` went on to the bit-faithful solve"}
+        if st.get("ref_pick_chunks"):  # the reference-seed draw: WeightedIndex<f32>'s sequential sums (csrc/kpp_refpick.hpp)
+            out["reference_seed_draw"] = {"chunks": st["ref_pick_chunks"], "walked_term_by_term": st["ref_pick_walked"],
+                                          "note": "256-term chunks over the K draws; a chunk inside one binade without a tie is one exact "
+                                                  "addition, the others are walked as the reference does"}
         out["mfma_bound"] = st
         mb_ms, mb_n = ms["mfma_bound"]
         if st["enabled"] and mb_ms > 0:

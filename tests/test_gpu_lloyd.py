@@ -3,6 +3,8 @@
 Every f32 the kernels produce follows the oracle's (= the reference's) operation order, so Sinkhorn costs,
 divergences, Elkan bounds, drifts and bucket assignments must be IDENTICAL, not merely close.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -120,6 +122,63 @@ def test_reference_seed_kmeanspp_picks_equal_the_oracle(gpu, kind, K, N, bins, m
     dev.step()
     ora.step()
     _check_state(dev, ora)
+
+
+def _host_weighted_index(w, v01):
+    """rand 0.9.2 WeightedIndex<f32>::new + sample for a given value0_1: sequential f32 running sums, x = v01 * scale, partition_point"""
+    cum = np.add.accumulate(w, dtype=np.float32)
+    total = cum[-1]
+    if not total > 0:
+        return len(w), total
+    scale = total
+    while np.float32(np.float32(scale * np.float32(1 - 2.0 ** -23)) + np.float32(0)) >= total:
+        scale = np.nextafter(scale, np.float32(0), dtype=np.float32)
+    x = np.float32(np.float32(v01) * scale)
+    return min(int(np.searchsorted(cum[:-1], x, side="right")), len(w) - 1), total
+
+
+def _weight_sets(big):
+    rng = np.random.default_rng(5)
+    n = 300_000 if big else 3_000
+    d2 = (rng.gamma(2.0, 0.02, n) ** 2).astype(np.float32)  # what potentials look like: squared distances
+    yield "squared distances", d2
+    yield "ones (the first pick)", np.ones(n, dtype=np.float32)
+    z = d2.copy()
+    z[rng.random(n) < 0.3] = 0
+    yield "a third zeros", z
+    t = np.ones(n, dtype=np.float32)
+    t[0] = np.float32(2.0 ** 24)  # every later 1.0 is half an ulp of the sum: a tie at every term
+    yield "ties at every term", t
+    h = d2.copy()
+    h[n // 2] = np.float32(1e9)  # one term that jumps thirty binades
+    h[n // 3] = np.float32(2.0 ** -140)  # a subnormal
+    yield "a huge term and a subnormal", h
+    g = (2.0 ** rng.integers(-30, 8, n)).astype(np.float32)  # powers of two: exact sums, binade edges hit exactly
+    yield "powers of two", g
+    yield "short", d2[:5]
+    yield "one chunk and one term", d2[:257]
+    yield "all zero", np.zeros(700, dtype=np.float32)
+
+
+def test_the_chunked_weighted_index_equals_a_term_by_term_walk(gpu):
+    # csrc/kpp_refpick.hpp: the reference-seed draw's N dependent f32 additions replaced by one exact integer addition per 256-term
+    # chunk wherever the running sum stays inside a binade and no term is a tie, walked term by term elsewhere — index AND total against
+    # a host loop (numpy's accumulate is sequential) and against round 5's one-wavefront kernel, on weights built to hit the exceptions
+    import os
+
+    from robopoker_amd import _lib
+
+    lib = _lib.load()
+    big = os.environ.get("RP_EMUL") != "1"
+    for name, w in _weight_sets(big):
+        for v01 in (0.0, 0.37, 0.5, 0.9999999):
+            want_i, want_t = _host_weighted_index(w, v01)
+            for mode in (0, 1):
+                out = (C.c_uint64 * 3)()
+                _lib.check(lib.rp_weighted_index_probe(0, len(w), w.ctypes.data_as(C.c_void_p), C.c_float(v01), mode, out))
+                assert int(out[0]) == want_i and int(out[1]) == int(np.float32(want_t).view(np.uint32)), (name, v01, mode, list(out), want_i)
+            if name == "squared distances" and big:
+                assert out[2] < 120, out[2]  # of 1172 chunks: the first, the binade crossings, the ties
 
 
 @pytest.mark.parametrize("kind,K,N,bins,mass", [("sinkhorn", 5, 150, 32, 20), ("sinkhorn", 70, 200, 48, 24),
