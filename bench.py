@@ -9,9 +9,12 @@ inputs resident in HBM before the timed region.  N > 1 (launched by torch.distri
 trees are sharded by rank and the per-cell composed maps are exchanged with one RCCL all-gather per step
 (weak scaling: per-GPU batch fixed).
 
-The same JSON line carries `roofline` (dominant kernel vs the HBM roofline, algorithmic bytes from SURVEY §8d),
-`cpu_baseline` (the CPU oracle timed on this host, rank 0, N=1 only) and `kmeans` (the second hot path's
-points/sec on a bounded slice of the flop-street configuration).
+The same JSON line carries `roofline` (dominant kernel vs its roofline, algorithmic bytes from SURVEY §8d),
+`cpu_baseline` (the CPU oracle timed on this host, rank 0, N=1 only) and, LAST, `kmeans`: the second hot path at
+BASELINE configs[2]'s full size in the reference's own arithmetic (glibc expf / logf, the reference's k-means++ draw — the pass whose
+buckets are the reference's bit for bit), with the f32 contract arithmetic on the same draw as `kmeans.contract_arithmetic` and how
+far apart the two partitions are.  The line printed by default is a compact view (compact_line) that fits the driver's stdout window;
+the whole detail object is written to gpurun_out/bench_detail.json and is the line itself under --verbose.
 """
 from __future__ import annotations
 
@@ -64,6 +67,11 @@ def parse():
                          "ordered: the reference's sequential tree-id order exactly (N=1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-oracle baseline sample length (0 = skip)")
     ap.add_argument("--no-kmeans", action="store_true", help="skip the secondary k-means measurement")
+    ap.add_argument("--verbose", action="store_true",
+                    help="print the whole detail object (per-iteration tables, notes, every leg) as the JSON line instead of the compact one; "
+                         "the detail is always written to gpurun_out/bench_detail.json as well")
+    ap.add_argument("--kmeans-counter-leg", action="store_true",
+                    help="also time the flop layer in the contract arithmetic with the counter-hash draw (rounds 1-5's default leg)")
     ap.add_argument("--no-kmeans-reference", action="store_true",
                     help="skip the flop layer in the reference's own arithmetic and draw (two more full-size passes, ~70 s)")
     ap.add_argument("--no-extras", action="store_true",
@@ -360,21 +368,75 @@ def convergence(args, g, local_rank, batch=1 << 16, epochs=512):
     return out
 
 
+def partition_agreement(a, b, K):
+    """How alike two clusterings of the same points are, whatever their label order: the adjusted Rand index (Hubert & Arabie) and the
+    fraction of points whose labels agree under the best one-to-one matching of clusters (Hungarian assignment on the K x K table)."""
+    a, b = np.asarray(a, dtype=np.int64), np.asarray(b, dtype=np.int64)
+    n = a.size
+    table = np.bincount(a * K + b, minlength=K * K).reshape(K, K).astype(np.float64)
+    comb = lambda x: x * (x - 1.0) / 2.0  # noqa: E731
+    s_ij, s_a, s_b = comb(table).sum(), comb(table.sum(1)).sum(), comb(table.sum(0)).sum()
+    expected = s_a * s_b / comb(float(n))
+    ari = (s_ij - expected) / (0.5 * (s_a + s_b) - expected) if 0.5 * (s_a + s_b) != expected else 1.0
+    try:
+        from scipy.optimize import linear_sum_assignment
+
+        r, c = linear_sum_assignment(-table)
+        matched = float(table[r, c].sum() / n)
+    except ImportError:
+        matched = None
+    return {"adjusted_rand_index": float(ari), "matched_label_fraction": matched}
+
+
 def kmeans_secondary(args):
+    """The second hot path.  At configs[2] (flop) the layer of record is the REFERENCE'S OWN arithmetic — glibc's expf / logf and
+    Layer::init_centroids' SmallRng + WeightedIndex<f32> draw — because that is the pass whose buckets are the reference's bit for bit
+    (north_star); the f32 contract arithmetic on the same draw rides beside it as `contract_arithmetic`."""
     try:
         from robopoker_amd import lloyd
     except ImportError:
         return None
     import oracle
 
-    pts, keep = None, {}
-    if args.kmeans == "flop" and not args.no_kmeans_reference:
+    if args.kmeans == "slice":
+        out = lloyd.bench_slice()
+        centroids = out.pop("_centroids", None)
+    elif args.kmeans == "turn":
+        out = lloyd.bench_full("turn")
+        centroids = out.pop("_centroids", None)
+    else:
         from robopoker_amd.fixtures import flop_like_points
 
-        pts = flop_like_points(1286792, bins=256, mass=47, seed=0xF10F)  # drawn once, shared by the three flop passes below
-    out = lloyd.bench_slice() if args.kmeans == "slice" else lloyd.bench_full(args.kmeans, pts=pts)
-    centroids = out.pop("_centroids", None)
-    if args.kmeans == "flop":
+        pts = flop_like_points(1286792, bins=256, mass=47, seed=0xF10F)  # drawn once, shared by the flop passes below
+        keep, same = {}, {}
+        libm, rng = ("contract", "counter") if args.no_kmeans_reference else ("glibc", "reference")
+        out = lloyd.bench_full("flop", pts=pts, libm=libm, rng=rng, keep=keep)
+        centroids = out.pop("_centroids", None)
+        out["arithmetic_note"] = ("rp_kmeans_set_libm(RP_LIBM_GLIBC) + rp_kmeans_set_rng(RP_RNG_REFERENCE, Flop): what a Linux build of the reference "
+                                  "computes for this layer, bit for bit (tests/test_gpu_z_glibc_mode.py, tests/test_reference_seed.py)"
+                                  if libm == "glibc" else "the f32 contract arithmetic with the counter-hash draw (--no-kmeans-reference)")
+        if not args.no_kmeans_reference:
+            # the f32 contract arithmetic (include/rp_math.h) on the same draw, and how far apart the two clusterings are
+            try:
+                con = lloyd.bench_full("flop", pts=pts, libm="contract", rng="reference", keep=same)
+                con.pop("_centroids", None)
+                slim = {k: con[k] for k in ("libm", "rng", "create_s", "kmeanspp_s", "init_bounds_s", "elkan_total_s", "lookup_s", "end_to_end_s",
+                                            "points_per_s", "distances_total", "rms", "kernels_ms", "roofline_sinkhorn", "roofline_mfma")}
+                slim["picks_differing"] = int((keep["picks"] != same["picks"]).sum())
+                slim["buckets_differing"] = int((keep["buckets"] != same["buckets"]).sum())
+                slim.update(partition_agreement(keep["buckets"], same["buckets"], 256))
+                slim["note"] = ("labels permute once a pick differs, so `buckets_differing` says 'another clustering', not how different: the "
+                                "adjusted Rand index and the matched-label fraction compare the two partitions themselves")
+                out["contract_arithmetic"] = slim
+            except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
+                out["contract_arithmetic"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if args.kmeans_counter_leg:
+            try:
+                cnt = lloyd.bench_full("flop", pts=pts)
+                cnt.pop("_centroids", None)
+                out["contract_counter_draw"] = cnt
+            except Exception as exc:  # noqa: BLE001
+                out["contract_counter_draw"] = {"error": f"{type(exc).__name__}: {exc}"}
         # configs[4]'s share of one GPU rides along (under a second of device time)
         try:
             turn = lloyd.bench_full("turn")
@@ -382,28 +444,6 @@ def kmeans_secondary(args):
             out["kmeans_turn"] = turn
         except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
             out["kmeans_turn"] = {"error": f"{type(exc).__name__}: {exc}"}
-    if pts is not None:
-        # north_star's "bit-exact bucket assignments" at configs[2]: the whole layer in the reference's own arithmetic (glibc's expf /
-        # logf) with the reference's own k-means++ draw (SmallRng + WeightedIndex<f32>), filters kept — and, for the comparison, the
-        # contract's arithmetic on the same draw: how many of the 1 286 792 buckets (and of the 256 picks) differ between the two
-        try:
-            ref = lloyd.bench_full("flop", pts=pts, libm="glibc", rng="reference", keep=keep)
-            ref.pop("_centroids", None)
-            same = {}
-            con = lloyd.bench_full("flop", pts=pts, libm="contract", rng="reference", keep=same)
-            slim = {k: ref[k] for k in ("libm", "rng", "create_s", "kmeanspp_s", "init_bounds_s", "elkan_total_s", "lookup_s", "end_to_end_s",
-                                        "points_per_s", "distances_total", "sinkhorn_iterations_total", "rms", "kernels_ms")}
-            slim["prune"] = {k: ref["mfma_bound"][k] for k in ("survivors", "candidates", "sampled_points", "sample_mismatches",
-                                                              "kpp_bound_pairs", "kpp_bound_kept")}
-            slim["contract_pass_same_draw"] = {k: con[k] for k in ("kmeanspp_s", "elkan_total_s", "lookup_s", "end_to_end_s", "rms")}
-            slim["picks_differing_from_contract_pass"] = int((keep["picks"] != same["picks"]).sum())
-            slim["buckets_differing_from_contract_pass"] = int((keep["buckets"] != same["buckets"]).sum())
-            slim["note"] = ("rp_kmeans_set_libm(RP_LIBM_GLIBC) + rp_kmeans_set_rng(RP_RNG_REFERENCE, Flop): what a Linux build of the reference "
-                            "computes for this layer, bit for bit (tests/test_gpu_z_glibc_mode.py, tests/test_reference_seed.py); the count "
-                            "compares its Layer::lookup buckets with the default f32 contract's on the same draw")
-            out["reference_arithmetic"] = slim
-        except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
-            out["reference_arithmetic"] = {"error": f"{type(exc).__name__}: {exc}"}
     if args.kmeans_libm == "glibc":
         try:
             small = lloyd.bench_slice(n_points=4096, iters=1)
@@ -412,7 +452,7 @@ def kmeans_secondary(args):
                                  "init_bounds_points_per_sec": gl["init_bounds_points_per_sec"],
                                  "contract_init_bounds_points_per_sec": small["init_bounds_points_per_sec"],
                                  "workload": "flop-layer slice N=4096, K=256, bins=256: one Elkan iteration after init_bounds, the contract pass "
-                                             "(pruned) beside the lm_glibc pass (unpruned)"}
+                                             "beside the lm_glibc pass"}
         except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
             out["glibc_pass"] = {"error": f"{type(exc).__name__}: {exc}"}
     if args.cpu_seconds > 0:
@@ -422,6 +462,82 @@ def kmeans_secondary(args):
                 out["cpu_baseline_all_cores"] = lloyd.cpu_baseline_full(oracle, out, centroids, threads=host_cores())
             except Exception as exc:  # noqa: BLE001  (a reported extra, never fatal)
                 out["cpu_baseline_all_cores"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _short(x, n=96):
+    return x if not isinstance(x, str) or len(x) <= n else x[: n - 1] + "…"
+
+
+def compact_line(line):
+    """The default stdout line: the contract's keys whole, every extra reduced to its numbers, the k-means object LAST (the driver keeps
+    the end of stdout).  Nothing is measured here: it is a view of `line`, whose full text goes to gpurun_out/bench_detail.json (and is
+    the line itself under --verbose)."""
+    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if k in line}
+    cfg = dict(line.get("config", {}))
+    cfg["update_tolerance"] = _short(cfg.get("update_tolerance"), 60)
+    out["config"] = cfg
+    rf = line.get("roofline", {})
+    out["roofline"] = {**_pick(rf, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "valu_source",
+                               "hbm_frac_measured", "updates_per_launch", "avg_launch_ms", "traversal_kernel"),
+                       **({"hbm_algorithmic": _pick(rf["hbm_algorithmic"], "achieved", "frac", "bytes_per_update")} if "hbm_algorithmic" in rf else {})}
+    cb = line.get("cpu_baseline")
+    out["cpu_baseline"] = {**_pick(cb, "value", "unit", "cores", "kind"), "sample": _short(cb.get("sample"), 120)} if isinstance(cb, dict) else cb
+    if isinstance(line.get("cpu_baseline_all_cores"), dict):
+        out["cpu_baseline_all_cores"] = _pick(line["cpu_baseline_all_cores"], "value", "unit", "cores", "kind", "error")
+    for k in ("other_update_mode", "other_scaling", "rccl_nranks"):
+        if k in line:
+            out[k] = line[k]
+    if isinstance(line.get("convergence"), dict):
+        out["convergence"] = _pick(line["convergence"], "exploitability", "epochs", "trees", "seconds", "error")
+    nl = line.get("nlhe")
+    if isinstance(nl, dict):
+        out["nlhe"] = {**_pick(nl, "value", "unit", "ms_per_step", "trees_per_step", "error"),
+                       "roofline": _pick(nl.get("roofline", {}), "bound", "kernel", "achieved", "peak", "frac", "traffic", "traffic_source"),
+                       "reference_batch_128": _pick(nl.get("reference_batch_128", {}), "value", "ms_per_step"),
+                       "cpu_baseline": _pick(nl.get("cpu_baseline", {}), "value", "cores"),
+                       "cpu_baseline_all_cores": _pick(nl.get("cpu_baseline_all_cores", {}), "value", "cores")}
+    ab = line.get("abstraction_inputs")
+    if isinstance(ab, dict):
+        out["abstraction_inputs"] = {"river_equity": _pick(ab.get("river_equity", {}), "n", "device_ms", "showdowns_per_s"),
+                                     "project_turn": _pick(ab.get("project_turn", {}), "n", "device_ms"),
+                                     "cpu_baseline": _pick(ab.get("cpu_baseline", {}), "value", "unit", "cores"), **_pick(ab, "error")}
+    km = line.get("kmeans")
+    if isinstance(km, dict):
+        def leg(d):  # one full-size layer: phase times, rates, the rooflines' numbers
+            r = _pick(d, "libm", "rng", "N", "K", "bins", "iterations", "create_s", "kmeanspp_s", "init_bounds_s", "elkan_total_s", "lookup_s",
+                      "end_to_end_s", "value", "points_per_s", "rms", "distances_total", "picks_differing", "buckets_differing",
+                      "adjusted_rand_index", "matched_label_fraction", "error")
+            if "kernels_ms" in d:
+                r["kernels_ms"] = {k: round(v["total_ms"]) for k, v in d["kernels_ms"].items()}
+            for name in ("roofline_sinkhorn", "roofline_mfma", "roofline_bounds", "roofline_variation"):
+                if name in d:
+                    r[name] = _pick(d[name], "bound", "kernel", "achieved", "peak", "unit", "frac", "useful_frac")
+                    if "issue" in d[name]:
+                        r[name]["issue_frac"] = d[name]["issue"].get("frac")
+            return r
+        k = {"metric": km.get("metric"), "unit": km.get("unit"), "workload": _short(km.get("workload"), 150)}
+        if isinstance(km.get("kmeans_turn"), dict):
+            k["kmeans_turn"] = _pick(leg(km["kmeans_turn"]), "N", "bins", "end_to_end_s", "value", "rms", "roofline_variation", "error")
+        if isinstance(km.get("cpu_baseline"), dict):
+            k["cpu_baseline"] = {**_pick(km["cpu_baseline"], "value", "unit", "cores", "kind"), "sample": _short(km["cpu_baseline"].get("sample"), 100)}
+        if isinstance(km.get("cpu_baseline_all_cores"), dict):
+            k["cpu_baseline_all_cores"] = _pick(km["cpu_baseline_all_cores"], "value", "unit", "cores", "estimate", "iteration_s_at_full_size", "error")
+        if isinstance(km.get("mfma_bound"), dict):
+            k["prune"] = _pick(km["mfma_bound"], "survivors", "candidates", "sampled_points", "sample_mismatches", "kpp_bound_pairs", "kpp_bound_kept")
+        if isinstance(km.get("reference_seed_draw"), dict):
+            k["reference_seed_draw"] = _pick(km["reference_seed_draw"], "chunks", "walked_term_by_term")
+        if isinstance(km.get("contract_arithmetic"), dict):
+            k["contract_arithmetic"] = leg(km["contract_arithmetic"])
+        k.update(leg(km))  # the layer of record last: kmeans.value / end_to_end_s are the last numbers of the line
+        k["end_to_end_s_by_arithmetic"] = {str(km.get("libm")): km.get("end_to_end_s"),
+                                           **({"contract": km["contract_arithmetic"].get("end_to_end_s")} if isinstance(km.get("contract_arithmetic"), dict) else {})}
+        out["kmeans"] = k
     return out
 
 
@@ -541,7 +657,13 @@ def nlhe_synth(args, rank, world, local_rank):
                                               f"in {dtc:.1f} s on 1 host thread"}
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        try:  # the whole detail beside the line (scratch: gpurun_out/ travels back from the GPU box)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as fh:
+                json.dump(line, fh)
+        except OSError:
+            pass
+        print(json.dumps(line if args.verbose else compact_line(line)), flush=True)
     prof.close()
     if sharded:
         dist.barrier()

@@ -461,8 +461,11 @@ def cpu_baseline_full(oracle, gpu_out, centroids, threads=None):
 HBM_PEAK_GBPS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2.0
-SOFTMIN_INSTR_PER_8_TERMS = 106  # VALU instructions per 8 softmin terms per lane in the shipped ISA
+SOFTMIN_INSTR_PER_8_TERMS = 106  # VALU instructions per 8 softmin terms per lane in the shipped ISA, contract arithmetic
 VALU_SUSTAINED_PLAIN = 8.2e11    # plain (unpacked) wave64 VALU instructions/s the chip sustains (profiles/r01_valu_issue_rates.txt)
+SOFTMIN_CONTRACT = (106, 457.0)  # (VALU instructions, SIMD-cycles of issue) per 8 terms: 155 plain-equivalent x 2.95 cycles
+SOFTMIN_GLIBC = (175, 700.0)     # 88 f64 instructions (5.1 / 4.2 - 4.5 cycles) + 87 f32 / integer (profiles/r06_valu_issue_rates.txt)
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
 
 
 def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None, seed: int = 1, log=None, libm: str = "contract",
@@ -573,27 +576,32 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
     if kind == "sinkhorn":
         exps = layer.exp_evals() - e0
         valu_s = (ms["pairwise"][0] + ms["step"][0] + ms["neighbor"][0] + ms["selfcost"][0] + ms["kpp"][0] + ms["drift"][0]) * 1e-3
-        instr = exps / 64.0 / 8.0 * SOFTMIN_INSTR_PER_8_TERMS  # wave64 VALU instructions if every lane carried a term
-        out["roofline_sinkhorn"] = {"bound": "valu", "kernel": "wave_sinkhorn_cost (softmin)", "achieved": instr / valu_s if valu_s else 0.0,
+        # per 8 softmin terms per lane, from the shipped ISA (scripts/isa_summary.py): VALU instructions, and the
+        # SIMD-cycles they take to issue at the measured per-instruction costs (profiles/r06_valu_issue_rates.txt):
+        #   contract  106 instructions, 44 of them packed f32 (two issue slots each): 155 plain x 2.95 cycles = 457
+        #   glibc     175 instructions, 88 of them f64 (5.1 cycles for fma / mul, 4.2 - 4.5 for cvt / rndne): 700
+        per8, cyc8 = SOFTMIN_GLIBC if libm == "glibc" else SOFTMIN_CONTRACT
+        instr = exps / 64.0 / 8.0 * per8  # wave64 VALU instructions if every lane carried a term
+        cyc = exps / 64.0 / 8.0 * cyc8
+        out["roofline_sinkhorn"] = {"bound": "valu", "kernel": "wave_sinkhorn_cost (softmin)", "arithmetic": libm,
+                                    "achieved": instr / valu_s if valu_s else 0.0,
                                     "peak": VALU_PEAK_WAVE_INSTR, "unit": "wave-instructions/s",
                                     "frac": instr / valu_s / VALU_PEAK_WAVE_INSTR if valu_s else 0.0, "exp_terms": exps,
-                                    "note": "bit-reproducible software exp: 106 VALU instructions per 8 softmin terms per lane; achieved = "
-                                            "terms / 64 / 8 x 106 / kernel time, i.e. counts only lanes that carry a term (a point fills "
-                                            "<= 47 of 64 lanes); peak = one wave64 instruction per 2 cycles per SIMD",
-                                    # what the counters say binds these kernels (profiles/r05_lloyd_sq_counters_before.json, reduced in
-                                    # profiles/r05_lloyd_valu_ceiling.json): 44 of the 106 instructions are packed f32 and cost two issue
-                                    # slots each (profiles/r01_valu_issue_rates.txt: no throughput gain from packing on gfx950), so a term
-                                    # is 155 / 8 plain-equivalent instructions against the chip's sustained 8.2e11 plain wave64 VALU/s
-                                    "issue": {"plain_equivalent_per_8_terms": 155,
-                                              "achieved": exps / 64.0 / 8.0 * 155 / valu_s if valu_s else 0.0,
-                                              "peak": VALU_SUSTAINED_PLAIN, "unit": "plain-equivalent wave-instructions/s",
-                                              "frac": exps / 64.0 / 8.0 * 155 / valu_s / VALU_SUSTAINED_PLAIN if valu_s else 0.0,
-                                              "counters": "profiles/r05_lloyd_valu_ceiling.json: SQ_INSTS_VALU x 1.46 / kernel time = 80 - 97 % "
-                                                          "of the sustained issue rate in k_refresh_pairs, k_pairwise, k_neighbor_masked, "
-                                                          "k_point_dist; the rest of the gap to this figure is lanes that carry no term"}}
+                                    "instructions_per_8_terms": per8,
+                                    "note": "bit-reproducible exp: VALU instructions per 8 softmin terms per lane from the shipped ISA; achieved = "
+                                            "terms / 64 / 8 x that / kernel time, i.e. counts only lanes that carry a term (a point fills "
+                                            "<= 47 of 64 lanes); peak = one wave64 instruction per 2 cycles per SIMD (nominal)",
+                                    # against what the pipe can actually issue: the measured cost of each instruction kind
+                                    "issue": {"simd_cycles_per_8_terms": cyc8, "achieved": cyc / valu_s if valu_s else 0.0,
+                                              "peak": SIMD_CYCLES_PER_S, "unit": "SIMD-cycles/s of VALU issue",
+                                              "frac": cyc / valu_s / SIMD_CYCLES_PER_S if valu_s else 0.0,
+                                              "counters": ("profiles/r06_lloyd_glibc_valu_ceiling.json" if libm == "glibc" else
+                                                           "profiles/r05_lloyd_valu_ceiling.json") +
+                                                          ": SQ_ACTIVE_INST_VALU per wave-cycle x wavefronts in flight; the gap to this figure "
+                                                          "is lanes that carry no term"}}
         kpp_ms, kpp_n = ms["kpp"]
         if kpp_ms > 0:  # k-means++ on its own: K rounds of (column-marginal filter, Sinkhorn solves of the survivors against ONE new centroid)
-            ki = e_kpp / 64.0 / 8.0 * SOFTMIN_INSTR_PER_8_TERMS
+            ki = e_kpp / 64.0 / 8.0 * per8
             out["roofline_kmeanspp"] = {"bound": "valu", "kernel": "k_kpp_filter + k_kpp_update* (softmin)", "achieved": ki / (kpp_ms * 1e-3),
                                         "peak": VALU_PEAK_WAVE_INSTR, "unit": "wave-instructions/s",
                                         "frac": ki / (kpp_ms * 1e-3) / VALU_PEAK_WAVE_INSTR, "exp_terms": e_kpp, "launches": kpp_n,

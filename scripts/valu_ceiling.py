@@ -24,6 +24,9 @@ for name, v in cnt.items():
         "dispatches": v["dispatches"], "kernel_ms": round(t / 1e3, 2), "SQ_INSTS_VALU": c["SQ_INSTS_VALU"],
         "valu_instructions_per_s": rate, "plain_equivalent_per_s": rate * WEIGHT, "frac_of_sustained_issue": rate * WEIGHT / SUSTAINED,
         "waves_in_flight": wc * 4 / (t * 1e-6 * 2.4e9),
+        # the fraction of SIMD-cycles in which a VALU instruction is issuing, whatever the instruction mix (f64 / packed / plain):
+        # SQ_ACTIVE_INST_VALU is per wavefront-cycle in 4-cycle quanta like SQ_WAVE_CYCLES, so busy x waves in flight / 1024 SIMDs
+        "simd_valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] / wc * (wc * 4 / (t * 1e-6 * 2.4e9)) / 1024.0,
         "per_wave_cycle": {"valu_busy": c["SQ_ACTIVE_INST_VALU"] / wc, "scalar_busy": c["SQ_ACTIVE_INST_SCA"] / wc,
                            "lds_busy": c["SQ_ACTIVE_INST_LDS"] / wc, "vmem_busy": c.get("SQ_ACTIVE_INST_VMEM", 0) / wc,
                            "wait_any": c["SQ_WAIT_ANY"] / wc, "wait_inst_any": c["SQ_WAIT_INST_ANY"] / wc},
@@ -37,4 +40,4 @@ doc = {"source": [sys.argv[1], sys.argv[2]],
        "sustained_plain_wave64_valu_per_s": SUSTAINED, "packed_weight": WEIGHT, "kernels": rows}
 json.dump(doc, open(sys.argv[3], "w"), indent=1)
 for k, r in sorted(rows.items(), key=lambda kv: -kv[1]["kernel_ms"]):
-    print(f"{k:28s} {r['kernel_ms']:9.1f} ms  issue {r['frac_of_sustained_issue']:.2f}  waves {r['waves_in_flight']:7.0f}  valu_busy/wave {r['per_wave_cycle']['valu_busy']:.3f}")
+    print(f"{k:28s} {r['kernel_ms']:9.1f} ms  issue {r['frac_of_sustained_issue']:.2f}  waves {r['waves_in_flight']:7.0f}  valu_busy/wave {r['per_wave_cycle']['valu_busy']:.3f}  SIMD busy {r['simd_valu_busy_frac']:.2f}")

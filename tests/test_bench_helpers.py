@@ -69,3 +69,40 @@ def test_strong_scaling_projection_runs_a_child_and_labels_its_result(monkeypatc
         raise AssertionError("a failed child must raise (the caller records the error in the line)")
     except RuntimeError as exc:
         assert "child exited 3" in str(exc)
+
+
+def test_the_compact_line_keeps_the_contract_keys_and_ends_with_the_kmeans_numbers():
+    # the driver keeps the END of stdout: the default line is a view of the detail object that fits its window (8 KB) with both
+    # arithmetics' end-to-end seconds inside the last 2 KB; nothing in it is computed, only selected
+    b = _bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
+    km = full["kmeans"]
+    km["contract_arithmetic"] = {k: km[k] for k in ("libm", "rng", "create_s", "kmeanspp_s", "init_bounds_s", "elkan_total_s", "lookup_s",
+                                                    "end_to_end_s", "points_per_s", "rms", "kernels_ms", "roofline_sinkhorn", "roofline_mfma")}
+    km["contract_arithmetic"].update({"picks_differing": 232, "buckets_differing": 1180039, "adjusted_rand_index": 0.5, "matched_label_fraction": 0.6})
+    line = b.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < 7800
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == full[k]
+    assert line["roofline"]["frac"] == full["roofline"]["frac"] and line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+    assert list(line)[-1] == "kmeans" and "per_iteration" not in text
+    tail = text[-2000:]
+    assert '"end_to_end_s_by_arithmetic"' in tail and '"end_to_end_s"' in tail and '"value"' in tail
+    assert line["kmeans"]["contract_arithmetic"]["adjusted_rand_index"] == 0.5
+
+
+def test_partition_agreement_ignores_label_order():
+    import numpy as np
+
+    b = _bench()
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, 50_000)
+    same = b.partition_agreement(a, rng.permutation(256)[a], 256)
+    assert abs(same["adjusted_rand_index"] - 1.0) < 1e-12 and same["matched_label_fraction"] == 1.0
+    other = b.partition_agreement(a, rng.integers(0, 256, 50_000), 256)
+    assert abs(other["adjusted_rand_index"]) < 0.01 and other["matched_label_fraction"] < 0.05
+    half = a.copy()
+    half[:25_000] = rng.integers(0, 256, 25_000)
+    mid = b.partition_agreement(a, half, 256)
+    assert 0.2 < mid["adjusted_rand_index"] < 0.3 and 0.49 < mid["matched_label_fraction"] < 0.52
