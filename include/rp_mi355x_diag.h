@@ -60,6 +60,20 @@ RP_API int rp_kmeans_bound_intervals(rp_kmeans* h, float* lo, float* hi);
  * centroid-first call, elkan.rs:68-77) for every point, each stopping window followed to its end; 0 where the pair does not fit the
  * register tile (either support above 48 bins) or no bound was obtained.  Tests compare it with the bit-faithful distances. */
 RP_API int rp_kmeans_kpp_bound_probe(rp_kmeans* h, uint32_t k, float* lo);
+/* The interval-decided refresh of the Elkan iterations (csrc/refresh_bound.hpp; rp_kmeans_set_prune(h, 0) switches it off with the other
+ * filters).  out8: [0] refreshes examined by the interval kernel, [1] settled by it (no bit-faithful solve), [2] scaling-domain
+ * iterations, [3] cost evaluations inside the stopping windows, [4] exactify solves (an interval of the previous step replaced by its
+ * exact value: a solve the reference does not repeat, not part of rp_kmeans_stats' distance count), [5] 1 if the layer uses it,
+ * [6] examined refreshes whose interval was remembered (the centroid's content had not changed: no iteration), [7] reserved.
+ * The reference's own distance count of the Elkan steps is evaluated + remembered (rp_kmeans_stats_ex) + out8[1]. */
+RP_API int rp_kmeans_refresh_stats(rp_kmeans* h, uint64_t* out8);
+/* While uiv[i] != 0 the upper bound rp_kmeans_bounds returns for point i is the upper end of an interval [ulo[i], upper[i]] that
+ * contains the reference's Bounds::error, and lower[i][bucket i] holds its lower end; where uiv[i] == 0 all three are the
+ * reference's values bit for bit (ulo[i] is then not meaningful).  Without the refresh bound: uiv = 0 everywhere. */
+RP_API int rp_kmeans_upper_interval(rp_kmeans* h, float* ulo, uint8_t* uiv);
+/* pairw[K*K]: the centroid-to-centroid distances (Elkan::pairwises, elkan.rs:83-88; unnormalised, row i = distance(c_i, c_k)) that the
+ * last rp_kmeans_step worked with — those of the centroids that were current when it began.  RP_ERR_INVALID before the first step. */
+RP_API int rp_kmeans_pairwise_last(rp_kmeans* h, float* pairw);
 /* rand 0.9.2's WeightedIndex::new(weights).sample() on n host weights for a given value0_1 (the UniformFloat draw in [0, 1)): the
  * reference-seed k-means++ draw (crates/lloyd/src/layer.rs:160-166) in isolation.  mode 0: one wavefront walks the n dependent f32
  * additions (round 5's kernel, kept as the checker); mode 1: the chunked walk the layer uses (csrc/kpp_refpick.hpp), exact by

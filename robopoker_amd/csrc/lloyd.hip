@@ -65,8 +65,8 @@ struct Clock {
     double total_ms = 0.0;
     uint64_t launches = 0;
 };
-const char* const CLOCK_NAMES[] = {"pairwise", "step", "recompute", "bounds", "neighbor", "selfcost", "kpp", "drift", "mfma_bound", "kpp_bound"};
-enum { CK_PAIRWISE, CK_STEP, CK_RECOMPUTE, CK_BOUNDS, CK_NEIGHBOR, CK_SELF, CK_KPP, CK_DRIFT, CK_BOUND, CK_KPP_BOUND, CK_COUNT };
+const char* const CLOCK_NAMES[] = {"pairwise", "step", "recompute", "bounds", "neighbor", "selfcost", "kpp", "drift", "mfma_bound", "kpp_bound", "refresh_bound"};
+enum { CK_PAIRWISE, CK_STEP, CK_RECOMPUTE, CK_BOUNDS, CK_NEIGHBOR, CK_SELF, CK_KPP, CK_DRIFT, CK_BOUND, CK_KPP_BOUND, CK_REFRESH_BOUND, CK_COUNT };
 }  // namespace
 
 // the reference-seed k-means++ draw (kpp_refpick.hpp): four launches on `stream`; out = [picked index, total bits, chunks walked]
@@ -137,6 +137,11 @@ struct rp_kmeans {
     KppLists kpp2{};                        // the pairs the solve is still needed for, per support class
     unsigned int* kb_cursor = nullptr;      // [3] work cursors of the three launches of a round
     unsigned long long* kb_stats = nullptr; // striped: pairs examined, kept, pair-iterations, cost passes
+    // the interval-decided refresh (refresh_bound.hpp): B.ulo / B.uiv, what each point needs this step, the kernel's counters
+    bool rb_on = false;
+    uint8_t* rb_code = nullptr;             // [N]
+    unsigned int* rb_cursor = nullptr;      // [2]
+    unsigned long long* rb_stats = nullptr; // striped: pairs examined, settled, pair-iterations, cost passes
     std::vector<uint8_t> ns_host;           // support size of every point (saturated at 255)
     std::vector<uint32_t> cent_m;           // [K] support size of the centroids installed one at a time (0 = not known on the host)
     // the MFMA bound in front of the neighbor passes (sinkhorn_bound.hpp)
@@ -495,6 +500,24 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
             KM_TRY(dev_alloc(h, &h->refresh.count, (size_t)K));
             KM_TRY(dev_alloc(h, &h->refresh.offset, (size_t)K + 1));
             KM_TRY(dev_alloc(h, &h->refresh.list, (size_t)N + 2 * (size_t)K));
+            // the interval-decided refresh needs the scaling-domain table of the MFMA bound, the remembered refreshes' versions and a
+            // cost matrix whose rows are 16-byte aligned (RP_LLOYD_NO_REFRESH_BOUND=1: off, every refresh is the bit-faithful solve)
+            if (h->sb_on && bins % 4 == 0 && !getenv("RP_LLOYD_NO_REFRESH_BOUND")) {
+                KM_TRY(dev_alloc(h, &h->B.ulo, N));
+                KM_TRY(dev_alloc(h, &h->B.uiv, N));
+                KM_TRY(dev_alloc(h, &h->B.im_lo, N));
+                KM_TRY(dev_alloc(h, &h->B.im_hi, N));
+                KM_TRY(dev_alloc(h, &h->B.im_ver, N));
+                KM_TRY(dev_alloc(h, &h->B.im_j, N));
+                KM_HIP(hipMemset(h->B.im_ver, 0, (size_t)N * 4));
+                KM_TRY(dev_alloc(h, &h->rb_code, N));
+                KM_TRY(dev_alloc(h, &h->rb_cursor, 2));
+                KM_TRY(dev_alloc(h, &h->rb_stats, (size_t)KM_STAT_STRIPES * STAT_STRIDE));
+                KM_HIP(hipMemset(h->rb_stats, 0, (size_t)KM_STAT_STRIPES * STAT_STRIDE * 8));
+                KM_HIP(hipMemset(h->B.uiv, 0, N));
+                KM_HIP(hipMemset(h->B.ulo, 0, (size_t)N * 4));
+                h->rb_on = true;
+            }
         }
         for (uint64_t i = 0; i < N; ++i) (ns[i] <= QUAD_ROWS && !no_quads ? tiny : (ns[i] <= PAIR_ROWS ? small : rest)).push_back((uint32_t)i);
         while (tiny.size() & 3u) {
@@ -726,6 +749,7 @@ int step_front(rp_kmeans* h) {
         hipLaunchKernelGGL(k_fill_u32, dim3((h->K + 255) / 256), dim3(256), 0, h->stream, h->cver, h->K, h->memo_epoch << 16);
         HIP_TRY(hipMemsetAsync(h->pver, 0, (size_t)h->K * h->K * 8, h->stream));
         HIP_TRY(hipMemsetAsync(h->B.memo_ver, 0, (size_t)h->N * 4, h->stream));
+        if (h->B.im_ver) HIP_TRY(hipMemsetAsync(h->B.im_ver, 0, (size_t)h->N * 4, h->stream));
         h->memo_dirty = false;
     }
     ck_begin(h, CK_PAIRWISE);
@@ -743,14 +767,42 @@ int step_front(rp_kmeans* h) {
     else {
         if (h->kind == RP_METRIC_SINKHORN && h->refresh.nsup) {
             const size_t entries = (size_t)h->N + 2 * (size_t)h->K;
-            HIP_TRY(hipMemsetAsync(h->refresh.count, 0, (size_t)h->K * 4, h->stream));
-            HIP_TRY(hipMemsetAsync(h->refresh.list, 0xff, entries * 4, h->stream));
-            if (h->B.memo_ver) hipLaunchKernelGGL(k_refresh_memo, dim3(1024), dim3(256), 0, h->stream, h->B, h->mid, h->N, h->K, h->M);
-            hipLaunchKernelGGL(k_refresh_count, dim3(1024), dim3(256), 0, h->stream, h->B, h->refresh, h->mid, h->N, h->K);
-            hipLaunchKernelGGL(k_refresh_offsets, dim3(1), dim3(1), 0, h->stream, h->refresh, h->K);
-            hipLaunchKernelGGL(k_refresh_fill, dim3(1024), dim3(256), 0, h->stream, h->B, h->refresh, h->mid, h->N);
+            // the stale-bound refresh as its own pass: points bucketed by centroid, two per wavefront (k_refresh_pairs)
+            auto bucket = [&](uint8_t want) -> int {
+                h->refresh.want = want;
+                HIP_TRY(hipMemsetAsync(h->refresh.count, 0, (size_t)h->K * 4, h->stream));
+                HIP_TRY(hipMemsetAsync(h->refresh.list, 0xff, entries * 4, h->stream));
+                hipLaunchKernelGGL(k_refresh_count, dim3(1024), dim3(256), 0, h->stream, h->B, h->refresh, h->mid, h->N, h->K);
+                hipLaunchKernelGGL(k_refresh_offsets, dim3(1), dim3(1), 0, h->stream, h->refresh, h->K);
+                hipLaunchKernelGGL(k_refresh_fill, dim3(1024), dim3(256), 0, h->stream, h->B, h->refresh, h->mid, h->N);
+                return RP_OK;
+            };
+            int rc = RP_OK;
+            if (h->rb_on) {
+                // interval mode (refresh_bound.hpp): (1) what every stale point needs; (2) interval-valued bounds the filter cannot be
+                // decided on become exact: one solve against the PREVIOUS centroids (cs[cur ^ 1] is still last step's set) and the last
+                // drift; (3) the refreshes: an interval first, settled where it stays under every threshold of the candidate loop;
+                // (4) the bit-faithful refresh for the rest
+                h->refresh.code = h->rb_code;
+                hipLaunchKernelGGL(k_rb_prepare, dim3(1024), dim3(256), 0, h->stream, h->B, h->refresh.nsup, h->mid, h->drift, h->N, h->K,
+                                   h->rb_code, h->stats);
+                if ((rc = bucket(3))) return rc;
+                hipLaunchKernelGGL(KSEL(h, k_refresh_pairs), dim3((unsigned)(entries / 2 + 1)), dim3(64), 0, h->stream, h->P, h->cs[cur ^ 1], h->K,
+                                   h->M, h->B, h->refresh, 1, h->drift, h->mid, h->rb_code);
+                if ((rc = bucket(1))) return rc;
+                HIP_TRY(hipMemsetAsync(h->rb_cursor, 0, 8, h->stream));
+                ck_begin(h, CK_REFRESH_BOUND);
+                hipLaunchKernelGGL((k_refresh_interval<32>), dim3(4096), dim3(64), 0, h->stream, h->P, h->cs[cur], h->K, h->bins, h->M.Cm,
+                                   h->sb, h->B, h->pairw, h->refresh.list, h->refresh.offset + h->K, h->rb_cursor, h->rb_code, h->rb_stats, h->stats);
+                ck_end(h, CK_REFRESH_BOUND);
+                if ((rc = bucket(2))) return rc;
+            } else {
+                h->refresh.code = nullptr;
+                if (h->B.memo_ver) hipLaunchKernelGGL(k_refresh_memo, dim3(1024), dim3(256), 0, h->stream, h->B, h->mid, h->N, h->K, h->M);
+                if ((rc = bucket(0))) return rc;
+            }
             hipLaunchKernelGGL(KSEL(h, k_refresh_pairs), dim3((unsigned)(entries / 2 + 1)), dim3(64), 0, h->stream, h->P, h->cs[cur], h->K, h->M,
-                               h->B, h->refresh);
+                               h->B, h->refresh, 0, (const float*)nullptr, (const float*)nullptr, (uint8_t*)nullptr);
         }
         hipLaunchKernelGGL(KSEL(h, k_elkan_step), dim3((unsigned)h->N), dim3(64), 0, h->stream, h->P, h->cs[cur], h->K, h->M, h->kind, h->B,
                            h->pairw, h->mid);
@@ -865,11 +917,16 @@ int rp_kmeans_set_libm(rp_kmeans* h, rp_libm_kind kind) {
 int rp_kmeans_set_prune(rp_kmeans* h, int enable) {
     if (!h) return rp::fail(RP_ERR_INVALID, "rp_kmeans_set_prune: NULL handle");
     if (h->centroids_ready || h->bounds_ready) return rp::fail(RP_ERR_INVALID, "rp_kmeans_set_prune: the layer already has centroids; set the mode first");
-    const bool has = h->kpp_lb || h->kb_on || h->sb_on;
+    const bool has = h->kpp_lb || h->kb_on || h->sb_on || h->rb_on;
     if (enable) return has ? RP_OK : rp::fail(RP_ERR_UNSUPPORTED, "rp_kmeans_set_prune: this layer has no filters (variation metric, switched off at creation, or given up)");
     h->kpp_lb = false;
     h->kb_on = false;
     h->sb_on = false;
+    if (h->rb_on) {  // every refresh is the bit-faithful solve again: the kernels see no interval arrays
+        h->rb_on = false;
+        h->B.ulo = nullptr;  // (the allocations stay with the handle)
+        h->B.uiv = nullptr;
+    }
     return RP_OK;
 }
 
@@ -1139,6 +1196,7 @@ int rp_kmeans_init_bounds(rp_kmeans* h) {
     } else if ((rc = launch_neighbor(h, h->prior, nullptr, h->B, NB_INIT_BOUNDS))) {  // Prior::from_bounds (prior.rs:23-32)
         return rc;
     }
+    if (h->rb_on) HIP_TRY(hipMemsetAsync(h->B.uiv, 0, h->N, h->stream));  // every upper bound is an exact distance again
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->bounds_ready = true;
     ck_drain(h);
@@ -1444,6 +1502,49 @@ int rp_kmeans_kpp_bound_probe(rp_kmeans* h, uint32_t k, float* lo) {
     (void)hipFree(scratch);
     if (e == hipSuccess) e = e2;
     if (e != hipSuccess) return rp::fail(RP_ERR_HIP, "rp_kmeans_kpp_bound_probe: %s", hipGetErrorString(e));
+    return RP_OK;
+}
+
+// diagnostics (rp_mi355x_diag.h): the interval-decided refresh (refresh_bound.hpp)
+int rp_kmeans_refresh_stats(rp_kmeans* h, uint64_t* out6) {  // (eight words: see rp_mi355x_diag.h)
+    if (!h || !out6) return rp::fail(RP_ERR_INVALID, "rp_kmeans_refresh_stats: NULL argument");
+    for (int k = 0; k < 8; ++k) out6[k] = 0;
+    out6[5] = h->rb_on ? 1u : 0u;
+    if (!h->rb_stats) return RP_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<unsigned long long> a((size_t)KM_STAT_STRIPES * STAT_STRIDE), b(a.size());
+    HIP_TRY(hipMemcpyAsync(a.data(), h->rb_stats, a.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(b.data(), h->stats, b.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (uint32_t q = 0; q < KM_STAT_STRIPES; ++q) {
+        for (uint32_t k = 0; k < 4; ++k) out6[k] += a[(size_t)q * STAT_STRIDE + k];
+        out6[4] += b[(size_t)q * STAT_STRIDE + 6];
+        out6[6] += a[(size_t)q * STAT_STRIDE + 4];
+    }
+    return RP_OK;
+}
+int rp_kmeans_upper_interval(rp_kmeans* h, float* ulo, uint8_t* uiv) {
+    if (!h || !ulo || !uiv) return rp::fail(RP_ERR_INVALID, "rp_kmeans_upper_interval: NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->rb_on) {  // every upper bound is exact
+        HIP_TRY(hipMemcpyAsync(ulo, h->B.u, h->N * 4, hipMemcpyDeviceToHost, h->stream));
+        memset(uiv, 0, h->N);
+    } else {
+        HIP_TRY(hipMemcpyAsync(ulo, h->B.ulo, h->N * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(uiv, h->B.uiv, h->N, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RP_OK;
+}
+
+// diagnostics (rp_mi355x_diag.h): the K x K table of centroid-to-centroid distances the LAST Elkan step worked with (elkan.rs:83-88,
+// unnormalised, both orders), i.e. of the centroids that were current when that step began
+int rp_kmeans_pairwise_last(rp_kmeans* h, float* pairw) {
+    if (!h || !pairw) return rp::fail(RP_ERR_INVALID, "rp_kmeans_pairwise_last: NULL argument");
+    if (!h->pairw_seen) return rp::fail(RP_ERR_INVALID, "rp_kmeans_pairwise_last: no Elkan step has run on these centroids yet");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(pairw, h->pairw, (size_t)h->K * h->K * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return RP_OK;
 }
 

@@ -772,6 +772,9 @@ __device__ __forceinline__ void memo_store(const Bounds& B, uint64_t i, uint32_t
     B.memo_j[i] = (uint8_t)j;
     B.memo_ver[i] = B.cver[j];
 }
+#if !LM_GLIBC  // like the other scaling-domain filters: one copy, in the contract namespace, for both passes
+#include "refresh_bound.hpp"
+#endif
 
 __global__ __launch_bounds__(64) void k_neighbor(Points P, CentroidSet cs, uint32_t K, Metric M, int kind,
                                                  uint8_t* out_j, float* out_d, Bounds init, const uint32_t* only) {
@@ -1310,6 +1313,7 @@ __global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uin
         B.u[i] = u;
         B.stale[i] = 0;
         if (exact) memo_store(B, i, j, u);
+        if (exact && B.uiv) B.uiv[i] = 0;
     }
 }
 
@@ -1323,6 +1327,7 @@ __global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uin
 // depend on its partner.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool needs_refresh(const Bounds& B, const Refresh& R, const float* mid, uint64_t i) {
+    if (R.code) return R.code[i] == R.want;  // interval mode: k_rb_prepare / k_refresh_interval / the exactify pass decided
     return B.stale[i] && B.u[i] > mid[B.j[i]] && R.nsup[i] <= PAIR_ROWS;
 }
 // stale bounds whose refresh is remembered: Bounds::refresh without the solve
@@ -1367,7 +1372,11 @@ __global__ __launch_bounds__(256) void k_refresh_fill(Bounds B, Refresh R, const
             R.list[R.offset[j] + atomicAdd(&R.count[j], 1u)] = (uint32_t)i;
         }
 }
-__global__ __launch_bounds__(64) void k_refresh_pairs(Points P, CentroidSet cs, uint32_t K, Metric M, Bounds B, Refresh R) {
+// exactify (interval mode, refresh_bound.hpp): `cs` is the PREVIOUS centroid set; the solve returns the value the last step's refresh
+// stood for, Bounds::update's additions of the last drift are replayed on it, and the reference's filter then sees an exact u
+// (code_out: 1 = it passes, the refresh against the current centroids follows; 0 = skipped like the reference skips it).
+__global__ __launch_bounds__(64) void k_refresh_pairs(Points P, CentroidSet cs, uint32_t K, Metric M, Bounds B, Refresh R, int exactify,
+                                                      const float* drift_prev, const float* mid, uint8_t* code_out) {
     LM_TABLES();
     __shared__ GroupLds<2> w;
     const uint32_t e0 = 2u * blockIdx.x;
@@ -1399,11 +1408,21 @@ __global__ __launch_bounds__(64) void k_refresh_pairs(Points P, CentroidSet cs, 
         const uint32_t i = lane ? ip[1] : ip[0];
         if (i != 0xffffffffu) {
             const float d = rp_maxf((lane ? xy[1] : xy[0]) - 0.5f * (lane ? sp[1] : sp[0]) - 0.5f * sc, 0.0f);
-            B.u[i] = d;
-            B.lower[(uint64_t)i * K + j] = d;
-            B.stale[i] = 0;
-            memo_store(B, i, j, d);
-            atomicAdd(STAT(M, 0), 1ull);
+            if (exactify) {
+                const float dp = drift_prev[j], u = d + dp;  // Bounds::update: error += movement, lower = (lower - movement).max(0)
+                B.u[i] = u;
+                B.lower[(uint64_t)i * K + j] = rp_maxf(d - dp, 0.0f);
+                B.uiv[i] = 0;
+                code_out[i] = u > mid[j] ? 1 : 0;
+                atomicAdd(STAT(M, 6), 1ull);  // a solve the reference does not repeat: counted apart
+            } else {
+                B.u[i] = d;
+                B.lower[(uint64_t)i * K + j] = d;
+                B.stale[i] = 0;
+                if (B.uiv) B.uiv[i] = 0;
+                memo_store(B, i, j, d);
+                atomicAdd(STAT(M, 0), 1ull);
+            }
         }
     }
 }
@@ -1758,6 +1777,7 @@ __global__ __launch_bounds__(256) void k_bounds_update(Bounds B, uint64_t N, uin
     }
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (uint64_t)gridDim.x * 256) {
         B.u[i] = B.u[i] + dr[B.j[i]];
+        if (B.ulo) B.ulo[i] = B.ulo[i] + dr[B.j[i]];  // the same addition on the interval's lower end: rounding is monotone
         B.stale[i] = 1;
     }
 }

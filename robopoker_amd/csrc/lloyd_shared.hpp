@@ -64,6 +64,14 @@ struct Bounds {
     uint32_t* memo_ver;     // [N]  cver[memo_j] at the time; 0 = nothing remembered
     uint8_t* memo_j;        // [N]
     const uint32_t* cver;   // [K]  content version of the centroids in use (starts at 1)
+    // interval-decided refresh (refresh_bound.hpp): while uiv[i] is set, [ulo[i], u[i]] contains the reference's Bounds::error
+    float* ulo;             // [N]  (NULL: the layer has no refresh bound)
+    uint8_t* uiv;           // [N]
+    // the last interval of distance(point, its centroid) and what it was computed against: like memo_d, for refreshes the interval settled
+    float* im_lo;           // [N]
+    float* im_hi;           // [N]
+    uint32_t* im_ver;       // [N]  cver[im_j] at the time; 0 = nothing remembered
+    uint8_t* im_j;          // [N]
 };
 
 struct KppLists {
@@ -72,6 +80,8 @@ struct KppLists {
 };
 
 struct Refresh {
+    const uint8_t* code;  // [N] interval mode: what each point needs this step (refresh_bound.hpp); NULL: the stale-bound predicate
+    uint8_t want;         //     the code this pass collects
     const uint8_t* nsup;  // [N] support sizes
     uint32_t* count;      // [K]   points needing a refresh per cluster, then the fill cursor
     uint32_t* offset;     // [K+1] start of each cluster's (even-padded) bucket; offset[K] = entries in the list

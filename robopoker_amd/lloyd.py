@@ -128,11 +128,11 @@ class Layer:
 
     assign = lookup
 
-    def bounds(self):
+    def bounds(self, lower=True):
         j = np.zeros(self.N, dtype=np.uint8)
         u = np.zeros(self.N, dtype=np.float32)
-        lo = np.zeros((self.N, self.K), dtype=np.float32)
-        _lib.check(self._lib.rp_kmeans_bounds(self._h, _p(j), _p(u), _p(lo)))
+        lo = np.zeros((self.N, self.K), dtype=np.float32) if lower else None
+        _lib.check(self._lib.rp_kmeans_bounds(self._h, _p(j), _p(u), _p(lo) if lower else None))
         return j, u, lo
 
     def centroids(self):
@@ -180,6 +180,26 @@ class Layer:
         hi = np.zeros((self.N, self.K), dtype=np.float32)
         _lib.check(self._lib.rp_kmeans_bound_intervals(self._h, _p(lo), _p(hi)))
         return lo, hi
+
+    def pairwise_last(self) -> np.ndarray:
+        """(K, K): the centroid-to-centroid distances the last step worked with (rp_mi355x_diag.h)"""
+        pw = np.zeros((self.K, self.K), dtype=np.float32)
+        _lib.check(self._lib.rp_kmeans_pairwise_last(self._h, _p(pw)))
+        return pw
+
+    def refresh_stats(self) -> dict:
+        """the interval-decided refresh of the Elkan iterations (rp_mi355x_diag.h)"""
+        a = np.zeros(8, dtype=np.uint64)
+        _lib.check(self._lib.rp_kmeans_refresh_stats(self._h, _p(a)))
+        return {"examined": int(a[0]), "settled": int(a[1]), "pair_iterations": int(a[2]), "cost_passes": int(a[3]),
+                "exactify_solves": int(a[4]), "enabled": int(a[5]), "remembered_intervals": int(a[6])}
+
+    def upper_interval(self):
+        """(ulo, uiv): where uiv != 0, [ulo, bounds()[1]] contains the reference's upper bound (rp_mi355x_diag.h)"""
+        ulo = np.zeros(self.N, dtype=np.float32)
+        uiv = np.zeros(self.N, dtype=np.uint8)
+        _lib.check(self._lib.rp_kmeans_upper_interval(self._h, _p(ulo), _p(uiv)))
+        return ulo, uiv
 
     def kpp_bound_probe(self, k: int) -> np.ndarray:
         """lo[N]: the second k-means++ filter's lower bound of distance(centroid k, point i) (rp_mi355x_diag.h)"""
@@ -550,7 +570,7 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
     out["distances_remembered"] = ex["remembered"]  # evaluated by the reference at that point, reused here (same centroid content)
     out["sinkhorn_iterations_total"] = i2
     ms = {name: layer.kernel_time(name) for name in ("pairwise", "step", "recompute", "bounds", "neighbor", "selfcost", "kpp",
-                                                     "drift", "mfma_bound", "kpp_bound")}
+                                                     "drift", "mfma_bound", "kpp_bound", "refresh_bound")}
     out["kernels_ms"] = {k: {"total_ms": round(v[0], 3), "launches": v[1]} for k, v in ms.items()}
     bd_ms, bd_n = ms["bounds"]
     if bd_n:
@@ -622,6 +642,13 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
             out["reference_seed_draw"] = {"chunks": st["ref_pick_chunks"], "walked_term_by_term": st["ref_pick_walked"],
                                           "note": "256-term chunks over the K draws; a chunk inside one binade without a tie is one exact "
                                                   "addition, the others are walked as the reference does"}
+        rs = layer.refresh_stats()
+        if rs["enabled"]:  # the interval-decided refresh of the Elkan iterations (csrc/refresh_bound.hpp)
+            rb_ms = ms["refresh_bound"][0]
+            out["refresh_interval"] = {**rs, "kernel_s": rb_ms * 1e-3,
+                                       "pair_iterations_per_s": rs["pair_iterations"] / (rb_ms * 1e-3) if rb_ms else 0.0,
+                                       "note": "stale-bound refreshes examined by a scaling-domain interval; `settled` needed no bit-faithful "
+                                               "solve; `exactify_solves` replaced an interval by its exact value before the next filter"}
         out["mfma_bound"] = st
         mb_ms, mb_n = ms["mfma_bound"]
         if st["enabled"] and mb_ms > 0:

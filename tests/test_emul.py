@@ -39,7 +39,8 @@ SELECTION = [
     # Path B: wave-cooperative Sinkhorn, Elkan iterations with remembered pairwise entries
     ("tests/test_gpu_lloyd.py", "(test_sinkhorn_random_pairs_bit_exact and 32-5-9) or test_sinkhorn_fixture_bit_exact"
                                 " or (test_elkan_iterations_bit_exact and sinkhorn-5-150) or test_equity_variation_bit_exact"
-                                " or test_empty_histogram_costs_zero or (test_layer_shape_corners_bit_exact and sinkhorn-65-130)"),
+                                " or test_empty_histogram_costs_zero or (test_layer_shape_corners_bit_exact and sinkhorn-65-130)"
+                                " or test_interval_decided_refresh_keeps_the_reference_state"),
 ]
 
 

@@ -226,12 +226,20 @@ def test_device_reproduces_big_composed_golden(gpu, index):
 
 
 @pytest.mark.gpu
-def test_device_reproduces_kmeans_k256_golden(gpu):
+@pytest.mark.parametrize("refresh_bound", [False, True])
+def test_device_reproduces_kmeans_k256_golden(gpu, monkeypatch, refresh_bound):
+    # refresh_bound False: every stale-bound refresh is the bit-faithful solve (RP_LLOYD_NO_REFRESH_BOUND=1) and the whole Elkan state
+    # — upper and lower bounds included — hashes to the committed values.  True (the default build): the interval-decided refresh
+    # (csrc/refresh_bound.hpp) holds intervals in place of some upper bounds, so the bound hashes do not apply; everything the layer
+    # hands out (assignments, drift, sizes, buckets, distances, centroids, rms) is still the golden's, bit for bit.
     from robopoker_amd import lloyd
 
+    if not refresh_bound:
+        monkeypatch.setenv("RP_LLOYD_NO_REFRESH_BOUND", "1")
     case = _big("kmeans_k256.json")
     pts = flop_like_points(case["N"], bins=case["bins"], mass=47, seed=case["seed"])
     km = lloyd.Layer(case["K"], pts, "sinkhorn", smooth_metric(case["bins"], 1), seed=case["seed"])
+    assert km.refresh_stats()["enabled"] == (1 if refresh_bound else 0)
     km.set_centroids(np.array(case["start"], dtype=np.uint64))
     km.init_bounds()
     j, u, lo = km.bounds()
@@ -240,7 +248,9 @@ def test_device_reproduces_kmeans_k256_golden(gpu):
         d, sizes, moved = km.step()
         assert bits(d) == want["drift_bits"] and sizes.tolist() == want["sizes"] and moved == want["moved"]
         j, u, lo = km.bounds()
-        assert _sha(j) == want["j_sha"] and _sha(u.view(np.uint32)) == want["u_sha"] and _sha(lo.view(np.uint32)) == want["lower_sha"]
+        assert _sha(j) == want["j_sha"]
+        if not refresh_bound:
+            assert _sha(u.view(np.uint32)) == want["u_sha"] and _sha(lo.view(np.uint32)) == want["lower_sha"]
     b, dist = km.lookup()
     assert b.tolist() == case["buckets"] and bits(dist) == case["distance_bits"]
     c, w = km.centroids()
@@ -248,6 +258,8 @@ def test_device_reproduces_kmeans_k256_golden(gpu):
     assert bits([km.rms()])[0] == case["rms_bits"]
     st = km.prune_stats()
     assert st["enabled"] == 1 and st["survivors"] < 2 * st["points"]
+    if refresh_bound:
+        assert km.refresh_stats()["settled"] > 0
 
 
 # ---- the NLHE blueprint traversal (tests/golden/nlmc.json, scripts/make_golden_nlmc.py): integer state and policy bits ----

@@ -97,14 +97,25 @@ def _pair(kind, K, N, bins, mass, seed, iters=None):
 
 
 def _check_state(dev, ora):
+    """assignments, centroids and every bound the device holds exactly: bit for bit.  Where the interval-decided refresh
+    (csrc/refresh_bound.hpp) settled a point, the device holds an interval instead of Bounds::error: [ulo, u] must contain the
+    oracle's value, and l[assigned centroid] (the reference sets it to u at the refresh) must lie in it too.  Returns the number
+    of interval-valued points."""
     j1, u1, l1 = dev.bounds()
     j2, u2, l2 = ora.bounds()
     assert np.array_equal(j1, j2), "assignments differ"
-    assert np.array_equal(bits(u1), bits(u2)), "upper bounds differ"
-    assert np.array_equal(bits(l1), bits(l2)), "lower bounds differ"
+    ulo, uiv = dev.upper_interval()
+    iv = uiv != 0
+    assert np.array_equal(bits(u1[~iv]), bits(u2[~iv])), "upper bounds differ"
+    assert np.all(ulo[iv] <= u2[iv]) and np.all(u2[iv] <= u1[iv]), "an interval does not contain the reference's upper bound"
+    own = np.zeros(l1.shape, dtype=bool)
+    own[np.nonzero(iv)[0], j1[iv].astype(np.int64)] = True
+    assert np.array_equal(bits(l1[~own]), bits(l2[~own])), "lower bounds differ"
+    assert np.all(l1[own] <= l2[own]), "the lower bound of an interval-valued point's own centroid exceeds the reference's"
     c1, w1 = dev.centroids()
     c2, w2 = ora.centroids()
     assert np.array_equal(c1, c2) and np.array_equal(w1, w2), "centroids differ"
+    return int(iv.sum())
 
 
 @pytest.mark.parametrize("kind,K,N,bins,mass,street", [("sinkhorn", 12, 1500, 32, 20, 1), ("variation", 40, 70001, 101, 46, 2),
@@ -191,21 +202,75 @@ def test_elkan_iterations_bit_exact(gpu, kind, K, N, bins, mass):
     ora.init_bounds()
     _check_state(dev, ora)
     for _ in range(4):
-        e0, o0 = dev.stats_ex(), oracle.lloyd_stats()[0]
+        e0, o0, r0 = dev.stats_ex(), oracle.lloyd_stats()[0], dev.refresh_stats()
         d1, s1, m1 = dev.step()
         d2, s2, m2 = ora.step()
         assert np.array_equal(bits(d1), bits(d2)), "drift differs"
         assert np.array_equal(s1, s2) and m1 == m2
         _check_state(dev, ora)
         # the distances Elkan's rule evaluates in this step (has_shifted BEFORE the distance, bounds.rs:57-61): the reference's count —
-        # solved here, or remembered from an earlier step (same centroid content); the turn kernels compute whole tiles on top
-        e1, o1 = dev.stats_ex(), oracle.lloyd_stats()[0]
-        assert (e1["evaluated"] - e0["evaluated"]) + (e1["remembered"] - e0["remembered"]) == o1 - o0, (kind, e0, e1, o0, o1)
+        # solved here, remembered from an earlier step (same centroid content), or a refresh settled by its interval (csrc/
+        # refresh_bound.hpp; the exactify solves are extra and counted apart); the turn kernels compute whole tiles on top
+        e1, o1, r1 = dev.stats_ex(), oracle.lloyd_stats()[0], dev.refresh_stats()
+        assert (e1["evaluated"] - e0["evaluated"]) + (e1["remembered"] - e0["remembered"]) + (r1["settled"] - r0["settled"]) == o1 - o0, \
+            (kind, e0, e1, r0, r1, o0, o1)
     b1, dd1 = dev.lookup()
     b2, dd2 = ora.assign()
     assert np.array_equal(b1, b2) and np.array_equal(bits(dd1), bits(dd2))
     assert np.array_equal(bits(dev.metric()), bits(ora.metric()))
     assert bits(dev.rms()) == bits(ora.rms())
+
+
+@pytest.mark.parametrize("libm", ["contract", "glibc"])
+def test_interval_decided_refresh_keeps_the_reference_state(gpu, libm):
+    # csrc/refresh_bound.hpp: from the second iteration on most stale-bound refreshes (elkan.rs:113-117) are settled by a scaling-domain
+    # interval instead of a bit-faithful solve.  Per step against the oracle: assignments, drift bits, sizes, centroids and every exact
+    # bound identical; interval-valued upper bounds contain the oracle's value (_check_state); the interval kernel really ran and
+    # settled points, intervals that could not decide the next filter were replaced by exact values (exactify), and the reference's
+    # distance count is evaluated + remembered + settled.  The same layer with rp_kmeans_set_prune(0) holds no interval at any step.
+    o = oracle.load()
+    o.ora_lloyd_set_libm.argtypes = [C.c_int]
+    if libm == "glibc":
+        o.ora_lloyd_set_libm(2)  # before the oracle's layer exists: its OT(p, p) terms are computed at creation
+    try:
+        dev, ora = _pair("sinkhorn", 12, 600, 32, 20, seed=7, iters=16)
+        if libm == "glibc":
+            dev.set_libm("glibc")
+        assert np.array_equal(dev.init_centroids(), ora.init_centroids()), "k-means++ picks differ"
+        dev.init_bounds()
+        ora.init_bounds()
+        assert _check_state(dev, ora) == 0
+        held = 0
+        for it in range(6):
+            e0, o0, r0 = dev.stats_ex(), oracle.lloyd_stats()[0], dev.refresh_stats()
+            d1, s1, m1 = dev.step()
+            d2, s2, m2 = ora.step()
+            assert np.array_equal(bits(d1), bits(d2)), ("drift differs", it)
+            assert np.array_equal(s1, s2) and m1 == m2
+            held += _check_state(dev, ora)
+            e1, o1, r1 = dev.stats_ex(), oracle.lloyd_stats()[0], dev.refresh_stats()
+            assert (e1["evaluated"] - e0["evaluated"]) + (e1["remembered"] - e0["remembered"]) + (r1["settled"] - r0["settled"]) == o1 - o0
+        st = dev.refresh_stats()
+        assert st["enabled"] == 1 and st["settled"] > 300 and st["exactify_solves"] > 0 and held > 300, st
+        b1, dd1 = dev.lookup()
+        b2, dd2 = ora.assign()
+        assert np.array_equal(b1, b2) and np.array_equal(bits(dd1), bits(dd2))
+        # the exact-by-construction mode: no interval anywhere, every bound the oracle's
+        plain, ora2 = _pair("sinkhorn", 12, 600, 32, 20, seed=7, iters=16)
+        if libm == "glibc":
+            plain.set_libm("glibc")
+        plain.set_prune(False)
+        plain.init_centroids()
+        ora2.init_centroids()
+        plain.init_bounds()
+        ora2.init_bounds()
+        for _ in range(3):
+            plain.step()
+            ora2.step()
+            assert _check_state(plain, ora2) == 0
+        assert plain.refresh_stats()["enabled"] == 0
+    finally:
+        o.ora_lloyd_set_libm(0)
 
 
 @pytest.mark.parametrize("kind,K,N,bins,mass", [("sinkhorn", 1, 5, 2, 3), ("sinkhorn", 2, 2, 5, 4), ("sinkhorn", 65, 130, 33, 7),

@@ -120,15 +120,7 @@ def _layer_pair(K, N, bins, mass, seed, iters):
     return dev, oracle.OracleKmeans(K, pts, "sinkhorn", tri, hp=hp, seed=seed)
 
 
-def _check_state(dev, ora):
-    j1, u1, l1 = dev.bounds()
-    j2, u2, l2 = ora.bounds()
-    assert np.array_equal(j1, j2), "assignments differ"
-    assert np.array_equal(bits(u1), bits(u2)), "upper bounds differ"
-    assert np.array_equal(bits(l1), bits(l2)), "lower bounds differ"
-    c1, w1 = dev.centroids()
-    c2, w2 = ora.centroids()
-    assert np.array_equal(c1, c2) and np.array_equal(w1, w2), "centroids differ"
+from test_gpu_lloyd import _check_state  # noqa: E402  (exact bounds bit for bit; interval-valued ones by containment)
 
 
 @pytest.fixture()
