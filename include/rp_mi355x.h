@@ -514,8 +514,22 @@ typedef enum rp_libm_kind { RP_LIBM_CONTRACT = 0, RP_LIBM_GLIBC = 1 } rp_libm_ki
  * AVX2 machine selects); rp_libm_glibc.h restates that one, and tests/test_libm_glibc.py compares it with the platform's libm. */
 RP_API int rp_kmeans_set_libm(rp_kmeans* h, rp_libm_kind kind);
 /* enable = 0: no filter in front of the exact solves (Elkan::neighbor / Layer::init_centroids as the reference loops them, every
- * (point, centroid) pair solved): the yardstick the filtered passes are audited against.  Before the first centroid; a layer that
- * gave its filters up does not get them back (enable = 1 on such a layer: RP_ERR_UNSUPPORTED). */
+ * (point, centroid) pair solved, every stale-bound refresh solved): the yardstick the filtered passes are audited against.  Before
+ * the first centroid; a layer that gave its filters up does not get them back (enable = 1 on such a layer: RP_ERR_UNSUPPORTED).
+ *
+ * WHAT THE FILTERED PASSES GUARANTEE — read before relying on "bit-exact buckets" through them.  The four filters (k-means++ column
+ * bound and interval filter, the MFMA bound of init_bounds / lookup, the interval-decided refresh of the Elkan iterations) replace a
+ * bit-faithful solve by a scaling-domain INTERVAL that must contain the value the reference would compute.  The column bound is
+ * rigorous.  The intervals are not proven: their margins (SbParams: kappa, rho, dc_abs 4e-6, dc_rel 4e-5) are a multiple of the worst
+ * float noise MEASURED between the scaling-domain and the log-domain iteration, and the smallest slack observed on a sampled pair was
+ * 0.88 of the margin (profiles/r05_glibc_audit.json), i.e. a safety factor of about 8 over the worst observed case, on synthetic
+ * points.  The evidence that they hold: full-size audits in both arithmetics with 0 of 1 286 792 points differing from the unpruned
+ * search on the synthetic layer (profiles/r05_glibc_audit.json, r05_kpp_audit*.json) and on the real flop layer (r03_mfma_audit.json),
+ * 0 differences over 32 Elkan iterations with and without the refresh bound (profiles/r06_refresh_audit_*.json), and a runtime
+ * tripwire: every 521st point is searched again without the MFMA prune after every pruned pass, a mismatch makes the next call that
+ * hands results out fail with RP_ERR_INTERNAL (never a silently different bucket).  That is a statistical claim with a tripwire, not a
+ * bound: a caller that needs exactness BY CONSTRUCTION uses rp_kmeans_set_prune(h, 0), the only such mode (and RP_LLOYD_AUDIT=1 runs
+ * the unpruned search behind every pruned pass and counts disagreements). */
 RP_API int rp_kmeans_set_prune(rp_kmeans* h, int enable);
 /* the three stand-alone operators (rp_sinkhorn_divergence / _cost / _flow): process-wide */
 RP_API int rp_sinkhorn_set_libm(rp_libm_kind kind);
@@ -545,7 +559,10 @@ RP_API int rp_kmeans_step(rp_kmeans* h, float* drift, uint64_t* sizes, double* r
 RP_API int rp_kmeans_step_naive(rp_kmeans* h);
 /* Layer::lookup (layer.rs:62-82): fresh neighbor(i) for every point; bucket[N], distance[N] (may be NULL) */
 RP_API int rp_kmeans_assign(rp_kmeans* h, uint8_t* bucket, float* distance);
-/* current Elkan bounds: j[N] (u8), upper[N]; lower[N*K] may be NULL */
+/* current Elkan bounds: j[N] (u8), upper[N]; lower[N*K] may be NULL.  With the interval-decided refresh (the default for Sinkhorn
+ * layers whose filters are on; csrc/refresh_bound.hpp) upper[i] may be the UPPER END of an interval around the reference's
+ * Bounds::error and lower[i][j[i]] its lower end: rp_kmeans_upper_interval (rp_mi355x_diag.h) says where and returns the lower ends.
+ * j[], and lower[i][k] for k != j[i], are the reference's bit for bit in every mode; after rp_kmeans_set_prune(h, 0) so is everything. */
 RP_API int rp_kmeans_bounds(rp_kmeans* h, uint8_t* j, float* upper, float* lower);
 /* centroids as integer sums: counts[K*bins] (u32), weight[K] (u64) (histogram.rs:286-294, bins.rs:75-82) */
 RP_API int rp_kmeans_centroids(rp_kmeans* h, uint32_t* counts, uint64_t* weight);
