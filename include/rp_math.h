@@ -276,8 +276,11 @@ RP_HD uint64_t rp_node_hash_tree(uint64_t step_hash, uint64_t tree) {
 }
 /* the per-DRAW half is 32-bit arithmetic (round 4): a draw reads only the top 32 bits of its hash (rp_u01: 24, rp_pick_uniform:
  * 32), and on gfx950 an integer multiply issues at a quarter of the VALU rate — the 64-bit mixer's eight multiplies per draw were a
- * fifth of the headline traversal's issue time.  Murmur3's 32-bit finaliser (full avalanche, a bijection: distinct keys of one tree
- * never collide) over the tree hash's low word and the folded key, the high word multiplied in afterwards: three multiplies. */
+ * fifth of the headline traversal's issue time.  Murmur3's 32-bit finaliser (full avalanche, a bijection of its 32-bit argument) over
+ * the tree hash's low word and the key FOLDED to 32 bits (low word ^ high word), the high word multiplied in afterwards: three
+ * multiplies.  Distinct keys of one tree never collide as long as they are distinct after the fold — always for the dense solvers,
+ * whose keys (infoset << 8 | salt) fit 32 bits; the NLHE traversal hands in 64-bit infoset hashes, where two nodes of one tree share
+ * a draw with probability 2^-32 per pair (both draws stay valid samples of their distributions; the oracle folds the same way). */
 RP_HD uint32_t rp_fmix32(uint32_t h) {
     h ^= h >> 16;
     h *= 0x85ebca6bu;

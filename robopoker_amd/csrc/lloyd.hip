@@ -1476,25 +1476,29 @@ int rp_kmeans_kpp_bound_probe(rp_kmeans* h, uint32_t k, float* lo) {
     if (!h || !lo || k >= h->K) return rp::fail(RP_ERR_INVALID, "rp_kmeans_kpp_bound_probe: bad argument");
     if (!h->kb_on) return rp::fail(RP_ERR_UNSUPPORTED, "rp_kmeans_kpp_bound_probe: the layer has no k-means++ interval filter");
     HIP_TRY(hipSetDevice(h->device));
-    // one scratch allocation (diagnostics: freed on every path): lo[N], pot[N], list in[N + 4], list out[N + 4], ctl[4]
+    // one scratch allocation (diagnostics: freed on every path): lo[N], pot[N], list in[N + 4], list out[N + 4], ctl[4], and the
+    // probe's OWN striped counters (the layer's kb_stats feed rp_kmeans_prune_stats: a diagnostic must not move them)
     const size_t N = (size_t)h->N;
+    const size_t stat_words = (size_t)KM_STAT_STRIPES * STAT_STRIDE * 2;  // u64 as two u32
     unsigned char* scratch = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), (4 * N + 8 + 4) * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), (4 * N + 8 + 4 + 2 + stat_words) * 4));
     float* d_lo = reinterpret_cast<float*>(scratch);
     float* d_pot = d_lo + N;
     uint32_t* d_list = reinterpret_cast<uint32_t*>(d_pot + N);
     unsigned int* d_ctl = reinterpret_cast<unsigned int*>(d_list + 2 * (N + 4));
+    unsigned long long* d_stats = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(d_ctl + 4) + 7u) & ~(uintptr_t)7u);
     std::vector<uint32_t> ids(N);
     for (size_t i = 0; i < N; ++i) ids[i] = (uint32_t)i;
     const unsigned int ctl[4] = {(unsigned int)N, 0u, 0u, 0u};  // [0] count in, [1] cursor, [2] count out
     hipError_t e = hipMemcpyAsync(d_list, ids.data(), N * 4, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_ctl, ctl, 16, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_lo, 0, N * 4, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_stats, 0, stat_words * 4, h->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, h->stream, d_pot, h->N, -1.0f);  // lo^2 >= -1 always: every window runs to its end
         hipLaunchKernelGGL((k_kpp_bound<64, 48>), dim3(2048), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
                            (const float*)d_pot, (const uint32_t*)d_list, (const unsigned int*)d_ctl, d_ctl + 1, d_list + N + 4, d_ctl + 2,
-                           h->kb_stats, d_lo);
+                           d_stats, d_lo);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(lo, d_lo, N * 4, hipMemcpyDeviceToHost, h->stream);

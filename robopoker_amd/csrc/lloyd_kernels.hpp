@@ -849,12 +849,15 @@ __global__ __launch_bounds__(64) void k_neighbor_chunk(Points P, CentroidSet cs,
     const uint32_t per = (K + NB_CHUNKS - 1u) / NB_CHUNKS, k0 = q * per, k1 = min(K, k0 + per);
     const uint32_t n = wave_load_hist(P.counts + i * P.stride, P.weight[i], M.bins, w.supB, w.lnB);
     const float sp = P.self[i];
+    // the sequential rule (k_neighbor: the first centroid is taken whatever its distance, a later one only if strictly smaller — a NaN
+    // never wins) holds across chunks only if a chunk other than the first starts "unset": +inf loses to every finite distance here
+    // and wins against nothing in k_neighbor_merge
     uint32_t bj = 0xffu;
-    float bd = 0.0f;
+    float bd = __builtin_inff();
     for (uint32_t k = k0; k < k1; ++k) {
         const uint32_t m = wave_load_centroid(cs, k, w.supA, w.lnA);
         const float d = wave_divergence(w, m, n, cs.self[k], sp, M);  // distance(centroid, point)
-        if (k == k0 || d < bd) {
+        if (k == 0 || d < bd) {
             bj = k;
             bd = d;
         }
@@ -1247,6 +1250,7 @@ __global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uin
         wave_variation_all(w.f, cs, K, M.bins, dv, M, false);  // distances to every centroid; the replay below uses (and
                                                                // counts) only the ones the sequential rule evaluates
     }
+    unsigned long long var_evaluated = 0;
     auto distance_to = [&](uint32_t k) -> float {  // distance(point, centroid k)
         if (kind == RP_METRIC_SINKHORN) {
             const uint32_t n = wave_load_centroid(cs, k, w.supB, w.lnB);
@@ -1256,7 +1260,7 @@ __global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uin
         }
         const uint32_t q = k >> 6, src = k & 63u;
         float mine = q == 0 ? dv[0] : (q == 1 ? dv[1] : (q == 2 ? dv[2] : dv[3]));
-        if (lane == 0) atomicAdd(STAT(M, 0), 1ull);
+        var_evaluated += 1;  // one atomic per wavefront at the end, not one per distance
         return __shfl(mine, (int)src, 64);
     };
     float lw[4];
@@ -1314,6 +1318,7 @@ __global__ __launch_bounds__(64) void k_elkan_step(Points P, CentroidSet cs, uin
         B.stale[i] = 0;
         if (exact) memo_store(B, i, j, u);
         if (exact && B.uiv) B.uiv[i] = 0;
+        if (var_evaluated) atomicAdd(STAT(M, 0), var_evaluated);
     }
 }
 

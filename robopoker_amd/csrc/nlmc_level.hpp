@@ -991,7 +991,8 @@ __global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t
 // batch-wide path.  ctl: err, n_nodes (sum over trees), pad[0] (deepest tree), the census.
 // ---------------------------------------------------------------------------------------------------------------
 #define NL_TREE_BATCH 2048u  // batches up to this many trees take k_nl_tree
-#define NL_TREE_CAP 8192u  // nodes of a tree's region (observed: <= 2 900 on fresh tables; a blueprint's trees are pruned smaller)
+#define NL_TREE_CAP 4096u  // nodes of a tree's region (observed: <= 2 900 on fresh tables; a blueprint's trees are pruned smaller); a tree that
+                           // outgrows it raises NERR_NODES and the handle moves to the batch-wide kernels.  (8 192 until round 5: 4.8 GB at 2 048 trees)
 __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes nd, uint32_t C, uint32_t WC) {
     __shared__ uint32_t lvl[NL_MAXL + 2];
     __shared__ uint32_t s_cursor, s_err, s_nw, s_wsum[4], s_census[5];
