@@ -94,8 +94,10 @@ def cluster_preflop(device=0, flop: Artifacts | None = None, flop_metric=None) -
     return art
 
 
-def cluster_layer(street: str, below: Artifacts, tri=None, K=None, iterations=None, seed=None, log=None, limit=None) -> Artifacts:
-    """Layer::cluster for the turn (below = river artifacts) or the flop (below = turn artifacts, tri = its metric)."""
+def cluster_layer(street: str, below: Artifacts, tri=None, K=None, iterations=None, seed=None, log=None, limit=None, libm="contract",
+                  rng="counter") -> Artifacts:
+    """Layer::cluster for the turn (below = river artifacts) or the flop (below = turn artifacts, tri = its metric).
+    libm="glibc" / rng="reference": the reference's own exp / ln and k-means++ draw (rp_kmeans_set_libm / rp_kmeans_set_rng)."""
     assert (street, below.street) in (("turn", "rive"), ("flop", "turn"))
     K = K or K_CLUSTERS[street]
     iterations = ITERATIONS[street] if iterations is None else iterations
@@ -117,6 +119,10 @@ def cluster_layer(street: str, below: Artifacts, tri=None, K=None, iterations=No
     t0 = time.perf_counter()
     layer = Layer(K, None, kind, tri, seed=deuce.STREETS[street] if seed is None else seed, device=dev.index or 0,
                   counts_dev_ptr=points.data_ptr(), shape=tuple(points.shape))
+    if libm != "contract":
+        layer.set_libm(libm)
+    if rng != "counter":
+        layer.set_rng(rng, deuce.STREETS[street])
     tm["create_s"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     layer.init_centroids()
@@ -147,6 +153,7 @@ def cluster_layer(street: str, below: Artifacts, tri=None, K=None, iterations=No
         import os
 
         tm["prune"] = layer.prune_stats()
+        tm["refresh"] = layer.refresh_stats()
         n_margin = int(os.environ.get("RP_LLOYD_MARGIN_SAMPLE", "0"))
         if n_margin:  # scripts/mfma_audit.py: the bound's room around the exact divergence on a sample of THESE points
             from .lloyd import margin_audit
@@ -158,14 +165,14 @@ def cluster_layer(street: str, below: Artifacts, tri=None, K=None, iterations=No
     return Artifacts(street, obs, torch.from_numpy(bucket).to(dev), metric, future, weight, tm)
 
 
-def run(device=0, log=None, flop_iterations=None, turn_iterations=None) -> dict[str, Artifacts]:
+def run(device=0, log=None, flop_iterations=None, turn_iterations=None, libm="contract", rng="counter") -> dict[str, Artifacts]:
     """PreTraining::run's clustering order: river, turn, flop, preflop (pretraining.rs:24-44, Street::all().rev())."""
     out = {}
     out["rive"] = cluster_river(device)
     if log:
         log(f"river: {out['rive'].obs.numel()} isomorphisms, equity {out['rive'].timings['equity_ms']:.0f} ms")
-    out["turn"] = cluster_layer("turn", out["rive"], iterations=turn_iterations, log=log)
-    out["flop"] = cluster_layer("flop", out["turn"], tri=out["turn"].metric, iterations=flop_iterations, log=log)
+    out["turn"] = cluster_layer("turn", out["rive"], iterations=turn_iterations, log=log, libm=libm, rng=rng)
+    out["flop"] = cluster_layer("flop", out["turn"], tri=out["turn"].metric, iterations=flop_iterations, log=log, libm=libm, rng=rng)
     out["pref"] = cluster_preflop(device, out["flop"], out["flop"].metric)
     return out
 

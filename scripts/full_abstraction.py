@@ -36,7 +36,9 @@ if world > 1:
     dist.barrier()
     torch.cuda.synchronize()
 else:
-    art = pretraining.run(local, log=say, flop_iterations=fi, turn_iterations=ti)
+    # RP_FULL_LIBM=glibc / RP_FULL_RNG=reference: the pipeline in the reference's own arithmetic and k-means++ draw
+    art = pretraining.run(local, log=say, flop_iterations=fi, turn_iterations=ti, libm=os.environ.get("RP_FULL_LIBM", "contract"),
+                          rng=os.environ.get("RP_FULL_RNG", "counter"))
 total = time.perf_counter() - t0
 if rank != 0:
     sys.exit(0)
