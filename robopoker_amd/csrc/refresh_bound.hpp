@@ -226,17 +226,27 @@ __global__ __launch_bounds__(64) void k_refresh_interval(Points P, CentroidSet c
             const bool possible = last || (err - noise < prm.tol * prm.rho);
             const bool certain = last || ((err + noise) * prm.rho < prm.tol);
             const bool flat = err <= prm.flat * SB_EPS23 * suv;
-            if (possible || flat) {  // wave uniform: the cost of this iterate, sum_y a_y sum_x K C b_x
+            // (every lane holds the same err / suv / mx — butterfly sums give both partners the same bits — so the flag is wave
+            // uniform; read through an SGPR it becomes a real branch: left as a lane predicate the compiler if-converted the cost
+            // pass into the loop body and every iteration issued its ~450 instructions with an empty exec mask)
+            if (__builtin_amdgcn_readfirstlane((int)(possible || flat))) {  // the cost of this iterate, sum_y a_y sum_x K C b_x
                 float part = 0.0f;
+                const uint32_t xb = 4u * lane < bins ? 4u * lane : 0u;  // bins is a multiple of four here; past it b = 0
 #pragma unroll
-                for (uint32_t y = 0; y < NR; ++y) {
-                    const uint32_t xb = 4u * lane < bins ? 4u * lane : 0u;  // bins is a multiple of four here; past it b = 0
-                    const float4 cq = *reinterpret_cast<const float4*>(Cm + (size_t)L.yP[y] * bins + xb);
-                    float q = (Kr[y][0] * cq.x) * b[0];
-                    q = __builtin_fmaf(Kr[y][1] * cq.y, b[1], q);
-                    q = __builtin_fmaf(Kr[y][2] * cq.z, b[2], q);
-                    q = __builtin_fmaf(Kr[y][3] * cq.w, b[3], q);
-                    part = __builtin_fmaf(L.a[y], q, part);
+                for (uint32_t y0 = 0; y0 < NR; y0 += 8) {  // eight rows of C in flight at a time: the loads of all NR rows at once cost
+                                                           // 4 NR registers on top of K's, and a wavefront per SIMD with them
+                    float4 cq[8];
+#pragma unroll
+                    for (uint32_t y = 0; y < 8; ++y) cq[y] = *reinterpret_cast<const float4*>(Cm + (size_t)L.yP[y0 + y] * bins + xb);
+#pragma unroll
+                    for (uint32_t y = 0; y < 8; ++y) {
+                        float q = (Kr[y0 + y][0] * cq[y].x) * b[0];
+                        q = __builtin_fmaf(Kr[y0 + y][1] * cq[y].y, b[1], q);
+                        q = __builtin_fmaf(Kr[y0 + y][2] * cq[y].z, b[2], q);
+                        q = __builtin_fmaf(Kr[y0 + y][3] * cq[y].w, b[3], q);
+                        part = __builtin_fmaf(L.a[y0 + y], q, part);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 const float cost = kb_allsum<64>(part);
                 my_costs += 1;
