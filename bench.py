@@ -657,13 +657,7 @@ def nlhe_synth(args, rank, world, local_rank):
                                               f"in {dtc:.1f} s on 1 host thread"}
         else:
             line["cpu_baseline"] = None
-        try:  # the whole detail beside the line (scratch: gpurun_out/ travels back from the GPU box)
-            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as fh:
-                json.dump(line, fh)
-        except OSError:
-            pass
-        print(json.dumps(line if args.verbose else compact_line(line)), flush=True)
+        print(json.dumps(line), flush=True)
     prof.close()
     if sharded:
         dist.barrier()
@@ -1254,7 +1248,13 @@ def main():
                 line["abstraction_inputs"] = {"error": f"{type(exc).__name__}: {exc}"}
         if sharded_mode:
             line["rccl_nranks"] = RCCL_NRANKS
-        print(json.dumps(line), flush=True)
+        try:  # the whole detail beside the line (scratch: gpurun_out/ travels back from the GPU box)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as fh:
+                json.dump(line, fh)
+        except OSError:
+            pass
+        print(json.dumps(line if args.verbose else compact_line(line)), flush=True)
 
     if sharded_mode and not args.no_kmeans:
         # The k-means exchange on the same ranks, AFTER the contract line is out (stdout carries exactly one JSON

@@ -35,7 +35,7 @@ def main() -> int:
     tab = exp2_table()
     for i in range(0, 32, 4):
         print(", ".join(f"0x{v:016x}ull" for v in tab[i : i + 4]) + ",")
-    body = text[text.index("T[32]") : text.index("return T[i")]
+    body = text[text.index("#define RP_GLIBC_EXP2F_TAB_INIT") : text.index("return T[i")]  # the initialiser macro (shared with the LDS copy)
     have = [int(h, 16) for h in re.findall(r"0x([0-9a-f]{16})ull", body)]
     ok = have == tab
     print("exp2 table in the header:", "matches" if ok else "DIFFERS")
@@ -43,7 +43,10 @@ def main() -> int:
     for fn, end, log in (("rp_glibc_logf", "const double A0 = -0x1.00ea", lambda v: -Decimal(v).ln()),
                          ("rp_glibc_powf", "const double A0 = 0x1.2761", lambda v: -Decimal(v).ln() / ln2)):
         at = text.index("RP_HD float " + fn)
-        body = text[text.index("LT[16][2]", at) : text.index(end, at)]
+        if fn == "rp_glibc_logf":  # its table is the macro in front of the function (shared with the kernels' LDS copy)
+            body = text[text.index("#define RP_GLIBC_LOGF_TAB_INIT") : at]
+        else:
+            body = text[text.index("LT[16][2]", at) : text.index(end, at)]
         pairs = re.findall(r"\{(-?0x[0-9a-fp.+-]+), (-?0x[0-9a-fp.+-]+)\}", body)
         assert len(pairs) == 16, (fn, len(pairs))
         same = all(float(log(float.fromhex(invc))) + 0.0 == float.fromhex(logc) for invc, logc in pairs)
