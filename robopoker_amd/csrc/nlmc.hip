@@ -878,3 +878,16 @@ int rp_nlhe_sync(rp_nlhe* h) {
 }
 
 }  // extern "C"
+
+#ifdef NL_TREE_PROF  // diagnostic build only (scripts/r6_nltree_prof.sh): k_nl_tree's phase clocks
+extern "C" RP_API int rp_nl_tree_prof(uint64_t* out16, int reset) {
+    unsigned long long z[16] = {0};
+    if (out16) HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(rp::g_nl_prof), sizeof(z)));
+    if (reset) HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rp::g_nl_prof), z, sizeof(z)));
+    return RP_OK;
+}
+extern "C" RP_API int rp_nl_tree_rec(uint32_t* out, uint32_t trees) {
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rp::g_nl_rec), (size_t)std::min<uint32_t>(trees, 2048u) * 16u * 4u));
+    return RP_OK;
+}
+#endif

@@ -993,7 +993,27 @@ __global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t
 #define NL_TREE_BATCH 2048u  // batches up to this many trees take k_nl_tree
 #define NL_TREE_CAP 4096u  // nodes of a tree's region (observed: <= 2 900 on fresh tables; a blueprint's trees are pruned smaller); a tree that
                            // outgrows it raises NERR_NODES and the handle moves to the batch-wide kernels.  (8 192 until round 5: 4.8 GB at 2 048 trees)
+#ifdef NL_TREE_PROF  // a diagnostic build (scripts/r6_nltree_prof.sh): 10 ns ticks per phase, summed over the trees of every launch
+__device__ unsigned long long g_nl_prof[16];
+__device__ unsigned int g_nl_rec[2048 * 16];  // the last launch, per tree: ticks by phase [0..8], levels, nodes, walker nodes
+#define NLP(k)                                          \
+    do {                                                \
+        if (threadIdx.x == 0) {                         \
+            const unsigned long long _t = wall_clock64(); \
+            atomicAdd(&g_nl_prof[k], _t - nlp_t0);      \
+            if (blockIdx.x < 2048u) g_nl_rec[blockIdx.x * 16u + (k)] += (unsigned int)(_t - nlp_t0); \
+            nlp_t0 = _t;                                \
+        }                                               \
+    } while (0)
+#else
+#define NLP(k)
+#endif
 __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes nd, uint32_t C, uint32_t WC) {
+#ifdef NL_TREE_PROF
+    unsigned long long nlp_t0 = wall_clock64();
+    if (threadIdx.x < 16 && blockIdx.x < 2048u) g_nl_rec[blockIdx.x * 16u + threadIdx.x] = 0u;
+    __syncthreads();
+#endif
     __shared__ uint32_t lvl[NL_MAXL + 2];
     __shared__ uint32_t s_cursor, s_err, s_nw, s_wsum[4], s_census[5];
     const uint32_t tree = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
@@ -1008,6 +1028,7 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
     }
     if (tid < 5) s_census[tid] = 0;
     __syncthreads();
+    NLP(0);
     const bool pruning = p.sampling == RP_SAMPLING_PRUNABLE || (p.sampling == RP_SAMPLING_PLURIBUS && p.epoch >= p.prune_warmup);
     uint32_t levels = 0, err = 0;
     for (uint32_t L = 0;; ++L) {
@@ -1037,6 +1058,7 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
             }
             if ((tid & 63u) == 63u) s_wsum[wave] = incl;
             __syncthreads();
+            NLP(1);
             const uint32_t cur = s_cursor;
             uint32_t wpre = 0, tot = 0;
 #pragma unroll
@@ -1049,6 +1071,7 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
             if (!fits) err |= NERR_NODES;
             if (nk && fits) nl_place_children(t, nd, i, seg, info, cur + wpre + incl - nk, aux, osig, oq);
             __syncthreads();  // every work-item has read the cursor and the wavefront sums
+            NLP(2);
             if (tid == 0 && fits) s_cursor = cur + tot;
             if (!fits) break;
         }
@@ -1061,6 +1084,7 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
         for (uint32_t c = hi + tid; c < chi; c += 256u) err |= nl_make_child(p, nd, c, (int)p.walker);
         if (err) atomicOr(&s_err, err);
         __syncthreads();  // the node records and the level table are read by other work-items from here on
+        NLP(3);
         if (s_err) break;
     }
     if (err) atomicOr(&s_err, err);
@@ -1082,15 +1106,19 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
         }
         __syncthreads();
     }
+    NLP(4);
     if (nd.ex_k)  // every chain value is in place: the walker nodes' action values (read by k_nl_emit, the next launch)
         for (uint32_t i = base + tid; i < s_cursor; i += 256u) {
             const uint32_t m = nd.meta[i];
             if (NL_META_KIND(m) == NK_WALKER && NL_META_NKIDS(m) != 0u) nl_ex_walker(nd, i, tree * WC, WC);
         }
+    __syncthreads();
+    NLP(5);
     for (uint32_t l = 0; l + 1 < levels; ++l) {
         for (uint32_t i = lvl[l] + tid; i < lvl[l + 1]; i += 256u) nl_down_node(nd, i);
         __syncthreads();
     }
+    NLP(6);
     // ---- the tree's walker nodes by ordinal (k_nl_fill's part), the census
     const uint32_t end = s_cursor, woff = tree * WC;
     uint32_t c4[4] = {0, 0, 0, 0}, wk = 0;
@@ -1111,6 +1139,7 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
     __syncthreads();
     if (tid < 4 && s_census[tid]) atomicAdd(&nd.ctl->kinds[tid], s_census[tid]);
     if (tid == 4 && s_census[4]) atomicAdd(&nd.ctl->walker_kids, s_census[4]);
+    NLP(7);
     if (tid == 0) {
         nd.t_nw[tree] = s_nw;
         nd.t_woff[tree] = woff;
@@ -1130,6 +1159,20 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
     }
     __syncthreads();  // t_woff[tree] and the walker list are read by other work-items below
     nl_group_tree<NL_WMAX, 256>(nd, tree, nw, tid, g_key, g_key2, g_hp, &g_count);
+    __syncthreads();
+    NLP(8);
+#ifdef NL_TREE_PROF
+    if (tid == 0) {
+        atomicAdd(&g_nl_prof[9], 1ull);
+        atomicAdd(&g_nl_prof[10], (unsigned long long)levels);
+        atomicAdd(&g_nl_prof[11], (unsigned long long)(end - base));
+        if (blockIdx.x < 2048u) {
+            g_nl_rec[blockIdx.x * 16u + 9] = levels;
+            g_nl_rec[blockIdx.x * 16u + 10] = end - base;
+            g_nl_rec[blockIdx.x * 16u + 11] = nw;
+        }
+    }
+#endif
 }
 
 }  // namespace rp

@@ -31,7 +31,7 @@
 //  A too-large N_t, rho or dc only widens intervals (more survivors, never a wrong answer).  RP_LLOYD_AUDIT=1 runs the
 //  unpruned pass next to the pruned one and counts disagreements (rp_kmeans_prune_stats); the GPU tests do that.
 //
-// MAPPING.  One workgroup (8 wavefronts) per point; wave w owns centroids 32w .. 32w+31 as two column blocks of 16.
+// MAPPING.  One workgroup (4 or 8 wavefronts) per point; a wavefront iterates 16 centroid columns at a time (k_sinkhorn_bound below).
 //  K[sup_y][.] of the point's support is gathered once into LDS in both orientations (row strides 264 / 72 floats:
 //  conflict-free ds_read_b128 for the A operands).  U, V live in registers in the MFMA C/D layout, which IS the B-operand
 //  layout of the next contraction when the k index is permuted (row 4g + r of an accumulator feeds k = g of step r), so
@@ -77,7 +77,7 @@ struct __attribute__((aligned(16))) SbLds {
     uint32_t sup[SB_MAXROWS];
     uint32_t np;
     uint32_t item;
-    uint32_t next;    // the point's next column block (16 of them, taken by whichever wavefront is free)
+    uint32_t next;    // the point's column queue: the next column slot of perm[] (taken by whichever wavefront has a free slot)
     uint8_t crank[256];  // the centroids' place in an order that keeps similar centroids together (ties of lb0 follow it)
 };
 #define SB_LB_SAFETY 0.999f
@@ -244,17 +244,19 @@ struct SbCol {  // per-column window state (replicated in the four lanes of the 
     bool complete;  // the stopping window was followed to its end (not dropped)
 };
 // Column order.  The rigorous bound  cost >= sum_y nu(y) min_{x in supp mu_j} C(x, y)  (the column sums of the coupling are nu
-// after every rhs update, at any iteration count) costs n reads per centroid and needs no iteration.  Columns are sorted by it
-// so that a 16-column block holds centroids of similar distance, wave w takes sorted blocks w and 15 - w (a near and a far
-// one), and a column whose bound exceeds an upper bound already published by a finished column is dropped at once — its
-// interval is [bound, inf), it cannot be the argmin.
+// after every rhs update, at any iteration count) costs n reads per centroid and needs no iteration.  The point's columns are queued
+// in ascending bound (the near ones first: their upper bounds are published while the far ones wait), and a column whose bound exceeds
+// an upper bound already published by a finished column is dropped at once — its interval is [bound, inf), it cannot be the argmin.
 
-// pstats: [0] survivors, [1] points, [2] column-block iterations, [3] cost passes, [4] MFMA instructions   (striped like Metric::stats)
-// A wavefront runs ONE column block at a time (64 + 12 NT accumulator registers: four wavefronts per SIMD for NT <= 2) and takes the
-// point's next block from an LDS counter when it is done: the sixteen blocks of a point differ in length by a factor of six, and with
-// two or three workgroups on a CU another point's wavefronts fill what a straggler leaves idle.
-// NT <= 2: four wavefronts per point and two points per CU (2 x 78 KB of LDS): a point's sixteen blocks spread evenly over four
-// wavefronts, and one point's gather / tail is covered by the other's iterations.  NT >= 3 (110 / 146 KB): eight wavefronts, one point.
+// pstats: [0] survivors, [1] points, [2] wavefront iterations, [3] cost passes, [4] MFMA instructions, [5] column iterations (live
+// slots summed over the wavefront iterations: [5] / (16 [2]) is the useful share)          (striped like Metric::stats)
+// A wavefront iterates sixteen column SLOTS (64 + 12 NT accumulator registers) and a slot whose column is done takes the point's next
+// column from an LDS counter: a point's columns differ in length by a factor of six.  Until round 6 a wavefront took sixteen columns
+// together and iterated until the slowest was done: 0.62 of the slot-iterations were live then, 0.75 now (what is left is each
+// wavefront's own drain at the end of the point: measured, neither a descending queue nor handing the last columns to the
+// wavefronts of highest priority changes it — DESIGN 4d).
+// NT <= 2: four wavefronts per point and two points per CU (2 x 78 KB of LDS): one point's gather / drain is covered by the other's
+// iterations.  NT >= 3 (110 / 146 KB): eight wavefronts, one point.
 template <int NT>
 __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Points P, CentroidSet cs, uint32_t K, uint32_t bins, SbParams prm,
                                                                    const uint32_t* list, uint32_t count, unsigned int* cursor,
@@ -348,50 +350,88 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
             L.perm[rank] = tid;
         }
         __syncthreads();
-        // ---- column blocks in ascending bound (the near ones first: their upper bounds are published while the far ones wait)
-        for (;;) {
-            uint32_t blk = 0;
-            if (lane == 0) blk = atomicAdd(&L.next, 1u);
-            blk = __builtin_amdgcn_readfirstlane(blk);
-            if (blk >= 16u) break;
+        // ---- columns in ascending bound (the near ones first: their upper bounds are published while the far ones wait).  A wavefront
+        // iterates 16 column SLOTS; a slot whose column is done takes the point's next column from the queue at once (round 6: until
+        // round 5 a wavefront took sixteen columns together and iterated until the slowest of them was done — 38 % of the
+        // block-iterations ran columns that were finished).  Everything a column owns is per lane (the four lanes c, c+16, c+32, c+48).
+        {
             f32x4 uo[16], v[NT];
-            const uint32_t j0 = L.perm[blk * 16 + c];
-            const float dlb0 = L.lb0[j0];
-            const uint32_t jc = j0 < K ? j0 : K - 1;
-            const uint32_t mj = cs.n[jc];
-            const bool valid = j0 < K && mj > 0;
-            const float* drow = cs.densR + (size_t)jc * 256;
-            {   // Potential::uniform (phi.rs:34-39): exp(lhs) = 1/|supp mu| on the support, exp(rhs) = 1/|supp nu|
-                const float iu = 1.0f / (float)(mj ? mj : 1u), iv = 1.0f / (float)np;
-#pragma unroll
-                for (int xt = 0; xt < 16; ++xt) {
-                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(drow + xt * 16 + 4 * g);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) uo[xt][r] = d0[r] > 0.0f ? iu : 0.0f;
-                    if (xt & 1) __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int yt = 0; yt < NT; ++yt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[yt][r] = (uint32_t)(yt * 16 + 4 * g + r) < np ? iv : 0.0f;
-            }
+            uint32_t j0 = 256u, jc = 0u, mj = 0u, tcol = 0u;
+            float dlb0 = 0.0f, sc = 0.0f;
+            bool valid = false, has = false;
+            const float* drow = cs.densR;
             SbCol st;
-            uint32_t t_done = 0;  // the iteration count at which this lane's column left the loop (statistics)
-            st.wmin = __builtin_inff();
-            st.wmax = -__builtin_inff();
-            st.nb_prev = SB_EPS23 * (8.0f + 0.37f * (float)np) + SB_EPS23 * 0.37f * (float)mj;
-            st.flatc = 0;
-            st.opened = false;
-            st.done = !valid || dlb0 > __uint_as_float(*(volatile uint32_t*)&L.ub);
-            st.complete = false;
-            const float sc = cs.self[jc];
-            for (uint32_t t = 0; t < prm.iters; ++t) {
-                if (__ballot(!st.done) == 0) break;
-                const bool last = t + 1 == prm.iters;
+            st.done = true;
+            // takes the next live column for the slots whose `want` is set (wave uniform call, lane-varying want); columns that can be
+            // settled without iterating (not a centroid, empty, or bound above a published upper bound) are written off on the way
+            auto refill = [&](bool want) {
+                bool fresh = false;
+                for (;;) {  // the queue: a cheap loop (a pop, four LDS reads), repeated while a wanting slot popped a column that never starts
+                    if (__ballot(want) == 0) break;
+                    uint32_t idx = 256u;
+                    if (want && g == 0) idx = atomicAdd(&L.next, 1u);
+                    idx = (uint32_t)__shfl((int)idx, (int)c, 64);  // the column's four lanes follow lane c
+                    if (want) {
+                        if (idx >= 256u) {
+                            want = false;  // the queue is empty: the slot stays idle (has == false)
+                        } else {
+                            j0 = L.perm[idx];
+                            dlb0 = L.lb0[j0];
+                            jc = j0 < K ? j0 : K - 1;
+                            mj = cs.n[jc];
+                            valid = j0 < K && mj > 0;
+                            if (!valid || dlb0 > __uint_as_float(*(volatile uint32_t*)&L.ub)) {  // never starts: [bound, inf)
+                                if (g == 0) {
+                                    L.dlo[j0] = j0 < K ? (valid ? dlb0 : 0.0f) : __builtin_inff();
+                                    L.dhi[j0] = __builtin_inff();
+                                }
+                            } else {
+                                fresh = true;
+                                want = false;
+                            }
+                        }
+                    }
+                }
+                if (__ballot(fresh) == 0) return;
+                if (fresh) {  // the start of a column, once per refill whatever the queue loop took
+                    has = true;
+                    drow = cs.densR + (size_t)jc * 256;
+                    sc = cs.self[jc];
+                    tcol = 0;
+                    // Potential::uniform (phi.rs:34-39): exp(lhs) = 1/|supp mu| on the support, exp(rhs) = 1/|supp nu|
+                    const float iu = 1.0f / (float)mj, iv = 1.0f / (float)np;
+#pragma unroll
+                    for (int xt = 0; xt < 16; ++xt) {
+                        const f32x4 d0 = *reinterpret_cast<const f32x4*>(drow + xt * 16 + 4 * g);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) uo[xt][r] = d0[r] > 0.0f ? iu : 0.0f;
+                    }
+#pragma unroll
+                    for (int yt = 0; yt < NT; ++yt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[yt][r] = (uint32_t)(yt * 16 + 4 * g + r) < np ? iv : 0.0f;
+                    st.wmin = __builtin_inff();
+                    st.wmax = -__builtin_inff();
+                    st.nb_prev = SB_EPS23 * (8.0f + 0.37f * (float)np) + SB_EPS23 * 0.37f * (float)mj;
+                    st.flatc = 0;
+                    st.opened = false;
+                    st.done = false;
+                    st.complete = false;
+                }
+            };
+#pragma unroll
+            for (int xt = 0; xt < 16; ++xt) uo[xt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int yt = 0; yt < NT; ++yt) v[yt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            refill(true);
+            for (;;) {
+                if (__ballot(has && !st.done) == 0) break;
+                const bool live = has && !st.done;
+                const bool last = tcol + 1 == prm.iters;
                 float err, sumu, umax, sumv, vmax, fused = 0.0f;
-                // once a column of the block is inside its stopping window every further iterate's cost is wanted: the cost contraction
+                // once a column of the wavefront is inside its stopping window every further iterate's cost is wanted: the cost contraction
                 // then rides on the iteration itself; the first iterate of a window (not known in advance) takes the separate pass below
-                const bool with_cost = __ballot(st.opened && !st.done) != 0;
+                const bool with_cost = __ballot(live && st.opened) != 0;
                 if (with_cost) sb_iterate<NT, true>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused);
                 else sb_iterate<NT, false>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused);
                 my_cb_iters += 1;
@@ -403,7 +443,7 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
                 const bool possible = last || (err - noise < prm.tol * prm.rho);
                 const bool certain = last || ((err + noise) * prm.rho < prm.tol);
                 const bool flat = err <= prm.flat * SB_EPS23 * (sumu + sumv);
-                const bool want = !st.done && (possible || flat);
+                const bool want = live && (possible || flat);
                 if (__ballot(want)) {  // wave uniform: one more contraction with K .* C for the cost of this iterate
                     const float cost = with_cost ? fused : sb_cost<NT>(uo, v, L, c, g, prm.neg_t_ln2);
                     my_cost_passes += 1;
@@ -415,31 +455,40 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
                     }
                 }
                 st.flatc = flat ? st.flatc + 1 : 0;
-                if (!st.done && (certain || st.flatc >= 2)) {
-                    st.done = true;
-                    st.complete = true;
-                    if (st.opened && g == 0) {  // publish this column's upper bound
-                        const float ch = st.wmax + (prm.dc_abs + prm.dc_rel * fabsf(st.wmax));
-                        const float hi = rp_maxf(ch - 0.5f * sc - 0.5f * sp, 0.0f);
-                        if (hi == hi && hi < __builtin_inff()) atomicMin(&L.ub, __float_as_uint(hi));
+                if (live) {
+                    tcol += 1;
+                    if (g == 0) my_col_iters += 1;
+                    if (certain || st.flatc >= 2) {
+                        st.done = true;
+                        st.complete = true;
+                        if (st.opened && g == 0) {  // publish this column's upper bound
+                            const float ch = st.wmax + (prm.dc_abs + prm.dc_rel * fabsf(st.wmax));
+                            const float hi = rp_maxf(ch - 0.5f * sc - 0.5f * sp, 0.0f);
+                            if (hi == hi && hi < __builtin_inff()) atomicMin(&L.ub, __float_as_uint(hi));
+                        }
                     }
+                    // a column whose rigorous lower bound exceeds a published upper bound cannot be the argmin: stop iterating it
+                    if (!st.done && dlb0 > __uint_as_float(*(volatile uint32_t*)&L.ub)) st.done = true;
                 }
-                // a column whose rigorous lower bound exceeds a published upper bound cannot be the argmin: stop iterating it
-                if (!st.done && dlb0 > __uint_as_float(*(volatile uint32_t*)&L.ub)) st.done = true;
-                if (!st.done) t_done = t + 1;
-            }
-            if (g == 0) my_col_iters += t_done;
-            // ---- interval of the divergence (sinkhorn.rs:166-171): the same three f32 operations, monotone in the cost
-            float lo = valid ? dlb0 : 0.0f, hi = __builtin_inff();
-            if (valid && st.opened && st.complete) {  // a column dropped inside its window keeps [dlb0, inf)
-                const float cl = st.wmin - (prm.dc_abs + prm.dc_rel * fabsf(st.wmin));
-                const float ch = st.wmax + (prm.dc_abs + prm.dc_rel * fabsf(st.wmax));
-                if (cl == cl && cl > -__builtin_inff()) lo = fmaxf(lo, rp_maxf(cl - 0.5f * sc - 0.5f * sp, 0.0f));
-                if (ch == ch) hi = rp_maxf(ch - 0.5f * sc - 0.5f * sp, 0.0f);
-            }
-            if (g == 0 && j0 < 256) {
-                L.dlo[j0] = j0 < K ? lo : __builtin_inff();
-                L.dhi[j0] = hi;
+                const bool finished = has && st.done;
+                if (__ballot(finished)) {
+                    if (finished) {
+                        // ---- interval of the divergence (sinkhorn.rs:166-171): the same three f32 operations, monotone in the cost
+                        float lo = dlb0, hi = __builtin_inff();
+                        if (st.opened && st.complete) {  // a column dropped inside its window keeps [dlb0, inf)
+                            const float cl = st.wmin - (prm.dc_abs + prm.dc_rel * fabsf(st.wmin));
+                            const float ch = st.wmax + (prm.dc_abs + prm.dc_rel * fabsf(st.wmax));
+                            if (cl == cl && cl > -__builtin_inff()) lo = fmaxf(lo, rp_maxf(cl - 0.5f * sc - 0.5f * sp, 0.0f));
+                            if (ch == ch) hi = rp_maxf(ch - 0.5f * sc - 0.5f * sp, 0.0f);
+                        }
+                        if (g == 0) {
+                            L.dlo[j0] = lo;
+                            L.dhi[j0] = hi;
+                        }
+                        has = false;
+                    }
+                    refill(finished);
+                }
             }
         }
         __syncthreads();
