@@ -103,6 +103,11 @@ struct rp_nlhe {
     // small batches (the reference's 128): one tree per workgroup, the whole traversal in one launch (k_nl_tree); tree_cap = nodes of a
     // tree's region (0: the node arrays were not sized for it), level_ncap = the batch-wide path's own node budget (its launch sizes)
     uint32_t tree_cap = 0, level_ncap = 0;
+    NlPost* post = nullptr;      // pinned, mapped host memory (k_nl_finish)
+    NlPost* post_dev = nullptr;  // the same words as the device addresses them
+    uint32_t post_seq = 0;
+    bool ctl_clean = false;      // the control block is zero (k_nl_finish cleared it; the batch-wide path leaves it dirty)
+    uint32_t tree_bt = 512;  // k_nl_tree's workgroup (RP_NL_TREE_BT = 256 / 512 / 1024 for the experiment; measured round 6: 0.483 / 0.428 / 0.443 ms per step)
     bool tree_mode_off = false;  // a tree outgrew its region once: the handle stays on the batch-wide path
     uint32_t* ex_k_parked = nullptr;  // rp_nlhe_set_exact(h, 0) on a large-batch handle: lv.ex_k while the exact evaluation is off
     uint32_t chunks = 1;  // passes per batch (RP_NLHE_CHUNKS; doubled when a pass runs out of nodes)
@@ -180,6 +185,28 @@ void nl_begin_step(rp_nlhe* h) {
     }
 }
 
+// waits for k_nl_finish's post of this step (h->post_seq).  Looks at the stream now and then: a failed launch never posts.
+int nl_wait_post(rp_nlhe* h, hipStream_t st) {
+    const volatile uint32_t* seq = &h->post->seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 1;; ++spins) {
+        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == h->post_seq) return RP_OK;
+        if ((spins & 0x3fffu) == 0) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) {  // everything launched has run: the word is there, or the kernel did not run
+                if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == h->post_seq) return RP_OK;
+                return rp::fail(RP_ERR_HIP, "rp_nlhe: the traversal finished without posting its counts");
+            }
+            if (q != hipErrorNotReady) return rp::fail(RP_ERR_HIP, "rp_nlhe: %s while waiting for the traversal", hipGetErrorString(q));
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+                return rp::fail(RP_ERR_HIP, "rp_nlhe: no post from the traversal after 30 s");
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+
 // ---- the level-synchronous traversal (nlmc_level.hpp)
 // the trees [lo, lo + B) of the batch, grown and evaluated together; their Decisions go behind the `d_base` already emitted.
 // *flags: the traversal's error flags when the return code is RP_ERR_CAPACITY (the caller retries a spent node budget in chunks)
@@ -195,19 +222,37 @@ int nl_traverse_chunk(rp_nlhe* h, uint32_t lo, uint32_t B, uint32_t d_base, uint
     if (h->tree_cap && !h->tree_mode_off && lo == 0 && B == h->batch) {
         // ---- a small batch: one tree per workgroup, one launch (k_nl_tree), then the partition and the Decisions as below
         const uint32_t WC = NL_WMAX;
-        HIP_TRY(hipMemsetAsync(lv.ctl, 0, sizeof(NlCtl), st));
+        if (!h->ctl_clean) HIP_TRY(hipMemsetAsync(lv.ctl, 0, sizeof(NlCtl), st));
+        h->ctl_clean = false;
         prm.tag = nl_next_tag(h);
         nl_clock_begin(h, 0);
-        hipLaunchKernelGGL(k_nl_tree, dim3(B), blk, 0, st, prm, h->tab, lv, h->tree_cap, WC);
+        // the workgroup that finishes last scans the trees' Decisions counts and posts the batch's total and control block to the host
+        // through pinned memory: the host spins on the sequence word (a scan launch + two copies + hipStreamSynchronize until round 6:
+        // three launches and an interrupt round trip per step)
+        h->post_seq += 1;
+        if (h->post_seq == 0) h->post_seq = 1;
+        if (h->tree_bt == 1024u) hipLaunchKernelGGL(k_nl_tree<1024>, dim3(B), dim3(1024), 0, st, prm, h->tab, lv, h->tree_cap, WC, h->d_total, h->post_dev, h->post_seq);
+        else if (h->tree_bt == 256u) hipLaunchKernelGGL(k_nl_tree<256>, dim3(B), blk, 0, st, prm, h->tab, lv, h->tree_cap, WC, h->d_total, h->post_dev, h->post_seq);
+        else hipLaunchKernelGGL(k_nl_tree<512>, dim3(B), dim3(512), 0, st, prm, h->tab, lv, h->tree_cap, WC, h->d_total, h->post_dev, h->post_seq);
         nl_clock_end(h, 0);
         nl_clock_begin(h, 3);
-        HIP_TRY(rp::ss::exclusive_scan<uint32_t>(lv.t_dcount, lv.t_doff, B, h->d_scan, st, h->d_total));
+        // the Decisions are emitted behind the traversal without waiting for the host (nothing of the launch depends on the counts; a
+        // tree that failed has no Decisions, and the host discards the buffer of a failed step): the post's way to the host and the
+        // update's launches hide behind this kernel
+        hipLaunchKernelGGL(k_nl_emit, dim3(B), blk, 0, st, lv, h->tab, B * WC, d_base, lo, h->out_cap, h->out, WC, (const float*)lv.wval);
         HIP_TRY(hipGetLastError());
-        uint32_t total0 = 0;
-        NlCtl ctl;
-        HIP_TRY(hipMemcpyAsync(&total0, h->d_total, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(&ctl, lv.ctl, sizeof(NlCtl), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        {
+            int rcw = nl_wait_post(h, st);
+            if (rcw) return rcw;
+        }
+        h->ctl_clean = true;
+        const uint32_t total0 = h->post->total;
+        NlCtl ctl{};
+        ctl.err = h->post->err;
+        ctl.n_nodes = h->post->n_nodes;
+        ctl.pad[0] = h->post->levels;
+        for (int k = 0; k < 4; ++k) ctl.kinds[k] = h->post->kinds[k];
+        ctl.walker_kids = h->post->walker_kids;
         if (ctl.err & (NERR_NODES | NERR_WALKERS)) {
             h->tree_mode_off = true;  // a tree outgrew its region: this step and the following ones on the batch-wide path
             nl_clock_end(h, 3);
@@ -222,8 +267,6 @@ int nl_traverse_chunk(rp_nlhe* h, uint32_t lo, uint32_t B, uint32_t d_base, uint
             }
             if ((uint64_t)d_base + total0 > h->out_cap)
                 return rp::fail(RP_ERR_CAPACITY, "rp_nlhe: %llu Decisions in one batch exceed the buffer (%u)", (unsigned long long)d_base + total0, h->out_cap);
-            hipLaunchKernelGGL(k_nl_emit, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(h->grid_cap, B * WC / 256u))), blk, 0, st, lv, h->tab, B * WC, d_base, lo,
-                               h->out_cap, h->out, WC, (const float*)lv.wval);
             nl_clock_end(h, 3);
             HIP_TRY(hipGetLastError());
             *n_dec = total0;
@@ -232,6 +275,7 @@ int nl_traverse_chunk(rp_nlhe* h, uint32_t lo, uint32_t B, uint32_t d_base, uint
             return RP_OK;
         }
     }
+    h->ctl_clean = false;
     HIP_TRY(hipMemsetAsync(lv.ctl, 0, sizeof(NlCtl), st));
     HIP_TRY(hipMemsetAsync(lv.t_nw, 0, (size_t)B * 4, st));
     prm.tag = nl_next_tag(h);
@@ -354,6 +398,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
     h->hp = *hp;
     h->seed = seed;
     if (getenv("RP_NLHE_CHUNKS")) h->chunks = (uint32_t)std::max(1, atoi(getenv("RP_NLHE_CHUNKS")));
+    if (getenv("RP_NL_TREE_BT")) h->tree_bt = (uint32_t)atoi(getenv("RP_NL_TREE_BT"));
 #define NL_TRY(expr)                    \
     do {                                \
         int _rc = (expr);               \
@@ -425,9 +470,7 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
         NL_TRY(nl_alloc(h, &lv.kid0, N)); NL_TRY(nl_alloc(h, &lv.row, N)); NL_TRY(nl_alloc(h, &lv.size, N));
         NL_TRY(nl_alloc(h, &lv.dfs, N)); NL_TRY(nl_alloc(h, &lv.aux, N));
         NL_TRY(nl_alloc(h, &lv.fac, N)); NL_TRY(nl_alloc(h, &lv.val, N)); NL_TRY(nl_alloc(h, &lv.reach, N));
-        NL_TRY(nl_alloc(h, &lv.w0, N)); NL_TRY(nl_alloc(h, &lv.w1, N)); NL_TRY(nl_alloc(h, &lv.w2, N));
-        NL_TRY(nl_alloc(h, &lv.blo, N)); NL_TRY(nl_alloc(h, &lv.bhi, N)); NL_TRY(nl_alloc(h, &lv.bucket, N));
-        NL_TRY(nl_alloc(h, &lv.past, N)); NL_TRY(nl_alloc(h, &lv.hkey, N)); NL_TRY(nl_alloc(h, &lv.chpath, N));
+        NL_TRY(nl_alloc(h, &lv.ga, N)); NL_TRY(nl_alloc(h, &lv.gb, N)); NL_TRY(nl_alloc(h, &lv.gc, N));
         NL_TRY(nl_alloc(h, &lv.hole0, B)); NL_TRY(nl_alloc(h, &lv.hole1, B));
         NL_TRY(nl_alloc(h, &lv.t_nw, B)); NL_TRY(nl_alloc(h, &lv.t_woff, B));
         NL_TRY(nl_alloc(h, &lv.t_dcount, B)); NL_TRY(nl_alloc(h, &lv.t_doff, B));
@@ -435,6 +478,18 @@ int rp_nlhe_create(int device, uint32_t cap_log2, rp_regret_kind regret, rp_weig
         NL_TRY(nl_alloc(h, &lv.big, B));
         NL_TRY(nl_alloc(h, &lv.ctl, 1));
         if (tree_mode) NL_TRY(nl_alloc_exact(h));  // a small batch is always evaluated in the reference's own order (k_nl_tree)
+        if (tree_mode) {
+            void* hp_ = nullptr;
+            void* dp_ = nullptr;
+            if (hipHostMalloc(&hp_, sizeof(NlPost), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+                hipHostGetDevicePointer(&dp_, hp_, 0) != hipSuccess) {
+                if (hp_) (void)hipHostFree(hp_);
+                NL_TRY(rp::fail(RP_ERR_HIP, "rp_nlhe_create: no pinned host memory for the traversal's post"));
+            }
+            memset(hp_, 0, sizeof(NlPost));
+            h->post = reinterpret_cast<NlPost*>(hp_);
+            h->post_dev = reinterpret_cast<NlPost*>(dp_);
+        }
     }
     h->out_cap = (uint32_t)dec_cap64;
     NL_TRY(nl_alloc(h, &h->out.row, h->out_cap));
@@ -504,6 +559,7 @@ int rp_nlhe_destroy(rp_nlhe* h) {
         (void)rp_profile_destroy(h->prof);
     }
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->post) (void)hipHostFree(h->post);
     for (void* p : {h->x_keys, h->x_counts, h->x_all, h->x_packed})
         if (p) (void)hipFree(p);
     delete h;

@@ -40,6 +40,7 @@
 #define RP_NLMC_LEVEL_HPP
 
 #include "nlmc_common.hpp"
+#include "sortscan.hpp"
 
 namespace rp {
 
@@ -69,9 +70,11 @@ struct NlNodes {
     // tree structure, by node
     uint32_t *link, *tree, *meta, *kid0, *row, *size, *dfs, *aux;
     float *fac, *val, *reach;
-    // game state, by node (decision and chance nodes only)
-    uint32_t *w0, *w1, *w2, *blo, *bhi, *bucket;
-    uint64_t *past, *hkey, *chpath;
+    // game state, by node (decision and chance nodes only), as three 16-byte records — a node's record is read and written whole, and
+    // a lane's 16-byte access is one request where five to eight 4-byte arrays were five to eight (round 6; the kernels are bound by
+    // the rate of memory requests):  ga = {w0, w1, w2, board lo}   gb = {board hi, buckets of the two seats, past lo, past hi}
+    // gc = {path hash lo, hi, choices path lo, hi}
+    uint4 *ga, *gb, *gc;
     // by tree
     uint64_t *hole0, *hole1;
     uint32_t *t_nw, *t_woff, *t_dcount, *t_doff;
@@ -101,14 +104,27 @@ __device__ __forceinline__ uint32_t nl_lane() { return __lane_id(); }
 __device__ __forceinline__ uint32_t nl_rank_in(unsigned long long mask) {  // set bits of mask below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-__device__ __forceinline__ void nl_store_game(const NlNodes& nd, uint32_t i, const G2& g) {
+// with_bucket == false (a child of a chance node in k_nl_tree): the bucket word belongs to the seats' lanes, which store its halves
+__device__ __forceinline__ void nl_store_game(const NlNodes& nd, uint32_t i, const G2& g, uint32_t bucket, uint64_t past, bool with_bucket = true) {
     const Packed pk = pack_game(g);
-    nd.w0[i] = pk.w0; nd.w1[i] = pk.w1; nd.w2[i] = pk.w2; nd.blo[i] = pk.blo; nd.bhi[i] = pk.bhi;
+    nd.ga[i] = make_uint4(pk.w0, pk.w1, pk.w2, pk.blo);
+    if (with_bucket) {
+        nd.gb[i] = make_uint4(pk.bhi, bucket, (uint32_t)past, (uint32_t)(past >> 32));
+    } else {
+        uint32_t* w = reinterpret_cast<uint32_t*>(nd.gb + i);
+        w[0] = pk.bhi;
+        *reinterpret_cast<uint64_t*>(w + 2) = past;
+    }
 }
-__device__ __forceinline__ void nl_load_game(const NlNodes& nd, uint32_t i, G2& g) {
-    unpack_game(Packed{nd.w0[i], nd.w1[i], nd.w2[i], nd.blo[i], nd.bhi[i]}, g);
+__device__ __forceinline__ void nl_load_game(const NlNodes& nd, uint32_t i, G2& g, uint32_t& bucket, uint64_t& past) {
+    const uint4 a = nd.ga[i], b = nd.gb[i];
+    unpack_game(Packed{a.x, a.y, a.z, a.w, b.x}, g);
     g.cards[0] = g.cards[1] = 0;
+    bucket = b.y;
+    past = (uint64_t)b.z | ((uint64_t)b.w << 32);
 }
+__device__ __forceinline__ uint64_t* nl_hkey_ptr(const NlNodes& nd, uint32_t i) { return reinterpret_cast<uint64_t*>(nd.gc + i); }
+__device__ __forceinline__ uint64_t* nl_chpath_ptr(const NlNodes& nd, uint32_t i) { return reinterpret_cast<uint64_t*>(nd.gc + i) + 1; }
 // the order of the two river hands: 1 = seat 0 stronger, 2 = equal, 3 = seat 1 stronger (0: the board is not complete)
 __device__ __forceinline__ uint32_t nl_showdown_order(uint64_t hole0, uint64_t hole1, uint64_t board) {
     const uint32_t s0 = strength_key(sw_of_hand(hole0 | board)), s1 = strength_key(sw_of_hand(hole1 | board));
@@ -143,10 +159,8 @@ __device__ __forceinline__ uint32_t nl_make_root(const NlParams& p, const NlNode
     const uint32_t b0 = nl_bucket(p, 0, g.cards[0], 0ull, &err), b1 = nl_bucket(p, 0, g.cards[1], 0ull, &err);
     const int turn = g.turn();  // a player: nobody is all-in after the blinds of a 200-chip stack
     const uint32_t kind = turn == (int)p.walker ? NK_WALKER : NK_OPP;
-    nl_store_game(nd, node, g);
-    nd.bucket[node] = b0 | (b1 << 16);
-    nd.past[node] = 0ull;
-    nd.hkey[node] = rp_mix64(0x726f6f74ull);
+    nl_store_game(nd, node, g, b0 | (b1 << 16), 0ull);
+    *nl_hkey_ptr(nd, node) = rp_mix64(0x726f6f74ull);
     nd.link[node] = NL_LINK_NONE;
     nd.tree[node] = tree;
     nd.meta[node] = kind;
@@ -178,7 +192,9 @@ __global__ __launch_bounds__(256) void k_nl_roots(NlParams p, NlNodes nd) {
 // 2 chance.  walker_count: the tree's counter of walker nodes.  Returns n_kids | expanded mask << 4 | sampled slot << 13; aux = the
 // infoset's row (walker) or the bits of sigma / q of the sampled edge (opponent).
 __device__ __forceinline__ uint32_t nl_expand_item(const NlParams& p, const NlTable& t, const NlNodes& nd, uint32_t node, uint32_t seg,
-                                                   bool pruning, uint32_t* walker_count, uint32_t& err, uint32_t& aux, float& osig, float& oq) {
+                                                   bool pruning, uint32_t* walker_count, uint32_t& err, uint32_t& aux, float& osig, float& oq,
+                                                   float* rf_out = nullptr, uint32_t* nch_out = nullptr /* k_nl_tree: the row's nine regrets and the
+                                                   number of choices, for nl_place_children */) {
     const uint32_t m = nd.meta[node];
     if (seg == 2) {  // chance: legal() = [reveal()] -> choices = [Draw] (kicker game.rs:253-260)
         nd.meta[node] = m | (1u << 2) | (1u << 6);
@@ -186,9 +202,9 @@ __device__ __forceinline__ uint32_t nl_expand_item(const NlParams& p, const NlTa
     }
     const uint32_t tree = nd.tree[node];
     G2 g;
-    nl_load_game(nd, node, g);
-    const uint32_t bk = nd.bucket[node];
-    const uint64_t past = nd.past[node];
+    uint32_t bk;
+    uint64_t past;
+    nl_load_game(nd, node, g, bk, past);
     const int turn = g.actor();
     const NlView view = nl_view(g);
     uint64_t chpath;
@@ -278,21 +294,31 @@ __device__ __forceinline__ uint32_t nl_expand_item(const NlParams& p, const NlTa
         aux = __float_as_uint(oppfac);
     }
     nd.row[node] = row;
-    nd.chpath[node] = chpath;
+    *nl_chpath_ptr(nd, node) = chpath;
     nd.meta[node] = m | (nch << 2) | (nkids << 6);
+    if (rf_out) {
+#pragma unroll
+        for (uint32_t a = 0; a < NLMC_A; ++a) rf_out[a] = rf[a];
+        *nch_out = nch;
+    }
     return nkids | (mask << 4) | (pick << 13);
 }
 // the children of one expanded node: a contiguous block of node indices from `run`, in slot order; per child its parent and the
 // factor of its edge (walker: sigma of every surviving edge, recomputed from the row with the operations of nl_expand_item;
 // opponent: sigma / q of the sampled edge; chance: 1).  info / aux: what nl_expand_item returned.
 __device__ __forceinline__ void nl_place_children(const NlTable& t, const NlNodes& nd, uint32_t node, uint32_t seg, uint32_t info, uint32_t run,
-                                                  uint32_t aux, float osig = 1.0f, float oq = 1.0f) {
+                                                  uint32_t aux, float osig = 1.0f, float oq = 1.0f, const float* rf_in = nullptr, uint32_t nch_in = 0) {
     const uint32_t mask = (info >> 4) & 0x1ffu;
     nd.kid0[node] = run;
     if (seg == 0) {
         float rf[12], sg[NLMC_A], rd = 0.0f;
-        nl_load_row(t.rows, aux, false, rf);
-        const uint32_t nch = NL_META_NCH(nd.meta[node]);
+        if (rf_in) {  // k_nl_tree: the regrets nl_expand_item read (a row does not change during a traversal)
+#pragma unroll
+            for (uint32_t a = 0; a < NLMC_A; ++a) rf[a] = rf_in[a];
+        } else {
+            nl_load_row(t.rows, aux, false, rf);
+        }
+        const uint32_t nch = rf_in ? nch_in : NL_META_NCH(nd.meta[node]);
 #pragma unroll
         for (uint32_t a = 0; a < NLMC_A; ++a) {
             sg[a] = 0.0f;
@@ -584,10 +610,19 @@ __device__ __forceinline__ void nl_ex_walker(const NlNodes& nd, uint32_t i, uint
 // k_nl_children: NlheGame::apply(edge) (nlhe/src/game.rs:33-53) for every child of the level, the child's node
 // ---------------------------------------------------------------------------------------------------------------
 // one child: NlheGame::apply(edge) on its parent's state, the child's node record.  Returns error bits.
-__device__ __forceinline__ uint32_t nl_make_child(const NlParams& p, const NlNodes& nd, uint32_t c, int walker) {
+// PART (k_nl_tree splits the child of a chance node over several lanes: the deal's two canonicalisations and the hand ranking are the
+// longest lane-serial stretch of a level otherwise):
+//   NL_CHILD_ALL     everything (k_nl_children)
+//   NL_CHILD_PLAIN   everything, but a child of a chance node is left to the three parts below
+//   NL_CHILD_DEAL    child of a chance node: everything but the buckets (the draw, apply, the showdown order on the river, the record)
+//   NL_CHILD_SEAT0/1 child of a chance node: that seat's bucket only (the draw again — a hash — and one canonicalisation), stored as its
+//                    half of the bucket word
+enum : uint32_t { NL_CHILD_ALL = 0, NL_CHILD_PLAIN = 1, NL_CHILD_DEAL = 2, NL_CHILD_SEAT0 = 3, NL_CHILD_SEAT1 = 4 };
+__device__ __forceinline__ uint32_t nl_make_child(const NlParams& p, const NlNodes& nd, uint32_t c, int walker, uint32_t part = NL_CHILD_ALL) {
     uint32_t err = 0;
     const uint32_t par = nd.link[c];
     const uint32_t pm = nd.meta[par], pkind = NL_META_KIND(pm);
+    if (part == NL_CHILD_PLAIN && pkind == NK_CHANCE) return 0u;
     // the child's slot among the parent's choices: children are stored in slot order, so it is the (c - kid0)-th expanded
     // edge of the parent's mask
     uint32_t slot = 0;
@@ -598,11 +633,14 @@ __device__ __forceinline__ uint32_t nl_make_child(const NlParams& p, const NlNod
     }
     const uint32_t tree = nd.tree[par];
     G2 g;
-    nl_load_game(nd, par, g);
-    const uint64_t phk = nd.hkey[par];
-    const uint32_t e = pkind == NK_CHANCE ? (uint32_t)NE_DRAW : (uint32_t)(nd.chpath[par] >> (5u * slot)) & 31u;
+    uint32_t bucket;
+    uint64_t ppast;
+    nl_load_game(nd, par, g, bucket, ppast);
+    const uint4 pc = nd.gc[par];
+    const uint64_t phk = (uint64_t)pc.x | ((uint64_t)pc.y << 32), pch = (uint64_t)pc.z | ((uint64_t)pc.w << 32);
+    const uint32_t e = pkind == NK_CHANCE ? (uint32_t)NE_DRAW : (uint32_t)(pch >> (5u * slot)) & 31u;
     const uint64_t hk = rp_mix64(phk ^ ((uint64_t)(e + 1u) * 0x9fb21c651e98df25ull));
-    uint32_t bucket = nd.bucket[par], cmp = NL_META_CMP(pm), cdepth, cplen;
+    uint32_t cmp = NL_META_CMP(pm), cdepth, cplen;
     uint64_t cpast;
     if (e == NE_DRAW) {
         const uint64_t h0 = nd.hole0[tree], h1 = nd.hole1[tree];
@@ -612,7 +650,12 @@ __device__ __forceinline__ uint32_t nl_make_child(const NlParams& p, const NlNod
         if (p.check_legal && !g.allowed(act)) err |= NERR_ILLEGAL;
         g.force_act(act);
         const int st = g.street();
-        bucket = nl_bucket(p, st, h0, g.board, &err) | (nl_bucket(p, st, h1, g.board, &err) << 16);
+        if (part == NL_CHILD_SEAT0 || part == NL_CHILD_SEAT1) {
+            const uint32_t seat = part - NL_CHILD_SEAT0;
+            (reinterpret_cast<uint16_t*>(nd.gb + c) + 2)[seat] = (uint16_t)nl_bucket(p, st, seat ? h1 : h0, g.board, &err);
+            return err;
+        }
+        if (part == NL_CHILD_ALL) bucket = nl_bucket(p, st, h0, g.board, &err) | (nl_bucket(p, st, h1, g.board, &err) << 16);
         if (st == 3) cmp = nl_showdown_order(h0, h1, g.board);
         cdepth = 0;
         cplen = 0;
@@ -626,7 +669,6 @@ __device__ __forceinline__ uint32_t nl_make_child(const NlParams& p, const NlNod
         g.force_act(act);
         const uint32_t pdepth = NL_META_DEPTH(pm), pplen = NL_META_PLEN(pm);
         const bool raise = e == NE_SHOVE || e >= NE_OPEN0;
-        const uint64_t ppast = nd.past[par];
         cdepth = pdepth + (raise ? 1u : 0u);
         cplen = pplen + 1u;
         cpast = pplen < 12u ? ppast | ((uint64_t)e << (5u * pplen)) : ppast;
@@ -647,10 +689,8 @@ __device__ __forceinline__ uint32_t nl_make_child(const NlParams& p, const NlNod
         if (nd.ex_k) nl_ex_child(nd, c, par, pkind, true, pay);
     } else {
         const uint32_t kind = turn == NT_CHANCE ? NK_CHANCE : (turn == walker ? NK_WALKER : NK_OPP);
-        nl_store_game(nd, c, g);
-        nd.bucket[c] = bucket;
-        nd.past[c] = cpast;
-        nd.hkey[c] = hk;
+        nl_store_game(nd, c, g, bucket, cpast, part != NL_CHILD_DEAL);  // NL_CHILD_DEAL: the bucket's two halves come from the seats' lanes
+        *nl_hkey_ptr(nd, c) = hk;
         nd.meta[c] = kind | ((cdepth & 7u) << 10) | ((cplen & 15u) << 13) | (cmp << 17) | (pkind << 19);
         nd.val[c] = 0.0f;
         if (nd.ex_k) nl_ex_child(nd, c, par, pkind, false, 0.0f);  // the parent's chains are a launch (a level) old
@@ -899,7 +939,12 @@ __global__ __launch_bounds__(256) void k_nl_emit(NlNodes nd, NlTable t, uint32_t
     __shared__ float tile[4][2][64 * NLMC_A];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t padded = (n + 255u) & ~255u;
-    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < padded; j += gridDim.x * 256u) {
+    // wc != 0 (k_nl_tree's fixed regions of wc slots per tree, of which a tree's first t_dcount stand for its spans — ~70 of 2 048): a
+    // workgroup walks the trees, not the slots
+    const uint32_t step = wc ? gridDim.x * wc : gridDim.x * 256u;
+    for (uint32_t j0 = wc ? blockIdx.x * wc : blockIdx.x * 256u; j0 < padded; j0 += step)
+    for (uint32_t sub = 0, nsub = wc && j0 < n ? (nd.t_dcount[j0 / wc] + 255u) & ~255u : 256u; sub < nsub; sub += 256u) {
+        const uint32_t j = j0 + sub + threadIdx.x;
         bool active = false;
         uint32_t d = 0, tr = 0, off = 0, g = 0;
         if (j < n) {
@@ -1008,21 +1053,74 @@ __device__ unsigned int g_nl_rec[2048 * 16];  // the last launch, per tree: tick
 #else
 #define NLP(k)
 #endif
-__global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes nd, uint32_t C, uint32_t WC) {
+// What the host must know between a small batch's traversal and its update (the number of Decisions sizes the update's launches):
+// written into pinned host memory by the last workgroup of k_nl_tree, `seq` last; the host waits on that word.
+struct NlPost {
+    uint32_t seq, total, err, n_nodes, levels, kinds[4], walker_kids;
+};
+// Every exit of k_nl_tree, by the whole workgroup: the workgroup that counts in last (ctl->pad[1]) scans the trees' Decisions counts
+// into their offsets, posts the batch's total and control block to the host and clears the block for the next step.
+template <uint32_t BT>
+__device__ __forceinline__ void nl_tree_exit(const NlNodes& nd, uint32_t B, uint32_t* total_out, NlPost* post, uint32_t seq) {
+    __shared__ uint64_t x_wt[BT / 64u];
+    __shared__ uint32_t x_last;
+    __syncthreads();  // this workgroup's stores to the per-tree words are issued
+    if (threadIdx.x == 0) {
+        __threadfence();
+        x_last = atomicAdd(&nd.ctl->pad[1], 1u) == B - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!x_last) return;
+    __threadfence();  // the other workgroups' words
+    const uint32_t per = (B + BT - 1u) / BT, lo = min(B, threadIdx.x * per), hi = min(B, lo + per);
+    uint64_t s = 0;
+    for (uint32_t t = lo; t < hi; ++t) s += __hip_atomic_load(&nd.t_dcount[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t tot;
+    uint32_t run = (uint32_t)ss::block_exscan64(s, x_wt, &tot);
+    for (uint32_t t = lo; t < hi; ++t) {
+        nd.t_doff[t] = run;
+        run += __hip_atomic_load(&nd.t_dcount[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) {
+        NlCtl* ctl = nd.ctl;
+        *total_out = (uint32_t)tot;
+        post->total = (uint32_t)tot;
+        post->err = __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        post->n_nodes = __hip_atomic_load(&ctl->n_nodes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        post->levels = __hip_atomic_load(&ctl->pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < 4; ++k) post->kinds[k] = __hip_atomic_load(&ctl->kinds[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        post->walker_kids = __hip_atomic_load(&ctl->walker_kids, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctl->err = 0;
+        ctl->n_nodes = 0;
+        ctl->pad[0] = 0;
+        ctl->pad[1] = 0;
+        for (int k = 0; k < 4; ++k) ctl->kinds[k] = 0;
+        ctl->walker_kids = 0;
+        __threadfence_system();
+        __hip_atomic_store(&post->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+#define NL_TREE_CC 1024u  // children of chance nodes in one level of one tree (observed: a few dozen); more raise NERR_NODES like a full region
+template <uint32_t BT>    // threads of the workgroup: one workgroup per CU at this batch, so a wide one costs nothing and shortens wide levels
+__global__ __launch_bounds__(BT) void k_nl_tree(NlParams p, NlTable t, NlNodes nd, uint32_t C, uint32_t WC, uint32_t* total_out, NlPost* post,
+                                                uint32_t seq) {
+    constexpr uint32_t NW = BT / 64u;
 #ifdef NL_TREE_PROF
     unsigned long long nlp_t0 = wall_clock64();
     if (threadIdx.x < 16 && blockIdx.x < 2048u) g_nl_rec[blockIdx.x * 16u + threadIdx.x] = 0u;
     __syncthreads();
 #endif
     __shared__ uint32_t lvl[NL_MAXL + 2];
-    __shared__ uint32_t s_cursor, s_err, s_nw, s_wsum[4], s_census[5];
-    const uint32_t tree = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    __shared__ uint32_t s_cursor, s_err, s_nw, s_wsum[NW], s_census[5];
+    __shared__ uint32_t s_cc[NL_TREE_CC], s_ncc;  // the children of this level's chance nodes: dealt by three lanes each (nl_make_child's parts)
+    const uint32_t tree = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const uint32_t base = tree * C;
     if (tid == 0) {
         s_err = nl_make_root(p, nd, tree, base);
         if (nd.ex_k) nd.ex_k[base] = 0u;
         s_cursor = base + 1u;
         s_nw = 0;
+        s_ncc = 0;
         lvl[0] = base;
         lvl[1] = base + 1u;
     }
@@ -1039,15 +1137,15 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
             err |= NERR_LEVELS;
             break;
         }
-        // ---- encoder.info + branches + sample for the level's nodes, 256 at a time; children in node order from the cursor
-        for (uint32_t c0 = lo; c0 < hi; c0 += 256u) {
+        // ---- encoder.info + branches + sample for the level's nodes, BT at a time; children in node order from the cursor
+        for (uint32_t c0 = lo; c0 < hi; c0 += BT) {
             const uint32_t i = c0 + tid;
-            uint32_t info = 0, aux = 0, seg = 3;
-            float osig = 1.0f, oq = 1.0f;
+            uint32_t info = 0, aux = 0, seg = 3, nch = 0;
+            float osig = 1.0f, oq = 1.0f, rf[NLMC_A];
             if (i < hi) {
                 const uint32_t kind = NL_META_KIND(nd.meta[i]);
                 seg = kind == NK_WALKER ? 0u : (kind == NK_OPP ? 1u : (kind == NK_CHANCE ? 2u : 3u));
-                if (seg < 3u) info = nl_expand_item(p, t, nd, i, seg, pruning, &s_nw, err, aux, osig, oq);
+                if (seg < 3u) info = nl_expand_item(p, t, nd, i, seg, pruning, &s_nw, err, aux, osig, oq, rf, &nch);
             }
             const uint32_t nk = info & 15u;
             uint32_t incl = nk;
@@ -1056,34 +1154,62 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
                 const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
                 if (nl_lane() >= d) incl += up;
             }
-            if ((tid & 63u) == 63u) s_wsum[wave] = incl;
+            if (lane == 63u) s_wsum[wave] = incl;
             __syncthreads();
             NLP(1);
             const uint32_t cur = s_cursor;
             uint32_t wpre = 0, tot = 0;
 #pragma unroll
-            for (uint32_t w = 0; w < 4; ++w) {
+            for (uint32_t w = 0; w < NW; ++w) {
                 const uint32_t v = s_wsum[w];
                 wpre += w < wave ? v : 0u;
                 tot += v;
             }
             const bool fits = cur + tot <= base + C;  // workgroup uniform
             if (!fits) err |= NERR_NODES;
-            if (nk && fits) nl_place_children(t, nd, i, seg, info, cur + wpre + incl - nk, aux, osig, oq);
+            const uint32_t run = cur + wpre + incl - nk;
+            if (nk && fits) nl_place_children(t, nd, i, seg, info, run, aux, osig, oq, rf, nch);
+            {   // the level's chance nodes hand their (one) child to the deal lanes
+                const bool cc = seg == 2u && nk && fits;
+                const unsigned long long cm = __ballot(cc);
+                if (cm) {
+                    uint32_t at = 0;
+                    if (lane == 0) at = atomicAdd(&s_ncc, (uint32_t)__popcll(cm));
+                    at = (uint32_t)__shfl((int)at, 0, 64) + nl_rank_in(cm);
+                    if (cc) {
+                        if (at < NL_TREE_CC) s_cc[at] = run;
+                        else err |= NERR_NODES;
+                    }
+                }
+            }
             __syncthreads();  // every work-item has read the cursor and the wavefront sums
             NLP(2);
             if (tid == 0 && fits) s_cursor = cur + tot;
             if (!fits) break;
         }
         if (err) atomicOr(&s_err, err);
-        __syncthreads();  // the cursor, the children's (parent, factor), the error word
+        __syncthreads();  // the cursor, the children's (parent, factor), the error word, the deal list
         if (s_err) break;
-        // ---- NlheGame::apply(edge) for the level's children: the next level's nodes
-        const uint32_t chi = s_cursor;
+        // ---- NlheGame::apply(edge) for the level's children: the next level's nodes.  Wavefront-sized tasks, the long ones first: per
+        // 64 children of chance nodes one task for each seat's bucket and one for the rest of the deal; per 64 children one for the others.
+        // Typical level: one task of each kind, one per wavefront.
+        const uint32_t chi = s_cursor, ncc = min(s_ncc, NL_TREE_CC);
         if (tid == 0) lvl[L + 2] = chi;
-        for (uint32_t c = hi + tid; c < chi; c += 256u) err |= nl_make_child(p, nd, c, (int)p.walker);
+        {
+            const uint32_t tb = (ncc + 63u) >> 6, ta = (chi - hi + 63u) >> 6;
+            for (uint32_t wt = wave; wt < 3u * tb + ta; wt += NW) {
+                if (wt < 3u * tb) {
+                    const uint32_t part = wt / tb, j = (wt - part * tb) * 64u + lane;  // 0 / 1: the seats, 2: the rest
+                    if (j < ncc) err |= nl_make_child(p, nd, s_cc[j], (int)p.walker, part == 2u ? (uint32_t)NL_CHILD_DEAL : (uint32_t)NL_CHILD_SEAT0 + part);
+                } else {
+                    const uint32_t c = hi + (wt - 3u * tb) * 64u + lane;
+                    if (c < chi) err |= nl_make_child(p, nd, c, (int)p.walker, NL_CHILD_PLAIN);
+                }
+            }
+        }
         if (err) atomicOr(&s_err, err);
         __syncthreads();  // the node records and the level table are read by other work-items from here on
+        if (tid == 0) s_ncc = 0;  // (read again only after the next level's barriers)
         NLP(3);
         if (s_err) break;
     }
@@ -1096,42 +1222,43 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
             nd.t_woff[tree] = tree * WC;
             nd.t_dcount[tree] = 0;
         }
+        nl_tree_exit<BT>(nd, gridDim.x, total_out, post, seq);
         return;
     }
     // ---- the sweeps: D(node) and subtree sizes bottom-up, creation indices top-down
     for (uint32_t l = levels; l-- > 0;) {
-        for (uint32_t i = lvl[l] + tid; i < lvl[l + 1]; i += 256u) {
+        for (uint32_t i = lvl[l] + tid; i < lvl[l + 1]; i += BT) {
             const uint32_t sz = nl_up_node(nd, i);
             if (l == 0 && sz >= 65536u) atomicOr(&nd.ctl->err, NERR_NODES);
         }
         __syncthreads();
     }
     NLP(4);
-    if (nd.ex_k)  // every chain value is in place: the walker nodes' action values (read by k_nl_emit, the next launch)
-        for (uint32_t i = base + tid; i < s_cursor; i += 256u) {
-            const uint32_t m = nd.meta[i];
-            if (NL_META_KIND(m) == NK_WALKER && NL_META_NKIDS(m) != 0u) nl_ex_walker(nd, i, tree * WC, WC);
-        }
-    __syncthreads();
-    NLP(5);
-    for (uint32_t l = 0; l + 1 < levels; ++l) {
-        for (uint32_t i = lvl[l] + tid; i < lvl[l + 1]; i += 256u) nl_down_node(nd, i);
-        __syncthreads();
-    }
-    NLP(6);
-    // ---- the tree's walker nodes by ordinal (k_nl_fill's part), the census
+    // The creation indices go top-down on the FIRST wavefront alone (a level is a store -> load dependency inside one wavefront: a fence,
+    // no workgroup barrier) while the other wavefronts compute the walker nodes' action values (every chain value is in place; read by
+    // k_nl_emit, the next launch), list the walker nodes by ordinal (k_nl_fill's part) and count the census: none of these reads dfs.
     const uint32_t end = s_cursor, woff = tree * WC;
     uint32_t c4[4] = {0, 0, 0, 0}, wk = 0;
-    for (uint32_t i = base + tid; i < end; i += 256u) {
-        const uint32_t m = nd.meta[i], kind = NL_META_KIND(m);
+    if (wave == 0) {
+        for (uint32_t l = 0; l + 1 < levels; ++l) {
+            for (uint32_t i = lvl[l] + lane; i < lvl[l + 1]; i += 64u) nl_down_node(nd, i);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        for (uint32_t i = base + tid - 64u; i < end; i += BT - 64u) {
+            const uint32_t m = nd.meta[i], kind = NL_META_KIND(m);
 #pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) c4[k] += kind == k ? 1u : 0u;
-        if (kind == NK_WALKER) {
-            wk += NL_META_NKIDS(m);
-            const uint32_t ord = nd.aux[i] & 0xffffu;
-            if (ord < WC) nd.wl[woff + ord] = i;
+            for (uint32_t k = 0; k < 4; ++k) c4[k] += kind == k ? 1u : 0u;
+            if (kind == NK_WALKER) {
+                wk += NL_META_NKIDS(m);
+                const uint32_t ord = nd.aux[i] & 0xffffu;
+                if (ord < WC) nd.wl[woff + ord] = i;
+                if (nd.ex_k && NL_META_NKIDS(m) != 0u) nl_ex_walker(nd, i, woff, WC);
+            }
         }
     }
+    NLP(6);
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k)
         if (c4[k]) atomicAdd(&s_census[k], c4[k]);
@@ -1155,10 +1282,11 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
     const uint32_t nw = s_nw;  // workgroup uniform (the barrier above)
     if (nw == 0 || nw > WC) {
         if (tid == 0) nd.t_dcount[tree] = 0;
+        nl_tree_exit<BT>(nd, gridDim.x, total_out, post, seq);
         return;
     }
     __syncthreads();  // t_woff[tree] and the walker list are read by other work-items below
-    nl_group_tree<NL_WMAX, 256>(nd, tree, nw, tid, g_key, g_key2, g_hp, &g_count);
+    nl_group_tree<NL_WMAX, BT>(nd, tree, nw, tid, g_key, g_key2, g_hp, &g_count);
     __syncthreads();
     NLP(8);
 #ifdef NL_TREE_PROF
@@ -1173,6 +1301,7 @@ __global__ __launch_bounds__(256) void k_nl_tree(NlParams p, NlTable t, NlNodes 
         }
     }
 #endif
+    nl_tree_exit<BT>(nd, gridDim.x, total_out, post, seq);
 }
 
 }  // namespace rp

@@ -270,6 +270,107 @@ static __global__ __launch_bounds__(256) void k_rs_scatter(const uint32_t* keys,
     }
 }
 
+// ---- the whole sort by ONE workgroup of 1024 (at most SORT_ONE keys): what a batch of the reference's size needs (128 trees, ~10^4
+// Decisions: six launches of five workgroups each through the tiled passes above).  Wavefront w owns a contiguous chunk of the input;
+// it ranks its keys digit by digit in rounds of 64 against ITS OWN running digit counts (LDS, no workgroup barrier inside the rounds);
+// one scan over (digit, wavefront) turns the counts into first slots; keys, values and ranks wait in registers meanwhile.  Between the
+// passes keys and values stay in LDS (64 + 32 KB: a value is a position below 16 384); only the first pass reads global memory and
+// only the last writes it.  A pass is four workgroup barriers.
+constexpr uint32_t SORT_ONE = 16384;  // 16 rounds of 64 per wavefront
+struct SortOneLds {
+    uint32_t key[SORT_ONE];
+    uint16_t val[SORT_ONE];
+    uint32_t wcount[16 * 512];
+    uint64_t wt[16];
+};
+template <uint32_t RB, bool FIRST, bool LAST>
+__device__ __forceinline__ void sort_one_pass(const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n, uint32_t shift, SortOneLds& L) {
+    constexpr uint32_t NB = 1u << RB, ROUNDS = SORT_ONE / 1024u;
+    static_assert(NB * 16u % 1024u == 0 && NB <= 512u, "whole (digit, wavefront) slices per thread");
+    const uint32_t tid = threadIdx.x, ln = tid & 63u, wv = tid >> 6;
+    const uint32_t chunk = ((n + 1023u) / 1024u) * 64u;  // keys per wavefront: whole rounds
+    for (uint32_t e = tid; e < 16u * NB; e += 1024u) L.wcount[e] = 0;
+    uint32_t key[ROUNDS], val[ROUNDS], rank[ROUNDS];
+    uint32_t* mine_cnt = L.wcount + wv * NB;
+#pragma unroll
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+        const uint32_t i = wv * chunk + r * 64u + ln;
+        const bool live = r * 64u < chunk && i < n;
+        key[r] = live ? (FIRST ? keys_in[i] : L.key[i]) : 0u;
+        val[r] = live ? (FIRST ? i : (uint32_t)L.val[i]) : 0u;
+    }
+    __syncthreads();  // the counters are zero; every key and value of the previous pass is in registers
+#pragma unroll
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+        if (r * 64u >= chunk) break;  // workgroup uniform
+        const uint32_t i = wv * chunk + r * 64u + ln;
+        const bool live = i < n;
+        const uint32_t d = (key[r] >> shift) & (NB - 1u);
+        unsigned long long peers = __ballot(live);
+#pragma unroll
+        for (uint32_t b = 0; b < RB; ++b) {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t before = (uint32_t)__popcll(peers & ((1ull << ln) - 1ull));
+        rank[r] = live ? mine_cnt[d] + before : 0u;  // the wavefront's keys of this digit in earlier rounds + the peers in front
+        __builtin_amdgcn_wave_barrier();             // every peer has read the count
+        if (live && before == 0u) mine_cnt[d] += (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {   // first slots: exclusive scan over (digit major, wavefront minor); thread t owns PER consecutive cells of that order
+        constexpr uint32_t PER = NB * 16u / 1024u;
+        uint32_t c[PER];
+        uint64_t sum = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q) {
+            const uint32_t cell = tid * PER + q, d = cell >> 4, w = cell & 15u;
+            c[q] = L.wcount[w * NB + d];
+            sum += c[q];
+        }
+        uint64_t tot;
+        uint32_t run = (uint32_t)block_exscan64(sum, L.wt, &tot);
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q) {
+            const uint32_t cell = tid * PER + q, d = cell >> 4, w = cell & 15u;
+            L.wcount[w * NB + d] = run;
+            run += c[q];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+        if (r * 64u >= chunk) break;
+        const uint32_t i = wv * chunk + r * 64u + ln;
+        if (i < n) {
+            const uint32_t pos = mine_cnt[(key[r] >> shift) & (NB - 1u)] + rank[r];
+            L.key[pos] = key[r];
+            if (LAST) {
+                keys_out[pos] = key[r];
+                vals_out[pos] = val[r];
+            } else {
+                L.val[pos] = (uint16_t)val[r];
+            }
+        }
+    }
+    __syncthreads();  // the pass' keys (and values) are in LDS for the next pass / the caller
+}
+// stable sort of (keys_in[i], i) by the low `bits` bits (at most 27) into (keys_out, vals_out) by the calling workgroup of 1024; the
+// sorted keys are in L.key as well when it returns
+__device__ __forceinline__ void sort_one_body(const uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n, uint32_t bits, SortOneLds& L) {
+    if (bits <= 9u) {
+        sort_one_pass<9, true, true>(keys_in, keys_out, vals_out, n, 0u, L);
+    } else if (bits <= 18u) {
+        sort_one_pass<9, true, false>(keys_in, keys_out, vals_out, n, 0u, L);
+        sort_one_pass<9, false, true>(keys_in, keys_out, vals_out, n, 9u, L);
+    } else {
+        sort_one_pass<9, true, false>(keys_in, keys_out, vals_out, n, 0u, L);
+        sort_one_pass<9, false, false>(keys_in, keys_out, vals_out, n, 9u, L);
+        sort_one_pass<9, false, true>(keys_in, keys_out, vals_out, n, 18u, L);
+    }
+}
+
 inline uint32_t rs_tiles(uint32_t n) { return (n + RS_TILE - 1) / RS_TILE; }
 constexpr uint32_t RS_SELF_OFFSETS = 512;  // tiles up to which a scatter workgroup derives its offsets itself
 // scratch: the digit-major histogram [512][tiles] + what its scan needs + one ping-pong pair of n keys and n values
@@ -382,9 +483,8 @@ static __global__ __launch_bounds__(256) void k_rle_tiles(const uint32_t* keys, 
     if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 255u) *n_runs = run;  // the last thread ends at the number of runs
 }
 // at most SCAN_ONE keys: one workgroup does all of it, counts included, in one launch
-static __global__ __launch_bounds__(1024) void k_rle_one(const uint32_t* keys, uint32_t n, uint32_t* uniq, uint32_t* starts, uint32_t* counts,
-                                                         uint32_t* n_runs) {
-    __shared__ uint64_t wt[16];
+__device__ __forceinline__ void rle_one_body(const uint32_t* keys, uint32_t n, uint32_t* uniq, uint32_t* starts, uint32_t* counts, uint32_t* n_runs,
+                                             uint64_t* wt /* [blockDim.x / 64] words of LDS */) {
     const uint32_t per = (n + blockDim.x - 1u) / blockDim.x, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
     uint64_t s = 0;
     for (uint32_t i = lo; i < hi; ++i) s += (i == 0u || keys[i] != keys[i - 1u]) ? 1u : 0u;
@@ -401,6 +501,11 @@ static __global__ __launch_bounds__(1024) void k_rle_one(const uint32_t* keys, u
     __syncthreads();  // every start of the workgroup is written
     const uint32_t runs = (uint32_t)tot;
     for (uint32_t g = threadIdx.x; g < runs; g += blockDim.x) counts[g] = (g + 1u < runs ? starts[g + 1u] : n) - starts[g];
+}
+static __global__ __launch_bounds__(1024) void k_rle_one(const uint32_t* keys, uint32_t n, uint32_t* uniq, uint32_t* starts, uint32_t* counts,
+                                                         uint32_t* n_runs) {
+    __shared__ uint64_t wt[16];
+    rle_one_body(keys, n, uniq, starts, counts, n_runs, wt);
 }
 
 // sorted keys -> uniq[r], starts[r] (= the exclusive scan of counts), counts[r] for r < *n_runs; work = n words of scratch.

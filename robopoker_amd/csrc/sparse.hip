@@ -422,9 +422,8 @@ __global__ __launch_bounds__(256) void k_blk_tiles(const uint32_t* nblk, const u
         run += v[k];
     }
 }
-__global__ __launch_bounds__(1024) void k_blk_one(const uint32_t* starts, const uint32_t* n_segs, uint32_t n, uint32_t* counts, uint32_t* nblk,
-                                                  uint32_t* boff, uint32_t* blkseg, uint32_t* hot_counter) {
-    __shared__ uint64_t wt[16];
+__device__ __forceinline__ void blk_one_body(const uint32_t* starts, const uint32_t* n_segs, uint32_t n, uint32_t* counts, uint32_t* nblk,
+                                             uint32_t* boff, uint32_t* blkseg, uint32_t* hot_counter, uint64_t* wt) {
     const uint32_t runs = *n_segs, per = (n + blockDim.x - 1u) / blockDim.x, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
     uint64_t s = 0;
     for (uint32_t g = lo; g < hi; ++g) {
@@ -445,6 +444,92 @@ __global__ __launch_bounds__(1024) void k_blk_one(const uint32_t* starts, const 
         run += nb;
     }
     if (threadIdx.x == 0) *hot_counter = 0;
+}
+__global__ __launch_bounds__(1024) void k_blk_one(const uint32_t* starts, const uint32_t* n_segs, uint32_t n, uint32_t* counts, uint32_t* nblk,
+                                                  uint32_t* boff, uint32_t* blkseg, uint32_t* hot_counter) {
+    __shared__ uint64_t wt[16];
+    blk_one_body(starts, n_segs, n, counts, nblk, boff, blkseg, hot_counter, wt);
+}
+// A batch of at most ss::SORT_ONE Decisions (the reference's 128 trees emit ~10^4): the stable sort by row, its run lengths and the
+// block index in ONE launch of one workgroup — what sort_and_segment + k_blk_one do in eight (six of them five workgroups wide).
+__global__ __launch_bounds__(1024) void k_prep_one(const uint32_t* rows, uint32_t n, uint32_t bits, uint32_t* keys_out, uint32_t* perm,
+                                                   uint32_t* seg_rows, uint32_t* seg_offsets, uint32_t* seg_counts, uint32_t* n_segs,
+                                                   uint32_t* nblk, uint32_t* boff, uint32_t* blkseg, uint32_t* hot_counter) {
+    __shared__ ss::SortOneLds L;
+    __shared__ uint32_t wsum[16];
+    ss::sort_one_body(rows, keys_out, perm, n, bits, L);
+    const uint32_t* lkey = L.key;  // the sorted keys
+    // ---- run lengths and block index.  Wavefront w owns the contiguous chunk w of the sorted keys and walks it in rounds of 64 (coalesced
+    // reads, ballots and shuffles instead of a serial walk per work-item); the run starts stay in LDS (16 bits: n <= 16 384) for the block
+    // counts, which therefore read no global memory at all.
+    uint16_t* s_start = reinterpret_cast<uint16_t*>(L.wcount);  // [n]; the sort is done with the counters
+    const uint32_t tid = threadIdx.x, ln = tid & 63u, wv = tid >> 6;
+    const uint32_t chunk = ((n + 1023u) / 1024u) * 64u, lo = min(n, wv * chunk), hi = min(n, lo + chunk);
+    uint32_t heads = 0;
+    for (uint32_t i0 = lo; i0 < hi; i0 += 64u) {
+        const uint32_t i = i0 + ln;
+        const bool head = i < hi && (i == 0u || lkey[i] != lkey[i - 1u]);
+        heads += (uint32_t)__popcll(__ballot(head));
+    }
+    if (ln == 0) wsum[wv] = heads;
+    __syncthreads();
+    uint32_t run = 0, runs = 0;
+    for (uint32_t w = 0; w < 16u; ++w) {
+        const uint32_t c = wsum[w];
+        run += w < wv ? c : 0u;
+        runs += c;
+    }
+    for (uint32_t i0 = lo; i0 < hi; i0 += 64u) {
+        const uint32_t i = i0 + ln;
+        const uint32_t key = i < hi ? lkey[i] : 0u;
+        const bool head = i < hi && (i == 0u || key != lkey[i - 1u]);
+        const unsigned long long m = __ballot(head);
+        if (head) {
+            const uint32_t r = run + (uint32_t)__popcll(m & ((1ull << ln) - 1ull));
+            seg_rows[r] = key;
+            seg_offsets[r] = i;
+            s_start[r] = (uint16_t)i;
+        }
+        run += (uint32_t)__popcll(m);
+    }
+    if (tid == 0) {
+        *n_segs = runs;
+        *hot_counter = 0;
+    }
+    __syncthreads();  // every run start is in LDS; wsum is read
+    // blocks per row and their exclusive scan, g in [0, n) (rows past the last run: no blocks), chunked the same way
+    uint32_t blocks = 0;
+    for (uint32_t g0 = lo; g0 < hi; g0 += 64u) {
+        const uint32_t g = g0 + ln;
+        const uint32_t cnt = g < hi && g < runs ? (g + 1u < runs ? (uint32_t)s_start[g + 1u] : n) - (uint32_t)s_start[g] : 0u;
+        uint32_t nb = (cnt + RP_SPARSE_BLOCK - 1u) / RP_SPARSE_BLOCK;
+        for (int d = 32; d > 0; d >>= 1) nb += (uint32_t)__shfl_xor((int)nb, d, 64);
+        blocks += nb;
+    }
+    __syncthreads();  // (wsum's first use is over)
+    if (ln == 0) wsum[wv] = blocks;
+    __syncthreads();
+    uint32_t brun = 0;
+    for (uint32_t w = 0; w < wv; ++w) brun += wsum[w];
+    for (uint32_t g0 = lo; g0 < hi; g0 += 64u) {
+        const uint32_t g = g0 + ln;
+        const bool in = g < hi;
+        const uint32_t cnt = in && g < runs ? (g + 1u < runs ? (uint32_t)s_start[g + 1u] : n) - (uint32_t)s_start[g] : 0u;
+        const uint32_t nb = (cnt + RP_SPARSE_BLOCK - 1u) / RP_SPARSE_BLOCK;
+        uint32_t incl = nb;
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (ln >= d) incl += up;
+        }
+        const uint32_t at = brun + incl - nb;
+        if (in) {
+            if (g < runs) seg_counts[g] = cnt;
+            nblk[g] = nb;
+            boff[g] = at;
+            for (uint32_t b = 0; b < nb; ++b) blkseg[at + b] = g;
+        }
+        brun += (uint32_t)__shfl((int)incl, 63, 64);
+    }
 }
 
 template <bool GATHER, bool APPLY>  // GATHER: the touches are read from the unsorted batch through sg.perm (no sorted copy exists);
@@ -749,6 +834,7 @@ struct rp_profile {
     unsigned char* blocks = nullptr;   // block records of multi-block rows
     uint32_t* blkseg = nullptr;        // [max blocks] row index of every block
     uint32_t* hot = nullptr;           // [HOT_CAP + 1] rows with more than RP_FOLD_GROUP blocks; last slot = counter
+    bool no_prep_one = false;          // RP_SPARSE_NO_PREP_ONE=1 (tests, A/B): small batches through the tiled sort as well
     float *srt_regret = nullptr, *srt_policy = nullptr, *srt_payoff = nullptr;  // the batch in sorted order (ordered mode)
     uint16_t* srt_expanded = nullptr;
     void* sort_tmp = nullptr;
@@ -904,12 +990,13 @@ static uint32_t group_blocks(uint32_t n) { return std::max(1u, std::min((n * GRO
 
 // segments (already built for this batch) -> entries[g] for g < n_segs
 static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch& b, const Segments& sg, uint32_t n,
-                            unsigned char* entries, bool apply_local = false) {
+                            unsigned char* entries, bool apply_local = false, bool prepped = false /* k_prep_one has built the block index */) {
     const uint32_t eb = (uint32_t)entry_bytes_of(h);
     const uint32_t mb = max_blocks_of(n);
     void* scan_tmp = reinterpret_cast<unsigned char*>(h->sort_tmp) + ss::sort_scratch_bytes(h->cap);
     const uint32_t tiles = (n + ss::SCAN_TILE - 1u) / ss::SCAN_TILE;
-    if (n <= ss::SCAN_ONE) {
+    if (prepped) {
+    } else if (n <= ss::SCAN_ONE) {
         hipLaunchKernelGGL(k_blk_one, dim3(1), dim3(ss::ONE_THREADS), 0, h->stream, h->seg_offsets, h->n_segs, n, h->seg_counts, h->nblk, h->boff, h->blkseg,
                            h->hot + HOT_CAP);
     } else if (tiles <= ss::SCAN_ONE) {
@@ -981,6 +1068,7 @@ int rp_profile_create(int device, uint64_t n_rows, uint32_t max_actions, rp_regr
     PF_TRY(hipMalloc(&h->tab, (size_t)n_rows * 4u * max_actions * 4u));
     PF_TRY(hipMalloc(&h->n_segs, 4));
     PF_TRY(hipMalloc(&h->hot, (HOT_CAP + 1) * 4));
+    h->no_prep_one = getenv("RP_SPARSE_NO_PREP_ONE") != nullptr;
     float* d_def = nullptr;
     std::vector<float> def(max_actions, 0.0f);
     if (default_regret) def.assign(default_regret, default_regret + max_actions);
@@ -1027,8 +1115,16 @@ int rp_profile_apply(rp_profile* h, const rp_decisions* batch, rp_update_mode mo
     if (mode == RP_UPDATE_COMPOSED && (rc = composed_params(h, p))) return rc;
     if (batch->n) {
         const DevBatch b{batch->row, batch->n_actions, batch->expanded, batch->regret, batch->policy, batch->payoff};
+        // a small batch (the reference's 128 trees): sort, run lengths and block index by one workgroup in one launch (k_prep_one)
+        const bool one = mode == RP_UPDATE_COMPOSED && batch->n <= ss::SORT_ONE && key_bits(h->n_rows) <= 27u && !h->no_prep_one;
         sp_begin(h, h->clk_sort);
-        if ((rc = sort_and_segment(h, batch->row, batch->n, mode == RP_UPDATE_COMPOSED))) return rc;
+        if (one) {
+            if ((rc = ensure_capacity(h, batch->n))) return rc;
+            hipLaunchKernelGGL(k_prep_one, dim3(1), dim3(1024), 0, h->stream, batch->row, batch->n, key_bits(h->n_rows), h->keys_out, h->perm,
+                               h->seg_rows, h->seg_offsets, h->seg_counts, h->n_segs, h->nblk, h->boff, h->blkseg, h->hot + HOT_CAP);
+        } else if ((rc = sort_and_segment(h, batch->row, batch->n, mode == RP_UPDATE_COMPOSED))) {
+            return rc;
+        }
         sp_end(h, h->clk_sort);
         const Segments sg{h->seg_rows, h->seg_counts, h->seg_offsets, h->n_segs, h->perm};
         sp_begin(h, h->clk_apply);
@@ -1048,7 +1144,7 @@ int rp_profile_apply(rp_profile* h, const rp_decisions* batch, rp_update_mode mo
         } else {
             // a single rank's entries have distinct rows and are applied where they are produced (k_fold's arithmetic, apply_cell):
             // no k_fold launch (measured round 4: apply 0.118 -> 0.113 ms at 2^17 Decisions, profiles/r04_optin_ab.json)
-            if ((rc = launch_summarize(h, p, b, sg, batch->n, h->entries, true))) return rc;
+            if ((rc = launch_summarize(h, p, b, sg, batch->n, h->entries, true, one))) return rc;
         }
         sp_end(h, h->clk_apply);
         HIP_TRY(hipGetLastError());

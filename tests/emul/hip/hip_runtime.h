@@ -115,6 +115,23 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int dev);
 hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b);
 }
+// pinned, mapped host memory: plain host memory here (the "device" reads host addresses); a launch has run when it returns
+#define hipHostMallocMapped 2u
+#define hipHostMallocCoherent 0x40000000u
+#define hipErrorNotReady 600
+static inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
+    *p = calloc(1, bytes);
+    return *p ? hipSuccess : (hipError_t)2;
+}
+static inline hipError_t hipHostFree(void* p) {
+    free(p);
+    return hipSuccess;
+}
+static inline hipError_t hipHostGetDevicePointer(void** dp, void* hp, unsigned) {
+    *dp = hp;
+    return hipSuccess;
+}
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 template <class T>
 static inline hipError_t hipMalloc(T** p, size_t bytes) {
     return emu_hipMalloc(reinterpret_cast<void**>(p), bytes);
@@ -217,6 +234,7 @@ static inline u32x2_t buf_load64(rsrc r, int voff, int soff) {
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define __threadfence() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define __threadfence_block() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define __threadfence_system() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) ::emu::mfma(EMU_SITE, (a), (b), (c))
 #define __builtin_amdgcn_mbcnt_lo(mask, v) ((uint32_t)(v) + (uint32_t)__builtin_popcount((uint32_t)(mask) & (::emu::lane() >= 32u ? 0xffffffffu : ((1u << ::emu::lane()) - 1u))))
 #define __builtin_amdgcn_mbcnt_hi(mask, v) ((uint32_t)(v) + (uint32_t)__builtin_popcount((uint32_t)(mask) & (::emu::lane() <= 32u ? 0u : ((1u << (::emu::lane() - 32u)) - 1u))))

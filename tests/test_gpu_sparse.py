@@ -76,6 +76,24 @@ def test_batches_just_past_one_scan_tile_set_bit_exact(gpu, n_rows, A, n):
     same(g.rows(rows), o.rows(rows))
 
 
+@pytest.mark.parametrize("n_rows,A", [(1 << 19, 2), (300, 9), (1 << 10, 9)])
+def test_small_batches_prepared_by_one_workgroup_bit_exact(gpu, n_rows, A):
+    # at most ss::SORT_ONE = 16 384 Decisions (the reference's 128 trees emit ~10^4): sort, run lengths and block index in one launch of
+    # one workgroup (k_prep_one): one / two / three radix passes (9, 10 and 19 key bits), the sizes around its round and chunk edges,
+    # and the first size that goes back to the tiled sort
+    g = SparseProfile(n_rows, A, "linear", "linear")
+    o = oracle.OracleProfile(n_rows, A, "linear", "linear")
+    seen = []
+    for e, n in enumerate([1, 63, 64, 65, 1023, 1024, 1025, 9000, 16383, 16384, 16385]):
+        batch = synthetic_batch(n, n_rows, A, seed=900 + e)
+        g.apply(DeviceBatch(*batch), "composed")
+        o.fold(o.summarize(batch))
+        seen.append(batch[0])
+    g.sync()
+    rows = np.unique(np.concatenate(seen))
+    same(g.rows(rows), o.rows(rows))
+
+
 def test_hot_rows_fold_their_block_groups_in_parallel_bit_exact(gpu):
     # 40 rows, 60 000 touches: the popular rows collect > RP_FOLD_GROUP * RP_SPARSE_BLOCK touches (k_hot_fold)
     n_rows, A = 40, 9
