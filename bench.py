@@ -996,7 +996,8 @@ def nlhe_real(args, rank, world, local_rank):
 
     big = run(args.nlhe_batch, args.steps, args.warmup, profile=True)
     # RP_BENCH_NO_REF=1 (profiling runs: scripts/r3_nlhe_traffic.sh): every dispatch of the process belongs to the big batch
-    ref = run(128, max(args.steps, 20), 3) if not os.environ.get("RP_BENCH_NO_REF") else {"infos": 0, "dt": 1.0}
+    ref_steps = max(args.steps, 100)  # 0.36 ms a step: a hundred of them, behind ten that fill the table's first infosets
+    ref = run(128, ref_steps, 10) if not os.environ.get("RP_BENCH_NO_REF") else {"infos": 0, "dt": 1.0}
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -1013,11 +1014,12 @@ def nlhe_real(args, rank, world, local_rank):
         "trees_per_s": trees / big["dt"], "nodes_per_s": big["nodes"] / big["dt"],
         "nodes_per_tree": big["nodes"] / trees, "infos_per_tree": big["infos"] / trees,
         "reference_batch_128": {"value": ref["infos"] / ref["dt"], "unit": "infoset-updates/s",
-                                "ms_per_step": ref["dt"] / max(args.steps, 20) * 1e3,
-                                "note": "nlhe/src/solver.rs:11 batch_size = 128: one tree per workgroup, the traversal in one launch "
-                                        "(k_nl_tree, ~0.4 ms: twenty tree levels of dependent work per step, values in the reference's "
-                                        "own order = bit-exact Decisions) + the sparse table update's dozen launches; latency bound by "
-                                        "construction — a step depends on the previous one"},
+                                "ms_per_step": ref["dt"] / ref_steps * 1e3, "steps": ref_steps, "warmup": 10,
+                                "note": "nlhe/src/solver.rs:11 batch_size = 128: one tree per workgroup of 512, the traversal in one launch "
+                                        "(k_nl_tree, ~0.29 ms = the slowest tree: ~13 us per tree level of dependent, lane-serial work; "
+                                        "values in the reference's own order = bit-exact Decisions); its last workgroup posts the "
+                                        "Decisions count to pinned host memory; four more launches (emit, k_prep_one, block maps, fold); "
+                                        "latency bound by construction — a step depends on the previous one (DESIGN 3c, round 6)"},
     }
     line["config"]["sampling"] = args.sampling
     if not sharded and not os.environ.get("RP_BENCH_NO_REF"):

@@ -107,7 +107,7 @@ struct rp_nlhe {
     NlPost* post_dev = nullptr;  // the same words as the device addresses them
     uint32_t post_seq = 0;
     bool ctl_clean = false;      // the control block is zero (k_nl_finish cleared it; the batch-wide path leaves it dirty)
-    uint32_t tree_bt = 512;  // k_nl_tree's workgroup (RP_NL_TREE_BT = 256 / 512 / 1024 for the experiment; measured round 6: 0.483 / 0.428 / 0.443 ms per step)
+    uint32_t tree_bt = 512;  // k_nl_tree's workgroup (RP_NL_TREE_BT = 256 / 1024: the experiment; measured round 6: 256 / 512 / 1024 = 0.483 / 0.428 / 0.443 ms per step)
     bool tree_mode_off = false;  // a tree outgrew its region once: the handle stays on the batch-wide path
     uint32_t* ex_k_parked = nullptr;  // rp_nlhe_set_exact(h, 0) on a large-batch handle: lv.ex_k while the exact evaluation is off
     uint32_t chunks = 1;  // passes per batch (RP_NLHE_CHUNKS; doubled when a pass runs out of nodes)
@@ -231,8 +231,8 @@ int nl_traverse_chunk(rp_nlhe* h, uint32_t lo, uint32_t B, uint32_t d_base, uint
         // three launches and an interrupt round trip per step)
         h->post_seq += 1;
         if (h->post_seq == 0) h->post_seq = 1;
-        if (h->tree_bt == 1024u) hipLaunchKernelGGL(k_nl_tree<1024>, dim3(B), dim3(1024), 0, st, prm, h->tab, lv, h->tree_cap, WC, h->d_total, h->post_dev, h->post_seq);
-        else if (h->tree_bt == 256u) hipLaunchKernelGGL(k_nl_tree<256>, dim3(B), blk, 0, st, prm, h->tab, lv, h->tree_cap, WC, h->d_total, h->post_dev, h->post_seq);
+        if (h->tree_bt == 256u) hipLaunchKernelGGL(k_nl_tree<256>, dim3(B), blk, 0, st, prm, h->tab, lv, h->tree_cap, WC, h->d_total, h->post_dev, h->post_seq);
+        else if (h->tree_bt == 1024u) hipLaunchKernelGGL(k_nl_tree<1024>, dim3(B), dim3(1024), 0, st, prm, h->tab, lv, h->tree_cap, WC, h->d_total, h->post_dev, h->post_seq);
         else hipLaunchKernelGGL(k_nl_tree<512>, dim3(B), dim3(512), 0, st, prm, h->tab, lv, h->tree_cap, WC, h->d_total, h->post_dev, h->post_seq);
         nl_clock_end(h, 0);
         nl_clock_begin(h, 3);

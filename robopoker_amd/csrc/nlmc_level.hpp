@@ -1101,7 +1101,11 @@ __device__ __forceinline__ void nl_tree_exit(const NlNodes& nd, uint32_t B, uint
     }
 }
 #define NL_TREE_CC 1024u  // children of chance nodes in one level of one tree (observed: a few dozen); more raise NERR_NODES like a full region
-template <uint32_t BT>    // threads of the workgroup: one workgroup per CU at this batch, so a wide one costs nothing and shortens wide levels
+// BT: threads of the workgroup (one workgroup per CU at this batch, so a wide one costs nothing and shortens wide levels).
+// (Measured and not kept, round 6: a variant with the sampling scheme, the draw and the legality check as compile-time constants —
+// 14 008 -> 11 025 instructions, 137 -> 117 registers — is 2 % SLOWER in an A/B on one box: the level loop is not bound by the
+// instruction cache.)
+template <uint32_t BT>
 __global__ __launch_bounds__(BT) void k_nl_tree(NlParams p, NlTable t, NlNodes nd, uint32_t C, uint32_t WC, uint32_t* total_out, NlPost* post,
                                                 uint32_t seq) {
     constexpr uint32_t NW = BT / 64u;
@@ -1198,13 +1202,16 @@ __global__ __launch_bounds__(BT) void k_nl_tree(NlParams p, NlTable t, NlNodes n
         {
             const uint32_t tb = (ncc + 63u) >> 6, ta = (chi - hi + 63u) >> 6;
             for (uint32_t wt = wave; wt < 3u * tb + ta; wt += NW) {
+                uint32_t c = NL_LINK_NONE, part = NL_CHILD_PLAIN;  // (one call site: the function is a third of the kernel's code)
                 if (wt < 3u * tb) {
-                    const uint32_t part = wt / tb, j = (wt - part * tb) * 64u + lane;  // 0 / 1: the seats, 2: the rest
-                    if (j < ncc) err |= nl_make_child(p, nd, s_cc[j], (int)p.walker, part == 2u ? (uint32_t)NL_CHILD_DEAL : (uint32_t)NL_CHILD_SEAT0 + part);
+                    const uint32_t q = wt / tb, j = (wt - q * tb) * 64u + lane;  // 0 / 1: the seats, 2: the rest
+                    if (j < ncc) c = s_cc[j];
+                    part = q == 2u ? (uint32_t)NL_CHILD_DEAL : (uint32_t)NL_CHILD_SEAT0 + q;
                 } else {
-                    const uint32_t c = hi + (wt - 3u * tb) * 64u + lane;
-                    if (c < chi) err |= nl_make_child(p, nd, c, (int)p.walker, NL_CHILD_PLAIN);
+                    const uint32_t cc = hi + (wt - 3u * tb) * 64u + lane;
+                    if (cc < chi) c = cc;
                 }
+                if (c != NL_LINK_NONE) err |= nl_make_child(p, nd, c, (int)p.walker, part);
             }
         }
         if (err) atomicOr(&s_err, err);

@@ -1018,7 +1018,12 @@ static int launch_summarize(rp_profile* h, const SparseParams& p, const DevBatch
     if (apply_local) RP_MAPS(true, true);  // the block maps read the touches through the sort permutation
     else RP_MAPS(true, false);
 #undef RP_MAPS
-    if (apply_local) {
+    if (apply_local && prepped) {
+        // a small batch: every row with several blocks folds in k_seg_fold (a hot-row capacity of 0: its own serial two-level fold, the
+        // same grouping as k_hot_fold's) — at most 16 384 touches, and one launch less
+        hipLaunchKernelGGL(k_seg_fold<true>, dim3(group_blocks(n)), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb,
+                           h->hot, h->hot + HOT_CAP, 0u);
+    } else if (apply_local) {
         hipLaunchKernelGGL(k_seg_fold<true>, dim3(group_blocks(n)), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb,
                            h->hot, h->hot + HOT_CAP, (uint32_t)HOT_CAP);
         hipLaunchKernelGGL(k_hot_fold<true>, dim3(64), dim3(256), 0, h->stream, p, sg, h->nblk, h->boff, entries, h->blocks, eb, h->hot,

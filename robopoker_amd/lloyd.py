@@ -653,11 +653,16 @@ def bench_full(which: str = "flop", iters: int = 32, n_points: int | None = None
         mb_ms, mb_n = ms["mfma_bound"]
         if st["enabled"] and mb_ms > 0:
             tf = st["mfma_instructions"] * 2048 / (mb_ms * 1e-3) / 1e12
+            # useful = the share of the issued column slots that held a column still iterating (16 slots per wavefront iteration)
+            live = st.get("column_iterations", 0) / max(16 * st.get("block_iterations", 0), 1)
             out["roofline_mfma"] = {"bound": "mfma", "kernel": "k_sinkhorn_bound", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
                                     "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
+                                    "live_slot_frac": live, "achieved_useful": tf * live, "frac_useful": tf * live / MFMA_F32_PEAK_TFLOPS,
+                                    "cost_pass_share": st.get("cost_passes", 0) / max(2 * st.get("block_iterations", 0) + st.get("cost_passes", 0), 1),
                                     "survivors_per_point": st["survivors"] / max(st["points"], 1),
                                     "note": "scaling-domain Sinkhorn bound in front of init_bounds and lookup; flops = MFMA "
-                                            "instructions issued x 2048"}
+                                            "instructions issued x 2048; *_useful counts the column slots that held a live column; "
+                                            "cost_pass_share = the K.*C contractions' share of the issued MFMAs"}
         out["_centroids"] = layer.centroids()[0]  # for the CPU baseline's pairwise sample; callers pop it before printing
     layer.close()
     return out

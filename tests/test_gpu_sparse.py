@@ -76,7 +76,7 @@ def test_batches_just_past_one_scan_tile_set_bit_exact(gpu, n_rows, A, n):
     same(g.rows(rows), o.rows(rows))
 
 
-@pytest.mark.parametrize("n_rows,A", [(1 << 19, 2), (300, 9), (1 << 10, 9)])
+@pytest.mark.parametrize("n_rows,A", [(1 << 19, 2), (300, 9), (1 << 10, 9), (3, 9)])  # 3 rows: more than 64 x 64 touches of one row, folded in k_seg_fold
 def test_small_batches_prepared_by_one_workgroup_bit_exact(gpu, n_rows, A):
     # at most ss::SORT_ONE = 16 384 Decisions (the reference's 128 trees emit ~10^4): sort, run lengths and block index in one launch of
     # one workgroup (k_prep_one): one / two / three radix passes (9, 10 and 19 key bits), the sizes around its round and chunk edges,
