@@ -520,7 +520,9 @@ RP_API int rp_kmeans_set_libm(rp_kmeans* h, rp_libm_kind kind);
  * WHAT THE FILTERED PASSES GUARANTEE — read before relying on "bit-exact buckets" through them.  The four filters (k-means++ column
  * bound and interval filter, the MFMA bound of init_bounds / lookup, the interval-decided refresh of the Elkan iterations) replace a
  * bit-faithful solve by a scaling-domain INTERVAL that must contain the value the reference would compute.  The column bound is
- * rigorous.  The intervals are not proven: their margins (SbParams: kappa, rho, dc_abs 4e-6, dc_rel 4e-5) are a multiple of the worst
+ * rigorous, and so is the rule by which the MFMA bound skips cost evaluations inside a stopping window (round 6: a Lipschitz bound of
+ * <P, C> in the coupling's L1 travel, exact arithmetic, applied only to columns that cannot be the argmin either way).  The intervals
+ * themselves are not proven: their margins (SbParams: kappa, rho, dc_abs 4e-6, dc_rel 4e-5) are a multiple of the worst
  * float noise MEASURED between the scaling-domain and the log-domain iteration, and the smallest slack observed on a sampled pair was
  * 0.88 of the margin (profiles/r05_glibc_audit.json), i.e. a safety factor of about 8 over the worst observed case, on synthetic
  * points.  The evidence that they hold: full-size audits in both arithmetics with 0 of 1 286 792 points differing from the unpruned

@@ -434,6 +434,7 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         h->sb.dc_abs = std::max(envf("RP_SB_DC_ABS", 4e-6f), 4e-6f);
         h->sb.dc_rel = std::max(envf("RP_SB_DC_REL", 4e-5f), 4e-5f);
         h->sb.flat = std::min(envf("RP_SB_FLAT", 4.0f), 4.0f);
+        h->sb.lip = getenv("RP_SB_LIP") ? atoi(getenv("RP_SB_LIP")) : 1;
         {
             float cmax = 0.0f;
             for (size_t t = 0; t < (size_t)bins * (bins - 1) / 2; ++t) cmax = std::max(cmax, tri_metric[t]);
@@ -660,15 +661,21 @@ int launch_bound(rp_kmeans* h, float* dbg_lo, float* dbg_hi, const float* ub0 = 
         if (!n) continue;
         const uint32_t per_cu = t <= 1 ? 2u : 1u;  // workgroups a CU holds (LDS: SbLds<NT>; registers: 8 wavefronts of up to 256)
         const dim3 grid(std::min<uint32_t>(n, (uint32_t)cus * per_cu)), block(t <= 1 ? 256u : 512u);
-#define SB_LAUNCH(NT)                                                                                                      \
-    hipLaunchKernelGGL(k_sinkhorn_bound<NT>, grid, block, 0, h->stream, h->P, cs, h->K, h->bins, h->sb, h->sb_list[t], n, \
-                       h->sb_cursor + t, h->sb_mask, dbg_lo, dbg_hi, h->sb_stats, ub0,                                   \
+#define SB_LAUNCH1(NT, LIP)                                                                                                        \
+    hipLaunchKernelGGL((k_sinkhorn_bound<NT, LIP>), grid, block, 0, h->stream, h->P, cs, h->K, h->bins, h->sb, h->sb_list[t], n, \
+                       h->sb_cursor + t, h->sb_mask, dbg_lo, dbg_hi, h->sb_stats, ub0,                                           \
                        (const uint8_t*)(h->sb_crank_set ? h->sb_crank : nullptr))
+#define SB_LAUNCH(NT)                   \
+    do {                                \
+        if (h->sb.lip) SB_LAUNCH1(NT, true); \
+        else SB_LAUNCH1(NT, false);     \
+    } while (0)
         if (t == 0) SB_LAUNCH(1);
         else if (t == 1) SB_LAUNCH(2);
         else if (t == 2) SB_LAUNCH(3);
         else SB_LAUNCH(4);
 #undef SB_LAUNCH
+#undef SB_LAUNCH1
     }
     if (h->sb_nbig) hipLaunchKernelGGL(k_mask_all, dim3((h->sb_nbig + 255) / 256), dim3(256), 0, h->stream, h->sb_big, h->sb_nbig, h->sb_mask);
     ck_end(h, CK_BOUND);

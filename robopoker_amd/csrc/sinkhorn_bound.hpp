@@ -28,6 +28,14 @@
 //      measured worst case) and takes the cost range over EVERY iteration at which the reference could stop:
 //         window = [ first t with err_t - N_t < tol * rho ,  first t with (err_t + N_t) * rho < tol ]   (or the cap, or
 //      the iteration at which the scaling iterate itself stops moving).  lo/hi = min/max of the cost over the window -/+ dc.
+//  (3) Window iterates without an evaluation (round 6, prm.lip).  One iteration moves the coupling P = diag(u) K diag(v) by
+//      dlt_t = sum_x (K v)_x |u'_x - u_x| + sum_y (K^T u')_y |v'_y - v_y| in L1 (the lhs update, then the rhs update; both sums
+//      ride on the iteration: (K v)_x and (K^T u')_y are its contractions), so |cost_t - cost_s| <= max C * sum_{s < tau <= t} dlt_tau
+//      — exact arithmetic, no measured constant; max C over the point's rows.  A column keeps its last evaluated cost and that
+//      sum; a window iterate whose divergence would exceed a published upper bound even at the lower end of the range enters the
+//      window as the range instead of an evaluation.  Such a column cannot be the argmin whatever the exact value; every other
+//      window iterate is evaluated as before.  On the flop layer 75 % of the wavefront iterations carried a cost contraction
+//      before, 4 % do now.
 //  A too-large N_t, rho or dc only widens intervals (more survivors, never a wrong answer).  RP_LLOYD_AUDIT=1 runs the
 //  unpruned pass next to the pruned one and counts disagreements (rp_kmeans_prune_stats); the GPU tests do that.
 //
@@ -58,6 +66,7 @@ struct SbParams {
     float dc_rel;
     float flat;    // the scaling iterate counts as stationary when err <= flat * 2^-23 * (sum u + sum v), twice in a row
     int use_lb0;   // the column-marginal bound is valid for this metric / temperature (max C / T <= 64): sort and drop by it
+    int lip;       // 1: the cost of a window iterate is taken from the last evaluated one and a Lipschitz bound when that is enough (see k_sinkhorn_bound)
 };
 
 // LDS per workgroup, sized by the point's support class: NT = 1 / 2 leave room for three / two workgroups per CU (46 / 78 KB of 160),
@@ -74,6 +83,7 @@ struct __attribute__((aligned(16))) SbLds {
     float lb0[256];   // per centroid: the column-marginal lower bound of the divergence (0 when not in use)
     uint32_t perm[256];  // column slot -> centroid, ascending lb0
     uint32_t ub;      // bits of the smallest upper bound published so far (non-negative floats order as integers)
+    uint32_t kmin;    // bits of the smallest K of the point's rows: max C over the point's couplings = neg_t_ln2 * log2(kmin)
     uint32_t sup[SB_MAXROWS];
     uint32_t np;
     uint32_t item;
@@ -104,17 +114,19 @@ __device__ __forceinline__ float sb_max4(float x) {
 // wavefronts per SIMD the LDS round trip is otherwise exposed twice per tile.  The K V chain of a tile is split over two
 // accumulators (its eight MFMAs depend on each other otherwise).  COST: the K .* C contraction of the cost (sb_cost) rides on
 // the second contraction's operands — the same K tile, the same fresh U — and returns the cost of the iterate this call produces.
-template <int NT, bool COST>
+// LIP: also returns dlt = sum_x |mu_x - u_x (K v)_x| + sum_y |nu_y - v_y (K^T u')_y| with the OLD u, v: the L1 distance the coupling
+// P = diag(u) K diag(v) moves in this iteration (first by the lhs update, then by the rhs update), so |cost' - cost| <= max C * dlt.
+template <int NT, bool COST, bool LIP>
 __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], const float* __restrict__ drow, const SbLds<NT>& L, uint32_t c,
                                            uint32_t g, float& err, float& sumu, float& umax, float& sumv, float& vmax, float neg_t_ln2,
-                                           float& cost) {
+                                           float& cost, float& dlt) {
     f32x4 racc[NT], w[NT];
 #pragma unroll
     for (int yt = 0; yt < NT; ++yt) {
         racc[yt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         w[yt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
-    float eu = 0.0f, su = 0.0f, mu_ = 0.0f;
+    float eu = 0.0f, su = 0.0f, mu_ = 0.0f, dl = 0.0f;
     constexpr int SB_KT = SbLds<NT>::KT;
     const float* kt = &L.ksubT[c * SB_KT + 4 * g];
     const float* ks = &L.ksub[c * SB_KS + 4 * g];
@@ -162,8 +174,11 @@ __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], cons
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float u0 = mcur[r] * sb_rcp(fmaxf(s0[r] + s1[r], 1e-37f));
-            eu += fabsf(u0 - uo[xt][r]);
+            const float sx = fmaxf(s0[r] + s1[r], 1e-37f);
+            const float u0 = mcur[r] * sb_rcp(sx);
+            const float du = fabsf(u0 - uo[xt][r]);
+            if (LIP) dl += sx * du;  // |mu_x - u_x (K v)_x| = (K v)_x |u'_x - u_x|   (u' (K v) = mu up to the reciprocal's rounding)
+            eu += du;
             su += u0;
             mu_ = fmaxf(mu_, u0);
             uo[xt][r] = u0;
@@ -192,8 +207,11 @@ __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], cons
         const f32x4 bq = *reinterpret_cast<const f32x4*>(&L.b[yt * 16 + 4 * g]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float vn = bq[r] * sb_rcp(fmaxf(racc[yt][r], 1e-37f));
-            ev += fabsf(vn - v[yt][r]);
+            const float ry = fmaxf(racc[yt][r], 1e-37f);
+            const float vn = bq[r] * sb_rcp(ry);
+            const float dv = fabsf(vn - v[yt][r]);
+            if (LIP) dl += ry * dv;
+            ev += dv;
             sv += vn;
             mv = fmaxf(mv, vn);
             v[yt][r] = vn;
@@ -206,6 +224,7 @@ __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], cons
     umax = sb_max4(mu_);
     vmax = sb_max4(mv);
     cost = COST ? sb_sum4(part) : 0.0f;
+    dlt = LIP ? sb_sum4(dl) : 0.0f;
 }
 
 // cost of the current iterate: sum_y v_y sum_x K[y][x] C[y][x] u_x, with C recovered from K (C = -T ln K)
@@ -239,6 +258,8 @@ __device__ __forceinline__ float sb_cost(const f32x4 (&uo)[16], const f32x4 (&v)
 
 struct SbCol {  // per-column window state (replicated in the four lanes of the column)
     float wmin, wmax, nb_prev;
+    float cref, acc;  // the last evaluated cost of this column and max C * the coupling's L1 travel since (prm.lip): cost in [cref - acc, cref + acc]
+    bool hasref;
     int flatc;
     bool opened, done;
     bool complete;  // the stopping window was followed to its end (not dropped)
@@ -257,7 +278,7 @@ struct SbCol {  // per-column window state (replicated in the four lanes of the 
 // wavefronts of highest priority changes it — DESIGN 4d).
 // NT <= 2: four wavefronts per point and two points per CU (2 x 78 KB of LDS): one point's gather / drain is covered by the other's
 // iterations.  NT >= 3 (110 / 146 KB): eight wavefronts, one point.
-template <int NT>
+template <int NT, bool LIP>  // LIP = prm.lip, at compile time (one pair of inlined iterations in the loop, not two: registers)
 __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Points P, CentroidSet cs, uint32_t K, uint32_t bins, SbParams prm,
                                                                    const uint32_t* list, uint32_t count, unsigned int* cursor,
                                                                    unsigned long long* mask_out, float* dbg_lo, float* dbg_hi,
@@ -274,6 +295,7 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
         if (tid == 0) {
             L.item = atomicAdd(cursor, 1u);
             L.next = 0;
+            L.kmin = 0x3f800000u;
         }
         __syncthreads();
         const uint32_t item = L.item;
@@ -311,11 +333,17 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
             L.b[tid] = 0.0f;
         }
         __syncthreads();
+        float kmin = 1.0f;
         for (uint32_t e = tid; e < NT * 16 * 256; e += THREADS) {
             const uint32_t y = e >> 8, x = e & 255u;
             const float k = prm.Kmat[L.sup[y] * 256u + x];
             L.ksub[y * SB_KS + x] = k;
             L.ksubT[x * SB_KT + y] = k;
+            kmin = fminf(kmin, k);
+        }
+        if (LIP) {  // (K in [0, 1]: non-negative floats order as their bits)
+            for (int o = 32; o > 0; o >>= 1) kmin = fminf(kmin, __shfl_xor(kmin, o, 64));
+            if (lane == 0) atomicMin(&L.kmin, __float_as_uint(kmin));
         }
         const float sp = P.self[i];
         if (tid < 256) {
@@ -417,8 +445,16 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
                     st.opened = false;
                     st.done = false;
                     st.complete = false;
+                    st.cref = 0.0f;
+                    st.acc = 0.0f;
+                    st.hasref = false;
                 }
             };
+            // max C over the point's rows (an over-estimate of the column's own: every x, not only supp mu_j), a hair above the rounding of
+            // the approximate log2; K = 0 (C / T beyond the float range) makes it infinite: every window iterate is evaluated, as without prm.lip
+            const float cmaxp = LIP ? (prm.neg_t_ln2 * __builtin_amdgcn_logf(__uint_as_float(L.kmin))) * 1.0001f : 0.0f;
+            // the divergence's lower end for a cost w (sinkhorn.rs:166-171 and the cost margin, as at the end of a column)
+            auto lo_of = [&](float w) { return rp_maxf((w - (prm.dc_abs + prm.dc_rel * fabsf(w))) - 0.5f * sc - 0.5f * sp, 0.0f); };
 #pragma unroll
             for (int xt = 0; xt < 16; ++xt) uo[xt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -431,9 +467,22 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
                 float err, sumu, umax, sumv, vmax, fused = 0.0f;
                 // once a column of the wavefront is inside its stopping window every further iterate's cost is wanted: the cost contraction
                 // then rides on the iteration itself; the first iterate of a window (not known in advance) takes the separate pass below
-                const bool with_cost = __ballot(live && st.opened) != 0;
-                if (with_cost) sb_iterate<NT, true>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused);
-                else sb_iterate<NT, false>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused);
+                // prm.lip: a column whose cost is known to lie in [cref - acc, cref + acc] and whose divergence is above a published upper
+                // bound even at cref - acc needs no evaluation for this iterate — it cannot be the argmin whatever the exact value, and
+                // its interval stays an interval (only wider).  The far columns, whose windows are the long ones, are of that kind;
+                // acc grows by max C * dlt per iteration until the test fails and the next evaluation resets it.
+                float dlt = 0.0f;
+                const float ubn = __uint_as_float(*(volatile uint32_t*)&L.ub);
+                bool near = !(LIP && st.hasref && lo_of(st.cref - st.acc) > ubn);
+                // (LIP: evaluations are rare — 2 % of the iterations on the flop layer — and always take the separate pass: the fused
+                // form's accumulators are what the register allocation of the whole loop is sized by)
+                const bool with_cost = !LIP && __ballot(live && st.opened && near) != 0;
+                if (with_cost) sb_iterate<NT, true, LIP>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused, dlt);
+                else sb_iterate<NT, false, LIP>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused, dlt);
+                if (LIP) {
+                    st.acc += cmaxp * dlt;
+                    near = !(st.hasref && lo_of(st.cref - st.acc) > ubn);
+                }
                 my_cb_iters += 1;
                 const float ln2 = 0.6931472f;
                 const float lu = fmaxf(__builtin_amdgcn_logf(umax) * ln2, 0.0f), lv = fmaxf(__builtin_amdgcn_logf(vmax) * ln2, 0.0f);
@@ -444,15 +493,25 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
                 const bool certain = last || ((err + noise) * prm.rho < prm.tol);
                 const bool flat = err <= prm.flat * SB_EPS23 * (sumu + sumv);
                 const bool want = live && (possible || flat);
-                if (__ballot(want)) {  // wave uniform: one more contraction with K .* C for the cost of this iterate
-                    const float cost = with_cost ? fused : sb_cost<NT>(uo, v, L, c, g, prm.neg_t_ln2);
+                if (with_cost || __ballot(want && near)) {  // wave uniform: the cost of this iterate, for all sixteen columns at once
+                    const float cost = with_cost ? fused : sb_cost<NT>(uo, v, L, c, g, prm.neg_t_ln2);  // (one more contraction with K .* C)
                     my_cost_passes += 1;
+                    if (live) {  // every live column takes the evaluation as its new reference
+                        st.cref = cost;
+                        st.acc = 0.0f;
+                        st.hasref = true;
+                    }
                     if (want) {
                         // a non-finite cost (under/overflow of the scaling form) poisons the window: the column survives
                         st.wmin = cost == cost ? fminf(st.wmin, cost) : -__builtin_inff();
                         st.wmax = cost == cost ? fmaxf(st.wmax, cost) : __builtin_inff();
                         st.opened = true;
                     }
+                } else if (want) {  // (prm.lip, a far column) the iterate's cost by its bounds; not a number: poisoned, as above
+                    const float wl = st.cref - st.acc, wh = st.cref + st.acc;
+                    st.wmin = wl == wl ? fminf(st.wmin, wl) : -__builtin_inff();
+                    st.wmax = wh == wh ? fmaxf(st.wmax, wh) : __builtin_inff();
+                    st.opened = true;
                 }
                 st.flatc = flat ? st.flatc + 1 : 0;
                 if (live) {

@@ -497,7 +497,10 @@ def test_mfma_bound_intervals_contain_the_oracle(gpu, monkeypatch, N, K, bins, m
     finite = np.isfinite(hi)
     assert finite.mean() > (0.2 if drop else 0.99)
     assert np.all(finite[np.arange(N), exact.argmin(axis=1)])  # the nearest centroid is always followed to the end
-    assert np.median((hi - lo)[finite]) < 2e-4  # typical width: the margin, not the stopping window
+    # typical width of the intervals that matter — the centroids within four times the smallest upper bound —: the margin, not the
+    # stopping window (a far column's window iterates may be taken from a Lipschitz bound: wider by design, round 6)
+    close = finite & (lo <= 4.0 * hi.min(axis=1, keepdims=True))
+    assert np.median((hi - lo)[close]) < 2e-4
     survivors = (lo <= hi.min(axis=1, keepdims=True)).sum(axis=1)
     assert survivors.mean() < 3.0, survivors
     # the pruned passes themselves: identical buckets and distances
