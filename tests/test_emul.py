@@ -20,7 +20,8 @@ SELECTION = [
     ("tests/test_gpu_mccfr.py", "(test_tables_bit_exact_vs_oracle and (kuhn or rps)) or (composed_mode_matches_oracle_world_semantics and 777)"
                                 " or test_static_skeleton_traversal_equals_generic_and_oracle or test_hyper_parameter_corners_bit_exact"),
     # the sparse profile: own radix sort / scan / run lengths, ordered and composed application
-    ("tests/test_gpu_sparse.py", "test_ordered_apply_bit_exact or test_composed_apply or (test_batches_just_past_one_scan_tile_set_bit_exact and 66000)"),
+    ("tests/test_gpu_sparse.py", "test_ordered_apply_bit_exact or test_composed_apply or (test_batches_just_past_one_scan_tile_set_bit_exact and 66000)"
+                                 " or test_small_batches_prepared_by_one_workgroup_bit_exact"),  # round 6: k_prep_one
     # NLHE traversal: level-synchronous expansion against the oracle, pruned schemes, ragged batches, the chunked retry
     ("tests/test_gpu_nlmc.py", "(test_first_batch_equals_the_oracle and 64) or test_pruned_sampling_schemes_equal_the_oracle"
                                " or test_ragged_batches_equal_the_oracle or test_a_batch_traversed_in_several_passes"
