@@ -434,7 +434,7 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         h->sb.dc_abs = std::max(envf("RP_SB_DC_ABS", 4e-6f), 4e-6f);
         h->sb.dc_rel = std::max(envf("RP_SB_DC_REL", 4e-5f), 4e-5f);
         h->sb.flat = std::min(envf("RP_SB_FLAT", 4.0f), 4.0f);
-        h->sb.lip = getenv("RP_SB_LIP") ? atoi(getenv("RP_SB_LIP")) : 1;
+        h->sb.lip = getenv("RP_SB_LIP") ? atoi(getenv("RP_SB_LIP")) : 2;
         {
             float cmax = 0.0f;
             for (size_t t = 0; t < (size_t)bins * (bins - 1) / 2; ++t) cmax = std::max(cmax, tri_metric[t]);
@@ -667,8 +667,9 @@ int launch_bound(rp_kmeans* h, float* dbg_lo, float* dbg_hi, const float* ub0 = 
                        (const uint8_t*)(h->sb_crank_set ? h->sb_crank : nullptr))
 #define SB_LAUNCH(NT)                   \
     do {                                \
-        if (h->sb.lip) SB_LAUNCH1(NT, true); \
-        else SB_LAUNCH1(NT, false);     \
+        if (h->sb.lip >= 2) SB_LAUNCH1(NT, 2); \
+        else if (h->sb.lip) SB_LAUNCH1(NT, 1); \
+        else SB_LAUNCH1(NT, 0);         \
     } while (0)
         if (t == 0) SB_LAUNCH(1);
         else if (t == 1) SB_LAUNCH(2);

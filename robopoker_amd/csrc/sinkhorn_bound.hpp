@@ -54,6 +54,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SB_MAXROWS 64   // a point with more support bins than this is not pruned (all its centroids go to the exact kernel)
 #define SB_EPS23 1.1920929e-7f
 #define SB_MU_AHEAD 4
+#define SB_DUAL_SLACK 1e-3f  // log2 units (x T ln 2 = 1.7e-5 of cost at T = 0.025)
 
 struct SbParams {
     const float* Kmat;  // [256][256] exp(-C/T); 1.0 outside the bins x bins block
@@ -66,7 +67,8 @@ struct SbParams {
     float dc_rel;
     float flat;    // the scaling iterate counts as stationary when err <= flat * 2^-23 * (sum u + sum v), twice in a row
     int use_lb0;   // the column-marginal bound is valid for this metric / temperature (max C / T <= 64): sort and drop by it
-    int lip;       // 1: the cost of a window iterate is taken from the last evaluated one and a Lipschitz bound when that is enough (see k_sinkhorn_bound)
+    int lip;       // >= 1: the cost of a window iterate is taken from the last evaluated one and a Lipschitz bound when that is enough;
+                   // 2 (the default): and a column leaves as soon as a Kantorovich dual bound puts it above a published upper bound (see k_sinkhorn_bound)
 };
 
 // LDS per workgroup, sized by the point's support class: NT = 1 / 2 leave room for three / two workgroups per CU (46 / 78 KB of 160),
@@ -116,17 +118,21 @@ __device__ __forceinline__ float sb_max4(float x) {
 // the second contraction's operands — the same K tile, the same fresh U — and returns the cost of the iterate this call produces.
 // LIP: also returns dlt = sum_x |mu_x - u_x (K v)_x| + sum_y |nu_y - v_y (K^T u')_y| with the OLD u, v: the L1 distance the coupling
 // P = diag(u) K diag(v) moves in this iteration (first by the lhs update, then by the rhs update), so |cost' - cost| <= max C * dlt.
-template <int NT, bool COST, bool LIP>
+// LIP == 2 (the dual exit, see k_sinkhorn_bound): also eprev = the first of the two sums = the L1 error of the row marginals of the
+// coupling this call STARTS from, and dual = the value of the Kantorovich pair  f(x) = T ln u'_x,  g(y) = -T ln (K^T u')_y  of the
+// iterate this call PRODUCES (feasible for the unregularised problem: u'_x K_xy is one term of (K^T u')_y), with ln u' taken from the
+// float's bits — (bits - bits(1)) 2^-23 <= log2: a lower bound, which f may be — and (K^T u')_y from the second contraction.
+template <int NT, bool COST, int LIP>
 __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], const float* __restrict__ drow, const SbLds<NT>& L, uint32_t c,
                                            uint32_t g, float& err, float& sumu, float& umax, float& sumv, float& vmax, float neg_t_ln2,
-                                           float& cost, float& dlt) {
+                                           float& cost, float& dlt, float& eprev, float& dual) {
     f32x4 racc[NT], w[NT];
 #pragma unroll
     for (int yt = 0; yt < NT; ++yt) {
         racc[yt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         w[yt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
-    float eu = 0.0f, su = 0.0f, mu_ = 0.0f, dl = 0.0f;
+    float eu = 0.0f, su = 0.0f, mu_ = 0.0f, dl = 0.0f, dlx = 0.0f, fd = 0.0f;
     constexpr int SB_KT = SbLds<NT>::KT;
     const float* kt = &L.ksubT[c * SB_KT + 4 * g];
     const float* ks = &L.ksub[c * SB_KS + 4 * g];
@@ -177,12 +183,16 @@ __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], cons
             const float sx = fmaxf(s0[r] + s1[r], 1e-37f);
             const float u0 = mcur[r] * sb_rcp(sx);
             const float du = fabsf(u0 - uo[xt][r]);
-            if (LIP) dl += sx * du;  // |mu_x - u_x (K v)_x| = (K v)_x |u'_x - u_x|   (u' (K v) = mu up to the reciprocal's rounding)
+            if (LIP) dlx += sx * du;  // |mu_x - u_x (K v)_x| = (K v)_x |u'_x - u_x|   (u' (K v) = mu up to the reciprocal's rounding)
+            if (LIP == 2) fd = fmaf(mcur[r], (float)((int)__float_as_uint(u0) - 0x3f800000), fd);  // mu_x * 2^23 * (a lower bound of log2 u'_x)
             eu += du;
             su += u0;
             mu_ = fmaxf(mu_, u0);
             uo[xt][r] = u0;
         }
+        // the tile's statistics are due HERE: left to itself the compiler sinks them behind the last tile, where they need the old u, the new
+        // u, (K v) and mu of all sixteen tiles at once (256 registers) and spills inside the loop
+        asm volatile("" : "+v"(eu), "+v"(su), "+v"(mu_), "+v"(dlx), "+v"(fd));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -201,7 +211,7 @@ __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], cons
             }
         }
     }
-    float ev = 0.0f, sv = 0.0f, mv = 0.0f, part = 0.0f;
+    float ev = 0.0f, sv = 0.0f, mv = 0.0f, part = 0.0f, gd = 0.0f;
 #pragma unroll
     for (int yt = 0; yt < NT; ++yt) {
         const f32x4 bq = *reinterpret_cast<const f32x4*>(&L.b[yt * 16 + 4 * g]);
@@ -211,6 +221,7 @@ __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], cons
             const float vn = bq[r] * sb_rcp(ry);
             const float dv = fabsf(vn - v[yt][r]);
             if (LIP) dl += ry * dv;
+            if (LIP == 2) gd = fmaf(bq[r], __builtin_amdgcn_logf(ry), gd);  // nu_y log2 (K^T u')_y  (padding rows: 0 * finite)
             ev += dv;
             sv += vn;
             mv = fmaxf(mv, vn);
@@ -224,7 +235,11 @@ __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], cons
     umax = sb_max4(mu_);
     vmax = sb_max4(mv);
     cost = COST ? sb_sum4(part) : 0.0f;
-    dlt = LIP ? sb_sum4(dl) : 0.0f;
+    dlt = LIP ? sb_sum4(dl + dlx) : 0.0f;
+    eprev = LIP == 2 ? sb_sum4(dlx) : 0.0f;
+    // T ln 2 * (sum_x mu_x log2 u'_x - sum_y nu_y log2 (K^T u')_y), less SB_DUAL_SLACK for the roundings of (K^T u')_y (an MFMA
+    // chain: <= 256 * 2^-24 relative = 2.2e-5 in log2), of v_log_f32 and of the two sums (<= 1e-4 in log2 at |log2| <= 40)
+    dual = LIP == 2 ? (-neg_t_ln2) * ((sb_sum4(fd) * 1.1920929e-7f - sb_sum4(gd)) - SB_DUAL_SLACK) : 0.0f;
 }
 
 // cost of the current iterate: sum_y v_y sum_x K[y][x] C[y][x] u_x, with C recovered from K (C = -T ln K)
@@ -278,7 +293,7 @@ struct SbCol {  // per-column window state (replicated in the four lanes of the 
 // wavefronts of highest priority changes it — DESIGN 4d).
 // NT <= 2: four wavefronts per point and two points per CU (2 x 78 KB of LDS): one point's gather / drain is covered by the other's
 // iterations.  NT >= 3 (110 / 146 KB): eight wavefronts, one point.
-template <int NT, bool LIP>  // LIP = prm.lip, at compile time (one pair of inlined iterations in the loop, not two: registers)
+template <int NT, int LIP>  // LIP = prm.lip, at compile time (one pair of inlined iterations in the loop, not two: registers)
 __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Points P, CentroidSet cs, uint32_t K, uint32_t bins, SbParams prm,
                                                                    const uint32_t* list, uint32_t count, unsigned int* cursor,
                                                                    unsigned long long* mask_out, float* dbg_lo, float* dbg_hi,
@@ -477,8 +492,9 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
                 // (LIP: evaluations are rare — 2 % of the iterations on the flop layer — and always take the separate pass: the fused
                 // form's accumulators are what the register allocation of the whole loop is sized by)
                 const bool with_cost = !LIP && __ballot(live && st.opened && near) != 0;
-                if (with_cost) sb_iterate<NT, true, LIP>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused, dlt);
-                else sb_iterate<NT, false, LIP>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused, dlt);
+                float eprev = 0.0f, dual = 0.0f;
+                if (with_cost) sb_iterate<NT, true, LIP>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused, dlt, eprev, dual);
+                else sb_iterate<NT, false, LIP>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused, dlt, eprev, dual);
                 if (LIP) {
                     st.acc += cmaxp * dlt;
                     near = !(st.hasref && lo_of(st.cref - st.acc) > ubn);
@@ -514,6 +530,21 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
                     st.opened = true;
                 }
                 st.flatc = flat ? st.flatc + 1 : 0;
+                if (LIP == 2 && prm.use_lb0 && live && tcol >= 1) {  // (RP_SB_NO_LB0 follows every column to the end of its window)
+                    // The dual exit (round 6).  Weak duality: the pair (f, g) of sb_iterate bounds the UNREGULARISED optimum OT_0(mu, nu)
+                    // from below whatever the iterate is.  After every rhs update the coupling's column marginals are nu exactly and its
+                    // row marginals a_s are within e_s of mu in L1, so cost_s = <P_s, C> >= OT_0(a_s, nu) >= OT_0(mu, nu) - max C e_s / 2;
+                    // and e_s does not grow with s (each half step pushes both marginals through one stochastic kernel), so with eprev =
+                    // e of the iterate this iteration started from:  cost_s >= dual - max C eprev / 2  for THIS iterate and every later one
+                    // (tcol >= 1: the start's coupling has had its rhs update).  The iterates at which the reference could have stopped
+                    // earlier are the window's (wmin).  A column whose divergence at that lower end exceeds a published upper bound
+                    // cannot be the argmin at any stopping time: its rigorous bound dlb0 is raised and the test below drops it.
+                    // (1 % and 5e-5 on eprev: its own rounding, and the f32 iterates against the real-number trajectory's.)
+                    const float lbc = dual - 0.5f * cmaxp * (1.01f * eprev + 5e-5f);
+                    const float cmin = st.opened ? fminf(st.wmin, lbc) : lbc;
+                    const float lbd = lo_of(cmin);
+                    if (lbd > dlb0) dlb0 = lbd;  // (not a number: no change)
+                }
                 if (live) {
                     tcol += 1;
                     if (g == 0) my_col_iters += 1;
@@ -559,7 +590,9 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
         }
         __syncthreads();
         if (tid < 256) {
-            const float ub = fminf(fminf(L.red[0], L.red[1]), fminf(L.red[2], L.red[3]));
+            // (L.ub: the published upper bounds and ub0, the exact distance to SOME centroid — a column dropped on the way keeps a lower
+            // bound that was above L.ub then, not necessarily above the smallest dhi)
+            const float ub = fminf(fminf(fminf(L.red[0], L.red[1]), fminf(L.red[2], L.red[3])), __uint_as_float(L.ub));
             const bool keep = tid < K && !(L.dlo[tid] > ub);
             const unsigned long long m = __ballot(keep);
             if (lane == 0) {
