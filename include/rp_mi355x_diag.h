@@ -60,6 +60,10 @@ RP_API int rp_kmeans_bound_intervals(rp_kmeans* h, float* lo, float* hi);
  * centroid-first call, elkan.rs:68-77) for every point, each stopping window followed to its end; 0 where the pair does not fit the
  * register tile (either support above 48 bins) or no bound was obtained.  Tests compare it with the bit-faithful distances. */
 RP_API int rp_kmeans_kpp_bound_probe(rp_kmeans* h, uint32_t k, float* lo);
+/* the same filter as production runs it against ONE potential for every point (potential >= 0: a pair leaves as soon as its bound squared
+ * reaches it — the window's bound or, from the second iteration on, the Kantorovich dual bound of csrc/kpp_bound.hpp); lo[i] = the
+ * lower bound the pair left with, 0 where it was kept for the bit-faithful solve.  potential < 0: rp_kmeans_kpp_bound_probe. */
+RP_API int rp_kmeans_kpp_bound_probe_at(rp_kmeans* h, uint32_t k, float potential, float* lo);
 /* The interval-decided refresh of the Elkan iterations (csrc/refresh_bound.hpp; rp_kmeans_set_prune(h, 0) switches it off with the other
  * filters).  out8: [0] refreshes examined by the interval kernel, [1] settled by it (no bit-faithful solve), [2] scaling-domain
  * iterations, [3] cost evaluations inside the stopping windows, [4] exactify solves (an interval of the previous step replaced by its

@@ -237,6 +237,7 @@ _SIGNATURES = {
     "rp_kmeans_prune_stats": (C.c_int, [C.c_void_p, C.POINTER(PruneStats)]),
     "rp_kmeans_bound_intervals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rp_kmeans_kpp_bound_probe": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rp_kmeans_kpp_bound_probe_at": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]),
     "rp_kmeans_refresh_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rp_kmeans_upper_interval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rp_kmeans_pairwise_last": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -18,6 +18,13 @@
 // round iff lo^2 >= potential (the solve could not lower it); as soon as an iterate inside the window falls below the potential the
 // pair is kept without finishing the window.  The noise bound is the MFMA kernel's with (sum u + sum v)(max(ln u_max, ln v_max) + 4)
 // in place of the two separate products: never smaller, so windows only widen.
+//
+// THE DUAL EXIT (round 6, prm.lip >= 2; sinkhorn_bound.hpp has the argument).  93 % of the pairs that reach this kernel end with
+// lo^2 >= potential, after following their window to its end (58 iterations on average).  From the second iteration on, the pair
+// f = T ln u', g = -T ln (K^T u') of the iterate just produced is feasible for the unregularised problem and the row marginals' L1 error
+// e of the iterate the iteration started from does not grow, so every iterate from here on costs at least  <mu, f> + <nu, g> - max C e / 2;
+// the iterates the reference could have stopped at before are the window's.  A pair whose divergence at that lower end already reaches
+// the potential leaves at once.  One more all-reduction and two logarithms per iteration.
 #pragma once
 
 #define KB_WAVES_PER_CU 8u
@@ -139,7 +146,7 @@ template <uint32_t ROWS, uint32_t R>
 __global__ __launch_bounds__(64) void k_kpp_bound(Points P, CentroidSet cs, uint32_t k, uint32_t bins, const float* Cm, SbParams prm,
                                                   const float* pot, const uint32_t* in_list, const unsigned int* in_count,
                                                   unsigned int* cursor, uint32_t* out_list, unsigned int* out_count,
-                                                  unsigned long long* kstats, float* dbg_lo) {
+                                                  unsigned long long* kstats, float* dbg_lo, int dual) {
     constexpr uint32_t G = 64u / ROWS;
     static_assert(R <= ROWS && R % 8 == 0, "register tile");
     __shared__ KbLds<ROWS> L;
@@ -207,6 +214,7 @@ __global__ __launch_bounds__(64) void k_kpp_bound(Points P, CentroidSet cs, uint
         const float nur = (fits && r < n) ? L.nuP[g][r] : 0.0f;
         // ---- K sub-matrix of the pair in registers: row r (centroid bin x_r against the point's bins) with K.C beside it, column r
         float Ku[R], KC[R], Kv[R];
+        float cmx = 0.0f;  // max C over the pair's supports (the dual exit)
 #pragma unroll
         for (uint32_t j = 0; j < R; ++j) {
             const bool ok = fits && r < m && j < n;
@@ -215,7 +223,9 @@ __global__ __launch_bounds__(64) void k_kpp_bound(Points P, CentroidSet cs, uint
             const float cc = ok ? Cm[xr * bins + y] : 0.0f;
             Ku[j] = kk;
             KC[j] = kk * cc;
+            cmx = fmaxf(cmx, cc);
         }
+        if (dual) cmx = kb_allmax<ROWS>(cmx) * 1.0001f;
 #pragma unroll
         for (uint32_t i = 0; i < R; ++i) {
             const bool ok = fits && i < m && r < n;
@@ -233,6 +243,8 @@ __global__ __launch_bounds__(64) void k_kpp_bound(Points P, CentroidSet cs, uint
         bool opened = false, complete = false, keep = false;
         bool done = !fits;
         if (n > 0 && !fits) keep = true;
+        bool dropped = false;  // left by the dual exit: dlq is its lower bound of the divergence
+        float dlq = 0.0f;
         __syncthreads();
         for (uint32_t t = 0; t < prm.iters; ++t) {
             if (__ballot(!done) == 0) break;
@@ -241,6 +253,10 @@ __global__ __launch_bounds__(64) void k_kpp_bound(Points P, CentroidSet cs, uint
             const float su = kb_dot<R>(Ku, L.vb[g], nlim);
             const float un = mur * sb_rcp(fmaxf(su, 1e-37f));
             float e = fabsf(un - u);
+            // this lane's share of  T ln 2 (mu_x log2 u'_x - nu_y log2 (K^T u')_y) - max C / 2 * 1.01 |mu_x - u_x (K v)_x|   (old u: the row
+            // marginal of the coupling the iteration starts from; log2 u' from the float's bits, a lower bound: sinkhorn_bound.hpp)
+            float dq = 0.0f;
+            if (dual) dq = (-prm.neg_t_ln2) * (mur * ((float)((int)__float_as_uint(un) - 0x3f800000) * 1.1920929e-7f)) - 0.505f * cmx * fabsf(mur - u * su);
             u = un;
             L.ub[g][r] = u;
             __syncthreads();
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(64) void k_kpp_bound(Points P, CentroidSet cs, uint
             e += fabsf(vn - v);
             v = vn;
             L.vb[g][r] = v;
+            if (dual) dq -= (-prm.neg_t_ln2) * (nur * __builtin_amdgcn_logf(fmaxf(sv, 1e-37f)));
             __syncthreads();
             const float err = kb_allsum<ROWS>(e);
             const float suv = kb_allsum<ROWS>(u + v);
@@ -284,9 +301,22 @@ __global__ __launch_bounds__(64) void k_kpp_bound(Points P, CentroidSet cs, uint
                 done = true;
                 complete = true;
             }
+            if (dual && t >= 1) {  // (t >= 1: the coupling the iteration started from has had its rhs update; wave uniform: the reduction)
+                const float lbc = kb_allsum<ROWS>(dq) - ((-prm.neg_t_ln2) * SB_DUAL_SLACK + 0.5f * cmx * 5e-5f);
+                const float cmin = opened ? fminf(wmin, lbc) : lbc;
+                const float cl = cmin - (prm.dc_abs + prm.dc_rel * fabsf(cmin));
+                const float dd = rp_maxf(cl - 0.5f * sc - 0.5f * sp, 0.0f);
+                if (!done && dd * dd >= potv) {  // every iterate the reference could stop at is at or above the potential (not a number: no)
+                    done = true;
+                    dropped = true;
+                    dlq = dd;
+                }
+            }
         }
         float dl = 0.0f;
-        if (fits && !keep) {
+        if (dropped) {
+            dl = dlq;
+        } else if (fits && !keep) {
             if (opened && complete) {
                 const float cl = wmin - (prm.dc_abs + prm.dc_rel * fabsf(wmin));
                 dl = (cl == cl && cl > -__builtin_inff()) ? rp_maxf(cl - 0.5f * sc - 0.5f * sp, 0.0f) : 0.0f;

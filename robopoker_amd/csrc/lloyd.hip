@@ -1028,11 +1028,11 @@ int rp_kmeans_kpp_update(rp_kmeans* h, uint32_t k) {
                     if (two)
                         hipLaunchKernelGGL((k_kpp_bound<32, 32>), dim3(grid), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
                                            (const float*)h->pot, (const uint32_t*)h->kpp.list[c], (const unsigned int*)(h->kpp.count + c),
-                                           h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr);
+                                           h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr, h->sb.lip >= 2 ? 1 : 0);
                     else
                         hipLaunchKernelGGL((k_kpp_bound<64, 48>), dim3(grid), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
                                            (const float*)h->pot, (const uint32_t*)h->kpp.list[c], (const unsigned int*)(h->kpp.count + c),
-                                           h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr);
+                                           h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr, h->sb.lip >= 2 ? 1 : 0);
                 }
                 todo = &h->kpp2;
                 ck_end(h, CK_KPP_BOUND);
@@ -1480,8 +1480,11 @@ static int prune_stats_full(rp_kmeans* h, rp_prune_stats* out) {
 
 // diagnostics (rp_mi355x_diag.h): the second k-means++ filter's lower bound of distance(centroid k, point i) for EVERY point,
 // against an infinite potential (no early exit); 0 where the pair is outside the register tile or its window did not close
-int rp_kmeans_kpp_bound_probe(rp_kmeans* h, uint32_t k, float* lo) {
-    if (!h || !lo || k >= h->K) return rp::fail(RP_ERR_INVALID, "rp_kmeans_kpp_bound_probe: bad argument");
+int rp_kmeans_kpp_bound_probe(rp_kmeans* h, uint32_t k, float* lo) { return rp_kmeans_kpp_bound_probe_at(h, k, -1.0f, lo); }
+// potential < 0: every stopping window is followed to its end (lo^2 >= potential always holds for the window's bound and the dual exit is
+// off); potential >= 0: the production rule against that potential for every point, dual exit included
+int rp_kmeans_kpp_bound_probe_at(rp_kmeans* h, uint32_t k, float potential, float* lo) {
+    if (!h || !lo || k >= h->K || !(potential == potential)) return rp::fail(RP_ERR_INVALID, "rp_kmeans_kpp_bound_probe: bad argument");
     if (!h->kb_on) return rp::fail(RP_ERR_UNSUPPORTED, "rp_kmeans_kpp_bound_probe: the layer has no k-means++ interval filter");
     HIP_TRY(hipSetDevice(h->device));
     // one scratch allocation (diagnostics: freed on every path): lo[N], pot[N], list in[N + 4], list out[N + 4], ctl[4], and the
@@ -1503,10 +1506,10 @@ int rp_kmeans_kpp_bound_probe(rp_kmeans* h, uint32_t k, float* lo) {
     if (e == hipSuccess) e = hipMemsetAsync(d_lo, 0, N * 4, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_stats, 0, stat_words * 4, h->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, h->stream, d_pot, h->N, -1.0f);  // lo^2 >= -1 always: every window runs to its end
+        hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, h->stream, d_pot, h->N, potential < 0.0f ? -1.0f : potential);  // lo^2 >= -1 always: every window runs to its end
         hipLaunchKernelGGL((k_kpp_bound<64, 48>), dim3(2048), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
                            (const float*)d_pot, (const uint32_t*)d_list, (const unsigned int*)d_ctl, d_ctl + 1, d_list + N + 4, d_ctl + 2,
-                           d_stats, d_lo);
+                           d_stats, d_lo, (potential >= 0.0f && h->sb.lip >= 2) ? 1 : 0);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(lo, d_lo, N * 4, hipMemcpyDeviceToHost, h->stream);

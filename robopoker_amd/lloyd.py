@@ -201,10 +201,14 @@ class Layer:
         _lib.check(self._lib.rp_kmeans_upper_interval(self._h, _p(ulo), _p(uiv)))
         return ulo, uiv
 
-    def kpp_bound_probe(self, k: int) -> np.ndarray:
-        """lo[N]: the second k-means++ filter's lower bound of distance(centroid k, point i) (rp_mi355x_diag.h)"""
+    def kpp_bound_probe(self, k: int, potential: float | None = None) -> np.ndarray:
+        """lo[N]: the second k-means++ filter's lower bound of distance(centroid k, point i) (rp_mi355x_diag.h); with a potential: the
+        production rule against it (dual exit included), 0 where the pair was kept for the solve"""
         lo = np.zeros(self.N, dtype=np.float32)
-        _lib.check(self._lib.rp_kmeans_kpp_bound_probe(self._h, C.c_uint32(k), _p(lo)))
+        if potential is None:
+            _lib.check(self._lib.rp_kmeans_kpp_bound_probe(self._h, C.c_uint32(k), _p(lo)))
+        else:
+            _lib.check(self._lib.rp_kmeans_kpp_bound_probe_at(self._h, C.c_uint32(k), C.c_float(potential), _p(lo)))
         return lo
 
     # ---- multi-GPU exchange (SURVEY §8e) --------------------------------------------------------

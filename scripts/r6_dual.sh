@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/r6dual
 mkdir -p $OUT
 cd $REPO
 export RP_FIXTURE_CACHE=/tmp
-timeout 900 python -m pytest tests/test_gpu_lloyd.py tests/test_gpu_z_glibc_mode.py tests/test_golden.py -m gpu -q -x -p no:cacheprovider --timeout 300 -k "mfma or pruned or k256 or set_prune or layer_shape or kmeans_golden" 2>&1 | tail -6
+timeout 900 python -m pytest tests/test_gpu_lloyd.py tests/test_gpu_z_glibc_mode.py tests/test_golden.py -m gpu -q -x -p no:cacheprovider --timeout 300 -k "${DUAL_K:-mfma or pruned or k256 or set_prune or layer_shape or kmeans_golden or kmeanspp or kpp}" 2>&1 | tail -6
 for LIP in ${DUAL_LIPS:-1 2}; do
 RP_SB_LIP=$LIP RP_FULL_LIBM=glibc RP_FULL_RNG=reference timeout 300 python scripts/full_kmeans.py flop 32 > $OUT/${TAG}_full_flop_lip$LIP.json 2> $OUT/full$LIP.err
 python - <<PY

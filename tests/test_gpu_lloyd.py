@@ -535,6 +535,17 @@ def test_kmeanspp_interval_filter_lower_bounds_hold(gpu, N, K, bins, mass, iters
         got = lo > 0
         tight.append(np.mean((exact[got] - lo[got]) <= 1e-4 + 1e-3 * exact[got]) if got.any() else 0.0)
         assert got.mean() > 0.5  # a bound for most pairs (0 = no bound: outside the tile, or a window that did not close)
+        # the production rule against one potential (round 6: a pair may leave by the Kantorovich dual bound before its window closes):
+        # whatever a pair leaves with is a lower bound of the exact distance and reaches the potential; most pairs beyond it do leave
+        for q in (0.1, 0.5):
+            pd = float(np.quantile(exact, q))
+            lo2 = dev.kpp_bound_probe(k, potential=pd * pd)
+            left = lo2 > 0
+            bad2 = np.flatnonzero(lo2 > exact)
+            assert bad2.size == 0, f"centroid {k}, potential {pd}^2: {[(lo2[i], exact[i]) for i in bad2[:3]]}"
+            assert np.all(lo2[left].astype(np.float32) ** 2 >= np.float32(pd * pd) * np.float32(0.999999))
+            beyond = exact > 1.5 * pd + 1e-3
+            assert beyond.sum() == 0 or left[beyond].mean() > 0.8, (k, q, left[beyond].mean())
     assert np.mean(tight) > 0.8, tight
 
 
