@@ -139,6 +139,26 @@ __device__ __forceinline__ float kb_dot(const float (&a)[R], const float* vec, u
     return s0 + s1;
 }
 
+// the same sum and, beside it, max_j a[j] * vec[j] (the dual exit's c-transform: -T ln of it is the largest g(y) that keeps f + g <= C)
+template <uint32_t R>
+__device__ __forceinline__ float kb_dot_max(const float (&a)[R], const float* vec, uint32_t lim, float& mx) {
+    float s0 = 0.0f, s1 = 0.0f, m0 = 0.0f, m1 = 0.0f;
+#pragma unroll
+    for (uint32_t j = 0; j < R; j += 4) {
+        if (j < lim) {
+            const float4 q = *reinterpret_cast<const float4*>(vec + j);
+            s0 = __builtin_fmaf(a[j], q.x, s0);
+            s1 = __builtin_fmaf(a[j + 1], q.y, s1);
+            s0 = __builtin_fmaf(a[j + 2], q.z, s0);
+            s1 = __builtin_fmaf(a[j + 3], q.w, s1);
+            m0 = fmaxf(m0, fmaxf(a[j] * q.x, a[j + 2] * q.z));
+            m1 = fmaxf(m1, fmaxf(a[j + 1] * q.y, a[j + 3] * q.w));
+        }
+    }
+    mx = fmaxf(m0, m1);
+    return s0 + s1;
+}
+
 // kstats (striped like Metric::stats): [0] pairs examined, [1] pairs kept, [2] pair-iterations, [3] cost passes
 // in_list / in_count: the round's candidates of one support class (k_kpp_filter); out_list / out_count: the ones the solve is still
 // needed for.  dbg_lo (tests): the lower bound of the divergence per point, 0 where the pair was kept without one.
@@ -261,12 +281,14 @@ __global__ __launch_bounds__(64) void k_kpp_bound(Points P, CentroidSet cs, uint
             L.ub[g][r] = u;
             __syncthreads();
             // rhs: v <- nu ./ (K^T u), on the fresh u (Gauss-Seidel, sinkhorn.rs:80-87)
-            const float sv = kb_dot<R>(Kv, L.ub[g], mlim);
+            float mxv = 0.0f;
+            const float sv = dual ? kb_dot_max<R>(Kv, L.ub[g], mlim, mxv) : kb_dot<R>(Kv, L.ub[g], mlim);
             const float vn = nur * sb_rcp(fmaxf(sv, 1e-37f));
             e += fabsf(vn - v);
             v = vn;
             L.vb[g][r] = v;
-            if (dual) dq -= (-prm.neg_t_ln2) * (nur * __builtin_amdgcn_logf(fmaxf(sv, 1e-37f)));
+            // g(y) = -T ln max_x K_xy u'_x (the c-transform of f; dual == 1: -T ln (K^T u')_y, the looser pair that needs no maximum)
+            if (dual) dq -= (-prm.neg_t_ln2) * (nur * __builtin_amdgcn_logf(fmaxf(dual >= 2 ? mxv : sv, 1e-37f)));
             __syncthreads();
             const float err = kb_allsum<ROWS>(e);
             const float suv = kb_allsum<ROWS>(u + v);

@@ -134,6 +134,7 @@ struct rp_kmeans {
     uint64_t kpp_cap[3] = {0, 0, 0};  // points per support class (<= QUAD_ROWS, <= PAIR_ROWS, more): grid bounds
     // the second k-means++ filter (kpp_bound.hpp): a scaling-domain interval per (new centroid, point) pair the column bound let through
     bool kb_on = false;
+    int kb_dual = 2;  // the dual exit's pair: 2 = (f, its c-transform), 1 = (f, -T ln K^T u) (RP_KPP_DUAL; measurements)
     KppLists kpp2{};                        // the pairs the solve is still needed for, per support class
     unsigned int* kb_cursor = nullptr;      // [3] work cursors of the three launches of a round
     unsigned long long* kb_stats = nullptr; // striped: pairs examined, kept, pair-iterations, cost passes
@@ -485,6 +486,7 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
             KM_TRY(dev_alloc(h, &h->kb_stats, (size_t)KM_STAT_STRIPES * STAT_STRIDE));
             KM_HIP(hipMemset(h->kb_stats, 0, (size_t)KM_STAT_STRIPES * STAT_STRIDE * 8));
             h->kb_on = true;
+            if (getenv("RP_KPP_DUAL")) h->kb_dual = std::max(1, std::min(2, atoi(getenv("RP_KPP_DUAL"))));
         }
     }
     h->ns_host = ns;
@@ -1028,11 +1030,11 @@ int rp_kmeans_kpp_update(rp_kmeans* h, uint32_t k) {
                     if (two)
                         hipLaunchKernelGGL((k_kpp_bound<32, 32>), dim3(grid), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
                                            (const float*)h->pot, (const uint32_t*)h->kpp.list[c], (const unsigned int*)(h->kpp.count + c),
-                                           h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr, h->sb.lip >= 2 ? 1 : 0);
+                                           h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr, h->sb.lip >= 2 ? h->kb_dual : 0);
                     else
                         hipLaunchKernelGGL((k_kpp_bound<64, 48>), dim3(grid), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
                                            (const float*)h->pot, (const uint32_t*)h->kpp.list[c], (const unsigned int*)(h->kpp.count + c),
-                                           h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr, h->sb.lip >= 2 ? 1 : 0);
+                                           h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr, h->sb.lip >= 2 ? h->kb_dual : 0);
                 }
                 todo = &h->kpp2;
                 ck_end(h, CK_KPP_BOUND);
@@ -1509,7 +1511,7 @@ int rp_kmeans_kpp_bound_probe_at(rp_kmeans* h, uint32_t k, float potential, floa
         hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, h->stream, d_pot, h->N, potential < 0.0f ? -1.0f : potential);  // lo^2 >= -1 always: every window runs to its end
         hipLaunchKernelGGL((k_kpp_bound<64, 48>), dim3(2048), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
                            (const float*)d_pot, (const uint32_t*)d_list, (const unsigned int*)d_ctl, d_ctl + 1, d_list + N + 4, d_ctl + 2,
-                           d_stats, d_lo, (potential >= 0.0f && h->sb.lip >= 2) ? 1 : 0);
+                           d_stats, d_lo, (potential >= 0.0f && h->sb.lip >= 2) ? h->kb_dual : 0);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(lo, d_lo, N * 4, hipMemcpyDeviceToHost, h->stream);
