@@ -661,8 +661,8 @@ int launch_bound(rp_kmeans* h, float* dbg_lo, float* dbg_hi, const float* ub0 = 
     for (int t = 3; t >= 0; --t) {  // the longest-running class first
         const uint32_t n = h->sb_count[t];
         if (!n) continue;
-        const uint32_t per_cu = t <= 1 ? 2u : 1u;  // workgroups a CU holds (LDS: SbLds<NT>; registers: 8 wavefronts of up to 256)
-        const dim3 grid(std::min<uint32_t>(n, (uint32_t)cus * per_cu)), block(t <= 1 ? 256u : 512u);
+        const uint32_t per_cu = t <= 1 ? 4u : 2u;  // workgroups (= points) a CU holds (LDS: SbLds<NT>; registers: 8 wavefronts of up to 256)
+        const dim3 grid(std::min<uint32_t>(n, (uint32_t)cus * per_cu)), block(t <= 1 ? 128u : 256u);
 #define SB_LAUNCH1(NT, LIP)                                                                                                        \
     hipLaunchKernelGGL((k_sinkhorn_bound<NT, LIP>), grid, block, 0, h->stream, h->P, cs, h->K, h->bins, h->sb, h->sb_list[t], n, \
                        h->sb_cursor + t, h->sb_mask, dbg_lo, dbg_hi, h->sb_stats, ub0,                                           \

@@ -49,8 +49,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define SB_THREADS 512
-#define SB_KS 264       // ksub  row stride in floats: 264 mod 64 = 8  -> the 16 lanes of a ds_read_b128 group hit 64 banks once
+#define SB_KS 260       // ksub row stride in floats: 260 mod 64 = 4 -> the 16 lanes of a ds_read_b128 group (address c KS + 4 g) hit 64 banks
+                        // once, and so do the 64 lanes of a ds_read_b32 at (4 g) KS + c (4 KS mod 64 = 16)
 #define SB_MAXROWS 64   // a point with more support bins than this is not pruned (all its centroids go to the exact kernel)
 #define SB_EPS23 1.1920929e-7f
 #define SB_MU_AHEAD 4
@@ -71,13 +71,12 @@ struct SbParams {
                    // 2 (the default): and a column leaves as soon as a Kantorovich dual bound puts it above a published upper bound (see k_sinkhorn_bound)
 };
 
-// LDS per workgroup, sized by the point's support class: NT = 1 / 2 leave room for three / two workgroups per CU (46 / 78 KB of 160),
-// whose wavefronts cover each other's tails; the transposed rows are NT*16 + 8 floats long (== 8 mod 16)
+// LDS per workgroup = per point, sized by the point's support class.  K's rows are kept in ONE orientation (until round 6 also transposed,
+// so that both contractions' A operands were ds_read_b128: 46 / 78 / 110 / 146 KB); the first contraction's operand is four ds_read_b32
+// now — the same LDS bandwidth — and a point takes 21 / 38 / 55 / 71 KB: FOUR points per CU for NT <= 2, two for NT >= 3.
 template <int NT>
 struct __attribute__((aligned(16))) SbLds {
-    static constexpr int KT = NT * 16 + 8;
     float ksub[NT * 16 * SB_KS];  // [y][x] = K[sup_y][x]
-    float ksubT[256 * KT];        // [x][y]
     float b[SB_MAXROWS];          // nu(sup_y), 0 on the padding rows
     float dlo[256];
     float dhi[256];
@@ -133,9 +132,8 @@ __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], cons
         w[yt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     float eu = 0.0f, su = 0.0f, mu_ = 0.0f, dl = 0.0f, dlx = 0.0f, fd = 0.0f;
-    constexpr int SB_KT = SbLds<NT>::KT;
-    const float* kt = &L.ksubT[c * SB_KT + 4 * g];
-    const float* ks = &L.ksub[c * SB_KS + 4 * g];
+    const float* kq = &L.ksub[(4 * g) * SB_KS + c];  // first contraction: A[x = 16 xt + c][k -> y = 16 yt + 4 g + r], r = the MFMA step
+    const float* ks = &L.ksub[c * SB_KS + 4 * g];    // second: A[y = 16 yt + c][k -> x = 16 xt + 4 g + r]
     f32x4 aS[NT], aR[NT];
     // the centroid's densities stream from L2 (a 256 KB table, 16 rows per wavefront: no L1 reuse): SB_MU_AHEAD tiles in flight
     f32x4 mq[SB_MU_AHEAD];
@@ -143,7 +141,8 @@ __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], cons
     for (int a = 0; a < SB_MU_AHEAD; ++a) mq[a] = *reinterpret_cast<const f32x4*>(drow + a * 16 + 4 * g);
 #pragma unroll
     for (int yt = 0; yt < NT; ++yt) {
-        aS[yt] = *reinterpret_cast<const f32x4*>(kt + yt * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) aS[yt][r] = kq[(yt * 16 + r) * SB_KS];
         aR[yt] = *reinterpret_cast<const f32x4*>(ks + yt * 16 * SB_KS);
     }
 #pragma unroll
@@ -154,7 +153,8 @@ __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], cons
         if (xt + 1 < 16) {  // the A operands one tile ahead
 #pragma unroll
             for (int yt = 0; yt < NT; ++yt) {
-                nS[yt] = *reinterpret_cast<const f32x4*>(kt + (xt + 1) * 16 * SB_KT + yt * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nS[yt][r] = kq[(yt * 16 + r) * SB_KS + (xt + 1) * 16];
                 nR[yt] = *reinterpret_cast<const f32x4*>(ks + yt * 16 * SB_KS + (xt + 1) * 16);
             }
         }
@@ -291,17 +291,18 @@ struct SbCol {  // per-column window state (replicated in the four lanes of the 
 // together and iterated until the slowest was done: 0.62 of the slot-iterations were live then, 0.75 now (what is left is each
 // wavefront's own drain at the end of the point: measured, neither a descending queue nor handing the last columns to the
 // wavefronts of highest priority changes it — DESIGN 4d).
-// NT <= 2: four wavefronts per point and two points per CU (2 x 78 KB of LDS): one point's gather / drain is covered by the other's
-// iterations.  NT >= 3 (110 / 146 KB): eight wavefronts, one point.
+// NT <= 2: TWO wavefronts per point and four points per CU; NT >= 3: four wavefronts, two points per CU (SbLds).  With the dual exit the far
+// columns leave after a few iterations and a point's time is its longest column's (the near ones: up to the cap of 128 iterations): on
+// four wavefronts a point had 102 iterations per wavefront and 0.57 of its slots live; fewer slots per point and more points per CU
+// fill them (one point's gather / drain is covered by the others' iterations).
 template <int NT, int LIP>  // LIP = prm.lip, at compile time (one pair of inlined iterations in the loop, not two: registers)
-__global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Points P, CentroidSet cs, uint32_t K, uint32_t bins, SbParams prm,
+__global__ __launch_bounds__((NT <= 2 ? 128 : 256), 2) void k_sinkhorn_bound(Points P, CentroidSet cs, uint32_t K, uint32_t bins, SbParams prm,
                                                                    const uint32_t* list, uint32_t count, unsigned int* cursor,
                                                                    unsigned long long* mask_out, float* dbg_lo, float* dbg_hi,
                                                                    unsigned long long* pstats, const float* ub0, const uint8_t* crank) {
     __shared__ SbLds<NT> L;
-    constexpr uint32_t THREADS = NT <= 2 ? 256u : 512u;
-    if (threadIdx.x < 256) L.crank[threadIdx.x] = crank ? crank[threadIdx.x] : (uint8_t)threadIdx.x;
-    constexpr int SB_KT = SbLds<NT>::KT;
+    constexpr uint32_t THREADS = NT <= 2 ? 128u : 256u, WAVES = THREADS / 64u;
+    for (uint32_t q = threadIdx.x; q < 256u; q += THREADS) L.crank[q] = crank ? crank[q] : (uint8_t)q;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t c = lane & 15u, g = lane >> 4;
     unsigned long long my_cb_iters = 0, my_cost_passes = 0, my_col_iters = 0;
@@ -349,11 +350,11 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
         }
         __syncthreads();
         float kmin = 1.0f;
+#pragma unroll 8
         for (uint32_t e = tid; e < NT * 16 * 256; e += THREADS) {
             const uint32_t y = e >> 8, x = e & 255u;
             const float k = prm.Kmat[L.sup[y] * 256u + x];
             L.ksub[y * SB_KS + x] = k;
-            L.ksubT[x * SB_KT + y] = k;
             kmin = fminf(kmin, k);
         }
         if (LIP) {  // (K in [0, 1]: non-negative floats order as their bits)
@@ -361,18 +362,18 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
             if (lane == 0) atomicMin(&L.kmin, __float_as_uint(kmin));
         }
         const float sp = P.self[i];
-        if (tid < 256) {
+        for (uint32_t q = tid; q < 256u; q += THREADS) {
             float key = __builtin_inff();
-            if (tid < K) {
+            if (q < K) {
                 key = 0.0f;
                 if (prm.use_lb0) {
                     float acc = 0.0f;
-                    for (uint32_t y = 0; y < np; ++y) acc += L.b[y] * cs.mincT[(size_t)L.sup[y] * 256u + tid];
-                    key = rp_maxf((acc * SB_LB_SAFETY - SB_LB_SLACK) - 0.5f * cs.self[tid] - 0.5f * sp, 0.0f);
+                    for (uint32_t y = 0; y < np; ++y) acc += L.b[y] * cs.mincT[(size_t)L.sup[y] * 256u + q];
+                    key = rp_maxf((acc * SB_LB_SAFETY - SB_LB_SLACK) - 0.5f * cs.self[q] - 0.5f * sp, 0.0f);
                     if (!(key == key)) key = 0.0f;
                 }
             }
-            L.lb0[tid] = key;
+            L.lb0[q] = key;
         }
         // ub0: an upper bound of the point's smallest distance known before the pass (the exact distance to SOME centroid:
         // the Elkan assignment for lookup, the k-means++ potential for init_bounds); columns whose bound exceeds it never start
@@ -381,16 +382,15 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
             L.ub = (u == u && u >= 0.0f) ? __float_as_uint(u) : 0x7f800000u;
         }
         __syncthreads();
-        if (tid < 256) {  // rank sort (256 keys, LDS broadcasts): ties follow the similarity order of the centroids — a block of 16
-            // columns iterates until its slowest one is done, and similar centroids take similar numbers of iterations against a point
-            const float mine = L.lb0[tid];
-            const uint32_t myr = L.crank[tid];
+        for (uint32_t q = tid; q < 256u; q += THREADS) {  // rank sort (256 keys, LDS broadcasts): ties follow the similarity order of the centroids
+            const float mine = L.lb0[q];
+            const uint32_t myr = L.crank[q];
             uint32_t rank = 0;
             for (uint32_t k = 0; k < 256; ++k) {
                 const float o = L.lb0[k];
                 rank += (o < mine || (o == mine && (uint32_t)L.crank[k] < myr)) ? 1u : 0u;
             }
-            L.perm[rank] = tid;
+            L.perm[rank] = q;
         }
         __syncthreads();
         // ---- columns in ascending bound (the near ones first: their upper bounds are published while the far ones wait).  A wavefront
@@ -583,25 +583,29 @@ __global__ __launch_bounds__((NT <= 2 ? 256 : 512), 2) void k_sinkhorn_bound(Poi
         }
         __syncthreads();
         // ---- survivors: every centroid whose lower bound does not exceed the smallest upper bound
-        if (tid < 256) {
-            float ub = tid < K ? L.dhi[tid] : __builtin_inff();
+        {
+            float ub = __builtin_inff();
+            for (uint32_t q = tid; q < K; q += THREADS) ub = fminf(ub, L.dhi[q]);
             for (int o = 32; o > 0; o >>= 1) ub = fminf(ub, __shfl_xor(ub, o, 64));
             if (lane == 0) L.red[wave] = ub;
         }
         __syncthreads();
-        if (tid < 256) {
+        {
             // (L.ub: the published upper bounds and ub0, the exact distance to SOME centroid — a column dropped on the way keeps a lower
             // bound that was above L.ub then, not necessarily above the smallest dhi)
-            const float ub = fminf(fminf(fminf(L.red[0], L.red[1]), fminf(L.red[2], L.red[3])), __uint_as_float(L.ub));
-            const bool keep = tid < K && !(L.dlo[tid] > ub);
-            const unsigned long long m = __ballot(keep);
-            if (lane == 0) {
-                mask_out[i * 4 + wave] = m;
-                atomicAdd(pstats + (size_t)(blockIdx.x % KM_STAT_STRIPES) * STAT_STRIDE + 0, (unsigned long long)__popcll(m));
-            }
-            if (dbg_lo && tid < K) {
-                dbg_lo[i * K + tid] = L.dlo[tid];
-                dbg_hi[i * K + tid] = L.dhi[tid];
+            float ub = __uint_as_float(L.ub);
+            for (uint32_t w = 0; w < WAVES; ++w) ub = fminf(ub, L.red[w]);
+            for (uint32_t q = tid; q < 256u; q += THREADS) {  // (q >> 6 is wave uniform)
+                const bool keep = q < K && !(L.dlo[q] > ub);
+                const unsigned long long m = __ballot(keep);
+                if (lane == 0) {
+                    mask_out[i * 4 + (q >> 6)] = m;
+                    atomicAdd(pstats + (size_t)(blockIdx.x % KM_STAT_STRIPES) * STAT_STRIDE + 0, (unsigned long long)__popcll(m));
+                }
+                if (dbg_lo && q < K) {
+                    dbg_lo[i * K + q] = L.dlo[q];
+                    dbg_hi[i * K + q] = L.dhi[q];
+                }
             }
         }
         if (tid == 0) atomicAdd(pstats + (size_t)(blockIdx.x % KM_STAT_STRIPES) * STAT_STRIDE + 1, 1ull);
