@@ -744,7 +744,13 @@ int launch_neighbor(rp_kmeans* h, uint8_t* out_j, float* out_d, Bounds init, int
 
 int launch_recompute(rp_kmeans* h, const uint8_t* assign, int set) {
     ck_begin(h, CK_RECOMPUTE);
-    hipLaunchKernelGGL(k_recompute, dim3(h->K), dim3(256), 0, h->stream, h->P, assign, h->bins, h->cs[set].counts,
+    const unsigned slices = h->N >= (1ull << 17) ? 8u : 1u;  // workgroups per centroid (k_recompute adds into zeroed outputs when > 1)
+    if (slices > 1) {
+        HIP_TRY(hipMemsetAsync(h->cs[set].counts, 0, (size_t)h->K * h->bins * 4, h->stream));
+        HIP_TRY(hipMemsetAsync(h->cs[set].weight, 0, (size_t)h->K * 4, h->stream));
+        HIP_TRY(hipMemsetAsync(h->sizes, 0, (size_t)h->K * 8, h->stream));
+    }
+    hipLaunchKernelGGL(k_recompute, dim3(h->K, slices), dim3(256), 0, h->stream, h->P, assign, h->bins, h->cs[set].counts,
                        h->cs[set].weight, h->sizes);
     ck_end(h, CK_RECOMPUTE);
     HIP_TRY(hipGetLastError());

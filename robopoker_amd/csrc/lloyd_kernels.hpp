@@ -1662,7 +1662,9 @@ __global__ __launch_bounds__(256) void k_recompute(Points P, const uint8_t* assi
     // together).  Integer sums: the order of members is free.
     uint32_t acc[4] = {0, 0, 0, 0};  // lane owns bins lane, lane+64, lane+128, lane+192
     unsigned long long mine = 0;
-    for (uint64_t cbase = 0; cbase < P.N; cbase += RC_CHUNK) {
+    // gridDim.y workgroups share a centroid (chunks interleaved) and ADD their sums to outputs the host has zeroed: one workgroup per
+    // centroid was one per CU, 1.3 ms per turn-layer iteration for 176 MB of rows; integer sums, any order
+    for (uint64_t cbase = (uint64_t)blockIdx.y * RC_CHUNK; cbase < P.N; cbase += (uint64_t)gridDim.y * RC_CHUNK) {
         if (tid == 0) qn = 0;
         __syncthreads();
         const uint64_t t0 = cbase + (uint64_t)tid * 64;
@@ -1712,7 +1714,8 @@ __global__ __launch_bounds__(256) void k_recompute(Points P, const uint8_t* assi
     __syncthreads();
     uint32_t wsum = 0;
     for (uint32_t b = tid; b < bins; b += 256) {
-        counts_out[(size_t)k * bins + b] = hist[b];
+        if (gridDim.y == 1) counts_out[(size_t)k * bins + b] = hist[b];
+        else if (hist[b]) atomicAdd(&counts_out[(size_t)k * bins + b], hist[b]);
         wsum += hist[b];
     }
     for (int d = 32; d > 0; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
@@ -1722,8 +1725,13 @@ __global__ __launch_bounds__(256) void k_recompute(Points P, const uint8_t* assi
     if (lane == 0) atomicAdd(&hist[0], wsum);
     __syncthreads();
     if (tid == 0) {
-        weight_out[k] = hist[0];
-        sizes_out[k] = members;
+        if (gridDim.y == 1) {
+            weight_out[k] = hist[0];
+            sizes_out[k] = members;
+        } else {
+            if (hist[0]) atomicAdd(&weight_out[k], hist[0]);
+            if (members) atomicAdd(&sizes_out[k], members);
+        }
     }
 }
 
@@ -1835,6 +1843,29 @@ __device__ __forceinline__ float lane_variation(const Points& P, uint64_t i, con
     const uint8_t* row = P.counts + i * P.stride;
     const float fw = (float)P.weight[i];
     float cx = 0.0f, cy = 0.0f, s = 0.0f;
+    if ((P.stride & 15u) == 0u) {
+        // rows padded to 16 bytes (every layer created from host counts): the lane's row as 16-byte loads, the next one in flight while
+        // this one is folded.  A byte load per bin made every wave instruction touch 64 cache lines for 64 bytes, and with 6.6 KB of rows
+        // per wavefront the lines were evicted between two of a lane's bytes: 0.7 ms per k-means++ round of the turn layer for 176 MB.
+        // Same folds in the same order (equity.rs:41-53).
+        const uint4* row4 = reinterpret_cast<const uint4*>(row);
+        uint4 q = row4[0];
+        for (uint32_t t0 = 0; t0 < bins; t0 += 16u) {
+            const uint4 cur = q;
+            if (t0 + 16u < bins) q = row4[(t0 >> 4) + 1u];
+            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (uint32_t b = 0; b < 16u; ++b) {
+                const uint32_t t = t0 + b;
+                if (t < bins) {
+                    cx += (float)((w[b >> 2] >> (8u * (b & 3u))) & 255u) / fw;
+                    cy += cs.dens[(size_t)t * K + k];
+                    s += rp_absf(cx - cy);
+                }
+            }
+        }
+        return s / (float)bins;
+    }
     for (uint32_t t = 0; t < bins; ++t) {
         cx += (float)row[t] / fw;
         cy += cs.dens[(size_t)t * K + k];

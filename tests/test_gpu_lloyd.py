@@ -221,6 +221,23 @@ def test_elkan_iterations_bit_exact(gpu, kind, K, N, bins, mass):
     assert bits(dev.rms()) == bits(ora.rms())
 
 
+def test_recompute_shared_by_several_workgroups_per_centroid(gpu):
+    # from 2^17 points on Elkan::recompute (elkan.rs:128-142) runs eight workgroups per centroid that add their integer sums into zeroed
+    # outputs (k_recompute, gridDim.y): centroids, sizes, drift bits and every bound of two steps against the oracle
+    dev, ora = _pair("variation", 6, 140000, 24, 12, seed=5, iters=16)
+    assert np.array_equal(dev.init_centroids(), ora.init_centroids()), "k-means++ picks differ"
+    dev.init_bounds()
+    ora.init_bounds()
+    _check_state(dev, ora)
+    for _ in range(2):
+        d1, s1, m1 = dev.step()
+        d2, s2, m2 = ora.step()
+        assert np.array_equal(bits(d1), bits(d2)), "drift differs"
+        assert np.array_equal(s1, s2) and m1 == m2 and int(np.sum(s1)) == 140000
+        _check_state(dev, ora)
+    assert bits(dev.rms()) == bits(ora.rms())
+
+
 @pytest.mark.parametrize("libm", ["contract", "glibc"])
 def test_interval_decided_refresh_keeps_the_reference_state(gpu, libm):
     # csrc/refresh_bound.hpp: from the second iteration on most stale-bound refreshes (elkan.rs:113-117) are settled by a scaling-domain
