@@ -436,6 +436,7 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
         h->sb.dc_rel = std::max(envf("RP_SB_DC_REL", 4e-5f), 4e-5f);
         h->sb.flat = std::min(envf("RP_SB_FLAT", 4.0f), 4.0f);
         h->sb.lip = getenv("RP_SB_LIP") ? atoi(getenv("RP_SB_LIP")) : 2;
+        h->sb.tight = getenv("RP_SB_TIGHT") ? (uint32_t)std::max(0, atoi(getenv("RP_SB_TIGHT"))) : SB_TIGHT_EVERY;
         {
             float cmax = 0.0f;
             for (size_t t = 0; t < (size_t)bins * (bins - 1) / 2; ++t) cmax = std::max(cmax, tri_metric[t]);

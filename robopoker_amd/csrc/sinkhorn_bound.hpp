@@ -64,6 +64,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SB_MAXROWS 64   // a point with more support bins than this is not pruned (all its centroids go to the exact kernel)
 #define SB_EPS23 1.1920929e-7f
 #define SB_MU_AHEAD 4
+#define SB_TIGHT_EVERY 16u  // wavefront iterations between two c-transform evaluations of the dual exit (0: never); measured 2 / 4 / 8 / 12 / 16 / 24 / 32: 2.72 / 2.16 / 1.92 / 1.86 / 1.84 / 1.84 / 1.87 s, without 2.38
 #define SB_DUAL_SLACK 1e-3f  // log2 units (x T ln 2 = 1.7e-5 of cost at T = 0.025)
 
 struct SbParams {
@@ -77,6 +78,7 @@ struct SbParams {
     float dc_rel;
     float flat;    // the scaling iterate counts as stationary when err <= flat * 2^-23 * (sum u + sum v), twice in a row
     int use_lb0;   // the column-marginal bound is valid for this metric / temperature (max C / T <= 64): sort and drop by it
+    uint32_t tight;  // the dual exit's c-transform pair every `tight`-th wavefront iteration (0: never; RP_SB_TIGHT)
     int lip;       // >= 1: the cost of a window iterate is taken from the last evaluated one and a Lipschitz bound when that is enough;
                    // 2 (the default): and a column leaves as soon as a Kantorovich dual bound puts it above a published upper bound (see k_sinkhorn_bound)
 };
@@ -134,7 +136,7 @@ __device__ __forceinline__ float sb_max4(float x) {
 template <int NT, bool COST, int LIP>
 __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], const float* __restrict__ drow, const SbLds<NT>& L, uint32_t c,
                                            uint32_t g, float& err, float& sumu, float& umax, float& sumv, float& vmax, float neg_t_ln2,
-                                           float& cost, float& dlt, float& eprev, float& dual) {
+                                           float& cost, float& dlt, float& eprev, float& dual, float& fsum) {
     f32x4 racc[NT], w[NT];
 #pragma unroll
     for (int yt = 0; yt < NT; ++yt) {
@@ -249,7 +251,30 @@ __device__ __forceinline__ void sb_iterate(f32x4 (&uo)[16], f32x4 (&v)[NT], cons
     eprev = LIP == 2 ? sb_sum4(dlx) : 0.0f;
     // T ln 2 * (sum_x mu_x log2 u'_x - sum_y nu_y log2 (K^T u')_y), less SB_DUAL_SLACK for the roundings of (K^T u')_y (an MFMA
     // chain: <= 256 * 2^-24 relative = 2.2e-5 in log2), of v_log_f32 and of the two sums (<= 1e-4 in log2 at |log2| <= 40)
-    dual = LIP == 2 ? (-neg_t_ln2) * ((sb_sum4(fd) * 1.1920929e-7f - sb_sum4(gd)) - SB_DUAL_SLACK) : 0.0f;
+    fsum = LIP == 2 ? sb_sum4(fd) * 1.1920929e-7f : 0.0f;  // sum_x mu_x log2 u'_x (from below)
+    dual = LIP == 2 ? (-neg_t_ln2) * ((fsum - sb_sum4(gd)) - SB_DUAL_SLACK) : 0.0f;
+}
+
+// The c-transform of f for the dual exit: sum_y nu_y log2 max_x K[y][x] u_x — the LARGEST g that keeps f + g <= C (g = -T ln of the
+// maximum; sb_iterate's g uses the sum over x instead, which the second contraction delivers for free).  A max-product over the point's
+// rows and all 256 x on the vector ALU: about one iteration's time for the sixteen columns of a wavefront, so it runs every
+// SB_TIGHT_EVERY-th iteration only.  u: the iterate sb_iterate just produced (C/D layout: lane (c, g) holds x = 16 xt + 4 g + r).
+template <int NT>
+__device__ __forceinline__ float sb_dual_ctransform(const f32x4 (&uo)[16], const SbLds<NT>& L, uint32_t g, uint32_t np) {
+    float gd = 0.0f;
+    const float* ks = &L.ksub[4 * g];
+    for (uint32_t y = 0; y < np; ++y) {  // (np is uniform over the workgroup)
+        float m0 = 0.0f, m1 = 0.0f;
+#pragma unroll
+        for (int xt = 0; xt < 16; ++xt) {
+            const f32x4 k = *reinterpret_cast<const f32x4*>(ks + y * SB_KS + xt * 16);  // the same address in the 16 lanes of a g: a broadcast
+            m0 = fmaxf(m0, fmaxf(k[0] * uo[xt][0], k[2] * uo[xt][2]));
+            m1 = fmaxf(m1, fmaxf(k[1] * uo[xt][1], k[3] * uo[xt][3]));
+        }
+        const float mx = sb_max4(fmaxf(m0, m1));
+        gd = fmaf(L.b[y], __builtin_amdgcn_logf(fmaxf(mx, 1e-37f)), gd);
+    }
+    return gd;  // (every lane of the column holds the whole sum: no reduction over g left)
 }
 
 // cost of the current iterate: sum_y v_y sum_x K[y][x] C[y][x] u_x, with C recovered from K (C = -T ln K)
@@ -502,9 +527,14 @@ __global__ __launch_bounds__((NT <= 2 ? 128 : 256), 2) void k_sinkhorn_bound(Poi
                 // (LIP: evaluations are rare — 2 % of the iterations on the flop layer — and always take the separate pass: the fused
                 // form's accumulators are what the register allocation of the whole loop is sized by)
                 const bool with_cost = !LIP && __ballot(live && st.opened && near) != 0;
-                float eprev = 0.0f, dual = 0.0f;
-                if (with_cost) sb_iterate<NT, true, LIP>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused, dlt, eprev, dual);
-                else sb_iterate<NT, false, LIP>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused, dlt, eprev, dual);
+                float eprev = 0.0f, dual = 0.0f, fsum = 0.0f;
+                if (with_cost) sb_iterate<NT, true, LIP>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused, dlt, eprev, dual, fsum);
+                else sb_iterate<NT, false, LIP>(uo, v, drow, L, c, g, err, sumu, umax, sumv, vmax, prm.neg_t_ln2, fused, dlt, eprev, dual, fsum);
+                if (LIP == 2 && prm.tight && prm.use_lb0 && (my_cb_iters % prm.tight) == prm.tight - 1u) {  // wave uniform
+                    const float gdt = sb_dual_ctransform<NT>(uo, L, g, np);
+                    const float dt = (-prm.neg_t_ln2) * ((fsum - gdt) - SB_DUAL_SLACK);
+                    dual = fmaxf(dual, dt);  // (both are lower bounds; not a number: the looser one stays)
+                }
                 if (LIP) {
                     st.acc += cmaxp * dlt;
                     near = !(st.hasref && lo_of(st.cref - st.acc) > ubn);

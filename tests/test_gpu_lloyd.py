@@ -512,7 +512,7 @@ def test_mfma_bound_intervals_contain_the_oracle(gpu, monkeypatch, N, K, bins, m
     assert bad.size == 0, f"{len(bad)} intervals miss the exact value, first {bad[:3]}: " \
                           f"{[(lo[i, k], exact[i, k], hi[i, k]) for i, k in bad[:3]]}"
     finite = np.isfinite(hi)
-    assert finite.mean() > (0.2 if drop else 0.99)
+    assert finite.mean() > (0.1 if drop else 0.99)  # (round 6: far columns leave by the dual bound — 0.15 of K = 37 are followed to the end)
     assert np.all(finite[np.arange(N), exact.argmin(axis=1)])  # the nearest centroid is always followed to the end
     # typical width of the intervals that matter — the centroids within four times the smallest upper bound —: the margin, not the
     # stopping window (a far column's window iterates may be taken from a Lipschitz bound: wider by design, round 6)
