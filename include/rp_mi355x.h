@@ -521,13 +521,17 @@ RP_API int rp_kmeans_set_libm(rp_kmeans* h, rp_libm_kind kind);
  * bound and interval filter, the MFMA bound of init_bounds / lookup, the interval-decided refresh of the Elkan iterations) replace a
  * bit-faithful solve by a scaling-domain INTERVAL that must contain the value the reference would compute.  The column bound is
  * rigorous, and so is the rule by which the MFMA bound skips cost evaluations inside a stopping window (round 6: a Lipschitz bound of
- * <P, C> in the coupling's L1 travel, exact arithmetic, applied only to columns that cannot be the argmin either way).  The intervals
- * themselves are not proven: their margins (SbParams: kappa, rho, dc_abs 4e-6, dc_rel 4e-5) are a multiple of the worst
+ * <P, C> in the coupling's L1 travel, exact arithmetic, applied only to columns that cannot be the argmin either way), and so is the
+ * rule by which a far column (MFMA bound) or a far pair (k-means++ interval filter) LEAVES before its stopping window closes (round 6:
+ * weak duality for a Kantorovich pair read off the iterate, f = T ln u with g = -T ln K^T u or f's c-transform, plus the L1 error of the
+ * row marginals, which never grows; float slack only — csrc/sinkhorn_bound.hpp "THE DUAL EXIT").  The intervals of the columns that are
+ * followed to the end are not proven: their margins (SbParams: kappa, rho, dc_abs 4e-6, dc_rel 4e-5) are a multiple of the worst
  * float noise MEASURED between the scaling-domain and the log-domain iteration, and the smallest slack observed on a sampled pair was
  * 0.88 of the margin (profiles/r05_glibc_audit.json), i.e. a safety factor of about 8 over the worst observed case, on synthetic
  * points.  The evidence that they hold: full-size audits in both arithmetics with 0 of 1 286 792 points differing from the unpruned
  * search on the synthetic layer (profiles/r05_glibc_audit.json, r05_kpp_audit*.json) and on the real flop layer (r03_mfma_audit.json),
- * 0 differences over 32 Elkan iterations with and without the refresh bound (profiles/r06_refresh_audit_*.json), and a runtime
+ * 0 differences over 32 Elkan iterations with and without the refresh bound (profiles/r06_refresh_audit_*.json; all of them again
+ * after the dual exits: profiles/r06p_*audit*.json, 0 of 2 573 584 audited points in each of the four), and a runtime
  * tripwire: every 521st point is searched again without the MFMA prune after every pruned pass, a mismatch makes the next call that
  * hands results out fail with RP_ERR_INTERNAL (never a silently different bucket).  That is a statistical claim with a tripwire, not a
  * bound: a caller that needs exactness BY CONSTRUCTION uses rp_kmeans_set_prune(h, 0), the only such mode (and RP_LLOYD_AUDIT=1 runs
