@@ -58,6 +58,7 @@
 #pragma once
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define SB_KS 260       // ksub row stride in floats: 260 mod 64 = 4 -> the 16 lanes of a ds_read_b128 group (address c KS + 4 g) hit 64 banks
                         // once, and so do the 64 lanes of a ds_read_b32 at (4 g) KS + c (4 KS mod 64 = 16)
@@ -108,7 +109,8 @@ struct __attribute__((aligned(16))) SbLds {
 
 __device__ __forceinline__ f32x4 sb_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float sb_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-// reductions over the four lanes (g = 0..3) that share a centroid column
+// reductions over the four lanes (g = 0..3) that share a centroid column: lanes c, c + 16, c + 32, c + 48
+#if defined(RP_EMUL)
 __device__ __forceinline__ float sb_sum4(float x) {
     x += __shfl_xor(x, 16, 64);
     x += __shfl_xor(x, 32, 64);
@@ -119,6 +121,38 @@ __device__ __forceinline__ float sb_max4(float x) {
     x = fmaxf(x, __shfl_xor(x, 32, 64));
     return x;
 }
+#else
+// v_permlane16_swap / v_permlane32_swap (vector ALU) instead of two ds_bpermute round trips through LDS: seven of these reductions stand
+// between one iteration's last MFMA and the next one's first.  The same additions as the xor butterfly: (x_l + x_{l^16}) + (the pair l^32's).
+__device__ __forceinline__ void sb_swap16(float x, float& a, float& b) {  // a: the even row of each row pair, b: the odd one
+    const uint32_t w = __builtin_bit_cast(uint32_t, x);
+    const auto r = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+    const uint32_t r0 = r[0], r1 = r[1];
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void sb_swap32(float x, float& a, float& b) {  // a: lanes 0-31's value, b: lanes 32-63's
+    const uint32_t w = __builtin_bit_cast(uint32_t, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    const uint32_t r0 = r[0], r1 = r[1];
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ float sb_sum4(float x) {
+    float a, b;
+    sb_swap16(x, a, b);
+    x = a + b;
+    sb_swap32(x, a, b);
+    return a + b;
+}
+__device__ __forceinline__ float sb_max4(float x) {
+    float a, b;
+    sb_swap16(x, a, b);
+    x = fmaxf(a, b);
+    sb_swap32(x, a, b);
+    return fmaxf(a, b);
+}
+#endif
 
 // One Gauss-Seidel iteration for a block of 16 centroid columns: U <- mu ./ (K V), then V <- nu ./ (K^T U).
 // uo: U of the previous iteration in C/D layout (lane (c, g), register r of tile xt = U[16 xt + 4g + r][column c]);
@@ -264,14 +298,19 @@ __device__ __forceinline__ float sb_dual_ctransform(const f32x4 (&uo)[16], const
     float gd = 0.0f;
     const float* ks = &L.ksub[4 * g];
     for (uint32_t y = 0; y < np; ++y) {  // (np is uniform over the workgroup)
-        float m0 = 0.0f, m1 = 0.0f;
+        // products are >= 0 (or not a number): their order is their bit patterns' as unsigned integers — two packed multiplies and two
+        // v_max3_u32 per tile (the float maximum canonicalises its operands: 115 instructions per row where these are 64); a NaN's
+        // pattern is above every number's, reaches the logarithm and keeps the column
+        uint32_t m0 = 0u, m1 = 0u;
 #pragma unroll
         for (int xt = 0; xt < 16; ++xt) {
             const f32x4 k = *reinterpret_cast<const f32x4*>(ks + y * SB_KS + xt * 16);  // the same address in the 16 lanes of a g: a broadcast
-            m0 = fmaxf(m0, fmaxf(k[0] * uo[xt][0], k[2] * uo[xt][2]));
-            m1 = fmaxf(m1, fmaxf(k[1] * uo[xt][1], k[3] * uo[xt][3]));
+            const f32x2 pa = f32x2{k[0], k[1]} * f32x2{uo[xt][0], uo[xt][1]};
+            const f32x2 pb = f32x2{k[2], k[3]} * f32x2{uo[xt][2], uo[xt][3]};
+            m0 = max(max(m0, __float_as_uint(pa[0])), __float_as_uint(pb[0]));
+            m1 = max(max(m1, __float_as_uint(pa[1])), __float_as_uint(pb[1]));
         }
-        const float mx = sb_max4(fmaxf(m0, m1));
+        const float mx = sb_max4(__uint_as_float(max(m0, m1)));
         gd = fmaf(L.b[y], __builtin_amdgcn_logf(fmaxf(mx, 1e-37f)), gd);
     }
     return gd;  // (every lane of the column holds the whole sum: no reduction over g left)
