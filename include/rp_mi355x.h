@@ -532,7 +532,8 @@ RP_API int rp_kmeans_set_libm(rp_kmeans* h, rp_libm_kind kind);
  * search on the synthetic layer (profiles/r05_glibc_audit.json, r05_kpp_audit*.json) and on the real flop layer (r03_mfma_audit.json),
  * 0 differences over 32 Elkan iterations with and without the refresh bound (profiles/r06_refresh_audit_*.json; all of them again
  * after the dual exits: profiles/r06p_*audit*.json, 0 of 2 573 584 audited points in each of the four), and a runtime
- * tripwire: every 521st point is searched again without the MFMA prune after every pruned pass, a mismatch makes the next call that
+ * tripwire: every 521st point is searched again without the MFMA prune after every pruned pass (and every 521st point a k-means++ round's
+ * interval filter drops is solved anyway and its bound compared with the exact distance), a mismatch makes the next call that
  * hands results out fail with RP_ERR_INTERNAL (never a silently different bucket).  That is a statistical claim with a tripwire, not a
  * bound: a caller that needs exactness BY CONSTRUCTION uses rp_kmeans_set_prune(h, 0), the only such mode (and RP_LLOYD_AUDIT=1 runs
  * the unpruned search behind every pruned pass and counts disagreements). */

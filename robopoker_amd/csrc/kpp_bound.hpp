@@ -159,14 +159,14 @@ __device__ __forceinline__ float kb_dot_max(const float (&a)[R], const float* ve
     return s0 + s1;
 }
 
-// kstats (striped like Metric::stats): [0] pairs examined, [1] pairs kept, [2] pair-iterations, [3] cost passes
+// kstats (striped like Metric::stats): [0] pairs examined, [1] pairs kept (without the tripwire's), [2] pair-iterations, [3] cost passes
 // in_list / in_count: the round's candidates of one support class (k_kpp_filter); out_list / out_count: the ones the solve is still
 // needed for.  dbg_lo (tests): the lower bound of the divergence per point, 0 where the pair was kept without one.
 template <uint32_t ROWS, uint32_t R>
 __global__ __launch_bounds__(64) void k_kpp_bound(Points P, CentroidSet cs, uint32_t k, uint32_t bins, const float* Cm, SbParams prm,
                                                   const float* pot, const uint32_t* in_list, const unsigned int* in_count,
                                                   unsigned int* cursor, uint32_t* out_list, unsigned int* out_count,
-                                                  unsigned long long* kstats, float* dbg_lo, int dual) {
+                                                  unsigned long long* kstats, float* dbg_lo, int dual, float* claim, float claim_scale) {
     constexpr uint32_t G = 64u / ROWS;
     static_assert(R <= ROWS && R % 8 == 0, "register tile");
     __shared__ KbLds<ROWS> L;
@@ -349,10 +349,15 @@ __global__ __launch_bounds__(64) void k_kpp_bound(Points P, CentroidSet cs, uint
         }
         if (r == 0 && n > 0) {
             my_pairs += 1;
-            if (keep) {
-                my_kept += 1;
-                out_list[atomicAdd(out_count, 1u)] = (uint32_t)ip;
+            // the tripwire of the rounds (Metric::kpp_claim): every 521st point that is dropped goes to the solve all the same, with the
+            // bound it was dropped with; the solve changes nothing if the bound holds (d^2 >= potential) and counts a disagreement if not
+            bool solve = keep;
+            if (!keep && claim && dl > 0.0f && ip % 521ull == 0ull) {
+                claim[ip] = dl * claim_scale;  // (claim_scale: 1; a test sets it to prove that the wire trips)
+                solve = true;
             }
+            if (keep) my_kept += 1;
+            if (solve) out_list[atomicAdd(out_count, 1u)] = (uint32_t)ip;
             if (dbg_lo) dbg_lo[ip] = keep ? 0.0f : dl;
         }
     }

@@ -134,6 +134,7 @@ struct rp_kmeans {
     uint64_t kpp_cap[3] = {0, 0, 0};  // points per support class (<= QUAD_ROWS, <= PAIR_ROWS, more): grid bounds
     // the second k-means++ filter (kpp_bound.hpp): a scaling-domain interval per (new centroid, point) pair the column bound let through
     bool kb_on = false;
+    float kb_claim_scale = 1.0f;  // RP_KPP_CLAIM_TEST: the tripwire's claims scaled (a test proves that it trips)
     int kb_dual = 2;  // the dual exit's pair: 2 = (f, its c-transform), 1 = (f, -T ln K^T u) (RP_KPP_DUAL; measurements)
     KppLists kpp2{};                        // the pairs the solve is still needed for, per support class
     unsigned int* kb_cursor = nullptr;      // [3] work cursors of the three launches of a round
@@ -488,6 +489,12 @@ int create_common(uint32_t K, uint64_t N, uint32_t bins, const void* counts, boo
             KM_HIP(hipMemset(h->kb_stats, 0, (size_t)KM_STAT_STRIPES * STAT_STRIDE * 8));
             h->kb_on = true;
             if (getenv("RP_KPP_DUAL")) h->kb_dual = std::max(1, std::min(2, atoi(getenv("RP_KPP_DUAL"))));
+            if (!getenv("RP_LLOYD_NO_SAMPLE_CHECK")) {  // the rounds' tripwire: claims of the sampled points, checked by the solves (kpp_note)
+                KM_TRY(dev_alloc(h, &h->M.kpp_claim, (size_t)N));
+                KM_HIP(hipMemset(h->M.kpp_claim, 0, (size_t)N * 4));
+                h->M.kpp_bad = h->sb_bad + 1;
+                if (getenv("RP_KPP_CLAIM_TEST")) h->kb_claim_scale = (float)atof(getenv("RP_KPP_CLAIM_TEST"));
+            }
         }
     }
     h->ns_host = ns;
@@ -1037,13 +1044,14 @@ int rp_kmeans_kpp_update(rp_kmeans* h, uint32_t k) {
                     if (two)
                         hipLaunchKernelGGL((k_kpp_bound<32, 32>), dim3(grid), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
                                            (const float*)h->pot, (const uint32_t*)h->kpp.list[c], (const unsigned int*)(h->kpp.count + c),
-                                           h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr, h->sb.lip >= 2 ? h->kb_dual : 0);
+                                           h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr, h->sb.lip >= 2 ? h->kb_dual : 0, h->M.kpp_claim, h->kb_claim_scale);
                     else
                         hipLaunchKernelGGL((k_kpp_bound<64, 48>), dim3(grid), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
                                            (const float*)h->pot, (const uint32_t*)h->kpp.list[c], (const unsigned int*)(h->kpp.count + c),
-                                           h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr, h->sb.lip >= 2 ? h->kb_dual : 0);
+                                           h->kb_cursor + c, h->kpp2.list[c], h->kpp2.count + c, h->kb_stats, (float*)nullptr, h->sb.lip >= 2 ? h->kb_dual : 0, h->M.kpp_claim, h->kb_claim_scale);
                 }
                 todo = &h->kpp2;
+                if (h->M.kpp_claim) h->sb_check_pending = true;  // the solves below check the sampled claims (prune_check reads the counter)
                 ck_end(h, CK_KPP_BOUND);
                 ck_begin(h, CK_KPP);
             }
@@ -1518,7 +1526,7 @@ int rp_kmeans_kpp_bound_probe_at(rp_kmeans* h, uint32_t k, float potential, floa
         hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, h->stream, d_pot, h->N, potential < 0.0f ? -1.0f : potential);  // lo^2 >= -1 always: every window runs to its end
         hipLaunchKernelGGL((k_kpp_bound<64, 48>), dim3(2048), dim3(64), 0, h->stream, h->P, h->cs[h->cur], k, h->bins, h->M.Cm, h->sb,
                            (const float*)d_pot, (const uint32_t*)d_list, (const unsigned int*)d_ctl, d_ctl + 1, d_list + N + 4, d_ctl + 2,
-                           d_stats, d_lo, (potential >= 0.0f && h->sb.lip >= 2) ? h->kb_dual : 0);
+                           d_stats, d_lo, (potential >= 0.0f && h->sb.lip >= 2) ? h->kb_dual : 0, (float*)nullptr, 1.0f);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(lo, d_lo, N * 4, hipMemcpyDeviceToHost, h->stream);

@@ -33,6 +33,13 @@ __device__ __forceinline__ void kpp_note(const Metric& M, uint64_t i, uint32_t k
         M.kpp_d[i] = d;
         M.kpp_j[i] = (uint8_t)k;
     }
+    if (M.kpp_claim) {  // a sampled point the interval filter dropped in this round: its bound against the distance just solved
+        const float c = M.kpp_claim[i];
+        if (c > 0.0f) {
+            if (d < c) atomicAdd(M.kpp_bad, 1ull);
+            M.kpp_claim[i] = 0.0f;
+        }
+    }
 }
 __device__ __forceinline__ unsigned long long* STAT(const Metric& M, uint32_t k) {
     return M.stats + (size_t)(blockIdx.x % M.stat_stripes) * STAT_STRIDE + k;

@@ -21,6 +21,10 @@ struct Metric {
     // -1 = not known (the picked point, whose potential is set to 0 without a solve).  See k_init_from_kpp.
     float* kpp_d;               // [N] or NULL
     uint8_t* kpp_j;             // [N]
+    // the k-means++ interval filter's tripwire (kpp_bound.hpp): every 521st point the filter would drop is solved anyway and the lower
+    // bound it was dropped with (kpp_claim[i] > 0) compared with the exact distance; a bound above it counts into kpp_bad
+    float* kpp_claim;               // [N] or NULL
+    unsigned long long* kpp_bad;    // one counter (the production sample check's)
 };
 
 #define STAT_STRIDE 16u  // u64 per stripe

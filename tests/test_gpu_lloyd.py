@@ -592,6 +592,35 @@ def test_kmeanspp_interval_filter_keeps_the_picks(gpu, monkeypatch):
     assert d1 < d0  # fewer bit-faithful solves
 
 
+def test_kmeanspp_rounds_tripwire(gpu, monkeypatch):
+    # every 521st point the k-means++ interval filter drops is solved anyway and the bound it was dropped with compared with the exact
+    # distance (Metric::kpp_claim, kpp_note).  On a healthy layer nothing is counted and results are those without the wire; with the claims
+    # scaled by RP_KPP_CLAIM_TEST (a bound 1000 x too high) the next call that hands results out fails with RP_ERR_INTERNAL.
+    from robopoker_amd import _lib
+    N, K, bins = 6000, 24, 256
+    pts = flop_like_points(N, bins=bins, mass=47, seed=21)
+    tri = smooth_metric(bins, 1)
+
+    def run(scale):
+        monkeypatch.delenv("RP_KPP_CLAIM_TEST", raising=False)
+        if scale:
+            monkeypatch.setenv("RP_KPP_CLAIM_TEST", scale)
+        layer = lloyd.Layer(K, pts, "sinkhorn", tri, seed=4)
+        chosen = np.asarray(layer.init_centroids())
+        layer.init_bounds()
+        return chosen, layer.prune_stats()
+
+    chosen, st = run(None)
+    assert st["kpp_bound_pairs"] > 0 and st["kpp_bound_kept"] < st["kpp_bound_pairs"] and st["sample_mismatches"] == 0
+    monkeypatch.setenv("RP_LLOYD_NO_SAMPLE_CHECK", "1")
+    chosen0, _ = run(None)
+    monkeypatch.delenv("RP_LLOYD_NO_SAMPLE_CHECK")
+    assert np.array_equal(chosen, chosen0)
+    with pytest.raises(_lib.RpError) as err:
+        run("1000")
+    assert "sampled points" in str(err.value)
+
+
 def test_mfma_bound_audit_against_the_unpruned_pass(gpu, monkeypatch):
     # RP_LLOYD_AUDIT=1: every pruned neighbor pass is followed by the unpruned one and compared point by point on the
     # device (the "debug build" of the prune); k-means++ picks, init_bounds, two Elkan iterations, lookup at the
